@@ -1,0 +1,229 @@
+"""Pins the oracle (oracle/) against (a) the golden vectors produced by the real reference
+(tests/golden/make_golden.py) and (b) the known-answer tables of the reference's own unit tests,
+restated here with file:line citations (the reference tests need `parameterized`, absent here).
+CPU only."""
+
+import hashlib
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import sliding_window as osw
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _toy(k_out):
+    def f(x):
+        return torch.cat([torch.sin(x[:, :1] * (1.0 + 0.37 * k)) + 0.05 * k * x[:, :1] for k in range(k_out)], dim=1)
+
+    return f
+
+
+def _digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+# ---------------------------------------------------------------- host index math
+def test_window_starts_match_reference(golden_dir):
+    g = _load(golden_dir, "host_math.npz")
+    i = 0
+    while f"slices_{i}_img" in g:
+        img, roi = tuple(g[f"slices_{i}_img"]), tuple(g[f"slices_{i}_roi"])
+        ov = float(g[f"slices_{i}_ov"])
+        itv = osw.get_scan_interval(img, roi, (ov,) * len(img))
+        assert tuple(itv) == tuple(g[f"slices_{i}_interval"])
+        starts, _ = osw.dense_patch_starts(img, roi, itv)
+        got = np.asarray(list(itertools.product(*starts)), dtype=np.int32)
+        np.testing.assert_array_equal(got, g[f"slices_{i}_starts"])
+        i += 1
+    assert i >= 6
+
+
+def test_bench_config_has_1000_windows():
+    itv = osw.get_scan_interval((512,) * 3, (96,) * 3, (0.5,) * 3)
+    starts, _ = osw.dense_patch_starts((512,) * 3, (96,) * 3, itv)
+    assert itv == (48, 48, 48)
+    assert starts[0] == [0, 48, 96, 144, 192, 240, 288, 336, 384, 416]
+    assert len(list(itertools.product(*starts))) == 1000
+
+
+def test_importance_map_matches_reference(golden_dir):
+    g = _load(golden_dir, "host_math.npz")
+    i = 0
+    while f"imp_{i}_ps" in g:
+        ps = tuple(int(v) for v in g[f"imp_{i}_ps"])
+        sig = g[f"imp_{i}_sigma"]
+        sig = float(sig) if sig.ndim == 0 else tuple(float(s) for s in sig)
+        m = osw.compute_importance_map(ps, mode=str(g[f"imp_{i}_mode"]), sigma_scale=sig)
+        if f"imp_{i}_map" in g:
+            np.testing.assert_array_equal(m.numpy(), g[f"imp_{i}_map"])
+        else:
+            np.testing.assert_array_equal(m.numpy()[::7, ::5, ::3], g[f"imp_{i}_sample"])
+            assert m.double().sum().item() == float(g[f"imp_{i}_sum"])
+            assert [m.min().item(), m.max().item()] == list(g[f"imp_{i}_minmax"])
+        i += 1
+    assert i >= 5
+
+
+# ---------------------------------------------------------------- blend, bit-exact vs the reference
+def test_blend_bitwise_vs_reference(golden_dir):
+    g = _load(golden_dir, "blend.npz")
+    i = 0
+    while f"blend_{i}_shape" in g:
+        shape = tuple(int(v) for v in g[f"blend_{i}_shape"])
+        torch.manual_seed(int(g[f"blend_{i}_seed"]))
+        x = torch.rand(shape)
+        y = osw.sliding_window_inference(
+            x, tuple(int(v) for v in g[f"blend_{i}_roi"]), int(g[f"blend_{i}_sw"]), _toy(int(g[f"blend_{i}_k"])),
+            overlap=float(g[f"blend_{i}_ov"]), mode=str(g[f"blend_{i}_mode"]), padding_mode="constant", cval=-0.5,
+        )
+        assert y.shape == g[f"blend_{i}_out"].shape
+        assert np.array_equal(y.numpy(), g[f"blend_{i}_out"]), f"blend case {i} not bit-identical"
+        i += 1
+    assert i >= 5
+
+
+# ---------------------------------------------------------------- reference unit-test tables
+class _Pred:
+    """stateful predictor of tests/inferers/test_sliding_window_inference.py:164-169"""
+
+    def __init__(self):
+        self.add = 1
+
+    def compute(self, data):
+        self.add += 1
+        return data + self.add
+
+
+def test_sigma_tables_constant_and_gaussian():
+    # /root/reference/tests/inferers/test_sliding_window_inference.py:158-241 (test_sigma)
+    x = torch.ones((1, 1, 7, 7))
+    r = osw.sliding_window_inference(x, (3, 3), 10, _Pred().compute, overlap=0.5, padding_mode="constant", cval=-1,
+                                     mode="constant", sigma_scale=1.0)
+    rows = [3.0, 3.0, 3.3333, 3.6667, 4.3333, 4.5, 5.0]
+    np.testing.assert_allclose(r.numpy()[0, 0], np.repeat(np.asarray(rows)[:, None], 7, 1), rtol=1e-4)
+    r = osw.sliding_window_inference(x, (3, 3), 10, _Pred().compute, overlap=0.5, padding_mode="constant", cval=-1,
+                                     mode="gaussian", sigma_scale=1.0)
+    exp = np.array(
+        [
+            [3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0],
+            [3.0, 3.0, 3.0, 3.0, 3.0, 3.0, 3.0],
+            [3.3271625, 3.3271623, 3.3271623, 3.3271623, 3.3271623, 3.3271623, 3.3271625],
+            [3.6728377, 3.6728377, 3.6728377, 3.6728377, 3.6728377, 3.6728377, 3.6728377],
+            [4.3271623, 4.3271623, 4.3271627, 4.3271627, 4.3271627, 4.3271623, 4.3271623],
+            [4.513757, 4.513757, 4.513757, 4.513757, 4.513757, 4.513757, 4.513757],
+            [4.9999995, 5.0, 5.0, 5.0, 5.0, 5.0, 4.9999995],
+        ]
+    )
+    np.testing.assert_allclose(r.numpy()[0, 0], exp, rtol=1e-4)
+
+
+def test_cval_padding_table():
+    # /root/reference/tests/inferers/test_sliding_window_inference.py:243-267 (test_cval): 3x3 ones,
+    # roi 5x5 padded with -1: data.sum() = 9 - 16 = -7 -> 1 + (-7) = -6 everywhere after the crop.
+    x = torch.ones((1, 1, 3, 3))
+    r = osw.sliding_window_inference(x, (5, 5), 10, lambda d: d + d.sum(), overlap=0.5, padding_mode="constant",
+                                     cval=-1, mode="constant", sigma_scale=1.0)
+    np.testing.assert_allclose(r.numpy(), np.full((1, 1, 3, 3), -6.0), rtol=1e-4)
+
+
+@pytest.mark.parametrize(
+    "image,roi,sw,ov,mode",
+    [  # subset of TEST_CASES, tests/inferers/test_sliding_window_inference.py:28-46
+        ((2, 3, 16), (4,), 3, 0.25, "constant"),
+        ((2, 3, 16, 15, 7, 9), 4, 3, 0.25, "constant"),
+        ((1, 3, 16, 15, 7), (4, -1, 7), 3, 0.25, "constant"),
+        ((2, 3, 16, 15, 7), (4, -1, 7), 3, 0.25, "constant"),
+        ((3, 3, 16, 15, 7), (4, -1, 7), 3, 0.25, "constant"),
+        ((2, 3, 16, 15, 7), (4, -1, 7), 3, 0.25, "gaussian"),
+        ((1, 3, 16, 15, 7), (4, 10, 7), 3, 0.25, "constant"),
+        ((1, 3, 16, 15, 7), (20, 22, 23), 10, 0.25, "constant"),
+        ((2, 3, 15, 7), (2, 6), 1000, 0.25, "constant"),
+        ((1, 3, 16, 7), (80, 50), 7, 0.25, "gaussian"),
+        ((1, 3, 16, 15, 7), (20, 22, 23), 10, 0.5, "gaussian"),
+        ((1, 3, 16, 15, 7), (20, 22, 23), 10, (0.5, 0.25, 0), "gaussian"),
+    ],
+)
+def test_identity_like_predictor_cases(image, roi, sw, ov, mode):
+    # test_sliding_window_default :98-121 -- predictor x+1 must come back as x+1
+    n = int(np.prod(image))
+    x = torch.arange(n, dtype=torch.float32).reshape(image) / n
+    r = osw.sliding_window_inference(x, roi, sw, lambda d: d + 1, overlap=ov, mode=mode)
+    np.testing.assert_allclose(r.numpy(), x.numpy() + 1, rtol=1e-6, atol=1e-6)
+
+
+def test_default_device_exact_arange():
+    # test_default_device :123-141: constant mode on an integer arange must reproduce x+1 EXACTLY
+    x = torch.arange(1 * 3 * 16 * 15 * 7, dtype=torch.float32).reshape(1, 3, 16, 15, 7)
+    r = osw.sliding_window_inference(x, (4, 10, 7), 3, lambda d: d + 1, overlap=0.25, mode="constant")
+    assert torch.equal(r, x + 1)
+
+
+def test_multioutput_tuple_and_dict():
+    # test_multioutput :314-373: outputs at 1x, 2x (upsampled), 1/3x resolution, tuple and dict
+    x = torch.ones((1, 6, 20, 20))
+
+    def compute(d):
+        return d + 1, d[:, ::3, ::2, ::2] + torch.tensor(2.0), d[:, ::2, ::4, ::4] + torch.tensor(3.0)
+
+    def compute_dict(d):
+        a, b, c = compute(d)
+        return {1: a, "2": b, "3.0": c} if False else {"1": a, "2": b, "3": c}
+
+    t = osw.sliding_window_inference(x, (8, 8), 10, compute, overlap=0.5, mode="constant")
+    assert [tuple(o.shape) for o in t] == [(1, 6, 20, 20), (1, 2, 10, 10), (1, 3, 5, 5)]
+    for o, v in zip(t, (2.0, 3.0, 4.0)):
+        np.testing.assert_allclose(o.numpy(), np.full(o.shape, v), rtol=1e-4)
+    d = osw.sliding_window_inference(x, (8, 8), 10, compute_dict, overlap=0.5, mode="constant")
+    assert sorted(d.keys()) == ["1", "2", "3"]
+    np.testing.assert_allclose(d["3"].numpy(), np.full((1, 3, 5, 5), 4.0), rtol=1e-4)
+
+
+# ---------------------------------------------------------------- network, bit-exact vs the reference
+def test_state_init_order_matches_reference(golden_dir):
+    g0, g5 = _load(golden_dir, "config0.npz"), _load(golden_dir, "net5.npz")
+    torch.manual_seed(0)
+    assert _digest(oracle.make_basic_unet_state(1, 2)) == str(g0["cfg0_state_sha256"])
+    torch.manual_seed(1)
+    sd = oracle.make_basic_unet_state(1, 5)
+    assert _digest(sd) == str(g5["net5_state_sha256"])
+    assert list(sd.keys()) == list(g5["net5_keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(g5["net5_shapes"])
+
+
+def test_basic_unet_forward_bitwise_vs_reference(golden_dir):
+    g = _load(golden_dir, "net5.npz")
+    torch.manual_seed(1)
+    sd = oracle.make_basic_unet_state(1, 5)
+    torch.manual_seed(21)
+    x = torch.rand(2, 1, 32, 32, 32)
+    with torch.no_grad():
+        assert np.array_equal(oracle.basic_unet_forward(sd, x).numpy(), g["net5_win32_out"])
+    torch.manual_seed(22)
+    x = torch.rand(1, 1, 48, 32, 16)
+    with torch.no_grad():
+        assert np.array_equal(oracle.basic_unet_forward(sd, x).numpy(), g["net5_win48x32x16_out"])
+
+
+def test_config0_end_to_end_bitwise_vs_reference(golden_dir):
+    """BASELINE.json configs[0]: BasicUNet(1->2), rand 64^3, roi 32^3, sw_batch 4, ov .5, gaussian."""
+    g = _load(golden_dir, "config0.npz")
+    torch.manual_seed(0)
+    sd = oracle.make_basic_unet_state(1, 2)
+    x = torch.rand(1, 1, 64, 64, 64)
+    assert x.double().sum().item() == float(g["cfg0_x_sum"])
+    with torch.no_grad():
+        y = osw.sliding_window_inference(x, (32, 32, 32), 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5,
+                                         mode="gaussian")
+    assert np.array_equal(y.numpy(), g["cfg0_out"])
