@@ -1,0 +1,109 @@
+/* monai_amd -- C ABI of the MI355X (gfx950) kernels behind MONAI's 3-D sliding-window segmentation
+ * hot path.  This library takes the place of the reference's native layer (`monai._C`, built from
+ * monai/csrc by setup.py:81-125, and the JIT loader monai/_extensions/loader.py:49-93) for this path,
+ * and of the ATen operators the reference's Python reaches on it.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (in practice
+ *     torch-ROCm tensors); nothing is allocated, freed or synchronised inside the library;
+ *   - every call enqueues its kernels on `stream` (a hipStream_t passed as void*) and returns at once;
+ *   - return value 0 = ok, negative = error; mh_last_error() gives the thread-local message.  This is
+ *     the AT_ERROR -> RuntimeError behaviour of the reference (monai/csrc/resample/pushpull.h:64-78);
+ *   - all data is fp32 ("compute_dtype = inputs.dtype", monai/inferers/utils.py:148), laid out NCDHW
+ *     with W contiguous.  2-D problems are passed with D = 1.
+ */
+#ifndef MONAI_AMD_H
+#define MONAI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MH_OK 0
+#define MH_ERR_ARG (-1)
+#define MH_ERR_LAUNCH (-2)
+#define MH_ERR_UNSUPPORTED (-3)
+
+/* Activation tensor view.  `nrm` is NULL or points at one {alpha, beta, slope, 0} float4 per (n, c):
+ * consumers see  y = fma(x, alpha, beta); y = y > 0 ? y : y*slope  (InstanceNorm3d(affine) followed by
+ * LeakyReLU -- the ADN("NDA") block of monai/networks/blocks/acti_norm.py:69-101 -- applied on load
+ * instead of in a pass of its own).  n_stride / nrm_n_stride are in floats. */
+typedef struct mh_tensor5 {
+    float* data;
+    int64_t n_stride;
+    const float* nrm;
+    int64_t nrm_n_stride;
+    int32_t N, C, D, H, W;
+} mh_tensor5;
+
+int mh_version(void);
+const char* mh_last_error(void);
+
+/* ---- sliding-window inferer (monai/inferers/utils.py:42-321) -------------------------------------- */
+
+/* The dense window grid of dense_patch_slices (monai/data/utils.py:166-206) is described by its per-axis
+ * start lists sz/sy/sx (ascending; HOST int32 arrays, copied into the kernel arguments -- at most 160
+ * windows per axis); window w = (iz*ny + iy)*nx + ix, i.e. row-major with the last axis fastest. */
+
+/* Window gather, utils.py:217-224 (`torch.cat([inputs[win_slice] ...])`).  vol is one image [C,D,H,W];
+ * windows w0 .. w0+nwin-1 of the grid are written to out [nwin, C, rd, rh, rw] (dense). */
+int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const int32_t* sz, int nz,
+                          const int32_t* sy, int ny, const int32_t* sx, int nx, int w0, int nwin, int rd, int rh,
+                          int rw, float* out, void* stream);
+
+/* Importance-weighted blend + normalise, utils.py:264-298 (`seg *= w; out[win] += seg; cnt[win] += w;
+ * out /= cnt`) as ONE gather pass: for every output voxel the covering windows are visited in
+ * ascending window index, acc += fp32(logit*w), cnt += w, out = acc/cnt -- bit-identical to the
+ * reference's scatter order.
+ *   logits  [nz*ny*nx][K][rd][rh][rw]   all windows of the grid, in window order
+ *   imp     [rd][rh][rw]                importance map (monai/data/utils.py:1084-1134)
+ *   out     [K][D][H][W]
+ * Every voxel must be covered by at least one window (true for dense_patch_slices). */
+int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd,
+                    int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
+                    int nx, void* stream);
+
+/* ---- network blocks (BasicUNet: monai/networks/nets/basic_unet.py:27-279) -------------------------- */
+
+/* Conv3d k=3, stride 1, padding 1 (+bias) -- the conv of `Convolution`, blocks/convolutions.py:98-171.
+ * Several kernel configurations exist; mh_conv3d_k3_select picks one (0 = direct VALU kernel, any
+ * channel counts; >= 1 = fp32-MFMA implicit-GEMM tiles).  Weights are repacked once per configuration. */
+int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W);
+int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
+/* w: torch layout [Cout][Cin][3][3][3] */
+int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream);
+/* number of statistics records per (n, c) this configuration emits (0: none, use mh_instnorm_stats) */
+int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W);
+/* out = conv(act(in)) + bias.  `stats`: NULL or [N][Cout][tiles][3] {count, mean, M2} partial records
+ * of the values written (fused InstanceNorm statistics). */
+int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias,
+                     const mh_tensor5* out, float* stats, void* stream);
+
+/* InstanceNorm3d statistics (nn.InstanceNorm3d(affine=True, eps) via layers/factories.py:228-241):
+ * partial {count, mean, M2} records per 4096-element chunk of each (n, c) plane, then a finalize that
+ * merges `tiles` records per (n, c) in fp64 and writes the consumer-side float4
+ * {alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha, slope, 0} (biased variance). */
+int mh_instnorm_stat_tiles(int D, int H, int W);
+int mh_instnorm_stats_f32(const mh_tensor5* x, float* stats, void* stream);
+int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const float* gamma, const float* beta,
+                             float eps, float slope, float* nrm, int64_t nrm_n_stride, void* stream);
+
+/* MaxPool3d(kernel_size=2) of act(in) -- `Down`, basic_unet.py:61-89.  out dims = floor(in/2). */
+int mh_maxpool2_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
+
+/* ConvTranspose3d(k=2, s=2) (+bias) of act(in) -- UpSample(mode="deconv"), blocks/upsample.py:102-116.
+ * w: torch layout [Cin][Cout][2][2][2].  out dims = 2*in. */
+int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
+                       void* stream);
+
+/* Conv3d k=1 (+bias) of act(in) -- `final_conv`, basic_unet.py:252.  w: [Cout][Cin]. */
+int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONAI_AMD_H */

@@ -1,0 +1,155 @@
+"""ctypes binding of ``libmonai_amd.so`` (C ABI declared in ``include/monai_amd.h``).
+
+The library is the HIP/gfx950 build produced by ``python -m monai_amd.build`` (or
+``__graft_entry__.build()``) and is loaded from the package directory.  There is NO fallback: if the
+shared object is missing or a tensor is not on a ROCm device the call raises ``RuntimeError`` -- the
+same contract as the reference's ``monai._C`` ("Not compiled with GPU support",
+monai/csrc/resample/pushpull.h:95).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmonai_amd.so")
+
+
+class MhTensor5(C.Structure):
+    """``mh_tensor5`` of include/monai_amd.h"""
+
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("n_stride", C.c_int64),
+        ("nrm", C.c_void_p),
+        ("nrm_n_stride", C.c_int64),
+        ("N", C.c_int32),
+        ("C", C.c_int32),
+        ("D", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+    ]
+
+
+_I, _L, _P, _F = C.c_int, C.c_int64, C.c_void_p, C.c_float
+_T = C.POINTER(MhTensor5)
+_IA = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "mh_version": (_I, []),
+    "mh_last_error": (C.c_char_p, []),
+    "mh_window_extract_f32": (_I, [_P, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "mh_sw_blend_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _P]),
+    "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I]),
+    "mh_conv3d_k3_packed_floats": (_L, [_I, _I, _I]),
+    "mh_conv3d_k3_pack_f32": (_I, [_I, _P, _I, _I, _P, _P]),
+    "mh_conv3d_k3_stat_tiles": (_I, [_I, _I, _I, _I]),
+    "mh_conv3d_k3_f32": (_I, [_I, _T, _P, _P, _T, _P, _P]),
+    "mh_instnorm_stat_tiles": (_I, [_I, _I, _I]),
+    "mh_instnorm_stats_f32": (_I, [_T, _P, _P]),
+    "mh_instnorm_finalize_f32": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _L, _P]),
+    "mh_maxpool2_f32": (_I, [_T, _T, _P]),
+    "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
+    "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
+}
+
+
+class Library:
+    """A loaded ``libmonai_amd`` with typed entry points and error translation."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"monai_amd: HIP extension not built ({path} missing). Run `python -m monai_amd.build` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback."
+            )
+        self.path = path
+        self._dll = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self._dll, name)  # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+            setattr(self, "_" + name, fn)
+
+    def last_error(self) -> str:
+        return self._mh_last_error().decode("utf-8", "replace")
+
+    def check(self, rc: int) -> None:
+        if rc != 0:
+            raise RuntimeError(f"monai_amd: {self.last_error()} (code {rc})")
+
+    def call(self, name: str, *args) -> None:
+        self.check(getattr(self, "_" + name)(*args))
+
+    def query(self, name: str, *args) -> int:
+        rc = getattr(self, "_" + name)(*args)
+        if rc < 0:
+            raise RuntimeError(f"monai_amd: {self.last_error()} (code {rc})")
+        return int(rc)
+
+
+_LIB: Optional[Library] = None
+
+
+def lib() -> Library:
+    """The process-wide library handle (loaded on first use; raises if the extension is missing)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = Library(LIB_PATH)
+    return _LIB
+
+
+def require_device(*tensors: torch.Tensor) -> None:
+    """Every tensor handed to a kernel must live on a ROCm device, be fp32 and be contiguous enough for
+    the view it is used as.  CPU tensors are an error, never a silent fallback."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "monai_amd: this path runs only on an MI355X (ROCm) device tensor; got a CPU tensor. "
+                "There is no CPU fallback in the product path."
+            )
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"monai_amd: fp32 tensors only on this path, got {t.dtype}")
+
+
+def stream_ptr(t: torch.Tensor) -> C.c_void_p:
+    """Raw hipStream_t of torch's current stream on t's device (0 = default stream for host stand-ins)."""
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def int_array(values: Sequence[int]):
+    return (C.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def tensor5(t: torch.Tensor, nrm: Optional[torch.Tensor] = None) -> MhTensor5:
+    """View descriptor of a 5-D NCDHW fp32 tensor whose (C, D, H, W) block is dense; the batch stride is
+    free, so channel slices of a wider buffer (``buf[:, 32:64]``) are valid views.  ``nrm`` is the matching
+    slice of a ``[N, Ctot, 4]`` parameter tensor."""
+    if t.dim() != 5:
+        raise RuntimeError(f"monai_amd: expected a 5-D NCDHW tensor, got shape {tuple(t.shape)}")
+    n, c, d, h, w = t.shape
+    st = t.stride()
+    if st[4] != 1 or st[3] != w or st[2] != h * w or st[1] != d * h * w:
+        raise RuntimeError(f"monai_amd: tensor view is not dense in (C,D,H,W): strides {st}")
+    m = MhTensor5()
+    m.data, m.n_stride = t.data_ptr(), (st[0] if n > 1 else max(st[0], c * d * h * w))
+    m.N, m.C, m.D, m.H, m.W = n, c, d, h, w
+    if nrm is not None:
+        if nrm.dim() != 3 or nrm.shape[0] != n or nrm.shape[1] != c or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
+            raise RuntimeError(f"monai_amd: nrm must be a [N,C,4] slice, got {tuple(nrm.shape)} strides {nrm.stride()}")
+        m.nrm, m.nrm_n_stride = nrm.data_ptr(), (nrm.stride(0) if n > 1 else max(nrm.stride(0), 4 * c))
+    else:
+        m.nrm, m.nrm_n_stride = None, 0
+    return m

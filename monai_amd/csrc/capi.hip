@@ -1,0 +1,289 @@
+// C ABI of libmonai_amd.so (declared in include/monai_amd.h): argument checks, kernel-configuration
+// choice and launches.  Everything is stream ordered; nothing allocates or synchronises.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "kernels/common.h"
+#include "kernels/conv3d_mfma.h"
+#include "kernels/nn_simple.h"
+#include "kernels/sliding.h"
+
+using namespace mh;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+static int launched(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(MH_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return MH_OK;
+}
+static inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static bool dense_ok(const mh_tensor5* t) {
+    return t && t->data && t->N > 0 && t->C > 0 && t->D > 0 && t->H > 0 && t->W > 0 &&
+           t->n_stride >= (int64_t)t->C * t->D * t->H * t->W;
+}
+
+// All mh_* functions below have C linkage through their declarations in include/monai_amd.h.
+
+int mh_version(void) { return 100; }
+const char* mh_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ inferer
+static int fill_grid(WindowGrid& g, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx) {
+    if (!sz || !sy || !sx || nz < 1 || ny < 1 || nx < 1) return fail(MH_ERR_ARG, "window grid: null/empty start list");
+    if (nz > MAX_AXIS_WINDOWS || ny > MAX_AXIS_WINDOWS || nx > MAX_AXIS_WINDOWS)
+        return fail(MH_ERR_UNSUPPORTED, "window grid: more than %d windows on one axis", MAX_AXIS_WINDOWS);
+    g.nz = nz; g.ny = ny; g.nx = nx;
+    memset(g.sz, 0, sizeof(g.sz)); memset(g.sy, 0, sizeof(g.sy)); memset(g.sx, 0, sizeof(g.sx));
+    memcpy(g.sz, sz, sizeof(int) * nz); memcpy(g.sy, sy, sizeof(int) * ny); memcpy(g.sx, sx, sizeof(int) * nx);
+    for (int i = 1; i < nz; ++i) if (sz[i] < sz[i - 1]) return fail(MH_ERR_ARG, "window starts must ascend (z)");
+    for (int i = 1; i < ny; ++i) if (sy[i] < sy[i - 1]) return fail(MH_ERR_ARG, "window starts must ascend (y)");
+    for (int i = 1; i < nx; ++i) if (sx[i] < sx[i - 1]) return fail(MH_ERR_ARG, "window starts must ascend (x)");
+    return MH_OK;
+}
+static bool all_mult4(const int32_t* s, int n) {
+    for (int i = 0; i < n; ++i) if (s[i] % 4) return false;
+    return true;
+}
+
+int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const int32_t* sz, int nz, const int32_t* sy,
+                          int ny, const int32_t* sx, int nx, int w0, int nwin, int rd, int rh, int rw, float* out,
+                          void* stream) {
+    if (!vol || !out || C < 1 || nwin < 1 || w0 < 0) return fail(MH_ERR_ARG, "window_extract: bad argument");
+    WindowGrid g;
+    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
+    if ((long long)w0 + nwin > (long long)nz * ny * nx) return fail(MH_ERR_ARG, "window_extract: window range out of grid");
+    if (sz[nz - 1] + rd > D || sy[ny - 1] + rh > H || sx[nx - 1] + rw > W || sz[0] < 0 || sy[0] < 0 || sx[0] < 0)
+        return fail(MH_ERR_ARG, "window_extract: window leaves the volume");
+    const bool v4 = rw % 4 == 0 && W % 4 == 0 && all_mult4(sx, nx) && aligned(vol, 16) && aligned(out, 16);
+    const long long total = (long long)nwin * C * rd * rh * (v4 ? rw / 4 : rw);
+    if (v4)
+        hipLaunchKernelGGL((window_extract_kernel<4>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D,
+                           H, W, g, w0, nwin, rd, rh, rw, out);
+    else
+        hipLaunchKernelGGL((window_extract_kernel<1>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D,
+                           H, W, g, w0, nwin, rd, rh, rw, out);
+    return launched("window_extract");
+}
+
+template <int VEC>
+static void launch_blend(int kt, unsigned nb, hipStream_t s, const float* logits, const float* imp, float* out, int K, int k0,
+                         int D, int H, int W, int rd, int rh, int rw, const WindowGrid& g) {
+#define MH_BLEND_CASE(KT)                                                                                              \
+    case KT:                                                                                                           \
+        hipLaunchKernelGGL((sw_blend_kernel<KT, VEC>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, \
+                           rh, rw, g);                                                                                 \
+        break;
+    switch (kt) {
+        MH_BLEND_CASE(1) MH_BLEND_CASE(2) MH_BLEND_CASE(3) MH_BLEND_CASE(4)
+        MH_BLEND_CASE(5) MH_BLEND_CASE(6) MH_BLEND_CASE(7) MH_BLEND_CASE(8)
+    }
+#undef MH_BLEND_CASE
+}
+
+int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
+                    const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, void* stream) {
+    if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "sw_blend: bad argument");
+    WindowGrid g;
+    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
+    // full coverage: first window at 0, last ends at the image end, no gaps
+    const int32_t* ss[3] = {sz, sy, sx};
+    const int nn[3] = {nz, ny, nx}, rr[3] = {rd, rh, rw}, dd[3] = {D, H, W};
+    for (int a = 0; a < 3; ++a) {
+        if (ss[a][0] != 0 || ss[a][nn[a] - 1] + rr[a] != dd[a]) return fail(MH_ERR_ARG, "sw_blend: windows do not span axis %d", a);
+        for (int i = 1; i < nn[a]; ++i)
+            if (ss[a][i] > ss[a][i - 1] + rr[a]) return fail(MH_ERR_ARG, "sw_blend: uncovered gap on axis %d", a);
+    }
+    const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16);
+    const long long total = (long long)D * H * (v4 ? W / 4 : W);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        const int kt = K - k0 < 8 ? K - k0 : 8;
+        if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g);
+        else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g);
+    }
+    return launched("sw_blend");
+}
+
+// ------------------------------------------------------------------------------------------ conv 3x3x3
+//                        MX MY MZ MT WM WN NT CC
+typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 8> Cfg1;   // tile 32x4x4, 32 couts   (96^3 level)
+typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 8> Cfg2;   // tile 16x8x4, 32 couts   (48^3 level)
+typedef ConvCfg<8, 4, 1, 2, 2, 2, 1, 8> Cfg3;    // tile 8x8x2,  64 couts   (24^3 level)
+typedef ConvCfg<4, 4, 2, 1, 1, 4, 1, 4> Cfg4;    // tile 4x4x2, 128 couts   (12^3 level)
+typedef ConvCfg<4, 4, 2, 1, 1, 4, 2, 2> Cfg5;    // tile 4x4x2, 256 couts   (6^3 level)
+typedef ConvCfg<8, 4, 1, 2, 4, 1, 1, 8> Cfg6;    // tile 8x8x4,  32 couts   (small volumes)
+#define MH_NUM_CFG 6
+
+struct CfgInfo { int tx, ty, tz, cn, cc; };
+static const CfgInfo kCfg[MH_NUM_CFG + 1] = {
+    {0, 0, 0, 0, 0},
+    {Cfg1::TX, Cfg1::TY, Cfg1::TZ, Cfg1::CN, Cfg1::CC}, {Cfg2::TX, Cfg2::TY, Cfg2::TZ, Cfg2::CN, Cfg2::CC},
+    {Cfg3::TX, Cfg3::TY, Cfg3::TZ, Cfg3::CN, Cfg3::CC}, {Cfg4::TX, Cfg4::TY, Cfg4::TZ, Cfg4::CN, Cfg4::CC},
+    {Cfg5::TX, Cfg5::TY, Cfg5::TZ, Cfg5::CN, Cfg5::CC}, {Cfg6::TX, Cfg6::TY, Cfg6::TZ, Cfg6::CN, Cfg6::CC},
+};
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
+    if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "conv3d_k3_select: bad argument");
+    int best = 0;
+    double best_score = 0.0;
+    if (Cin <= Cfg1::NRM_MAX) {
+        for (int c = 1; c <= MH_NUM_CFG; ++c) {
+            const CfgInfo& k = kCfg[c];
+            if (Cout % k.cn || Cin % k.cc) continue;
+            const double util = (double)D * H * W / ((double)cdiv(D, k.tz) * k.tz * cdiv(H, k.ty) * k.ty * cdiv(W, k.tx) * k.tx);
+            // prefer full tiles; among equals the wider cout tile (input staged once for more outputs)
+            const double score = util * (1.0 + 0.02 * (k.cn / 32)) * (1.0 + 0.001 * (MH_NUM_CFG - c));
+            if (score > best_score) { best_score = score; best = c; }
+        }
+    }
+    return best;
+}
+
+int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
+    if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    return (int64_t)Cin * Cout * 27;
+}
+
+int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream) {
+    if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
+    const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
+    if (Cout % cn) return fail(MH_ERR_ARG, "conv3d_k3_pack: Cout %d not a multiple of %d", Cout, cn);
+    hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for((long long)Cin * Cout * 27)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cin, Cout, cn, packed);
+    return launched("conv3d_k3_pack");
+}
+
+int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
+    if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
+    const CfgInfo& k = kCfg[cfg];
+    return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
+}
+
+template <class Cfg>
+static void launch_mfma(const Tensor& in, const float* wp, const float* bias, const Tensor& out, float* stats, hipStream_t s) {
+    const int tx = cdiv(out.W, Cfg::TX), ty = cdiv(out.H, Cfg::TY), tz = cdiv(out.D, Cfg::TZ);
+    const dim3 grid((unsigned)(tx * ty * tz), (unsigned)(out.C / Cfg::CN), (unsigned)out.N);
+    if (stats)
+        hipLaunchKernelGGL((conv3d_k3_mfma_kernel<Cfg, true>), grid, dim3(256), 0, s, in, wp, bias, out, stats, tx, ty, tz);
+    else
+        hipLaunchKernelGGL((conv3d_k3_mfma_kernel<Cfg, false>), grid, dim3(256), 0, s, in, wp, bias, out, stats, tx, ty, tz);
+}
+
+int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
+                     float* stats, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
+    if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    if (cfg == 0) {
+        if (stats) return fail(MH_ERR_ARG, "conv3d_k3: the direct kernel emits no statistics");
+        constexpr int COT = 16;
+        const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
+        hipLaunchKernelGGL((conv3d_k3_direct_kernel<COT>), grid, dim3(256), 0, s, in, packed_w, bias, out);
+        return launched("conv3d_k3_direct");
+    }
+    const CfgInfo& k = kCfg[cfg];
+    if (out.C % k.cn || in.C % k.cc || in.C > Cfg1::NRM_MAX)
+        return fail(MH_ERR_ARG, "conv3d_k3: configuration %d does not take Cin=%d Cout=%d", cfg, in.C, out.C);
+    if (!aligned(packed_w, 16)) return fail(MH_ERR_ARG, "conv3d_k3: packed weights must be 16-byte aligned");
+    switch (cfg) {
+        case 1: launch_mfma<Cfg1>(in, packed_w, bias, out, stats, s); break;
+        case 2: launch_mfma<Cfg2>(in, packed_w, bias, out, stats, s); break;
+        case 3: launch_mfma<Cfg3>(in, packed_w, bias, out, stats, s); break;
+        case 4: launch_mfma<Cfg4>(in, packed_w, bias, out, stats, s); break;
+        case 5: launch_mfma<Cfg5>(in, packed_w, bias, out, stats, s); break;
+        case 6: launch_mfma<Cfg6>(in, packed_w, bias, out, stats, s); break;
+    }
+    return launched("conv3d_k3_mfma");
+}
+
+// ------------------------------------------------------------------------------------------ instance norm
+int mh_instnorm_stat_tiles(int D, int H, int W) {
+    return (int)(((long long)D * H * W + STAT_CHUNK - 1) / STAT_CHUNK);
+}
+
+int mh_instnorm_stats_f32(const mh_tensor5* x_, float* stats, void* stream) {
+    if (!dense_ok(x_) || !stats) return fail(MH_ERR_ARG, "instnorm_stats: bad argument");
+    const Tensor x = from_c(*x_);
+    const int tiles = mh_instnorm_stat_tiles(x.D, x.H, x.W);
+    hipLaunchKernelGGL(instnorm_stats_kernel, dim3((unsigned)tiles, (unsigned)x.C, (unsigned)x.N), dim3(256), 0,
+                       (hipStream_t)stream, x, stats, tiles);
+    return launched("instnorm_stats");
+}
+
+int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const float* gamma, const float* beta, float eps,
+                             float slope, float* nrm, int64_t nrm_n_stride, void* stream) {
+    if (!stats || !nrm || tiles < 1 || N < 1 || C < 1 || nrm_n_stride < 4LL * C) return fail(MH_ERR_ARG, "instnorm_finalize: bad argument");
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)C, (unsigned)N), dim3(64), 0, (hipStream_t)stream, stats, tiles,
+                       C, gamma, beta, eps, slope, nrm, (long long)nrm_n_stride);
+    return launched("instnorm_finalize");
+}
+
+// ------------------------------------------------------------------------------------------ pool / deconv / 1x1
+int mh_maxpool2_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "maxpool2: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.C != out.C || out.D != in.D / 2 || out.H != in.H / 2 || out.W != in.W / 2)
+        return fail(MH_ERR_ARG, "maxpool2: output must be floor(input/2)");
+    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)out.C, (unsigned)out.N);
+    const bool pair = in.W % 2 == 0 && aligned(in.data, 8) && in.n_stride % 2 == 0;
+    if (pair) hipLaunchKernelGGL((maxpool2_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    else hipLaunchKernelGGL((maxpool2_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    return launched("maxpool2");
+}
+
+int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !w) return fail(MH_ERR_ARG, "deconv_k2s2: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D != 2 * in.D || out.H != 2 * in.H || out.W != 2 * in.W)
+        return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
+    if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
+    constexpr int COT = 4;
+    const dim3 grid(blocks_for((long long)in.D * in.H * in.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
+    hipLaunchKernelGGL((deconv_k2s2_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
+    return launched("deconv_k2s2");
+}
+
+template <int VEC>
+static void launch_1x1(int co, unsigned nb, unsigned nbatch, hipStream_t s, const Tensor& in, const float* w, const float* bias,
+                       const Tensor& out, int co0) {
+#define MH_1X1_CASE(CO)                                                                                               \
+    case CO:                                                                                                          \
+        hipLaunchKernelGGL((conv1x1_kernel<CO, VEC>), dim3(nb, nbatch), dim3(256), 0, s, in, w, bias, out, co0);      \
+        break;
+    switch (co) {
+        MH_1X1_CASE(1) MH_1X1_CASE(2) MH_1X1_CASE(3) MH_1X1_CASE(4)
+        MH_1X1_CASE(5) MH_1X1_CASE(6) MH_1X1_CASE(7) MH_1X1_CASE(8)
+    }
+#undef MH_1X1_CASE
+}
+
+int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !w) return fail(MH_ERR_ARG, "conv1x1: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv1x1: shape mismatch");
+    const long long DHW = (long long)in.D * in.H * in.W;
+    const bool v4 = DHW % 4 == 0 && aligned(in.data, 16) && aligned(out.data, 16) && in.n_stride % 4 == 0 && out.n_stride % 4 == 0;
+    const unsigned nb = blocks_for(v4 ? DHW / 4 : DHW);
+    for (int co0 = 0; co0 < out.C; co0 += 8) {
+        const int co = out.C - co0 < 8 ? out.C - co0 : 8;
+        if (v4) launch_1x1<4>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
+        else launch_1x1<1>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
+    }
+    return launched("conv1x1");
+}
+

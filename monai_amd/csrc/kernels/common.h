@@ -1,0 +1,65 @@
+// Shared device helpers for the gfx950 kernels of the sliding-window segmentation path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/monai_amd.h"
+
+namespace mh {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Activation tensor view, NCDHW fp32: W contiguous, H stride W, D stride H*W, C stride D*H*W, batch
+// stride free (so a view can be a channel range of a wider buffer, e.g. one half of a concat buffer).
+// `nrm` (may be null) holds one float4 {alpha, beta, slope, 0} per (n, c): the value a consumer must
+// see is  y = fma(x, alpha, beta);  y = y > 0 ? y : y * slope  -- i.e. InstanceNorm(affine) followed
+// by LeakyReLU, deferred from the producer to the consumer's load (alpha=1, beta=0, slope=1: identity).
+struct Tensor {
+    float* data;
+    long long n_stride;
+    const float* nrm;
+    long long nrm_n_stride;
+    int N, C, D, H, W;
+};
+
+__host__ __device__ inline Tensor from_c(const mh_tensor5& t) {
+    Tensor r;
+    r.data = t.data; r.n_stride = t.n_stride; r.nrm = t.nrm; r.nrm_n_stride = t.nrm_n_stride;
+    r.N = t.N; r.C = t.C; r.D = t.D; r.H = t.H; r.W = t.W;
+    return r;
+}
+
+__device__ __forceinline__ float act(float x, float alpha, float beta, float slope) {
+    float y = fmaf(x, alpha, beta);
+    return y > 0.0f ? y : y * slope;
+}
+
+__device__ __forceinline__ float4 load_nrm(const Tensor& t, int n, int c) {
+    if (t.nrm == nullptr) return make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    return *reinterpret_cast<const float4*>(t.nrm + (long long)n * t.nrm_n_stride + 4LL * c);
+}
+
+// Statistics record used for instance norm: element count, mean, and M2 = sum (x - mean)^2.
+// Combination is Chan et al.'s pairwise update, safe for empty sides.
+struct Stat {
+    float n, mean, m2;
+};
+__device__ __forceinline__ Stat stat_merge(Stat a, Stat b) {
+    Stat r;
+    r.n = a.n + b.n;
+    if (r.n <= 0.0f) { r.mean = 0.0f; r.m2 = 0.0f; return r; }
+    const float d = b.mean - a.mean;
+    const float f = b.n / r.n;
+    r.mean = a.mean + d * f;
+    r.m2 = a.m2 + b.m2 + d * d * a.n * f;
+    return r;
+}
+
+// XCD-aware, bijective remap of a 1-D block index: the dispatcher places block b on XCD b % 8
+// (observed, used for L2 locality only), so give each XCD a contiguous run of logical tiles.
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nb) {
+    const unsigned q = nb / 8u, r = nb % 8u, x = b % 8u, i = b / 8u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
+}
+
+}  // namespace mh

@@ -1,0 +1,268 @@
+// HBM-bound network kernels of the BasicUNet path (everything except the 3x3x3 implicit-GEMM conv):
+// direct conv (first layer / odd channel counts), max-pool, transposed conv k2s2, 1x1 conv, and the
+// InstanceNorm statistics.  All of them apply the producer's deferred InstanceNorm+LeakyReLU on load
+// (`act`, common.h) and stream W-contiguous rows, one or four voxels per lane.
+#pragma once
+#include "common.h"
+
+namespace mh {
+
+// ---------------------------------------------------------------------------------------------------
+// Conv3d 3x3x3 pad 1, direct form.  One thread = one output voxel x COT output channels; weights come from
+// the packed layout [Cin][27][Cout] (block-uniform addresses -> scalar loads).  Used for Cin = 1 (first
+// layer: 27 taps, HBM-write bound) and as the general path for channel counts the MFMA tiles do not take.
+template <int COT>
+__global__ void __launch_bounds__(256)
+conv3d_k3_direct_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out) {
+    const int D = out.D, H = out.H, W = out.W, Cin = in.C, Cout = out.C;
+    const long long DHW = (long long)D * H * W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= DHW) return;
+    const int x = (int)(idx % W);
+    const long long t = idx / W;
+    const int y = (int)(t % H), z = (int)(t / H);
+
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+
+    const float* src = in.data + (long long)n * in.n_stride;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float* plane = src + (long long)ci * DHW;
+        const float* wrow = wp + (long long)ci * 27 * Cout + co0;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xx = x + tap % 3 - 1;
+            float v = 0.0f;
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = act(plane[((long long)zz * H + yy) * W + xx], a.x, a.y, a.z);
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+                if (co0 + j < Cout) acc[j] = fmaf(v, wrow[tap * Cout + j], acc[j]);
+        }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+        if (co0 + j < Cout) dst[(long long)(co0 + j) * DHW] = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// MaxPool3d(2) of act(in).  One thread per output voxel; the two x-neighbours come in as one float2.
+template <bool PAIR>
+__global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
+    const int Do = out.D, Ho = out.H, Wo = out.W, H = in.H, W = in.W;
+    const long long ovol = (long long)Do * Ho * Wo;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    if (idx >= ovol) return;
+    const int xo = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int yo = (int)(t % Ho), zo = (int)(t / Ho);
+    const float4 a = load_nrm(in, n, c);
+    const float* src = in.data + (long long)n * in.n_stride + (long long)c * in.D * H * W;
+    float m = -3.402823466e+38f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const float* row = src + ((long long)(2 * zo + dz) * H + (2 * yo + dy)) * W + 2 * xo;
+            float v0, v1;
+            if (PAIR) {
+                const float2 q = *reinterpret_cast<const float2*>(row);
+                v0 = q.x; v1 = q.y;
+            } else {
+                v0 = row[0]; v1 = row[1];
+            }
+            m = fmaxf(m, fmaxf(act(v0, a.x, a.y, a.z), act(v1, a.x, a.y, a.z)));
+        }
+    out.data[(long long)n * out.n_stride + (long long)c * ovol + idx] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d k=2 s=2 of act(in): every input voxel owns a disjoint 2x2x2 output block, so it is eight
+// independent 1x1 convs.  One thread = one input voxel x COT output channels x 8 taps; weights
+// [Cin][Cout][8] are block-uniform (scalar loads); each (cout, dz, dy) row pair is one coalesced float2 store.
+template <int COT>
+__global__ void __launch_bounds__(256)
+deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
+    const int Di = in.D, Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
+    const long long ivol = (long long)Di * Hi * Wi;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= ivol) return;
+    const int x = (int)(idx % Wi);
+    const long long t = idx / Wi;
+    const int y = (int)(t % Hi), z = (int)(t / Hi);
+
+    float acc[COT][8];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const float bj = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[j][k] = bj;
+    }
+    const float* src = in.data + (long long)n * in.n_stride + idx;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float v = act(src[(long long)ci * ivol], a.x, a.y, a.z);
+        const float* wr = w + ((long long)ci * Cout + co0) * 8;
+#pragma unroll
+        for (int j = 0; j < COT; ++j)
+            if (co0 + j < Cout) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(v, wr[j * 8 + k], acc[j][k]);
+            }
+    }
+    const int Ho = out.H, Wo = out.W;
+    const long long ovol = (long long)out.D * Ho * Wo;
+    float* dst = out.data + (long long)n * out.n_stride;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+        if (co0 + j < Cout) {
+#pragma unroll
+            for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    float* p = dst + (long long)(co0 + j) * ovol + ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
+                    *reinterpret_cast<float2*>(p) = make_float2(acc[j][dz * 4 + dy * 2], acc[j][dz * 4 + dy * 2 + 1]);
+                }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Conv3d k=1 of act(in): CO output channels [co0, co0+CO) per thread, VEC voxels per thread.
+template <int CO, int VEC>
+__global__ void __launch_bounds__(256)
+conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int co0) {
+    const int Cin = in.C;
+    const long long DHW = (long long)in.D * in.H * in.W;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int n = blockIdx.y;
+    if (idx >= DHW) return;
+    float acc[CO][VEC];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        const float bj = bias ? bias[co0 + j] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[j][v] = bj;
+    }
+    const float* src = in.data + (long long)n * in.n_stride + idx;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        float xv[VEC];
+        if (VEC == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(src + (long long)ci * DHW);
+            xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
+        } else {
+            xv[0] = src[(long long)ci * DHW];
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const float f = act(xv[v], a.x, a.y, a.z);
+#pragma unroll
+            for (int j = 0; j < CO; ++j) acc[j][v] = fmaf(f, w[(long long)(co0 + j) * Cin + ci], acc[j][v]);
+        }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        float* p = dst + (long long)(co0 + j) * DHW;
+        if (VEC == 4) {
+            *reinterpret_cast<float4*>(p) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+        } else {
+            p[0] = acc[j][0];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// InstanceNorm statistics, stand-alone pass: one {count, mean, M2} record per 4096-element chunk of each
+// (n, c) plane; M2 is taken about the chunk mean (two passes over registers), so no E[x^2]-E[x]^2 cancellation.
+constexpr int STAT_CHUNK = 4096;
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` from the previous use
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256) instnorm_stats_kernel(Tensor x, float* __restrict__ stats, int tiles) {
+    __shared__ float red[4];
+    const long long DHW = (long long)x.D * x.H * x.W;
+    const int tile = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+    const long long start = (long long)tile * STAT_CHUNK;
+    const float* src = x.data + (long long)n * x.n_stride + (long long)c * DHW;
+    float v[16];
+    float cnt = 0.0f, sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long i = start + j * 256 + threadIdx.x;
+        const bool ok = i < DHW;
+        v[j] = ok ? src[i] : 0.0f;
+        if (ok) { cnt += 1.0f; sum += v[j]; }
+    }
+    const float tot = block_sum_256(cnt, red);
+    const float mean = block_sum_256(sum, red) / tot;
+    float m2 = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const long long i = start + j * 256 + threadIdx.x;
+        const float d = v[j] - mean;
+        if (i < DHW) m2 += d * d;
+    }
+    m2 = block_sum_256(m2, red);
+    if (threadIdx.x == 0) {
+        float* rec = stats + (((long long)n * x.C + c) * tiles + tile) * 3;
+        rec[0] = tot; rec[1] = mean; rec[2] = m2;
+    }
+}
+
+// Merge `tiles` records per (n, c) in fp64 and emit the consumer-side {alpha, beta, slope, 0}.
+// fp32 steps mirror ATen's CPU batch-norm: invstd = 1/sqrt(var + eps), alpha = gamma*invstd,
+// beta = bias - mean*alpha (the reference normalises as x*alpha + beta).
+__global__ void __launch_bounds__(64)
+instnorm_finalize_kernel(const float* __restrict__ stats, int tiles, int C, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, float eps, float slope, float* __restrict__ nrm,
+                         long long nrm_n_stride) {
+    const int c = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const float* rec = stats + ((long long)n * C + c) * tiles * 3;
+    double cnt = 0.0, ws = 0.0;
+    for (int i = lane; i < tiles; i += 64) {
+        cnt += (double)rec[i * 3];
+        ws += (double)rec[i * 3] * (double)rec[i * 3 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        cnt += __shfl_xor(cnt, o);
+        ws += __shfl_xor(ws, o);
+    }
+    const double mean = ws / cnt;
+    double m2 = 0.0;
+    for (int i = lane; i < tiles; i += 64) {
+        const double d = (double)rec[i * 3 + 1] - mean;
+        m2 += (double)rec[i * 3 + 2] + (double)rec[i * 3] * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+    if (lane == 0) {
+        const float var = (float)(m2 / cnt);
+        const float invstd = __fdiv_rn(1.0f, __fsqrt_rn(var + eps));
+        const float g = gamma ? gamma[c] : 1.0f;
+        const float bb = beta ? beta[c] : 0.0f;
+        const float alpha = g * invstd;
+        float* o = nrm + (long long)n * nrm_n_stride + 4LL * c;
+        o[0] = alpha;
+        o[1] = bb - (float)mean * alpha;
+        o[2] = slope;
+        o[3] = 0.0f;
+    }
+}
+
+}  // namespace mh

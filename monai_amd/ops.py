@@ -1,0 +1,123 @@
+"""Thin typed wrappers over the C ABI (include/monai_amd.h): torch tensors in, kernel launches out.
+
+Each function checks devices/dtypes, builds the ``mh_tensor5`` view descriptors and enqueues on torch's
+current HIP stream.  No arithmetic happens in Python.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+
+Grid = Sequence[Sequence[int]]  # per-axis ascending window starts (z, y, x)
+
+
+def _s(t):
+    return _lib.stream_ptr(t)
+
+
+def window_extract(vol: torch.Tensor, grid: Grid, w0: int, nwin: int, roi: Sequence[int], out: torch.Tensor) -> torch.Tensor:
+    """vol [C,D,H,W] -> out [nwin,C,rd,rh,rw]: windows w0..w0+nwin-1 of the dense window grid
+    (reference: ``torch.cat([inputs[win_slice] ...])``, monai/inferers/utils.py:217-224)."""
+    _lib.require_device(vol, out)
+    if vol.dim() != 4 or not vol.is_contiguous() or not out.is_contiguous():
+        raise RuntimeError("monai_amd.window_extract: vol must be a contiguous [C,D,H,W] tensor")
+    c, d, h, w = vol.shape
+    sz, sy, sx = grid
+    _lib.lib().call(
+        "mh_window_extract_f32", _lib.ptr(vol), c, d, h, w, _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy),
+        _lib.int_array(sx), len(sx), int(w0), int(nwin), int(roi[0]), int(roi[1]), int(roi[2]), _lib.ptr(out), _s(vol),
+    )
+    return out
+
+
+def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int]) -> torch.Tensor:
+    """logits [nwin,K,rd,rh,rw] (all windows of the grid, in order), imp [rd,rh,rw] -> out [K,D,H,W] =
+    sum_w logits*imp / sum_w imp in the reference's summation order (monai/inferers/utils.py:264-298)."""
+    _lib.require_device(logits, imp, out)
+    if not (logits.is_contiguous() and imp.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("monai_amd.sw_blend: contiguous tensors required")
+    k, d, h, w = out.shape
+    sz, sy, sx = grid
+    if logits.shape[0] != len(sz) * len(sy) * len(sx) or logits.shape[1] != k or tuple(logits.shape[2:]) != tuple(roi):
+        raise RuntimeError(f"monai_amd.sw_blend: logits shape {tuple(logits.shape)} does not match the window grid")
+    _lib.lib().call(
+        "mh_sw_blend_f32", _lib.ptr(logits), _lib.ptr(imp), _lib.ptr(out), k, d, h, w, int(roi[0]), int(roi[1]), int(roi[2]),
+        _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), _s(out),
+    )
+    return out
+
+
+def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_conv3d_k3_select", cin, cout, d, h, w)
+
+
+def conv3d_k3_pack(cfg: int, weight: torch.Tensor) -> torch.Tensor:
+    """torch conv weight [Cout,Cin,3,3,3] -> the packed layout of configuration `cfg`."""
+    _lib.require_device(weight)
+    cout, cin = weight.shape[:2]
+    wc = weight.detach().contiguous()
+    packed = torch.empty(_lib.lib().query("mh_conv3d_k3_packed_floats", cfg, cin, cout), dtype=torch.float32, device=weight.device)
+    _lib.lib().call("mh_conv3d_k3_pack_f32", cfg, _lib.ptr(wc), cin, cout, _lib.ptr(packed), _s(weight))
+    return packed
+
+
+def conv3d_k3_stat_tiles(cfg: int, d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_conv3d_k3_stat_tiles", cfg, d, h, w)
+
+
+def conv3d_k3(cfg, x, x_nrm, packed_w, bias, out, stats: Optional[torch.Tensor] = None):
+    """out = conv3x3x3(act(x)) + bias; optionally emits the fused InstanceNorm statistics records."""
+    _lib.require_device(x, x_nrm, packed_w, bias, out, stats)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv3d_k3_f32", int(cfg), C.byref(xi), _lib.ptr(packed_w), _lib.ptr(bias), C.byref(xo), _lib.ptr(stats), _s(x))
+    return out
+
+
+def instnorm_stat_tiles(d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_instnorm_stat_tiles", d, h, w)
+
+
+def instnorm_stats(x: torch.Tensor, stats: torch.Tensor):
+    _lib.require_device(x, stats)
+    xi = _lib.tensor5(x)
+    _lib.lib().call("mh_instnorm_stats_f32", C.byref(xi), _lib.ptr(stats), _s(x))
+    return stats
+
+
+def instnorm_finalize(stats, tiles: int, n: int, c: int, gamma, beta, eps: float, slope: float, nrm: torch.Tensor):
+    """Merge `tiles` records per (n, c); write {alpha, beta, slope, 0} into nrm ([N, C, 4] slice)."""
+    _lib.require_device(stats, gamma, beta, nrm)
+    if nrm.dim() != 3 or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
+        raise RuntimeError("monai_amd.instnorm_finalize: nrm must be a [N,C,4] slice")
+    ns = nrm.stride(0) if n > 1 else max(nrm.stride(0), 4 * c)
+    _lib.lib().call(
+        "mh_instnorm_finalize_f32", _lib.ptr(stats), int(tiles), int(n), int(c), _lib.ptr(gamma), _lib.ptr(beta), float(eps),
+        float(slope), _lib.ptr(nrm), int(ns), _s(stats),
+    )
+    return nrm
+
+
+def maxpool2(x, x_nrm, out):
+    _lib.require_device(x, x_nrm, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_maxpool2_f32", C.byref(xi), C.byref(xo), _s(x))
+    return out
+
+
+def deconv_k2s2(x, x_nrm, weight, bias, out):
+    _lib.require_device(x, x_nrm, weight, bias, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_deconv_k2s2_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
+    return out
+
+
+def conv1x1(x, x_nrm, weight, bias, out):
+    _lib.require_device(x, x_nrm, weight, bias, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv1x1_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
+    return out

@@ -5,6 +5,8 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -18,3 +20,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture()
+def emu():
+    """Kernel library compiled for the x86 SIMT emulator (tests/emu); CPU tensors allowed inside."""
+    from emu_backend import emu_backend
+
+    with emu_backend() as lib:
+        yield lib

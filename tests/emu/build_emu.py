@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE: build the x86 SIMT-emulator flavour of the kernel library.
+
+Compiles the UNMODIFIED product translation unit ``monai_amd/csrc/capi.hip`` as host C++ with
+``tests/emu/stub`` first on the include path, so ``<hip/hip_runtime.h>`` resolves to the fiber-based
+emulator.  The result (``tests/emu/_build/libmonai_amd_emu.so``) exports the same C ABI but takes HOST
+pointers; CPU tests load it explicitly to check kernel logic against the oracle.  The product package
+never loads it.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT_DIR = os.path.join(HERE, "_build")
+OUT = os.path.join(OUT_DIR, "libmonai_amd_emu.so")
+SRC = os.path.join(ROOT, "monai_amd", "csrc", "capi.hip")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def sources():
+    deps = [SRC, os.path.join(HERE, "stub", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "monai_amd.h")]
+    kd = os.path.join(ROOT, "monai_amd", "csrc", "kernels")
+    deps += [os.path.join(kd, f) for f in sorted(os.listdir(kd)) if f.endswith(".h")]
+    return deps
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OUT_DIR, exist_ok=True)
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
+        return OUT
+    cxx = CLANG if os.path.exists(CLANG) else "clang++"
+    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-mfma", "-mavx2",
+           "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi", "-I", os.path.join(HERE, "stub"), SRC, "-o", OUT]
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,195 @@
+"""Kernel-level parity cases, shared by the CPU (SIMT-emulator) and the GPU (-m gpu) test modules.
+
+Every case builds seeded inputs on the CPU, runs the C-ABI entry point through monai_amd.ops on `device`
+("cpu" under the emulator fixture, "cuda" on the MI355X) and compares with a plain torch-CPU restatement
+of the reference operator (the same ATen ops the oracle in oracle/ uses).  Tolerances are stated per case:
+bit-exact for the blend / gather / pooling, 1e-5-class for fp32 convolutions whose summation order differs.
+"""
+
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from monai_amd import ops
+from oracle import sliding_window as osw
+
+
+def _act(x, nrm):
+    """consumer-side view of a stored tensor: fma(x, alpha, beta) then leaky(slope) -- float4 per (n,c)"""
+    if nrm is None:
+        return x
+    a = nrm[:, :, 0][:, :, None, None, None]
+    b = nrm[:, :, 1][:, :, None, None, None]
+    s = nrm[:, :, 2][:, :, None, None, None]
+    y = torch.addcmul(b, x, a)
+    return torch.where(y > 0, y, y * s)
+
+
+def _rand_nrm(n, c, gen):
+    nrm = torch.zeros(n, c, 4)
+    nrm[:, :, 0] = torch.rand(n, c, generator=gen) * 1.5 + 0.25
+    nrm[:, :, 0] *= torch.where(torch.rand(n, c, generator=gen) > 0.8, -1.0, 1.0)
+    nrm[:, :, 1] = torch.randn(n, c, generator=gen) * 0.3
+    nrm[:, :, 2] = 0.1
+    return nrm
+
+
+# ------------------------------------------------------------------------------------------ sliding window
+def case_window_extract(device, img=(2, 20, 24, 28), roi=(8, 12, 16), overlap=0.5):
+    gen = torch.Generator().manual_seed(1)
+    vol = torch.rand(img, generator=gen)
+    itv = osw.get_scan_interval(img[1:], roi, (overlap,) * 3)
+    starts, _ = osw.dense_patch_starts(img[1:], roi, itv)
+    wins = list(itertools.product(*starts))
+    w0, n = 3, len(wins) - 5
+    out = torch.empty((n, img[0]) + tuple(roi), device=device)
+    ops.window_extract(vol.to(device), starts, w0, n, roi, out)
+    exp = torch.stack([vol[:, z:z + roi[0], y:y + roi[1], x:x + roi[2]] for (z, y, x) in wins[w0:w0 + n]])
+    assert torch.equal(out.cpu(), exp)
+
+
+def reference_blend(logits, imp, img, roi, starts):
+    """The reference's scatter accumulation, monai/inferers/utils.py:264-298, on precomputed logits."""
+    k = logits.shape[1]
+    out = torch.zeros((1, k) + tuple(img))
+    cnt = torch.zeros((1, 1) + tuple(img))
+    wins = list(itertools.product(*starts))
+    for (z, y, x) in wins:
+        cnt[:, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] += imp[None, None]
+    for i, (z, y, x) in enumerate(wins):
+        seg = logits[i:i + 1].clone()
+        seg *= imp[None, None]
+        out[:, :, z:z + roi[0], y:y + roi[1], x:x + roi[2]] += seg
+    out /= cnt
+    return out[0]
+
+
+def case_sw_blend(device, img=(24, 20, 32), roi=(16, 12, 16), overlap=0.5, k=5, mode="gaussian"):
+    gen = torch.Generator().manual_seed(2)
+    itv = osw.get_scan_interval(img, roi, (overlap,) * 3)
+    starts, _ = osw.dense_patch_starts(img, roi, itv)
+    nwin = int(np.prod([len(s) for s in starts]))
+    logits = torch.randn((nwin, k) + tuple(roi), generator=gen)
+    imp = osw.compute_importance_map(roi, mode=mode, sigma_scale=0.125)
+    out = torch.empty((k,) + tuple(img), device=device)
+    ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
+    exp = reference_blend(logits, imp, img, roi, starts)
+    assert torch.equal(out.cpu(), exp), f"blend not bit-exact: max diff {(out.cpu() - exp).abs().max().item()}"
+
+
+# ------------------------------------------------------------------------------------------ network blocks
+def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True, tol=2e-5):
+    gen = torch.Generator().manual_seed(100 + cin + cout + dims[0])
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _rand_nrm(n, cin, gen) if with_nrm else None
+    exp = F.conv3d(_act(x.double(), None if nrm is None else nrm.double()), w.double(), b.double(), padding=1)
+
+    if cfg is None:
+        cfg = ops.conv3d_k3_select(cin, cout, *dims)
+    packed = ops.conv3d_k3_pack(cfg, w.to(device))
+    out = torch.full((n, cout) + tuple(dims), float("nan"), device=device)
+    tiles = ops.conv3d_k3_stat_tiles(cfg, *dims) if fused_stats else 0
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if tiles else None
+    ops.conv3d_k3(cfg, x.to(device), None if nrm is None else nrm.to(device), packed, b.to(device), out, stats)
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"conv cfg {cfg} {cin}->{cout} {dims}: max err {err}"
+
+    # statistics -> finalize -> {alpha, beta, slope}
+    gamma = torch.rand(cout, generator=gen) + 0.5
+    beta = torch.randn(cout, generator=gen) * 0.2
+    if stats is None:
+        tiles = ops.instnorm_stat_tiles(*dims)
+        stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+        ops.instnorm_stats(out, stats)
+    nrm_out = torch.full((n, cout, 4), float("nan"), device=device)
+    ops.instnorm_finalize(stats, tiles, n, cout, gamma.to(device), beta.to(device), 1e-5, 0.1, nrm_out)
+    mean = got.mean(dim=(2, 3, 4))
+    var = got.var(dim=(2, 3, 4), unbiased=False)
+    alpha = gamma.double()[None] / torch.sqrt(var + 1e-5)
+    r = nrm_out.cpu().double()
+    assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+    assert (r[:, :, 1] - (beta.double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    assert torch.all(r[:, :, 2] == torch.tensor(0.1, dtype=torch.float32).double()) and torch.all(r[:, :, 3] == 0)
+    return cfg
+
+
+def case_conv3d_into_channel_slice(device):
+    """The skip connection writes straight into the first channels of the concat buffer (batch stride of the
+    wider buffer), and reads use a nrm slice with the wider stride."""
+    gen = torch.Generator().manual_seed(7)
+    n, cin, cout, dims = 2, 8, 32, (8, 8, 16)
+    x = torch.randn((n, cin) + dims, generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    cfg = ops.conv3d_k3_select(cin, cout, *dims)
+    assert cfg >= 1
+    packed = ops.conv3d_k3_pack(cfg, w.to(device))
+    buf = torch.full((n, 2 * cout) + dims, 7.0, device=device)
+    ops.conv3d_k3(cfg, x.to(device), None, packed, None, buf[:, cout:], None)
+    exp = F.conv3d(x.double(), w.double(), None, padding=1)
+    got = buf.cpu().double()
+    assert (got[:, cout:] - exp).abs().max().item() < 2e-5
+    assert torch.all(got[:, :cout] == 7.0)
+
+
+def case_maxpool(device, n=2, c=5, dims=(8, 12, 20)):
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((n, c) + dims, generator=gen)
+    nrm = _rand_nrm(n, c, gen)
+    out = torch.empty((n, c) + tuple(d // 2 for d in dims), device=device)
+    ops.maxpool2(x.to(device), nrm.to(device), out)
+    a, b, s = (nrm[:, :, i][:, :, None, None, None] for i in range(3))
+    y = torch.addcmul(b, x, a)  # fp32; the kernel's fmaf differs from mul+add by <= 1 ulp
+    exp = F.max_pool3d(torch.where(y > 0, y, y * s), 2)
+    assert (out.cpu() - exp).abs().max().item() < 1e-6
+    out2 = torch.empty_like(out)
+    ops.maxpool2(x.to(device), None, out2)
+    assert torch.equal(out2.cpu(), F.max_pool3d(x, 2))
+
+
+def case_deconv(device, n=2, cin=16, cout=6, dims=(4, 6, 10)):
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn((n, cin) + dims, generator=gen)
+    w = torch.randn((cin, cout, 2, 2, 2), generator=gen) / np.sqrt(cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _rand_nrm(n, cin, gen)
+    buf = torch.zeros((n, 3 + cout) + tuple(2 * d for d in dims), device=device)
+    ops.deconv_k2s2(x.to(device), nrm.to(device), w.to(device), b.to(device), buf[:, 3:])
+    exp = F.conv_transpose3d(_act(x.double(), nrm.double()), w.double(), b.double(), stride=2)
+    got = buf.cpu().double()
+    assert (got[:, 3:] - exp).abs().max().item() < 1e-5
+    assert torch.all(got[:, :3] == 0)
+
+
+def case_conv1x1(device, n=2, cin=32, cout=5, dims=(6, 8, 12)):
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn((n, cin) + dims, generator=gen)
+    w = torch.randn((cout, cin), generator=gen) / np.sqrt(cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _rand_nrm(n, cin, gen)
+    out = torch.empty((n, cout) + dims, device=device)
+    ops.conv1x1(x.to(device), nrm.to(device), w.to(device), b.to(device), out)
+    exp = F.conv3d(_act(x.double(), nrm.double()), w.double()[:, :, None, None, None], b.double())
+    assert (out.cpu().double() - exp).abs().max().item() < 1e-5
+
+
+def case_instnorm_stats(device, n=2, c=3, dims=(10, 17, 31)):
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn((n, c) + dims, generator=gen) * 3 + 50.0  # large mean: E[x^2]-E[x]^2 would lose digits
+    tiles = ops.instnorm_stat_tiles(*dims)
+    stats = torch.empty((n, c, tiles, 3), device=device)
+    ops.instnorm_stats(x.to(device), stats)
+    nrm = torch.empty((n, c, 4), device=device)
+    ops.instnorm_finalize(stats, tiles, n, c, None, None, 1e-5, 0.25, nrm)
+    xd = x.double()
+    alpha = 1.0 / torch.sqrt(xd.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    r = nrm.cpu().double()
+    assert (r[:, :, 0] - alpha).abs().max().item() < 1e-6
+    assert (r[:, :, 1] + xd.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 2e-5
+    assert torch.all(r[:, :, 2] == 0.25)

@@ -1,0 +1,73 @@
+"""CPU checks of the kernel LOGIC: the unmodified HIP sources compiled against the SIMT emulator
+(tests/emu) and compared with torch-CPU restatements of the reference operators.  These do not replace the
+-m gpu parity tests (tests/test_kernels_gpu.py runs the same cases on the MI355X); they exist because the
+build container has no GPU and every index/LDS/barrier bug caught here saves a GPU round trip."""
+import pytest
+
+import kernel_cases as kc
+
+
+def test_window_extract(emu):
+    kc.case_window_extract("cpu")
+    kc.case_window_extract("cpu", img=(1, 13, 10, 11), roi=(5, 4, 3), overlap=0.25)  # unaligned -> scalar path
+
+
+@pytest.mark.parametrize("mode", ["gaussian", "constant"])
+def test_sw_blend_bitwise(emu, mode):
+    kc.case_sw_blend("cpu", mode=mode)
+    kc.case_sw_blend("cpu", img=(11, 13, 10), roi=(4, 5, 3), overlap=0.25, k=3, mode=mode)   # scalar path, ragged
+    kc.case_sw_blend("cpu", img=(1, 20, 24), roi=(1, 8, 8), overlap=0.75, k=11, mode=mode)   # 2-D, K > 8, 4x overlap
+
+
+def test_conv_direct(emu):
+    assert kc.case_conv3d("cpu", 0, 2, 1, 32, (6, 7, 9), with_nrm=False, fused_stats=False) == 0
+    kc.case_conv3d("cpu", 0, 1, 5, 7, (4, 5, 6), fused_stats=False)
+
+
+@pytest.mark.parametrize(
+    "cfg,cin,cout,dims",
+    [
+        (1, 8, 32, (4, 8, 32)),     # exact tiles of the 96^3-level configuration
+        (1, 16, 32, (5, 6, 40)),    # ragged in every axis -> masked stores / masked statistics
+        (2, 8, 32, (4, 8, 16)),
+        (2, 8, 32, (6, 10, 24)),
+        (3, 8, 64, (2, 8, 8)),
+        (3, 16, 64, (3, 12, 12)),
+        (4, 4, 128, (2, 4, 4)),
+        (4, 8, 128, (3, 6, 6)),
+        (5, 2, 256, (2, 4, 4)),
+        (5, 4, 256, (3, 3, 3)),
+        (6, 8, 32, (4, 8, 8)),
+        (6, 8, 32, (5, 9, 7)),
+    ],
+)
+def test_conv_mfma_configs(emu, cfg, cin, cout, dims):
+    kc.case_conv3d("cpu", cfg, 2, cin, cout, dims, fused_stats=True)
+
+
+def test_conv_mfma_separate_stats_and_select(emu):
+    cfg = kc.case_conv3d("cpu", None, 1, 8, 32, (4, 8, 32), fused_stats=False)
+    assert cfg == 1
+    from monai_amd import ops
+
+    assert ops.conv3d_k3_select(32, 32, 96, 96, 96) == 1
+    assert ops.conv3d_k3_select(64, 32, 96, 96, 96) == 1
+    assert ops.conv3d_k3_select(32, 32, 48, 48, 48) == 2
+    assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 3
+    assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 4
+    assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 5
+    assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 0
+    assert ops.conv3d_k3_select(32, 5, 96, 96, 96) == 0
+
+
+def test_conv_into_channel_slice(emu):
+    kc.case_conv3d_into_channel_slice("cpu")
+
+
+def test_pool_deconv_1x1_stats(emu):
+    kc.case_maxpool("cpu")
+    kc.case_maxpool("cpu", dims=(4, 6, 7))  # odd W -> scalar path, floor
+    kc.case_deconv("cpu")
+    kc.case_conv1x1("cpu")
+    kc.case_conv1x1("cpu", cin=7, cout=11, dims=(3, 5, 7))
+    kc.case_instnorm_stats("cpu")
