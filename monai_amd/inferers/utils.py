@@ -1,0 +1,317 @@
+"""``sliding_window_inference`` on the MI355X kernels -- drop-in for monai/inferers/utils.py:42-321.
+
+Same signature and results as the reference (bit-identical blend for the same window logits), different
+schedule.  The reference runs a Python loop that, per window batch, multiplies the predictor output by the
+importance map and read-modify-writes it into the output volume and a count map (5x the algorithmic HBM
+traffic).  Here:
+
+  1. windows are gathered by ``mh_window_extract_f32`` straight from the volume into a batch buffer;
+  2. the predictor writes its logits into ONE buffer holding every window of the image
+     (``[num_win, K, roi]`` -- 17.7 GB for 512^3 / 96^3 / overlap 0.5 / 5 classes; HBM is 288 GB);
+  3. ``mh_sw_blend_f32`` produces every output voxel in a single gather pass that walks the covering windows
+     in ascending window index: ``acc += logit*w; cnt += w; out = acc/cnt`` -- exactly the floating-point
+     operations, in exactly the order, of the reference's ``*=``, ``+=``, ``/=``; the count map is never stored.
+
+With window sharding enabled (monai_amd.parallel) each rank runs the predictor on a contiguous range of
+windows and one RCCL all-gather of the logits precedes the (replicated, deterministic) blend.
+"""
+
+from __future__ import annotations
+
+import os
+from collections.abc import Callable, Mapping, Sequence
+from typing import Any
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib, ops, parallel
+from ..data.utils import compute_importance_map, get_valid_patch_size, window_starts
+from ..utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple, look_up_option
+
+__all__ = ["sliding_window_inference"]
+
+_PAD_MODES = ("constant", "reflect", "replicate", "circular")
+_NEAREST = "nearest-exact"
+
+
+def _get_scan_interval(image_size, roi_size, num_spatial_dims: int, overlap) -> tuple:
+    """monai/inferers/utils.py:363-384: ``int(roi * (1 - overlap))``, at least 1; the roi itself when it spans the image."""
+    if len(image_size) != num_spatial_dims:
+        raise ValueError(f"len(image_size) {len(image_size)} different from spatial dims {num_spatial_dims}.")
+    if len(roi_size) != num_spatial_dims:
+        raise ValueError(f"len(roi_size) {len(roi_size)} different from spatial dims {num_spatial_dims}.")
+    steps = []
+    for size, roi, o in zip(image_size, roi_size, overlap):
+        if roi == size:
+            steps.append(int(roi))
+        else:
+            step = int(roi * (1 - o))
+            steps.append(step if step > 0 else 1)
+    return tuple(steps)
+
+
+def _flatten_struct(seg_out):
+    """tensor | tuple | dict -> (sorted keys or None, tuple of tensors)  (utils.py:387-398)"""
+    if isinstance(seg_out, torch.Tensor):
+        return None, (seg_out,)
+    if isinstance(seg_out, Mapping):
+        keys = sorted(seg_out.keys())
+        return keys, tuple(seg_out[k] for k in keys)
+    return None, ensure_tuple(seg_out)
+
+
+def _pack_struct(seg_out, dict_keys=None):
+    if dict_keys is not None:
+        return dict(zip(dict_keys, seg_out))
+    if isinstance(seg_out, (list, tuple)) and len(seg_out) == 1:
+        return seg_out[0]
+    return ensure_tuple(seg_out)
+
+
+def _to3(values, fill):
+    """left-pad a 1/2/3-element spatial tuple to 3 entries"""
+    values = tuple(values)
+    return (fill,) * (3 - len(values)) + values
+
+
+def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device) -> int:
+    """Windows per predictor call.  A generic predictor gets exactly the user's ``sw_batch_size``.  The fused
+    BasicUNet engine sizes the batch for 288 GB of HBM instead (results do not depend on the batch: InstanceNorm is
+    per sample): deep U-Net levels are tiny, so more windows per launch fill the 256 CUs.  Override with
+    MONAI_AMD_SW_BATCH; MONAI_AMD_STRICT_SW_BATCH=1 keeps the user's value."""
+    if not hasattr(predictor, "forward_into") or os.environ.get("MONAI_AMD_STRICT_SW_BATCH") == "1":
+        return max(1, int(sw_batch_size))
+    env = os.environ.get("MONAI_AMD_SW_BATCH")
+    if env:
+        return max(1, min(int(env), num_win))
+    cap = 25
+    if device.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(device)
+        per_win = 6.0 * 4 * max(getattr(predictor, "features", (32,))[0], 1) * roi3[0] * roi3[1] * roi3[2]
+        cap = int(max(1, min(cap, (0.35 * free) // max(per_win, 1))))
+    cap = max(cap, int(sw_batch_size)) if cap >= sw_batch_size else cap
+    cap = min(cap, num_win)
+    for b in range(cap, max(cap // 2, 1) - 1, -1):  # prefer a divisor of the window count: one buffer plan
+        if num_win % b == 0:
+            return b
+    return cap
+
+
+def sliding_window_inference(
+    inputs: torch.Tensor,
+    roi_size: Sequence[int] | int,
+    sw_batch_size: int,
+    predictor: Callable[..., Any],
+    overlap: Sequence[float] | float = 0.25,
+    mode: str = "constant",
+    sigma_scale: Sequence[float] | float = 0.125,
+    padding_mode: str = "constant",
+    cval: float = 0.0,
+    sw_device=None,
+    device=None,
+    progress: bool = False,
+    roi_weight_map: torch.Tensor | None = None,
+    process_fn: Callable | None = None,
+    buffer_steps: int | None = None,
+    buffer_dim: int = -1,
+    with_coord: bool = False,
+    *args: Any,
+    **kwargs: Any,
+):
+    """See the reference docstring (monai/inferers/utils.py:63-141) for the argument semantics; they are kept.
+
+    Differences, all result-neutral: ``buffer_steps`` / ``buffer_dim`` are validated and otherwise ignored (they are
+    a memory-saving schedule of the reference, not a different result -- the blend here never materialises partial
+    volumes); ``sw_device`` must be the ROCm device the inputs live on; ``process_fn`` is not supported yet.
+    """
+    num_spatial_dims = inputs.dim() - 2
+    buffered = buffer_steps is not None and buffer_steps > 0
+    if buffered:
+        if buffer_dim < -num_spatial_dims or buffer_dim > num_spatial_dims:
+            raise ValueError(f"buffer_dim must be in [{-num_spatial_dims}, {num_spatial_dims}], got {buffer_dim}.")
+    overlap = ensure_tuple_rep(overlap, num_spatial_dims)
+    for o in overlap:
+        if o < 0 or o >= 1:
+            raise ValueError(f"overlap must be >= 0 and < 1, got {overlap}.")
+    if num_spatial_dims < 1 or num_spatial_dims > 3:
+        raise NotImplementedError(f"monai_amd: sliding windows over {num_spatial_dims} spatial dims are not supported (1-3 are)")
+    if process_fn is not None:
+        raise NotImplementedError("monai_amd: process_fn is not supported on the HIP path yet")
+
+    meta_src = inputs if (type(inputs) is not torch.Tensor and hasattr(inputs, "as_tensor")) else None
+    if meta_src is not None:
+        inputs = inputs.as_tensor()
+    _lib.require_device(inputs)
+    compute_dtype = inputs.dtype
+    batch_size, in_ch, *image_size_ = inputs.shape
+    out_device = torch.device(device) if device is not None else inputs.device
+    if sw_device is not None and torch.device(sw_device).type != inputs.device.type:
+        raise RuntimeError("monai_amd: sw_device must be the ROCm device of the inputs (windows are gathered in HBM)")
+    roi_size = fall_back_tuple(roi_size, image_size_)
+
+    # pad when the image is smaller than the roi (utils.py:163-170), centred, last dim first
+    image_size = tuple(max(image_size_[i], roi_size[i]) for i in range(num_spatial_dims))
+    pad_size = []
+    for k in range(inputs.dim() - 1, 1, -1):
+        diff = max(roi_size[k - 2] - inputs.shape[k], 0)
+        half = diff // 2
+        pad_size.extend([half, diff - half])
+    if any(pad_size):
+        inputs = F.pad(inputs, pad=pad_size, mode=look_up_option(padding_mode, _PAD_MODES, "padding_mode"), value=cval)
+    inputs = inputs.contiguous()
+
+    scan_interval = _get_scan_interval(image_size, roi_size, num_spatial_dims, overlap)
+    starts = window_starts(image_size, roi_size, scan_interval)
+    num_win = 1
+    for s in starts:
+        num_win *= len(s)
+
+    # importance map, always evaluated on the host in fp32 (bit-identical to the reference's CPU map)
+    valid_patch_size = get_valid_patch_size(image_size, roi_size)
+    if valid_patch_size == tuple(roi_size) and roi_weight_map is not None:
+        imp = roi_weight_map
+    else:
+        try:
+            imp = compute_importance_map(valid_patch_size, mode=mode, sigma_scale=sigma_scale, device="cpu", dtype=compute_dtype)
+        except Exception as e:  # same wrapping as the reference (utils.py:205-209)
+            raise RuntimeError(
+                f"patch size {valid_patch_size}, mode={mode}, sigma_scale={sigma_scale}, device={device}\n"
+                "Seems to be OOM. Please try smaller patch size or mode='constant' instead of mode='gaussian'."
+            ) from e
+    imp = imp.to(dtype=compute_dtype)
+    while imp.dim() > num_spatial_dims:
+        imp = imp[0]
+
+    roi3 = _to3(roi_size, 1)
+    img3 = _to3(image_size, 1)
+    grid3 = [[0]] * (3 - num_spatial_dims) + [list(s) for s in starts]
+    dev = inputs.device
+
+    # window range owned by this rank (all of them unless window sharding is on)
+    shard = parallel.window_shard(num_win)
+    my_lo, my_hi = shard.lo, shard.hi
+    nb = _auto_batch(predictor, roi3, max(my_hi - my_lo, 1), sw_batch_size, dev)
+    fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs
+    win_buf = torch.empty((nb, in_ch) + roi3, dtype=compute_dtype, device=dev)
+
+    windows_nd = None
+    if with_coord:
+        import itertools
+
+        windows_nd = [tuple(slice(s, s + roi_size[d]) for d, s in enumerate(w)) for w in itertools.product(*starts)]
+
+    logits = None      # per output: [num_win_padded, K, *seg3]
+    seg_shapes = None  # per output: spatial shape of one window's prediction (native dims)
+    dict_keys = None
+    outputs = None     # per output: [B, K, *out_img3]
+    weights = None     # per output: importance map resampled to the prediction size (device)
+    zscales = None
+
+    fused = fused and hasattr(predictor, "out_channels")
+    for b in range(batch_size):
+        vol3 = inputs[b].reshape((in_ch,) + img3)
+        steps = range(my_lo, my_hi, nb)
+        if progress:
+            try:
+                from tqdm import tqdm
+
+                steps = tqdm(steps)
+            except ImportError:
+                pass
+        for w0 in steps:
+            n = min(nb, my_hi - w0)
+            ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
+            win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
+            if fused:
+                if logits is None:
+                    k = int(predictor.out_channels)
+                    seg_shapes, zscales = [tuple(roi_size)], [None]
+                    logits = [_alloc_logits(shard, k, roi3, compute_dtype, dev)]
+                predictor.forward_into(win_buf[:n], logits[0][w0 - shard.base : w0 - shard.base + n])
+                continue
+            if with_coord:
+                coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
+                seg_out = predictor(win_data, coords, *args, **kwargs)
+            else:
+                seg_out = predictor(win_data, *args, **kwargs)
+            dict_keys, segs = _flatten_struct(seg_out)
+            if logits is None:
+                seg_shapes = [tuple(s.shape[2:]) for s in segs]
+                zscales = [
+                    None if sh == tuple(roi_size) else [o / float(i) for o, i in zip(sh, roi_size)] for sh in seg_shapes
+                ]
+                logits = [_alloc_logits(shard, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
+            for ss, s in enumerate(segs):
+                _lib.require_device(s)
+                dst = logits[ss][w0 - shard.base : w0 - shard.base + n]
+                dst.copy_(s.reshape(dst.shape))
+
+        if logits is None:
+            raise RuntimeError("monai_amd: no windows were processed")
+        gathered = [shard.all_gather(lg) for lg in logits]
+
+        if weights is None:  # importance map per output resolution (the reference resamples cumulatively, utils.py:260-263)
+            weights, w_t = [], imp[None, None]
+            for sh, z in zip(seg_shapes, zscales):
+                if z is not None:
+                    w_t = F.interpolate(w_t, sh, mode=_NEAREST)
+                weights.append(w_t[0, 0].reshape(_to3(sh, 1)).contiguous().to(dev))
+            outputs = []
+            for lg, z in zip(gathered, zscales):
+                osz = [int(i * zz) for i, zz in zip(image_size, z)] if z else list(image_size)
+                outputs.append(torch.empty((batch_size, lg.shape[1]) + _to3(osz, 1), dtype=compute_dtype, device=dev))
+        for ss, (lg, z) in enumerate(zip(gathered, zscales)):
+            if z is None:
+                g = grid3
+            else:
+                g = [[0]] * (3 - num_spatial_dims) + [[int(s * zz) for s in ax] for ax, zz in zip(starts, z)]
+            ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
+
+    # back to the caller's rank / crop the padding (utils.py:300-313) / output device
+    finals = []
+    for ss, o in enumerate(outputs):
+        z = zscales[ss]
+        osz = [int(i * zz) for i, zz in zip(image_size, z)] if z else list(image_size)
+        o = o.reshape((batch_size, o.shape[1]) + tuple(osz))
+        if any(pad_size):
+            zoom = [sd / float(rd) for sd, rd in zip(o.shape[2:], roi_size)]
+            cut = []
+            for sp in range(num_spatial_dims):
+                si = num_spatial_dims - sp - 1
+                cut.insert(0, slice(int(round(pad_size[sp * 2] * zoom[si])), int(round((pad_size[sp * 2] + image_size_[si]) * zoom[si]))))
+            o = o[(slice(None), slice(None), *cut)]
+        if o.device != out_device:
+            o = o.to(out_device)
+        if meta_src is not None:
+            o = _restore_meta(o, meta_src)
+        finals.append(o)
+    if any(pad_size):
+        kwargs.update({"pad_size": pad_size})
+    return _pack_struct(finals, dict_keys)
+
+
+def _alloc_logits(shard, k: int, seg3, dtype, dev) -> torch.Tensor:
+    """Logits of the windows this rank computes.  Without sharding that is every window (and the buffer is the
+    blend input itself); with sharding it is the rank's equal-sized chunk, all-gathered before the blend."""
+    need = shard.chunk * k * seg3[0] * seg3[1] * seg3[2] * 4 * (shard.world + 1 if shard.world > 1 else 1)
+    if dev.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(dev)
+        if need > 0.9 * free:
+            raise RuntimeError(
+                f"monai_amd: the all-window logits buffer needs {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB of HBM "
+                "are free; use a smaller volume or more classes per pass (slab-wise blending is not implemented yet)"
+            )
+    return torch.empty((shard.chunk, k) + tuple(seg3), dtype=dtype, device=dev)
+
+
+def _restore_meta(out: torch.Tensor, src):
+    """Give the result the input's MetaTensor type and metadata (the reference's ``convert_to_dst_type(final_output,
+    temp_meta)``, utils.py:316-319) when the input was a MetaTensor-like tensor subclass."""
+    try:
+        res = type(src)(out)
+        if hasattr(res, "copy_meta_from"):
+            res.copy_meta_from(src, copy_attr=False)
+        return res
+    except Exception:
+        return out

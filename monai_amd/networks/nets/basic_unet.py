@@ -1,0 +1,276 @@
+"""BasicUNet on the MI355X kernels -- drop-in for ``monai.networks.nets.BasicUNet``.
+
+Reference: monai/networks/nets/basic_unet.py:27-279 (TwoConv / Down / UpCat / BasicUNet), whose blocks are
+``Convolution`` = Conv3d(k3, p1) -> InstanceNorm3d(affine) -> Dropout(0) -> LeakyReLU(0.1)
+(blocks/convolutions.py:98-171, blocks/acti_norm.py:69-101) and ``UpSample("deconv")`` = ConvTranspose3d(k2, s2)
+(blocks/upsample.py:102-116).
+
+Same constructor signature, same module tree and ``state_dict`` keys/shapes (``conv_0.conv_0.conv.weight``,
+``conv_0.conv_0.adn.N.weight``, ``upcat_4.upsample.deconv.weight``, ``final_conv.weight`` ...), same parameter
+initialisation order -- so reference checkpoints load unchanged and the same seed gives the same weights.
+The forward pass is an inference engine over the C ABI (include/monai_amd.h):
+
+  * every conv output is stored RAW once; its InstanceNorm+LeakyReLU is folded into a per-(n, c)
+    {alpha, beta, slope} record and applied by the consumer while it loads (no normalisation pass);
+  * InstanceNorm statistics come out of the producing conv's epilogue (fp32-MFMA tiles) or one reduction
+    pass (direct kernel), merged in fp64;
+  * skip connections are written straight into the first channels of the decoder's concat buffer and the
+    transposed conv writes the remaining channels: ``torch.cat`` never runs;
+  * all buffers are planned once per (batch, window shape) and reused; weights are repacked once per
+    kernel configuration.
+
+There is no CPU path: tensors must live on a ROCm device (RuntimeError otherwise).
+"""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+
+__all__ = ["BasicUNet", "BasicUnet", "Basicunet", "basicunet"]
+
+
+# --------------------------------------------------------------------------- parameter containers
+class _ADN(nn.Module):
+    def __init__(self, channels: int, affine: bool, eps: float, slope: float):
+        super().__init__()
+        self.N = nn.InstanceNorm3d(channels, eps=eps, affine=affine)
+        self.negative_slope = slope
+
+
+class _Convolution(nn.Module):
+    """conv + adn parameter holder (reference: blocks/convolutions.py:98-171)"""
+
+    def __init__(self, cin: int, cout: int, bias: bool, affine: bool, eps: float, slope: float):
+        super().__init__()
+        self.conv = nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.adn = _ADN(cout, affine, eps, slope)
+
+
+class _TwoConv(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv_0 = _Convolution(cin, cout, **kw)
+        self.conv_1 = _Convolution(cout, cout, **kw)
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.max_pooling = nn.MaxPool3d(kernel_size=2)
+        self.convs = _TwoConv(cin, cout, **kw)
+
+
+class _UpSample(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.deconv = nn.ConvTranspose3d(cin, cout, kernel_size=2, stride=2, bias=bias)
+
+
+class _UpCat(nn.Module):
+    def __init__(self, cin, cat, cout, halves=True, **kw):
+        super().__init__()
+        up = cin // 2 if halves else cin
+        self.upsample = _UpSample(cin, up)
+        self.convs = _TwoConv(cat + up, cout, **kw)
+
+
+def _parse_act(act) -> float:
+    name, args = (act, {}) if isinstance(act, str) else (act[0], act[1] if len(act) > 1 else {})
+    name = str(name).lower()
+    if name == "leakyrelu":
+        return float(args.get("negative_slope", 0.01))
+    if name == "relu":
+        return 0.0
+    raise NotImplementedError(f"monai_amd.BasicUNet: activation {act!r} is not on the HIP path yet (LeakyReLU / ReLU are)")
+
+
+def _parse_norm(norm):
+    name, args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
+    if str(name).lower() != "instance":
+        raise NotImplementedError(f"monai_amd.BasicUNet: norm {norm!r} is not on the HIP path yet (instance norm is)")
+    return bool(args.get("affine", False)), float(args.get("eps", 1e-5))
+
+
+# --------------------------------------------------------------------------- the module
+class BasicUNet(nn.Module):
+    def __init__(
+        self,
+        spatial_dims: int = 3,
+        in_channels: int = 1,
+        out_channels: int = 2,
+        features: Sequence[int] = (32, 32, 64, 128, 256, 32),
+        act: str | tuple = ("LeakyReLU", {"negative_slope": 0.1, "inplace": True}),
+        norm: str | tuple = ("instance", {"affine": True}),
+        bias: bool = True,
+        dropout: float | tuple = 0.0,
+        upsample: str = "deconv",
+    ):
+        super().__init__()
+        if spatial_dims != 3:
+            raise NotImplementedError("monai_amd.BasicUNet: only spatial_dims=3 is on the HIP path")
+        if upsample != "deconv":
+            raise NotImplementedError("monai_amd.BasicUNet: only upsample='deconv' is on the HIP path")
+        if isinstance(dropout, (tuple, list)) or float(dropout) != 0.0:
+            raise NotImplementedError("monai_amd.BasicUNet: dropout must be 0 (inference path)")
+        fea = tuple(features)
+        if len(fea) != 6:
+            raise ValueError(f"Sequence must have length 6, got length {len(fea)}.")  # ensure_tuple_rep
+        print(f"BasicUNet features: {fea}.")  # the reference prints this too (basic_unet.py:239)
+        slope = _parse_act(act)
+        affine, eps = _parse_norm(norm)
+        kw = dict(bias=bias, affine=affine, eps=eps, slope=slope)
+        self.features, self.in_channels, self.out_channels = fea, in_channels, out_channels
+        self.negative_slope, self.eps = slope, eps
+
+        self.conv_0 = _TwoConv(in_channels, fea[0], **kw)
+        self.down_1 = _Down(fea[0], fea[1], **kw)
+        self.down_2 = _Down(fea[1], fea[2], **kw)
+        self.down_3 = _Down(fea[2], fea[3], **kw)
+        self.down_4 = _Down(fea[3], fea[4], **kw)
+        self.upcat_4 = _UpCat(fea[4], fea[3], fea[3], **kw)
+        self.upcat_3 = _UpCat(fea[3], fea[2], fea[2], **kw)
+        self.upcat_2 = _UpCat(fea[2], fea[1], fea[1], **kw)
+        self.upcat_1 = _UpCat(fea[1], fea[0], fea[5], halves=False, **kw)
+        self.final_conv = nn.Conv3d(fea[5], out_channels, kernel_size=1)
+
+        self._plans: dict = {}      # (N, D, H, W, device) -> _Plan
+        self._packed: dict = {}     # (layer name, cfg) -> (version key, packed weights)
+        self.fused_stats = True     # take InstanceNorm statistics from the conv epilogue when the tile kernel runs
+
+    # ---- weights ---------------------------------------------------------------------------------
+    def _packed_weight(self, name: str, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((name, cfg))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, w))
+            self._packed[(name, cfg)] = hit
+        return hit[1]
+
+    # ---- forward ---------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """``(B, in_channels, D, H, W)`` -> raw predictions ``(B, out_channels, D, H, W)`` (basic_unet.py:254-279)."""
+        _lib.require_device(x)
+        if x.dim() != 5 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"monai_amd.BasicUNet: expected input (B,{self.in_channels},D,H,W), got {tuple(x.shape)}")
+        out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        return self.forward_into(x, out)
+
+    @torch.no_grad()
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
+        _lib.require_device(x, out)
+        if self.training:
+            raise RuntimeError("monai_amd.BasicUNet is an inference engine: call .eval() first")
+        x = x.contiguous()
+        n, _, d, h, w = x.shape
+        if d % 16 or h % 16 or w % 16:
+            raise NotImplementedError(
+                f"monai_amd.BasicUNet: window {d}x{h}x{w} must be divisible by 16 (the replicate-padded odd-edge "
+                "case of UpCat, basic_unet.py:163-170, is not on the HIP path yet)"
+            )
+        key = (n, d, h, w, str(x.device))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 4:
+                self._plans.clear()
+            plan = self._plans[key] = _Plan(self, n, (d, h, w), x.device)
+        plan.run(self, x, out)
+        return out
+
+
+BasicUnet = Basicunet = basicunet = BasicUNet
+
+
+# --------------------------------------------------------------------------- buffers + schedule
+class _Plan:
+    """All activation / statistics buffers for one (batch, window shape), allocated once.
+
+    Level l has spatial size dims / 2^l.  ``cat[l]`` is the decoder's concat buffer [N, f_l + up_l, ...]: the
+    encoder's skip output lives in channels [0, f_l), the transposed conv writes [f_l, f_l + up_l)."""
+
+    def __init__(self, net: "BasicUNet", n: int, dims, device):
+        f = net.features
+        self.n, self.dims = n, tuple(dims)
+        self.sp = [tuple(v >> l for v in dims) for l in range(5)]
+        up = [f[1], f[2] // 2, f[3] // 2, f[4] // 2]            # channels the deconv adds at level 0..3
+        dec_out = [f[5], f[1], f[2], f[3]]                      # output channels of the decoder TwoConv at level 0..3
+        e = lambda c, l: torch.empty((n, c) + self.sp[l], dtype=torch.float32, device=device)  # noqa: E731
+        nz = lambda c: torch.zeros((n, c, 4), dtype=torch.float32, device=device)              # noqa: E731
+        self.cat = [e(f[l] + up[l], l) for l in range(4)]
+        self.cat_nrm = [nz(f[l] + up[l]) for l in range(4)]
+        for l in range(4):  # channels written by the transposed conv carry no norm / activation
+            self.cat_nrm[l][:, f[l]:, 0] = 1.0
+            self.cat_nrm[l][:, f[l]:, 2] = 1.0
+        self.tmp = [e(max(f[l], dec_out[l]) if l < 4 else f[4], l) for l in range(5)]
+        self.tmp_nrm = [nz(max(f[l], dec_out[l]) if l < 4 else f[4]) for l in range(5)]
+        self.pool = [None] + [e(f[l - 1], l) for l in range(1, 5)]
+        self.x4, self.x4_nrm = e(f[4], 4), nz(f[4])
+        self.u = [e(dec_out[l], l) for l in range(4)]
+        self.u_nrm = [nz(dec_out[l]) for l in range(4)]
+        self.up, self.dec_out = up, dec_out
+        self.stats: Optional[torch.Tensor] = None
+        self.device = device
+
+    def _stats_buf(self, floats: int) -> torch.Tensor:
+        if self.stats is None or self.stats.numel() < floats:
+            self.stats = torch.empty(floats, dtype=torch.float32, device=self.device)
+        return self.stats
+
+    def _conv(self, net, name: str, block: _Convolution, x, x_nrm, out, out_nrm):
+        """conv -> raw `out`; InstanceNorm statistics -> `out_nrm` ({alpha, beta, slope})."""
+        n, cout, d, h, w = out.shape
+        cin = x.shape[1]
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+        packed = net._packed_weight(name, block.conv, cfg)
+        tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if net.fused_stats else 0
+        if tiles:
+            stats = self._stats_buf(n * cout * tiles * 3)
+            ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, stats)
+        else:
+            ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, None)
+            tiles = ops.instnorm_stat_tiles(d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3)
+            ops.instnorm_stats(out, stats)
+        inorm = block.adn.N
+        ops.instnorm_finalize(stats, tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, block.adn.negative_slope, out_nrm)
+
+    def run(self, net: "BasicUNet", x: torch.Tensor, logits: torch.Tensor) -> None:
+        f = net.features
+        downs = [None, net.down_1, net.down_2, net.down_3, net.down_4]
+        ups = [net.upcat_1, net.upcat_2, net.upcat_3, net.upcat_4]
+
+        # encoder
+        t, tn = self.tmp[0][:, : f[0]], self.tmp_nrm[0][:, : f[0]]
+        self._conv(net, "conv_0.conv_0", net.conv_0.conv_0, x, None, t, tn)
+        self._conv(net, "conv_0.conv_1", net.conv_0.conv_1, t, tn, self.cat[0][:, : f[0]], self.cat_nrm[0][:, : f[0]])
+        for l in range(1, 5):
+            skip, skip_nrm = self.cat[l - 1][:, : f[l - 1]], self.cat_nrm[l - 1][:, : f[l - 1]]
+            ops.maxpool2(skip, skip_nrm, self.pool[l])
+            t, tn = self.tmp[l][:, : f[l]], self.tmp_nrm[l][:, : f[l]]
+            self._conv(net, f"down_{l}.convs.conv_0", downs[l].convs.conv_0, self.pool[l], None, t, tn)
+            if l < 4:
+                o, on = self.cat[l][:, : f[l]], self.cat_nrm[l][:, : f[l]]
+            else:
+                o, on = self.x4, self.x4_nrm
+            self._conv(net, f"down_{l}.convs.conv_1", downs[l].convs.conv_1, t, tn, o, on)
+
+        # decoder
+        src, src_nrm = self.x4, self.x4_nrm
+        for l in range(3, -1, -1):
+            upc = ups[l]
+            ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.cat[l][:, f[l]:])
+            co = self.dec_out[l]
+            t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
+            self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn)
+            self._conv(net, f"upcat_{l + 1}.convs.conv_1", upc.convs.conv_1, t, tn, self.u[l], self.u_nrm[l])
+            src, src_nrm = self.u[l], self.u_nrm[l]
+
+        fc = net.final_conv
+        ops.conv1x1(src, src_nrm, fc.weight.view(fc.weight.shape[0], -1), fc.bias, logits)

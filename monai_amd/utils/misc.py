@@ -1,0 +1,53 @@
+"""Host-side helpers with the reference's semantics (monai/utils/misc.py:162-299, monai/utils/module.py:61)."""
+
+from __future__ import annotations
+
+from collections.abc import Iterable, Sequence
+from typing import Any
+
+import numpy as np
+import torch
+
+
+def _issequence(x: Any) -> bool:
+    if isinstance(x, torch.Tensor):
+        return x.ndim > 0
+    return isinstance(x, Iterable) and not isinstance(x, (str, bytes))
+
+
+def ensure_tuple(vals: Any) -> tuple:
+    """monai/utils/misc.py:162-167"""
+    if isinstance(vals, (torch.Tensor, np.ndarray)) and vals.ndim == 0:
+        return (vals.item(),)
+    return tuple(vals) if _issequence(vals) else (vals,)
+
+
+def ensure_tuple_rep(tup: Any, dim: int) -> tuple:
+    """monai/utils/misc.py:190-228: a scalar is repeated `dim` times, a sequence must have length `dim`."""
+    if isinstance(tup, torch.Tensor):
+        tup = tup.detach().cpu().numpy()
+    if isinstance(tup, np.ndarray):
+        tup = tup.tolist()
+    if not _issequence(tup):
+        return (tup,) * dim
+    if len(tup) == dim:
+        return tuple(tup)
+    raise ValueError(f"Sequence must have length {dim}, got {len(tup)}.")
+
+
+def fall_back_tuple(user_provided: Any, default: Sequence, func=lambda x: x and x > 0) -> tuple:
+    """monai/utils/misc.py:256-299: invalid (None / non-positive) components fall back to `default`."""
+    ndim = len(default)
+    user = ensure_tuple_rep(user_provided, ndim)
+    return tuple(u if func(u) else d for d, u in zip(default, user))
+
+
+def look_up_option(opt: Any, supported: Sequence[str], name: str = "option") -> str:
+    """String-valued restatement of monai/utils/module.py:61-130 (accepts enum members through `.value`)."""
+    val = getattr(opt, "value", opt)
+    if isinstance(val, str):
+        val = val.strip().lower()
+    for s in supported:
+        if val == s:
+            return s
+    raise ValueError(f"Unsupported {name}: {opt}, available options are {list(supported)}.")

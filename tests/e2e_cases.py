@@ -1,0 +1,109 @@
+"""End-to-end parity cases (inferer + BasicUNet engine), shared by the emulator (CPU) and GPU test modules."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+import oracle
+from oracle import sliding_window as osw
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_TOL = 1e-4  # BASELINE.json north_star: fp32 logits within 1e-4 of the reference CPU inferer
+
+
+def make_net(seed, in_ch, out_ch, device, features=(32, 32, 64, 128, 256, 32)):
+    from monai_amd.networks.nets import BasicUNet
+
+    torch.manual_seed(seed)
+    net = BasicUNet(3, in_ch, out_ch, features=features).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    return net.to(device), sd
+
+
+def report(got: torch.Tensor, exp: torch.Tensor):
+    """max |logit diff|, argmax agreement and the top-2 margin statistics the north_star asks for."""
+    d = (got.double() - exp.double()).abs()
+    top2 = exp.double().topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    mism = (got.argmax(1) != exp.argmax(1))
+    return dict(max_abs=d.max().item(), mean_abs=d.mean().item(), argmax_mismatch=int(mism.sum().item()),
+                min_margin=margin.min().item(), n_margin_lt_1e4=int((margin < 1e-4).sum().item()),
+                max_margin_at_mismatch=(margin[mism].max().item() if mism.any() else 0.0))
+
+
+def case_net_single_window_vs_golden(device):
+    """5-class bench weights (seed 1) on the golden windows produced by the REAL reference."""
+    g = np.load(os.path.join(GOLDEN, "net5.npz"))
+    net, sd = make_net(1, 1, 5, device)
+    import hashlib
+
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode()); h.update(v.contiguous().numpy().tobytes())
+    assert h.hexdigest() == str(g["net5_state_sha256"]), "same seed must give the reference's weights"
+    torch.manual_seed(21)
+    x = torch.rand(2, 1, 32, 32, 32)
+    got = net(x.to(device)).cpu()
+    r = report(got, torch.from_numpy(g["net5_win32_out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    torch.manual_seed(22)
+    x = torch.rand(1, 1, 48, 32, 16)
+    got = net(x.to(device)).cpu()
+    r2 = report(got, torch.from_numpy(g["net5_win48x32x16_out"]))
+    assert r2["max_abs"] < LOGIT_TOL, r2
+    return r, r2
+
+
+def case_sliding_window_net5_vs_golden(device):
+    from monai_amd.inferers import SlidingWindowInferer
+
+    g = np.load(os.path.join(GOLDEN, "net5.npz"))
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(23)
+    x = torch.rand(1, 1, 48, 40, 32)
+    y = SlidingWindowInferer(roi_size=(32, 32, 32), sw_batch_size=4, overlap=0.5, mode="gaussian")(x.to(device), net)
+    r = report(y.cpu(), torch.from_numpy(g["net5_sw_out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    assert r["argmax_mismatch"] == 0 or r["max_margin_at_mismatch"] < 2 * LOGIT_TOL, r
+    return r
+
+
+def case_config0_vs_golden(device):
+    """BASELINE.json configs[0]: BasicUNet(1->2), rand 64^3, roi 32^3, sw_batch 4, overlap .5, gaussian."""
+    from monai_amd.inferers import SlidingWindowInferer
+
+    g = np.load(os.path.join(GOLDEN, "config0.npz"))
+    net, _ = make_net(0, 1, 2, device)
+    x = torch.rand(1, 1, 64, 64, 64)  # continues the seed-0 stream exactly like make_golden.py
+    assert x.double().sum().item() == float(g["cfg0_x_sum"])
+    y = SlidingWindowInferer(roi_size=(32, 32, 32), sw_batch_size=4, overlap=0.5, mode="gaussian")(x.to(device), net)
+    r = report(y.cpu(), torch.from_numpy(g["cfg0_out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    return r
+
+
+def case_blend_only_vs_golden(device):
+    """Generic (non-fused) predictor path, bit-exact against the reference's outputs (tests/golden/blend.npz)."""
+    from monai_amd.inferers import sliding_window_inference
+
+    g = np.load(os.path.join(GOLDEN, "blend.npz"))
+
+    def toy(k_out):
+        return lambda x: torch.cat([torch.sin(x[:, :1] * (1.0 + 0.37 * k)) + 0.05 * k * x[:, :1] for k in range(k_out)], dim=1)
+
+    i = 0
+    while f"blend_{i}_shape" in g:
+        shape = tuple(int(v) for v in g[f"blend_{i}_shape"])
+        torch.manual_seed(int(g[f"blend_{i}_seed"]))
+        x = torch.rand(shape)
+        k = int(g[f"blend_{i}_k"])
+        cpu_toy = toy(k)
+        # the predictor arithmetic itself (sin) must be the CPU's to be bit-comparable: evaluate it on the host
+        pred = (lambda w: cpu_toy(w.cpu()).to(w.device))
+        y = sliding_window_inference(x.to(device), tuple(int(v) for v in g[f"blend_{i}_roi"]), int(g[f"blend_{i}_sw"]), pred,
+                                     overlap=float(g[f"blend_{i}_ov"]), mode=str(g[f"blend_{i}_mode"]), padding_mode="constant", cval=-0.5)
+        assert np.array_equal(y.cpu().numpy(), g[f"blend_{i}_out"]), f"blend case {i}: not bit-identical to the reference"
+        i += 1
+    assert i >= 5

@@ -1,0 +1,16 @@
+"""End-to-end product path (SlidingWindowInferer -> BasicUNet engine -> blend) on the CPU through the SIMT
+emulator build of the kernels, checked against the golden outputs of the real reference."""
+import e2e_cases as ec
+
+
+def test_blend_only_bitwise_vs_reference(emu):
+    ec.case_blend_only_vs_golden("cpu")
+
+
+def test_net_single_window_vs_reference(emu):
+    r, r2 = ec.case_net_single_window_vs_golden("cpu")
+    print(r, r2)
+
+
+def test_sliding_window_net5_vs_reference(emu):
+    print(ec.case_sliding_window_net5_vs_golden("cpu"))
