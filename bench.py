@@ -1,0 +1,180 @@
+"""Headline benchmark (BASELINE.json): output voxels/s of 3-D sliding-window segmentation --
+512^3 fp32 synthetic volume, 96^3 windows, overlap 0.5 (1000 windows), 5-class BasicUNet, gaussian blend.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete ``SlidingWindowInferer(...)(volume, net)`` call: window gather, the BasicUNet forward of
+all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + normalise.  The volume is resident in
+HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2
+of BASELINE.json).  Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant
+kernel's launches inside the timed region, `cpu_baseline` times the CPU oracle (a port of the reference path:
+torch-CPU ATen ops, bit-identical to the reference -- tests/test_oracle_golden.py) on a bounded sample.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "voxels/s sliding-window 3D seg (512^3 vol, 96^3 win, ov 0.5) at 1/8 GPU"
+PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (≈6.3 TB/s achievable)
+
+
+def cpu_baseline(size: int, roi: int, windows: int):
+    """The CPU oracle on `windows` windows of the same workload; value = size^3 / (1000 windows * mean window time)."""
+    import oracle
+
+    torch.manual_seed(1)
+    sd = oracle.make_basic_unet_state(1, 5)
+    torch.manual_seed(0)
+    x = torch.rand(4, 1, roi, roi, roi)
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        oracle.basic_unet_forward(sd, x[:1])  # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        while done < windows:
+            oracle.basic_unet_forward(sd, x)  # sw_batch_size = 4, as in the workload
+            done += 4
+        dt = time.perf_counter() - t0
+    from oracle.sliding_window import dense_patch_starts, get_scan_interval
+
+    starts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
+    nwin = len(starts[0]) * len(starts[1]) * len(starts[2])
+    per_win = dt / done
+    return {
+        "value": size ** 3 / (nwin * per_win),
+        "unit": "voxels/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{done} of {nwin} windows ({roi}^3, sw_batch 4) through the CPU oracle's BasicUNet: {per_win:.3f} s/window; "
+                  f"value = {size}^3 voxels / ({nwin} windows x that), blend time (1-2 % on CPU) not included",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
+    ap.add_argument("--roi", type=int, default=96)
+    ap.add_argument("--cpu-windows", type=int, default=16, help="windows timed for cpu_baseline (0 = skip)")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+
+    from monai_amd import _prof, parallel
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.networks.nets import BasicUNet
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        parallel.enable_window_sharding()
+
+    # weights / volume exactly as SURVEY.md 8(d) config 1 (fallback volume: seeded uniform noise)
+    torch.manual_seed(1)
+    net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
+    torch.manual_seed(0)
+    vol = torch.rand(1, 1, args.size, args.size, args.size).to(dev)
+    inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = inferer(vol, net)
+    sync()
+    _prof.start()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = inferer(vol, net)
+    sync()
+    dt = time.perf_counter() - t0
+    spans = _prof.stop()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        voxels = float(args.size) ** 3
+        ms = 1e3 * dt / args.steps
+        conv = spans.get("conv3d_k3/cfg1")
+        roof = None
+        if conv:
+            tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                    "traffic": None, "kernel": "conv3d_k3_mfma_kernel<ConvCfg<32,1,1,4,4,1,1,8>> (3x3x3 conv, 32|64->32 ch @96^3)",
+                    "launches": conv["launches"], "ms_avg": conv["ms_avg"],
+                    "flops_per_launch": conv["work"] / conv["launches"]}
+        blend = spans.get("sw_blend")
+        roof_hbm = None
+        if blend:
+            gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
+            roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "traffic": None, "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+                        "bytes_per_launch": blend["work"] / blend["launches"]}
+        conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
+                    for k, v in spans.items() if k.startswith("conv3d_k3/")}
+        line = {
+            "metric": METRIC,
+            "value": voxels / (dt / args.steps),
+            "unit": "voxels/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BasicUNet 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
+                            f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 25 windows per launch)",
+                "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
+            },
+            "roofline": roof,
+            "roofline_hbm": roof_hbm,
+            "conv_ms_per_step": conv_all,
+            "checksum": float(out.double().sum().item()),
+        }
+        if world == 1 and args.cpu_windows > 0:
+            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

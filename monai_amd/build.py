@@ -1,0 +1,44 @@
+"""Build the HIP extension in-tree:  ``python -m monai_amd.build``  ->  monai_amd/csrc/libmonai_amd.so
+
+One translation unit (csrc/capi.hip + kernels/*.h), compiled for gfx950 only.  hipcc cross-compiles without a
+GPU, so this also runs in the GPU-less build container; the resulting .so travels to the GPU box in-tree."""
+
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "capi.hip")
+OUT = os.path.join(HERE, "csrc", "libmonai_amd.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def _deps():
+    kd = os.path.join(HERE, "csrc", "kernels")
+    deps = [SRC, os.path.join(os.path.dirname(HERE), "include", "monai_amd.h")]
+    deps += [os.path.join(kd, f) for f in sorted(os.listdir(kd)) if f.endswith(".h")]
+    return deps
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("monai_amd.build: hipcc not found (set HIPCC or install ROCm)")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
+        return OUT
+    cmd = [hipcc()] + FLAGS + [SRC, "-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -25,7 +25,7 @@ from typing import Any
 import torch
 import torch.nn.functional as F
 
-from .. import _lib, ops, parallel
+from .. import _lib, _prof, ops, parallel
 from ..data.utils import compute_importance_map, get_valid_patch_size, window_starts
 from ..utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple, look_up_option
 
@@ -266,7 +266,9 @@ def sliding_window_inference(
                 g = grid3
             else:
                 g = [[0]] * (3 - num_spatial_dims) + [[int(s * zz) for s in ax] for ax, zz in zip(starts, z)]
-            ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
+            nbytes = 4.0 * (lg[:num_win].numel() + outputs[ss][b].numel())  # logits read once + output written once
+            with _prof.span("sw_blend", nbytes):
+                ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
 
     # back to the caller's rank / crop the padding (utils.py:300-313) / output device
     finals = []

@@ -30,7 +30,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ... import _lib, ops
+from ... import _lib, _prof, ops
 
 __all__ = ["BasicUNet", "BasicUnet", "Basicunet", "basicunet"]
 
@@ -230,11 +230,14 @@ class _Plan:
         cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
         packed = net._packed_weight(name, block.conv, cfg)
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if net.fused_stats else 0
+        flops = 2.0 * 27 * cin * cout * d * h * w * n
         if tiles:
             stats = self._stats_buf(n * cout * tiles * 3)
-            ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, stats)
+            with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+                ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, stats)
         else:
-            ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, None)
+            with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+                ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, None)
             tiles = ops.instnorm_stat_tiles(d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3)
             ops.instnorm_stats(out, stats)

@@ -1,0 +1,104 @@
+"""-m gpu: end-to-end parity of the product path on the MI355X against (a) the golden outputs of the real
+reference (tests/golden) and (b) the CPU oracle on bench-shaped windows, plus size-independent properties at the
+full BASELINE.json size."""
+import numpy as np
+import pytest
+import torch
+
+import e2e_cases as ec
+import oracle
+from oracle import sliding_window as osw
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_blend_only_bitwise_vs_reference():
+    ec.case_blend_only_vs_golden(DEV)
+
+
+def test_net_single_window_vs_reference():
+    print(ec.case_net_single_window_vs_golden(DEV))
+
+
+def test_sliding_window_net5_vs_reference():
+    print(ec.case_sliding_window_net5_vs_golden(DEV))
+
+
+def test_config0_vs_reference():
+    """BASELINE.json configs[0]"""
+    print(ec.case_config0_vs_golden(DEV))
+
+
+def test_bench_shaped_windows_vs_oracle():
+    """96^3 windows (the tile configurations the 512^3 bench uses), 144x96x96 volume = 2 windows, vs the CPU oracle."""
+    from monai_amd.inferers import SlidingWindowInferer
+
+    net, sd = ec.make_net(1, 1, 5, DEV)
+    torch.manual_seed(5)
+    x = torch.rand(1, 1, 144, 96, 96)
+    y = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")(x.to(DEV), net)
+    with torch.no_grad():
+        ref = osw.sliding_window_inference(x, (96, 96, 96), 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian")
+    r = ec.report(y.cpu(), ref)
+    print(r)
+    assert r["max_abs"] < ec.LOGIT_TOL, r
+    assert r["argmax_mismatch"] == 0 or r["max_margin_at_mismatch"] < 2 * ec.LOGIT_TOL, r
+
+
+def test_fused_and_separate_instnorm_statistics_agree():
+    net, _ = ec.make_net(1, 1, 5, DEV)
+    torch.manual_seed(6)
+    x = torch.rand(2, 1, 32, 48, 64, device=DEV)
+    a = net(x).clone()
+    net.fused_stats = False
+    b = net(x)
+    assert (a - b).abs().max().item() < 2e-5
+
+
+def test_batch_independence_and_determinism():
+    """InstanceNorm is per sample: the engine's larger window batches must not change any window's logits."""
+    net, _ = ec.make_net(1, 1, 5, DEV)
+    torch.manual_seed(7)
+    x = torch.rand(5, 1, 32, 32, 32, device=DEV)
+    full = net(x).clone()
+    for i in range(5):
+        assert torch.equal(net(x[i : i + 1]), full[i : i + 1])
+    assert torch.equal(net(x), full)
+
+
+def test_full_size_properties_512():
+    """BASELINE.json configs[1] size: 512^3, 96^3 windows, overlap 0.5 (1000 windows).  Size-independent checks:
+    (1) a predictor that returns a constant per class gives back exactly that constant everywhere (partition of
+    unity of the normalised blend, both modes); (2) the K-channel blend of an affine function of the window data is
+    that function of the volume up to rounding; (3) the fused network path is finite and matches itself across two runs."""
+    from monai_amd.inferers import SlidingWindowInferer, sliding_window_inference
+
+    torch.manual_seed(0)
+    vol = torch.rand(1, 1, 512, 512, 512, device=DEV)
+
+    def affine_pred(w):
+        return torch.cat([w * (k + 1.0) - 0.25 * k for k in range(5)], dim=1)
+
+    y = sliding_window_inference(vol, (96, 96, 96), 20, affine_pred, overlap=0.5, mode="gaussian")
+    for k in range(5):
+        assert (y[:, k : k + 1] - (vol * (k + 1.0) - 0.25 * k)).abs().max().item() < 2e-6 * (k + 1)
+    del y
+
+    def const_pred(w):
+        return torch.stack([torch.full_like(w[:, 0], 0.5 + k) for k in range(3)], dim=1)
+
+    y = sliding_window_inference(vol, (96, 96, 96), 20, const_pred, overlap=0.5, mode="constant")
+    for k in range(3):
+        assert (y[:, k] - (0.5 + k)).abs().max().item() < 1e-6
+    del y
+
+    net, _ = ec.make_net(1, 1, 5, DEV)
+    inf = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")
+    a = inf(vol, net)
+    assert a.shape == (1, 5, 512, 512, 512) and bool(torch.isfinite(a).all())
+    s1 = a.double().sum().item()
+    lab = a.argmax(1)
+    del a
+    b = inf(vol, net)
+    assert b.double().sum().item() == s1 and torch.equal(b.argmax(1), lab)  # deterministic: no atomics anywhere

@@ -1,0 +1,73 @@
+"""-m gpu: the kernel parity cases of tests/kernel_cases.py on the real MI355X, through the C ABI of the in-tree
+libmonai_amd.so (the same cases run on the CPU against the emulator build in tests/test_kernels_emu.py)."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu_and_native_lib():
+    if not torch.cuda.is_available():
+        pytest.fail("the -m gpu tests need an MI355X")
+    from monai_amd import _lib
+
+    assert _lib.lib().path.endswith("libmonai_amd.so")  # the HIP build, loaded from the package tree
+
+
+def test_window_extract():
+    kc.case_window_extract(DEV)
+    kc.case_window_extract(DEV, img=(1, 13, 10, 11), roi=(5, 4, 3), overlap=0.25)
+    kc.case_window_extract(DEV, img=(1, 128, 120, 112), roi=(96, 96, 96), overlap=0.5)
+
+
+@pytest.mark.parametrize("mode", ["gaussian", "constant"])
+def test_sw_blend_bitwise(mode):
+    kc.case_sw_blend(DEV, mode=mode)
+    kc.case_sw_blend(DEV, img=(11, 13, 10), roi=(4, 5, 3), overlap=0.25, k=3, mode=mode)
+    kc.case_sw_blend(DEV, img=(1, 20, 24), roi=(1, 8, 8), overlap=0.75, k=11, mode=mode)
+    kc.case_sw_blend(DEV, img=(144, 112, 160), roi=(96, 96, 96), overlap=0.5, k=5, mode=mode)  # bench-shaped windows
+
+
+def test_conv_direct():
+    kc.case_conv3d(DEV, 0, 2, 1, 32, (6, 7, 9), with_nrm=False, fused_stats=False)
+    kc.case_conv3d(DEV, 0, 1, 5, 7, (4, 5, 6), fused_stats=False)
+    kc.case_conv3d(DEV, 0, 2, 1, 32, (32, 48, 96), with_nrm=False, fused_stats=False)
+
+
+@pytest.mark.parametrize(
+    "cfg,cin,cout,dims",
+    [
+        (1, 8, 32, (4, 8, 32)), (1, 16, 32, (5, 6, 40)), (1, 64, 32, (16, 16, 96)),
+        (2, 8, 32, (4, 8, 16)), (2, 32, 32, (6, 10, 24)), (2, 64, 32, (16, 48, 48)),
+        (3, 8, 64, (2, 8, 8)), (3, 64, 64, (3, 12, 12)), (3, 128, 64, (24, 24, 24)),
+        (4, 4, 128, (2, 4, 4)), (4, 256, 128, (12, 12, 12)),
+        (5, 2, 256, (2, 4, 4)), (5, 256, 256, (6, 6, 6)),
+        (6, 8, 32, (4, 8, 8)), (6, 32, 32, (5, 9, 7)),
+    ],
+)
+def test_conv_mfma_configs(cfg, cin, cout, dims):
+    kc.case_conv3d(DEV, cfg, 2, cin, cout, dims, fused_stats=True, tol=5e-5)
+
+
+def test_conv_mfma_separate_stats_and_select():
+    assert kc.case_conv3d(DEV, None, 1, 8, 32, (4, 8, 32), fused_stats=False) == 1
+
+
+def test_conv_into_channel_slice():
+    kc.case_conv3d_into_channel_slice(DEV)
+
+
+def test_pool_deconv_1x1_stats():
+    kc.case_maxpool(DEV)
+    kc.case_maxpool(DEV, dims=(4, 6, 7))
+    kc.case_maxpool(DEV, n=2, c=32, dims=(32, 32, 96))
+    kc.case_deconv(DEV)
+    kc.case_deconv(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
+    kc.case_conv1x1(DEV)
+    kc.case_conv1x1(DEV, cin=7, cout=11, dims=(3, 5, 7))
+    kc.case_instnorm_stats(DEV)
+    kc.case_instnorm_stats(DEV, n=2, c=32, dims=(32, 48, 96))
