@@ -72,6 +72,8 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
  * Several kernel configurations exist; mh_conv3d_k3_select picks one (0 = direct VALU kernel, any
  * channel counts; >= 1 = fp32-MFMA implicit-GEMM tiles).  Weights are repacked once per configuration. */
 int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W);
+int mh_conv3d_k3_num_configs(void);                    /* highest configuration id */
+int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 /* w: torch layout [Cout][Cin][3][3][3] */
 int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream);

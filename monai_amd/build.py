@@ -13,7 +13,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "capi.hip")
 OUT = os.path.join(HERE, "csrc", "libmonai_amd.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+# -ffp-contract=off: no implicit FMA formation anywhere.  The blend must round the multiply and the add
+# separately to stay bit-identical to the reference (HIP's __fmul_rn/__fadd_rn are plain * and + and WOULD be
+# fused under the default -ffp-contract=fast); every intended FMA in the kernels is an explicit fmaf().
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value"]
 
 
 def _deps():

@@ -116,52 +116,65 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
 }
 
 // ------------------------------------------------------------------------------------------ conv 3x3x3
-//                        MX MY MZ MT WM WN NT CC
-typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 8> Cfg1;   // tile 32x4x4, 32 couts   (96^3 level)
-typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 8> Cfg2;   // tile 16x8x4, 32 couts   (48^3 level)
-typedef ConvCfg<8, 4, 1, 2, 2, 2, 1, 8> Cfg3;    // tile 8x8x2,  64 couts   (24^3 level)
-typedef ConvCfg<4, 4, 2, 1, 1, 4, 1, 4> Cfg4;    // tile 4x4x2, 128 couts   (12^3 level)
-typedef ConvCfg<4, 4, 2, 1, 1, 4, 2, 2> Cfg5;    // tile 4x4x2, 256 couts   (6^3 level)
-typedef ConvCfg<8, 4, 1, 2, 4, 1, 1, 8> Cfg6;    // tile 8x8x4,  32 couts   (small volumes)
-#define MH_NUM_CFG 6
+//                MX MY MZ MT WM WN NT CC OCC
+typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 8, 2> Cfg1;   // tile 32x4x4, 32 couts   (96^3 level)
+typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 8, 2> Cfg2;   // tile 16x8x4, 32 couts   (48^3 level)
+typedef ConvCfg<8, 4, 1, 2, 2, 2, 1, 8, 2> Cfg3;    // tile 8x8x2,  64 couts   (24^3 level)
+typedef ConvCfg<4, 4, 2, 1, 1, 4, 1, 4, 2> Cfg4;    // tile 4x4x2, 128 couts   (12^3 level)
+typedef ConvCfg<4, 4, 2, 1, 1, 4, 2, 2, 2> Cfg5;    // tile 4x4x2, 256 couts   (6^3 level)
+typedef ConvCfg<8, 4, 1, 2, 4, 1, 1, 8, 2> Cfg6;    // tile 8x8x4,  32 couts   (small volumes)
+typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 2, 4> Cfg7;   // tile 32x4x4, 32 couts, 2-channel chunks (first layer, Cin = 1)
+typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 4, 3> Cfg8;   // cfg1 with 4-channel chunks: 3 workgroups per CU
+typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 4, 3> Cfg9;   // cfg2 with 4-channel chunks
+#define MH_NUM_CFG 9
 
 struct CfgInfo { int tx, ty, tz, cn, cc; };
+#define MH_CFG_ROW(C) {C::TX, C::TY, C::TZ, C::CN, C::CC}
 static const CfgInfo kCfg[MH_NUM_CFG + 1] = {
-    {0, 0, 0, 0, 0},
-    {Cfg1::TX, Cfg1::TY, Cfg1::TZ, Cfg1::CN, Cfg1::CC}, {Cfg2::TX, Cfg2::TY, Cfg2::TZ, Cfg2::CN, Cfg2::CC},
-    {Cfg3::TX, Cfg3::TY, Cfg3::TZ, Cfg3::CN, Cfg3::CC}, {Cfg4::TX, Cfg4::TY, Cfg4::TZ, Cfg4::CN, Cfg4::CC},
-    {Cfg5::TX, Cfg5::TY, Cfg5::TZ, Cfg5::CN, Cfg5::CC}, {Cfg6::TX, Cfg6::TY, Cfg6::TZ, Cfg6::CN, Cfg6::CC},
+    {0, 0, 0, 0, 0}, MH_CFG_ROW(Cfg1), MH_CFG_ROW(Cfg2), MH_CFG_ROW(Cfg3), MH_CFG_ROW(Cfg4), MH_CFG_ROW(Cfg5),
+    MH_CFG_ROW(Cfg6), MH_CFG_ROW(Cfg7), MH_CFG_ROW(Cfg8), MH_CFG_ROW(Cfg9),
 };
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int cin_padded(int cfg, int Cin) { return cfg == 0 ? Cin : cdiv(Cin, kCfg[cfg].cc) * kCfg[cfg].cc; }
 
+int mh_conv3d_k3_num_configs(void) { return MH_NUM_CFG; }
+
+int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
+    if (cfg == 0) return 1;
+    if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
+    return Cout % kCfg[cfg].cn == 0 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
+}
+
+// Heuristic choice: the configuration that wastes the least matrix work -- masked voxels of partial tiles and
+// zero-padded input channels both count -- preferring the wider cout tile, then the lower id.  (cfg 8/9 are
+// alternatives to 1/2 that are only picked explicitly.)
 int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
     if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "conv3d_k3_select: bad argument");
     int best = 0;
     double best_score = 0.0;
-    if (Cin <= Cfg1::NRM_MAX) {
-        for (int c = 1; c <= MH_NUM_CFG; ++c) {
-            const CfgInfo& k = kCfg[c];
-            if (Cout % k.cn || Cin % k.cc) continue;
-            const double util = (double)D * H * W / ((double)cdiv(D, k.tz) * k.tz * cdiv(H, k.ty) * k.ty * cdiv(W, k.tx) * k.tx);
-            // prefer full tiles; among equals the wider cout tile (input staged once for more outputs)
-            const double score = util * (1.0 + 0.02 * (k.cn / 32)) * (1.0 + 0.001 * (MH_NUM_CFG - c));
-            if (score > best_score) { best_score = score; best = c; }
-        }
+    for (int c = 1; c <= 7; ++c) {
+        const CfgInfo& k = kCfg[c];
+        if (!mh_conv3d_k3_accepts(c, Cin, Cout)) continue;
+        const double util = (double)D * H * W / ((double)cdiv(D, k.tz) * k.tz * cdiv(H, k.ty) * k.ty * cdiv(W, k.tx) * k.tx);
+        const double cpad = (double)Cin / cin_padded(c, Cin);
+        const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * (1.0 + 0.001 * (MH_NUM_CFG - c));
+        if (score > best_score) { best_score = score; best = c; }
     }
     return best;
 }
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
-    return (int64_t)Cin * Cout * 27;
+    return (int64_t)cin_padded(cfg, Cin) * Cout * 27;
 }
 
 int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream) {
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
     if (Cout % cn) return fail(MH_ERR_ARG, "conv3d_k3_pack: Cout %d not a multiple of %d", Cout, cn);
-    hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for((long long)Cin * Cout * 27)), dim3(256), 0, (hipStream_t)stream, w,
-                       Cin, Cout, cn, packed);
+    const int cinp = cin_padded(cfg, Cin);
+    hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for((long long)cinp * Cout * 27)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cin, cinp, Cout, cn, packed);
     return launched("conv3d_k3_pack");
 }
 
@@ -197,7 +210,8 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         return launched("conv3d_k3_direct");
     }
     const CfgInfo& k = kCfg[cfg];
-    if (out.C % k.cn || in.C % k.cc || in.C > Cfg1::NRM_MAX)
+    (void)k;
+    if (!mh_conv3d_k3_accepts(cfg, in.C, out.C))
         return fail(MH_ERR_ARG, "conv3d_k3: configuration %d does not take Cin=%d Cout=%d", cfg, in.C, out.C);
     if (!aligned(packed_w, 16)) return fail(MH_ERR_ARG, "conv3d_k3: packed weights must be 16-byte aligned");
     switch (cfg) {
@@ -207,6 +221,9 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         case 4: launch_mfma<Cfg4>(in, packed_w, bias, out, stats, s); break;
         case 5: launch_mfma<Cfg5>(in, packed_w, bias, out, stats, s); break;
         case 6: launch_mfma<Cfg6>(in, packed_w, bias, out, stats, s); break;
+        case 7: launch_mfma<Cfg7>(in, packed_w, bias, out, stats, s); break;
+        case 8: launch_mfma<Cfg8>(in, packed_w, bias, out, stats, s); break;
+        case 9: launch_mfma<Cfg9>(in, packed_w, bias, out, stats, s); break;
     }
     return launched("conv3d_k3_mfma");
 }

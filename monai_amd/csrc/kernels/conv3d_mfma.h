@@ -23,9 +23,9 @@
 
 namespace mh {
 
-template <int MX_, int MY_, int MZ_, int MT_, int WM_, int WN_, int NT_, int CC_>
+template <int MX_, int MY_, int MZ_, int MT_, int WM_, int WN_, int NT_, int CC_, int OCC_ = 2>
 struct ConvCfg {
-    static constexpr int MX = MX_, MY = MY_, MZ = MZ_, MT = MT_, WM = WM_, WN = WN_, NT = NT_, CC = CC_;
+    static constexpr int MX = MX_, MY = MY_, MZ = MZ_, MT = MT_, WM = WM_, WN = WN_, NT = NT_, CC = CC_, OCC = OCC_;
     static constexpr int TX = MX, TY = MY * MT, TZ = MZ * WM;
     static constexpr int TXH = TX + 2, TYH = TY + 2, TZH = TZ + 2;
     static constexpr int PLANE = TXH * TYH;
@@ -33,6 +33,8 @@ struct ConvCfg {
     static constexpr int CN = 32 * NT * WN;       // output channels per workgroup
     static constexpr int IN_FLOATS = CC * CHS;
     static constexpr int W_FLOATS = CC * 27 * CN;
+    static constexpr int SLOTS = (CHS + 255) / 256;          // halo-tile elements per thread per channel
+    static constexpr int WV4 = (W_FLOATS / 4 + 255) / 256;   // weight float4s per thread per chunk
     static constexpr int NRM_MAX = 512;           // max input channels (float4 each) kept in LDS
     static constexpr int SMEM_FLOATS = IN_FLOATS + W_FLOATS + 4 * NRM_MAX;
     static_assert(MX * MY * MZ == 32, "an M-tile is 32 voxels");
@@ -42,12 +44,48 @@ struct ConvCfg {
     static_assert(3 * WM * CN <= IN_FLOATS + W_FLOATS, "statistics scratch fits the tile area");
 };
 
+// One software-pipelined step of the matrix loop (compile-time step index S): consume the operands fetched by the
+// previous step, request the next step's operands, issue the MFMAs, fence the scheduler.
+template <class Cfg, int S, int NSTEP>
+__device__ __forceinline__ void mfma_steps(f32x16 (&acc)[Cfg::MT][Cfg::NT], float (&an)[Cfg::MT], float (&bn)[Cfg::NT],
+                                           const float* xs, const float* ws, int abase, int bbase) {
+    if constexpr (S < NSTEP) {
+        constexpr int MT = Cfg::MT, NT = Cfg::NT, CC = Cfg::CC, CN = Cfg::CN;
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = an[m];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) bv[q] = bn[q];
+        if constexpr (S + 1 < NSTEP) {
+            constexpr int t = (S + 1) / (CC / 2), p = (S + 1) % (CC / 2);
+            constexpr int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) bn[q] = ws[bbase + (2 * p) * 27 * CN + t * CN + q * 32];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                an[m] = xs[abase + (2 * p) * Cfg::CHS + dz * Cfg::PLANE + (m * Cfg::MY + dy) * Cfg::TXH + dx];
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < NT; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[q], acc[m][q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps<Cfg, S + 1, NSTEP>(acc, an, bn, xs, ws, abase, bbase);
+    }
+}
+
+// Staging pipeline (per input-channel chunk):   loads(c+1) -> registers are issued BEFORE the MFMA loop of
+// chunk c, so their HBM/L2 latency hides under ~10 us of matrix work; after the loop one barrier, then the
+// registers are normalised/activated and written to LDS (a few hundred VALU/DS instructions), one barrier,
+// next chunk.  Each thread owns the same SLOTS positions of the halo tile in every channel, so the
+// global offsets / bounds of its positions are computed once per workgroup.
 template <class Cfg, bool STATS>
-__global__ void __launch_bounds__(256, 2)  // 2 waves/SIMD: two workgroups per CU (LDS-limited), <= 256 registers
+__global__ void __launch_bounds__(256, Cfg::OCC)
 conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out,
                       float* __restrict__ stats, int tiles_x, int tiles_y, int tiles_z) {
     constexpr int MX = Cfg::MX, MY = Cfg::MY, MZ = Cfg::MZ, MT = Cfg::MT, WM = Cfg::WM, NT = Cfg::NT;
     constexpr int CC = Cfg::CC, TXH = Cfg::TXH, PLANE = Cfg::PLANE, CHS = Cfg::CHS, CN = Cfg::CN;
+    constexpr int SLOTS = Cfg::SLOTS, WV4 = Cfg::WV4;
 
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     float* xs = smem;
@@ -58,6 +96,7 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     const int wm = wave % WM, wn = wave / WM;
     const int kh = lane >> 5, li = lane & 31;
     const int Cin = in.C, Cout = out.C, D = out.D, H = out.H, W = out.W;
+    const int CinP = (Cin + CC - 1) / CC * CC;    // the packed weights are zero-padded to a multiple of CC
     const long long DHW = (long long)D * H * W;
 
     const unsigned ntiles = gridDim.x;
@@ -67,7 +106,21 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     const int tz0 = (int)(b / (tiles_x * tiles_y)) * Cfg::TZ;
     const int ct = blockIdx.y, n = blockIdx.z;
 
-    for (int c = tid; c < Cin; c += 256) nrm_s[c] = load_nrm(in, n, c);
+    for (int c = tid; c < CinP; c += 256)
+        nrm_s[c] = c < Cin ? load_nrm(in, n, c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    // this thread's positions in the halo tile: global offset inside a channel plane, and validity
+    int soff[SLOTS];
+    bool sok[SLOTS];
+#pragma unroll
+    for (int j = 0; j < SLOTS; ++j) {
+        const int r = tid + 256 * j;
+        const int lz = r / PLANE, r2 = r - lz * PLANE;
+        const int ly = r2 / TXH, lx = r2 - ly * TXH;
+        const int gz = tz0 + lz - 1, gy = ty0 + ly - 1, gx = tx0 + lx - 1;
+        sok[j] = r < CHS && gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        soff[j] = sok[j] ? (gz * H + gy) * W + gx : 0;
+    }
 
     // per-lane LDS bases (floats)
     const int ix = li % MX, iy = (li / MX) % MY, iz = li / (MX * MY);
@@ -83,52 +136,73 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.0f;
 
     const float* src = in.data + (long long)n * in.n_stride;
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(wp + (long long)ct * CinP * 27 * CN);
 
-    for (int c0 = 0; c0 < Cin; c0 += CC) {
-        __syncthreads();  // previous chunk fully consumed (first pass: nrm_s visible)
-        {   // weight slab: CC*27*CN contiguous floats of the packed tensor [ct][cin][27][CN]
-            const float4* wsrc = reinterpret_cast<const float4*>(wp + ((long long)ct * Cin + c0) * 27 * CN);
-            float4* wdst = reinterpret_cast<float4*>(ws);
-            for (int i = tid; i < Cfg::W_FLOATS / 4; i += 256) wdst[i] = wsrc[i];
-        }
-        for (int i = tid; i < Cfg::IN_FLOATS; i += 256) {   // halo tile, normalise + activate on load
-            const int c = i / CHS, r = i - c * CHS;
-            const int lz = r / PLANE, r2 = r - lz * PLANE;
-            const int ly = r2 / TXH, lx = r2 - ly * TXH;
-            const int gz = tz0 + lz - 1, gy = ty0 + ly - 1, gx = tx0 + lx - 1;
-            float v = 0.0f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                const float4 a = nrm_s[c0 + c];
-                v = act(src[(long long)(c0 + c) * DHW + ((long long)gz * H + gy) * W + gx], a.x, a.y, a.z);
+    float xin[CC][SLOTS];
+    f32x4 win[WV4];
+    // unconditional loads from clamped addresses (no control flow: they all issue back to back)
+#define MH_ISSUE_LOADS(C0)                                                                                 \
+    {                                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < CC; ++c) {                                                   \
+            const int cg = (C0) + c < Cin ? (C0) + c : Cin - 1;                                            \
+            const float* plane = src + (long long)cg * DHW;                                                \
+            _Pragma("unroll") for (int j = 0; j < SLOTS; ++j) xin[c][j] = plane[soff[j]];                  \
+        }                                                                                                  \
+        const f32x4* wq = wsrc + (long long)(C0) * 27 * CN / 4;                                            \
+        _Pragma("unroll") for (int k = 0; k < WV4; ++k) {                                                  \
+            const int i = tid + 256 * k;                                                                   \
+            win[k] = wq[i < Cfg::W_FLOATS / 4 ? i : 0];                                                    \
+        }                                                                                                  \
+    }
+
+    MH_ISSUE_LOADS(0)
+    __syncthreads();  // nrm_s visible
+
+    for (int c0 = 0; c0 < CinP; c0 += CC) {
+        // registers -> LDS: halo tile with the producer's InstanceNorm + LeakyReLU applied, zero outside the
+        // volume (the conv's zero padding acts on the ACTIVATED tensor) and for padded channels
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const float4 a = nrm_s[c0 + c];
+            const bool cok = c0 + c < Cin;
+#pragma unroll
+            for (int j = 0; j < SLOTS; ++j) {
+                const int r = tid + 256 * j;
+                if (r < CHS) xs[c * CHS + r] = (cok && sok[j]) ? act(xin[c][j], a.x, a.y, a.z) : 0.0f;
             }
-            xs[i] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < WV4; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Cfg::W_FLOATS / 4) reinterpret_cast<f32x4*>(ws)[i] = win[k];
         }
         __syncthreads();
+        if (c0 + CC < CinP) MH_ISSUE_LOADS(c0 + CC)   // in flight during the matrix loop below
 
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const int dz = t / 9, dy = (t / 3) % 3, dx = t % 3;
-#pragma unroll
-            for (int p = 0; p < CC / 2; ++p) {
-                float bv[NT], av[MT];
-#pragma unroll
-                for (int q = 0; q < NT; ++q) bv[q] = ws[bbase + (2 * p) * 27 * CN + t * CN + q * 32];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) av[m] = xs[abase + (2 * p) * CHS + dz * PLANE + (m * MY + dy) * TXH + dx];
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[q], acc[m][q], 0, 0, 0);
-            }
-        }
+        // matrix loop, software-pipelined by hand: the LDS operands of step s+1 are requested before the MFMAs of
+        // step s issue, and sched_barrier(0) keeps the compiler from hoisting further ahead (it otherwise
+        // prefetches dozens of steps and spills).  One step = one tap x one channel pair = MT*NT MFMAs.
+        constexpr int NSTEP = 27 * (CC / 2);
+        float an[MT], bn[NT];
+#define MH_LOAD_STEP(S)                                                                                          \
+    {                                                                                                            \
+        constexpr int t_ = (S) / (CC / 2), p_ = (S) % (CC / 2);                                                  \
+        constexpr int dz_ = t_ / 9, dy_ = (t_ / 3) % 3, dx_ = t_ % 3;                                            \
+        _Pragma("unroll") for (int q = 0; q < NT; ++q) bn[q] = ws[bbase + (2 * p_) * 27 * CN + t_ * CN + q * 32]; \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                           \
+            an[m] = xs[abase + (2 * p_) * CHS + dz_ * PLANE + (m * MY + dy_) * TXH + dx_];                       \
     }
+        MH_LOAD_STEP(0)
+        mfma_steps<Cfg, 0, NSTEP>(acc, an, bn, xs, ws, abase, bbase);
+#undef MH_LOAD_STEP
+        __syncthreads();  // every wave is done reading this chunk before LDS is overwritten
+    }
+#undef MH_ISSUE_LOADS
 
     // ---- epilogue: bias, store, fused InstanceNorm statistics --------------------------------------
     float* dst = out.data + (long long)n * out.n_stride;
     const bool vec_ok = (MX % 4 == 0) && (W % 4 == 0) && ((reinterpret_cast<uintptr_t>(out.data) & 15) == 0) &&
                         (out.n_stride % 4 == 0);
-    if (STATS) __syncthreads();  // all waves done with xs/ws before it is reused as statistics scratch
 #pragma unroll
     for (int q = 0; q < NT; ++q) {
         const int col = (wn * NT + q) * 32 + li;   // cout within the workgroup's CN
@@ -212,20 +286,20 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     }
 }
 
-// Repack torch conv weights [Cout][Cin][27] into [Cout/CN][Cin][27][CN] (the per-chunk LDS slab becomes one
-// contiguous run).  CN = Cout gives the layout of the direct kernel.
+// Repack torch conv weights [Cout][Cin][27] into [Cout/CN][CinP][27][CN] (the per-chunk LDS slab becomes one
+// contiguous run); CinP >= Cin pads the input channels with zero rows.  CN = Cout is the direct kernel's layout.
 __global__ void __launch_bounds__(256)
-conv3d_k3_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int CN, float* __restrict__ packed) {
-    const long long total = (long long)Cout * Cin * 27;
+conv3d_k3_pack_kernel(const float* __restrict__ w, int Cin, int CinP, int Cout, int CN, float* __restrict__ packed) {
+    const long long total = (long long)Cout * CinP * 27;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int col = (int)(idx % CN);
     long long t = idx / CN;
     const int tap = (int)(t % 27); t /= 27;
-    const int ci = (int)(t % Cin);
-    const int ct = (int)(t / Cin);
+    const int ci = (int)(t % CinP);
+    const int ct = (int)(t / CinP);
     const int co = ct * CN + col;
-    packed[idx] = w[((long long)co * Cin + ci) * 27 + tap];
+    packed[idx] = ci < Cin ? w[((long long)co * Cin + ci) * 27 + tap] : 0.0f;
 }
 
 }  // namespace mh

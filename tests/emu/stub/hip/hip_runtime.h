@@ -216,6 +216,7 @@ inline f32x16_t mfma_f32_32x32x2f32(float a, float b, f32x16_t cin, int, int, in
 #define gridDim (emu::ctx().gridDim)
 #define __syncthreads() emu::yield_to_sched(emu::BLOCK_WAIT)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu::mfma_f32_32x32x2f32
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu::wave_read(v, emu::ctx().cur->lane ^ mask); }
 template <class T> static inline T __shfl_down(T v, int d, int = 64) {

@@ -39,6 +39,12 @@ def test_conv_direct(emu):
         (5, 4, 256, (3, 3, 3)),
         (6, 8, 32, (4, 8, 8)),
         (6, 8, 32, (5, 9, 7)),
+        (7, 1, 32, (4, 8, 32)),     # first layer: Cin = 1 zero-padded to the 2-channel chunk
+        (7, 3, 32, (5, 5, 33)),     # odd Cin, ragged
+        (8, 8, 32, (4, 8, 32)),
+        (8, 6, 32, (5, 6, 40)),     # Cin padded 6 -> 8
+        (9, 8, 32, (6, 10, 24)),
+        (1, 5, 32, (4, 4, 32)),     # Cin padded 5 -> 8 in the 8-channel configuration
     ],
 )
 def test_conv_mfma_configs(emu, cfg, cin, cout, dims):
@@ -56,7 +62,7 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 3
     assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 4
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 5
-    assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 0
+    assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 7
     assert ops.conv3d_k3_select(32, 5, 96, 96, 96) == 0
 
 

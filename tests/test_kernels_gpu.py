@@ -47,6 +47,9 @@ def test_conv_direct():
         (4, 4, 128, (2, 4, 4)), (4, 256, 128, (12, 12, 12)),
         (5, 2, 256, (2, 4, 4)), (5, 256, 256, (6, 6, 6)),
         (6, 8, 32, (4, 8, 8)), (6, 32, 32, (5, 9, 7)),
+        (7, 1, 32, (4, 8, 32)), (7, 3, 32, (5, 5, 33)), (7, 1, 32, (32, 32, 96)),
+        (8, 8, 32, (4, 8, 32)), (8, 6, 32, (5, 6, 40)), (8, 64, 32, (16, 16, 96)),
+        (9, 8, 32, (6, 10, 24)), (9, 64, 32, (16, 48, 48)), (1, 5, 32, (4, 4, 32)),
     ],
 )
 def test_conv_mfma_configs(cfg, cin, cout, dims):

@@ -42,22 +42,29 @@ layers = [  # (name, cin, cout, edge)
     ("upcat_3.c0", 128, 64, 24), ("upcat_3.c1", 64, 64, 24), ("upcat_2.c0", 64, 32, 48), ("upcat_2.c1", 32, 32, 48),
     ("upcat_1.c0", 64, 32, 96), ("upcat_1.c1", 32, 32, 96),
 ]
+from monai_amd import _lib  # noqa: E402
+
+ncfg = _lib.lib().query("mh_conv3d_k3_num_configs")
 for name, cin, cout, e in layers:
     x = torch.randn(B, cin, e, e, e, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     bias = torch.zeros(cout, device=dev)
     out = torch.empty(B, cout, e, e, e, device=dev)
-    cfg = ops.conv3d_k3_select(cin, cout, e, e, e)
-    packed = ops.conv3d_k3_pack(cfg, w)
-    tiles = ops.conv3d_k3_stat_tiles(cfg, e, e, e)
-    stats = torch.empty(B * cout * max(tiles, 1) * 3, device=dev) if tiles else None
+    chosen = ops.conv3d_k3_select(cin, cout, e, e, e)
     xn = nrm(B, cin) if cin > 1 else None
-    ms = timeit(lambda: ops.conv3d_k3(cfg, x, xn, packed, bias, out, stats))
     fl = 2.0 * 27 * cin * cout * e ** 3 * B
-    res["conv"].append({"layer": name, "cfg": cfg, "cin": cin, "cout": cout, "edge": e, "ms": ms, "tflops": fl / ms / 1e9})
-    if tiles:
-        ms2 = timeit(lambda: ops.conv3d_k3(cfg, x, xn, packed, bias, out, None))
-        res["conv"][-1]["ms_no_stats"] = ms2
+    row = {"layer": name, "cin": cin, "cout": cout, "edge": e, "selected": chosen, "cfgs": {}}
+    for cfg in range(0, ncfg + 1):
+        if not _lib.lib().query("mh_conv3d_k3_accepts", cfg, cin, cout):
+            continue
+        if cfg == 0 and cin > 1:
+            continue  # the direct kernel is only interesting for the first layer
+        packed = ops.conv3d_k3_pack(cfg, w)
+        tiles = ops.conv3d_k3_stat_tiles(cfg, e, e, e)
+        stats = torch.empty(B * cout * max(tiles, 1) * 3, device=dev) if tiles else None
+        ms = timeit(lambda: ops.conv3d_k3(cfg, x, xn, packed, bias, out, stats), iters=3, warm=1)
+        row["cfgs"][cfg] = {"ms": ms, "tflops": fl / ms / 1e9}
+    res["conv"].append(row)
     del x, out
 
 e = 96
