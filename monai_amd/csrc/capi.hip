@@ -126,14 +126,23 @@ typedef ConvCfg<8, 4, 1, 2, 4, 1, 1, 8, 2> Cfg6;    // tile 8x8x4,  32 couts   (
 typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 2, 4> Cfg7;   // tile 32x4x4, 32 couts, 2-channel chunks (first layer, Cin = 1)
 typedef ConvCfg<32, 1, 1, 4, 4, 1, 1, 4, 3> Cfg8;   // cfg1 with 4-channel chunks: 3 workgroups per CU
 typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 4, 3> Cfg9;   // cfg2 with 4-channel chunks
-#define MH_NUM_CFG 9
+typedef ConvCfg<16, 2, 1, 4, 4, 1, 1, 2, 4> Cfg10;  // cfg2 with 2-channel chunks: 4 workgroups per CU
+typedef ConvCfg<8, 4, 1, 2, 2, 2, 1, 4, 3> Cfg11;   // cfg3 with 4-channel chunks
+typedef ConvCfg<8, 4, 1, 2, 2, 2, 1, 2, 4> Cfg12;   // cfg3 with 2-channel chunks
+typedef ConvCfg<4, 4, 2, 1, 1, 4, 1, 2, 4> Cfg13;   // cfg4 with 2-channel chunks
+typedef ConvCfg<8, 4, 1, 2, 4, 1, 1, 2, 4> Cfg14;   // cfg6 with 2-channel chunks
+#define MH_NUM_CFG 14
 
 struct CfgInfo { int tx, ty, tz, cn, cc; };
 #define MH_CFG_ROW(C) {C::TX, C::TY, C::TZ, C::CN, C::CC}
 static const CfgInfo kCfg[MH_NUM_CFG + 1] = {
     {0, 0, 0, 0, 0}, MH_CFG_ROW(Cfg1), MH_CFG_ROW(Cfg2), MH_CFG_ROW(Cfg3), MH_CFG_ROW(Cfg4), MH_CFG_ROW(Cfg5),
-    MH_CFG_ROW(Cfg6), MH_CFG_ROW(Cfg7), MH_CFG_ROW(Cfg8), MH_CFG_ROW(Cfg9),
+    MH_CFG_ROW(Cfg6), MH_CFG_ROW(Cfg7), MH_CFG_ROW(Cfg8), MH_CFG_ROW(Cfg9), MH_CFG_ROW(Cfg10), MH_CFG_ROW(Cfg11),
+    MH_CFG_ROW(Cfg12), MH_CFG_ROW(Cfg13), MH_CFG_ROW(Cfg14),
 };
+// measured preference among configurations of equal tile utilisation (kernel sweep on MI355X, profiles/):
+// short channel chunks + more resident workgroups beat long chunks
+static const double kPref[MH_NUM_CFG + 1] = {0, 1.00, 1.00, 1.00, 1.00, 0.90, 1.00, 1.06, 1.04, 1.03, 1.05, 1.01, 1.02, 1.01, 1.02};
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int cin_padded(int cfg, int Cin) { return cfg == 0 ? Cin : cdiv(Cin, kCfg[cfg].cc) * kCfg[cfg].cc; }
 
@@ -146,18 +155,17 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
 }
 
 // Heuristic choice: the configuration that wastes the least matrix work -- masked voxels of partial tiles and
-// zero-padded input channels both count -- preferring the wider cout tile, then the lower id.  (cfg 8/9 are
-// alternatives to 1/2 that are only picked explicitly.)
+// zero-padded input channels both count -- preferring the wider cout tile, then the measured preference.
 int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
     if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "conv3d_k3_select: bad argument");
     int best = 0;
     double best_score = 0.0;
-    for (int c = 1; c <= 7; ++c) {
+    for (int c = 1; c <= MH_NUM_CFG; ++c) {
         const CfgInfo& k = kCfg[c];
         if (!mh_conv3d_k3_accepts(c, Cin, Cout)) continue;
         const double util = (double)D * H * W / ((double)cdiv(D, k.tz) * k.tz * cdiv(H, k.ty) * k.ty * cdiv(W, k.tx) * k.tx);
         const double cpad = (double)Cin / cin_padded(c, Cin);
-        const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * (1.0 + 0.001 * (MH_NUM_CFG - c));
+        const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * kPref[c];
         if (score > best_score) { best_score = score; best = c; }
     }
     return best;
@@ -224,6 +232,11 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         case 7: launch_mfma<Cfg7>(in, packed_w, bias, out, stats, s); break;
         case 8: launch_mfma<Cfg8>(in, packed_w, bias, out, stats, s); break;
         case 9: launch_mfma<Cfg9>(in, packed_w, bias, out, stats, s); break;
+        case 10: launch_mfma<Cfg10>(in, packed_w, bias, out, stats, s); break;
+        case 11: launch_mfma<Cfg11>(in, packed_w, bias, out, stats, s); break;
+        case 12: launch_mfma<Cfg12>(in, packed_w, bias, out, stats, s); break;
+        case 13: launch_mfma<Cfg13>(in, packed_w, bias, out, stats, s); break;
+        case 14: launch_mfma<Cfg14>(in, packed_w, bias, out, stats, s); break;
     }
     return launched("conv3d_k3_mfma");
 }

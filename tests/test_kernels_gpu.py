@@ -50,6 +50,8 @@ def test_conv_direct():
         (7, 1, 32, (4, 8, 32)), (7, 3, 32, (5, 5, 33)), (7, 1, 32, (32, 32, 96)),
         (8, 8, 32, (4, 8, 32)), (8, 6, 32, (5, 6, 40)), (8, 64, 32, (16, 16, 96)),
         (9, 8, 32, (6, 10, 24)), (9, 64, 32, (16, 48, 48)), (1, 5, 32, (4, 4, 32)),
+        (10, 6, 32, (6, 10, 24)), (10, 64, 32, (16, 48, 48)), (11, 8, 64, (3, 12, 12)), (12, 6, 64, (2, 8, 8)),
+        (12, 128, 64, (24, 24, 24)), (13, 4, 128, (3, 6, 6)), (13, 256, 256, (6, 6, 6)), (14, 4, 32, (5, 9, 7)),
     ],
 )
 def test_conv_mfma_configs(cfg, cin, cout, dims):
@@ -57,7 +59,7 @@ def test_conv_mfma_configs(cfg, cin, cout, dims):
 
 
 def test_conv_mfma_separate_stats_and_select():
-    assert kc.case_conv3d(DEV, None, 1, 8, 32, (4, 8, 32), fused_stats=False) == 1
+    assert kc.case_conv3d(DEV, None, 1, 8, 32, (4, 8, 32), fused_stats=False) >= 1
 
 
 def test_conv_into_channel_slice():
