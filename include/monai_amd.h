@@ -105,6 +105,25 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, 
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
                    void* stream);
 
+/* ---- resampling (Spacingd / SpatialResample / Resample / AffineTransform / grid_pull) -------------------- */
+
+/* Output voxel (oz, oy, ox) samples the source at index  m[row*4+0..2] . (oz, oy, ox) + m[row*4+3]  (rows z, y, x;
+ * `m` is 12 HOST doubles: the voxel-space composition of to_norm_affine + F.affine_grid + F.grid_sample's
+ * unnormalisation, monai/networks/layers/spatial_transforms.py:564-591, monai/networks/utils.py:243-326).  All NC
+ * channel volumes [NC][Di][Hi][Wi] share the coordinates.  mode: 0 nearest, 1 (tri)linear; pad: 0 zeros, 1 border,
+ * 2 reflection, with ATen grid_sampler semantics (the rule acts on the coordinate; `align_corners` selects the
+ * reflection interval).  compute_f64: interpolation arithmetic in fp64 (the reference's default dtype=float64,
+ * monai/transforms/spatial/array.py:141,355) or fp32; input and output are fp32 (functional.py:183). */
+int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo,
+                           const double* m, int mode, int pad, int align_corners, int compute_f64, void* stream);
+
+/* Same sampler with an explicit coordinate field `coords` [3][Do][Ho][Wo] (planes z, y, x; source voxel indices;
+ * fp32 or fp64 DEVICE memory) -- `Resample.__call__` (array.py:2015-2117) and `grid_pull` order 0/1
+ * (monai/csrc/resample/pushpull.h:58-110). */
+int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const void* coords, int coords_f64,
+                         float* dst, int Do, int Ho, int Wo, int mode, int pad, int align_corners, int compute_f64,
+                         void* stream);
+
 #ifdef __cplusplus
 }
 #endif

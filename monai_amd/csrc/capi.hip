@@ -9,6 +9,7 @@
 #include "kernels/common.h"
 #include "kernels/conv3d_mfma.h"
 #include "kernels/nn_simple.h"
+#include "kernels/resample.h"
 #include "kernels/sliding.h"
 
 using namespace mh;
@@ -317,3 +318,45 @@ int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, con
     return launched("conv1x1");
 }
 
+
+// ------------------------------------------------------------------------------------------ resampling
+static int fill_resample(ResampleArgs& a, int NC, int Di, int Hi, int Wi, int Do, int Ho, int Wo, int mode, int pad, int align_corners) {
+    if (NC < 1 || Di < 1 || Hi < 1 || Wi < 1 || Do < 1 || Ho < 1 || Wo < 1) return fail(MH_ERR_ARG, "resample: bad shape");
+    if (mode != RS_NEAREST && mode != RS_LINEAR) return fail(MH_ERR_UNSUPPORTED, "resample: interpolation mode %d (0 nearest, 1 linear)", mode);
+    if (pad < RS_ZEROS || pad > RS_REFLECTION) return fail(MH_ERR_UNSUPPORTED, "resample: padding mode %d (0 zeros, 1 border, 2 reflection)", pad);
+    a.mode = mode; a.pad = pad; a.align_corners = align_corners ? 1 : 0; a.C = NC;
+    a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
+    for (int i = 0; i < 12; ++i) a.m[i] = 0.0;
+    return MH_OK;
+}
+
+int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo, const double* m,
+                           int mode, int pad, int align_corners, int compute_f64, void* stream) {
+    if (!src || !dst || !m) return fail(MH_ERR_ARG, "affine_resample: null pointer");
+    ResampleArgs a;
+    if (int e = fill_resample(a, NC, Di, Hi, Wi, Do, Ho, Wo, mode, pad, align_corners)) return e;
+    for (int i = 0; i < 12; ++i) a.m[i] = m[i];
+    const unsigned nb = blocks_for((long long)Do * Ho * Wo);
+    if (compute_f64) hipLaunchKernelGGL((affine_resample_kernel<double>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, a);
+    else hipLaunchKernelGGL((affine_resample_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, a);
+    return launched("affine_resample");
+}
+
+int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const void* coords, int coords_f64, float* dst, int Do,
+                         int Ho, int Wo, int mode, int pad, int align_corners, int compute_f64, void* stream) {
+    if (!src || !dst || !coords) return fail(MH_ERR_ARG, "grid_resample: null pointer");
+    ResampleArgs a;
+    if (int e = fill_resample(a, NC, Di, Hi, Wi, Do, Ho, Wo, mode, pad, align_corners)) return e;
+    const unsigned nb = blocks_for((long long)Do * Ho * Wo);
+    hipStream_t s = (hipStream_t)stream;
+    if (coords_f64) {
+        const double* g = static_cast<const double*>(coords);
+        if (compute_f64) hipLaunchKernelGGL((grid_resample_kernel<double, double>), dim3(nb), dim3(256), 0, s, src, g, dst, a);
+        else hipLaunchKernelGGL((grid_resample_kernel<float, double>), dim3(nb), dim3(256), 0, s, src, g, dst, a);
+    } else {
+        const float* g = static_cast<const float*>(coords);
+        if (compute_f64) hipLaunchKernelGGL((grid_resample_kernel<double, float>), dim3(nb), dim3(256), 0, s, src, g, dst, a);
+        else hipLaunchKernelGGL((grid_resample_kernel<float, float>), dim3(nb), dim3(256), 0, s, src, g, dst, a);
+    }
+    return launched("grid_resample");
+}

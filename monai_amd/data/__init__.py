@@ -1,1 +1,11 @@
-from .utils import compute_importance_map, dense_patch_slices, get_valid_patch_size  # noqa: F401
+from .meta_tensor import MetaTensor  # noqa: F401
+from .utils import (  # noqa: F401
+    affine_to_spacing,
+    compute_importance_map,
+    compute_shape_offset,
+    dense_patch_slices,
+    get_valid_patch_size,
+    to_affine_nd,
+    window_starts,
+    zoom_affine,
+)

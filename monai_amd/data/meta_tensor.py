@@ -1,0 +1,93 @@
+"""A small ``MetaTensor``: a ``torch.Tensor`` subclass that carries ``meta`` (with the 4x4 ``affine``) and the list of
+``applied_operations`` -- the parts of monai/data/meta_tensor.py:52-609 that the spatial transforms of this package
+read and write.  When the real MONAI is installed its own ``MetaTensor`` works just as well: the transforms only
+rely on the duck-typed surface (``.affine``, ``.meta``, ``.applied_operations``, ``.as_tensor()``,
+``type(x)(tensor, affine=..., meta=..., applied_operations=...)``)."""
+
+from __future__ import annotations
+
+import copy
+from typing import Any
+
+import torch
+
+__all__ = ["MetaTensor", "is_meta", "get_affine"]
+
+
+class MetaTensor(torch.Tensor):
+    @staticmethod
+    def __new__(cls, x, affine=None, meta=None, applied_operations=None, *args, **kwargs):
+        kw = {k: kwargs[k] for k in ("device", "dtype") if k in kwargs}
+        return torch.as_tensor(x, **kw).as_subclass(cls)
+
+    def __init__(self, x, affine=None, meta=None, applied_operations=None, *_a, **_k) -> None:
+        super().__init__()
+        if meta is not None:
+            self.meta = dict(meta)
+        elif isinstance(x, MetaTensor):
+            self.meta = copy.deepcopy(x.meta)
+        else:
+            self.meta = {}
+        if affine is not None:
+            self.meta["affine"] = torch.as_tensor(affine, dtype=torch.float64)
+        elif "affine" not in self.meta:
+            self.meta["affine"] = torch.eye(4, dtype=torch.float64)
+        if applied_operations is not None:
+            self.applied_operations = list(applied_operations)
+        elif isinstance(x, MetaTensor):
+            self.applied_operations = copy.deepcopy(x.applied_operations)
+        else:
+            self.applied_operations = []
+
+    # -- metadata surface ------------------------------------------------------------------------------
+    @property
+    def affine(self) -> torch.Tensor:
+        return self.meta.get("affine", torch.eye(4, dtype=torch.float64))
+
+    @affine.setter
+    def affine(self, value) -> None:
+        self.meta["affine"] = torch.as_tensor(value, dtype=torch.float64)
+
+    @property
+    def pixdim(self):
+        a = self.affine.double()
+        return torch.sqrt(torch.sum(a[:3, :3] * a[:3, :3], dim=0)).tolist()
+
+    def as_tensor(self) -> torch.Tensor:
+        return self.as_subclass(torch.Tensor)
+
+    def peek_pending_shape(self):
+        return tuple(self.shape[1:])
+
+    def peek_pending_affine(self):
+        return self.affine
+
+    def copy_meta_from(self, src, copy_attr: bool = True, keys=None):
+        self.meta = copy.deepcopy(getattr(src, "meta", {})) if copy_attr else dict(getattr(src, "meta", {}))
+        ops = getattr(src, "applied_operations", [])
+        self.applied_operations = copy.deepcopy(ops) if copy_attr else list(ops)
+        return self
+
+    def __repr__(self, **kw):  # pragma: no cover
+        return f"meta{self.as_tensor().__repr__()}"
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None) -> Any:
+        ret = super().__torch_function__(func, types, args, kwargs or {})
+        if isinstance(ret, MetaTensor) and not hasattr(ret, "meta"):
+            first = next((a for a in args if isinstance(a, MetaTensor) and hasattr(a, "meta")), None)
+            if first is not None:
+                ret.meta = dict(first.meta)
+                ret.applied_operations = list(first.applied_operations)
+            else:
+                ret.meta, ret.applied_operations = {"affine": torch.eye(4, dtype=torch.float64)}, []
+        return ret
+
+
+def is_meta(x) -> bool:
+    """MetaTensor of this package or of an installed MONAI (duck-typed)."""
+    return isinstance(x, torch.Tensor) and type(x) is not torch.Tensor and hasattr(x, "meta") and hasattr(x, "as_tensor")
+
+
+def get_affine(x):
+    return x.meta.get("affine") if is_meta(x) and "affine" in x.meta else None

@@ -11,11 +11,15 @@ import itertools
 import math
 from collections.abc import Sequence
 
+import numpy as np
 import torch
 
 from ..utils.misc import ensure_tuple_rep, look_up_option
 
-__all__ = ["window_starts", "dense_patch_slices", "get_valid_patch_size", "compute_importance_map"]
+__all__ = [
+    "window_starts", "dense_patch_slices", "get_valid_patch_size", "compute_importance_map",
+    "affine_to_spacing", "to_affine_nd", "zoom_affine", "compute_shape_offset",
+]
 
 
 def get_valid_patch_size(image_size: Sequence[int], patch_size) -> tuple:
@@ -78,3 +82,104 @@ def compute_importance_map(patch_size, mode="constant", sigma_scale=0.125, devic
     floor = max(torch.min(weights).item(), 1e-3)
     weights = torch.clamp_(weights.to(torch.float), min=floor).to(dtype)
     return weights.to(device)
+
+
+# --------------------------------------------------------------------------------------------------------
+# voxel <-> world affine helpers (fp64, host) -- monai/data/utils.py:737-982
+
+AFFINE_TOL = 1e-3
+
+
+def _np(a) -> np.ndarray:
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.array(a, dtype=np.float64, copy=True)
+
+
+def affine_to_spacing(affine, r: int = 3, suppress_zeros: bool = True) -> np.ndarray:
+    """Voxel spacing = column norms of the top-left r x r block (:737-761)."""
+    a = _np(affine)
+    if a.ndim != 2 or a.shape[0] != a.shape[1]:
+        raise ValueError(f"affine must be a square matrix, got {a.shape}.")
+    block = a[:r, :r]
+    spacing = np.sqrt(np.sum(block * block, axis=0))
+    if suppress_zeros:
+        spacing[spacing == 0] = 1.0
+    return spacing
+
+
+def to_affine_nd(r, affine) -> np.ndarray:
+    """An (r+1)x(r+1) affine (or one shaped like the matrix `r`) filled from `affine`'s top-left block and last
+    column (:938-982)."""
+    a = _np(affine)
+    if a.ndim != 2:
+        raise ValueError(f"affine must have 2 dimensions, got {a.ndim}.")
+    new = np.array(r, dtype=np.float64, copy=True)
+    if new.ndim == 0:
+        sr = int(new)
+        if sr < 0:
+            raise ValueError(f"r must be positive, got {sr}.")
+        new = np.eye(sr + 1, dtype=np.float64)
+    d = max(min(len(new) - 1, len(a) - 1), 1)
+    new[:d, :d] = a[:d, :d]
+    if d > 1:
+        new[:d, -1] = a[:d, -1]
+    return new
+
+
+def zoom_affine(affine, scale, diagonal: bool = True) -> np.ndarray:
+    """An affine whose column norms are `scale` (no translation): diagonal, or the original rotation times the new
+    zooms with shears removed via a Cholesky factor of RZS^T RZS (:823-872)."""
+    a = _np(affine)
+    if len(a) != len(a[0]):
+        raise ValueError(f"affine must be n x n, got {len(a)} x {len(a[0])}.")
+    sc = np.array(scale, dtype=float, copy=True).reshape(-1)
+    d = len(a) - 1
+    norm = affine_to_spacing(a, r=d)
+    if len(sc) < d:
+        sc = np.append(sc, norm[len(sc):])
+    sc = sc[:d]
+    sc = np.asarray([s if (s and s > 0) else n for s, n in zip(sc, norm)], dtype=float)
+    sc[sc == 0] = 1.0
+    if diagonal:
+        return np.diag(np.append(sc, [1.0]))
+    rzs = a[:-1, :-1]
+    zs = np.linalg.cholesky(rzs.T @ rzs).T
+    rotation = rzs @ np.linalg.inv(zs)
+    s = np.sign(np.diag(zs)) * np.abs(sc)
+    out = np.eye(len(a))
+    out[:-1, :-1] = rotation @ np.diag(s)
+    return out
+
+
+def compute_shape_offset(spatial_shape, in_affine, out_affine, scale_extent: bool = False):
+    """Output shape that keeps the input field of view under `out_affine`, and the world offset that puts it in
+    place (:875-935): map the input corners into output voxel space, round the extent, anchor at the corner that
+    is minimal in every axis (or centre-align)."""
+    shape = np.array(spatial_shape, copy=True, dtype=float)
+    sr = len(shape)
+    ia, oa = to_affine_nd(sr, in_affine), to_affine_nd(sr, out_affine)
+    spans = [(-0.5, dim - 0.5) if scale_extent else (0.0, dim - 1.0) for dim in shape]
+    corners = np.asarray(np.meshgrid(*spans, indexing="ij")).reshape((sr, -1))
+    corners = np.concatenate((corners, np.ones_like(corners[:1])))
+    try:
+        corners_out = np.linalg.solve(oa, ia) @ corners
+    except np.linalg.LinAlgError as e:
+        raise ValueError(f"Affine {oa} is not invertible") from e
+    corners = ia @ corners
+    all_dist = corners_out[:-1].copy()
+    corners_out = corners_out[:-1] / corners_out[-1]
+    ptp = np.ptp(corners_out, axis=1)
+    out_shape = np.round(ptp) if scale_extent else np.round(ptp + 1.0)
+    offset = None
+    for i in range(corners.shape[1]):
+        min_corner = np.min(all_dist - all_dist[:, i:i + 1], 1)
+        if np.allclose(min_corner, 0.0, rtol=AFFINE_TOL):
+            offset = corners[:-1, i]
+            break
+    if offset is None:
+        offset = ia[:-1, :-1] @ (shape / 2.0) + ia[:-1, -1] - oa[:-1, :-1] @ (out_shape / 2.0)
+    if scale_extent:
+        in_offset = np.append(0.5 * (shape / out_shape - 1.0), 1.0)
+        offset = np.abs((ia @ in_offset / in_offset[-1])[:-1]) * np.sign(offset)
+    return out_shape.astype(int, copy=False), offset

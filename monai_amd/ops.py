@@ -121,3 +121,38 @@ def conv1x1(x, x_nrm, weight, bias, out):
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
     _lib.lib().call("mh_conv1x1_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
     return out
+
+
+_MODES = {"nearest": 0, "bilinear": 1, "linear": 1, "trilinear": 1}
+_PADS = {"zeros": 0, "border": 1, "reflection": 2}
+
+
+def affine_resample(src: torch.Tensor, m, out_size: Sequence[int], mode: str, padding_mode: str, align_corners: bool, compute_f64: bool):
+    """src [NC, Di, Hi, Wi] fp32 -> [NC, Do, Ho, Wo] fp32, sampling at  index = m @ (oz, oy, ox, 1)  (m: 3x4, fp64, host)."""
+    _lib.require_device(src)
+    if src.dim() != 4 or not src.is_contiguous():
+        raise RuntimeError("monai_amd.affine_resample: src must be a contiguous [NC, D, H, W] tensor")
+    nc, di, hi, wi = src.shape
+    do, ho, wo = (int(v) for v in out_size)
+    out = torch.empty((nc, do, ho, wo), dtype=torch.float32, device=src.device)
+    mm = (C.c_double * 12)(*[float(v) for v in m])
+    _lib.lib().call("mh_affine_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(out), do, ho, wo, mm, _MODES[mode], _PADS[padding_mode],
+                    int(bool(align_corners)), int(bool(compute_f64)), _s(src))
+    return out
+
+
+def grid_resample(src: torch.Tensor, coords: torch.Tensor, mode: str, padding_mode: str, align_corners: bool, compute_f64: bool):
+    """src [NC, Di, Hi, Wi] fp32, coords [3, Do, Ho, Wo] (z, y, x source indices; fp32/fp64) -> [NC, Do, Ho, Wo] fp32."""
+    _lib.require_device(src)
+    if not coords.is_cuda and src.is_cuda:
+        raise RuntimeError("monai_amd.grid_resample: coords must be on the device of src")
+    if src.dim() != 4 or coords.dim() != 4 or coords.shape[0] != 3 or not src.is_contiguous() or not coords.is_contiguous():
+        raise RuntimeError("monai_amd.grid_resample: src [NC,D,H,W] and coords [3,Do,Ho,Wo] must be contiguous")
+    if coords.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("monai_amd.grid_resample: coords must be fp32 or fp64")
+    nc, di, hi, wi = src.shape
+    _, do, ho, wo = coords.shape
+    out = torch.empty((nc, do, ho, wo), dtype=torch.float32, device=src.device)
+    _lib.lib().call("mh_grid_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(coords), int(coords.dtype == torch.float64), _lib.ptr(out),
+                    do, ho, wo, _MODES[mode], _PADS[padding_mode], int(bool(align_corners)), int(bool(compute_f64)), _s(src))
+    return out

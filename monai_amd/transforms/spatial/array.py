@@ -1,0 +1,148 @@
+"""``SpatialResample`` and ``Spacing`` -- same call signatures and results as
+monai/transforms/spatial/array.py:122-253 and :338-546 (eager mode), on the HIP resampling kernel."""
+
+from __future__ import annotations
+
+import warnings
+from collections.abc import Sequence
+from itertools import zip_longest
+
+import numpy as np
+import torch
+
+from ...data.meta_tensor import MetaTensor, is_meta
+from ...data.utils import AFFINE_TOL, affine_to_spacing, compute_shape_offset, to_affine_nd, zoom_affine
+from ...utils.misc import ensure_tuple
+from .functional import spatial_resample
+
+__all__ = ["SpatialResample", "Spacing"]
+
+_NP2T = {np.float64: torch.float64, np.float32: torch.float32, float: torch.float64, "float64": torch.float64, "float32": torch.float32}
+
+
+def _torch_dtype(dtype, default):
+    if dtype is None:
+        return default
+    if isinstance(dtype, torch.dtype):
+        return dtype
+    try:
+        return _NP2T[dtype]
+    except (KeyError, TypeError):
+        return {np.dtype("float64"): torch.float64, np.dtype("float32"): torch.float32}.get(np.dtype(dtype), torch.float64)
+
+
+def _wrap(out: torch.Tensor, src, new_affine, op_record):
+    """Result as the input's MetaTensor type with the updated affine and the operation pushed on
+    ``applied_operations`` (what ``TraceableTransform.track_transform_meta`` does, inverse.py:168-297)."""
+    if not is_meta(src):
+        return out
+    res = type(src)(out, meta=dict(src.meta), applied_operations=list(getattr(src, "applied_operations", [])))
+    if new_affine is not None:
+        res.meta["affine"] = torch.as_tensor(new_affine, dtype=torch.float64)
+    if op_record is not None:
+        res.applied_operations.append(op_record)
+    return res
+
+
+class SpatialResample:
+    """Resample from the image's affine to ``dst_affine``: ``xform = solve(src_affine, dst_affine)``, then an affine
+    pull with that matrix."""
+
+    def __init__(self, mode="bilinear", padding_mode="border", align_corners: bool = False, dtype=np.float64, lazy: bool = False):
+        if lazy:
+            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
+        self.mode, self.padding_mode, self.align_corners, self.dtype, self.lazy = mode, padding_mode, align_corners, dtype, False
+
+    def __call__(self, img, dst_affine=None, spatial_size=None, mode=None, padding_mode=None, align_corners=None, dtype=None, lazy=None):
+        if lazy:
+            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
+        dtype_pt = _torch_dtype(dtype or self.dtype, img.dtype if img.dtype.is_floating_point else torch.float64)
+        align_corners = self.align_corners if align_corners is None else align_corners
+        mode = self.mode if mode is None else mode
+        padding_mode = self.padding_mode if padding_mode is None else padding_mode
+        orig_size = tuple(img.shape[1:])
+        out, xform, out_size, src_a = spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_corners, dtype_pt)
+        record = None
+        new_affine = None
+        if is_meta(img):
+            record = {
+                "class": type(self).__name__, "orig_size": orig_size,
+                "extra_info": {"dtype": str(dtype_pt)[6:], "mode": getattr(mode, "value", mode),
+                               "padding_mode": getattr(padding_mode, "value", padding_mode), "align_corners": align_corners,
+                               "src_affine": torch.as_tensor(src_a)},
+            }
+            if xform is not None:  # new affine = old affine @ xform, on the image's full (4x4) affine
+                full = np.asarray(img.meta["affine"], dtype=np.float64)
+                new_affine = full @ to_affine_nd(len(full) - 1, xform)
+        return _wrap(out, img, new_affine, record)
+
+    def inverse(self, data):
+        rec = data.applied_operations[-1]
+        info = rec["extra_info"]
+        prev = type(data)(data.as_tensor(), meta=dict(data.meta), applied_operations=list(data.applied_operations[:-1]))
+        out = SpatialResample.__call__(
+            self, prev, dst_affine=info["src_affine"], spatial_size=rec["orig_size"], mode=info["mode"], padding_mode=info["padding_mode"],
+            align_corners=bool(info["align_corners"]) if info["align_corners"] is not None else False, dtype=getattr(torch, info["dtype"]),
+        )
+        if is_meta(out):
+            out.applied_operations = list(data.applied_operations[:-1])
+        return out
+
+
+class Spacing:
+    """Resample the image to voxel size ``pixdim`` (array.py:338-546)."""
+
+    def __init__(self, pixdim, diagonal: bool = False, mode="bilinear", padding_mode="border", align_corners: bool = False, dtype=np.float64,
+                 scale_extent: bool = False, recompute_affine: bool = False, min_pixdim=None, max_pixdim=None, lazy: bool = False):
+        if lazy:
+            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
+        self.pixdim = np.array(ensure_tuple(pixdim), dtype=np.float64)
+        self.min_pixdim = np.array(ensure_tuple(min_pixdim), dtype=np.float64)
+        self.max_pixdim = np.array(ensure_tuple(max_pixdim), dtype=np.float64)
+        self.diagonal, self.scale_extent, self.recompute_affine = diagonal, scale_extent, recompute_affine
+        for mn, mx in zip(self.min_pixdim, self.max_pixdim):
+            if (not np.isnan(mn)) and (not np.isnan(mx)) and ((mx < mn) or (mn < 0)):
+                raise ValueError(f"min_pixdim {self.min_pixdim} must be positive, smaller than max {self.max_pixdim}.")
+        self.sp_resample = SpatialResample(mode=mode, padding_mode=padding_mode, align_corners=align_corners, dtype=dtype)
+
+    def __call__(self, data_array, mode=None, padding_mode=None, align_corners=None, dtype=None, scale_extent=None, output_spatial_shape=None,
+                 lazy=None):
+        if lazy:
+            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
+        original_shape = tuple(data_array.shape[1:])
+        sr = len(original_shape)
+        if sr <= 0:
+            raise ValueError(f"data_array must have at least one spatial dimension, got {original_shape}.")
+        if is_meta(data_array) and "affine" in data_array.meta:
+            input_affine = data_array.meta["affine"]
+        else:
+            warnings.warn("`data_array` is not of type MetaTensor, assuming affine to be identity.")
+            input_affine = np.eye(sr + 1, dtype=np.float64)
+        affine_ = to_affine_nd(sr, input_affine)
+        out_d = self.pixdim[:sr].copy()
+        if out_d.size < sr:
+            out_d = np.append(out_d, [out_d[-1]] * (sr - out_d.size))
+        orig_d = affine_to_spacing(affine_, sr)
+        for idx, (_d, mn, mx) in enumerate(zip_longest(orig_d, self.min_pixdim[:sr], self.max_pixdim[:sr], fillvalue=np.nan)):
+            target = out_d[idx]
+            mn = target if np.isnan(mn) else min(mn, target)
+            mx = target if np.isnan(mx) else max(mx, target)
+            if mn > mx:
+                raise ValueError(f"min_pixdim is larger than max_pixdim at dim {idx}: min {mn} max {mx} out {target}.")
+            out_d[idx] = _d if (mn - AFFINE_TOL) <= _d <= (mx + AFFINE_TOL) else target
+        ac = self.sp_resample.align_corners if align_corners is None else align_corners
+        scale_extent = self.scale_extent if scale_extent is None else scale_extent
+        if not ac and scale_extent:
+            warnings.warn("align_corners=False is not compatible with scale_extent=True.")
+        new_affine = zoom_affine(affine_, out_d, diagonal=self.diagonal)
+        output_shape, offset = compute_shape_offset(original_shape, affine_, new_affine, scale_extent)
+        new_affine[:sr, -1] = offset[:sr]
+        actual_shape = list(output_shape) if output_spatial_shape is None else output_spatial_shape
+        out = self.sp_resample(data_array, dst_affine=torch.as_tensor(new_affine), spatial_size=actual_shape, mode=mode, padding_mode=padding_mode,
+                               align_corners=align_corners, dtype=dtype)
+        if self.recompute_affine and is_meta(out):
+            raise NotImplementedError("monai_amd: recompute_affine is not implemented")
+        return out
+
+    def inverse(self, data):
+        return self.sp_resample.inverse(data)

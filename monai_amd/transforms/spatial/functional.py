@@ -1,0 +1,85 @@
+"""``spatial_resample`` on the MI355X resampling kernel -- the eager path of
+monai/transforms/spatial/functional.py:68-184."""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from ... import _lib, ops
+from ...data.meta_tensor import is_meta
+from ...data.utils import AFFINE_TOL, compute_shape_offset, to_affine_nd
+from ...networks.utils import index_matrix
+from ...utils.misc import ensure_tuple, fall_back_tuple
+
+__all__ = ["spatial_resample"]
+
+
+def _mode_name(mode) -> str:
+    m = getattr(mode, "value", mode)
+    if isinstance(m, (int, np.integer)) and not isinstance(m, bool):
+        raise NotImplementedError("monai_amd: spline-order (integer) interpolation modes use scipy in the reference and are not on the HIP path")
+    m = str(m).lower()
+    if m in ("bilinear", "trilinear", "linear"):
+        return "bilinear"
+    if m == "nearest":
+        return "nearest"
+    raise ValueError(f"Unsupported mode: {mode}, available options are ['bilinear', 'nearest'].")
+
+
+def _pad_name(padding_mode) -> str:
+    p = str(getattr(padding_mode, "value", padding_mode)).lower()
+    if p not in ("zeros", "border", "reflection"):
+        raise ValueError(f"Unsupported padding_mode: {padding_mode}, available options are ['zeros', 'border', 'reflection'].")
+    return p
+
+
+def spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_corners, dtype_pt, transform_info=None):
+    """Resample channel-first `img` from its own affine to `dst_affine` / `spatial_size`.
+
+    Same decisions as the reference: ``xform = solve(src_affine, dst_affine)`` in fp64 (:126-132); unchanged affine and
+    size -> the input comes back as float32 without resampling (:133-151); otherwise the default (non-compiled)
+    branch, ``AffineTransform(normalized=False, reverse_indexing=True)`` (:174-179).  The interpolation arithmetic
+    runs in `dtype_pt` (fp64 by default); input is read and output written as fp32 (:183).
+    Returns (tensor, xform or None, output spatial size)."""
+    src_affine = img.meta["affine"] if is_meta(img) and "affine" in img.meta else torch.eye(4, dtype=torch.float64)
+    data = img.as_tensor() if is_meta(img) else img
+    original_shape = tuple(data.shape[1:])
+    spatial_rank = min(data.dim() - 1, src_affine.shape[0] - 1, 3)
+    if (not isinstance(spatial_size, int) or spatial_size != -1) and spatial_size is not None:
+        spatial_rank = min(len(ensure_tuple(spatial_size)), 3)
+    src_a = to_affine_nd(spatial_rank, src_affine)
+    dst_a = to_affine_nd(spatial_rank, dst_affine) if dst_affine is not None else src_a
+    in_size = np.asarray(original_shape[:spatial_rank])
+    if isinstance(spatial_size, int) and spatial_size == -1:
+        out_size = in_size
+    elif spatial_size is None and spatial_rank > 1:
+        out_size, _ = compute_shape_offset(in_size, src_a, dst_a)
+    else:
+        out_size = spatial_size
+    out_size = np.asarray(fall_back_tuple(ensure_tuple(out_size)[:spatial_rank], in_size, lambda x: x >= 0), dtype=int)
+    try:
+        xform = np.eye(spatial_rank + 1) if spatial_rank < 2 else np.linalg.solve(src_a, dst_a)
+    except np.linalg.LinAlgError as e:
+        raise ValueError(f"src affine is not invertible {src_a}, {dst_a}.") from e
+    same_size = np.allclose(out_size, in_size)
+    unchanged = (np.allclose(src_a, dst_a, atol=AFFINE_TOL) and same_size) or (np.allclose(xform, np.eye(len(xform)), atol=AFFINE_TOL) and same_size)
+    if unchanged:
+        return data.to(torch.float32), None, tuple(int(v) for v in out_size), src_a
+
+    sizes = list(data.shape)
+    chns, in_sp, extra = sizes[0], sizes[1:spatial_rank + 1], sizes[spatial_rank + 1:]
+    x = data.reshape([-1] + in_sp) if extra else data
+    x = x.to(torch.float32).contiguous()
+    _lib.require_device(x)
+    if spatial_rank == 1:
+        raise NotImplementedError("monai_amd: 1-D spatial_resample is not on the HIP path")
+    m = index_matrix(xform, in_sp, [int(v) for v in out_size], normalized=False, align_corners=bool(align_corners), reverse_indexing=True)
+    pad = 3 - spatial_rank
+    vol = x.reshape((x.shape[0],) + (1,) * pad + tuple(in_sp))
+    out = ops.affine_resample(vol, m.reshape(-1), (1,) * pad + tuple(int(v) for v in out_size), _mode_name(mode), _pad_name(padding_mode),
+                              bool(align_corners), dtype_pt == torch.float64)
+    out = out.reshape((x.shape[0],) + tuple(int(v) for v in out_size))
+    if extra:
+        out = out.reshape((chns, *[int(v) for v in out_size], *extra))
+    return out, xform, tuple(int(v) for v in out_size), src_a
