@@ -117,12 +117,21 @@ int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, cons
 int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo,
                            const double* m, int mode, int pad, int align_corners, int compute_f64, void* stream);
 
-/* Same sampler with an explicit coordinate field `coords` [3][Do][Ho][Wo] (planes z, y, x; source voxel indices;
- * fp32 or fp64 DEVICE memory) -- `Resample.__call__` (array.py:2015-2117) and `grid_pull` order 0/1
- * (monai/csrc/resample/pushpull.h:58-110). */
+/* Same sampler with an explicit coordinate field `coords` [3][Do][Ho][Wo] (planes z, y, x; fp32 or fp64 DEVICE
+ * memory) -- the torch branch of `Resample.__call__` (monai/transforms/spatial/array.py:2101-2116).  The source index
+ * along axis a is  scale3[a] * coord + offset3[a]  (HOST doubles, NULL = 1 / 0): the reference's `norm_coords`
+ * scaling and grid_sample's unnormalisation folded into one affine per axis, so the grid is never rewritten. */
 int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const void* coords, int coords_f64,
-                         float* dst, int Do, int Ho, int Wo, int mode, int pad, int align_corners, int compute_f64,
-                         void* stream);
+                         const double* scale3, const double* offset3, float* dst, int Do, int Ho, int Wo, int mode,
+                         int pad, int align_corners, int compute_f64, void* stream);
+
+/* monai._C.grid_pull (monai/csrc/ext.cpp:67, monai/csrc/resample/pushpull.h:58-110), interpolation orders 0 and 1,
+ * boundary conditions replicate(0) dct1(1) dct2(2) dst1(3) dst2(4) dft(5) zero(7) per axis, `extrapolate` as in the
+ * reference (out-of-FOV samples, tolerance 5e-2, are zero when false).  src (B,C,X,Y,Z), grid (B,Xo,Yo,Zo,3) with the
+ * last axis holding voxel coordinates in tensor-axis order, out (B,C,Xo,Yo,Zo); all three fp32 or all three fp64
+ * (is_f64), dense.  bound3 / interp3 are HOST int32[3] (2-D / 1-D problems pad with size-1 axes). */
+int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B, int C, int X, int Y, int Z, int Xo,
+                 int Yo, int Zo, const int32_t* bound3, const int32_t* interp3, int extrapolate, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,8 @@ SIGNATURES = {
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_affine_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _I, _P]),
-    "mh_grid_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mh_grid_pull": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _IA, _I, _P]),
+    "mh_grid_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 
 
@@ -107,7 +108,7 @@ def lib() -> Library:
     return _LIB
 
 
-def require_device(*tensors: torch.Tensor) -> None:
+def require_device(*tensors: torch.Tensor, dtypes=(torch.float32,)) -> None:
     """Every tensor handed to a kernel must live on a ROCm device, be fp32 and be contiguous enough for
     the view it is used as.  CPU tensors are an error, never a silent fallback."""
     for t in tensors:
@@ -118,8 +119,8 @@ def require_device(*tensors: torch.Tensor) -> None:
                 "monai_amd: this path runs only on an MI355X (ROCm) device tensor; got a CPU tensor. "
                 "There is no CPU fallback in the product path."
             )
-        if t.dtype != torch.float32:
-            raise RuntimeError(f"monai_amd: fp32 tensors only on this path, got {t.dtype}")
+        if t.dtype not in dtypes:
+            raise RuntimeError(f"monai_amd: dtype {t.dtype} is not accepted on this path (expected one of {dtypes})")
 
 
 def stream_ptr(t: torch.Tensor) -> C.c_void_p:

@@ -8,6 +8,7 @@
 
 #include "kernels/common.h"
 #include "kernels/conv3d_mfma.h"
+#include "kernels/grid_pull.h"
 #include "kernels/nn_simple.h"
 #include "kernels/resample.h"
 #include "kernels/sliding.h"
@@ -327,6 +328,7 @@ static int fill_resample(ResampleArgs& a, int NC, int Di, int Hi, int Wi, int Do
     a.mode = mode; a.pad = pad; a.align_corners = align_corners ? 1 : 0; a.C = NC;
     a.Di = Di; a.Hi = Hi; a.Wi = Wi; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
     for (int i = 0; i < 12; ++i) a.m[i] = 0.0;
+    for (int i = 0; i < 3; ++i) { a.ga[i] = 1.0; a.gb[i] = 0.0; }
     return MH_OK;
 }
 
@@ -342,11 +344,16 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
     return launched("affine_resample");
 }
 
-int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const void* coords, int coords_f64, float* dst, int Do,
-                         int Ho, int Wo, int mode, int pad, int align_corners, int compute_f64, void* stream) {
+int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const void* coords, int coords_f64, const double* scale3,
+                         const double* offset3, float* dst, int Do, int Ho, int Wo, int mode, int pad, int align_corners,
+                         int compute_f64, void* stream) {
     if (!src || !dst || !coords) return fail(MH_ERR_ARG, "grid_resample: null pointer");
     ResampleArgs a;
     if (int e = fill_resample(a, NC, Di, Hi, Wi, Do, Ho, Wo, mode, pad, align_corners)) return e;
+    for (int i = 0; i < 3; ++i) {
+        if (scale3) a.ga[i] = scale3[i];
+        if (offset3) a.gb[i] = offset3[i];
+    }
     const unsigned nb = blocks_for((long long)Do * Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
     if (coords_f64) {
@@ -359,4 +366,33 @@ int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const
         else hipLaunchKernelGGL((grid_resample_kernel<float, float>), dim3(nb), dim3(256), 0, s, src, g, dst, a);
     }
     return launched("grid_resample");
+}
+
+// ------------------------------------------------------------------------------------------ grid_pull (monai._C)
+int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B, int C, int X, int Y, int Z, int Xo, int Yo,
+                 int Zo, const int32_t* bound3, const int32_t* interp3, int extrapolate, void* stream) {
+    if (!src || !grid || !out || !bound3 || !interp3) return fail(MH_ERR_ARG, "grid_pull: null pointer");
+    if (B < 1 || C < 1 || X < 1 || Y < 1 || Z < 1 || Xo < 1 || Yo < 1 || Zo < 1) return fail(MH_ERR_ARG, "grid_pull: bad shape");
+    GridPullArgs a;
+    a.B = B; a.C = C; a.X = X; a.Y = Y; a.Z = Z; a.Xo = Xo; a.Yo = Yo; a.Zo = Zo; a.extrapolate = extrapolate ? 1 : 0;
+    for (int d = 0; d < 3; ++d) {
+        a.bound[d] = bound3[d]; a.interp[d] = interp3[d];
+        if (interp3[d] < 0 || interp3[d] > 1)
+            return fail(MH_ERR_UNSUPPORTED, "grid_pull: interpolation order %d is not built (orders 0 and 1 are)", interp3[d]);
+        if (bound3[d] < 0 || bound3[d] > 7 || bound3[d] == GB_SLIDING)
+            return fail(MH_ERR_UNSUPPORTED, "grid_pull: bound type %d is not built", bound3[d]);
+    }
+    // mixed per-axis orders take the reference's generic B-spline path, whose results this kernel does not reproduce
+    const int o0 = interp3[0];
+    for (int d = 1; d < 3; ++d)
+        if ((d == 1 ? Y : Z) > 1 && interp3[d] != o0 && (Xo * Yo * Zo > 0))
+            return fail(MH_ERR_UNSUPPORTED, "grid_pull: per-axis interpolation orders must be equal (got %d,%d,%d)", interp3[0], interp3[1], interp3[2]);
+    const unsigned nb = blocks_for((long long)B * Xo * Yo * Zo);
+    if (is_f64)
+        hipLaunchKernelGGL((grid_pull_kernel<double>), dim3(nb), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(src),
+                           static_cast<const double*>(grid), static_cast<double*>(out), a);
+    else
+        hipLaunchKernelGGL((grid_pull_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(src),
+                           static_cast<const float*>(grid), static_cast<float*>(out), a);
+    return launched("grid_pull");
 }

@@ -18,6 +18,7 @@ enum { RS_ZEROS = 0, RS_BORDER = 1, RS_REFLECTION = 2 };
 struct ResampleArgs {
     double m[12];        // source index (z, y, x) = m[row*4 + 0..2] . (oz, oy, ox) + m[row*4 + 3]
     int mode, pad, align_corners;
+    double ga[3], gb[3]; // dense-grid variant: source index = ga[axis] * coord + gb[axis]
     int C;               // channels sharing the coordinates (N*C of the tensor)
     int Di, Hi, Wi, Do, Ho, Wo;
 };
@@ -100,7 +101,8 @@ __global__ void __launch_bounds__(256) affine_resample_kernel(const float* __res
     rs_sample<T>(src, dst, a, cz, cy, cx, oidx);
 }
 
-// Dense grid: coords [3][Do][Ho][Wo] (planes z, y, x) of source voxel indices, fp32 or fp64 (GT).
+// Dense grid: coords [3][Do][Ho][Wo] (planes z, y, x), fp32 or fp64 (GT); a per-axis affine (ga, gb) turns the stored
+// coordinate convention (centred voxel units or [-1, 1]) into source voxel indices without rewriting the grid.
 template <typename T, typename GT>
 __global__ void __launch_bounds__(256)
 grid_resample_kernel(const float* __restrict__ src, const GT* __restrict__ coords, float* __restrict__ dst, ResampleArgs a) {
@@ -108,7 +110,8 @@ grid_resample_kernel(const float* __restrict__ src, const GT* __restrict__ coord
     const long long ovol = (long long)a.Do * a.Ho * a.Wo;
     const long long oidx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (oidx >= ovol) return;
-    rs_sample<T>(src, dst, a, (double)coords[oidx], (double)coords[ovol + oidx], (double)coords[2 * ovol + oidx], oidx);
+    rs_sample<T>(src, dst, a, a.ga[0] * (double)coords[oidx] + a.gb[0], a.ga[1] * (double)coords[ovol + oidx] + a.gb[1],
+                 a.ga[2] * (double)coords[2 * ovol + oidx] + a.gb[2], oidx);
 }
 
 }  // namespace mh

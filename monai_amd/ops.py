@@ -141,18 +141,19 @@ def affine_resample(src: torch.Tensor, m, out_size: Sequence[int], mode: str, pa
     return out
 
 
-def grid_resample(src: torch.Tensor, coords: torch.Tensor, mode: str, padding_mode: str, align_corners: bool, compute_f64: bool):
-    """src [NC, Di, Hi, Wi] fp32, coords [3, Do, Ho, Wo] (z, y, x source indices; fp32/fp64) -> [NC, Do, Ho, Wo] fp32."""
+def grid_resample(src: torch.Tensor, coords: torch.Tensor, mode: str, padding_mode: str, align_corners: bool, compute_f64: bool,
+                  scale=(1.0, 1.0, 1.0), offset=(0.0, 0.0, 0.0)):
+    """src [NC, Di, Hi, Wi] fp32, coords [3, Do, Ho, Wo] (z, y, x planes; fp32/fp64) -> [NC, Do, Ho, Wo] fp32; the source
+    index along axis a is scale[a] * coords[a] + offset[a]."""
     _lib.require_device(src)
-    if not coords.is_cuda and src.is_cuda:
-        raise RuntimeError("monai_amd.grid_resample: coords must be on the device of src")
+    _lib.require_device(coords, dtypes=(torch.float32, torch.float64))
     if src.dim() != 4 or coords.dim() != 4 or coords.shape[0] != 3 or not src.is_contiguous() or not coords.is_contiguous():
         raise RuntimeError("monai_amd.grid_resample: src [NC,D,H,W] and coords [3,Do,Ho,Wo] must be contiguous")
-    if coords.dtype not in (torch.float32, torch.float64):
-        raise RuntimeError("monai_amd.grid_resample: coords must be fp32 or fp64")
     nc, di, hi, wi = src.shape
     _, do, ho, wo = coords.shape
     out = torch.empty((nc, do, ho, wo), dtype=torch.float32, device=src.device)
-    _lib.lib().call("mh_grid_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(coords), int(coords.dtype == torch.float64), _lib.ptr(out),
-                    do, ho, wo, _MODES[mode], _PADS[padding_mode], int(bool(align_corners)), int(bool(compute_f64)), _s(src))
+    sc = (C.c_double * 3)(*[float(v) for v in scale])
+    of = (C.c_double * 3)(*[float(v) for v in offset])
+    _lib.lib().call("mh_grid_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(coords), int(coords.dtype == torch.float64), sc, of,
+                    _lib.ptr(out), do, ho, wo, _MODES[mode], _PADS[padding_mode], int(bool(align_corners)), int(bool(compute_f64)), _s(src))
     return out

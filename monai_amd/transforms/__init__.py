@@ -1,1 +1,1 @@
-from .spatial import SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401
+from .spatial import Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401

@@ -40,3 +40,35 @@ def test_spacingd_two_keys_and_inverse(emu):
 
 def test_affine_transform_flags(emu):
     tc.case_affine_transform("cpu")
+
+
+def test_grid_pull_vs_reference_build(emu):
+    print("worst grid_pull error", tc.case_grid_pull_vs_reference_build("cpu"))
+
+
+def test_grid_pull_reference_golden_rows(emu):
+    tc.case_grid_pull_reference_golden_rows("cpu")
+
+
+def test_resample_dense_grid(emu):
+    tc.case_resample_dense_grid("cpu")
+
+
+def test_grid_pull_live_against_oracle_ref(emu):
+    """When oracle/_ref (the reference's own C++ resampler, built by oracle/build_ref.py) is present, compare live."""
+    import pytest
+
+    from monai_amd import _C
+    from oracle import build_ref
+
+    ref = build_ref.load()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py in the build container)")
+    torch.manual_seed(9)
+    inp = torch.randn(1, 2, 6, 7, 8)
+    grid = (torch.rand(1, 5, 4, 6, 3) * 2.4 - 0.7) * torch.tensor([6.0, 7.0, 8.0])
+    for b in (0, 1, 2, 3, 4, 5, 7):
+        for interp in (0, 1):
+            exp = ref.grid_pull(inp, grid, [ref.BoundType(b)], [ref.InterpolationType(interp)], True)
+            got = _C.grid_pull(inp, grid, [_C.BoundType(b)], [_C.InterpolationType(interp)], True)
+            assert (got - exp).abs().max().item() < 2e-5, (b, interp)

@@ -1,0 +1,74 @@
+"""-m gpu: resampling transforms (Spacing/Spacingd/SpatialResample/AffineTransform/Resample/grid_pull) on the MI355X
+against the real reference's outputs (tests/golden), the reference's compiled C++ resampler (oracle/_ref, when the
+prebuilt .so travelled with the snapshot) and the CPU oracle at a larger size."""
+import numpy as np
+import pytest
+import torch
+
+import transform_cases as tc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def test_spacing_reference_tables():
+    tc.case_spacing_reference_tables(DEV)
+
+
+def test_spacing_3d_all_modes():
+    print("worst bilinear error", tc.case_spacing_3d(DEV))
+
+
+def test_spacingd_two_keys_and_inverse():
+    tc.case_spacingd(DEV)
+
+
+def test_affine_transform_flags():
+    tc.case_affine_transform(DEV)
+
+
+def test_grid_pull_vs_reference_build():
+    print("worst grid_pull error", tc.case_grid_pull_vs_reference_build(DEV))
+
+
+def test_grid_pull_reference_golden_rows():
+    tc.case_grid_pull_reference_golden_rows(DEV)
+
+
+def test_resample_dense_grid():
+    tc.case_resample_dense_grid(DEV)
+
+
+def test_grid_pull_live_against_oracle_ref():
+    from monai_amd import _C
+    from oracle import build_ref
+
+    ref = build_ref.load()
+    if ref is None:
+        pytest.skip("oracle/_ref not present in this snapshot")
+    torch.manual_seed(9)
+    inp = torch.randn(2, 3, 24, 28, 20)
+    grid = (torch.rand(2, 18, 22, 26, 3) * 2.4 - 0.7) * torch.tensor([24.0, 28.0, 20.0])
+    for b in (0, 1, 2, 3, 4, 5, 7):
+        for interp in (0, 1):
+            exp = ref.grid_pull(inp, grid, [ref.BoundType(b)], [ref.InterpolationType(interp)], True)
+            got = _C.grid_pull(inp.to(DEV), grid.to(DEV), [_C.BoundType(b)], [_C.InterpolationType(interp)], True)
+            assert (got.cpu() - exp).abs().max().item() < 5e-5, (b, interp)
+
+
+def test_spacing_config4_shape_vs_oracle():
+    """BASELINE.json configs[4] geometry at 1/4 size: affine diag(0.8, 0.8, 1.6) -> pixdim 1: (128^3 -> 103x103x205), fp64
+    and fp32 interpolation against the CPU oracle (torch affine_grid + grid_sample)."""
+    from monai_amd.data import MetaTensor
+    from monai_amd.transforms import Spacing
+    from oracle import resample as orz
+
+    torch.manual_seed(0)
+    x = torch.rand(1, 128, 128, 128)
+    aff = np.diag([0.8, 0.8, 1.6, 1.0])
+    for dt, tol in ((np.float64, tc.TOL_F64), (np.float32, tc.TOL_F32)):
+        y = Spacing(pixdim=(1.0, 1.0, 1.0), mode="bilinear", padding_mode="border", dtype=dt)(MetaTensor(x.to(DEV), affine=aff))
+        assert tuple(y.shape) == (1, 103, 103, 205)
+        xform = np.linalg.solve(aff, np.asarray(y.affine))
+        ref = orz.spatial_resample_eager(x, xform, (103, 103, 205), "bilinear", "border", False, torch.float64 if dt is np.float64 else torch.float32)
+        assert (y.cpu() - ref).abs().max().item() < tol
