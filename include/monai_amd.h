@@ -133,6 +133,15 @@ int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const
 int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B, int C, int X, int Y, int Z, int Xo,
                  int Yo, int Zo, const int32_t* bound3, const int32_t* interp3, int extrapolate, void* stream);
 
+/* ---- Gaussian smoothing (GaussianSmooth / GaussianFilter / separable_filtering) ----------------------------- */
+
+/* dst = src convolved with kz (x) ky (x) kx, zero padding, per channel volume [NC][D][H][W]
+ * (monai/networks/layers/simplelayers.py:170-249; kernels from gaussian_1d, layers/convutils.py:78-131).  The three
+ * 1-D kernels are HOST float arrays with odd tap counts (at most 33 each; a single tap 1.0 skips an axis, 2-D
+ * images are passed with D = 1 and kz = {1}).  One fused pass: every voxel is read once and written once. */
+int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H, int W, const float* kz, int kz_n,
+                              const float* ky, int ky_n, const float* kx, int kx_n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@
 
 #include "kernels/common.h"
 #include "kernels/conv3d_mfma.h"
+#include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/nn_simple.h"
 #include "kernels/resample.h"
@@ -395,4 +396,27 @@ int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B
         hipLaunchKernelGGL((grid_pull_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(src),
                            static_cast<const float*>(grid), static_cast<float*>(out), a);
     return launched("grid_pull");
+}
+
+// ------------------------------------------------------------------------------------------ Gaussian smoothing
+int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H, int W, const float* kz, int kz_n, const float* ky,
+                              int ky_n, const float* kx, int kx_n, void* stream) {
+    if (!src || !dst || !kz || !ky || !kx || NC < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "separable_filter3d: bad argument");
+    const int n[3] = {kz_n, ky_n, kx_n};
+    for (int i = 0; i < 3; ++i) {
+        if (n[i] < 1 || n[i] % 2 == 0) return fail(MH_ERR_ARG, "separable_filter3d: tap counts must be odd and positive");
+        if (n[i] > GS_MAX_TAPS) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: %d taps on one axis (at most %d)", n[i], GS_MAX_TAPS);
+    }
+    if (src == dst) return fail(MH_ERR_ARG, "separable_filter3d: in-place operation is not supported");
+    GaussArgs a;
+    a.NC = NC; a.D = D; a.H = H; a.W = W; a.kz_n = kz_n; a.ky_n = ky_n; a.kx_n = kx_n;
+    memset(a.kz, 0, sizeof(a.kz)); memset(a.ky, 0, sizeof(a.ky)); memset(a.kx, 0, sizeof(a.kx));
+    memcpy(a.kz, kz, sizeof(float) * kz_n); memcpy(a.ky, ky, sizeof(float) * ky_n); memcpy(a.kx, kx, sizeof(float) * kx_n);
+    const dim3 grid((unsigned)(cdiv(W, GS_TX) * cdiv(H, GS_TY)), (unsigned)NC);
+    hipStream_t s = (hipStream_t)stream;
+    if (kz_n == 1) hipLaunchKernelGGL((gauss3d_stream_kernel<1>), grid, dim3(256), 0, s, src, dst, a);
+    else if (kz_n <= 9) hipLaunchKernelGGL((gauss3d_stream_kernel<9>), grid, dim3(256), 0, s, src, dst, a);
+    else if (kz_n <= 17) hipLaunchKernelGGL((gauss3d_stream_kernel<17>), grid, dim3(256), 0, s, src, dst, a);
+    else hipLaunchKernelGGL((gauss3d_stream_kernel<33>), grid, dim3(256), 0, s, src, dst, a);
+    return launched("separable_filter3d");
 }

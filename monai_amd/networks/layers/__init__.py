@@ -1,1 +1,2 @@
+from .simplelayers import GaussianFilter, gaussian_1d, separable_filtering  # noqa: F401
 from .spatial_transforms import AffineTransform  # noqa: F401

@@ -157,3 +157,16 @@ def grid_resample(src: torch.Tensor, coords: torch.Tensor, mode: str, padding_mo
     _lib.lib().call("mh_grid_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(coords), int(coords.dtype == torch.float64), sc, of,
                     _lib.ptr(out), do, ho, wo, _MODES[mode], _PADS[padding_mode], int(bool(align_corners)), int(bool(compute_f64)), _s(src))
     return out
+
+
+def separable_filter3d(src: torch.Tensor, kernels) -> torch.Tensor:
+    """src [NC, D, H, W] fp32; kernels = (kz, ky, kx) 1-D float sequences with odd lengths; zero padding."""
+    _lib.require_device(src)
+    if src.dim() != 4 or not src.is_contiguous():
+        raise RuntimeError("monai_amd.separable_filter3d: src must be a contiguous [NC, D, H, W] tensor")
+    out = torch.empty_like(src)
+    arrs = [(C.c_float * len(k))(*[float(v) for v in k]) for k in kernels]
+    nc, d, h, w = src.shape
+    _lib.lib().call("mh_separable_filter3d_f32", _lib.ptr(src), _lib.ptr(out), nc, d, h, w, arrs[0], len(kernels[0]), arrs[1], len(kernels[1]),
+                    arrs[2], len(kernels[2]), _s(src))
+    return out

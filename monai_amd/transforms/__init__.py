@@ -1,1 +1,2 @@
+from .intensity import GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd  # noqa: F401
 from .spatial import Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401

@@ -1,0 +1,28 @@
+"""``GaussianSmoothd`` -- monai/transforms/intensity/dictionary.py:1184-1216."""
+
+from __future__ import annotations
+
+from ...utils.misc import ensure_tuple
+from .array import GaussianSmooth
+
+__all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict"]
+
+
+class GaussianSmoothd:
+    def __init__(self, keys, sigma=1.0, approx: str = "erf", allow_missing_keys: bool = False) -> None:
+        self.keys = ensure_tuple(keys)
+        self.allow_missing_keys = allow_missing_keys
+        self.converter = GaussianSmooth(sigma, approx=approx)
+
+    def __call__(self, data):
+        d = dict(data)
+        for key in self.keys:
+            if key not in d:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(f"Key `{key}` of transform `{type(self).__name__}` was missing in the data and allow_missing_keys==False.")
+            d[key] = self.converter(d[key])
+        return d
+
+
+GaussianSmoothD = GaussianSmoothDict = GaussianSmoothd

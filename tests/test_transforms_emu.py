@@ -72,3 +72,11 @@ def test_grid_pull_live_against_oracle_ref(emu):
             exp = ref.grid_pull(inp, grid, [ref.BoundType(b)], [ref.InterpolationType(interp)], True)
             got = _C.grid_pull(inp, grid, [_C.BoundType(b)], [_C.InterpolationType(interp)], True)
             assert (got - exp).abs().max().item() < 2e-5, (b, interp)
+
+
+def test_gaussian_1d_tables():
+    tc.case_gaussian_1d_tables()
+
+
+def test_gaussian_smooth(emu):
+    tc.case_gaussian_smooth("cpu")

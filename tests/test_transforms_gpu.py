@@ -72,3 +72,29 @@ def test_spacing_config4_shape_vs_oracle():
         xform = np.linalg.solve(aff, np.asarray(y.affine))
         ref = orz.spatial_resample_eager(x, xform, (103, 103, 205), "bilinear", "border", False, torch.float64 if dt is np.float64 else torch.float32)
         assert (y.cpu() - ref).abs().max().item() < tol
+
+
+def test_gaussian_smooth():
+    tc.case_gaussian_smooth(DEV)
+
+
+def test_gaussian_smooth_128_vs_torch():
+    """sigma = 1 (9 taps) on 2 x 128^3 against the reference operator sequence on the CPU (F.pad + depthwise F.conv3d)."""
+    import torch.nn.functional as F
+
+    from monai_amd.networks.layers import gaussian_1d
+    from monai_amd.transforms import GaussianSmooth
+
+    torch.manual_seed(3)
+    x = torch.rand(2, 128, 128, 128)
+    y = GaussianSmooth(sigma=1.0)(x.to(DEV)).cpu()
+    k = gaussian_1d(1.0)
+    ref = x[None]
+    for ax in range(3):
+        shape = [1, 1, 1]
+        shape[ax] = -1
+        w = k.reshape(shape)[None, None].repeat(2, 1, 1, 1, 1)
+        pad = [0, 0, 0, 0, 0, 0]
+        pad[2 * (2 - ax)] = pad[2 * (2 - ax) + 1] = 4
+        ref = F.conv3d(F.pad(ref, pad), w, groups=2)
+    assert (y - ref[0]).abs().max().item() < 1e-5

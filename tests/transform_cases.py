@@ -252,3 +252,45 @@ def case_resample_dense_grid(device):
             assert (got == exp).mean() > 0.99, (k, (got == exp).mean())
         else:
             assert np.abs(got - exp).max() < 5e-6, (k, np.abs(got - exp).max())
+
+
+# ------------------------------------------------------------------------------------------ Gaussian smoothing
+def case_gaussian_1d_tables():
+    """Host taps vs the reference's gaussian_1d (convutils.py:78-131): erf / sampled bit-exact, scalespace to 1e-6."""
+    from monai_amd.networks.layers import gaussian_1d
+
+    g = np.load(os.path.join(GOLDEN, "gaussian.npz"))
+    for i in range(int(g["g1d_n"])):
+        sigma, trunc = (float(v) for v in g[f"g1d_{i}_cfg"])
+        approx = str(g[f"g1d_{i}_approx"])
+        k = gaussian_1d(torch.tensor(sigma), truncated=trunc, approx=approx).numpy()
+        exp = g[f"g1d_{i}_k"]
+        assert k.shape == exp.shape, (i, k.shape, exp.shape)
+        if approx == "scalespace":
+            np.testing.assert_allclose(k, exp, rtol=2e-6, atol=1e-9)
+        else:
+            assert np.array_equal(k, exp), (i, approx)
+    # tests/networks/layers/test_gaussian.py: gaussian_1d(0.5, 8) is the 9-tap erf table, gaussian_1d(1, 1) three taps
+    k = gaussian_1d(0.5, 8.0).numpy()
+    assert k.shape == (9,) and abs(k[4] - 0.6826895) < 1e-6 and abs(k[3] - 0.1573054) < 1e-6
+
+
+def case_gaussian_smooth(device):
+    """GaussianSmooth known-answer tables of tests/transforms/test_gaussian_smooth.py:24-92 (2x3x3, sigma 1.5 / 0.5 /
+    [1.5, 0.5]) and seeded 3-D volumes for erf / sampled / scalespace; expected = the reference's outputs."""
+    from monai_amd.networks.layers import GaussianFilter
+    from monai_amd.transforms import GaussianSmooth
+
+    g = np.load(os.path.join(GOLDEN, "gaussian.npz"))
+    for i in range(int(g["gs_n"])):
+        sigma = g[f"gs_{i}_sigma"]
+        sigma = float(sigma) if sigma.ndim == 0 else [float(s) for s in sigma]
+        y = GaussianSmooth(sigma=sigma, approx=str(g[f"gs_{i}_approx"]))(torch.from_numpy(g[f"gs_{i}_in"]).to(device))
+        np.testing.assert_allclose(y.cpu().numpy(), g[f"gs_{i}_out"], atol=1e-5, rtol=1e-5, err_msg=f"gaussian smooth case {i}")
+    # first table literally (test_gaussian_smooth.py:24-46), atol of the reference test
+    x = np.array([[[1, 1, 1], [2, 2, 2], [3, 3, 3]], [[4, 4, 4], [5, 5, 5], [6, 6, 6]]], dtype=np.float32)
+    exp = np.array([[[0.59167546, 0.69312394, 0.59167546], [0.7956997, 0.93213004, 0.7956997], [0.7668002, 0.8982755, 0.7668002]],
+                    [[1.6105323, 1.8866735, 1.6105323], [1.9892492, 2.3303251, 1.9892492], [1.7856569, 2.091825, 1.7856569]]])
+    np.testing.assert_allclose(GaussianSmooth(sigma=1.5)(torch.from_numpy(x).to(device)).cpu().numpy(), exp, atol=1e-4)
+    y = GaussianFilter(3, [1.0, 2.0, 0.7])(torch.from_numpy(g["gf_in"]).to(device))
+    np.testing.assert_allclose(y.cpu().numpy(), g["gf_out"], atol=1e-5, rtol=1e-5)
