@@ -57,7 +57,7 @@ def test_grid_pull_live_against_oracle_ref():
 
 
 def test_spacing_config4_shape_vs_oracle():
-    """BASELINE.json configs[4] geometry at 1/4 size: affine diag(0.8, 0.8, 1.6) -> pixdim 1: (128^3 -> 103x103x205), fp64
+    """BASELINE.json configs[4] geometry at 1/4 size: affine diag(0.8, 0.8, 1.6) -> pixdim 1: (128^3 -> 103x103x204), fp64
     and fp32 interpolation against the CPU oracle (torch affine_grid + grid_sample)."""
     from monai_amd.data import MetaTensor
     from monai_amd.transforms import Spacing
@@ -68,9 +68,9 @@ def test_spacing_config4_shape_vs_oracle():
     aff = np.diag([0.8, 0.8, 1.6, 1.0])
     for dt, tol in ((np.float64, tc.TOL_F64), (np.float32, tc.TOL_F32)):
         y = Spacing(pixdim=(1.0, 1.0, 1.0), mode="bilinear", padding_mode="border", dtype=dt)(MetaTensor(x.to(DEV), affine=aff))
-        assert tuple(y.shape) == (1, 103, 103, 205)
+        assert tuple(y.shape) == (1, 103, 103, 204)  # round(127 * s) + 1 per axis
         xform = np.linalg.solve(aff, np.asarray(y.affine))
-        ref = orz.spatial_resample_eager(x, xform, (103, 103, 205), "bilinear", "border", False, torch.float64 if dt is np.float64 else torch.float32)
+        ref = orz.spatial_resample_eager(x, xform, (103, 103, 204), "bilinear", "border", False, torch.float64 if dt is np.float64 else torch.float32)
         assert (y.cpu() - ref).abs().max().item() < tol
 
 
