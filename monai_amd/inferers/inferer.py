@@ -13,7 +13,7 @@ from ..data.utils import compute_importance_map
 from ..utils.misc import ensure_tuple, look_up_option
 from .utils import sliding_window_inference
 
-__all__ = ["Inferer", "SlidingWindowInferer"]
+__all__ = ["Inferer", "SlidingWindowInferer", "SlidingWindowInfererAdapt", "SliceInferer"]
 
 
 class Inferer(ABC):
@@ -108,3 +108,63 @@ class SlidingWindowInferer(Inferer):
             *args,
             **kwargs,
         )
+
+
+class SlidingWindowInfererAdapt(SlidingWindowInferer):
+    """``SlidingWindowInferer`` that survives an HBM out-of-memory error (reference: inferer.py:555-641).
+
+    The reference degrades GPU stitching -> buffered stitching -> CPU stitching.  Here stitching never holds a
+    partial volume, so the ladder has two rungs: (1) everything in HBM; (2) on ``OutOfMemoryError`` retry with the
+    stitched volume handed back on the CPU (``device="cpu"``), remembering the image size in ``cpu_thresh`` so the next
+    image of that size goes there directly -- the same externally visible behaviour (the output may land on the CPU)."""
+
+    def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
+        if self.device is not None:
+            return super().__call__(inputs, network, *args, **kwargs)
+        cpu_cond = self.cpu_thresh is not None and inputs.shape[2:].numel() > self.cpu_thresh
+        gpu_stitching = inputs.is_cuda and not cpu_cond
+        for _ in range(2):
+            try:
+                return super().__call__(inputs, network, *args, device=inputs.device if gpu_stitching else torch.device("cpu"), **kwargs)
+            except RuntimeError as e:
+                if not gpu_stitching or "OutOfMemoryError" not in type(e).__name__:
+                    raise
+                warnings.warn(f"GPU stitching failed, attempting on CPU, image dim {tuple(inputs.shape)}.")
+                gpu_stitching = False
+                self.cpu_thresh = inputs.shape[2:].numel() - 1
+                torch.cuda.empty_cache()
+        raise RuntimeError(f"SlidingWindowInfererAdapt could not finish: cpu_cond={cpu_cond} gpu_stitching={gpu_stitching}")
+
+
+class SliceInferer(SlidingWindowInferer):
+    """Slice-by-slice (2-D network) inference over a 3-D volume (reference: inferer.py:691-771): a 2-D ``roi_size`` gets a
+    singleton inserted at ``spatial_dim`` and the network sees the windows with that axis squeezed."""
+
+    def __init__(self, spatial_dim: int = 0, *args: Any, **kwargs: Any) -> None:
+        self.spatial_dim = spatial_dim
+        super().__init__(*args, **kwargs)
+        self.orig_roi_size = ensure_tuple(self.roi_size)
+
+    def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
+        if self.spatial_dim > 2:
+            raise ValueError("`spatial_dim` can only be `0, 1, 2` with `[H, W, D]` respectively.")
+        self.roi_size = ensure_tuple(self.roi_size)
+        if len(self.orig_roi_size) == 2 and len(inputs.shape[2:]) == 3:
+            self.roi_size = list(self.orig_roi_size)
+            self.roi_size.insert(self.spatial_dim, 1)
+        else:
+            raise RuntimeError(
+                f"Currently, only 2D `roi_size` ({self.orig_roi_size}) with 3D `inputs` tensor (shape={inputs.shape}) is supported."
+            )
+        return super().__call__(inputs=inputs, network=lambda x: self.network_wrapper(network, x, *args, **kwargs))
+
+    def network_wrapper(self, network: Callable, x: torch.Tensor, *args: Any, **kwargs: Any):
+        from collections.abc import Mapping
+
+        x = x.squeeze(dim=self.spatial_dim + 2)
+        out = network(x, *args, **kwargs)
+        if isinstance(out, torch.Tensor):
+            return out.unsqueeze(dim=self.spatial_dim + 2)
+        if isinstance(out, Mapping):
+            return {k: v.unsqueeze(dim=self.spatial_dim + 2) for k, v in out.items()}
+        return tuple(o.unsqueeze(dim=self.spatial_dim + 2) for o in out)
