@@ -113,9 +113,13 @@ int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, cons
  * channel volumes [NC][Di][Hi][Wi] share the coordinates.  mode: 0 nearest, 1 (tri)linear; pad: 0 zeros, 1 border,
  * 2 reflection, with ATen grid_sampler semantics (the rule acts on the coordinate; `align_corners` selects the
  * reflection interval).  compute_f64: interpolation arithmetic in fp64 (the reference's default dtype=float64,
- * monai/transforms/spatial/array.py:141,355) or fp32; input and output are fp32 (functional.py:183). */
+ * monai/transforms/spatial/array.py:141,355) or fp32; input and output are fp32 (functional.py:183).
+ * `workspace` (DEVICE, mh_affine_resample_workspace_bytes(Do,Ho,Wo) bytes, may be NULL) enables the separable fast
+ * path for axis-aligned matrices: per-axis tap tables are built on the device, then every voxel is 8 loads + 7 blends. */
+int64_t mh_affine_resample_workspace_bytes(int Do, int Ho, int Wo);
 int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo,
-                           const double* m, int mode, int pad, int align_corners, int compute_f64, void* stream);
+                           const double* m, int mode, int pad, int align_corners, int compute_f64, void* workspace,
+                           void* stream);
 
 /* Same sampler with an explicit coordinate field `coords` [3][Do][Ho][Wo] (planes z, y, x; fp32 or fp64 DEVICE
  * memory) -- the torch branch of `Resample.__call__` (monai/transforms/spatial/array.py:2101-2116).  The source index

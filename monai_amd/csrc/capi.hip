@@ -333,15 +333,41 @@ static int fill_resample(ResampleArgs& a, int NC, int Di, int Hi, int Wi, int Do
     return MH_OK;
 }
 
+static bool fits_i32(long long n) { return n < 2147483647LL; }
+
+int64_t mh_affine_resample_workspace_bytes(int Do, int Ho, int Wo) { return (int64_t)(Do + Ho + Wo) * (int64_t)sizeof(AxisTap<double>); }
+
 int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, float* dst, int Do, int Ho, int Wo, const double* m,
-                           int mode, int pad, int align_corners, int compute_f64, void* stream) {
+                           int mode, int pad, int align_corners, int compute_f64, void* workspace, void* stream) {
     if (!src || !dst || !m) return fail(MH_ERR_ARG, "affine_resample: null pointer");
     ResampleArgs a;
     if (int e = fill_resample(a, NC, Di, Hi, Wi, Do, Ho, Wo, mode, pad, align_corners)) return e;
     for (int i = 0; i < 12; ++i) a.m[i] = m[i];
-    const unsigned nb = blocks_for((long long)Do * Ho * Wo);
-    if (compute_f64) hipLaunchKernelGGL((affine_resample_kernel<double>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, a);
-    else hipLaunchKernelGGL((affine_resample_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, a);
+    hipStream_t s = (hipStream_t)stream;
+    const long long ovol = (long long)Do * Ho * Wo;
+    const unsigned nb = blocks_for(ovol);
+    const bool i32 = fits_i32((long long)NC * ovol) && fits_i32((long long)NC * Di * Hi * Wi);
+    const bool axis_aligned = m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0;
+    if (axis_aligned && workspace && i32) {
+        const unsigned tb = blocks_for(Do + Ho + Wo);
+        if (compute_f64) {
+            AxisTap<double>* tab = static_cast<AxisTap<double>*>(workspace);
+            hipLaunchKernelGGL((resample_axis_table_kernel<double>), dim3(tb), dim3(256), 0, s, tab, a);
+            hipLaunchKernelGGL((separable_resample_kernel<double, int>), dim3(nb), dim3(256), 0, s, src, dst, (const AxisTap<double>*)tab, a);
+        } else {
+            AxisTap<float>* tab = static_cast<AxisTap<float>*>(workspace);
+            hipLaunchKernelGGL((resample_axis_table_kernel<float>), dim3(tb), dim3(256), 0, s, tab, a);
+            hipLaunchKernelGGL((separable_resample_kernel<float, int>), dim3(nb), dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a);
+        }
+        return launched("separable_resample");
+    }
+    if (compute_f64) {
+        if (i32) hipLaunchKernelGGL((affine_resample_kernel<double, int>), dim3(nb), dim3(256), 0, s, src, dst, a);
+        else hipLaunchKernelGGL((affine_resample_kernel<double, long long>), dim3(nb), dim3(256), 0, s, src, dst, a);
+    } else {
+        if (i32) hipLaunchKernelGGL((affine_resample_kernel<float, int>), dim3(nb), dim3(256), 0, s, src, dst, a);
+        else hipLaunchKernelGGL((affine_resample_kernel<float, long long>), dim3(nb), dim3(256), 0, s, src, dst, a);
+    }
     return launched("affine_resample");
 }
 
@@ -408,15 +434,23 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
         if (n[i] > GS_MAX_TAPS) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: %d taps on one axis (at most %d)", n[i], GS_MAX_TAPS);
     }
     if (src == dst) return fail(MH_ERR_ARG, "separable_filter3d: in-place operation is not supported");
+    const int kmax = n[0] > n[1] ? (n[0] > n[2] ? n[0] : n[2]) : (n[1] > n[2] ? n[1] : n[2]);
+    const int rk = kmax <= 3 ? 3 : kmax <= 5 ? 5 : kmax <= 9 ? 9 : kmax <= 17 ? 17 : 33;
     GaussArgs a;
-    a.NC = NC; a.D = D; a.H = H; a.W = W; a.kz_n = kz_n; a.ky_n = ky_n; a.kx_n = kx_n;
+    a.NC = NC; a.D = D; a.H = H; a.W = W;
     memset(a.kz, 0, sizeof(a.kz)); memset(a.ky, 0, sizeof(a.ky)); memset(a.kx, 0, sizeof(a.kx));
-    memcpy(a.kz, kz, sizeof(float) * kz_n); memcpy(a.ky, ky, sizeof(float) * ky_n); memcpy(a.kx, kx, sizeof(float) * kx_n);
+    // centre every kernel inside the RK taps the kernel template unrolls (zero taps on both sides)
+    memcpy(a.kz + (rk - kz_n) / 2, kz, sizeof(float) * kz_n);
+    memcpy(a.ky + (rk - ky_n) / 2, ky, sizeof(float) * ky_n);
+    memcpy(a.kx + (rk - kx_n) / 2, kx, sizeof(float) * kx_n);
     const dim3 grid((unsigned)(cdiv(W, GS_TX) * cdiv(H, GS_TY)), (unsigned)NC);
     hipStream_t s = (hipStream_t)stream;
-    if (kz_n == 1) hipLaunchKernelGGL((gauss3d_stream_kernel<1>), grid, dim3(256), 0, s, src, dst, a);
-    else if (kz_n <= 9) hipLaunchKernelGGL((gauss3d_stream_kernel<9>), grid, dim3(256), 0, s, src, dst, a);
-    else if (kz_n <= 17) hipLaunchKernelGGL((gauss3d_stream_kernel<17>), grid, dim3(256), 0, s, src, dst, a);
-    else hipLaunchKernelGGL((gauss3d_stream_kernel<33>), grid, dim3(256), 0, s, src, dst, a);
+    switch (rk) {
+        case 3: hipLaunchKernelGGL((gauss3d_stream_kernel<3>), grid, dim3(256), 0, s, src, dst, a); break;
+        case 5: hipLaunchKernelGGL((gauss3d_stream_kernel<5>), grid, dim3(256), 0, s, src, dst, a); break;
+        case 9: hipLaunchKernelGGL((gauss3d_stream_kernel<9>), grid, dim3(256), 0, s, src, dst, a); break;
+        case 17: hipLaunchKernelGGL((gauss3d_stream_kernel<17>), grid, dim3(256), 0, s, src, dst, a); break;
+        default: hipLaunchKernelGGL((gauss3d_stream_kernel<33>), grid, dim3(256), 0, s, src, dst, a); break;
+    }
     return launched("separable_filter3d");
 }

@@ -136,8 +136,9 @@ def affine_resample(src: torch.Tensor, m, out_size: Sequence[int], mode: str, pa
     do, ho, wo = (int(v) for v in out_size)
     out = torch.empty((nc, do, ho, wo), dtype=torch.float32, device=src.device)
     mm = (C.c_double * 12)(*[float(v) for v in m])
+    ws = torch.empty(_lib.lib().query("mh_affine_resample_workspace_bytes", do, ho, wo), dtype=torch.uint8, device=src.device)
     _lib.lib().call("mh_affine_resample_f32", _lib.ptr(src), nc, di, hi, wi, _lib.ptr(out), do, ho, wo, mm, _MODES[mode], _PADS[padding_mode],
-                    int(bool(align_corners)), int(bool(compute_f64)), _s(src))
+                    int(bool(align_corners)), int(bool(compute_f64)), _lib.ptr(ws), _s(src))
     return out
 
 

@@ -1,0 +1,37 @@
+"""Launch the HBM-bound kernels a few times each (blend at the full 512^3 configuration, separable/general affine
+resample and fused Gaussian on one 512^3 volume) so a `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE` pass can attribute
+HBM traffic per kernel."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monai_amd import ops  # noqa: E402
+from monai_amd.data.utils import compute_importance_map, window_starts  # noqa: E402
+
+dev = torch.device("cuda")
+starts = window_starts((512,) * 3, (96,) * 3, (48,) * 3)
+logits = torch.randn(1000, 5, 96, 96, 96, device=dev)
+imp = compute_importance_map((96,) * 3, "gaussian", 0.125).to(dev)
+out = torch.empty(5, 512, 512, 512, device=dev)
+for _ in range(3):
+    ops.sw_blend(logits, imp, out, starts, (96,) * 3)
+del logits, out
+vol = torch.rand(1, 512, 512, 512, device=dev)
+m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
+for f64 in (True, False):
+    for _ in range(3):
+        ops.affine_resample(vol, m.reshape(-1), (410, 410, 819), "bilinear", "border", False, f64)
+mr = m.copy()
+mr[0, 1] = 1e-9  # not axis aligned -> general kernel
+for f64 in (True, False):
+    for _ in range(3):
+        ops.affine_resample(vol, mr.reshape(-1), (410, 410, 819), "bilinear", "border", False, f64)
+from monai_amd.networks.layers import gaussian_1d  # noqa: E402
+
+k = gaussian_1d(1.0).numpy()
+for _ in range(3):
+    ops.separable_filter3d(vol, [k, k, k])
+torch.cuda.synchronize()

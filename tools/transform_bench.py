@@ -47,4 +47,22 @@ plain = [v.as_tensor() for v in vols]
 ms = timeit(lambda: [gs(v) for v in plain])
 nbytes = 4.0 * N * 2 * E ** 3
 res["runs"].append({"op": "GaussianSmooth sigma=1 (9 taps/axis, fused 3-axis pass)", "ms": ms, "GBps": nbytes / ms / 1e6, "bytes": nbytes})
+# kernel-only timings (no host-side affine algebra / MetaTensor bookkeeping)
+from monai_amd import ops  # noqa: E402
+from monai_amd.networks.layers import gaussian_1d  # noqa: E402
+
+raw = vols[0].as_tensor()
+m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
+osz = tuple(int(v) for v in out.shape[1:])
+for f64 in (True, False):
+    for tag, mm in (("separable", m), ("general", m + np.array([[0, 1e-9, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]]))):
+        ms = timeit(lambda: ops.affine_resample(raw, mm.reshape(-1), osz, "bilinear", "border", False, f64))
+        nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
+        res["runs"].append({"op": f"kernel affine_resample {tag} {'fp64' if f64 else 'fp32'} (1 volume)", "ms": ms, "GBps": nb / ms / 1e6, "bytes": nb})
+k = gaussian_1d(1.0).numpy()
+ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
+res["runs"].append({"op": "kernel separable_filter3d 9 taps (1 volume)", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6, "bytes": 8.0 * raw.numel()})
+k2 = gaussian_1d(2.0).numpy()
+ms = timeit(lambda: ops.separable_filter3d(raw, [k2, k2, k2]))
+res["runs"].append({"op": "kernel separable_filter3d 17 taps (1 volume)", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6, "bytes": 8.0 * raw.numel()})
 print(json.dumps(res, indent=1))
