@@ -33,34 +33,47 @@ PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (≈6.3 TB/s achievable)
 
 
 def cpu_baseline(size: int, roi: int, windows: int):
-    """The CPU oracle on `windows` windows of the same workload; value = size^3 / (1000 windows * mean window time)."""
+    """The CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
+    tests/test_oracle_golden.py) on a bounded sample of windows; value = size^3 / (num_windows * mean window time).
+
+    `torch.set_num_threads(os.cpu_count())` (BASELINE.md's plan) oversubscribes oneDNN on a 256-thread host, so a few
+    thread counts are probed with one window each and the fastest is used for the timed sample; `cores` reports it."""
     import oracle
+    from oracle.sliding_window import dense_patch_starts, get_scan_interval
 
     torch.manual_seed(1)
     sd = oracle.make_basic_unet_state(1, 5)
     torch.manual_seed(0)
     x = torch.rand(4, 1, roi, roi, roi)
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    best, best_t = cands[0], float("inf")
     with torch.no_grad():
-        oracle.basic_unet_forward(sd, x[:1])  # warm-up
+        for c in cands:
+            torch.set_num_threads(c)
+            oracle.basic_unet_forward(sd, x[:1])
+            t0 = time.perf_counter()
+            oracle.basic_unet_forward(sd, x[:1])
+            dt = time.perf_counter() - t0
+            if dt < best_t:
+                best, best_t = c, dt
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
         done = 0
         while done < windows:
             oracle.basic_unet_forward(sd, x)  # sw_batch_size = 4, as in the workload
             done += 4
         dt = time.perf_counter() - t0
-    from oracle.sliding_window import dense_patch_starts, get_scan_interval
-
     starts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
     nwin = len(starts[0]) * len(starts[1]) * len(starts[2])
     per_win = dt / done
     return {
         "value": size ** 3 / (nwin * per_win),
         "unit": "voxels/s",
-        "cores": torch.get_num_threads(),
+        "cores": best,
         "kind": "port",
-        "sample": f"{done} of {nwin} windows ({roi}^3, sw_batch 4) through the CPU oracle's BasicUNet: {per_win:.3f} s/window; "
-                  f"value = {size}^3 voxels / ({nwin} windows x that), blend time (1-2 % on CPU) not included",
+        "sample": f"{done} of {nwin} windows ({roi}^3, sw_batch 4) through the CPU oracle's BasicUNet on {best} of {ncpu} host threads "
+                  f"(fastest of {cands}): {per_win:.3f} s/window; value = {size}^3 voxels / ({nwin} windows x that); the blend (1-2 % on CPU) is not included",
     }
 
 
@@ -71,7 +84,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
-    ap.add_argument("--cpu-windows", type=int, default=16, help="windows timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=12, help="windows timed for cpu_baseline (0 = skip)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():

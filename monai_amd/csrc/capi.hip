@@ -348,16 +348,17 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
     const unsigned nb = blocks_for(ovol);
     const bool i32 = fits_i32((long long)NC * ovol) && fits_i32((long long)NC * Di * Hi * Wi);
     const bool axis_aligned = m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0;
-    if (axis_aligned && workspace && i32) {
+    if (axis_aligned && workspace) {
         const unsigned tb = blocks_for(Do + Ho + Wo);
+        const unsigned nblk = (unsigned)(cdiv(Wo, RS_TOX) * cdiv(Ho, RS_TOY) * cdiv(Do, RS_TOZ));
         if (compute_f64) {
             AxisTap<double>* tab = static_cast<AxisTap<double>*>(workspace);
             hipLaunchKernelGGL((resample_axis_table_kernel<double>), dim3(tb), dim3(256), 0, s, tab, a);
-            hipLaunchKernelGGL((separable_resample_kernel<double, int>), dim3(nb), dim3(256), 0, s, src, dst, (const AxisTap<double>*)tab, a);
+            hipLaunchKernelGGL((separable_resample_lds_kernel<double>), dim3(nblk), dim3(256), 0, s, src, dst, (const AxisTap<double>*)tab, a);
         } else {
             AxisTap<float>* tab = static_cast<AxisTap<float>*>(workspace);
             hipLaunchKernelGGL((resample_axis_table_kernel<float>), dim3(tb), dim3(256), 0, s, tab, a);
-            hipLaunchKernelGGL((separable_resample_kernel<float, int>), dim3(nb), dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a);
+            hipLaunchKernelGGL((separable_resample_lds_kernel<float>), dim3(nblk), dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a);
         }
         return launched("separable_resample");
     }

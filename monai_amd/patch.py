@@ -1,0 +1,100 @@
+"""Install the MI355X implementations into an installed MONAI, so existing bundles / scripts pick them up unchanged.
+
+    import monai_amd.patch; monai_amd.patch.install()
+
+Bundle configs name components by short name (``"_target_": "SlidingWindowInferer"``); MONAI's ``ComponentLocator``
+(monai/bundle/config_item.py:60-112) resolves those by scanning ``sys.modules`` for modules whose name starts with
+``monai`` and indexing the classes whose ``__module__`` equals that module.  ``install()`` therefore rebinds the
+reference's names IN PLACE -- e.g. ``monai.inferers.inferer.SlidingWindowInferer = monai_amd...SlidingWindowInferer``
+with ``__module__ = "monai.inferers.inferer"`` -- and re-exports them from the parent packages.  When MONAI was
+installed without its compiled extension (``monai._C`` missing), ``monai_amd._C`` is registered under that name.
+Without MONAI installed this module is not needed: use ``"_target_": "monai_amd.inferers.SlidingWindowInferer"``.
+"""
+
+from __future__ import annotations
+
+import importlib
+import sys
+
+_TARGETS = {
+    # reference module                         : {name: (our module, our name)}
+    "monai.inferers.inferer": {
+        "SlidingWindowInferer": ("monai_amd.inferers.inferer", "SlidingWindowInferer"),
+        "SlidingWindowInfererAdapt": ("monai_amd.inferers.inferer", "SlidingWindowInfererAdapt"),
+        "SliceInferer": ("monai_amd.inferers.inferer", "SliceInferer"),
+    },
+    "monai.inferers.utils": {"sliding_window_inference": ("monai_amd.inferers.utils", "sliding_window_inference")},
+    "monai.networks.nets.basic_unet": {
+        "BasicUNet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
+        "BasicUnet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
+        "Basicunet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
+        "basicunet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
+    },
+    "monai.transforms.spatial.array": {
+        "Spacing": ("monai_amd.transforms.spatial.array", "Spacing"),
+        "SpatialResample": ("monai_amd.transforms.spatial.array", "SpatialResample"),
+        "Resample": ("monai_amd.transforms.spatial.array", "Resample"),
+    },
+    "monai.transforms.spatial.dictionary": {
+        "Spacingd": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
+        "SpacingD": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
+        "SpacingDict": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
+    },
+    "monai.transforms.intensity.array": {"GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth")},
+    "monai.transforms.intensity.dictionary": {
+        "GaussianSmoothd": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
+        "GaussianSmoothD": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
+        "GaussianSmoothDict": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
+    },
+    "monai.networks.layers.spatial_transforms": {"AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform")},
+    "monai.networks.layers.simplelayers": {"GaussianFilter": ("monai_amd.networks.layers.simplelayers", "GaussianFilter")},
+}
+# parent packages that re-export the names above
+_REEXPORT = ["monai.inferers", "monai.networks.nets", "monai.transforms", "monai.networks.layers"]
+
+_installed: dict = {}
+
+
+def install(native_module: bool = True) -> list:
+    """Rebind the reference's names to the MI355X implementations.  Returns the list of rebound ``module.name``s."""
+    import monai  # noqa: F401  (ImportError if MONAI is not installed: nothing to patch)
+
+    done = []
+    for ref_mod_name, names in _TARGETS.items():
+        ref_mod = importlib.import_module(ref_mod_name)
+        for name, (our_mod_name, our_name) in names.items():
+            obj = getattr(importlib.import_module(our_mod_name), our_name)
+            if (ref_mod_name, name) not in _installed:
+                _installed[(ref_mod_name, name)] = getattr(ref_mod, name, None)
+            try:
+                obj.__module__ = ref_mod_name      # what ComponentLocator compares against
+            except (AttributeError, TypeError):
+                pass
+            setattr(ref_mod, name, obj)
+            for parent in _REEXPORT:
+                pm = sys.modules.get(parent)
+                if pm is not None and ref_mod_name.startswith(parent) and hasattr(pm, name):
+                    if (parent, name) not in _installed:
+                        _installed[(parent, name)] = getattr(pm, name)
+                    setattr(pm, name, obj)
+            done.append(f"{ref_mod_name}.{name}")
+    if native_module and "monai._C" not in sys.modules:
+        try:
+            importlib.import_module("monai._C")
+        except Exception:
+            from . import _C
+
+            sys.modules["monai._C"] = _C
+            done.append("monai._C")
+    return done
+
+
+def uninstall() -> None:
+    """Restore the reference's own objects."""
+    for (mod_name, name), obj in list(_installed.items()):
+        mod = sys.modules.get(mod_name)
+        if mod is not None and obj is not None:
+            setattr(mod, name, obj)
+    _installed.clear()
+    if sys.modules.get("monai._C") is not None and sys.modules["monai._C"].__name__ == "monai_amd._C":
+        del sys.modules["monai._C"]

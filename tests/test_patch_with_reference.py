@@ -1,0 +1,74 @@
+"""Drop-in check against the real MONAI (only where /root/reference exists, i.e. the build container): after
+``monai_amd.patch.install()`` the reference's own bundle machinery resolves ``"_target_": "SlidingWindowInferer"`` /
+``"BasicUNet"`` / ``"Spacingd"`` to the MI355X classes, reference checkpoints load into our BasicUNet, and uninstall
+restores everything."""
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "monai")), reason="reference MONAI not available here")
+
+
+@pytest.fixture()
+def monai_ref():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import monai
+
+    yield monai
+    import monai_amd.patch as patch
+
+    patch.uninstall()
+    sys.path.remove(REF)
+
+
+def test_bundle_targets_resolve_to_amd_classes(monai_ref):
+    import monai_amd.patch as patch
+    from monai.bundle import ConfigParser
+    from monai_amd.inferers.inferer import SlidingWindowInferer as Ours
+
+    ref_cls = monai_ref.inferers.SlidingWindowInferer
+    done = patch.install()
+    assert "monai.inferers.inferer.SlidingWindowInferer" in done and "monai._C" in done
+    assert monai_ref.inferers.SlidingWindowInferer is Ours and monai_ref.inferers.inferer.SlidingWindowInferer is Ours
+    cfg = {
+        "inferer": {"_target_": "SlidingWindowInferer", "roi_size": [96, 96, 96], "sw_batch_size": 4, "overlap": 0.5, "mode": "gaussian"},
+        "network": {"_target_": "BasicUNet", "spatial_dims": 3, "in_channels": 1, "out_channels": 5},
+        "pre": {"_target_": "Spacingd", "keys": ["image"], "pixdim": [1.0, 1.0, 1.0], "mode": "bilinear"},
+        "smooth": {"_target_": "GaussianSmoothd", "keys": ["image"], "sigma": 1.0},
+    }
+    parser = ConfigParser(cfg)
+    assert type(parser.get_parsed_content("inferer")).__module__ == "monai.inferers.inferer"
+    assert isinstance(parser.get_parsed_content("inferer"), Ours)
+    from monai_amd.networks.nets.basic_unet import BasicUNet as OurNet
+    from monai_amd.transforms.intensity.dictionary import GaussianSmoothd as OurSmooth
+    from monai_amd.transforms.spatial.dictionary import Spacingd as OurSpacingd
+
+    assert isinstance(parser.get_parsed_content("network"), OurNet)
+    assert isinstance(parser.get_parsed_content("pre"), OurSpacingd)
+    assert isinstance(parser.get_parsed_content("smooth"), OurSmooth)
+    import monai._C as native
+
+    assert native.BoundType.__members__["reflect"] == 2 and hasattr(native, "grid_pull")
+    patch.uninstall()
+    assert monai_ref.inferers.SlidingWindowInferer is ref_cls
+
+
+def test_reference_checkpoint_loads_into_amd_basic_unet(monai_ref):
+    from monai.networks.nets import BasicUNet as RefNet
+
+    from monai_amd.networks.nets.basic_unet import BasicUNet as OurNet
+
+    torch.manual_seed(3)
+    ref = RefNet(spatial_dims=3, in_channels=1, out_channels=5)
+    ours = OurNet(spatial_dims=3, in_channels=1, out_channels=5)
+    missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected
+    assert list(ours.state_dict().keys()) == list(ref.state_dict().keys())
+    torch.manual_seed(3)
+    ours2 = OurNet(spatial_dims=3, in_channels=1, out_channels=5)   # same seed -> same initial weights as the reference
+    for (k, a), (_, b) in zip(ref.state_dict().items(), ours2.state_dict().items()):
+        assert torch.equal(a, b), k

@@ -80,3 +80,7 @@ def test_gaussian_1d_tables():
 
 def test_gaussian_smooth(emu):
     tc.case_gaussian_smooth("cpu")
+
+
+def test_separable_fast_path_equals_general(emu):
+    tc.case_separable_vs_general("cpu")

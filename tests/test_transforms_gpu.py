@@ -98,3 +98,7 @@ def test_gaussian_smooth_128_vs_torch():
         pad[2 * (2 - ax)] = pad[2 * (2 - ax) + 1] = 4
         ref = F.conv3d(F.pad(ref, pad), w, groups=2)
     assert (y - ref[0]).abs().max().item() < 1e-5
+
+
+def test_separable_fast_path_equals_general():
+    tc.case_separable_vs_general(DEV)
