@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
     ap.add_argument("--cpu-windows", type=int, default=12, help="windows timed for cpu_baseline (0 = skip)")
+    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr"],
+                    help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -101,7 +103,7 @@ def main():
 
     from monai_amd import _prof, parallel
     from monai_amd.inferers import SlidingWindowInferer
-    from monai_amd.networks.nets import BasicUNet
+    from monai_amd.networks.nets import UNETR, BasicUNet
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -110,7 +112,10 @@ def main():
 
     # weights / volume exactly as SURVEY.md 8(d) config 1 (fallback volume: seeded uniform noise)
     torch.manual_seed(1)
-    net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
+    if args.net == "unetr":
+        net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
+    else:
+        net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
     torch.manual_seed(0)
     vol = torch.rand(1, 1, args.size, args.size, args.size).to(dev)
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
@@ -173,16 +178,20 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"BasicUNet 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
+                "workload": f"{'UNETR ViT-B/16' if args.net == 'unetr' else 'BasicUNet'} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
                             f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 25 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
             "roofline": roof,
             "roofline_hbm": roof_hbm,
+            "attention": ({"kernel": "attention_kernel<7> (fp32 MFMA, S=216, 12 heads x 64)", "ms_per_step": spans["attention"]["ms_total"] / args.steps,
+                           "tflops": spans["attention"]["work"] / (spans["attention"]["ms_total"] * 1e-3) / 1e12,
+                           "frac_of_fp32_mfma_peak": spans["attention"]["work"] / (spans["attention"]["ms_total"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
+                          if "attention" in spans else None),
             "conv_ms_per_step": conv_all,
             "checksum": float(out.double().sum().item()),
         }
-        if world == 1 and args.cpu_windows > 0:
+        if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
             line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows)
         else:
             line["cpu_baseline"] = None

@@ -105,6 +105,17 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, 
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
                    void* stream);
 
+/* ---- UNETR pieces (monai/networks/nets/unetr.py, blocks/selfattention.py, blocks/dynunet_block.py) ------------ */
+
+/* out = lrelu_slope(act(a) + act(b)): the residual join of UnetResBlock (dynunet_block.py:96-111); a, b carry their
+ * deferred InstanceNorm records (b->nrm NULL = identity shortcut). */
+int mh_add_act_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const mh_tensor5* out, void* stream);
+
+/* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*64] (the qkv Linear's output,
+ * feature index = which*heads*64 + head*64 + d) -> out [B][S][heads*64] = softmax(Q K^T * scale) V per head, on
+ * v_mfma_f32_32x32x2_f32 with K/V of a head resident in LDS.  head_dim 64, S <= 224 (ViT-B/16 on 96^3: S = 216). */
+int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream);
+
 /* ---- resampling (Spacingd / SpatialResample / Resample / AffineTransform / grid_pull) -------------------- */
 
 /* Output voxel (oz, oy, ox) samples the source at index  m[row*4+0..2] . (oz, oy, ox) + m[row*4+3]  (rows z, y, x;

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "kernels/common.h"
+#include "kernels/attention.h"
 #include "kernels/conv3d_mfma.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
@@ -148,13 +149,14 @@ static const CfgInfo kCfg[MH_NUM_CFG + 1] = {
 static const double kPref[MH_NUM_CFG + 1] = {0, 1.00, 1.00, 1.00, 1.00, 0.90, 1.00, 1.06, 1.04, 1.03, 1.05, 1.01, 1.02, 1.01, 1.02};
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int cin_padded(int cfg, int Cin) { return cfg == 0 ? Cin : cdiv(Cin, kCfg[cfg].cc) * kCfg[cfg].cc; }
+static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv(Cout, kCfg[cfg].cn) * kCfg[cfg].cn; }
 
 int mh_conv3d_k3_num_configs(void) { return MH_NUM_CFG; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
-    return Cout % kCfg[cfg].cn == 0 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
+    return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
 
 // Heuristic choice: the configuration that wastes the least matrix work -- masked voxels of partial tiles and
@@ -167,7 +169,7 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
         const CfgInfo& k = kCfg[c];
         if (!mh_conv3d_k3_accepts(c, Cin, Cout)) continue;
         const double util = (double)D * H * W / ((double)cdiv(D, k.tz) * k.tz * cdiv(H, k.ty) * k.ty * cdiv(W, k.tx) * k.tx);
-        const double cpad = (double)Cin / cin_padded(c, Cin);
+        const double cpad = ((double)Cin / cin_padded(c, Cin)) * ((double)Cout / cout_padded(c, Cout));
         const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * kPref[c];
         if (score > best_score) { best_score = score; best = c; }
     }
@@ -176,16 +178,15 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
-    return (int64_t)cin_padded(cfg, Cin) * Cout * 27;
+    return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
 
 int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream) {
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
-    if (Cout % cn) return fail(MH_ERR_ARG, "conv3d_k3_pack: Cout %d not a multiple of %d", Cout, cn);
-    const int cinp = cin_padded(cfg, Cin);
-    hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for((long long)cinp * Cout * 27)), dim3(256), 0, (hipStream_t)stream, w,
-                       Cin, cinp, Cout, cn, packed);
+    const int cinp = cin_padded(cfg, Cin), coutp = cout_padded(cfg, Cout);
+    hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for((long long)cinp * coutp * 27)), dim3(256), 0, (hipStream_t)stream, w,
+                       Cin, cinp, Cout, coutp, cn, packed);
     return launched("conv3d_k3_pack");
 }
 
@@ -198,7 +199,7 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
 template <class Cfg>
 static void launch_mfma(const Tensor& in, const float* wp, const float* bias, const Tensor& out, float* stats, hipStream_t s) {
     const int tx = cdiv(out.W, Cfg::TX), ty = cdiv(out.H, Cfg::TY), tz = cdiv(out.D, Cfg::TZ);
-    const dim3 grid((unsigned)(tx * ty * tz), (unsigned)(out.C / Cfg::CN), (unsigned)out.N);
+    const dim3 grid((unsigned)(tx * ty * tz), (unsigned)cdiv(out.C, Cfg::CN), (unsigned)out.N);
     if (stats)
         hipLaunchKernelGGL((conv3d_k3_mfma_kernel<Cfg, true>), grid, dim3(256), 0, s, in, wp, bias, out, stats, tx, ty, tz);
     else
@@ -454,4 +455,34 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
         default: hipLaunchKernelGGL((gauss3d_stream_kernel<33>), grid, dim3(256), 0, s, src, dst, a); break;
     }
     return launched("separable_filter3d");
+}
+
+// ------------------------------------------------------------------------------------------ UNETR pieces
+int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(a_) || !dense_ok(b_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "add_act: bad tensor");
+    const Tensor a = from_c(*a_), b = from_c(*b_), out = from_c(*out_);
+    if (a.N != b.N || a.C != b.C || a.D != b.D || a.H != b.H || a.W != b.W || a.N != out.N || a.C != out.C || a.D != out.D ||
+        a.H != out.H || a.W != out.W)
+        return fail(MH_ERR_ARG, "add_act: shape mismatch");
+    const long long DHW = (long long)a.D * a.H * a.W;
+    const bool v4 = DHW % 4 == 0 && aligned(a.data, 16) && aligned(b.data, 16) && aligned(out.data, 16) && a.n_stride % 4 == 0 &&
+                    b.n_stride % 4 == 0 && out.n_stride % 4 == 0;
+    const dim3 grid(blocks_for(v4 ? DHW / 4 : DHW), (unsigned)a.C, (unsigned)a.N);
+    if (v4) hipLaunchKernelGGL((add_act_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
+    else hipLaunchKernelGGL((add_act_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
+    return launched("add_act");
+}
+
+int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream) {
+    if (!qkv || !out || B < 1 || S < 1 || heads < 1) return fail(MH_ERR_ARG, "attention: bad argument");
+    if (head_dim != 64) return fail(MH_ERR_UNSUPPORTED, "attention: head_dim %d is not built (64 is)", head_dim);
+    if (S > 224) return fail(MH_ERR_UNSUPPORTED, "attention: sequence length %d exceeds the LDS-resident limit of 224", S);
+    const dim3 grid((unsigned)heads, (unsigned)B);
+    hipStream_t s = (hipStream_t)stream;
+    const int kt = cdiv(S, 32);
+    if (kt <= 1) hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
+    else if (kt <= 2) hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
+    else if (kt <= 4) hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
+    else hipLaunchKernelGGL((attention_kernel<7>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
+    return launched("attention");
 }

@@ -207,7 +207,8 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     for (int q = 0; q < NT; ++q) {
         const int col = (wn * NT + q) * 32 + li;   // cout within the workgroup's CN
         const int co = ct * CN + col;
-        const float bco = bias ? bias[co] : 0.0f;
+        const bool cvalid = co < Cout;             // Cout is zero-padded up to a multiple of CN in the packed weights
+        const float bco = (bias && cvalid) ? bias[co] : 0.0f;
         float cnt = 0.0f, sum = 0.0f;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -221,7 +222,7 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
                     const int row = j + 8 * g4 + 4 * kh;     // (r&3) + 8*(r>>2) + 4*(lane>>5)
                     const int jx = row % MX, jy = (row / MX) % MY, jz = row / (MX * MY);
                     const int z = tz0 + wm * MZ + jz, y = ty0 + m * MY + jy, x = tx0 + jx;
-                    ok[j] = z < D && y < H && x < W;
+                    ok[j] = cvalid && z < D && y < H && x < W;
                     v[j] = acc[m][q][r] + bco;
                     acc[m][q][r] = v[j];
                     if (ok[j]) { cnt += 1.0f; sum += v[j]; }
@@ -254,7 +255,7 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int jx = row % MX, jy = (row / MX) % MY, jz = row / (MX * MY);
-                    const bool ok = (tz0 + wm * MZ + jz) < D && (ty0 + m * MY + jy) < H && (tx0 + jx) < W;
+                    const bool ok = cvalid && (tz0 + wm * MZ + jz) < D && (ty0 + m * MY + jy) < H && (tx0 + jx) < W;
                     const float d = acc[m][q][r] - s.mean;
                     if (ok) s.m2 += d * d;
                 }
@@ -271,7 +272,7 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     }
     if (STATS) {
         __syncthreads();
-        if (tid < CN) {
+        if (tid < CN && ct * CN + tid < Cout) {
             Stat s;
             s.n = smem[tid * 3]; s.mean = smem[tid * 3 + 1]; s.m2 = smem[tid * 3 + 2];
 #pragma unroll
@@ -286,11 +287,11 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     }
 }
 
-// Repack torch conv weights [Cout][Cin][27] into [Cout/CN][CinP][27][CN] (the per-chunk LDS slab becomes one
-// contiguous run); CinP >= Cin pads the input channels with zero rows.  CN = Cout is the direct kernel's layout.
+// Repack torch conv weights [Cout][Cin][27] into [CoutP/CN][CinP][27][CN] (the per-chunk LDS slab becomes one
+// contiguous run); CinP >= Cin and CoutP >= Cout pad with zeros.  CN = Cout is the direct kernel's layout.
 __global__ void __launch_bounds__(256)
-conv3d_k3_pack_kernel(const float* __restrict__ w, int Cin, int CinP, int Cout, int CN, float* __restrict__ packed) {
-    const long long total = (long long)Cout * CinP * 27;
+conv3d_k3_pack_kernel(const float* __restrict__ w, int Cin, int CinP, int Cout, int CoutP, int CN, float* __restrict__ packed) {
+    const long long total = (long long)CoutP * CinP * 27;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int col = (int)(idx % CN);
@@ -299,7 +300,7 @@ conv3d_k3_pack_kernel(const float* __restrict__ w, int Cin, int CinP, int Cout, 
     const int ci = (int)(t % CinP);
     const int ct = (int)(t / CinP);
     const int co = ct * CN + col;
-    packed[idx] = ci < Cin ? w[((long long)co * Cin + ci) * 27 + tap] : 0.0f;
+    packed[idx] = (ci < Cin && co < Cout) ? w[((long long)co * Cin + ci) * 27 + tap] : 0.0f;
 }
 
 }  // namespace mh

@@ -179,6 +179,37 @@ conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Residual join of UnetResBlock (monai/networks/blocks/dynunet_block.py:96-111): out = lrelu(norm2(conv2) + residual),
+// both operands given as raw tensors + their deferred {alpha, beta, slope} records; one read of each, one write.
+template <int VEC>
+__global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float slope, Tensor out) {
+    const long long DHW = (long long)a.D * a.H * a.W;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int c = blockIdx.y, n = blockIdx.z;
+    if (idx >= DHW) return;
+    const float4 na = load_nrm(a, n, c), nb = load_nrm(b, n, c);
+    const float* pa = a.data + (long long)n * a.n_stride + (long long)c * DHW + idx;
+    const float* pb = b.data + (long long)n * b.n_stride + (long long)c * DHW + idx;
+    float* po = out.data + (long long)n * out.n_stride + (long long)c * DHW + idx;
+    float va[VEC], vb[VEC];
+    if (VEC == 4) {
+        const float4 qa = *reinterpret_cast<const float4*>(pa), qb = *reinterpret_cast<const float4*>(pb);
+        va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w;
+        vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
+    } else {
+        va[0] = pa[0]; vb[0] = pb[0];
+    }
+    float r[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        const float y = act(va[v], na.x, na.y, na.z) + act(vb[v], nb.x, nb.y, nb.z);
+        r[v] = y > 0.0f ? y : y * slope;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(r[0], r[1], r[2], r[3]);
+    else po[0] = r[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // InstanceNorm statistics, stand-alone pass: one {count, mean, M2} record per 4096-element chunk of each
 // (n, c) plane; M2 is taken about the chunk mean (two passes over registers), so no E[x^2]-E[x]^2 cancellation.
 constexpr int STAT_CHUNK = 4096;

@@ -157,40 +157,36 @@ separable_resample_kernel(const float* __restrict__ src, float* __restrict__ dst
 // LDS with row-contiguous (coalesced) loads -- every source element once per workgroup instead of up to 8 gathers per
 // output through L1 -- and takes the 8 corners from LDS.  If the box does not fit (strong down-sampling, reflection
 // wrap-around) the workgroup falls back to global gathers; results are identical either way.
-constexpr int RS_TOZ = 4, RS_TOY = 8, RS_TOX = 64, RS_LDS_FLOATS = 12288;
+constexpr int RS_TOZ = 4, RS_TOY = 8, RS_TOX = 64, RS_LDS_FLOATS = 6144;
 
 template <typename T>
 __global__ void __launch_bounds__(256)
 separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a) {
     __shared__ float box[RS_LDS_FLOATS];
     __shared__ int lim[6];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbx = (a.Wo + RS_TOX - 1) / RS_TOX, nby = (a.Ho + RS_TOY - 1) / RS_TOY;
     const int bx = blockIdx.x % nbx, by = (blockIdx.x / nbx) % nby, bz = blockIdx.x / (nbx * nby);
     const int ox0 = bx * RS_TOX, oy0 = by * RS_TOY, oz0 = bz * RS_TOZ;
     const int nz = min(RS_TOZ, a.Do - oz0), ny = min(RS_TOY, a.Ho - oy0), nx = min(RS_TOX, a.Wo - ox0);
     const bool nearest = a.mode == RS_NEAREST;
 
-    // bounding box of the taps (one wave scans the nz + ny + nx table entries of this block)
-    if (tid < 6) lim[tid] = (tid & 1) ? -1 : 0x7fffffff;
-    __syncthreads();
-    if (tid < 64) {
-        for (int axis = 0; axis < 3; ++axis) {
-            const int n = axis == 0 ? nz : axis == 1 ? ny : nx;
-            const int base = axis == 0 ? oz0 : axis == 1 ? a.Do + oy0 : a.Do + a.Ho + ox0;
-            int lo = 0x7fffffff, hi = -1;
-            for (int i = tid; i < n; i += 64) {
-                const AxisTap<T> t = tab[base + i];
-                if (t.i0 >= 0) { lo = min(lo, t.i0); hi = max(hi, t.i0); }
-                if (t.i1 >= 0) { lo = min(lo, t.i1); hi = max(hi, t.i1); }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                lo = min(lo, __shfl_xor(lo, o));
-                hi = max(hi, __shfl_xor(hi, o));
-            }
-            if (tid == 0) { lim[2 * axis] = lo; lim[2 * axis + 1] = hi; }
+    // bounding box of the taps: wave w < 3 scans the table entries of axis w
+    if (wave < 3) {
+        const int n = wave == 0 ? nz : wave == 1 ? ny : nx;
+        const int base = wave == 0 ? oz0 : wave == 1 ? a.Do + oy0 : a.Do + a.Ho + ox0;
+        int lo = 0x7fffffff, hi = -1;
+        if (lane < n) {
+            const AxisTap<T> t = tab[base + lane];
+            if (t.i0 >= 0) { lo = min(lo, t.i0); hi = max(hi, t.i0); }
+            if (t.i1 >= 0) { lo = min(lo, t.i1); hi = max(hi, t.i1); }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0) { lim[2 * wave] = lo; lim[2 * wave + 1] = hi; }
     }
     __syncthreads();
     const int lz = lim[0], ly = lim[2], lx = lim[4];
@@ -199,46 +195,69 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
     const bool staged = any && (long long)ez * ey * ex <= RS_LDS_FLOATS;
     const long long ivol = (long long)a.Di * a.Hi * a.Wi, ovol = (long long)a.Do * a.Ho * a.Wo;
 
+    // this thread's outputs: column jx = lane, rows jy = wave and wave + 4, every jz of the block
+    const int jx = lane;
+    const AxisTap<T> tx = tab[a.Do + a.Ho + ox0 + min(jx, nx - 1)];
+    const int xo0 = tx.i0 >= 0 ? tx.i0 - lx : 0, xo1 = tx.i1 >= 0 ? tx.i1 - lx : 0;
+
     for (int c = 0; c < a.C; ++c) {
         const float* p = src + (long long)c * ivol;
         if (staged) {
             __syncthreads();   // previous channel's reads are done
             const int rows = ez * ey;
-            for (int r = tid / 64; r < rows; r += 4) {          // one wave per source row: contiguous along x
-                const int rz = r / ey, ry = r - rz * ey;
-                const float* row = p + ((long long)(lz + rz) * a.Hi + (ly + ry)) * a.Wi + lx;
-                for (int i = tid & 63; i < ex; i += 64) box[r * ex + i] = row[i];
+            for (int x0 = 0; x0 < ex; x0 += 64) {                 // rows are contiguous along x: coalesced
+                const bool xin = x0 + lane < ex;
+                for (int r0 = wave; r0 < rows; r0 += 32) {        // 8 rows per wave in flight
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 + 4 * u;
+                        const int rz = r / ey, ry = r - rz * ey;
+                        const bool ok = xin && r < rows;
+                        v[u] = ok ? p[((long long)(lz + rz) * a.Hi + (ly + ry)) * a.Wi + lx + x0 + lane] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int r = r0 + 4 * u;
+                        if (xin && r < rows) box[r * ex + x0 + lane] = v[u];
+                    }
+                }
             }
             __syncthreads();
         }
-        for (int o = tid; o < RS_TOZ * RS_TOY * RS_TOX; o += 256) {
-            const int jx = o % RS_TOX, jy = (o / RS_TOX) % RS_TOY, jz = o / (RS_TOX * RS_TOY);
-            if (jx >= nx || jy >= ny || jz >= nz) continue;
-            const AxisTap<T> tz = tab[oz0 + jz], ty = tab[a.Do + oy0 + jy], tx = tab[a.Do + a.Ho + ox0 + jx];
-            const long long oidx = ((long long)(oz0 + jz) * a.Ho + (oy0 + jy)) * a.Wo + ox0 + jx;
-            float res;
-            if (nearest) {
-                const bool ok = tz.i0 >= 0 && ty.i0 >= 0 && tx.i0 >= 0;
-                if (!ok) res = 0.0f;
-                else if (staged) res = box[((tz.i0 - lz) * ey + (ty.i0 - ly)) * ex + (tx.i0 - lx)];
-                else res = p[((long long)tz.i0 * a.Hi + ty.i0) * a.Wi + tx.i0];
-            } else {
-                const int zi[2] = {tz.i0, tz.i1}, yi[2] = {ty.i0, ty.i1}, xi[2] = {tx.i0, tx.i1};
-                T v[8];
+        for (int jz = 0; jz < nz; ++jz) {
+            const AxisTap<T> tz = tab[oz0 + jz];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int z = zi[k >> 2], y = yi[(k >> 1) & 1], x = xi[k & 1];
-                    const bool ok = z >= 0 && y >= 0 && x >= 0;
-                    float f = 0.0f;
-                    if (ok) f = staged ? box[((z - lz) * ey + (y - ly)) * ex + (x - lx)] : p[((long long)z * a.Hi + y) * a.Wi + x];
-                    v[k] = (T)f;
+            for (int h = 0; h < 2; ++h) {
+                const int jy = wave + 4 * h;
+                if (jy >= ny || jx >= nx) continue;
+                const AxisTap<T> ty = tab[a.Do + oy0 + jy];
+                const long long oidx = ((long long)(oz0 + jz) * a.Ho + (oy0 + jy)) * a.Wo + ox0 + jx;
+                float res;
+                if (nearest) {
+                    const bool ok = tz.i0 >= 0 && ty.i0 >= 0 && tx.i0 >= 0;
+                    if (!ok) res = 0.0f;
+                    else if (staged) res = box[((tz.i0 - lz) * ey + (ty.i0 - ly)) * ex + xo0];
+                    else res = p[((long long)tz.i0 * a.Hi + ty.i0) * a.Wi + tx.i0];
+                } else {
+                    const int zi[2] = {tz.i0, tz.i1}, yi[2] = {ty.i0, ty.i1}, xi[2] = {tx.i0, tx.i1};
+                    const int xo[2] = {xo0, xo1};
+                    T v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int z = zi[k >> 2], y = yi[(k >> 1) & 1], x = xi[k & 1];
+                        const bool ok = z >= 0 && y >= 0 && x >= 0;
+                        float f = 0.0f;
+                        if (ok) f = staged ? box[((z - lz) * ey + (y - ly)) * ex + xo[k & 1]] : p[((long long)z * a.Hi + y) * a.Wi + x];
+                        v[k] = (T)f;
+                    }
+                    const T r0 = v[0] * tx.w0 + v[1] * tx.w1, r1 = v[2] * tx.w0 + v[3] * tx.w1;
+                    const T r2 = v[4] * tx.w0 + v[5] * tx.w1, r3 = v[6] * tx.w0 + v[7] * tx.w1;
+                    const T p0 = r0 * ty.w0 + r1 * ty.w1, p1 = r2 * ty.w0 + r3 * ty.w1;
+                    res = (float)(p0 * tz.w0 + p1 * tz.w1);
                 }
-                const T r0 = v[0] * tx.w0 + v[1] * tx.w1, r1 = v[2] * tx.w0 + v[3] * tx.w1;
-                const T r2 = v[4] * tx.w0 + v[5] * tx.w1, r3 = v[6] * tx.w0 + v[7] * tx.w1;
-                const T p0 = r0 * ty.w0 + r1 * ty.w1, p1 = r2 * ty.w0 + r3 * ty.w1;
-                res = (float)(p0 * tz.w0 + p1 * tz.w1);
+                dst[(long long)c * ovol + oidx] = res;
             }
-            dst[(long long)c * ovol + oidx] = res;
         }
     }
 }

@@ -1,1 +1,2 @@
 from .basic_unet import BasicUNet, BasicUnet, Basicunet, basicunet  # noqa: F401
+from .unetr import UNETR  # noqa: F401

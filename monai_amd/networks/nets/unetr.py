@@ -1,0 +1,333 @@
+"""UNETR on the MI355X kernels -- drop-in for ``monai.networks.nets.UNETR`` (monai/networks/nets/unetr.py:30-213).
+
+Same constructor signature, module tree and ``state_dict`` keys/shapes as the reference (including the unused
+``cross_attn`` / ``norm_cross_attn`` parameters every ``TransformerBlock`` carries, transformerblock.py:83-91) and the same
+parameter-initialisation order, so reference checkpoints load unchanged and the same seed gives the same weights.
+
+Inference engine:
+  * ViT-B encoder: the self-attention core (QK^T, softmax, PV -- selfattention.py:189-212) is the hand-written fp32-MFMA kernel
+    ``mh_attention_f32`` working straight on the qkv projection's output; the dense projections (patch embedding, qkv, out_proj,
+    MLP) are plain library GEMMs (``F.linear`` -> hipBLASLt), LayerNorm / GELU / residual adds are torch element-wise ops;
+  * conv decoder (UnetrBasicBlock / UnetrPrUpBlock / UnetrUpBlock with UnetResBlock): the same fp32-MFMA 3x3x3 conv with fused
+    InstanceNorm statistics, deferred normalise+LeakyReLU(0.01) on load, transposed-conv and 1x1 kernels as BasicUNet, plus
+    ``mh_add_act_f32`` for the residual join; concat buffers are written in place (no ``torch.cat``).
+"""
+
+from __future__ import annotations
+
+import math
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import _lib, _prof, ops
+from ...utils.misc import ensure_tuple_rep
+
+__all__ = ["UNETR"]
+
+
+def _trunc_normal_(t: torch.Tensor, mean=0.0, std=1.0, a=-2.0, b=2.0) -> torch.Tensor:
+    """inverse-CDF truncated normal (the initialiser the reference uses for the position embedding)"""
+    cdf = lambda v: (1.0 + math.erf(v / math.sqrt(2.0))) / 2.0  # noqa: E731
+    lo, hi = cdf((a - mean) / std), cdf((b - mean) / std)
+    with torch.no_grad():
+        t.uniform_(2 * lo - 1, 2 * hi - 1).erfinv_().mul_(std * math.sqrt(2.0)).add_(mean).clamp_(min=a, max=b)
+    return t
+
+
+# --------------------------------------------------------------------------- parameter containers (reference names)
+class _PatchEmbedding(nn.Module):
+    def __init__(self, in_channels, hidden_size, n_patches):
+        super().__init__()
+        self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=16, stride=16)
+        self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, hidden_size))
+        _trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
+
+
+class _MLP(nn.Module):
+    def __init__(self, hidden, mlp_dim):
+        super().__init__()
+        self.linear1 = nn.Linear(hidden, mlp_dim)
+        self.linear2 = nn.Linear(mlp_dim, hidden)
+
+
+class _SA(nn.Module):
+    def __init__(self, hidden, qkv_bias):
+        super().__init__()
+        self.out_proj = nn.Linear(hidden, hidden)
+        self.qkv = nn.Linear(hidden, hidden * 3, bias=qkv_bias)
+
+
+class _CrossAttn(nn.Module):   # instantiated by the reference's TransformerBlock, never used by ViT
+    def __init__(self, hidden, qkv_bias):
+        super().__init__()
+        self.out_proj = nn.Linear(hidden, hidden)
+        self.to_q = nn.Linear(hidden, hidden, bias=qkv_bias)
+        self.to_k = nn.Linear(hidden, hidden, bias=qkv_bias)
+        self.to_v = nn.Linear(hidden, hidden, bias=qkv_bias)
+
+
+class _TransformerBlock(nn.Module):
+    def __init__(self, hidden, mlp_dim, qkv_bias):
+        super().__init__()
+        self.mlp = _MLP(hidden, mlp_dim)
+        self.norm1 = nn.LayerNorm(hidden)
+        self.attn = _SA(hidden, qkv_bias)
+        self.norm2 = nn.LayerNorm(hidden)
+        self.norm_cross_attn = nn.LayerNorm(hidden)
+        self.cross_attn = _CrossAttn(hidden, False)
+
+
+class _ViT(nn.Module):
+    def __init__(self, in_channels, hidden, mlp_dim, num_layers, n_patches, qkv_bias):
+        super().__init__()
+        self.patch_embedding = _PatchEmbedding(in_channels, hidden, n_patches)
+        self.blocks = nn.ModuleList([_TransformerBlock(hidden, mlp_dim, qkv_bias) for _ in range(num_layers)])
+        self.norm = nn.LayerNorm(hidden)
+
+
+class _Conv(nn.Module):
+    """``Convolution(conv_only=True)``: the parameter lives at ``<name>.conv.weight``"""
+
+    def __init__(self, cin, cout, k, transposed=False, bias=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=2, stride=2, bias=bias)
+        else:
+            self.conv = nn.Conv3d(cin, cout, kernel_size=k, padding=k // 2, bias=bias)
+
+
+class _ResBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = _Conv(cin, cout, 3)
+        self.conv2 = _Conv(cout, cout, 3)
+        if cin != cout:
+            self.conv3 = _Conv(cin, cout, 1)
+
+
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.layer = _ResBlock(cin, cout)
+
+
+class _PrUpBlock(nn.Module):
+    def __init__(self, cin, cout, num_layer):
+        super().__init__()
+        self.transp_conv_init = _Conv(cin, cout, 2, transposed=True)
+        self.blocks = nn.ModuleList([nn.Sequential(_Conv(cout, cout, 2, transposed=True), _ResBlock(cout, cout)) for _ in range(num_layer)])
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.transp_conv = _Conv(cin, cout, 2, transposed=True)
+        self.conv_block = _ResBlock(cout + cout, cout)
+
+
+class _OutBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _Conv(cin, cout, 1, bias=True)
+
+
+# --------------------------------------------------------------------------- the module
+class UNETR(nn.Module):
+    def __init__(
+        self,
+        in_channels: int,
+        out_channels: int,
+        img_size: Sequence[int] | int,
+        feature_size: int = 16,
+        hidden_size: int = 768,
+        mlp_dim: int = 3072,
+        num_heads: int = 12,
+        proj_type: str = "conv",
+        norm_name: tuple | str = "instance",
+        conv_block: bool = True,
+        res_block: bool = True,
+        dropout_rate: float = 0.0,
+        spatial_dims: int = 3,
+        qkv_bias: bool = False,
+        save_attn: bool = False,
+    ) -> None:
+        super().__init__()
+        if not (0 <= dropout_rate <= 1):
+            raise ValueError("dropout_rate should be between 0 and 1.")
+        if hidden_size % num_heads != 0:
+            raise ValueError("hidden_size should be divisible by num_heads.")
+        if spatial_dims != 3 or proj_type != "conv" or not conv_block or not res_block or dropout_rate != 0.0 or save_attn:
+            raise NotImplementedError("monai_amd.UNETR: only the default 3-D / conv-projection / res-block / no-dropout configuration is on the HIP path")
+        norm = norm_name if isinstance(norm_name, str) else norm_name[0]
+        if str(norm).lower() != "instance":
+            raise NotImplementedError("monai_amd.UNETR: only norm_name='instance' is on the HIP path")
+        if hidden_size // num_heads != 64:
+            raise NotImplementedError("monai_amd.UNETR: the MFMA attention kernel is built for head_dim 64")
+        self.num_layers = 12
+        img_size = ensure_tuple_rep(img_size, spatial_dims)
+        self.img_size = tuple(int(v) for v in img_size)
+        self.patch_size = (16,) * spatial_dims
+        self.feat_size = tuple(d // 16 for d in self.img_size)
+        n_patches = 1
+        for f in self.feat_size:
+            n_patches *= f
+        if n_patches > 224:
+            raise NotImplementedError(f"monai_amd.UNETR: {n_patches} tokens exceed the LDS-resident attention limit (224)")
+        self.hidden_size, self.num_heads, self.in_channels, self.out_channels = hidden_size, num_heads, in_channels, out_channels
+        self.feature_size = fs = feature_size
+        self.features = (2 * fs,)   # used by the inferer to size its window batch
+
+        self.vit = _ViT(in_channels, hidden_size, mlp_dim, self.num_layers, n_patches, qkv_bias)
+        self.encoder1 = _BasicBlock(in_channels, fs)
+        self.encoder2 = _PrUpBlock(hidden_size, fs * 2, 2)
+        self.encoder3 = _PrUpBlock(hidden_size, fs * 4, 1)
+        self.encoder4 = _PrUpBlock(hidden_size, fs * 8, 0)
+        self.decoder5 = _UpBlock(hidden_size, fs * 8)
+        self.decoder4 = _UpBlock(fs * 8, fs * 4)
+        self.decoder3 = _UpBlock(fs * 4, fs * 2)
+        self.decoder2 = _UpBlock(fs * 2, fs)
+        self.out = _OutBlock(fs, out_channels)
+        self._packed: dict = {}
+        self._stats = None
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device), cfg)
+        hit = self._packed.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, w))
+            self._packed[id(conv)] = hit
+        return hit[1]
+
+    def _stats_buf(self, floats: int, device) -> torch.Tensor:
+        if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
+            self._stats = torch.empty(floats, dtype=torch.float32, device=device)
+        return self._stats
+
+    def _conv3_in(self, conv: nn.Conv3d, x, x_nrm, slope: float):
+        """3x3x3 conv (no bias) + InstanceNorm(no affine) statistics -> (raw output, its {alpha, beta, slope} record)."""
+        n, cin, d, h, w = x.shape
+        cout = conv.weight.shape[0]
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+        out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
+        nrm = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
+        tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+        flops = 2.0 * 27 * cin * cout * d * h * w * n
+        if tiles:
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+                ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), None, out, stats)
+        else:
+            ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), None, out, None)
+            tiles = ops.instnorm_stat_tiles(d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            ops.instnorm_stats(out, stats)
+        ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, slope, nrm)
+        return out, nrm
+
+    def _res_block(self, blk: _ResBlock, x, out):
+        """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` into `out`."""
+        c1, n1 = self._conv3_in(blk.conv1.conv, x, None, 0.01)      # conv1 -> norm1 -> lrelu, applied on load by conv2
+        c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 1.0)        # conv2 -> norm2 (no activation before the add)
+        if hasattr(blk, "conv3"):
+            w3 = blk.conv3.conv.weight
+            n, cout = x.shape[0], w3.shape[0]
+            r = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            ops.conv1x1(x, None, w3.view(cout, -1), None, r)
+            tiles = ops.instnorm_stat_tiles(*x.shape[2:])
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            ops.instnorm_stats(r, stats)
+            n3 = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
+            ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, n3)
+            ops.add_act(c2, n2, r, n3, 0.01, out)
+        else:
+            ops.add_act(c2, n2, x, None, 0.01, out)
+        return out
+
+    @staticmethod
+    def _tconv(conv: nn.ConvTranspose3d, x, out):
+        return ops.deconv_k2s2(x, None, conv.weight, conv.bias, out)
+
+    def _new(self, like, c, scale=1):
+        n = like.shape[0]
+        sp = tuple(int(v * scale) for v in like.shape[2:])
+        return torch.empty((n, c) + sp, dtype=torch.float32, device=like.device)
+
+    # ---- ViT ---------------------------------------------------------------------------------------
+    def _vit(self, x_in):
+        pe = self.vit.patch_embedding
+        b = x_in.shape[0]
+        fz, fy, fx = self.feat_size
+        c = x_in.shape[1]
+        patches = x_in.reshape(b, c, fz, 16, fy, 16, fx, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, fz * fy * fx, c * 4096)
+        t = F.linear(patches, pe.patch_embeddings.weight.reshape(self.hidden_size, -1), pe.patch_embeddings.bias) + pe.position_embeddings
+        hidden = []
+        scale = 64 ** -0.5
+        h = self.hidden_size
+        for blk in self.vit.blocks:
+            qkv = F.linear(F.layer_norm(t, (h,), blk.norm1.weight, blk.norm1.bias, 1e-5), blk.attn.qkv.weight, blk.attn.qkv.bias)
+            with _prof.span("attention", 4.0 * qkv.shape[1] ** 2 * 64 * self.num_heads * b):
+                a = ops.attention(qkv.contiguous(), self.num_heads, scale)
+            t = t + F.linear(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+            m = F.layer_norm(t, (h,), blk.norm2.weight, blk.norm2.bias, 1e-5)
+            t = t + F.linear(F.gelu(F.linear(m, blk.mlp.linear1.weight, blk.mlp.linear1.bias)), blk.mlp.linear2.weight, blk.mlp.linear2.bias)
+            hidden.append(t)
+        return F.layer_norm(t, (h,), self.vit.norm.weight, self.vit.norm.bias, 1e-5), hidden
+
+    def _proj_feat(self, t):
+        return t.view(t.size(0), *self.feat_size, self.hidden_size).permute(0, 4, 1, 2, 3).contiguous()
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x_in: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((x_in.shape[0], self.out_channels) + tuple(x_in.shape[2:]), dtype=torch.float32, device=x_in.device)
+        return self.forward_into(x_in, out)
+
+    @torch.no_grad()
+    def forward_into(self, x_in: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
+        _lib.require_device(x_in, logits)
+        if self.training:
+            raise RuntimeError("monai_amd.UNETR is an inference engine: call .eval() first")
+        if tuple(x_in.shape[2:]) != self.img_size or x_in.shape[1] != self.in_channels:
+            raise RuntimeError(f"monai_amd.UNETR: expected input (B,{self.in_channels},{self.img_size}), got {tuple(x_in.shape)}")
+        x_in = x_in.contiguous()
+        fs = self.feature_size
+        x, hs = self._vit(x_in)
+
+        # decoder concat buffers: [upsampled | skip]
+        cat2 = self._new(x_in, 2 * fs)                       # decoder2 @ full resolution
+        self._res_block(self.encoder1.layer, x_in, cat2[:, fs:])
+
+        def prup(blk: _PrUpBlock, t, dst):
+            cout = blk.transp_conv_init.conv.weight.shape[1]
+            cur = self._tconv(blk.transp_conv_init.conv, t, dst if len(blk.blocks) == 0 else self._new(t, cout, 2))
+            for i, seq in enumerate(blk.blocks):
+                up = self._tconv(seq[0].conv, cur, self._new(cur, cout, 2))
+                last = i == len(blk.blocks) - 1
+                cur = self._res_block(seq[1], up, dst if last else self._new(up, cout))
+            return cur
+
+        p2 = self._proj_feat(hs[3])
+        cat3 = self._new(p2, 4 * fs, 8)                      # decoder3 @ 1/2 resolution
+        prup(self.encoder2, p2, cat3[:, 2 * fs:])
+        p3 = self._proj_feat(hs[6])
+        cat4 = self._new(p3, 8 * fs, 4)                      # decoder4 @ 1/4
+        prup(self.encoder3, p3, cat4[:, 4 * fs:])
+        p4 = self._proj_feat(hs[9])
+        cat5 = self._new(p4, 16 * fs, 2)                     # decoder5 @ 1/8
+        prup(self.encoder4, p4, cat5[:, 8 * fs:])
+
+        def up(blk: _UpBlock, inp, cat, cout, dst):
+            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout])
+            return self._res_block(blk.conv_block, cat, dst)
+
+        dec3 = up(self.decoder5, self._proj_feat(x), cat5, 8 * fs, self._new(cat5, 8 * fs))
+        dec2 = up(self.decoder4, dec3, cat4, 4 * fs, self._new(cat4, 4 * fs))
+        dec1 = up(self.decoder3, dec2, cat3, 2 * fs, self._new(cat3, 2 * fs))
+        last = up(self.decoder2, dec1, cat2, fs, self._new(cat2, fs))
+        oc = self.out.conv.conv
+        ops.conv1x1(last, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
+        return logits

@@ -171,3 +171,22 @@ def separable_filter3d(src: torch.Tensor, kernels) -> torch.Tensor:
     _lib.lib().call("mh_separable_filter3d_f32", _lib.ptr(src), _lib.ptr(out), nc, d, h, w, arrs[0], len(kernels[0]), arrs[1], len(kernels[1]),
                     arrs[2], len(kernels[2]), _s(src))
     return out
+
+
+def add_act(a, a_nrm, b, b_nrm, slope: float, out):
+    """out = leaky_relu(act(a) + act(b), slope) -- residual join of UnetResBlock."""
+    _lib.require_device(a, a_nrm, b, b_nrm, out)
+    ta, tb, to = _lib.tensor5(a, a_nrm), _lib.tensor5(b, b_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_add_act_f32", C.byref(ta), C.byref(tb), float(slope), C.byref(to), _s(a))
+    return out
+
+
+def attention(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """qkv [B, S, 3*heads*64] -> [B, S, heads*64] = softmax(Q K^T * scale) V per head (fp32 MFMA)."""
+    _lib.require_device(qkv)
+    if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] != 3 * heads * 64:
+        raise RuntimeError(f"monai_amd.attention: qkv must be contiguous [B, S, {3 * heads * 64}], got {tuple(qkv.shape)}")
+    b, s, _ = qkv.shape
+    out = torch.empty((b, s, heads * 64), dtype=torch.float32, device=qkv.device)
+    _lib.lib().call("mh_attention_f32", _lib.ptr(qkv), _lib.ptr(out), b, s, int(heads), 64, float(scale), _s(qkv))
+    return out

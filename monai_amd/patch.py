@@ -30,6 +30,7 @@ _TARGETS = {
         "Basicunet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
         "basicunet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
     },
+    "monai.networks.nets.unetr": {"UNETR": ("monai_amd.networks.nets.unetr", "UNETR")},
     "monai.transforms.spatial.array": {
         "Spacing": ("monai_amd.transforms.spatial.array", "Spacing"),
         "SpatialResample": ("monai_amd.transforms.spatial.array", "SpatialResample"),

@@ -107,3 +107,52 @@ def case_blend_only_vs_golden(device):
         assert np.array_equal(y.cpu().numpy(), g[f"blend_{i}_out"]), f"blend case {i}: not bit-identical to the reference"
         i += 1
     assert i >= 5
+
+
+# ------------------------------------------------------------------------------------------ UNETR
+def _digest(sd):
+    import hashlib
+
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def case_unetr_small_vs_golden(device):
+    """UNETR(img 32^3, hidden 128 = 2 heads x 64, mlp 256, feature 16, 3 classes), seed 2, against the reference's output."""
+    from monai_amd.networks.nets import UNETR
+
+    g = np.load(os.path.join(GOLDEN, "unetr.npz"))
+    torch.manual_seed(2)
+    net = UNETR(in_channels=1, out_channels=3, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=256, num_heads=2).eval()
+    assert _digest(net.state_dict()) == str(g["small_state_sha256"]), "same seed must give the reference's weights"
+    net = net.to(device)
+    torch.manual_seed(32)
+    x = torch.rand(2, 1, 32, 32, 32)
+    y = net(x.to(device)).cpu()
+    r = report(y, torch.from_numpy(g["small_out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    return r
+
+
+def case_unetr_vitb_vs_golden(device):
+    """BASELINE.json configs[3] network: UNETR(ViT-B/16, 96^3 window, 5 classes), seed 1, one window vs the reference."""
+    from monai_amd.networks.nets import UNETR
+
+    g = np.load(os.path.join(GOLDEN, "unetr.npz"))
+    torch.manual_seed(1)
+    net = UNETR(in_channels=1, out_channels=5, img_size=(96, 96, 96)).eval()
+    assert list(net.state_dict().keys()) == list(g["vitb_keys"])
+    assert _digest(net.state_dict()) == str(g["vitb_state_sha256"])
+    net = net.to(device)
+    torch.manual_seed(31)
+    x = torch.rand(1, 1, 96, 96, 96)
+    y = net(x.to(device)).cpu()
+    sub = y[:, :, ::4, ::4, ::4]
+    err = (sub - torch.from_numpy(g["vitb_out_sub"])).abs().max().item()
+    assert err < LOGIT_TOL, err
+    assert abs(y.double().sum().item() - float(g["vitb_out_sum"])) < 1e-4 * y.numel() ** 0.5 + 50.0
+    mism = (y.argmax(1)[:, ::2, ::2, ::2].numpy().astype(np.uint8) != g["vitb_argmax_sub"]).mean()
+    assert mism < 1e-4, mism
+    return err, mism

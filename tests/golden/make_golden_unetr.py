@@ -1,0 +1,51 @@
+"""Golden vectors for UNETR from the REAL reference.  Build container only."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+from monai.networks.nets import UNETR  # noqa: E402
+
+
+def digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def main():
+    out = {}
+    # (a) the BASELINE.json configs[3] network: ViT-B/16 encoder, 96^3 window, 5 classes, seed-1 default init
+    torch.manual_seed(1)
+    net = UNETR(in_channels=1, out_channels=5, img_size=(96, 96, 96)).eval()
+    out["vitb_state_sha256"] = np.asarray(digest(net.state_dict()))
+    out["vitb_keys"] = np.asarray(list(net.state_dict().keys()))
+    torch.manual_seed(31)
+    x = torch.rand(1, 1, 96, 96, 96)
+    with torch.no_grad():
+        y = net(x)
+    out["vitb_out_sub"] = y[:, :, ::4, ::4, ::4].numpy()
+    out["vitb_out_sum"] = np.asarray(y.double().sum().item())
+    out["vitb_argmax_sub"] = y.argmax(1)[:, ::2, ::2, ::2].numpy().astype(np.uint8)
+    # (b) a small configuration the CPU emulator can run end to end: 32^3 input (8 tokens), hidden 128 = 2 heads x 64
+    torch.manual_seed(2)
+    net = UNETR(in_channels=1, out_channels=3, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=256, num_heads=2).eval()
+    out["small_state_sha256"] = np.asarray(digest(net.state_dict()))
+    torch.manual_seed(32)
+    x = torch.rand(2, 1, 32, 32, 32)
+    with torch.no_grad():
+        out["small_out"] = net(x).numpy()
+    np.savez_compressed(os.path.join(HERE, "unetr.npz"), **out)
+    print("unetr golden written")
+
+
+if __name__ == "__main__":
+    main()

@@ -193,3 +193,32 @@ def case_instnorm_stats(device, n=2, c=3, dims=(10, 17, 31)):
     assert (r[:, :, 0] - alpha).abs().max().item() < 1e-6
     assert (r[:, :, 1] + xd.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 2e-5
     assert torch.all(r[:, :, 2] == 0.25)
+
+
+def case_attention(device, b=2, s=216, heads=3):
+    """softmax(Q K^T * scale) V against the reference's einsum formulation (selfattention.py:189-212) in fp64."""
+    gen = torch.Generator().manual_seed(8)
+    qkv = torch.randn(b, s, 3 * heads * 64, generator=gen) * 0.7
+    out = ops.attention(qkv.to(device), heads, 64 ** -0.5)
+    t = qkv.double().reshape(b, s, 3, heads, 64).permute(2, 0, 3, 1, 4)       # "b h (qkv l d) -> qkv b l h d"
+    q, k, v = t[0], t[1], t[2]
+    att = (torch.einsum("blxd,blyd->blxy", q, k) * (64 ** -0.5)).softmax(dim=-1)
+    exp = torch.einsum("bhxy,bhyd->bhxd", att, v).permute(0, 2, 1, 3).reshape(b, s, heads * 64)
+    err = (out.cpu().double() - exp).abs().max().item()
+    assert err < 2e-6, err
+    return err
+
+
+def case_add_act(device):
+    gen = torch.Generator().manual_seed(9)
+    a, b = torch.randn(2, 5, 6, 8, 12, generator=gen), torch.randn(2, 5, 6, 8, 12, generator=gen)
+    na, nb = _rand_nrm(2, 5, gen), _rand_nrm(2, 5, gen)
+    na[:, :, 2] = 1.0
+    nb[:, :, 2] = 1.0
+    out = torch.empty_like(a).to(device)
+    ops.add_act(a.to(device), na.to(device), b.to(device), nb.to(device), 0.01, out)
+    y = _act(a, na) + _act(b, nb)
+    assert (out.cpu() - torch.where(y > 0, y, y * 0.01)).abs().max().item() < 2e-6
+    ops.add_act(a.to(device), na.to(device), b.to(device), None, 0.01, out)
+    y = _act(a, na) + b
+    assert (out.cpu() - torch.where(y > 0, y, y * 0.01)).abs().max().item() < 2e-6

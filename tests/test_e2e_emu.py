@@ -14,3 +14,7 @@ def test_net_single_window_vs_reference(emu):
 
 def test_sliding_window_net5_vs_reference(emu):
     print(ec.case_sliding_window_net5_vs_golden("cpu"))
+
+
+def test_unetr_small_vs_reference(emu):
+    print(ec.case_unetr_small_vs_golden("cpu"))

@@ -102,3 +102,32 @@ def test_full_size_properties_512():
     del a
     b = inf(vol, net)
     assert b.double().sum().item() == s1 and torch.equal(b.argmax(1), lab)  # deterministic: no atomics anywhere
+
+
+def test_unetr_small_vs_reference():
+    print(ec.case_unetr_small_vs_golden(DEV))
+
+
+def test_unetr_vitb_window_vs_reference():
+    """BASELINE.json configs[3]: ViT-B/16 UNETR on a 96^3 window -- exercises the MFMA attention kernel at S = 216."""
+    print(ec.case_unetr_vitb_vs_golden(DEV))
+
+
+def test_unetr_sliding_window_192():
+    """UNETR through the SlidingWindowInferer (8 windows of 96^3 over a 144^3 volume) vs the CPU oracle."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.networks.nets import UNETR
+    from oracle import unetr as ou
+
+    torch.manual_seed(1)
+    net = UNETR(in_channels=1, out_channels=5, img_size=(96, 96, 96)).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    torch.manual_seed(33)
+    x = torch.rand(1, 1, 144, 96, 96)
+    y = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")(x.to(DEV), net)
+    with torch.no_grad():
+        ref = osw.sliding_window_inference(x, (96, 96, 96), 4, lambda w: ou.unetr_forward(sd, w), overlap=0.5, mode="gaussian")
+    r = ec.report(y.cpu(), ref)
+    print(r)
+    assert r["max_abs"] < ec.LOGIT_TOL, r

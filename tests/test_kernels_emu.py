@@ -69,7 +69,6 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 12
     assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 13
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13
-    assert ops.conv3d_k3_select(32, 5, 96, 96, 96) == 0   # Cout not a multiple of 32 -> direct kernel
 
 
 def test_conv_into_channel_slice(emu):
@@ -83,3 +82,19 @@ def test_pool_deconv_1x1_stats(emu):
     kc.case_conv1x1("cpu")
     kc.case_conv1x1("cpu", cin=7, cout=11, dims=(3, 5, 7))
     kc.case_instnorm_stats("cpu")
+
+
+def test_attention_and_add_act(emu):
+    kc.case_attention("cpu", b=1, s=8, heads=2)       # one key tile, mostly masked
+    kc.case_attention("cpu", b=2, s=45, heads=1)      # two tiles, ragged
+    kc.case_attention("cpu", b=1, s=216, heads=1)     # ViT-B/16 on 96^3
+    kc.case_add_act("cpu")
+
+
+def test_conv_mfma_cout_padding(emu):
+    kc.case_conv3d("cpu", 7, 2, 1, 16, (4, 8, 32))    # UNETR feature_size 16: Cout padded 16 -> 32
+    kc.case_conv3d("cpu", 10, 1, 32, 16, (6, 10, 24))
+    kc.case_conv3d("cpu", 13, 1, 8, 48, (3, 6, 6))    # 48 -> 128
+    from monai_amd import ops
+
+    assert ops.conv3d_k3_select(32, 16, 96, 96, 96) >= 1 and ops.conv3d_k3_select(32, 5, 96, 96, 96) >= 1

@@ -76,3 +76,16 @@ def test_pool_deconv_1x1_stats():
     kc.case_conv1x1(DEV, cin=7, cout=11, dims=(3, 5, 7))
     kc.case_instnorm_stats(DEV)
     kc.case_instnorm_stats(DEV, n=2, c=32, dims=(32, 48, 96))
+
+
+def test_attention_and_add_act():
+    kc.case_attention(DEV, b=1, s=8, heads=2)
+    kc.case_attention(DEV, b=2, s=45, heads=1)
+    print("attention max err", kc.case_attention(DEV, b=3, s=216, heads=12))
+    kc.case_add_act(DEV)
+
+
+def test_conv_mfma_cout_padding():
+    kc.case_conv3d(DEV, 7, 2, 1, 16, (4, 8, 32), tol=5e-5)
+    kc.case_conv3d(DEV, 10, 1, 32, 16, (6, 10, 24), tol=5e-5)
+    kc.case_conv3d(DEV, 13, 1, 8, 48, (3, 6, 6), tol=5e-5)
