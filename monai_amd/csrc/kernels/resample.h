@@ -171,22 +171,48 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
     const int nz = min(RS_TOZ, a.Do - oz0), ny = min(RS_TOY, a.Ho - oy0), nx = min(RS_TOX, a.Wo - ox0);
     const bool nearest = a.mode == RS_NEAREST;
 
-    // bounding box of the taps: wave w < 3 scans the table entries of axis w
-    if (wave < 3) {
-        const int n = wave == 0 ? nz : wave == 1 ? ny : nx;
-        const int base = wave == 0 ? oz0 : wave == 1 ? a.Do + oy0 : a.Do + a.Ho + ox0;
-        int lo = 0x7fffffff, hi = -1;
-        if (lane < n) {
-            const AxisTap<T> t = tab[base + lane];
-            if (t.i0 >= 0) { lo = min(lo, t.i0); hi = max(hi, t.i0); }
-            if (t.i1 >= 0) { lo = min(lo, t.i1); hi = max(hi, t.i1); }
-        }
+    // bounding box of the taps.  Border / zeros padding give monotone tap tables, so the box is spanned by the first and
+    // last entries of each axis; reflection can fold back, so wave w < 3 scans the entries of axis w.
+    if (a.pad == RS_REFLECTION) {
+        if (wave < 3) {
+            const int n = wave == 0 ? nz : wave == 1 ? ny : nx;
+            const int base = wave == 0 ? oz0 : wave == 1 ? a.Do + oy0 : a.Do + a.Ho + ox0;
+            int lo = 0x7fffffff, hi = -1;
+            if (lane < n) {
+                const AxisTap<T> t = tab[base + lane];
+                if (t.i0 >= 0) { lo = min(lo, t.i0); hi = max(hi, t.i0); }
+                if (t.i1 >= 0) { lo = min(lo, t.i1); hi = max(hi, t.i1); }
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            lo = min(lo, __shfl_xor(lo, o));
-            hi = max(hi, __shfl_xor(hi, o));
+            for (int o = 32; o > 0; o >>= 1) {
+                lo = min(lo, __shfl_xor(lo, o));
+                hi = max(hi, __shfl_xor(hi, o));
+            }
+            if (lane == 0) { lim[2 * wave] = lo; lim[2 * wave + 1] = hi; }
         }
-        if (lane == 0) { lim[2 * wave] = lo; lim[2 * wave + 1] = hi; }
+    } else if (tid < 3) {
+        const int n = tid == 0 ? nz : tid == 1 ? ny : nx;
+        const int base = tid == 0 ? oz0 : tid == 1 ? a.Do + oy0 : a.Do + a.Ho + ox0;
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = 0; i < n; ++i) {          // first valid tap from the front ...
+            const AxisTap<T> t = tab[base + i];
+            const int v = t.i0 >= 0 ? t.i0 : t.i1;
+            if (v >= 0) { lo = v; break; }
+        }
+        for (int i = n - 1; i >= 0; --i) {     // ... last valid tap from the back
+            const AxisTap<T> t = tab[base + i];
+            const int v = t.i1 >= 0 ? t.i1 : t.i0;
+            if (v >= 0) { hi = v; break; }
+        }
+        // a decreasing table (negative scale) swaps the roles
+        if (hi >= 0 && lo > hi) { const int s0 = lo; lo = hi; hi = s0; }
+        if (hi >= 0) {   // taps of an entry pair are (i0, i0+1): widen by the partner tap on both ends
+            const AxisTap<T> f = tab[base], l = tab[base + n - 1];
+            const int c0 = f.i0 >= 0 ? f.i0 : lo, c1 = f.i1 >= 0 ? f.i1 : lo, c2 = l.i0 >= 0 ? l.i0 : hi, c3 = l.i1 >= 0 ? l.i1 : hi;
+            lo = min(min(lo, c0), min(c1, min(c2, c3)));
+            hi = max(max(hi, c0), max(c1, max(c2, c3)));
+        }
+        lim[2 * tid] = lo; lim[2 * tid + 1] = hi;
     }
     __syncthreads();
     const int lz = lim[0], ly = lim[2], lx = lim[4];
@@ -207,17 +233,17 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
             const int rows = ez * ey;
             for (int x0 = 0; x0 < ex; x0 += 64) {                 // rows are contiguous along x: coalesced
                 const bool xin = x0 + lane < ex;
-                for (int r0 = wave; r0 < rows; r0 += 32) {        // 8 rows per wave in flight
-                    float v[8];
+                for (int r0 = wave; r0 < rows; r0 += 96) {        // up to 24 rows per wave in flight
+                    float v[24];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 24; ++u) {
                         const int r = r0 + 4 * u;
                         const int rz = r / ey, ry = r - rz * ey;
                         const bool ok = xin && r < rows;
                         v[u] = ok ? p[((long long)(lz + rz) * a.Hi + (ly + ry)) * a.Wi + lx + x0 + lane] : 0.0f;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 24; ++u) {
                         const int r = r0 + 4 * u;
                         if (xin && r < rows) box[r * ex + x0 + lane] = v[u];
                     }

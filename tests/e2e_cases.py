@@ -111,10 +111,13 @@ def case_blend_only_vs_golden(device):
 
 # ------------------------------------------------------------------------------------------ UNETR
 def _digest(sd):
+    """all parameters except the position embedding (see tests/golden/make_golden_unetr.py:digest)"""
     import hashlib
 
     h = hashlib.sha256()
     for k, v in sd.items():
+        if k.endswith("position_embeddings"):
+            continue
         h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
 
@@ -127,6 +130,8 @@ def case_unetr_small_vs_golden(device):
     torch.manual_seed(2)
     net = UNETR(in_channels=1, out_channels=3, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=256, num_heads=2).eval()
     assert _digest(net.state_dict()) == str(g["small_state_sha256"]), "same seed must give the reference's weights"
+    pe = net.state_dict()["vit.patch_embedding.position_embeddings"].flatten()[::13].numpy()
+    np.testing.assert_allclose(pe, g["small_pos_sample"], rtol=2e-6, atol=1e-9)
     net = net.to(device)
     torch.manual_seed(32)
     x = torch.rand(2, 1, 32, 32, 32)
@@ -145,6 +150,8 @@ def case_unetr_vitb_vs_golden(device):
     net = UNETR(in_channels=1, out_channels=5, img_size=(96, 96, 96)).eval()
     assert list(net.state_dict().keys()) == list(g["vitb_keys"])
     assert _digest(net.state_dict()) == str(g["vitb_state_sha256"])
+    pe = net.state_dict()["vit.patch_embedding.position_embeddings"].flatten()[::997].numpy()
+    np.testing.assert_allclose(pe, g["vitb_pos_sample"], rtol=2e-6, atol=1e-9)
     net = net.to(device)
     torch.manual_seed(31)
     x = torch.rand(1, 1, 96, 96, 96)

@@ -14,8 +14,13 @@ from monai.networks.nets import UNETR  # noqa: E402
 
 
 def digest(sd):
+    """sha256 over every parameter except the position embedding: its trunc-normal init goes through `erfinv_`, whose
+    vectorised CPU implementation rounds differently on AVX2 and AVX-512 hosts (seen on the GPU box), so it is pinned
+    by value statistics instead."""
     h = hashlib.sha256()
     for k, v in sd.items():
+        if k.endswith("position_embeddings"):
+            continue
         h.update(k.encode())
         h.update(v.detach().cpu().contiguous().numpy().tobytes())
     return h.hexdigest()
@@ -28,6 +33,8 @@ def main():
     net = UNETR(in_channels=1, out_channels=5, img_size=(96, 96, 96)).eval()
     out["vitb_state_sha256"] = np.asarray(digest(net.state_dict()))
     out["vitb_keys"] = np.asarray(list(net.state_dict().keys()))
+    pe = net.state_dict()["vit.patch_embedding.position_embeddings"]
+    out["vitb_pos_sample"] = pe.flatten()[::997].numpy()
     torch.manual_seed(31)
     x = torch.rand(1, 1, 96, 96, 96)
     with torch.no_grad():
@@ -39,6 +46,7 @@ def main():
     torch.manual_seed(2)
     net = UNETR(in_channels=1, out_channels=3, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=256, num_heads=2).eval()
     out["small_state_sha256"] = np.asarray(digest(net.state_dict()))
+    out["small_pos_sample"] = net.state_dict()["vit.patch_embedding.position_embeddings"].flatten()[::13].numpy()
     torch.manual_seed(32)
     x = torch.rand(2, 1, 32, 32, 32)
     with torch.no_grad():

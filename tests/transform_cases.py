@@ -304,13 +304,14 @@ def case_separable_vs_general(device):
 
     torch.manual_seed(11)
     vol = torch.rand(2, 24, 40, 300).to(device)
-    for scale, osz in (((1.25, 1.25, 0.625), (19, 32, 480)), ((1.0, 3.0, 4.1), (24, 13, 73)), ((0.5, 0.5, 0.5), (47, 79, 599))):
+    for scale, osz in (((1.25, 1.25, 0.625), (19, 32, 480)), ((1.0, 3.0, 4.1), (24, 13, 73)), ((0.5, 0.5, 0.5), (47, 79, 599)),
+                       ((-1.0, 0.8, -0.9), (24, 50, 333))):   # flips: decreasing tap tables
         for mode in ("bilinear", "nearest"):
             for pad in PADS:
                 for f64 in (True, False):
                     m = np.zeros((3, 4))
                     m[0, 0], m[1, 1], m[2, 2] = scale
-                    m[:, 3] = (-0.7, 0.4, -2.3)
+                    m[:, 3] = (-0.7, 0.4, -2.3) if scale[0] > 0 else (23.0, 0.4, 299.5)
                     a = ops.affine_resample(vol, m.reshape(-1), osz, mode, pad, False, f64)
                     m2 = m.copy()
                     m2[0, 1] = 1e-300
