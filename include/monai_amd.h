@@ -108,13 +108,25 @@ int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, cons
 /* ---- UNETR pieces (monai/networks/nets/unetr.py, blocks/selfattention.py, blocks/dynunet_block.py) ------------ */
 
 /* out = lrelu_slope(act(a) + act(b)): the residual join of UnetResBlock (dynunet_block.py:96-111); a, b carry their
- * deferred InstanceNorm records (b->nrm NULL = identity shortcut). */
+ * deferred InstanceNorm records (b->nrm NULL = identity shortcut; b NULL = no second operand: materialises act(a)). */
 int mh_add_act_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const mh_tensor5* out, void* stream);
 
 /* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*64] (the qkv Linear's output,
  * feature index = which*heads*64 + head*64 + d) -> out [B][S][heads*64] = softmax(Q K^T * scale) V per head, on
  * v_mfma_f32_32x32x2_f32 with K/V of a head resident in LDS.  head_dim 64, S <= 224 (ViT-B/16 on 96^3: S = 216). */
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream);
+
+/* ---- UNet pieces (monai/networks/nets/unet.py:106-298) --------------------------------------------------------- */
+
+/* Conv3d k=3, stride s, padding 1 (+bias) of act(in): the strided `Convolution` / `ResidualUnit` convs of the down path
+ * (unet.py:197-237).  packed_w is the configuration-0 layout of mh_conv3d_k3_pack_f32 ([Cin][27][Cout]). */
+int mh_conv3d_k3_strided_f32(const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out,
+                             int stride, void* stream);
+
+/* ConvTranspose3d k=3, stride s, padding 1, output_padding s-1 (+bias) of act(in): the up path (unet.py:249-294).
+ * w: torch layout [Cin][Cout][3][3][3].  out dims = s * in. */
+int mh_deconv_k3_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out, int stride,
+                     void* stream);
 
 /* ---- resampling (Spacingd / SpatialResample / Resample / AffineTransform / grid_pull) -------------------- */
 

@@ -459,13 +459,15 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
 
 // ------------------------------------------------------------------------------------------ UNETR pieces
 int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, const mh_tensor5* out_, void* stream) {
-    if (!dense_ok(a_) || !dense_ok(b_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "add_act: bad tensor");
-    const Tensor a = from_c(*a_), b = from_c(*b_), out = from_c(*out_);
+    if (!dense_ok(a_) || (b_ && !dense_ok(b_)) || !dense_ok(out_)) return fail(MH_ERR_ARG, "add_act: bad tensor");
+    Tensor bnull = from_c(*a_);
+    bnull.data = nullptr; bnull.nrm = nullptr;
+    const Tensor a = from_c(*a_), b = b_ ? from_c(*b_) : bnull, out = from_c(*out_);
     if (a.N != b.N || a.C != b.C || a.D != b.D || a.H != b.H || a.W != b.W || a.N != out.N || a.C != out.C || a.D != out.D ||
         a.H != out.H || a.W != out.W)
         return fail(MH_ERR_ARG, "add_act: shape mismatch");
     const long long DHW = (long long)a.D * a.H * a.W;
-    const bool v4 = DHW % 4 == 0 && aligned(a.data, 16) && aligned(b.data, 16) && aligned(out.data, 16) && a.n_stride % 4 == 0 &&
+    const bool v4 = DHW % 4 == 0 && aligned(a.data, 16) && (!b.data || aligned(b.data, 16)) && aligned(out.data, 16) && a.n_stride % 4 == 0 &&
                     b.n_stride % 4 == 0 && out.n_stride % 4 == 0;
     const dim3 grid(blocks_for(v4 ? DHW / 4 : DHW), (unsigned)a.C, (unsigned)a.N);
     if (v4) hipLaunchKernelGGL((add_act_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
@@ -485,4 +487,28 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
     else if (kt <= 4) hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
     else hipLaunchKernelGGL((attention_kernel<7>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
     return launched("attention");
+}
+
+// ------------------------------------------------------------------------------------------ UNet pieces
+int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, int stride,
+                             void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed_w || stride < 1) return fail(MH_ERR_ARG, "conv3d_k3_strided: bad argument");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D != (in.D - 1) / stride + 1 || out.H != (in.H - 1) / stride + 1 || out.W != (in.W - 1) / stride + 1)
+        return fail(MH_ERR_ARG, "conv3d_k3_strided: output must be floor((in - 1) / stride) + 1");
+    constexpr int COT = 16;
+    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
+    hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
+    return launched("conv3d_k3_strided");
+}
+
+int mh_deconv_k3_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, int stride, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !w || stride < 1) return fail(MH_ERR_ARG, "deconv_k3: bad argument");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D != in.D * stride || out.H != in.H * stride || out.W != in.W * stride)
+        return fail(MH_ERR_ARG, "deconv_k3: output must be stride * input (padding 1, output_padding stride - 1)");
+    constexpr int COT = 16;
+    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
+    hipLaunchKernelGGL((deconv_k3_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out, stride);
+    return launched("deconv_k3");
 }

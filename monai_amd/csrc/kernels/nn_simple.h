@@ -50,6 +50,92 @@ conv3d_k3_direct_kernel(Tensor in, const float* __restrict__ wp, const float* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Strided Conv3d 3x3x3 pad 1 (UNet's down path: monai/networks/nets/unet.py:197-237 -> Convolution(strides=s)).
+// Same direct form as above with  input index = stride * output index + tap - 1;  out dims = floor((in - 1) / stride) + 1.
+template <int COT>
+__global__ void __launch_bounds__(256)
+conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out, int stride) {
+    const int D = in.D, H = in.H, W = in.W, Do = out.D, Ho = out.H, Wo = out.W, Cin = in.C, Cout = out.C;
+    const long long ivol = (long long)D * H * W, ovol = (long long)Do * Ho * Wo;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= ovol) return;
+    const int x = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int y = (int)(t % Ho), z = (int)(t / Ho);
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+    const float* src = in.data + (long long)n * in.n_stride;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float* plane = src + (long long)ci * ivol;
+        const float* wrow = wp + (long long)ci * 27 * Cout + co0;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int zz = z * stride + tap / 9 - 1, yy = y * stride + (tap / 3) % 3 - 1, xx = x * stride + tap % 3 - 1;
+            float v = 0.0f;
+            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                v = act(plane[((long long)zz * H + yy) * W + xx], a.x, a.y, a.z);
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+                if (co0 + j < Cout) acc[j] = fmaf(v, wrow[tap * Cout + j], acc[j]);
+        }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+        if (co0 + j < Cout) dst[(long long)(co0 + j) * ovol] = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d k=3, stride s, padding 1, output_padding s-1 (UNet's up path: unet.py:249-294; out dims = s * in).
+// Gather form: output o takes input i through tap k whenever  i * s + k - 1 == o.  Weights [Cin][Cout][27].
+template <int COT>
+__global__ void __launch_bounds__(256)
+deconv_k3_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int stride) {
+    const int D = in.D, H = in.H, W = in.W, Do = out.D, Ho = out.H, Wo = out.W, Cin = in.C, Cout = out.C;
+    const long long ivol = (long long)D * H * W, ovol = (long long)Do * Ho * Wo;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= ovol) return;
+    const int x = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int y = (int)(t % Ho), z = (int)(t / Ho);
+    // per-axis: which taps hit an input sample, and which one
+    int iz[3], iy[3], ix[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int tz = z + 1 - k, ty = y + 1 - k, tx = x + 1 - k;
+        iz[k] = (tz >= 0 && tz % stride == 0 && tz / stride < D) ? tz / stride : -1;
+        iy[k] = (ty >= 0 && ty % stride == 0 && ty / stride < H) ? ty / stride : -1;
+        ix[k] = (tx >= 0 && tx % stride == 0 && tx / stride < W) ? tx / stride : -1;
+    }
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+    const float* src = in.data + (long long)n * in.n_stride;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float* plane = src + (long long)ci * ivol;
+        const float* wrow = w + ((long long)ci * Cout + co0) * 27;
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+            float v = 0.0f;
+            if (iz[kz] >= 0 && iy[ky] >= 0 && ix[kx] >= 0) v = act(plane[((long long)iz[kz] * H + iy[ky]) * W + ix[kx]], a.x, a.y, a.z);
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+                if (co0 + j < Cout) acc[j] = fmaf(v, wrow[j * 27 + tap], acc[j]);
+        }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+        if (co0 + j < Cout) dst[(long long)(co0 + j) * ovol] = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // MaxPool3d(2) of act(in).  One thread per output voxel; the two x-neighbours come in as one float2.
 template <bool PAIR>
 __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
@@ -187,9 +273,10 @@ __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float 
     const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int c = blockIdx.y, n = blockIdx.z;
     if (idx >= DHW) return;
+    const bool has_b = b.data != nullptr;          // no second operand: out = lrelu(act(a)) (materialise a deferred tensor)
     const float4 na = load_nrm(a, n, c), nb = load_nrm(b, n, c);
     const float* pa = a.data + (long long)n * a.n_stride + (long long)c * DHW + idx;
-    const float* pb = b.data + (long long)n * b.n_stride + (long long)c * DHW + idx;
+    const float* pb = has_b ? b.data + (long long)n * b.n_stride + (long long)c * DHW + idx : pa;
     float* po = out.data + (long long)n * out.n_stride + (long long)c * DHW + idx;
     float va[VEC], vb[VEC];
     if (VEC == 4) {
@@ -202,7 +289,7 @@ __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float 
     float r[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-        const float y = act(va[v], na.x, na.y, na.z) + act(vb[v], nb.x, nb.y, nb.z);
+        const float y = act(va[v], na.x, na.y, na.z) + (has_b ? act(vb[v], nb.x, nb.y, nb.z) : 0.0f);
         r[v] = y > 0.0f ? y : y * slope;
     }
     if (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(r[0], r[1], r[2], r[3]);

@@ -1,0 +1,275 @@
+"""MONAI ``UNet`` on the MI355X kernels -- drop-in for ``monai.networks.nets.UNet`` (monai/networks/nets/unet.py:106-298).
+
+Same constructor signature, the same recursive module tree (``model.0`` down layer, ``model.1.submodule`` skip-connected
+sub-block, ``model.2`` up layer; ``ResidualUnit`` = ``conv.unit{i}`` + ``residual``) and therefore the same ``state_dict``
+keys/shapes and parameter-initialisation order as the reference.
+
+Inference engine over the C ABI: every conv output is stored raw with its InstanceNorm+PReLU folded into a per-(n, c)
+{alpha, beta, slope} record applied by the consumer on load (the PReLU weight is the slope); stride-1 3x3x3 convs run on the
+fp32-MFMA tiles, the strided encoder convs and the k3 transposed convs on direct kernels (UNet is 11.8 GFLOP per 96^3 window --
+bandwidth, not FLOPs, dominates it); residual adds are one fused kernel; ``torch.cat`` of the skip connection never runs (both
+producers write straight into the concat buffer)."""
+
+from __future__ import annotations
+
+import warnings
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, ops
+
+__all__ = ["UNet", "Unet"]
+
+
+# --------------------------------------------------------------------------- parameter containers (reference names)
+class _ADN(nn.Module):
+    def __init__(self, channels: int, affine: bool):
+        super().__init__()
+        self.N = nn.InstanceNorm3d(channels, affine=affine)
+        self.D = nn.Dropout(0.0)
+        self.A = nn.PReLU()
+
+
+class _Convolution(nn.Module):
+    def __init__(self, cin, cout, strides=1, bias=True, conv_only=False, is_transposed=False, affine=False):
+        super().__init__()
+        self.strides, self.is_transposed = int(strides), is_transposed
+        if is_transposed:
+            self.conv = nn.ConvTranspose3d(cin, cout, 3, stride=strides, padding=1, output_padding=strides - 1, bias=bias)
+        else:
+            self.conv = nn.Conv3d(cin, cout, 3, stride=strides, padding=1, bias=bias)
+        if not conv_only:
+            self.adn = _ADN(cout, affine)
+
+
+class _ResidualUnit(nn.Module):
+    def __init__(self, cin, cout, strides=1, subunits=2, bias=True, last_conv_only=False, affine=False):
+        super().__init__()
+        self.strides = int(strides)
+        self.conv = nn.Sequential()
+        self.residual = nn.Identity()
+        sc, ss = cin, strides
+        for su in range(max(1, subunits)):
+            self.conv.add_module(f"unit{su:d}", _Convolution(sc, cout, ss, bias, conv_only=last_conv_only and su == max(1, subunits) - 1, affine=affine))
+            sc, ss = cout, 1
+        if strides != 1 or cin != cout:
+            k = 3 if strides != 1 else 1
+            self.residual = nn.Conv3d(cin, cout, k, strides, 1 if k == 3 else 0, bias=bias)
+
+
+class _SkipConnection(nn.Module):
+    def __init__(self, submodule):
+        super().__init__()
+        self.submodule = submodule
+
+
+# --------------------------------------------------------------------------- the module
+class UNet(nn.Module):
+    def __init__(
+        self,
+        spatial_dims: int,
+        in_channels: int,
+        out_channels: int,
+        channels: Sequence[int],
+        strides: Sequence[int],
+        kernel_size: Sequence[int] | int = 3,
+        up_kernel_size: Sequence[int] | int = 3,
+        num_res_units: int = 0,
+        act: tuple | str = "PRELU",
+        norm: tuple | str = "INSTANCE",
+        dropout: float = 0.0,
+        bias: bool = True,
+        adn_ordering: str = "NDA",
+    ) -> None:
+        super().__init__()
+        if len(channels) < 2:
+            raise ValueError("the length of `channels` should be no less than 2.")
+        delta = len(strides) - (len(channels) - 1)
+        if delta < 0:
+            raise ValueError("the length of `strides` should equal to `len(channels) - 1`.")
+        if delta > 0:
+            warnings.warn(f"`len(strides) > len(channels) - 1`, the last {delta} values of strides will not be used.")
+        if isinstance(kernel_size, Sequence) and len(kernel_size) != spatial_dims:
+            raise ValueError("the length of `kernel_size` should equal to `dimensions`.")
+        if isinstance(up_kernel_size, Sequence) and len(up_kernel_size) != spatial_dims:
+            raise ValueError("the length of `up_kernel_size` should equal to `dimensions`.")
+        act_name = (act if isinstance(act, str) else act[0]).upper()
+        norm_name, norm_args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
+        if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or act_name != "PRELU"
+                or str(norm_name).upper() != "INSTANCE" or dropout != 0.0 or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
+            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance norm, no dropout, strides 1/2, 'NDA'")
+        self.dimensions, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
+        self.channels, self.strides, self.num_res_units, self.bias = tuple(channels), tuple(int(s) for s in strides), num_res_units, bias
+        self.kernel_size, self.up_kernel_size, self.act, self.norm, self.dropout, self.adn_ordering = kernel_size, up_kernel_size, act, norm, dropout, adn_ordering
+        affine = bool(norm_args.get("affine", False))
+        self.features = (channels[0],)
+
+        def down(cin, cout, s):
+            if num_res_units > 0:
+                return _ResidualUnit(cin, cout, s, num_res_units, bias, affine=affine)
+            return _Convolution(cin, cout, s, bias, affine=affine)
+
+        def up(cin, cout, s, is_top):
+            conv = _Convolution(cin, cout, s, bias, conv_only=is_top and num_res_units == 0, is_transposed=True, affine=affine)
+            if num_res_units > 0:
+                return nn.Sequential(conv, _ResidualUnit(cout, cout, 1, 1, bias, last_conv_only=is_top, affine=affine))
+            return conv
+
+        def create(inc, outc, chans, strs, is_top):
+            c, s = chans[0], strs[0]
+            if len(chans) > 2:
+                sub = create(c, c, chans[1:], strs[1:], False)
+                upc = c * 2
+            else:
+                sub = down(c, chans[1], 1)
+                upc = c + chans[1]
+            d = down(inc, c, s)
+            u = up(upc, outc, s, is_top)
+            return nn.Sequential(d, _SkipConnection(sub), u)
+
+        self.model = create(in_channels, out_channels, self.channels, self.strides, True)
+        self._packed: dict = {}
+        self._slopes: dict = {}
+        self._stats = None
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((id(conv), cfg))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, w))
+            self._packed[(id(conv), cfg)] = hit
+        return hit[1]
+
+    def _slope(self, prelu: nn.PReLU) -> float:
+        w = prelu.weight
+        if w.numel() != 1:
+            raise NotImplementedError("monai_amd.UNet: per-channel PReLU is not on the HIP path")
+        key = (w.data_ptr(), w._version)
+        hit = self._slopes.get(id(prelu))
+        if hit is None or hit[0] != key:
+            hit = (key, float(w.detach().cpu()))     # one host read per weight version
+            self._slopes[id(prelu)] = hit
+        return hit[1]
+
+    def _stats_buf(self, floats: int, device) -> torch.Tensor:
+        if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
+            self._stats = torch.empty(floats, dtype=torch.float32, device=device)
+        return self._stats
+
+    def _conv_unit(self, unit: _Convolution, x, x_nrm):
+        """`Convolution`: conv (+bias) of the (deferred) input -> (raw output, {alpha, beta, slope} record or None)."""
+        n, cin, d, h, w = x.shape
+        conv = unit.conv
+        s = unit.strides
+        if unit.is_transposed:
+            cout = conv.weight.shape[1]
+            out = torch.empty((n, cout, d * s, h * s, w * s), dtype=torch.float32, device=x.device)
+            ops.deconv_k3(x, x_nrm, conv.weight, conv.bias, out, s)
+            stats_tiles = 0
+        else:
+            cout = conv.weight.shape[0]
+            do, ho, wo = (d - 1) // s + 1, (h - 1) // s + 1, (w - 1) // s + 1
+            out = torch.empty((n, cout, do, ho, wo), dtype=torch.float32, device=x.device)
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w) if s == 1 else 0
+            stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and hasattr(unit, "adn")) else 0
+            if s == 1:
+                stats = self._stats_buf(n * cout * stats_tiles * 3, x.device) if stats_tiles else None
+                ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
+            else:
+                ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, s)
+        if not hasattr(unit, "adn"):
+            return out, None
+        if not stats_tiles:
+            stats_tiles = ops.instnorm_stat_tiles(*out.shape[2:])
+            stats = self._stats_buf(n * cout * stats_tiles * 3, x.device)
+            ops.instnorm_stats(out, stats)
+        nrm = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
+        inorm = unit.adn.N
+        ops.instnorm_finalize(stats, stats_tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, self._slope(unit.adn.A), nrm)
+        return out, nrm
+
+    def _residual_unit(self, ru: _ResidualUnit, x, x_nrm, dst):
+        """cx + res into `dst` (plain).  `x` may be deferred (raw + record): both the sub-units and the shortcut consume it."""
+        n = x.shape[0]
+        if isinstance(ru.residual, nn.Identity):
+            res, res_nrm = x, x_nrm
+        else:
+            rc = ru.residual
+            cout = rc.weight.shape[0]
+            s = ru.strides
+            if rc.kernel_size[0] == 3:
+                res = torch.empty((n, cout) + tuple((v - 1) // s + 1 for v in x.shape[2:]), dtype=torch.float32, device=x.device)
+                ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(rc, 0), rc.bias, res, s)
+            else:
+                res = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+                ops.conv1x1(x, x_nrm, rc.weight.view(cout, -1), rc.bias, res)
+            res_nrm = None
+        cx, cn = x, x_nrm
+        for unit in ru.conv:
+            cx, cn = self._conv_unit(unit, cx, cn)
+        return ops.add_act(cx, cn, res, res_nrm, 1.0, dst)
+
+    def _down(self, mod, x, dst):
+        if isinstance(mod, _ResidualUnit):
+            return self._residual_unit(mod, x, None, dst)
+        c, cn = self._conv_unit(mod, x, None)
+        return ops.add_act(c, cn, None, None, 1.0, dst)          # materialise norm + PReLU
+
+    def _up(self, mod, x, dst):
+        if isinstance(mod, nn.Sequential):
+            c, cn = self._conv_unit(mod[0], x, None)
+            return self._residual_unit(mod[1], c, cn, dst)
+        c, cn = self._conv_unit(mod, x, None)
+        if cn is None:
+            dst.copy_(c)
+            return dst
+        return ops.add_act(c, cn, None, None, 1.0, dst)
+
+    @staticmethod
+    def _out_channels(mod) -> int:
+        if isinstance(mod, _ResidualUnit):
+            return mod.conv[0].conv.weight.shape[0]
+        if isinstance(mod, nn.Sequential):
+            return mod[0].conv.weight.shape[1]
+        return mod.conv.weight.shape[1] if mod.is_transposed else mod.conv.weight.shape[0]
+
+    def _block(self, seq: nn.Sequential, x, dst):
+        down, skip, up = seq[0], seq[1], seq[2]
+        s = down.strides
+        n = x.shape[0]
+        sp = tuple((v - 1) // s + 1 for v in x.shape[2:])
+        cd = self._out_channels(down)
+        sub = skip.submodule
+        cs = self._out_channels(sub[2]) if isinstance(sub, nn.Sequential) and isinstance(sub[1], _SkipConnection) else self._out_channels(sub)
+        cat = torch.empty((n, cd + cs) + sp, dtype=torch.float32, device=x.device)      # SkipConnection: cat([x, sub(x)], 1)
+        d = self._down(down, x, cat[:, :cd])
+        if isinstance(sub, nn.Sequential) and isinstance(sub[1], _SkipConnection):
+            self._block(sub, d, cat[:, cd:])
+        else:
+            self._down(sub, d, cat[:, cd:])
+        return self._up(up, cat, dst)
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+        return self.forward_into(x, out)
+
+    @torch.no_grad()
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        _lib.require_device(x, out)
+        if self.training:
+            raise RuntimeError("monai_amd.UNet is an inference engine: call .eval() first")
+        total = 1
+        for s in self.strides[: len(self.channels) - 1]:
+            total *= s
+        if x.dim() != 5 or x.shape[1] != self.in_channels or any(int(v) % total for v in x.shape[2:]):
+            raise NotImplementedError(f"monai_amd.UNet: input (B,{self.in_channels},D,H,W) with edges divisible by {total} expected, got {tuple(x.shape)}")
+        self._block(self.model, x.contiguous(), out)
+        return out
+
+
+Unet = UNet

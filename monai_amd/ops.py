@@ -176,8 +176,9 @@ def separable_filter3d(src: torch.Tensor, kernels) -> torch.Tensor:
 def add_act(a, a_nrm, b, b_nrm, slope: float, out):
     """out = leaky_relu(act(a) + act(b), slope) -- residual join of UnetResBlock."""
     _lib.require_device(a, a_nrm, b, b_nrm, out)
-    ta, tb, to = _lib.tensor5(a, a_nrm), _lib.tensor5(b, b_nrm), _lib.tensor5(out)
-    _lib.lib().call("mh_add_act_f32", C.byref(ta), C.byref(tb), float(slope), C.byref(to), _s(a))
+    ta, to = _lib.tensor5(a, a_nrm), _lib.tensor5(out)
+    tb = None if b is None else _lib.tensor5(b, b_nrm)
+    _lib.lib().call("mh_add_act_f32", C.byref(ta), None if tb is None else C.byref(tb), float(slope), C.byref(to), _s(a))
     return out
 
 
@@ -189,4 +190,20 @@ def attention(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     b, s, _ = qkv.shape
     out = torch.empty((b, s, heads * 64), dtype=torch.float32, device=qkv.device)
     _lib.lib().call("mh_attention_f32", _lib.ptr(qkv), _lib.ptr(out), b, s, int(heads), 64, float(scale), _s(qkv))
+    return out
+
+
+def conv3d_k3_strided(x, x_nrm, packed_w0, bias, out, stride: int):
+    """out = conv3x3x3(act(x), stride, padding 1) + bias; packed_w0 = conv3d_k3_pack(0, weight)."""
+    _lib.require_device(x, x_nrm, packed_w0, bias, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv3d_k3_strided_f32", C.byref(xi), _lib.ptr(packed_w0), _lib.ptr(bias), C.byref(xo), int(stride), _s(x))
+    return out
+
+
+def deconv_k3(x, x_nrm, weight, bias, out, stride: int):
+    """out = conv_transpose3d(act(x), k=3, stride, padding 1, output_padding stride-1) + bias."""
+    _lib.require_device(x, x_nrm, weight, bias, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_deconv_k3_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), int(stride), _s(x))
     return out

@@ -31,6 +31,7 @@ _TARGETS = {
         "basicunet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),
     },
     "monai.networks.nets.unetr": {"UNETR": ("monai_amd.networks.nets.unetr", "UNETR")},
+    "monai.networks.nets.unet": {"UNet": ("monai_amd.networks.nets.unet", "UNet"), "Unet": ("monai_amd.networks.nets.unet", "UNet")},
     "monai.transforms.spatial.array": {
         "Spacing": ("monai_amd.transforms.spatial.array", "Spacing"),
         "SpatialResample": ("monai_amd.transforms.spatial.array", "SpatialResample"),

@@ -163,3 +163,54 @@ def case_unetr_vitb_vs_golden(device):
     mism = (y.argmax(1)[:, ::2, ::2, ::2].numpy().astype(np.uint8) != g["vitb_argmax_sub"]).mean()
     assert mism < 1e-4, mism
     return err, mism
+
+
+# ------------------------------------------------------------------------------------------ UNet
+UNET_CFGS = {   # tests/golden/make_golden_unet.py
+    "res2": dict(channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2, shape=(2, 1, 32, 32, 32), seed=4),
+    "plain": dict(channels=(8, 16, 32), strides=(2, 2), num_res_units=0, shape=(1, 1, 24, 16, 16), seed=5),
+    "mixed": dict(channels=(8, 16, 32), strides=(2, 1), num_res_units=1, shape=(1, 1, 16, 12, 20), seed=6),
+}
+
+
+def _full_digest(sd):
+    import hashlib
+
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def make_unet(name, device=None):
+    """The reference-seeded UNet of tests/golden/unet.npz: same seed -> same init; PReLU slopes set as the generator did."""
+    from monai_amd.networks.nets import UNet
+
+    c = UNET_CFGS[name]
+    torch.manual_seed(c["seed"])
+    net = UNet(spatial_dims=3, in_channels=1, out_channels=3, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"])
+    init = _full_digest(net.state_dict())
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if k.endswith("adn.A.weight"):
+                v.fill_(0.1 + 0.01 * (len(k) % 7))
+    net = net.eval()
+    return (net.to(device) if device is not None else net), init
+
+
+def case_unet_vs_golden(device, names=("res2", "plain", "mixed")):
+    """MONAI UNet (residual units / plain / stride-1 level) against the reference's own output: keys, init digest, logits."""
+    g = np.load(os.path.join(GOLDEN, "unet.npz"))
+    out = {}
+    for name in names:
+        net, init = make_unet(name)
+        assert list(net.state_dict().keys()) == list(g[f"{name}_keys"]), name
+        assert init == str(g[f"{name}_init_sha256"]), f"{name}: same seed must give the reference's weights"
+        net = net.to(device)
+        torch.manual_seed(100 + UNET_CFGS[name]["seed"])
+        x = torch.rand(UNET_CFGS[name]["shape"])
+        y = net(x.to(device)).cpu()
+        r = report(y, torch.from_numpy(g[f"{name}_out"]))
+        assert r["max_abs"] < LOGIT_TOL, (name, r)
+        out[name] = r["max_abs"]
+    return out

@@ -222,3 +222,29 @@ def case_add_act(device):
     ops.add_act(a.to(device), na.to(device), b.to(device), None, 0.01, out)
     y = _act(a, na) + b
     assert (out.cpu() - torch.where(y > 0, y, y * 0.01)).abs().max().item() < 2e-6
+
+
+def case_strided_conv_and_deconv_k3(device):
+    """UNet's strided conv (k3 s2 p1) and transposed conv (k3 s2 p1 op1), plus stride 1, vs ATen in fp64."""
+    gen = torch.Generator().manual_seed(12)
+    for stride, dims in ((2, (8, 10, 12)), (1, (5, 6, 7)), (2, (7, 9, 6))):
+        n, cin, cout = 2, 6, 20
+        x = torch.randn((n, cin) + dims, generator=gen)
+        nrm = _rand_nrm(n, cin, gen)
+        w = torch.randn((cout, cin, 3, 3, 3), generator=gen) * 0.1
+        b = torch.randn(cout, generator=gen) * 0.1
+        exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), b.double(), stride=stride, padding=1)
+        out = torch.full(tuple(exp.shape), float("nan"), device=device)
+        ops.conv3d_k3_strided(x.to(device), nrm.to(device), ops.conv3d_k3_pack(0, w.to(device)), b.to(device), out, stride)
+        assert (out.cpu().double() - exp).abs().max().item() < 2e-5, stride
+        wt = torch.randn((cin, cout, 3, 3, 3), generator=gen) * 0.1
+        exp = F.conv_transpose3d(_act(x.double(), nrm.double()), wt.double(), b.double(), stride=stride, padding=1, output_padding=stride - 1)
+        out = torch.full(tuple(exp.shape), float("nan"), device=device)
+        ops.deconv_k3(x.to(device), nrm.to(device), wt.to(device), b.to(device), out, stride)
+        assert (out.cpu().double() - exp).abs().max().item() < 2e-5, stride
+    # materialise a deferred tensor (add_act without a second operand)
+    a = torch.randn(2, 3, 4, 5, 8, generator=gen)
+    na = _rand_nrm(2, 3, gen)
+    out = torch.empty_like(a).to(device)
+    ops.add_act(a.to(device), na.to(device), None, None, 1.0, out)
+    assert (out.cpu() - _act(a, na)).abs().max().item() < 2e-6

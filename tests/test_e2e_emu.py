@@ -18,3 +18,8 @@ def test_sliding_window_net5_vs_reference(emu):
 
 def test_unetr_small_vs_reference(emu):
     print(ec.case_unetr_small_vs_golden("cpu"))
+
+
+def test_unet_vs_reference(emu):
+    """UNet with residual units, plain, and with a stride-1 level."""
+    print(ec.case_unet_vs_golden("cpu"))

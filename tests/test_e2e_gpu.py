@@ -131,3 +131,7 @@ def test_unetr_sliding_window_192():
     r = ec.report(y.cpu(), ref)
     print(r)
     assert r["max_abs"] < ec.LOGIT_TOL, r
+
+
+def test_unet_vs_reference():
+    print(ec.case_unet_vs_golden(DEV))

@@ -98,3 +98,7 @@ def test_conv_mfma_cout_padding(emu):
     from monai_amd import ops
 
     assert ops.conv3d_k3_select(32, 16, 96, 96, 96) >= 1 and ops.conv3d_k3_select(32, 5, 96, 96, 96) >= 1
+
+
+def test_strided_conv_and_deconv_k3(emu):
+    kc.case_strided_conv_and_deconv_k3("cpu")

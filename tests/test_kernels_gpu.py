@@ -89,3 +89,7 @@ def test_conv_mfma_cout_padding():
     kc.case_conv3d(DEV, 7, 2, 1, 16, (4, 8, 32), tol=5e-5)
     kc.case_conv3d(DEV, 10, 1, 32, 16, (6, 10, 24), tol=5e-5)
     kc.case_conv3d(DEV, 13, 1, 8, 48, (3, 6, 6), tol=5e-5)
+
+
+def test_strided_conv_and_deconv_k3():
+    kc.case_strided_conv_and_deconv_k3(DEV)

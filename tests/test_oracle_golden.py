@@ -227,3 +227,52 @@ def test_config0_end_to_end_bitwise_vs_reference(golden_dir):
         y = osw.sliding_window_inference(x, (32, 32, 32), 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5,
                                          mode="gaussian")
     assert np.array_equal(y.numpy(), g["cfg0_out"])
+
+
+# ------------------------------------------------------------------------------------------ UNet / UNETR oracles
+def _sha(sd, skip=()):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        if k.endswith(tuple(skip)) if skip else False:
+            continue
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", ["res2", "plain", "mixed"])
+def test_unet_oracle_bitwise_vs_reference(golden_dir, name):
+    """oracle/unet.py against tests/golden/unet.npz (made by the real monai.networks.nets.UNet): keys, init, logits."""
+    from e2e_cases import UNET_CFGS
+    from oracle import unet as ou
+
+    g = _load(golden_dir, "unet.npz")
+    c = UNET_CFGS[name]
+    torch.manual_seed(c["seed"])
+    sd = ou.make_unet_state(1, 3, c["channels"], c["strides"], c["num_res_units"])
+    assert list(sd.keys()) == list(g[f"{name}_keys"])
+    assert _sha(sd) == str(g[f"{name}_init_sha256"])
+    for k, v in sd.items():
+        if k.endswith("adn.A.weight"):
+            v.fill_(0.1 + 0.01 * (len(k) % 7))
+    torch.manual_seed(100 + c["seed"])
+    x = torch.rand(c["shape"])
+    with torch.no_grad():
+        y = ou.unet_forward(sd, x, c["channels"], c["strides"], c["num_res_units"])
+    assert np.array_equal(y.numpy(), g[f"{name}_out"])
+
+
+def test_unetr_oracle_small_vs_reference(golden_dir):
+    """oracle/unetr.py against tests/golden/unetr.npz (real monai UNETR, 32^3, hidden 128): init digest and logits."""
+    from oracle import unetr as our
+
+    g = _load(golden_dir, "unetr.npz")
+    torch.manual_seed(2)
+    sd = our.make_unetr_state(1, 3, (32, 32, 32), 16, 128, 256)
+    assert _sha(sd, skip=("position_embeddings",)) == str(g["small_state_sha256"])
+    np.testing.assert_allclose(sd["vit.patch_embedding.position_embeddings"].flatten()[::13].numpy(), g["small_pos_sample"], rtol=2e-6, atol=1e-9)
+    torch.manual_seed(32)
+    x = torch.rand(2, 1, 32, 32, 32)
+    with torch.no_grad():
+        y = our.unetr_forward(sd, x, heads=2)
+    assert np.abs(y.numpy() - g["small_out"]).max() < 1e-5

@@ -72,3 +72,27 @@ def test_reference_checkpoint_loads_into_amd_basic_unet(monai_ref):
     ours2 = OurNet(spatial_dims=3, in_channels=1, out_channels=5)   # same seed -> same initial weights as the reference
     for (k, a), (_, b) in zip(ref.state_dict().items(), ours2.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("which", ["UNet", "UNETR"])
+def test_reference_checkpoint_loads_into_amd_unet_and_unetr(monai_ref, which):
+    import monai_amd.patch as patch
+    from monai.bundle import ConfigParser
+
+    if which == "UNet":
+        from monai.networks.nets import UNet as RefNet
+        from monai_amd.networks.nets.unet import UNet as OurNet
+        kw = dict(spatial_dims=3, in_channels=1, out_channels=2, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2)
+    else:
+        from monai.networks.nets import UNETR as RefNet
+        from monai_amd.networks.nets.unetr import UNETR as OurNet
+        kw = dict(in_channels=1, out_channels=3, img_size=(32, 32, 32), feature_size=16, hidden_size=128, mlp_dim=256, num_heads=2)
+    ref = RefNet(**kw)
+    ours = OurNet(**kw)
+    missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected
+    assert list(ours.state_dict().keys()) == list(ref.state_dict().keys())
+    patch.install()
+    net = ConfigParser({"network": {"_target_": which, **{k: list(v) if isinstance(v, tuple) else v for k, v in kw.items()}}}).get_parsed_content("network")
+    assert isinstance(net, OurNet)
+    patch.uninstall()
