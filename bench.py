@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
     ap.add_argument("--cpu-windows", type=int, default=12, help="windows timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr"],
-                    help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path)")
+    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr", "unet"],
+                    help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -103,7 +103,7 @@ def main():
 
     from monai_amd import _prof, parallel
     from monai_amd.inferers import SlidingWindowInferer
-    from monai_amd.networks.nets import UNETR, BasicUNet
+    from monai_amd.networks.nets import UNETR, BasicUNet, UNet
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -114,6 +114,8 @@ def main():
     torch.manual_seed(1)
     if args.net == "unetr":
         net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
+    elif args.net == "unet":
+        net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2).eval().to(dev)
     else:
         net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
     torch.manual_seed(0)
@@ -178,7 +180,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{'UNETR ViT-B/16' if args.net == 'unetr' else 'BasicUNet'} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
+                "workload": f"{ {'unetr': 'UNETR ViT-B/16', 'unet': 'UNet 16-256 res2', 'basicunet': 'BasicUNet'}[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
                             f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 25 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },

@@ -352,6 +352,35 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
     if (axis_aligned && workspace) {
         const unsigned tb = blocks_for(Do + Ho + Wo);
         const unsigned nblk = (unsigned)(cdiv(Wo, RS_TOX) * cdiv(Ho, RS_TOY) * cdiv(Do, RS_TOZ));
+        // trilinear without reflection and a tap box that fits the LDS plane (conservative bound from the scales): the
+        // z-streaming kernel; everything else (nearest, reflection, strong in-plane down-sampling) the per-block kernel
+        const double sy = m[5] < 0 ? -m[5] : m[5], sx = m[10] < 0 ? -m[10] : m[10];
+        const double box_bound = ((double)RZ_TOY * sy + 3.0) * ((double)RZ_TOX * sx + 3.0);
+        const bool stream_ok = mode == RS_LINEAR && pad != RS_REFLECTION && box_bound <= 4096.0;
+        if (stream_ok) {
+            const long long tiles = (long long)cdiv(Wo, RZ_TOX) * cdiv(Ho, RZ_TOY);
+            int nchunk = (int)((2048 + tiles * NC - 1) / (tiles * NC));
+            if (nchunk > cdiv(Do, 8)) nchunk = cdiv(Do, 8);
+            if (nchunk < 1) nchunk = 1;
+            const int zchunk = cdiv(Do, nchunk);
+            nchunk = cdiv(Do, zchunk);
+            const long long nwg = tiles * nchunk * NC;
+            if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "affine_resample: problem too large for one launch");
+            const dim3 g((unsigned)nwg);
+            const bool small = box_bound <= 2048.0;
+            if (compute_f64) {
+                AxisTap<double>* tab = static_cast<AxisTap<double>*>(workspace);
+                hipLaunchKernelGGL((resample_axis_table_kernel<double>), dim3(tb), dim3(256), 0, s, tab, a);
+                if (small) hipLaunchKernelGGL((separable_resample_stream_kernel<double, 8>), g, dim3(256), 0, s, src, dst, (const AxisTap<double>*)tab, a, zchunk, nchunk);
+                else hipLaunchKernelGGL((separable_resample_stream_kernel<double, 16>), g, dim3(256), 0, s, src, dst, (const AxisTap<double>*)tab, a, zchunk, nchunk);
+            } else {
+                AxisTap<float>* tab = static_cast<AxisTap<float>*>(workspace);
+                hipLaunchKernelGGL((resample_axis_table_kernel<float>), dim3(tb), dim3(256), 0, s, tab, a);
+                if (small) hipLaunchKernelGGL((separable_resample_stream_kernel<float, 8>), g, dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a, zchunk, nchunk);
+                else hipLaunchKernelGGL((separable_resample_stream_kernel<float, 16>), g, dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a, zchunk, nchunk);
+            }
+            return launched("separable_resample_stream");
+        }
         if (compute_f64) {
             AxisTap<double>* tab = static_cast<AxisTap<double>*>(workspace);
             hipLaunchKernelGGL((resample_axis_table_kernel<double>), dim3(tb), dim3(256), 0, s, tab, a);
@@ -445,7 +474,17 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     memcpy(a.kz + (rk - kz_n) / 2, kz, sizeof(float) * kz_n);
     memcpy(a.ky + (rk - ky_n) / 2, ky, sizeof(float) * ky_n);
     memcpy(a.kx + (rk - kx_n) / 2, kx, sizeof(float) * kx_n);
-    const dim3 grid((unsigned)(cdiv(W, GS_TX) * cdiv(H, GS_TY)), (unsigned)NC);
+    // enough workgroups to keep ~8 per CU in flight: cut z into chunks (each re-filters rk-1 halo planes)
+    const long long tiles = (long long)cdiv(W, GS_TX) * cdiv(H, GS_TY);
+    const int min_chunk = 4 * rk > 16 ? 4 * rk : 16;
+    int nchunk = (int)((2048 + tiles * NC - 1) / (tiles * NC));
+    if (nchunk > cdiv(D, min_chunk)) nchunk = cdiv(D, min_chunk);
+    if (nchunk < 1) nchunk = 1;
+    a.zchunk = cdiv(D, nchunk);
+    a.nchunk = cdiv(D, a.zchunk);
+    const long long nwg = tiles * a.nchunk * NC;
+    if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: problem too large for one launch");
+    const dim3 grid((unsigned)nwg);
     hipStream_t s = (hipStream_t)stream;
     switch (rk) {
         case 3: hipLaunchKernelGGL((gauss3d_stream_kernel<3>), grid, dim3(256), 0, s, src, dst, a); break;

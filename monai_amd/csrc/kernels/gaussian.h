@@ -21,6 +21,7 @@ constexpr int GS_TX = 64, GS_TY = 16, GS_P = (GS_TX * GS_TY) / 256;
 
 struct GaussArgs {
     int NC, D, H, W;
+    int zchunk, nchunk;                                        // the z axis is cut into nchunk runs of zchunk output planes
     float kz[GS_MAX_TAPS], ky[GS_MAX_TAPS], kx[GS_MAX_TAPS];   // each zero-padded symmetrically to the kernel's RK taps
 };
 
@@ -38,9 +39,16 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
     __shared__ __attribute__((aligned(16))) float in_s[INH * INW];
     __shared__ __attribute__((aligned(16))) float mid_s[INH * GS_TX];
     const int tid = threadIdx.x;
-    const int tiles_x = (a.W + GS_TX - 1) / GS_TX;
-    const int tx0 = (int)(blockIdx.x % tiles_x) * GS_TX, ty0 = (int)(blockIdx.x / tiles_x) * GS_TY;
-    const int nc = blockIdx.y;
+    // 1-D launch, XCD-aware: each XCD's L2 gets a contiguous run of (tile, chunk, volume) work items, so the in-plane
+    // halo shared by neighbouring tiles is an L2 hit instead of a second HBM read.
+    const int tiles_x = (a.W + GS_TX - 1) / GS_TX, tiles = tiles_x * ((a.H + GS_TY - 1) / GS_TY);
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % (unsigned)tiles);
+    lid /= (unsigned)tiles;
+    const int chunk = (int)(lid % (unsigned)a.nchunk), nc = (int)(lid / (unsigned)a.nchunk);
+    const int tx0 = (tile % tiles_x) * GS_TX, ty0 = (tile / tiles_x) * GS_TY;
+    const int zs = chunk * a.zchunk, ze = min(zs + a.zchunk, a.D);      // output planes of this workgroup
+    const int zfirst = max(zs - HR, 0), zend = min(ze + HR, a.D + HR);  // filtered planes it needs (zero outside the volume)
     const long long plane = (long long)a.H * a.W;
     const float* vol = src + (long long)nc * a.D * plane;
     float* ovol = dst + (long long)nc * a.D * plane;
@@ -59,7 +67,7 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
     }
     float pre[NLOAD];
 #pragma unroll
-    for (int j = 0; j < NLOAD; ++j) pre[j] = vol[goff[j]];
+    for (int j = 0; j < NLOAD; ++j) pre[j] = vol[(long long)zfirst * plane + goff[j]];
 
     float ring[GS_P][RK];
 #pragma unroll
@@ -67,7 +75,7 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < RK; ++k) ring[p][k] = 0.0f;
 
-    for (int z = 0; z < a.D + HR; ++z) {
+    for (int z = zfirst; z < zend; ++z) {
         const bool live = z < a.D;          // beyond the volume the filtered plane is exactly zero (zero padding)
         if (live) {
 #pragma unroll
@@ -77,7 +85,7 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
             }
         }
         __syncthreads();
-        if (z + 1 < a.D) {                  // next plane's loads fly while this plane is filtered
+        if (z + 1 < zend && z + 1 < a.D) {                  // next plane's loads fly while this plane is filtered
             const float* pl = vol + (long long)(z + 1) * plane;
 #pragma unroll
             for (int j = 0; j < NLOAD; ++j) pre[j] = pl[goff[j]];
@@ -121,7 +129,7 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
             for (int k = 0; k < RK - 1; ++k) ring[p][k] = ring[p][k + 1];
             ring[p][RK - 1] = v;
             const int gy = ty0 + y4 + p;
-            if (zo >= 0 && gy < a.H && gx < a.W) {
+            if (zo >= zs && gy < a.H && gx < a.W) {
                 float acc = 0.0f;
 #pragma unroll
                 for (int k = 0; k < RK; ++k) acc = acc + a.kz[k] * ring[p][k];

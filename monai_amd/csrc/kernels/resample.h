@@ -73,6 +73,11 @@ __device__ __forceinline__ AxisTap<T> rs_axis(double coord, int size, int mode, 
     return t;
 }
 
+// Two-term combine of one interpolation axis: a0*w0 + a1*w1 with the second product fused (one rounding less than the
+// separate multiply-add; every kernel of this file uses this same form, so they agree bit for bit with each other).
+__device__ __forceinline__ double rs_comb(double a0, double w0, double a1, double w1) { return fma(a1, w1, a0 * w0); }
+__device__ __forceinline__ float rs_comb(float a0, float w0, float a1, float w1) { return fmaf(a1, w1, a0 * w0); }
+
 // value = sum over the (up to) 8 corners of v * wx * wy * wz, combined axis by axis (x, then y, then z).
 template <typename T, typename IDX>
 __device__ __forceinline__ void rs_gather(const float* __restrict__ src, float* __restrict__ dst, int C, IDX ivol, IDX ovol, IDX oidx,
@@ -97,10 +102,10 @@ __device__ __forceinline__ void rs_gather(const float* __restrict__ src, float* 
         for (int r = 0; r < 4; ++r) {
             const bool rk = zok[r >> 1] && yok[r & 1];
             const T a0 = (rk && xok[0]) ? (T)v[2 * r] : (T)0, a1 = (rk && xok[1]) ? (T)v[2 * r + 1] : (T)0;
-            row[r] = a0 * tx.w0 + a1 * tx.w1;
+            row[r] = rs_comb(a0, tx.w0, a1, tx.w1);
         }
-        const T p0 = row[0] * ty.w0 + row[1] * ty.w1, p1 = row[2] * ty.w0 + row[3] * ty.w1;
-        dst[(IDX)c * ovol + oidx] = (float)(p0 * tz.w0 + p1 * tz.w1);
+        const T p0 = rs_comb(row[0], ty.w0, row[1], ty.w1), p1 = rs_comb(row[2], ty.w0, row[3], ty.w1);
+        dst[(IDX)c * ovol + oidx] = (float)rs_comb(p0, tz.w0, p1, tz.w1);
     }
 }
 
@@ -277,15 +282,238 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
                         if (ok) f = staged ? box[((z - lz) * ey + (y - ly)) * ex + xo[k & 1]] : p[((long long)z * a.Hi + y) * a.Wi + x];
                         v[k] = (T)f;
                     }
-                    const T r0 = v[0] * tx.w0 + v[1] * tx.w1, r1 = v[2] * tx.w0 + v[3] * tx.w1;
-                    const T r2 = v[4] * tx.w0 + v[5] * tx.w1, r3 = v[6] * tx.w0 + v[7] * tx.w1;
-                    const T p0 = r0 * ty.w0 + r1 * ty.w1, p1 = r2 * ty.w0 + r3 * ty.w1;
-                    res = (float)(p0 * tz.w0 + p1 * tz.w1);
+                    const T r0 = rs_comb(v[0], tx.w0, v[1], tx.w1), r1 = rs_comb(v[2], tx.w0, v[3], tx.w1);
+                    const T r2 = rs_comb(v[4], tx.w0, v[5], tx.w1), r3 = rs_comb(v[6], tx.w0, v[7], tx.w1);
+                    const T p0 = rs_comb(r0, ty.w0, r1, ty.w1), p1 = rs_comb(r2, ty.w0, r3, ty.w1);
+                    res = (float)rs_comb(p0, tz.w0, p1, tz.w1);
                 }
                 dst[(long long)c * ovol + oidx] = res;
             }
         }
     }
+}
+
+// Streaming variant for trilinear, non-reflecting, axis-aligned affines (the Spacingd case): trilinear interpolation
+// factors into an in-plane (x, then y) interpolation of a SOURCE plane followed by a two-plane z combine.  A workgroup
+// owns a 16 x 128 (oy, ox) output tile and marches along oz over one z-chunk:
+//   source plane z: the tile's bounding box of (y, x) taps -> LDS (row-contiguous loads, prefetched into registers one
+//   plane ahead, double-buffered: one barrier per plane) -> each thread interpolates its 8 outputs in-plane (4 LDS reads
+//   at addresses fixed for the whole march + 3 combines each) into a register plane; the last two planes stay in
+//   registers, an output plane is one more combine per voxel.  Every source plane is interpolated once per tile (the old
+//   kernels redo the in-plane work and all index arithmetic for every output voxel): ~30 VALU instructions per output
+//   instead of ~170, which is what bounded the per-voxel kernels (they were VALU-issue bound, not HBM bound).
+// Arithmetic is the same rs_comb chain (x, y, z) on the same values as the other kernels: identical results.
+constexpr int RZ_TOY = 16, RZ_TOX = 128;
+
+template <typename T> struct RzTile {     // per-thread constants of the march
+    int ad[4][2];                         // LDS address of the (y0, x0) corner of output (row j, column h)
+    int adn[4][2];                        // ... of its (y1, x0) corner in the interior path (= ad + row pitch)
+    int dx[2], dy[4];                     // boundary tiles: address steps to the x1 / y1 corner (0 when that tap is dropped or clamped)
+    T wx0[2], wx1[2], wy0[4], wy1[4];
+    unsigned okm;                         // boundary tiles: bit (j*2+h)*4 + corner set = corner contributes
+};
+
+// In-plane (x, then y) interpolation of the staged source plane at this thread's 8 outputs.  Interior tiles (every tap
+// valid, so x1 = x0 + 1 and y1 = y0 + 1): two paired LDS reads per output at addresses fixed for the whole march.
+template <typename T, bool MASKED>
+__device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, const RzTile<T>& t, T (&P)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[4];
+            if (MASKED) {
+                const int a0 = t.ad[j][h], a1 = a0 + t.dy[j];
+                v[0] = box[a0]; v[1] = box[a0 + t.dx[h]]; v[2] = box[a1]; v[3] = box[a1 + t.dx[h]];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = ((t.okm >> ((j * 2 + h) * 4 + k)) & 1u) ? v[k] : 0.0f;
+            } else {
+                const float* b0 = box + t.ad[j][h];
+                const float* b1 = box + t.adn[j][h];
+                v[0] = b0[0]; v[1] = b0[1]; v[2] = b1[0]; v[3] = b1[1];
+            }
+            const T r0 = rs_comb((T)v[0], t.wx0[h], (T)v[1], t.wx1[h]), r1 = rs_comb((T)v[2], t.wx0[h], (T)v[3], t.wx1[h]);
+            P[j * 2 + h] = rs_comb(r0, t.wy0[j], r1, t.wy1[j]);
+        }
+}
+
+// NLOAD = staged floats per thread and plane (box capacity 256 * NLOAD; chosen by the launcher from the scales)
+template <typename T, int NLOAD>
+__global__ void __launch_bounds__(256)
+separable_resample_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a,
+                                 int zchunk, int nchunk) {
+    constexpr int CAP = NLOAD * 256;
+    __shared__ float box[2][CAP];
+    __shared__ int lim[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbx = (a.Wo + RZ_TOX - 1) / RZ_TOX, nby = (a.Ho + RZ_TOY - 1) / RZ_TOY, tiles = nbx * nby;
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);        // neighbouring tiles share an XCD's L2 (their boxes overlap)
+    const int tile = (int)(lid % (unsigned)tiles);
+    lid /= (unsigned)tiles;
+    const int chunk = (int)(lid % (unsigned)nchunk), c = (int)(lid / (unsigned)nchunk);
+    const int ox0 = (tile % nbx) * RZ_TOX, oy0 = (tile / nbx) * RZ_TOY;
+    const int ny = min(RZ_TOY, a.Ho - oy0), nx = min(RZ_TOX, a.Wo - ox0);
+    const int oz_s = chunk * zchunk, oz_e = min(oz_s + zchunk, a.Do);
+    const long long iplane = (long long)a.Hi * a.Wi, oplane = (long long)a.Ho * a.Wo;
+    const float* p = src + (long long)c * a.Di * iplane;
+    float* q = dst + (long long)c * a.Do * oplane;
+
+    // bounding box of the tile's y and x taps
+    if (tid == 0) lim[4] = 0;
+    if (tid < 2) {
+        const int n = tid == 0 ? ny : nx;
+        const int base = tid == 0 ? a.Do + oy0 : a.Do + a.Ho + ox0;
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = 0; i < n; ++i) {
+            const AxisTap<T> e = tab[base + i];
+            if (e.i0 >= 0) { lo = min(lo, e.i0); hi = max(hi, e.i0); }
+            if (e.i1 >= 0) { lo = min(lo, e.i1); hi = max(hi, e.i1); }
+        }
+        lim[2 * tid] = lo; lim[2 * tid + 1] = hi;
+    }
+    __syncthreads();
+    const int ly = lim[0], lx = lim[2];
+    const int ey = lim[1] - ly + 1, ex = lim[3] - lx + 1;
+    const bool any = lim[1] >= 0 && lim[3] >= 0;      // otherwise a whole axis of the tile samples outside the volume
+    const bool staged = any && ey * ex <= CAP;
+
+    if (!staged) {
+        // every tap of one axis outside the volume (all zeros), or a box larger than the LDS plane: per-voxel gathers
+        for (int oz = oz_s; oz < oz_e; ++oz) {
+            const AxisTap<T> tz = tab[oz];
+            for (int j = 0; j < 4; ++j)
+                for (int h = 0; h < 2; ++h) {
+                    const int jy = wave + 4 * j, jx = lane + 64 * h;
+                    if (jy >= ny || jx >= nx) continue;
+                    const AxisTap<T> ty = tab[a.Do + oy0 + jy], tx = tab[a.Do + a.Ho + ox0 + jx];
+                    const int zi[2] = {tz.i0, tz.i1}, yi[2] = {ty.i0, ty.i1}, xi[2] = {tx.i0, tx.i1};
+                    T v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int z = zi[k >> 2], y = yi[(k >> 1) & 1], x = xi[k & 1];
+                        v[k] = (z >= 0 && y >= 0 && x >= 0) ? (T)p[(long long)z * iplane + (long long)y * a.Wi + x] : (T)0;
+                    }
+                    const T r0 = rs_comb(v[0], tx.w0, v[1], tx.w1), r1 = rs_comb(v[2], tx.w0, v[3], tx.w1);
+                    const T r2 = rs_comb(v[4], tx.w0, v[5], tx.w1), r3 = rs_comb(v[6], tx.w0, v[7], tx.w1);
+                    const T p0 = rs_comb(r0, ty.w0, r1, ty.w1), p1 = rs_comb(r2, ty.w0, r3, ty.w1);
+                    q[(long long)oz * oplane + (long long)(oy0 + jy) * a.Wo + ox0 + jx] = (float)rs_comb(p0, tz.w0, p1, tz.w1);
+                }
+        }
+        return;
+    }
+
+    // per-thread march constants: columns lane and lane + 64, rows wave, wave + 4, wave + 8, wave + 12
+    RzTile<T> t;
+    t.okm = 0u;
+    bool bad = false;
+    {
+        int xa[2], ya[4];
+        bool xok[2][2], yok[4][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const AxisTap<T> e = tab[a.Do + a.Ho + ox0 + min(lane + 64 * h, nx - 1)];
+            xok[h][0] = e.i0 >= 0; xok[h][1] = e.i1 >= 0;
+            xa[h] = (xok[h][0] ? e.i0 : xok[h][1] ? e.i1 : lx) - lx;
+            t.dx[h] = (xok[h][0] && xok[h][1]) ? e.i1 - e.i0 : 0;
+            t.wx0[h] = e.w0; t.wx1[h] = e.w1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const AxisTap<T> e = tab[a.Do + oy0 + min(wave + 4 * j, ny - 1)];
+            yok[j][0] = e.i0 >= 0; yok[j][1] = e.i1 >= 0;
+            ya[j] = (yok[j][0] ? e.i0 : yok[j][1] ? e.i1 : ly) - ly;
+            t.dy[j] = (yok[j][0] && yok[j][1]) ? (e.i1 - e.i0) * ex : 0;
+            t.wy0[j] = e.w0; t.wy1[j] = e.w1;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                t.ad[j][h] = ya[j] * ex + xa[h];
+                t.adn[j][h] = t.ad[j][h] + ex;
+                const unsigned m = (unsigned)(yok[j][0] && xok[h][0]) | (unsigned)(yok[j][0] && xok[h][1]) << 1 |
+                                   (unsigned)(yok[j][1] && xok[h][0]) << 2 | (unsigned)(yok[j][1] && xok[h][1]) << 3;
+                t.okm |= m << ((j * 2 + h) * 4);
+                bad = bad || m != 15u;
+            }
+    }
+    if (bad) lim[4] = 1;            // benign race: every writer stores the same value
+    __syncthreads();
+    const bool masked = lim[4] != 0;
+
+    // loader: element i = tid + 256 j of the box, row-major with pitch ex
+    int goff[NLOAD];
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+        const int i = tid + 256 * j;
+        const int r = i / ex, col = i - r * ex;
+        goff[j] = i < ey * ex ? (ly + r) * a.Wi + lx + col : -1;
+    }
+    float pre[NLOAD];
+    int pre_z = -1, buf = 0;
+    const int dir = a.m[0] < 0.0 ? -1 : 1;
+    T Pa[8], Pb[8];
+    int cur0 = -1, cur1 = -1;
+
+#define RZ_LOAD_PLANE(Z)                                                                        \
+    {                                                                                           \
+        const float* pl_ = p + (long long)(Z) * iplane;                                         \
+        _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) pre[j] = goff[j] >= 0 ? pl_[goff[j]] : 0.0f; \
+        pre_z = (Z);                                                                            \
+    }
+#define RZ_COMPUTE_PLANE(Z, P)                                                                  \
+    {                                                                                           \
+        if (pre_z != (Z)) RZ_LOAD_PLANE(Z)                                                      \
+        _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) if (goff[j] >= 0) box[buf][tid + 256 * j] = pre[j]; \
+        __syncthreads();                                                                        \
+        const int zn_ = (Z) + dir;                                                              \
+        if (zn_ >= 0 && zn_ < a.Di) RZ_LOAD_PLANE(zn_)                                          \
+        if (masked) rz_interp_plane<T, true>(box[buf], t, P);                                   \
+        else rz_interp_plane<T, false>(box[buf], t, P);                                         \
+        buf ^= 1;                                                                               \
+    }
+
+    for (int oz = oz_s; oz < oz_e; ++oz) {
+        const AxisTap<T> tz = tab[oz];
+        const bool z0ok = tz.i0 >= 0, z1ok = tz.i1 >= 0;
+        if (z0ok || z1ok) {
+            const int z0 = z0ok ? tz.i0 : tz.i1, z1 = z1ok ? tz.i1 : tz.i0;
+            if (z1 != cur1 && z1 == cur0) {          // decreasing table: the old lower plane becomes the upper one
+#pragma unroll
+                for (int k = 0; k < 8; ++k) Pb[k] = Pa[k];
+                cur1 = cur0;
+            }
+            if (z0 != cur0) {
+                if (z0 == cur1) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) Pa[k] = Pb[k];
+                } else RZ_COMPUTE_PLANE(z0, Pa)
+                cur0 = z0;
+            }
+            if (z1 != cur1) {
+                if (z1 == cur0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) Pb[k] = Pa[k];
+                } else RZ_COMPUTE_PLANE(z1, Pb)
+                cur1 = z1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int jy = wave + 4 * j, jx = lane + 64 * h;
+                if (jy >= ny || jx >= nx) continue;
+                float res = 0.0f;
+                if (z0ok || z1ok) {
+                    const T p0 = z0ok ? Pa[j * 2 + h] : (T)0, p1 = z1ok ? Pb[j * 2 + h] : (T)0;
+                    res = (float)rs_comb(p0, tz.w0, p1, tz.w1);
+                }
+                q[(long long)oz * oplane + (long long)(oy0 + jy) * a.Wo + ox0 + jx] = res;
+            }
+    }
+#undef RZ_LOAD_PLANE
+#undef RZ_COMPUTE_PLANE
 }
 
 // Dense grid: coords [3][Do][Ho][Wo] (planes z, y, x), fp32 or fp64 (GT); a per-axis affine (ga, gb) turns the stored

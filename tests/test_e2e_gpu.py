@@ -135,3 +135,24 @@ def test_unetr_sliding_window_192():
 
 def test_unet_vs_reference():
     print(ec.case_unet_vs_golden(DEV))
+
+
+def test_unet_sliding_window_vs_oracle():
+    """MONAI UNet (16..256, 2 residual units) through the SlidingWindowInferer: 8 windows of 96^3 vs the CPU oracle."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.networks.nets import UNet
+    from oracle import unet as ou
+
+    ch, st = (16, 32, 64, 128, 256), (2, 2, 2, 2)
+    torch.manual_seed(7)
+    net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=ch, strides=st, num_res_units=2).eval()
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    torch.manual_seed(34)
+    x = torch.rand(1, 1, 144, 96, 144)
+    y = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")(x.to(DEV), net)
+    with torch.no_grad():
+        ref = osw.sliding_window_inference(x, (96, 96, 96), 4, lambda w: ou.unet_forward(sd, w, ch, st, 2), overlap=0.5, mode="gaussian")
+    r = ec.report(y.cpu(), ref)
+    print(r)
+    assert r["max_abs"] < ec.LOGIT_TOL, r

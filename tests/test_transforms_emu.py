@@ -84,3 +84,7 @@ def test_gaussian_smooth(emu):
 
 def test_separable_fast_path_equals_general(emu):
     tc.case_separable_vs_general("cpu")
+
+
+def test_gaussian_z_chunks(emu):
+    tc.case_gaussian_z_chunks("cpu")

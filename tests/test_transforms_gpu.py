@@ -102,3 +102,7 @@ def test_gaussian_smooth_128_vs_torch():
 
 def test_separable_fast_path_equals_general():
     tc.case_separable_vs_general(DEV)
+
+
+def test_gaussian_z_chunks():
+    tc.case_gaussian_z_chunks(DEV)

@@ -296,6 +296,28 @@ def case_gaussian_smooth(device):
     np.testing.assert_allclose(y.cpu().numpy(), g["gf_out"], atol=1e-5, rtol=1e-5)
 
 
+def case_gaussian_z_chunks(device):
+    """Long z axis: the streaming kernel cuts z into chunks with re-filtered halo planes; vs a zero-padded fp64 conv."""
+    import torch.nn.functional as F
+
+    from monai_amd import ops
+    from monai_amd.networks.layers import gaussian_1d
+
+    torch.manual_seed(21)
+    for shape, sig in (((2, 90, 20, 70), (1.0, 1.0, 1.0)), ((1, 133, 17, 9), (0.5, 1.0, 2.0)), ((1, 50, 16, 64), (0.4, 0.4, 0.4))):
+        x = torch.rand(shape)
+        ks = [gaussian_1d(torch.tensor(s)) for s in sig]
+        ref = x.double()[None]
+        for ax, k in enumerate(ks):
+            shp = [1, 1, 1, 1, 1]
+            shp[2 + ax] = k.numel()
+            pad = [0, 0, 0]
+            pad[ax] = k.numel() // 2
+            ref = F.conv3d(ref.transpose(0, 1), k.double().reshape(shp), padding=pad).transpose(0, 1)
+        y = ops.separable_filter3d(x.to(device), [k.numpy() for k in ks])
+        assert (y.cpu().double() - ref[0]).abs().max().item() < 2e-6, shape
+
+
 def case_separable_vs_general(device):
     """The axis-aligned fast path (per-axis tap tables + LDS-staged source box, with its global-gather fallback when the
     box does not fit) must give exactly what the general kernel gives for the same matrix: a 1e-300 off-diagonal makes
@@ -317,3 +339,16 @@ def case_separable_vs_general(device):
                     m2[0, 1] = 1e-300
                     b = ops.affine_resample(vol, m2.reshape(-1), osz, mode, pad, False, f64)
                     assert torch.equal(a, b), (scale, mode, pad, f64, (a - b).abs().max().item())
+    # the z-streaming kernel's other paths: the 16-loads-per-thread box, tiles (and planes) entirely outside the volume
+    for scale, off, osz in (((1.25, 1.25, 1.0), (-0.7, 0.4, -2.3), (19, 32, 300)), ((1.25, 1.25, 0.625), (-9.0, -25.0, -100.0), (30, 40, 700)),
+                            ((-1.25, 1.0, 0.625), (30.0, 30.0, 250.0), (33, 30, 300))):
+        for pad in PADS:
+            for f64 in (True, False):
+                m = np.zeros((3, 4))
+                m[0, 0], m[1, 1], m[2, 2] = scale
+                m[:, 3] = off
+                a = ops.affine_resample(vol, m.reshape(-1), osz, "bilinear", pad, False, f64)
+                m2 = m.copy()
+                m2[0, 1] = 1e-300
+                b = ops.affine_resample(vol, m2.reshape(-1), osz, "bilinear", pad, False, f64)
+                assert torch.equal(a, b), (scale, off, pad, f64, (a - b).abs().max().item())
