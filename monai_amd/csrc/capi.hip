@@ -481,18 +481,25 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     if (nchunk > cdiv(D, min_chunk)) nchunk = cdiv(D, min_chunk);
     if (nchunk < 1) nchunk = 1;
     a.zchunk = cdiv(D, nchunk);
+    a.pair_ok = (W % 2 == 0 && aligned(dst, 8)) ? 1 : 0;
     a.nchunk = cdiv(D, a.zchunk);
     const long long nwg = tiles * a.nchunk * NC;
     if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: problem too large for one launch");
     const dim3 grid((unsigned)nwg);
     hipStream_t s = (hipStream_t)stream;
+    bool iso = kz_n == ky_n && ky_n == kx_n;
+    for (int i = 0; iso && i < kz_n; ++i) iso = kz[i] == ky[i] && ky[i] == kx[i];
+#define MH_GAUSS(RK_)                                                                                             \
+    if (iso) hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, true>), grid, dim3(256), 0, s, src, dst, a);          \
+    else hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, false>), grid, dim3(256), 0, s, src, dst, a);
     switch (rk) {
-        case 3: hipLaunchKernelGGL((gauss3d_stream_kernel<3>), grid, dim3(256), 0, s, src, dst, a); break;
-        case 5: hipLaunchKernelGGL((gauss3d_stream_kernel<5>), grid, dim3(256), 0, s, src, dst, a); break;
-        case 9: hipLaunchKernelGGL((gauss3d_stream_kernel<9>), grid, dim3(256), 0, s, src, dst, a); break;
-        case 17: hipLaunchKernelGGL((gauss3d_stream_kernel<17>), grid, dim3(256), 0, s, src, dst, a); break;
-        default: hipLaunchKernelGGL((gauss3d_stream_kernel<33>), grid, dim3(256), 0, s, src, dst, a); break;
+        case 3: MH_GAUSS(3) break;
+        case 5: MH_GAUSS(5) break;
+        case 9: MH_GAUSS(9) break;
+        case 17: MH_GAUSS(17) break;
+        default: MH_GAUSS(33) break;
     }
+#undef MH_GAUSS
     return launched("separable_filter3d");
 }
 
@@ -537,7 +544,8 @@ int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const
         return fail(MH_ERR_ARG, "conv3d_k3_strided: output must be floor((in - 1) / stride) + 1");
     constexpr int COT = 16;
     const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
-    hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
+    if (out.C % COT == 0) hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, true>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
+    else hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, false>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
     return launched("conv3d_k3_strided");
 }
 
@@ -546,6 +554,15 @@ int mh_deconv_k3_f32(const mh_tensor5* in_, const float* w, const float* bias, c
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || out.D != in.D * stride || out.H != in.H * stride || out.W != in.W * stride)
         return fail(MH_ERR_ARG, "deconv_k3: output must be stride * input (padding 1, output_padding stride - 1)");
+    if (stride == 2 && aligned(out.data, 8) && out.n_stride % 2 == 0) {
+        const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
+        hipStream_t s = (hipStream_t)stream;
+        if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k3s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, s, in, w, bias, out);
+        else if (out.C == 5) hipLaunchKernelGGL((deconv_k3s2_kernel<5, true>), dim3(nb, 1u, (unsigned)out.N), dim3(256), 0, s, in, w, bias, out);
+        else if (out.C <= 4) hipLaunchKernelGGL((deconv_k3s2_kernel<4, false>), dim3(nb, 1u, (unsigned)out.N), dim3(256), 0, s, in, w, bias, out);
+        else hipLaunchKernelGGL((deconv_k3s2_kernel<8, false>), dim3(nb, (unsigned)cdiv(out.C, 8), (unsigned)out.N), dim3(256), 0, s, in, w, bias, out);
+        return launched("deconv_k3s2");
+    }
     constexpr int COT = 16;
     const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
     hipLaunchKernelGGL((deconv_k3_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out, stride);

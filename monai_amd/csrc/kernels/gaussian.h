@@ -3,42 +3,57 @@
 // Reference: monai/transforms/intensity/array.py:1590-1622 -> GaussianFilter (monai/networks/layers/simplelayers.py:
 // 542-595) -> separable_filtering :207-249: per axis a zero-padded copy (F.pad) and a depthwise F.conv3d with a
 // [C,1,k,1,1]-style kernel -- three padded copies + three conv passes, ~12x the volume in HBM traffic.
-// Here a workgroup owns a 16 x 64 (y, x) column of one channel volume and streams along z:
+// Here a workgroup owns a 16 x 64 (y, x) column of one channel volume and streams along one z-chunk:
 //   plane z (with its y/x halo, zeros outside the image; prefetched into registers one plane ahead) -> LDS -> x-pass
-//   (4 outputs per task from one register window) -> LDS -> y-pass -> one value per owned position, pushed into a
-//   per-thread register ring of the last RK filtered planes; the z-pass is a dot product of the ring with the z-kernel.  Every input element is read once (plus the in-plane halo, served by
-//   L2) and every output written once: 8 B per voxel, the algorithmic minimum.
-// fp32 throughout, taps accumulated in ascending tap order per axis; the axis order (x, y, then z) differs from the
-// reference's (first axis first), which only reorders fp32 roundings (tests: 1e-5 tolerance; the reference's own
-// tests use 1e-4).
+//   -> LDS -> y-pass -> a per-thread register ring of the last RK filtered planes; the z-pass is a dot product of the
+//   ring with the z-kernel.  Every input element is read once (plus the halos, served by L2: the launch is XCD-aware)
+//   and every output written once: 8 B per voxel, the algorithmic minimum.
+// The kernel is VALU-issue bound, not HBM bound, unless the taps are packed: every multiply-add below is a
+// v_pk_fma_f32 on an (x, x+1) pair of neighbouring outputs.  The x-pass gets its register-aligned pairs for the odd
+// taps from a second copy of the staged plane shifted by one float.
+// fp32 throughout, taps accumulated in ascending tap order per axis with fused multiply-adds; the axis order (x, y,
+// then z) differs from the reference's (first axis first); both only reorder fp32 roundings (tests: 1e-5 tolerance;
+// the reference's own tests use 1e-4).
 #pragma once
 #include "common.h"
 
 namespace mh {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int GS_MAX_TAPS = 33;   // per axis (sigma up to 4 at the reference's truncation of 4 sigma)
-constexpr int GS_TX = 64, GS_TY = 16, GS_P = (GS_TX * GS_TY) / 256;
+constexpr int GS_TX = 64, GS_TY = 16;
 
 struct GaussArgs {
     int NC, D, H, W;
     int zchunk, nchunk;                                        // the z axis is cut into nchunk runs of zchunk output planes
+    int pair_ok;                                               // W even and dst 8-byte aligned: (x, x+1) outputs go out as one store
     float kz[GS_MAX_TAPS], ky[GS_MAX_TAPS], kx[GS_MAX_TAPS];   // each zero-padded symmetrically to the kernel's RK taps
 };
 
-// RK = taps per axis (compile time: every tap loop is unrolled, weights sit in SGPRs), HR = halo.
-// Thread t owns column x = t & 63 and the four rows 4*(t >> 6) .. +3 of the 16 x 64 tile.
-template <int RK>
+__device__ __forceinline__ f32x2 gs_fma(float k, f32x2 v, f32x2 acc) {
+    const f32x2 kk = {k, k};
+    return __builtin_elementwise_fma(kk, v, acc);
+}
+
+// RK = taps per axis (compile time: every tap loop is unrolled, weights sit in SGPRs), HR = halo.  ISO: the three axis
+// kernels are identical (scalar sigma), one set of weights is kept (a third of the SGPRs).
+// Thread t owns the column pair x = 2 (t & 31), +1 and the rows 2 (t >> 5), +1 of the 16 x 64 tile.
+template <int RK, bool ISO>
 __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, GaussArgs a) {
-#pragma clang fp contract(off)
     constexpr int HR = (RK - 1) / 2;
     constexpr int INH = GS_TY + 2 * HR;
-    constexpr int XSPAN = (4 + 2 * HR + 3) / 4 * 4;          // floats one x-pass task reads (whole float4s)
-    constexpr int INW = GS_TX - 4 + XSPAN;                   // row stride of the staged plane (multiple of 4)
+    constexpr int XSPAN = (RK + 3 + 3) / 4 * 4;              // floats one x-pass task reads per copy (whole float4s)
+    constexpr int INW = GS_TX - 4 + XSPAN;                   // row pitch of the staged plane (multiple of 4)
     constexpr int NLOAD = (INH * INW + 255) / 256;
     constexpr int NTASK = INH * (GS_TX / 4);                 // x-pass tasks: (row, quad of 4 outputs)
-    __shared__ __attribute__((aligned(16))) float in_s[INH * INW];
+    __shared__ __attribute__((aligned(16))) float in_a[INH * INW];       // staged plane
+    __shared__ __attribute__((aligned(16))) float in_b[INH * INW + 4];   // the same shifted left by one float
     __shared__ __attribute__((aligned(16))) float mid_s[INH * GS_TX];
     const int tid = threadIdx.x;
+    const float* wkx = a.kx;
+    const float* wky = ISO ? a.kx : a.ky;
+    const float* wkz = ISO ? a.kx : a.kz;
     // 1-D launch, XCD-aware: each XCD's L2 gets a contiguous run of (tile, chunk, volume) work items, so the in-plane
     // halo shared by neighbouring tiles is an L2 hit instead of a second HBM read.
     const int tiles_x = (a.W + GS_TX - 1) / GS_TX, tiles = tiles_x * ((a.H + GS_TY - 1) / GS_TY);
@@ -48,95 +63,115 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
     const int chunk = (int)(lid % (unsigned)a.nchunk), nc = (int)(lid / (unsigned)a.nchunk);
     const int tx0 = (tile % tiles_x) * GS_TX, ty0 = (tile / tiles_x) * GS_TY;
     const int zs = chunk * a.zchunk, ze = min(zs + a.zchunk, a.D);      // output planes of this workgroup
-    const int zfirst = max(zs - HR, 0), zend = min(ze + HR, a.D + HR);  // filtered planes it needs (zero outside the volume)
+    const int zfirst = max(zs - HR, 0), zlast = min(ze + HR, a.D);      // source planes it filters; planes beyond the volume are zero
     const long long plane = (long long)a.H * a.W;
     const float* vol = src + (long long)nc * a.D * plane;
     float* ovol = dst + (long long)nc * a.D * plane;
-    const int x = tid & 63, y4 = (tid >> 6) * 4;
+    const int xp = tid & 31, y2 = (tid >> 5) * 2;
 
     // staging positions of this thread inside the halo plane (fixed for the whole march along z)
     int goff[NLOAD];
-    bool gok[NLOAD];
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
         const int i = tid + 256 * j;
         const int ly = i / INW, lx = i - ly * INW;
         const int gy = ty0 + ly - HR, gx = tx0 + lx - HR;
-        gok[j] = i < INH * INW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        goff[j] = gok[j] ? gy * a.W + gx : 0;
+        const bool ok = i < INH * INW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        goff[j] = ok ? gy * a.W + gx : -1;
     }
     float pre[NLOAD];
 #pragma unroll
-    for (int j = 0; j < NLOAD; ++j) pre[j] = vol[(long long)zfirst * plane + goff[j]];
+    for (int j = 0; j < NLOAD; ++j) pre[j] = goff[j] >= 0 ? vol[(long long)zfirst * plane + goff[j]] : 0.0f;
 
-    float ring[GS_P][RK];
+    f32x2 ring[2][RK];
 #pragma unroll
-    for (int p = 0; p < GS_P; ++p)
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int k = 0; k < RK; ++k) ring[p][k] = 0.0f;
+        for (int k = 0; k < RK; ++k) ring[p][k] = f32x2{0.0f, 0.0f};
 
-    for (int z = zfirst; z < zend; ++z) {
-        const bool live = z < a.D;          // beyond the volume the filtered plane is exactly zero (zero padding)
-        if (live) {
+    const int gx = tx0 + 2 * xp;
+    const bool ok0 = ty0 + y2 < a.H && gx < a.W, ok1 = ty0 + y2 + 1 < a.H && gx < a.W;
+    const bool pair_store = a.pair_ok != 0 && gx + 1 < a.W;
+    const bool second = gx + 1 < a.W;
+    float* obase = ovol + (long long)(ty0 + y2) * a.W + gx;
+
+    // z-pass of the ring + store of output plane zo (both rows' accumulation chains interleaved)
+#define GS_EMIT(ZO)                                                                                   \
+    {                                                                                                 \
+        f32x2 acc0 = {0.0f, 0.0f}, acc1 = {0.0f, 0.0f};                                               \
+        _Pragma("unroll") for (int k = 0; k < RK; ++k) {                                              \
+            acc0 = gs_fma(wkz[k], ring[0][k], acc0);                                                  \
+            acc1 = gs_fma(wkz[k], ring[1][k], acc1);                                                  \
+        }                                                                                             \
+        float* o = obase + (long long)(ZO) * plane;                                                   \
+        if (pair_store) {                                                                             \
+            if (ok0) *reinterpret_cast<f32x2*>(o) = acc0;                                             \
+            if (ok1) *reinterpret_cast<f32x2*>(o + a.W) = acc1;                                       \
+        } else {                                                                                      \
+            if (ok0) { o[0] = acc0[0]; if (second) o[1] = acc0[1]; }                                  \
+            if (ok1) { o[a.W] = acc1[0]; if (second) o[a.W + 1] = acc1[1]; }                          \
+        }                                                                                             \
+    }
+
+    for (int z = zfirst; z < zlast; ++z) {
 #pragma unroll
-            for (int j = 0; j < NLOAD; ++j) {
-                const int i = tid + 256 * j;
-                if (i < INH * INW) in_s[i] = gok[j] ? pre[j] : 0.0f;
+        for (int j = 0; j < NLOAD; ++j) {
+            const int i = tid + 256 * j;
+            if (i < INH * INW) {
+                in_a[i] = pre[j];
+                if (i > 0) in_b[i - 1] = pre[j];
             }
         }
         __syncthreads();
-        if (z + 1 < zend && z + 1 < a.D) {                  // next plane's loads fly while this plane is filtered
+        if (z + 1 < zlast) {                // next plane's loads fly while this plane is filtered
             const float* pl = vol + (long long)(z + 1) * plane;
 #pragma unroll
-            for (int j = 0; j < NLOAD; ++j) pre[j] = pl[goff[j]];
+            for (int j = 0; j < NLOAD; ++j) pre[j] = goff[j] >= 0 ? pl[goff[j]] : 0.0f;
         }
-        if (live) {                         // x-pass: 4 neighbouring outputs per task from one sliding register window
-            for (int task = tid; task < NTASK; task += 256) {
-                const int r = task / (GS_TX / 4), q = task - r * (GS_TX / 4);
-                float win[XSPAN];
-                const f32x4* rp = reinterpret_cast<const f32x4*>(in_s + r * INW + 4 * q);
+        // x-pass: outputs (4q, 4q+1) and (4q+2, 4q+3) of one row; even taps pair up in in_a, odd taps in in_b
+        for (int task = tid; task < NTASK; task += 256) {
+            const int r = task / (GS_TX / 4), q = task - r * (GS_TX / 4);
+            const f32x4* ra = reinterpret_cast<const f32x4*>(in_a + r * INW + 4 * q);
+            const f32x4* rb = reinterpret_cast<const f32x4*>(in_b + r * INW + 4 * q);
+            f32x2 wa[XSPAN / 2], wb[XSPAN / 2];          // wa[i] = (in[2i], in[2i+1]), wb[i] = (in[2i+1], in[2i+2])
 #pragma unroll
-                for (int v = 0; v < XSPAN / 4; ++v) {
-                    const f32x4 t4 = rp[v];
-                    win[4 * v] = t4[0]; win[4 * v + 1] = t4[1]; win[4 * v + 2] = t4[2]; win[4 * v + 3] = t4[3];
-                }
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < RK; ++k) acc = acc + a.kx[k] * win[e + k];
-                    o[e] = acc;
-                }
-                *reinterpret_cast<f32x4*>(mid_s + r * GS_TX + 4 * q) = o;
+            for (int v = 0; v < XSPAN / 4; ++v) {
+                const f32x4 t4 = ra[v], u4 = rb[v];
+                wa[2 * v] = f32x2{t4[0], t4[1]}; wa[2 * v + 1] = f32x2{t4[2], t4[3]};
+                wb[2 * v] = f32x2{u4[0], u4[1]}; wb[2 * v + 1] = f32x2{u4[2], u4[3]};
             }
+            f32x2 o0 = {0.0f, 0.0f}, o1 = {0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < RK; ++k) {
+                if (k % 2 == 0) { o0 = gs_fma(wkx[k], wa[k / 2], o0); o1 = gs_fma(wkx[k], wa[k / 2 + 1], o1); }
+                else { o0 = gs_fma(wkx[k], wb[k / 2], o0); o1 = gs_fma(wkx[k], wb[k / 2 + 1], o1); }
+            }
+            *reinterpret_cast<f32x4*>(mid_s + r * GS_TX + 4 * q) = f32x4{o0[0], o0[1], o1[0], o1[1]};
         }
         __syncthreads();
-        float col[GS_P + 2 * HR];
-        if (live) {
+        // y-pass for this thread's two rows (chains interleaved), pushed into the ring
+        f32x2 col[2 + 2 * HR];
 #pragma unroll
-            for (int j = 0; j < GS_P + 2 * HR; ++j) col[j] = mid_s[(y4 + j) * GS_TX + x];
+        for (int j = 0; j < 2 + 2 * HR; ++j) col[j] = *reinterpret_cast<const f32x2*>(mid_s + (y2 + j) * GS_TX + 2 * xp);
+        f32x2 v0 = {0.0f, 0.0f}, v1 = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < RK; ++k) {
+            v0 = gs_fma(wky[k], col[k], v0);
+            v1 = gs_fma(wky[k], col[k + 1], v1);
         }
-        const int zo = z - HR, gx = tx0 + x;
 #pragma unroll
-        for (int p = 0; p < GS_P; ++p) {
-            float v = 0.0f;
-            if (live) {
-#pragma unroll
-                for (int k = 0; k < RK; ++k) v = v + a.ky[k] * col[p + k];
-            }
-#pragma unroll
-            for (int k = 0; k < RK - 1; ++k) ring[p][k] = ring[p][k + 1];
-            ring[p][RK - 1] = v;
-            const int gy = ty0 + y4 + p;
-            if (zo >= zs && gy < a.H && gx < a.W) {
-                float acc = 0.0f;
-#pragma unroll
-                for (int k = 0; k < RK; ++k) acc = acc + a.kz[k] * ring[p][k];
-                ovol[(long long)zo * plane + (long long)gy * a.W + gx] = acc;
-            }
-        }
+        for (int k = 0; k < RK - 1; ++k) { ring[0][k] = ring[0][k + 1]; ring[1][k] = ring[1][k + 1]; }
+        ring[0][RK - 1] = v0; ring[1][RK - 1] = v1;
+        if (z - HR >= zs) GS_EMIT(z - HR)
     }
+    // planes beyond the end of the volume filter to exactly zero (zero padding): drain the ring
+    for (int z = zlast; z < ze + HR; ++z) {
+#pragma unroll
+        for (int k = 0; k < RK - 1; ++k) { ring[0][k] = ring[0][k + 1]; ring[1][k] = ring[1][k + 1]; }
+        ring[0][RK - 1] = f32x2{0.0f, 0.0f}; ring[1][RK - 1] = f32x2{0.0f, 0.0f};
+        if (z - HR >= zs) GS_EMIT(z - HR)
+    }
+#undef GS_EMIT
 }
 
 }  // namespace mh

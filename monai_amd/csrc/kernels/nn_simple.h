@@ -52,7 +52,7 @@ conv3d_k3_direct_kernel(Tensor in, const float* __restrict__ wp, const float* __
 // ---------------------------------------------------------------------------------------------------
 // Strided Conv3d 3x3x3 pad 1 (UNet's down path: monai/networks/nets/unet.py:197-237 -> Convolution(strides=s)).
 // Same direct form as above with  input index = stride * output index + tap - 1;  out dims = floor((in - 1) / stride) + 1.
-template <int COT>
+template <int COT, bool FULL>     // FULL: every channel group is complete (Cout % COT == 0): no guards in the hot loop
 __global__ void __launch_bounds__(256)
 conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out, int stride) {
     const int D = in.D, H = in.H, W = in.W, Do = out.D, Ho = out.H, Wo = out.W, Cin = in.C, Cout = out.C;
@@ -63,6 +63,20 @@ conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* _
     const int x = (int)(idx % Wo);
     const long long t = idx / Wo;
     const int y = (int)(t % Ho), z = (int)(t / Ho);
+    // per-axis tap offsets clamped into the volume + a 27-bit validity mask: all 27 loads of a channel are issued
+    // unconditionally (they overlap in flight), padding taps are zeroed afterwards
+    int zo[3], yo[3], xo[3];
+    unsigned zm = 0u, ym = 0u, xm = 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int zz = z * stride + k - 1, yy = y * stride + k - 1, xx = x * stride + k - 1;
+        zm |= (unsigned)(zz >= 0 && zz < D) << k; ym |= (unsigned)(yy >= 0 && yy < H) << k; xm |= (unsigned)(xx >= 0 && xx < W) << k;
+        zo[k] = min(max(zz, 0), D - 1) * H * W; yo[k] = min(max(yy, 0), H - 1) * W; xo[k] = min(max(xx, 0), W - 1);
+    }
+    unsigned okm = 0u;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap)
+        okm |= (((zm >> (tap / 9)) & (ym >> ((tap / 3) % 3)) & (xm >> (tap % 3))) & 1u) << tap;
     float acc[COT];
 #pragma unroll
     for (int j = 0; j < COT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
@@ -71,15 +85,16 @@ conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* _
         const float4 a = load_nrm(in, n, ci);
         const float* plane = src + (long long)ci * ivol;
         const float* wrow = wp + (long long)ci * 27 * Cout + co0;
+        float v[27];
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) v[tap] = plane[zo[tap / 9] + yo[(tap / 3) % 3] + xo[tap % 3]];
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) v[tap] = ((okm >> tap) & 1u) ? act(v[tap], a.x, a.y, a.z) : 0.0f;
 #pragma unroll
         for (int tap = 0; tap < 27; ++tap) {
-            const int zz = z * stride + tap / 9 - 1, yy = y * stride + (tap / 3) % 3 - 1, xx = x * stride + tap % 3 - 1;
-            float v = 0.0f;
-            if (zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W)
-                v = act(plane[((long long)zz * H + yy) * W + xx], a.x, a.y, a.z);
 #pragma unroll
             for (int j = 0; j < COT; ++j)
-                if (co0 + j < Cout) acc[j] = fmaf(v, wrow[tap * Cout + j], acc[j]);
+                if (FULL || co0 + j < Cout) acc[j] = fmaf(v[tap], wrow[tap * Cout + j], acc[j]);
         }
     }
     float* dst = out.data + (long long)n * out.n_stride + idx;
@@ -89,7 +104,82 @@ conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------
-// ConvTranspose3d k=3, stride s, padding 1, output_padding s-1 (UNet's up path: unet.py:249-294; out dims = s * in).
+// ConvTranspose3d k=3, stride 2, padding 1, output_padding 1 (UNet's up path, unet.py:249-294): out dims = 2 * in.
+// Output o = 2 i - 1 + k: an even output takes tap 1 of input o/2; an odd output 2i+1 takes tap 2 of input i and tap 0
+// of input i+1.  One thread owns an INPUT position and produces its 2x2x2 output block for COT channels from the 2x2x2
+// input neighbourhood: the 27 weights of a (ci, co) pair are each used exactly once (1+2+2+2+4+4+4+8 = 27 MACs per
+// 8 outputs) -- no tap is tested and thrown away, and the 8 loads of a channel fly together.
+// Weights [Cin][Cout][27] (PyTorch ConvTranspose3d layout), read with uniform indices (scalar loads).
+template <int COT, bool FULL>
+__global__ void __launch_bounds__(256)
+deconv_k3s2_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
+    const int D = in.D, H = in.H, W = in.W, Cin = in.C, Cout = out.C;
+    const long long ivol = (long long)D * H * W, ovol = 8 * ivol;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= ivol) return;
+    const int ix = (int)(idx % W);
+    const long long t = idx / W;
+    const int iy = (int)(t % H), iz = (int)(t / H);
+    const bool okz = iz + 1 < D, oky = iy + 1 < H, okx = ix + 1 < W;
+    const int oz = okz ? H * W : 0, oy = oky ? W : 0, ox = okx ? 1 : 0;
+    float acc[8][COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        const float b = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[o][j] = b;
+    }
+    const float* src = in.data + (long long)n * in.n_stride + idx;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float* p = src + (long long)ci * ivol;
+        float v[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) v[d] = p[(d >> 2) * oz + ((d >> 1) & 1) * oy + (d & 1) * ox];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const bool ok = (!(d >> 2) || okz) && (!((d >> 1) & 1) || oky) && (!(d & 1) || okx);
+            v[d] = ok ? act(v[d], a.x, a.y, a.z) : 0.0f;
+        }
+        const float* wr = w + ((long long)ci * Cout + co0) * 27;
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+            if (!FULL && co0 + j >= Cout) continue;
+#pragma unroll
+            for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int px = 0; px < 2; ++px)
+#pragma unroll
+                        for (int dz = 0; dz <= pz; ++dz)
+#pragma unroll
+                            for (int dy = 0; dy <= py; ++dy)
+#pragma unroll
+                                for (int dx = 0; dx <= px; ++dx) {
+                                    const int kz = pz ? (dz ? 0 : 2) : 1, ky = py ? (dy ? 0 : 2) : 1, kx = px ? (dx ? 0 : 2) : 1;
+                                    acc[pz * 4 + py * 2 + px][j] =
+                                        fmaf(v[dz * 4 + dy * 2 + dx], wr[j * 27 + kz * 9 + ky * 3 + kx], acc[pz * 4 + py * 2 + px][j]);
+                                }
+        }
+    }
+    const int Ho = 2 * H, Wo = 2 * W;
+    float* dst = out.data + (long long)n * out.n_stride + ((long long)(2 * iz) * Ho + 2 * iy) * Wo + 2 * ix;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) {
+        if (co0 + j >= Cout) continue;
+        float* q = dst + (long long)(co0 + j) * ovol;
+#pragma unroll
+        for (int pz = 0; pz < 2; ++pz)
+#pragma unroll
+            for (int py = 0; py < 2; ++py)      // the (x, x+1) pair is 8-byte aligned (launcher checks base and strides)
+                *reinterpret_cast<float2*>(q + ((long long)pz * Ho + py) * Wo) = make_float2(acc[pz * 4 + py * 2][j], acc[pz * 4 + py * 2 + 1][j]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d k=3, any stride s, padding 1, output_padding s-1 (out dims = s * in): generic fallback of the kernel above.
 // Gather form: output o takes input i through tap k whenever  i * s + k - 1 == o.  Weights [Cin][Cout][27].
 template <int COT>
 __global__ void __launch_bounds__(256)
