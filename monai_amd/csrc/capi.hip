@@ -4,11 +4,13 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kernels/common.h"
 #include "kernels/attention.h"
 #include "kernels/conv3d_mfma.h"
+#include "kernels/conv3d_winograd.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/nn_simple.h"
@@ -151,10 +153,23 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int cin_padded(int cfg, int Cin) { return cfg == 0 ? Cin : cdiv(Cin, kCfg[cfg].cc) * kCfg[cfg].cc; }
 static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv(Cout, kCfg[cfg].cn) * kCfg[cfg].cn; }
 
-int mh_conv3d_k3_num_configs(void) { return MH_NUM_CFG; }
+// configuration MH_CFG_WINOGRAD: Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32 (kernels/conv3d_winograd.h)
+#define MH_CFG_WINOGRAD (MH_NUM_CFG + 1)
+static inline int winograd_regions(int D, int H, int W) { return cdiv(W, WG_OX) * cdiv(H, WG_OY) * cdiv(D, WG_OZ); }
+// MONAI_AMD_CONV_ALGO = direct | winograd | auto (default): restricts what mh_conv3d_k3_select may return
+static int conv_algo_mode() {
+    const char* e = getenv("MONAI_AMD_CONV_ALGO");
+    if (!e) return 0;
+    if (!strcmp(e, "direct")) return 1;
+    if (!strcmp(e, "winograd")) return 2;
+    return 0;
+}
+
+int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINOGRAD; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
+    if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -173,15 +188,25 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
         const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * kPref[c];
         if (score > best_score) { best_score = score; best = c; }
     }
+    // 3-D Winograd: 3.375x fewer matrix-core cycles, but with its 256 accumulation registers it runs one wave per SIMD and is
+    // issue-bound: measured at parity with the direct tiles (profiles/), so it is opt-in (MONAI_AMD_CONV_ALGO=winograd).
+    const int mode = conv_algo_mode();
+    if (mode == 2 && mh_conv3d_k3_accepts(MH_CFG_WINOGRAD, Cin, Cout) && D % 2 == 0 && H % 2 == 0 && W % 2 == 0) best = MH_CFG_WINOGRAD;
     return best;
 }
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
+    if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
 
 int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream) {
+    if (cfg == MH_CFG_WINOGRAD) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0");
+        hipLaunchKernelGGL(conv3d_k3_winograd_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
+        return launched("conv3d_k3_winograd_pack");
+    }
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
     const int cinp = cin_padded(cfg, Cin), coutp = cout_padded(cfg, Cout);
@@ -191,6 +216,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 }
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
+    if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -211,9 +237,19 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_WINOGRAD) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == MH_CFG_WINOGRAD) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % 2 || in.H % 2 || in.W % 2)
+            return fail(MH_ERR_ARG, "conv3d_k3: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0 and even extents (got %d -> %d, %dx%dx%d)", in.C,
+                        out.C, in.D, in.H, in.W);
+        const int rx = cdiv(out.W, WG_OX), ry = cdiv(out.H, WG_OY), rz = cdiv(out.D, WG_OZ);
+        const dim3 grid((unsigned)(rx * ry * rz), (unsigned)(out.C / WG_CN), (unsigned)out.N);
+        if (stats) hipLaunchKernelGGL((conv3d_k3_winograd_kernel<true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, rx, ry, rz);
+        else hipLaunchKernelGGL((conv3d_k3_winograd_kernel<false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, rx, ry, rz);
+        return launched("conv3d_k3_winograd");
+    }
     if (cfg == 0) {
         if (stats) return fail(MH_ERR_ARG, "conv3d_k3: the direct kernel emits no statistics");
         constexpr int COT = 16;

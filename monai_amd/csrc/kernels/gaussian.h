@@ -19,8 +19,6 @@
 
 namespace mh {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int GS_MAX_TAPS = 33;   // per axis (sigma up to 4 at the reference's truncation of 4 sigma)
 constexpr int GS_TX = 64, GS_TY = 16;
 

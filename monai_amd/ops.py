@@ -56,6 +56,15 @@ def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv3d_k3_select", cin, cout, d, h, w)
 
 
+def conv3d_k3_num_configs() -> int:
+    """Highest configuration id (= the Winograd configuration; 1 .. n-1 are the direct implicit-GEMM tiles, 0 the plain kernel)."""
+    return _lib.lib().query("mh_conv3d_k3_num_configs")
+
+
+def conv3d_k3_accepts(cfg: int, cin: int, cout: int) -> bool:
+    return bool(_lib.lib().query("mh_conv3d_k3_accepts", int(cfg), int(cin), int(cout)))
+
+
 def conv3d_k3_pack(cfg: int, weight: torch.Tensor) -> torch.Tensor:
     """torch conv weight [Cout,Cin,3,3,3] -> the packed layout of configuration `cfg`."""
     _lib.require_device(weight)

@@ -201,6 +201,30 @@ inline f32x16_t mfma_f32_32x32x2f32(float a, float b, f32x16_t cin, int, int, in
     wave_sync();
     return d;
 }
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D: col = l & 15, row = 4 (l >> 4) + r
+inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int) {
+    Ctx& c = ctx();
+    Fiber* f = c.cur;
+    memcpy(c.slots[f->wave][f->lane][0], &a, 4);
+    memcpy(c.slots[f->wave][f->lane][1], &b, 4);
+    wave_sync();
+    const int lane = f->lane, col = lane & 15;
+    f32x4_t d = cin;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float acc = cin[r];
+        for (int k = 0; k < 4; ++k) {
+            float av, bv;
+            memcpy(&av, c.slots[f->wave][row + 16 * k][0], 4);
+            memcpy(&bv, c.slots[f->wave][col + 16 * k][1], 4);
+            acc = std::fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
 }  // namespace emu
 
 // ------------------------------------------------------------------ HIP surface used by the product sources
@@ -216,7 +240,10 @@ inline f32x16_t mfma_f32_32x32x2f32(float a, float b, f32x16_t cin, int, int, in
 #define gridDim (emu::ctx().gridDim)
 #define __syncthreads() emu::yield_to_sched(emu::BLOCK_WAIT)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu::mfma_f32_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu::wave_read(v, emu::ctx().cur->lane ^ mask); }
 template <class T> static inline T __shfl_down(T v, int d, int = 64) {

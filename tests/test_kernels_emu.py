@@ -102,3 +102,14 @@ def test_conv_mfma_cout_padding(emu):
 
 def test_strided_conv_and_deconv_k3(emu):
     kc.case_strided_conv_and_deconv_k3("cpu")
+
+
+@pytest.mark.parametrize("cin,cout,dims,n", [(4, 16, (4, 8, 16), 2), (8, 32, (8, 8, 32), 1), (12, 16, (6, 10, 18), 1), (4, 16, (2, 2, 2), 1)])
+def test_conv3d_winograd(emu, cin, cout, dims, n):
+    """Winograd F(2x2x2, 3x3x3) configuration: full regions, several regions / cout groups, ragged regions."""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_num_configs()
+    assert ops.conv3d_k3_accepts(cfg, cin, cout)
+    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)

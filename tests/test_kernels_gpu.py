@@ -93,3 +93,14 @@ def test_conv_mfma_cout_padding():
 
 def test_strided_conv_and_deconv_k3():
     kc.case_strided_conv_and_deconv_k3(DEV)
+
+
+@pytest.mark.parametrize("cin,cout,dims,n", [(4, 16, (4, 8, 16), 2), (8, 32, (8, 8, 32), 1), (12, 16, (6, 10, 18), 1), (4, 16, (2, 2, 2), 1),
+                                              (32, 32, (48, 48, 48), 2), (64, 32, (24, 24, 24), 1), (128, 64, (12, 12, 12), 1)])
+def test_conv3d_winograd(cin, cout, dims, n):
+    """Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32: the emulator cases plus BasicUNet layer shapes."""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_num_configs()
+    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
+    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
