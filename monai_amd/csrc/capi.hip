@@ -11,6 +11,7 @@
 #include "kernels/attention.h"
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_winograd.h"
+#include "kernels/conv3d_wino2d.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/nn_simple.h"
@@ -162,14 +163,29 @@ static int conv_algo_mode() {
     if (!e) return 0;
     if (!strcmp(e, "direct")) return 1;
     if (!strcmp(e, "winograd")) return 2;
+    if (!strcmp(e, "wino2d")) return 3;
     return 0;
 }
 
-int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINOGRAD; }
+// configuration MH_CFG_WINO2D: Winograd F(2x2, 3x3) in-plane + three direct z taps, z-streaming (kernels/conv3d_wino2d.h)
+#define MH_CFG_WINO2D (MH_NUM_CFG + 2)
+// z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
+static inline int wino2d_chunks(int D, int H, int W) {
+    const int blocks = cdiv(W, W2_B) * cdiv(H, W2_B);
+    int nchunk = cdiv(64, blocks);
+    if (nchunk > D / 12) nchunk = D / 12;
+    if (nchunk < 1) nchunk = 1;
+    return nchunk;
+}
+static inline int wino2d_zchunk(int D, int H, int W) { return cdiv(D, wino2d_chunks(D, H, W)); }
+static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cdiv(H, W2_B) * cdiv(D, wino2d_zchunk(D, H, W)); }
+
+int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
+    if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -192,11 +208,19 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
     // issue-bound: measured at parity with the direct tiles (profiles/), so it is opt-in (MONAI_AMD_CONV_ALGO=winograd).
     const int mode = conv_algo_mode();
     if (mode == 2 && mh_conv3d_k3_accepts(MH_CFG_WINOGRAD, Cin, Cout) && D % 2 == 0 && H % 2 == 0 && W % 2 == 0) best = MH_CFG_WINOGRAD;
+    // in-plane Winograd, z-streaming: 2.25x fewer matrix-core cycles.  On gfx950 the fp32 MFMA does not co-issue with VALU
+    // work of the same wave (tools/ubench/issue.hip), so its transforms are paid for serially: measured 1.11-1.13x over the
+    // best direct tile at 96^3, 1.04x at 48^3, slower below (profiles/) -- chosen for full 16 x 16 regions of large planes.
+    if (mh_conv3d_k3_accepts(MH_CFG_WINO2D, Cin, Cout) && H % 2 == 0 && W % 8 == 0) {
+        const bool big = H % W2_B == 0 && W % W2_B == 0 && D >= 48 && H >= 48 && W >= 48;
+        if (mode == 3 || (mode == 0 && big)) best = MH_CFG_WINO2D;
+    }
     return best;
 }
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
+    if (cfg == MH_CFG_WINO2D) return (int64_t)Cin * Cout * 48;
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -206,6 +230,11 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0");
         hipLaunchKernelGGL(conv3d_k3_winograd_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
         return launched("conv3d_k3_winograd_pack");
+    }
+    if (cfg == MH_CFG_WINO2D) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0");
+        hipLaunchKernelGGL(conv3d_k3_wino2d_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
+        return launched("conv3d_k3_wino2d_pack");
     }
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
@@ -217,6 +246,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
+    if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -237,9 +267,23 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_CFG_WINOGRAD) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_WINO2D) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == MH_CFG_WINO2D) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.H % 2 || in.W % 8)
+            return fail(MH_ERR_ARG, "conv3d_k3: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0, even H and W %% 8 == 0 (got %d -> %d, %dx%dx%d)",
+                        in.C, out.C, in.D, in.H, in.W);
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
+            return fail(MH_ERR_ARG, "conv3d_k3: in-plane Winograd needs 16-byte aligned output and weights");
+        const int bxn = cdiv(out.W, W2_B), byn = cdiv(out.H, W2_B), zc = wino2d_zchunk(out.D, out.H, out.W);
+        const dim3 grid((unsigned)(bxn * byn * cdiv(out.D, zc)), (unsigned)(out.C / W2_CN), (unsigned)out.N);
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
+        else hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
+        return launched("conv3d_k3_wino2d");
+    }
     if (cfg == MH_CFG_WINOGRAD) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % 2 || in.H % 2 || in.W % 2)
             return fail(MH_ERR_ARG, "conv3d_k3: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0 and even extents (got %d -> %d, %dx%dx%d)", in.C,

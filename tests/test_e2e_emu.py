@@ -23,3 +23,9 @@ def test_unetr_small_vs_reference(emu):
 def test_unet_vs_reference(emu):
     """UNet with residual units, plain, and with a stride-1 level."""
     print(ec.case_unet_vs_golden("cpu"))
+
+
+def test_basic_unet_with_inplane_winograd(emu, monkeypatch):
+    """The whole BasicUNet window path with every eligible 3x3x3 conv on the in-plane Winograd configuration."""
+    monkeypatch.setenv("MONAI_AMD_CONV_ALGO", "wino2d")
+    print(ec.case_net_single_window_vs_golden("cpu"))

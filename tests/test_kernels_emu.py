@@ -61,11 +61,13 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert cfg >= 1
     from monai_amd import ops
 
-    # the BASELINE.json network: every 3x3x3 conv runs on an fp32-MFMA tile configuration
+    # the BASELINE.json network: every 3x3x3 conv runs on the fp32 matrix cores -- the large planes on the in-plane
+    # Winograd configuration (the highest id), the rest on direct implicit-GEMM tiles
+    wino2d = ops.conv3d_k3_num_configs()
     assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 7
-    assert ops.conv3d_k3_select(32, 32, 96, 96, 96) == 7
-    assert ops.conv3d_k3_select(64, 32, 96, 96, 96) == 7
-    assert ops.conv3d_k3_select(32, 32, 48, 48, 48) == 10
+    assert ops.conv3d_k3_select(32, 32, 96, 96, 96) == wino2d
+    assert ops.conv3d_k3_select(64, 32, 96, 96, 96) == wino2d
+    assert ops.conv3d_k3_select(32, 32, 48, 48, 48) == wino2d
     assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 12
     assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 13
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13
@@ -107,6 +109,18 @@ def test_strided_conv_and_deconv_k3(emu):
 @pytest.mark.parametrize("cin,cout,dims,n", [(4, 16, (4, 8, 16), 2), (8, 32, (8, 8, 32), 1), (12, 16, (6, 10, 18), 1), (4, 16, (2, 2, 2), 1)])
 def test_conv3d_winograd(emu, cin, cout, dims, n):
     """Winograd F(2x2x2, 3x3x3) configuration: full regions, several regions / cout groups, ragged regions."""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_num_configs() - 1
+    assert ops.conv3d_k3_accepts(cfg, cin, cout)
+    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+
+
+WINO2D_CASES = [(8, 16, (4, 16, 16), 2), (16, 32, (6, 8, 24), 1), (8, 16, (30, 4, 8), 1), (24, 16, (3, 18, 16), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", WINO2D_CASES)
+def test_conv3d_wino2d(emu, cin, cout, dims, n):
+    """In-plane Winograd F(2x2, 3x3) + direct z taps, z-streaming: chunk halos, ragged regions, several cout groups."""
     from monai_amd import ops
 
     cfg = ops.conv3d_k3_num_configs()

@@ -101,6 +101,19 @@ def test_conv3d_winograd(cin, cout, dims, n):
     """Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32: the emulator cases plus BasicUNet layer shapes."""
     from monai_amd import ops
 
+    cfg = ops.conv3d_k3_num_configs() - 1
+    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
+    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
+
+
+WINO2D_CASES = [(8, 16, (4, 16, 16), 2), (16, 32, (6, 8, 24), 1), (8, 16, (30, 4, 8), 1), (24, 16, (3, 18, 16), 1),
+                (32, 32, (48, 48, 48), 2), (64, 32, (96, 96, 96), 1), (128, 64, (24, 24, 24), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", WINO2D_CASES)
+def test_conv3d_wino2d(cin, cout, dims, n):
+    """In-plane Winograd F(2x2, 3x3) + direct z taps, z-streaming: chunk halos, ragged regions, several cout groups."""
+    from monai_amd import ops
+
     cfg = ops.conv3d_k3_num_configs()
+    assert ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)

@@ -62,7 +62,10 @@ for name, cin, cout, e in layers:
         packed = ops.conv3d_k3_pack(cfg, w)
         tiles = ops.conv3d_k3_stat_tiles(cfg, e, e, e)
         stats = torch.empty(B * cout * max(tiles, 1) * 3, device=dev) if tiles else None
-        ms = timeit(lambda: ops.conv3d_k3(cfg, x, xn, packed, bias, out, stats), iters=3, warm=1)
+        try:
+            ms = timeit(lambda: ops.conv3d_k3(cfg, x, xn, packed, bias, out, stats), iters=3, warm=1)
+        except RuntimeError:
+            continue      # a Winograd configuration that does not take these extents
         row["cfgs"][cfg] = {"ms": ms, "tflops": fl / ms / 1e9}
     res["conv"].append(row)
     del x, out

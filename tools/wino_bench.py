@@ -30,9 +30,13 @@ def timeit(fn, iters=4, warm=1):
     return a.elapsed_time(b) / iters
 
 
-wino = ops.conv3d_k3_num_configs()
+wino2d = ops.conv3d_k3_num_configs()
+wino3d = wino2d - 1
 rows = []
-for cin, cout, e, direct in ((32, 32, 96, 7), (64, 32, 96, 7), (32, 32, 48, 10), (64, 64, 24, 12), (128, 128, 12, 13)):
+LAYERS = ((32, 32, 96, 7), (64, 32, 96, 7), (32, 32, 48, 10), (64, 64, 24, 12), (128, 128, 12, 13))
+if os.environ.get("WB_FIRST"):
+    LAYERS = LAYERS[:1]
+for cin, cout, e, direct in LAYERS:
     x = torch.randn(B, cin, e, e, e, device=dev)
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05
     bias = torch.zeros(cout, device=dev)
@@ -43,8 +47,14 @@ for cin, cout, e, direct in ((32, 32, 96, 7), (64, 32, 96, 7), (32, 32, 48, 10),
     xn[:, :, 2] = 0.1
     fl = 2.0 * 27 * cin * cout * e ** 3 * B
     row = {"cin": cin, "cout": cout, "edge": e}
-    for name, cfg in (("direct", direct), ("winograd", wino)):
+    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d)):
+        if name == "wino3d" and not os.environ.get("WB_WINO3D"):
+            continue
+        if not ops.conv3d_k3_accepts(cfg, cin, cout):
+            continue
         if name == "direct" and os.environ.get("WB_SKIP_DIRECT"):
+            continue
+        if name == "wino2d" and (e % 8 or e < 16):
             continue
         packed = ops.conv3d_k3_pack(cfg, w)
         tiles = ops.conv3d_k3_stat_tiles(cfg, e, e, e)
