@@ -152,9 +152,23 @@ def main():
         if convs:
             key, conv = max(convs.items(), key=lambda kv: kv[1]["ms_total"])
             tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12
+            cfg_id = int(key.split("/cfg")[1])
+            from monai_amd import ops as _ops
+            ncfg = _ops.conv3d_k3_num_configs()
+            if cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
+                kname = (f"conv3d_k3_wino2d_kernel (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, "
+                         f"32|64 -> 32 ch @ {args.roi}^3)")
+                pipe = tf / 2.25
+            elif cfg_id == ncfg - 1:
+                kname, pipe = "conv3d_k3_winograd_kernel (Winograd F(2x2x2,3x3x3) on v_mfma_f32_16x16x4_f32)", tf / 3.375
+            else:
+                kname = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)"
+                pipe = tf
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                    "traffic": None,
-                    "kernel": f"conv3d_k3_mfma_kernel ({key.split('/')[1]}: 3x3x3 conv on v_mfma_f32_32x32x2_f32, 1|32|64 -> 32 ch @ {args.roi}^3)",
+                    "traffic": None, "kernel": kname,
+                    "note": "achieved = ALGORITHMIC flops of the 3x3x3 convolution (2*27*Cin*Cout per voxel) / kernel time; "
+                            "mfma_pipe_frac = matrix-core flops actually issued / time / peak",
+                    "mfma_pipe_frac": pipe / PEAK_FP32_TFLOPS,
                     "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch": conv["work"] / conv["launches"],
                     "share_of_step": conv["ms_total"] / args.steps / ms}
         blend = spans.get("sw_blend")

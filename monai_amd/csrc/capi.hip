@@ -220,7 +220,7 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
-    if (cfg == MH_CFG_WINO2D) return (int64_t)Cin * Cout * 48;
+    if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -233,6 +233,8 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
     }
     if (cfg == MH_CFG_WINO2D) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0");
+        if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)mh_conv3d_k3_packed_floats(cfg, Cin, Cout), (hipStream_t)stream) != hipSuccess)
+            return fail(MH_ERR_LAUNCH, "conv3d_k3_pack: memset failed");
         hipLaunchKernelGGL(conv3d_k3_wino2d_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
         return launched("conv3d_k3_wino2d_pack");
     }
@@ -366,9 +368,9 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
     if (in.N != out.N || out.D != 2 * in.D || out.H != 2 * in.H || out.W != 2 * in.W)
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
-    constexpr int COT = 4;
-    const dim3 grid(blocks_for((long long)in.D * in.H * in.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
-    hipLaunchKernelGGL((deconv_k2s2_kernel<COT>), grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
+    const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
+    if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
+    else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
 }
 

@@ -34,11 +34,12 @@ constexpr int W2_R = 18, W2_PX = 20;                       // input region edge,
 constexpr int W2_CS = W2_R * W2_PX;                        // LDS channel stride (360)
 constexpr int W2_KC = 4;                                   // input channels per step (MFMA K)
 constexpr int W2_XBUF = W2_KC * W2_CS;                     // staged planes of one step (floats)
-constexpr int W2_UBUF = 3 * 16 * 64;                       // weight slab of one step: [kz][xi][cin & 3][cout & 15]
+constexpr int W2_UPITCH = 52;                              // B operands of one lane: 48 floats [kz][xi] + 4 pad (conflict-free 16-byte reads)
+constexpr int W2_UBUF = 4096;                              // weight slab of one step: [lane = (cin & 3) * 16 + (cout & 15)][52], zero padded
 constexpr int W2_SLOTS = (W2_R * W2_R + 63) / 64;          // 6 region elements per lane (wave w stages channel w)
 constexpr int W2_CN = 16;                                  // couts per workgroup
 constexpr int W2_NBUF = 3;                                 // LDS ring
-constexpr int W2_ZSLAB = 16 * 64;                           // zero weights: z-taps that leave the chunk multiply by these
+constexpr int W2_ZSLAB = 64;                                // zero weights: z-taps that leave the chunk multiply by these
 constexpr int W2_SMEM = W2_NBUF * (W2_XBUF + W2_UBUF) + W2_ZSLAB + 64;   // + a dump row for the unused staging slots
 
 #define MH_W2_BT(o0, o1, o2, o3, d0, d1, d2, d3) \
@@ -82,29 +83,37 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
     const float* src = in.data + (long long)n * in.n_stride + (long long)wave * DHW;
     const f32x4* ug = reinterpret_cast<const f32x4*>(up + (long long)cg * KS * W2_UBUF) + tid;
 
-    // cursors of the load stream: (plane, channel step) of the next ISSUE and of the next COMMIT
+    // cursors of the load stream, kept as running pointers (a few scalar adds per step instead of 64-bit multiplies):
+    // xptr / uptr = region plane and weight slab of the next ISSUE, nptr = norm record of the next COMMIT
     int ip = max(zs - 1, 0), is = 0, cs = 0;
+    const float* xptr = src + (long long)ip * HW;
+    const f32x4* uptr = ug;
+    const long long xstep = (long long)W2_KC * DHW, xwrap = (long long)KS * W2_KC * DHW;
+    const float* nptr = NRM ? in.nrm + (long long)n * in.nrm_n_stride + 4LL * wave : nullptr;
     float xin[2][W2_SLOTS];
-    f32x4 uin[2][3];
+    f32x4 uin[2][4];
 #define MH_W2_ISSUE(SET)                                                                              \
     {                                                                                                 \
-        const float* pl_ = src + ((long long)is * W2_KC * D + ip) * HW;                               \
-        _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) xin[SET][j] = pl_[soff[j]];              \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j) uin[SET][j] = ug[(long long)is * (W2_UBUF / 4) + 256 * j]; \
-        if (++is == KS) { is = 0; ip = min(ip + 1, p_last); }                                         \
+        _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) xin[SET][j] = xptr[soff[j]];             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) uin[SET][j] = uptr[256 * j];                    \
+        xptr += xstep; uptr += W2_UBUF / 4;                                                           \
+        if (++is == KS) {                                                                             \
+            is = 0; uptr = ug; xptr -= xwrap;                                                         \
+            if (ip < p_last) { ++ip; xptr += HW; }                                                    \
+        }                                                                                             \
     }
     // branch-free (it is scheduled into the MFMA shadow): a slot outside the region writes to the dump row
 #define MH_W2_COMMIT(SET, BUF)                                                                        \
     {                                                                                                 \
         float4 a_ = make_float4(1.0f, 0.0f, 1.0f, 0.0f);                                              \
-        if (NRM) a_ = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * (cs * W2_KC + wave)); \
+        if (NRM) a_ = *reinterpret_cast<const float4*>(nptr + 16 * cs);                               \
         float* xb_ = xs + (BUF) * W2_XBUF;                                                            \
         _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) {                                        \
             const float val_ = ((sokm >> j) & 1u) ? act(xin[SET][j], a_.x, a_.y, a_.z) : 0.0f;        \
             if (64 * j + 63 < W2_R * W2_R) xb_[loff[j]] = val_;                                       \
             else *(loff[j] >= 0 ? xb_ + loff[j] : dump) = val_;                                       \
         }                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
             reinterpret_cast<f32x4*>(us + (BUF) * W2_UBUF)[tid + 256 * j] = uin[SET][j];              \
         if (++cs == KS) cs = 0;                                                                       \
     }
@@ -151,7 +160,11 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
     // B operands live in two alternating register sets: while 16 MFMAs consume one, the other is fetched from LDS for
     // the next 16 (an LDS read issued next to its MFMA would expose the full LDS latency 48 times per step)
     float ubr[2][16];
-#define MH_W2_UBLOAD(UR, UB) _Pragma("unroll") for (int i = 0; i < 16; ++i) ubr[UR][i] = (UB)[i * 64];
+#define MH_W2_UBLOAD(UR, UB)                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+        const f32x4 t4_ = reinterpret_cast<const f32x4*>(UB)[q];                                      \
+        ubr[UR][4 * q] = t4_[0]; ubr[UR][4 * q + 1] = t4_[1]; ubr[UR][4 * q + 2] = t4_[2]; ubr[UR][4 * q + 3] = t4_[3]; \
+    }
 #define MH_W2_MFMA16(SET, UR, PAR)                                                                    \
     _Pragma("unroll") for (int i = 0; i < 16; ++i)                                                    \
         acc[SET][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[PAR][i], ubr[UR][i], acc[SET][i], 0, 0, 0);
@@ -161,40 +174,28 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
 #define MH_W2_STEP(PAR, SP1, S0, SM1)                                                                 \
     {                                                                                                 \
         const int bnext_ = bcur + 1 == W2_NBUF ? 0 : bcur + 1;                                        \
-        const float* ub_ = us + bcur * W2_UBUF + lane;                                                \
-        const float* un_ = us + bnext_ * W2_UBUF + lane;                                              \
-        /* phase 1: z-tap 0 | fetch z-tap 1's B operands | commit the next step's staged registers */ \
-        MH_W2_UBLOAD(1 - (PAR), k1ok ? ub_ + 16 * 64 : zslab)                                         \
-        MH_W2_MFMA16(SP1, PAR, PAR)                                                                   \
-        MH_W2_COMMIT(1 - (PAR), bnext_)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                        \
-        }                                                                                             \
-        __syncthreads();                                                                              \
-        /* phase 2a: z-tap 1 | fetch z-tap 2's B operands | loads of step g + 3 | patch of step g + 1 */ \
-        MH_W2_UBLOAD(PAR, k2ok ? ub_ + 32 * 64 : zslab)                                               \
-        MH_W2_ISSUE(1 - (PAR))                                                                        \
-        MH_W2_READ_PATCH(bnext_)                                                                      \
-        MH_W2_MFMA16(S0, 1 - (PAR), PAR)                                                              \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                                        \
-        }                                                                                             \
+        const float* ub_ = us + bcur * W2_UBUF + lane * W2_UPITCH;                                    \
+        const float* un_ = us + bnext_ * W2_UBUF + lane * W2_UPITCH;                                  \
+        /* On gfx950 an fp32 MFMA does not overlap with the wave's own VALU / LDS instructions, and every switch   */ \
+        /* between the two costs ~17 cycles (tools/ubench/issue.hip): the three z-taps issue as bursts of 16       */ \
+        /* back-to-back MFMAs, the other work sits in lumps between them (operands are fetched one burst ahead).   */ \
+        MH_W2_UBLOAD(1 - (PAR), k1ok ? ub_ + 16 : zslab)                                              \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        /* phase 2b: z-tap 2 | fetch the next step's z-tap 0 B operands | transform of step g + 1 */   \
+        MH_W2_MFMA16(SP1, PAR, PAR)                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        MH_W2_COMMIT(1 - (PAR), bnext_)                   /* next step's staged registers -> LDS */   \
+        __syncthreads();                                                                              \
+        MH_W2_UBLOAD(PAR, k2ok ? ub_ + 32 : zslab)                                                    \
+        MH_W2_ISSUE(1 - (PAR))                            /* global loads of step g + 3 */            \
+        MH_W2_READ_PATCH(bnext_)                          /* patch of step g + 1 */                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        MH_W2_MFMA16(S0, 1 - (PAR), PAR)                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
         MH_W2_UBLOAD(1 - (PAR), k0next ? un_ : zslab)                                                 \
-        MH_W2_TRANSFORM(1 - (PAR))                                                                    \
+        MH_W2_TRANSFORM(1 - (PAR))                        /* transform of step g + 1 */               \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
         MH_W2_MFMA16(SM1, PAR, PAR)                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                        \
-        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
         bcur = bnext_;                                                                                \
     }
 
@@ -257,9 +258,8 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
     // prologue: the first two steps' loads, commit the first, transform its patch, issue the third step's loads
     int bcur = 0;
     float* const zslab_w = smem + W2_NBUF * (W2_XBUF + W2_UBUF);
-#pragma unroll
-    for (int j = 0; j < W2_ZSLAB / 256; ++j) zslab_w[tid + 256 * j] = 0.0f;
-    const float* const zslab = zslab_w + lane;
+    if (tid < W2_ZSLAB) zslab_w[tid] = 0.0f;
+    const float* const zslab = zslab_w;             // every lane reads the same 16 zeros
     float* const dump = zslab_w + W2_ZSLAB + lane;
     MH_W2_ISSUE(0)
     MH_W2_ISSUE(1)
@@ -270,7 +270,7 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
     MH_W2_ISSUE(0)
     {   // B operands of the first step's z-tap 0 (the first real plane is zs - 1 or 0: its z-tap 0 feeds plane zs or 1)
         const int pf = max(zs - 1, 0);
-        const float* u0 = pf + 1 < ze ? us + lane : zslab;
+        const float* u0 = pf + 1 < ze ? us + lane * W2_UPITCH : zslab;
         MH_W2_UBLOAD(0, u0)
     }
 
@@ -323,14 +323,15 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
 #undef MH_W2_BT
 
 // Weight transform U^kz = G g[kz] G^T (y, x), written in the order operand B is read:
-// up[cout group][cin step][kz * 16 + xi][(cin & 3) * 16 + (cout & 15)].  One thread per (cout, cin).
+// up[cout group][cin step][lane = (cin & 3) * 16 + (cout & 15)][kz * 16 + xi] with lane pitch 52 inside a 4096-float
+// slab (the launcher zeroes the padding).  One thread per (cout, cin).
 __global__ void __launch_bounds__(256)
 conv3d_k3_wino2d_pack_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ up) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= Cin * Cout) return;
     const int ci = idx % Cin, co = idx / Cin;
     const int KS = Cin / W2_KC;
-    float* dst = up + (((long long)(co / W2_CN) * KS + ci / W2_KC) * 48) * 64 + (ci % W2_KC) * 16 + (co % W2_CN);
+    float* dst = up + ((long long)(co / W2_CN) * KS + ci / W2_KC) * W2_UBUF + ((ci % W2_KC) * 16 + (co % W2_CN)) * W2_UPITCH;
 #pragma unroll
     for (int kz = 0; kz < 3; ++kz) {
         float g[3][3], a[4][3], u[4][4];
@@ -351,7 +352,7 @@ conv3d_k3_wino2d_pack_kernel(const float* __restrict__ w, int Cin, int Cout, flo
             u[y][3] = a[y][2];
         }
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) dst[(long long)(kz * 16 + xi) * 64] = u[xi / 4][xi % 4];
+        for (int xi = 0; xi < 16; ++xi) dst[kz * 16 + xi] = u[xi / 4][xi % 4];
     }
 }
 

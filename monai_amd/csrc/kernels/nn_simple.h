@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
 // ConvTranspose3d k=2 s=2 of act(in): every input voxel owns a disjoint 2x2x2 output block, so it is eight
 // independent 1x1 convs.  One thread = one input voxel x COT output channels x 8 taps; weights
 // [Cin][Cout][8] are block-uniform (scalar loads); each (cout, dz, dy) row pair is one coalesced float2 store.
-template <int COT>
+template <int COT, bool FULL>     // FULL: Cout % COT == 0 (no channel guards in the hot loop)
 __global__ void __launch_bounds__(256)
 deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
     const int Di = in.D, Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
@@ -276,28 +276,38 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
     float acc[COT][8];
 #pragma unroll
     for (int j = 0; j < COT; ++j) {
-        const float bj = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+        const float bj = (bias && (FULL || co0 + j < Cout)) ? bias[co0 + j] : 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[j][k] = bj;
     }
     const float* src = in.data + (long long)n * in.n_stride + idx;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float4 a = load_nrm(in, n, ci);
-        const float v = act(src[(long long)ci * ivol], a.x, a.y, a.z);
-        const float* wr = w + ((long long)ci * Cout + co0) * 8;
+    constexpr int CB = 8;      // input channels whose loads fly together (one load per iteration would expose its latency Cin times)
+    for (int c0 = 0; c0 < Cin; c0 += CB) {
+        float v[CB];
 #pragma unroll
-        for (int j = 0; j < COT; ++j)
-            if (co0 + j < Cout) {
+        for (int c = 0; c < CB; ++c) v[c] = src[(long long)min(c0 + c, Cin - 1) * ivol];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(v, wr[j * 8 + k], acc[j][k]);
+        for (int c = 0; c < CB; ++c) {
+            const int ci = c0 + c;
+            if (ci < Cin) {
+                const float4 a = load_nrm(in, n, ci);
+                const float va = act(v[c], a.x, a.y, a.z);
+                const float* wr = w + ((long long)ci * Cout + co0) * 8;
+#pragma unroll
+                for (int j = 0; j < COT; ++j)
+                    if (FULL || co0 + j < Cout) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(va, wr[j * 8 + k], acc[j][k]);
+                    }
             }
+        }
     }
     const int Ho = out.H, Wo = out.W;
     const long long ovol = (long long)out.D * Ho * Wo;
     float* dst = out.data + (long long)n * out.n_stride;
 #pragma unroll
     for (int j = 0; j < COT; ++j)
-        if (co0 + j < Cout) {
+        if (FULL || co0 + j < Cout) {
 #pragma unroll
             for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
