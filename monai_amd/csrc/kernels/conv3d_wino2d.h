@@ -220,21 +220,16 @@ conv3d_k3_wino2d_kernel(Tensor in, const float* __restrict__ up, const float* __
                 *reinterpret_cast<f32x4*>(op_ + f * W + 4) = f32x4{o[f][0][2], o[f][1][2], o[f][0][3], o[f][1][3]}; \
             }                                                                                         \
         }                                                                                             \
-        if (STATS) {                                                                                  \
+        if (STATS) {      /* short dependency chains: quad-wise partial sums, rows masked by 0 / 1 */ \
             Stat loc_;                                                                                \
-            loc_.n = (rok0 ? 8.0f : 0.0f) + (rok1 ? 8.0f : 0.0f);                                     \
-            float sum_ = 0.0f;                                                                        \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                             \
-                _Pragma("unroll") for (int e = 0; e < 2; ++e)                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) sum_ += ((f == 0 ? rok0 : rok1) ? o[f][e][r] : 0.0f); \
+            const float w0_ = rok0 ? 1.0f : 0.0f, w1_ = rok1 ? 1.0f : 0.0f;                           \
+            loc_.n = 8.0f * (w0_ + w1_);                                                              \
+            const f32x4 s4_ = (o[0][0] + o[0][1]) * w0_ + (o[1][0] + o[1][1]) * w1_;                  \
+            const float sum_ = (s4_[0] + s4_[1]) + (s4_[2] + s4_[3]);                                 \
             loc_.mean = loc_.n > 0.0f ? sum_ / loc_.n : 0.0f;                                         \
-            loc_.m2 = 0.0f;                                                                           \
-            _Pragma("unroll") for (int f = 0; f < 2; ++f)                                             \
-                _Pragma("unroll") for (int e = 0; e < 2; ++e)                                         \
-                    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
-                        const float d_ = o[f][e][r] - loc_.mean;                                      \
-                        loc_.m2 += (f == 0 ? rok0 : rok1) ? d_ * d_ : 0.0f;                           \
-                    }                                                                                 \
+            const f32x4 d00_ = o[0][0] - loc_.mean, d01_ = o[0][1] - loc_.mean, d10_ = o[1][0] - loc_.mean, d11_ = o[1][1] - loc_.mean; \
+            const f32x4 q4_ = (d00_ * d00_ + d01_ * d01_) * w0_ + (d10_ * d10_ + d11_ * d11_) * w1_;  \
+            loc_.m2 = (q4_[0] + q4_[1]) + (q4_[2] + q4_[3]);                                          \
             run = stat_merge(run, loc_);                                                              \
         }                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[S][i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};     \

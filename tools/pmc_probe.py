@@ -35,3 +35,22 @@ k = gaussian_1d(1.0).numpy()
 for _ in range(3):
     ops.separable_filter3d(vol, [k, k, k])
 torch.cuda.synchronize()
+# the dominant conv of the headline workload: 32 -> 32 channels at 96^3, 25 windows per launch (in-plane Winograd and the
+# best direct tile): algorithmic HBM bytes = input + output = 2 x 25 x 32 x 96^3 x 4 B = 5.66 GB per launch
+del vol
+B = 25
+x = torch.randn(B, 32, 96, 96, 96, device=dev)
+w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
+bias = torch.zeros(32, device=dev)
+y = torch.empty(B, 32, 96, 96, 96, device=dev)
+xn = torch.zeros(B, 32, 4, device=dev)
+xn[:, :, 0] = 1.1
+xn[:, :, 1] = 0.1
+xn[:, :, 2] = 0.1
+for cfg in (ops.conv3d_k3_num_configs(), 7):
+    packed = ops.conv3d_k3_pack(cfg, w)
+    tiles = ops.conv3d_k3_stat_tiles(cfg, 96, 96, 96)
+    stats = torch.empty(B * 32 * tiles * 3, device=dev)
+    for _ in range(3):
+        ops.conv3d_k3(cfg, x, xn, packed, bias, y, stats)
+torch.cuda.synchronize()
