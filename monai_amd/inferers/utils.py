@@ -188,10 +188,11 @@ def sliding_window_inference(
     grid3 = [[0]] * (3 - num_spatial_dims) + [list(s) for s in starts]
     dev = inputs.device
 
-    # window range owned by this rank (all of them unless window sharding is on)
+    # windows owned by this rank: all of them, or (window sharding on) its slot of every round -- monai_amd/parallel.py
     shard = parallel.window_shard(num_win)
-    my_lo, my_hi = shard.lo, shard.hi
-    nb = _auto_batch(predictor, roi3, max(my_hi - my_lo, 1), sw_batch_size, dev)
+    nb = _auto_batch(predictor, roi3, max(-(-num_win // shard.world), 1), sw_batch_size, dev)
+    nb = shard.agree_batch(nb, dev)
+    my_rounds = shard.rounds(nb)
     fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs
     win_buf = torch.empty((nb, in_ch) + roi3, dtype=compute_dtype, device=dev)
 
@@ -211,7 +212,7 @@ def sliding_window_inference(
     fused = fused and hasattr(predictor, "out_channels")
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
-        steps = range(my_lo, my_hi, nb)
+        steps = list(enumerate(my_rounds))
         if progress:
             try:
                 from tqdm import tqdm
@@ -219,37 +220,46 @@ def sliding_window_inference(
                 steps = tqdm(steps)
             except ImportError:
                 pass
-        for w0 in steps:
-            n = min(nb, my_hi - w0)
-            ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
-            win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
-            if fused:
+        pending = []
+        for q, (w0, n) in steps:
+            if n > 0:
+                ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
+                win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
+                if fused:
+                    if logits is None:
+                        k = int(predictor.out_channels)
+                        seg_shapes, zscales = [tuple(roi_size)], [None]
+                        logits = [_alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
+                    predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
+                else:
+                    if with_coord:
+                        coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
+                        seg_out = predictor(win_data, coords, *args, **kwargs)
+                    else:
+                        seg_out = predictor(win_data, *args, **kwargs)
+                    dict_keys, segs = _flatten_struct(seg_out)
+                    if logits is None:
+                        seg_shapes = [tuple(s.shape[2:]) for s in segs]
+                        zscales = [
+                            None if sh == tuple(roi_size) else [o / float(i) for o, i in zip(sh, roi_size)] for sh in seg_shapes
+                        ]
+                        logits = [_alloc_logits(shard, nb, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
+                    for ss, s in enumerate(segs):
+                        _lib.require_device(s)
+                        dst = logits[ss][w0 : w0 + n]
+                        dst.copy_(s.reshape(dst.shape))
+            if shard.world > 1:
                 if logits is None:
-                    k = int(predictor.out_channels)
-                    seg_shapes, zscales = [tuple(roi_size)], [None]
-                    logits = [_alloc_logits(shard, k, roi3, compute_dtype, dev)]
-                predictor.forward_into(win_buf[:n], logits[0][w0 - shard.base : w0 - shard.base + n])
-                continue
-            if with_coord:
-                coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
-                seg_out = predictor(win_data, coords, *args, **kwargs)
-            else:
-                seg_out = predictor(win_data, *args, **kwargs)
-            dict_keys, segs = _flatten_struct(seg_out)
-            if logits is None:
-                seg_shapes = [tuple(s.shape[2:]) for s in segs]
-                zscales = [
-                    None if sh == tuple(roi_size) else [o / float(i) for o, i in zip(sh, roi_size)] for sh in seg_shapes
-                ]
-                logits = [_alloc_logits(shard, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
-            for ss, s in enumerate(segs):
-                _lib.require_device(s)
-                dst = logits[ss][w0 - shard.base : w0 - shard.base + n]
-                dst.copy_(s.reshape(dst.shape))
+                    raise RuntimeError("monai_amd: a rank without windows in the first round cannot size the logits buffer "
+                                       "(fewer windows than ranks x windows per launch: lower sw_batch_size)")
+                # this round's rows travel while the next round computes
+                pending += [shard.gather_round(lg, q, nb) for lg in logits]
 
         if logits is None:
             raise RuntimeError("monai_amd: no windows were processed")
-        gathered = [shard.all_gather(lg) for lg in logits]
+        for work in pending:
+            work.wait()
+        gathered = logits
 
         if weights is None:  # importance map per output resolution (the reference resamples cumulatively, utils.py:260-263)
             weights, w_t = [], imp[None, None]
@@ -293,10 +303,11 @@ def sliding_window_inference(
     return _pack_struct(finals, dict_keys)
 
 
-def _alloc_logits(shard, k: int, seg3, dtype, dev) -> torch.Tensor:
-    """Logits of the windows this rank computes.  Without sharding that is every window (and the buffer is the
-    blend input itself); with sharding it is the rank's equal-sized chunk, all-gathered before the blend."""
-    need = shard.chunk * k * seg3[0] * seg3[1] * seg3[2] * 4 * (shard.world + 1 if shard.world > 1 else 1)
+def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
+    """Logits of every window of the image, [num_win (padded to whole rounds when sharded), K, *seg3]: the predictor
+    writes its windows' rows, window sharding completes the others, the blend reads it once."""
+    rows = shard.padded_windows(nb)
+    need = rows * k * seg3[0] * seg3[1] * seg3[2] * 4
     if dev.type == "cuda":
         free, _ = torch.cuda.mem_get_info(dev)
         if need > 0.9 * free:
@@ -304,7 +315,7 @@ def _alloc_logits(shard, k: int, seg3, dtype, dev) -> torch.Tensor:
                 f"monai_amd: the all-window logits buffer needs {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB of HBM "
                 "are free; use a smaller volume or more classes per pass (slab-wise blending is not implemented yet)"
             )
-    return torch.empty((shard.chunk, k) + tuple(seg3), dtype=dtype, device=dev)
+    return torch.empty((rows, k) + tuple(seg3), dtype=dtype, device=dev)
 
 
 def _restore_meta(out: torch.Tensor, src):

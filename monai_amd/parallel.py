@@ -1,10 +1,13 @@
 """Window sharding across the GPUs of one node.
 
-The sliding-window path shards naturally: windows are independent until the blend.  With sharding enabled each
-rank (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests) runs the
-predictor on one contiguous, equal-sized range of window indices and a single ``all_gather_into_tensor`` of the
-per-window logits rebuilds the full ``[num_win, K, roi]`` buffer on every rank; the deterministic gather blend then
-runs unchanged, so the result is identical to the single-GPU result on every rank.  The reference has no
+The sliding-window path shards naturally: windows are independent until the blend.  With sharding enabled the window
+index space is cut into ROUNDS of ``world x nb`` consecutive windows (nb = windows per predictor launch); in round q
+rank r (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests) runs the
+predictor on windows ``[q*world*nb + r*nb, +nb)`` and writes their logits straight into its slice of the full
+``[rounds*world*nb, K, roi]`` buffer; one ``all_gather_into_tensor`` per round -- issued asynchronously, so it
+travels over xGMI while the next round computes -- completes that round's rows on every rank.  After the last round
+every rank holds every window's logits and the deterministic gather blend runs unchanged: the result is identical to
+the single-GPU result on every rank (the blend never depended on who computed a window).  The reference has no
 counterpart (monai/utils/dist.py:59-140 only gathers metrics).
 
 Nothing here runs unless ``enable_window_sharding()`` was called (bench.py does, for --gpus > 1): the public
@@ -36,6 +39,17 @@ def disable_window_sharding() -> None:
     _GROUP, _ENABLED = None, False
 
 
+class _Pending:
+    """An in-flight collective together with the send buffer it reads."""
+
+    def __init__(self, work, keep):
+        self.work, self.keep = work, keep
+
+    def wait(self):
+        self.work.wait()
+        self.keep = None
+
+
 @dataclass
 class WindowShard:
     """Rank-local view of the window index space [0, num_win)."""
@@ -44,7 +58,7 @@ class WindowShard:
     world: int
     rank: int
     chunk: int   # windows per rank (equal on every rank; the last ranks may own fewer real windows)
-    lo: int      # first global window index of this rank
+    lo: int      # first global window index of this rank (contiguous partition, see `partition`)
     hi: int      # one past the last REAL window of this rank
     group: Optional[object] = None
 
@@ -59,6 +73,42 @@ class WindowShard:
         out = torch.empty((self.world * self.chunk,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
+
+    # ---- round-interleaved schedule: communication of round q overlaps the computation of round q + 1 -------------
+    def agree_batch(self, nb: int, device) -> int:
+        """Windows per predictor launch, identical on every rank (the minimum of the ranks' own choices)."""
+        if self.world == 1:
+            return nb
+        t = torch.tensor([int(nb)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
+
+    def rounds(self, nb: int):
+        """(first global window, number of real windows) of this rank in each round; windows beyond num_win are padding."""
+        span = self.world * nb
+        out = []
+        for q in range((self.num_win + span - 1) // span):
+            w0 = q * span + self.rank * nb
+            out.append((w0, max(0, min(nb, self.num_win - w0))))
+        return out
+
+    def padded_windows(self, nb: int) -> int:
+        span = self.world * nb
+        return (self.num_win + span - 1) // span * span if self.world > 1 else self.num_win
+
+    def gather_round(self, full: torch.Tensor, q: int, nb: int):
+        """Complete rows [q*world*nb, (q+1)*world*nb) of `full` on every rank (this rank has written its own nb rows).
+        Returns the async work handle (None when world == 1)."""
+        if self.world == 1:
+            return None
+        span = self.world * nb
+        out = full[q * span : (q + 1) * span]
+        mine = out[self.rank * nb : (self.rank + 1) * nb]
+        # a private copy of the rank's rows as the send buffer (0.4 GB per round at the BASELINE sizes, ~0.2 ms): no
+        # aliasing rules of the backend to depend on; the handle keeps it alive until the collective has completed
+        src = mine.clone()
+        work = dist.all_gather_into_tensor(out, src, group=self.group, async_op=True)
+        return _Pending(work, src)
 
 
 def partition(num_win: int, world: int, rank: int, group=None) -> WindowShard:

@@ -40,6 +40,10 @@ def _worker(rank, world, port, shape, roi, ret):
             single = inf(x, net).clone()
             parallel.enable_window_sharding()
             sharded = inf(x, net).clone()
+            os.environ["MONAI_AMD_SW_BATCH"] = "2"      # 2 windows per launch -> 2 rounds of 4, the last one half padding
+            sharded2 = inf(x, net).clone()
+            del os.environ["MONAI_AMD_SW_BATCH"]
+            assert torch.equal(sharded, sharded2), "the result must not depend on the round size"
             parallel.disable_window_sharding()
             shard = parallel.partition(7, world, rank)
         ret[rank] = (single, sharded, (shard.lo, shard.hi, shard.chunk))
