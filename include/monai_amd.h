@@ -69,8 +69,15 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
 /* ---- network blocks (BasicUNet: monai/networks/nets/basic_unet.py:27-279) -------------------------- */
 
 /* Conv3d k=3, stride 1, padding 1 (+bias) -- the conv of `Convolution`, blocks/convolutions.py:98-171.
- * Several kernel configurations exist; mh_conv3d_k3_select picks one (0 = direct VALU kernel, any
- * channel counts; >= 1 = fp32-MFMA implicit-GEMM tiles).  Weights are repacked once per configuration. */
+ * Several kernel configurations exist; mh_conv3d_k3_select picks one:
+ *   0                      direct VALU kernel, any channel counts
+ *   1 .. n-2               fp32-MFMA implicit-GEMM tiles (v_mfma_f32_32x32x2_f32)
+ *   n-1                    Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32 (Cin % 4 == 0, Cout % 16 == 0, even extents);
+ *                          only selected under MONAI_AMD_CONV_ALGO=winograd
+ *   n = num_configs()      Winograd F(2x2, 3x3) in (y, x) + three direct z taps, z-streaming (Cin % 8 == 0, Cout % 16 == 0,
+ *                          even H, W % 8 == 0); selected for full 16 x 16 regions of planes >= 48^2 with D >= 48
+ * (MONAI_AMD_CONV_ALGO = direct | wino2d | winograd pins the family.)  Weights are repacked (Winograd: transformed)
+ * once per configuration. */
 int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W);
 int mh_conv3d_k3_num_configs(void);                    /* highest configuration id */
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */

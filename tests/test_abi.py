@@ -1,0 +1,43 @@
+"""-m "not gpu": the C-ABI library builds for gfx950, loads on a GPU-less host and exports every entry point that
+include/monai_amd.h declares -- and the Python binding table (monai_amd/_lib.py:SIGNATURES) names exactly those."""
+import ctypes
+import os
+import re
+
+from monai_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "monai_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return sorted(set(re.findall(r"\b(mh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _declared()
+    assert len(names) >= 26 and "mh_sw_blend_f32" in names and "mh_conv3d_k3_f32" in names
+    assert os.path.isfile(_lib.LIB_PATH), "build the extension first: python -m monai_amd.build (or __graft_entry__.build())"
+    dll = ctypes.CDLL(_lib.LIB_PATH)          # loading needs no GPU; no compute entry point is called here
+    missing = [n for n in names if not hasattr(dll, n)]
+    assert not missing, missing
+    dll.mh_version.restype = ctypes.c_int
+    assert dll.mh_version() >= 100
+    dll.mh_last_error.restype = ctypes.c_char_p
+    assert isinstance(dll.mh_last_error(), bytes)
+
+
+def test_binding_table_matches_the_header():
+    assert sorted(_lib.SIGNATURES) == _declared()
+
+
+def test_host_side_queries_need_no_gpu():
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    dll.mh_conv3d_k3_select.restype = ctypes.c_int
+    dll.mh_conv3d_k3_num_configs.restype = ctypes.c_int
+    n = dll.mh_conv3d_k3_num_configs()
+    assert 1 <= dll.mh_conv3d_k3_select(1, 32, 96, 96, 96) <= n
+    assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == n          # large planes: the in-plane Winograd configuration
+    assert dll.mh_instnorm_stat_tiles(96, 96, 96) > 0
