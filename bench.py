@@ -32,7 +32,7 @@ PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (≈6.3 TB/s achievable)
 
 
-def cpu_baseline(size: int, roi: int, windows: int):
+def cpu_baseline(size: int, roi: int, windows: int, vol=None, net=None):
     """The CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
     tests/test_oracle_golden.py) on a bounded sample of windows; value = size^3 / (num_windows * mean window time).
 
@@ -43,8 +43,16 @@ def cpu_baseline(size: int, roi: int, windows: int):
 
     torch.manual_seed(1)
     sd = oracle.make_basic_unet_state(1, 5)
+    starts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
     torch.manual_seed(0)
     x = torch.rand(4, 1, roi, roi, roi)
+    sample = None
+    if vol is not None:     # time the oracle on REAL windows of the benchmark volume, so its logits can be compared below
+        import itertools
+
+        first = list(itertools.islice(itertools.product(*starts), ((windows + 3) // 4) * 4))
+        sample = torch.stack([vol[0, :, a:a + roi, b:b + roi, c:c + roi] for a, b, c in first]).cpu()
+        x = sample[:4]
     ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
     best, best_t = cands[0], float("inf")
@@ -60,11 +68,25 @@ def cpu_baseline(size: int, roi: int, windows: int):
         torch.set_num_threads(best)
         t0 = time.perf_counter()
         done = 0
+        ref = []
         while done < windows:
-            oracle.basic_unet_forward(sd, x)  # sw_batch_size = 4, as in the workload
+            xb = x if sample is None else sample[done:done + 4]
+            ref.append(oracle.basic_unet_forward(sd, xb))  # sw_batch_size = 4, as in the workload
             done += 4
         dt = time.perf_counter() - t0
-    starts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
+    parity = None
+    if sample is not None and net is not None:   # the same windows through the HIP path: logits and label maps vs the oracle
+        with torch.no_grad():
+            got = net(sample.to(vol.device)).cpu()
+        exp = torch.cat(ref)
+        la, lb = got.argmax(1), exp.argmax(1)
+        dice = []
+        for k in range(exp.shape[1]):
+            a, b = la == k, lb == k
+            den = int(a.sum()) + int(b.sum())
+            dice.append(1.0 if den == 0 else 2.0 * int((a & b).sum()) / den)
+        parity = {"windows": int(exp.shape[0]), "max_abs_logit_diff": float((got - exp).abs().max()), "tolerance": 1e-4,
+                  "argmax_mismatch_voxels": int((la != lb).sum()), "voxels": int(la.numel()), "min_class_dice": min(dice)}
     nwin = len(starts[0]) * len(starts[1]) * len(starts[2])
     per_win = dt / done
     return {
@@ -72,6 +94,7 @@ def cpu_baseline(size: int, roi: int, windows: int):
         "unit": "voxels/s",
         "cores": best,
         "kind": "port",
+        "parity_vs_gpu": parity,
         "sample": f"{done} of {nwin} windows ({roi}^3, sw_batch 4) through the CPU oracle's BasicUNet on {best} of {ncpu} host threads "
                   f"(fastest of {cands}): {per_win:.3f} s/window; value = {size}^3 voxels / ({nwin} windows x that); the blend (1-2 % on CPU) is not included",
     }
@@ -208,7 +231,7 @@ def main():
             "checksum": float(out.double().sum().item()),
         }
         if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
-            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

@@ -118,6 +118,10 @@ int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, cons
  * deferred InstanceNorm records (b->nrm NULL = identity shortcut; b NULL = no second operand: materialises act(a)). */
 int mh_add_act_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const mh_tensor5* out, void* stream);
 
+/* Replicate padding at the far end of each axis (out extents = in extents + 0 or 1): `UpCat`'s
+ * F.pad(x_0, sp, "replicate") for odd encoder extents -- monai/networks/nets/basic_unet.py:163-170.  Raw copy. */
+int mh_pad_replicate_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
+
 /* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*64] (the qkv Linear's output,
  * feature index = which*heads*64 + head*64 + d) -> out [B][S][heads*64] = softmax(Q K^T * scale) V per head, on
  * v_mfma_f32_32x32x2_f32 with K/V of a head resident in LDS.  head_dim 64, S <= 224 (ViT-B/16 on 96^3: S = 216). */

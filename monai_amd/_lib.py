@@ -61,6 +61,7 @@ SIGNATURES = {
     "mh_conv3d_k3_strided_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_deconv_k3_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_add_act_f32": (_I, [_T, _T, _F, _T, _P]),
+    "mh_pad_replicate_f32": (_I, [_T, _T, _P]),
     "mh_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "mh_affine_resample_workspace_bytes": (_L, [_I, _I, _I]),
     "mh_affine_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _I, _P, _P]),

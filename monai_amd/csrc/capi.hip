@@ -603,6 +603,16 @@ int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, cons
     return launched("add_act");
 }
 
+int mh_pad_replicate_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "pad_replicate: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.C != out.C || out.D < in.D || out.H < in.H || out.W < in.W || out.D > in.D + 1 || out.H > in.H + 1 || out.W > in.W + 1)
+        return fail(MH_ERR_ARG, "pad_replicate: output extents must be the input's plus 0 or 1");
+    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)out.C, (unsigned)out.N);
+    hipLaunchKernelGGL(pad_replicate_kernel, grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    return launched("pad_replicate");
+}
+
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream) {
     if (!qkv || !out || B < 1 || S < 1 || heads < 1) return fail(MH_ERR_ARG, "attention: bad argument");
     if (head_dim != 64) return fail(MH_ERR_UNSUPPORTED, "attention: head_dim %d is not built (64 is)", head_dim);

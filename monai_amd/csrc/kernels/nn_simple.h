@@ -397,6 +397,21 @@ __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Replicate padding at the far end of each axis: out[z, y, x] = in[min(z, Di-1), min(y, Hi-1), min(x, Wi-1)] -- UpCat's
+// F.pad(x_0, sp, "replicate") for odd encoder extents (monai/networks/nets/basic_unet.py:163-170).  Raw copy (no norm).
+__global__ void __launch_bounds__(256) pad_replicate_kernel(Tensor in, Tensor out) {
+    const long long ovol = (long long)out.D * out.H * out.W, ivol = (long long)in.D * in.H * in.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    if (idx >= ovol) return;
+    const int x = (int)(idx % out.W);
+    const long long t = idx / out.W;
+    const int y = (int)(t % out.H), z = (int)(t / out.H);
+    const long long src = ((long long)min(z, in.D - 1) * in.H + min(y, in.H - 1)) * in.W + min(x, in.W - 1);
+    out.data[(long long)n * out.n_stride + (long long)c * ovol + idx] = in.data[(long long)n * in.n_stride + (long long)c * ivol + src];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // InstanceNorm statistics, stand-alone pass: one {count, mean, M2} record per 4096-element chunk of each
 // (n, c) plane; M2 is taken about the chunk mean (two passes over registers), so no E[x^2]-E[x]^2 cancellation.
 constexpr int STAT_CHUNK = 4096;

@@ -170,11 +170,8 @@ class BasicUNet(nn.Module):
             raise RuntimeError("monai_amd.BasicUNet is an inference engine: call .eval() first")
         x = x.contiguous()
         n, _, d, h, w = x.shape
-        if d % 16 or h % 16 or w % 16:
-            raise NotImplementedError(
-                f"monai_amd.BasicUNet: window {d}x{h}x{w} must be divisible by 16 (the replicate-padded odd-edge "
-                "case of UpCat, basic_unet.py:163-170, is not on the HIP path yet)"
-            )
+        if min(d, h, w) < 16:
+            raise RuntimeError(f"monai_amd.BasicUNet: window {d}x{h}x{w} is too small for four 2x poolings")
         key = (n, d, h, w, str(x.device))
         plan = self._plans.get(key)
         if plan is None:
@@ -211,6 +208,11 @@ class _Plan:
         self.tmp = [e(max(f[l], dec_out[l]) if l < 4 else f[4], l) for l in range(5)]
         self.tmp_nrm = [nz(max(f[l], dec_out[l]) if l < 4 else f[4]) for l in range(5)]
         self.pool = [None] + [e(f[l - 1], l) for l in range(1, 5)]
+        # odd extents: the transposed conv of level l+1 yields 2 * floor(sp[l] / 2); UpCat replicate-pads the far end
+        # (basic_unet.py:163-170).  Those levels deconvolve into a dense scratch tensor and pad-copy it into the concat buffer.
+        self.odd = [any(v & 1 for v in self.sp[l]) for l in range(4)]
+        self.up_scratch = [torch.empty((n, up[l]) + tuple(2 * v for v in self.sp[l + 1]), dtype=torch.float32, device=device)
+                           if self.odd[l] else None for l in range(4)]
         self.x4, self.x4_nrm = e(f[4], 4), nz(f[4])
         self.u = [e(dec_out[l], l) for l in range(4)]
         self.u_nrm = [nz(dec_out[l]) for l in range(4)]
@@ -268,7 +270,11 @@ class _Plan:
         src, src_nrm = self.x4, self.x4_nrm
         for l in range(3, -1, -1):
             upc = ups[l]
-            ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.cat[l][:, f[l]:])
+            if self.odd[l]:
+                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.up_scratch[l])
+                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:])
+            else:
+                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.cat[l][:, f[l]:])
             co = self.dec_out[l]
             t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
             self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn)

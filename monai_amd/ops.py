@@ -191,6 +191,14 @@ def add_act(a, a_nrm, b, b_nrm, slope: float, out):
     return out
 
 
+def pad_replicate(x, out):
+    """out[z, y, x] = x[min(z, D-1), min(y, H-1), min(x, W-1)]: replicate padding at the far end (UpCat's odd-edge case)."""
+    _lib.require_device(x, out)
+    xi, xo = _lib.tensor5(x), _lib.tensor5(out)
+    _lib.lib().call("mh_pad_replicate_f32", C.byref(xi), C.byref(xo), _s(x))
+    return out
+
+
 def attention(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     """qkv [B, S, 3*heads*64] -> [B, S, heads*64] = softmax(Q K^T * scale) V per head (fp32 MFMA)."""
     _lib.require_device(qkv)

@@ -56,6 +56,18 @@ def case_net_single_window_vs_golden(device):
     return r, r2
 
 
+def case_net_odd_window_vs_golden(device):
+    """Window extents that are odd at levels 1, 2 and 3: UpCat's replicate padding (basic_unet.py:163-170) vs the reference."""
+    g = np.load(os.path.join(GOLDEN, "net5_odd.npz"))
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(23)
+    x = torch.rand(1, 1, 40, 36, 34)
+    got = net(x.to(device)).cpu()
+    r = report(got, torch.from_numpy(g["out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    return r
+
+
 def case_sliding_window_net5_vs_golden(device):
     from monai_amd.inferers import SlidingWindowInferer
 

@@ -29,3 +29,7 @@ def test_basic_unet_with_inplane_winograd(emu, monkeypatch):
     """The whole BasicUNet window path with every eligible 3x3x3 conv on the in-plane Winograd configuration."""
     monkeypatch.setenv("MONAI_AMD_CONV_ALGO", "wino2d")
     print(ec.case_net_single_window_vs_golden("cpu"))
+
+
+def test_basic_unet_odd_window_vs_reference(emu):
+    print(ec.case_net_odd_window_vs_golden("cpu"))

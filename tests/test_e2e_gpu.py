@@ -156,3 +156,7 @@ def test_unet_sliding_window_vs_oracle():
     r = ec.report(y.cpu(), ref)
     print(r)
     assert r["max_abs"] < ec.LOGIT_TOL, r
+
+
+def test_basic_unet_odd_window_vs_reference():
+    print(ec.case_net_odd_window_vs_golden(DEV))

@@ -276,3 +276,15 @@ def test_unetr_oracle_small_vs_reference(golden_dir):
     with torch.no_grad():
         y = our.unetr_forward(sd, x, heads=2)
     assert np.abs(y.numpy() - g["small_out"]).max() < 1e-5
+
+
+def test_basic_unet_oracle_odd_window_bitwise_vs_reference(golden_dir):
+    """UpCat's replicate padding of odd extents (basic_unet.py:163-170): oracle vs the real reference, bit for bit."""
+    g = _load(golden_dir, "net5_odd.npz")
+    torch.manual_seed(1)
+    sd = oracle.make_basic_unet_state(1, 5)
+    torch.manual_seed(23)
+    x = torch.rand(1, 1, 40, 36, 34)
+    with torch.no_grad():
+        y = oracle.basic_unet_forward(sd, x)
+    assert np.array_equal(y.numpy(), g["out"])
