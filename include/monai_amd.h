@@ -61,10 +61,12 @@ int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const in
  *   logits  [nz*ny*nx][K][rd][rh][rw]   all windows of the grid, in window order
  *   imp     [rd][rh][rw]                importance map (monai/data/utils.py:1084-1134)
  *   out     [K][D][H][W]
- * Every voxel must be covered by at least one window (true for dense_patch_slices). */
+ * Every voxel must be covered by at least one window (true for dense_patch_slices).
+ * premultiplied != 0: `logits` already hold logit*w (the `process_fn` path, utils.py:232-234, where the weight may change
+ * per window batch): acc += logit, cnt += imp -- the reference's `seg *= w_t` followed by `+=`, with its count map. */
 int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd,
                     int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
-                    int nx, void* stream);
+                    int nx, int premultiplied, void* stream);
 
 /* ---- network blocks (BasicUNet: monai/networks/nets/basic_unet.py:27-279) -------------------------- */
 

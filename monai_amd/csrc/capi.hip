@@ -86,11 +86,11 @@ int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const in
 
 template <int VEC>
 static void launch_blend(int kt, unsigned nb, hipStream_t s, const float* logits, const float* imp, float* out, int K, int k0,
-                         int D, int H, int W, int rd, int rh, int rw, const WindowGrid& g) {
+                         int D, int H, int W, int rd, int rh, int rw, const WindowGrid& g, int premul) {
 #define MH_BLEND_CASE(KT)                                                                                              \
     case KT:                                                                                                           \
         hipLaunchKernelGGL((sw_blend_kernel<KT, VEC>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, \
-                           rh, rw, g);                                                                                 \
+                           rh, rw, g, premul);                                                                         \
         break;
     switch (kt) {
         MH_BLEND_CASE(1) MH_BLEND_CASE(2) MH_BLEND_CASE(3) MH_BLEND_CASE(4)
@@ -100,7 +100,7 @@ static void launch_blend(int kt, unsigned nb, hipStream_t s, const float* logits
 }
 
 int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
-                    const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, void* stream) {
+                    const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
     if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "sw_blend: bad argument");
     WindowGrid g;
     if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
@@ -116,8 +116,8 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
     for (int k0 = 0; k0 < K; k0 += 8) {
         const int kt = K - k0 < 8 ? K - k0 : 8;
-        if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g);
-        else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g);
+        if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
+        else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
     }
     return launched("sw_blend");
 }

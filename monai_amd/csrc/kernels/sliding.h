@@ -62,7 +62,7 @@ window_extract_kernel(const float* __restrict__ vol, int C, int D, int H, int W,
 template <int KT, int VEC>
 __global__ void __launch_bounds__(256)
 sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K,
-                int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g) {
+                int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g, int premul) {
     const int wv = W / VEC;
     const long long total = (long long)D * H * wv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -113,7 +113,8 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) acc[k][v] = __fadd_rn(acc[k][v], __fmul_rn(lv[k][v], wt[v]));
+                    // premul: the logits were already multiplied by their (per-batch) weight (process_fn); x * 1.0f is exact
+                    for (int k = 0; k < KT; ++k) acc[k][v] = __fadd_rn(acc[k][v], __fmul_rn(lv[k][v], premul ? 1.0f : wt[v]));
                     cnt[v] = __fadd_rn(cnt[v], wt[v]);
                 }
             }

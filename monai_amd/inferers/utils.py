@@ -123,7 +123,8 @@ def sliding_window_inference(
 
     Differences, all result-neutral: ``buffer_steps`` / ``buffer_dim`` are validated and otherwise ignored (they are
     a memory-saving schedule of the reference, not a different result -- the blend here never materialises partial
-    volumes); ``sw_device`` must be the ROCm device the inputs live on; ``process_fn`` is not supported yet.
+    volumes); ``sw_device`` must be the ROCm device the inputs live on.  ``process_fn`` (utils.py:232-234) is honoured with
+    the reference's semantics: each batch is multiplied by the weight map it returns, the count map uses the first batch's.
     """
     num_spatial_dims = inputs.dim() - 2
     buffered = buffer_steps is not None and buffer_steps > 0
@@ -136,9 +137,6 @@ def sliding_window_inference(
             raise ValueError(f"overlap must be >= 0 and < 1, got {overlap}.")
     if num_spatial_dims < 1 or num_spatial_dims > 3:
         raise NotImplementedError(f"monai_amd: sliding windows over {num_spatial_dims} spatial dims are not supported (1-3 are)")
-    if process_fn is not None:
-        raise NotImplementedError("monai_amd: process_fn is not supported on the HIP path yet")
-
     meta_src = inputs if (type(inputs) is not torch.Tensor and hasattr(inputs, "as_tensor")) else None
     if meta_src is not None:
         inputs = inputs.as_tensor()
@@ -193,7 +191,7 @@ def sliding_window_inference(
     nb = _auto_batch(predictor, roi3, max(-(-num_win // shard.world), 1), sw_batch_size, dev)
     nb = shard.agree_batch(nb, dev)
     my_rounds = shard.rounds(nb)
-    fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs
+    fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs and process_fn is None
     win_buf = torch.empty((nb, in_ch) + roi3, dtype=compute_dtype, device=dev)
 
     windows_nd = None
@@ -207,6 +205,8 @@ def sliding_window_inference(
     dict_keys = None
     outputs = None     # per output: [B, K, *out_img3]
     weights = None     # per output: importance map resampled to the prediction size (device)
+    proc_weights = None  # process_fn: per output, the first batch's weight map (the reference's count map uses only that one)
+    imp_dev = None
     zscales = None
 
     fused = fused and hasattr(predictor, "out_channels")
@@ -238,6 +238,15 @@ def sliding_window_inference(
                     else:
                         seg_out = predictor(win_data, *args, **kwargs)
                     dict_keys, segs = _flatten_struct(seg_out)
+                    w_batch = None
+                    if process_fn is not None:     # utils.py:232-238: the callback may edit the predictions and the weight map
+                        if imp_dev is None:
+                            imp_dev = imp.to(dev)
+                        segs, w_t = process_fn(segs, win_data, imp_dev)
+                        segs = tuple(segs) if isinstance(segs, (list, tuple)) else (segs,)
+                        if w_t.dim() == num_spatial_dims:
+                            w_t = w_t[None, None]
+                        w_batch = w_t.to(dtype=compute_dtype, device=dev)
                     if logits is None:
                         seg_shapes = [tuple(s.shape[2:]) for s in segs]
                         zscales = [
@@ -247,7 +256,19 @@ def sliding_window_inference(
                     for ss, s in enumerate(segs):
                         _lib.require_device(s)
                         dst = logits[ss][w0 : w0 + n]
-                        dst.copy_(s.reshape(dst.shape))
+                        if w_batch is None:
+                            dst.copy_(s.reshape(dst.shape))
+                            continue
+                        if zscales[ss] is not None:      # cumulative nearest resampling, as utils.py:260-263
+                            w_batch = F.interpolate(w_batch, seg_shapes[ss], mode=_NEAREST)
+                        if w_batch.shape[0] != 1 or w_batch.shape[1] != 1:
+                            raise RuntimeError("monai_amd: process_fn must return a weight map broadcastable over batch and channels "
+                                               f"(got {tuple(w_batch.shape)}; the reference's count map needs [1, 1, *spatial])")
+                        if proc_weights is None:
+                            proc_weights = []
+                        if len(proc_weights) <= ss:      # the count map is built from the FIRST batch's map (utils.py:270-275)
+                            proc_weights.append(w_batch[0, 0].reshape(_to3(seg_shapes[ss], 1)).contiguous().clone())
+                        torch.mul(s.reshape(dst.shape), w_batch.reshape((1, 1) + tuple(dst.shape[2:])), out=dst)   # `seg *= w_t`
             if shard.world > 1:
                 if logits is None:
                     raise RuntimeError("monai_amd: a rank without windows in the first round cannot size the logits buffer "
@@ -278,7 +299,10 @@ def sliding_window_inference(
                 g = [[0]] * (3 - num_spatial_dims) + [[int(s * zz) for s in ax] for ax, zz in zip(starts, z)]
             nbytes = 4.0 * (lg[:num_win].numel() + outputs[ss][b].numel())  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
-                ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
+                if proc_weights is not None:
+                    ops.sw_blend(lg[:num_win], proc_weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1), premultiplied=True)
+                else:
+                    ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
 
     # back to the caller's rank / crop the padding (utils.py:300-313) / output device
     finals = []

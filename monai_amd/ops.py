@@ -35,9 +35,10 @@ def window_extract(vol: torch.Tensor, grid: Grid, w0: int, nwin: int, roi: Seque
     return out
 
 
-def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int]) -> torch.Tensor:
+def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int], premultiplied: bool = False) -> torch.Tensor:
     """logits [nwin,K,rd,rh,rw] (all windows of the grid, in order), imp [rd,rh,rw] -> out [K,D,H,W] =
-    sum_w logits*imp / sum_w imp in the reference's summation order (monai/inferers/utils.py:264-298)."""
+    sum_w logits*imp / sum_w imp in the reference's summation order (monai/inferers/utils.py:264-298).
+    premultiplied: `logits` already hold logit * weight (process_fn path); only the count uses `imp`."""
     _lib.require_device(logits, imp, out)
     if not (logits.is_contiguous() and imp.is_contiguous() and out.is_contiguous()):
         raise RuntimeError("monai_amd.sw_blend: contiguous tensors required")
@@ -47,7 +48,7 @@ def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: G
         raise RuntimeError(f"monai_amd.sw_blend: logits shape {tuple(logits.shape)} does not match the window grid")
     _lib.lib().call(
         "mh_sw_blend_f32", _lib.ptr(logits), _lib.ptr(imp), _lib.ptr(out), k, d, h, w, int(roi[0]), int(roi[1]), int(roi[2]),
-        _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), _s(out),
+        _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), int(bool(premultiplied)), _s(out),
     )
     return out
 

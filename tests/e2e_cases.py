@@ -121,6 +121,37 @@ def case_blend_only_vs_golden(device):
     assert i >= 5
 
 
+def case_process_fn_vs_golden(device):
+    """`process_fn` (utils.py:232-238): predictions edited per batch, a weight map that changes from batch to batch, the
+    count map built from the first batch's -- bit-exact against the real reference (tests/golden/make_golden_process_fn.py)."""
+    from monai_amd.inferers import sliding_window_inference
+
+    g = np.load(os.path.join(GOLDEN, "process_fn.npz"))
+
+    def toy(x):
+        return torch.cat([torch.sin(x[:, :1] * (1.0 + 0.37 * k)) + 0.05 * k * x[:, :1] for k in range(3)], dim=1)
+
+    def make_process_fn():
+        calls = {"n": 0}
+
+        def process_fn(segs, win_data, imp):
+            calls["n"] += 1
+            segs = tuple(s * 0.5 + 0.25 * win_data.mean() for s in segs)
+            return segs, imp * (1.0 + 0.125 * (calls["n"] % 3)) + 0.0625
+
+        return process_fn
+
+    i = 0
+    while f"pf_{i}_shape" in g:
+        torch.manual_seed(40 + i)
+        x = torch.rand(tuple(int(v) for v in g[f"pf_{i}_shape"]))
+        y = sliding_window_inference(x.to(device), tuple(int(v) for v in g[f"pf_{i}_roi"]), int(g[f"pf_{i}_sw"]), toy,
+                                     overlap=float(g[f"pf_{i}_ov"]), mode=str(g[f"pf_{i}_mode"]), process_fn=make_process_fn())
+        assert np.array_equal(y.cpu().numpy(), g[f"pf_{i}_out"]), f"process_fn case {i}: not bit-identical to the reference"
+        i += 1
+    assert i == 2
+
+
 # ------------------------------------------------------------------------------------------ UNETR
 def _digest(sd):
     """all parameters except the position embedding (see tests/golden/make_golden_unetr.py:digest)"""

@@ -33,3 +33,7 @@ def test_basic_unet_with_inplane_winograd(emu, monkeypatch):
 
 def test_basic_unet_odd_window_vs_reference(emu):
     print(ec.case_net_odd_window_vs_golden("cpu"))
+
+
+def test_process_fn_bitwise_vs_reference(emu):
+    ec.case_process_fn_vs_golden("cpu")

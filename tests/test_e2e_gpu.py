@@ -160,3 +160,7 @@ def test_unet_sliding_window_vs_oracle():
 
 def test_basic_unet_odd_window_vs_reference():
     print(ec.case_net_odd_window_vs_golden(DEV))
+
+
+def test_process_fn_bitwise_vs_reference():
+    ec.case_process_fn_vs_golden(DEV)
