@@ -135,12 +135,16 @@ def case_process_fn_vs_golden(device):
         calls = {"n": 0}
 
         def process_fn(segs, win_data, imp):
+            # the callback's own arithmetic (mean, scaling) must be the CPU's to be bit-comparable: evaluate it on the host
             calls["n"] += 1
-            segs = tuple(s * 0.5 + 0.25 * win_data.mean() for s in segs)
-            return segs, imp * (1.0 + 0.125 * (calls["n"] % 3)) + 0.0625
+            dev = segs[0].device
+            segs = tuple((s.cpu() * 0.5 + 0.25 * win_data.cpu().mean()).to(dev) for s in segs)
+            return segs, (imp.cpu() * (1.0 + 0.125 * (calls["n"] % 3)) + 0.0625).to(dev)
 
         return process_fn
 
+    cpu_toy = toy
+    toy = lambda w: cpu_toy(w.cpu()).to(w.device)      # noqa: E731  (same reason)
     i = 0
     while f"pf_{i}_shape" in g:
         torch.manual_seed(40 + i)
