@@ -223,7 +223,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{ {'unetr': 'UNETR ViT-B/16', 'unet': 'UNet 16-256 res2', 'basicunet': 'BasicUNet'}[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
-                            f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 25 windows per launch)",
+                            f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
             "roofline": roof,
