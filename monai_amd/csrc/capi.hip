@@ -172,7 +172,13 @@ static int conv_algo_mode() {
 // z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
 static inline int wino2d_chunks(int D, int H, int W) {
     const int blocks = cdiv(W, W2_B) * cdiv(H, W2_B);
-    int nchunk = cdiv(64, blocks);
+    if (const char* e = getenv("MONAI_AMD_W2_CHUNKS")) {          // tuning knob (development)
+        const int v = atoi(e);
+        if (v >= 1 && v <= D) return v;
+    }
+    // measured at 64 windows per launch (profiles/): one chunk at 96^3 (36 regions), two at 48^3 (9 regions); every extra
+    // chunk re-reads two halo planes
+    int nchunk = cdiv(16, blocks);
     if (nchunk > D / 12) nchunk = D / 12;
     if (nchunk < 1) nchunk = 1;
     return nchunk;
