@@ -285,11 +285,14 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
             return fail(MH_ERR_ARG, "conv3d_k3: in-plane Winograd needs 16-byte aligned output and weights");
         const int bxn = cdiv(out.W, W2_B), byn = cdiv(out.H, W2_B), zc = wino2d_zchunk(out.D, out.H, out.W);
-        const dim3 grid((unsigned)(bxn * byn * cdiv(out.D, zc)), (unsigned)(out.C / W2_CN), (unsigned)out.N);
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
-        else hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc);
+        const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
+        const long long total = (long long)nblk * (out.C / W2_CN) * out.N;
+        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
+        const dim3 grid((unsigned)total);
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
         return launched("conv3d_k3_wino2d");
     }
     if (cfg == MH_CFG_WINOGRAD) {

@@ -13,7 +13,7 @@ find gpurun_out/prof -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stat
 python bench.py --steps 2 --warmup 1 --net unetr --cpu-windows 0 > gpurun_out/bench_unetr.log 2>&1; tail -1 gpurun_out/bench_unetr.log | cut -c1-300
 python bench.py --steps 2 --warmup 1 --net unet --cpu-windows 0 > gpurun_out/bench_unet.log 2>&1; tail -1 gpurun_out/bench_unet.log | cut -c1-300
 python tools/transform_bench.py > gpurun_out/transform_bench.json 2> gpurun_out/transform_bench.err
-KB_BATCH=25 python tools/kernel_bench.py > gpurun_out/kernel_bench.json 2> gpurun_out/kernel_bench.err
+KB_BATCH=64 python tools/kernel_bench.py > gpurun_out/kernel_bench.json 2> gpurun_out/kernel_bench.err
 rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f -- python tools/pmc_probe.py > gpurun_out/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o w -- python tools/pmc_probe.py > gpurun_out/pmc_write.log 2>&1

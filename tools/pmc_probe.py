@@ -38,7 +38,7 @@ torch.cuda.synchronize()
 # the dominant conv of the headline workload: 32 -> 32 channels at 96^3, 25 windows per launch (in-plane Winograd and the
 # best direct tile): algorithmic HBM bytes = input + output = 2 x 25 x 32 x 96^3 x 4 B = 5.66 GB per launch
 del vol
-B = 25
+B = 64
 x = torch.randn(B, 32, 96, 96, 96, device=dev)
 w = torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05
 bias = torch.zeros(32, device=dev)
