@@ -203,7 +203,20 @@ def main():
         roof_hbm = None
         if blend:
             gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
+            # the practical ceiling on this box: a plain device-to-device copy of the output-sized buffer (read + write streams)
+            ca = torch.empty(out.numel(), dtype=torch.float32, device=dev)
+            cb = torch.empty_like(ca)
+            cb.copy_(ca)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                cb.copy_(ca)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 3 * 8.0 * ca.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del ca, cb
             roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                        "device_copy_GBps": copy_gbs, "frac_of_device_copy": gbs / copy_gbs,
                         "traffic": None, "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
                         "bytes_per_launch": blend["work"] / blend["launches"]}
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}

@@ -65,4 +65,12 @@ res["runs"].append({"op": "kernel separable_filter3d 9 taps (1 volume)", "ms": m
 k2 = gaussian_1d(2.0).numpy()
 ms = timeit(lambda: ops.separable_filter3d(raw, [k2, k2, k2]))
 res["runs"].append({"op": "kernel separable_filter3d 17 taps (1 volume)", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6, "bytes": 8.0 * raw.numel()})
+# what a plain device-to-device copy of the same bytes reaches on this box (the practical HBM ceiling: read + write streams)
+a = torch.empty(N, E, E, E, device=dev)
+b = torch.empty_like(a)
+ms = timeit(lambda: b.copy_(a))
+res["device_copy"] = {"bytes": 8.0 * a.numel(), "ms": ms, "GBps": 8.0 * a.numel() / ms / 1e6}
+for r in res["runs"]:
+    r["frac_of_8TBps"] = r["GBps"] / 8000.0
+    r["frac_of_device_copy"] = r["GBps"] / res["device_copy"]["GBps"]
 print(json.dumps(res, indent=1))
