@@ -392,7 +392,7 @@ static void launch_1x1(int co, unsigned nb, unsigned nbatch, hipStream_t s, cons
         break;
     switch (co) {
         MH_1X1_CASE(1) MH_1X1_CASE(2) MH_1X1_CASE(3) MH_1X1_CASE(4)
-        MH_1X1_CASE(5) MH_1X1_CASE(6) MH_1X1_CASE(7) MH_1X1_CASE(8)
+        MH_1X1_CASE(5) MH_1X1_CASE(6) MH_1X1_CASE(7) MH_1X1_CASE(8) MH_1X1_CASE(16)
     }
 #undef MH_1X1_CASE
 }
@@ -404,10 +404,12 @@ int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, con
     const long long DHW = (long long)in.D * in.H * in.W;
     const bool v4 = DHW % 4 == 0 && aligned(in.data, 16) && aligned(out.data, 16) && in.n_stride % 4 == 0 && out.n_stride % 4 == 0;
     const unsigned nb = blocks_for(v4 ? DHW / 4 : DHW);
-    for (int co0 = 0; co0 < out.C; co0 += 8) {
-        const int co = out.C - co0 < 8 ? out.C - co0 : 8;
+    for (int co0 = 0; co0 < out.C;) {      // 16 output channels per pass where they exist (the input is read once per pass)
+        const int left = out.C - co0;
+        const int co = left >= 16 ? 16 : left < 8 ? left : 8;
         if (v4) launch_1x1<4>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
         else launch_1x1<1>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
+        co0 += co;
     }
     return launched("conv1x1");
 }

@@ -336,20 +336,31 @@ conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__
         for (int v = 0; v < VEC; ++v) acc[j][v] = bj;
     }
     const float* src = in.data + (long long)n * in.n_stride + idx;
-    for (int ci = 0; ci < Cin; ++ci) {
-        const float4 a = load_nrm(in, n, ci);
-        float xv[VEC];
-        if (VEC == 4) {
-            const float4 q = *reinterpret_cast<const float4*>(src + (long long)ci * DHW);
-            xv[0] = q.x; xv[1] = q.y; xv[2] = q.z; xv[3] = q.w;
-        } else {
-            xv[0] = src[(long long)ci * DHW];
+    constexpr int CB = VEC == 4 ? 4 : 8;   // input channels whose loads fly together (one load per iteration would expose its latency Cin times)
+    for (int c0 = 0; c0 < Cin; c0 += CB) {
+        float xv[CB][VEC];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const float* p = src + (long long)min(c0 + c, Cin - 1) * DHW;
+            if (VEC == 4) {
+                const float4 q = *reinterpret_cast<const float4*>(p);
+                xv[c][0] = q.x; xv[c][1] = q.y; xv[c][2] = q.z; xv[c][3] = q.w;
+            } else {
+                xv[c][0] = p[0];
+            }
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const float f = act(xv[v], a.x, a.y, a.z);
+        for (int c = 0; c < CB; ++c) {
+            const int ci = c0 + c;
+            if (ci < Cin) {
+                const float4 a = load_nrm(in, n, ci);
 #pragma unroll
-            for (int j = 0; j < CO; ++j) acc[j][v] = fmaf(f, w[(long long)(co0 + j) * Cin + ci], acc[j][v]);
+                for (int v = 0; v < VEC; ++v) {
+                    const float f = act(xv[c][v], a.x, a.y, a.z);
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j][v] = fmaf(f, w[(long long)(co0 + j) * Cin + ci], acc[j][v]);
+                }
+            }
         }
     }
     float* dst = out.data + (long long)n * out.n_stride + idx;
