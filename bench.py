@@ -105,6 +105,20 @@ def cpu_baseline(size: int, roi: int, windows: int, vol=None, net=None):
     }
 
 
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch of `kernel_key` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied -- counters cannot be collected inside this process)."""
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            k = json.load(f)["kernels"].get(kernel_key)
+        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
+                                       "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"],
+                                       "measured_on": "32->32 ch, 96^3, 64 windows per launch" if "conv" in kernel_key else "the bench configuration",
+                                       "source": "profiles/r01_pmc_hbm_traffic.txt"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,7 +207,8 @@ def main():
                 kname = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)"
                 pipe = tf
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                    "traffic": None, "kernel": kname,
+                    "traffic": pmc_traffic("conv3d_k3_wino2d_kernel" if cfg_id == ncfg else "conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else ""),
+                    "kernel": kname,
                     "note": "achieved = ALGORITHMIC flops of the 3x3x3 convolution (2*27*Cin*Cout per voxel) / kernel time; "
                             "mfma_pipe_frac = matrix-core flops actually issued / time / peak",
                     "mfma_pipe_frac": pipe / PEAK_FP32_TFLOPS,
@@ -217,7 +232,7 @@ def main():
             del ca, cb
             roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "device_copy_GBps": copy_gbs, "frac_of_device_copy": gbs / copy_gbs,
-                        "traffic": None, "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+                        "traffic": pmc_traffic("sw_blend_kernel"), "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
                         "bytes_per_launch": blend["work"] / blend["launches"]}
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
                     for k, v in spans.items() if k.startswith("conv3d_k3/")}

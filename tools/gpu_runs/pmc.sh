@@ -1,0 +1,8 @@
+mkdir -p gpurun_out; export TMPDIR=/tmp
+rm -rf gpurun_out/pmc_fetch gpurun_out/pmc_write
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f -- python tools/pmc_probe.py > gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o w -- python tools/pmc_probe.py > gpurun_out/pmc_write.log 2>&1
+find gpurun_out/pmc_fetch -name "*.db" | head -1 | xargs -I{} python tools/pmc_stats.py {} "%mh::%" > gpurun_out/pmc_fetch_stats.txt 2>&1
+find gpurun_out/pmc_write -name "*.db" | head -1 | xargs -I{} python tools/pmc_stats.py {} "%mh::%" > gpurun_out/pmc_write_stats.txt 2>&1
+find gpurun_out -name "*.db" -delete
+grep -A1 "wino2d_kernel\|conv3d_k3_mfma" gpurun_out/pmc_fetch_stats.txt gpurun_out/pmc_write_stats.txt | cut -c1-160
