@@ -207,13 +207,15 @@ def main():
                 kname = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)"
                 pipe = tf
             roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
-                    "traffic": pmc_traffic("conv3d_k3_wino2d_kernel" if cfg_id == ncfg else "conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else ""),
-                    "kernel": kname,
+                    "traffic": None, "kernel": kname,
                     "note": "achieved = ALGORITHMIC flops of the 3x3x3 convolution (2*27*Cin*Cout per voxel) / kernel time; "
                             "mfma_pipe_frac = matrix-core flops actually issued / time / peak",
                     "mfma_pipe_frac": pipe / PEAK_FP32_TFLOPS,
                     "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch": conv["work"] / conv["launches"],
                     "share_of_step": conv["ms_total"] / args.steps / ms}
+            td = pmc_traffic("conv3d_k3_wino2d_kernel" if cfg_id == ncfg else "conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
+            if td:
+                roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
         blend = spans.get("sw_blend")
         roof_hbm = None
         if blend:
@@ -232,8 +234,11 @@ def main():
             del ca, cb
             roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                         "device_copy_GBps": copy_gbs, "frac_of_device_copy": gbs / copy_gbs,
-                        "traffic": pmc_traffic("sw_blend_kernel"), "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+                        "traffic": None, "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
                         "bytes_per_launch": blend["work"] / blend["launches"]}
+            td = pmc_traffic("sw_blend_kernel")
+            if td:
+                roof_hbm["traffic"], roof_hbm["traffic_detail"] = td["hbm_bytes_per_launch"], td
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
                     for k, v in spans.items() if k.startswith("conv3d_k3/")}
         line = {
