@@ -645,10 +645,24 @@ int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || out.D != (in.D - 1) / stride + 1 || out.H != (in.H - 1) / stride + 1 || out.W != (in.W - 1) / stride + 1)
         return fail(MH_ERR_ARG, "conv3d_k3_strided: output must be floor((in - 1) / stride) + 1");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nbv = blocks_for((long long)out.D * out.H * out.W);
+    if (out.C <= 8) {      // few output channels (e.g. UNet's 5-class top level): one exact-width pass, no channel guards
+#define MH_STRIDED_CASE(C_)                                                                                                     \
+    case C_:                                                                                                                    \
+        hipLaunchKernelGGL((conv3d_k3_strided_kernel<C_, true>), dim3(nbv, 1u, (unsigned)out.N), dim3(256), 0, s, in, packed_w, bias, out, stride); \
+        break;
+        switch (out.C) {
+            MH_STRIDED_CASE(1) MH_STRIDED_CASE(2) MH_STRIDED_CASE(3) MH_STRIDED_CASE(4)
+            MH_STRIDED_CASE(5) MH_STRIDED_CASE(6) MH_STRIDED_CASE(7) MH_STRIDED_CASE(8)
+        }
+#undef MH_STRIDED_CASE
+        return launched("conv3d_k3_strided");
+    }
     constexpr int COT = 16;
-    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)cdiv(out.C, COT), (unsigned)out.N);
-    if (out.C % COT == 0) hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, true>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
-    else hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, false>), grid, dim3(256), 0, (hipStream_t)stream, in, packed_w, bias, out, stride);
+    const dim3 grid(nbv, (unsigned)cdiv(out.C, COT), (unsigned)out.N);
+    if (out.C % COT == 0) hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stride);
+    else hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stride);
     return launched("conv3d_k3_strided");
 }
 

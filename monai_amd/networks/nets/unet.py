@@ -174,9 +174,12 @@ class UNet(nn.Module):
             cout = conv.weight.shape[0]
             do, ho, wo = (d - 1) // s + 1, (h - 1) // s + 1, (w - 1) // s + 1
             out = torch.empty((n, cout, do, ho, wo), dtype=torch.float32, device=x.device)
-            cfg = ops.conv3d_k3_select(cin, cout, d, h, w) if s == 1 else 0
-            stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and hasattr(unit, "adn")) else 0
-            if s == 1:
+            # few channels on both sides (the 5-class top level): the matrix tiles would pad them to 32; the direct kernel runs at
+            # the channels' true width
+            tiny = s == 1 and cin <= 8 and cout <= 8
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w) if (s == 1 and not tiny) else 0
+            stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and hasattr(unit, "adn")) else 0
+            if s == 1 and not tiny:
                 stats = self._stats_buf(n * cout * stats_tiles * 3, x.device) if stats_tiles else None
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
             else:

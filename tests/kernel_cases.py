@@ -227,7 +227,8 @@ def case_add_act(device):
 def case_strided_conv_and_deconv_k3(device):
     """UNet's strided conv (k3 s2 p1) and transposed conv (k3 s2 p1 op1), plus stride 1, vs ATen in fp64."""
     gen = torch.Generator().manual_seed(12)
-    for stride, dims, cout in ((2, (8, 10, 12), 20), (1, (5, 6, 7), 20), (2, (7, 9, 6), 20), (2, (4, 6, 10), 5), (2, (5, 4, 6), 16), (2, (3, 4, 5), 32)):
+    for stride, dims, cout in ((2, (8, 10, 12), 20), (1, (5, 6, 7), 20), (2, (7, 9, 6), 20), (2, (4, 6, 10), 5), (2, (5, 4, 6), 16), (2, (3, 4, 5), 32),
+                              (1, (4, 6, 10), 5), (1, (3, 5, 4), 3), (1, (4, 4, 6), 8)):      # exact-width passes (UNet's tiny top level)
         n, cin = 2, 6
         x = torch.randn((n, cin) + dims, generator=gen)
         nrm = _rand_nrm(n, cin, gen)
