@@ -84,3 +84,24 @@ def test_partition_covers_every_window_once():
                 assert p.hi - p.lo <= p.chunk and p.chunk * world >= num_win
                 seen += list(range(p.lo, p.hi))
             assert seen == list(range(num_win))
+
+
+def test_round_schedule_covers_every_window_once():
+    """The round-interleaved schedule (monai_amd/parallel.py): every real window is computed by exactly one rank, each rank's
+    slot of round q is [q*world*nb + rank*nb, +nb), the padded row count is a whole number of rounds."""
+    from monai_amd import parallel
+
+    for num_win in (1, 7, 200, 1000, 1001):
+        for world in (1, 2, 3, 8):
+            for nb in (1, 4, 32):
+                seen = []
+                padded = parallel.partition(num_win, world, 0).padded_windows(nb)
+                assert padded >= num_win and (world == 1 or padded % (world * nb) == 0)
+                for r in range(world):
+                    sh = parallel.partition(num_win, world, r)
+                    rounds = sh.rounds(nb)
+                    assert len(rounds) == -(-num_win // (world * nb))
+                    for q, (w0, n) in enumerate(rounds):
+                        assert w0 == q * world * nb + r * nb and 0 <= n <= nb and w0 + n <= max(num_win, w0)
+                        seen += list(range(w0, w0 + n))
+                assert sorted(seen) == list(range(num_win))
