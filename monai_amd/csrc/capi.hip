@@ -427,6 +427,36 @@ static int fill_resample(ResampleArgs& a, int NC, int Di, int Hi, int Wi, int Do
     return MH_OK;
 }
 
+// Workgroups of `kernel` that are resident on the device at once (CUs x occupancy), queried once per kernel.
+template <typename K> static int resident_wgs(K kernel, int threads) {
+    int cus = 0, per_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    return cus * per_cu;
+}
+
+// z-chunks of a streaming launch of `units` (tile, channel) columns: the count whose workgroups fill whole rounds of the
+// resident slots -- the last, partly filled round of a 2.1-round launch takes as long as a full one -- discounted by the
+// `prime` extra planes every chunk has to read before its first output.  Chunks keep >= min_chunk output planes.
+static int stream_chunks(long long units, int Do, int slots, int prime, int min_chunk, const char* env_knob) {
+    if (const char* e = getenv(env_knob)) {                          // tuning knob (development)
+        const int v = atoi(e);
+        if (v >= 1 && v <= Do) return v;
+    }
+    const int max_chunks = cdiv(Do, min_chunk) < 1 ? 1 : cdiv(Do, min_chunk);
+    int best = 1;
+    double best_score = -1.0;
+    for (int n = 1; n <= max_chunks; ++n) {
+        const int zc = cdiv(Do, n), real = cdiv(Do, zc);
+        if (real != n) continue;
+        const long long nwg = units * n;
+        const long long rounds = (nwg + slots - 1) / slots;
+        const double score = (double)nwg / (double)(rounds * slots) * ((double)zc / (double)(zc + prime));
+        if (score > best_score) { best_score = score; best = n; }
+    }
+    return best;
+}
+
 static bool fits_i32(long long n) { return n < 2147483647LL; }
 
 int64_t mh_affine_resample_workspace_bytes(int Do, int Ho, int Wo) { return (int64_t)(Do + Ho + Wo) * (int64_t)sizeof(AxisTap<double>); }
@@ -452,15 +482,18 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
         const bool stream_ok = mode == RS_LINEAR && pad != RS_REFLECTION && box_bound <= 4096.0;
         if (stream_ok) {
             const long long tiles = (long long)cdiv(Wo, RZ_TOX) * cdiv(Ho, RZ_TOY);
-            int nchunk = (int)((2048 + tiles * NC - 1) / (tiles * NC));
-            if (nchunk > cdiv(Do, 8)) nchunk = cdiv(Do, 8);
-            if (nchunk < 1) nchunk = 1;
+            const bool small = box_bound <= 2048.0;
+            static int slots[2][2] = {{0, 0}, {0, 0}};     // [f64][small]
+            int& sl = slots[compute_f64 ? 1 : 0][small ? 1 : 0];
+            if (sl == 0)
+                sl = compute_f64 ? (small ? resident_wgs(separable_resample_stream_kernel<double, 8>, 256) : resident_wgs(separable_resample_stream_kernel<double, 16>, 256))
+                                 : (small ? resident_wgs(separable_resample_stream_kernel<float, 8>, 256) : resident_wgs(separable_resample_stream_kernel<float, 16>, 256));
+            int nchunk = stream_chunks(tiles * NC, Do, sl, 1, 8, "MONAI_AMD_RS_CHUNKS");
             const int zchunk = cdiv(Do, nchunk);
             nchunk = cdiv(Do, zchunk);
             const long long nwg = tiles * nchunk * NC;
             if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "affine_resample: problem too large for one launch");
             const dim3 g((unsigned)nwg);
-            const bool small = box_bound <= 2048.0;
             if (compute_f64) {
                 AxisTap<double>* tab = static_cast<AxisTap<double>*>(workspace);
                 hipLaunchKernelGGL((resample_axis_table_kernel<double>), dim3(tb), dim3(256), 0, s, tab, a);
@@ -567,12 +600,26 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     memcpy(a.kz + (rk - kz_n) / 2, kz, sizeof(float) * kz_n);
     memcpy(a.ky + (rk - ky_n) / 2, ky, sizeof(float) * ky_n);
     memcpy(a.kx + (rk - kx_n) / 2, kx, sizeof(float) * kx_n);
-    // enough workgroups to keep ~8 per CU in flight: cut z into chunks (each re-filters rk-1 halo planes)
+    // cut z into chunks (each re-filters rk-1 halo planes) that fill whole rounds of the resident workgroup slots
     const long long tiles = (long long)cdiv(W, GS_TX) * cdiv(H, GS_TY);
     const int min_chunk = 4 * rk > 16 ? 4 * rk : 16;
-    int nchunk = (int)((2048 + tiles * NC - 1) / (tiles * NC));
-    if (nchunk > cdiv(D, min_chunk)) nchunk = cdiv(D, min_chunk);
-    if (nchunk < 1) nchunk = 1;
+    bool iso = kz_n == ky_n && ky_n == kx_n;
+    for (int i = 0; iso && i < kz_n; ++i) iso = kz[i] == ky[i] && ky[i] == kx[i];
+    static int slots[5][2];
+    const int ri = rk == 3 ? 0 : rk == 5 ? 1 : rk == 9 ? 2 : rk == 17 ? 3 : 4;
+    int& sl = slots[ri][iso ? 1 : 0];
+    if (sl == 0) {
+#define MH_GAUSS_SLOTS(RK_) sl = iso ? resident_wgs(gauss3d_stream_kernel<RK_, true>, 256) : resident_wgs(gauss3d_stream_kernel<RK_, false>, 256);
+        switch (rk) {
+            case 3: MH_GAUSS_SLOTS(3) break;
+            case 5: MH_GAUSS_SLOTS(5) break;
+            case 9: MH_GAUSS_SLOTS(9) break;
+            case 17: MH_GAUSS_SLOTS(17) break;
+            default: MH_GAUSS_SLOTS(33) break;
+        }
+#undef MH_GAUSS_SLOTS
+    }
+    const int nchunk = stream_chunks(tiles * NC, D, sl, rk - 1, min_chunk, "MONAI_AMD_GS_CHUNKS");
     a.zchunk = cdiv(D, nchunk);
     a.pair_ok = (W % 2 == 0 && aligned(dst, 8)) ? 1 : 0;
     a.nchunk = cdiv(D, a.zchunk);
@@ -580,8 +627,6 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: problem too large for one launch");
     const dim3 grid((unsigned)nwg);
     hipStream_t s = (hipStream_t)stream;
-    bool iso = kz_n == ky_n && ky_n == kx_n;
-    for (int i = 0; iso && i < kz_n; ++i) iso = kz[i] == ky[i] && ky[i] == kx[i];
 #define MH_GAUSS(RK_)                                                                                             \
     if (iso) hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, true>), grid, dim3(256), 0, s, src, dst, a);          \
     else hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, false>), grid, dim3(256), 0, s, src, dst, a);

@@ -344,7 +344,7 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
                                  int zchunk, int nchunk) {
     constexpr int CAP = NLOAD * 256;
     __shared__ float box[2][CAP];
-    __shared__ int lim[5];
+    __shared__ int lim[5], part[6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbx = (a.Wo + RZ_TOX - 1) / RZ_TOX, nby = (a.Ho + RZ_TOY - 1) / RZ_TOY, tiles = nbx * nby;
     unsigned lid = xcd_remap(blockIdx.x, gridDim.x);        // neighbouring tiles share an XCD's L2 (their boxes overlap)
@@ -358,18 +358,31 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
     const float* p = src + (long long)c * a.Di * iplane;
     float* q = dst + (long long)c * a.Do * oplane;
 
-    // bounding box of the tile's y and x taps
+    // bounding box of the tile's y and x taps: wave 0 reduces the <= 16 row taps, waves 1 and 2 the <= 128 column taps
+    // (one tap per lane; a serial scan by one thread costs ~128 dependent-latency loads per workgroup)
+    static_assert(RZ_TOY <= 64 && RZ_TOX <= 128, "tap bounding box: one lane per tap in waves 0 (rows) and 1-2 (columns)");
     if (tid == 0) lim[4] = 0;
-    if (tid < 2) {
-        const int n = tid == 0 ? ny : nx;
-        const int base = tid == 0 ? a.Do + oy0 : a.Do + a.Ho + ox0;
+    {
+        int ti = -1;
+        if (wave == 0) { if (lane < ny) ti = a.Do + oy0 + lane; }
+        else if (wave <= 2) { if (lane + 64 * (wave - 1) < nx) ti = a.Do + a.Ho + ox0 + lane + 64 * (wave - 1); }
         int lo = 0x7fffffff, hi = -1;
-        for (int i = 0; i < n; ++i) {
-            const AxisTap<T> e = tab[base + i];
+        if (ti >= 0) {
+            const AxisTap<T> e = tab[ti];
             if (e.i0 >= 0) { lo = min(lo, e.i0); hi = max(hi, e.i0); }
             if (e.i1 >= 0) { lo = min(lo, e.i1); hi = max(hi, e.i1); }
         }
-        lim[2 * tid] = lo; lim[2 * tid + 1] = hi;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            lo = min(lo, __shfl_xor(lo, o));
+            hi = max(hi, __shfl_xor(hi, o));
+        }
+        if (lane == 0 && wave <= 2) { part[2 * wave] = lo; part[2 * wave + 1] = hi; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        lim[0] = part[0]; lim[1] = part[1];
+        lim[2] = min(part[2], part[4]); lim[3] = max(part[3], part[5]);
     }
     __syncthreads();
     const int ly = lim[0], lx = lim[2];
