@@ -165,13 +165,34 @@ int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const
                          const double* scale3, const double* offset3, float* dst, int Do, int Ho, int Wo, int mode,
                          int pad, int align_corners, int compute_f64, void* stream);
 
-/* monai._C.grid_pull (monai/csrc/ext.cpp:67, monai/csrc/resample/pushpull.h:58-110), interpolation orders 0 and 1,
- * boundary conditions replicate(0) dct1(1) dct2(2) dst1(3) dst2(4) dft(5) zero(7) per axis, `extrapolate` as in the
- * reference (out-of-FOV samples, tolerance 5e-2, are zero when false).  src (B,C,X,Y,Z), grid (B,Xo,Yo,Zo,3) with the
- * last axis holding voxel coordinates in tensor-axis order, out (B,C,Xo,Yo,Zo); all three fp32 or all three fp64
- * (is_f64), dense.  bound3 / interp3 are HOST int32[3] (2-D / 1-D problems pad with size-1 axes). */
+/* monai._C.grid_pull (monai/csrc/ext.cpp:67, monai/csrc/resample/pushpull.h:58-110) for 3-D volumes: B-spline
+ * interpolation orders 0-7 and boundary conditions replicate(0) dct1(1) dct2(2) dst1(3) dst2(4) dft(5) zero(7) per
+ * axis, `extrapolate` as in the reference (out-of-FOV samples, tolerance 5e-2, are zero when false).  src (B,C,X,Y,Z),
+ * grid (B,Xo,Yo,Zo,3) with the last axis holding voxel coordinates in tensor-axis order, out (B,C,Xo,Yo,Zo); all three
+ * fp32 or all three fp64 (is_f64), dense.  bound3 / interp3 are HOST int32[3].  Shorthand for mh_pushpull(ndim = 3,
+ * do_pull); 1-D / 2-D problems go through mh_pushpull, which reproduces the reference's lower-dimensional arithmetic. */
 int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B, int C, int X, int Y, int Z, int Xo,
                  int Yo, int Zo, const int32_t* bound3, const int32_t* interp3, int extrapolate, void* stream);
+
+/* The dispatcher behind every other monai._C resampling entry point -- grid_pull_backward, grid_push(_backward),
+ * grid_count(_backward), grid_grad(_backward) (monai/csrc/ext.cpp:67-74, monai/csrc/resample/pushpull.h:112-509) -- with
+ * the reference's own flag set (`pushpull(source, grid, target, bound, interpolation, extrapolate, do_pull, do_push,
+ * do_count, do_grad, do_sgrad)`, pushpull.h:24-50) and B-spline interpolation orders 0-7 per axis.
+ *   ndim     real spatial axes (1-3); tensors are passed as 3-D with trailing size-1 axes, vector axes have ndim entries
+ *   source   (B,C,X,Y,Z) for pull / sgrad / grad, NULL for push / count (the volume being splatted into is `out`)
+ *   grid     (B,Xo,Yo,Zo,ndim) voxel coordinates in tensor-axis order
+ *   target   NULL, (B,C,Xo,Yo,Zo) or -- target_k != 0 -- (B,C,Xo,Yo,Zo,ndim)
+ *   out      do_pull: (B,C,Xo,Yo,Zo); do_sgrad: (B,C,Xo,Yo,Zo,ndim); do_push: (B,C,X,Y,Z); do_count: (B,1,X,Y,Z) (C is
+ *            ignored); push / count outputs are zero-filled by the call; NULL when none of the four is set
+ *   grad     do_grad: (B,Xo,Yo,Zo,ndim) gradient with respect to the grid, else NULL
+ * At most one of do_pull / do_sgrad / do_push / do_count, optionally combined with do_grad, as the reference calls it.
+ * All tensors fp32 or all fp64 (is_f64), dense.  bound3 / interp3: HOST int32[3]; entries beyond ndim only take part in
+ * the reference's "all three orders equal" test that selects the nearest / linear fast paths (pushpull_cpu.cpp:136);
+ * like the reference's kernels (pushpull_cpu.cpp:501) the third axis is interpolated with the SECOND entry's order.
+ * push / count scatter with floating-point atomics (summation order undefined, as in the reference's GPU path). */
+int mh_pushpull(const void* source, const void* grid, const void* target, void* out, void* grad, int is_f64, int ndim, int B,
+                int C, int X, int Y, int Z, int Xo, int Yo, int Zo, const int32_t* bound3, const int32_t* interp3,
+                int extrapolate, int do_pull, int do_push, int do_count, int do_grad, int do_sgrad, int target_k, void* stream);
 
 /* ---- Gaussian smoothing (GaussianSmooth / GaussianFilter / separable_filtering) ----------------------------- */
 

@@ -1,9 +1,10 @@
 """Stand-in for the reference's native module ``monai._C`` (pybind11, monai/csrc/ext.cpp:20-80) on the MI355X kernels.
 
-Exports the same names the reference's Python reaches for -- ``grid_pull`` and the ``BoundType`` /
-``InterpolationType`` enums with ``__members__`` lookup including the aliases (used at
-monai/networks/layers/spatial_transforms.py:123-127).  Entry points this build does not provide raise
-``RuntimeError`` the way ``AT_ERROR("Not compiled with GPU support.")`` does (monai/csrc/resample/pushpull.h:95).
+Exports the resampling surface of that module -- ``grid_pull`` / ``grid_push`` / ``grid_count`` / ``grid_grad`` and their
+``*_backward`` functions (ext.cpp:67-74, interpolation orders 0-7, every index-remapping boundary condition) -- and
+the ``BoundType`` / ``InterpolationType`` enums with ``__members__`` lookup including the aliases (used at
+monai/networks/layers/spatial_transforms.py:123-127).  The "sliding" boundary condition (unfinished in the reference,
+pushpull_cpu.cpp:29-34) raises ``RuntimeError``.
 ``monai_amd.patch.install()`` can register this module as ``monai._C`` when the real MONAI is installed without its
 own compiled extension.
 """
@@ -16,7 +17,10 @@ import torch
 
 from . import _lib
 
-__all__ = ["BoundType", "InterpolationType", "grid_pull"]
+__all__ = [
+    "BoundType", "InterpolationType", "grid_pull", "grid_pull_backward", "grid_push", "grid_push_backward", "grid_count",
+    "grid_count_backward", "grid_grad", "grid_grad_backward",
+]
 
 
 class BoundType(enum.IntEnum):
@@ -48,57 +52,136 @@ class InterpolationType(enum.IntEnum):
     seventh = 7
 
 
-def _rep3(values, n):
+def _ext3(values):
+    """The reference extends bound / interpolation vectors to three entries by repeating the last one
+    (PushPullAllocator constructor, monai/csrc/resample/pushpull_cpu.cpp:100-133); the nearest / linear fast paths are
+    taken when all THREE orders are equal, whatever the dimensionality (:136)."""
     values = [int(v) for v in values]
     if not values:
         raise RuntimeError("bound/interpolation vector must not be empty")
-    values = values + [values[-1]] * (n - len(values))
-    return values[:n]
+    return (values + [values[-1]] * 3)[:3]
+
+
+def _check(name, *tensors):
+    first = tensors[0]
+    for t in tensors:
+        if t.dtype != first.dtype or t.device != first.device:
+            raise RuntimeError(f"{name}: tensors must have the same dtype and device")
+    if first.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError(f"{name}: dtype {first.dtype} is not built (float32 and float64 are)")
+    _lib.require_device(*tensors, dtypes=(torch.float32, torch.float64))
+
+
+def _pad3(shape):
+    shape = tuple(int(v) for v in shape)
+    return shape + (1,) * (3 - len(shape))
+
+
+def _pushpull(name, source, source_size, grid, target, bound, interpolation, extrapolate, do_pull=False, do_push=False,
+              do_count=False, do_grad=False, do_sgrad=False):
+    """The reference's `pushpull(source | source_size, grid[, target], ...)` (pushpull.h:24-50): returns the list of
+    outputs in the order of PushPullAllocator::init_output (:390-480): [pull | sgrad | push | count][, grad]."""
+    sd = grid.dim() - 2
+    if sd < 1 or sd > 3 or grid.shape[-1] != sd:
+        raise RuntimeError(f"{name}: grid must be (B, spatial..., D) with D = 1, 2 or 3 spatial dimensions, got {tuple(grid.shape)}")
+    tensors = [t for t in (source, grid, target) if t is not None]
+    _check(name, *tensors)
+    b = int(grid.shape[0])
+    osp = tuple(int(v) for v in grid.shape[1:-1])
+    if source is not None:
+        if source.dim() != sd + 2 or source.shape[0] != b:
+            raise RuntimeError(f"{name}: source must be (B, C, {sd} spatial dims), got {tuple(source.shape)}")
+        isp = tuple(int(v) for v in source.shape[2:])
+        c = int(source.shape[1])
+    else:
+        isp = tuple(int(v) for v in source_size)
+        if len(isp) != sd:
+            raise RuntimeError(f"{name}: source size must have {sd} entries, got {isp}")
+        c = int(target.shape[1]) if target is not None else 1
+    if min(isp + osp) < 1:
+        raise RuntimeError(f"{name}: empty spatial dimensions")
+    tk = 0
+    if target is not None:
+        if target.dim() == sd + 3:
+            tk = int(target.shape[-1])
+            if tk != sd:
+                raise RuntimeError(f"{name}: target gradient axis must have {sd} components")
+        elif target.dim() != sd + 2:
+            raise RuntimeError(f"{name}: target must be (B, C, spatial[, D])")
+        if tuple(target.shape[2 : 2 + sd]) != osp or target.shape[0] != b:
+            raise RuntimeError(f"{name}: target and grid shapes differ")
+        if do_push or source is None:
+            c = int(target.shape[1])
+        elif int(target.shape[1]) != c:
+            raise RuntimeError(f"{name}: source and target channel counts differ")
+    dt, dev = grid.dtype, grid.device
+    out = grad = None
+    if do_pull:
+        out = torch.empty((b, c) + osp, dtype=dt, device=dev)
+    elif do_sgrad:
+        out = torch.empty((b, c) + osp + (sd,), dtype=dt, device=dev)
+    elif do_push:
+        out = torch.empty((b, c) + isp, dtype=dt, device=dev)
+    elif do_count:
+        out = torch.empty((b, 1) + isp, dtype=dt, device=dev)
+    if do_grad:
+        grad = torch.empty((b,) + osp + (sd,), dtype=dt, device=dev)
+    src = source.contiguous() if source is not None else None
+    g = grid.contiguous()
+    tg = target.contiguous() if target is not None else None
+    x3, o3 = _pad3(isp), _pad3(osp)
+    _lib.lib().call(
+        "mh_pushpull", _lib.ptr(src), _lib.ptr(g), _lib.ptr(tg), _lib.ptr(out), _lib.ptr(grad), int(dt == torch.float64), sd, b, c,
+        *x3, *o3, _lib.int_array(_ext3(bound)), _lib.int_array(_ext3(interpolation)), int(bool(extrapolate)), int(do_pull), int(do_push),
+        int(do_count), int(do_grad), int(do_sgrad), tk, _lib.stream_ptr(grid),
+    )
+    return [t for t in (out, grad) if t is not None]
 
 
 def grid_pull(input: torch.Tensor, grid: torch.Tensor, bound, interpolation, extrapolate: bool) -> torch.Tensor:
-    """``monai._C.grid_pull``: input (B, C, X[, Y[, Z]]), grid (B, Xo[, Yo[, Zo]], D) voxel coordinates -> (B, C, Xo...)."""
-    if input.dim() < 3 or input.dim() > 5:
-        raise RuntimeError("grid_pull: input must be (B, C, spatial) with 1, 2 or 3 spatial dimensions")
-    sd = input.dim() - 2
-    if grid.dim() != sd + 2 or grid.shape[-1] != sd:
-        raise RuntimeError(f"grid_pull: grid must be (B, spatial..., {sd}), got {tuple(grid.shape)}")
-    if input.dtype != grid.dtype or input.device != grid.device:
-        raise RuntimeError("grid_pull: input and grid must have the same dtype and device")
-    if input.dtype not in (torch.float32, torch.float64):
-        raise RuntimeError(f"grid_pull: dtype {input.dtype} is not built (float32 and float64 are)")
-    _lib.require_device(input, grid, dtypes=(torch.float32, torch.float64))
-    b, c = input.shape[:2]
-    pad = 3 - sd
-    src = input.contiguous().reshape((b, c) + tuple(input.shape[2:]) + (1,) * pad)
-    g = grid.contiguous()
-    if pad:
-        z = torch.zeros(g.shape[:-1] + (pad,), dtype=g.dtype, device=g.device)
-        g = torch.cat([g, z], dim=-1).reshape((b,) + tuple(grid.shape[1:-1]) + (1,) * pad + (3,)).contiguous()
-    osp = tuple(g.shape[1:4])
-    out = torch.empty((b, c) + osp, dtype=input.dtype, device=input.device)
-    bd = _rep3(bound, sd) + [int(BoundType.replicate)] * pad
-    it = _rep3(interpolation, sd)
-    it = it + [it[0]] * pad  # padded size-1 axes sample at coordinate 0 exactly under either order
-    _lib.lib().call(
-        "mh_grid_pull", _lib.ptr(src), _lib.ptr(g), _lib.ptr(out), int(input.dtype == torch.float64), b, c, *[int(v) for v in src.shape[2:]],
-        *[int(v) for v in osp], _lib.int_array(bd), _lib.int_array(it), int(bool(extrapolate)), _lib.stream_ptr(input),
-    )
-    return out.reshape((b, c) + tuple(grid.shape[1:-1]))
+    """``monai._C.grid_pull`` (pushpull.h:58-110): input (B, C, X[, Y[, Z]]), grid (B, Xo[, Yo[, Zo]], D) voxel
+    coordinates -> (B, C, Xo...)."""
+    return _pushpull("grid_pull", input, None, grid, None, bound, interpolation, extrapolate, do_pull=True)[0]
 
 
-def _not_built(name):
-    def f(*_a, **_k):
-        raise RuntimeError(f"monai_amd._C.{name}: not built for the MI355X path (grid_pull orders 0/1 are)")
-
-    f.__name__ = name
-    return f
+def grid_pull_backward(grad, input, grid, bound, interpolation, extrapolate):
+    """``monai._C.grid_pull_backward`` (pushpull.h:112-150): [d/d input if input.requires_grad][, d/d grid if grid.requires_grad]."""
+    return _pushpull("grid_pull_backward", input, None, grid, grad, bound, interpolation, extrapolate,
+                     do_push=input.requires_grad, do_grad=grid.requires_grad)
 
 
-grid_pull_backward = _not_built("grid_pull_backward")
-grid_push = _not_built("grid_push")
-grid_push_backward = _not_built("grid_push_backward")
-grid_count = _not_built("grid_count")
-grid_count_backward = _not_built("grid_count_backward")
-grid_grad = _not_built("grid_grad")
-grid_grad_backward = _not_built("grid_grad_backward")
+def grid_push(input, grid, source_size, bound, interpolation, extrapolate):
+    """``monai._C.grid_push`` (pushpull.h:153-249): splat input (B, C, spatial of grid) into a (B, C, *source_size) volume."""
+    size = tuple(source_size) if source_size is not None and len(source_size) else tuple(input.shape[2:])
+    return _pushpull("grid_push", None, size, grid, input, bound, interpolation, extrapolate, do_push=True)[0]
+
+
+def grid_push_backward(grad, input, grid, bound, interpolation, extrapolate):
+    """``monai._C.grid_push_backward`` (pushpull.h:251-289)."""
+    return _pushpull("grid_push_backward", grad, None, grid, input, bound, interpolation, extrapolate,
+                     do_pull=input.requires_grad, do_grad=grid.requires_grad)
+
+
+def grid_count(grid, source_size, bound, interpolation, extrapolate):
+    """``monai._C.grid_count`` (pushpull.h:292-373): splat an image of ones -> (B, 1, *source_size)."""
+    size = tuple(source_size) if source_size is not None and len(source_size) else tuple(grid.shape[1:-1])
+    return _pushpull("grid_count", None, size, grid, None, bound, interpolation, extrapolate, do_count=True)[0]
+
+
+def grid_count_backward(grad, grid, bound, interpolation, extrapolate):
+    """``monai._C.grid_count_backward`` (pushpull.h:375-413): gradient with respect to the grid."""
+    res = _pushpull("grid_count_backward", grad, None, grid, None, bound, interpolation, extrapolate, do_grad=grid.requires_grad)
+    if not res:
+        raise RuntimeError("grid_count_backward: grid does not require a gradient")
+    return res[0]
+
+
+def grid_grad(input, grid, bound, interpolation, extrapolate):
+    """``monai._C.grid_grad`` (pushpull.h:415-467): spatial gradients of the sampled image -> (B, C, spatial of grid, D)."""
+    return _pushpull("grid_grad", input, None, grid, None, bound, interpolation, extrapolate, do_sgrad=True)[0]
+
+
+def grid_grad_backward(grad, input, grid, bound, interpolation, extrapolate):
+    """``monai._C.grid_grad_backward`` (pushpull.h:469-507); grad is (B, C, spatial of grid, D)."""
+    return _pushpull("grid_grad_backward", input, None, grid, grad, bound, interpolation, extrapolate,
+                     do_push=input.requires_grad, do_grad=grid.requires_grad)

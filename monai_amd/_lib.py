@@ -67,6 +67,7 @@ SIGNATURES = {
     "mh_affine_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _I, _P, _P]),
     "mh_separable_filter3d_f32": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, _P]),
     "mh_grid_pull": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _IA, _I, _P]),
+    "mh_pushpull": (_I, [_P, _P, _P, _P, _P] + [_I] * 10 + [_IA, _IA] + [_I] * 7 + [_P]),
     "mh_grid_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, C.POINTER(C.c_double), C.POINTER(C.c_double), _P, _I, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -14,6 +14,7 @@
 #include "kernels/conv3d_wino2d.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
+#include "kernels/pushpull.h"
 #include "kernels/nn_simple.h"
 #include "kernels/resample.h"
 #include "kernels/sliding.h"
@@ -553,32 +554,64 @@ int mh_grid_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, const
 }
 
 // ------------------------------------------------------------------------------------------ grid_pull (monai._C)
+int mh_pushpull(const void* source, const void* grid, const void* target, void* out, void* grad, int is_f64, int ndim, int B,
+                int C, int X, int Y, int Z, int Xo, int Yo, int Zo, const int32_t* bound3, const int32_t* interp3,
+                int extrapolate, int do_pull, int do_push, int do_count, int do_grad, int do_sgrad, int target_k, void* stream);
+
+// the 3-D pull-only subset kept for ABI compatibility: grid (B,Xo,Yo,Zo,3)
 int mh_grid_pull(const void* src, const void* grid, void* out, int is_f64, int B, int C, int X, int Y, int Z, int Xo, int Yo,
                  int Zo, const int32_t* bound3, const int32_t* interp3, int extrapolate, void* stream) {
     if (!src || !grid || !out || !bound3 || !interp3) return fail(MH_ERR_ARG, "grid_pull: null pointer");
-    if (B < 1 || C < 1 || X < 1 || Y < 1 || Z < 1 || Xo < 1 || Yo < 1 || Zo < 1) return fail(MH_ERR_ARG, "grid_pull: bad shape");
-    GridPullArgs a;
-    a.B = B; a.C = C; a.X = X; a.Y = Y; a.Z = Z; a.Xo = Xo; a.Yo = Yo; a.Zo = Zo; a.extrapolate = extrapolate ? 1 : 0;
+    return mh_pushpull(src, grid, nullptr, out, nullptr, is_f64, 3, B, C, X, Y, Z, Xo, Yo, Zo, bound3, interp3, extrapolate, 1, 0, 0, 0, 0, 0, stream);
+}
+
+int mh_pushpull(const void* source, const void* grid, const void* target, void* out, void* grad, int is_f64, int ndim, int B,
+                int C, int X, int Y, int Z, int Xo, int Yo, int Zo, const int32_t* bound3, const int32_t* interp3,
+                int extrapolate, int do_pull, int do_push, int do_count, int do_grad, int do_sgrad, int target_k, void* stream) {
+    if (!grid || !bound3 || !interp3) return fail(MH_ERR_ARG, "pushpull: null pointer");
+    if (ndim < 1 || ndim > 3) return fail(MH_ERR_ARG, "pushpull: %d spatial dimensions (1, 2 or 3)", ndim);
+    if (B < 1 || C < 1 || X < 1 || Y < 1 || Z < 1 || Xo < 1 || Yo < 1 || Zo < 1) return fail(MH_ERR_ARG, "pushpull: bad shape");
+    if ((ndim < 3 && (Z != 1 || Zo != 1)) || (ndim < 2 && (Y != 1 || Yo != 1)))
+        return fail(MH_ERR_ARG, "pushpull: axes beyond ndim must have size 1");
+    const int nout = (do_pull != 0) + (do_sgrad != 0) + (do_push != 0) + (do_count != 0);
+    if (nout > 1) return fail(MH_ERR_ARG, "pushpull: at most one of do_pull / do_sgrad / do_push / do_count");
+    if (nout + (do_grad != 0) == 0) return MH_OK;
+    if (nout && !out) return fail(MH_ERR_ARG, "pushpull: output pointer is null");
+    if (do_grad && !grad) return fail(MH_ERR_ARG, "pushpull: gradient pointer is null");
+    if ((do_pull || do_sgrad || do_grad) && !source) return fail(MH_ERR_ARG, "pushpull: source is null");
+    if (do_push && !target) return fail(MH_ERR_ARG, "pushpull: push needs a target");
+    if (target_k && !target) return fail(MH_ERR_ARG, "pushpull: target_k without a target");
+    PushPullArgs a;
+    a.B = B; a.C = do_count ? 1 : C; a.X = X; a.Y = Y; a.Z = Z; a.Xo = Xo; a.Yo = Yo; a.Zo = Zo;
+    a.ndim = ndim; a.extrapolate = extrapolate ? 1 : 0;
+    a.do_pull = do_pull ? 1 : 0; a.do_push = do_push ? 1 : 0; a.do_count = do_count ? 1 : 0; a.do_grad = do_grad ? 1 : 0;
+    a.do_sgrad = do_sgrad ? 1 : 0; a.trgt_k = target_k ? ndim : 0;
     for (int d = 0; d < 3; ++d) {
         a.bound[d] = bound3[d]; a.interp[d] = interp3[d];
-        if (interp3[d] < 0 || interp3[d] > 1)
-            return fail(MH_ERR_UNSUPPORTED, "grid_pull: interpolation order %d is not built (orders 0 and 1 are)", interp3[d]);
-        if (bound3[d] < 0 || bound3[d] > 7 || bound3[d] == GB_SLIDING)
-            return fail(MH_ERR_UNSUPPORTED, "grid_pull: bound type %d is not built", bound3[d]);
+        if (interp3[d] < 0 || interp3[d] > 7) return fail(MH_ERR_ARG, "pushpull: interpolation order %d (0-7)", interp3[d]);
+        if (d < ndim && (bound3[d] < 0 || bound3[d] > 7 || bound3[d] == GB_SLIDING))
+            return fail(MH_ERR_UNSUPPORTED, "pushpull: bound type %d is not built", bound3[d]);
     }
-    // mixed per-axis orders take the reference's generic B-spline path, whose results this kernel does not reproduce
-    const int o0 = interp3[0];
-    for (int d = 1; d < 3; ++d)
-        if ((d == 1 ? Y : Z) > 1 && interp3[d] != o0 && (Xo * Yo * Zo > 0))
-            return fail(MH_ERR_UNSUPPORTED, "grid_pull: per-axis interpolation orders must be equal (got %d,%d,%d)", interp3[0], interp3[1], interp3[2]);
-    const unsigned nb = blocks_for((long long)B * Xo * Yo * Zo);
+    const bool iso = interp3[0] == interp3[1] && interp3[0] == interp3[2];
+    a.path = iso && interp3[0] == 0 ? PP_NEAREST : iso && interp3[0] == 1 ? PP_LINEAR : PP_GENERIC;
+    // The reference's kernels take the third axis' order from the SECOND entry (`interpolation2(info.interpolation1)`,
+    // pushpull_cpu.cpp:501 and pushpull_cuda.cu:498) while `iso` above sees the real third entry: reproduced, so that
+    // mixed per-axis orders give the reference's results.
+    a.interp[2] = interp3[1];
+    hipStream_t s = (hipStream_t)stream;
+    const size_t esz = is_f64 ? 8 : 4;
+    if (do_push || do_count)
+        if (hipMemsetAsync(out, 0, esz * (size_t)B * (size_t)a.C * X * Y * Z, s) != hipSuccess) return fail(MH_ERR_LAUNCH, "pushpull: memset failed");
+    const long long total = (long long)B * Xo * Yo * Zo;
+    if (total > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "pushpull: problem too large for one launch");
+    const unsigned nb = blocks_for(total);
     if (is_f64)
-        hipLaunchKernelGGL((grid_pull_kernel<double>), dim3(nb), dim3(256), 0, (hipStream_t)stream, static_cast<const double*>(src),
-                           static_cast<const double*>(grid), static_cast<double*>(out), a);
+        hipLaunchKernelGGL((pushpull_kernel<double>), dim3(nb), dim3(256), 0, s, static_cast<const double*>(source), static_cast<const double*>(grid),
+                           static_cast<const double*>(target), static_cast<double*>(out), static_cast<double*>(grad), a);
     else
-        hipLaunchKernelGGL((grid_pull_kernel<float>), dim3(nb), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(src),
-                           static_cast<const float*>(grid), static_cast<float*>(out), a);
-    return launched("grid_pull");
+        hipLaunchKernelGGL((pushpull_kernel<float>), dim3(nb), dim3(256), 0, s, static_cast<const float*>(source), static_cast<const float*>(grid),
+                           static_cast<const float*>(target), static_cast<float*>(out), static_cast<float*>(grad), a);
+    return launched("pushpull");
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian smoothing

@@ -1,0 +1,477 @@
+// The full monai._C resampling surface: pull / push / count / spatial gradients and their backward passes, B-spline
+// interpolation orders 0-7 per axis, the seven index-remapping boundary conditions.
+//
+// Reference: the `pushpull` dispatcher every entry point of monai/csrc/resample/pushpull.h:58-509 funnels into
+// (flags do_pull / do_push / do_count / do_grad / do_sgrad, :24-50), CPU implementation monai/csrc/resample/pushpull_cpu.cpp:
+//   check3d :786-838  -- read the coordinate, zero the outputs of a target voxel whose coordinate is out of bounds
+//                        (only when !extrapolate; tolerance TINY = 5e-2 :67), pick the path;
+//   interpolate3d :938-1146 -- generic path: per-axis tap ranges (interpolation_common.h bounds0-7), weights /
+//                        first / second derivatives of the B-spline (fastweight / fastgrad / fasthess), index + sign of
+//                        every tap (bounds_common.h), then taps z-outer, y, x-inner;
+//   interpolate3d_trilinear :1476-1760, interpolate3d_nearest :2057-2098 -- the paths taken when all three orders
+//                        are equal (`iso` :136) to 1 resp. 0; their arithmetic differs from the generic path's, so
+//                        they are restated separately;
+//   the 2-D / 1-D variants (:1152-1470, :1766-2050, :2104-2175) are the restrictions of the 3-D code to fewer axes.
+//
+// One kernel serves 1-D / 2-D / 3-D: tensors are viewed as 3-D with trailing axes of size 1 (`ndim` real axes).  A
+// padded axis is sampled at coordinate 0: the linear path skips its far corner (weight 0; the reference's 2-D code
+// has no such corner) and its near weight is exactly 1, the generic path gives it order 0 (one tap, weight 1,
+// derivative 0), so every product and sum has the value the reference's lower-dimensional code computes.
+// Gradient / target component axes have `ndim` entries, not 3.
+//
+// One thread per target voxel, lanes along the last axis (coalesced grid reads and output writes); `push` / `count`
+// scatter with hardware floating-point atomics like the reference's CUDA path (summation order is not defined there
+// either: parity for those two is to rounding, everything else is bit-exact against the reference's CPU build).
+// Arithmetic notes: the reference writes its polynomial constants as double literals, so with scalar_t = float every
+// weight is evaluated in double and rounded once on return (or at each assignment to a scalar_t variable); the
+// functions below keep that evaluation order.  -ffp-contract=off (no fused multiply-add) like the CPU build.
+#pragma once
+#include "common.h"
+#include "grid_pull.h"
+
+namespace mh {
+
+enum { PP_NEAREST = 0, PP_LINEAR = 1, PP_GENERIC = 2 };
+
+struct PushPullArgs {
+    int B, C, X, Y, Z, Xo, Yo, Zo;
+    int bound[3], interp[3];
+    int ndim;           // real spatial axes = components of grid / gradient / target-gradient vectors
+    int extrapolate, path;
+    int do_pull, do_push, do_count, do_grad, do_sgrad;
+    int trgt_k;         // 0: target is (B, C, spatial); > 0: target carries ndim gradient components (backward of sgrad)
+};
+
+// ---- B-spline basis, orders 0-7 (interpolation_common.h:52-640).  `x` is the signed distance coordinate - node.
+// S(...) marks a store into a scalar_t variable of the reference (a rounding to T when T = float).
+template <typename T> __device__ __forceinline__ T pp_weight(int order, T x) {
+#define S(e) ((T)(e))
+    x = fabs(x);
+    switch (order) {
+        case 0: return (T)1;
+        case 2:
+            if (x < 0.5) return S(0.75 - x * x);
+            x = S(1.5 - x);
+            return S(0.5 * x * x);
+        case 3:
+            if (x < 1.) return S((x * x * (x - 2.) * 3. + 4.) / 6.);
+            x = S(2. - x);
+            return S((x * x * x) / 6.);
+        case 4:
+            if (x < 0.5) {
+                x = x * x;
+                return S(x * (x * 0.25 - 0.625) + 115. / 192.);
+            }
+            if (x < 1.5) return S(x * (x * (x * (5. - x) / 6. - 1.25) + 5. / 24.) + 55. / 96.);
+            x = S(x - 2.5);
+            x = x * x;
+            return S((x * x) / 24.);
+        case 5:
+            if (x < 1.) {
+                const T f = x * x;
+                return S(f * (f * (0.25 - x * (1. / 12.)) - 0.5) + 0.55);
+            }
+            if (x < 2.) return S(x * (x * (x * (x * (x * (1. / 24.) - 0.375) + 1.25) - 1.75) + 0.625) + 0.425);
+            {
+                const T f = S(3. - x);
+                x = f * f;
+                return S(f * x * x * (1. / 120.));
+            }
+        case 6:
+            if (x < 0.5) {
+                x = x * x;
+                return S(x * (x * (7. / 48. - x * (1. / 36.)) - 77. / 192.) + 5887. / 11520.0);
+            }
+            if (x < 1.5)
+                return S(x * (x * (x * (x * (x * (x * (1. / 48.) - 7. / 48.) + 0.328125) - 35. / 288.) - 91. / 256.) - 7. / 768.) + 7861. / 15360.0);
+            if (x < 2.5)
+                return S(x * (x * (x * (x * (x * (7. / 60. - x * (1. / 120.)) - 0.65625) + 133. / 72.) - 2.5703125) + 1267. / 960.) + 1379. / 7680.0);
+            x = S(x - 3.5);
+            x = x * (x * x);
+            return S(x * x * (1. / 720.));
+        case 7:
+            if (x < 1.) {
+                const T f = x * x;
+                return S(f * (f * (f * (x * (1. / 144.) - 1. / 36.) + 1. / 9.) - 1. / 3.) + 151. / 315.0);
+            }
+            if (x < 2.)
+                return S(x * (x * (x * (x * (x * (x * (0.05 - x * (1. / 240.)) - 7. / 30.) + 0.5) - 7. / 18.) - 0.1) - 7. / 90.) + 103. / 210.0);
+            if (x < 3.)
+                return S(x * (x * (x * (x * (x * (x * (x * (1. / 720.) - 1. / 36.) + 7. / 30.) - 19. / 18.) + 49. / 18.) - 23. / 6.) + 217. / 90.) - 139. / 630.0);
+            {
+                const T f = S(4. - x);
+                x = f * f * f;
+                return S((x * x * f) / 5040.);
+            }
+        default: return (T)1 - x;      // order 1 (and the reference's `default:` branch)
+    }
+}
+
+template <typename T> __device__ __forceinline__ T pp_grad(int order, T x) {
+    if (order == 0) return (T)0;
+    if (order == 1 || order > 7) return x < (T)0 ? (T)1 : (T)-1;
+    const bool neg = x < 0;
+    if (neg) x = -x;
+    switch (order) {
+        case 2:
+            if (x < 0.5) x = S(-2. * x);
+            else x = S(x - 1.5);
+            break;
+        case 3:
+            if (x < 1.) x = S(x * (x * 1.5 - 2.));
+            else {
+                x = S(2. - x);
+                x = S(-(x * x) * 0.5);
+            }
+            break;
+        case 4:
+            if (x < 0.5) x = S(x * (x * x - 1.25));
+            else if (x < 1.5) x = S(x * (x * (x * (-2. / 3.) + 2.5) - 2.5) + 5. / 24.);
+            else {
+                x = S(x * 2. - 5.);
+                x = S((x * x * x) / 48.);
+            }
+            break;
+        case 5:
+            if (x < 1.) x = S(x * (x * (x * (x * (-5. / 12.) + 1.)) - 1.));
+            else if (x < 2.) x = S(x * (x * (x * (x * (5. / 24.) - 1.5) + 3.75) - 3.5) + 0.625);
+            else {
+                x = S(x - 3.);
+                x = x * x;
+                x = S(-(x * x) / 24.);
+            }
+            break;
+        case 6:
+            if (x < .5) {
+                const T x2 = x * x;
+                x = S(x * (x2 * (7. / 12.) - (x2 * x2) / 6. - 77. / 96.));
+            } else if (x < 1.5) x = S(x * (x * (x * (x * (x * 0.125 - 35. / 48.) + 1.3125) - 35. / 96.) - 0.7109375) - 7.0 / 768.0);
+            else if (x < 2.5) x = S(x * (x * (x * (x * (x * (-1. / 20.) + 7. / 12.) - 2.625) + 133. / 24.) - 5.140625) + 1267. / 960.);
+            else {
+                x = S(x * 2.);
+                x = S(x - 7.);
+                const T x2 = x * x;
+                x = S((x2 * x2 * x) / 3840.);
+            }
+            break;
+        default:  // 7
+            if (x < 1.) {
+                const T x2 = x * x;
+                x = S(x * (x2 * (x2 * (x * (7. / 144.) - 1. / 6.) + 4. / 9.) - 2. / 3.));
+            } else if (x < 2.) x = S(x * (x * (x * (x * (x * (x * (-7. / 240.) + 3. / 10.) - 7. / 6.) + 2.) - 7. / 6.) - 1. / 5.) - 7. / 90.);
+            else if (x < 3.) x = S(x * (x * (x * (x * (x * (x * (7. / 720.) - 1. / 6.) + 7. / 6.) - 38. / 9.) + 49. / 6.) - 23. / 3.) + 217. / 90.);
+            else {
+                x = x - 4;
+                x = x * (x * x);
+                x = x * x;
+                x = S(-x / 720.);
+            }
+            break;
+    }
+    return neg ? -x : x;
+}
+
+// second derivative: orders 2-4 only (the reference returns 0 for orders 5-7, interpolation_common.h:797-823)
+template <typename T> __device__ __forceinline__ T pp_hess(int order, T x) {
+    x = fabs(x);
+    switch (order) {
+        case 2: return x < 0.5 ? (T)-2. : (T)1.;
+        case 3: return x < 1. ? S(x * 3. - 2.) : S(2. - x);
+        case 4:
+            if (x < 0.5) return S((x * x) * 3. - 1.25);
+            if (x < 1.5) return S(x * (x * (-2.) + 5.) - 2.5);
+            x = S(x * 2. - 5.);
+            return S((x * x) / 8.);
+        default: return (T)0;
+    }
+#undef S
+}
+
+// first node of the support (interpolation_common.h bounds0-7); the support has order + 1 nodes
+template <typename T> __device__ __forceinline__ long long pp_low(int order, T x) {
+    switch (order) {
+        case 0: return (long long)round(x);
+        case 2: return (long long)floor(x - .5);
+        case 3: return (long long)floor(x - 1.);
+        case 4: return (long long)floor(x - 1.5);
+        case 5: return (long long)floor(x - 2.);
+        case 6: return (long long)floor(x - 2.5);
+        case 7: return (long long)floor(x - 3.);
+        default: return (long long)floor(x);
+    }
+}
+
+template <typename T> __device__ __forceinline__ void pp_add(T* p, long long off, T v, int sign) {
+    if (sign == -1) unsafeAtomicAdd(p + off, -v);
+    else if (sign) unsafeAtomicAdd(p + off, v);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* __restrict__ trgt, T* __restrict__ out,
+                T* __restrict__ grad, PushPullArgs a) {
+#pragma clang fp contract(off)
+    const long long ovol = (long long)a.Xo * a.Yo * a.Zo, ivol = (long long)a.X * a.Y * a.Z;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= ovol * a.B) return;
+    const long long n = idx / ovol, o = idx % ovol;
+    const int K = a.ndim, C = a.C;
+    T cc[3] = {(T)0, (T)0, (T)0};
+    for (int d = 0; d < K; ++d) cc[d] = grid[idx * K + d];
+    const long long nn[3] = {a.X, a.Y, a.Z};
+    const long long st[3] = {(long long)a.Y * a.Z, a.Z, 1};        // strides of the source / push volume
+    // pull: (B,C,ovol); sgrad: (B,C,ovol,K); push: (B,C,ivol); count: (B,1,ivol); target: (B,C,ovol[,K]); grad: (B,ovol,K)
+    const T* sp = src ? src + n * C * ivol : nullptr;
+    const long long tk = a.trgt_k > 0 ? K : 1;
+    const T* tp = trgt ? trgt + (n * C * ovol + o) * tk : nullptr;
+    const long long tsc = ovol * tk;
+    T* gp = grad ? grad + idx * K : nullptr;
+
+    // ---- out of bounds and no extrapolation: zeros (check3d :796-819)
+    {
+        const T tiny = (T)5e-2;
+        bool inb = true;
+        for (int d = 0; d < K; ++d) inb = inb && cc[d] >= -tiny && cc[d] < (T)(nn[d] - 1) + tiny;
+        if (!(a.extrapolate || inb)) {
+            if (a.do_pull) for (int c = 0; c < C; ++c) out[(n * C + c) * ovol + o] = (T)0;
+            else if (a.do_sgrad) for (int c = 0; c < C; ++c) for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = (T)0;
+            if (a.do_grad) for (int k = 0; k < K; ++k) gp[k] = (T)0;
+            return;
+        }
+    }
+
+    // =================================================================================================== nearest
+    if (a.path == PP_NEAREST) {
+        long long off = 0;
+        int s = 1;
+        for (int d = 0; d < K; ++d) {
+            const long long r = (long long)round(cc[d]);
+            s *= gp_sign(a.bound[d], r, nn[d]);
+            off += gp_index(a.bound[d], r, nn[d]) * st[d];
+        }
+        if (a.do_pull) for (int c = 0; c < C; ++c) out[(n * C + c) * ovol + o] = gp_get(sp + c * ivol, off, s);
+        else if (a.do_sgrad) for (int c = 0; c < C; ++c) for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = (T)0;
+        else if (a.do_push && a.trgt_k == 0) for (int c = 0; c < C; ++c) pp_add(out + (n * C + c) * ivol, off, tp[c * tsc], s);
+        else if (a.do_count) pp_add(out + n * ivol, off, (T)1, s);
+        if (a.do_grad) for (int k = 0; k < K; ++k) gp[k] = (T)0;
+        return;
+    }
+
+    // ==================================================================================================== linear
+    if (a.path == PP_LINEAR) {
+        long long i0[3], i1[3];
+        int s0[3], s1[3];
+        T d0[3], d1[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const long long f = (long long)floor(cc[d]);
+            d1[d] = cc[d] - (T)f;
+            d0[d] = (T)(1. - d1[d]);
+            const int bd = d < K ? a.bound[d] : GB_REPLICATE;
+            s1[d] = gp_sign(bd, f + 1, nn[d]);
+            s0[d] = gp_sign(bd, f, nn[d]);
+            i1[d] = gp_index(bd, f + 1, nn[d]);
+            i0[d] = gp_index(bd, f, nn[d]);
+        }
+        const int ncorner = 1 << K;
+        // corner k: bit 0 = x, bit 1 = y, bit 2 = z -- the order 000,100,010,110,001,101,011,111 of the reference
+        long long off[8];
+        int sg[8];
+        T w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+            off[k] = (bx ? i1[0] : i0[0]) * st[0] + (by ? i1[1] : i0[1]) * st[1] + (bz ? i1[2] : i0[2]);
+            sg[k] = (bx ? s1[0] : s0[0]) * (by ? s1[1] : s0[1]) * (bz ? s1[2] : s0[2]);
+            w[k] = (bx ? d1[0] : d0[0]) * (by ? d1[1] : d0[1]) * (bz ? d1[2] : d0[2]);
+        }
+        if (a.do_grad) {
+            T g[3] = {(T)0, (T)0, (T)0};
+            for (int c = 0; c < C; ++c) {
+                const T* p = sp + c * ivol;
+                if (a.trgt_k == 0) {
+                    const T t = tp ? tp[c * tsc] : (T)1;
+                    for (int k = 0; k < ncorner; ++k) {
+                        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+                        const T wx = bx ? d1[0] : d0[0], wy = by ? d1[1] : d0[1], wz = bz ? d1[2] : d0[2];
+                        T v = gp_get(p, off[k], sg[k]);
+                        if (tp) v = v * t;
+                        const T cx = wy * wz * v, cy = wx * wz * v, cz = wx * wy * v;
+                        g[0] = bx ? g[0] + cx : g[0] - cx;
+                        g[1] = by ? g[1] + cy : g[1] - cy;
+                        g[2] = bz ? g[2] + cz : g[2] - cz;
+                    }
+                } else {
+                    const T t0 = tp[c * tsc], t1 = K > 1 ? tp[c * tsc + 1] : (T)0, t2 = K > 2 ? tp[c * tsc + 2] : (T)0;
+                    for (int k = 0; k < ncorner; ++k) {
+                        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+                        const T wx = bx ? d1[0] : d0[0], wy = by ? d1[1] : d0[1], wz = bz ? d1[2] : d0[2];
+                        const bool pxy = bx == by, pxz = bx == bz, pyz = by == bz;      // sign products e_x e_y, ...
+                        const T v = gp_get(p, off[k], sg[k]);
+                        g[0] = g[0] + ((pxy ? wz : -wz) * t1 + (pxz ? wy : -wy) * t2) * v;
+                        g[1] = g[1] + ((pxy ? wz : -wz) * t0 + (pyz ? wx : -wx) * t2) * v;
+                        g[2] = g[2] + ((pxz ? wy : -wy) * t0 + (pyz ? wx : -wx) * t1) * v;
+                    }
+                }
+            }
+            if (a.trgt_k != 0 && K == 1) g[0] = (T)0;       // interpolate1d_linear :2001-2003 leaves the zero-filled gradient
+            for (int k = 0; k < K; ++k) gp[k] = g[k];
+        }
+        if (a.do_pull) {
+            for (int c = 0; c < C; ++c) {
+                const T* p = sp + c * ivol;
+                T acc = gp_get(p, off[0], sg[0]) * w[0];
+                for (int k = 1; k < ncorner; ++k) acc = acc + gp_get(p, off[k], sg[k]) * w[k];
+                out[(n * C + c) * ovol + o] = acc;
+            }
+        } else if (a.do_sgrad) {
+            for (int c = 0; c < C; ++c) {
+                const T* p = sp + c * ivol;
+                T r[3] = {(T)0, (T)0, (T)0};
+                for (int k = 0; k < ncorner; ++k) {
+                    const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+                    const T wx = bx ? d1[0] : d0[0], wy = by ? d1[1] : d0[1], wz = bz ? d1[2] : d0[2];
+                    const T v = gp_get(p, off[k], sg[k]);
+                    const T tx = (bx ? wy : -wy) * wz * v, ty = (by ? wx : -wx) * wz * v, tz = (bz ? wx : -wx) * wy * v;
+                    r[0] = k ? r[0] + tx : tx;
+                    r[1] = k ? r[1] + ty : ty;
+                    r[2] = k ? r[2] + tz : tz;
+                }
+                for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = r[k];
+            }
+        } else if (a.do_push) {
+            for (int c = 0; c < C; ++c) {
+                T* q = out + (n * C + c) * ivol;
+                if (a.trgt_k == 0) {
+                    const T t = tp[c * tsc];
+                    for (int k = 0; k < ncorner; ++k) pp_add(q, off[k], w[k] * t, sg[k]);
+                } else {
+                    const T t0 = tp[c * tsc], t1 = K > 1 ? tp[c * tsc + 1] : (T)0, t2 = K > 2 ? tp[c * tsc + 2] : (T)0;
+                    for (int k = 0; k < ncorner; ++k) {
+                        const int bx = k & 1, by = (k >> 1) & 1, bz = k >> 2;
+                        const T wx = bx ? d1[0] : d0[0], wy = by ? d1[1] : d0[1], wz = bz ? d1[2] : d0[2];
+                        T val = (bx ? wy : -wy) * wz * t0;
+                        if (K > 1) val = val + (by ? wx : -wx) * wz * t1;
+                        if (K > 2) val = val + (bz ? wx : -wx) * wy * t2;
+                        pp_add(q, off[k], val, sg[k]);
+                    }
+                }
+            }
+        } else if (a.do_count) {
+            for (int k = 0; k < ncorner; ++k) pp_add(out + n * ivol, off[k], w[k], sg[k]);
+        }
+        return;
+    }
+
+    // =================================================================================================== generic
+    T wt[3][8], gt[3][8], ht[3][8];
+    long long it[3][8];
+    int sn[3][8], nt[3];
+    // (the reference evaluates the first derivatives only under do_grad || do_sgrad, :1005, and pushes uninitialised values
+    // in the backward pass of grid_grad when only the image requires a gradient; here they are always evaluated when used)
+    const bool need_g = a.do_grad || a.do_sgrad || (a.do_push && a.trgt_k > 0), need_h = a.do_grad && a.trgt_k > 0;
+    for (int d = 0; d < 3; ++d) {
+        const int order = d < K ? a.interp[d] : 0, bd = d < K ? a.bound[d] : GB_REPLICATE;
+        const long long lo = pp_low(order, cc[d]);
+        nt[d] = (order >= 0 && order <= 7 ? order : 1) + 1;
+        for (int t = 0; t < nt[d]; ++t) {
+            const long long b = lo + t;
+            const T dist = cc[d] - (T)b;
+            wt[d][t] = pp_weight(order, dist);
+            gt[d][t] = need_g ? pp_grad(order, dist) : (T)0;
+            ht[d][t] = need_h ? pp_hess(order, dist) : (T)0;
+            sn[d][t] = gp_sign(bd, b, nn[d]);
+            it[d][t] = gp_index(bd, b, nn[d]);
+        }
+    }
+    if (a.do_pull) {
+        for (int c = 0; c < C; ++c) {
+            const T* p = sp + c * ivol;
+            T acc = (T)0;
+            for (int k = 0; k < nt[2]; ++k)
+                for (int j = 0; j < nt[1]; ++j)
+                    for (int i = 0; i < nt[0]; ++i)
+                        acc = acc + gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], sn[2][k] * sn[1][j] * sn[0][i]) *
+                                        (wt[0][i] * wt[1][j] * wt[2][k]);
+            out[(n * C + c) * ovol + o] = acc;
+        }
+    } else if (a.do_sgrad) {
+        for (int c = 0; c < C; ++c) {
+            const T* p = sp + c * ivol;
+            T r[3] = {(T)0, (T)0, (T)0};
+            for (int k = 0; k < nt[2]; ++k)
+                for (int j = 0; j < nt[1]; ++j)
+                    for (int i = 0; i < nt[0]; ++i) {
+                        const T v = gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], sn[2][k] * sn[1][j] * sn[0][i]);
+                        r[0] = r[0] + v * (gt[0][i] * wt[1][j] * wt[2][k]);
+                        r[1] = r[1] + v * (wt[0][i] * gt[1][j] * wt[2][k]);
+                        r[2] = r[2] + v * (wt[0][i] * wt[1][j] * gt[2][k]);
+                    }
+            for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = r[k];
+        }
+    } else if (a.do_push) {
+        for (int k = 0; k < nt[2]; ++k)
+            for (int j = 0; j < nt[1]; ++j)
+                for (int i = 0; i < nt[0]; ++i) {
+                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + it[2][k];
+                    const int s = sn[2][k] * sn[1][j] * sn[0][i];
+                    for (int c = 0; c < C; ++c) {
+                        T val;
+                        if (a.trgt_k == 0) val = (wt[0][i] * wt[1][j] * wt[2][k]) * tp[c * tsc];
+                        else {
+                            val = (gt[0][i] * wt[1][j] * wt[2][k]) * tp[c * tsc];
+                            if (K > 1) val = val + (wt[0][i] * gt[1][j] * wt[2][k]) * tp[c * tsc + 1];
+                            if (K > 2) val = val + (wt[0][i] * wt[1][j] * gt[2][k]) * tp[c * tsc + 2];
+                        }
+                        pp_add(out + (n * C + c) * ivol, off, val, s);
+                    }
+                }
+    } else if (a.do_count) {
+        for (int k = 0; k < nt[2]; ++k)
+            for (int j = 0; j < nt[1]; ++j)
+                for (int i = 0; i < nt[0]; ++i)
+                    pp_add(out + n * ivol, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], wt[0][i] * wt[1][j] * wt[2][k], sn[2][k] * sn[1][j] * sn[0][i]);
+    }
+    if (a.do_grad) {
+        T g[3] = {(T)0, (T)0, (T)0};
+        for (int k = 0; k < nt[2]; ++k)
+            for (int j = 0; j < nt[1]; ++j)
+                for (int i = 0; i < nt[0]; ++i) {
+                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + it[2][k];
+                    const int s = sn[2][k] * sn[1][j] * sn[0][i];
+                    const T wx = wt[0][i], wy = wt[1][j], wz = wt[2][k], gx = gt[0][i], gy = gt[1][j], gz = gt[2][k];
+                    if (a.trgt_k == 0) {
+                        T dot = (T)0;
+                        for (int c = 0; c < C; ++c) {
+                            const T v = gp_get(sp + c * ivol, off, s);
+                            dot = dot + (tp ? v * tp[c * tsc] : v);
+                        }
+                        g[0] = g[0] + (gx * wy * wz) * dot;
+                        g[1] = g[1] + (wx * gy * wz) * dot;
+                        g[2] = g[2] + (wx * wy * gz) * dot;
+                    } else {
+                        const T hx = ht[0][i], hy = ht[1][j], hz = ht[2][k];
+                        T dot0 = (T)0, dot1 = (T)0, dot2 = (T)0;
+                        for (int c = 0; c < C; ++c) {
+                            const T v = gp_get(sp + c * ivol, off, s);
+                            dot0 = dot0 + v * tp[c * tsc];
+                            if (K > 1) dot1 = dot1 + v * tp[c * tsc + 1];
+                            if (K > 2) dot2 = dot2 + v * tp[c * tsc + 2];
+                        }
+                        // the mixed terms are the reference's (interpolate3d :1129-1131, interpolate2d :1312-1313), as written there
+                        if (K == 1) g[0] = g[0] + hx * dot0;
+                        else if (K == 2) {
+                            g[0] = g[0] + ((hx * wy) * dot0 + (gx * gy) * dot1);
+                            g[1] = g[1] + ((gx * gy) * dot0 + (wx * hy) * dot1);
+                        } else {
+                            g[0] = g[0] + ((hx * wy * wz) * dot0 + (gx * gy * wz) * dot1 + (gx * wy * gz) * dot2);
+                            g[1] = g[1] + ((gx * gy * wz) * dot0 + (wx * hy * wz) * dot1 + (wx * gy * gz) * dot2);
+                            g[2] = g[2] + ((gx * wy * gz) * dot0 + (wx * gy * gz) * dot1 + (wx * wy * hz) * dot2);
+                        }
+                    }
+                }
+        for (int k = 0; k < K; ++k) gp[k] = g[k];
+    }
+}
+
+}  // namespace mh

@@ -1,5 +1,6 @@
 """``AffineTransform`` on the MI355X resampling kernel -- drop-in for
-monai/networks/layers/spatial_transforms.py:439-592 (``F.affine_grid`` + ``F.grid_sample``)."""
+monai/networks/layers/spatial_transforms.py:439-592 (``F.affine_grid`` + ``F.grid_sample``) -- and the differentiable
+``grid_pull`` / ``grid_push`` / ``grid_count`` / ``grid_grad`` functions of the same file (:35-436) on ``monai_amd._C``."""
 
 from __future__ import annotations
 
@@ -8,11 +9,11 @@ from collections.abc import Sequence
 import torch
 import torch.nn as nn
 
-from ... import _lib, ops
+from ... import _C, _lib, ops
 from ...utils.misc import ensure_tuple, look_up_option
 from ..utils import index_matrix
 
-__all__ = ["AffineTransform"]
+__all__ = ["AffineTransform", "grid_pull", "grid_push", "grid_count", "grid_grad"]
 
 
 class AffineTransform(nn.Module):
@@ -82,3 +83,134 @@ class AffineTransform(nn.Module):
                                     self.align_corners, f64)
             outs.append(o.reshape((x.shape[1],) + tuple(int(v) for v in dst_sp)))
         return torch.stack(outs).to(plain.dtype)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# grid_pull / grid_push / grid_count / grid_grad (monai/networks/layers/spatial_transforms.py:35-436): spline sampling
+# with respect to a deformation field in VOXEL coordinates, its adjoint (splatting), the splatted image of ones and the
+# spatial gradients of the sampled image, each differentiable with respect to the image and the field.
+
+
+def _modes(bound, interpolation):
+    """Names / ints / enum members -> lists of enum members, the reference's conversion (:123-127)."""
+    b = [_C.BoundType.__members__[v] if isinstance(v, str) else _C.BoundType(v) for v in ensure_tuple(bound)]
+    i = [_C.InterpolationType.__members__[v] if isinstance(v, str) else _C.InterpolationType(v) for v in ensure_tuple(interpolation)]
+    return b, i
+
+
+def _like_input(out: torch.Tensor, input) -> torch.Tensor:
+    from ...data.meta_tensor import MetaTensor
+
+    if isinstance(input, MetaTensor):
+        return MetaTensor(out).copy_meta_from(input)
+    return out
+
+
+def _two_grads(ctx, grads, n_extra):
+    """Order of the reference's backward passes: [d input][, d grid], each present when the tensor required it."""
+    extra = (None,) * n_extra
+    if ctx.needs_input_grad[0]:
+        return (grads[0], grads[1] if ctx.needs_input_grad[1] else None) + extra
+    return (None, grads[0]) + extra
+
+
+class _GridPull(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+        opt = (bound, interpolation, extrapolate)
+        if input.requires_grad or grid.requires_grad:
+            ctx.opt = opt
+            ctx.save_for_backward(input, grid)
+        return _C.grid_pull(input, grid, *opt)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None, None
+        return _two_grads(ctx, _C.grid_pull_backward(grad, *ctx.saved_tensors, *ctx.opt), 3)
+
+
+class _GridPush(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, grid, shape, interpolation, bound, extrapolate):
+        opt = (bound, interpolation, extrapolate)
+        if input.requires_grad or grid.requires_grad:
+            ctx.opt = opt
+            ctx.save_for_backward(input, grid)
+        return _C.grid_push(input, grid, shape, *opt)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None, None, None
+        return _two_grads(ctx, _C.grid_push_backward(grad, *ctx.saved_tensors, *ctx.opt), 4)
+
+
+class _GridCount(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, grid, shape, interpolation, bound, extrapolate):
+        opt = (bound, interpolation, extrapolate)
+        if grid.requires_grad:
+            ctx.opt = opt
+            ctx.save_for_backward(grid)
+        return _C.grid_count(grid, shape, *opt)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if ctx.needs_input_grad[0]:
+            return _C.grid_count_backward(grad, *ctx.saved_tensors, *ctx.opt), None, None, None, None
+        return None, None, None, None, None
+
+
+class _GridGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, input, grid, interpolation, bound, extrapolate):
+        opt = (bound, interpolation, extrapolate)
+        if input.requires_grad or grid.requires_grad:
+            ctx.opt = opt
+            ctx.save_for_backward(input, grid)
+        return _C.grid_grad(input, grid, *opt)
+
+    @staticmethod
+    def backward(ctx, grad):
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None, None
+        return _two_grads(ctx, _C.grid_grad_backward(grad, *ctx.saved_tensors, *ctx.opt), 3)
+
+
+def grid_pull(input: torch.Tensor, grid: torch.Tensor, interpolation="linear", bound="zero", extrapolate: bool = True) -> torch.Tensor:
+    """Sample ``input`` (B, C, Wi, Hi, Di) at the voxel coordinates ``grid`` (B, Wo, Ho, Do, 1|2|3) -> (B, C, Wo, Ho, Do).
+
+    ``interpolation``: 0-7 or "nearest" / "linear" / "quadratic" / "cubic" / "fourth" ... "seventh" (B-spline order),
+    ``bound``: "replicate"|"nearest"|"border" (0), "dct1"|"mirror" (1), "dct2"|"reflect" (2), "dst1"|"antimirror" (3),
+    "dst2"|"antireflect" (4), "dft"|"wrap" (5), "zero"|"zeros" (7); either may be a list in the order [W, H, D].
+    ``extrapolate=False`` zeroes samples whose coordinate lies outside the field of view.  Reference:
+    monai/networks/layers/spatial_transforms.py:60-132."""
+    b, i = _modes(bound, interpolation)
+    return _like_input(_GridPull.apply(input, grid, i, b, extrapolate), input)
+
+
+def grid_push(input: torch.Tensor, grid: torch.Tensor, shape=None, interpolation="linear", bound="zero", extrapolate: bool = True):
+    """Splat ``input`` (B, C, Wi, Hi, Di) along ``grid`` (B, Wi, Hi, Di, 1|2|3) into a volume of spatial ``shape``
+    (default: the input's) -- the adjoint of ``grid_pull``.  Reference: spatial_transforms.py:160-237."""
+    b, i = _modes(bound, interpolation)
+    if shape is None:
+        shape = tuple(input.shape[2:])
+    return _like_input(_GridPush.apply(input, grid, shape, i, b, extrapolate), input)
+
+
+def grid_count(grid: torch.Tensor, shape=None, interpolation="linear", bound="zero", extrapolate: bool = True):
+    """Splat an image of ones along ``grid`` -> (B, 1, *shape).  Reference: spatial_transforms.py:261-337; like there the
+    default ``shape`` is ``grid.shape[2:]`` (the trailing grid axes INCLUDING the coordinate axis), so pass ``shape``
+    explicitly for anything but a quick look."""
+    b, i = _modes(bound, interpolation)
+    if shape is None:
+        shape = tuple(grid.shape[2:])
+    return _GridCount.apply(grid, shape, i, b, extrapolate)
+
+
+def grid_grad(input: torch.Tensor, grid: torch.Tensor, interpolation="linear", bound="zero", extrapolate: bool = True):
+    """Spatial gradients of ``input`` sampled at ``grid`` -> (B, C, Wo, Ho, Do, 1|2|3).  Reference:
+    spatial_transforms.py:365-436."""
+    b, i = _modes(bound, interpolation)
+    return _like_input(_GridGrad.apply(input, grid, i, b, extrapolate), input)

@@ -263,6 +263,21 @@ typedef void* hipStream_t;
 typedef int hipError_t;
 #define hipSuccess 0
 static inline hipError_t hipGetLastError() { return 0; }
+// floating-point atomics: workgroups run on a pool of host threads, so these are real compare-and-swap loops
+template <class T, class U> static inline T emu_atomic_add(T* p, T v) {
+    static_assert(sizeof(T) == sizeof(U), "size");
+    U* q = reinterpret_cast<U*>(p);
+    U old = __atomic_load_n(q, __ATOMIC_RELAXED), neu;
+    T cur;
+    do {
+        memcpy(&cur, &old, sizeof(T));
+        const T sum = cur + v;
+        memcpy(&neu, &sum, sizeof(T));
+    } while (!__atomic_compare_exchange_n(q, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
+    return cur;
+}
+static inline float unsafeAtomicAdd(float* p, float v) { return emu_atomic_add<float, unsigned int>(p, v); }
+static inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add<double, unsigned long long>(p, v); }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return 0; }

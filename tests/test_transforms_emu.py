@@ -50,6 +50,18 @@ def test_grid_pull_reference_golden_rows(emu):
     tc.case_grid_pull_reference_golden_rows("cpu")
 
 
+def test_pushpull_vs_reference_build(emu):
+    print("worst scatter error", tc.case_pushpull_vs_reference_build("cpu"))
+
+
+def test_grid_pull_reference_rows_all_orders(emu):
+    tc.case_grid_pull_reference_rows_all_orders("cpu")
+
+
+def test_grid_functions_autograd(emu):
+    print(tc.case_grid_functions_autograd("cpu"))
+
+
 def test_resample_dense_grid(emu):
     tc.case_resample_dense_grid("cpu")
 

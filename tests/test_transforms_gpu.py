@@ -35,6 +35,18 @@ def test_grid_pull_reference_golden_rows():
     tc.case_grid_pull_reference_golden_rows(DEV)
 
 
+def test_pushpull_vs_reference_build():
+    print("worst scatter error", tc.case_pushpull_vs_reference_build(DEV))
+
+
+def test_grid_pull_reference_rows_all_orders():
+    tc.case_grid_pull_reference_rows_all_orders(DEV)
+
+
+def test_grid_functions_autograd():
+    print(tc.case_grid_functions_autograd(DEV))
+
+
 def test_resample_dense_grid():
     tc.case_resample_dense_grid(DEV)
 
