@@ -605,12 +605,27 @@ int mh_pushpull(const void* source, const void* grid, const void* target, void* 
     const long long total = (long long)B * Xo * Yo * Zo;
     if (total > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "pushpull: problem too large for one launch");
     const unsigned nb = blocks_for(total);
-    if (is_f64)
-        hipLaunchKernelGGL((pushpull_kernel<double>), dim3(nb), dim3(256), 0, s, static_cast<const double*>(source), static_cast<const double*>(grid),
-                           static_cast<const double*>(target), static_cast<double*>(out), static_cast<double*>(grad), a);
-    else
-        hipLaunchKernelGGL((pushpull_kernel<float>), dim3(nb), dim3(256), 0, s, static_cast<const float*>(source), static_cast<const float*>(grid),
-                           static_cast<const float*>(target), static_cast<float*>(out), static_cast<float*>(grad), a);
+    int maxo = 0;
+    for (int d = 0; d < ndim; ++d) maxo = a.interp[d] > maxo ? a.interp[d] : maxo;
+    const bool pull_only = do_pull && !do_grad;
+#define MH_PP_LAUNCH1(T_, PATH_, NT_, PULL_)                                                                              \
+    hipLaunchKernelGGL((pushpull_kernel<T_, PATH_, NT_, PULL_>), dim3(nb), dim3(256), 0, s, static_cast<const T_*>(source), \
+                       static_cast<const T_*>(grid), static_cast<const T_*>(target), static_cast<T_*>(out), static_cast<T_*>(grad), a)
+#define MH_PP_LAUNCH(T_, PATH_, NT_)                         \
+    {                                                        \
+        if (pull_only) MH_PP_LAUNCH1(T_, PATH_, NT_, true);  \
+        else MH_PP_LAUNCH1(T_, PATH_, NT_, false);           \
+    }
+#define MH_PP_PATHS(T_)                                                     \
+    if (a.path == PP_NEAREST) MH_PP_LAUNCH(T_, PP_NEAREST, 1)               \
+    else if (a.path == PP_LINEAR) MH_PP_LAUNCH(T_, PP_LINEAR, 2)            \
+    else if (maxo <= 2) MH_PP_LAUNCH(T_, PP_GENERIC, 3)                     \
+    else if (maxo == 3) MH_PP_LAUNCH(T_, PP_GENERIC, 4)                     \
+    else MH_PP_LAUNCH(T_, PP_GENERIC, 8)
+    if (is_f64) { MH_PP_PATHS(double) } else { MH_PP_PATHS(float) }
+#undef MH_PP_PATHS
+#undef MH_PP_LAUNCH
+#undef MH_PP_LAUNCH1
     return launched("pushpull");
 }
 

@@ -14,7 +14,10 @@ struct GridPullArgs {
     int extrapolate;
 };
 
+// Every rule maps an in-range index to itself with sign +1: that case (nearly every tap of a sampling grid that stays
+// inside the volume) returns before any of the 64-bit modulo arithmetic below.
 __device__ __forceinline__ long long gp_index(int bound, long long c, long long n) {
+    if (c >= 0 && c < n) return c;
     switch (bound) {
         case GB_REPLICATE: return c <= 0 ? 0 : (c >= n ? n - 1 : c);
         case GB_DCT1: {
@@ -43,6 +46,7 @@ __device__ __forceinline__ long long gp_index(int bound, long long c, long long 
 }
 
 __device__ __forceinline__ int gp_sign(int bound, long long c, long long n) {
+    if (c >= 0 && c < n) return 1;
     switch (bound) {
         case GB_DST1: {
             if (n == 1) return 1;

@@ -206,18 +206,183 @@ template <typename T> __device__ __forceinline__ void pp_add(T* p, long long off
     else if (sign) unsafeAtomicAdd(p + off, v);
 }
 
-template <typename T>
+// one tap of one axis: weight, first / second derivative, remapped index and sign
+template <typename T> struct PPTap {
+    T w, g, h;
+    long long i;
+    int s;
+    __device__ __forceinline__ PPTap(int order, int bound, long long node, T coord, long long n, bool need_g, bool need_h) {
+        const T dist = coord - (T)node;
+        w = pp_weight(order, dist);
+        g = need_g ? pp_grad(order, dist) : (T)0;
+        h = need_h ? pp_hess(order, dist) : (T)0;
+        s = gp_sign(bound, node, n);
+        i = gp_index(bound, node, n);
+    }
+};
+
+// The launch's flags; PULL = true pins them to "forward pull only" at compile time, so that instantiation carries no
+// code or registers of the other modes (the common forward call of grid_pull / Resample).
+template <bool PULL> struct PPFlags {
+    int B, C, X, Y, Z, Xo, Yo, Zo, ndim, extrapolate;
+    int bound[3], interp[3];
+    int do_pull, do_push, do_count, do_grad, do_sgrad, trgt_k;
+    __device__ __forceinline__ explicit PPFlags(const PushPullArgs& s)
+        : B(s.B), C(s.C), X(s.X), Y(s.Y), Z(s.Z), Xo(s.Xo), Yo(s.Yo), Zo(s.Zo), ndim(s.ndim), extrapolate(s.extrapolate),
+          do_pull(PULL ? 1 : s.do_pull), do_push(PULL ? 0 : s.do_push), do_count(PULL ? 0 : s.do_count), do_grad(PULL ? 0 : s.do_grad),
+          do_sgrad(PULL ? 0 : s.do_sgrad), trgt_k(PULL ? 0 : s.trgt_k) {
+        for (int d = 0; d < 3; ++d) { bound[d] = s.bound[d]; interp[d] = s.interp[d]; }
+    }
+};
+
+#define MH_PP_UNROLL _Pragma("unroll NT <= 4 ? NT : 1")
+// the z taps are evaluated inside a ROLLED z loop (the same arithmetic as a table look-up): unrolling all three tap loops
+// keeps NT^3 offsets and values live and needs more than 256 registers at NT = 4
+#define MH_PP_ZLOOP                                                                              \
+    _Pragma("unroll 1") for (int k = 0; k < nt[2]; ++k)                                          \
+        if (const PPTap<T> zt_ = PPTap<T>(zorder, zbound, zlo + k, cc[2], nn[2], need_g, need_h); true)     \
+            if (const T wz_ = zt_.w, gz_ = zt_.g, hz_ = zt_.h; true)                             \
+                if (const long long iz_ = zt_.i; true)                                           \
+                    if (const int sz_ = zt_.s; true)
+// Generic path (pushpull_cpu.cpp interpolate3d :938-1146).  NT = compile-time bound on the taps per axis (order + 1):
+// with NT <= 4 the tap tables live in registers and the tap loops unroll; NT = 8 serves orders 4-7.
+template <typename T, int NT, bool PULL>
+__device__ __forceinline__ void pp_generic(const PushPullArgs& a_, const T* __restrict__ sp, const T* __restrict__ tp, T* __restrict__ out,
+                                           T* __restrict__ gp, const T (&cc)[3], long long n, long long o, long long ovol, long long ivol,
+                                           long long tsc) {
+#pragma clang fp contract(off)
+    const PPFlags<PULL> a(a_);
+    const int K = a.ndim, C = a.C;
+    const long long nn[3] = {a.X, a.Y, a.Z};
+    const long long st[3] = {(long long)a.Y * a.Z, a.Z, 1};
+    T wt[2][NT], gt[2][NT], ht[2][NT];
+    long long it[2][NT];
+    int sn[2][NT], nt[3];
+    // (the reference evaluates the first derivatives only under do_grad || do_sgrad, :1005, and pushes uninitialised values
+    // in the backward pass of grid_grad when only the image requires a gradient; here they are always evaluated when used)
+    const bool need_g = a.do_grad || a.do_sgrad || (a.do_push && a.trgt_k > 0), need_h = a.do_grad && a.trgt_k > 0;
+    const int zorder = K > 2 ? a.interp[2] : 0, zbound = K > 2 ? a.bound[2] : GB_REPLICATE;
+    const long long zlo = pp_low(zorder, cc[2]);
+    nt[2] = (zorder >= 0 && zorder <= 7 ? zorder : 1) + 1;
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const int order = d < K ? a.interp[d] : 0, bd = d < K ? a.bound[d] : GB_REPLICATE;
+        const long long lo = pp_low(order, cc[d]);
+        nt[d] = (order >= 0 && order <= 7 ? order : 1) + 1;
+        MH_PP_UNROLL for (int t = 0; t < NT; ++t) {
+            if (t >= nt[d]) break;
+            const PPTap<T> tap(order, bd, lo + t, cc[d], nn[d], need_g, need_h);
+            wt[d][t] = tap.w; gt[d][t] = tap.g; ht[d][t] = tap.h; sn[d][t] = tap.s; it[d][t] = tap.i;
+        }
+    }
+    if (a.do_pull) {
+        for (int c = 0; c < C; ++c) {
+            const T* p = sp + c * ivol;
+            T acc = (T)0;
+            MH_PP_ZLOOP
+                MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
+                    MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0])
+                        acc = acc + gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + iz_, sz_ * sn[1][j] * sn[0][i]) *
+                                        (wt[0][i] * wt[1][j] * wz_);
+            out[(n * C + c) * ovol + o] = acc;
+        }
+    } else if (a.do_sgrad) {
+        for (int c = 0; c < C; ++c) {
+            const T* p = sp + c * ivol;
+            T r[3] = {(T)0, (T)0, (T)0};
+            MH_PP_ZLOOP
+                MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
+                    MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0]) {
+                        const T v = gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + iz_, sz_ * sn[1][j] * sn[0][i]);
+                        r[0] = r[0] + v * (gt[0][i] * wt[1][j] * wz_);
+                        r[1] = r[1] + v * (wt[0][i] * gt[1][j] * wz_);
+                        r[2] = r[2] + v * (wt[0][i] * wt[1][j] * gz_);
+                    }
+            for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = r[k];
+        }
+    } else if (a.do_push) {
+        MH_PP_ZLOOP
+            MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
+                MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0]) {
+                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + iz_;
+                    const int s = sz_ * sn[1][j] * sn[0][i];
+                    for (int c = 0; c < C; ++c) {
+                        T val;
+                        if (a.trgt_k == 0) val = (wt[0][i] * wt[1][j] * wz_) * tp[c * tsc];
+                        else {
+                            val = (gt[0][i] * wt[1][j] * wz_) * tp[c * tsc];
+                            if (K > 1) val = val + (wt[0][i] * gt[1][j] * wz_) * tp[c * tsc + 1];
+                            if (K > 2) val = val + (wt[0][i] * wt[1][j] * gz_) * tp[c * tsc + 2];
+                        }
+                        pp_add(out + (n * C + c) * ivol, off, val, s);
+                    }
+                }
+    } else if (a.do_count) {
+        MH_PP_ZLOOP
+            MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
+                MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0])
+                    pp_add(out + n * ivol, it[0][i] * st[0] + it[1][j] * st[1] + iz_, wt[0][i] * wt[1][j] * wz_, sz_ * sn[1][j] * sn[0][i]);
+    }
+    if (a.do_grad) {
+        T g[3] = {(T)0, (T)0, (T)0};
+        MH_PP_ZLOOP
+            MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
+                MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0]) {
+                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + iz_;
+                    const int s = sz_ * sn[1][j] * sn[0][i];
+                    const T wx = wt[0][i], wy = wt[1][j], wz = wz_, gx = gt[0][i], gy = gt[1][j], gz = gz_;
+                    if (a.trgt_k == 0) {
+                        T dot = (T)0;
+                        for (int c = 0; c < C; ++c) {
+                            const T v = gp_get(sp + c * ivol, off, s);
+                            dot = dot + (tp ? v * tp[c * tsc] : v);
+                        }
+                        g[0] = g[0] + (gx * wy * wz) * dot;
+                        g[1] = g[1] + (wx * gy * wz) * dot;
+                        g[2] = g[2] + (wx * wy * gz) * dot;
+                    } else {
+                        const T hx = ht[0][i], hy = ht[1][j], hz = hz_;
+                        T dot0 = (T)0, dot1 = (T)0, dot2 = (T)0;
+                        for (int c = 0; c < C; ++c) {
+                            const T v = gp_get(sp + c * ivol, off, s);
+                            dot0 = dot0 + v * tp[c * tsc];
+                            if (K > 1) dot1 = dot1 + v * tp[c * tsc + 1];
+                            if (K > 2) dot2 = dot2 + v * tp[c * tsc + 2];
+                        }
+                        // the mixed terms are the reference's (interpolate3d :1129-1131, interpolate2d :1312-1313), as written there
+                        if (K == 1) g[0] = g[0] + hx * dot0;
+                        else if (K == 2) {
+                            g[0] = g[0] + ((hx * wy) * dot0 + (gx * gy) * dot1);
+                            g[1] = g[1] + ((gx * gy) * dot0 + (wx * hy) * dot1);
+                        } else {
+                            g[0] = g[0] + ((hx * wy * wz) * dot0 + (gx * gy * wz) * dot1 + (gx * wy * gz) * dot2);
+                            g[1] = g[1] + ((gx * gy * wz) * dot0 + (wx * hy * wz) * dot1 + (wx * gy * gz) * dot2);
+                            g[2] = g[2] + ((gx * wy * gz) * dot0 + (wx * gy * gz) * dot1 + (wx * wy * hz) * dot2);
+                        }
+                    }
+                }
+        for (int k = 0; k < K; ++k) gp[k] = g[k];
+    }
+}
+#undef MH_PP_ZLOOP
+#undef MH_PP_UNROLL
+
+// PATH / NT are compile-time so that each launch carries only its own path's registers (one kernel with all three
+// paths inlined needs 256 VGPRs + scratch and runs at one wave per SIMD).
+template <typename T, int PATH, int NT, bool PULL>
 __global__ void __launch_bounds__(256)
 pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* __restrict__ trgt, T* __restrict__ out,
-                T* __restrict__ grad, PushPullArgs a) {
+                T* __restrict__ grad, PushPullArgs a_) {
 #pragma clang fp contract(off)
+    const PPFlags<PULL> a(a_);
     const long long ovol = (long long)a.Xo * a.Yo * a.Zo, ivol = (long long)a.X * a.Y * a.Z;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= ovol * a.B) return;
-    const long long n = idx / ovol, o = idx % ovol;
+    const long long n = a.B == 1 ? 0 : idx / ovol, o = idx - n * ovol;
     const int K = a.ndim, C = a.C;
     T cc[3] = {(T)0, (T)0, (T)0};
-    for (int d = 0; d < K; ++d) cc[d] = grid[idx * K + d];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) if (d < K) cc[d] = grid[idx * K + d];
     const long long nn[3] = {a.X, a.Y, a.Z};
     const long long st[3] = {(long long)a.Y * a.Z, a.Z, 1};        // strides of the source / push volume
     // pull: (B,C,ovol); sgrad: (B,C,ovol,K); push: (B,C,ivol); count: (B,1,ivol); target: (B,C,ovol[,K]); grad: (B,ovol,K)
@@ -231,7 +396,8 @@ pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* 
     {
         const T tiny = (T)5e-2;
         bool inb = true;
-        for (int d = 0; d < K; ++d) inb = inb && cc[d] >= -tiny && cc[d] < (T)(nn[d] - 1) + tiny;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) if (d < K) inb = inb && cc[d] >= -tiny && cc[d] < (T)(nn[d] - 1) + tiny;
         if (!(a.extrapolate || inb)) {
             if (a.do_pull) for (int c = 0; c < C; ++c) out[(n * C + c) * ovol + o] = (T)0;
             else if (a.do_sgrad) for (int c = 0; c < C; ++c) for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = (T)0;
@@ -241,14 +407,16 @@ pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* 
     }
 
     // =================================================================================================== nearest
-    if (a.path == PP_NEAREST) {
+    if (PATH == PP_NEAREST) {
         long long off = 0;
         int s = 1;
-        for (int d = 0; d < K; ++d) {
-            const long long r = (long long)round(cc[d]);
-            s *= gp_sign(a.bound[d], r, nn[d]);
-            off += gp_index(a.bound[d], r, nn[d]) * st[d];
-        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (d < K) {
+                const long long r = (long long)round(cc[d]);
+                s *= gp_sign(a.bound[d], r, nn[d]);
+                off += gp_index(a.bound[d], r, nn[d]) * st[d];
+            }
         if (a.do_pull) for (int c = 0; c < C; ++c) out[(n * C + c) * ovol + o] = gp_get(sp + c * ivol, off, s);
         else if (a.do_sgrad) for (int c = 0; c < C; ++c) for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = (T)0;
         else if (a.do_push && a.trgt_k == 0) for (int c = 0; c < C; ++c) pp_add(out + (n * C + c) * ivol, off, tp[c * tsc], s);
@@ -258,7 +426,7 @@ pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* 
     }
 
     // ==================================================================================================== linear
-    if (a.path == PP_LINEAR) {
+    if (PATH == PP_LINEAR) {
         long long i0[3], i1[3];
         int s0[3], s1[3];
         T d0[3], d1[3];
@@ -364,114 +532,7 @@ pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* 
     }
 
     // =================================================================================================== generic
-    T wt[3][8], gt[3][8], ht[3][8];
-    long long it[3][8];
-    int sn[3][8], nt[3];
-    // (the reference evaluates the first derivatives only under do_grad || do_sgrad, :1005, and pushes uninitialised values
-    // in the backward pass of grid_grad when only the image requires a gradient; here they are always evaluated when used)
-    const bool need_g = a.do_grad || a.do_sgrad || (a.do_push && a.trgt_k > 0), need_h = a.do_grad && a.trgt_k > 0;
-    for (int d = 0; d < 3; ++d) {
-        const int order = d < K ? a.interp[d] : 0, bd = d < K ? a.bound[d] : GB_REPLICATE;
-        const long long lo = pp_low(order, cc[d]);
-        nt[d] = (order >= 0 && order <= 7 ? order : 1) + 1;
-        for (int t = 0; t < nt[d]; ++t) {
-            const long long b = lo + t;
-            const T dist = cc[d] - (T)b;
-            wt[d][t] = pp_weight(order, dist);
-            gt[d][t] = need_g ? pp_grad(order, dist) : (T)0;
-            ht[d][t] = need_h ? pp_hess(order, dist) : (T)0;
-            sn[d][t] = gp_sign(bd, b, nn[d]);
-            it[d][t] = gp_index(bd, b, nn[d]);
-        }
-    }
-    if (a.do_pull) {
-        for (int c = 0; c < C; ++c) {
-            const T* p = sp + c * ivol;
-            T acc = (T)0;
-            for (int k = 0; k < nt[2]; ++k)
-                for (int j = 0; j < nt[1]; ++j)
-                    for (int i = 0; i < nt[0]; ++i)
-                        acc = acc + gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], sn[2][k] * sn[1][j] * sn[0][i]) *
-                                        (wt[0][i] * wt[1][j] * wt[2][k]);
-            out[(n * C + c) * ovol + o] = acc;
-        }
-    } else if (a.do_sgrad) {
-        for (int c = 0; c < C; ++c) {
-            const T* p = sp + c * ivol;
-            T r[3] = {(T)0, (T)0, (T)0};
-            for (int k = 0; k < nt[2]; ++k)
-                for (int j = 0; j < nt[1]; ++j)
-                    for (int i = 0; i < nt[0]; ++i) {
-                        const T v = gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], sn[2][k] * sn[1][j] * sn[0][i]);
-                        r[0] = r[0] + v * (gt[0][i] * wt[1][j] * wt[2][k]);
-                        r[1] = r[1] + v * (wt[0][i] * gt[1][j] * wt[2][k]);
-                        r[2] = r[2] + v * (wt[0][i] * wt[1][j] * gt[2][k]);
-                    }
-            for (int k = 0; k < K; ++k) out[((n * C + c) * ovol + o) * K + k] = r[k];
-        }
-    } else if (a.do_push) {
-        for (int k = 0; k < nt[2]; ++k)
-            for (int j = 0; j < nt[1]; ++j)
-                for (int i = 0; i < nt[0]; ++i) {
-                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + it[2][k];
-                    const int s = sn[2][k] * sn[1][j] * sn[0][i];
-                    for (int c = 0; c < C; ++c) {
-                        T val;
-                        if (a.trgt_k == 0) val = (wt[0][i] * wt[1][j] * wt[2][k]) * tp[c * tsc];
-                        else {
-                            val = (gt[0][i] * wt[1][j] * wt[2][k]) * tp[c * tsc];
-                            if (K > 1) val = val + (wt[0][i] * gt[1][j] * wt[2][k]) * tp[c * tsc + 1];
-                            if (K > 2) val = val + (wt[0][i] * wt[1][j] * gt[2][k]) * tp[c * tsc + 2];
-                        }
-                        pp_add(out + (n * C + c) * ivol, off, val, s);
-                    }
-                }
-    } else if (a.do_count) {
-        for (int k = 0; k < nt[2]; ++k)
-            for (int j = 0; j < nt[1]; ++j)
-                for (int i = 0; i < nt[0]; ++i)
-                    pp_add(out + n * ivol, it[0][i] * st[0] + it[1][j] * st[1] + it[2][k], wt[0][i] * wt[1][j] * wt[2][k], sn[2][k] * sn[1][j] * sn[0][i]);
-    }
-    if (a.do_grad) {
-        T g[3] = {(T)0, (T)0, (T)0};
-        for (int k = 0; k < nt[2]; ++k)
-            for (int j = 0; j < nt[1]; ++j)
-                for (int i = 0; i < nt[0]; ++i) {
-                    const long long off = it[0][i] * st[0] + it[1][j] * st[1] + it[2][k];
-                    const int s = sn[2][k] * sn[1][j] * sn[0][i];
-                    const T wx = wt[0][i], wy = wt[1][j], wz = wt[2][k], gx = gt[0][i], gy = gt[1][j], gz = gt[2][k];
-                    if (a.trgt_k == 0) {
-                        T dot = (T)0;
-                        for (int c = 0; c < C; ++c) {
-                            const T v = gp_get(sp + c * ivol, off, s);
-                            dot = dot + (tp ? v * tp[c * tsc] : v);
-                        }
-                        g[0] = g[0] + (gx * wy * wz) * dot;
-                        g[1] = g[1] + (wx * gy * wz) * dot;
-                        g[2] = g[2] + (wx * wy * gz) * dot;
-                    } else {
-                        const T hx = ht[0][i], hy = ht[1][j], hz = ht[2][k];
-                        T dot0 = (T)0, dot1 = (T)0, dot2 = (T)0;
-                        for (int c = 0; c < C; ++c) {
-                            const T v = gp_get(sp + c * ivol, off, s);
-                            dot0 = dot0 + v * tp[c * tsc];
-                            if (K > 1) dot1 = dot1 + v * tp[c * tsc + 1];
-                            if (K > 2) dot2 = dot2 + v * tp[c * tsc + 2];
-                        }
-                        // the mixed terms are the reference's (interpolate3d :1129-1131, interpolate2d :1312-1313), as written there
-                        if (K == 1) g[0] = g[0] + hx * dot0;
-                        else if (K == 2) {
-                            g[0] = g[0] + ((hx * wy) * dot0 + (gx * gy) * dot1);
-                            g[1] = g[1] + ((gx * gy) * dot0 + (wx * hy) * dot1);
-                        } else {
-                            g[0] = g[0] + ((hx * wy * wz) * dot0 + (gx * gy * wz) * dot1 + (gx * wy * gz) * dot2);
-                            g[1] = g[1] + ((gx * gy * wz) * dot0 + (wx * hy * wz) * dot1 + (wx * gy * gz) * dot2);
-                            g[2] = g[2] + ((gx * wy * gz) * dot0 + (wx * gy * gz) * dot1 + (wx * wy * hz) * dot2);
-                        }
-                    }
-                }
-        for (int k = 0; k < K; ++k) gp[k] = g[k];
-    }
+    if (PATH == PP_GENERIC) pp_generic<T, NT, PULL>(a_, sp, tp, out, gp, cc, n, o, ovol, ivol, tsc);
 }
 
 }  // namespace mh

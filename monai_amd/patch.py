@@ -48,7 +48,13 @@ _TARGETS = {
         "GaussianSmoothD": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
         "GaussianSmoothDict": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
     },
-    "monai.networks.layers.spatial_transforms": {"AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform")},
+    "monai.networks.layers.spatial_transforms": {
+        "AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform"),
+        "grid_pull": ("monai_amd.networks.layers.spatial_transforms", "grid_pull"),
+        "grid_push": ("monai_amd.networks.layers.spatial_transforms", "grid_push"),
+        "grid_count": ("monai_amd.networks.layers.spatial_transforms", "grid_count"),
+        "grid_grad": ("monai_amd.networks.layers.spatial_transforms", "grid_grad"),
+    },
     "monai.networks.layers.simplelayers": {"GaussianFilter": ("monai_amd.networks.layers.simplelayers", "GaussianFilter")},
 }
 # parent packages that re-export the names above

@@ -53,6 +53,12 @@ def test_bundle_targets_resolve_to_amd_classes(monai_ref):
     import monai._C as native
 
     assert native.BoundType.__members__["reflect"] == 2 and hasattr(native, "grid_pull")
+    for fn in ("grid_pull", "grid_push", "grid_count", "grid_grad"):       # the differentiable wrappers and their backends
+        import monai.networks.layers as ref_layers
+        from monai_amd.networks import layers as our_layers
+
+        assert getattr(ref_layers, fn) is getattr(our_layers, fn), fn
+        assert hasattr(native, fn) and hasattr(native, fn + "_backward")
     patch.uninstall()
     assert monai_ref.inferers.SlidingWindowInferer is ref_cls
 
