@@ -123,7 +123,8 @@ def sliding_window_inference(
 
     Differences, all result-neutral: ``buffer_steps`` / ``buffer_dim`` are validated and otherwise ignored (they are
     a memory-saving schedule of the reference, not a different result -- the blend here never materialises partial
-    volumes); ``sw_device`` must be the ROCm device the inputs live on.  ``process_fn`` (utils.py:232-234) is honoured with
+    volumes; when the logits of all windows do not fit in HBM the volume is processed slab by slab along its first spatial
+    axis with bit-identical results, see ``_slabwise``); ``sw_device`` must be the ROCm device the inputs live on.  ``process_fn`` (utils.py:232-234) is honoured with
     the reference's semantics: each batch is multiplied by the weight map it returns, the count map uses the first batch's.
     """
     num_spatial_dims = inputs.dim() - 2
@@ -164,6 +165,26 @@ def sliding_window_inference(
     num_win = 1
     for s in starts:
         num_win *= len(s)
+
+    # all-window logits that do not fit in HBM: slab by slab along the first spatial axis (see _slabwise)
+    slab_ok = (not kwargs.pop("_monai_amd_no_slabs", False) and not with_coord and process_fn is None and not any(pad_size)
+               and len(starts[0]) > 1 and parallel.window_shard(num_win).world == 1)
+    if slab_ok:
+        sub_kwargs = dict(kwargs, _monai_amd_no_slabs=True)
+
+        def _whole(x):
+            return sliding_window_inference(x, roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, sw_device,
+                                            device, progress, roi_weight_map, None, buffer_steps, buffer_dim, False, *args, **sub_kwargs)
+
+        try:
+            return _whole(meta_src if meta_src is not None else inputs)
+        except _LogitsDoNotFit as e:      # leave the handler before retrying: the traceback keeps the failed call's buffers alive
+            need, budget = e.need, (0.9 * e.budget if _logits_budget(inputs.device) is None else e.budget)
+        out = _slabwise(inputs, roi_size, starts[0], need, budget, _whole)
+        if meta_src is not None:
+            keys, parts = _flatten_struct(out)
+            out = _pack_struct([_restore_meta(t, meta_src) for t in parts], keys)
+        return out
 
     # importance map, always evaluated on the host in fp32 (bit-identical to the reference's CPU map)
     valid_patch_size = get_valid_patch_size(image_size, roi_size)
@@ -335,11 +356,77 @@ def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
     if dev.type == "cuda":
         free, _ = torch.cuda.mem_get_info(dev)
         if need > 0.9 * free:
-            raise RuntimeError(
-                f"monai_amd: the all-window logits buffer needs {need / 2**30:.1f} GiB but only {free / 2**30:.1f} GiB of HBM "
-                "are free; use a smaller volume or more classes per pass (slab-wise blending is not implemented yet)"
-            )
+            raise _LogitsDoNotFit(need, free)
+    limit = _logits_budget(dev)
+    if limit is not None and need > limit:
+        raise _LogitsDoNotFit(need, limit)
     return torch.empty((rows, k) + tuple(seg3), dtype=dtype, device=dev)
+
+
+class _LogitsDoNotFit(RuntimeError):
+    """The all-window logits buffer exceeds the memory budget: the caller retries slab by slab (`_slabwise`)."""
+
+    def __init__(self, need: int, budget: float):
+        super().__init__(
+            f"monai_amd: the all-window logits buffer needs {need / 2**30:.2f} GiB, the budget is {budget / 2**30:.2f} GiB of HBM "
+            "(and the volume cannot be cut into slabs along its first spatial axis: a single row of windows does not fit, or the "
+            "call uses with_coord / process_fn / window sharding, whose semantics are tied to the whole volume)"
+        )
+        self.need, self.budget = need, budget
+
+
+def _logits_budget(dev):
+    """Explicit cap on the logits buffer (bytes) from MONAI_AMD_MAX_LOGITS_BYTES -- tests use it to force the slab-wise
+    path on small volumes; without it the cap is 90 % of the free HBM (checked in _alloc_logits)."""
+    env = os.environ.get("MONAI_AMD_MAX_LOGITS_BYTES")
+    return float(env) if env else None
+
+
+def _slabwise(inputs, roi_size, starts0, need: int, budget: float, call):
+    """Volumes whose all-window logits do not fit in HBM: cut the FIRST spatial axis into slabs of whole window rows and run
+    the same inference on each slab's sub-volume -- the span of every window row that intersects the slab, so each owned
+    output plane sees exactly the windows it sees in the whole volume, at the same positions and in the same order
+    (results are bit-identical; the rows shared by two neighbouring sub-volumes are computed twice: one extra row per slab at
+    overlap 0.5).  `call(sub_inputs)` runs the normal path; returns the packed outputs of the whole volume."""
+    rows = len(starts0)
+    roi0 = int(roi_size[0])
+    size0 = int(inputs.shape[2])
+    per_row = need / rows
+    first_of = lambda a: min(r for r in range(rows) if starts0[r] + roi0 > starts0[a])  # noqa: E731
+    # greedy grouping of owned rows [a, b): owned + re-computed rows must fit in the budget
+    groups, a = [], 0
+    while a < rows:
+        b = a + 1
+        while b < rows and (b + 1 - first_of(a)) * per_row <= budget:
+            b += 1
+        if (b - first_of(a)) * per_row > budget:
+            raise _LogitsDoNotFit(int((b - first_of(a)) * per_row), budget)
+        groups.append((a, b))
+        a = b
+    if len(groups) < 2:
+        raise _LogitsDoNotFit(need, budget)
+    finals, keys = None, None
+    for a, b in groups:
+        r0 = first_of(a)
+        lo, hi = int(starts0[r0]), int(starts0[b - 1]) + roi0
+        own_lo, own_hi = int(starts0[a]), (int(starts0[b]) if b < rows else size0)
+        res = call(inputs[:, :, lo:hi])
+        keys, parts = _flatten_struct(res)
+        if finals is None:
+            finals = []
+            for t in parts:
+                scale = t.shape[2] / float(hi - lo)
+                finals.append(torch.empty(tuple(t.shape[:2]) + (int(round(size0 * scale)),) + tuple(t.shape[3:]), dtype=t.dtype, device=t.device))
+        for t, f in zip(parts, finals):
+            scale = t.shape[2] / float(hi - lo)
+            p0, p1, q0 = own_lo * scale, own_hi * scale, lo * scale
+            if abs(p0 - round(p0)) > 1e-6 or abs(p1 - round(p1)) > 1e-6 or abs(q0 - round(q0)) > 1e-6:
+                raise RuntimeError("monai_amd: slab-wise blending needs output planes aligned with the window rows "
+                                   f"(output/input scale {scale} along the first spatial axis)")
+            p0, p1, q0 = int(round(p0)), int(round(p1)), int(round(q0))
+            f[:, :, p0:p1] = t[:, :, p0 - q0 : p1 - q0]
+        del res, parts
+    return _pack_struct(finals, keys)
 
 
 def _restore_meta(out: torch.Tensor, src):

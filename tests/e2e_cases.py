@@ -82,6 +82,58 @@ def case_sliding_window_net5_vs_golden(device):
     return r
 
 
+def case_slabwise_equals_whole(device):
+    """Volumes whose all-window logits exceed the budget are processed slab by slab along the first spatial axis
+    (monai_amd/inferers/utils.py:_slabwise): the result must be BIT-IDENTICAL to the one-pass result -- fused engine and a
+    generic predictor (tuple of two outputs, one at half resolution), gaussian and constant blending."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.inferers import utils as U
+
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(31)
+    x = torch.rand(1, 1, 40, 24, 16).to(device)          # roi 16, overlap 0.5 -> 4 rows of 2 x 1 windows along the first axis
+
+    def two_heads(w):                                    # generic predictor: full-resolution and half-resolution outputs
+        a = torch.cat([w * 2.0, w.flip(2) - 0.5], dim=1)
+        return a, torch.nn.functional.avg_pool3d(a, 2)
+
+    calls = []
+    real = U._slabwise
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+
+    res = {}
+    for name, pred, mode in (("net", net, "gaussian"), ("generic", two_heads, "constant")):
+        inf = SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode=mode)
+        whole = inf(x, pred)
+        k = 5 if name == "net" else 2
+        row_bytes = 2 * k * 16 ** 3 * 4
+        os.environ["MONAI_AMD_MAX_LOGITS_BYTES"] = str(2.5 * row_bytes)      # two rows fit, four do not
+        U._slabwise = spy
+        try:
+            n0 = len(calls)
+            slabs = inf(x, pred)
+            assert len(calls) == n0 + 1, "the slab-wise path did not run"
+        finally:
+            U._slabwise = real
+            del os.environ["MONAI_AMD_MAX_LOGITS_BYTES"]
+        for a, b in zip(whole if isinstance(whole, tuple) else (whole,), slabs if isinstance(slabs, tuple) else (slabs,)):
+            assert a.shape == b.shape and torch.equal(a, b), (name, float((a - b).abs().max()))
+        res[name] = True
+    os.environ["MONAI_AMD_MAX_LOGITS_BYTES"] = "1000"    # not even one row fits: a clear error, no silent fallback
+    try:
+        try:
+            SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5)(x, net)
+            raise AssertionError("expected the logits budget error")
+        except RuntimeError as e:
+            assert "logits buffer" in str(e)
+    finally:
+        del os.environ["MONAI_AMD_MAX_LOGITS_BYTES"]
+    return res
+
+
 def case_config0_vs_golden(device):
     """BASELINE.json configs[0]: BasicUNet(1->2), rand 64^3, roi 32^3, sw_batch 4, overlap .5, gaussian."""
     from monai_amd.inferers import SlidingWindowInferer

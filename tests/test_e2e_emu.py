@@ -37,3 +37,7 @@ def test_basic_unet_odd_window_vs_reference(emu):
 
 def test_process_fn_bitwise_vs_reference(emu):
     ec.case_process_fn_vs_golden("cpu")
+
+
+def test_slabwise_equals_whole(emu):
+    print(ec.case_slabwise_equals_whole("cpu"))

@@ -164,3 +164,7 @@ def test_basic_unet_odd_window_vs_reference():
 
 def test_process_fn_bitwise_vs_reference():
     ec.case_process_fn_vs_golden(DEV)
+
+
+def test_slabwise_equals_whole():
+    print(ec.case_slabwise_equals_whole(DEV))
