@@ -14,6 +14,7 @@ from ...data.meta_tensor import MetaTensor, is_meta
 from ...data.utils import AFFINE_TOL, affine_to_spacing, compute_shape_offset, to_affine_nd, zoom_affine
 from ...utils.misc import ensure_tuple
 from ... import ops
+from ... import config
 from .functional import _mode_name, _pad_name, spatial_resample
 
 __all__ = ["SpatialResample", "Spacing", "Resample"]
@@ -169,6 +170,9 @@ class Resample:
         dtype_pt = _torch_dtype(dtype or self.dtype, data.dtype if data.dtype.is_floating_point else torch.float64)
         ac = self.align_corners if align_corners is None else align_corners
         sr = min(data.dim() - 1, 3)
+        if config.USE_COMPILED:
+            return self._compiled(img, data, grid, sr, self.mode if mode is None else mode,
+                                  self.padding_mode if padding_mode is None else padding_mode, dtype_pt, ac)
         if sr < 2:
             raise NotImplementedError("monai_amd.Resample: 1-D images are not on the HIP path")
         sizes = [int(v) for v in data.shape[1:1 + sr]]
@@ -192,3 +196,38 @@ class Resample:
                                 scale=[1.0] * pad + scale, offset=[0.0] * pad + offset)
         out = out.reshape((data.shape[0],) + osp)
         return _wrap(out, img, None, None)
+
+    def _compiled(self, img, data, grid, sr, mode, padding_mode, dtype_pt, ac):
+        """``USE_COMPILED`` branch (array.py:2076-2092): the grid is turned into voxel indices and sampled with the native
+        ``grid_pull`` (extrapolate=True) in ``dtype``.  Mode mapping of ``resolves_modes(use_compiled=True)``
+        (transforms/utils.py:2339-2347): *linear -> order 1, bicubic -> order 3 (a cubic B-spline, not ATen's bicubic),
+        nearest -> 0; padding zeros -> zero, border -> replicate, reflection -> dct1."""
+        from ...networks.layers import grid_pull
+
+        m = str(getattr(mode, "value", mode)).lower()
+        if isinstance(getattr(mode, "value", mode), (int, np.integer)) and not isinstance(mode, bool):
+            raise NotImplementedError("monai_amd: spline-order (integer) interpolation modes use scipy in the reference and are not on the HIP path")
+        if m.endswith("linear"):
+            order = 1
+        elif m == "bicubic":
+            order = 3
+        elif m in ("nearest", "nearest-exact"):
+            order = "nearest"
+        else:
+            raise ValueError(f"Unsupported mode: {mode}, available options are ['bilinear', 'nearest', 'bicubic'].")
+        p = _pad_name(padding_mode)
+        bound = 1 if p == "reflection" else p
+        g = torch.as_tensor(grid)[:sr].to(device=data.device)
+        if not g.dtype.is_floating_point:
+            g = g.to(torch.float64)
+        g = g.clone(memory_format=torch.contiguous_format)
+        for i, dim in enumerate(data.shape[1:1 + sr]):
+            d_ = max(2, int(dim))
+            t = (d_ - 1) / 2.0
+            if self.norm_coords:
+                g[i] = ((d_ - 1) / d_) * g[i] + t if ac else g[i] + t
+            elif ac:
+                g[i] = ((d_ - 1) / d_) * (g[i] + 0.5)
+        x = data.to(dtype_pt)
+        out = grid_pull(x.unsqueeze(0), torch.movedim(g, 0, -1).unsqueeze(0).to(x), bound=bound, extrapolate=True, interpolation=order)[0]
+        return _wrap(out.to(torch.float32), img, None, None)

@@ -100,3 +100,7 @@ def test_separable_fast_path_equals_general(emu):
 
 def test_gaussian_z_chunks(emu):
     tc.case_gaussian_z_chunks("cpu")
+
+
+def test_resample_compiled_vs_reference(emu):
+    print("worst error", tc.case_resample_compiled_vs_reference("cpu"))

@@ -118,3 +118,7 @@ def test_separable_fast_path_equals_general():
 
 def test_gaussian_z_chunks():
     tc.case_gaussian_z_chunks(DEV)
+
+
+def test_resample_compiled_vs_reference():
+    print("worst error", tc.case_resample_compiled_vs_reference(DEV))

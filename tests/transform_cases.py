@@ -373,6 +373,63 @@ def case_grid_functions_autograd(device):
     return errs
 
 
+# ---- Resample, USE_COMPILED branch ------------------------------------------------------------------------------------
+def _rc_cases():
+    cases = []
+    for sd in (3, 2):
+        for mode in ("bilinear", "nearest", "bicubic"):
+            for pad in ("zeros", "border", "reflection"):
+                for ac in (False, True):
+                    cases.append({"sd": sd, "mode": mode, "padding_mode": pad, "align_corners": ac, "norm_coords": True,
+                                  "dtype": np.float64, "seed": len(cases)})
+    cases.append({"sd": 3, "mode": "bilinear", "padding_mode": "border", "align_corners": False, "norm_coords": False, "dtype": np.float64, "seed": 90})
+    cases.append({"sd": 3, "mode": "bilinear", "padding_mode": "zeros", "align_corners": True, "norm_coords": False, "dtype": np.float32, "seed": 91})
+    cases.append({"sd": 3, "mode": "bicubic", "padding_mode": "border", "align_corners": False, "norm_coords": True, "dtype": np.float32, "seed": 92})
+    return cases
+
+
+RC_CASES = _rc_cases()
+
+
+def rc_inputs(case):
+    sd = case["sd"]
+    gen = torch.Generator().manual_seed(500 + case["seed"])
+    isp, osp = (7, 8, 9)[:sd], (5, 6, 4)[:sd]
+    img = torch.rand(2, *isp, generator=gen, dtype=torch.float32)
+    half = torch.tensor([(n - 1) / 2.0 for n in isp], dtype=torch.float64).reshape((sd,) + (1,) * sd)
+    u = torch.rand(sd, *osp, generator=gen, dtype=torch.float64) * 2.6 - 1.3          # beyond the field of view on both sides
+    grid = u * half if case["norm_coords"] else u                                      # voxel units centred on the image | [-1, 1]
+    return img, grid
+
+
+def case_resample_compiled_vs_reference(device):
+    """``Resample`` with ``USE_COMPILED`` (array.py:2076-2092) against the REAL reference transform run with its own
+    native module (tests/golden/make_golden_resample_compiled.py).  The native sampler is bit-exact and the coordinate
+    arithmetic is the same fp64 / grid-dtype expression; outputs are float32."""
+    from monai_amd import config
+    from monai_amd.transforms import Resample
+
+    g = np.load(os.path.join(GOLDEN, "resample_compiled.npz"))
+    assert int(g["rc_n"]) == len(RC_CASES)
+    old = config.USE_COMPILED
+    config.USE_COMPILED = True
+    worst = 0.0
+    try:
+        for k, case in enumerate(RC_CASES):
+            img, grid = rc_inputs(case)
+            tr = Resample(mode=case["mode"], padding_mode=case["padding_mode"], norm_coords=case["norm_coords"],
+                          align_corners=case["align_corners"], dtype=case["dtype"])
+            y = tr(img.to(device), grid.to(device)).cpu().numpy()
+            exp = g[f"rc_{k}"]
+            assert y.shape == exp.shape and y.dtype == np.float32, (k, y.shape, exp.shape, y.dtype)
+            err = float(np.abs(y - exp).max())
+            worst = max(worst, err)
+            assert err <= 1e-6, (k, case, err)
+    finally:
+        config.USE_COMPILED = old
+    return worst
+
+
 def case_grid_pull_reference_golden_rows(device):
     """tests/testing_data/1D_BP_fwd.txt (read by tests/testing_data/cpp_resample_answers.py:19-42, used at
     tests/networks/layers/test_grid_pull.py:35-100): input arange(10), grid arange(20)+0.5; rows for orders 0 and 1."""
