@@ -56,9 +56,10 @@ _TARGETS = {
         "grid_grad": ("monai_amd.networks.layers.spatial_transforms", "grid_grad"),
     },
     "monai.networks.layers.simplelayers": {"GaussianFilter": ("monai_amd.networks.layers.simplelayers", "GaussianFilter")},
+    "monai.networks.blocks.warp": {"Warp": ("monai_amd.networks.blocks.warp", "Warp"), "DVF2DDF": ("monai_amd.networks.blocks.warp", "DVF2DDF")},
 }
 # parent packages that re-export the names above
-_REEXPORT = ["monai.inferers", "monai.networks.nets", "monai.transforms", "monai.networks.layers"]
+_REEXPORT = ["monai.inferers", "monai.networks.nets", "monai.transforms", "monai.networks.layers", "monai.networks.blocks"]
 
 _installed: dict = {}
 

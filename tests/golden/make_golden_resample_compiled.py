@@ -20,7 +20,7 @@ sys.modules["monai._C"] = build_ref.load()          # before `import monai`: opt
 sys.path.insert(0, "/root/reference")
 import monai  # noqa: E402
 from monai.transforms import Resample  # noqa: E402
-from transform_cases import RC_CASES, rc_inputs  # noqa: E402
+from transform_cases import RC_CASES, WARP_CASES, rc_inputs, warp_inputs  # noqa: E402
 
 assert monai.config.USE_COMPILED and monai.transforms.spatial.array.USE_COMPILED
 
@@ -34,8 +34,23 @@ def main():
         y = tr(img, grid)
         out[f"rc_{k}"] = np.asarray(y)
     out["rc_n"] = np.asarray(len(RC_CASES))
+    # Warp / DVF2DDF (monai/networks/blocks/warp.py) in both build modes; the module reads USE_COMPILED at call time
+    import warnings
+
+    import monai.networks.blocks.warp as W
+
+    for k, case in enumerate(WARP_CASES):
+        image, ddf = warp_inputs(case)
+        W.USE_COMPILED = bool(case["compiled"])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            layer = W.DVF2DDF(num_steps=3, mode=case["mode"], padding_mode=case["padding_mode"]) if case["dvf"] else W.Warp(mode=case["mode"], padding_mode=case["padding_mode"])
+        y = layer(ddf) if case["dvf"] else layer(image, ddf)
+        out[f"warp_{k}"] = y.detach().numpy()
+    W.USE_COMPILED = True
+    out["warp_n"] = np.asarray(len(WARP_CASES))
     np.savez_compressed(os.path.join(HERE, "resample_compiled.npz"), **out)
-    print("resample_compiled golden:", len(RC_CASES), "cases")
+    print("resample_compiled golden:", len(RC_CASES), "Resample cases,", len(WARP_CASES), "Warp cases")
 
 
 if __name__ == "__main__":

@@ -104,3 +104,7 @@ def test_gaussian_z_chunks(emu):
 
 def test_resample_compiled_vs_reference(emu):
     print("worst error", tc.case_resample_compiled_vs_reference("cpu"))
+
+
+def test_warp_vs_reference(emu):
+    print("worst error by build mode", tc.case_warp_vs_reference("cpu"))

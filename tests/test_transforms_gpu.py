@@ -122,3 +122,7 @@ def test_gaussian_z_chunks():
 
 def test_resample_compiled_vs_reference():
     print("worst error", tc.case_resample_compiled_vs_reference(DEV))
+
+
+def test_warp_vs_reference():
+    print("worst error by build mode", tc.case_warp_vs_reference(DEV))

@@ -430,6 +430,66 @@ def case_resample_compiled_vs_reference(device):
     return worst
 
 
+# ---- Warp / DVF2DDF ---------------------------------------------------------------------------------------------------
+def _warp_cases():
+    cases = []
+    for compiled in (1, 0):
+        for sd in (3, 2):
+            for mode in (("bilinear", "nearest", "bicubic") if compiled else ("bilinear", "nearest")):
+                for pad in ("zeros", "border", "reflection"):
+                    cases.append({"compiled": compiled, "sd": sd, "mode": mode, "padding_mode": pad, "dvf": 0, "seed": len(cases)})
+        cases.append({"compiled": compiled, "sd": 3, "mode": "bilinear", "padding_mode": "zeros", "dvf": 1, "seed": len(cases)})
+    return cases
+
+
+WARP_CASES = _warp_cases()
+
+
+def warp_inputs(case):
+    sd = case["sd"]
+    gen = torch.Generator().manual_seed(700 + case["seed"])
+    sp = (6, 7, 8)[:sd]
+    image = torch.rand(2, 3, *sp, generator=gen, dtype=torch.float32)
+    ddf = (torch.rand(2, sd, *sp, generator=gen, dtype=torch.float32) - 0.5) * (3.0 if case["dvf"] else 6.0)
+    return image, ddf
+
+
+def case_warp_vs_reference(device):
+    """``Warp`` / ``DVF2DDF`` against the reference blocks (tests/golden/make_golden_resample_compiled.py): with USE_COMPILED
+    (native grid_pull: bit-exact sampler) and without (the reference normalises the grid to [-1, 1] in fp32 and lets
+    grid_sample unnormalise it; here the kernel samples at the voxel coordinates directly: <= 2e-5)."""
+    import warnings
+
+    from monai_amd import config
+    from monai_amd.networks.blocks import DVF2DDF, Warp
+
+    g = np.load(os.path.join(GOLDEN, "resample_compiled.npz"))
+    assert int(g["warp_n"]) == len(WARP_CASES)
+    old = config.USE_COMPILED
+    worst = {0: 0.0, 1: 0.0}
+    try:
+        for k, case in enumerate(WARP_CASES):
+            image, ddf = warp_inputs(case)
+            config.USE_COMPILED = bool(case["compiled"])
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                layer = DVF2DDF(num_steps=3, mode=case["mode"], padding_mode=case["padding_mode"]) if case["dvf"] else Warp(mode=case["mode"], padding_mode=case["padding_mode"])
+            y = layer(ddf.to(device)) if case["dvf"] else layer(image.to(device), ddf.to(device))
+            exp = g[f"warp_{k}"]
+            y = y.cpu().numpy()
+            assert y.shape == exp.shape, (k, y.shape, exp.shape)
+            err = float(np.abs(y - exp).max())
+            worst[case["compiled"]] = max(worst[case["compiled"]], err)
+            if case["mode"] == "nearest" and not case["compiled"]:
+                # exact .5 ties can round the other way after the reference's normalise / unnormalise round trip
+                assert float((np.abs(y - exp) > 2e-5).mean()) < 0.02, (k, case)
+            else:
+                assert err <= (0.0 if case["compiled"] else 2e-5), (k, case, err)
+    finally:
+        config.USE_COMPILED = old
+    return worst
+
+
 def case_grid_pull_reference_golden_rows(device):
     """tests/testing_data/1D_BP_fwd.txt (read by tests/testing_data/cpp_resample_answers.py:19-42, used at
     tests/networks/layers/test_grid_pull.py:35-100): input arange(10), grid arange(20)+0.5; rows for orders 0 and 1."""
