@@ -608,14 +608,29 @@ int mh_pushpull(const void* source, const void* grid, const void* target, void* 
     int maxo = 0;
     for (int d = 0; d < ndim; ++d) maxo = a.interp[d] > maxo ? a.interp[d] : maxo;
     const bool pull_only = do_pull && !do_grad;
+    const bool scatter = do_push || do_count;
+    PushPullArgs ag = a;                   // the gathering part of the launch (everything but push / count)
+    ag.do_push = 0; ag.do_count = 0;
+    const bool gather = ag.do_pull || ag.do_sgrad || ag.do_grad;
 #define MH_PP_LAUNCH1(T_, PATH_, NT_, PULL_)                                                                              \
     hipLaunchKernelGGL((pushpull_kernel<T_, PATH_, NT_, PULL_>), dim3(nb), dim3(256), 0, s, static_cast<const T_*>(source), \
-                       static_cast<const T_*>(grid), static_cast<const T_*>(target), static_cast<T_*>(out), static_cast<T_*>(grad), a)
-#define MH_PP_LAUNCH(T_, PATH_, NT_)                         \
-    {                                                        \
-        if (pull_only) MH_PP_LAUNCH1(T_, PATH_, NT_, true);  \
-        else MH_PP_LAUNCH1(T_, PATH_, NT_, false);           \
+                       static_cast<const T_*>(grid), static_cast<const T_*>(target), static_cast<T_*>(out), static_cast<T_*>(grad), ag)
+#define MH_PP_SCATTER(T_, PATH_, NT_)                                                                                        \
+    hipLaunchKernelGGL((pushpull_scatter_kernel<T_, PATH_, NT_>), dim3(nbs), dim3(256), 0, s, static_cast<const T_*>(grid),   \
+                       static_cast<const T_*>(target), static_cast<T_*>(out), a, tx, ty, tz)
+#define MH_PP_LAUNCH(T_, PATH_, NT_)                                    \
+    {                                                                   \
+        if (gather) {                                                   \
+            if (pull_only) MH_PP_LAUNCH1(T_, PATH_, NT_, true);         \
+            else MH_PP_LAUNCH1(T_, PATH_, NT_, false);                  \
+        }                                                               \
+        if (scatter) MH_PP_SCATTER(T_, PATH_, NT_);                     \
     }
+    // scatter modes: a workgroup owns a tile of target voxels (lanes along the last real axis)
+    const int tx = ndim == 3 ? 4 : ndim == 2 ? 16 : 256, ty = ndim == 3 ? 4 : ndim == 2 ? 16 : 1, tz = ndim == 3 ? 16 : 1;
+    const long long nbs_ll = (long long)B * cdiv(Xo, tx) * cdiv(Yo, ty) * cdiv(Zo, tz);
+    if (nbs_ll > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "pushpull: problem too large for one launch");
+    const unsigned nbs = (unsigned)nbs_ll;
 #define MH_PP_PATHS(T_)                                                     \
     if (a.path == PP_NEAREST) MH_PP_LAUNCH(T_, PP_NEAREST, 1)               \
     else if (a.path == PP_LINEAR) MH_PP_LAUNCH(T_, PP_LINEAR, 2)            \
@@ -625,6 +640,7 @@ int mh_pushpull(const void* source, const void* grid, const void* target, void* 
     if (is_f64) { MH_PP_PATHS(double) } else { MH_PP_PATHS(float) }
 #undef MH_PP_PATHS
 #undef MH_PP_LAUNCH
+#undef MH_PP_SCATTER
 #undef MH_PP_LAUNCH1
     return launched("pushpull");
 }

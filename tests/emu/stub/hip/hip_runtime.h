@@ -276,6 +276,8 @@ template <class T, class U> static inline T emu_atomic_add(T* p, T v) {
     } while (!__atomic_compare_exchange_n(q, &old, neu, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return cur;
 }
+static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }     // LDS only: fibers of one block share a host thread
+static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 static inline float unsafeAtomicAdd(float* p, float v) { return emu_atomic_add<float, unsigned int>(p, v); }
 static inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add<double, unsigned long long>(p, v); }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
