@@ -38,10 +38,11 @@ __device__ __forceinline__ long long gp_index(int bound, long long c, long long 
             const long long t = (n + 1) * 2;
             c = c == -1 ? 0 : (c < 0 ? -c - 2 : c);
             c = c % t;
-            return c == n ? n - 1 : (c > n ? t - c - 2 : c);
+            c = c == n ? n - 1 : (c > n ? t - c - 2 : c);
+            return c < 0 ? 0 : c;      // c = 2n + 1 maps to -1 in the reference (a tap whose sign is 0, never read there); keep it loadable
         }
         case GB_DFT: return c < 0 ? (n + c % n) % n : c % n;
-        default: return c;  // zero: the sign masks out-of-bound taps
+        default: return c < 0 ? 0 : (c >= n ? n - 1 : c);  // zero: the sign masks out-of-bound taps; the index stays loadable
     }
 }
 
@@ -69,8 +70,11 @@ __device__ __forceinline__ int gp_sign(int bound, long long c, long long n) {
     }
 }
 
+// Branch-free: every remapped index is inside the volume, so the load is unconditional and the gathers of one voxel can
+// be in flight together (a load guarded by the sign is waited for before the next one is even issued).
 template <typename T> __device__ __forceinline__ T gp_get(const T* p, long long off, int sign) {
-    return sign == -1 ? -p[off] : (sign ? p[off] : (T)0);
+    const T v = p[off];
+    return sign == -1 ? -v : (sign ? v : (T)0);
 }
 
 }  // namespace mh

@@ -280,11 +280,28 @@ __device__ __forceinline__ void pp_generic(const PushPullArgs& a_, const T* __re
         for (int c = 0; c < C; ++c) {
             const T* p = sp + c * ivol;
             T acc = (T)0;
-            MH_PP_ZLOOP
-                MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : nt[1]); ++j) if (NT > 4 || j < nt[1])
-                    MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : nt[0]); ++i) if (NT > 4 || i < nt[0])
-                        acc = acc + gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + iz_, sz_ * sn[1][j] * sn[0][i]) *
-                                        (wt[0][i] * wt[1][j] * wz_);
+            if (NT <= 4) {
+                // the NT x NT gathers of one z tap are issued together, then consumed in the reference's order
+                MH_PP_ZLOOP {
+                    T raw[NT <= 4 ? NT : 1][NT <= 4 ? NT : 1];
+                    MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : 1); ++j)
+                        MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : 1); ++i)
+                            raw[j][i] = p[(i < nt[0] ? it[0][i] : 0) * st[0] + (j < nt[1] ? it[1][j] : 0) * st[1] + iz_];
+                    __builtin_amdgcn_sched_barrier(0);
+                    MH_PP_UNROLL for (int j = 0; j < (NT <= 4 ? NT : 1); ++j) if (j < nt[1])
+                        MH_PP_UNROLL for (int i = 0; i < (NT <= 4 ? NT : 1); ++i) if (i < nt[0]) {
+                            const int s_ = sz_ * sn[1][j] * sn[0][i];
+                            const T v_ = s_ == -1 ? -raw[j][i] : (s_ ? raw[j][i] : (T)0);
+                            acc = acc + v_ * (wt[0][i] * wt[1][j] * wz_);
+                        }
+                }
+            } else {
+                MH_PP_ZLOOP
+                    for (int j = 0; j < nt[1]; ++j)
+                        for (int i = 0; i < nt[0]; ++i)
+                            acc = acc + gp_get(p, it[0][i] * st[0] + it[1][j] * st[1] + iz_, sz_ * sn[1][j] * sn[0][i]) *
+                                            (wt[0][i] * wt[1][j] * wz_);
+            }
             out[(n * C + c) * ovol + o] = acc;
         }
     } else if (a.do_sgrad) {
@@ -489,8 +506,15 @@ pushpull_kernel(const T* __restrict__ src, const T* __restrict__ grid, const T* 
         if (a.do_pull) {
             for (int c = 0; c < C; ++c) {
                 const T* p = sp + c * ivol;
-                T acc = gp_get(p, off[0], sg[0]) * w[0];
-                for (int k = 1; k < ncorner; ++k) acc = acc + gp_get(p, off[k], sg[k]) * w[k];
+                T v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = p[off[k]];      // all eight in flight (padded axes: index 0, loadable)
+                __builtin_amdgcn_sched_barrier(0);                 // keep the loads together: the scheduler otherwise pairs load + use
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = sg[k] == -1 ? -v[k] : (sg[k] ? v[k] : (T)0);
+                T acc = v[0] * w[0];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) if (k < ncorner) acc = acc + v[k] * w[k];
                 out[(n * C + c) * ovol + o] = acc;
             }
         } else if (a.do_sgrad) {

@@ -108,3 +108,7 @@ def test_resample_compiled_vs_reference(emu):
 
 def test_warp_vs_reference(emu):
     print("worst error by build mode", tc.case_warp_vs_reference("cpu"))
+
+
+def test_pushpull_tiny_extents_wide_coordinates(emu):
+    print("cases", tc.case_pushpull_tiny_extents_wide_coordinates("cpu"))

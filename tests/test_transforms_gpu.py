@@ -126,3 +126,7 @@ def test_resample_compiled_vs_reference():
 
 def test_warp_vs_reference():
     print("worst error by build mode", tc.case_warp_vs_reference(DEV))
+
+
+def test_pushpull_tiny_extents_wide_coordinates():
+    print("cases", tc.case_pushpull_tiny_extents_wide_coordinates(DEV))

@@ -303,6 +303,31 @@ def case_pushpull_vs_reference_build(device):
     return worst
 
 
+def case_pushpull_tiny_extents_wide_coordinates(device):
+    """Extents 1-4 per axis and coordinates from -4n to +4n: every branch of every boundary rule, including the taps whose
+    sign is 0 (dst1's index -1, `zero`'s outside indices) -- the gathers load unconditionally, so those indices must stay
+    inside the allocation.  Checked against the reference build when oracle/_ref travelled, else for finiteness only."""
+    from monai_amd import _C
+    from oracle import build_ref
+
+    ref = build_ref.load()
+    gen = torch.Generator().manual_seed(77)
+    n_checked = 0
+    for isp in ((1, 2, 3), (2, 1, 4), (3, 3, 1), (4, 2, 2)):
+        inp = torch.randn(1, 2, *isp, generator=gen, dtype=torch.float64)
+        grid = (torch.rand(1, 6, 5, 7, 3, generator=gen, dtype=torch.float64) * 8.0 - 4.0) * torch.tensor(isp, dtype=torch.float64)
+        for b in (0, 1, 2, 3, 4, 5, 7):
+            for o in (0, 1, 2, 3):
+                got = _C.grid_pull(inp.to(device), grid.to(device), [_C.BoundType(b)], [_C.InterpolationType(o)], True).cpu()
+                sg = _C.grid_grad(inp.to(device), grid.to(device), [_C.BoundType(b)], [_C.InterpolationType(o)], True).cpu()
+                assert torch.isfinite(got).all() and torch.isfinite(sg).all()
+                if ref is not None:
+                    exp = ref.grid_pull(inp, grid, [ref.BoundType(b)], [ref.InterpolationType(o)], True)
+                    assert torch.equal(got, exp), (isp, b, o, float((got - exp).abs().max()))
+                n_checked += 1
+    return n_checked
+
+
 def case_grid_pull_reference_rows_all_orders(device):
     """The reference's own golden rows (tests/testing_data/1D_BP_fwd.txt and 1D_BP_bwd.txt, used by
     tests/networks/layers/test_grid_pull.py:35-100): input arange(10), grid arange(20) + 0.5, every interpolation order
