@@ -82,6 +82,10 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
  * once per configuration. */
 int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W);
 int mh_conv3d_k3_num_configs(void);                    /* highest configuration id */
+/* EXPERIMENTAL configuration outside 0 .. num_configs(): direct implicit GEMM on the bf16 matrix cores in 3-piece split
+ * precision (fp32-equivalent results: every product is evaluated from six exact bf16 piece products with fp32 accumulation);
+ * Cin % 16 == 0, Cout % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0; selected only under MONAI_AMD_CONV_ALGO=split. */
+int mh_conv3d_k3_split_config(void);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 /* w: torch layout [Cout][Cin][3][3][3] */

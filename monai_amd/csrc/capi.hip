@@ -12,6 +12,7 @@
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_winograd.h"
 #include "kernels/conv3d_wino2d.h"
+#include "kernels/conv3d_split.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/pushpull.h"
@@ -165,11 +166,17 @@ static int conv_algo_mode() {
     if (!strcmp(e, "direct")) return 1;
     if (!strcmp(e, "winograd")) return 2;
     if (!strcmp(e, "wino2d")) return 3;
+    if (!strcmp(e, "split")) return 4;
     return 0;
 }
 
 // configuration MH_CFG_WINO2D: Winograd F(2x2, 3x3) in-plane + three direct z taps, z-streaming (kernels/conv3d_wino2d.h)
 #define MH_CFG_WINO2D (MH_NUM_CFG + 2)
+// configuration MH_CFG_SPLIT: direct implicit GEMM on the bf16 matrix cores in 3-piece split precision (kernels/conv3d_split.h);
+// experimental, not counted by mh_conv3d_k3_num_configs, selected only under MONAI_AMD_CONV_ALGO=split
+#define MH_CFG_SPLIT (MH_NUM_CFG + 3)
+// z-tiles (of 4 planes) a workgroup of the split-precision kernel marches through: a pure function of D
+static inline int split_ztiles(int D) { const int t = D / SP_TZ; return t % 4 == 0 ? 4 : t % 3 == 0 ? 3 : t % 2 == 0 ? 2 : 1; }
 // z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
 static inline int wino2d_chunks(int D, int H, int W) {
     const int blocks = cdiv(W, W2_B) * cdiv(H, W2_B);
@@ -188,11 +195,13 @@ static inline int wino2d_zchunk(int D, int H, int W) { return cdiv(D, wino2d_chu
 static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cdiv(H, W2_B) * cdiv(D, wino2d_zchunk(D, H, W)); }
 
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
+int mh_conv3d_k3_split_config(void) { return MH_CFG_SPLIT; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
+    if (cfg == MH_CFG_SPLIT) return Cin >= SP_CC && Cin % SP_CC == 0 && Cin <= SP_NRM_MAX && Cout >= SP_CN && Cout % SP_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -222,12 +231,14 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
         const bool big = H % W2_B == 0 && W % W2_B == 0 && D >= 48 && H >= 48 && W >= 48;
         if (mode == 3 || (mode == 0 && big)) best = MH_CFG_WINO2D;
     }
+    if (mode == 4 && mh_conv3d_k3_accepts(MH_CFG_SPLIT, Cin, Cout) && D % SP_TZ == 0 && H % SP_TY == 0 && W % SP_TX == 0) best = MH_CFG_SPLIT;
     return best;
 }
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
+    if (cfg == MH_CFG_SPLIT) return (int64_t)Cin * Cout * 27 * SP_NP / 2;      // three bf16 pieces per weight
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -245,6 +256,11 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
         hipLaunchKernelGGL(conv3d_k3_wino2d_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
         return launched("conv3d_k3_wino2d_pack");
     }
+    if (cfg == MH_CFG_SPLIT) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the split-precision kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
+        hipLaunchKernelGGL(conv3d_k3_split_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, reinterpret_cast<__bf16*>(packed));
+        return launched("conv3d_k3_split_pack");
+    }
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
     const int cinp = cin_padded(cfg, Cin), coutp = cout_padded(cfg, Cout);
@@ -256,6 +272,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
     if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
+    if (cfg == MH_CFG_SPLIT) return cdiv(W, SP_TX) * cdiv(H, SP_TY) * cdiv(D, SP_TZ * split_ztiles(D));
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -276,9 +293,33 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_CFG_WINO2D) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_SPLIT) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == MH_CFG_SPLIT) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % SP_TZ || in.H % SP_TY || in.W % SP_TX)
+            return fail(MH_ERR_ARG, "conv3d_k3: the split-precision kernel needs Cin %% 16 == 0, Cout %% 32 == 0, D %% 4 == 0, H %% 8 == 0, W %% 8 == 0 (got %d -> %d, %dx%dx%d)",
+                        in.C, out.C, in.D, in.H, in.W);
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
+            return fail(MH_ERR_ARG, "conv3d_k3: the split-precision kernel needs 16-byte aligned output and weights");
+        const int bxn = out.W / SP_TX, byn = out.H / SP_TY;
+        const int zt = split_ztiles(out.D);
+        const unsigned nblk = (unsigned)(bxn * byn * (out.D / (SP_TZ * zt)));
+        const long long total = (long long)nblk * (out.C / SP_CN) * out.N;
+        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
+        const dim3 grid((unsigned)total);
+        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
+#define MH_SPLIT_LAUNCH(T_)                                                                                                                          \
+    {                                                                                                                                                \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_split_kernel<true, true, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_split_kernel<true, false, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_split_kernel<false, true, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);      \
+        else hipLaunchKernelGGL((conv3d_k3_split_kernel<false, false, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);                 \
+    }
+        if (zt == 4) MH_SPLIT_LAUNCH(4) else if (zt == 3) MH_SPLIT_LAUNCH(3) else if (zt == 2) MH_SPLIT_LAUNCH(2) else MH_SPLIT_LAUNCH(1)
+#undef MH_SPLIT_LAUNCH
+        return launched("conv3d_k3_split");
+    }
     if (cfg == MH_CFG_WINO2D) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.H % 2 || in.W % 8)
             return fail(MH_ERR_ARG, "conv3d_k3: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0, even H and W %% 8 == 0 (got %d -> %d, %dx%dx%d)",

@@ -62,6 +62,12 @@ def conv3d_k3_num_configs() -> int:
     return _lib.lib().query("mh_conv3d_k3_num_configs")
 
 
+def conv3d_k3_split_config() -> int:
+    """Id of the experimental split-precision configuration (bf16 matrix cores, three pieces per operand, fp32-equivalent
+    results); outside 1 .. conv3d_k3_num_configs(), selected by conv3d_k3_select only under MONAI_AMD_CONV_ALGO=split."""
+    return _lib.lib().query("mh_conv3d_k3_split_config")
+
+
 def conv3d_k3_accepts(cfg: int, cin: int, cout: int) -> bool:
     return bool(_lib.lib().query("mh_conv3d_k3_accepts", int(cfg), int(cin), int(cout)))
 

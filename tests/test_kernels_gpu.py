@@ -119,3 +119,16 @@ def test_conv3d_wino2d(cin, cout, dims, n):
     assert ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
+
+
+SPLIT_CASES = [(16, 32, (4, 8, 8), 1), (32, 32, (8, 16, 8), 2), (48, 64, (4, 8, 16), 1), (16, 32, (12, 8, 8), 1), (32, 32, (16, 8, 16), 1), (32, 32, (48, 48, 48), 2), (64, 32, (24, 24, 24), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", SPLIT_CASES)
+def test_conv3d_split_precision(cin, cout, dims, n):
+    """Experimental configuration: direct implicit GEMM on the bf16 matrix cores, three bf16 pieces per operand and six
+    exact piece products per multiply with fp32 accumulation -- the same tolerance as the fp32 kernels."""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_split_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
+    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)

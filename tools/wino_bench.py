@@ -47,7 +47,10 @@ for cin, cout, e, direct in LAYERS:
     xn[:, :, 2] = 0.1
     fl = 2.0 * 27 * cin * cout * e ** 3 * B
     row = {"cin": cin, "cout": cout, "edge": e}
-    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d)):
+    split = ops.conv3d_k3_split_config()
+    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d), ("split", split)):
+        if name == "split" and (e % 8 or os.environ.get("WB_SKIP_SPLIT")):
+            continue
         if name == "wino3d" and not os.environ.get("WB_WINO3D"):
             continue
         if not ops.conv3d_k3_accepts(cfg, cin, cout):
