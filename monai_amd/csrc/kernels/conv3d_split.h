@@ -162,13 +162,13 @@ conv3d_k3_split_kernel(Tensor in, const uint4* __restrict__ wp, const float* __r
 #endif
 #if SP_PRODUCTS == 6
 #define MH_SP_TAP(BUF, TI)                                                                                  \
-    {   /* smallest terms first: hi*lo, lo*hi, mid*mid, hi*mid, mid*hi, hi*hi */                            \
-        MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][2]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][2])       \
-        MH_SP_MFMA(acc[TI][0], a0[BUF][2], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][2], bb[BUF][0])       \
-        MH_SP_MFMA(acc[TI][0], a0[BUF][1], bb[BUF][1]) MH_SP_MFMA(acc[TI][1], a1[BUF][1], bb[BUF][1])       \
+    {   /* in the order the pieces arrive from LDS (hi, mid, lo): hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi */ \
+        MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][0])       \
         MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][1]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][1])       \
         MH_SP_MFMA(acc[TI][0], a0[BUF][1], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][1], bb[BUF][0])       \
-        MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][0])       \
+        MH_SP_MFMA(acc[TI][0], a0[BUF][1], bb[BUF][1]) MH_SP_MFMA(acc[TI][1], a1[BUF][1], bb[BUF][1])       \
+        MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][2]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][2])       \
+        MH_SP_MFMA(acc[TI][0], a0[BUF][2], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][2], bb[BUF][0])       \
     }
 #else
 #define MH_SP_TAP(BUF, TI)                                                                                  \
@@ -178,11 +178,20 @@ conv3d_k3_split_kernel(Tensor in, const uint4* __restrict__ wp, const float* __r
         MH_SP_MFMA(acc[TI][0], a0[BUF][0], bb[BUF][0]) MH_SP_MFMA(acc[TI][1], a1[BUF][0], bb[BUF][0])       \
     }
 #endif
+// The operand reads of tap t+1 are INTERLEAVED with the MFMAs of tap t (one read behind each MFMA): issued as a burst in
+// front of them, the 9 reads of the four (barrier-synchronised) waves queue up on the LDS for about as long as the 12 MFMAs
+// take, and an in-order wave cannot start its MFMAs before its last read has been accepted (measured: 820 cycles per tap).
 #define MH_SP_STEP(TAP, TI)                                                                                 \
     {                                                                                                       \
         if ((TAP) + 1 < 27) MH_SP_FETCH(((TAP) + 1) & 1, ((TAP) + 1 < 27 ? (TAP) + 1 : 0))                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                  \
         MH_SP_TAP((TAP) & 1, TI)                                                                            \
+        if ((TAP) + 1 < 27) {                                                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3 * SP_NP; ++i_) {                                      \
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                      \
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      /* one LDS read */                  \
+            }                                                                                               \
+        }                                                                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);             /* the remaining MFMAs */           \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
     // one (tile, chunk): the registers in flight become the LDS tile, the next (tile, chunk) is requested, 27 taps
