@@ -207,9 +207,6 @@ conv3d_k3_split_kernel(Tensor in, const uint4* __restrict__ wp, const float* __r
         __syncthreads();                                                                                    \
         if ((TI) + 1 < T) MH_SP_ISSUE_INPUT(ch, (TI) + 1)                                                   \
         else if (ch + 1 < nchunk) MH_SP_ISSUE_INPUT(ch + 1, 0)                                              \
-        /* compiler-level fence: without it the loads are sunk below the matrix loop, next to their first use (seen in  \
-           the ISA), and their whole latency is exposed once per (tile, chunk) */                           \
-        asm volatile("" ::: "memory");                                                                      \
         MH_SP_FETCH(0, 0)                                                                                   \
         MH_SP_STEP(0, TI) MH_SP_STEP(1, TI) MH_SP_STEP(2, TI) MH_SP_STEP(3, TI) MH_SP_STEP(4, TI) MH_SP_STEP(5, TI)         \
         MH_SP_STEP(6, TI) MH_SP_STEP(7, TI) MH_SP_STEP(8, TI) MH_SP_STEP(9, TI) MH_SP_STEP(10, TI) MH_SP_STEP(11, TI)       \
