@@ -194,19 +194,36 @@ conv3d_k3_split_kernel(Tensor in, const uint4* __restrict__ wp, const float* __r
         __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);             /* the remaining MFMAs */           \
         __builtin_amdgcn_sched_barrier(0);                                                                  \
     }
+    // development-only timing knobs (results become wrong): where do the cycles outside the matrix loop go?
+#ifdef SP_DIAG_NOLOAD
+#define MH_SP_DIAG_LOAD_GUARD if (false)
+#else
+#define MH_SP_DIAG_LOAD_GUARD
+#endif
+#ifdef SP_DIAG_NOCONVERT
+#define MH_SP_DIAG_CONVERT_GUARD(F_) if (ch == 0 && (F_))
+#else
+#define MH_SP_DIAG_CONVERT_GUARD(F_)
+#endif
     // one (tile, chunk): the registers in flight become the LDS tile, the next (tile, chunk) is requested, 27 taps
 #define MH_SP_TILE(TI, FIRST)                                                                               \
     if ((TI) < T) {                                                                                         \
         if (!(FIRST)) __syncthreads();       /* the previous tile's matrix loop is done with xs */          \
         okc = okn;                                                                                          \
-        MH_SP_CONVERT(ch)                                                                                   \
+        MH_SP_DIAG_CONVERT_GUARD(FIRST)                                                                     \
+        {                                                                                                   \
+            MH_SP_CONVERT(ch)                                                                               \
+        }                                                                                                   \
         if (FIRST) {                                                                                        \
             _Pragma("unroll") for (int i = 0; i < NWV; ++i)                                                 \
                 if (tid + 256 * i < SP_NP * SP_WV) ws[tid + 256 * i] = wr[i];                               \
         }                                                                                                   \
         __syncthreads();                                                                                    \
-        if ((TI) + 1 < T) MH_SP_ISSUE_INPUT(ch, (TI) + 1)                                                   \
-        else if (ch + 1 < nchunk) MH_SP_ISSUE_INPUT(ch + 1, 0)                                              \
+        MH_SP_DIAG_LOAD_GUARD                                                                               \
+        {                                                                                                   \
+            if ((TI) + 1 < T) MH_SP_ISSUE_INPUT(ch, (TI) + 1)                                               \
+            else if (ch + 1 < nchunk) MH_SP_ISSUE_INPUT(ch + 1, 0)                                          \
+        }                                                                                                   \
         MH_SP_FETCH(0, 0)                                                                                   \
         MH_SP_STEP(0, TI) MH_SP_STEP(1, TI) MH_SP_STEP(2, TI) MH_SP_STEP(3, TI) MH_SP_STEP(4, TI) MH_SP_STEP(5, TI)         \
         MH_SP_STEP(6, TI) MH_SP_STEP(7, TI) MH_SP_STEP(8, TI) MH_SP_STEP(9, TI) MH_SP_STEP(10, TI) MH_SP_STEP(11, TI)       \
@@ -228,6 +245,8 @@ conv3d_k3_split_kernel(Tensor in, const uint4* __restrict__ wp, const float* __r
         MH_SP_TILE(3, false)
     }
 #undef MH_SP_TILE
+#undef MH_SP_DIAG_LOAD_GUARD
+#undef MH_SP_DIAG_CONVERT_GUARD
 #undef MH_SP_STEP
 #undef MH_SP_TAP
 #undef MH_SP_MFMA
