@@ -68,6 +68,13 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
                     int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
                     int nx, int premultiplied, void* stream);
 
+/* AvgMerger of the PatchInferer family (monai/inferers/merger.py:103-205): one patch, `values[slice] += patch; counts[slice] += 1`
+ * (values / patch [NC][...] fp32 dense, counts uint8 like the reference's default count_dtype; the patch must lie inside the
+ * merged volume), and the final in-place `values /= counts`.  2-D / 1-D problems pad with leading size-1 axes. */
+int mh_patch_accumulate_f32(float* values, uint8_t* counts, const float* patch, int NC, int D, int H, int W, int pd, int ph,
+                            int pw, int z0, int y0, int x0, void* stream);
+int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* stream);
+
 /* ---- network blocks (BasicUNet: monai/networks/nets/basic_unet.py:27-279) -------------------------- */
 
 /* Conv3d k=3, stride 1, padding 1 (+bias) -- the conv of `Convolution`, blocks/convolutions.py:98-171.

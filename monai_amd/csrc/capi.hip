@@ -101,6 +101,25 @@ static void launch_blend(int kt, unsigned nb, hipStream_t s, const float* logits
 #undef MH_BLEND_CASE
 }
 
+int mh_patch_accumulate_f32(float* values, uint8_t* counts, const float* patch, int NC, int D, int H, int W, int pd, int ph, int pw,
+                            int z0, int y0, int x0, void* stream) {
+    if (!values || !counts || !patch) return fail(MH_ERR_ARG, "patch_accumulate: null pointer");
+    if (NC < 1 || D < 1 || H < 1 || W < 1 || pd < 1 || ph < 1 || pw < 1) return fail(MH_ERR_ARG, "patch_accumulate: bad shape");
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + pd > D || y0 + ph > H || x0 + pw > W)
+        return fail(MH_ERR_ARG, "patch_accumulate: the patch (%d,%d,%d)+(%d,%d,%d) leaves the merged volume (%d,%d,%d)", z0, y0, x0, pd, ph, pw, D, H, W);
+    const long long total = (long long)NC * pd * ph * pw;
+    if (total > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "patch_accumulate: problem too large for one launch");
+    hipLaunchKernelGGL(patch_accumulate_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, values, counts, patch, NC, D, H, W, pd, ph, pw, z0, y0, x0);
+    return launched("patch_accumulate");
+}
+
+int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* stream) {
+    if (!values || !counts || n < 1) return fail(MH_ERR_ARG, "avg_finalize: bad argument");
+    if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "avg_finalize: problem too large for one launch");
+    hipLaunchKernelGGL(avg_finalize_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, values, counts, (long long)n);
+    return launched("avg_finalize");
+}
+
 int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
                     const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
     if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "sw_blend: bad argument");

@@ -136,4 +136,27 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
     }
 }
 
+// AvgMerger (monai/inferers/merger.py:103-205): `values[slice] += patch; counts[slice] += 1` for one patch -- the patches
+// of a PatchInferer arrive one by one through a user-visible Merger object, so the accumulation order (= patch order) is
+// the reference's -- and the final `values /= counts`.  One thread per patch element, lanes along x; HBM-bound read-modify-
+// write of the patch footprint (12 B per element + 2 B of counts).
+__global__ void __launch_bounds__(256)
+patch_accumulate_kernel(float* __restrict__ values, unsigned char* __restrict__ counts, const float* __restrict__ patch, int NC, int D, int H, int W,
+                        int pd, int ph, int pw, int z0, int y0, int x0) {
+    const long long pvol = (long long)pd * ph * pw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= pvol * NC) return;
+    const long long c = idx / pvol, r = idx - c * pvol;
+    const int x = (int)(r % pw), y = (int)((r / pw) % ph), z = (int)(r / ((long long)pw * ph));
+    const long long o = ((c * D + (z0 + z)) * H + (y0 + y)) * W + (x0 + x);
+    values[o] += patch[idx];
+    counts[o] = (unsigned char)(counts[o] + 1);
+}
+
+__global__ void __launch_bounds__(256)
+avg_finalize_kernel(float* __restrict__ values, const unsigned char* __restrict__ counts, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) values[i] = values[i] / (float)counts[i];
+}
+
 }  // namespace mh

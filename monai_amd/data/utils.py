@@ -183,3 +183,21 @@ def compute_shape_offset(spatial_shape, in_affine, out_affine, scale_extent: boo
         in_offset = np.append(0.5 * (shape / out_shape - 1.0), 1.0)
         offset = np.abs((ia @ in_offset / in_offset[-1])[:-1]) * np.sign(offset)
     return out_shape.astype(int, copy=False), offset
+
+
+def iter_patch_position(image_size, patch_size, start_pos=(), overlap=0.0, padded: bool = False):
+    """Upper-left corners of the patches of a regular grid, row-major (monai/data/utils.py:209-254): step = round(patch *
+    (1 - overlap)) for a float overlap, patch - overlap for an int one; the last start is image - patch unless `padded`."""
+    from itertools import product, starmap
+
+    ndim = len(image_size)
+    patch_size_ = get_valid_patch_size(image_size, patch_size)
+    start_pos = tuple(start_pos) + (0,) * (ndim - len(tuple(start_pos)))
+    start_pos = start_pos[:ndim]
+    overlap = ensure_tuple_rep(overlap, ndim)
+    if isinstance(overlap[0], float):
+        steps = tuple(round(p * (1.0 - o)) for p, o in zip(patch_size_, overlap))
+    else:
+        steps = tuple(p - o for p, o in zip(patch_size_, overlap))
+    end_pos = image_size if padded else tuple(s - round(p) + 1 for s, p in zip(image_size, patch_size_))
+    return product(*starmap(range, zip(start_pos, end_pos, steps)))

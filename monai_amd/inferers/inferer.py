@@ -11,6 +11,8 @@ import torch
 
 from ..data.utils import compute_importance_map
 from ..utils.misc import ensure_tuple, look_up_option
+from .merger import AvgMerger, Merger
+from .splitter import Splitter
 from .utils import sliding_window_inference
 
 __all__ = ["Inferer", "SlidingWindowInferer", "SlidingWindowInfererAdapt", "SliceInferer"]
@@ -22,6 +24,160 @@ class Inferer(ABC):
     @abstractmethod
     def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any) -> Any:
         raise NotImplementedError(f"Subclass {self.__class__.__name__} must implement this method.")
+
+
+class PatchInferer(Inferer):
+    """Inference on patches: ``splitter`` -> batches of patches -> ``network`` -> one ``Merger`` per output.  Drop-in for
+    monai/inferers/inferer.py:100-370 with the same arguments; ``buffer_size`` (a prefetch thread in the reference) is
+    accepted and has no effect here -- the patches are views of a tensor that is already in HBM."""
+
+    def __init__(
+        self,
+        splitter: Splitter | None = None,
+        merger_cls: type[Merger] | str = AvgMerger,
+        batch_size: int = 1,
+        preprocessing: Callable | None = None,
+        postprocessing: Callable | None = None,
+        output_keys: Sequence | None = None,
+        match_spatial_shape: bool = True,
+        buffer_size: int = 0,
+        **merger_kwargs: Any,
+    ) -> None:
+        Inferer.__init__(self)
+        if not isinstance(splitter, (Splitter, type(None))):
+            raise TypeError(
+                "'splitter' should be a `Splitter` object that returns: "
+                "an iterable of pairs of (patch, location) or a MetaTensor that has `PatchKeys.LOCATION` metadata)."
+                f"{type(splitter)} is given."
+            )
+        self.splitter = splitter
+        if isinstance(merger_cls, str):
+            from pydoc import locate
+
+            from . import merger as _merger_mod
+
+            found = getattr(_merger_mod, merger_cls, None) or locate(merger_cls)
+            if found is None:
+                raise ValueError(f"The requested `merger_cls` ['{merger_cls}'] does not exist.")
+            merger_cls = found
+        if not (isinstance(merger_cls, type) and issubclass(merger_cls, Merger)):
+            raise TypeError(f"'merger' should be a subclass of `Merger`, {merger_cls} is given.")
+        self.merger_cls = merger_cls
+        self.merger_kwargs = merger_kwargs
+        if preprocessing is not None and not callable(preprocessing):
+            raise TypeError(f"'preprocessing' should be a callable object, {type(preprocessing)} is given.")
+        self.preprocessing = preprocessing
+        if postprocessing is not None and not callable(postprocessing):
+            raise TypeError(f"'postprocessing' should be a callable object, {type(postprocessing)} is given.")
+        self.postprocessing = postprocessing
+        if batch_size < 1:
+            raise ValueError(f"`batch_size` must be a positive number, {batch_size} is given.")
+        self.batch_size = batch_size
+        self.output_keys = output_keys
+        self.match_spatial_shape = match_spatial_shape
+        self.buffer_size = buffer_size
+
+    def _batch_sampler(self, patches):
+        """(batch of patches, their locations, number of patches in the batch)."""
+        if hasattr(patches, "meta") and isinstance(patches, torch.Tensor):     # MetaTensor of already split patches
+            total = len(patches)
+            for i in range(0, total, self.batch_size):
+                n = min(self.batch_size, total - i)
+                yield patches[i : i + n], patches[i : i + n].meta["location"], n
+            return
+        batch, locs = [], []
+        for patch, loc in patches:
+            batch.append(patch)
+            locs.append(loc)
+            if len(batch) == self.batch_size:
+                yield torch.cat(batch), locs, len(batch)
+                batch, locs = [], []
+        if batch:
+            yield torch.cat(batch), locs, len(batch)
+
+    def _ensure_tuple_outputs(self, outputs: Any) -> tuple:
+        if isinstance(outputs, dict):
+            if self.output_keys is None:
+                self.output_keys = list(outputs.keys())
+            return tuple(outputs[k] for k in self.output_keys)
+        return tuple(outputs) if isinstance(outputs, (list, tuple)) else (outputs,)
+
+    def _run_inference(self, network: Callable, patch: torch.Tensor, *args: Any, **kwargs: Any) -> tuple:
+        if self.preprocessing:
+            patch = self.preprocessing(patch)
+        outputs = network(patch, *args, **kwargs)
+        if self.postprocessing:
+            outputs = self.postprocessing(outputs)
+        return self._ensure_tuple_outputs(outputs)
+
+    def _get_merged_shapes(self, inputs, out_patch, ratio):
+        if self.splitter is None:
+            return None, None
+        original = self.splitter.get_input_shape(inputs)
+        padded = self.splitter.get_padded_shape(inputs)
+        cropped_shape = tuple(out_patch.shape[:2]) + tuple(round(s * r) for s, r in zip(original, ratio))
+        merged_shape = tuple(out_patch.shape[:2]) + tuple(round(s * r) for s, r in zip(padded, ratio))
+        if not self.match_spatial_shape:
+            cropped_shape = merged_shape
+        return cropped_shape, merged_shape
+
+    def _initialize_mergers(self, inputs, outputs, patches, batch_size):
+        in_patch = torch.chunk(patches, batch_size)[0]
+        mergers, ratios = [], []
+        for out_patch_batch in outputs:
+            out_patch = torch.chunk(out_patch_batch, batch_size)[0]
+            ratio = tuple(op / ip for ip, op in zip(in_patch.shape[2:], out_patch.shape[2:]))
+            merger_kwargs = self.merger_kwargs.copy()
+            cropped_shape, merged_shape = self._get_merged_shapes(inputs, out_patch, ratio)
+            if "merged_shape" not in merger_kwargs:
+                merger_kwargs["merged_shape"] = merged_shape
+                if merger_kwargs["merged_shape"] is None:
+                    raise ValueError("`merged_shape` cannot be `None`.")
+            if "cropped_shape" not in merger_kwargs:
+                merger_kwargs["cropped_shape"] = cropped_shape
+            mergers.append(self.merger_cls(**merger_kwargs))
+            ratios.append(ratio)
+        return mergers, ratios
+
+    def _aggregate(self, outputs, locations, batch_size, mergers, ratios):
+        for output_patches, merger, ratio in zip(outputs, mergers, ratios):
+            for in_loc, out_patch in zip(locations, torch.chunk(output_patches, batch_size)):
+                merger.aggregate(out_patch, [round(l * r) for l, r in zip(in_loc, ratio)])
+
+    def __call__(self, inputs, network: Callable, *args: Any, **kwargs: Any) -> Any:
+        if self.splitter is None:
+            if isinstance(inputs, torch.Tensor):
+                if hasattr(inputs, "meta"):
+                    if "location" not in inputs.meta:
+                        raise ValueError(
+                            "`PatchKey.LOCATION` does not exists in `inputs.meta`. "
+                            "If the inputs are already split into patches, the location of patches needs to be "
+                            "provided as `PatchKey.LOCATION` metadata in a MetaTensor. "
+                            "If the input is not already split, please provide `splitter`."
+                        )
+                else:
+                    raise ValueError(
+                        "`splitter` should be set if the input is not already split into patches. "
+                        "For inputs that are split, the location of patches needs to be provided as "
+                        "(image, location) pairs, or as `PatchKey.LOCATION` metadata in a MetaTensor. "
+                        f"The provided inputs type is {type(inputs)}."
+                    )
+            patches_locations = inputs
+        else:
+            patches_locations = self.splitter(inputs)
+        ratios: list = []
+        mergers: list = []
+        for patches, locations, batch_size in self._batch_sampler(patches_locations):
+            outputs = self._run_inference(network, patches, *args, **kwargs)
+            if not mergers:
+                mergers, ratios = self._initialize_mergers(inputs, outputs, patches, batch_size)
+            self._aggregate(outputs, locations, batch_size, mergers, ratios)
+        merged_outputs = [merger.finalize() for merger in mergers]
+        if self.output_keys:
+            return dict(zip(self.output_keys, merged_outputs))
+        if len(merged_outputs) == 1:
+            return merged_outputs[0]
+        return merged_outputs
 
 
 class SlidingWindowInferer(Inferer):

@@ -53,6 +53,34 @@ def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: G
     return out
 
 
+def patch_accumulate(values: torch.Tensor, counts: torch.Tensor, patch: torch.Tensor, location: Sequence[int]) -> None:
+    """AvgMerger.aggregate: values[..., loc:loc+size] += patch; counts[...] += 1 (values / patch fp32 [B, C, spatial 1-3],
+    counts uint8 of the same shape as values)."""
+    _lib.require_device(values, patch)
+    _lib.require_device(counts, dtypes=(torch.uint8,))
+    if not (values.is_contiguous() and counts.is_contiguous() and patch.is_contiguous()):
+        raise RuntimeError("monai_amd.patch_accumulate: contiguous tensors required")
+    sd = values.dim() - 2
+    if sd < 1 or sd > 3 or patch.dim() != values.dim() or tuple(patch.shape[:2]) != tuple(values.shape[:2]) or counts.shape != values.shape:
+        raise RuntimeError(f"monai_amd.patch_accumulate: shapes {tuple(values.shape)} / {tuple(counts.shape)} / {tuple(patch.shape)} do not match")
+    pad = 3 - sd
+    v3 = [1] * pad + [int(v) for v in values.shape[2:]]
+    p3 = [1] * pad + [int(v) for v in patch.shape[2:]]
+    l3 = [0] * pad + [int(v) for v in location]
+    _lib.lib().call("mh_patch_accumulate_f32", _lib.ptr(values), _lib.ptr(counts), _lib.ptr(patch), int(values.shape[0] * values.shape[1]),
+                    *v3, *p3, *l3, _s(values))
+
+
+def avg_finalize(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """AvgMerger.finalize: values /= counts, in place."""
+    _lib.require_device(values)
+    _lib.require_device(counts, dtypes=(torch.uint8,))
+    if not (values.is_contiguous() and counts.is_contiguous()) or counts.shape != values.shape:
+        raise RuntimeError("monai_amd.avg_finalize: contiguous tensors of one shape required")
+    _lib.lib().call("mh_avg_finalize_f32", _lib.ptr(values), _lib.ptr(counts), int(values.numel()), _s(values))
+    return values
+
+
 def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv3d_k3_select", cin, cout, d, h, w)
 

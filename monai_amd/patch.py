@@ -22,7 +22,13 @@ _TARGETS = {
         "SlidingWindowInferer": ("monai_amd.inferers.inferer", "SlidingWindowInferer"),
         "SlidingWindowInfererAdapt": ("monai_amd.inferers.inferer", "SlidingWindowInfererAdapt"),
         "SliceInferer": ("monai_amd.inferers.inferer", "SliceInferer"),
+        "PatchInferer": ("monai_amd.inferers.inferer", "PatchInferer"),
     },
+    "monai.inferers.splitter": {
+        "Splitter": ("monai_amd.inferers.splitter", "Splitter"),
+        "SlidingWindowSplitter": ("monai_amd.inferers.splitter", "SlidingWindowSplitter"),
+    },
+    "monai.inferers.merger": {"Merger": ("monai_amd.inferers.merger", "Merger"), "AvgMerger": ("monai_amd.inferers.merger", "AvgMerger")},
     "monai.inferers.utils": {"sliding_window_inference": ("monai_amd.inferers.utils", "sliding_window_inference")},
     "monai.networks.nets.basic_unet": {
         "BasicUNet": ("monai_amd.networks.nets.basic_unet", "BasicUNet"),

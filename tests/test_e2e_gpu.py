@@ -168,3 +168,10 @@ def test_process_fn_bitwise_vs_reference():
 
 def test_slabwise_equals_whole():
     print(ec.case_slabwise_equals_whole(DEV))
+
+
+def test_patch_inferer_vs_reference():
+    import patch_cases as pc
+
+    print("cases", pc.case_patch_inferer_vs_reference(DEV))
+    pc.case_patch_inferer_api(DEV)

@@ -93,3 +93,15 @@ def test_slice_inferer_and_adapt(emu):
         SliceInferer(roi_size=(4, 4, 4), spatial_dim=0)(x, lambda s: s)
     r = SlidingWindowInfererAdapt((8, 8, 8), 2, overlap=0.25)(x, lambda s: s + 1)
     np.testing.assert_allclose(r.numpy(), x.numpy() + 1, rtol=1e-6)
+
+
+def test_patch_inferer_vs_reference(emu):
+    import patch_cases as pc
+
+    print("cases", pc.case_patch_inferer_vs_reference("cpu"))
+
+
+def test_patch_inferer_api(emu):
+    import patch_cases as pc
+
+    pc.case_patch_inferer_api("cpu")
