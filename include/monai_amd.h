@@ -205,6 +205,16 @@ int mh_pushpull(const void* source, const void* grid, const void* target, void* 
                 int C, int X, int Y, int Z, int Xo, int Yo, int Zo, const int32_t* bound3, const int32_t* interp3,
                 int extrapolate, int do_pull, int do_push, int do_count, int do_grad, int do_sgrad, int target_k, void* stream);
 
+/* ---- post-processing (Activations / AsDiscrete, monai/transforms/post/array.py:61-237) ----------------------- */
+
+/* element-wise: op 0 = sigmoid, 1 = (x >= param) as 0/1, 2 = round half to even (torch.round) */
+int mh_pointwise_f32(int op, const float* src, float* dst, int64_t n, float param, void* stream);
+/* over the channel axis of a channel-first tensor [C][n]: op 0 = argmax (first maximal index, NaN maximal; written as
+ * float into dst[n]), 1 = softmax (dst [C][n]) */
+int mh_channel_reduce_f32(int op, const float* src, float* dst, int C, int64_t n, void* stream);
+/* one_hot (monai/networks/utils.py:170-221): float labels [n] -> dst [K][n] of 0/1 */
+int mh_onehot_f32(const float* labels, float* dst, int K, int64_t n, void* stream);
+
 /* ---- Gaussian smoothing (GaussianSmooth / GaussianFilter / separable_filtering) ----------------------------- */
 
 /* dst = src convolved with kz (x) ky (x) kx, zero padding, per channel volume [NC][D][H][W]

@@ -46,6 +46,9 @@ SIGNATURES = {
     "mh_window_extract_f32": (_I, [_P, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mh_patch_accumulate_f32": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "mh_avg_finalize_f32": (_I, [_P, _P, C.c_int64, _P]),
+    "mh_pointwise_f32": (_I, [_I, _P, _P, _L, _F, _P]),
+    "mh_channel_reduce_f32": (_I, [_I, _P, _P, _I, _L, _P]),
+    "mh_onehot_f32": (_I, [_P, _P, _I, _L, _P]),
     "mh_sw_blend_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I]),
     "mh_conv3d_k3_split_config": (_I, []),

@@ -16,6 +16,7 @@
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/pushpull.h"
+#include "kernels/post.h"
 #include "kernels/nn_simple.h"
 #include "kernels/resample.h"
 #include "kernels/sliding.h"
@@ -703,6 +704,29 @@ int mh_pushpull(const void* source, const void* grid, const void* target, void* 
 #undef MH_PP_SCATTER
 #undef MH_PP_LAUNCH1
     return launched("pushpull");
+}
+
+// ------------------------------------------------------------------------------------------ post-processing (Activations / AsDiscrete)
+int mh_pointwise_f32(int op, const float* src, float* dst, int64_t n, float param, void* stream) {
+    if (!src || !dst || n < 1 || op < 0 || op > PW_ROUND) return fail(MH_ERR_ARG, "pointwise: bad argument");
+    if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "pointwise: problem too large for one launch");
+    hipLaunchKernelGGL(pointwise_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, op, param);
+    return launched("pointwise");
+}
+
+int mh_channel_reduce_f32(int op, const float* src, float* dst, int C, int64_t n, void* stream) {
+    if (!src || !dst || C < 1 || n < 1 || (op != CR_ARGMAX && op != CR_SOFTMAX)) return fail(MH_ERR_ARG, "channel_reduce: bad argument");
+    if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "channel_reduce: problem too large for one launch");
+    if (op == CR_ARGMAX) hipLaunchKernelGGL(channel_argmax_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, (long long)n);
+    else hipLaunchKernelGGL(channel_softmax_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, C, (long long)n);
+    return launched("channel_reduce");
+}
+
+int mh_onehot_f32(const float* labels, float* dst, int K, int64_t n, void* stream) {
+    if (!labels || !dst || K < 1 || n < 1) return fail(MH_ERR_ARG, "onehot: bad argument");
+    if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "onehot: problem too large for one launch");
+    hipLaunchKernelGGL(onehot_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, labels, dst, K, (long long)n);
+    return launched("onehot");
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian smoothing

@@ -53,6 +53,41 @@ def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: G
     return out
 
 
+def pointwise(op: str, src: torch.Tensor, param: float = 0.0) -> torch.Tensor:
+    """sigmoid | threshold (x >= param -> 0/1) | round (half to even) on a contiguous fp32 tensor."""
+    _lib.require_device(src)
+    if not src.is_contiguous():
+        raise RuntimeError("monai_amd.pointwise: contiguous tensor required")
+    out = torch.empty_like(src)
+    if src.numel():
+        _lib.lib().call("mh_pointwise_f32", {"sigmoid": 0, "threshold": 1, "round": 2}[op], _lib.ptr(src), _lib.ptr(out), int(src.numel()), float(param), _s(src))
+    return out
+
+
+def channel_reduce(op: str, src: torch.Tensor) -> torch.Tensor:
+    """argmax (-> [1, spatial] float) | softmax (-> like src) over axis 0 of a contiguous channel-first fp32 tensor."""
+    _lib.require_device(src)
+    if not src.is_contiguous() or src.dim() < 1:
+        raise RuntimeError("monai_amd.channel_reduce: contiguous channel-first tensor required")
+    c = int(src.shape[0])
+    n = int(src.numel() // max(c, 1))
+    out = torch.empty((1,) + tuple(src.shape[1:]), dtype=torch.float32, device=src.device) if op == "argmax" else torch.empty_like(src)
+    if n:
+        _lib.lib().call("mh_channel_reduce_f32", {"argmax": 0, "softmax": 1}[op], _lib.ptr(src), _lib.ptr(out), c, n, _s(src))
+    return out
+
+
+def onehot(labels: torch.Tensor, num_classes: int) -> torch.Tensor:
+    """labels [1, spatial] fp32 -> [num_classes, spatial] fp32 of 0 / 1."""
+    _lib.require_device(labels)
+    if not labels.is_contiguous() or labels.shape[0] != 1:
+        raise RuntimeError("monai_amd.onehot: contiguous [1, spatial] tensor required")
+    out = torch.empty((int(num_classes),) + tuple(labels.shape[1:]), dtype=torch.float32, device=labels.device)
+    if labels.numel():
+        _lib.lib().call("mh_onehot_f32", _lib.ptr(labels), _lib.ptr(out), int(num_classes), int(labels.numel()), _s(labels))
+    return out
+
+
 def patch_accumulate(values: torch.Tensor, counts: torch.Tensor, patch: torch.Tensor, location: Sequence[int]) -> None:
     """AvgMerger.aggregate: values[..., loc:loc+size] += patch; counts[...] += 1 (values / patch fp32 [B, C, spatial 1-3],
     counts uint8 of the same shape as values)."""

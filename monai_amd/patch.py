@@ -49,6 +49,18 @@ _TARGETS = {
         "SpacingDict": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
     },
     "monai.transforms.intensity.array": {"GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth")},
+    "monai.transforms.post.array": {
+        "Activations": ("monai_amd.transforms.post.array", "Activations"),
+        "AsDiscrete": ("monai_amd.transforms.post.array", "AsDiscrete"),
+    },
+    "monai.transforms.post.dictionary": {
+        "Activationsd": ("monai_amd.transforms.post.dictionary", "Activationsd"),
+        "ActivationsD": ("monai_amd.transforms.post.dictionary", "Activationsd"),
+        "ActivationsDict": ("monai_amd.transforms.post.dictionary", "Activationsd"),
+        "AsDiscreted": ("monai_amd.transforms.post.dictionary", "AsDiscreted"),
+        "AsDiscreteD": ("monai_amd.transforms.post.dictionary", "AsDiscreted"),
+        "AsDiscreteDict": ("monai_amd.transforms.post.dictionary", "AsDiscreted"),
+    },
     "monai.transforms.intensity.dictionary": {
         "GaussianSmoothd": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
         "GaussianSmoothD": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),

@@ -112,3 +112,15 @@ def test_warp_vs_reference(emu):
 
 def test_pushpull_tiny_extents_wide_coordinates(emu):
     print("cases", tc.case_pushpull_tiny_extents_wide_coordinates("cpu"))
+
+
+def test_post_transforms_vs_reference(emu):
+    import post_cases as pc
+
+    print("arrays", pc.case_post_transforms_vs_reference("cpu"))
+
+
+def test_post_transforms_api(emu):
+    import post_cases as pc
+
+    pc.case_post_transforms_api("cpu")

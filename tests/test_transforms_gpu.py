@@ -130,3 +130,10 @@ def test_warp_vs_reference():
 
 def test_pushpull_tiny_extents_wide_coordinates():
     print("cases", tc.case_pushpull_tiny_extents_wide_coordinates(DEV))
+
+
+def test_post_transforms_vs_reference():
+    import post_cases as pc
+
+    print("arrays", pc.case_post_transforms_vs_reference(DEV))
+    pc.case_post_transforms_api(DEV)
