@@ -48,3 +48,9 @@ def test_single_window_with_split_precision_convolutions(emu, monkeypatch):
     multiply) keeps the end-to-end logits within the same 1e-4 bound of the reference golden window."""
     monkeypatch.setenv("MONAI_AMD_CONV_ALGO", "split")
     print(ec.case_net_single_window_vs_golden("cpu"))
+
+
+def test_bundle_shaped_pipeline_vs_reference(emu):
+    import pipeline_case as pl
+
+    print(pl.case_pipeline_vs_reference("cpu"))

@@ -175,3 +175,9 @@ def test_patch_inferer_vs_reference():
 
     print("cases", pc.case_patch_inferer_vs_reference(DEV))
     pc.case_patch_inferer_api(DEV)
+
+
+def test_bundle_shaped_pipeline_vs_reference():
+    import pipeline_case as pl
+
+    print(pl.case_pipeline_vs_reference(DEV))
