@@ -215,6 +215,24 @@ int mh_channel_reduce_f32(int op, const float* src, float* dst, int C, int64_t n
 /* one_hot (monai/networks/utils.py:170-221): float labels [n] -> dst [K][n] of 0/1 */
 int mh_onehot_f32(const float* labels, float* dst, int K, int64_t n, void* stream);
 
+/* ---- pre-processing in front of the path ------------------------------------------------- */
+
+/* ScaleIntensityRange (monai/transforms/intensity/array.py:958-1012):
+ *   y = (x - a_min) / a_div;  if (rescale) y = y * b_scale + b_min;  if (clip_lo) y = max(y, lo);  if (clip_hi) y = min(y, hi)
+ * with the reference's roundings (true division, separate multiply and add; NaN passes the clamp like torch.clamp).
+ * The a_min == a_max branch of the reference (no division) is a_div = 1, b_scale = 1 by the host side. */
+int mh_scale_intensity_range_f32(const float* src, float* dst, int64_t n, float a_min, float a_div, int rescale, float b_scale, float b_min,
+                                 int clip_lo, float lo, int clip_hi, float hi, void* stream);
+/* generate_spatial_bounding_box with the default select_fn (monai/transforms/utils.py:1069-1129): box6 (DEVICE int32[6]) =
+ * {zmin, ymin, xmin, zmax, ymax, xmax} (inclusive) of the voxels of src [C][D][H][W] where any channel is > 0; zmax == -1
+ * when there is no foreground.  workspace: DEVICE int32[mh_foreground_bbox_workspace_ints(D, H)], caller-owned. */
+int mh_foreground_bbox_workspace_ints(int D, int H);
+int mh_foreground_bbox_f32(const float* src, int C, int D, int H, int W, int32_t* workspace, int32_t* box6, void* stream);
+/* CropForeground.crop_pad (monai/transforms/croppad/array.py:884-927), constant mode: dst [C][Do][Ho][Wo],
+ * dst[c][z][y][x] = src[c][z+sz][y+sy][x+sx] inside src [C][D][H][W], `value` outside (starts may be negative). */
+int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, int Do, int Ho, int Wo, int sz, int sy, int sx, float value,
+                    void* stream);
+
 /* ---- Gaussian smoothing (GaussianSmooth / GaussianFilter / separable_filtering) ----------------------------- */
 
 /* dst = src convolved with kz (x) ky (x) kx, zero padding, per channel volume [NC][D][H][W]

@@ -49,6 +49,10 @@ SIGNATURES = {
     "mh_pointwise_f32": (_I, [_I, _P, _P, _L, _F, _P]),
     "mh_channel_reduce_f32": (_I, [_I, _P, _P, _I, _L, _P]),
     "mh_onehot_f32": (_I, [_P, _P, _I, _L, _P]),
+    "mh_scale_intensity_range_f32": (_I, [_P, _P, _L, _F, _F, _I, _F, _F, _I, _F, _I, _F, _P]),
+    "mh_foreground_bbox_workspace_ints": (_I, [_I, _I]),
+    "mh_foreground_bbox_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mh_crop_pad_f32": (_I, [_P, _P] + [_I] * 10 + [_F, _P]),
     "mh_sw_blend_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I]),
     "mh_conv3d_k3_split_config": (_I, []),

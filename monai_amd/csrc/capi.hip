@@ -17,6 +17,7 @@
 #include "kernels/grid_pull.h"
 #include "kernels/pushpull.h"
 #include "kernels/post.h"
+#include "kernels/preproc.h"
 #include "kernels/nn_simple.h"
 #include "kernels/resample.h"
 #include "kernels/sliding.h"
@@ -727,6 +728,49 @@ int mh_onehot_f32(const float* labels, float* dst, int K, int64_t n, void* strea
     if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "onehot: problem too large for one launch");
     hipLaunchKernelGGL(onehot_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, labels, dst, K, (long long)n);
     return launched("onehot");
+}
+
+// ------------------------------------------------------------------------------------------ pre-processing (ScaleIntensityRange / CropForeground)
+int mh_scale_intensity_range_f32(const float* src, float* dst, int64_t n, float a_min, float a_div, int rescale, float b_scale, float b_min,
+                                 int clip_lo, float lo, int clip_hi, float hi, void* stream) {
+    if (!src || !dst || n < 1) return fail(MH_ERR_ARG, "scale_intensity_range: bad argument");
+    if (n > 0x7fffffffLL * 1024) return fail(MH_ERR_UNSUPPORTED, "scale_intensity_range: problem too large for one launch");
+    ScaleRange p;
+    p.a_min = a_min; p.div = a_div; p.b_scale = b_scale; p.b_min = b_min; p.lo = lo; p.hi = hi;
+    p.rescale = rescale != 0; p.clip_lo = clip_lo != 0; p.clip_hi = clip_hi != 0;
+    const dim3 grid(blocks_for((n + 3) / 4));
+    if (aligned(src, 16) && aligned(dst, 16))
+        hipLaunchKernelGGL(scale_range_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, p);
+    else
+        hipLaunchKernelGGL(scale_range_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, p);
+    return launched("scale_intensity_range");
+}
+
+int mh_foreground_bbox_workspace_ints(int D, int H) {
+    if (D < 1 || H < 1) return fail(MH_ERR_ARG, "foreground_bbox: bad argument");
+    const long long groups = ((long long)D * H + 3) / 4;
+    return 6 * (int)(groups < 2048 ? groups : 2048);
+}
+
+int mh_foreground_bbox_f32(const float* src, int C, int D, int H, int W, int32_t* workspace, int32_t* box6, void* stream) {
+    if (!src || !workspace || !box6 || C < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "foreground_bbox: bad argument");
+    const int parts = mh_foreground_bbox_workspace_ints(D, H) / 6;
+    if (W % 4 == 0 && aligned(src, 16) && ((long long)D * H * W) % 4 == 0)
+        hipLaunchKernelGGL(bbox_partial_kernel<true>, dim3(parts), dim3(256), 0, (hipStream_t)stream, src, C, D, H, W, workspace);
+    else
+        hipLaunchKernelGGL(bbox_partial_kernel<false>, dim3(parts), dim3(256), 0, (hipStream_t)stream, src, C, D, H, W, workspace);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, parts, box6);
+    return launched("foreground_bbox");
+}
+
+int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, int Do, int Ho, int Wo, int sz, int sy, int sx, float value,
+                    void* stream) {
+    if (!src || !dst || C < 1 || D < 1 || H < 1 || W < 1 || Do < 1 || Ho < 1 || Wo < 1) return fail(MH_ERR_ARG, "crop_pad: bad argument");
+    const long long rows = (long long)C * Do * Ho;
+    if (rows > 0x7fffffffLL || (Wo + 255) / 256 > 65535) return fail(MH_ERR_UNSUPPORTED, "crop_pad: problem too large for one launch");
+    hipLaunchKernelGGL(crop_pad_kernel, dim3((unsigned)rows, (unsigned)((Wo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W, Do,
+                       Ho, Wo, sz, sy, sx, value);
+    return launched("crop_pad");
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian smoothing

@@ -1,0 +1,121 @@
+// Intensity / crop pre-processing in front of the sliding-window path: ScaleIntensityRange
+// (monai/transforms/intensity/array.py:958-1012), the foreground bounding box of CropForeground
+// (generate_spatial_bounding_box, monai/transforms/utils.py:1069-1129) and its crop + constant pad
+// (monai/transforms/croppad/array.py:776-960).  Channel-first fp32 volumes [C][D][H][W], lanes along W.
+// All three are HBM-bound: scale reads 4 B + writes 4 B per voxel, the box reads C x 4 B per voxel and writes 24 B per
+// workgroup, crop+pad reads <= 4 B and writes 4 B per output voxel.
+#pragma once
+#include "common.h"
+
+namespace mh {
+
+// y = (x - a_min) / div [ * b_scale + b_min ] [ clamp ]: the reference's operator sequence with every rounding kept
+// (true division, separate multiply and add: the library is built with -ffp-contract=off); NaN passes through the clamp
+// like torch.clamp.  VEC: 16-byte loads / stores, four voxels per lane.
+struct ScaleRange {
+    float a_min, div, b_scale, b_min, lo, hi;
+    int rescale, clip_lo, clip_hi;
+};
+__device__ __forceinline__ float scale_range_one(float x, const ScaleRange& p) {
+    float v = (x - p.a_min) / p.div;
+    if (p.rescale) { v = v * p.b_scale; v = v + p.b_min; }
+    if (p.clip_lo && v < p.lo) v = p.lo;
+    if (p.clip_hi && v > p.hi) v = p.hi;
+    return v;
+}
+template <bool VEC>
+__global__ void __launch_bounds__(256) scale_range_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, ScaleRange p) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (VEC && i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + i);
+        float4 r;
+        r.x = scale_range_one(v.x, p); r.y = scale_range_one(v.y, p); r.z = scale_range_one(v.z, p); r.w = scale_range_one(v.w, p);
+        *reinterpret_cast<float4*>(dst + i) = r;
+        return;
+    }
+    for (long long j = i; j < n && j < i + 4; ++j) dst[j] = scale_range_one(src[j], p);
+}
+
+// Foreground box, stage 1: {zmin, ymin, xmin, zmax, ymax, xmax} of the voxels with ANY channel > 0 (NaN is not foreground,
+// as `img > 0`), per workgroup.  A wave owns one (z, y) row at a time, lanes stride along x; every lane keeps private
+// extrema, merged once per workgroup through LDS.  No global atomics: stage 2 folds the per-workgroup records.
+#define MH_BOX_EMPTY_MIN 0x7fffffff
+template <bool VEC>
+__global__ void __launch_bounds__(256) bbox_partial_kernel(const float* __restrict__ src, int C, int D, int H, int W, int* __restrict__ partial) {
+    __shared__ int box[6];
+    if (threadIdx.x < 3) box[threadIdx.x] = MH_BOX_EMPTY_MIN;
+    else if (threadIdx.x < 6) box[threadIdx.x] = -1;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long long rows = (long long)D * H, cs = rows * W;
+    int zmin = MH_BOX_EMPTY_MIN, ymin = MH_BOX_EMPTY_MIN, xmin = MH_BOX_EMPTY_MIN, zmax = -1, ymax = -1, xmax = -1;
+    for (long long r = (long long)blockIdx.x * 4 + wave; r < rows; r += (long long)gridDim.x * 4) {
+        const int z = (int)(r / H), y = (int)(r % H);
+        const float* row = src + r * W;
+        int lo = MH_BOX_EMPTY_MIN, hi = -1;
+        if (VEC) {
+            for (int x = lane * 4; x < W; x += 256) {
+                bool f0 = false, f1 = false, f2 = false, f3 = false;
+                for (int c = 0; c < C; ++c) {
+                    const float4 v = *reinterpret_cast<const float4*>(row + (long long)c * cs + x);
+                    f0 |= v.x > 0.0f; f1 |= v.y > 0.0f; f2 |= v.z > 0.0f; f3 |= v.w > 0.0f;
+                }
+                if (f0 | f1 | f2 | f3) {
+                    const int first = f0 ? x : f1 ? x + 1 : f2 ? x + 2 : x + 3;
+                    const int last = f3 ? x + 3 : f2 ? x + 2 : f1 ? x + 1 : x;
+                    lo = min(lo, first); hi = max(hi, last);
+                }
+            }
+        } else {
+            for (int x = lane; x < W; x += 64) {
+                bool f = false;
+                for (int c = 0; c < C; ++c) f |= row[(long long)c * cs + x] > 0.0f;
+                if (f) { lo = min(lo, x); hi = max(hi, x); }
+            }
+        }
+        if (hi >= 0) {
+            xmin = min(xmin, lo); xmax = max(xmax, hi);
+            zmin = min(zmin, z); zmax = max(zmax, z);
+            ymin = min(ymin, y); ymax = max(ymax, y);
+        }
+    }
+    if (zmax >= 0) {
+        atomicMin(&box[0], zmin); atomicMin(&box[1], ymin); atomicMin(&box[2], xmin);
+        atomicMax(&box[3], zmax); atomicMax(&box[4], ymax); atomicMax(&box[5], xmax);
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) partial[(long long)blockIdx.x * 6 + threadIdx.x] = box[threadIdx.x];
+}
+
+// stage 2: one workgroup folds the `nparts` records into out[6] (zmax == -1: no foreground at all)
+__global__ void __launch_bounds__(256) bbox_final_kernel(const int* __restrict__ partial, int nparts, int* __restrict__ out) {
+    __shared__ int box[6];
+    if (threadIdx.x < 3) box[threadIdx.x] = MH_BOX_EMPTY_MIN;
+    else if (threadIdx.x < 6) box[threadIdx.x] = -1;
+    __syncthreads();
+    int mn[3] = {MH_BOX_EMPTY_MIN, MH_BOX_EMPTY_MIN, MH_BOX_EMPTY_MIN}, mx[3] = {-1, -1, -1};
+    for (int b = threadIdx.x; b < nparts; b += 256)
+        for (int k = 0; k < 3; ++k) { mn[k] = min(mn[k], partial[b * 6 + k]); mx[k] = max(mx[k], partial[b * 6 + 3 + k]); }
+    if (mx[0] >= 0)
+        for (int k = 0; k < 3; ++k) { atomicMin(&box[k], mn[k]); atomicMax(&box[3 + k], mx[k]); }
+    __syncthreads();
+    if (threadIdx.x < 6) out[threadIdx.x] = box[threadIdx.x];
+}
+
+// dst[c][z][y][x] = src[c][z + sz][y + sy][x + sx] inside the source, `value` outside: SpatialCrop of the clipped box and
+// the constant pad of the part that sticks out, in one pass.  blockIdx.x = output row (c, z, y), blockIdx.y = x chunk.
+__global__ void __launch_bounds__(256) crop_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, int D, int H, int W, int Do, int Ho,
+                                                       int Wo, int sz, int sy, int sx, float value) {
+    const int x = blockIdx.y * 256 + threadIdx.x;
+    if (x >= Wo) return;
+    const long long row = blockIdx.x;
+    const int y = (int)(row % Ho), z = (int)((row / Ho) % Do);
+    const long long c = row / ((long long)Ho * Do);
+    const int iz = z + sz, iy = y + sy, ix = x + sx;
+    float v = value;
+    if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) v = src[((c * D + iz) * H + iy) * (long long)W + ix];
+    dst[row * Wo + x] = v;
+}
+
+}  // namespace mh

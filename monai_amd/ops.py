@@ -294,3 +294,47 @@ def deconv_k3(x, x_nrm, weight, bias, out, stride: int):
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
     _lib.lib().call("mh_deconv_k3_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), int(stride), _s(x))
     return out
+
+
+# ---- pre-processing in front of the path (ScaleIntensityRange / CropForeground) -------------------------------------
+def scale_intensity_range(src: torch.Tensor, a_min: float, a_div: float, b_scale: Optional[float], b_min: float,
+                          lo: Optional[float], hi: Optional[float]) -> torch.Tensor:
+    """y = (x - a_min) / a_div [* b_scale + b_min when b_scale is not None] [clamped to lo / hi when given]; contiguous fp32."""
+    _lib.require_device(src)
+    if not src.is_contiguous():
+        raise RuntimeError("monai_amd.scale_intensity_range: contiguous tensor required")
+    out = torch.empty_like(src)
+    if src.numel():
+        _lib.lib().call("mh_scale_intensity_range_f32", _lib.ptr(src), _lib.ptr(out), int(src.numel()), float(a_min), float(a_div),
+                        int(b_scale is not None), float(b_scale or 0.0), float(b_min), int(lo is not None), float(lo or 0.0),
+                        int(hi is not None), float(hi or 0.0), _s(src))
+    return out
+
+
+def foreground_bbox(src: torch.Tensor):
+    """src [C, D, H, W] fp32 -> (zmin, ymin, xmin, zmax, ymax, xmax), inclusive, of the voxels with any channel > 0, or None
+    when there is no foreground.  One device -> host read of 24 bytes (the caller needs the box to size its output)."""
+    _lib.require_device(src)
+    if src.dim() != 4 or not src.is_contiguous() or not src.numel():
+        raise RuntimeError("monai_amd.foreground_bbox: contiguous non-empty [C, D, H, W] tensor required")
+    c, d, h, w = (int(v) for v in src.shape)
+    L = _lib.lib()
+    ws = torch.empty(L.query("mh_foreground_bbox_workspace_ints", d, h) + 6, dtype=torch.int32, device=src.device)
+    box = ws[-6:]
+    L.call("mh_foreground_bbox_f32", _lib.ptr(src), c, d, h, w, _lib.ptr(ws), _lib.ptr(box), _s(src))
+    b = [int(v) for v in box.cpu().tolist()]
+    return None if b[3] < 0 else tuple(b)
+
+
+def crop_pad(src: torch.Tensor, start: Sequence[int], size: Sequence[int], value: float = 0.0) -> torch.Tensor:
+    """src [C, D, H, W] -> [C, *size]: out[c, z, y, x] = src[c, z + start_z, ...] inside the source, `value` outside."""
+    _lib.require_device(src)
+    if src.dim() != 4 or not src.is_contiguous() or not src.numel():
+        raise RuntimeError("monai_amd.crop_pad: contiguous non-empty [C, D, H, W] tensor required")
+    c, d, h, w = (int(v) for v in src.shape)
+    do, ho, wo = (int(v) for v in size)
+    out = torch.empty((c, do, ho, wo), dtype=torch.float32, device=src.device)
+    if out.numel():
+        _lib.lib().call("mh_crop_pad_f32", _lib.ptr(src), _lib.ptr(out), c, d, h, w, do, ho, wo, int(start[0]), int(start[1]), int(start[2]),
+                        float(value), _s(src))
+    return out

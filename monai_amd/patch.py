@@ -48,7 +48,16 @@ _TARGETS = {
         "SpacingD": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
         "SpacingDict": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
     },
-    "monai.transforms.intensity.array": {"GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth")},
+    "monai.transforms.intensity.array": {
+        "GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth"),
+        "ScaleIntensityRange": ("monai_amd.transforms.intensity.array", "ScaleIntensityRange"),
+    },
+    "monai.transforms.croppad.array": {"CropForeground": ("monai_amd.transforms.croppad.array", "CropForeground")},
+    "monai.transforms.croppad.dictionary": {
+        "CropForegroundd": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
+        "CropForegroundD": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
+        "CropForegroundDict": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
+    },
     "monai.transforms.post.array": {
         "Activations": ("monai_amd.transforms.post.array", "Activations"),
         "AsDiscrete": ("monai_amd.transforms.post.array", "AsDiscrete"),
@@ -65,6 +74,9 @@ _TARGETS = {
         "GaussianSmoothd": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
         "GaussianSmoothD": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
         "GaussianSmoothDict": ("monai_amd.transforms.intensity.dictionary", "GaussianSmoothd"),
+        "ScaleIntensityRanged": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
+        "ScaleIntensityRangeD": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
+        "ScaleIntensityRangeDict": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
     },
     "monai.networks.layers.spatial_transforms": {
         "AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform"),

@@ -1,3 +1,7 @@
-from .intensity import GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd  # noqa: F401
+from .croppad import CropForeground, CropForegroundD, CropForegroundDict, CropForegroundd  # noqa: F401
+from .intensity import (  # noqa: F401
+    GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
+    ScaleIntensityRanged,
+)
 from .spatial import Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401
 from .post import Activations, ActivationsD, ActivationsDict, Activationsd, AsDiscrete, AsDiscreteD, AsDiscreteDict, AsDiscreted  # noqa: F401

@@ -1,0 +1,45 @@
+"""``CropForegroundd`` -- monai/transforms/croppad/dictionary.py:703-800: one bounding box from ``source_key``, every key
+cropped (and padded) to it."""
+
+from __future__ import annotations
+
+from collections.abc import Callable, Sequence
+
+from ...utils.misc import ensure_tuple, ensure_tuple_rep
+from .array import CropForeground, is_positive
+
+__all__ = ["CropForegroundd", "CropForegroundD", "CropForegroundDict"]
+
+
+class CropForegroundd:
+    def __init__(self, keys, source_key: str, select_fn: Callable = is_positive, channel_indices=None, margin: Sequence[int] | int = 0,
+                 allow_smaller: bool = False, k_divisible: Sequence[int] | int = 1, mode="constant",
+                 start_coord_key: str | None = "foreground_start_coord", end_coord_key: str | None = "foreground_end_coord",
+                 allow_missing_keys: bool = False, lazy: bool = False, **pad_kwargs) -> None:
+        self.keys = ensure_tuple(keys)
+        self.allow_missing_keys = allow_missing_keys
+        self.source_key, self.start_coord_key, self.end_coord_key = source_key, start_coord_key, end_coord_key
+        self.cropper = CropForeground(select_fn=select_fn, channel_indices=channel_indices, margin=margin, allow_smaller=allow_smaller,
+                                      k_divisible=k_divisible, lazy=lazy, **pad_kwargs)
+        self.mode = ensure_tuple_rep(mode, len(self.keys))
+        self.lazy = False
+
+    def __call__(self, data, lazy: bool | None = None):
+        if lazy:
+            raise NotImplementedError("monai_amd.CropForegroundd: lazy execution is not implemented")
+        d = dict(data)
+        box_start, box_end = self.cropper.compute_bounding_box(img=d[self.source_key])
+        if self.start_coord_key is not None:
+            d[self.start_coord_key] = box_start
+        if self.end_coord_key is not None:
+            d[self.end_coord_key] = box_end
+        for key, m in zip(self.keys, self.mode):
+            if key not in d:
+                if self.allow_missing_keys:
+                    continue
+                raise KeyError(f"Key `{key}` of transform `{type(self).__name__}` was missing in the data and allow_missing_keys==False.")
+            d[key] = self.cropper.crop_pad(img=d[key], box_start=box_start, box_end=box_end, mode=m)
+        return d
+
+
+CropForegroundD = CropForegroundDict = CropForegroundd

@@ -1,2 +1,4 @@
-from .array import GaussianSmooth  # noqa: F401
-from .dictionary import GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd  # noqa: F401
+from .array import GaussianSmooth, ScaleIntensityRange  # noqa: F401
+from .dictionary import (  # noqa: F401
+    GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, ScaleIntensityRangeD, ScaleIntensityRangeDict, ScaleIntensityRanged,
+)

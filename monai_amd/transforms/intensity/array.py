@@ -1,4 +1,5 @@
-"""``GaussianSmooth`` -- monai/transforms/intensity/array.py:1590-1622 on the fused smoothing kernel."""
+"""``GaussianSmooth`` (monai/transforms/intensity/array.py:1590-1622, the fused smoothing kernel) and ``ScaleIntensityRange``
+(array.py:958-1012, one element-wise pass)."""
 
 from __future__ import annotations
 
@@ -9,7 +10,7 @@ import torch
 from ...data.meta_tensor import is_meta
 from ...networks.layers.simplelayers import GaussianFilter
 
-__all__ = ["GaussianSmooth"]
+__all__ = ["GaussianSmooth", "ScaleIntensityRange"]
 
 
 class GaussianSmooth:
@@ -23,6 +24,54 @@ class GaussianSmooth:
         x = data.to(torch.float)
         sigma = list(self.sigma) if isinstance(self.sigma, Sequence) else self.sigma
         out = GaussianFilter(x.ndim - 1, sigma, approx=self.approx)(x.unsqueeze(0)).squeeze(0)
+        if is_meta(img):
+            return type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
+        return out
+
+
+_NP2T = {"float32": torch.float32, "float64": torch.float64, "float16": torch.float16, "int16": torch.int16, "int32": torch.int32,
+         "int64": torch.int64, "uint8": torch.uint8, "int8": torch.int8, "bool": torch.bool}
+
+
+def _to_torch_dtype(dtype):
+    if dtype is None or isinstance(dtype, torch.dtype):
+        return dtype
+    import numpy as np
+
+    return _NP2T[np.dtype(dtype).name]
+
+
+class ScaleIntensityRange:
+    """``monai.transforms.ScaleIntensityRange`` (monai/transforms/intensity/array.py:958-1012) as one HIP pass over the device
+    tensor: ``(img - a_min) / (a_max - a_min)``, optionally ``* (b_max - b_min) + b_min``, optionally clamped -- the reference's
+    operator sequence with each of its fp32 roundings kept, so the results are bit-identical to the reference's.  Integer images
+    are promoted to float32 first (what the reference's first subtraction does); float64 / half images are not on this path."""
+
+    def __init__(self, a_min: float, a_max: float, b_min: float | None = None, b_max: float | None = None, clip: bool = False,
+                 dtype=torch.float32) -> None:
+        self.a_min, self.a_max, self.b_min, self.b_max, self.clip, self.dtype = a_min, a_max, b_min, b_max, clip, dtype
+
+    def __call__(self, img):
+        from ... import ops
+        import warnings
+
+        data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        if data.dtype in (torch.float64, torch.float16, torch.bfloat16) or data.is_complex():
+            raise NotImplementedError(f"monai_amd.ScaleIntensityRange: {data.dtype} images are not on the HIP path (float32 / integer images are)")
+        x = data.to(torch.float32).contiguous()
+        dtype = _to_torch_dtype(self.dtype) or x.dtype
+        if self.a_max - self.a_min == 0.0:                       # array.py:999-1003: no division, no clip, no dtype conversion
+            warnings.warn("Divide by zero (a_min == a_max)", Warning)
+            out = ops.scale_intensity_range(x, self.a_min, 1.0, None if self.b_min is None else 1.0, self.b_min or 0.0, None, None)
+        else:
+            rescale = self.b_min is not None and self.b_max is not None
+            if self.clip and self.b_min is None and self.b_max is None:       # array.py:1009 -> torch.clamp(img, None, None)
+                raise RuntimeError("torch.clamp: At least one of 'min' or 'max' must not be None")
+            out = ops.scale_intensity_range(
+                x, self.a_min, self.a_max - self.a_min, (self.b_max - self.b_min) if rescale else None, self.b_min if rescale else 0.0,
+                self.b_min if self.clip else None, self.b_max if self.clip else None)
+            if out.dtype != dtype:
+                out = out.to(dtype)
         if is_meta(img):
             return type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
         return out

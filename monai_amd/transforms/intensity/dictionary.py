@@ -1,11 +1,11 @@
-"""``GaussianSmoothd`` -- monai/transforms/intensity/dictionary.py:1184-1216."""
+"""``GaussianSmoothd`` (monai/transforms/intensity/dictionary.py:1184-1216) and ``ScaleIntensityRanged`` (dictionary.py:855-892)."""
 
 from __future__ import annotations
 
 from ...utils.misc import ensure_tuple
-from .array import GaussianSmooth
+from .array import GaussianSmooth, ScaleIntensityRange
 
-__all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict"]
+__all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict", "ScaleIntensityRanged", "ScaleIntensityRangeD", "ScaleIntensityRangeDict"]
 
 
 class GaussianSmoothd:
@@ -26,3 +26,16 @@ class GaussianSmoothd:
 
 
 GaussianSmoothD = GaussianSmoothDict = GaussianSmoothd
+
+
+class ScaleIntensityRanged(GaussianSmoothd):
+    """Dictionary version of :class:`ScaleIntensityRange` (same key handling as the class above)."""
+
+    def __init__(self, keys, a_min: float, a_max: float, b_min=None, b_max=None, clip: bool = False, dtype="float32", allow_missing_keys: bool = False) -> None:
+
+        self.keys = ensure_tuple(keys)
+        self.allow_missing_keys = allow_missing_keys
+        self.scaler = self.converter = ScaleIntensityRange(a_min, a_max, b_min, b_max, clip, dtype)
+
+
+ScaleIntensityRangeD = ScaleIntensityRangeDict = ScaleIntensityRanged

@@ -124,3 +124,16 @@ def test_post_transforms_api(emu):
     import post_cases as pc
 
     pc.case_post_transforms_api("cpu")
+
+
+def test_preproc_vs_reference(emu):
+    import preproc_cases as pc
+
+    print("arrays", pc.case_preproc_vs_reference("cpu"))
+    print("boxes", pc.case_bbox_large("cpu"))
+
+
+def test_preproc_api(emu):
+    import preproc_cases as pc
+
+    pc.case_preproc_api("cpu")
