@@ -230,7 +230,7 @@ def sliding_window_inference(
     imp_dev = None
     zscales = None
 
-    fused = fused and hasattr(predictor, "out_channels")
+    fused = fused and hasattr(predictor, "out_channels") and getattr(predictor, "window_sized_output", True)
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
         steps = list(enumerate(my_rounds))

@@ -1,0 +1,317 @@
+"""``DynUNet`` (the nnU-Net architecture) on the MI355X kernels -- drop-in for ``monai.networks.nets.DynUNet``
+(monai/networks/nets/dynunet.py:32-418; blocks: monai/networks/blocks/dynunet_block.py:25-328).
+
+Same constructor signature, the same module tree (``input_block`` / ``downsamples`` / ``bottleneck`` / ``upsamples`` /
+``output_block`` / ``deep_supervision_heads`` and the recursive ``skip_layers`` that re-registers the same blocks) and therefore
+the same ``state_dict`` keys / shapes, and the same order of random draws at construction (default Conv initialisers, the
+``torch.rand(1)`` of ``self.heads``, then ``kaiming_normal_(a=0.01)`` in ``apply`` order): reference checkpoints load unchanged
+and the same seed gives the same weights.
+
+Inference engine (the same convolution / normalisation engine as BasicUNet / UNet / UNETR): every 3x3x3 conv
+output is stored raw with its InstanceNorm (affine) + LeakyReLU folded into a per-(n, c) {alpha, beta, slope} record that the
+consumer applies on load; stride-1 convs run on the fp32-MFMA tiles with fused statistics, stride-2 convs on the direct
+kernel, the k2s2 transposed convs and the 1x1 head on their own kernels; the encoder output of each level is materialised
+exactly once, straight into the skip half of that level's concat buffer (``torch.cat`` never runs).
+On the HIP path: 3-D, kernel 3, strides 1 / 2 (isotropic), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
+no dropout, ``res_block`` False or True; deep-supervision heads are parameters only (they feed the training loss, the
+inference output does not depend on them)."""
+
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import torch
+import torch.nn as nn
+
+from ... import _lib, _prof, ops
+
+__all__ = ["DynUNet", "DynUnet", "Dynunet"]
+
+
+def _iso(v, what: str) -> int:
+    """an int or an isotropic 3-sequence -> int"""
+    if isinstance(v, (list, tuple)):
+        if len(v) != 3:
+            raise ValueError(f"length of {what} should be the same as spatial_dims.")
+        if len(set(int(a) for a in v)) != 1:
+            raise NotImplementedError(f"monai_amd.DynUNet: anisotropic {what} {tuple(v)} is not on the HIP path")
+        return int(v[0])
+    return int(v)
+
+
+# --------------------------------------------------------------------------- parameter containers (reference names)
+class _Conv(nn.Module):
+    """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose only child is ``conv``"""
+
+    def __init__(self, cin, cout, k, stride=1, transposed=False, bias=False):
+        super().__init__()
+        if transposed:
+            self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, bias=bias)
+        else:
+            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=(k - stride + 1) // 2, bias=bias)
+
+
+class _Block(nn.Module):
+    """UnetBasicBlock (dynunet_block.py:114-166) / UnetResBlock (:25-111): same children in the same order"""
+
+    def __init__(self, cin, cout, stride, affine, slope, res):
+        super().__init__()
+        self.stride, self.res = int(stride), bool(res)
+        self.conv1 = _Conv(cin, cout, 3, stride)
+        self.conv2 = _Conv(cout, cout, 3, 1)
+        self.lrelu = nn.LeakyReLU(slope, inplace=True) if slope != 0.0 else nn.ReLU(inplace=True)
+        self.norm1 = nn.InstanceNorm3d(cout, affine=affine)
+        self.norm2 = nn.InstanceNorm3d(cout, affine=affine)
+        if res and (cin != cout or stride != 1):
+            self.conv3 = _Conv(cin, cout, 1, stride)
+            self.norm3 = nn.InstanceNorm3d(cout, affine=affine)
+
+
+class _UpBlock(nn.Module):
+    """UnetUpBlock (dynunet_block.py:169-229)"""
+
+    def __init__(self, cin, cout, up, affine, slope, trans_bias):
+        super().__init__()
+        self.transp_conv = _Conv(cin, cout, up, up, transposed=True, bias=trans_bias)
+        self.conv_block = _Block(cout + cout, cout, 1, affine, slope, False)
+
+
+class _OutBlock(nn.Module):
+    """UnetOutBlock (dynunet_block.py:232-253)"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = _Conv(cin, cout, 1, bias=True)
+
+
+class _SkipLayer(nn.Module):
+    """DynUNetSkipLayer (dynunet.py:32-65): parameter-free, re-registers the blocks under ``skip_layers.*``"""
+
+    def __init__(self, index, downsample, upsample, next_layer, super_head=None):
+        super().__init__()
+        self.downsample, self.next_layer, self.upsample, self.super_head, self.index = downsample, next_layer, upsample, super_head, index
+
+
+# --------------------------------------------------------------------------- the module
+class DynUNet(nn.Module):
+    def __init__(
+        self,
+        spatial_dims: int,
+        in_channels: int,
+        out_channels: int,
+        kernel_size: Sequence,
+        strides: Sequence,
+        upsample_kernel_size: Sequence,
+        filters: Sequence[int] | None = None,
+        dropout=None,
+        norm_name: tuple | str = ("INSTANCE", {"affine": True}),
+        act_name: tuple | str = ("leakyrelu", {"inplace": True, "negative_slope": 0.01}),
+        deep_supervision: bool = False,
+        deep_supr_num: int = 1,
+        res_block: bool = False,
+        trans_bias: bool = False,
+    ) -> None:
+        super().__init__()
+        self.spatial_dims, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
+        self.kernel_size, self.strides, self.upsample_kernel_size = kernel_size, strides, upsample_kernel_size
+        self.norm_name, self.act_name, self.dropout, self.trans_bias = norm_name, act_name, dropout, trans_bias
+        # dynunet.py:213-231 (checked before any parameter exists here; the reference checks after building)
+        if len(kernel_size) != len(strides) or len(kernel_size) < 3:
+            raise ValueError("length of kernel_size and strides should be the same, and no less than 3.")
+        if spatial_dims != 3:
+            raise NotImplementedError("monai_amd.DynUNet: only spatial_dims=3 is on the HIP path")
+        ks = [_iso(k, f"kernel_size in block {i}") for i, k in enumerate(kernel_size)]
+        ss = [_iso(s, f"stride in block {i}") for i, s in enumerate(strides)]
+        us = [_iso(u, "upsample_kernel_size") for u in upsample_kernel_size]
+        if any(k != 3 for k in ks) or any(s not in (1, 2) for s in ss):
+            raise NotImplementedError("monai_amd.DynUNet: the HIP path covers kernel size 3 and strides 1 / 2")
+        if len(us) != len(ss) - 1 or any(u != s or u != 2 for u, s in zip(us, ss[1:])):
+            raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] (all 2) on the HIP path")
+        if dropout is not None and dropout != 0.0:
+            raise NotImplementedError("monai_amd.DynUNet: dropout is not on the (inference-only) HIP path")
+        nname, nargs = (norm_name, {}) if isinstance(norm_name, str) else (norm_name[0], norm_name[1] if len(norm_name) > 1 else {})
+        if str(nname).lower() != "instance":
+            raise NotImplementedError("monai_amd.DynUNet: only instance norm is on the HIP path")
+        affine = bool(nargs.get("affine", False))
+        aname, aargs = (act_name, {}) if isinstance(act_name, str) else (act_name[0], act_name[1] if len(act_name) > 1 else {})
+        if str(aname).lower() == "leakyrelu":
+            slope = float(aargs.get("negative_slope", 0.01))
+        elif str(aname).lower() == "relu":
+            slope = 0.0
+        else:
+            raise NotImplementedError("monai_amd.DynUNet: only (leaky) ReLU is on the HIP path")
+        self._strides, self._slope = ss, slope
+        if filters is not None:
+            if len(filters) < len(strides):
+                raise ValueError("length of filters should be no less than the length of strides.")
+            self.filters = list(filters[: len(strides)])
+        else:
+            self.filters = [min(2 ** (5 + i), 320) for i in range(len(strides))]
+        f = self.filters
+        self.features = (f[0],)    # used by the inferer to size its window batch
+        self.window_sized_output = ss[0] == 1     # the inferer writes straight into its logits buffer only then
+
+        def block(cin, cout, s):
+            return _Block(cin, cout, s, affine, slope, res_block)
+
+        # construction order = the reference's (dynunet.py:154-166): it fixes the random stream of the default initialisers
+        self.input_block = block(in_channels, f[0], ss[0])
+        self.downsamples = nn.ModuleList([block(i, o, s) for i, o, s in zip(f[:-2], f[1:-1], ss[1:-1])])
+        self.bottleneck = block(f[-2], f[-1], ss[-1])
+        self.upsamples = nn.ModuleList([_UpBlock(i, o, u, affine, slope, trans_bias) for i, o, u in zip(f[1:][::-1], f[:-1][::-1], us[::-1])])
+        self.output_block = _OutBlock(f[0], out_channels)
+        self.deep_supervision, self.deep_supr_num = deep_supervision, deep_supr_num
+        self.heads = [torch.rand(1)] * deep_supr_num            # one draw from the global generator, as the reference
+        if deep_supervision:
+            self.deep_supervision_heads = nn.ModuleList([_OutBlock(f[i + 1], out_channels) for i in range(deep_supr_num)])
+            if deep_supr_num >= len(strides) - 1:
+                raise ValueError("deep_supr_num should be less than the number of up sample layers.")
+            if deep_supr_num < 1:
+                raise ValueError("deep_supr_num should be larger than 0.")
+        self.apply(self.initialize_weights)
+
+        def create_skips(index, downs, ups, heads):
+            if len(downs) != len(ups):
+                raise ValueError(f"{len(downs)} != {len(ups)}")
+            if len(downs) == 0:
+                return self.bottleneck
+            if heads is None:
+                return _SkipLayer(index, downs[0], ups[0], create_skips(index + 1, downs[1:], ups[1:], None))
+            head, rest = None, heads
+            if index > 0:
+                head, rest = (heads[0], heads[1:]) if len(heads) > 0 else (None, nn.ModuleList())
+            return _SkipLayer(index, downs[0], ups[0], create_skips(index + 1, downs[1:], ups[1:], rest), super_head=head)
+
+        self.skip_layers = create_skips(0, [self.input_block] + list(self.downsamples), self.upsamples[::-1],
+                                        self.deep_supervision_heads if deep_supervision else None)
+        self._packed: dict = {}
+        self._stats = None
+
+    @staticmethod
+    def initialize_weights(module):
+        """dynunet.py:412-417"""
+        if isinstance(module, (nn.Conv3d, nn.Conv2d, nn.ConvTranspose3d, nn.ConvTranspose2d)):
+            module.weight = nn.init.kaiming_normal_(module.weight, a=0.01)
+            if module.bias is not None:
+                module.bias = nn.init.constant_(module.bias, 0)
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int, expand: bool = False) -> torch.Tensor:
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((id(conv), cfg))
+        if hit is None or hit[0] != key:
+            if expand:      # a strided 1x1 conv as the centre tap of a 3x3x3 one (same sample positions: 2i with padding 1)
+                w3 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=w.dtype, device=w.device)
+                w3[:, :, 1, 1, 1] = w[:, :, 0, 0, 0]
+                w = w3
+            hit = (key, ops.conv3d_k3_pack(cfg, w))
+            self._packed[(id(conv), cfg)] = hit
+        return hit[1]
+
+    def _stats_buf(self, floats: int, device) -> torch.Tensor:
+        if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
+            self._stats = torch.empty(floats, dtype=torch.float32, device=device)
+        return self._stats
+
+    def _finalize(self, norm: nn.InstanceNorm3d, raw, stats, tiles, slope):
+        n, c = raw.shape[:2]
+        if not tiles:
+            tiles = ops.instnorm_stat_tiles(*raw.shape[2:])
+            stats = self._stats_buf(n * c * tiles * 3, raw.device)
+            ops.instnorm_stats(raw, stats)
+        nrm = torch.empty((n, c, 4), dtype=torch.float32, device=raw.device)
+        ops.instnorm_finalize(stats, tiles, n, c, norm.weight, norm.bias, norm.eps, slope, nrm)
+        return nrm
+
+    def _conv_norm(self, conv: nn.Conv3d, norm, x, x_nrm, stride: int, slope: float):
+        """3x3x3 conv (no bias) of the (deferred) input + InstanceNorm statistics -> (raw output, {alpha, beta, slope} record)"""
+        n, cin, d, h, w = x.shape
+        cout = conv.weight.shape[0]
+        sp = tuple((v - 1) // stride + 1 for v in (d, h, w))
+        out = torch.empty((n, cout) + sp, dtype=torch.float32, device=x.device)
+        tiles, stats = 0, None
+        flops = 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n
+        if stride == 1 and not (cin <= 8 and cout <= 8):
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+            tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
+            with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+                ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
+        else:       # strided, or so few channels that the matrix tiles would mostly pad: the direct kernel at the true width
+            ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
+        return out, self._finalize(norm, out, stats, tiles, slope)
+
+    def _basic(self, blk: _Block, x, x_nrm):
+        """UnetBasicBlock: conv1 -> norm1 -> lrelu -> conv2 -> norm2 -> lrelu, the last normalise + activate left to the consumer"""
+        c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, x_nrm, blk.stride, self._slope)
+        return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, 1, self._slope)
+
+    def _res(self, blk: _Block, x, dst):
+        """UnetResBlock of a plain tensor into `dst` (plain): lrelu(norm2(conv2(lrelu(norm1(conv1 x)))) + shortcut)"""
+        c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, None, blk.stride, self._slope)
+        c2, n2 = self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, 1, 1.0)
+        if not hasattr(blk, "conv3"):
+            return ops.add_act(c2, n2, x, None, self._slope, dst)
+        w3 = blk.conv3.conv.weight
+        cout = w3.shape[0]
+        r = torch.empty_like(c2)
+        if blk.stride == 1:
+            ops.conv1x1(x, None, w3.view(cout, -1), None, r)
+        else:
+            ops.conv3d_k3_strided(x, None, self._packed_weight(blk.conv3.conv, 0, expand=True), None, r, blk.stride)
+        n3 = self._finalize(blk.norm3, r, None, 0, 1.0)
+        return ops.add_act(c2, n2, r, n3, self._slope, dst)
+
+    def _encode(self, blk: _Block, x, dst):
+        """an encoder block of a plain tensor, materialised into `dst` (the skip half of a concat buffer)"""
+        if blk.res:
+            return self._res(blk, x, dst)
+        c, cn = self._basic(blk, x, None)
+        return ops.add_act(c, cn, None, None, 1.0, dst)
+
+    def _level(self, i: int, x, downs, ups):
+        """DynUNetSkipLayer.forward at depth i: down -> next level -> transposed conv + [up | skip] concat -> conv block (deferred)"""
+        blk, up = downs[i], ups[i]
+        cout = blk.conv1.conv.weight.shape[0]
+        n = x.shape[0]
+        sp = tuple((v - 1) // blk.stride + 1 for v in x.shape[2:])
+        cat = torch.empty((n, 2 * cout) + sp, dtype=torch.float32, device=x.device)       # torch.cat((out, skip), dim=1)
+        skip = self._encode(blk, x, cat[:, cout:])
+        if i + 1 < len(downs):
+            t, tn = self._level(i + 1, skip, downs, ups)
+        elif self.bottleneck.res:
+            bsp = tuple((v - 1) // self.bottleneck.stride + 1 for v in sp)
+            t, tn = self._res(self.bottleneck, skip, torch.empty((n, self.filters[-1]) + bsp, dtype=torch.float32, device=x.device)), None
+        else:
+            t, tn = self._basic(self.bottleneck, skip, None)
+        tc = up.transp_conv.conv
+        ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout])
+        return self._basic(up.conv_block, cat, None)
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        sp = tuple((v - 1) // self._strides[0] + 1 for v in x.shape[2:])
+        out = torch.empty((x.shape[0], self.out_channels) + sp, dtype=torch.float32, device=x.device)
+        return self.forward_into(x, out)
+
+    @torch.no_grad()
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        _lib.require_device(x, out)
+        if self.training:
+            raise RuntimeError("monai_amd.DynUNet is an inference engine: call .eval() first")
+        total = 1
+        for s in self._strides:
+            total *= s
+        if x.dim() != 5 or x.shape[1] != self.in_channels or any(int(v) % total for v in x.shape[2:]):
+            raise NotImplementedError(f"monai_amd.DynUNet: input (B,{self.in_channels},D,H,W) with edges divisible by {total} expected, got {tuple(x.shape)}")
+        if tuple(out.shape) != (x.shape[0], self.out_channels) + tuple((int(v) - 1) // self._strides[0] + 1 for v in x.shape[2:]):
+            raise RuntimeError(f"monai_amd.DynUNet: output buffer of shape {tuple(out.shape)} does not fit input {tuple(x.shape)}")
+        downs = [self.input_block] + list(self.downsamples)
+        t, tn = self._level(0, x.contiguous(), downs, list(self.upsamples[::-1]))
+        oc = self.output_block.conv.conv
+        ops.conv1x1(t, tn, oc.weight.view(oc.weight.shape[0], -1), oc.bias, out)
+        return out
+
+
+DynUnet = Dynunet = DynUNet

@@ -1,0 +1,126 @@
+"""DynUNet cases shared by the golden generator (real reference, CPU) and the emulator / MI355X tests."""
+import hashlib
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LOGIT_TOL = 1e-4   # BASELINE.json north_star: fp32 logits within 1e-4 of the reference
+
+K3 = [3, 3, 3, 3]
+CFGS = {
+    # the nnU-Net shape: basic blocks, affine instance norm, leaky ReLU 0.01, matrix-core convolutions at every level
+    "basic": dict(kw=dict(kernel_size=K3, strides=[1, 2, 2, 2], upsample_kernel_size=[2, 2, 2], filters=[16, 32, 48, 64]),
+                  shape=(2, 1, 32, 32, 32), seed=11),
+    # residual blocks (strided 1x1 shortcut), deep-supervision heads present, few channels at the top (direct kernel)
+    "res_ds": dict(kw=dict(kernel_size=K3, strides=[1, 2, 2, 2], upsample_kernel_size=[2, 2, 2], filters=[8, 16, 32, 64], res_block=True,
+                           deep_supervision=True, deep_supr_num=2),
+                   shape=(1, 2, 16, 24, 32), seed=12),
+    # three levels, first block strided, plain instance norm, ReLU, biased transposed convs, per-block sequences for kernel / stride
+    "stride0": dict(kw=dict(kernel_size=[[3, 3, 3]] * 3, strides=[2, [2, 2, 2], 2], upsample_kernel_size=[[2, 2, 2], 2], norm_name="instance",
+                            act_name="relu", trans_bias=True),
+                    shape=(1, 1, 16, 16, 24), seed=13),
+}
+IN_CH = {"basic": 1, "res_ds": 2, "stride0": 1}
+
+
+def digest(sd):
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+def build(cls, name):
+    """seeded construction -> (eval net with perturbed norm affine / bias parameters, digest of the fresh state_dict)"""
+    c = CFGS[name]
+    torch.manual_seed(c["seed"])
+    net = cls(spatial_dims=3, in_channels=IN_CH[name], out_channels=3, **c["kw"])
+    init = digest(net.state_dict())
+    gen = torch.Generator().manual_seed(500 + c["seed"])
+    with torch.no_grad():
+        seen = set()
+        for k, v in net.state_dict().items():     # the default norm affine / bias values (1 / 0) would hide a swapped or dropped parameter
+            if v.data_ptr() in seen:
+                continue
+            seen.add(v.data_ptr())
+            if ".norm" in k and k.endswith("weight"):
+                v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=gen))
+            elif k.endswith("bias"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=gen))
+    return net.eval(), init
+
+
+def inputs(name):
+    return torch.rand(CFGS[name]["shape"], generator=torch.Generator().manual_seed(700 + CFGS[name]["seed"]))
+
+
+def case_dynunet_vs_reference(device, names=tuple(CFGS)):
+    """DynUNet against the real reference's output (tests/golden/make_golden_dynunet.py): state_dict keys, the same weights from the
+    same seed, logits within 1e-4, identical argmax outside near-ties."""
+    from monai_amd.networks.nets import DynUNet
+
+    g = np.load(os.path.join(GOLDEN, "dynunet.npz"))
+    out = {}
+    for name in names:
+        net, init = build(DynUNet, name)
+        assert list(net.state_dict().keys()) == list(g[f"{name}_keys"]), name
+        assert init == str(g[f"{name}_init_sha256"]), f"{name}: same seed must give the reference's weights"
+        y = net.to(device)(inputs(name).to(device)).cpu()
+        exp = torch.from_numpy(g[f"{name}_out"])
+        assert y.shape == exp.shape, (name, y.shape, exp.shape)
+        err = (y.double() - exp.double()).abs().max().item()
+        assert err < LOGIT_TOL, (name, err)
+        top2 = exp.topk(2, dim=1).values
+        mism = y.argmax(1) != exp.argmax(1)
+        assert not mism.any() or float((top2[:, 0] - top2[:, 1])[mism].max()) < 2 * LOGIT_TOL, name
+        out[name] = err
+    return out
+
+
+SW = dict(roi_size=(32, 32, 32), sw_batch_size=2, overlap=0.5, mode="gaussian")
+
+
+def sw_volume():
+    return torch.rand((1, 1, 48, 48, 40), generator=torch.Generator().manual_seed(801))
+
+
+def case_dynunet_sliding_window(device):
+    """SlidingWindowInferer over DynUNet ("basic" and the half-resolution "stride0" net) against the reference inferer + reference net."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.networks.nets import DynUNet
+
+    g = np.load(os.path.join(GOLDEN, "dynunet.npz"))
+    out = {}
+    for name in ("basic", "stride0"):
+        net, _ = build(DynUNet, name)
+        y = SlidingWindowInferer(**SW)(sw_volume().to(device), net.to(device)).cpu()
+        exp = torch.from_numpy(g[f"{name}_sw_out"])
+        assert y.shape == exp.shape, (name, y.shape, exp.shape)
+        out[name] = (y.double() - exp.double()).abs().max().item()
+        assert out[name] < LOGIT_TOL, (name, out[name])
+    return out
+
+
+def case_dynunet_api(device):
+    import pytest
+
+    from monai_amd.networks.nets import DynUNet
+
+    with pytest.raises(ValueError):
+        DynUNet(3, 1, 2, [3, 3], [1, 2], [2])
+    with pytest.raises(ValueError):
+        DynUNet(3, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2], filters=[8, 16])
+    with pytest.raises(ValueError):
+        DynUNet(3, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2], deep_supervision=True, deep_supr_num=3)
+    with pytest.raises(NotImplementedError):
+        DynUNet(3, 1, 2, [3, [3, 3, 1], 3], [1, 2, 2], [2, 2])
+    with pytest.raises(NotImplementedError):
+        DynUNet(2, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2])
+    net = DynUNet(3, 1, 2, [3, 3, 3], [1, 2, 2], [2, 2], filters=[8, 8, 8])
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 8, 8, 8, device=device))           # training mode: inference engine only
+    with pytest.raises(NotImplementedError):
+        net.eval().to(device)(torch.zeros(1, 1, 10, 8, 8, device=device))

@@ -54,3 +54,16 @@ def test_bundle_shaped_pipeline_vs_reference(emu):
     import pipeline_case as pl
 
     print(pl.case_pipeline_vs_reference("cpu"))
+
+
+def test_dynunet_vs_reference(emu):
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_vs_reference("cpu"))
+    dc.case_dynunet_api("cpu")
+
+
+def test_dynunet_sliding_window_vs_reference(emu):
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_sliding_window("cpu"))

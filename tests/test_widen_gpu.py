@@ -18,3 +18,16 @@ def test_preproc_api():
     import preproc_cases as pc
 
     pc.case_preproc_api(DEV)
+
+
+def test_dynunet_vs_reference():
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_vs_reference(DEV))
+    dc.case_dynunet_api(DEV)
+
+
+def test_dynunet_sliding_window_vs_reference():
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_sliding_window(DEV))
