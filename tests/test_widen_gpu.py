@@ -31,3 +31,25 @@ def test_dynunet_sliding_window_vs_reference():
     import dynunet_cases as dc
 
     print("max |dlogit|", dc.case_dynunet_sliding_window(DEV))
+
+
+def test_loaded_extension_runs_on_the_device():
+    """boundary B2: an extension built by ``load_module`` (hipcc on the box) launches on the device"""
+    import ctypes
+    import os
+
+    import torch
+
+    from monai_amd._extensions import loader
+
+    loader.EXTENSION_DIRS.append(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ext_sample"))
+    try:
+        m = loader.load_module("axpb", defines={"AXPB_SCALE": 2})
+    finally:
+        loader.EXTENSION_DIRS.pop()
+    x = torch.arange(1000, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    m.axpb_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p]
+    assert m.axpb_f32(x.data_ptr(), y.data_ptr(), x.numel(), 0.5, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), 2 * x.cpu() + 0.5)
