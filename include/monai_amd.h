@@ -112,6 +112,11 @@ int mh_instnorm_stat_tiles(int D, int H, int W);
 int mh_instnorm_stats_f32(const mh_tensor5* x, float* stats, void* stream);
 int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const float* gamma, const float* beta,
                              float eps, float slope, float* nrm, int64_t nrm_n_stride, void* stream);
+/* GroupNorm (nn.GroupNorm(groups, C, eps, affine), monai/networks/layers/utils.py get_norm_layer("group")): the same
+ * per-(n, c) records, merged over the C / groups consecutive channels of each group; every channel of a group gets the
+ * group's mean / variance with its own gamma / beta.  groups == C is InstanceNorm. */
+int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int groups, const float* gamma, const float* beta, float eps,
+                              float slope, float* nrm, int64_t nrm_n_stride, void* stream);
 
 /* MaxPool3d(kernel_size=2) of act(in) -- `Down`, basic_unet.py:61-89.  out dims = floor(in/2). */
 int mh_maxpool2_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
@@ -232,6 +237,11 @@ int mh_foreground_bbox_f32(const float* src, int C, int D, int H, int W, int32_t
  * dst[c][z][y][x] = src[c][z+sz][y+sy][x+sx] inside src [C][D][H][W], `value` outside (starts may be negative). */
 int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, int Do, int Ho, int Wo, int sz, int sy, int sx, float value,
                     void* stream);
+
+/* Orientation (monai/transforms/spatial/functional.py:187-229: torch.flip over the reversed axes, then permute):
+ * src [C][in_size3] -> dst [C][out], out axis k = input axis perm3[k] (HOST int32[3], a permutation of 0..2), input axis a
+ * read backwards when flip3[a] != 0 (HOST int32[3]).  Images with fewer spatial axes pass leading extents of 1. */
+int mh_flip_permute_f32(const float* src, float* dst, int C, const int32_t* in_size3, const int32_t* perm3, const int32_t* flip3, void* stream);
 
 /* ---- Gaussian smoothing (GaussianSmooth / GaussianFilter / separable_filtering) ----------------------------- */
 

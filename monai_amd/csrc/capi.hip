@@ -417,8 +417,17 @@ int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const 
                              float slope, float* nrm, int64_t nrm_n_stride, void* stream) {
     if (!stats || !nrm || tiles < 1 || N < 1 || C < 1 || nrm_n_stride < 4LL * C) return fail(MH_ERR_ARG, "instnorm_finalize: bad argument");
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)C, (unsigned)N), dim3(64), 0, (hipStream_t)stream, stats, tiles,
-                       C, gamma, beta, eps, slope, nrm, (long long)nrm_n_stride);
+                       C, 1, gamma, beta, eps, slope, nrm, (long long)nrm_n_stride);
     return launched("instnorm_finalize");
+}
+
+int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int groups, const float* gamma, const float* beta, float eps,
+                              float slope, float* nrm, int64_t nrm_n_stride, void* stream) {
+    if (!stats || !nrm || tiles < 1 || N < 1 || C < 1 || groups < 1 || C % groups || nrm_n_stride < 4LL * C)
+        return fail(MH_ERR_ARG, "groupnorm_finalize: bad argument (channels must be divisible by groups)");
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((unsigned)groups, (unsigned)N), dim3(64), 0, (hipStream_t)stream, stats, tiles,
+                       C, C / groups, gamma, beta, eps, slope, nrm, (long long)nrm_n_stride);
+    return launched("groupnorm_finalize");
 }
 
 // ------------------------------------------------------------------------------------------ pool / deconv / 1x1
@@ -771,6 +780,30 @@ int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, in
     hipLaunchKernelGGL(crop_pad_kernel, dim3((unsigned)rows, (unsigned)((Wo + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, D, H, W, Do,
                        Ho, Wo, sz, sy, sx, value);
     return launched("crop_pad");
+}
+
+int mh_flip_permute_f32(const float* src, float* dst, int C, const int32_t* in_size3, const int32_t* perm3, const int32_t* flip3, void* stream) {
+    if (!src || !dst || !in_size3 || !perm3 || !flip3 || C < 1) return fail(MH_ERR_ARG, "flip_permute: bad argument");
+    int seen = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (in_size3[k] < 1 || perm3[k] < 0 || perm3[k] > 2) return fail(MH_ERR_ARG, "flip_permute: bad size / permutation");
+        seen |= 1 << perm3[k];
+    }
+    if (seen != 7) return fail(MH_ERR_ARG, "flip_permute: perm3 is not a permutation of (0, 1, 2)");
+    const long long in_stride[3] = {(long long)in_size3[1] * in_size3[2], in_size3[2], 1};
+    long long base = 0, st[3];
+    int out_size[3];
+    for (int k = 0; k < 3; ++k) {            // output axis k reads input axis a = perm3[k], reversed when flip3[a]
+        const int a = perm3[k];
+        out_size[k] = in_size3[a];
+        st[k] = flip3[a] ? -in_stride[a] : in_stride[a];
+        if (flip3[a]) base += (long long)(in_size3[a] - 1) * in_stride[a];
+    }
+    const long long rows = (long long)C * out_size[0] * out_size[1];
+    if (rows > 0x7fffffffLL || (out_size[2] + 255) / 256 > 65535) return fail(MH_ERR_UNSUPPORTED, "flip_permute: problem too large for one launch");
+    hipLaunchKernelGGL(flip_permute_kernel, dim3((unsigned)rows, (unsigned)((out_size[2] + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       out_size[0], out_size[1], out_size[2], in_stride[0] * in_size3[0], base, st[0], st[1], st[2]);
+    return launched("flip_permute");
 }
 
 // ------------------------------------------------------------------------------------------ Gaussian smoothing

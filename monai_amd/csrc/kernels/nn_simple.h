@@ -472,11 +472,14 @@ __global__ void __launch_bounds__(256) instnorm_stats_kernel(Tensor x, float* __
 // fp32 steps mirror ATen's CPU batch-norm: invstd = 1/sqrt(var + eps), alpha = gamma*invstd,
 // beta = bias - mean*alpha (the reference normalises as x*alpha + beta).
 __global__ void __launch_bounds__(64)
-instnorm_finalize_kernel(const float* __restrict__ stats, int tiles, int C, const float* __restrict__ gamma,
+instnorm_finalize_kernel(const float* __restrict__ stats, int tiles, int C, int G, const float* __restrict__ gamma,
                          const float* __restrict__ beta, float eps, float slope, float* __restrict__ nrm,
                          long long nrm_n_stride) {
-    const int c = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    // G = channels per normalisation group (1: InstanceNorm; > 1: GroupNorm -- the records of a group's channels are
+    // contiguous, so a group is simply G * tiles records and every channel of it gets the group's mean / variance)
+    const int c = blockIdx.x * G, n = blockIdx.y, lane = threadIdx.x;
     const float* rec = stats + ((long long)n * C + c) * tiles * 3;
+    tiles *= G;
     double cnt = 0.0, ws = 0.0;
     for (int i = lane; i < tiles; i += 64) {
         cnt += (double)rec[i * 3];
@@ -495,13 +498,14 @@ instnorm_finalize_kernel(const float* __restrict__ stats, int tiles, int C, cons
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
-    if (lane == 0) {
+    for (int k = lane; k < G; k += 64) {          // the butterfly left the totals in every lane
+        const int ch = c + k;
         const float var = (float)(m2 / cnt);
         const float invstd = __fdiv_rn(1.0f, __fsqrt_rn(var + eps));
-        const float g = gamma ? gamma[c] : 1.0f;
-        const float bb = beta ? beta[c] : 0.0f;
+        const float g = gamma ? gamma[ch] : 1.0f;
+        const float bb = beta ? beta[ch] : 0.0f;
         const float alpha = g * invstd;
-        float* o = nrm + (long long)n * nrm_n_stride + 4LL * c;
+        float* o = nrm + (long long)n * nrm_n_stride + 4LL * ch;
         o[0] = alpha;
         o[1] = bb - (float)mean * alpha;
         o[2] = slope;

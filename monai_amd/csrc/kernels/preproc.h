@@ -1,7 +1,7 @@
 // Intensity / crop pre-processing in front of the sliding-window path: ScaleIntensityRange
 // (monai/transforms/intensity/array.py:958-1012), the foreground bounding box of CropForeground
 // (generate_spatial_bounding_box, monai/transforms/utils.py:1069-1129) and its crop + constant pad
-// (monai/transforms/croppad/array.py:776-960).  Channel-first fp32 volumes [C][D][H][W], lanes along W.
+// (monai/transforms/croppad/array.py:776-960), the flip + axis permutation of Orientation.  Channel-first fp32 volumes [C][D][H][W], lanes along W.
 // All three are HBM-bound: scale reads 4 B + writes 4 B per voxel, the box reads C x 4 B per voxel and writes 24 B per
 // workgroup, crop+pad reads <= 4 B and writes 4 B per output voxel.
 #pragma once
@@ -116,6 +116,20 @@ __global__ void __launch_bounds__(256) crop_pad_kernel(const float* __restrict__
     float v = value;
     if (iz >= 0 && iz < D && iy >= 0 && iy < H && ix >= 0 && ix < W) v = src[((c * D + iz) * H + iy) * (long long)W + ix];
     dst[row * Wo + x] = v;
+}
+
+// Orientation (monai/transforms/spatial/functional.py:187-229): torch.flip + permute of the spatial axes as one strided
+// gather.  dst is dense [C][Do][Ho][Wo]; output axis k walks the source with the signed element stride s_k from `base`.
+// Pure flips keep the innermost axis innermost (|sx| == 1): the wave reads one contiguous row, forwards or backwards.
+// blockIdx.x = output row (c, z, y), blockIdx.y = x chunk.
+__global__ void __launch_bounds__(256) flip_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int Do, int Ho, int Wo,
+                                                           long long c_stride, long long base, long long sz, long long sy, long long sx) {
+    const int x = blockIdx.y * 256 + threadIdx.x;
+    if (x >= Wo) return;
+    const long long row = blockIdx.x;
+    const int y = (int)(row % Ho), z = (int)((row / Ho) % Do);
+    const long long c = row / ((long long)Ho * Do);
+    dst[row * Wo + x] = src[c * c_stride + base + z * sz + y * sy + x * sx];
 }
 
 }  // namespace mh

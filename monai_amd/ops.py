@@ -338,3 +338,28 @@ def crop_pad(src: torch.Tensor, start: Sequence[int], size: Sequence[int], value
         _lib.lib().call("mh_crop_pad_f32", _lib.ptr(src), _lib.ptr(out), c, d, h, w, do, ho, wo, int(start[0]), int(start[1]), int(start[2]),
                         float(value), _s(src))
     return out
+
+
+def groupnorm_finalize(stats, tiles: int, n: int, c: int, groups: int, gamma, beta, eps: float, slope: float, nrm: torch.Tensor):
+    """GroupNorm flavour of `instnorm_finalize`: the records of the C / groups channels of a group are merged; every channel
+    gets {alpha = gamma_c / sqrt(var_g + eps), beta = beta_c - mean_g * alpha, slope, 0}."""
+    _lib.require_device(stats, gamma, beta, nrm)
+    if nrm.dim() != 3 or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
+        raise RuntimeError("monai_amd.groupnorm_finalize: nrm must be a [N,C,4] slice")
+    ns = nrm.stride(0) if n > 1 else max(nrm.stride(0), 4 * c)
+    _lib.lib().call("mh_groupnorm_finalize_f32", _lib.ptr(stats), int(tiles), int(n), int(c), int(groups), _lib.ptr(gamma), _lib.ptr(beta),
+                    float(eps), float(slope), _lib.ptr(nrm), int(ns), _s(stats))
+    return nrm
+
+
+def flip_permute(src: torch.Tensor, perm: Sequence[int], flip: Sequence[bool]) -> torch.Tensor:
+    """src [C, D, H, W] -> [C, size[perm[0]], size[perm[1]], size[perm[2]]]: output axis k is input axis perm[k]; input axis a is
+    reversed when flip[a] (== torch.flip over those axes followed by permute)."""
+    _lib.require_device(src)
+    if src.dim() != 4 or not src.is_contiguous() or not src.numel():
+        raise RuntimeError("monai_amd.flip_permute: contiguous non-empty [C, D, H, W] tensor required")
+    size = [int(v) for v in src.shape[1:]]
+    out = torch.empty((int(src.shape[0]),) + tuple(size[int(p)] for p in perm), dtype=torch.float32, device=src.device)
+    _lib.lib().call("mh_flip_permute_f32", _lib.ptr(src), _lib.ptr(out), int(src.shape[0]), _lib.int_array(size), _lib.int_array(perm),
+                    _lib.int_array([1 if f else 0 for f in flip]), _s(src))
+    return out

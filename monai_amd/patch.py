@@ -47,11 +47,15 @@ _TARGETS = {
         "Spacing": ("monai_amd.transforms.spatial.array", "Spacing"),
         "SpatialResample": ("monai_amd.transforms.spatial.array", "SpatialResample"),
         "Resample": ("monai_amd.transforms.spatial.array", "Resample"),
+        "Orientation": ("monai_amd.transforms.spatial.orientation", "Orientation"),
     },
     "monai.transforms.spatial.dictionary": {
         "Spacingd": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
         "SpacingD": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
         "SpacingDict": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
+        "Orientationd": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
+        "OrientationD": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
+        "OrientationDict": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
     },
     "monai.transforms.intensity.array": {
         "GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth"),

@@ -3,5 +3,5 @@ from .intensity import (  # noqa: F401
     GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
     ScaleIntensityRanged,
 )
-from .spatial import Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401
+from .spatial import Orientation, OrientationD, OrientationDict, Orientationd, Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401
 from .post import Activations, ActivationsD, ActivationsDict, Activationsd, AsDiscrete, AsDiscreteD, AsDiscreteDict, AsDiscreted  # noqa: F401

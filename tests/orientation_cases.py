@@ -1,0 +1,123 @@
+"""Orientation cases.  The reference's Orientation needs nibabel, which is not installed in the build container, so these are
+the KNOWN-ANSWER tables of the reference's own unit tests restated (tests/transforms/test_orientation.py:29-187: image, affine,
+expected data, expected axis codes of the result's affine), plus kernel-level checks against torch.flip + permute and the
+inverse round trip."""
+import numpy as np
+import torch
+
+
+def _rot3(a, b, c):
+    """monai/transforms/utils.py create_rotate(3, (a, b, c)): Rx(a) @ Ry(b) @ Rz(c)"""
+    rx, ry, rz = np.eye(4), np.eye(4), np.eye(4)
+    rx[1, 1], rx[1, 2], rx[2, 1], rx[2, 2] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    ry[0, 0], ry[0, 2], ry[2, 0], ry[2, 2] = np.cos(b), np.sin(b), -np.sin(b), np.cos(b)
+    rz[0, 0], rz[0, 1], rz[1, 0], rz[1, 1] = np.cos(c), -np.sin(c), np.sin(c), np.cos(c)
+    return rx @ ry @ rz
+
+
+def _rot2(a):
+    r = np.eye(3)
+    r[0, 0], r[0, 1], r[1, 0], r[1, 1] = np.cos(a), -np.sin(a), np.sin(a), np.cos(a)
+    return r
+
+
+def _trans(n, t):
+    m = np.eye(n + 1)
+    m[:n, -1] = t
+    return m
+
+
+A3 = _trans(3, (10, 20, 30)) @ _rot3(np.pi / 2, np.pi / 2, np.pi / 4) @ np.diag([-1, 1, 1, 1])
+A2 = _trans(2, (10, 20)) @ _rot2(np.pi / 3) @ np.diag([-1, -0.2, 1])
+
+# (init kwargs, image, affine, expected data, expected axis codes)  -- test_orientation.py:29-157 (the 4-D rows are not on the HIP path)
+TABLE = [
+    ({"axcodes": "RAS"}, torch.arange(12).reshape((2, 1, 2, 3)), np.eye(4), torch.arange(12).reshape((2, 1, 2, 3)), "RAS"),
+    ({"axcodes": "ALS"}, torch.arange(12).reshape((2, 1, 2, 3)), np.diag([-1, -1, 1, 1]),
+     torch.tensor([[[[3, 4, 5]], [[0, 1, 2]]], [[[9, 10, 11]], [[6, 7, 8]]]]), "ALS"),
+    ({"axcodes": "RAS"}, torch.arange(12).reshape((2, 1, 2, 3)), np.diag([-1, -1, 1, 1]),
+     torch.tensor([[[[3, 4, 5], [0, 1, 2]]], [[[9, 10, 11], [6, 7, 8]]]]), "RAS"),
+    ({"axcodes": "AL"}, torch.arange(6).reshape((2, 1, 3)), np.eye(3), torch.tensor([[[0], [1], [2]], [[3], [4], [5]]]), "AL"),
+    ({"axcodes": "L"}, torch.arange(6).reshape((2, 3)), np.eye(2), torch.tensor([[2, 1, 0], [5, 4, 3]]), "L"),
+    ({"axcodes": "L"}, torch.arange(6).reshape((2, 3)), np.diag([-1, 1]), torch.arange(6).reshape((2, 3)), "L"),
+    ({"axcodes": "LPS"}, torch.arange(12).reshape((2, 1, 2, 3)), A3,
+     torch.tensor([[[[2, 5]], [[1, 4]], [[0, 3]]], [[[8, 11]], [[7, 10]], [[6, 9]]]]), "LPS"),
+    ({"as_closest_canonical": True}, torch.arange(12).reshape((2, 1, 2, 3)), A3,
+     torch.tensor([[[[0, 3]], [[1, 4]], [[2, 5]]], [[[6, 9]], [[7, 10]], [[8, 11]]]]), "RAS"),
+    ({"as_closest_canonical": True}, torch.arange(6).reshape((1, 2, 3)), A2, torch.tensor([[[3, 0], [4, 1], [5, 2]]]), "RA"),
+    ({"axcodes": "LP"}, torch.arange(6).reshape((1, 2, 3)), A2, torch.tensor([[[2, 5], [1, 4], [0, 3]]]), "LP"),
+]
+
+
+def case_orientation_reference_tables(device):
+    """every 1-3-D row of the reference's table: data exact, axis codes of the new affine as expected"""
+    from monai_amd.data.meta_tensor import MetaTensor
+    from monai_amd.transforms import Orientation
+    from monai_amd.transforms.spatial.orientation import aff2axcodes
+
+    for kw, img, affine, exp, code in TABLE:
+        res = Orientation(**kw)(MetaTensor(img.float().to(device), affine=torch.as_tensor(affine)))
+        assert tuple(res.shape) == tuple(exp.shape), (kw, res.shape, exp.shape)
+        assert torch.equal(res.as_tensor().cpu(), exp.float()), (kw, res)
+        assert "".join(aff2axcodes(np.asarray(res.affine))) == code, (kw, aff2axcodes(np.asarray(res.affine)), code)
+    return len(TABLE)
+
+
+def case_orientation_kernel_and_inverse(device):
+    """all 48 axis-code triples on a ragged volume: the kernel equals torch.flip + permute of the same orientation; world
+    coordinates of every voxel are preserved by the new affine; inverse() restores data and affine (test_orientation.py:221-233)"""
+    import itertools
+
+    from monai_amd.data.meta_tensor import MetaTensor
+    from monai_amd.transforms import Orientation, Orientationd
+    from monai_amd.transforms.spatial.orientation import axcodes2ornt, io_orientation, ornt_transform
+
+    gen = torch.Generator().manual_seed(31)
+    x = torch.rand((2, 5, 7, 66), generator=gen)
+    affine = _trans(3, (3.0, -4.0, 5.5)) @ _rot3(0.2, -0.1, 0.3) @ np.diag([0.8, -1.2, 2.0, 1.0])
+    n = 0
+    for axes in itertools.permutations(range(3)):
+        for signs in itertools.product((0, 1), repeat=3):
+            code = "".join((("L", "R"), ("P", "A"), ("I", "S"))[a][s] for a, s in zip(axes, signs))
+            img = MetaTensor(x.to(device), affine=torch.as_tensor(affine))
+            tr = Orientation(axcodes=code)
+            res = tr(img)
+            ornt = ornt_transform(io_orientation(affine), axcodes2ornt(code))
+            exp = torch.flip(x, [i + 1 for i, f in enumerate(ornt[:, 1]) if f == -1]).permute([0] + [int(v) + 1 for v in np.argsort(ornt[:, 0])])
+            assert torch.equal(res.as_tensor().cpu(), exp), code
+            # voxel (i, j, k) of the result and its source voxel share world coordinates
+            new_aff = np.asarray(res.affine)
+            idx = np.array([1, 2, 3, 1.0])
+            src_idx = np.linalg.solve(affine, new_aff @ idx)
+            si = np.rint(src_idx[:3]).astype(int)
+            assert np.allclose(src_idx[:3], si, atol=1e-9) and float(x[0, si[0], si[1], si[2]]) == float(exp[0, 1, 2, 3]), code
+            back = tr.inverse(res)
+            assert torch.equal(back.as_tensor().cpu(), x) and np.allclose(np.asarray(back.affine), affine, atol=1e-12), code
+            assert len(back.applied_operations) == 0
+            n += 1
+    d = Orientationd(keys=["image", "label"], axcodes="LPS")({"image": MetaTensor(x.to(device), affine=torch.as_tensor(affine)),
+                                                             "label": MetaTensor(x.to(device), affine=torch.as_tensor(affine))})
+    assert torch.equal(d["image"].as_tensor(), d["label"].as_tensor())
+    return n
+
+
+def case_orientation_api(device):
+    import pytest
+
+    from monai_amd.data.meta_tensor import MetaTensor
+    from monai_amd.transforms import Orientation, Orientationd
+
+    with pytest.raises(ValueError):
+        Orientation()
+    with pytest.warns(UserWarning):
+        Orientation(axcodes="RAS", as_closest_canonical=True)
+    x = torch.arange(12.0).reshape((2, 1, 2, 3)).to(device)
+    with pytest.raises(ValueError):                                  # test_orientation.py:182-186: too short axcodes
+        Orientation(axcodes="RA")(MetaTensor(x, affine=torch.eye(4)))
+    with pytest.warns(UserWarning):                                  # plain tensors: identity affine assumed
+        y = Orientation(axcodes="LPS")(x)
+    assert torch.equal(y.cpu(), torch.flip(x.cpu(), [1, 2]))
+    with pytest.raises(NotImplementedError):
+        Orientation(axcodes="RAS", lazy=True)
+    with pytest.raises(KeyError):
+        Orientationd(keys=["missing"], axcodes="RAS")({"image": x})

@@ -137,3 +137,16 @@ def test_preproc_api(emu):
     import preproc_cases as pc
 
     pc.case_preproc_api("cpu")
+
+
+def test_orientation_reference_tables(emu):
+    import orientation_cases as oc
+
+    print("rows", oc.case_orientation_reference_tables("cpu"))
+    oc.case_orientation_api("cpu")
+
+
+def test_orientation_kernel_and_inverse(emu):
+    import orientation_cases as oc
+
+    print("axis codes", oc.case_orientation_kernel_and_inverse("cpu"))

@@ -53,3 +53,11 @@ def test_loaded_extension_runs_on_the_device():
     assert m.axpb_f32(x.data_ptr(), y.data_ptr(), x.numel(), 0.5, torch.cuda.current_stream().cuda_stream) == 0
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), 2 * x.cpu() + 0.5)
+
+
+def test_orientation():
+    import orientation_cases as oc
+
+    print("rows", oc.case_orientation_reference_tables(DEV))
+    print("axis codes", oc.case_orientation_kernel_and_inverse(DEV))
+    oc.case_orientation_api(DEV)
