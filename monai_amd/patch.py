@@ -41,6 +41,7 @@ _TARGETS = {
         "DynUnet": ("monai_amd.networks.nets.dynunet", "DynUNet"),
         "Dynunet": ("monai_amd.networks.nets.dynunet", "DynUNet"),
     },
+    "monai.networks.nets.segresnet": {"SegResNet": ("monai_amd.networks.nets.segresnet", "SegResNet")},
     "monai.networks.nets.unetr": {"UNETR": ("monai_amd.networks.nets.unetr", "UNETR")},
     "monai.networks.nets.unet": {"UNet": ("monai_amd.networks.nets.unet", "UNet"), "Unet": ("monai_amd.networks.nets.unet", "UNet")},
     "monai.transforms.spatial.array": {

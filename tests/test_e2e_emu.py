@@ -67,3 +67,11 @@ def test_dynunet_sliding_window_vs_reference(emu):
     import dynunet_cases as dc
 
     print("max |dlogit|", dc.case_dynunet_sliding_window("cpu"))
+
+
+def test_segresnet_vs_reference(emu):
+    import segresnet_cases as sc
+
+    print("max |dlogit|", sc.case_segresnet_vs_reference("cpu"))
+    print("sliding window", sc.case_segresnet_sliding_window("cpu"))
+    sc.case_segresnet_api("cpu")

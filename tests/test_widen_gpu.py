@@ -61,3 +61,11 @@ def test_orientation():
     print("rows", oc.case_orientation_reference_tables(DEV))
     print("axis codes", oc.case_orientation_kernel_and_inverse(DEV))
     oc.case_orientation_api(DEV)
+
+
+def test_segresnet_vs_reference():
+    import segresnet_cases as sc
+
+    print("max |dlogit|", sc.case_segresnet_vs_reference(DEV))
+    print("sliding window", sc.case_segresnet_sliding_window(DEV))
+    sc.case_segresnet_api(DEV)
