@@ -75,3 +75,9 @@ def test_segresnet_vs_reference(emu):
     print("max |dlogit|", sc.case_segresnet_vs_reference("cpu"))
     print("sliding window", sc.case_segresnet_sliding_window("cpu"))
     sc.case_segresnet_api("cpu")
+
+
+def test_ct_bundle_pipeline_vs_reference(emu):
+    import pipeline_ct_case as pc
+
+    print(pc.case_ct_pipeline_vs_reference("cpu"))

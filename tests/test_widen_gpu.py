@@ -69,3 +69,9 @@ def test_segresnet_vs_reference():
     print("max |dlogit|", sc.case_segresnet_vs_reference(DEV))
     print("sliding window", sc.case_segresnet_sliding_window(DEV))
     sc.case_segresnet_api(DEV)
+
+
+def test_ct_bundle_pipeline_vs_reference():
+    import pipeline_ct_case as pc
+
+    print(pc.case_ct_pipeline_vs_reference(DEV))
