@@ -127,8 +127,9 @@ def main():
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
     ap.add_argument("--cpu-windows", type=int, default=12, help="windows timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr", "unet"],
-                    help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11)")
+    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr", "unet", "dynunet", "segresnet"],
+                    help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
+                         "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16) (SURVEY 8f-4)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -145,7 +146,7 @@ def main():
 
     from monai_amd import _prof, parallel
     from monai_amd.inferers import SlidingWindowInferer
-    from monai_amd.networks.nets import UNETR, BasicUNet, UNet
+    from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, UNet
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -158,6 +159,10 @@ def main():
         net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
     elif args.net == "unet":
         net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2).eval().to(dev)
+    elif args.net == "dynunet":
+        net = DynUNet(spatial_dims=3, in_channels=1, out_channels=5, kernel_size=[3] * 5, strides=[1, 2, 2, 2, 2], upsample_kernel_size=[2] * 4).eval().to(dev)
+    elif args.net == "segresnet":
+        net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=5).eval().to(dev)
     else:
         net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
     torch.manual_seed(0)
@@ -255,7 +260,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{ {'unetr': 'UNETR ViT-B/16', 'unet': 'UNet 16-256 res2', 'basicunet': 'BasicUNet'}[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
+                "workload": f"{ {'unetr': 'UNETR ViT-B/16', 'unet': 'UNet 16-256 res2', 'basicunet': 'BasicUNet', 'dynunet': 'DynUNet 32-320 (5 levels)', 'segresnet': 'SegResNet f16'}[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
                             f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },

@@ -126,6 +126,25 @@ class CropForeground:
                                        "extra_info": {"box_start": start, "box_end": end, "pad_value": value}})
         return res
 
+    def inverse(self, img):
+        """Undo the most recent crop + pad (array.py:950-960: crop the padding away, zero-pad back to the original size) -- the
+        same kernel with the negated start: voxels outside the crop box come back as 0."""
+        if not is_meta(img) or not getattr(img, "applied_operations", None):
+            raise RuntimeError("monai_amd.CropForeground.inverse: a MetaTensor with the forward call's record is required")
+        rec = img.applied_operations[-1]
+        if rec.get("class") != type(self).__name__:
+            raise RuntimeError(f"monai_amd.CropForeground.inverse: the most recent operation is {rec.get('class')!r}")
+        data = img.as_tensor()
+        start, orig = rec["extra_info"]["box_start"], tuple(int(v) for v in rec["orig_size"])
+        nsp = len(orig)
+        out = ops.crop_pad(_as4(data), [0] * (3 - nsp) + [-s for s in start], [1] * (3 - nsp) + list(orig), 0.0).reshape((data.shape[0],) + orig)
+        res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
+        aff = np.asarray(img.meta["affine"], dtype=np.float64)
+        shift = np.eye(aff.shape[0])
+        shift[:nsp, -1] = [-s for s in start][: aff.shape[0] - 1]
+        res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
+        return res
+
     def __call__(self, img, mode: str | None = None, lazy: bool | None = None, **pad_kwargs):
         if lazy:
             raise NotImplementedError("monai_amd.CropForeground: lazy execution is not implemented")

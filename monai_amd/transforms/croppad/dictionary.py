@@ -41,5 +41,14 @@ class CropForegroundd:
             d[key] = self.cropper.crop_pad(img=d[key], box_start=box_start, box_end=box_end, mode=m)
         return d
 
+    def inverse(self, data):
+        d = dict(data)
+        for key in self.keys:
+            if key in d:
+                d[key] = self.cropper.inverse(d[key])
+            elif not self.allow_missing_keys:
+                raise KeyError(f"Key `{key}` of transform `{type(self).__name__}` was missing in the data and allow_missing_keys==False.")
+        return d
+
 
 CropForegroundD = CropForegroundDict = CropForegroundd

@@ -87,8 +87,13 @@ def run_all(mod_transforms, device, make_meta):
         out[name + "__start"] = np.asarray(s)
         out[name + "__end"] = np.asarray(e)
         if img.dim() == 4:
-            m = mod_transforms.CropForeground(**kw)(make_meta(img, aff))
+            tr = mod_transforms.CropForeground(**kw)
+            m = tr(make_meta(img, aff))
             out[name + "__affine"] = np.asarray(torch.as_tensor(m.affine).cpu(), dtype=np.float64)
+            if m.numel():
+                inv = tr.inverse(m)
+                out[name + "__inverse"] = torch.as_tensor(inv).cpu().numpy()
+                out[name + "__inverse_affine"] = np.asarray(torch.as_tensor(inv.affine).cpu(), dtype=np.float64)
     img, lab = blob(9).to(device), (blob(9) > 0).float().to(device)
     d = mod_transforms.CropForegroundd(keys=["image", "label"], source_key="label", margin=1, k_divisible=2)({"image": img, "label": lab})
     out["cropd_image"] = torch.as_tensor(d["image"]).cpu().numpy()
@@ -113,7 +118,7 @@ def case_preproc_vs_reference(device):
         assert y.shape == exp.shape, (name, y.shape, exp.shape)
         if name.endswith(("__start", "__end", "_start", "_end")):
             np.testing.assert_array_equal(y.astype(np.int64), exp.astype(np.int64), err_msg=name)
-        elif name.endswith("__affine"):
+        elif name.endswith("affine"):
             np.testing.assert_allclose(y, exp, rtol=0, atol=1e-12, err_msg=name)
         else:
             assert y.dtype == exp.dtype, (name, y.dtype, exp.dtype)
