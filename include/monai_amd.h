@@ -238,6 +238,13 @@ int mh_foreground_bbox_f32(const float* src, int C, int D, int H, int W, int32_t
 int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, int Do, int Ho, int Wo, int sz, int sy, int sx, float value,
                     void* stream);
 
+/* NormalizeIntensity (monai/transforms/intensity/array.py:816-907).  src = C runs of n contiguous values (C = 1: whole image;
+ * C = channels: channel_wise).  _stats: subdiv (DEVICE float[C][2]) = {mean, population std (0 -> 1)} of all / the non-zero
+ * values of each run, fp64 accumulation; workspace: DEVICE double[mh_normalize_stats_workspace_doubles(C, n)], caller-owned.
+ * _apply: dst = (src - subdiv[c][0]) / subdiv[c][1]; with nonzero != 0 zeros pass through unchanged.  No host synchronisation. */
+int64_t mh_normalize_stats_workspace_doubles(int C, int64_t n);
+int mh_normalize_stats_f32(const float* src, int C, int64_t n, int nonzero, double* workspace, float* subdiv, void* stream);
+int mh_normalize_apply_f32(const float* src, float* dst, int C, int64_t n, int nonzero, const float* subdiv, void* stream);
 /* Orientation (monai/transforms/spatial/functional.py:187-229: torch.flip over the reversed axes, then permute):
  * src [C][in_size3] -> dst [C][out], out axis k = input axis perm3[k] (HOST int32[3], a permutation of 0..2), input axis a
  * read backwards when flip3[a] != 0 (HOST int32[3]).  Images with fewer spatial axes pass leading extents of 1. */

@@ -67,6 +67,9 @@ SIGNATURES = {
     "mh_instnorm_finalize_f32": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _L, _P]),
     "mh_groupnorm_finalize_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _F, _F, _P, _L, _P]),
     "mh_flip_permute_f32": (_I, [_P, _P, _I, _IA, _IA, _IA, _P]),
+    "mh_normalize_stats_workspace_doubles": (_L, [_I, _L]),
+    "mh_normalize_stats_f32": (_I, [_P, _I, _L, _I, _P, _P, _P]),
+    "mh_normalize_apply_f32": (_I, [_P, _P, _I, _L, _I, _P, _P]),
     "mh_maxpool2_f32": (_I, [_T, _T, _P]),
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),

@@ -782,6 +782,41 @@ int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, in
     return launched("crop_pad");
 }
 
+static inline int normalize_parts(int64_t n) {
+    const long long want = (n + 4095) / 4096;        // >= 16 voxels per lane
+    return (int)(want < 1 ? 1 : want > 1024 ? 1024 : want);
+}
+
+int64_t mh_normalize_stats_workspace_doubles(int C, int64_t n) {
+    if (C < 1 || n < 1) return fail(MH_ERR_ARG, "normalize_stats: bad argument");
+    return (int64_t)C * normalize_parts(n) * 3;
+}
+
+int mh_normalize_stats_f32(const float* src, int C, int64_t n, int nonzero, double* workspace, float* subdiv, void* stream) {
+    if (!src || !workspace || !subdiv || C < 1 || C > 65535 || n < 1) return fail(MH_ERR_ARG, "normalize_stats: bad argument");
+    const int parts = normalize_parts(n);
+    const bool vec = aligned(src, 16) && n % 4 == 0;
+    const dim3 grid((unsigned)parts, (unsigned)C);
+#define MH_NS_LAUNCH(NZ_, V_) hipLaunchKernelGGL((masked_stats_kernel<NZ_, V_>), grid, dim3(256), 0, (hipStream_t)stream, src, (long long)n, workspace)
+    if (nonzero) { if (vec) MH_NS_LAUNCH(true, true); else MH_NS_LAUNCH(true, false); }
+    else { if (vec) MH_NS_LAUNCH(false, true); else MH_NS_LAUNCH(false, false); }
+#undef MH_NS_LAUNCH
+    hipLaunchKernelGGL(masked_stats_finalize_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, workspace, parts, subdiv);
+    return launched("normalize_stats");
+}
+
+int mh_normalize_apply_f32(const float* src, float* dst, int C, int64_t n, int nonzero, const float* subdiv, void* stream) {
+    if (!src || !dst || !subdiv || C < 1 || C > 65535 || n < 1) return fail(MH_ERR_ARG, "normalize_apply: bad argument");
+    if (n > 0x7fffffffLL * 1024) return fail(MH_ERR_UNSUPPORTED, "normalize_apply: problem too large for one launch");
+    const bool vec = aligned(src, 16) && aligned(dst, 16) && n % 4 == 0;
+    const dim3 grid(blocks_for((n + 3) / 4), (unsigned)C);
+#define MH_NA_LAUNCH(NZ_, V_) hipLaunchKernelGGL((masked_normalize_kernel<NZ_, V_>), grid, dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, subdiv)
+    if (nonzero) { if (vec) MH_NA_LAUNCH(true, true); else MH_NA_LAUNCH(true, false); }
+    else { if (vec) MH_NA_LAUNCH(false, true); else MH_NA_LAUNCH(false, false); }
+#undef MH_NA_LAUNCH
+    return launched("normalize_apply");
+}
+
 int mh_flip_permute_f32(const float* src, float* dst, int C, const int32_t* in_size3, const int32_t* perm3, const int32_t* flip3, void* stream) {
     if (!src || !dst || !in_size3 || !perm3 || !flip3 || C < 1) return fail(MH_ERR_ARG, "flip_permute: bad argument");
     int seen = 0;

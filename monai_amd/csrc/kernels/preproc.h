@@ -1,7 +1,7 @@
 // Intensity / crop pre-processing in front of the sliding-window path: ScaleIntensityRange
 // (monai/transforms/intensity/array.py:958-1012), the foreground bounding box of CropForeground
 // (generate_spatial_bounding_box, monai/transforms/utils.py:1069-1129) and its crop + constant pad
-// (monai/transforms/croppad/array.py:776-960), the flip + axis permutation of Orientation.  Channel-first fp32 volumes [C][D][H][W], lanes along W.
+// (monai/transforms/croppad/array.py:776-960), the flip + axis permutation of Orientation, NormalizeIntensity.  Channel-first fp32 volumes [C][D][H][W], lanes along W.
 // All three are HBM-bound: scale reads 4 B + writes 4 B per voxel, the box reads C x 4 B per voxel and writes 24 B per
 // workgroup, crop+pad reads <= 4 B and writes 4 B per output voxel.
 #pragma once
@@ -130,6 +130,83 @@ __global__ void __launch_bounds__(256) flip_permute_kernel(const float* __restri
     const int y = (int)(row % Ho), z = (int)((row / Ho) % Do);
     const long long c = row / ((long long)Ho * Do);
     dst[row * Wo + x] = src[c * c_stride + base + z * sz + y * sy + x * sx];
+}
+
+// NormalizeIntensity (monai/transforms/intensity/array.py:816-907): (x - mean) / std over the whole image or per channel,
+// optionally over the non-zero voxels only (which are then the only ones rewritten).  Statistics: fp64 sums {count, sum, sum of
+// squares} per lane, wave shuffles, one record per workgroup; a one-wave finalize per channel turns the records into the fp32
+// {subtrahend, divisor} pair the reference gets from torch.mean / torch.std(unbiased=False) (divisor 0 -> 1), left in device
+// memory for the apply pass: no host round trip between the two.  Both passes are HBM-bound: 4 B read per voxel, then 4 + 4 B.
+template <bool NONZERO, bool VEC>
+__global__ void __launch_bounds__(256) masked_stats_kernel(const float* __restrict__ src, long long n, double* __restrict__ partial) {
+    const float* p = src + (long long)blockIdx.y * n;
+    double cnt = 0.0, s = 0.0, ss = 0.0;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (VEC) {
+        for (long long i = t0; i < n / 4; i += step) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (!NONZERO || e[k] != 0.0f) { cnt += 1.0; s += (double)e[k]; ss += (double)e[k] * (double)e[k]; }
+        }
+    } else {
+        for (long long i = t0; i < n; i += step) {
+            const float v = p[i];
+            if (!NONZERO || v != 0.0f) { cnt += 1.0; s += (double)v; ss += (double)v * (double)v; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    __shared__ double red[4][3];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = cnt; red[wave][1] = s; red[wave][2] = ss; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double* o = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 3;
+        o[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    }
+}
+
+// one wave per channel: fold `nparts` records -> subdiv[c] = {mean, std or 1}
+__global__ void __launch_bounds__(64) masked_stats_finalize_kernel(const double* __restrict__ partial, int nparts, float* __restrict__ subdiv) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const double* rec = partial + (long long)c * nparts * 3;
+    double cnt = 0.0, s = 0.0, ss = 0.0;
+    for (int i = lane; i < nparts; i += 64) { cnt += rec[i * 3]; s += rec[i * 3 + 1]; ss += rec[i * 3 + 2]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o); s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (lane == 0) {
+        const double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float sd = (float)sqrt(var);
+        subdiv[2 * c] = (float)mean;
+        subdiv[2 * c + 1] = sd == 0.0f ? 1.0f : sd;      // array.py:866-868 (a NaN std stays NaN, as in the reference)
+    }
+}
+
+template <bool NONZERO, bool VEC>
+__global__ void __launch_bounds__(256) masked_normalize_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
+                                                               const float* __restrict__ subdiv) {
+    const long long off = (long long)blockIdx.y * n;
+    const float sub = subdiv[2 * blockIdx.y], div = subdiv[2 * blockIdx.y + 1];
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (VEC && i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + off + i);
+        float4 r;
+        r.x = (NONZERO && v.x == 0.0f) ? v.x : (v.x - sub) / div;
+        r.y = (NONZERO && v.y == 0.0f) ? v.y : (v.y - sub) / div;
+        r.z = (NONZERO && v.z == 0.0f) ? v.z : (v.z - sub) / div;
+        r.w = (NONZERO && v.w == 0.0f) ? v.w : (v.w - sub) / div;
+        *reinterpret_cast<float4*>(dst + off + i) = r;
+        return;
+    }
+    for (long long j = i; j < n && j < i + 4; ++j) {
+        const float v = src[off + j];
+        dst[off + j] = (NONZERO && v == 0.0f) ? v : (v - sub) / div;
+    }
 }
 
 }  // namespace mh

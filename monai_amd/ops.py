@@ -363,3 +363,26 @@ def flip_permute(src: torch.Tensor, perm: Sequence[int], flip: Sequence[bool]) -
     _lib.lib().call("mh_flip_permute_f32", _lib.ptr(src), _lib.ptr(out), int(src.shape[0]), _lib.int_array(size), _lib.int_array(perm),
                     _lib.int_array([1 if f else 0 for f in flip]), _s(src))
     return out
+
+
+def normalize_stats(src: torch.Tensor, channels: int, n: int, nonzero: bool) -> torch.Tensor:
+    """src = `channels` runs of n contiguous fp32 values -> DEVICE table [channels, 2] of {mean, std (population; 0 -> 1)} over all
+    (or only the non-zero) values of each run.  No host synchronisation."""
+    _lib.require_device(src)
+    if not src.is_contiguous() or src.numel() != channels * n or n < 1:
+        raise RuntimeError("monai_amd.normalize_stats: contiguous tensor of channels * n elements required")
+    L = _lib.lib()
+    ws = torch.empty(L.query("mh_normalize_stats_workspace_doubles", int(channels), int(n)), dtype=torch.float64, device=src.device)
+    table = torch.empty((int(channels), 2), dtype=torch.float32, device=src.device)
+    L.call("mh_normalize_stats_f32", _lib.ptr(src), int(channels), int(n), int(bool(nonzero)), _lib.ptr(ws), _lib.ptr(table), _s(src))
+    return table
+
+
+def normalize_apply(src: torch.Tensor, channels: int, n: int, nonzero: bool, table: torch.Tensor) -> torch.Tensor:
+    """y = (x - table[c, 0]) / table[c, 1] per run c (non-zero values only when `nonzero`; zeros pass through)."""
+    _lib.require_device(src, table)
+    if not src.is_contiguous() or src.numel() != channels * n or tuple(table.shape) != (channels, 2) or not table.is_contiguous():
+        raise RuntimeError("monai_amd.normalize_apply: contiguous tensor of channels * n elements and a [channels, 2] table required")
+    out = torch.empty_like(src)
+    _lib.lib().call("mh_normalize_apply_f32", _lib.ptr(src), _lib.ptr(out), int(channels), int(n), int(bool(nonzero)), _lib.ptr(table), _s(src))
+    return out

@@ -61,6 +61,7 @@ _TARGETS = {
     "monai.transforms.intensity.array": {
         "GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth"),
         "ScaleIntensityRange": ("monai_amd.transforms.intensity.array", "ScaleIntensityRange"),
+        "NormalizeIntensity": ("monai_amd.transforms.intensity.array", "NormalizeIntensity"),
     },
     "monai.transforms.croppad.array": {"CropForeground": ("monai_amd.transforms.croppad.array", "CropForeground")},
     "monai.transforms.croppad.dictionary": {
@@ -87,6 +88,9 @@ _TARGETS = {
         "ScaleIntensityRanged": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
         "ScaleIntensityRangeD": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
         "ScaleIntensityRangeDict": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityRanged"),
+        "NormalizeIntensityd": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
+        "NormalizeIntensityD": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
+        "NormalizeIntensityDict": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
     },
     "monai.networks.layers.spatial_transforms": {
         "AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform"),

@@ -1,6 +1,7 @@
 from .croppad import CropForeground, CropForegroundD, CropForegroundDict, CropForegroundd  # noqa: F401
 from .intensity import (  # noqa: F401
-    GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
+    GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, NormalizeIntensity, NormalizeIntensityD, NormalizeIntensityDict,
+    NormalizeIntensityd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
     ScaleIntensityRanged,
 )
 from .spatial import Orientation, OrientationD, OrientationDict, Orientationd, Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401

@@ -3,9 +3,10 @@
 from __future__ import annotations
 
 from ...utils.misc import ensure_tuple
-from .array import GaussianSmooth, ScaleIntensityRange
+from .array import GaussianSmooth, NormalizeIntensity, ScaleIntensityRange
 
-__all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict", "ScaleIntensityRanged", "ScaleIntensityRangeD", "ScaleIntensityRangeDict"]
+__all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict", "ScaleIntensityRanged", "ScaleIntensityRangeD", "ScaleIntensityRangeDict",
+           "NormalizeIntensityd", "NormalizeIntensityD", "NormalizeIntensityDict"]
 
 
 class GaussianSmoothd:
@@ -39,3 +40,16 @@ class ScaleIntensityRanged(GaussianSmoothd):
 
 
 ScaleIntensityRangeD = ScaleIntensityRangeDict = ScaleIntensityRanged
+
+
+class NormalizeIntensityd(GaussianSmoothd):
+    """Dictionary version of :class:`NormalizeIntensity` (monai/transforms/intensity/dictionary.py:782-820)."""
+
+    def __init__(self, keys, subtrahend=None, divisor=None, nonzero: bool = False, channel_wise: bool = False, dtype="float32",
+                 allow_missing_keys: bool = False) -> None:
+        self.keys = ensure_tuple(keys)
+        self.allow_missing_keys = allow_missing_keys
+        self.normalizer = self.converter = NormalizeIntensity(subtrahend, divisor, nonzero, channel_wise, dtype)
+
+
+NormalizeIntensityD = NormalizeIntensityDict = NormalizeIntensityd

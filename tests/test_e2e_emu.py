@@ -81,3 +81,9 @@ def test_ct_bundle_pipeline_vs_reference(emu):
     import pipeline_ct_case as pc
 
     print(pc.case_ct_pipeline_vs_reference("cpu"))
+
+
+def test_mri_bundle_pipeline_vs_reference(emu):
+    import normalize_cases as nc
+
+    print(nc.case_mri_pipeline_vs_reference("cpu"))

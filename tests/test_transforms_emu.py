@@ -150,3 +150,10 @@ def test_orientation_kernel_and_inverse(emu):
     import orientation_cases as oc
 
     print("axis codes", oc.case_orientation_kernel_and_inverse("cpu"))
+
+
+def test_normalize_intensity_vs_reference(emu):
+    import normalize_cases as nc
+
+    print("worst relative error", nc.case_normalize_vs_reference("cpu"))
+    nc.case_normalize_api("cpu")

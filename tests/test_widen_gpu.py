@@ -75,3 +75,11 @@ def test_ct_bundle_pipeline_vs_reference():
     import pipeline_ct_case as pc
 
     print(pc.case_ct_pipeline_vs_reference(DEV))
+
+
+def test_normalize_intensity_and_mri_pipeline():
+    import normalize_cases as nc
+
+    print("worst relative error", nc.case_normalize_vs_reference(DEV))
+    nc.case_normalize_api(DEV)
+    print(nc.case_mri_pipeline_vs_reference(DEV))
