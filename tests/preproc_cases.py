@@ -70,9 +70,11 @@ def run_all(mod_transforms, device, make_meta):
     out = {}
     x = ct().to(device)
     for name, kw in SCALE_CASES:
+        # float -> uint8 of NaN / inf is implementation-defined (CPU and GPU casts may differ): the integer-output case gets finite values
+        xin = torch.nan_to_num(x, nan=0.0, posinf=1e4, neginf=-1e4) if "dtype" in kw else x
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            y = mod_transforms.ScaleIntensityRange(**kw)(x)
+            y = mod_transforms.ScaleIntensityRange(**kw)(xin)
         out[name] = torch.as_tensor(y).cpu().numpy()
     xi = (ct(1) * 0.5).to(torch.int16).to(device)
     out["scale_int16_input"] = torch.as_tensor(mod_transforms.ScaleIntensityRange(-175.0, 250.0, 0.0, 1.0, clip=True)(xi)).cpu().numpy()
