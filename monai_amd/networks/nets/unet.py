@@ -4,6 +4,9 @@ Same constructor signature, the same recursive module tree (``model.0`` down lay
 sub-block, ``model.2`` up layer; ``ResidualUnit`` = ``conv.unit{i}`` + ``residual``) and therefore the same ``state_dict``
 keys/shapes and parameter-initialisation order as the reference.
 
+``norm="batch"`` (the spleen / tutorial configuration) is on the path as well: eval-mode BatchNorm3d is a per-channel affine map, i.e. directly
+the consumer-side record, with no statistics pass at all.
+
 Inference engine over the C ABI: every conv output is stored raw with its InstanceNorm+PReLU folded into a per-(n, c)
 {alpha, beta, slope} record applied by the consumer on load (the PReLU weight is the slope); stride-1 3x3x3 convs run on the
 fp32-MFMA tiles, the strided encoder convs and the k3 transposed convs on direct kernels (UNet is 11.8 GFLOP per 96^3 window --
@@ -25,9 +28,13 @@ __all__ = ["UNet", "Unet"]
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
 class _ADN(nn.Module):
-    def __init__(self, channels: int, affine: bool):
+    def __init__(self, channels: int, affine):
         super().__init__()
-        self.N = nn.InstanceNorm3d(channels, affine=affine)
+        # `affine`: bool -> InstanceNorm3d(affine); ("batch", kwargs) -> BatchNorm3d (evaluated with its running statistics)
+        if isinstance(affine, tuple):
+            self.N = nn.BatchNorm3d(channels, **affine[1])
+        else:
+            self.N = nn.InstanceNorm3d(channels, affine=affine)
         self.D = nn.Dropout(0.0)
         self.A = nn.PReLU()
 
@@ -98,12 +105,14 @@ class UNet(nn.Module):
         act_name = (act if isinstance(act, str) else act[0]).upper()
         norm_name, norm_args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
         if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or act_name != "PRELU"
-                or str(norm_name).upper() != "INSTANCE" or dropout != 0.0 or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
-            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance norm, no dropout, strides 1/2, 'NDA'")
+                or str(norm_name).upper() not in ("INSTANCE", "BATCH") or dropout != 0.0 or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
+            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance / batch norm, no dropout, strides 1/2, 'NDA'")
         self.dimensions, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
         self.channels, self.strides, self.num_res_units, self.bias = tuple(channels), tuple(int(s) for s in strides), num_res_units, bias
         self.kernel_size, self.up_kernel_size, self.act, self.norm, self.dropout, self.adn_ordering = kernel_size, up_kernel_size, act, norm, dropout, adn_ordering
         affine = bool(norm_args.get("affine", False))
+        if str(norm_name).upper() == "BATCH":       # eval-mode BatchNorm is a per-channel affine map: it IS a {alpha, beta} record, no statistics pass
+            affine = ("batch", {k: v for k, v in norm_args.items() if k in ("eps", "momentum", "affine", "track_running_stats")})
         self.features = (channels[0],)
 
         def down(cin, cout, s):
@@ -155,6 +164,24 @@ class UNet(nn.Module):
             self._slopes[id(prelu)] = hit
         return hit[1]
 
+    def _bn_record(self, bn: nn.BatchNorm3d, slope: float, n: int) -> torch.Tensor:
+        """Eval-mode BatchNorm3d + PReLU as the consumer-side record [n, C, 4] = {alpha, beta, slope, 0}: alpha = weight / sqrt(running_var
+        + eps), beta = bias - running_mean * alpha -- the x * alpha + beta form of ATen's CPU batch norm.  A parameter fold over C values
+        (cached per parameter version), not a pass over activations."""
+        if bn.running_mean is None or bn.running_var is None:
+            raise NotImplementedError("monai_amd.UNet: BatchNorm without running statistics is not on the (inference) HIP path")
+        parts = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+        key = tuple((t.data_ptr(), t._version) for t in parts) + (slope, str(bn.running_mean.device))
+        hit = self._packed.get(("bn", id(bn)))
+        if hit is None or hit[0] != key:
+            invstd = 1.0 / torch.sqrt(bn.running_var.float() + bn.eps)
+            alpha = invstd * bn.weight.float() if bn.affine else invstd
+            beta = (bn.bias.float() if bn.affine else 0.0) - bn.running_mean.float() * alpha
+            tab = torch.stack([alpha, beta, torch.full_like(alpha, slope), torch.zeros_like(alpha)], dim=1).contiguous()
+            hit = (key, tab)
+            self._packed[("bn", id(bn))] = hit
+        return hit[1].unsqueeze(0).expand(n, -1, -1).contiguous()
+
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
         if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
             self._stats = torch.empty(floats, dtype=torch.float32, device=device)
@@ -178,7 +205,8 @@ class UNet(nn.Module):
             # the channels' true width
             tiny = s == 1 and cin <= 8 and cout <= 8
             cfg = ops.conv3d_k3_select(cin, cout, d, h, w) if (s == 1 and not tiny) else 0
-            stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and hasattr(unit, "adn")) else 0
+            wants_stats = hasattr(unit, "adn") and not isinstance(unit.adn.N, nn.BatchNorm3d)
+            stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and wants_stats) else 0
             if s == 1 and not tiny:
                 stats = self._stats_buf(n * cout * stats_tiles * 3, x.device) if stats_tiles else None
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
@@ -186,6 +214,8 @@ class UNet(nn.Module):
                 ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, s)
         if not hasattr(unit, "adn"):
             return out, None
+        if isinstance(unit.adn.N, nn.BatchNorm3d):
+            return out, self._bn_record(unit.adn.N, self._slope(unit.adn.A), n)
         if not stats_tiles:
             stats_tiles = ops.instnorm_stat_tiles(*out.shape[2:])
             stats = self._stats_buf(n * cout * stats_tiles * 3, x.device)

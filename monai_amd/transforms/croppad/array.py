@@ -120,7 +120,8 @@ class CropForeground:
         res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
         aff = np.asarray(img.meta["affine"], dtype=np.float64) if "affine" in img.meta else np.eye(4)
         shift = np.eye(aff.shape[0])
-        shift[:nsp, -1] = start[: aff.shape[0] - 1]              # crop moves the origin by +start, the front pad by -pad: in total `start`
+        r = min(nsp, aff.shape[0] - 1)
+        shift[:r, -1] = start[:r]                                # crop moves the origin by +start, the front pad by -pad: in total `start`
         res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
         res.applied_operations.append({"class": type(self).__name__, "orig_size": tuple(data.shape[1:]),
                                        "extra_info": {"box_start": start, "box_end": end, "pad_value": value}})
@@ -141,7 +142,8 @@ class CropForeground:
         res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
         aff = np.asarray(img.meta["affine"], dtype=np.float64)
         shift = np.eye(aff.shape[0])
-        shift[:nsp, -1] = [-s for s in start][: aff.shape[0] - 1]
+        r = min(nsp, aff.shape[0] - 1)
+        shift[:r, -1] = [-s for s in start][:r]
         res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
         return res
 

@@ -269,7 +269,35 @@ UNET_CFGS = {   # tests/golden/make_golden_unet.py
     "res2": dict(channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2, shape=(2, 1, 32, 32, 32), seed=4),
     "plain": dict(channels=(8, 16, 32), strides=(2, 2), num_res_units=0, shape=(1, 1, 24, 16, 16), seed=5),
     "mixed": dict(channels=(8, 16, 32), strides=(2, 1), num_res_units=1, shape=(1, 1, 16, 12, 20), seed=6),
+    # the spleen-bundle configuration: batch norm (evaluated with its running statistics), two residual units
+    "batch": dict(channels=(16, 32, 64, 128), strides=(2, 2, 2), num_res_units=2, shape=(2, 1, 32, 32, 32), seed=7, norm="batch"),
 }
+
+
+def unet_kwargs(name):
+    c = UNET_CFGS[name]
+    kw = dict(spatial_dims=3, in_channels=1, out_channels=3, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"])
+    if "norm" in c:
+        kw["norm"] = c["norm"]
+    return kw
+
+
+def perturb_unet(net, name):
+    """PReLU slopes distinguishable from the default; batch norm: non-trivial running statistics and affine parameters"""
+    gen = torch.Generator().manual_seed(600 + UNET_CFGS[name]["seed"])
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if k.endswith("adn.A.weight"):
+                v.fill_(0.1 + 0.01 * (len(k) % 7))
+            elif "norm" in UNET_CFGS[name] and k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=gen))
+            elif "norm" in UNET_CFGS[name] and k.endswith("running_var"):
+                v.copy_(0.75 + 0.5 * torch.rand(v.shape, generator=gen))
+            elif "norm" in UNET_CFGS[name] and k.endswith("adn.N.weight"):
+                v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=gen))
+            elif "norm" in UNET_CFGS[name] and k.endswith("adn.N.bias"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=gen))
+    return net
 
 
 def _full_digest(sd):
@@ -287,17 +315,13 @@ def make_unet(name, device=None):
 
     c = UNET_CFGS[name]
     torch.manual_seed(c["seed"])
-    net = UNet(spatial_dims=3, in_channels=1, out_channels=3, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"])
+    net = UNet(**unet_kwargs(name))
     init = _full_digest(net.state_dict())
-    with torch.no_grad():
-        for k, v in net.state_dict().items():
-            if k.endswith("adn.A.weight"):
-                v.fill_(0.1 + 0.01 * (len(k) % 7))
-    net = net.eval()
+    net = perturb_unet(net, name).eval()
     return (net.to(device) if device is not None else net), init
 
 
-def case_unet_vs_golden(device, names=("res2", "plain", "mixed")):
+def case_unet_vs_golden(device, names=("res2", "plain", "mixed", "batch")):
     """MONAI UNet (residual units / plain / stride-1 level) against the reference's own output: keys, init digest, logits."""
     g = np.load(os.path.join(GOLDEN, "unet.npz"))
     out = {}

@@ -134,7 +134,7 @@ def test_unetr_sliding_window_192():
 
 
 def test_unet_vs_reference():
-    print(ec.case_unet_vs_golden(DEV))
+    print(ec.case_unet_vs_golden(DEV, names=("res2", "plain", "mixed")))
 
 
 def test_unet_sliding_window_vs_oracle():
