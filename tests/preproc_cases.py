@@ -170,3 +170,37 @@ def case_preproc_api(device):
         ScaleIntensityRange(1.0, 1.0)(x)
     with pytest.raises(RuntimeError):                 # the reference's torch.clamp(img, None, None) raises the same way
         ScaleIntensityRange(0.0, 1.0, clip=True)(x)
+
+
+def case_preproc_full_size(device, edge=512):
+    """Size-independent properties at the BASELINE volume size (edge^3, one channel): the scale against the same operator sequence in
+    torch, NormalizeIntensity's output moments, the crop against a slice of the known box, Orientation against torch.flip and its
+    inverse round trip."""
+    from monai_amd.data.meta_tensor import MetaTensor
+    from monai_amd.transforms import CropForeground, NormalizeIntensity, Orientation, ScaleIntensityRange
+
+    gen = torch.Generator().manual_seed(77)
+    lo, hi = edge // 8, edge - edge // 8 - 3
+    x = torch.full((1, edge, edge, edge), -1000.0)
+    x[:, lo:hi, lo + 1:hi, lo + 2:hi] = torch.rand((1, hi - lo, hi - lo - 1, hi - lo - 2), generator=gen) * 500.0 - 200.0
+    x = x.to(device)
+    y = ScaleIntensityRange(-175.0, 250.0, 0.0, 1.0, clip=True)(x)
+    exp = torch.clamp(((x - (-175.0)) / 425.0) * 1.0 + 0.0, 0.0, 1.0)       # the device's own division may round differently: 1e-6
+    assert float((y - exp).abs().max()) <= 1e-6 and float(y.min()) == 0.0 and float(y.max()) <= 1.0
+    body = y[:, lo:hi, lo + 1:hi, lo + 2:hi]
+    assert float(body.min()) >= 0.0 and float(y.sum()) == float(y.sum())    # no NaN
+    # the body's corners are foreground with probability 1 - 1e-... only statistically; box the ">= 0" mask through a custom select_fn
+    c, s, e = CropForeground(select_fn=lambda t: t > -500.0, return_coords=True, margin=0)(x)
+    assert list(s) == [lo, lo + 1, lo + 2] and list(e) == [hi, hi, hi], (s, e)
+    assert torch.equal(c, x[:, lo:hi, lo + 1:hi, lo + 2:hi])
+    z = NormalizeIntensity(nonzero=True, channel_wise=True)(y)
+    nz = z[y != 0]
+    assert abs(float(nz.double().mean())) < 1e-4 and abs(float(nz.double().std(unbiased=False)) - 1.0) < 1e-4
+    assert bool((z[y == 0] == 0).all())
+    m = MetaTensor(x, affine=torch.as_tensor(np.diag([-0.8, -0.8, 1.6, 1.0])))
+    tr = Orientation(axcodes="RAS")
+    o = tr(m)
+    assert torch.equal(o.as_tensor(), torch.flip(x, [1, 2]))
+    assert np.allclose(np.asarray(o.affine), np.array([[0.8, 0, 0, -0.8 * (edge - 1)], [0, 0.8, 0, -0.8 * (edge - 1)], [0, 0, 1.6, 0], [0, 0, 0, 1.0]]))
+    assert torch.equal(tr.inverse(o).as_tensor(), x)
+    return edge

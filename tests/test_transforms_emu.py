@@ -157,3 +157,9 @@ def test_normalize_intensity_vs_reference(emu):
 
     print("worst relative error", nc.case_normalize_vs_reference("cpu"))
     nc.case_normalize_api("cpu")
+
+
+def test_preproc_properties_small(emu):
+    import preproc_cases as pc
+
+    pc.case_preproc_full_size("cpu", 48)      # the -m gpu run does this at 512^3

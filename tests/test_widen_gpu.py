@@ -89,3 +89,9 @@ def test_unet_batch_norm_vs_reference():
     import e2e_cases as ec
 
     print(ec.case_unet_vs_golden(DEV, names=("batch",)))
+
+
+def test_preproc_properties_at_512():
+    import preproc_cases as pc
+
+    pc.case_preproc_full_size(DEV, 512)
