@@ -124,3 +124,27 @@ def case_dynunet_api(device):
         net(torch.zeros(1, 1, 8, 8, 8, device=device))           # training mode: inference engine only
     with pytest.raises(NotImplementedError):
         net.eval().to(device)(torch.zeros(1, 1, 10, 8, 8, device=device))
+
+
+def case_nets_window_vs_oracle(device, edge=96, filters=(32, 64, 128, 256)):
+    """DynUNet (nnU-Net filters) and SegResNet on one BASELINE-sized window (edge^3) against the CPU oracle (oracle/dynunet.py, itself pinned
+    to the reference's goldens): the large-plane convolution configurations that the 32^3 goldens do not reach."""
+    from monai_amd.networks.nets import DynUNet, SegResNet
+    from oracle import dynunet as od
+
+    out = {}
+    x = torch.rand((1, 1, edge, edge, edge), generator=torch.Generator().manual_seed(4096))
+    torch.manual_seed(41)
+    net = DynUNet(3, 1, 5, [3] * len(filters), [1] + [2] * (len(filters) - 1), [2] * (len(filters) - 1), filters=list(filters)).eval()
+    with torch.no_grad():
+        exp = od.dynunet_forward(net.state_dict(), x, [1] + [2] * (len(filters) - 1))
+    y = net.to(device)(x.to(device)).cpu()
+    out["dynunet"] = (y.double() - exp.double()).abs().max().item()
+    torch.manual_seed(42)
+    seg = SegResNet(init_filters=filters[0] // 2, in_channels=1, out_channels=5, blocks_down=(1, 2, 2), blocks_up=(1, 1)).eval()
+    with torch.no_grad():
+        exp = od.segresnet_forward(seg.state_dict(), x, (1, 2, 2), (1, 1))
+    y = seg.to(device)(x.to(device)).cpu()
+    out["segresnet"] = (y.double() - exp.double()).abs().max().item()
+    assert max(out.values()) < LOGIT_TOL, out
+    return out

@@ -87,3 +87,9 @@ def test_mri_bundle_pipeline_vs_reference(emu):
     import normalize_cases as nc
 
     print(nc.case_mri_pipeline_vs_reference("cpu"))
+
+
+def test_dynunet_segresnet_window_vs_oracle(emu):
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_nets_window_vs_oracle("cpu", 48, (16, 32, 64)))     # the -m gpu run does this at 96^3 with nnU-Net filters

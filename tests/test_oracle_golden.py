@@ -288,3 +288,72 @@ def test_basic_unet_oracle_odd_window_bitwise_vs_reference(golden_dir):
     with torch.no_grad():
         y = oracle.basic_unet_forward(sd, x)
     assert np.array_equal(y.numpy(), g["out"])
+
+
+# ------------------------------------------------------------------------------------------------ widening rows
+@pytest.mark.parametrize("name", ["basic", "res_ds", "stride0"])
+def test_dynunet_oracle_vs_reference(golden_dir, name):
+    """oracle/dynunet.py against tests/golden/dynunet.npz (made by the real monai DynUNet); parameters from the product module, whose
+    keys / seeded values are themselves pinned to the reference's (tests/dynunet_cases.py)."""
+    import dynunet_cases as dc
+    from monai_amd.networks.nets import DynUNet
+    from oracle import dynunet as od
+
+    g = _load(golden_dir, "dynunet.npz")
+    net, init = dc.build(DynUNet, name)
+    assert init == str(g[f"{name}_init_sha256"])
+    kw = dc.CFGS[name]["kw"]
+    strides = [s if isinstance(s, int) else s[0] for s in kw["strides"]]
+    slope = 0.0 if kw.get("act_name") == "relu" else 0.01
+    with torch.no_grad():
+        y = od.dynunet_forward(net.state_dict(), dc.inputs(name), strides, slope, kw.get("res_block", False))
+    np.testing.assert_allclose(y.numpy(), g[f"{name}_out"], rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["default", "f16", "deconv_inst", "features"])
+def test_segresnet_oracle_vs_reference(golden_dir, name):
+    import segresnet_cases as sc
+    from monai_amd.networks.nets import SegResNet
+    from oracle import dynunet as od
+
+    g = _load(golden_dir, "segresnet.npz")
+    net, init = sc.build(SegResNet, name)
+    assert init == str(g[f"{name}_init_sha256"])
+    kw = sc.CFGS[name]["kw"]
+    inst = isinstance(kw.get("norm"), tuple) and kw["norm"][0] == "instance"
+    act = kw.get("act", ("RELU",))
+    with torch.no_grad():
+        y = od.segresnet_forward(net.state_dict(), sc.inputs(name), kw.get("blocks_down", (1, 2, 2, 4)), kw.get("blocks_up", (1, 1, 1)),
+                                 0 if inst else 8, act[1]["negative_slope"] if act[0] == "leakyrelu" else 0.0,
+                                 kw.get("upsample_mode", "nontrainable"), kw.get("use_conv_final", True))
+    np.testing.assert_allclose(y.numpy(), g[f"{name}_out"], rtol=0, atol=1e-6)
+
+
+def test_preproc_oracle_vs_reference(golden_dir):
+    """oracle/preproc.py against the real reference's outputs (tests/golden/{preproc,normalize}.npz)"""
+    import normalize_cases as nc
+    import preproc_cases as pc
+    from oracle import preproc as op
+
+    g = _load(golden_dir, "preproc.npz")
+    x = pc.ct()
+    for name, kw in pc.SCALE_CASES:
+        if "dtype" in kw:
+            continue
+        y = op.scale_intensity_range(x, kw["a_min"], kw["a_max"], kw.get("b_min"), kw.get("b_max"), kw.get("clip", False))
+        assert np.array_equal(y.numpy(), g[name], equal_nan=True), name
+    for name, make, kw in pc.CROP_CASES:
+        if "select_fn" in kw or "channel_indices" in kw or make().dim() != 4:
+            continue
+        img = make()
+        s, e = op.foreground_box(img, kw.get("margin", 0), kw.get("allow_smaller", False), kw.get("k_divisible", 1))
+        assert list(s) == list(g[name + "__start"]) and list(e) == list(g[name + "__end"]), name
+        assert np.array_equal(op.crop_pad(img, s, e, kw.get("value", 0.0)).numpy(), g[name], equal_nan=True), name
+    gn = _load(golden_dir, "normalize.npz")
+    for name, kw in nc.NORM_CASES:
+        if "subtrahend" in kw or "divisor" in kw:
+            continue
+        y = op.normalize_intensity(nc.mri(), kw.get("nonzero", False), kw.get("channel_wise", False))
+        assert np.array_equal(y.numpy(), gn[name]), name
+    t = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
+    assert torch.equal(op.flip_permute(t, [2, 0, 1], [True, False, True]), torch.flip(t, [1, 3]).permute(0, 3, 1, 2))

@@ -95,3 +95,9 @@ def test_preproc_properties_at_512():
     import preproc_cases as pc
 
     pc.case_preproc_full_size(DEV, 512)
+
+
+def test_dynunet_segresnet_96_window_vs_oracle():
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_nets_window_vs_oracle(DEV, 96, (32, 64, 128, 256)))
