@@ -151,6 +151,13 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
  * (unet.py:197-237).  packed_w is the configuration-0 layout of mh_conv3d_k3_pack_f32 ([Cin][27][Cout]). */
 int mh_conv3d_k3_strided_f32(const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out,
                              int stride, void* stream);
+/* the same with one stride per axis (DynUNet on anisotropic nnU-Net plans, e.g. strides (1, 2, 2); a kernel extent of 1 along an
+ * axis is a 3-tap kernel whose outer taps are zero -- the host expands the weights) */
+int mh_conv3d_k3_strided3_f32(const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out, int sz, int sy, int sx,
+                              void* stream);
+/* ConvTranspose3d with kernel == stride == (fz, fy, fx), each 1 or 2 (UnetUpBlock.transp_conv, monai/networks/blocks/dynunet_block.py:188-201);
+ * w in torch layout [Cin][Cout][fz][fy][fx]; out = factor * in per axis */
+int mh_deconv_ks_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out, int fz, int fy, int fx, void* stream);
 
 /* ConvTranspose3d k=3, stride s, padding 1, output_padding s-1 (+bias) of act(in): the up path (unet.py:249-294).
  * w: torch layout [Cin][Cout][3][3][3].  out dims = s * in. */

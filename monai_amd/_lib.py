@@ -74,6 +74,8 @@ SIGNATURES = {
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv3d_k3_strided_f32": (_I, [_T, _P, _P, _T, _I, _P]),
+    "mh_conv3d_k3_strided3_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _P]),
+    "mh_deconv_ks_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _P]),
     "mh_deconv_k3_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_add_act_f32": (_I, [_T, _T, _F, _T, _P]),
     "mh_pad_replicate_f32": (_I, [_T, _T, _P]),

@@ -946,16 +946,21 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
 // ------------------------------------------------------------------------------------------ UNet pieces
 int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, int stride,
                              void* stream) {
-    if (!dense_ok(in_) || !dense_ok(out_) || !packed_w || stride < 1) return fail(MH_ERR_ARG, "conv3d_k3_strided: bad argument");
+    return mh_conv3d_k3_strided3_f32(in_, packed_w, bias, out_, stride, stride, stride, stream);
+}
+
+int mh_conv3d_k3_strided3_f32(const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, int sz, int sy, int sx,
+                              void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed_w || sz < 1 || sy < 1 || sx < 1) return fail(MH_ERR_ARG, "conv3d_k3_strided: bad argument");
     const Tensor in = from_c(*in_), out = from_c(*out_);
-    if (in.N != out.N || out.D != (in.D - 1) / stride + 1 || out.H != (in.H - 1) / stride + 1 || out.W != (in.W - 1) / stride + 1)
+    if (in.N != out.N || out.D != (in.D - 1) / sz + 1 || out.H != (in.H - 1) / sy + 1 || out.W != (in.W - 1) / sx + 1)
         return fail(MH_ERR_ARG, "conv3d_k3_strided: output must be floor((in - 1) / stride) + 1");
     hipStream_t s = (hipStream_t)stream;
     const unsigned nbv = blocks_for((long long)out.D * out.H * out.W);
     if (out.C <= 8) {      // few output channels (e.g. UNet's 5-class top level): one exact-width pass, no channel guards
 #define MH_STRIDED_CASE(C_)                                                                                                     \
     case C_:                                                                                                                    \
-        hipLaunchKernelGGL((conv3d_k3_strided_kernel<C_, true>), dim3(nbv, 1u, (unsigned)out.N), dim3(256), 0, s, in, packed_w, bias, out, stride); \
+        hipLaunchKernelGGL((conv3d_k3_strided_kernel<C_, true>), dim3(nbv, 1u, (unsigned)out.N), dim3(256), 0, s, in, packed_w, bias, out, sz, sy, sx); \
         break;
         switch (out.C) {
             MH_STRIDED_CASE(1) MH_STRIDED_CASE(2) MH_STRIDED_CASE(3) MH_STRIDED_CASE(4)
@@ -966,9 +971,19 @@ int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const
     }
     constexpr int COT = 16;
     const dim3 grid(nbv, (unsigned)cdiv(out.C, COT), (unsigned)out.N);
-    if (out.C % COT == 0) hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stride);
-    else hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stride);
+    if (out.C % COT == 0) hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, sz, sy, sx);
+    else hipLaunchKernelGGL((conv3d_k3_strided_kernel<COT, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, sz, sy, sx);
     return launched("conv3d_k3_strided");
+}
+
+int mh_deconv_ks_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, int fz, int fy, int fx, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !w || fz < 1 || fz > 2 || fy < 1 || fy > 2 || fx < 1 || fx > 2)
+        return fail(MH_ERR_ARG, "deconv_ks: bad argument (factors are 1 or 2 per axis)");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D != fz * in.D || out.H != fy * in.H || out.W != fx * in.W) return fail(MH_ERR_ARG, "deconv_ks: output must be factor * input");
+    const unsigned nb = blocks_for((long long)out.D * out.H * out.W);
+    hipLaunchKernelGGL((deconv_ks_kernel<8>), dim3(nb, (unsigned)cdiv(out.C, 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out, fz, fy, fx);
+    return launched("deconv_ks");
 }
 
 int mh_deconv_k3_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, int stride, void* stream) {

@@ -51,10 +51,10 @@ conv3d_k3_direct_kernel(Tensor in, const float* __restrict__ wp, const float* __
 
 // ---------------------------------------------------------------------------------------------------
 // Strided Conv3d 3x3x3 pad 1 (UNet's down path: monai/networks/nets/unet.py:197-237 -> Convolution(strides=s)).
-// Same direct form as above with  input index = stride * output index + tap - 1;  out dims = floor((in - 1) / stride) + 1.
+// Same direct form as above with  input index = stride * output index + tap - 1  per axis;  out dims = floor((in - 1) / stride) + 1.
 template <int COT, bool FULL>     // FULL: every channel group is complete (Cout % COT == 0): no guards in the hot loop
 __global__ void __launch_bounds__(256)
-conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out, int stride) {
+conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* __restrict__ bias, Tensor out, int sz, int sy, int sx) {
     const int D = in.D, H = in.H, W = in.W, Do = out.D, Ho = out.H, Wo = out.W, Cin = in.C, Cout = out.C;
     const long long ivol = (long long)D * H * W, ovol = (long long)Do * Ho * Wo;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -69,7 +69,7 @@ conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* _
     unsigned zm = 0u, ym = 0u, xm = 0u;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int zz = z * stride + k - 1, yy = y * stride + k - 1, xx = x * stride + k - 1;
+        const int zz = z * sz + k - 1, yy = y * sy + k - 1, xx = x * sx + k - 1;      // one stride per axis (nnU-Net plans such as (1, 2, 2))
         zm |= (unsigned)(zz >= 0 && zz < D) << k; ym |= (unsigned)(yy >= 0 && yy < H) << k; xm |= (unsigned)(xx >= 0 && xx < W) << k;
         zo[k] = min(max(zz, 0), D - 1) * H * W; yo[k] = min(max(yy, 0), H - 1) * W; xo[k] = min(max(xx, 0), W - 1);
     }
@@ -96,6 +96,40 @@ conv3d_k3_strided_kernel(Tensor in, const float* __restrict__ wp, const float* _
             for (int j = 0; j < COT; ++j)
                 if (FULL || co0 + j < Cout) acc[j] = fmaf(v[tap], wrow[tap * Cout + j], acc[j]);
         }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+        if (co0 + j < Cout) dst[(long long)(co0 + j) * ovol] = acc[j];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// ConvTranspose3d with kernel == stride == (fz, fy, fx), each 1 or 2 (DynUNet's upsampling for anisotropic nnU-Net plans, e.g. (1, 2, 2):
+// monai/networks/blocks/dynunet_block.py:188-201).  Gather form: one thread = one OUTPUT voxel x COT channels; the voxel's input is
+// (z / fz, y / fy, x / fx), its tap ((z % fz) * fy + y % fy) * fx + x % fx of the torch layout [Cin][Cout][fz][fy][fx].
+template <int COT>
+__global__ void __launch_bounds__(256)
+deconv_ks_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int fz, int fy, int fx) {
+    const int Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C, Ho = out.H, Wo = out.W;
+    const long long ivol = (long long)in.D * Hi * Wi, ovol = (long long)out.D * Ho * Wo;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int co0 = blockIdx.y * COT, n = blockIdx.z;
+    if (idx >= ovol) return;
+    const int x = (int)(idx % Wo);
+    const long long t = idx / Wo;
+    const int y = (int)(t % Ho), z = (int)(t / Ho);
+    const int taps = fz * fy * fx, tap = ((z % fz) * fy + y % fy) * fx + x % fx;
+    const float* src = in.data + (long long)n * in.n_stride + ((long long)(z / fz) * Hi + y / fy) * Wi + x / fx;
+    float acc[COT];
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[j] = (bias && co0 + j < Cout) ? bias[co0 + j] : 0.0f;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float4 a = load_nrm(in, n, ci);
+        const float v = act(src[(long long)ci * ivol], a.x, a.y, a.z);
+        const float* wr = w + ((long long)ci * Cout + co0) * taps + tap;
+#pragma unroll
+        for (int j = 0; j < COT; ++j)
+            if (co0 + j < Cout) acc[j] = fmaf(v, wr[(long long)j * taps], acc[j]);
     }
     float* dst = out.data + (long long)n * out.n_stride + idx;
 #pragma unroll

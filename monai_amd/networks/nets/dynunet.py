@@ -12,7 +12,9 @@ output is stored raw with its InstanceNorm (affine) + LeakyReLU folded into a pe
 consumer applies on load; stride-1 convs run on the fp32-MFMA tiles with fused statistics, stride-2 convs on the direct
 kernel, the k2s2 transposed convs and the 1x1 head on their own kernels; the encoder output of each level is materialised
 exactly once, straight into the skip half of that level's concat buffer (``torch.cat`` never runs).
-On the HIP path: 3-D, kernel 3, strides 1 / 2 (isotropic), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
+On the HIP path: 3-D, kernel extents 1 / 3 and strides 1 / 2 PER AXIS (anisotropic nnU-Net plans such as kernel (1, 3, 3), stride (1, 2, 2): an
+extent-1 axis runs as a 3-tap kernel with zero outer taps, per-axis strides on the direct kernel, kernel == stride transposed convs on a gather
+kernel), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
 no dropout, ``res_block`` False or True; deep-supervision heads are parameters only (they feed the training loss, the
 inference output does not depend on them)."""
 
@@ -28,41 +30,48 @@ from ... import _lib, _prof, ops
 __all__ = ["DynUNet", "DynUnet", "Dynunet"]
 
 
-def _iso(v, what: str) -> int:
-    """an int or an isotropic 3-sequence -> int"""
+def _triple(v, what: str, allowed) -> tuple:
+    """an int or a 3-sequence -> (z, y, x) ints, each one of `allowed`"""
     if isinstance(v, (list, tuple)):
         if len(v) != 3:
             raise ValueError(f"length of {what} should be the same as spatial_dims.")
-        if len(set(int(a) for a in v)) != 1:
-            raise NotImplementedError(f"monai_amd.DynUNet: anisotropic {what} {tuple(v)} is not on the HIP path")
-        return int(v[0])
-    return int(v)
+        t = tuple(int(a) for a in v)
+    else:
+        t = (int(v),) * 3
+    if any(a not in allowed for a in t):
+        raise NotImplementedError(f"monai_amd.DynUNet: {what} {t} is not on the HIP path (per axis: {sorted(allowed)})")
+    return t
+
+
+def _out_size(size, stride):
+    return tuple((int(v) - 1) // s + 1 for v, s in zip(size, stride))
 
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
 class _Conv(nn.Module):
     """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose only child is ``conv``"""
 
-    def __init__(self, cin, cout, k, stride=1, transposed=False, bias=False):
+    def __init__(self, cin, cout, k, stride=(1, 1, 1), transposed=False, bias=False):
         super().__init__()
+        k = (k,) * 3 if isinstance(k, int) else tuple(k)
         if transposed:
             self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, bias=bias)
-        else:
-            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=(k - stride + 1) // 2, bias=bias)
+        else:       # get_padding, dynunet_block.py:304-315: (k - s + 1) / 2 per axis, truncated
+            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=tuple((a - b + 1) // 2 for a, b in zip(k, stride)), bias=bias)
 
 
 class _Block(nn.Module):
     """UnetBasicBlock (dynunet_block.py:114-166) / UnetResBlock (:25-111): same children in the same order"""
 
-    def __init__(self, cin, cout, stride, affine, slope, res):
+    def __init__(self, cin, cout, kernel, stride, affine, slope, res):
         super().__init__()
-        self.stride, self.res = int(stride), bool(res)
-        self.conv1 = _Conv(cin, cout, 3, stride)
-        self.conv2 = _Conv(cout, cout, 3, 1)
+        self.stride, self.res = tuple(stride), bool(res)
+        self.conv1 = _Conv(cin, cout, kernel, stride)
+        self.conv2 = _Conv(cout, cout, kernel)
         self.lrelu = nn.LeakyReLU(slope, inplace=True) if slope != 0.0 else nn.ReLU(inplace=True)
         self.norm1 = nn.InstanceNorm3d(cout, affine=affine)
         self.norm2 = nn.InstanceNorm3d(cout, affine=affine)
-        if res and (cin != cout or stride != 1):
+        if res and (cin != cout or any(a != 1 for a in stride)):
             self.conv3 = _Conv(cin, cout, 1, stride)
             self.norm3 = nn.InstanceNorm3d(cout, affine=affine)
 
@@ -70,10 +79,11 @@ class _Block(nn.Module):
 class _UpBlock(nn.Module):
     """UnetUpBlock (dynunet_block.py:169-229)"""
 
-    def __init__(self, cin, cout, up, affine, slope, trans_bias):
+    def __init__(self, cin, cout, kernel, up, affine, slope, trans_bias):
         super().__init__()
+        self.up = tuple(up)
         self.transp_conv = _Conv(cin, cout, up, up, transposed=True, bias=trans_bias)
-        self.conv_block = _Block(cout + cout, cout, 1, affine, slope, False)
+        self.conv_block = _Block(cout + cout, cout, kernel, (1, 1, 1), affine, slope, False)
 
 
 class _OutBlock(nn.Module):
@@ -120,13 +130,11 @@ class DynUNet(nn.Module):
             raise ValueError("length of kernel_size and strides should be the same, and no less than 3.")
         if spatial_dims != 3:
             raise NotImplementedError("monai_amd.DynUNet: only spatial_dims=3 is on the HIP path")
-        ks = [_iso(k, f"kernel_size in block {i}") for i, k in enumerate(kernel_size)]
-        ss = [_iso(s, f"stride in block {i}") for i, s in enumerate(strides)]
-        us = [_iso(u, "upsample_kernel_size") for u in upsample_kernel_size]
-        if any(k != 3 for k in ks) or any(s not in (1, 2) for s in ss):
-            raise NotImplementedError("monai_amd.DynUNet: the HIP path covers kernel size 3 and strides 1 / 2")
-        if len(us) != len(ss) - 1 or any(u != s or u != 2 for u, s in zip(us, ss[1:])):
-            raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] (all 2) on the HIP path")
+        ks = [_triple(k, f"kernel_size in block {i}", {1, 3}) for i, k in enumerate(kernel_size)]
+        ss = [_triple(s, f"stride in block {i}", {1, 2}) for i, s in enumerate(strides)]
+        us = [_triple(u, "upsample_kernel_size", {1, 2}) for u in upsample_kernel_size]
+        if len(us) != len(ss) - 1 or any(u != s for u, s in zip(us, ss[1:])):
+            raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] on the HIP path")
         if dropout is not None and dropout != 0.0:
             raise NotImplementedError("monai_amd.DynUNet: dropout is not on the (inference-only) HIP path")
         nname, nargs = (norm_name, {}) if isinstance(norm_name, str) else (norm_name[0], norm_name[1] if len(norm_name) > 1 else {})
@@ -149,16 +157,17 @@ class DynUNet(nn.Module):
             self.filters = [min(2 ** (5 + i), 320) for i in range(len(strides))]
         f = self.filters
         self.features = (f[0],)    # used by the inferer to size its window batch
-        self.window_sized_output = ss[0] == 1     # the inferer writes straight into its logits buffer only then
+        self.window_sized_output = ss[0] == (1, 1, 1)     # the inferer writes straight into its logits buffer only then
 
-        def block(cin, cout, s):
-            return _Block(cin, cout, s, affine, slope, res_block)
+        def block(cin, cout, k, s):
+            return _Block(cin, cout, k, s, affine, slope, res_block)
 
         # construction order = the reference's (dynunet.py:154-166): it fixes the random stream of the default initialisers
-        self.input_block = block(in_channels, f[0], ss[0])
-        self.downsamples = nn.ModuleList([block(i, o, s) for i, o, s in zip(f[:-2], f[1:-1], ss[1:-1])])
-        self.bottleneck = block(f[-2], f[-1], ss[-1])
-        self.upsamples = nn.ModuleList([_UpBlock(i, o, u, affine, slope, trans_bias) for i, o, u in zip(f[1:][::-1], f[:-1][::-1], us[::-1])])
+        self.input_block = block(in_channels, f[0], ks[0], ss[0])
+        self.downsamples = nn.ModuleList([block(i, o, k, s) for i, o, k, s in zip(f[:-2], f[1:-1], ks[1:-1], ss[1:-1])])
+        self.bottleneck = block(f[-2], f[-1], ks[-1], ss[-1])
+        self.upsamples = nn.ModuleList([_UpBlock(i, o, k, u, affine, slope, trans_bias)
+                                        for i, o, k, u in zip(f[1:][::-1], f[:-1][::-1], ks[1:][::-1], us[::-1])])
         self.output_block = _OutBlock(f[0], out_channels)
         self.deep_supervision, self.deep_supr_num = deep_supervision, deep_supr_num
         self.heads = [torch.rand(1)] * deep_supr_num            # one draw from the global generator, as the reference
@@ -196,14 +205,17 @@ class DynUNet(nn.Module):
                 module.bias = nn.init.constant_(module.bias, 0)
 
     # ---- helpers -----------------------------------------------------------------------------------
-    def _packed_weight(self, conv: nn.Conv3d, cfg: int, expand: bool = False) -> torch.Tensor:
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
         w = conv.weight
         key = (w.data_ptr(), w._version, str(w.device))
         hit = self._packed.get((id(conv), cfg))
         if hit is None or hit[0] != key:
-            if expand:      # a strided 1x1 conv as the centre tap of a 3x3x3 one (same sample positions: 2i with padding 1)
+            if tuple(w.shape[2:]) != (3, 3, 3):
+                # a kernel extent of 1 along an axis = a 3-tap kernel whose outer taps are zero: with padding 1 the centre tap sits on the
+                # same sample (s * o) as the reference's padding-0 extent-1 kernel.  Exact; the zero taps cost matrix time, not accuracy.
                 w3 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=w.dtype, device=w.device)
-                w3[:, :, 1, 1, 1] = w[:, :, 0, 0, 0]
+                sl = tuple(slice(0, 3) if k == 3 else slice(1, 2) for k in w.shape[2:])
+                w3[(slice(None), slice(None)) + sl] = w
                 w = w3
             hit = (key, ops.conv3d_k3_pack(cfg, w))
             self._packed[(id(conv), cfg)] = hit
@@ -224,42 +236,42 @@ class DynUNet(nn.Module):
         ops.instnorm_finalize(stats, tiles, n, c, norm.weight, norm.bias, norm.eps, slope, nrm)
         return nrm
 
-    def _conv_norm(self, conv: nn.Conv3d, norm, x, x_nrm, stride: int, slope: float):
+    def _conv_norm(self, conv: nn.Conv3d, norm, x, x_nrm, stride, slope: float):
         """3x3x3 conv (no bias) of the (deferred) input + InstanceNorm statistics -> (raw output, {alpha, beta, slope} record)"""
         n, cin, d, h, w = x.shape
         cout = conv.weight.shape[0]
-        sp = tuple((v - 1) // stride + 1 for v in (d, h, w))
+        sp = _out_size((d, h, w), stride)
         out = torch.empty((n, cout) + sp, dtype=torch.float32, device=x.device)
         tiles, stats = 0, None
         flops = 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n
-        if stride == 1 and not (cin <= 8 and cout <= 8):
+        if stride == (1, 1, 1) and not (cin <= 8 and cout <= 8):
             cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
             tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
             with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
         else:       # strided, or so few channels that the matrix tiles would mostly pad: the direct kernel at the true width
-            ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
+            ops.conv3d_k3_strided3(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
         return out, self._finalize(norm, out, stats, tiles, slope)
 
     def _basic(self, blk: _Block, x, x_nrm):
         """UnetBasicBlock: conv1 -> norm1 -> lrelu -> conv2 -> norm2 -> lrelu, the last normalise + activate left to the consumer"""
         c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, x_nrm, blk.stride, self._slope)
-        return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, 1, self._slope)
+        return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), self._slope)
 
     def _res(self, blk: _Block, x, dst):
         """UnetResBlock of a plain tensor into `dst` (plain): lrelu(norm2(conv2(lrelu(norm1(conv1 x)))) + shortcut)"""
         c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, None, blk.stride, self._slope)
-        c2, n2 = self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, 1, 1.0)
+        c2, n2 = self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), 1.0)
         if not hasattr(blk, "conv3"):
             return ops.add_act(c2, n2, x, None, self._slope, dst)
         w3 = blk.conv3.conv.weight
         cout = w3.shape[0]
         r = torch.empty_like(c2)
-        if blk.stride == 1:
+        if blk.stride == (1, 1, 1):
             ops.conv1x1(x, None, w3.view(cout, -1), None, r)
-        else:
-            ops.conv3d_k3_strided(x, None, self._packed_weight(blk.conv3.conv, 0, expand=True), None, r, blk.stride)
+        else:       # the strided 1x1 shortcut as the centre tap of the strided 3x3x3 kernel
+            ops.conv3d_k3_strided3(x, None, self._packed_weight(blk.conv3.conv, 0), None, r, blk.stride)
         n3 = self._finalize(blk.norm3, r, None, 0, 1.0)
         return ops.add_act(c2, n2, r, n3, self._slope, dst)
 
@@ -275,23 +287,26 @@ class DynUNet(nn.Module):
         blk, up = downs[i], ups[i]
         cout = blk.conv1.conv.weight.shape[0]
         n = x.shape[0]
-        sp = tuple((v - 1) // blk.stride + 1 for v in x.shape[2:])
+        sp = _out_size(x.shape[2:], blk.stride)
         cat = torch.empty((n, 2 * cout) + sp, dtype=torch.float32, device=x.device)       # torch.cat((out, skip), dim=1)
         skip = self._encode(blk, x, cat[:, cout:])
         if i + 1 < len(downs):
             t, tn = self._level(i + 1, skip, downs, ups)
         elif self.bottleneck.res:
-            bsp = tuple((v - 1) // self.bottleneck.stride + 1 for v in sp)
+            bsp = _out_size(sp, self.bottleneck.stride)
             t, tn = self._res(self.bottleneck, skip, torch.empty((n, self.filters[-1]) + bsp, dtype=torch.float32, device=x.device)), None
         else:
             t, tn = self._basic(self.bottleneck, skip, None)
         tc = up.transp_conv.conv
-        ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout])
+        if up.up == (2, 2, 2):
+            ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout])
+        else:
+            ops.deconv_ks(t, tn, tc.weight, tc.bias, cat[:, :cout], up.up)
         return self._basic(up.conv_block, cat, None)
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        sp = tuple((v - 1) // self._strides[0] + 1 for v in x.shape[2:])
+        sp = _out_size(x.shape[2:], self._strides[0])
         out = torch.empty((x.shape[0], self.out_channels) + sp, dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
 
@@ -300,12 +315,12 @@ class DynUNet(nn.Module):
         _lib.require_device(x, out)
         if self.training:
             raise RuntimeError("monai_amd.DynUNet is an inference engine: call .eval() first")
-        total = 1
-        for s in self._strides:
-            total *= s
-        if x.dim() != 5 or x.shape[1] != self.in_channels or any(int(v) % total for v in x.shape[2:]):
-            raise NotImplementedError(f"monai_amd.DynUNet: input (B,{self.in_channels},D,H,W) with edges divisible by {total} expected, got {tuple(x.shape)}")
-        if tuple(out.shape) != (x.shape[0], self.out_channels) + tuple((int(v) - 1) // self._strides[0] + 1 for v in x.shape[2:]):
+        total = [1, 1, 1]
+        for st in self._strides:
+            total = [a * b for a, b in zip(total, st)]
+        if x.dim() != 5 or x.shape[1] != self.in_channels or any(int(v) % t for v, t in zip(x.shape[2:], total)):
+            raise NotImplementedError(f"monai_amd.DynUNet: input (B,{self.in_channels},D,H,W) with edges divisible by {tuple(total)} expected, got {tuple(x.shape)}")
+        if tuple(out.shape) != (x.shape[0], self.out_channels) + _out_size(x.shape[2:], self._strides[0]):
             raise RuntimeError(f"monai_amd.DynUNet: output buffer of shape {tuple(out.shape)} does not fit input {tuple(x.shape)}")
         downs = [self.input_block] + list(self.downsamples)
         t, tn = self._level(0, x.contiguous(), downs, list(self.upsamples[::-1]))

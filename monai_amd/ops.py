@@ -386,3 +386,22 @@ def normalize_apply(src: torch.Tensor, channels: int, n: int, nonzero: bool, tab
     out = torch.empty_like(src)
     _lib.lib().call("mh_normalize_apply_f32", _lib.ptr(src), _lib.ptr(out), int(channels), int(n), int(bool(nonzero)), _lib.ptr(table), _s(src))
     return out
+
+
+def conv3d_k3_strided3(x, x_nrm, packed_w0, bias, out, strides: Sequence[int]):
+    """out = conv3x3x3(act(x), strides (sz, sy, sx), padding 1) + bias; packed_w0 = conv3d_k3_pack(0, weight)."""
+    _lib.require_device(x, x_nrm, packed_w0, bias, out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv3d_k3_strided3_f32", C.byref(xi), _lib.ptr(packed_w0), _lib.ptr(bias), C.byref(xo), int(strides[0]), int(strides[1]),
+                    int(strides[2]), _s(x))
+    return out
+
+
+def deconv_ks(x, x_nrm, weight, bias, out, factors: Sequence[int]):
+    """out = conv_transpose3d(act(x), kernel == stride == factors (each 1 or 2)) + bias; weight [Cin, Cout, fz, fy, fx] contiguous."""
+    _lib.require_device(x, x_nrm, weight, bias, out)
+    if not weight.is_contiguous() or tuple(weight.shape[2:]) != tuple(int(f) for f in factors):
+        raise RuntimeError("monai_amd.deconv_ks: contiguous weight [Cin, Cout, fz, fy, fx] required")
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_deconv_ks_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), int(factors[0]), int(factors[1]), int(factors[2]), _s(x))
+    return out

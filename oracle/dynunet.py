@@ -8,7 +8,7 @@ Reference followed (paths relative to /root/reference):
   * ``SegResNet.encode`` / ``decode`` / ``forward``               monai/networks/nets/segresnet.py:170-198
   * ``ResBlock``                                                  monai/networks/blocks/segresnet_block.py:48-100
   * ``UpSample`` (nontrainable = ``nn.Upsample(trilinear, align_corners=False)``; deconv)   monai/networks/blocks/upsample.py:43-184
-3-D, isotropic kernels / strides, inference (deep-supervision heads and dropout do not act).
+3-D, inference (deep-supervision heads and dropout do not act).
 """
 
 from __future__ import annotations
@@ -25,22 +25,33 @@ def _act(x, slope):
     return F.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
 
 
+def _t3(v):
+    return (int(v),) * 3 if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+def _dyn_conv(x, w, stride):
+    """get_conv_layer (dynunet_block.py:256-301): padding = (kernel - stride + 1) / 2 per axis, truncated (get_padding :304-315)"""
+    stride = _t3(stride)
+    return F.conv3d(x, w, None, stride=stride, padding=tuple((k - s + 1) // 2 for k, s in zip(w.shape[2:], stride)))
+
+
 def _dyn_block(sd, p, x, stride, slope, res):
     """UnetBasicBlock (dynunet_block.py:155-166) / UnetResBlock (:96-111)"""
-    out = F.conv3d(x, sd[p + ".conv1.conv.weight"], None, stride=stride, padding=1)
+    out = _dyn_conv(x, sd[p + ".conv1.conv.weight"], stride)
     out = _act(_inorm(sd, p + ".norm1", out), slope)
-    out = F.conv3d(out, sd[p + ".conv2.conv.weight"], None, stride=1, padding=1)
+    out = _dyn_conv(out, sd[p + ".conv2.conv.weight"], 1)
     out = _inorm(sd, p + ".norm2", out)
     if not res:
         return _act(out, slope)
     residual = x
     if p + ".conv3.conv.weight" in sd:
-        residual = _inorm(sd, p + ".norm3", F.conv3d(x, sd[p + ".conv3.conv.weight"], None, stride=stride, padding=0))
+        residual = _inorm(sd, p + ".norm3", _dyn_conv(x, sd[p + ".conv3.conv.weight"], stride))
     return _act(out + residual, slope)
 
 
 def dynunet_forward(sd, x, strides, slope=0.01, res_block=False):
-    """``strides``: one int per level (``strides[0]`` the input block's, ``strides[-1]`` the bottleneck's); upsample kernels = strides[1:]"""
+    """``strides``: one int or (z, y, x) triple per level (``strides[0]`` the input block's, ``strides[-1]`` the bottleneck's); upsample
+    kernels = strides[1:]"""
     n_down = len(strides) - 2
     downs = ["input_block"] + [f"downsamples.{i}" for i in range(n_down)]
     ups = [f"upsamples.{n_down - i}" for i in range(n_down + 1)]          # self.upsamples[::-1]
@@ -49,8 +60,7 @@ def dynunet_forward(sd, x, strides, slope=0.01, res_block=False):
         d = _dyn_block(sd, downs[i], t, strides[i], slope, res_block)
         nxt = level(i + 1, d) if i + 1 < len(downs) else _dyn_block(sd, "bottleneck", d, strides[-1], slope, res_block)
         up = ups[i]
-        s = strides[i + 1]
-        u = F.conv_transpose3d(nxt, sd[up + ".transp_conv.conv.weight"], sd.get(up + ".transp_conv.conv.bias"), stride=s)
+        u = F.conv_transpose3d(nxt, sd[up + ".transp_conv.conv.weight"], sd.get(up + ".transp_conv.conv.bias"), stride=_t3(strides[i + 1]))
         return _dyn_block(sd, up + ".conv_block", torch.cat((u, d), dim=1), 1, slope, False)      # dynunet_block.py:223-229
 
     out = level(0, x)

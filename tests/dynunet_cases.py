@@ -21,8 +21,16 @@ CFGS = {
     "stride0": dict(kw=dict(kernel_size=[[3, 3, 3]] * 3, strides=[2, [2, 2, 2], 2], upsample_kernel_size=[[2, 2, 2], 2], norm_name="instance",
                             act_name="relu", trans_bias=True),
                     shape=(1, 1, 16, 16, 24), seed=13),
+    # an anisotropic nnU-Net plan (thick slices along the first axis): in-plane kernels / strides first, residual blocks with anisotropic
+    # strided shortcuts, kernel == stride transposed convs of (1, 2, 2) and (2, 2, 1)
+    "aniso": dict(kw=dict(kernel_size=[[1, 3, 3], [1, 3, 3], [3, 3, 3], [3, 3, 3]], strides=[[1, 1, 1], [1, 2, 2], [2, 2, 2], [2, 2, 1]],
+                          upsample_kernel_size=[[1, 2, 2], [2, 2, 2], [2, 2, 1]], filters=[16, 32, 48, 64], res_block=True),
+                  shape=(1, 1, 12, 32, 24), seed=14),
+    "aniso_basic": dict(kw=dict(kernel_size=[[3, 3, 1], [3, 3, 3], [3, 3, 3]], strides=[1, [2, 2, 1], [2, 2, 2]],
+                                upsample_kernel_size=[[2, 2, 1], [2, 2, 2]], filters=[8, 16, 32]),
+                        shape=(2, 1, 16, 24, 6), seed=15),
 }
-IN_CH = {"basic": 1, "res_ds": 2, "stride0": 1}
+IN_CH = {"basic": 1, "res_ds": 2, "stride0": 1, "aniso": 1, "aniso_basic": 1}
 
 
 def digest(sd):
@@ -116,7 +124,9 @@ def case_dynunet_api(device):
     with pytest.raises(ValueError):
         DynUNet(3, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2], deep_supervision=True, deep_supr_num=3)
     with pytest.raises(NotImplementedError):
-        DynUNet(3, 1, 2, [3, [3, 3, 1], 3], [1, 2, 2], [2, 2])
+        DynUNet(3, 1, 2, [3, [3, 3, 5], 3], [1, 2, 2], [2, 2])
+    with pytest.raises(NotImplementedError):
+        DynUNet(3, 1, 2, [3, 3, 3], [1, 2, [2, 2, 1]], [2, 2])        # upsample kernels must equal the strides
     with pytest.raises(NotImplementedError):
         DynUNet(2, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2])
     net = DynUNet(3, 1, 2, [3, 3, 3], [1, 2, 2], [2, 2], filters=[8, 8, 8])

@@ -291,7 +291,7 @@ def test_basic_unet_oracle_odd_window_bitwise_vs_reference(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ widening rows
-@pytest.mark.parametrize("name", ["basic", "res_ds", "stride0"])
+@pytest.mark.parametrize("name", ["basic", "res_ds", "stride0", "aniso", "aniso_basic"])
 def test_dynunet_oracle_vs_reference(golden_dir, name):
     """oracle/dynunet.py against tests/golden/dynunet.npz (made by the real monai DynUNet); parameters from the product module, whose
     keys / seeded values are themselves pinned to the reference's (tests/dynunet_cases.py)."""
@@ -303,7 +303,7 @@ def test_dynunet_oracle_vs_reference(golden_dir, name):
     net, init = dc.build(DynUNet, name)
     assert init == str(g[f"{name}_init_sha256"])
     kw = dc.CFGS[name]["kw"]
-    strides = [s if isinstance(s, int) else s[0] for s in kw["strides"]]
+    strides = kw["strides"]
     slope = 0.0 if kw.get("act_name") == "relu" else 0.01
     with torch.no_grad():
         y = od.dynunet_forward(net.state_dict(), dc.inputs(name), strides, slope, kw.get("res_block", False))
