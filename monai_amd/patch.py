@@ -63,11 +63,14 @@ _TARGETS = {
         "ScaleIntensityRange": ("monai_amd.transforms.intensity.array", "ScaleIntensityRange"),
         "NormalizeIntensity": ("monai_amd.transforms.intensity.array", "NormalizeIntensity"),
     },
-    "monai.transforms.croppad.array": {"CropForeground": ("monai_amd.transforms.croppad.array", "CropForeground")},
+    "monai.transforms.croppad.array": {n: ("monai_amd.transforms.croppad.array", n) for n in
+                                       ("CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop")},
     "monai.transforms.croppad.dictionary": {
         "CropForegroundd": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
         "CropForegroundD": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
         "CropForegroundDict": ("monai_amd.transforms.croppad.dictionary", "CropForegroundd"),
+        **{n + suffix: ("monai_amd.transforms.croppad.dictionary", n + "d") for n in ("SpatialPad", "BorderPad", "DivisiblePad", "SpatialCrop", "CenterSpatialCrop")
+           for suffix in ("d", "D", "Dict")},
     },
     "monai.transforms.post.array": {
         "Activations": ("monai_amd.transforms.post.array", "Activations"),

@@ -1,4 +1,8 @@
-from .croppad import CropForeground, CropForegroundD, CropForegroundDict, CropForegroundd  # noqa: F401
+from .croppad import (  # noqa: F401
+    BorderPad, BorderPadD, BorderPadDict, BorderPadd, CenterSpatialCrop, CenterSpatialCropD, CenterSpatialCropDict, CenterSpatialCropd, Crop,
+    CropForeground, CropForegroundD, CropForegroundDict, CropForegroundd, DivisiblePad, DivisiblePadD, DivisiblePadDict, DivisiblePadd, Pad,
+    SpatialCrop, SpatialCropD, SpatialCropDict, SpatialCropd, SpatialPad, SpatialPadD, SpatialPadDict, SpatialPadd,
+)
 from .intensity import (  # noqa: F401
     GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, NormalizeIntensity, NormalizeIntensityD, NormalizeIntensityDict,
     NormalizeIntensityd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,

@@ -13,7 +13,8 @@ from ... import ops
 from ...data.meta_tensor import is_meta
 from ...utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple
 
-__all__ = ["CropForeground", "is_positive", "generate_spatial_bounding_box", "compute_divisible_spatial_size"]
+__all__ = ["CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop", "is_positive",
+           "generate_spatial_bounding_box", "compute_divisible_spatial_size"]
 
 
 def is_positive(img):
@@ -27,6 +28,218 @@ def _as4(data: torch.Tensor) -> torch.Tensor:
     if nsp < 1 or nsp > 3:
         raise NotImplementedError(f"monai_amd.CropForeground: channel-first images with 1-3 spatial axes expected, got shape {tuple(data.shape)}")
     return data.reshape((data.shape[0],) + (1,) * (3 - nsp) + tuple(data.shape[1:])).contiguous()
+
+
+_INT_DTYPES = (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool)
+
+
+def _run_crop_pad(data: torch.Tensor, start, size, value: float) -> torch.Tensor:
+    """out[c, o] = data[c, o + start] inside `data`, `value` outside -- the crop + constant-pad kernel on a channel-first image with 1-3
+    spatial axes.  float32 directly; integer / bool images (label maps) through float32 and back, which is exact below 2^24."""
+    if data.dtype != torch.float32 and data.dtype not in _INT_DTYPES:
+        raise NotImplementedError(f"monai_amd crop / pad: {data.dtype} images are not on the HIP path (float32 and integer images are)")
+    nsp = data.dim() - 1
+    size = [int(v) for v in size]
+    if any(v < 1 for v in size) or not data.numel():
+        return data.new_zeros((data.shape[0],) + tuple(max(v, 0) for v in size))
+    x = _as4(data if data.dtype == torch.float32 else data.to(torch.float32))
+    out = ops.crop_pad(x, [0] * (3 - nsp) + [int(v) for v in start], [1] * (3 - nsp) + size, float(value)).reshape((data.shape[0],) + tuple(size))
+    return out if data.dtype == torch.float32 else out.to(data.dtype)
+
+
+def _wrap_crop_pad(img, out: torch.Tensor, start, cls_name: str, value: float):
+    """MetaTensor bookkeeping of a crop / pad whose output voxel o shows source voxel o + start: affine @ translate(start), and the
+    record `inverse` needs (what TraceableTransform.track_transform_meta keeps, monai/transforms/inverse.py:168-297)."""
+    if not is_meta(img):
+        return out
+    nsp = out.dim() - 1
+    res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
+    aff = np.asarray(img.meta["affine"], dtype=np.float64) if "affine" in img.meta else np.eye(4)
+    shift = np.eye(aff.shape[0])
+    r = min(nsp, aff.shape[0] - 1)
+    shift[:r, -1] = [int(v) for v in start][:r]
+    res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
+    res.applied_operations.append({"class": cls_name, "orig_size": tuple(int(v) for v in img.shape[1:]),
+                                   "extra_info": {"box_start": [int(v) for v in start], "pad_value": float(value)}})
+    return res
+
+
+def _inverse_crop_pad(img, cls_name: str):
+    """Undo the most recent crop / pad of `cls_name`: the same kernel with the negated start (cropped-away voxels come back as 0,
+    padding is cut off) -- Pad.inverse / Crop.inverse, monai/transforms/croppad/array.py:190-204, 441-450."""
+    if not is_meta(img) or not getattr(img, "applied_operations", None):
+        raise RuntimeError(f"monai_amd.{cls_name}.inverse: a MetaTensor with the forward call's record is required")
+    rec = img.applied_operations[-1]
+    if rec.get("class") != cls_name:
+        raise RuntimeError(f"monai_amd.{cls_name}.inverse: the most recent operation is {rec.get('class')!r}")
+    start, orig = rec["extra_info"]["box_start"], tuple(int(v) for v in rec["orig_size"])
+    out = _run_crop_pad(img.as_tensor(), [-s for s in start], orig, 0.0)
+    res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
+    aff = np.asarray(img.meta["affine"], dtype=np.float64)
+    shift = np.eye(aff.shape[0])
+    r = min(len(orig), aff.shape[0] - 1)
+    shift[:r, -1] = [-s for s in start][:r]
+    res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
+    return res
+
+
+def _pad_value(mode, kwargs) -> float:
+    if str(getattr(mode, "value", mode)).lower() != "constant":
+        raise NotImplementedError(f"monai_amd crop / pad: padding mode {mode!r} is not on the HIP path (constant is)")
+    kw = dict(kwargs)
+    return float(kw.pop("value", kw.pop("constant_values", 0.0)))
+
+
+class Pad:
+    """``monai.transforms.Pad`` (monai/transforms/croppad/array.py:84-204): pad by ``to_pad`` = ``[(before, after), ...]`` including the
+    channel axis; constant mode on the crop + pad kernel."""
+
+    def __init__(self, to_pad=None, mode: str = "constant", lazy: bool = False, **kwargs) -> None:
+        if lazy:
+            raise NotImplementedError("monai_amd pad: lazy execution is not implemented")
+        self.to_pad, self.mode, self.kwargs, self.lazy = to_pad, mode, kwargs, False
+
+    def compute_pad_width(self, spatial_shape):
+        raise NotImplementedError(f"subclass {self.__class__.__name__} must implement this method.")
+
+    def __call__(self, img, to_pad=None, mode: str | None = None, lazy: bool | None = None, **kwargs):
+        if lazy:
+            raise NotImplementedError("monai_amd pad: lazy execution is not implemented")
+        data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        to_pad_ = self.to_pad if to_pad is None else to_pad
+        if to_pad_ is None:
+            to_pad_ = self.compute_pad_width(tuple(int(v) for v in data.shape[1:]))
+        kw = dict(self.kwargs)
+        kw.update(kwargs)
+        value = _pad_value(self.mode if mode is None else mode, kw)
+        to_pad_ = [tuple(int(v) for v in p) for p in to_pad_]
+        if len(to_pad_) != data.dim() or to_pad_[0] != (0, 0):
+            raise NotImplementedError(f"monai_amd pad: to_pad must list every axis and leave the channel axis alone, got {to_pad_}")
+        start = [-p[0] for p in to_pad_[1:]]
+        size = [int(n) + p[0] + p[1] for n, p in zip(data.shape[1:], to_pad_[1:])]
+        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, value), start, type(self).__name__, value)
+
+    def inverse(self, img):
+        return _inverse_crop_pad(img, type(self).__name__)
+
+
+class SpatialPad(Pad):
+    """array.py:207-266: pad up to ``spatial_size`` (symmetric or at the end); axes already large enough are left alone."""
+
+    def __init__(self, spatial_size, method: str = "symmetric", mode: str = "constant", lazy: bool = False, **kwargs) -> None:
+        self.spatial_size = spatial_size
+        self.method = str(getattr(method, "value", method)).lower()
+        if self.method not in ("symmetric", "end"):
+            raise ValueError(f"Unsupported method: {method}, available options are ['symmetric', 'end'].")
+        super().__init__(mode=mode, lazy=lazy, **kwargs)
+
+    def compute_pad_width(self, spatial_shape):
+        spatial_size = fall_back_tuple(self.spatial_size, spatial_shape)
+        if self.method == "symmetric":
+            widths = [max(sp - spatial_shape[i], 0) for i, sp in enumerate(spatial_size)]
+            return tuple([(0, 0)] + [(int(w // 2), int(w - w // 2)) for w in widths])
+        return tuple([(0, 0)] + [(0, int(max(sp - spatial_shape[i], 0))) for i, sp in enumerate(spatial_size)])
+
+
+class BorderPad(Pad):
+    """array.py:269-327: the same border on every side, one per axis, or (before, after) per axis."""
+
+    def __init__(self, spatial_border, mode: str = "constant", lazy: bool = False, **kwargs) -> None:
+        self.spatial_border = spatial_border
+        super().__init__(mode=mode, lazy=lazy, **kwargs)
+
+    def compute_pad_width(self, spatial_shape):
+        b = ensure_tuple(self.spatial_border)
+        if not all(isinstance(v, int) for v in b):
+            raise ValueError(f"self.spatial_border must contain only ints, got {b}.")
+        b = tuple(max(0, v) for v in b)
+        n = len(spatial_shape)
+        if len(b) == 1:
+            w = [(b[0], b[0])] * n
+        elif len(b) == n:
+            w = [(v, v) for v in b]
+        elif len(b) == 2 * n:
+            w = [(b[2 * i], b[2 * i + 1]) for i in range(n)]
+        else:
+            raise ValueError(f"Unsupported spatial_border length: {len(b)}, available options are [1, len(spatial_shape)={n}, 2*len(spatial_shape)={2 * n}].")
+        return tuple([(0, 0)] + w)
+
+
+class DivisiblePad(Pad):
+    """array.py:330-376: pad every spatial extent up to the next multiple of ``k``."""
+
+    def __init__(self, k, mode: str = "constant", method: str = "symmetric", lazy: bool = False, **kwargs) -> None:
+        self.k, self.method = k, method
+        super().__init__(mode=mode, lazy=lazy, **kwargs)
+
+    def compute_pad_width(self, spatial_shape):
+        return SpatialPad(compute_divisible_spatial_size(spatial_shape, self.k), method=self.method).compute_pad_width(spatial_shape)
+
+
+class Crop:
+    """``monai.transforms.Crop`` (array.py:379-450): crop by per-axis slices (step 1); the result is a dense copy."""
+
+    def __init__(self, lazy: bool = False):
+        if lazy:
+            raise NotImplementedError("monai_amd crop: lazy execution is not implemented")
+        self.lazy = False
+
+    @staticmethod
+    def compute_slices(roi_center=None, roi_size=None, roi_start=None, roi_end=None, roi_slices=None):
+        """array.py:388-424: slices from centre + size, start + end (clamped to >= 0, end >= start) or given slices"""
+        if roi_slices:
+            if not all(s.step is None or s.step == 1 for s in roi_slices):
+                raise ValueError(f"only slice steps of 1/None are currently supported, got {roi_slices}.")
+            return tuple(roi_slices)
+        as_list = lambda v: [int(a) for a in np.atleast_1d(np.asarray(v.cpu() if isinstance(v, torch.Tensor) else v))]  # noqa: E731
+        if roi_center is not None and roi_size is not None:
+            c, sz = as_list(roi_center), as_list(roi_size)
+            start = [max(a - b // 2, 0) for a, b in zip(c, sz)]
+            end = [max(a + b, a) for a, b in zip(start, sz)]
+        else:
+            if roi_start is None or roi_end is None:
+                raise ValueError("please specify either roi_center, roi_size or roi_start, roi_end.")
+            start = [max(a, 0) for a in as_list(roi_start)]
+            end = [max(a, b) for a, b in zip(as_list(roi_end), start)]
+        return tuple(slice(a, b) for a, b in zip(start, end))
+
+    def __call__(self, img, slices, lazy: bool | None = None):
+        if lazy:
+            raise NotImplementedError("monai_amd crop: lazy execution is not implemented")
+        data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        sd = data.dim() - 1
+        slices_ = (list(slices) + [slice(None)] * sd)[:sd]
+        rng = [s.indices(int(n)) for s, n in zip(slices_, data.shape[1:])]
+        start = [r[0] for r in rng]
+        size = [max(r[1] - r[0], 0) for r in rng]
+        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, 0.0), start, type(self).__name__, 0.0)
+
+    def inverse(self, img):
+        return _inverse_crop_pad(img, type(self).__name__)
+
+
+class SpatialCrop(Crop):
+    """array.py:453-500"""
+
+    def __init__(self, roi_center=None, roi_size=None, roi_start=None, roi_end=None, roi_slices=None, lazy: bool = False) -> None:
+        super().__init__(lazy)
+        self.slices = self.compute_slices(roi_center=roi_center, roi_size=roi_size, roi_start=roi_start, roi_end=roi_end, roi_slices=roi_slices)
+
+    def __call__(self, img, lazy: bool | None = None):
+        return super().__call__(img=img, slices=ensure_tuple(self.slices), lazy=lazy)
+
+
+class CenterSpatialCrop(Crop):
+    """array.py:503-539: a centred box of ``roi_size`` (non-positive components keep the axis whole)"""
+
+    def __init__(self, roi_size, lazy: bool = False) -> None:
+        super().__init__(lazy=lazy)
+        self.roi_size = roi_size
+
+    def __call__(self, img, lazy: bool | None = None):
+        spatial = tuple(int(v) for v in (img.as_tensor() if is_meta(img) else torch.as_tensor(img)).shape[1:])
+        roi_size = fall_back_tuple(self.roi_size, spatial)
+        return super().__call__(img=img, slices=Crop.compute_slices(roi_center=[i // 2 for i in spatial], roi_size=roi_size), lazy=lazy)
 
 
 def generate_spatial_bounding_box(img, select_fn: Callable = is_positive, channel_indices=None, margin: Sequence[int] | int = 0,
@@ -96,56 +309,22 @@ class CropForeground:
         """Crop to ``[max(start, 0), end)`` and pad what lies outside the image (array.py:884-927) -- one kernel pass."""
         if lazy:
             raise NotImplementedError("monai_amd.CropForeground: lazy execution is not implemented")
-        mode = self.mode if mode is None else mode
-        if str(getattr(mode, "value", mode)).lower() != "constant":
-            raise NotImplementedError(f"monai_amd.CropForeground: padding mode {mode!r} is not on the HIP path (constant is)")
         kw = dict(self.pad_kwargs)
         kw.update(pad_kwargs)
-        value = float(kw.pop("value", kw.pop("constant_values", 0.0)))
+        value = _pad_value(self.mode if mode is None else mode, kw)
         data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
-        if data.dtype != torch.float32:
-            raise NotImplementedError(f"monai_amd.CropForeground: {data.dtype} images are not on the HIP path (float32 is)")
         nsp = data.dim() - 1
         start = [int(v) for v in np.asarray(box_start).tolist()]
         end = [max(int(e), max(s, 0)) for s, e in zip(start, np.asarray(box_end).tolist())]       # Crop.compute_slices: end >= start >= 0
         if len(start) != nsp:
             raise ValueError(f"monai_amd.CropForeground: a {len(start)}-D box does not fit an image of shape {tuple(data.shape)}")
         size = [e - s for s, e in zip(start, end)]
-        if any(s < 1 for s in size):
-            out = data.new_empty((data.shape[0],) + tuple(max(s, 0) for s in size))
-        else:
-            out = ops.crop_pad(_as4(data), [0] * (3 - nsp) + start, [1] * (3 - nsp) + size, value).reshape((data.shape[0],) + tuple(size))
-        if not is_meta(img):
-            return out
-        res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
-        aff = np.asarray(img.meta["affine"], dtype=np.float64) if "affine" in img.meta else np.eye(4)
-        shift = np.eye(aff.shape[0])
-        r = min(nsp, aff.shape[0] - 1)
-        shift[:r, -1] = start[:r]                                # crop moves the origin by +start, the front pad by -pad: in total `start`
-        res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
-        res.applied_operations.append({"class": type(self).__name__, "orig_size": tuple(data.shape[1:]),
-                                       "extra_info": {"box_start": start, "box_end": end, "pad_value": value}})
-        return res
+        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, value), start, type(self).__name__, value)
 
     def inverse(self, img):
         """Undo the most recent crop + pad (array.py:950-960: crop the padding away, zero-pad back to the original size) -- the
         same kernel with the negated start: voxels outside the crop box come back as 0."""
-        if not is_meta(img) or not getattr(img, "applied_operations", None):
-            raise RuntimeError("monai_amd.CropForeground.inverse: a MetaTensor with the forward call's record is required")
-        rec = img.applied_operations[-1]
-        if rec.get("class") != type(self).__name__:
-            raise RuntimeError(f"monai_amd.CropForeground.inverse: the most recent operation is {rec.get('class')!r}")
-        data = img.as_tensor()
-        start, orig = rec["extra_info"]["box_start"], tuple(int(v) for v in rec["orig_size"])
-        nsp = len(orig)
-        out = ops.crop_pad(_as4(data), [0] * (3 - nsp) + [-s for s in start], [1] * (3 - nsp) + list(orig), 0.0).reshape((data.shape[0],) + orig)
-        res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
-        aff = np.asarray(img.meta["affine"], dtype=np.float64)
-        shift = np.eye(aff.shape[0])
-        r = min(nsp, aff.shape[0] - 1)
-        shift[:r, -1] = [-s for s in start][:r]
-        res.meta["affine"] = torch.as_tensor(aff @ shift, dtype=torch.float64)
-        return res
+        return _inverse_crop_pad(img, type(self).__name__)
 
     def __call__(self, img, mode: str | None = None, lazy: bool | None = None, **pad_kwargs):
         if lazy:

@@ -1,0 +1,105 @@
+"""Pad / Crop family cases (SpatialPad, BorderPad, DivisiblePad, SpatialCrop, CenterSpatialCrop + dictionary versions) shared by the golden
+generator (real reference, CPU) and the emulator / MI355X tests: data, MetaTensor affine, inverse."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+AFF = torch.tensor([[0.8, 0.1, 0.0, -12.0], [0.0, 0.9, 0.2, 7.0], [0.05, 0.0, 1.6, 30.0], [0.0, 0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def image(seed=0, shape=(2, 9, 14, 19)):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(3300 + seed))
+
+
+# name, class, init kwargs, call kwargs
+CASES = [
+    ("spad_sym", "SpatialPad", {"spatial_size": (12, 14, 24)}, {}),
+    ("spad_end", "SpatialPad", {"spatial_size": (12, 16, 19), "method": "end"}, {}),
+    ("spad_partial", "SpatialPad", {"spatial_size": (4, -1, 30), "value": 1.5}, {}),
+    ("spad_call_value", "SpatialPad", {"spatial_size": 20}, {"value": -3.0}),
+    ("bpad_one", "BorderPad", {"spatial_border": 2}, {}),
+    ("bpad_axis", "BorderPad", {"spatial_border": [1, 0, 3]}, {}),
+    ("bpad_pairs", "BorderPad", {"spatial_border": [1, 2, 0, 0, 3, 4]}, {}),
+    ("dpad_16", "DivisiblePad", {"k": 16}, {}),
+    ("dpad_axis_end", "DivisiblePad", {"k": [4, 7, 0], "method": "end"}, {}),
+    ("scrop_center", "SpatialCrop", {"roi_center": [4, 7, 9], "roi_size": [4, 6, 8]}, {}),
+    ("scrop_center_edge", "SpatialCrop", {"roi_center": [1, 2, 17], "roi_size": [6, 8, 10]}, {}),
+    ("scrop_start_end", "SpatialCrop", {"roi_start": [-2, 3, 5], "roi_end": [6, 30, 4]}, {}),
+    ("scrop_slices", "SpatialCrop", {"roi_slices": [slice(2, 7), slice(None), slice(-6, None)]}, {}),
+    ("ccrop", "CenterSpatialCrop", {"roi_size": [4, 6, 8]}, {}),
+    ("ccrop_mixed", "CenterSpatialCrop", {"roi_size": [100, -1, 7]}, {}),
+]
+
+
+def run_all(ns, device, make_meta):
+    out = {}
+    for name, cls, init, call in CASES:
+        tr = getattr(ns, cls)(**init)
+        m = tr(make_meta(image().to(device), AFF), **call)
+        out[name] = torch.as_tensor(m).cpu().numpy()
+        out[name + "__affine"] = np.asarray(torch.as_tensor(m.affine).cpu(), dtype=np.float64)
+        inv = tr.inverse(m)
+        out[name + "__inverse"] = torch.as_tensor(inv).cpu().numpy()
+        out[name + "__inverse_affine"] = np.asarray(torch.as_tensor(inv.affine).cpu(), dtype=np.float64)
+    # 2-D image, integer label map, plain tensor
+    out["spad_2d"] = torch.as_tensor(ns.SpatialPad((12, 20))(image(1, (3, 9, 14)).to(device))).cpu().numpy()
+    lab = (image(2) * 3).to(torch.int16).to(device)
+    out["dpad_int16"] = torch.as_tensor(ns.DivisiblePad(8)(lab)).cpu().numpy()
+    out["ccrop_uint8"] = torch.as_tensor(ns.CenterSpatialCrop((5, 5, 5))((image(3).abs() * 40).to(torch.uint8).to(device))).cpu().numpy()
+    d = {"image": make_meta(image(4).to(device), AFF), "label": make_meta(image(5).to(device), AFF)}
+    d = ns.SpatialPadd(keys=["image", "label"], spatial_size=(16, 16, 32))(d)
+    d = ns.CenterSpatialCropd(keys=["image", "label"], roi_size=(12, 12, 12))(d)
+    d = ns.DivisiblePadd(keys=["image"], k=8)(d)
+    d = ns.BorderPadd(keys=["label"], spatial_border=1)(d)
+    d = ns.SpatialCropd(keys=["label"], roi_start=[1, 1, 1], roi_end=[13, 13, 13])(d)
+    for k in ("image", "label"):
+        out["dict_" + k] = torch.as_tensor(d[k]).cpu().numpy()
+        out["dict_" + k + "__affine"] = np.asarray(torch.as_tensor(d[k].affine).cpu(), dtype=np.float64)
+    return out
+
+
+def case_croppad_vs_reference(device):
+    """bit-identical data (copies), exact affines, inverses equal to the reference's"""
+    import monai_amd.transforms as ours
+    from monai_amd.data.meta_tensor import MetaTensor
+
+    g = np.load(os.path.join(GOLDEN, "croppad.npz"))
+    got = run_all(ours, device, lambda t, a: MetaTensor(t, affine=a))
+    assert set(got) == set(g.files), set(got) ^ set(g.files)
+    for name, y in got.items():
+        exp = g[name]
+        assert y.shape == exp.shape, (name, y.shape, exp.shape)
+        if name.endswith("affine"):
+            np.testing.assert_allclose(y, exp, rtol=0, atol=1e-12, err_msg=name)
+        else:
+            assert y.dtype == exp.dtype, (name, y.dtype, exp.dtype)
+            np.testing.assert_array_equal(y, exp, err_msg=name)
+    return len(got)
+
+
+def case_croppad_api(device):
+    import pytest
+
+    from monai_amd.transforms import BorderPad, SpatialCrop, SpatialPad, SpatialPadd
+
+    x = image().to(device)
+    with pytest.raises(NotImplementedError):
+        SpatialPad((20, 20, 20), mode="reflect")(x)
+    with pytest.raises(ValueError):
+        SpatialPad((20, 20, 20), method="middle")
+    with pytest.raises(ValueError):
+        BorderPad([1, 2])(x)
+    with pytest.raises(ValueError):
+        BorderPad([1.5])(x)
+    with pytest.raises(ValueError):
+        SpatialCrop(roi_center=[1, 1, 1])
+    with pytest.raises(ValueError):
+        SpatialCrop(roi_slices=[slice(0, 4, 2)])
+    with pytest.raises(NotImplementedError):
+        SpatialPad(8, lazy=True)
+    with pytest.raises(KeyError):
+        SpatialPadd(keys=["missing"], spatial_size=8)({"image": x})
+    with pytest.raises(NotImplementedError):
+        SpatialPad(20)(x.double())

@@ -163,3 +163,10 @@ def test_preproc_properties_small(emu):
     import preproc_cases as pc
 
     pc.case_preproc_full_size("cpu", 48)      # the -m gpu run does this at 512^3
+
+
+def test_croppad_family_vs_reference(emu):
+    import croppad_cases as cc
+
+    print("arrays", cc.case_croppad_vs_reference("cpu"))
+    cc.case_croppad_api("cpu")

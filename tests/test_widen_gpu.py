@@ -101,3 +101,10 @@ def test_dynunet_segresnet_96_window_vs_oracle():
     import dynunet_cases as dc
 
     print("max |dlogit|", dc.case_nets_window_vs_oracle(DEV, 96, (32, 64, 128, 256)))
+
+
+def test_croppad_family_vs_reference():
+    import croppad_cases as cc
+
+    print("arrays", cc.case_croppad_vs_reference(DEV))
+    cc.case_croppad_api(DEV)
