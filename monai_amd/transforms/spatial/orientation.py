@@ -166,12 +166,13 @@ class Orientation:
         # output axis k shows input axis perm[k]; input axis a is reversed when its flip is -1 (functional.py:192-218)
         perm = [int(v) for v in np.argsort(spatial_ornt[:, 0])]
         flips = [bool(f == -1) for f in spatial_ornt[:, 1]]
-        if data.dtype != torch.float32:
-            raise NotImplementedError(f"monai_amd.Orientation: {data.dtype} images are not on the HIP path (float32 is)")
+        ints = (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool)
+        if data.dtype != torch.float32 and data.dtype not in ints:
+            raise NotImplementedError(f"monai_amd.Orientation: {data.dtype} images are not on the HIP path (float32 and integer images are)")
         pad = 3 - sr
-        x4 = data.reshape((data.shape[0],) + (1,) * pad + spatial_shape).contiguous()
+        x4 = data.to(torch.float32).reshape((data.shape[0],) + (1,) * pad + spatial_shape).contiguous()      # label maps: exact below 2^24
         out = ops.flip_permute(x4, list(range(pad)) + [p + pad for p in perm], [False] * pad + flips)
-        out = out.reshape((data.shape[0],) + tuple(spatial_shape[p] for p in perm))
+        out = out.reshape((data.shape[0],) + tuple(spatial_shape[p] for p in perm)).to(data.dtype)
         if not is_meta(data_array):
             return out
         res = type(data_array)(out, meta=dict(data_array.meta), applied_operations=list(getattr(data_array, "applied_operations", [])))

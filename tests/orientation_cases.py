@@ -117,6 +117,10 @@ def case_orientation_api(device):
     with pytest.warns(UserWarning):                                  # plain tensors: identity affine assumed
         y = Orientation(axcodes="LPS")(x)
     assert torch.equal(y.cpu(), torch.flip(x.cpu(), [1, 2]))
+    lab = (torch.arange(24).reshape(1, 2, 3, 4) % 5).to(torch.int16).to(device)            # an integer label map keeps its dtype
+    with pytest.warns(UserWarning):
+        yl = Orientation(axcodes="LAS")(lab)
+    assert yl.dtype == torch.int16 and torch.equal(yl.cpu(), torch.flip(lab.cpu(), [1]))
     with pytest.raises(NotImplementedError):
         Orientation(axcodes="RAS", lazy=True)
     with pytest.raises(KeyError):
