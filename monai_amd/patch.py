@@ -49,6 +49,8 @@ _TARGETS = {
         "SpatialResample": ("monai_amd.transforms.spatial.array", "SpatialResample"),
         "Resample": ("monai_amd.transforms.spatial.array", "Resample"),
         "Orientation": ("monai_amd.transforms.spatial.orientation", "Orientation"),
+        "Flip": ("monai_amd.transforms.spatial.flip_rotate", "Flip"),
+        "Rotate90": ("monai_amd.transforms.spatial.flip_rotate", "Rotate90"),
     },
     "monai.transforms.spatial.dictionary": {
         "Spacingd": ("monai_amd.transforms.spatial.dictionary", "Spacingd"),
@@ -57,6 +59,7 @@ _TARGETS = {
         "Orientationd": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
         "OrientationD": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
         "OrientationDict": ("monai_amd.transforms.spatial.orientation", "Orientationd"),
+        **{n + suffix: ("monai_amd.transforms.spatial.flip_rotate", n + "d") for n in ("Flip", "Rotate90") for suffix in ("d", "D", "Dict")},
     },
     "monai.transforms.intensity.array": {
         "GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth"),

@@ -170,3 +170,10 @@ def test_croppad_family_vs_reference(emu):
 
     print("arrays", cc.case_croppad_vs_reference("cpu"))
     cc.case_croppad_api("cpu")
+
+
+def test_flip_rotate90_vs_reference(emu):
+    import flip_cases as fc
+
+    print("arrays", fc.case_flip_rotate_vs_reference("cpu"))
+    fc.case_flip_rotate_api("cpu")

@@ -108,3 +108,10 @@ def test_croppad_family_vs_reference():
 
     print("arrays", cc.case_croppad_vs_reference(DEV))
     cc.case_croppad_api(DEV)
+
+
+def test_flip_rotate90_vs_reference():
+    import flip_cases as fc
+
+    print("arrays", fc.case_flip_rotate_vs_reference(DEV))
+    fc.case_flip_rotate_api(DEV)
