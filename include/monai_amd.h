@@ -252,6 +252,14 @@ int mh_crop_pad_f32(const float* src, float* dst, int C, int D, int H, int W, in
 int64_t mh_normalize_stats_workspace_doubles(int C, int64_t n);
 int mh_normalize_stats_f32(const float* src, int C, int64_t n, int nonzero, double* workspace, float* subdiv, void* stream);
 int mh_normalize_apply_f32(const float* src, float* dst, int C, int64_t n, int nonzero, const float* subdiv, void* stream);
+/* ScaleIntensity (monai/transforms/intensity/array.py:445-491; rescale_array, monai/transforms/utils.py:229-251).  src = C runs of n values.
+ * mh_minmax_f32: table (DEVICE float[C][2]) = {min, max} of each run (NaN if the run holds one, as torch.min / max); workspace: DEVICE
+ * float[mh_minmax_workspace_floats(C, n)].  mh_minmax_scale_f32: dst = (src - min) / (max - min) [* b_scale + b_min when rescale]; a run
+ * with min == max takes the reference's branch instead: src * flat_mul when flat_has_mul, else src.  No host synchronisation. */
+int64_t mh_minmax_workspace_floats(int C, int64_t n);
+int mh_minmax_f32(const float* src, int C, int64_t n, float* workspace, float* table, void* stream);
+int mh_minmax_scale_f32(const float* src, float* dst, int C, int64_t n, const float* table, int rescale, float b_scale, float b_min,
+                        int flat_has_mul, float flat_mul, void* stream);
 /* Orientation (monai/transforms/spatial/functional.py:187-229: torch.flip over the reversed axes, then permute):
  * src [C][in_size3] -> dst [C][out], out axis k = input axis perm3[k] (HOST int32[3], a permutation of 0..2), input axis a
  * read backwards when flip3[a] != 0 (HOST int32[3]).  Images with fewer spatial axes pass leading extents of 1. */

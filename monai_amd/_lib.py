@@ -70,6 +70,9 @@ SIGNATURES = {
     "mh_normalize_stats_workspace_doubles": (_L, [_I, _L]),
     "mh_normalize_stats_f32": (_I, [_P, _I, _L, _I, _P, _P, _P]),
     "mh_normalize_apply_f32": (_I, [_P, _P, _I, _L, _I, _P, _P]),
+    "mh_minmax_workspace_floats": (_L, [_I, _L]),
+    "mh_minmax_f32": (_I, [_P, _I, _L, _P, _P, _P]),
+    "mh_minmax_scale_f32": (_I, [_P, _P, _I, _L, _P, _I, _F, _F, _I, _F, _P]),
     "mh_maxpool2_f32": (_I, [_T, _T, _P]),
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),

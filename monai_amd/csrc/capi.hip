@@ -817,6 +817,33 @@ int mh_normalize_apply_f32(const float* src, float* dst, int C, int64_t n, int n
     return launched("normalize_apply");
 }
 
+int64_t mh_minmax_workspace_floats(int C, int64_t n) {
+    if (C < 1 || n < 1) return fail(MH_ERR_ARG, "minmax: bad argument");
+    return (int64_t)C * normalize_parts(n) * 2;
+}
+
+int mh_minmax_f32(const float* src, int C, int64_t n, float* workspace, float* table, void* stream) {
+    if (!src || !workspace || !table || C < 1 || C > 65535 || n < 1) return fail(MH_ERR_ARG, "minmax: bad argument");
+    const int parts = normalize_parts(n);
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, (hipStream_t)stream, src, (long long)n, workspace);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, workspace, parts, table);
+    return launched("minmax");
+}
+
+int mh_minmax_scale_f32(const float* src, float* dst, int C, int64_t n, const float* table, int rescale, float b_scale, float b_min,
+                        int flat_has_mul, float flat_mul, void* stream) {
+    if (!src || !dst || !table || C < 1 || C > 65535 || n < 1) return fail(MH_ERR_ARG, "minmax_scale: bad argument");
+    if (n > 0x7fffffffLL * 1024) return fail(MH_ERR_UNSUPPORTED, "minmax_scale: problem too large for one launch");
+    MinMaxScale p;
+    p.b_scale = b_scale; p.b_min = b_min; p.flat_mul = flat_mul; p.rescale = rescale != 0; p.flat_has_mul = flat_has_mul != 0;
+    const dim3 grid(blocks_for((n + 3) / 4), (unsigned)C);
+    if (aligned(src, 16) && aligned(dst, 16) && n % 4 == 0)
+        hipLaunchKernelGGL(minmax_scale_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, table, p);
+    else
+        hipLaunchKernelGGL(minmax_scale_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, dst, (long long)n, table, p);
+    return launched("minmax_scale");
+}
+
 int mh_flip_permute_f32(const float* src, float* dst, int C, const int32_t* in_size3, const int32_t* perm3, const int32_t* flip3, void* stream) {
     if (!src || !dst || !in_size3 || !perm3 || !flip3 || C < 1) return fail(MH_ERR_ARG, "flip_permute: bad argument");
     int seen = 0;

@@ -1,7 +1,7 @@
 // Intensity / crop pre-processing in front of the sliding-window path: ScaleIntensityRange
 // (monai/transforms/intensity/array.py:958-1012), the foreground bounding box of CropForeground
 // (generate_spatial_bounding_box, monai/transforms/utils.py:1069-1129) and its crop + constant pad
-// (monai/transforms/croppad/array.py:776-960), the flip + axis permutation of Orientation, NormalizeIntensity.  Channel-first fp32 volumes [C][D][H][W], lanes along W.
+// (monai/transforms/croppad/array.py:776-960), the flip + axis permutation of Orientation, NormalizeIntensity, ScaleIntensity.  Channel-first fp32 volumes [C][D][H][W], lanes along W.
 // All three are HBM-bound: scale reads 4 B + writes 4 B per voxel, the box reads C x 4 B per voxel and writes 24 B per
 // workgroup, crop+pad reads <= 4 B and writes 4 B per output voxel.
 #pragma once
@@ -207,6 +207,75 @@ __global__ void __launch_bounds__(256) masked_normalize_kernel(const float* __re
         const float v = src[off + j];
         dst[off + j] = (NONZERO && v == 0.0f) ? v : (v - sub) / div;
     }
+}
+
+// ScaleIntensity (monai/transforms/intensity/array.py:445-491 -> rescale_array, monai/transforms/utils.py:229-251): min / max of the whole
+// image or of each channel, then (x - min) / (max - min) [* (maxv - minv) + minv].  Exact reductions (NaN propagates like torch.min / max),
+// one {min, max} record per workgroup, a one-wave fold per channel that leaves {min, max} in device memory; the apply pass forms
+// max - min in fp32 itself (the reference's rounding) and takes the reference's `min == max` branch (x * minv, or x) per channel.
+__global__ void __launch_bounds__(256) minmax_partial_kernel(const float* __restrict__ src, long long n, float* __restrict__ partial) {
+    const float* p = src + (long long)blockIdx.y * n;
+    float mn = INFINITY, mx = -INFINITY;
+    bool nan = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = p[i];
+        nan |= v != v;
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    }
+    if (nan) { mn = NAN; mx = NAN; }
+    __shared__ float red[2][256];
+    red[0][threadIdx.x] = mn; red[1][threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool any_nan = false;
+        for (int k = 0; k < 256; ++k) {
+            any_nan |= red[0][k] != red[0][k];
+            mn = fminf(mn, red[0][k]); mx = fmaxf(mx, red[1][k]);
+        }
+        float* o = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        o[0] = any_nan ? NAN : mn; o[1] = any_nan ? NAN : mx;
+    }
+}
+__global__ void __launch_bounds__(64) minmax_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ table) {
+    if (threadIdx.x != 0) return;
+    const float* rec = partial + (long long)blockIdx.x * nparts * 2;
+    float mn = INFINITY, mx = -INFINITY;
+    bool any_nan = false;
+    for (int i = 0; i < nparts; ++i) {
+        any_nan |= rec[2 * i] != rec[2 * i];
+        mn = fminf(mn, rec[2 * i]); mx = fmaxf(mx, rec[2 * i + 1]);
+    }
+    table[2 * blockIdx.x] = any_nan ? NAN : mn;
+    table[2 * blockIdx.x + 1] = any_nan ? NAN : mx;
+}
+struct MinMaxScale {
+    float b_scale, b_min, flat_mul;
+    int rescale, flat_has_mul;
+};
+__device__ __forceinline__ float minmax_scale_one(float x, float mn, float div, bool flat, const MinMaxScale& p) {
+    if (flat) return p.flat_has_mul ? x * p.flat_mul : x;          // rescale_array: `arr * minv if minv is not None else arr`
+    float v = (x - mn) / div;
+    if (p.rescale) { v = v * p.b_scale; v = v + p.b_min; }
+    return v;
+}
+template <bool VEC>
+__global__ void __launch_bounds__(256) minmax_scale_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n,
+                                                           const float* __restrict__ table, MinMaxScale p) {
+    const long long off = (long long)blockIdx.y * n;
+    const float mn = table[2 * blockIdx.y], mx = table[2 * blockIdx.y + 1];
+    const bool flat = mn == mx;
+    const float div = mx - mn;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (VEC && i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(src + off + i);
+        float4 r;
+        r.x = minmax_scale_one(v.x, mn, div, flat, p); r.y = minmax_scale_one(v.y, mn, div, flat, p);
+        r.z = minmax_scale_one(v.z, mn, div, flat, p); r.w = minmax_scale_one(v.w, mn, div, flat, p);
+        *reinterpret_cast<float4*>(dst + off + i) = r;
+        return;
+    }
+    for (long long j = i; j < n && j < i + 4; ++j) dst[off + j] = minmax_scale_one(src[off + j], mn, div, flat, p);
 }
 
 }  // namespace mh

@@ -405,3 +405,19 @@ def deconv_ks(x, x_nrm, weight, bias, out, factors: Sequence[int]):
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
     _lib.lib().call("mh_deconv_ks_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), int(factors[0]), int(factors[1]), int(factors[2]), _s(x))
     return out
+
+
+def minmax_scale(src: torch.Tensor, channels: int, n: int, b_scale: Optional[float], b_min: float, flat_mul: Optional[float]) -> torch.Tensor:
+    """rescale_array per run of n values: (x - min) / (max - min) [* b_scale + b_min when b_scale is not None]; a constant run becomes
+    x * flat_mul (x when flat_mul is None).  Min / max stay on the device between the two passes."""
+    _lib.require_device(src)
+    if not src.is_contiguous() or src.numel() != channels * n or n < 1:
+        raise RuntimeError("monai_amd.minmax_scale: contiguous tensor of channels * n elements required")
+    L = _lib.lib()
+    ws = torch.empty(L.query("mh_minmax_workspace_floats", int(channels), int(n)) + 2 * int(channels), dtype=torch.float32, device=src.device)
+    table = ws[-2 * int(channels):]
+    out = torch.empty_like(src)
+    L.call("mh_minmax_f32", _lib.ptr(src), int(channels), int(n), _lib.ptr(ws), _lib.ptr(table), _s(src))
+    L.call("mh_minmax_scale_f32", _lib.ptr(src), _lib.ptr(out), int(channels), int(n), _lib.ptr(table), int(b_scale is not None), float(b_scale or 0.0),
+           float(b_min), int(flat_mul is not None), float(flat_mul or 0.0), _s(src))
+    return out

@@ -65,6 +65,7 @@ _TARGETS = {
         "GaussianSmooth": ("monai_amd.transforms.intensity.array", "GaussianSmooth"),
         "ScaleIntensityRange": ("monai_amd.transforms.intensity.array", "ScaleIntensityRange"),
         "NormalizeIntensity": ("monai_amd.transforms.intensity.array", "NormalizeIntensity"),
+        "ScaleIntensity": ("monai_amd.transforms.intensity.array", "ScaleIntensity"),
     },
     "monai.transforms.croppad.array": {n: ("monai_amd.transforms.croppad.array", n) for n in
                                        ("CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop")},
@@ -97,6 +98,9 @@ _TARGETS = {
         "NormalizeIntensityd": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
         "NormalizeIntensityD": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
         "NormalizeIntensityDict": ("monai_amd.transforms.intensity.dictionary", "NormalizeIntensityd"),
+        "ScaleIntensityd": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityd"),
+        "ScaleIntensityD": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityd"),
+        "ScaleIntensityDict": ("monai_amd.transforms.intensity.dictionary", "ScaleIntensityd"),
     },
     "monai.networks.layers.spatial_transforms": {
         "AffineTransform": ("monai_amd.networks.layers.spatial_transforms", "AffineTransform"),

@@ -5,7 +5,7 @@ from .croppad import (  # noqa: F401
 )
 from .intensity import (  # noqa: F401
     GaussianSmooth, GaussianSmoothD, GaussianSmoothDict, GaussianSmoothd, NormalizeIntensity, NormalizeIntensityD, NormalizeIntensityDict,
-    NormalizeIntensityd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
+    NormalizeIntensityd, ScaleIntensity, ScaleIntensityD, ScaleIntensityDict, ScaleIntensityd, ScaleIntensityRange, ScaleIntensityRangeD, ScaleIntensityRangeDict,
     ScaleIntensityRanged,
 )
 from .spatial import Flip, FlipD, FlipDict, Flipd, Rotate90, Rotate90D, Rotate90Dict, Rotate90d  # noqa: F401

@@ -10,7 +10,7 @@ import torch
 from ...data.meta_tensor import is_meta
 from ...networks.layers.simplelayers import GaussianFilter
 
-__all__ = ["GaussianSmooth", "ScaleIntensityRange", "NormalizeIntensity"]
+__all__ = ["GaussianSmooth", "ScaleIntensityRange", "NormalizeIntensity", "ScaleIntensity"]
 
 
 class GaussianSmooth:
@@ -136,6 +136,42 @@ class NormalizeIntensity:
             out = ops.normalize_apply(x, c, n, self.nonzero, table)
         if out.dtype != dtype:
             out = out.to(dtype)
+        if is_meta(img):
+            return type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
+        return out
+
+
+class ScaleIntensity:
+    """``monai.transforms.ScaleIntensity`` (monai/transforms/intensity/array.py:445-491): rescale to ``[minv, maxv]`` from the image's (or
+    each channel's) own minimum / maximum, or multiply by ``1 + factor`` when both are None.  Min / max are exact reductions left in device
+    memory, the apply pass keeps the reference's fp32 operator sequence: bit-identical results, no host round trip.  The reference
+    converts the image to ``dtype`` BEFORE the arithmetic (rescale_array, monai/transforms/utils.py:229-251); float32 is on the HIP path."""
+
+    def __init__(self, minv: float | None = 0.0, maxv: float | None = 1.0, factor: float | None = None, channel_wise: bool = False,
+                 dtype=torch.float32) -> None:
+        self.minv, self.maxv, self.factor, self.channel_wise, self.dtype = minv, maxv, factor, channel_wise, dtype
+
+    def __call__(self, img):
+        from ... import ops
+
+        data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        dtype = _to_torch_dtype(self.dtype)
+        if data.dtype in (torch.float64, torch.float16, torch.bfloat16) or data.is_complex() or dtype not in (None, torch.float32):
+            raise NotImplementedError("monai_amd.ScaleIntensity: float32 arithmetic only (float32 / integer images, dtype float32 or None)")
+        if dtype is None and data.dtype != torch.float32:
+            raise NotImplementedError("monai_amd.ScaleIntensity: dtype=None on an integer image is integer arithmetic in the reference; not on the HIP path")
+        x = data.to(torch.float32).contiguous()
+        if self.minv is not None or self.maxv is not None:
+            c = int(x.shape[0]) if self.channel_wise and x.dim() > 0 else 1
+            if not x.numel():
+                out = x
+            else:
+                both = self.minv is not None and self.maxv is not None
+                out = ops.minmax_scale(x, c, x.numel() // c, (self.maxv - self.minv) if both else None, self.minv if both else 0.0, self.minv)
+        elif self.factor is not None:
+            out = ops.scale_intensity_range(x, 0.0, 1.0, 1 + self.factor, 0.0, None, None)      # (x - 0) / 1 * (1 + factor) + 0: exact steps around one multiply
+        else:
+            out = x
         if is_meta(img):
             return type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
         return out

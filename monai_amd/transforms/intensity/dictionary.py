@@ -3,10 +3,10 @@
 from __future__ import annotations
 
 from ...utils.misc import ensure_tuple
-from .array import GaussianSmooth, NormalizeIntensity, ScaleIntensityRange
+from .array import GaussianSmooth, NormalizeIntensity, ScaleIntensity, ScaleIntensityRange
 
 __all__ = ["GaussianSmoothd", "GaussianSmoothD", "GaussianSmoothDict", "ScaleIntensityRanged", "ScaleIntensityRangeD", "ScaleIntensityRangeDict",
-           "NormalizeIntensityd", "NormalizeIntensityD", "NormalizeIntensityDict"]
+           "NormalizeIntensityd", "NormalizeIntensityD", "NormalizeIntensityDict", "ScaleIntensityd", "ScaleIntensityD", "ScaleIntensityDict"]
 
 
 class GaussianSmoothd:
@@ -53,3 +53,15 @@ class NormalizeIntensityd(GaussianSmoothd):
 
 
 NormalizeIntensityD = NormalizeIntensityDict = NormalizeIntensityd
+
+
+class ScaleIntensityd(GaussianSmoothd):
+    """Dictionary version of :class:`ScaleIntensity` (monai/transforms/intensity/dictionary.py:547-590)."""
+
+    def __init__(self, keys, minv=0.0, maxv=1.0, factor=None, channel_wise: bool = False, dtype="float32", allow_missing_keys: bool = False) -> None:
+        self.keys = ensure_tuple(keys)
+        self.allow_missing_keys = allow_missing_keys
+        self.scaler = self.converter = ScaleIntensity(minv, maxv, factor, channel_wise, dtype)
+
+
+ScaleIntensityD = ScaleIntensityDict = ScaleIntensityd

@@ -15,11 +15,14 @@ sys.path.insert(0, "/root/reference")
 import monai.transforms as ref  # noqa: E402
 from monai.inferers import SlidingWindowInferer  # noqa: E402
 from monai.networks.nets import SegResNet  # noqa: E402
-from normalize_cases import make_net, run_all, run_pipeline  # noqa: E402
+from normalize_cases import make_net, run_all, run_pipeline, run_scale_intensity  # noqa: E402
 
 out = {k: np.asarray(v) for k, v in run_all(ref, "cpu").items()}
 np.savez_compressed(os.path.join(HERE, "normalize.npz"), **out)
 print("normalize golden:", len(out), "arrays")
+si = {k: np.asarray(v) for k, v in run_scale_intensity(ref, "cpu").items()}
+np.savez_compressed(os.path.join(HERE, "scale_intensity.npz"), **si)
+print("scale_intensity golden:", len(si), "arrays")
 ns = SimpleNamespace(NormalizeIntensityd=ref.NormalizeIntensityd, SlidingWindowInferer=SlidingWindowInferer, Activationsd=ref.Activationsd,
                      AsDiscreted=ref.AsDiscreted)
 pipe = run_pipeline(ns, make_net(SegResNet), "cpu")

@@ -131,3 +131,47 @@ def case_mri_pipeline_vs_reference(device):
     assert dn < 1e-5 and dl < 1e-4 and dp < 1e-4, (dn, dl, dp)
     assert worst < 2e-4, (int(mism.sum()), worst)
     return {"max_normalized_diff": dn, "max_logit_diff": dl, "max_prob_diff": dp, "mask_mismatches": int(mism.sum()), "voxels": int(mism.size)}
+
+
+# ---------------------------------------------------------------------------------------------- ScaleIntensity
+SCALE_INT_CASES = [
+    ("si_default", {}),
+    ("si_range", {"minv": -1.0, "maxv": 2.5}),
+    ("si_channel", {"channel_wise": True}),
+    ("si_channel_range", {"minv": 10.0, "maxv": 20.0, "channel_wise": True}),
+    ("si_minv_only", {"minv": 3.0, "maxv": None}),
+    ("si_maxv_only", {"minv": None, "maxv": 3.0}),
+    ("si_factor", {"minv": None, "maxv": None, "factor": 0.37}),
+    ("si_nothing", {"minv": None, "maxv": None}),
+]
+
+
+def run_scale_intensity(mod_transforms, device):
+    out = {}
+    for name, kw in SCALE_INT_CASES:
+        out[name] = torch.as_tensor(mod_transforms.ScaleIntensity(**kw)(mri().to(device))).cpu().numpy()
+    flat = mri()
+    flat[2] = 4.25                                              # one constant channel: the reference's `min == max` branch
+    out["si_flat_channel"] = torch.as_tensor(mod_transforms.ScaleIntensity(minv=2.0, maxv=3.0, channel_wise=True)(flat.to(device))).cpu().numpy()
+    out["si_flat_noscale"] = torch.as_tensor(mod_transforms.ScaleIntensity(minv=None, maxv=1.0)(torch.full((1, 3, 4, 5), -2.0).to(device))).cpu().numpy()
+    withnan = mri()
+    withnan[1, 3, 3, 3] = float("nan")
+    out["si_nan_channel"] = torch.as_tensor(mod_transforms.ScaleIntensity(channel_wise=True)(withnan.to(device))).cpu().numpy()
+    out["si_int16"] = torch.as_tensor(mod_transforms.ScaleIntensity()(mri(1).to(torch.int16).to(device))).cpu().numpy()
+    out["si_odd"] = torch.as_tensor(mod_transforms.ScaleIntensity(channel_wise=True)(mri(2, (3, 5, 7, 9)).to(device))).cpu().numpy()
+    d = mod_transforms.ScaleIntensityd(keys=["image"], minv=0.0, maxv=255.0)({"image": mri(3).to(device)})
+    out["sid_image"] = torch.as_tensor(d["image"]).cpu().numpy()
+    return out
+
+
+def case_scale_intensity_vs_reference(device):
+    """ScaleIntensity(d) against the real reference transform: bit-identical (exact reductions, the reference's fp32 operator sequence)"""
+    import monai_amd.transforms as ours
+
+    g = np.load(os.path.join(GOLDEN, "scale_intensity.npz"))
+    got = run_scale_intensity(ours, device)
+    assert set(got) == set(g.files), set(got) ^ set(g.files)
+    for name, y in got.items():
+        assert y.shape == g[name].shape and y.dtype == g[name].dtype, name
+        np.testing.assert_array_equal(y, g[name], err_msg=name)
+    return len(got)

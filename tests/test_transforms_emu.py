@@ -177,3 +177,9 @@ def test_flip_rotate90_vs_reference(emu):
 
     print("arrays", fc.case_flip_rotate_vs_reference("cpu"))
     fc.case_flip_rotate_api("cpu")
+
+
+def test_scale_intensity_vs_reference(emu):
+    import normalize_cases as nc
+
+    print("arrays", nc.case_scale_intensity_vs_reference("cpu"))

@@ -83,6 +83,7 @@ def test_normalize_intensity_and_mri_pipeline():
     print("worst relative error", nc.case_normalize_vs_reference(DEV))
     nc.case_normalize_api(DEV)
     print(nc.case_mri_pipeline_vs_reference(DEV))
+    print("ScaleIntensity arrays", nc.case_scale_intensity_vs_reference(DEV))
 
 
 def test_unet_batch_norm_vs_reference():
