@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from monai_amd import ops  # noqa: E402
 from monai_amd.data import MetaTensor  # noqa: E402
-from monai_amd.transforms import CropForeground, NormalizeIntensity, Orientation, ScaleIntensityRange  # noqa: E402
+from monai_amd.transforms import CropForeground, NormalizeIntensity, Orientation, ScaleIntensity, ScaleIntensityRange  # noqa: E402
 
 dev = torch.device("cuda")
 E = int(os.environ.get("PB_EDGE", "512"))
@@ -47,6 +47,8 @@ add("device copy (read + write)", timeit(lambda: y.copy_(x)), 2 * vol)
 sc = ScaleIntensityRange(-175.0, 250.0, 0.0, 1.0, clip=True)
 add("ScaleIntensityRange (transform call)", timeit(lambda: sc(x)), 2 * vol)
 add("scale_range_kernel", timeit(lambda: ops.scale_intensity_range(x, -175.0, 425.0, 1.0, 0.0, 0.0, 1.0)), 2 * vol)
+si = ScaleIntensity(minv=0.0, maxv=1.0)
+add("ScaleIntensity (min / max + fold + apply)", timeit(lambda: si(x)), 3 * vol)
 nz = NormalizeIntensity(nonzero=True, channel_wise=True)
 add("NormalizeIntensity nonzero channel_wise (stats + fold + apply)", timeit(lambda: nz(x)), 3 * vol)
 add("masked_stats_kernel + fold", timeit(lambda: ops.normalize_stats(x, 1, x.numel(), True)), vol)
