@@ -141,6 +141,7 @@ def install(native_module: bool = True) -> list:
                         _installed[(parent, name)] = getattr(pm, name)
                     setattr(pm, name, obj)
             done.append(f"{ref_mod_name}.{name}")
+    _register_transform_traits()
     if native_module and "monai._C" not in sys.modules:
         try:
             importlib.import_module("monai._C")
@@ -150,6 +151,27 @@ def install(native_module: bool = True) -> list:
             sys.modules["monai._C"] = _C
             done.append("monai._C")
     return done
+
+
+def _register_transform_traits() -> None:
+    """MONAI's ``Compose`` / ``Invertd`` / ``allow_missing_keys_mode`` select transforms with ``isinstance`` checks against ``MapTransform`` and
+    ``InvertibleTransform`` (monai/transforms/compose.py:600-625, monai/transforms/utils.py:1705-1745).  ``Transform`` is an ABC, so the
+    MI355X classes are registered as VIRTUAL subclasses: dictionary transforms as ``MapTransform``, everything with an ``inverse`` as
+    ``InvertibleTransform`` -- a bundle's ``Invertd(transform="@preprocessing")`` then walks them like the reference's own classes."""
+    from monai.transforms import InvertibleTransform, MapTransform, Transform
+
+    for ref_mod_name, names in _TARGETS.items():
+        if not ref_mod_name.startswith("monai.transforms."):
+            continue
+        for our_mod_name, our_name in set(names.values()):
+            cls = getattr(importlib.import_module(our_mod_name), our_name)
+            if not isinstance(cls, type):
+                continue
+            Transform.register(cls)
+            if ref_mod_name.endswith(".dictionary"):
+                MapTransform.register(cls)
+            if callable(getattr(cls, "inverse", None)):
+                InvertibleTransform.register(cls)
 
 
 def uninstall() -> None:

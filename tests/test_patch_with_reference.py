@@ -102,3 +102,42 @@ def test_reference_checkpoint_loads_into_amd_unet_and_unetr(monai_ref, which):
     net = ConfigParser({"network": {"_target_": which, **{k: list(v) if isinstance(v, tuple) else v for k, v in kw.items()}}}).get_parsed_content("network")
     assert isinstance(net, OurNet)
     patch.uninstall()
+
+
+def test_monai_compose_and_invertd_drive_the_amd_transforms(monai_ref, emu):
+    """An unchanged bundle's pre-processing ``Compose`` and its ``Invertd(transform="@preprocessing")`` post-processing run on the MI355X classes
+    after ``patch.install()`` (virtual ``MapTransform`` / ``InvertibleTransform`` registration): forward result, inverted prediction and its
+    affine equal the pure-reference run of the same chain."""
+    import numpy as np
+
+    import monai_amd.patch as patch
+    import pipeline_ct_case as pc
+    from monai.data import MetaTensor
+
+    def run(ns):
+        pre = ns.Compose([
+            ns.ScaleIntensityRanged(keys=["image"], a_min=-175.0, a_max=250.0, b_min=0.0, b_max=1.0, clip=True),
+            ns.CropForegroundd(keys=["image"], source_key="image", margin=2),
+            ns.Spacingd(keys=["image"], pixdim=(1.5, 1.5, 2.0), mode="bilinear"),
+            ns.DivisiblePadd(keys=["image"], k=8),
+            ns.Flipd(keys=["image"], spatial_axis=0),
+        ])
+        post = ns.Compose([ns.Invertd(keys="pred", transform=pre, orig_keys="image", nearest_interp=False, to_tensor=True)])
+        d = pre({"image": MetaTensor(pc.volume(), affine=pc.AFFINE)})
+        x = d["image"]
+        d["pred"] = MetaTensor(torch.sin(x.as_tensor() * 3.0), meta=dict(x.meta), applied_operations=[])     # a stand-in prediction
+        return x, post(d)["pred"]
+
+    import monai.transforms as T
+
+    x_ref, inv_ref = run(T)
+    patch.install()
+    from monai_amd.transforms.spatial.dictionary import Spacingd as OurSpacingd
+
+    assert T.Spacingd is OurSpacingd and isinstance(OurSpacingd(keys=["image"], pixdim=(1.0, 1.0, 1.0)), T.MapTransform)
+    x_our, inv_our = run(T)
+    patch.uninstall()
+    assert tuple(x_our.shape) == tuple(x_ref.shape) and tuple(inv_our.shape) == tuple(inv_ref.shape) == (1, 48, 56, 40)
+    assert float((x_our.as_tensor() - x_ref.as_tensor()).abs().max()) < 2e-6
+    assert float((torch.as_tensor(inv_our) - torch.as_tensor(inv_ref)).abs().max()) < 2e-6
+    np.testing.assert_allclose(np.asarray(inv_our.affine), np.asarray(inv_ref.affine), rtol=0, atol=1e-9)
