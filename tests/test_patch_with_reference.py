@@ -141,3 +141,69 @@ def test_monai_compose_and_invertd_drive_the_amd_transforms(monai_ref, emu):
     assert float((x_our.as_tensor() - x_ref.as_tensor()).abs().max()) < 2e-6
     assert float((torch.as_tensor(inv_our) - torch.as_tensor(inv_ref)).abs().max()) < 2e-6
     np.testing.assert_allclose(np.asarray(inv_our.affine), np.asarray(inv_ref.affine), rtol=0, atol=1e-9)
+
+
+def test_spleen_shaped_bundle_config_runs_on_the_amd_classes(monai_ref, emu):
+    """A bundle ``inference.json`` in the shape of MONAI's CT segmentation bundles (Orientationd / Spacingd / ScaleIntensityRanged / CropForegroundd ->
+    UNet(norm="batch") under SlidingWindowInferer -> Activationsd / Invertd / AsDiscreted), parsed by the reference's own ``ConfigParser``: every
+    ``_target_`` resolves to the MI355X class after ``patch.install()`` and the result equals the reference classes' run of the same chain (the
+    volume is already RAS, so the reference chain -- which cannot import nibabel here -- simply omits the no-op Orientationd)."""
+    import numpy as np
+
+    import monai_amd.patch as patch
+    import pipeline_ct_case as pc
+    from monai.bundle import ConfigParser
+    from monai.data import MetaTensor
+
+    def config(with_orientation):
+        pre = [
+            {"_target_": "Spacingd", "keys": "image", "pixdim": [1.5, 1.5, 2.0], "mode": "bilinear"},
+            {"_target_": "ScaleIntensityRanged", "keys": "image", "a_min": -57, "a_max": 164, "b_min": 0.0, "b_max": 1.0, "clip": True},
+            {"_target_": "CropForegroundd", "keys": "image", "source_key": "image", "k_divisible": 16},
+        ]
+        if with_orientation:
+            pre.insert(0, {"_target_": "Orientationd", "keys": "image", "axcodes": "RAS"})
+        return {
+            "network_def": {"_target_": "UNet", "spatial_dims": 3, "in_channels": 1, "out_channels": 2, "channels": [16, 32, 64], "strides": [2, 2],
+                            "num_res_units": 2, "norm": "batch"},
+            "preprocessing": {"_target_": "Compose", "transforms": pre},
+            "inferer": {"_target_": "SlidingWindowInferer", "roi_size": [32, 32, 32], "sw_batch_size": 2, "overlap": 0.5},
+            "postprocessing": {"_target_": "Compose", "transforms": [
+                {"_target_": "Activationsd", "keys": "pred", "softmax": True},
+                {"_target_": "Invertd", "keys": "pred", "transform": "@preprocessing", "orig_keys": "image", "nearest_interp": False, "to_tensor": True},
+                {"_target_": "AsDiscreted", "keys": "pred", "argmax": True},
+            ]},
+        }
+
+    def run(with_orientation):
+        parser = ConfigParser(config(with_orientation))
+        torch.manual_seed(21)
+        net = parser.get_parsed_content("network_def").eval()
+        with torch.no_grad():
+            for k, v in net.state_dict().items():          # non-trivial batch-norm statistics
+                if k.endswith("running_var"):
+                    v.fill_(0.8)
+                elif k.endswith("running_mean"):
+                    v.fill_(0.05)
+        pre, post, inferer = (parser.get_parsed_content(k) for k in ("preprocessing", "postprocessing", "inferer"))
+        d = pre({"image": MetaTensor(pc.volume(), affine=pc.AFFINE)})
+        with torch.no_grad():
+            logits = inferer(d["image"][None], net)
+        d["pred"] = MetaTensor(logits[0], meta=dict(d["image"].meta), applied_operations=[])
+        out = post(d)
+        return parser, logits, out["pred"]
+
+    _, logits_ref, label_ref = run(False)
+    patch.install()
+    parser, logits_our, label_our = run(True)
+    names = {k: type(parser.get_parsed_content(k)).__module__ for k in ("network_def", "inferer")}
+    pre_mods = [type(t).__module__ for t in parser.get_parsed_content("preprocessing").transforms]
+    patch.uninstall()
+    from monai_amd.networks.nets.unet import UNet as OurUNet
+
+    assert isinstance(parser.get_parsed_content("network_def"), OurUNet) and names["inferer"] == "monai.inferers.inferer"
+    assert all(m.startswith("monai.transforms.") for m in pre_mods)            # rebound in place: ComponentLocator found them by short name
+    assert tuple(label_our.shape) == tuple(label_ref.shape) == (1, 48, 56, 40)
+    assert float((logits_our - logits_ref).abs().max()) < 1e-4
+    mism = torch.as_tensor(label_our) != torch.as_tensor(label_ref)
+    assert int(mism.sum()) <= 8, int(mism.sum())       # argmax after a resampling inverse: ties at interpolated probabilities ~0.5 only
