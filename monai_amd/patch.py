@@ -172,6 +172,10 @@ def _register_transform_traits() -> None:
                 MapTransform.register(cls)
             if callable(getattr(cls, "inverse", None)):
                 InvertibleTransform.register(cls)
+    from monai.inferers import Inferer          # an ABC as well: `isinstance(x, Inferer)` checks in user code keep holding
+
+    for our_mod_name, our_name in set(_TARGETS["monai.inferers.inferer"].values()):
+        Inferer.register(getattr(importlib.import_module(our_mod_name), our_name))
 
 
 def uninstall() -> None:

@@ -43,6 +43,9 @@ def test_bundle_targets_resolve_to_amd_classes(monai_ref):
     parser = ConfigParser(cfg)
     assert type(parser.get_parsed_content("inferer")).__module__ == "monai.inferers.inferer"
     assert isinstance(parser.get_parsed_content("inferer"), Ours)
+    from monai.inferers import Inferer
+
+    assert isinstance(parser.get_parsed_content("inferer"), Inferer)        # virtual subclass of the reference's ABC
     from monai_amd.networks.nets.basic_unet import BasicUNet as OurNet
     from monai_amd.transforms.intensity.dictionary import GaussianSmoothd as OurSmooth
     from monai_amd.transforms.spatial.dictionary import Spacingd as OurSpacingd
