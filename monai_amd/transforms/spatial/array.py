@@ -84,7 +84,8 @@ class SpatialResample:
         prev = type(data)(data.as_tensor(), meta=dict(data.meta), applied_operations=list(data.applied_operations[:-1]))
         out = SpatialResample.__call__(
             self, prev, dst_affine=info["src_affine"], spatial_size=rec["orig_size"], mode=info["mode"], padding_mode=info["padding_mode"],
-            align_corners=bool(info["align_corners"]) if info["align_corners"] is not None else False, dtype=getattr(torch, info["dtype"]),
+            # MONAI's convert_applied_interp_mode (Invertd(nearest_interp=True)) rewrites the record with TraceKeys.NONE = "none"
+            align_corners=bool(info["align_corners"]) if info["align_corners"] not in (None, "none") else False, dtype=getattr(torch, info["dtype"]),
         )
         if is_meta(out):
             out.applied_operations = list(data.applied_operations[:-1])

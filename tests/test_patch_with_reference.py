@@ -117,15 +117,16 @@ def test_monai_compose_and_invertd_drive_the_amd_transforms(monai_ref, emu):
     import pipeline_ct_case as pc
     from monai.data import MetaTensor
 
-    def run(ns):
+    def run(ns, nearest=False):
         pre = ns.Compose([
             ns.ScaleIntensityRanged(keys=["image"], a_min=-175.0, a_max=250.0, b_min=0.0, b_max=1.0, clip=True),
             ns.CropForegroundd(keys=["image"], source_key="image", margin=2),
-            ns.Spacingd(keys=["image"], pixdim=(1.5, 1.5, 2.0), mode="bilinear"),
+            # nearest: spacing ratios without exact .5 source coordinates (a tie may legitimately resolve either way)
+            ns.Spacingd(keys=["image"], pixdim=(1.37, 1.11, 1.83) if nearest else (1.5, 1.5, 2.0), mode="bilinear"),
             ns.DivisiblePadd(keys=["image"], k=8),
             ns.Flipd(keys=["image"], spatial_axis=0),
         ])
-        post = ns.Compose([ns.Invertd(keys="pred", transform=pre, orig_keys="image", nearest_interp=False, to_tensor=True)])
+        post = ns.Compose([ns.Invertd(keys="pred", transform=pre, orig_keys="image", nearest_interp=nearest, to_tensor=True)])
         d = pre({"image": MetaTensor(pc.volume(), affine=pc.AFFINE)})
         x = d["image"]
         d["pred"] = MetaTensor(torch.sin(x.as_tensor() * 3.0), meta=dict(x.meta), applied_operations=[])     # a stand-in prediction
@@ -134,12 +135,16 @@ def test_monai_compose_and_invertd_drive_the_amd_transforms(monai_ref, emu):
     import monai.transforms as T
 
     x_ref, inv_ref = run(T)
+    xn_ref, invn_ref = run(T, nearest=True)
     patch.install()
     from monai_amd.transforms.spatial.dictionary import Spacingd as OurSpacingd
 
     assert T.Spacingd is OurSpacingd and isinstance(OurSpacingd(keys=["image"], pixdim=(1.0, 1.0, 1.0)), T.MapTransform)
     x_our, inv_our = run(T)
+    xn_our, invn_our = run(T, nearest=True)       # Invertd's default: the recorded interpolation modes rewritten to "nearest" (TraceKeys.NONE align_corners)
     patch.uninstall()
+    assert float((xn_our.as_tensor() - xn_ref.as_tensor()).abs().max()) < 2e-6
+    assert float((torch.as_tensor(invn_our) - torch.as_tensor(invn_ref)).abs().max()) < 2e-6
     assert tuple(x_our.shape) == tuple(x_ref.shape) and tuple(inv_our.shape) == tuple(inv_ref.shape) == (1, 48, 56, 40)
     assert float((x_our.as_tensor() - x_ref.as_tensor()).abs().max()) < 2e-6
     assert float((torch.as_tensor(inv_our) - torch.as_tensor(inv_ref)).abs().max()) < 2e-6
