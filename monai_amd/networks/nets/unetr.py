@@ -295,7 +295,10 @@ class UNETR(nn.Module):
             raise RuntimeError(f"monai_amd.UNETR: expected input (B,{self.in_channels},{self.img_size}), got {tuple(x_in.shape)}")
         x_in = x_in.contiguous()
         fs = self.feature_size
-        x, hs = self._vit(x_in)
+        # an evaluator with amp=True calls the network under torch.autocast: the library GEMMs of the ViT would come back in half precision
+        # and the fp32 attention kernel would (rightly) refuse them.  This engine computes in fp32 throughout (>= the reference's precision).
+        with torch.autocast(device_type=x_in.device.type, enabled=False):
+            x, hs = self._vit(x_in)
 
         # decoder concat buffers: [upsampled | skip]
         cat2 = self._new(x_in, 2 * fs)                       # decoder2 @ full resolution

@@ -93,3 +93,18 @@ def test_dynunet_segresnet_window_vs_oracle(emu):
     import dynunet_cases as dc
 
     print("max |dlogit|", dc.case_nets_window_vs_oracle("cpu", 48, (16, 32, 64)))     # the -m gpu run does this at 96^3 with nnU-Net filters
+
+
+def test_unetr_under_autocast_stays_fp32(emu):
+    """an evaluator with amp=True calls the network inside torch.autocast: the engine keeps computing in fp32 and returns the same logits"""
+    import torch
+
+    from monai_amd.networks.nets import UNETR
+
+    torch.manual_seed(5)
+    net = UNETR(in_channels=1, out_channels=2, img_size=(32, 32, 32), feature_size=8, hidden_size=128, mlp_dim=256, num_heads=2).eval()
+    x = torch.rand(1, 1, 32, 32, 32)
+    y = net(x)
+    with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
+        ya = net(x)
+    assert ya.dtype == torch.float32 and torch.equal(y, ya)
