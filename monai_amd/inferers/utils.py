@@ -275,6 +275,10 @@ def sliding_window_inference(
                         ]
                         logits = [_alloc_logits(shard, nb, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
                     for ss, s in enumerate(segs):
+                        if s.dtype != compute_dtype and s.is_floating_point():
+                            # a predictor under torch.autocast returns half precision; the reference weights it in that precision and
+                            # accumulates in compute_dtype (utils.py:286-288) -- here it is widened first (never less precise)
+                            s = s.to(compute_dtype)
                         _lib.require_device(s)
                         dst = logits[ss][w0 : w0 + n]
                         if w_batch is None:

@@ -105,3 +105,18 @@ def test_patch_inferer_api(emu):
     import patch_cases as pc
 
     pc.case_patch_inferer_api("cpu")
+
+
+def test_half_precision_predictor_output_is_accepted(emu):
+    """a predictor under torch.autocast hands back half precision: widened to the compute dtype, blended in fp32 (the reference blends it too)"""
+    import torch
+
+    from monai_amd.inferers import SlidingWindowInferer
+
+    net = torch.nn.Conv3d(1, 2, 3, padding=1).eval()
+    x = torch.rand(1, 1, 24, 24, 24)
+    inf = SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian")
+    with torch.no_grad():
+        y = inf(x, net)
+        yh = inf(x, lambda w: net(w).to(torch.bfloat16))
+    assert yh.dtype == torch.float32 and float((y - yh).abs().max()) < 1e-2
