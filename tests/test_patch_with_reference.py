@@ -215,3 +215,37 @@ def test_spleen_shaped_bundle_config_runs_on_the_amd_classes(monai_ref, emu):
     assert float((logits_our - logits_ref).abs().max()) < 1e-4
     mism = torch.as_tensor(label_our) != torch.as_tensor(label_ref)
     assert int(mism.sum()) <= 8, int(mism.sum())       # argmax after a resampling inverse: ties at interpolated probabilities ~0.5 only
+
+
+def test_dataset_loader_decollate_invertd_flow(monai_ref, emu):
+    """The evaluator-shaped data flow of a bundle -- ``Dataset(transform=pre)`` -> ``DataLoader`` (MetaTensor collate) -> network on the batch ->
+    ``decollate_batch`` -> per-item ``Invertd`` + ``AsDiscreted`` -- over the patched classes: the records the MI355X transforms push on
+    ``applied_operations`` survive MONAI's collate / decollate, and every label map equals the pure-reference run."""
+    import monai_amd.patch as patch
+    import pipeline_ct_case as pc
+    from monai.data import DataLoader, Dataset, MetaTensor, decollate_batch
+
+    def run(ns):
+        pre = ns.Compose([
+            ns.ScaleIntensityRanged(keys=["image"], a_min=-175.0, a_max=250.0, b_min=0.0, b_max=1.0, clip=True),
+            ns.Spacingd(keys=["image"], pixdim=(1.37, 1.11, 1.83), mode="bilinear"),
+            ns.CenterSpatialCropd(keys=["image"], roi_size=(24, 24, 24)),
+            ns.SpatialPadd(keys=["image"], spatial_size=(32, 32, 32)),
+        ])
+        post = ns.Compose([ns.Invertd(keys="pred", transform=pre, orig_keys="image", nearest_interp=True, to_tensor=True),
+                           ns.AsDiscreted(keys="pred", threshold=0.5)])
+        items = [{"image": MetaTensor(pc.volume() + 10.0 * i, affine=pc.AFFINE)} for i in range(2)]
+        batch = next(iter(DataLoader(Dataset(items, transform=pre), batch_size=2, num_workers=0)))
+        batch["pred"] = torch.sigmoid(batch["image"] * 4.0 - 2.0)            # a stand-in network output on the batch
+        return batch["image"], [post(i)["pred"] for i in decollate_batch(batch)]
+
+    import monai.transforms as T
+
+    x_ref, p_ref = run(T)
+    patch.install()
+    x_our, p_our = run(T)
+    patch.uninstall()
+    assert tuple(x_our.shape) == tuple(x_ref.shape) == (2, 1, 32, 32, 32)
+    assert float((torch.as_tensor(x_our) - torch.as_tensor(x_ref)).abs().max()) < 2e-6
+    for a, b in zip(p_our, p_ref):
+        assert tuple(a.shape) == tuple(b.shape) == (1, 48, 56, 40) and int((torch.as_tensor(a) != torch.as_tensor(b)).sum()) == 0
