@@ -39,6 +39,11 @@ def test_bundle_targets_resolve_to_amd_classes(monai_ref):
         "network": {"_target_": "BasicUNet", "spatial_dims": 3, "in_channels": 1, "out_channels": 5},
         "pre": {"_target_": "Spacingd", "keys": ["image"], "pixdim": [1.0, 1.0, 1.0], "mode": "bilinear"},
         "smooth": {"_target_": "GaussianSmoothd", "keys": ["image"], "sigma": 1.0},
+        "dyn": {"_target_": "DynUNet", "spatial_dims": 3, "in_channels": 1, "out_channels": 2, "kernel_size": [3, 3, 3], "strides": [1, 2, 2],
+                "upsample_kernel_size": [2, 2]},
+        "seg": {"_target_": "SegResNet", "spatial_dims": 3, "in_channels": 4, "out_channels": 3},
+        "crop": {"_target_": "CropForegroundd", "keys": ["image"], "source_key": "image"},
+        "norm": {"_target_": "NormalizeIntensityd", "keys": ["image"], "nonzero": True, "channel_wise": True},
     }
     parser = ConfigParser(cfg)
     assert type(parser.get_parsed_content("inferer")).__module__ == "monai.inferers.inferer"
@@ -53,6 +58,9 @@ def test_bundle_targets_resolve_to_amd_classes(monai_ref):
     assert isinstance(parser.get_parsed_content("network"), OurNet)
     assert isinstance(parser.get_parsed_content("pre"), OurSpacingd)
     assert isinstance(parser.get_parsed_content("smooth"), OurSmooth)
+    for key in ("dyn", "seg", "crop", "norm"):
+        assert type(parser.get_parsed_content(key)).__module__.startswith("monai."), key            # rebound in place ...
+        assert sys.modules[type(parser.get_parsed_content(key)).__init__.__module__].__name__.startswith("monai_amd."), key    # ... to the MI355X class
     import monai._C as native
 
     assert native.BoundType.__members__["reflect"] == 2 and hasattr(native, "grid_pull")
@@ -249,3 +257,26 @@ def test_dataset_loader_decollate_invertd_flow(monai_ref, emu):
     assert float((torch.as_tensor(x_our) - torch.as_tensor(x_ref)).abs().max()) < 2e-6
     for a, b in zip(p_our, p_ref):
         assert tuple(a.shape) == tuple(b.shape) == (1, 48, 56, 40) and int((torch.as_tensor(a) != torch.as_tensor(b)).sum()) == 0
+
+
+def test_reference_checkpoints_load_into_amd_dynunet_and_segresnet(monai_ref, emu):
+    """``state_dict``s of the REAL DynUNet (deep supervision, residual blocks: includes the re-registered ``skip_layers.*`` entries) and SegResNet load
+    with ``strict=True``; the loaded nets reproduce the reference's outputs."""
+    import dynunet_cases as dc
+    import segresnet_cases as sc
+    from monai.networks.nets import DynUNet as RefDyn
+    from monai.networks.nets import SegResNet as RefSeg
+
+    from monai_amd.networks.nets import DynUNet, SegResNet
+
+    for ref_cls, our_cls, cases, name, in_kw in ((RefDyn, DynUNet, dc, "res_ds", dict(spatial_dims=3, in_channels=2, out_channels=3)),
+                                                 (RefSeg, SegResNet, sc, "f16", dict(spatial_dims=3))):
+        torch.manual_seed(99)
+        ref = ref_cls(**in_kw, **cases.CFGS[name]["kw"]).eval()
+        torch.manual_seed(1234)                        # different initial weights: everything must come from the checkpoint
+        ours = our_cls(**in_kw, **cases.CFGS[name]["kw"]).eval()
+        missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=True)
+        assert not missing and not unexpected
+        x = cases.inputs(name)
+        with torch.no_grad():
+            assert float((ours(x) - ref(x)).abs().max()) < 1e-4, name
