@@ -825,7 +825,10 @@ int64_t mh_minmax_workspace_floats(int C, int64_t n) {
 int mh_minmax_f32(const float* src, int C, int64_t n, float* workspace, float* table, void* stream) {
     if (!src || !workspace || !table || C < 1 || C > 65535 || n < 1) return fail(MH_ERR_ARG, "minmax: bad argument");
     const int parts = normalize_parts(n);
-    hipLaunchKernelGGL(minmax_partial_kernel, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, (hipStream_t)stream, src, (long long)n, workspace);
+    if (aligned(src, 16) && n % 4 == 0)
+        hipLaunchKernelGGL(minmax_partial_kernel<true>, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, (hipStream_t)stream, src, (long long)n, workspace);
+    else
+        hipLaunchKernelGGL(minmax_partial_kernel<false>, dim3((unsigned)parts, (unsigned)C), dim3(256), 0, (hipStream_t)stream, src, (long long)n, workspace);
     hipLaunchKernelGGL(minmax_final_kernel, dim3((unsigned)C), dim3(64), 0, (hipStream_t)stream, workspace, parts, table);
     return launched("minmax");
 }

@@ -213,27 +213,40 @@ __global__ void __launch_bounds__(256) masked_normalize_kernel(const float* __re
 // image or of each channel, then (x - min) / (max - min) [* (maxv - minv) + minv].  Exact reductions (NaN propagates like torch.min / max),
 // one {min, max} record per workgroup, a one-wave fold per channel that leaves {min, max} in device memory; the apply pass forms
 // max - min in fp32 itself (the reference's rounding) and takes the reference's `min == max` branch (x * minv, or x) per channel.
+template <bool VEC>
 __global__ void __launch_bounds__(256) minmax_partial_kernel(const float* __restrict__ src, long long n, float* __restrict__ partial) {
     const float* p = src + (long long)blockIdx.y * n;
     float mn = INFINITY, mx = -INFINITY;
-    bool nan = false;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const float v = p[i];
-        nan |= v != v;
-        mn = fminf(mn, v); mx = fmaxf(mx, v);
+    int nan = 0;
+    const long long t0 = (long long)blockIdx.x * 256 + threadIdx.x, step = (long long)gridDim.x * 256;
+    if (VEC) {
+        for (long long i = t0; i < n / 4; i += step) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * i);
+            nan |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
+            mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (long long i = t0; i < n; i += step) {
+            const float v = p[i];
+            nan |= v != v;
+            mn = fminf(mn, v); mx = fmaxf(mx, v);
+        }
     }
-    if (nan) { mn = NAN; mx = NAN; }
-    __shared__ float red[2][256];
-    red[0][threadIdx.x] = mn; red[1][threadIdx.x] = mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); nan |= __shfl_xor(nan, o);
+    }
+    __shared__ float red[4][2];
+    __shared__ int red_nan[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[wave][0] = mn; red[wave][1] = mx; red_nan[wave] = nan; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        bool any_nan = false;
-        for (int k = 0; k < 256; ++k) {
-            any_nan |= red[0][k] != red[0][k];
-            mn = fminf(mn, red[0][k]); mx = fmaxf(mx, red[1][k]);
-        }
+        const bool any_nan = (red_nan[0] | red_nan[1] | red_nan[2] | red_nan[3]) != 0;
         float* o = partial + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-        o[0] = any_nan ? NAN : mn; o[1] = any_nan ? NAN : mx;
+        o[0] = any_nan ? NAN : fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+        o[1] = any_nan ? NAN : fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
     }
 }
 __global__ void __launch_bounds__(64) minmax_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ table) {
