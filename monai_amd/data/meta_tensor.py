@@ -11,7 +11,7 @@ from typing import Any
 
 import torch
 
-__all__ = ["MetaTensor", "is_meta", "get_affine"]
+__all__ = ["MetaTensor", "is_meta", "get_affine", "affine_np"]
 
 
 class MetaTensor(torch.Tensor):
@@ -91,3 +91,15 @@ def is_meta(x) -> bool:
 
 def get_affine(x):
     return x.meta.get("affine") if is_meta(x) and "affine" in x.meta else None
+
+
+def affine_np(x, default_rank: int = 3):
+    """the image's affine as a float64 numpy matrix on the host (wherever the MetaTensor's meta keeps it); identity when there is none"""
+    import numpy as np
+
+    a = x.meta.get("affine") if is_meta(x) else None
+    if a is None:
+        return np.eye(default_rank + 1)
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu()
+    return np.asarray(a, dtype=np.float64)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ...data.meta_tensor import is_meta
+from ...data.meta_tensor import affine_np, is_meta
 from ...utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple
 
 __all__ = ["CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop", "is_positive",
@@ -54,7 +54,7 @@ def _wrap_crop_pad(img, out: torch.Tensor, start, cls_name: str, value: float):
         return out
     nsp = out.dim() - 1
     res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
-    aff = np.asarray(img.meta["affine"], dtype=np.float64) if "affine" in img.meta else np.eye(4)
+    aff = affine_np(img)
     shift = np.eye(aff.shape[0])
     r = min(nsp, aff.shape[0] - 1)
     shift[:r, -1] = [int(v) for v in start][:r]
@@ -75,7 +75,7 @@ def _inverse_crop_pad(img, cls_name: str):
     start, orig = rec["extra_info"]["box_start"], tuple(int(v) for v in rec["orig_size"])
     out = _run_crop_pad(img.as_tensor(), [-s for s in start], orig, 0.0)
     res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
-    aff = np.asarray(img.meta["affine"], dtype=np.float64)
+    aff = affine_np(img)
     shift = np.eye(aff.shape[0])
     r = min(len(orig), aff.shape[0] - 1)
     shift[:r, -1] = [-s for s in start][:r]

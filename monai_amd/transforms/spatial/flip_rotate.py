@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ...data.meta_tensor import is_meta
+from ...data.meta_tensor import affine_np, is_meta
 from ...utils.misc import ensure_tuple
 
 __all__ = ["Flip", "Flipd", "FlipD", "FlipDict", "Rotate90", "Rotate90d", "Rotate90D", "Rotate90Dict"]
@@ -35,7 +35,7 @@ def _flip_permute(img, perm, flips, record):
     if not is_meta(img):
         return out
     res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))
-    aff = np.asarray(img.meta["affine"], dtype=np.float64) if "affine" in img.meta else np.eye(4)
+    aff = affine_np(img)
     r = aff.shape[0] - 1
     xform = np.zeros((r + 1, r + 1))
     xform[-1, -1] = 1.0
