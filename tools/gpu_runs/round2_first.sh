@@ -1,7 +1,7 @@
 # First GPU call of the next round: everything that was added after round 1's GPU budget was spent.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_runs/round2_first.sh'
 mkdir -p gpurun_out
-python -m pytest tests/test_widen_gpu.py -q -m gpu 2>&1 | tail -15 > gpurun_out/widen_gpu_tests.txt
+python -m pytest tests -q -m gpu 2>&1 | tail -25 > gpurun_out/widen_gpu_tests.txt      # the whole GPU suite; tests/test_widen_gpu.py (never run on hardware in round 1) sorts last
 python tools/preproc_bench.py > gpurun_out/preproc_bench.json 2> gpurun_out/preproc_bench.err
 python bench.py --net dynunet --steps 2 --warmup 1 --cpu-windows 0 > gpurun_out/bench_dynunet.json 2> gpurun_out/bench_dynunet.err
 python bench.py --net segresnet --steps 2 --warmup 1 --cpu-windows 0 > gpurun_out/bench_segresnet.json 2> gpurun_out/bench_segresnet.err
