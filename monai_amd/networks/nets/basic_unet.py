@@ -116,8 +116,8 @@ class BasicUNet(nn.Module):
             raise NotImplementedError("monai_amd.BasicUNet: only spatial_dims=3 is on the HIP path")
         if upsample != "deconv":
             raise NotImplementedError("monai_amd.BasicUNet: only upsample='deconv' is on the HIP path")
-        if isinstance(dropout, (tuple, list)) or float(dropout) != 0.0:
-            raise NotImplementedError("monai_amd.BasicUNet: dropout must be 0 (inference path)")
+        # dropout: accepted and inert -- this is an inference engine (forward refuses training mode) and Dropout holds no parameters, so
+        # checkpoints of nets trained with dropout load unchanged
         fea = tuple(features)
         if len(fea) != 6:
             raise ValueError(f"Sequence must have length 6, got length {len(fea)}.")  # ensure_tuple_rep

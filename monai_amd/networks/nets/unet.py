@@ -105,8 +105,8 @@ class UNet(nn.Module):
         act_name = (act if isinstance(act, str) else act[0]).upper()
         norm_name, norm_args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
         if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or act_name != "PRELU"
-                or str(norm_name).upper() not in ("INSTANCE", "BATCH") or dropout != 0.0 or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
-            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance / batch norm, no dropout, strides 1/2, 'NDA'")
+                or str(norm_name).upper() not in ("INSTANCE", "BATCH") or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
+            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance / batch norm, strides 1/2, 'NDA' (dropout is inference-inert)")
         self.dimensions, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
         self.channels, self.strides, self.num_res_units, self.bias = tuple(channels), tuple(int(s) for s in strides), num_res_units, bias
         self.kernel_size, self.up_kernel_size, self.act, self.norm, self.dropout, self.adn_ordering = kernel_size, up_kernel_size, act, norm, dropout, adn_ordering

@@ -108,3 +108,21 @@ def test_unetr_under_autocast_stays_fp32(emu):
     with torch.autocast(device_type="cpu", dtype=torch.bfloat16):
         ya = net(x)
     assert ya.dtype == torch.float32 and torch.equal(y, ya)
+
+
+def test_dropout_arguments_are_inference_inert(emu):
+    """bundles configure nets with dropout; Dropout holds no parameters and the engines only run in eval mode: same weights, same logits"""
+    import torch
+
+    from monai_amd.networks.nets import BasicUNet, DynUNet, UNet
+
+    x = torch.rand(1, 1, 16, 16, 16)
+    for make, none in ((lambda d: UNet(3, 1, 2, (8, 16), (2,), num_res_units=1, dropout=d), 0.0),
+                       (lambda d: BasicUNet(3, 1, 2, features=(8, 8, 16, 16, 16, 8), dropout=d), 0.0),
+                       (lambda d: DynUNet(3, 1, 2, [3, 3, 3], [1, 2, 2], [2, 2], filters=[8, 8, 8], dropout=d), None)):
+        torch.manual_seed(8)
+        a = make(none).eval()
+        torch.manual_seed(8)
+        b = make(0.3).eval()
+        assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+        assert torch.equal(a(x), b(x))
