@@ -159,8 +159,8 @@ class UNETR(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden_size should be divisible by num_heads.")
-        if spatial_dims != 3 or proj_type != "conv" or not conv_block or not res_block or dropout_rate != 0.0 or save_attn:
-            raise NotImplementedError("monai_amd.UNETR: only the default 3-D / conv-projection / res-block / no-dropout configuration is on the HIP path")
+        if spatial_dims != 3 or proj_type != "conv" or not conv_block or not res_block or save_attn:       # dropout_rate: inference-inert
+            raise NotImplementedError("monai_amd.UNETR: only the default 3-D / conv-projection / res-block configuration is on the HIP path")
         norm = norm_name if isinstance(norm_name, str) else norm_name[0]
         if str(norm).lower() != "instance":
             raise NotImplementedError("monai_amd.UNETR: only norm_name='instance' is on the HIP path")
