@@ -14,6 +14,7 @@ from __future__ import annotations
 import ctypes
 import os
 import platform
+import signal
 import subprocess
 import sys
 from glob import glob
@@ -72,14 +73,21 @@ def load_module(module_name: str, defines: dict | None = None, verbose_build: bo
         cmd = [hipcc()] + ["-x", "hip"] + FLAGS + define_args + sources + ["-o", tmp]
         if verbose_build:
             print(" ".join(cmd), file=sys.stderr)
+        pipe = None if verbose_build else subprocess.PIPE
+        proc = subprocess.Popen(cmd, stdout=pipe, stderr=pipe, text=True, start_new_session=True)     # own process group: hipcc forks clang / lld
         try:
-            proc = subprocess.run(cmd, timeout=build_timeout, capture_output=not verbose_build, text=True)
+            _, err = proc.communicate(timeout=build_timeout)
         except subprocess.TimeoutExpired as e:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)       # exactly the group started above, compiler children included
+            except ProcessLookupError:
+                pass
+            proc.wait()
             _rm(tmp)
             raise TimeoutError("Build appears to be blocked. Is there a stopped process building the same extension?") from e
         if proc.returncode != 0:
             _rm(tmp)
-            raise RuntimeError(f"Error building extension '{name}'" + ("" if verbose_build else f":\n{proc.stderr}"))
+            raise RuntimeError(f"Error building extension '{name}'" + ("" if verbose_build else f":\n{err}"))
         os.replace(tmp, out)        # atomic: a concurrent builder of the same configuration never sees a partial file
 
     cdll = ctypes.CDLL(out)
