@@ -45,8 +45,11 @@ const char* mh_last_error(void);
 /* ---- sliding-window inferer (monai/inferers/utils.py:42-321) -------------------------------------- */
 
 /* The dense window grid of dense_patch_slices (monai/data/utils.py:166-206) is described by its per-axis
- * start lists sz/sy/sx (ascending; HOST int32 arrays, copied into the kernel arguments -- at most 160
- * windows per axis); window w = (iz*ny + iy)*nx + ix, i.e. row-major with the last axis fastest. */
+ * start lists sz/sy/sx (ascending HOST int32 arrays); window w = (iz*ny + iy)*nx + ix, i.e. row-major with
+ * the last axis fastest.  Lists of dense_patch_slices' own form -- i*interval, the last one clipped to
+ * image - roi -- are recognised and evaluated in closed form inside the kernels (any number of windows per
+ * axis, e.g. SliceInferer's one window per slice); any other ascending list is copied into the kernel
+ * arguments (at most 160 windows per axis). */
 
 /* Window gather, utils.py:217-224 (`torch.cat([inputs[win_slice] ...])`).  vol is one image [C,D,H,W];
  * windows w0 .. w0+nwin-1 of the grid are written to out [nwin, C, rd, rh, rw] (dense). */
@@ -67,6 +70,16 @@ int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const in
 int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd,
                     int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
                     int nx, int premultiplied, void* stream);
+
+/* The same blend with the post-processing step that follows it in segmentation bundles fused into its epilogue:
+ * AsDiscrete(argmax=True) (monai/transforms/post/array.py:132-237, `torch.argmax(img, dim=0, keepdim=True)`).  Every voxel's K
+ * blended values are formed in registers exactly as mh_sw_blend_f32 forms them and only the label -- index of the first maximal
+ * value, NaN counts as maximal -- is written: labels [D][H][W] as float32 (labels_u8 = 0, AsDiscrete's default output dtype) or
+ * uint8 (labels_u8 = 1, K <= 256).  Output traffic K*4 B per voxel -> 4 B or 1 B.  Regular (dense_patch_slices) grids only;
+ * MH_ERR_UNSUPPORTED otherwise (blend, then mh_channel_reduce_f32). */
+int mh_sw_blend_argmax_f32(const float* logits, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd,
+                           int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
+                           int premultiplied, void* stream);
 
 /* AvgMerger of the PatchInferer family (monai/inferers/merger.py:103-205): one patch, `values[slice] += patch; counts[slice] += 1`
  * (values / patch [NC][...] fp32 dense, counts uint8 like the reference's default count_dtype; the patch must lie inside the

@@ -24,6 +24,9 @@
 
 using namespace mh;
 
+#define MH_BLEND_G 2       /* windows requested per batch by the regular-grid blend (measured: profiles/r02_blend_variants_v1.json) */
+#define MH_BLEND_NT 0      /* non-temporal logit loads / output stores: slower here (half-rows of a cache line are shared by two requests) */
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char* fmt, ...) {
@@ -67,18 +70,49 @@ static bool all_mult4(const int32_t* s, int n) {
     for (int i = 0; i < n; ++i) if (s[i] % 4) return false;
     return true;
 }
+// dense_patch_slices' form: start(i) = i * step (i < n - 1), start(n - 1) = last <= (n - 1) * step; `extent` bounds the coordinates
+static bool regular_axis(const int32_t* s, int n, int extent, AxisWin& a) {
+    if (n < 1 || s[0] != 0) return false;
+    a.n = n; a.step = n > 1 ? s[1] : 1; a.last = s[n - 1]; a.magic = 0;
+    if (n == 1) { a.step = 1; a.last = 0; return true; }
+    if (n == 2) { a.step = s[1] > 0 ? s[1] : 1; a.last = s[1]; }
+    if (a.step < 1) return false;
+    for (int i = 1; i < n - 1; ++i) if (s[i] != i * a.step) return false;
+    if (a.last > (n - 1) * a.step || (n > 2 && a.last <= (n - 2) * a.step)) return false;
+    if (a.step > 1 && (long long)extent * a.step < (1LL << 32)) a.magic = (unsigned)((1ULL << 32) / (unsigned)a.step) + 1u;
+    return true;
+}
+static bool regular_grid(RegGrid& g, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int D, int H, int W) {
+    return sz && sy && sx && regular_axis(sz, nz, D, g.z) && regular_axis(sy, ny, H, g.y) && regular_axis(sx, nx, W, g.x);
+}
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
 
 int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const int32_t* sz, int nz, const int32_t* sy,
                           int ny, const int32_t* sx, int nx, int w0, int nwin, int rd, int rh, int rw, float* out,
                           void* stream) {
     if (!vol || !out || C < 1 || nwin < 1 || w0 < 0) return fail(MH_ERR_ARG, "window_extract: bad argument");
-    WindowGrid g;
-    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
+    if (!sz || !sy || !sx || nz < 1 || ny < 1 || nx < 1) return fail(MH_ERR_ARG, "window grid: null/empty start list");
     if ((long long)w0 + nwin > (long long)nz * ny * nx) return fail(MH_ERR_ARG, "window_extract: window range out of grid");
     if (sz[nz - 1] + rd > D || sy[ny - 1] + rh > H || sx[nx - 1] + rw > W || sz[0] < 0 || sy[0] < 0 || sx[0] < 0)
         return fail(MH_ERR_ARG, "window_extract: window leaves the volume");
     const bool v4 = rw % 4 == 0 && W % 4 == 0 && all_mult4(sx, nx) && aligned(vol, 16) && aligned(out, 16);
     const long long total = (long long)nwin * C * rd * rh * (v4 ? rw / 4 : rw);
+    if (total > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "window_extract: problem too large for one launch");
+    RegGrid rg;
+    if (regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W)) {      // dense_patch_slices: closed-form starts, any number of windows per axis
+        if (v4)
+            hipLaunchKernelGGL((window_extract_reg_kernel<4>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D, H, W, rg,
+                               w0, nwin, rd, rh, rw, out);
+        else
+            hipLaunchKernelGGL((window_extract_reg_kernel<1>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D, H, W, rg,
+                               w0, nwin, rd, rh, rw, out);
+        return launched("window_extract");
+    }
+    WindowGrid g;
+    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
     if (v4)
         hipLaunchKernelGGL((window_extract_kernel<4>), dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, vol, C, D,
                            H, W, g, w0, nwin, rd, rh, rw, out);
@@ -122,27 +156,98 @@ int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* s
     return launched("avg_finalize");
 }
 
-int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
-                    const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
-    if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "sw_blend: bad argument");
-    WindowGrid g;
-    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
+// Blend on a regular grid: KT channels per launch (or all K inside the thread for the argmax epilogue), G windows requested
+// per batch.  MONAI_AMD_BLEND_G / MONAI_AMD_BLEND_NT are development knobs (profiles/r02_blend_variants.txt).
+template <bool ARGMAX>
+static int launch_blend_reg(int kt, bool v4, int G, bool nt, unsigned nb, hipStream_t s, const float* logits, const float* imp, void* out,
+                            int K, int k0, int D, int H, int W, int rd, int rh, int rw, const RegGrid& g, int premul, int out_u8) {
+#define MH_BR(KT, VEC, GG, NTT)                                                                                              \
+    hipLaunchKernelGGL((sw_blend_reg_kernel<KT, VEC, GG, NTT, ARGMAX>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, k0, D, H, \
+                       W, rd, rh, rw, g, premul, out_u8)
+#define MH_BR_CASE(KT)                                                                      \
+    case KT:                                                                                \
+        if (!v4) MH_BR(KT, 1, 1, false);                                                    \
+        else if (nt) MH_BR(KT, 4, MH_BLEND_G, true);                                        \
+        else MH_BR(KT, 4, MH_BLEND_G, false);                                               \
+        break;
+    if (v4 && kt == 5 && !ARGMAX && G != MH_BLEND_G) {       // the benchmark shape carries every batch size
+        switch (G) {
+            case 1: if (nt) MH_BR(5, 4, 1, true); else MH_BR(5, 4, 1, false); return MH_OK;
+            case 2: if (nt) MH_BR(5, 4, 2, true); else MH_BR(5, 4, 2, false); return MH_OK;
+            case 4: if (nt) MH_BR(5, 4, 4, true); else MH_BR(5, 4, 4, false); return MH_OK;
+            case 8: if (nt) MH_BR(5, 4, 8, true); else MH_BR(5, 4, 8, false); return MH_OK;
+            default: break;
+        }
+    }
+    switch (kt) {
+        MH_BR_CASE(1) MH_BR_CASE(2) MH_BR_CASE(3) MH_BR_CASE(4)
+        MH_BR_CASE(5) MH_BR_CASE(6) MH_BR_CASE(7) MH_BR_CASE(8)
+        default: return fail(MH_ERR_ARG, "sw_blend: bad channel chunk %d", kt);
+    }
+#undef MH_BR_CASE
+#undef MH_BR
+    return MH_OK;
+}
+
+static int blend_checks(const char* what, const float* logits, const float* imp, const void* out, int K, int D, int H, int W, int rd, int rh, int rw,
+                        const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx) {
+    if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "%s: bad argument", what);
+    if (!sz || !sy || !sx || nz < 1 || ny < 1 || nx < 1) return fail(MH_ERR_ARG, "window grid: null/empty start list");
     // full coverage: first window at 0, last ends at the image end, no gaps
     const int32_t* ss[3] = {sz, sy, sx};
     const int nn[3] = {nz, ny, nx}, rr[3] = {rd, rh, rw}, dd[3] = {D, H, W};
     for (int a = 0; a < 3; ++a) {
-        if (ss[a][0] != 0 || ss[a][nn[a] - 1] + rr[a] != dd[a]) return fail(MH_ERR_ARG, "sw_blend: windows do not span axis %d", a);
-        for (int i = 1; i < nn[a]; ++i)
-            if (ss[a][i] > ss[a][i - 1] + rr[a]) return fail(MH_ERR_ARG, "sw_blend: uncovered gap on axis %d", a);
+        if (ss[a][0] != 0 || ss[a][nn[a] - 1] + rr[a] != dd[a]) return fail(MH_ERR_ARG, "%s: windows do not span axis %d", what, a);
+        for (int i = 1; i < nn[a]; ++i) {
+            if (ss[a][i] < ss[a][i - 1]) return fail(MH_ERR_ARG, "window starts must ascend (axis %d)", a);
+            if (ss[a][i] > ss[a][i - 1] + rr[a]) return fail(MH_ERR_ARG, "%s: uncovered gap on axis %d", what, a);
+        }
     }
+    if ((long long)D * H * W > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "%s: problem too large for one launch", what);
+    return MH_OK;
+}
+
+int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
+                    const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
+    if (int e = blend_checks("sw_blend", logits, imp, out, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx)) return e;
     const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16);
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
+    RegGrid rg;
+    if (regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W) && env_int("MONAI_AMD_BLEND_LEGACY", 0) == 0) {
+        const int G = env_int("MONAI_AMD_BLEND_G", MH_BLEND_G);
+        const bool nt = env_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            const int kt = K - k0 < 8 ? K - k0 : 8;
+            if (int e = launch_blend_reg<false>(kt, v4, G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, rg,
+                                                premultiplied ? 1 : 0, 0))
+                return e;
+        }
+        return launched("sw_blend");
+    }
+    WindowGrid g;      // irregular start lists (e.g. a multi-resolution output whose scaled starts round unevenly): tables by value
+    if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
     for (int k0 = 0; k0 < K; k0 += 8) {
         const int kt = K - k0 < 8 ? K - k0 : 8;
         if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
         else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
     }
     return launched("sw_blend");
+}
+
+int mh_sw_blend_argmax_f32(const float* logits, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd, int rh, int rw,
+                           const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
+    if (int e = blend_checks("sw_blend_argmax", logits, imp, labels, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx)) return e;
+    if (labels_u8 && K > 256) return fail(MH_ERR_UNSUPPORTED, "sw_blend_argmax: %d classes do not fit a uint8 label", K);
+    RegGrid rg;
+    if (!regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W))
+        return fail(MH_ERR_UNSUPPORTED, "sw_blend_argmax: irregular window starts (blend, then argmax)");
+    const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(labels, labels_u8 ? 4 : 16);
+    const long long total = (long long)D * H * (v4 ? W / 4 : W);
+    const bool nt = env_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
+    if (int e = launch_blend_reg<true>(K < 8 ? K : 8, v4, MH_BLEND_G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, labels, K, 0, D, H, W, rd, rh,
+                                       rw, rg, premultiplied ? 1 : 0, labels_u8 ? 1 : 0))
+        return e;
+    return launched("sw_blend_argmax");
 }
 
 // ------------------------------------------------------------------------------------------ conv 3x3x3

@@ -136,6 +136,190 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Regular window grids.  dense_patch_slices (monai/data/utils.py:166-206) only ever produces starts of the form
+//   start(i) = i * step  for i < n - 1,   start(n - 1) = last <= (n - 1) * step      (the clip to image - roi)
+// so the covering range of a coordinate has a closed form: no start tables in the kernel arguments, no per-thread table
+// walk (a chain of dependent loads in front of the first logit load), and no limit on the number of windows per axis
+// (SliceInferer: one window per slice).  `magic` = floor(2^32 / step) + 1 gives floor(p / step) = umulhi(p, magic) for
+// p * step < 2^32 (the launcher checks it; 0 = use a real division, e.g. step 1).
+struct AxisWin {
+    int n, step, last;
+    unsigned magic;
+};
+struct RegGrid {
+    AxisWin z, y, x;
+};
+
+__device__ __forceinline__ int axis_start(const AxisWin& a, int i) { return i == a.n - 1 ? a.last : i * a.step; }
+__device__ __forceinline__ int axis_div(const AxisWin& a, int p) { return a.magic ? (int)__umulhi((unsigned)p, a.magic) : p / a.step; }
+// windows i with start(i) <= p < start(i) + r: a contiguous range [lo, hi] (every p is covered by at least one window)
+__device__ __forceinline__ void axis_cover(const AxisWin& a, int r, int p, int& lo, int& hi) {
+    lo = p >= r ? axis_div(a, p - r) + 1 : 0;
+    if (lo > a.n - 1) lo = a.n - 1;
+    hi = axis_div(a, p);
+    if (hi > a.n - 2) hi = a.n - 2;
+    if (p >= a.last) hi = a.n - 1;
+    if (hi < lo) hi = lo;
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(256)
+window_extract_reg_kernel(const float* __restrict__ vol, int C, int D, int H, int W, RegGrid g, int w0, int nwin, int rd, int rh,
+                          int rw, float* __restrict__ out) {
+    const int rwv = rw / VEC;
+    const long long total = (long long)nwin * C * rd * rh * rwv;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int xv = (int)(idx % rwv);
+    long long t = idx / rwv;
+    const int ly = (int)(t % rh); t /= rh;
+    const int lz = (int)(t % rd); t /= rd;
+    const int c = (int)(t % C);
+    const int w = w0 + (int)(t / C);
+    const int ix = w % g.x.n, iy = (w / g.x.n) % g.y.n, iz = w / (g.x.n * g.y.n);
+    const int z = axis_start(g.z, iz) + lz, y = axis_start(g.y, iy) + ly, x = axis_start(g.x, ix) + xv * VEC;
+    const float* src = vol + (((long long)c * D + z) * H + y) * W + x;
+    float* dst = out + idx * VEC;
+    if (VEC == 4) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+    else dst[0] = src[0];
+}
+
+// The blend on a regular grid.  Same arithmetic, in the same order, as sw_blend_kernel (acc = acc + fp32(logit * w),
+// cnt = cnt + w, out = acc / cnt, windows in ascending index), organised for the memory system: the covering box is walked
+// G windows at a time -- the G x KT logit vectors and G weight vectors of a batch are all requested before the first add
+// (the adds keep the window order) -- and the read-once logits / write-once output can bypass the caches (NT).
+// ARGMAX = false writes channels [k0, k0 + KT); ARGMAX = true walks ALL K channels in chunks of KT inside the thread
+// and writes only the label -- index of the first maximal blended value, NaN maximal, i.e. torch.argmax of the blended
+// logits (AsDiscrete(argmax=True), monai/transforms/post/array.py:132-237) -- as float or uint8: K x 4 B per voxel of output
+// traffic become 4 B or 1 B.
+template <int KT, int VEC, int G, bool NT, bool ARGMAX>
+__global__ void __launch_bounds__(256)
+sw_blend_reg_kernel(const float* __restrict__ logits, const float* __restrict__ imp, void* __restrict__ out_, int K, int k0_, int D,
+                    int H, int W, int rd, int rh, int rw, RegGrid g, int premul, int out_u8) {
+    const int wv = W / VEC;
+    const long long total = (long long)D * H * wv;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % wv) * VEC;
+    const long long t = idx / wv;
+    const int y = (int)(t % H), z = (int)(t / H);
+
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    axis_cover(g.z, rd, z, zlo, zhi);
+    axis_cover(g.y, rh, y, ylo, yhi);
+    axis_cover(g.x, rw, x, xlo, xhi);     // VEC == 4: starts and rw are multiples of 4, x .. x+3 share the covering set
+    const int nw = (zhi - zlo + 1) * (yhi - ylo + 1) * (xhi - xlo + 1);
+    const long long plane = (long long)rh * rw, roi = plane * rd;
+    const long long vox = (long long)D * H * W;
+    const long long opos = ((long long)z * H + y) * W + x;
+
+    float best[VEC];
+    int besti[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { best[v] = 0.0f; besti[v] = 0; }
+
+    const int kbeg = ARGMAX ? 0 : k0_, kend = ARGMAX ? K : k0_ + KT;
+    for (int k0 = kbeg; k0 < kend; k0 += KT) {
+        float acc[KT][VEC];
+        float cnt[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            cnt[v] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k][v] = 0.0f;
+        }
+        int iz = zlo, iy = ylo, ix = xlo;
+        for (int done = 0; done < nw; done += G) {
+            float wt[G][VEC];
+            float lv[G][KT][VEC];
+            long long off0 = 0, base0 = 0;
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const bool ok = done + b < nw;
+                const int lz = z - axis_start(g.z, iz), ly = y - axis_start(g.y, iy), lx = x - axis_start(g.x, ix);
+                const long long w = ((long long)iz * g.y.n + iy) * g.x.n + ix;
+                long long off = (long long)lz * plane + (long long)ly * rw + lx;
+                long long base = w * K * roi + off;
+                if (b == 0) { off0 = off; base0 = base; }
+                if (!ok) { off = off0; base = base0; }        // past the end of the box: re-request the batch's first window (values unused)
+                if (ok) {                                     // next window of the box, last axis fastest = ascending window index
+                    if (++ix > xhi) { ix = xlo; if (++iy > yhi) { iy = ylo; ++iz; } }
+                }
+                if (VEC == 4) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(imp + off);
+                    wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
+                } else {
+                    wt[b][0] = imp[off];
+                }
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    int kc = k0 + k;
+                    if (ARGMAX && kc > K - 1) kc = K - 1;       // tail chunk of the argmax walk: clamped, ignored below
+                    const float* lp = logits + base + (long long)kc * roi;
+                    if (VEC == 4) {
+                        const f32x4 a = NT ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lp)) : *reinterpret_cast<const f32x4*>(lp);
+                        lv[b][k][0] = a[0]; lv[b][k][1] = a[1]; lv[b][k][2] = a[2]; lv[b][k][3] = a[3];
+                    } else {
+                        lv[b][k][0] = NT ? __builtin_nontemporal_load(lp) : *lp;
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const bool ok = done + b < nw;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) {
+                        const float s = __fadd_rn(acc[k][v], __fmul_rn(lv[b][k][v], premul ? 1.0f : wt[b][v]));
+                        acc[k][v] = ok ? s : acc[k][v];
+                    }
+                    const float c = __fadd_rn(cnt[v], wt[b][v]);
+                    cnt[v] = ok ? c : cnt[v];
+                }
+            }
+        }
+        if (!ARGMAX) {
+            float* op = reinterpret_cast<float*>(out_) + (long long)k0 * vox + opos;
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                if (VEC == 4) {
+                    const f32x4 r = {__fdiv_rn(acc[k][0], cnt[0]), __fdiv_rn(acc[k][1], cnt[1]), __fdiv_rn(acc[k][2], cnt[2]), __fdiv_rn(acc[k][3], cnt[3])};
+                    if (NT) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op + k * vox));
+                    else *reinterpret_cast<f32x4*>(op + k * vox) = r;
+                } else {
+                    op[k * vox] = __fdiv_rn(acc[k][0], cnt[0]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                if (k0 + k < K) {
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float r = __fdiv_rn(acc[k][v], cnt[v]);
+                        const bool take = (k0 + k == 0) || r > best[v] || (r != r && best[v] == best[v]);
+                        best[v] = take ? r : best[v];
+                        besti[v] = take ? k0 + k : besti[v];
+                    }
+                }
+            }
+        }
+    }
+    if (ARGMAX) {
+        if (out_u8) {
+            unsigned char* op = reinterpret_cast<unsigned char*>(out_) + opos;
+            if (VEC == 4) *reinterpret_cast<unsigned*>(op) = (unsigned)besti[0] | ((unsigned)besti[1] << 8) | ((unsigned)besti[2] << 16) | ((unsigned)besti[3] << 24);
+            else op[0] = (unsigned char)besti[0];
+        } else {
+            float* op = reinterpret_cast<float*>(out_) + opos;
+            if (VEC == 4) *reinterpret_cast<f32x4*>(op) = f32x4{(float)besti[0], (float)besti[1], (float)besti[2], (float)besti[3]};
+            else op[0] = (float)besti[0];
+        }
+    }
+}
+
 // AvgMerger (monai/inferers/merger.py:103-205): `values[slice] += patch; counts[slice] += 1` for one patch -- the patches
 // of a PatchInferer arrive one by one through a user-visible Merger object, so the accumulation order (= patch order) is
 // the reference's -- and the final `values /= counts`.  One thread per patch element, lanes along x; HBM-bound read-modify-

@@ -53,6 +53,27 @@ def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: G
     return out
 
 
+def sw_blend_argmax(logits: torch.Tensor, imp: torch.Tensor, labels: torch.Tensor, grid: Grid, roi: Sequence[int], num_classes: int,
+                    premultiplied: bool = False) -> torch.Tensor:
+    """The blend of ``sw_blend`` with ``torch.argmax(out, dim=0)`` fused into its epilogue: labels [D,H,W] (float32 or uint8) =
+    index of the first maximal blended value per voxel (AsDiscrete(argmax=True), monai/transforms/post/array.py:132-237)."""
+    _lib.require_device(logits, imp)
+    _lib.require_device(labels, dtypes=(torch.float32, torch.uint8))
+    if not (logits.is_contiguous() and imp.is_contiguous() and labels.is_contiguous()):
+        raise RuntimeError("monai_amd.sw_blend_argmax: contiguous tensors required")
+    d, h, w = labels.shape
+    k = int(num_classes)
+    sz, sy, sx = grid
+    if logits.shape[0] != len(sz) * len(sy) * len(sx) or logits.shape[1] != k or tuple(logits.shape[2:]) != tuple(roi):
+        raise RuntimeError(f"monai_amd.sw_blend_argmax: logits shape {tuple(logits.shape)} does not match the window grid")
+    _lib.lib().call(
+        "mh_sw_blend_argmax_f32", _lib.ptr(logits), _lib.ptr(imp), _lib.ptr(labels), int(labels.dtype == torch.uint8), k, d, h, w,
+        int(roi[0]), int(roi[1]), int(roi[2]), _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx),
+        int(bool(premultiplied)), _s(labels),
+    )
+    return labels
+
+
 def pointwise(op: str, src: torch.Tensor, param: float = 0.0) -> torch.Tensor:
     """sigmoid | threshold (x >= param -> 0/1) | round (half to even) on a contiguous fp32 tensor."""
     _lib.require_device(src)

@@ -79,6 +79,65 @@ def case_sw_blend(device, img=(24, 20, 32), roi=(16, 12, 16), overlap=0.5, k=5, 
     ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
     exp = reference_blend(logits, imp, img, roi, starts)
     assert torch.equal(out.cpu(), exp), f"blend not bit-exact: max diff {(out.cpu() - exp).abs().max().item()}"
+    # the argmax epilogue (AsDiscrete(argmax=True) fused into the blend): labels == torch.argmax of the blended logits, both dtypes
+    for dt in (torch.float32, torch.uint8):
+        lab = torch.full(tuple(img), 77, dtype=dt, device=device)
+        ops.sw_blend_argmax(logits.to(device), imp.to(device), lab, starts, roi, k)
+        assert torch.equal(lab.cpu().long(), exp.argmax(0)), f"fused argmax ({dt}) differs from argmax(blend)"
+
+
+def case_sw_blend_special_values(device):
+    """ties, NaN and infinities through the fused argmax: torch.argmax's rule (first maximal value, NaN maximal)"""
+    img, roi, k = (8, 8, 16), (8, 8, 8), 6
+    starts = [[0], [0], [0, 4, 8]]
+    gen = torch.Generator().manual_seed(5)
+    logits = torch.randint(-2, 3, (3, k) + roi, generator=gen).float()      # many exact ties
+    logits[0, 2, 1, :, :4] = float("nan")
+    logits[1, 4, 2, :, 4:] = float("inf")
+    logits[2, 1, 3] = float("-inf")
+    imp = torch.ones(roi)
+    out = torch.empty((k,) + img, device=device)
+    ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
+    exp = reference_blend(logits, imp, img, roi, starts)
+    assert torch.equal(torch.nan_to_num(out.cpu(), nan=123.0), torch.nan_to_num(exp, nan=123.0))
+    lab = torch.empty(img, dtype=torch.uint8, device=device)
+    ops.sw_blend_argmax(logits.to(device), imp.to(device), lab, starts, roi, k)
+    assert torch.equal(lab.cpu().long(), exp.argmax(0))
+
+
+def case_sw_blend_irregular(device):
+    """start lists that are not of dense_patch_slices' form take the table kernels (multi-resolution outputs whose scaled
+    starts round unevenly): same bit-exact blend"""
+    img, roi, k = (9, 12, 20), (4, 6, 8), 3
+    starts = [[0, 1, 3, 5], [0, 6], [0, 4, 12]]
+    gen = torch.Generator().manual_seed(7)
+    nwin = 4 * 2 * 3
+    logits = torch.randn((nwin, k) + roi, generator=gen)
+    imp = osw.compute_importance_map(roi, mode="gaussian", sigma_scale=0.125)
+    out = torch.empty((k,) + img, device=device)
+    ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
+    assert torch.equal(out.cpu(), reference_blend(logits, imp, img, roi, starts))
+    vol = torch.rand((2,) + img, generator=gen)
+    got = torch.empty((nwin, 2) + roi, device=device)
+    ops.window_extract(vol.to(device), starts, 0, nwin, roi, got)
+    exp = torch.stack([vol[:, z:z + roi[0], y:y + roi[1], x:x + roi[2]] for (z, y, x) in itertools.product(*starts)])
+    assert torch.equal(got.cpu(), exp)
+
+
+def case_sw_blend_many_windows(device, slices=170):
+    """more than 160 windows on one axis (SliceInferer: roi 1 along the slice axis, one window per slice)"""
+    img, roi, k = (slices, 8, 8), (1, 8, 8), 2
+    starts = [list(range(slices)), [0], [0]]
+    gen = torch.Generator().manual_seed(9)
+    logits = torch.randn((slices, k) + roi, generator=gen)
+    imp = torch.ones(roi)
+    out = torch.empty((k,) + img, device=device)
+    ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
+    assert torch.equal(out.cpu(), reference_blend(logits, imp, img, roi, starts))
+    vol = torch.rand((1,) + img, generator=gen)
+    got = torch.empty((slices, 1) + roi, device=device)
+    ops.window_extract(vol.to(device), starts, 0, slices, roi, got)
+    assert torch.equal(got.cpu()[:, 0, 0], vol[0])
 
 
 # ------------------------------------------------------------------------------------------ network blocks

@@ -19,6 +19,23 @@ def test_sw_blend_bitwise(emu, mode):
     kc.case_sw_blend("cpu", img=(1, 20, 24), roi=(1, 8, 8), overlap=0.75, k=11, mode=mode)   # 2-D, K > 8, 4x overlap
 
 
+@pytest.mark.parametrize("g", ["1", "2", "8"])
+def test_sw_blend_batch_sizes(emu, g, monkeypatch):
+    """every window-batch size of the regular-grid blend gives the same bits (K = 5 carries all of them)"""
+    monkeypatch.setenv("MONAI_AMD_BLEND_G", g)
+    monkeypatch.setenv("MONAI_AMD_BLEND_NT", "0" if g == "2" else "1")
+    kc.case_sw_blend("cpu")
+    kc.case_sw_blend("cpu", img=(20, 40, 52), roi=(8, 16, 16), overlap=0.5)       # clipped last window: 3 covering windows per axis
+
+
+def test_sw_blend_special_cases(emu, monkeypatch):
+    kc.case_sw_blend_special_values("cpu")
+    kc.case_sw_blend_irregular("cpu")
+    kc.case_sw_blend_many_windows("cpu")
+    monkeypatch.setenv("MONAI_AMD_BLEND_LEGACY", "1")      # the table kernels on a regular grid: same bits
+    kc.case_sw_blend("cpu")
+
+
 def test_conv_direct(emu):
     assert kc.case_conv3d("cpu", 0, 2, 1, 32, (6, 7, 9), with_nrm=False, fused_stats=False) == 0
     kc.case_conv3d("cpu", 0, 1, 5, 7, (4, 5, 6), fused_stats=False)

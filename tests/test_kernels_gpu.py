@@ -32,6 +32,24 @@ def test_sw_blend_bitwise(mode):
     kc.case_sw_blend(DEV, img=(144, 112, 160), roi=(96, 96, 96), overlap=0.5, k=5, mode=mode)  # bench-shaped windows
 
 
+@pytest.mark.parametrize("g", ["1", "2", "4", "8"])
+def test_sw_blend_batch_sizes(g, monkeypatch):
+    monkeypatch.setenv("MONAI_AMD_BLEND_G", g)
+    monkeypatch.setenv("MONAI_AMD_BLEND_NT", "0" if g == "2" else "1")
+    kc.case_sw_blend(DEV)
+    kc.case_sw_blend(DEV, img=(20, 40, 52), roi=(8, 16, 16), overlap=0.5)
+    kc.case_sw_blend(DEV, img=(144, 112, 160), roi=(96, 96, 96), overlap=0.5, k=5)
+
+
+def test_sw_blend_special_cases(monkeypatch):
+    kc.case_sw_blend_special_values(DEV)
+    kc.case_sw_blend_irregular(DEV)
+    kc.case_sw_blend_many_windows(DEV)
+    kc.case_sw_blend_many_windows(DEV, slices=700)
+    monkeypatch.setenv("MONAI_AMD_BLEND_LEGACY", "1")
+    kc.case_sw_blend(DEV)
+
+
 def test_conv_direct():
     kc.case_conv3d(DEV, 0, 2, 1, 32, (6, 7, 9), with_nrm=False, fused_stats=False)
     kc.case_conv3d(DEV, 0, 1, 5, 7, (4, 5, 6), fused_stats=False)
