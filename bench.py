@@ -1,16 +1,26 @@
 """Headline benchmark (BASELINE.json): output voxels/s of 3-D sliding-window segmentation --
-512^3 fp32 synthetic volume, 96^3 windows, overlap 0.5 (1000 windows), 5-class BasicUNet, gaussian blend.
+512^3 fp32 synthetic CT volume, 96^3 windows, overlap 0.5 (1000 windows), 5-class BasicUNet, gaussian blend.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
 One "step" = one complete ``SlidingWindowInferer(...)(volume, net)`` call: window gather, the BasicUNet forward of
-all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + normalise.  The volume is resident in
-HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2
-of BASELINE.json).  Rank 0 prints ONE JSON line; `roofline` is measured live with HIP events around the dominant
-kernel's launches inside the timed region, `cpu_baseline` times the CPU oracle (a port of the reference path:
-torch-CPU ATen ops, bit-identical to the reference -- tests/test_oracle_golden.py) on a bounded sample.
+all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + normalise.  The volume -- the reference's own
+``create_test_image_3d`` phantom of SURVEY.md 8(d) config 1, restated bit-identically in oracle/synthetic.py -- is resident
+in HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2 of
+BASELINE.json).  Rank 0 prints ONE JSON line:
+
+  roofline      the dominant kernel (the Winograd 3x3x3 convolution of the 96^3 / 48^3 levels), HIP events around its
+                launches inside the timed region: `achieved` = matrix-core flops ISSUED per launch / average launch time,
+                `frac` = achieved / fp32-MFMA peak (a true fraction); the convolution's own (direct) flops are
+                `algorithmic_tflops`, their ratio is Winograd's 2.25x;
+  roofline_hbm  the blend: 20.38 GB of algorithmic traffic / its launch time, against the 8 TB/s spec; the
+                streaming ceilings of this chip are measured by tools/ubench/hbm_stream.hip (profiles/r02_ubench_hbm_stream_*.txt);
+  cpu_baseline  the CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
+                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on a 12-window
+                sub-volume of the benchmark volume on the host cores, extrapolated per window; the same sub-volume goes
+                through the HIP path and `parity_vs_gpu` reports the headline parity rule (oracle/parity.py).
 """
 
 from __future__ import annotations
@@ -29,118 +39,136 @@ if ROOT not in sys.path:
 
 METRIC = "voxels/s sliding-window 3D seg (512^3 vol, 96^3 win, ov 0.5) at 1/8 GPU"
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
-PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (≈6.3 TB/s achievable)
+PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (~6.3 TB/s achievable: the guide; 6.2-7.0 TB/s measured by tools/ubench/hbm_stream.hip)
+NETS = {"unetr": "UNETR ViT-B/16", "unet": "UNet 16-256 res2", "basicunet": "BasicUNet", "dynunet": "DynUNet 32-320 (5 levels)", "segresnet": "SegResNet f16"}
 
 
-def cpu_baseline(size: int, roi: int, windows: int, vol=None, net=None):
-    """The CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
-    tests/test_oracle_golden.py) on a bounded sample of windows; value = size^3 / (num_windows * mean window time).
+def benchmark_volume(size: int) -> torch.Tensor:
+    """create_test_image_3d(512, 512, 512, num_objs=40, rad_max=60, rad_min=10, noise_max=0.2,
+    num_seg_classes=4, RandomState(0)) -> [1, 1, size, size, size] fp32 in [0, 1] (oracle/synthetic.py, bit-identical to the
+    reference's generator; input data, generated on the host before anything is timed)."""
+    from oracle import synthetic
 
-    `torch.set_num_threads(os.cpu_count())` (BASELINE.md's plan) oversubscribes oneDNN on a 256-thread host, so a few
-    thread counts are probed with one window each and the fastest is used for the timed sample; `cores` reports it."""
+    return torch.from_numpy(synthetic.benchmark_volume(size))[None, None]
+
+
+def sub_volume_extents(size: int, roi: int, windows: int):
+    """Extents of a corner sub-volume that the inferer covers with (about) `windows` windows at overlap 0.5: 2 x 2 x 3 for 12."""
+    counts = [1, 1, 1]
+    step = max(roi // 2, 1)
+    most = max(1, (size - roi) // step + 1)
+    ax = 2
+    while counts[0] * counts[1] * counts[2] < windows and any(c < most for c in counts):
+        if counts[ax] < most:
+            counts[ax] += 1
+        ax = (ax - 1) % 3
+    return tuple(min(size, roi + (c - 1) * step) for c in counts)
+
+
+def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer):
+    """CPU oracle = port of the reference path (kind "port"): the complete sliding-window inference -- window loop, BasicUNet,
+    importance-weighted blend -- of a corner sub-volume of the benchmark volume on the host cores; value = size^3 voxels /
+    (windows of the full volume x measured time per window).  `torch.set_num_threads(os.cpu_count())` oversubscribes oneDNN on
+    a 256-thread host, so a few thread counts are probed with one window each and the fastest is used; `cores` reports it.
+    The same sub-volume goes through the HIP inferer: `parity_vs_gpu` is the headline parity rule on the BLENDED output."""
     import oracle
     from oracle.sliding_window import dense_patch_starts, get_scan_interval
 
     torch.manual_seed(1)
     sd = oracle.make_basic_unet_state(1, 5)
-    starts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
-    torch.manual_seed(0)
-    x = torch.rand(4, 1, roi, roi, roi)
-    sample = None
-    if vol is not None:     # time the oracle on REAL windows of the benchmark volume, so its logits can be compared below
-        import itertools
-
-        first = list(itertools.islice(itertools.product(*starts), ((windows + 3) // 4) * 4))
-        sample = torch.stack([vol[0, :, a:a + roi, b:b + roi, c:c + roi] for a, b, c in first]).cpu()
-        x = sample[:4]
+    ext = sub_volume_extents(size, roi, windows)
+    sub = vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
+    sub_cpu = sub.cpu()
+    rr = tuple(min(roi, e) for e in ext)
+    starts, _ = dense_patch_starts(ext, rr, get_scan_interval(ext, rr, (0.5,) * 3))
+    nsub = len(starts[0]) * len(starts[1]) * len(starts[2])
+    fstarts, _ = dense_patch_starts((size,) * 3, (roi,) * 3, get_scan_interval((size,) * 3, (roi,) * 3, (0.5,) * 3))
+    nfull = len(fstarts[0]) * len(fstarts[1]) * len(fstarts[2])
     ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
     best, best_t = cands[0], float("inf")
+    probe = sub_cpu[:, :, : rr[0], : rr[1], : rr[2]]
     with torch.no_grad():
         for c in cands:
             torch.set_num_threads(c)
-            oracle.basic_unet_forward(sd, x[:1])
+            oracle.basic_unet_forward(sd, probe)
             t0 = time.perf_counter()
-            oracle.basic_unet_forward(sd, x[:1])
+            oracle.basic_unet_forward(sd, probe)
             dt = time.perf_counter() - t0
             if dt < best_t:
                 best, best_t = c, dt
         torch.set_num_threads(best)
         t0 = time.perf_counter()
-        done = 0
-        ref = []
-        while done < windows:
-            xb = x if sample is None else sample[done:done + 4]
-            ref.append(oracle.basic_unet_forward(sd, xb))  # sw_batch_size = 4, as in the workload
-            done += 4
+        ref = oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
         dt = time.perf_counter() - t0
-    parity = None
-    if sample is not None and net is not None:   # the same windows through the HIP path: logits and label maps vs the oracle
-        with torch.no_grad():
-            got = net(sample.to(vol.device)).cpu()
-        exp = torch.cat(ref)
-        la, lb = got.argmax(1), exp.argmax(1)
-        dice = []
-        for k in range(exp.shape[1]):
-            a, b = la == k, lb == k
-            den = int(a.sum()) + int(b.sum())
-            dice.append(1.0 if den == 0 else 2.0 * int((a & b).sum()) / den)
-        top2 = exp.topk(2, dim=1).values
-        margin = (top2[:, 0] - top2[:, 1])[la != lb]          # the oracle's own top-2 margin where the label maps differ
-        parity = {"windows": int(exp.shape[0]), "max_abs_logit_diff": float((got - exp).abs().max()), "tolerance": 1e-4,
-                  "argmax_mismatch_voxels": int((la != lb).sum()), "voxels": int(la.numel()), "min_class_dice": min(dice),
-                  "max_top2_margin_at_mismatch": float(margin.max()) if margin.numel() else 0.0,
-                  "note": "label maps can only differ where the reference's own top-2 logits are closer than the fp32 "
-                          "reordering noise of two different conv summation orders (random-init weights: near-ties exist)"}
-    nwin = len(starts[0]) * len(starts[1]) * len(starts[2])
-    per_win = dt / done
+        got = inferer(sub, net)
+    parity = oracle.label_parity(got, ref, tol=1e-4)
+    parity["compared"] = (f"complete inferer output (blended logits) of the {ext[0]}x{ext[1]}x{ext[2]} corner sub-volume, {nsub} windows; rule: max|dlogit| <= 1e-4 and "
+                          "every argmax difference at a voxel whose oracle top-2 margin < 2 max|dlogit| (mismatch_outside_margin == 0)")
+    per_win = dt / nsub
     return {
-        "value": size ** 3 / (nwin * per_win),
+        "value": size ** 3 / (nfull * per_win),
         "unit": "voxels/s",
         "cores": best,
         "kind": "port",
         "parity_vs_gpu": parity,
-        "sample": f"{done} of {nwin} windows ({roi}^3, sw_batch 4) through the CPU oracle's BasicUNet on {best} of {ncpu} host threads "
-                  f"(fastest of {cands}): {per_win:.3f} s/window; value = {size}^3 voxels / ({nwin} windows x that); the blend (1-2 % on CPU) is not included",
+        "sample": f"complete CPU-oracle sliding-window inference (windows + BasicUNet + gaussian blend, sw_batch 4) of a {ext[0]}x{ext[1]}x{ext[2]} corner of the benchmark "
+                  f"volume = {nsub} of {nfull} windows ({roi}^3) on {best} of {ncpu} host threads (fastest of {cands}): {dt:.2f} s = {per_win:.3f} s/window; "
+                  f"value = {size}^3 voxels / ({nfull} windows x that)",
     }
 
 
 def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch of `kernel_key` from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied -- counters cannot be collected inside this process)."""
+    """HBM bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
+    gfx950 corrections applied -- counters cannot be collected inside this process); the newest profiles/r*_pmc_hbm_traffic.json wins."""
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            k = json.load(f)["kernels"].get(kernel_key)
-        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
-                                       "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"],
-                                       "measured_on": "32->32 ch, 96^3, 64 windows per launch" if "conv" in kernel_key else "the bench configuration",
-                                       "source": "profiles/r01_pmc_hbm_traffic.txt"}
+        for name in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json")), reverse=True):
+            with open(os.path.join(pdir, name)) as f:
+                k = json.load(f)["kernels"].get(kernel_key)
+            if k is not None:
+                return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
+                        "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"], "measured_on": k.get("measured_on", "the bench configuration"),
+                        "source": "profiles/" + name.replace(".json", ".txt")}
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
-    ap.add_argument("--cpu-windows", type=int, default=12, help="windows timed for cpu_baseline (0 = skip)")
-    ap.add_argument("--net", default="basicunet", choices=["basicunet", "unetr", "unet", "dynunet", "segresnet"],
+    ap.add_argument("--cpu-windows", type=int, default=12, help="windows of the sub-volume the CPU baseline runs (0 = skip)")
+    ap.add_argument("--net", default="basicunet", choices=sorted(NETS),
                     help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
                          "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16) (SURVEY 8f-4)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    emulated = False
+    if not torch.cuda.is_available():
+        # TEST HARNESS ONLY (tests/test_bench_harness.py): the same code path on the SIMT-emulator build of the kernels with gloo,
+        # so that the torch.distributed.run wiring, the rank-0 JSON line and its keys are exercised without a GPU.  Never a result.
+        if os.environ.get("MONAI_AMD_BENCH_EMULATOR") != "1":
+            raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emu_backend import emu_backend
+
+        emulated = True
+        ctx = emu_backend()
+        ctx.__enter__()
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
 
@@ -150,10 +178,13 @@ def main():
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emulated:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         parallel.enable_window_sharding()
 
-    # weights / volume exactly as SURVEY.md 8(d) config 1 (fallback volume: seeded uniform noise)
+    # weights / volume exactly as SURVEY.md 8(d) config 1
     torch.manual_seed(1)
     if args.net == "unetr":
         net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
@@ -165,14 +196,14 @@ def main():
         net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=5).eval().to(dev)
     else:
         net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
-    torch.manual_seed(0)
-    vol = torch.rand(1, 1, args.size, args.size, args.size).to(dev)
+    vol = benchmark_volume(args.size).to(dev)
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not emulated:
+            torch.cuda.synchronize()
 
     out = None
     for _ in range(args.warmup):
@@ -198,26 +229,27 @@ def main():
         roof = None
         if convs:
             key, conv = max(convs.items(), key=lambda kv: kv[1]["ms_total"])
-            tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12
+            tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12          # the convolution's own flops: 2 * 27 * Cin * Cout per voxel
             cfg_id = int(key.split("/cfg")[1])
             from monai_amd import ops as _ops
             ncfg = _ops.conv3d_k3_num_configs()
             if cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
-                kname = (f"conv3d_k3_wino2d_kernel (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, "
-                         f"32|64 -> 32 ch @ {args.roi}^3)")
-                pipe = tf / 2.25
+                impl = "conv3d_k3_wino2d_kernel, one wave per SIMD" if os.environ.get("MONAI_AMD_W2_IMPL", "p")[:1] == "d" else "conv3d_k3_wino2p_kernel, two waves per SIMD"
+                kname = f"{impl} (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, 32|64 -> 32 ch @ {args.roi}^3 / {args.roi // 2}^3)"
+                gain = 2.25
             elif cfg_id == ncfg - 1:
-                kname, pipe = "conv3d_k3_winograd_kernel (Winograd F(2x2x2,3x3x3) on v_mfma_f32_16x16x4_f32)", tf / 3.375
+                kname, gain = "conv3d_k3_winograd_kernel (Winograd F(2x2x2,3x3x3) on v_mfma_f32_16x16x4_f32)", 3.375
             else:
-                kname = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)"
-                pipe = tf
-            roof = {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS,
+                kname, gain = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)", 1.0
+            issued = tf / gain
+            roof = {"bound": "mfma", "achieved": issued, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_FP32_TFLOPS,
                     "traffic": None, "kernel": kname,
-                    "note": "achieved = ALGORITHMIC flops of the 3x3x3 convolution (2*27*Cin*Cout per voxel) / kernel time; "
-                            "mfma_pipe_frac = matrix-core flops actually issued / time / peak",
-                    "mfma_pipe_frac": pipe / PEAK_FP32_TFLOPS,
-                    "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch": conv["work"] / conv["launches"],
-                    "share_of_step": conv["ms_total"] / args.steps / ms}
+                    "note": "achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); frac = the fraction of the "
+                            "fp32-MFMA peak the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops (2*27*Cin*Cout per voxel): "
+                            "Winograd needs winograd_algorithmic_gain x fewer multiply-adds for them",
+                    "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / PEAK_FP32_TFLOPS, "winograd_algorithmic_gain": gain,
+                    "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
+                    "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / args.steps / ms}
             td = pmc_traffic("conv3d_k3_wino2d_kernel" if cfg_id == ncfg else "conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
             if td:
                 roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
@@ -225,22 +257,11 @@ def main():
         roof_hbm = None
         if blend:
             gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
-            # the practical ceiling on this box: a plain device-to-device copy of the output-sized buffer (read + write streams)
-            ca = torch.empty(out.numel(), dtype=torch.float32, device=dev)
-            cb = torch.empty_like(ca)
-            cb.copy_(ca)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                cb.copy_(ca)
-            e1.record()
-            torch.cuda.synchronize()
-            copy_gbs = 3 * 8.0 * ca.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
-            del ca, cb
             roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "device_copy_GBps": copy_gbs, "frac_of_device_copy": gbs / copy_gbs,
-                        "traffic": None, "kernel": "sw_blend_kernel<5,4>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
-                        "bytes_per_launch": blend["work"] / blend["launches"]}
+                        "traffic": None, "kernel": "sw_blend_reg_kernel<5,4,2> (regular-grid gather blend)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+                        "bytes_per_launch": blend["work"] / blend["launches"],
+                        "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s "
+                                              "(profiles/r02_ubench_hbm_stream_v1.txt)"}
             td = pmc_traffic("sw_blend_kernel")
             if td:
                 roof_hbm["traffic"], roof_hbm["traffic_detail"] = td["hbm_bytes_per_launch"], td
@@ -260,8 +281,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{ {'unetr': 'UNETR ViT-B/16', 'unet': 'UNet 16-256 res2', 'basicunet': 'BasicUNet', 'dynunet': 'DynUNet 32-320 (5 levels)', 'segresnet': 'SegResNet f16'}[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic volume resident in HBM, "
-                            f"{args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
+                "workload": f"{NETS[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic CT volume (the reference's create_test_image_3d phantom, "
+                            f"SURVEY 8d config 1) resident in HBM, {args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
             "roofline": roof,
@@ -273,8 +294,10 @@ def main():
             "conv_ms_per_step": conv_all,
             "checksum": float(out.double().sum().item()),
         }
+        if emulated:
+            line["emulated"] = "SIMT emulator + gloo: harness test only, not a measurement"
         if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
-            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))

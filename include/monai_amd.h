@@ -61,14 +61,16 @@ int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const in
  * out /= cnt`) as ONE gather pass: for every output voxel the covering windows are visited in
  * ascending window index, acc += fp32(logit*w), cnt += w, out = acc/cnt -- bit-identical to the
  * reference's scatter order.
- *   logits  [nz*ny*nx][K][rd][rh][rw]   all windows of the grid, in window order
+ *   logits  [nz*ny*nx][K][rd][rh][rw]   all windows of the grid, in window order; consecutive windows are `window_stride`
+ *                                       floats apart (0 = dense, K*rd*rh*rw).  A stride that is not a multiple of a large power
+ *                                       of two spreads the concurrently read (window, class) streams over the HBM channels.
  *   imp     [rd][rh][rw]                importance map (monai/data/utils.py:1084-1134)
  *   out     [K][D][H][W]
  * Every voxel must be covered by at least one window (true for dense_patch_slices).
  * premultiplied != 0: `logits` already hold logit*w (the `process_fn` path, utils.py:232-234, where the weight may change
  * per window batch): acc += logit, cnt += imp -- the reference's `seg *= w_t` followed by `+=`, with its count map. */
-int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd,
-                    int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
+int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp, float* out, int K, int D, int H, int W,
+                    int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
                     int nx, int premultiplied, void* stream);
 
 /* The same blend with the post-processing step that follows it in segmentation bundles fused into its epilogue:
@@ -77,9 +79,9 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
  * value, NaN counts as maximal -- is written: labels [D][H][W] as float32 (labels_u8 = 0, AsDiscrete's default output dtype) or
  * uint8 (labels_u8 = 1, K <= 256).  Output traffic K*4 B per voxel -> 4 B or 1 B.  Regular (dense_patch_slices) grids only;
  * MH_ERR_UNSUPPORTED otherwise (blend, then mh_channel_reduce_f32). */
-int mh_sw_blend_argmax_f32(const float* logits, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd,
-                           int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
-                           int premultiplied, void* stream);
+int mh_sw_blend_argmax_f32(const float* logits, int64_t window_stride, const float* imp, void* labels, int labels_u8, int K, int D,
+                           int H, int W, int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny,
+                           const int32_t* sx, int nx, int premultiplied, void* stream);
 
 /* AvgMerger of the PatchInferer family (monai/inferers/merger.py:103-205): one patch, `values[slice] += patch; counts[slice] += 1`
  * (values / patch [NC][...] fp32 dense, counts uint8 like the reference's default count_dtype; the patch must lie inside the

@@ -53,8 +53,8 @@ SIGNATURES = {
     "mh_foreground_bbox_workspace_ints": (_I, [_I, _I]),
     "mh_foreground_bbox_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mh_crop_pad_f32": (_I, [_P, _P] + [_I] * 10 + [_F, _P]),
-    "mh_sw_blend_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
-    "mh_sw_blend_argmax_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
+    "mh_sw_blend_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
+    "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I]),
     "mh_conv3d_k3_split_config": (_I, []),
     "mh_conv3d_k3_num_configs": (_I, []),

@@ -12,6 +12,7 @@
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_winograd.h"
 #include "kernels/conv3d_wino2d.h"
+#include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_split.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
@@ -124,11 +125,11 @@ int mh_window_extract_f32(const float* vol, int C, int D, int H, int W, const in
 
 template <int VEC>
 static void launch_blend(int kt, unsigned nb, hipStream_t s, const float* logits, const float* imp, float* out, int K, int k0,
-                         int D, int H, int W, int rd, int rh, int rw, const WindowGrid& g, int premul) {
+                         int D, int H, int W, int rd, int rh, int rw, const WindowGrid& g, int premul, long long wstride) {
 #define MH_BLEND_CASE(KT)                                                                                              \
     case KT:                                                                                                           \
         hipLaunchKernelGGL((sw_blend_kernel<KT, VEC>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, \
-                           rh, rw, g, premul);                                                                         \
+                           rh, rw, g, premul, wstride);                                                                \
         break;
     switch (kt) {
         MH_BLEND_CASE(1) MH_BLEND_CASE(2) MH_BLEND_CASE(3) MH_BLEND_CASE(4)
@@ -160,10 +161,10 @@ int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* s
 // per batch.  MONAI_AMD_BLEND_G / MONAI_AMD_BLEND_NT are development knobs (profiles/r02_blend_variants.txt).
 template <bool ARGMAX>
 static int launch_blend_reg(int kt, bool v4, int G, bool nt, unsigned nb, hipStream_t s, const float* logits, const float* imp, void* out,
-                            int K, int k0, int D, int H, int W, int rd, int rh, int rw, const RegGrid& g, int premul, int out_u8) {
+                            int K, int k0, int D, int H, int W, int rd, int rh, int rw, const RegGrid& g, int premul, int out_u8, long long wstride) {
 #define MH_BR(KT, VEC, GG, NTT)                                                                                              \
     hipLaunchKernelGGL((sw_blend_reg_kernel<KT, VEC, GG, NTT, ARGMAX>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, k0, D, H, \
-                       W, rd, rh, rw, g, premul, out_u8)
+                       W, rd, rh, rw, g, premul, out_u8, wstride)
 #define MH_BR_CASE(KT)                                                                      \
     case KT:                                                                                \
         if (!v4) MH_BR(KT, 1, 1, false);                                                    \
@@ -190,8 +191,11 @@ static int launch_blend_reg(int kt, bool v4, int G, bool nt, unsigned nb, hipStr
 }
 
 static int blend_checks(const char* what, const float* logits, const float* imp, const void* out, int K, int D, int H, int W, int rd, int rh, int rw,
-                        const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx) {
+                        const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int64_t& wstride) {
     if (!logits || !imp || !out || K < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "%s: bad argument", what);
+    const int64_t dense = (int64_t)K * rd * rh * rw;
+    if (wstride == 0) wstride = dense;
+    if (wstride < dense) return fail(MH_ERR_ARG, "%s: window stride %lld is smaller than one window's logits (%lld floats)", what, (long long)wstride, (long long)dense);
     if (!sz || !sy || !sx || nz < 1 || ny < 1 || nx < 1) return fail(MH_ERR_ARG, "window grid: null/empty start list");
     // full coverage: first window at 0, last ends at the image end, no gaps
     const int32_t* ss[3] = {sz, sy, sx};
@@ -207,10 +211,10 @@ static int blend_checks(const char* what, const float* logits, const float* imp,
     return MH_OK;
 }
 
-int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
+int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
                     const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
-    if (int e = blend_checks("sw_blend", logits, imp, out, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx)) return e;
-    const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16);
+    if (int e = blend_checks("sw_blend", logits, imp, out, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx, window_stride)) return e;
+    const bool v4 = W % 4 == 0 && rw % 4 == 0 && window_stride % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16);
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
     RegGrid rg;
     if (regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W) && env_int("MONAI_AMD_BLEND_LEGACY", 0) == 0) {
@@ -219,7 +223,7 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
         for (int k0 = 0; k0 < K; k0 += 8) {
             const int kt = K - k0 < 8 ? K - k0 : 8;
             if (int e = launch_blend_reg<false>(kt, v4, G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, rg,
-                                                premultiplied ? 1 : 0, 0))
+                                                premultiplied ? 1 : 0, 0, window_stride))
                 return e;
         }
         return launched("sw_blend");
@@ -228,24 +232,25 @@ int mh_sw_blend_f32(const float* logits, const float* imp, float* out, int K, in
     if (int e = fill_grid(g, sz, nz, sy, ny, sx, nx)) return e;
     for (int k0 = 0; k0 < K; k0 += 8) {
         const int kt = K - k0 < 8 ? K - k0 : 8;
-        if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
-        else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0);
+        if (v4) launch_blend<4>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0, window_stride);
+        else launch_blend<1>(kt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, premultiplied ? 1 : 0, window_stride);
     }
     return launched("sw_blend");
 }
 
-int mh_sw_blend_argmax_f32(const float* logits, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd, int rh, int rw,
-                           const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
-    if (int e = blend_checks("sw_blend_argmax", logits, imp, labels, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx)) return e;
+int mh_sw_blend_argmax_f32(const float* logits, int64_t window_stride, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd,
+                           int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
+    if (int e = blend_checks("sw_blend_argmax", logits, imp, labels, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx, window_stride)) return e;
     if (labels_u8 && K > 256) return fail(MH_ERR_UNSUPPORTED, "sw_blend_argmax: %d classes do not fit a uint8 label", K);
     RegGrid rg;
     if (!regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W))
         return fail(MH_ERR_UNSUPPORTED, "sw_blend_argmax: irregular window starts (blend, then argmax)");
-    const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(labels, labels_u8 ? 4 : 16);
+    const bool v4 = W % 4 == 0 && rw % 4 == 0 && window_stride % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) &&
+                    aligned(labels, labels_u8 ? 4 : 16);
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
     const bool nt = env_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
     if (int e = launch_blend_reg<true>(K < 8 ? K : 8, v4, MH_BLEND_G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, labels, K, 0, D, H, W, rd, rh,
-                                       rw, rg, premultiplied ? 1 : 0, labels_u8 ? 1 : 0))
+                                       rw, rg, premultiplied ? 1 : 0, labels_u8 ? 1 : 0, window_stride))
         return e;
     return launched("sw_blend_argmax");
 }
@@ -457,6 +462,17 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const long long total = (long long)nblk * (out.C / W2_CN) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
+        // two implementations of the same configuration (same packing, statistics records and launch geometry):
+        // conv3d_wino2p.h -- two 256-register waves per SIMD, the Winograd positions split over the pair -- and the round-1
+        // kernel with one 384-register wave per SIMD (MONAI_AMD_W2_IMPL=d)
+        const char* impl = getenv("MONAI_AMD_W2_IMPL");
+        if (!(impl && impl[0] == 'd')) {
+            if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            return launched("conv3d_k3_wino2p");
+        }
         if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
         else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);

@@ -62,7 +62,7 @@ window_extract_kernel(const float* __restrict__ vol, int C, int D, int H, int W,
 template <int KT, int VEC>
 __global__ void __launch_bounds__(256)
 sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K,
-                int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g, int premul) {
+                int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g, int premul, long long wstride) {
     const int wv = W / VEC;
     const long long total = (long long)D * H * wv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -94,7 +94,7 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
                 const int lx = x - g.sx[ix];
                 const long long w = ((long long)iz * g.ny + iy) * g.nx + ix;
                 const long long off = (long long)lz * plane + (long long)ly * rw + lx;
-                const float* lp = logits + (w * K + k0) * roi + off;
+                const float* lp = logits + w * wstride + k0 * roi + off;
                 float wt[VEC];
                 float lv[KT][VEC];
                 if (VEC == 4) {
@@ -189,6 +189,8 @@ window_extract_reg_kernel(const float* __restrict__ vol, int C, int D, int H, in
 // cnt = cnt + w, out = acc / cnt, windows in ascending index), organised for the memory system: the covering box is walked
 // G windows at a time -- the G x KT logit vectors and G weight vectors of a batch are all requested before the first add
 // (the adds keep the window order) -- and the read-once logits / write-once output can bypass the caches (NT).
+// `wstride` = floats between consecutive windows' logits (>= K * roi): a stride that is not a multiple of a large power of two
+// spreads the 8 x K concurrently read (window, class) streams of a voxel over the HBM channels (profiles/r02_ubench_hbm_stream_v2.txt).
 // ARGMAX = false writes channels [k0, k0 + KT); ARGMAX = true walks ALL K channels in chunks of KT inside the thread
 // and writes only the label -- index of the first maximal blended value, NaN maximal, i.e. torch.argmax of the blended
 // logits (AsDiscrete(argmax=True), monai/transforms/post/array.py:132-237) -- as float or uint8: K x 4 B per voxel of output
@@ -196,7 +198,7 @@ window_extract_reg_kernel(const float* __restrict__ vol, int C, int D, int H, in
 template <int KT, int VEC, int G, bool NT, bool ARGMAX>
 __global__ void __launch_bounds__(256)
 sw_blend_reg_kernel(const float* __restrict__ logits, const float* __restrict__ imp, void* __restrict__ out_, int K, int k0_, int D,
-                    int H, int W, int rd, int rh, int rw, RegGrid g, int premul, int out_u8) {
+                    int H, int W, int rd, int rh, int rw, RegGrid g, int premul, int out_u8, long long wstride) {
     const int wv = W / VEC;
     const long long total = (long long)D * H * wv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -240,7 +242,7 @@ sw_blend_reg_kernel(const float* __restrict__ logits, const float* __restrict__ 
                 const int lz = z - axis_start(g.z, iz), ly = y - axis_start(g.y, iy), lx = x - axis_start(g.x, ix);
                 const long long w = ((long long)iz * g.y.n + iy) * g.x.n + ix;
                 long long off = (long long)lz * plane + (long long)ly * rw + lx;
-                long long base = w * K * roi + off;
+                long long base = w * wstride + off;
                 if (b == 0) { off0 = off; base0 = base; }
                 if (!ok) { off = off0; base = base0; }        // past the end of the box: re-request the batch's first window (values unused)
                 if (ok) {                                     // next window of the box, last axis fastest = ascending window index

@@ -75,19 +75,22 @@ def _to3(values, fill):
     return (fill,) * (3 - len(values)) + values
 
 
-def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, sharded: bool = False) -> int:
+def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world: int = 1) -> int:
     """Windows per predictor call.  A generic predictor gets exactly the user's ``sw_batch_size``.  The fused engines
     size the batch for 288 GB of HBM instead (results do not depend on the batch: InstanceNorm is per sample): more
     windows per launch fill the 256 CUs at the deep U-Net levels, and a power-of-two count keeps the workgroup grids of
     the large layers whole multiples of the CU count -- measured on the BASELINE workload (profiles/): 25 windows per
-    launch 1.85 s, 32: 1.75 s, 64: 1.73 s, 128: 1.72 s.  Default 64 (32 when windows are sharded over GPUs: more, smaller
-    all-gather rounds to overlap).  Override with MONAI_AMD_SW_BATCH; MONAI_AMD_STRICT_SW_BATCH=1 keeps the user's value."""
+    launch 1.85 s, 32: 1.75 s, 64: 1.73 s, 128: 1.72 s.  Default 64 on one GPU.  When the windows are sharded over `world`
+    GPUs a round is world x nb windows and the last round is padded to a whole one: nb is the value in [32, 64] that pads the
+    fewest windows (1000 windows: 2 or 4 GPUs 50 -> none padded, 8 GPUs 63 -> 8 padded; 64 would pad 24), ties to the larger.
+    `num_win` is the TOTAL number of windows.  Override with MONAI_AMD_SW_BATCH; MONAI_AMD_STRICT_SW_BATCH=1 keeps the user's value."""
     if not hasattr(predictor, "forward_into") or os.environ.get("MONAI_AMD_STRICT_SW_BATCH") == "1":
         return max(1, int(sw_batch_size))
+    per_rank = max(-(-num_win // world), 1)
     env = os.environ.get("MONAI_AMD_SW_BATCH")
     if env:
-        return max(1, min(int(env), num_win))
-    cap = 32 if sharded else 64
+        return max(1, min(int(env), per_rank))
+    cap = 64
     if device.type == "cuda":
         free, _ = torch.cuda.mem_get_info(device)
         per_win = 6.0 * 4 * max(getattr(predictor, "features", (32,))[0], 1) * roi3[0] * roi3[1] * roi3[2]
@@ -95,7 +98,16 @@ def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, shard
         while cap > 1 and cap > fit:
             cap //= 2
     cap = max(cap, int(sw_batch_size)) if cap >= sw_batch_size else cap
-    return max(1, min(cap, num_win))
+    cap = max(1, min(cap, per_rank))
+    if world > 1 and cap > 1:
+        best, best_pad = cap, None
+        for nb in range(cap, max(cap // 2, 1) - 1, -1):
+            span = world * nb
+            pad = -(-num_win // span) * span - num_win
+            if best_pad is None or pad < best_pad:
+                best, best_pad = nb, pad
+        cap = best
+    return cap
 
 
 def sliding_window_inference(
@@ -209,7 +221,7 @@ def sliding_window_inference(
 
     # windows owned by this rank: all of them, or (window sharding on) its slot of every round -- monai_amd/parallel.py
     shard = parallel.window_shard(num_win)
-    nb = _auto_batch(predictor, roi3, max(-(-num_win // shard.world), 1), sw_batch_size, dev, sharded=shard.world > 1)
+    nb = _auto_batch(predictor, roi3, num_win, sw_batch_size, dev, world=shard.world)
     nb = shard.agree_batch(nb, dev)
     my_rounds = shard.rounds(nb)
     fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs and process_fn is None
@@ -352,11 +364,29 @@ def sliding_window_inference(
     return _pack_struct(finals, dict_keys)
 
 
+def _window_stride(dense: int) -> int:
+    """Floats between consecutive windows' logits.  The blend reads the K class blocks of up to 8 (27) covering windows of a
+    voxel concurrently; with the dense stride (K * roi * 4 B, a multiple of 128 KiB at 96^3) those streams fall on the same HBM
+    channels.  Large windows get a stride of 17 x 256 B modulo 128 KiB (measured with tools/ubench/hbm_stream.hip and
+    tools/blend_bench.py, profiles/r02_*); MONAI_AMD_LOGITS_PAD (floats, multiple of 4) overrides, 0 = dense."""
+    env = os.environ.get("MONAI_AMD_LOGITS_PAD")
+    if env is not None and env != "":
+        pad = max(0, int(env))
+        return dense + pad - pad % 4
+    if dense % 4 or dense * 4 < (1 << 20):
+        return dense
+    pad_bytes = (17 * 256 - dense * 4) % (1 << 17)
+    return dense + pad_bytes // 4
+
+
 def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
-    """Logits of every window of the image, [num_win (padded to whole rounds when sharded), K, *seg3]: the predictor
-    writes its windows' rows, window sharding completes the others, the blend reads it once."""
+    """Logits of every window of the image, [num_win (padded to whole rounds when sharded), K, *seg3] as a view of one flat
+    buffer with a padded window stride (`_window_stride`): the predictor writes its windows' rows, window sharding completes
+    the others (`flat_rows`), the blend reads it once."""
     rows = shard.padded_windows(nb)
-    need = rows * k * seg3[0] * seg3[1] * seg3[2] * 4
+    dense = k * seg3[0] * seg3[1] * seg3[2]
+    ws = _window_stride(dense)
+    need = rows * ws * 4
     if dev.type == "cuda":
         free, _ = torch.cuda.mem_get_info(dev)
         if need > 0.9 * free:
@@ -364,7 +394,15 @@ def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
     limit = _logits_budget(dev)
     if limit is not None and need > limit:
         raise _LogitsDoNotFit(need, limit)
-    return torch.empty((rows, k) + tuple(seg3), dtype=dtype, device=dev)
+    flat = torch.empty(rows * ws, dtype=dtype, device=dev)
+    return flat.as_strided((rows, k) + tuple(seg3), (ws, seg3[0] * seg3[1] * seg3[2], seg3[1] * seg3[2], seg3[2], 1))
+
+
+def flat_rows(logits: torch.Tensor, r0: int, r1: int) -> torch.Tensor:
+    """Rows [r0, r1) of an `_alloc_logits` buffer as ONE contiguous 1-D tensor (padding included): what a collective sends."""
+    ws = logits.stride(0)
+    base = logits._base if logits._base is not None else logits
+    return base.reshape(-1)[r0 * ws : r1 * ws]
 
 
 class _LogitsDoNotFit(RuntimeError):

@@ -35,19 +35,28 @@ def window_extract(vol: torch.Tensor, grid: Grid, w0: int, nwin: int, roi: Seque
     return out
 
 
+def _window_rows(logits: torch.Tensor, k: int, roi, nwin: int, who: str) -> int:
+    """logits [nwin, K, rd, rh, rw]: every window's [K, rd, rh, rw] block dense, windows `stride(0)` floats apart (a padded
+    window stride spreads the blend's concurrent read streams over the HBM channels) -> that stride"""
+    if logits.dim() != 5 or logits.shape[0] != nwin or logits.shape[1] != k or tuple(logits.shape[2:]) != tuple(roi):
+        raise RuntimeError(f"monai_amd.{who}: logits shape {tuple(logits.shape)} does not match the window grid")
+    if not logits[0].is_contiguous() or (nwin > 1 and logits.stride(0) < logits[0].numel()):
+        raise RuntimeError(f"monai_amd.{who}: each window's logits must be dense (strides {logits.stride()})")
+    return int(logits.stride(0)) if nwin > 1 else 0
+
+
 def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int], premultiplied: bool = False) -> torch.Tensor:
-    """logits [nwin,K,rd,rh,rw] (all windows of the grid, in order), imp [rd,rh,rw] -> out [K,D,H,W] =
-    sum_w logits*imp / sum_w imp in the reference's summation order (monai/inferers/utils.py:264-298).
+    """logits [nwin,K,rd,rh,rw] (all windows of the grid, in order; the window stride may be padded), imp [rd,rh,rw] ->
+    out [K,D,H,W] = sum_w logits*imp / sum_w imp in the reference's summation order (monai/inferers/utils.py:264-298).
     premultiplied: `logits` already hold logit * weight (process_fn path); only the count uses `imp`."""
     _lib.require_device(logits, imp, out)
-    if not (logits.is_contiguous() and imp.is_contiguous() and out.is_contiguous()):
+    if not (imp.is_contiguous() and out.is_contiguous()):
         raise RuntimeError("monai_amd.sw_blend: contiguous tensors required")
     k, d, h, w = out.shape
     sz, sy, sx = grid
-    if logits.shape[0] != len(sz) * len(sy) * len(sx) or logits.shape[1] != k or tuple(logits.shape[2:]) != tuple(roi):
-        raise RuntimeError(f"monai_amd.sw_blend: logits shape {tuple(logits.shape)} does not match the window grid")
+    ws = _window_rows(logits, k, roi, len(sz) * len(sy) * len(sx), "sw_blend")
     _lib.lib().call(
-        "mh_sw_blend_f32", _lib.ptr(logits), _lib.ptr(imp), _lib.ptr(out), k, d, h, w, int(roi[0]), int(roi[1]), int(roi[2]),
+        "mh_sw_blend_f32", _lib.ptr(logits), ws, _lib.ptr(imp), _lib.ptr(out), k, d, h, w, int(roi[0]), int(roi[1]), int(roi[2]),
         _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), int(bool(premultiplied)), _s(out),
     )
     return out
@@ -59,15 +68,14 @@ def sw_blend_argmax(logits: torch.Tensor, imp: torch.Tensor, labels: torch.Tenso
     index of the first maximal blended value per voxel (AsDiscrete(argmax=True), monai/transforms/post/array.py:132-237)."""
     _lib.require_device(logits, imp)
     _lib.require_device(labels, dtypes=(torch.float32, torch.uint8))
-    if not (logits.is_contiguous() and imp.is_contiguous() and labels.is_contiguous()):
+    if not (imp.is_contiguous() and labels.is_contiguous()):
         raise RuntimeError("monai_amd.sw_blend_argmax: contiguous tensors required")
     d, h, w = labels.shape
     k = int(num_classes)
     sz, sy, sx = grid
-    if logits.shape[0] != len(sz) * len(sy) * len(sx) or logits.shape[1] != k or tuple(logits.shape[2:]) != tuple(roi):
-        raise RuntimeError(f"monai_amd.sw_blend_argmax: logits shape {tuple(logits.shape)} does not match the window grid")
+    ws = _window_rows(logits, k, roi, len(sz) * len(sy) * len(sx), "sw_blend_argmax")
     _lib.lib().call(
-        "mh_sw_blend_argmax_f32", _lib.ptr(logits), _lib.ptr(imp), _lib.ptr(labels), int(labels.dtype == torch.uint8), k, d, h, w,
+        "mh_sw_blend_argmax_f32", _lib.ptr(logits), ws, _lib.ptr(imp), _lib.ptr(labels), int(labels.dtype == torch.uint8), k, d, h, w,
         int(roi[0]), int(roi[1]), int(roi[2]), _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx),
         int(bool(premultiplied)), _s(labels),
     )

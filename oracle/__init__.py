@@ -25,3 +25,4 @@ from .sliding_window import (  # noqa: F401
     sliding_window_inference,
 )
 from .basic_unet import basic_unet_forward, make_basic_unet_state  # noqa: F401
+from .parity import assert_label_parity, label_parity  # noqa: F401

@@ -79,6 +79,15 @@ def case_sw_blend(device, img=(24, 20, 32), roi=(16, 12, 16), overlap=0.5, k=5, 
     ops.sw_blend(logits.to(device), imp.to(device), out, starts, roi)
     exp = reference_blend(logits, imp, img, roi, starts)
     assert torch.equal(out.cpu(), exp), f"blend not bit-exact: max diff {(out.cpu() - exp).abs().max().item()}"
+    # a padded window stride (the inferer's logits buffer, monai_amd/inferers/utils.py:_window_stride): same bits
+    ws = logits[0].numel() + 12
+    flat = torch.full((nwin * ws,), float("nan"))
+    padded = flat.as_strided(logits.shape, (ws,) + tuple(logits.stride()[1:]))
+    padded.copy_(logits)
+    out2 = torch.empty((k,) + tuple(img), device=device)
+    ops.sw_blend(padded.to(device) if device == "cpu" else flat.to(device).as_strided(logits.shape, (ws,) + tuple(logits.stride()[1:])),
+                 imp.to(device), out2, starts, roi)
+    assert torch.equal(out2.cpu(), exp), "blend with a padded window stride differs"
     # the argmax epilogue (AsDiscrete(argmax=True) fused into the blend): labels == torch.argmax of the blended logits, both dtypes
     for dt in (torch.float32, torch.uint8):
         lab = torch.full(tuple(img), 77, dtype=dt, device=device)
@@ -141,6 +150,39 @@ def case_sw_blend_many_windows(device, slices=170):
 
 
 # ------------------------------------------------------------------------------------------ network blocks
+def case_wino2d_impls_agree(device, n, cin, cout, dims):
+    """conv3d_wino2p.h (two waves per SIMD, Winograd positions split over a wave pair) performs the operations of
+    conv3d_wino2d.h in the same order: the convolution values of the two implementations are bit-identical."""
+    import os
+
+    gen = torch.Generator().manual_seed(300 + cin + cout + dims[0])
+    x = torch.randn((n, cin) + tuple(dims), generator=gen).to(device)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)).to(device)
+    b = (torch.randn(cout, generator=gen) * 0.1).to(device)
+    nrm = _rand_nrm(n, cin, gen).to(device)
+    cfg = ops.conv3d_k3_num_configs()
+    packed = ops.conv3d_k3_pack(cfg, w)
+    tiles = ops.conv3d_k3_stat_tiles(cfg, *dims)
+    res = {}
+    saved = os.environ.get("MONAI_AMD_W2_IMPL")
+    try:
+        for impl in ("d", "p"):
+            os.environ["MONAI_AMD_W2_IMPL"] = impl
+            out = torch.full((n, cout) + tuple(dims), float("nan"), device=device)
+            stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+            ops.conv3d_k3(cfg, x, nrm, packed, b, out, stats)
+            res[impl] = (out.cpu(), stats.cpu())
+    finally:
+        if saved is None:
+            os.environ.pop("MONAI_AMD_W2_IMPL", None)
+        else:
+            os.environ["MONAI_AMD_W2_IMPL"] = saved
+    assert torch.equal(res["d"][0], res["p"][0]), f"max diff {(res['d'][0] - res['p'][0]).abs().max().item()}"
+    sd, sp = res["d"][1], res["p"][1]
+    assert torch.equal(sd[..., 0], sp[..., 0])                                   # counts
+    assert torch.allclose(sd[..., 1:], sp[..., 1:], rtol=2e-5, atol=1e-5)        # mean / M2: other merge order
+
+
 def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True, tol=2e-5):
     gen = torch.Generator().manual_seed(100 + cin + cout + dims[0])
     x = torch.randn((n, cin) + tuple(dims), generator=gen)

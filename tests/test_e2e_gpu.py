@@ -46,6 +46,47 @@ def test_bench_shaped_windows_vs_oracle():
     assert r["argmax_mismatch"] == 0 or r["max_margin_at_mismatch"] < 2 * ec.LOGIT_TOL, r
 
 
+def test_headline_many_windows_vs_oracle_192():
+    """The COMPLETE inferer on a volume with 27 windows of 96^3 (3 per axis, overlap 0.5, gaussian blend) -- the headline
+    configuration's window size, tile configurations and blend pattern, on the reference's synthetic CT volume
+    (create_test_image_3d, oracle/synthetic.py) -- product path vs the CPU oracle, with the parity rule of oracle/parity.py:
+    max |dlogit| <= 1e-4 and every argmax mismatch inside the oracle's own top-2 margin < 2 max|dlogit|."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from oracle import synthetic
+
+    net, sd = ec.make_net(1, 1, 5, DEV)
+    x = torch.from_numpy(synthetic.benchmark_volume(192))[None, None]
+    y = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)(x.to(DEV), net)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = osw.sliding_window_inference(x, (96, 96, 96), 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian")
+    rep = oracle.assert_label_parity(y, ref, tol=ec.LOGIT_TOL, what="192^3 / 27 windows of 96^3")
+    print(rep)
+
+
+def test_slice_inferer_and_adapt_on_device():
+    """SURVEY 8 row a9 on the MI355X: SliceInferer drives a 2-D predictor over every slice of a 3-D volume (one window per slice --
+    more than 160 windows on the slice axis), SlidingWindowInfererAdapt falls through to the plain inferer when nothing overflows."""
+    from monai_amd.inferers import SliceInferer, SlidingWindowInfererAdapt
+
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(1, 3, 3, padding=1).eval().to(DEV)
+    x = torch.rand(1, 1, 200, 40, 48, device=DEV)
+    with torch.no_grad():
+        for sd, roi in ((0, (40, 48)), (1, (200, 48)), (2, (200, 40))):
+            r = SliceInferer(roi_size=roi, spatial_dim=sd, sw_batch_size=16)(x, conv)
+            exp = torch.stack([conv(x.select(sd + 2, i)) for i in range(x.shape[sd + 2])], dim=sd + 2)
+            assert r.shape == exp.shape and float((r - exp).abs().max()) < 1e-5, (sd, float((r - exp).abs().max()))
+        # overlapping 2-D windows inside each slice: equals the reference blend of the same per-window predictions (CPU oracle)
+        r = SliceInferer(roi_size=(24, 32), spatial_dim=0, sw_batch_size=8, overlap=0.5, mode="gaussian")(x[:, :, :6], conv)
+        cpu_conv = torch.nn.Conv2d(1, 3, 3, padding=1).eval()
+        cpu_conv.load_state_dict({k: v.cpu() for k, v in conv.state_dict().items()})
+        ref = osw.sliding_window_inference(x[:, :, :6].cpu(), (1, 24, 32), 8, lambda w: cpu_conv(w.squeeze(2)).unsqueeze(2), overlap=0.5, mode="gaussian")
+        assert float((r.cpu() - ref).abs().max()) < 1e-5
+        a = SlidingWindowInfererAdapt((16, 16, 16), 4, overlap=0.25)(x[:, :, :32], lambda w: w * 2.0 + 1.0)
+        assert float((a - (x[:, :, :32] * 2.0 + 1.0)).abs().max()) < 1e-6 and a.is_cuda
+
+
 def test_fused_and_separate_instnorm_statistics_agree():
     net, _ = ec.make_net(1, 1, 5, DEV)
     torch.manual_seed(6)

@@ -149,6 +149,11 @@ def test_conv3d_wino2d(emu, cin, cout, dims, n):
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
+@pytest.mark.parametrize("cin,cout,dims,n", [(8, 16, (5, 16, 16), 2), (16, 32, (30, 10, 24), 1)])
+def test_conv3d_wino2d_two_implementations(emu, cin, cout, dims, n):
+    kc.case_wino2d_impls_agree("cpu", n, cin, cout, dims)
+
+
 SPLIT_CASES = [(16, 32, (4, 8, 8), 1), (32, 32, (8, 16, 8), 2), (48, 64, (4, 8, 16), 1), (16, 32, (12, 8, 8), 1), (32, 32, (16, 8, 16), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", SPLIT_CASES)
 def test_conv3d_split_precision(emu, cin, cout, dims, n):

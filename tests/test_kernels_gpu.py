@@ -139,6 +139,11 @@ def test_conv3d_wino2d(cin, cout, dims, n):
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
 
 
+@pytest.mark.parametrize("cin,cout,dims,n", [(8, 16, (5, 16, 16), 2), (16, 32, (30, 10, 24), 1), (32, 32, (96, 96, 96), 2), (64, 32, (48, 48, 48), 3)])
+def test_conv3d_wino2d_two_implementations(cin, cout, dims, n):
+    kc.case_wino2d_impls_agree(DEV, n, cin, cout, dims)
+
+
 SPLIT_CASES = [(16, 32, (4, 8, 8), 1), (32, 32, (8, 16, 8), 2), (48, 64, (4, 8, 16), 1), (16, 32, (12, 8, 8), 1), (32, 32, (16, 8, 16), 1), (32, 32, (48, 48, 48), 2), (64, 32, (24, 24, 24), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", SPLIT_CASES)
 def test_conv3d_split_precision(cin, cout, dims, n):

@@ -357,3 +357,27 @@ def test_preproc_oracle_vs_reference(golden_dir):
         assert np.array_equal(y.numpy(), gn[name]), name
     t = torch.arange(2 * 3 * 4 * 5, dtype=torch.float32).reshape(2, 3, 4, 5)
     assert torch.equal(op.flip_permute(t, [2, 0, 1], [True, False, True]), torch.flip(t, [1, 3]).permute(0, 3, 1, 2))
+
+
+def test_synthetic_ct_volume_matches_reference(golden_dir):
+    """oracle/synthetic.py restates monai/data/synthetic.py:97-170 (+ rescale_array, monai/transforms/utils.py:229-257): bit-identical
+    volumes and label maps for the seeded cases of tests/golden/make_golden_synthetic.py, and the 512^3 benchmark volume of SURVEY.md 8(d)
+    config 1 by digest."""
+    import hashlib
+
+    from oracle import synthetic
+
+    g = np.load(os.path.join(golden_dir, "synthetic.npz"))
+    for name, seed in (("a", 7), ("b", 7), ("c", 0)):
+        h, w, d, nobj, rmax, rmin, ncls = (int(v) for v in g[f"{name}_args"])
+        img, lab = synthetic.create_test_image_3d(h, w, d, num_objs=nobj, rad_max=rmax, rad_min=rmin, noise_max=float(g[f"{name}_noise"]),
+                                                  num_seg_classes=ncls, random_state=np.random.RandomState(seed))
+        assert img.dtype == np.float32 and np.array_equal(img, g[f"{name}_img"]), name
+        assert np.array_equal(lab, g[f"{name}_lab"].astype(np.int32)), name
+    small = synthetic.benchmark_volume(64)          # reduced-size bench / test volumes scale the sphere radii
+    assert small.shape == (64, 64, 64) and 0.0 == small.min() and small.max() == 1.0
+    vol = synthetic.benchmark_volume(512)
+    assert vol.shape == (512, 512, 512) and vol.dtype == np.float32
+    for idx, val in zip(g["bench_probe_idx"], g["bench_probe_val"]):
+        assert vol[tuple(idx)] == val
+    assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest() == bytes(g["bench_sha256"])

@@ -69,6 +69,21 @@ for g in (1, 2, 4, 8):
         res["runs"][-1]["bitwise_equal_to_round1"] = bool(torch.equal(out, ref))
 run("library default", {})
 res["runs"][-1]["bitwise_equal_to_round1"] = bool(torch.equal(out, ref))
+# padded window stride (floats between consecutive windows' logits): HBM channel spread.  Each variant twice, interleaved.
+dense = K * R ** 3
+padded = {}
+for pad in (0, 64, 1088, 16448, ((17 * 256 - dense * 4) % (1 << 17)) // 4):
+    ws = dense + pad
+    flat = torch.empty(nwin * ws, device=dev)
+    view = flat.as_strided(logits.shape, (ws,) + tuple(logits.stride()[1:]))
+    view.copy_(logits)
+    padded[pad] = (flat, view)
+for rep in range(2):
+    for pad, (flat, view) in padded.items():
+        out.zero_()
+        run(f"library default, window stride dense + {pad} floats (pass {rep})", {}, lambda: ops.sw_blend(view, imp, out, starts, (R,) * 3))
+        res["runs"][-1]["bitwise_equal_to_round1"] = bool(torch.equal(out, ref))
+del padded
 lab_ref = ref.argmax(0)
 for dt, nm in ((torch.float32, "float32"), (torch.uint8, "uint8")):
     lab = torch.empty((E, E, E), dtype=dt, device=dev)

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) write_k(f4* __restrict__ dst, long long n
 // window-cell (s x s x W bricks), so fewer distinct windows are live at once (TLB / DRAM page locality probe).
 template <int K, bool NT, int ORDER>
 __global__ void __launch_bounds__(256) blend_shape_k(const float* __restrict__ logits, float* __restrict__ out, int D, int H, int W, int r, int s,
-                                                     int n) {
+                                                     int n, long long kstride = 0, long long wstride = 0, long long ostride = 0) {
     const int wv = W / 4;
     long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     int x, y, z;
@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) blend_shape_k(const float* __restrict__ l
         if (h < l) h = l;
         lo[a] = l; hi[a] = h;
     }
-    const long long plane = (long long)r * r, roi = plane * r;
+    const long long plane = (long long)r * r, roi = kstride ? kstride : plane * r;
+    const long long wst = wstride ? wstride : K * roi;
     f4 acc[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) acc[k] = f4{0, 0, 0, 0};
@@ -122,7 +123,7 @@ __global__ void __launch_bounds__(256) blend_shape_k(const float* __restrict__ l
             for (int ix = lo[2]; ix <= hi[2]; ++ix) {
                 const int lx = x - (ix == n - 1 ? last : ix * s);
                 const long long w = ((long long)iz * n + iy) * n + ix;
-                const float* lp = logits + w * K * roi + lz * plane + (long long)ly * r + lx;
+                const float* lp = logits + w * wst + lz * plane + (long long)ly * r + lx;
                 f4 v[K];
 #pragma unroll
                 for (int k = 0; k < K; ++k) v[k] = NT ? __builtin_nontemporal_load(reinterpret_cast<const f4*>(lp + k * roi)) : *reinterpret_cast<const f4*>(lp + k * roi);
@@ -131,13 +132,28 @@ __global__ void __launch_bounds__(256) blend_shape_k(const float* __restrict__ l
             }
         }
     }
-    const long long vox = (long long)D * H * W;
+    const long long vox = ostride ? ostride : (long long)D * H * W;
     float* op = out + ((long long)z * H + y) * W + x;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (NT) __builtin_nontemporal_store(acc[k], reinterpret_cast<f4*>(op + k * vox));
         else *reinterpret_cast<f4*>(op + k * vox) = acc[k];
     }
+}
+
+// S streams `stride` bytes apart, read in lockstep: thread i reads 16 B at offset 16 i of every stream (the blend reads its 40
+// (window, class) streams like this: are strides that are multiples of a large power of two slower -- channel camping?)
+template <int S>
+__global__ void __launch_bounds__(256) strided_read_k(const char* __restrict__ base, long long stride, long long nvec, float* __restrict__ sink) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    f4 v[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) v[q] = *reinterpret_cast<const f4*>(base + q * stride + i * 16);
+    f4 a = v[0];
+#pragma unroll
+    for (int q = 1; q < S; ++q) a += v[q];
+    if (a[0] + a[1] + a[2] + a[3] == 12345.678f) sink[threadIdx.x] = 1.0f;
 }
 
 static double time_ms(hipEvent_t e0, hipEvent_t e1) { float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
@@ -179,6 +195,7 @@ int main() {
     const int D = 512, r = 96, s = 48, n = 10, K = 5;
     const long long roi = (long long)r * r * r, nlog = 1000LL * K * roi, nout = (long long)K * D * D * D;
     float *lg, *out;
+    CHECK(hipMalloc(&sink, 4096));
     CHECK(hipMalloc(&lg, nlog * 4)); CHECK(hipMalloc(&out, nout * 4));
     CHECK(hipMemset(lg, 0x3c, nlog * 4));
     const double bb = 4.0 * (nlog + nout);
@@ -190,5 +207,31 @@ int main() {
     RUN("blend shape (no weights), brick block order", bb, 5, (blend_shape_k<5, false, 1><<<nb1, 256>>>(lg, out, D, D, D, r, s, n)))
     RUN("blend shape (no weights), brick block order, non-temporal", bb, 5, (blend_shape_k<5, true, 1><<<nb1, 256>>>(lg, out, D, D, D, r, s, n)))
     CHECK(hipFree(lg)); CHECK(hipFree(out));
+
+    // stream-stride probes: 40 streams of 96 MB each
+    {
+        const long long per = 96LL << 20, nv = per / 16;
+        const long long strides[] = {per, per + 256, per + 4096 + 256, per + (1 << 16) + 256, per + (1 << 17)};
+        char* buf; CHECK(hipMalloc(&buf, 40 * (per + (1 << 17)) + (1 << 20))); CHECK(hipMemset(buf, 0x3c, 40 * (per + (1 << 17))));
+        for (long long st : strides) {
+            if (st < per) continue;
+            char nm[128]; snprintf(nm, sizeof nm, "40 lock-step read streams, stride %lld B (= 2^%d x %lld)", st, __builtin_ctzll(st), st >> __builtin_ctzll(st));
+            RUN(nm, 40.0 * per, 3, (strided_read_k<40><<<(unsigned)((nv + 255) / 256), 256>>>(buf, st, nv, sink)))
+        }
+        CHECK(hipFree(buf));
+    }
+    // the blend shape with padded strides: class stride roi + pad, window stride K * (roi + pad) + pad2, output channel stride vox + pad
+    {
+        const long long pads[][3] = {{0, 0, 0}, {0, 1088, 0}, {64, 1088, 0}, {1088, 1088, 0}, {0, 1088, 0}, {64, 1088, 0}, {1088, 1088, 0}, {0, 0, 0}};
+        for (auto& pd : pads) {
+            const long long ks = roi + pd[0], ws = K * ks + pd[1], os = (long long)D * D * D + pd[2];
+            float *lg2, *out2;
+            CHECK(hipMalloc(&lg2, 1000LL * ws * 4)); CHECK(hipMalloc(&out2, K * os * 4));
+            CHECK(hipMemset(lg2, 0x3c, 1000LL * ws * 4));
+            char nm[160]; snprintf(nm, sizeof nm, "blend shape, class stride roi+%lld, window stride +%lld, out channel stride +%lld floats", pd[0], pd[1], pd[2]);
+            RUN(nm, bb, 5, (blend_shape_k<5, false, 0><<<nb0, 256>>>(lg2, out2, D, D, D, r, s, n, ks, ws, os)))
+            CHECK(hipFree(lg2)); CHECK(hipFree(out2));
+        }
+    }
     return 0;
 }
