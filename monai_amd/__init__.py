@@ -5,3 +5,7 @@ Public names mirror the reference (`monai.inferers.SlidingWindowInferer`, `monai
 """
 
 __version__ = "0.1.0"
+
+from . import _fallback as _fallback  # noqa: E402
+
+_fallback.apply_all()      # every class falls through to the reference object of the same name for calls outside the HIP path (B3)

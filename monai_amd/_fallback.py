@@ -22,6 +22,8 @@ from __future__ import annotations
 
 import functools
 import importlib
+import os
+import threading
 import warnings
 
 __all__ = ["UnsupportedOnDevice", "reference_object", "reference_fallback", "function_fallback", "fell_through"]
@@ -41,7 +43,10 @@ def fell_through() -> list:
 
 
 def reference_object(ref_module: str, name: str):
-    """The reference's own ``ref_module.name`` (the displaced object when the patch is installed), or None without MONAI."""
+    """The reference's own ``ref_module.name`` (the displaced object when the patch is installed), or None without MONAI
+    (or when MONAI_AMD_NO_FALLTHROUGH=1 asks for the explicit errors: strict deployments, and the tests that pin them)."""
+    if os.environ.get("MONAI_AMD_NO_FALLTHROUGH") == "1":
+        return None
     try:
         from . import patch
 
@@ -90,42 +95,53 @@ def _share_module_state(src, dst) -> None:
     assert isinstance(dst, torch.nn.Module)
 
 
+_active = threading.local()       # ids of the instances whose wrapped method is running: only the OUTERMOST wrapper falls through
+
+
 def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_state: bool = False):
     """Class decorator: see the module docstring.  `methods` are wrapped for call-time fall-through; `share_state` (networks) makes
-    the twin share parameters / buffers and follow ``.training``."""
+    the twin share parameters / buffers and follow ``.training``.  An unsupported configuration turns the object under
+    construction into an instance of the reference class (``__class__`` assignment inside ``__init__``)."""
 
     def deco(cls):
-        orig_init = cls.__init__
         cls._mh_is_product = True
         cls._mh_ref = (ref_module, name)
 
-        def __new__(klass, *args, **kwargs):
-            self = object.__new__(klass)
-            if klass is not cls:                      # subclasses construct normally
-                return self
-            try:
-                orig_init(self, *args, **kwargs)
-            except NotImplementedError as e:
-                ref = reference_object(ref_module, name)
-                if ref is None:
-                    raise
-                _note(f"{name}(...)", e)
-                return ref(*args, **kwargs)
-            object.__setattr__(self, "_mh_ctor", (args, kwargs))
-            object.__setattr__(self, "_mh_init_done", True)
-            return self
+        orig_init = cls.__init__
 
         @functools.wraps(orig_init)
         def __init__(self, *args, **kwargs):
-            if self.__dict__.get("_mh_init_done"):
+            try:
+                orig_init(self, *args, **kwargs)
+            except NotImplementedError as e:
+                own = type(self).__dict__.get("_mh_ref")      # a user's subclass must not silently become the reference BASE class
+                ref = reference_object(*own) if own else None
+                if ref is None or not isinstance(ref, type):
+                    raise
+                _note(f"{own[1]}(...)", e)
+                # the object BECOMES an instance of the reference class, built from the same arguments (copy / pickle never come
+                # here); where the two classes' C layouts differ (__slots__ somewhere in the reference's bases) it becomes a proxy
+                # instead: every method and attribute goes to a reference instance held in `_mh_delegate`
+                self.__dict__.clear()
+                try:
+                    self.__class__ = ref
+                except TypeError:
+                    object.__setattr__(self, "_mh_delegate", ref(*args, **kwargs))
+                    return
+                ref.__init__(self, *args, **kwargs)
                 return
-            orig_init(self, *args, **kwargs)
-            object.__setattr__(self, "_mh_ctor", (args, kwargs))
+            if "_mh_ctor" not in self.__dict__:               # the outermost (most derived) constructor call wins
+                object.__setattr__(self, "_mh_ctor", (args, kwargs))
+
+        cls.__init__ = __init__
 
         def _mh_twin(self):
+            own = type(self).__dict__.get("_mh_ref")
+            if own is None:
+                return None
             twin = self.__dict__.get("_mh_twin_obj")
             if twin is None:
-                ref = reference_object(ref_module, name)
+                ref = reference_object(*own)
                 if ref is None:
                     return None
                 args, kwargs = self.__dict__.get("_mh_ctor", ((), {}))
@@ -135,13 +151,11 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                 object.__setattr__(self, "_mh_twin_obj", twin)
             if share_state:
                 twin.train(self.training)
-            else:                                     # transforms: keep the user-visible switches in step
-                for attr in ("lazy",):
-                    if attr in self.__dict__ or hasattr(type(self), attr):
-                        try:
-                            setattr(twin, attr, getattr(self, attr))
-                        except Exception:
-                            pass
+            elif "lazy" in self.__dict__ or hasattr(type(self), "lazy"):     # transforms: keep the user-visible switch in step
+                try:
+                    twin.lazy = self.lazy
+                except Exception:
+                    pass
             return twin
 
         def wrap(mname):
@@ -149,23 +163,63 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
 
             @functools.wraps(orig)
             def method(self, *args, **kwargs):
+                if "_mh_delegate" in self.__dict__:
+                    return getattr(self.__dict__["_mh_delegate"], mname)(*args, **kwargs)
+                stack = _active.__dict__.setdefault("ids", [])
+                outermost = id(self) not in stack
+                stack.append(id(self))
                 try:
                     return orig(self, *args, **kwargs)
                 except _FALLBACK_ERRORS as e:
+                    if not outermost:
+                        raise
                     twin = self._mh_twin()
                     if twin is None:
                         raise
-                    _note(f"{name}.{mname}", e)
-                    return getattr(twin, mname)(*args, **kwargs)
+                    _note(f"{type(self).__name__}.{mname}", e)
+                    err = e
+                finally:
+                    stack.pop()
+                del err
+                return getattr(twin, mname)(*args, **kwargs)
 
             return method
 
-        cls.__new__ = staticmethod(__new__)
-        cls.__init__ = __init__
         cls._mh_twin = _mh_twin
         for m in methods:
-            if hasattr(cls, m):
+            if m in cls.__dict__ or (hasattr(cls, m) and not getattr(getattr(cls, m), "__wrapped__", None)):
                 setattr(cls, m, wrap(m))
+        if not share_state and "__getattr__" not in cls.__dict__ and not any("__getattr__" in b.__dict__ for b in cls.__mro__[1:-1]):
+            import types
+
+            def delegating(fname, fn):
+                @functools.wraps(fn)
+                def method(self, *args, **kwargs):
+                    d = self.__dict__.get("_mh_delegate")
+                    return fn(self, *args, **kwargs) if d is None else getattr(d, fname)(*args, **kwargs)
+
+                return method
+
+            for fname, fn in list(cls.__dict__.items()):      # proxy mode: the class's other public methods go to the delegate too
+                if isinstance(fn, types.FunctionType) and not fname.startswith("_") and fname not in methods:
+                    setattr(cls, fname, delegating(fname, fn))
+
+            def __getattr__(self, attr):                      # only reached for attributes the (emptied) proxy does not have
+                d = self.__dict__.get("_mh_delegate")
+                if d is None or attr.startswith("__"):
+                    raise AttributeError(f"{type(self).__name__!r} object has no attribute {attr!r}")
+                return getattr(d, attr)
+
+            def __setattr__(self, attr, value):
+                d = self.__dict__.get("_mh_delegate")
+                if d is None:
+                    object.__setattr__(self, attr, value)
+                else:
+                    setattr(d, attr, value)
+
+            cls.__getattr__ = __getattr__
+            if "__setattr__" not in cls.__dict__:
+                cls.__setattr__ = __setattr__
         return cls
 
     return deco
@@ -191,3 +245,29 @@ def function_fallback(ref_module: str, name: str):
         return wrapper
 
     return deco
+
+
+def apply_all() -> None:
+    """Decorate every class / function `monai_amd.patch` can install with its fall-through to the reference object of the same
+    name (the table of `patch._TARGETS` is the single list of what this package stands in for).  Idempotent."""
+    import inspect
+
+    from . import patch
+
+    seen = set()
+    for ref_mod, names in patch._TARGETS.items():
+        for name, (our_mod, our_name) in names.items():
+            mod = importlib.import_module(our_mod)
+            obj = getattr(mod, our_name)
+            if id(obj) in seen or getattr(obj, "_mh_ref", None) is not None:
+                seen.add(id(obj))
+                continue
+            seen.add(id(obj))
+            if inspect.isclass(obj):
+                is_module = any(b.__name__ == "Module" and b.__module__.startswith("torch.nn") for b in obj.__mro__)
+                if is_module:
+                    reference_fallback(ref_mod, name, methods=("forward",), share_state=True)(obj)
+                else:
+                    methods = tuple(m for m in ("__call__", "inverse", "aggregate", "finalize") if callable(getattr(obj, m, None)))
+                    reference_fallback(ref_mod, name, methods=methods)(obj)
+            # plain functions are decorated where they are defined (other modules hold direct references to them)

@@ -15,6 +15,8 @@ from typing import Optional, Sequence
 
 import torch
 
+from ._fallback import UnsupportedOnDevice
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmonai_amd.so")
 
@@ -144,12 +146,12 @@ def require_device(*tensors: torch.Tensor, dtypes=(torch.float32,)) -> None:
         if t is None:
             continue
         if not t.is_cuda:
-            raise RuntimeError(
+            raise UnsupportedOnDevice(
                 "monai_amd: this path runs only on an MI355X (ROCm) device tensor; got a CPU tensor. "
                 "There is no CPU fallback in the product path."
             )
         if t.dtype not in dtypes:
-            raise RuntimeError(f"monai_amd: dtype {t.dtype} is not accepted on this path (expected one of {dtypes})")
+            raise UnsupportedOnDevice(f"monai_amd: dtype {t.dtype} is not accepted on this path (expected one of {dtypes})")
 
 
 def stream_ptr(t: torch.Tensor) -> C.c_void_p:

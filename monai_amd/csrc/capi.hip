@@ -13,6 +13,7 @@
 #include "kernels/conv3d_winograd.h"
 #include "kernels/conv3d_wino2d.h"
 #include "kernels/conv3d_wino2p.h"
+#include "kernels/conv3d_wino2s.h"
 #include "kernels/conv3d_split.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
@@ -462,11 +463,21 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const long long total = (long long)nblk * (out.C / W2_CN) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
-        // two implementations of the same configuration (same packing, statistics records and launch geometry):
-        // conv3d_wino2p.h -- two 256-register waves per SIMD, the Winograd positions split over the pair -- and the round-1
-        // kernel with one 384-register wave per SIMD (MONAI_AMD_W2_IMPL=d)
+        // three implementations of the same configuration (same packing, statistics records and launch geometry, bit-identical
+        // convolution values), MONAI_AMD_W2_IMPL = p | s | d (measured at 32 -> 32 ch, 96^3, 64 windows: profiles/r02_wino2_impls.json):
+        //   p (default) conv3d_wino2p.h -- two 256-register waves per SIMD, the Winograd positions split over the pair: 17.7-17.9 ms
+        //   s           conv3d_wino2s.h -- one matrix wave + one staging wave per SIMD: 18.8 ms (a staging wave gets one VALU
+        //                                  instruction per gap of the matrix wave's MFMA stream: it becomes the critical path)
+        //   d           conv3d_wino2d.h -- round 1, one 384-register wave per SIMD: 18.7-18.9 ms
         const char* impl = getenv("MONAI_AMD_W2_IMPL");
-        if (!(impl && impl[0] == 'd')) {
+        if (impl && impl[0] == 's') {        // conv3d_wino2s.h: one matrix wave + one staging wave per SIMD
+            if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            else hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<false, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+            return launched("conv3d_k3_wino2s");
+        }
+        if (!impl || impl[0] != 'd') {
             if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
             else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
             else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);

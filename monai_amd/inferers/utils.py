@@ -26,6 +26,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import _lib, _prof, ops, parallel
+from .._fallback import function_fallback
 from ..data.utils import compute_importance_map, get_valid_patch_size, window_starts
 from ..utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple, look_up_option
 
@@ -110,6 +111,7 @@ def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world
     return cap
 
 
+@function_fallback("monai.inferers.utils", "sliding_window_inference")
 def sliding_window_inference(
     inputs: torch.Tensor,
     roi_size: Sequence[int] | int,

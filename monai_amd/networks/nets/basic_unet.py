@@ -156,6 +156,8 @@ class BasicUNet(nn.Module):
     # ---- forward ---------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """``(B, in_channels, D, H, W)`` -> raw predictions ``(B, out_channels, D, H, W)`` (basic_unet.py:254-279)."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("monai_amd.BasicUNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
         _lib.require_device(x)
         if x.dim() != 5 or x.shape[1] != self.in_channels:
             raise RuntimeError(f"monai_amd.BasicUNet: expected input (B,{self.in_channels},D,H,W), got {tuple(x.shape)}")
@@ -167,7 +169,7 @@ class BasicUNet(nn.Module):
         """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
         _lib.require_device(x, out)
         if self.training:
-            raise RuntimeError("monai_amd.BasicUNet is an inference engine: call .eval() first")
+            raise NotImplementedError("monai_amd.BasicUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         x = x.contiguous()
         n, _, d, h, w = x.shape
         if min(d, h, w) < 16:

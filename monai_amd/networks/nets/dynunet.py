@@ -305,6 +305,8 @@ class DynUNet(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("monai_amd.DynUNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
         sp = _out_size(x.shape[2:], self._strides[0])
         out = torch.empty((x.shape[0], self.out_channels) + sp, dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
@@ -313,7 +315,7 @@ class DynUNet(nn.Module):
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.require_device(x, out)
         if self.training:
-            raise RuntimeError("monai_amd.DynUNet is an inference engine: call .eval() first")
+            raise NotImplementedError("monai_amd.DynUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         total = [1, 1, 1]
         for st in self._strides:
             total = [a * b for a, b in zip(total, st)]

@@ -190,6 +190,8 @@ class SegResNet(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("monai_amd.SegResNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
         c = self.out_channels if self.use_conv_final else self.init_filters
         out = torch.empty((x.shape[0], c) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
@@ -198,7 +200,7 @@ class SegResNet(nn.Module):
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.require_device(x, out)
         if self.training:
-            raise RuntimeError("monai_amd.SegResNet is an inference engine: call .eval() first")
+            raise NotImplementedError("monai_amd.SegResNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         total = 2 ** (len(self.blocks_down) - 1)
         if x.dim() != 5 or x.shape[1] != self.in_channels or any(int(v) % total for v in x.shape[2:]):
             raise NotImplementedError(f"monai_amd.SegResNet: input (B,{self.in_channels},D,H,W) with edges divisible by {total} expected, got {tuple(x.shape)}")

@@ -288,6 +288,8 @@ class UNet(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("monai_amd.UNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
         out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
 
@@ -295,7 +297,7 @@ class UNet(nn.Module):
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.require_device(x, out)
         if self.training:
-            raise RuntimeError("monai_amd.UNet is an inference engine: call .eval() first")
+            raise NotImplementedError("monai_amd.UNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         total = 1
         for s in self.strides[: len(self.channels) - 1]:
             total *= s

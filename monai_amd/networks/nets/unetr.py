@@ -283,6 +283,8 @@ class UNETR(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x_in: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x_in.requires_grad:
+            raise NotImplementedError("monai_amd.UNETR: gradients w.r.t. the input are not on the (inference-only) HIP path")
         out = torch.empty((x_in.shape[0], self.out_channels) + tuple(x_in.shape[2:]), dtype=torch.float32, device=x_in.device)
         return self.forward_into(x_in, out)
 
@@ -290,7 +292,7 @@ class UNETR(nn.Module):
     def forward_into(self, x_in: torch.Tensor, logits: torch.Tensor) -> torch.Tensor:
         _lib.require_device(x_in, logits)
         if self.training:
-            raise RuntimeError("monai_amd.UNETR is an inference engine: call .eval() first")
+            raise NotImplementedError("monai_amd.UNETR: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         if tuple(x_in.shape[2:]) != self.img_size or x_in.shape[1] != self.in_channels:
             raise RuntimeError(f"monai_amd.UNETR: expected input (B,{self.in_channels},{self.img_size}), got {tuple(x_in.shape)}")
         x_in = x_in.contiguous()

@@ -15,6 +15,16 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fallthrough: the test exercises the fall-through to an importable reference MONAI (monai_amd/_fallback.py)")
+
+
+@pytest.fixture(autouse=True)
+def _explicit_errors_unless_asked(request, monkeypatch):
+    """Tests pin the explicit `NotImplementedError` / `RuntimeError` of calls outside the HIP path; once another test of the same
+    worker process has imported the reference MONAI those calls would fall through to it instead -- only the tests marked
+    `fallthrough` want that."""
+    if "fallthrough" not in request.keywords:
+        monkeypatch.setenv("MONAI_AMD_NO_FALLTHROUGH", "1")
 
 
 @pytest.fixture(scope="session")

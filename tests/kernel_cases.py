@@ -151,8 +151,9 @@ def case_sw_blend_many_windows(device, slices=170):
 
 # ------------------------------------------------------------------------------------------ network blocks
 def case_wino2d_impls_agree(device, n, cin, cout, dims):
-    """conv3d_wino2p.h (two waves per SIMD, Winograd positions split over a wave pair) performs the operations of
-    conv3d_wino2d.h in the same order: the convolution values of the two implementations are bit-identical."""
+    """conv3d_wino2s.h (matrix wave + staging wave per SIMD, the default) and conv3d_wino2p.h (two identical waves per SIMD, the
+    Winograd positions split over the pair) perform the operations of conv3d_wino2d.h in the same order: the convolution values of
+    the three implementations are bit-identical."""
     import os
 
     gen = torch.Generator().manual_seed(300 + cin + cout + dims[0])
@@ -166,7 +167,7 @@ def case_wino2d_impls_agree(device, n, cin, cout, dims):
     res = {}
     saved = os.environ.get("MONAI_AMD_W2_IMPL")
     try:
-        for impl in ("d", "p"):
+        for impl in ("d", "p", "s"):
             os.environ["MONAI_AMD_W2_IMPL"] = impl
             out = torch.full((n, cout) + tuple(dims), float("nan"), device=device)
             stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
@@ -178,6 +179,8 @@ def case_wino2d_impls_agree(device, n, cin, cout, dims):
         else:
             os.environ["MONAI_AMD_W2_IMPL"] = saved
     assert torch.equal(res["d"][0], res["p"][0]), f"max diff {(res['d'][0] - res['p'][0]).abs().max().item()}"
+    assert torch.equal(res["d"][0], res["s"][0]), f"max diff {(res['d'][0] - res['s'][0]).abs().max().item()}"
+    assert torch.equal(res["d"][1], res["s"][1])                                 # the specialised kernel reduces exactly like the round-1 kernel
     sd, sp = res["d"][1], res["p"][1]
     assert torch.equal(sd[..., 0], sp[..., 0])                                   # counts
     assert torch.allclose(sd[..., 1:], sp[..., 1:], rtol=2e-5, atol=1e-5)        # mean / M2: other merge order

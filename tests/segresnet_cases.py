@@ -91,7 +91,7 @@ def case_segresnet_api(device):
     with pytest.raises(NotImplementedError):
         SegResNet(upsample_mode="pixelshuffle")
     net = SegResNet()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(NotImplementedError):
         net(torch.zeros(1, 1, 8, 8, 8, device=device))
     with pytest.raises(NotImplementedError):
         net.eval().to(device)(torch.zeros(1, 1, 12, 8, 8, device=device))

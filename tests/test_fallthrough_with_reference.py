@@ -1,0 +1,156 @@
+"""SURVEY.md 8b, boundary B3: after ``monai_amd.patch.install()`` no call that is valid with the unpatched reference may fail.
+The argument matrices of the reference's own tests -- tests/networks/nets/test_basic_unet.py:23-84 (1-D / 2-D / 3-D, every
+up-sampling mode), tests/inferers/test_sliding_window_inference.py (device / cpu cases, positional call :280-300),
+tests/networks/nets/test_unet.py / test_segresnet.py / test_dynunet.py style configurations, Resample spline orders, lazy=True --
+run over the PATCHED names on CPU tensors (no GPU here: every call is outside the HIP path and has to fall through to the
+displaced reference objects, monai_amd/_fallback.py), and are compared with the unpatched reference's results.
+Only where /root/reference exists (the build container)."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = [pytest.mark.fallthrough, pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "monai")), reason="reference MONAI not available here")]
+
+CASES_1D = [[{"spatial_dims": 1, "in_channels": 5, "out_channels": 8, **({"upsample": m} if m else {})}, (10, 5, 33), (10, 8, 33)]
+            for m in ["pixelshuffle", "nontrainable", "deconv", None]]
+CASES_2D = [[{"spatial_dims": 2, "in_channels": 2, "out_channels": 3, "features": (12, 12, 13, 14, 15, 16), "upsample": m}, (2, 2, d1, d2), (2, 3, d1, d2)]
+            for m in ["pixelshuffle", "nontrainable", "deconv"] for d1 in range(33, 64, 14) for d2 in range(63, 33, -21)]
+CASES_3D = [
+    [{"spatial_dims": 3, "in_channels": 1, "out_channels": 2, "features": (16, 20, 21, 22, 23, 11), "upsample": "pixelshuffle"}, (2, 1, 33, 34, 35), (2, 2, 33, 34, 35)],
+    [{"spatial_dims": 3, "in_channels": 2, "out_channels": 7, "features": (14, 15, 16, 17, 18, 11), "upsample": "deconv"}, (3, 2, 33, 37, 34), (3, 7, 33, 37, 34)],
+    [{"spatial_dims": 3, "in_channels": 4, "out_channels": 2, "features": (14, 15, 16, 17, 18, 10), "upsample": "nontrainable"}, (5, 4, 34, 35, 37), (5, 2, 34, 35, 37)],
+]
+
+
+@pytest.fixture()
+def patched():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import monai
+    import monai_amd.patch as patch
+
+    ref = {"BasicUNet": monai.networks.nets.BasicUNet, "swi": monai.inferers.utils.sliding_window_inference}
+    patch.install()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        yield monai, ref
+    patch.uninstall()
+    sys.path.remove(REF)
+
+
+@pytest.mark.parametrize("kwargs,in_shape,out_shape", CASES_1D + CASES_2D[::3] + CASES_3D)
+def test_basic_unet_argument_matrix(patched, kwargs, in_shape, out_shape):
+    """tests/networks/nets/test_basic_unet.py:86-95 (`test_shape`) over the patched name, plus equality with the displaced class."""
+    monai, ref = patched
+    from monai.networks import eval_mode
+    from monai.networks.nets import BasicUNet          # the MI355X class after install()
+
+    assert getattr(BasicUNet, "_mh_is_product", False)
+    torch.manual_seed(3)
+    net = BasicUNet(**kwargs)
+    torch.manual_seed(3)
+    ref_net = ref["BasicUNet"](**kwargs)
+    x = torch.randn(in_shape)
+    with eval_mode(net), eval_mode(ref_net):
+        y, y_ref = net(x), ref_net(x)
+    assert tuple(y.shape) == out_shape
+    assert torch.equal(y, y_ref)                         # same seed -> same initial weights -> the same reference arithmetic
+
+
+def test_training_step_through_the_shared_parameters(patched):
+    monai, _ = patched
+    from monai.networks.nets import BasicUNet, SegResNet, UNet
+
+    for net in (BasicUNet(spatial_dims=3, in_channels=1, out_channels=2, features=(8, 8, 16, 16, 32, 8)),
+                UNet(spatial_dims=3, in_channels=1, out_channels=2, channels=(4, 8, 16), strides=(2, 2), num_res_units=1),
+                SegResNet(spatial_dims=3, init_filters=8, in_channels=1, out_channels=2)):
+        assert getattr(type(net), "_mh_is_product", False)
+        net.train()
+        opt = torch.optim.SGD(net.parameters(), lr=0.1)
+        before = [p.detach().clone() for p in net.parameters()]
+        loss = net(torch.rand(2, 1, 32, 32, 32)).square().mean()
+        loss.backward()
+        opt.step()
+        assert any(not torch.equal(a, b) for a, b in zip(before, net.parameters())), type(net).__name__
+        # state_dict still the reference's layout, loadable into a fresh reference module
+        fresh = type(net._mh_twin())(*net._mh_ctor[0], **net._mh_ctor[1])
+        fresh.load_state_dict(net.state_dict(), strict=True)
+
+
+def test_sliding_window_cpu_cases(patched):
+    """tests/inferers/test_sliding_window_inference.py: cpu tensors, sw_device / device arguments, the fully positional call (:280-300),
+    SlidingWindowInfererAdapt, SliceInferer with a 2-D network -- valid reference calls, outside the HIP path."""
+    monai, ref = patched
+    from monai.inferers import SliceInferer, SlidingWindowInferer, SlidingWindowInfererAdapt, sliding_window_inference
+    from monai.networks.nets import BasicUNet
+
+    inputs = torch.ones((1, 1, 3, 3))
+    t1, t2 = torch.ones(1), torch.ones(1)
+
+    def compute(data, test1, test2):
+        return data + test1 + test2
+
+    r = sliding_window_inference(inputs, (5, 5), 10, compute, 0.5, "constant", 1.0, "constant", 0.0, "cpu:0", "cpu:0", False, None, None, None, 0, False, t1, test2=t2)
+    np.testing.assert_allclose(r.numpy(), np.ones((1, 1, 3, 3)) + 2.0, rtol=1e-4)
+    for cls in (SlidingWindowInferer, SlidingWindowInfererAdapt):
+        r = cls((5, 5), 10, overlap=0.5, mode="constant", cval=-1)(inputs, compute, t1, test2=t2)
+        np.testing.assert_allclose(r.numpy(), np.ones((1, 1, 3, 3)) + 2.0, rtol=1e-4)
+    # random volume, gaussian mode, equality with the displaced function
+    torch.manual_seed(0)
+    vol = torch.rand(1, 1, 20, 24, 28)
+    a = sliding_window_inference(vol, (8, 12, 16), 3, lambda w: w * 3 + 1, overlap=0.5, mode="gaussian")
+    b = ref["swi"](vol, (8, 12, 16), 3, lambda w: w * 3 + 1, overlap=0.5, mode="gaussian")
+    assert torch.equal(a, b)
+    # half / double precision volumes (the reference computes in the input dtype)
+    for dt in (torch.float64, torch.float16):
+        out = sliding_window_inference(vol.to(dt), (8, 12, 16), 3, lambda w: w + 1, overlap=0.25)
+        assert out.dtype == dt
+    # a 2-D network over a 3-D volume (tests/inferers/test_slice_inferer.py): BasicUNet(spatial_dims=2) is outside the HIP path
+    net2d = BasicUNet(spatial_dims=2, in_channels=1, out_channels=2, features=(4, 4, 8, 8, 16, 4)).eval()
+    with torch.no_grad():
+        s = SliceInferer(roi_size=(32, 32), spatial_dim=2, sw_batch_size=4)(torch.rand(1, 1, 32, 32, 6), net2d)
+    assert tuple(s.shape) == (1, 2, 32, 32, 6)
+
+
+def test_transform_options_outside_the_hip_path(patched):
+    monai, _ = patched
+    from monai.data import MetaTensor
+    from monai.transforms import GaussianSmooth, Resample, ScaleIntensityRanged, Spacing, Spacingd
+    from monai.transforms.utils import create_grid
+
+    img = MetaTensor(torch.rand(1, 12, 14, 16), affine=torch.diag(torch.tensor([2.0, 2.0, 2.0, 1.0])))
+    # numpy / cpu inputs
+    assert GaussianSmooth(sigma=1.0)(np.random.rand(1, 8, 8, 8).astype(np.float32)).shape == (1, 8, 8, 8)
+    out = Spacing(pixdim=(1.0, 1.0, 1.0), mode="bilinear")(img)
+    assert tuple(out.shape) == (1, 23, 27, 31)
+    # spline interpolation orders (scipy branch of the reference, monai/transforms/spatial/array.py:2092-2100)
+    grid = create_grid((12, 14, 16), backend="torch")
+    r = Resample(mode=3, padding_mode="nearest")(img, grid=grid)
+    assert tuple(r.shape) == (1, 12, 14, 16)
+    # lazy resampling: pending operations recorded, nothing resampled yet (monai/transforms/lazy)
+    lz = Spacingd(keys="image", pixdim=(1.0, 1.0, 1.0), lazy=True)({"image": img})["image"]
+    assert len(lz.pending_operations) == 1 and tuple(lz.shape) == (1, 12, 14, 16)
+    # float64 image
+    d = ScaleIntensityRanged(keys="image", a_min=0.0, a_max=1.0, b_min=0.0, b_max=2.0)({"image": img.to(torch.float64)})["image"]
+    assert d.dtype == torch.float32 or d.dtype == torch.float64
+
+
+def test_no_monai_keeps_the_explicit_error():
+    """Without MONAI on the path nothing can be delegated: the original explicit error is raised."""
+    for m in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]:
+        del sys.modules[m]
+    import monai_amd._fallback as fb
+    from monai_amd.networks.nets import BasicUNet
+
+    if REF in sys.path:
+        sys.path.remove(REF)
+    assert fb.reference_object("monai.networks.nets.basic_unet", "BasicUNet") is None
+    with pytest.raises(NotImplementedError):
+        BasicUNet(spatial_dims=2)
+    with pytest.raises(RuntimeError):
+        BasicUNet(spatial_dims=3).eval()(torch.rand(1, 1, 32, 32, 32))
