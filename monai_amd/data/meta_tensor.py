@@ -56,16 +56,63 @@ class MetaTensor(torch.Tensor):
     def as_tensor(self) -> torch.Tensor:
         return self.as_subclass(torch.Tensor)
 
+    # -- pending (lazy) operations: monai/data/meta_obj.py:214-232, meta_tensor.py:470-509 -------------------------------------
+    @property
+    def pending_operations(self) -> list:
+        ops = self.__dict__.get("_pending_operations")
+        if ops is None:
+            ops = self.__dict__["_pending_operations"] = []
+        return ops
+
+    @property
+    def has_pending_operations(self) -> bool:
+        return len(self.pending_operations) > 0
+
+    def push_pending_operation(self, t) -> None:
+        self.pending_operations.append(t)
+
+    def pop_pending_operation(self):
+        return self.pending_operations.pop()
+
+    def clear_pending_operations(self) -> None:
+        self.__dict__["_pending_operations"] = []
+
+    def push_applied_operation(self, t) -> None:
+        self.applied_operations.append(t)
+
     def peek_pending_shape(self):
-        return tuple(self.shape[1:])
+        """spatial shape after the pending operations (the last one's ``lazy_shape``), monai/data/meta_tensor.py:470-480"""
+        pend = self.pending_operations
+        res = pend[-1].get("lazy_shape") if pend else None
+        return tuple(int(v) for v in self.shape[1:]) if res is None else tuple(int(v) for v in res)
 
     def peek_pending_affine(self):
-        return self.affine
+        """affine after the pending operations: ``affine @ A_1 @ A_2 ...`` (meta_tensor.py:482-497)"""
+        res = self.affine.double()
+        r = len(res) - 1
+        for p in self.pending_operations:
+            nxt = p.get("lazy_affine")
+            if nxt is None:
+                continue
+            nxt = torch.as_tensor(nxt, dtype=torch.float64)
+            if nxt.shape[0] - 1 != r:       # to_affine_nd: embed / crop to rank r
+                full = torch.eye(r + 1, dtype=torch.float64)
+                d = min(r, nxt.shape[0] - 1)
+                full[:d, :d] = nxt[:d, :d]
+                full[:d, -1] = nxt[:d, -1]
+                nxt = full
+            res = res @ nxt
+        return res
+
+    def peek_pending_rank(self) -> int:
+        a = self.pending_operations[-1].get("lazy_affine") if self.pending_operations else self.affine
+        return 1 if a is None else int(max(1, len(a) - 1))
 
     def copy_meta_from(self, src, copy_attr: bool = True, keys=None):
         self.meta = copy.deepcopy(getattr(src, "meta", {})) if copy_attr else dict(getattr(src, "meta", {}))
         ops = getattr(src, "applied_operations", [])
         self.applied_operations = copy.deepcopy(ops) if copy_attr else list(ops)
+        self.__dict__["_pending_operations"] = list(getattr(src, "pending_operations", []))
         return self
 
     def __repr__(self, **kw):  # pragma: no cover
@@ -79,6 +126,7 @@ class MetaTensor(torch.Tensor):
             if first is not None:
                 ret.meta = dict(first.meta)
                 ret.applied_operations = list(first.applied_operations)
+                ret.__dict__["_pending_operations"] = list(first.pending_operations)
             else:
                 ret.meta, ret.applied_operations = {"affine": torch.eye(4, dtype=torch.float64)}, []
         return ret

@@ -266,6 +266,25 @@ class SlidingWindowInferer(Inferer):
         )
 
 
+    def argmax(self, inputs: torch.Tensor, network: Callable, *args: Any, labels_dtype=torch.float32, **kwargs: Any):
+        """``AsDiscrete(argmax=True)(self(inputs, network))`` per batch element with the argmax fused into the blend epilogue
+        (``monai_amd.inferers.utils.sliding_window_argmax``): returns ``[B, 1, *spatial]`` labels, never writes the logits volume."""
+        return self.__call__(inputs, network, *args, _monai_amd_argmax=labels_dtype, **kwargs)
+
+
+class SlidingWindowArgmaxInferer(SlidingWindowInferer):
+    """A ``SlidingWindowInferer`` whose result is the label map: ``"_target_": "monai_amd.inferers.SlidingWindowArgmaxInferer"`` in a
+    bundle replaces the pair (SlidingWindowInferer, AsDiscreted(argmax=True)) -- same constructor arguments plus ``labels_dtype``."""
+
+    def __init__(self, *args: Any, labels_dtype=torch.float32, **kwargs: Any) -> None:
+        super().__init__(*args, **kwargs)
+        self.labels_dtype = labels_dtype
+
+    def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
+        kwargs.setdefault("_monai_amd_argmax", self.labels_dtype)
+        return super().__call__(inputs, network, *args, **kwargs)
+
+
 class SlidingWindowInfererAdapt(SlidingWindowInferer):
     """``SlidingWindowInferer`` that survives an HBM out-of-memory error (reference: inferer.py:555-641).
 

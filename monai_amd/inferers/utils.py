@@ -30,7 +30,7 @@ from .._fallback import function_fallback
 from ..data.utils import compute_importance_map, get_valid_patch_size, window_starts
 from ..utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple, look_up_option
 
-__all__ = ["sliding_window_inference"]
+__all__ = ["sliding_window_inference", "sliding_window_argmax"]
 
 _PAD_MODES = ("constant", "reflect", "replicate", "circular")
 _NEAREST = "nearest-exact"
@@ -181,10 +181,11 @@ def sliding_window_inference(
         num_win *= len(s)
 
     # all-window logits that do not fit in HBM: slab by slab along the first spatial axis (see _slabwise)
+    argmax_dtype = kwargs.pop("_monai_amd_argmax", None)      # fused AsDiscrete(argmax=True) epilogue (sliding_window_argmax below)
     slab_ok = (not kwargs.pop("_monai_amd_no_slabs", False) and not with_coord and process_fn is None and not any(pad_size)
                and len(starts[0]) > 1 and parallel.window_shard(num_win).world == 1)
     if slab_ok:
-        sub_kwargs = dict(kwargs, _monai_amd_no_slabs=True)
+        sub_kwargs = dict(kwargs, _monai_amd_no_slabs=True, _monai_amd_argmax=argmax_dtype)
 
         def _whole(x):
             return sliding_window_inference(x, roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, sw_device,
@@ -330,15 +331,21 @@ def sliding_window_inference(
             outputs = []
             for lg, z in zip(gathered, zscales):
                 osz = [int(i * zz) for i, zz in zip(image_size, z)] if z else list(image_size)
-                outputs.append(torch.empty((batch_size, lg.shape[1]) + _to3(osz, 1), dtype=compute_dtype, device=dev))
+                if argmax_dtype is not None:       # only the label map is ever written: [B, 1, ...]
+                    outputs.append(torch.empty((batch_size, 1) + _to3(osz, 1), dtype=argmax_dtype, device=dev))
+                else:
+                    outputs.append(torch.empty((batch_size, lg.shape[1]) + _to3(osz, 1), dtype=compute_dtype, device=dev))
         for ss, (lg, z) in enumerate(zip(gathered, zscales)):
             if z is None:
                 g = grid3
             else:
                 g = [[0]] * (3 - num_spatial_dims) + [[int(s * zz) for s in ax] for ax, zz in zip(starts, z)]
-            nbytes = 4.0 * (lg[:num_win].numel() + outputs[ss][b].numel())  # logits read once + output written once
+            nbytes = 4.0 * lg[:num_win].numel() + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
-                if proc_weights is not None:
+                if argmax_dtype is not None:
+                    _blend_argmax(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b, 0], g,
+                                  _to3(seg_shapes[ss], 1), premultiplied=proc_weights is not None)
+                elif proc_weights is not None:
                     ops.sw_blend(lg[:num_win], proc_weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1), premultiplied=True)
                 else:
                     ops.sw_blend(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1))
@@ -398,6 +405,32 @@ def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
         raise _LogitsDoNotFit(need, limit)
     flat = torch.empty(rows * ws, dtype=dtype, device=dev)
     return flat.as_strided((rows, k) + tuple(seg3), (ws, seg3[0] * seg3[1] * seg3[2], seg3[1] * seg3[2], seg3[2], 1))
+
+
+def _blend_argmax(logits, imp, labels, grid, seg3, premultiplied: bool) -> None:
+    """labels [D, H, W] = argmax over the classes of the blended logits, in ONE pass when the window grid has
+    dense_patch_slices' regular form (mh_sw_blend_argmax_f32); otherwise blend, then the channel argmax kernel."""
+    try:
+        ops.sw_blend_argmax(logits, imp, labels, grid, seg3, int(logits.shape[1]), premultiplied=premultiplied)
+    except RuntimeError as e:
+        if "irregular window starts" not in str(e):
+            raise
+        tmp = torch.empty((int(logits.shape[1]),) + tuple(labels.shape), dtype=logits.dtype, device=logits.device)
+        ops.sw_blend(logits, imp, tmp, grid, seg3, premultiplied=premultiplied)
+        labels.copy_(ops.channel_reduce("argmax", tmp)[0].to(labels.dtype))
+
+
+def sliding_window_argmax(inputs, roi_size, sw_batch_size, predictor, *args, labels_dtype=torch.float32, **kwargs):
+    """``sliding_window_inference`` followed by ``AsDiscrete(argmax=True)`` -- the post-processing step segmentation bundles put
+    behind the inferer (monai/transforms/post/array.py:132-237: ``torch.argmax(img, dim=0, keepdim=True)`` converted to float32)
+    -- with the argmax fused into the blend's epilogue: every voxel's K blended values are formed in registers exactly as the
+    blend forms them and only the label is written (K x 4 B of output traffic per voxel -> 4 B, or 1 B with
+    ``labels_dtype=torch.uint8``).  Same positional / keyword arguments as ``sliding_window_inference``; returns
+    ``[B, 1, *spatial]`` labels (tuple / dict outputs: one label map per output), bit-identical to
+    ``AsDiscrete(argmax=True)`` applied to each batch element of the unfused result (ties -> first index, NaN maximal)."""
+    if labels_dtype not in (torch.float32, torch.uint8):
+        raise ValueError("sliding_window_argmax: labels_dtype must be torch.float32 (AsDiscrete's output dtype) or torch.uint8")
+    return sliding_window_inference(inputs, roi_size, sw_batch_size, predictor, *args, _monai_amd_argmax=labels_dtype, **kwargs)
 
 
 def flat_rows(logits: torch.Tensor, r0: int, r1: int) -> torch.Tensor:

@@ -172,6 +172,22 @@ def _register_transform_traits() -> None:
                 MapTransform.register(cls)
             if callable(getattr(cls, "inverse", None)):
                 InvertibleTransform.register(cls)
+    # lazy resampling: `Compose(..., lazy=True)` asks `isinstance(t, LazyTrait)` (monai/transforms/lazy/functional.py:185-188,
+    # monai/transforms/transform.py:90-134) -- LazyTrait is a plain class, so it becomes a real base of the lazy-capable mixin --
+    # and executes pending operations through `resample` (monai/transforms/lazy/utils.py:148-229), rebound to the fused kernel path
+    from monai.transforms.traits import LazyTrait
+
+    from .transforms import lazy as _lazy
+
+    if LazyTrait not in _lazy.LazyCapable.__bases__:
+        _lazy.LazyCapable.__bases__ = _lazy.LazyCapable.__bases__ + (LazyTrait,)
+    import monai.transforms.lazy.functional as _lf
+    import monai.transforms.lazy.utils as _lu
+
+    for mod in (_lf, _lu):
+        if ("lazy", mod.__name__) not in _installed:
+            _installed[("lazy", mod.__name__)] = mod.resample
+        mod.resample = _lazy.resample
     from monai.inferers import Inferer          # an ABC as well: `isinstance(x, Inferer)` checks in user code keep holding
 
     for our_mod_name, our_name in set(_TARGETS["monai.inferers.inferer"].values()):
@@ -184,6 +200,15 @@ def uninstall() -> None:
         mod = sys.modules.get(mod_name)
         if mod is not None and obj is not None:
             setattr(mod, name, obj)
+    for (kind, mod_name), obj in list(_installed.items()):
+        if kind == "lazy" and sys.modules.get(mod_name) is not None:
+            sys.modules[mod_name].resample = obj
     _installed.clear()
+    try:
+        from .transforms import lazy as _lazy
+
+        _lazy.LazyCapable.__bases__ = (_lazy._Root,)
+    except Exception:
+        pass
     if sys.modules.get("monai._C") is not None and sys.modules["monai._C"].__name__ == "monai_amd._C":
         del sys.modules["monai._C"]

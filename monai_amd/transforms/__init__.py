@@ -11,3 +11,4 @@ from .intensity import (  # noqa: F401
 from .spatial import Flip, FlipD, FlipDict, Flipd, Rotate90, Rotate90D, Rotate90Dict, Rotate90d  # noqa: F401
 from .spatial import Orientation, OrientationD, OrientationDict, Orientationd, Resample, SpatialResample, Spacing, SpacingD, SpacingDict, Spacingd, spatial_resample  # noqa: F401
 from .post import Activations, ActivationsD, ActivationsDict, Activationsd, AsDiscrete, AsDiscreteD, AsDiscreteDict, AsDiscreted  # noqa: F401
+from .lazy import ApplyPending, ApplyPendingd, apply_pending, apply_pending_transforms  # noqa: F401

@@ -11,6 +11,7 @@ import torch
 
 from ... import ops
 from ...data.meta_tensor import affine_np, is_meta
+from ..lazy import LazyCapable, materialize, peek_shape, push_pending
 from ...utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple
 
 __all__ = ["CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop", "is_positive",
@@ -64,6 +65,18 @@ def _wrap_crop_pad(img, out: torch.Tensor, start, cls_name: str, value: float):
     return res
 
 
+def _crop_pad_op(img, transform, start, size, value: float, lazy: bool):
+    """One crop / pad: output voxel o shows source voxel o + start (`value` outside the source).  Eager: the kernel pass + the
+    MetaTensor bookkeeping; lazy (croppad/functional.py:151-248 with lazy=True): only the pending record translate(start) / size."""
+    if lazy:
+        r = len(size)
+        shift = np.eye(r + 1)
+        shift[:r, -1] = [int(v) for v in start]
+        return push_pending(img, transform, shift, size, {"box_start": [int(v) for v in start], "pad_value": float(value)}, orig_size=peek_shape(img))
+    data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+    return _wrap_crop_pad(img, _run_crop_pad(data, start, size, value), start, type(transform).__name__, value)
+
+
 def _inverse_crop_pad(img, cls_name: str):
     """Undo the most recent crop / pad of `cls_name`: the same kernel with the negated start (cropped-away voxels come back as 0,
     padding is cut off) -- Pad.inverse / Crop.inverse, monai/transforms/croppad/array.py:190-204, 441-450."""
@@ -90,25 +103,26 @@ def _pad_value(mode, kwargs) -> float:
     return float(kw.pop("value", kw.pop("constant_values", 0.0)))
 
 
-class Pad:
+class Pad(LazyCapable):
     """``monai.transforms.Pad`` (monai/transforms/croppad/array.py:84-204): pad by ``to_pad`` = ``[(before, after), ...]`` including the
     channel axis; constant mode on the crop + pad kernel."""
 
     def __init__(self, to_pad=None, mode: str = "constant", lazy: bool = False, **kwargs) -> None:
-        if lazy:
-            raise NotImplementedError("monai_amd pad: lazy execution is not implemented")
-        self.to_pad, self.mode, self.kwargs, self.lazy = to_pad, mode, kwargs, False
+        self.to_pad, self.mode, self.kwargs = to_pad, mode, kwargs
+        self.lazy = lazy
 
     def compute_pad_width(self, spatial_shape):
         raise NotImplementedError(f"subclass {self.__class__.__name__} must implement this method.")
 
     def __call__(self, img, to_pad=None, mode: str | None = None, lazy: bool | None = None, **kwargs):
-        if lazy:
-            raise NotImplementedError("monai_amd pad: lazy execution is not implemented")
+        lazy_ = self.lazy if lazy is None else lazy
+        if not lazy_:
+            img = materialize(img)
         data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        shape_ = peek_shape(img) if is_meta(img) else tuple(int(v) for v in data.shape[1:])
         to_pad_ = self.to_pad if to_pad is None else to_pad
         if to_pad_ is None:
-            to_pad_ = self.compute_pad_width(tuple(int(v) for v in data.shape[1:]))
+            to_pad_ = self.compute_pad_width(shape_)
         kw = dict(self.kwargs)
         kw.update(kwargs)
         value = _pad_value(self.mode if mode is None else mode, kw)
@@ -116,8 +130,8 @@ class Pad:
         if len(to_pad_) != data.dim() or to_pad_[0] != (0, 0):
             raise NotImplementedError(f"monai_amd pad: to_pad must list every axis and leave the channel axis alone, got {to_pad_}")
         start = [-p[0] for p in to_pad_[1:]]
-        size = [int(n) + p[0] + p[1] for n, p in zip(data.shape[1:], to_pad_[1:])]
-        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, value), start, type(self).__name__, value)
+        size = [int(n) + p[0] + p[1] for n, p in zip(shape_, to_pad_[1:])]
+        return _crop_pad_op(img, self, start, size, value, lazy_)
 
     def inverse(self, img):
         return _inverse_crop_pad(img, type(self).__name__)
@@ -176,13 +190,11 @@ class DivisiblePad(Pad):
         return SpatialPad(compute_divisible_spatial_size(spatial_shape, self.k), method=self.method).compute_pad_width(spatial_shape)
 
 
-class Crop:
+class Crop(LazyCapable):
     """``monai.transforms.Crop`` (array.py:379-450): crop by per-axis slices (step 1); the result is a dense copy."""
 
     def __init__(self, lazy: bool = False):
-        if lazy:
-            raise NotImplementedError("monai_amd crop: lazy execution is not implemented")
-        self.lazy = False
+        self.lazy = lazy
 
     @staticmethod
     def compute_slices(roi_center=None, roi_size=None, roi_start=None, roi_end=None, roi_slices=None):
@@ -204,15 +216,17 @@ class Crop:
         return tuple(slice(a, b) for a, b in zip(start, end))
 
     def __call__(self, img, slices, lazy: bool | None = None):
-        if lazy:
-            raise NotImplementedError("monai_amd crop: lazy execution is not implemented")
+        lazy_ = self.lazy if lazy is None else lazy
+        if not lazy_:
+            img = materialize(img)
         data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
+        shape_ = peek_shape(img) if is_meta(img) else tuple(int(v) for v in data.shape[1:])
         sd = data.dim() - 1
         slices_ = (list(slices) + [slice(None)] * sd)[:sd]
-        rng = [s.indices(int(n)) for s, n in zip(slices_, data.shape[1:])]
+        rng = [s.indices(int(n)) for s, n in zip(slices_, shape_)]
         start = [r[0] for r in rng]
         size = [max(r[1] - r[0], 0) for r in rng]
-        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, 0.0), start, type(self).__name__, 0.0)
+        return _crop_pad_op(img, self, start, size, 0.0, lazy_)
 
     def inverse(self, img):
         return _inverse_crop_pad(img, type(self).__name__)
@@ -237,7 +251,8 @@ class CenterSpatialCrop(Crop):
         self.roi_size = roi_size
 
     def __call__(self, img, lazy: bool | None = None):
-        spatial = tuple(int(v) for v in (img.as_tensor() if is_meta(img) else torch.as_tensor(img)).shape[1:])
+        lazy_ = self.lazy if lazy is None else lazy
+        spatial = peek_shape(img) if (lazy_ and is_meta(img)) else tuple(int(v) for v in materialize(img).shape[1:])
         roi_size = fall_back_tuple(self.roi_size, spatial)
         return super().__call__(img=img, slices=Crop.compute_slices(roi_center=[i // 2 for i in spatial], roi_size=roi_size), lazy=lazy)
 
@@ -280,19 +295,23 @@ def compute_divisible_spatial_size(spatial_shape: Sequence[int], k: Sequence[int
     return tuple(int(np.ceil(dim / k_d) * k_d) if k_d > 0 else dim for k_d, dim in zip(k, spatial_shape))
 
 
-class CropForeground:
+class CropForeground(LazyCapable):
     """Crop an image to the bounding box of its foreground (``select_fn``, default ``> 0``), with ``margin``, ``k_divisible``
     and a constant pad where the box leaves the image.  Same constructor / call signature as the reference; ``mode`` other
-    than ``"constant"`` and lazy execution are not on the HIP path (they raise)."""
+    than ``"constant"`` is not on the HIP path.  ``lazy=True``: the box needs the CURRENT voxel values (``requires_current_data``, as in
+    the reference): pending operations are executed first, then the crop + pad itself is recorded as one pending operation."""
+
+    @property
+    def requires_current_data(self):
+        return True
 
     def __init__(self, select_fn: Callable = is_positive, channel_indices=None, margin: Sequence[int] | int = 0, allow_smaller: bool = False,
                  return_coords: bool = False, k_divisible: Sequence[int] | int = 1, mode: str = "constant", lazy: bool = False, **pad_kwargs) -> None:
-        if lazy:
-            raise NotImplementedError("monai_amd.CropForeground: lazy execution is not implemented")
         self.select_fn = select_fn
         self.channel_indices = ensure_tuple(channel_indices) if channel_indices is not None else None
         self.margin, self.allow_smaller, self.return_coords, self.k_divisible = margin, allow_smaller, return_coords, k_divisible
-        self.mode, self.pad_kwargs, self.lazy = mode, pad_kwargs, False
+        self.mode, self.pad_kwargs = mode, pad_kwargs
+        self.lazy = lazy
 
     def compute_bounding_box(self, img):
         """Box of the foreground, grown symmetrically to sizes divisible by ``k_divisible`` (array.py:847-867)."""
@@ -307,8 +326,6 @@ class CropForeground:
 
     def crop_pad(self, img, box_start: np.ndarray, box_end: np.ndarray, mode: str | None = None, lazy: bool = False, **pad_kwargs):
         """Crop to ``[max(start, 0), end)`` and pad what lies outside the image (array.py:884-927) -- one kernel pass."""
-        if lazy:
-            raise NotImplementedError("monai_amd.CropForeground: lazy execution is not implemented")
         kw = dict(self.pad_kwargs)
         kw.update(pad_kwargs)
         value = _pad_value(self.mode if mode is None else mode, kw)
@@ -319,7 +336,7 @@ class CropForeground:
         if len(start) != nsp:
             raise ValueError(f"monai_amd.CropForeground: a {len(start)}-D box does not fit an image of shape {tuple(data.shape)}")
         size = [e - s for s, e in zip(start, end)]
-        return _wrap_crop_pad(img, _run_crop_pad(data, start, size, value), start, type(self).__name__, value)
+        return _crop_pad_op(img, self, start, size, value, lazy)
 
     def inverse(self, img):
         """Undo the most recent crop + pad (array.py:950-960: crop the padding away, zero-pad back to the original size) -- the
@@ -327,10 +344,10 @@ class CropForeground:
         return _inverse_crop_pad(img, type(self).__name__)
 
     def __call__(self, img, mode: str | None = None, lazy: bool | None = None, **pad_kwargs):
-        if lazy:
-            raise NotImplementedError("monai_amd.CropForeground: lazy execution is not implemented")
+        lazy_ = self.lazy if lazy is None else lazy
+        img = materialize(img)                         # the box is computed on the current data (array.py:929-948)
         box_start, box_end = self.compute_bounding_box(img)
-        cropped = self.crop_pad(img, box_start, box_end, mode, **pad_kwargs)
+        cropped = self.crop_pad(img, box_start, box_end, mode, lazy=bool(lazy_), **pad_kwargs)
         if self.return_coords:
             return cropped, box_start, box_end
         return cropped

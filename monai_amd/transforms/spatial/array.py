@@ -15,7 +15,8 @@ from ...data.utils import AFFINE_TOL, affine_to_spacing, compute_shape_offset, t
 from ...utils.misc import ensure_tuple
 from ... import ops
 from ... import config
-from .functional import _mode_name, _pad_name, spatial_resample
+from ..lazy import LazyCapable, materialize, peek_affine, peek_shape, push_pending
+from .functional import _mode_name, _pad_name, resample_plan, spatial_resample
 
 __all__ = ["SpatialResample", "Spacing", "Resample"]
 
@@ -46,22 +47,28 @@ def _wrap(out: torch.Tensor, src, new_affine, op_record):
     return res
 
 
-class SpatialResample:
+class SpatialResample(LazyCapable):
     """Resample from the image's affine to ``dst_affine``: ``xform = solve(src_affine, dst_affine)``, then an affine
-    pull with that matrix."""
+    pull with that matrix.  ``lazy=True`` records xform and the output size as a pending operation (monai_amd/transforms/lazy.py)."""
 
     def __init__(self, mode="bilinear", padding_mode="border", align_corners: bool = False, dtype=np.float64, lazy: bool = False):
-        if lazy:
-            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
-        self.mode, self.padding_mode, self.align_corners, self.dtype, self.lazy = mode, padding_mode, align_corners, dtype, False
+        self.mode, self.padding_mode, self.align_corners, self.dtype = mode, padding_mode, align_corners, dtype
+        self.lazy = lazy
 
     def __call__(self, img, dst_affine=None, spatial_size=None, mode=None, padding_mode=None, align_corners=None, dtype=None, lazy=None):
-        if lazy:
-            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
+        lazy_ = self.lazy if lazy is None else lazy
         dtype_pt = _torch_dtype(dtype or self.dtype, img.dtype if img.dtype.is_floating_point else torch.float64)
         align_corners = self.align_corners if align_corners is None else align_corners
         mode = self.mode if mode is None else mode
         padding_mode = self.padding_mode if padding_mode is None else padding_mode
+        if lazy_:          # functional.py:141-151: nothing is resampled, the composed affine is executed by apply_pending
+            _mode_name(mode), _pad_name(padding_mode)         # the same argument errors as the eager call
+            orig = peek_shape(img)
+            out_size, xform, src_a, _ = resample_plan(orig, peek_affine(img), dst_affine, spatial_size)
+            info = {"dtype": str(dtype_pt)[6:], "mode": getattr(mode, "value", mode), "padding_mode": getattr(padding_mode, "value", padding_mode),
+                    "align_corners": align_corners, "src_affine": torch.as_tensor(src_a)}
+            return push_pending(img, self, xform, [int(v) for v in out_size], info, orig_size=orig)
+        img = materialize(img)
         orig_size = tuple(img.shape[1:])
         out, xform, out_size, src_a = spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_corners, dtype_pt)
         record = None
@@ -92,13 +99,11 @@ class SpatialResample:
         return out
 
 
-class Spacing:
+class Spacing(LazyCapable):
     """Resample the image to voxel size ``pixdim`` (array.py:338-546)."""
 
     def __init__(self, pixdim, diagonal: bool = False, mode="bilinear", padding_mode="border", align_corners: bool = False, dtype=np.float64,
                  scale_extent: bool = False, recompute_affine: bool = False, min_pixdim=None, max_pixdim=None, lazy: bool = False):
-        if lazy:
-            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
         self.pixdim = np.array(ensure_tuple(pixdim), dtype=np.float64)
         self.min_pixdim = np.array(ensure_tuple(min_pixdim), dtype=np.float64)
         self.max_pixdim = np.array(ensure_tuple(max_pixdim), dtype=np.float64)
@@ -106,18 +111,29 @@ class Spacing:
         for mn, mx in zip(self.min_pixdim, self.max_pixdim):
             if (not np.isnan(mn)) and (not np.isnan(mx)) and ((mx < mn) or (mn < 0)):
                 raise ValueError(f"min_pixdim {self.min_pixdim} must be positive, smaller than max {self.max_pixdim}.")
-        self.sp_resample = SpatialResample(mode=mode, padding_mode=padding_mode, align_corners=align_corners, dtype=dtype)
+        self.sp_resample = SpatialResample(mode=mode, padding_mode=padding_mode, align_corners=align_corners, dtype=dtype, lazy=lazy)
+        self._lazy = lazy
+
+    @property
+    def lazy(self):
+        return self._lazy
+
+    @lazy.setter
+    def lazy(self, val) -> None:
+        object.__setattr__(self, "_lazy", val)
+        self.sp_resample.lazy = val
 
     def __call__(self, data_array, mode=None, padding_mode=None, align_corners=None, dtype=None, scale_extent=None, output_spatial_shape=None,
                  lazy=None):
-        if lazy:
-            raise NotImplementedError("monai_amd: lazy resampling is not implemented")
-        original_shape = tuple(data_array.shape[1:])
+        lazy_ = self.lazy if lazy is None else lazy
+        if not lazy_:
+            data_array = materialize(data_array)
+        original_shape = peek_shape(data_array)
         sr = len(original_shape)
         if sr <= 0:
             raise ValueError(f"data_array must have at least one spatial dimension, got {original_shape}.")
         if is_meta(data_array) and "affine" in data_array.meta:
-            input_affine = data_array.meta["affine"]
+            input_affine = peek_affine(data_array)
         else:
             warnings.warn("`data_array` is not of type MetaTensor, assuming affine to be identity.")
             input_affine = np.eye(sr + 1, dtype=np.float64)
@@ -142,7 +158,7 @@ class Spacing:
         new_affine[:sr, -1] = offset[:sr]
         actual_shape = list(output_shape) if output_spatial_shape is None else output_spatial_shape
         out = self.sp_resample(data_array, dst_affine=torch.as_tensor(new_affine), spatial_size=actual_shape, mode=mode, padding_mode=padding_mode,
-                               align_corners=align_corners, dtype=dtype)
+                               align_corners=align_corners, dtype=dtype, lazy=lazy_)
         if self.recompute_affine and is_meta(out):
             raise NotImplementedError("monai_amd: recompute_affine is not implemented")
         return out

@@ -8,12 +8,15 @@ from collections.abc import Hashable, Mapping, Sequence
 import numpy as np
 
 from ...utils.misc import ensure_tuple, ensure_tuple_rep
+from ..lazy import LazyCapableDict, peek_shape
 from .array import Spacing
 
 __all__ = ["Spacingd", "SpacingD", "SpacingDict"]
 
 
-class Spacingd:
+class Spacingd(LazyCapableDict):
+    _lazy_inner = ("spacing_transform",)
+
     def __init__(self, keys, pixdim, diagonal: bool = False, mode="bilinear", padding_mode="border", align_corners=False, dtype=np.float64,
                  scale_extent: bool = False, recompute_affine: bool = False, min_pixdim=None, max_pixdim=None, ensure_same_shape: bool = True,
                  allow_missing_keys: bool = False, lazy: bool = False) -> None:
@@ -30,8 +33,10 @@ class Spacingd:
         self.dtype = ensure_tuple_rep(dtype, n)
         self.scale_extent = ensure_tuple_rep(scale_extent, n)
         self.ensure_same_shape = ensure_same_shape
+        self.lazy = lazy
 
     def __call__(self, data: Mapping[Hashable, object], lazy=None) -> dict:
+        lazy_ = self.lazy if lazy is None else lazy
         d = dict(data)
         _init_shape, _pixdim, should_match = None, None, False
         output_shape_k = None  # first key's output shape, reused so that image / label keep matching shapes (:503-512)
@@ -43,13 +48,13 @@ class Spacingd:
                 raise KeyError(f"Key `{key}` of transform `{type(self).__name__}` was missing in the data and allow_missing_keys==False.")
             if self.ensure_same_shape and hasattr(d[key], "meta"):
                 if _init_shape is None and _pixdim is None:
-                    _init_shape, _pixdim = tuple(d[key].shape[1:]), _pixdim_of(d[key])
+                    _init_shape, _pixdim = peek_shape(d[key]), _pixdim_of(d[key])
                 else:
-                    should_match = np.allclose(_init_shape, tuple(d[key].shape[1:])) and np.allclose(_pixdim, _pixdim_of(d[key]), atol=1e-3)
+                    should_match = np.allclose(_init_shape, peek_shape(d[key])) and np.allclose(_pixdim, _pixdim_of(d[key]), atol=1e-3)
             d[key] = self.spacing_transform(d[key], mode=mode, padding_mode=padding_mode, align_corners=align_corners, dtype=dtype,
-                                            scale_extent=scale_extent, output_spatial_shape=output_shape_k if should_match else None)
+                                            scale_extent=scale_extent, output_spatial_shape=output_shape_k if should_match else None, lazy=lazy_)
             if output_shape_k is None:
-                output_shape_k = tuple(d[key].shape[1:])
+                output_shape_k = peek_shape(d[key])
         return d
 
     def inverse(self, data: Mapping[Hashable, object]) -> dict:

@@ -45,7 +45,18 @@ def spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_co
     src_affine = img.meta["affine"] if is_meta(img) and "affine" in img.meta else torch.eye(4, dtype=torch.float64)
     data = img.as_tensor() if is_meta(img) else img
     original_shape = tuple(data.shape[1:])
-    spatial_rank = min(data.dim() - 1, src_affine.shape[0] - 1, 3)
+    out_size, xform, src_a, unchanged = resample_plan(original_shape, src_affine, dst_affine, spatial_size)
+    spatial_rank = len(xform) - 1
+    if unchanged:
+        return data.to(torch.float32), None, tuple(int(v) for v in out_size), src_a
+    return _execute_resample(data, xform, out_size, spatial_rank, mode, padding_mode, align_corners, dtype_pt) + (src_a,)
+
+
+def resample_plan(original_shape, src_affine, dst_affine, spatial_size):
+    """Host algebra of ``spatial_resample`` (functional.py:100-151): (output size, xform = solve(src, dst), src affine at the
+    spatial rank, unchanged?) -- shared by the eager path and the lazy path (which only records xform and the size)."""
+    src_affine = np.asarray(src_affine.detach().cpu() if isinstance(src_affine, torch.Tensor) else src_affine, dtype=np.float64)
+    spatial_rank = min(len(original_shape), src_affine.shape[0] - 1, 3)
     if (not isinstance(spatial_size, int) or spatial_size != -1) and spatial_size is not None:
         spatial_rank = min(len(ensure_tuple(spatial_size)), 3)
     src_a = to_affine_nd(spatial_rank, src_affine)
@@ -64,9 +75,10 @@ def spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_co
         raise ValueError(f"src affine is not invertible {src_a}, {dst_a}.") from e
     same_size = np.allclose(out_size, in_size)
     unchanged = (np.allclose(src_a, dst_a, atol=AFFINE_TOL) and same_size) or (np.allclose(xform, np.eye(len(xform)), atol=AFFINE_TOL) and same_size)
-    if unchanged:
-        return data.to(torch.float32), None, tuple(int(v) for v in out_size), src_a
+    return out_size, xform, src_a, bool(unchanged)
 
+
+def _execute_resample(data, xform, out_size, spatial_rank, mode, padding_mode, align_corners, dtype_pt):
     sizes = list(data.shape)
     chns, in_sp, extra = sizes[0], sizes[1:spatial_rank + 1], sizes[spatial_rank + 1:]
     x = data.reshape([-1] + in_sp) if extra else data
@@ -82,4 +94,4 @@ def spatial_resample(img, dst_affine, spatial_size, mode, padding_mode, align_co
     out = out.reshape((x.shape[0],) + tuple(int(v) for v in out_size))
     if extra:
         out = out.reshape((chns, *[int(v) for v in out_size], *extra))
-    return out, xform, tuple(int(v) for v in out_size), src_a
+    return out, xform, tuple(int(v) for v in out_size)

@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from ... import ops
+from ..lazy import LazyCapable, LazyCapableDict, materialize, peek_affine, peek_shape, push_pending
 from ...data.meta_tensor import is_meta
 from ...data.utils import to_affine_nd
 from ...utils.misc import ensure_tuple
@@ -117,32 +118,33 @@ def aff2axcodes(aff, labels=None, tol=None):
     return tuple(codes)
 
 
-class Orientation:
+class Orientation(LazyCapable):
     """Change the input image's orientation into the one given by ``axcodes`` (or the closest canonical one), updating the
-    MetaTensor's affine.  Same constructor / call signature as the reference; lazy execution is not on the HIP path."""
+    MetaTensor's affine.  Same constructor / call signature as the reference; ``lazy=True`` records the signed axis permutation as a
+    pending operation (monai_amd/transforms/lazy.py)."""
 
     def __init__(self, axcodes: str | None = None, as_closest_canonical: bool = False, labels: Sequence[tuple[str, str]] | None = _LABELS,
                  lazy: bool = False) -> None:
-        if lazy:
-            raise NotImplementedError("monai_amd.Orientation: lazy execution is not implemented")
         if axcodes is None and not as_closest_canonical:
             raise ValueError("Incompatible values: axcodes=None and as_closest_canonical=True.")
         if axcodes is not None and as_closest_canonical:
             warnings.warn("using as_closest_canonical=True, axcodes ignored.")
-        self.axcodes, self.as_closest_canonical, self.labels, self.lazy = axcodes, as_closest_canonical, labels, False
+        self.axcodes, self.as_closest_canonical, self.labels = axcodes, as_closest_canonical, labels
+        self.lazy = lazy
 
     def __call__(self, data_array, lazy: bool | None = None):
-        if lazy:
-            raise NotImplementedError("monai_amd.Orientation: lazy execution is not implemented")
+        lazy_ = self.lazy if lazy is None else lazy
+        if not lazy_:
+            data_array = materialize(data_array)
         data = data_array.as_tensor() if is_meta(data_array) else torch.as_tensor(data_array)
-        spatial_shape = tuple(int(v) for v in data.shape[1:])
+        spatial_shape = peek_shape(data_array) if is_meta(data_array) else tuple(int(v) for v in data.shape[1:])
         sr = len(spatial_shape)
         if sr <= 0:
             raise ValueError(f"data_array must have at least one spatial dimension, got {spatial_shape}.")
         if sr > 3:
             raise NotImplementedError(f"monai_amd.Orientation: {sr} spatial axes are not on the HIP path (1-3 are)")
         if is_meta(data_array):
-            affine_np = np.asarray(torch.as_tensor(data_array.affine).cpu(), dtype=np.float64)
+            affine_np = peek_affine(data_array)
             affine_ = to_affine_nd(sr, affine_np)
         else:
             warnings.warn("`data_array` is not of type `MetaTensor, assuming affine to be identity.")
@@ -166,6 +168,8 @@ class Orientation:
         # output axis k shows input axis perm[k]; input axis a is reversed when its flip is -1 (functional.py:192-218)
         perm = [int(v) for v in np.argsort(spatial_ornt[:, 0])]
         flips = [bool(f == -1) for f in spatial_ornt[:, 1]]
+        if lazy_:          # functional.py:219-228: only the record; apply_pending runs it as a flip / permute (or fused into a resampling)
+            return push_pending(data_array, self, xform, [spatial_shape[p] for p in perm], {"original_affine": affine_np}, orig_size=spatial_shape)
         ints = (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, torch.bool)
         if data.dtype != torch.float32 and data.dtype not in ints:
             raise NotImplementedError(f"monai_amd.Orientation: {data.dtype} images are not on the HIP path (float32 and integer images are)")
@@ -191,14 +195,17 @@ class Orientation:
         return out
 
 
-class Orientationd:
+class Orientationd(LazyCapableDict):
     """Dictionary version (monai/transforms/spatial/dictionary.py:534-606)."""
+
+    _lazy_inner = ("ornt_transform",)
 
     def __init__(self, keys, axcodes: str | None = None, as_closest_canonical: bool = False, labels: Sequence[tuple[str, str]] | None = _LABELS,
                  allow_missing_keys: bool = False, lazy: bool = False) -> None:
         self.keys = ensure_tuple(keys)
         self.allow_missing_keys = allow_missing_keys
         self.ornt_transform = Orientation(axcodes=axcodes, as_closest_canonical=as_closest_canonical, labels=labels, lazy=lazy)
+        self.lazy = lazy
 
     def _each(self, data, fn):
         d = dict(data)
@@ -211,7 +218,8 @@ class Orientationd:
         return d
 
     def __call__(self, data, lazy: bool | None = None):
-        return self._each(data, lambda v: self.ornt_transform(v, lazy=lazy))
+        lazy_ = self.lazy if lazy is None else lazy
+        return self._each(data, lambda v: self.ornt_transform(v, lazy=lazy_))
 
     def inverse(self, data):
         return self._each(data, self.ornt_transform.inverse)

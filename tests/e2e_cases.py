@@ -134,6 +134,40 @@ def case_slabwise_equals_whole(device):
     return res
 
 
+def case_fused_argmax_epilogue(device):
+    """the argmax of AsDiscrete(argmax=True) fused into the blend epilogue.  Inferer + fused network, generic predictor with
+    two outputs (one at half resolution -> scaled window starts), the slab-wise path, uint8 labels: every label map equals
+    AsDiscrete(argmax=True) of the unfused inferer output, bit for bit."""
+    from monai_amd.inferers import SlidingWindowArgmaxInferer, SlidingWindowInferer, sliding_window_argmax
+    from monai_amd.transforms import AsDiscrete
+
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(41)
+    x = torch.rand(2, 1, 40, 24, 16).to(device)
+    inf = SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian")
+    ref = inf(x, net)
+    exp = torch.stack([AsDiscrete(argmax=True)(ref[i]) for i in range(2)])
+    got = inf.argmax(x, net)
+    assert got.shape == (2, 1, 40, 24, 16) and got.dtype == torch.float32 and torch.equal(got, exp)
+    got8 = SlidingWindowArgmaxInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian", labels_dtype=torch.uint8)(x, net)
+    assert got8.dtype == torch.uint8 and torch.equal(got8.float(), exp)
+
+    def two_heads(w):
+        a = torch.cat([w * 2.0, w.flip(2) - 0.5, (w - 0.5).abs()], dim=1)
+        return a, torch.nn.functional.avg_pool3d(a, 2)
+
+    r2 = inf(x[:1], two_heads)
+    g2 = sliding_window_argmax(x[:1], (16, 16, 16), 2, two_heads, overlap=0.5, mode="gaussian")
+    for a, b in zip(r2, g2):
+        assert torch.equal(b[0], AsDiscrete(argmax=True)(a[0]))
+    os.environ["MONAI_AMD_MAX_LOGITS_BYTES"] = str(2.5 * 2 * 5 * 16 ** 3 * 4)       # slab-wise: two window rows at a time
+    try:
+        assert torch.equal(inf.argmax(x[:1], net), exp[:1])
+    finally:
+        del os.environ["MONAI_AMD_MAX_LOGITS_BYTES"]
+    return True
+
+
 def case_config0_vs_golden(device):
     """BASELINE.json configs[0]: BasicUNet(1->2), rand 64^3, roi 32^3, sw_batch 4, overlap .5, gaussian."""
     from monai_amd.inferers import SlidingWindowInferer

@@ -43,6 +43,10 @@ def test_slabwise_equals_whole(emu):
     print(ec.case_slabwise_equals_whole("cpu"))
 
 
+def test_fused_argmax_epilogue(emu):
+    assert ec.case_fused_argmax_epilogue("cpu")
+
+
 def test_single_window_with_split_precision_convolutions(emu, monkeypatch):
     """The opt-in split-precision convolution (MONAI_AMD_CONV_ALGO=split: bf16 matrix cores, six exact piece products per
     multiply) keeps the end-to-end logits within the same 1e-4 bound of the reference golden window."""

@@ -87,6 +87,10 @@ def test_slice_inferer_and_adapt_on_device():
         assert float((a - (x[:, :, :32] * 2.0 + 1.0)).abs().max()) < 1e-6 and a.is_cuda
 
 
+def test_fused_argmax_epilogue():
+    assert ec.case_fused_argmax_epilogue(DEV)
+
+
 def test_fused_and_separate_instnorm_statistics_agree():
     net, _ = ec.make_net(1, 1, 5, DEV)
     torch.manual_seed(6)

@@ -280,3 +280,42 @@ def test_reference_checkpoints_load_into_amd_dynunet_and_segresnet(monai_ref, em
         x = cases.inputs(name)
         with torch.no_grad():
             assert float((ours(x) - ref(x)).abs().max()) < 1e-4, name
+
+
+def test_reference_compose_lazy_runs_the_fused_resampling(monai_ref, emu):
+    """SURVEY 8f-2 through the reference's own machinery: after install() `monai.transforms.Compose(..., lazy=True)` sees the MI355X
+    transforms as LazyTrait instances, lets them record their affines, and executes the pending group through the rebound
+    `monai.transforms.lazy.utils.resample` = ONE `mh_affine_resample_f32` launch per image.  Results equal the pure-reference lazy run
+    (tests/golden/lazy.npz)."""
+    import numpy as np
+
+    import lazy_cases as lc
+    import monai_amd.patch as patch
+
+    patch.install()
+    from monai.data import MetaTensor
+    from monai.transforms import Compose, CropForegroundd, Flipd, SpatialPadd, Spacingd
+    from monai.transforms.traits import LazyTrait
+
+    assert getattr(Spacingd, "_mh_is_product", False) and isinstance(Spacingd("image", pixdim=(1, 1, 1)), LazyTrait)
+    g = np.load(lc.GOLDEN)
+    aff = torch.as_tensor(g["affine"])
+    chains = {
+        "a": [Flipd(lc.KEYS, spatial_axis=[0, 1]), Spacingd(lc.KEYS, pixdim=(1.0, 1.0, 1.0), mode=("bilinear", "nearest"))],
+        "b": [Flipd(lc.KEYS, spatial_axis=[0, 1]), Spacingd(lc.KEYS, pixdim=(1.1, 0.7, 1.3), mode=("bilinear", "nearest")),
+              CropForegroundd(lc.KEYS, source_key="image", margin=2), SpatialPadd(lc.KEYS, spatial_size=(48, 48, 48))],
+    }
+    for name, ts in chains.items():
+        data = {k: MetaTensor(torch.as_tensor(g[k]), affine=aff.clone()) for k in lc.KEYS}
+        with lc._Count() as c:
+            out = Compose(ts, lazy=True)(data)
+        assert c.n == 2, (name, c.n)                      # one interpolating launch per image, whatever the chain length
+        for k in lc.KEYS:
+            exp = torch.as_tensor(g[f"{name}_lazy_{k}"])
+            assert out[k].shape == exp.shape and float((out[k].as_tensor() - exp).abs().max()) < 2e-5, (name, k)
+            assert np.allclose(out[k].affine.numpy(), g[f"{name}_lazy_{k}_affine"], atol=1e-9)
+            assert not out[k].pending_operations
+    patch.uninstall()
+    from monai.transforms.lazy import utils as lu
+
+    assert lu.resample.__module__ == "monai.transforms.lazy.utils"          # the reference's own function is back

@@ -126,6 +126,13 @@ def test_post_transforms_api(emu):
     pc.case_post_transforms_api("cpu")
 
 
+def test_lazy_resampling_vs_reference(emu):
+    import lazy_cases as lc
+
+    print("launches", lc.case_lazy_chains_vs_reference("cpu"))
+    assert lc.case_lazy_orientation_spacing_fused("cpu")
+
+
 def test_preproc_vs_reference(emu):
     import preproc_cases as pc
 

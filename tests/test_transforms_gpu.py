@@ -137,3 +137,11 @@ def test_post_transforms_vs_reference():
 
     print("arrays", pc.case_post_transforms_vs_reference(DEV))
     pc.case_post_transforms_api(DEV)
+
+
+def test_lazy_resampling_vs_reference():
+    """SURVEY 8f-2 on the MI355X: the chains of tests/golden/lazy.npz (real reference, Compose(lazy=True)) with one fused launch per image"""
+    import lazy_cases as lc
+
+    print("launches", lc.case_lazy_chains_vs_reference("cuda"))
+    assert lc.case_lazy_orientation_spacing_fused("cuda")

@@ -141,6 +141,56 @@ __global__ void __launch_bounds__(256) blend_shape_k(const float* __restrict__ l
     }
 }
 
+// The blend shape with the classes interleaved at ROW granularity: logits [nwin][r][r][K][r] -- the K class values of a window
+// row are K consecutive 384-byte rows, so a voxel's K loads per window fall into one 1920-byte span (8 streams per voxel
+// instead of 8 K).
+template <int K>
+__global__ void __launch_bounds__(256) blend_shape_rows_k(const float* __restrict__ logits, float* __restrict__ out, int D, int H, int W, int r, int s,
+                                                          int n, long long wstride) {
+    const int wv = W / 4;
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int x = (int)(idx % wv) * 4;
+    const long long t = idx / wv;
+    const int y = (int)(t % H), z = (int)(t / H);
+    if (z >= D) return;
+    const int last = (n - 1) * s < D - r ? (n - 1) * s : D - r;
+    int lo[3], hi[3];
+    const int p[3] = {z, y, x};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int l = p[a] - r >= 0 ? (p[a] - r) / s + 1 : 0;
+        if (l > n - 1) l = n - 1;
+        int h = p[a] / s;
+        if (h > n - 2) h = n - 2;
+        if (p[a] >= last) h = n - 1;
+        if (h < l) h = l;
+        lo[a] = l; hi[a] = h;
+    }
+    f4 acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = f4{0, 0, 0, 0};
+    for (int iz = lo[0]; iz <= hi[0]; ++iz) {
+        const int lz = z - (iz == n - 1 ? last : iz * s);
+        for (int iy = lo[1]; iy <= hi[1]; ++iy) {
+            const int ly = y - (iy == n - 1 ? last : iy * s);
+            for (int ix = lo[2]; ix <= hi[2]; ++ix) {
+                const int lx = x - (ix == n - 1 ? last : ix * s);
+                const long long w = ((long long)iz * n + iy) * n + ix;
+                const float* lp = logits + w * wstride + ((long long)(lz * r + ly) * K) * r + lx;
+                f4 v[K];
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[k] = *reinterpret_cast<const f4*>(lp + k * r);
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] += v[k];
+            }
+        }
+    }
+    const long long vox = (long long)D * H * W;
+    float* op = out + ((long long)z * H + y) * W + x;
+#pragma unroll
+    for (int k = 0; k < K; ++k) *reinterpret_cast<f4*>(op + k * vox) = acc[k];
+}
+
 // S streams `stride` bytes apart, read in lockstep: thread i reads 16 B at offset 16 i of every stream (the blend reads its 40
 // (window, class) streams like this: are strides that are multiples of a large power of two slower -- channel camping?)
 template <int S>
@@ -230,6 +280,18 @@ int main() {
             CHECK(hipMemset(lg2, 0x3c, 1000LL * ws * 4));
             char nm[160]; snprintf(nm, sizeof nm, "blend shape, class stride roi+%lld, window stride +%lld, out channel stride +%lld floats", pd[0], pd[1], pd[2]);
             RUN(nm, bb, 5, (blend_shape_k<5, false, 0><<<nb0, 256>>>(lg2, out2, D, D, D, r, s, n, ks, ws, os)))
+            CHECK(hipFree(lg2)); CHECK(hipFree(out2));
+        }
+    }
+    {
+        const long long pads2[] = {0, 1088, 0, 1088};
+        for (long long pd : pads2) {
+            const long long ws = (long long)K * roi + pd;
+            float *lg2, *out2;
+            CHECK(hipMalloc(&lg2, 1000LL * ws * 4)); CHECK(hipMalloc(&out2, (long long)K * D * D * D * 4));
+            CHECK(hipMemset(lg2, 0x3c, 1000LL * ws * 4));
+            char nm[160]; snprintf(nm, sizeof nm, "blend shape, classes interleaved per window row, window stride +%lld floats", pd);
+            RUN(nm, bb, 5, (blend_shape_rows_k<5><<<nb0, 256>>>(lg2, out2, D, D, D, r, s, n, ws)))
             CHECK(hipFree(lg2)); CHECK(hipFree(out2));
         }
     }
