@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 METRIC = "voxels/s sliding-window 3D seg (512^3 vol, 96^3 win, ov 0.5) at 1/8 GPU"
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (~6.3 TB/s achievable: the guide; 6.2-7.0 TB/s measured by tools/ubench/hbm_stream.hip)
-NETS = {"unetr": "UNETR ViT-B/16", "unet": "UNet 16-256 res2", "basicunet": "BasicUNet", "dynunet": "DynUNet 32-320 (5 levels)", "segresnet": "SegResNet f16"}
+NETS = {"swinunetr": "SwinUNETR f48", "unetr": "UNETR ViT-B/16", "unet": "UNet 16-256 res2", "basicunet": "BasicUNet", "dynunet": "DynUNet 32-320 (5 levels)", "segresnet": "SegResNet f16"}
 
 
 def benchmark_volume(size: int) -> torch.Tensor:
@@ -145,7 +145,7 @@ def main(argv=None):
     ap.add_argument("--cpu-windows", type=int, default=12, help="windows of the sub-volume the CPU baseline runs (0 = skip)")
     ap.add_argument("--net", default="basicunet", choices=sorted(NETS),
                     help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
-                         "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16) (SURVEY 8f-4)")
+                         "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16); swinunetr = SwinUNETR(feature_size=48) (SURVEY 8f-4)")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +174,7 @@ def main(argv=None):
 
     from monai_amd import _prof, parallel
     from monai_amd.inferers import SlidingWindowInferer
-    from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, UNet
+    from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, SwinUNETR, UNet
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -186,7 +186,9 @@ def main(argv=None):
 
     # weights / volume exactly as SURVEY.md 8(d) config 1
     torch.manual_seed(1)
-    if args.net == "unetr":
+    if args.net == "swinunetr":
+        net = SwinUNETR(in_channels=1, out_channels=5, feature_size=48).eval().to(dev)
+    elif args.net == "unetr":
         net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
     elif args.net == "unet":
         net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2).eval().to(dev)

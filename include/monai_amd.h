@@ -160,6 +160,16 @@ int mh_pad_replicate_f32(const mh_tensor5* in, const mh_tensor5* out, void* stre
  * v_mfma_f32_32x32x2_f32 with K/V of a head resident in LDS.  head_dim 64, S <= 224 (ViT-B/16 on 96^3: S = 216). */
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream);
 
+/* Window attention of SwinUNETR's Swin transformer (WindowAttention.forward, monai/networks/nets/swin_unetr.py:519-541):
+ * softmax((q * scale) k^T + relative_position_bias[head] + mask[window % nW]) v per (window, head).
+ *   qkv     [BW][S][3][heads][head_dim]   the qkv Linear's output of BW windows of S tokens
+ *   bias_t  [heads][S][S] or NULL         relative position bias, TRANSPOSED: bias_t[h][key][query] = bias[h][query][key]
+ *   mask    [nW][S][S] or NULL            shifted-window mask (0 / -100, symmetric); window w uses mask[w % nW]
+ *   out     [BW][S][heads * head_dim]
+ * head_dim 8 / 16 / 32 (feature sizes 24 / 48 / 96). */
+int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads,
+                            int head_dim, float scale, void* stream);
+
 /* ---- UNet pieces (monai/networks/nets/unet.py:106-298) --------------------------------------------------------- */
 
 /* Conv3d k=3, stride s, padding 1 (+bias) of act(in): the strided `Convolution` / `ResidualUnit` convs of the down path

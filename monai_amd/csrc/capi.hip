@@ -1105,6 +1105,24 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
     return launched("attention");
 }
 
+int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads, int head_dim,
+                            float scale, void* stream) {
+    if (!qkv || !out || BW < 1 || S < 1 || heads < 1 || nW < 1) return fail(MH_ERR_ARG, "window_attention: bad argument");
+    if (mask && BW % nW) return fail(MH_ERR_ARG, "window_attention: %d windows are not a multiple of the %d mask windows", BW, nW);
+    if (!aligned(qkv, 16) || !aligned(out, 16)) return fail(MH_ERR_ARG, "window_attention: 16-byte aligned tensors required");
+    if (S > WA_MAX_TOKENS) return fail(MH_ERR_UNSUPPORTED, "window_attention: %d tokens per window exceed the LDS-resident limit of %d", S, WA_MAX_TOKENS);
+    const size_t lds = 0;
+    const dim3 grid((unsigned)heads, (unsigned)BW);
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 8: hipLaunchKernelGGL((window_attention_kernel<8>), grid, dim3(256), lds, s, qkv, bias_t, mask, out, S, heads, nW, scale); break;
+        case 16: hipLaunchKernelGGL((window_attention_kernel<16>), grid, dim3(256), lds, s, qkv, bias_t, mask, out, S, heads, nW, scale); break;
+        case 32: hipLaunchKernelGGL((window_attention_kernel<32>), grid, dim3(256), lds, s, qkv, bias_t, mask, out, S, heads, nW, scale); break;
+        default: return fail(MH_ERR_UNSUPPORTED, "window_attention: head_dim %d is not built (8, 16, 32 are)", head_dim);
+    }
+    return launched("window_attention");
+}
+
 // ------------------------------------------------------------------------------------------ UNet pieces
 int mh_conv3d_k3_strided_f32(const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, int stride,
                              void* stream) {

@@ -104,4 +104,65 @@ __global__ void __launch_bounds__(256) attention_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Window attention of the Swin transformer (WindowAttention.forward, monai/networks/nets/swin_unetr.py:519-541):
+//   attn = softmax((q * scale) k^T + relative_position_bias[head] + mask[window % nW]) v      per (window, head)
+// on the qkv projection's output [BW][S][3][heads][HD]; writes [BW][S][heads * HD] (the pre-`proj` tensor).  Small heads
+// (HD = 8 / 16 / 32 at feature sizes 24 / 48 / 96), S = window volume (343 for 7^3; 27 ... 216 when the feature map is
+// smaller than the window): the products are too thin for a 32x32 MFMA tile to pay (K = HD), so this is a VALU kernel --
+// one workgroup per (window, head), K and V of the head in LDS (broadcast reads), one query row per thread with an online
+// softmax; bias and mask rows are read TRANSPOSED ([key][query]) so that the threads of a wave read consecutive addresses.
+// `bias_t` [heads][S][S] = bias[head][query][key] stored as [head][key][query]; `mask` [nW][S][S] (symmetric: 0 / -100) or null.
+constexpr int WA_MAX_TOKENS = 352;       // 7^3 = 343 tokens per window
+
+template <int HD>
+__global__ void __launch_bounds__(256) window_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t,
+                                                               const float* __restrict__ mask, float* __restrict__ out, int S, int heads, int nW,
+                                                               float scale) {
+    __shared__ __attribute__((aligned(16))) float ks[WA_MAX_TOKENS * HD];      // [S][HD]
+    __shared__ __attribute__((aligned(16))) float vs[WA_MAX_TOKENS * HD];
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x, w = blockIdx.y;
+    const int C3 = 3 * heads * HD;
+    const float* base = qkv + (long long)w * S * C3 + head * HD;
+    for (int i = tid; i < S * (HD / 4); i += 256) {
+        const int r = i / (HD / 4), c4 = i - r * (HD / 4);
+        reinterpret_cast<f32x4*>(ks)[i] = *reinterpret_cast<const f32x4*>(base + (long long)r * C3 + heads * HD + 4 * c4);
+        reinterpret_cast<f32x4*>(vs)[i] = *reinterpret_cast<const f32x4*>(base + (long long)r * C3 + 2 * heads * HD + 4 * c4);
+    }
+    __syncthreads();
+    const float* bt = bias_t ? bias_t + (long long)head * S * S : nullptr;
+    const float* mk = mask ? mask + (long long)(w % nW) * S * S : nullptr;
+    for (int r = tid; r < S; r += 256) {
+        float q[HD];
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(base + (long long)r * C3 + 4 * c4);
+            q[4 * c4] = t[0] * scale; q[4 * c4 + 1] = t[1] * scale; q[4 * c4 + 2] = t[2] * scale; q[4 * c4 + 3] = t[3] * scale;
+        }
+        float m = -INFINITY, l = 0.0f;
+        float acc[HD];
+#pragma unroll
+        for (int d = 0; d < HD; ++d) acc[d] = 0.0f;
+        for (int j = 0; j < S; ++j) {
+            float sc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) sc = fmaf(q[d], ks[j * HD + d], sc);
+            if (bt) sc += bt[(long long)j * S + r];
+            if (mk) sc += mk[(long long)j * S + r];
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn), pj = expf(sc - mn);
+            l = fmaf(l, corr, pj);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(acc[d], corr, pj * vs[j * HD + d]);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+        float* o = out + ((long long)w * S + r) * (heads * HD) + head * HD;
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4)
+            *reinterpret_cast<f32x4*>(o + 4 * c4) = f32x4{acc[4 * c4] * inv, acc[4 * c4 + 1] * inv, acc[4 * c4 + 2] * inv, acc[4 * c4 + 3] * inv};
+    }
+}
+
 }  // namespace mh

@@ -67,7 +67,8 @@ conv3d_k3_wino2p_kernel(Tensor in, const float* __restrict__ up, const float* __
     const int T = (p_last - p_first + 1) * NSTG;              // stages this workgroup runs
 
     // staging: wave w stages channel w of the stage; lane elements e = lane + 64 j of the 18 x 18 region
-    int soff[W2_SLOTS], loff[W2_SLOTS];
+    unsigned soff[W2_SLOTS];          // BYTE offsets, unsigned: `global_load_dword v, v_off, s[base]` -- no per-load 64-bit VALU address arithmetic
+    int loff[W2_SLOTS];
     unsigned sokm = 0u;
 #pragma unroll
     for (int j = 0; j < W2_SLOTS; ++j) {
@@ -77,7 +78,7 @@ conv3d_k3_wino2p_kernel(Tensor in, const float* __restrict__ up, const float* __
         const bool inreg = e < W2_R * W2_R;
         const bool ok = inreg && gy >= 0 && gy < H && gx >= 0 && gx < W;
         sokm |= (unsigned)ok << j;
-        soff[j] = ok ? gy * W + gx : 0;
+        soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
         loff[j] = inreg ? wave * W2_CS + ly * W2_PX + lx : -1;
     }
     float* const dump = zslab_w + W2_ZSLAB + lane;
@@ -95,20 +96,39 @@ conv3d_k3_wino2p_kernel(Tensor in, const float* __restrict__ up, const float* __
     f32x4 uin[4];
 #define MH_W2P_ISSUE                                                                                  \
     {                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) xin[j] = xptr[soff[j]];                  \
+        const unsigned long long xa_ = reinterpret_cast<unsigned long long>(xptr);                   \
+        const char* xq_ = reinterpret_cast<const char*>(                                              \
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa_ >> 32)) << 32) |  \
+            (unsigned)__builtin_amdgcn_readfirstlane((int)xa_));          /* wave-uniform base in SGPRs */ \
+        _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) xin[j] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) uin[j] = uptr[512 * j];                         \
         xptr += xstep; uptr += W2P_UST / 4;                                                           \
         if (++is == NSTG) { is = 0; uptr = ug; xptr -= xwrap; ++ip; xptr += HW; }                     \
     }
+    // normalise + activate on the way into LDS.  y = fma(x, alpha, beta); leaky(y) = y > 0 ? y : y * slope equals max(y, y * slope)
+    // whenever slope <= 1 (LeakyReLU, ReLU, identity): three packed operations per PAIR of elements instead of four scalar ones
+    // per element; a slope > 1 (a trained PReLU could have one) takes the general form.  The records of a stage's channel are
+    // wave-uniform, so the choice is a scalar branch.
 #define MH_W2P_COMMIT(BUF)                                                                            \
     {                                                                                                 \
         float4 a_ = make_float4(1.0f, 0.0f, 1.0f, 0.0f);                                              \
         if (NRM) a_ = *reinterpret_cast<const float4*>(nptr + 4 * W2P_KB * cs);                       \
         float* xb_ = xs + (BUF) * W2P_XST;                                                            \
+        float val_[W2_SLOTS];                                                                         \
+        if (__builtin_amdgcn_readfirstlane(__float_as_int(a_.z)) <= 0x3f800000) {   /* slope <= 1 (or negative) */ \
+            const f32x2 al_ = {a_.x, a_.x}, be_ = {a_.y, a_.y}, sl_ = {a_.z, a_.z};                   \
+            _Pragma("unroll") for (int j = 0; j < W2_SLOTS; j += 2) {                                 \
+                f32x2 y_ = __builtin_elementwise_fma(f32x2{xin[j], xin[j + 1]}, al_, be_);            \
+                y_ = __builtin_elementwise_max(y_, y_ * sl_);                                         \
+                val_[j] = y_[0]; val_[j + 1] = y_[1];                                                 \
+            }                                                                                         \
+        } else {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) val_[j] = act(xin[j], a_.x, a_.y, a_.z); \
+        }                                                                                             \
         _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) {                                        \
-            const float val_ = ((sokm >> j) & 1u) ? act(xin[j], a_.x, a_.y, a_.z) : 0.0f;             \
-            if (64 * j + 63 < W2_R * W2_R) xb_[loff[j]] = val_;                                       \
-            else *(loff[j] >= 0 ? xb_ + loff[j] : dump) = val_;                                       \
+            const float v_ = ((sokm >> j) & 1u) ? val_[j] : 0.0f;                                     \
+            if (64 * j + 63 < W2_R * W2_R) xb_[loff[j]] = v_;                                         \
+            else *(loff[j] >= 0 ? xb_ + loff[j] : dump) = v_;                                         \
         }                                                                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
             reinterpret_cast<f32x4*>(us + (BUF) * W2P_UST)[tid + 512 * j] = uin[j];                   \

@@ -309,6 +309,27 @@ def attention(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
     return out
 
 
+def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qkv [BW, S, 3*heads*hd] -> [BW, S, heads*hd] = softmax((q*scale) k^T + bias[head] + mask[window % nW]) v per (window, head);
+    bias_t [heads, S, S] holds the relative position bias transposed (key-major), mask [nW, S, S] the shifted-window mask."""
+    _lib.require_device(qkv, bias_t, mask)
+    if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] % (3 * heads):
+        raise RuntimeError(f"monai_amd.window_attention: qkv must be contiguous [BW, S, 3*heads*hd], got {tuple(qkv.shape)}")
+    bw, s, c3 = qkv.shape
+    hd = c3 // (3 * heads)
+    if hd not in (8, 16, 32):
+        raise NotImplementedError(f"monai_amd.window_attention: head_dim {hd} is not on the HIP path (8, 16, 32 are)")
+    for t, nm in ((bias_t, "bias_t"), (mask, "mask")):
+        if t is not None and (not t.is_contiguous() or tuple(t.shape[1:]) != (s, s)):
+            raise RuntimeError(f"monai_amd.window_attention: {nm} must be contiguous [*, {s}, {s}], got {tuple(t.shape)}")
+    if bias_t is not None and bias_t.shape[0] != heads:
+        raise RuntimeError("monai_amd.window_attention: bias_t must have one [S, S] table per head")
+    nw = int(mask.shape[0]) if mask is not None else 1
+    out = torch.empty((bw, s, heads * hd), dtype=torch.float32, device=qkv.device)
+    _lib.lib().call("mh_window_attention_f32", _lib.ptr(qkv), _lib.ptr(bias_t), _lib.ptr(mask), _lib.ptr(out), bw, nw, s, int(heads), hd, float(scale), _s(qkv))
+    return out
+
+
 def conv3d_k3_strided(x, x_nrm, packed_w0, bias, out, stride: int):
     """out = conv3x3x3(act(x), stride, padding 1) + bias; packed_w0 = conv3d_k3_pack(0, weight)."""
     _lib.require_device(x, x_nrm, packed_w0, bias, out)

@@ -43,6 +43,7 @@ _TARGETS = {
     },
     "monai.networks.nets.segresnet": {"SegResNet": ("monai_amd.networks.nets.segresnet", "SegResNet")},
     "monai.networks.nets.unetr": {"UNETR": ("monai_amd.networks.nets.unetr", "UNETR")},
+    "monai.networks.nets.swin_unetr": {"SwinUNETR": ("monai_amd.networks.nets.swin_unetr", "SwinUNETR")},
     "monai.networks.nets.unet": {"UNet": ("monai_amd.networks.nets.unet", "UNet"), "Unet": ("monai_amd.networks.nets.unet", "UNet")},
     "monai.transforms.spatial.array": {
         "Spacing": ("monai_amd.transforms.spatial.array", "Spacing"),

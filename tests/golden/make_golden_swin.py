@@ -1,0 +1,40 @@
+"""Golden vectors for SwinUNETR from the REAL reference (build container only):
+    PYTHONPATH=/root/reference python tests/golden/make_golden_swin.py
+Seeded default initialisation (state_dict digest), logits of small configurations on CPU."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, "/root/reference")
+from monai.networks.nets import SwinUNETR  # noqa: E402
+
+out = {}
+CASES = {
+    "a": dict(kw=dict(in_channels=1, out_channels=3, feature_size=24), shape=(1, 1, 64, 64, 64), seed=5),
+    "b": dict(kw=dict(in_channels=2, out_channels=4, feature_size=24, downsample="mergingv2", qkv_bias=False, normalize=False), shape=(2, 2, 64, 64, 96), seed=6),
+    "c": dict(kw=dict(in_channels=1, out_channels=5, feature_size=48), shape=(1, 1, 96, 96, 96), seed=7),
+}
+for name, c in CASES.items():
+    torch.manual_seed(c["seed"])
+    net = SwinUNETR(**c["kw"]).eval()
+    sd = net.state_dict()
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().numpy().tobytes())
+    out[f"{name}_digest"] = np.frombuffer(h.digest(), dtype=np.uint8)
+    out[f"{name}_keys"] = np.array(sorted(sd))
+    torch.manual_seed(100 + c["seed"])
+    x = torch.rand(c["shape"])
+    with torch.no_grad():
+        y = net(x)
+    # inputs are regenerated from the seed (torch CPU generator); outputs are stored on a stride-2 (a, b) / stride-3 (c) sub-lattice
+    st = 3 if name == "c" else 2
+    out[f"{name}_y"] = y.numpy()[:, :, ::st, ::st, ::st].copy()
+    out[f"{name}_stride"] = np.array(st)
+    out[f"{name}_xsum"] = np.array(float(x.double().sum()))
+    print(name, y.shape, float(y.abs().max()))
+np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "swin_unetr.npz"), **out)

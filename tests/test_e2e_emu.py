@@ -43,6 +43,12 @@ def test_slabwise_equals_whole(emu):
     print(ec.case_slabwise_equals_whole("cpu"))
 
 
+def test_swin_unetr_vs_reference(emu):
+    import swin_cases as sc
+
+    print(sc.case_swin_unetr_vs_golden("cpu", names=("a",)))
+
+
 def test_fused_argmax_epilogue(emu):
     assert ec.case_fused_argmax_epilogue("cpu")
 

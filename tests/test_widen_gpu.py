@@ -116,3 +116,10 @@ def test_flip_rotate90_vs_reference():
 
     print("arrays", fc.case_flip_rotate_vs_reference(DEV))
     fc.case_flip_rotate_api(DEV)
+
+
+def test_swin_unetr_vs_reference():
+    """SwinUNETR (windowed attention kernel + the shared conv engine) against the real reference's logits"""
+    import swin_cases as sc
+
+    print(sc.case_swin_unetr_vs_golden("cuda"))
