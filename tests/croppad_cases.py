@@ -97,8 +97,8 @@ def case_croppad_api(device):
         SpatialCrop(roi_center=[1, 1, 1])
     with pytest.raises(ValueError):
         SpatialCrop(roi_slices=[slice(0, 4, 2)])
-    with pytest.raises(NotImplementedError):
-        SpatialPad(8, lazy=True)
+    # lazy execution is supported (monai_amd/transforms/lazy.py): the switch is recorded, nothing raises
+    assert SpatialPad(8, lazy=True).lazy is True
     with pytest.raises(KeyError):
         SpatialPadd(keys=["missing"], spatial_size=8)({"image": x})
     with pytest.raises(NotImplementedError):

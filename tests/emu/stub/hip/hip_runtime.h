@@ -284,6 +284,7 @@ static inline float __fadd_rn(float a, float b) { volatile float r = a + b; retu
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline float __fsqrt_rn(float a) { return std::sqrt(a); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 using std::fmaf;
 using std::max;
 using std::min;

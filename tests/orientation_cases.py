@@ -121,7 +121,7 @@ def case_orientation_api(device):
     with pytest.warns(UserWarning):
         yl = Orientation(axcodes="LAS")(lab)
     assert yl.dtype == torch.int16 and torch.equal(yl.cpu(), torch.flip(lab.cpu(), [1]))
-    with pytest.raises(NotImplementedError):
-        Orientation(axcodes="RAS", lazy=True)
+    # lazy execution is supported (monai_amd/transforms/lazy.py): the switch is recorded, nothing raises
+    assert Orientation(axcodes="RAS", lazy=True).lazy is True
     with pytest.raises(KeyError):
         Orientationd(keys=["missing"], axcodes="RAS")({"image": x})

@@ -158,8 +158,8 @@ def case_preproc_api(device):
         CropForeground(margin=-1)(x)
     with pytest.raises(NotImplementedError):
         CropForeground(mode="reflect")(x)
-    with pytest.raises(NotImplementedError):
-        CropForeground(lazy=True)
+    # lazy execution is supported (monai_amd/transforms/lazy.py): the switch is recorded, nothing raises
+    assert CropForeground(lazy=True).lazy is True
     with pytest.raises(NotImplementedError):
         ScaleIntensityRange(0.0, 1.0)(x.double())
     with pytest.raises(KeyError):

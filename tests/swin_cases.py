@@ -27,10 +27,15 @@ def case_swin_unetr_vs_golden(device, names=("a", "b", "c")):
         sd = net.state_dict()
         assert sorted(sd) == list(g[f"{name}_keys"]), name
         h = hashlib.sha256()
+        tabs = []
         for k in sorted(sd):
+            if k.endswith("relative_position_bias_table"):      # truncated normal: erfinv_ differs in the last bit between CPU vector ISAs
+                tabs.append(sd[k].detach().cpu().numpy().reshape(-1))
+                continue
             h.update(k.encode())
             h.update(sd[k].detach().cpu().numpy().tobytes())
         assert h.digest() == bytes(g[f"{name}_digest"]), f"{name}: same seed must give the reference's initial weights"
+        assert np.allclose(np.concatenate(tabs), g[f"{name}_tables"], rtol=0, atol=1e-6), name
         torch.manual_seed(100 + c["seed"])
         x = torch.rand(c["shape"])
         assert abs(float(x.double().sum()) - float(g[f"{name}_xsum"])) < 1e-6
