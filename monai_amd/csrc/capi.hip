@@ -1022,11 +1022,49 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     memcpy(a.kz + (rk - kz_n) / 2, kz, sizeof(float) * kz_n);
     memcpy(a.ky + (rk - ky_n) / 2, ky, sizeof(float) * ky_n);
     memcpy(a.kx + (rk - kx_n) / 2, kx, sizeof(float) * kx_n);
+    bool iso = kz_n == ky_n && ky_n == kx_n;
+    for (int i = 0; iso && i < kz_n; ++i) iso = kz[i] == ky[i] && ky[i] == kx[i];
+    hipStream_t s = (hipStream_t)stream;
+    // float4-aligned volumes and up to 17 taps: the row-vector kernel (gaussian.h: 16-byte loads / stores, register x-pass, one barrier
+    // per plane); MONAI_AMD_GS_IMPL=tile forces the round-1 tile kernel (bit-identical results)
+    const char* impl = getenv("MONAI_AMD_GS_IMPL");
+    if (rk <= 17 && W % 4 == 0 && aligned(src, 16) && aligned(dst, 16) && !(impl && impl[0] == 't')) {
+        const long long vtiles = (long long)cdiv(W, GV_TX) * cdiv(H, GV_TY);
+        static int vslots[4][2];
+        const int vi = rk == 3 ? 0 : rk == 5 ? 1 : rk == 9 ? 2 : 3;
+        int& vs = vslots[vi][iso ? 1 : 0];
+        if (vs == 0) {
+#define MH_GV_SLOTS(RK_) vs = iso ? resident_wgs(gauss3d_rowvec_kernel<RK_, true>, 64 * gv_waves(RK_)) : resident_wgs(gauss3d_rowvec_kernel<RK_, false>, 64 * gv_waves(RK_));
+            switch (rk) {
+                case 3: MH_GV_SLOTS(3) break;
+                case 5: MH_GV_SLOTS(5) break;
+                case 9: MH_GV_SLOTS(9) break;
+                default: MH_GV_SLOTS(17) break;
+            }
+#undef MH_GV_SLOTS
+        }
+        const int vmin = 4 * rk > 16 ? 4 * rk : 16;
+        const int vchunks = stream_chunks(vtiles * NC, D, vs, rk - 1, vmin, "MONAI_AMD_GS_CHUNKS");
+        a.zchunk = cdiv(D, vchunks);
+        a.nchunk = cdiv(D, a.zchunk);
+        a.pair_ok = 1;
+        const long long vwg = vtiles * a.nchunk * NC;
+        if (vwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: problem too large for one launch");
+#define MH_GV(RK_)                                                                                                        \
+        if (iso) hipLaunchKernelGGL((gauss3d_rowvec_kernel<RK_, true>), dim3((unsigned)vwg), dim3(64 * gv_waves(RK_)), 0, s, src, dst, a);   \
+        else hipLaunchKernelGGL((gauss3d_rowvec_kernel<RK_, false>), dim3((unsigned)vwg), dim3(64 * gv_waves(RK_)), 0, s, src, dst, a);
+        switch (rk) {
+            case 3: MH_GV(3) break;
+            case 5: MH_GV(5) break;
+            case 9: MH_GV(9) break;
+            default: MH_GV(17) break;
+        }
+#undef MH_GV
+        return launched("separable_filter3d_rowvec");
+    }
     // cut z into chunks (each re-filters rk-1 halo planes) that fill whole rounds of the resident workgroup slots
     const long long tiles = (long long)cdiv(W, GS_TX) * cdiv(H, GS_TY);
     const int min_chunk = 4 * rk > 16 ? 4 * rk : 16;
-    bool iso = kz_n == ky_n && ky_n == kx_n;
-    for (int i = 0; iso && i < kz_n; ++i) iso = kz[i] == ky[i] && ky[i] == kx[i];
     static int slots[5][2];
     const int ri = rk == 3 ? 0 : rk == 5 ? 1 : rk == 9 ? 2 : rk == 17 ? 3 : 4;
     int& sl = slots[ri][iso ? 1 : 0];
@@ -1048,7 +1086,6 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     const long long nwg = tiles * a.nchunk * NC;
     if (nwg > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "separable_filter3d: problem too large for one launch");
     const dim3 grid((unsigned)nwg);
-    hipStream_t s = (hipStream_t)stream;
 #define MH_GAUSS(RK_)                                                                                             \
     if (iso) hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, true>), grid, dim3(256), 0, s, src, dst, a);          \
     else hipLaunchKernelGGL((gauss3d_stream_kernel<RK_, false>), grid, dim3(256), 0, s, src, dst, a);

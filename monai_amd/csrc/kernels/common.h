@@ -5,6 +5,14 @@
 
 #include "../../../include/monai_amd.h"
 
+// value barrier for the optimiser (no instruction): keeps a scalar chain out of SLP vectorisation where packing costs more moves than it
+// saves.  The SIMT emulator of tests/emu compiles these sources for the host, where the register constraint does not exist.
+#ifdef MH_SIMT_EMULATOR
+#define MH_OPAQUE(x) ((void)0)
+#else
+#define MH_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
+
 namespace mh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -172,4 +172,165 @@ __global__ void __launch_bounds__(256) gauss3d_stream_kernel(const float* __rest
 #undef GS_EMIT
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Row-vector variant for float4-aligned volumes (W % 4 == 0, 16-byte aligned pointers) -- the same single HBM pass,
+// organised so that the memory system, not LDS staging or VALU issue, is the bound:
+//   * a workgroup = 8 waves owns a 16 (y) x 256 (x) output tile of one z-chunk; a lane owns FOUR consecutive x (one 16-byte
+//     load / store per row and plane: 1 KB per wave-instruction);
+//   * x-pass in registers: the wave's row segment goes through a wave-private LDS row (one 16-byte write, 2 * ceil(HR / 4)
+//     16-byte reads of the neighbouring lanes' vectors -- no second, shifted copy of the plane, no workgroup barrier);
+//     the 4 * HL-float halo on either side of the segment is loaded by the first / last HL lanes;
+//   * y-pass through one LDS plane of x-filtered rows (16-byte reads), double buffered: ONE barrier per plane;
+//   * z-pass from a register ring of the last RK y-filtered rows (two output rows per wave); for RK <= 9 the march is unrolled
+//     RK planes at a time so the ring never moves.
+// Tap order, fused multiply-adds and zero padding as in gauss3d_stream_kernel: the results are bit-identical to it.
+// (hipcc's SLP pass packs the x-pass tap chains into v_pk_fma_f32 although their register pairs are unaligned; keeping them scalar
+// with a value barrier after every FMA was measured SLOWER: 0.313 vs 0.272 ms per 512^3 volume.)
+constexpr int GV_LANES = 64, GV_TX = 4 * GV_LANES, GV_TY = 16;
+// waves per workgroup: 16 (one output row each, 86 registers, four waves per SIMD) up to 9 taps -- measured 0.241 ms per 512^3 volume
+// against 0.268 with 8 waves x 2 rows (206 registers, two waves per SIMD: issue- and latency-bound) and 0.286 for the tile kernel;
+// 17 taps keep 8 x 2 (their register ring does not fit 128 registers: 0.47 vs 0.58 ms)
+constexpr int gv_waves(int rk) { return rk <= 9 ? 16 : 8; }
+
+template <int RK, bool ISO>
+__global__ void __launch_bounds__(64 * gv_waves(RK)) gauss3d_rowvec_kernel(const float* __restrict__ src, float* __restrict__ dst, GaussArgs a) {
+    constexpr int GV_WAVES = gv_waves(RK), GV_ROWS = GV_TY / GV_WAVES;
+    constexpr int HR = (RK - 1) / 2;
+    constexpr int HL = (HR + 3) / 4;                         // halo vectors on either side of a lane's vector
+    constexpr int NR = GV_TY + 2 * HR;                       // rows of the tile's halo plane
+    constexpr int XR = (NR + GV_WAVES - 1) / GV_WAVES;       // rows a wave x-filters per plane
+    constexpr int RP = GV_LANES + 2 * HL;                    // vectors in a wave-private row
+    constexpr int OFF = 4 * HL - HR;                         // first tap of output 0 inside the window of 4 + 8 HL floats
+    constexpr int DEPTH = 1;                                 // source planes in flight (two were measured: no gain, +40 registers)
+    __shared__ __attribute__((aligned(16))) float mid[2][NR * GV_TX];
+    __shared__ __attribute__((aligned(16))) float rowbuf[GV_WAVES][RP * 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* wkx = a.kx;
+    const float* wky = ISO ? a.kx : a.ky;
+    const float* wkz = ISO ? a.kx : a.kz;
+    const int tiles_x = (a.W + GV_TX - 1) / GV_TX, tiles = tiles_x * ((a.H + GV_TY - 1) / GV_TY);
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % (unsigned)tiles);
+    lid /= (unsigned)tiles;
+    const int chunk = (int)(lid % (unsigned)a.nchunk), nc = (int)(lid / (unsigned)a.nchunk);
+    const int tx0 = (tile % tiles_x) * GV_TX, ty0 = (tile / tiles_x) * GV_TY;
+    const int zs = chunk * a.zchunk, ze = min(zs + a.zchunk, a.D);
+    const int zfirst = max(zs - HR, 0), zlast = min(ze + HR, a.D);
+    const long long plane = (long long)a.H * a.W;
+    const float* vol = src + (long long)nc * a.D * plane;
+    float* ovol = dst + (long long)nc * a.D * plane;
+
+    // this lane's global offsets inside a plane: centre vector of each of its x-pass rows, and -- for the first / last HL
+    // lanes -- the halo vector left / right of the wave's segment (-1: outside the image, zeros)
+    const int gx = tx0 + 4 * lane;
+    int coff[XR], eoff[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int r = wave + GV_WAVES * i, gy = ty0 + r - HR;
+        const bool rok = r < NR && gy >= 0 && gy < a.H;
+        coff[i] = rok && gx < a.W ? gy * a.W + gx : -1;
+        int hx = -1;
+        if (lane < HL) hx = tx0 - 4 * HL + 4 * lane;
+        else if (lane >= GV_LANES - HL) hx = tx0 + GV_TX + 4 * (lane - (GV_LANES - HL));
+        eoff[i] = rok && hx >= 0 && hx < a.W && (lane < HL || lane >= GV_LANES - HL) ? gy * a.W + hx : -1;
+    }
+    f32x4 cur[DEPTH][XR], ext[DEPTH][XR];          // two planes in flight: one alone leaves too few bytes outstanding per CU for HBM's latency
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#define GV_LOAD(Z, SET)                                                                               \
+    {                                                                                                 \
+        const float* pl_ = vol + (long long)(Z) * plane;                                              \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                              \
+            cur[SET][i] = coff[i] >= 0 ? *reinterpret_cast<const f32x4*>(pl_ + coff[i]) : zero4;      \
+            ext[SET][i] = eoff[i] >= 0 ? *reinterpret_cast<const f32x4*>(pl_ + eoff[i]) : zero4;      \
+        }                                                                                             \
+    }
+    f32x4 ring[GV_ROWS][RK];
+#pragma unroll
+    for (int p = 0; p < GV_ROWS; ++p)
+#pragma unroll
+        for (int k = 0; k < RK; ++k) ring[p][k] = zero4;
+    const int y2 = GV_ROWS * wave;
+    bool rowok[GV_ROWS];
+#pragma unroll
+    for (int p = 0; p < GV_ROWS; ++p) rowok[p] = ty0 + y2 + p < a.H && gx < a.W;
+    float* const obase = ovol + (long long)(ty0 + y2) * a.W + gx;
+    f32x4* const myrow = reinterpret_cast<f32x4*>(rowbuf[wave]);
+    int buf = 0;
+
+    // x- and y-pass of source plane Z -> this wave's GV_ROWS y-filtered row vectors v_[]; prefetches plane Z + 1
+#define GV_PLANE(Z, V, SET)                                                                           \
+    {                                                                                                 \
+        float* mb_ = mid[buf];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                              \
+            const int r_ = wave + GV_WAVES * i;                                                       \
+            if (r_ < NR) {                                                                            \
+                myrow[HL + lane] = cur[SET][i];                                                       \
+                if (lane < HL) myrow[lane] = ext[SET][i];                                             \
+                else if (lane >= GV_LANES - HL) myrow[2 * HL + lane] = ext[SET][i];                   \
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                \
+                __builtin_amdgcn_wave_barrier();                                                      \
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                \
+                float w_[4 + 8 * HL];                                                                 \
+                _Pragma("unroll") for (int j = 0; j <= 2 * HL; ++j) {                                 \
+                    const f32x4 t_ = j == HL ? cur[SET][i] : myrow[lane + j];                         \
+                    w_[4 * j] = t_[0]; w_[4 * j + 1] = t_[1]; w_[4 * j + 2] = t_[2]; w_[4 * j + 3] = t_[3]; \
+                }                                                                                     \
+                float o_[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                               \
+                _Pragma("unroll") for (int k = 0; k < RK; ++k)                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[e] = fmaf(wkx[k], w_[OFF + e + k], o_[e]); \
+                *reinterpret_cast<f32x4*>(mb_ + r_ * GV_TX + 4 * lane) = f32x4{o_[0], o_[1], o_[2], o_[3]}; \
+                __builtin_amdgcn_wave_barrier();        /* the row buffer is reused by the next row */ \
+            }                                                                                         \
+        }                                                                                             \
+        if ((Z) + DEPTH < zlast) GV_LOAD((Z) + DEPTH, SET)                                            \
+        __syncthreads();                                                                              \
+        _Pragma("unroll") for (int p = 0; p < GV_ROWS; ++p) V[p] = zero4;                             \
+        _Pragma("unroll") for (int j = 0; j < RK + GV_ROWS - 1; ++j) {                                \
+            const f32x4 m_ = *reinterpret_cast<const f32x4*>(mb_ + (y2 + j) * GV_TX + 4 * lane);      \
+            _Pragma("unroll") for (int p = 0; p < GV_ROWS; ++p)                                       \
+                if (j - p >= 0 && j - p < RK)       /* two v_pk_fma_f32: the kernel is VALU-issue bound, not HBM bound, without them */ \
+                    V[p] = __builtin_elementwise_fma(f32x4{wky[j - p], wky[j - p], wky[j - p], wky[j - p]}, m_, V[p]); \
+        }                                                                                             \
+        buf ^= 1;                                                                                     \
+    }
+    // z-pass over the ring in slot order S0, S0+1, ... (oldest first) and store of output plane ZO
+#define GV_EMIT(ZO, S0)                                                                               \
+    {                                                                                                 \
+        _Pragma("unroll") for (int p = 0; p < GV_ROWS; ++p) {                                         \
+            f32x4 acc_ = zero4;                                                                       \
+            _Pragma("unroll") for (int k = 0; k < RK; ++k) {                                          \
+                const f32x4 rv_ = ring[p][((S0) + k) % RK];                                           \
+                acc_ = __builtin_elementwise_fma(f32x4{wkz[k], wkz[k], wkz[k], wkz[k]}, rv_, acc_);     \
+            }                                                                                         \
+            if (rowok[p]) *reinterpret_cast<f32x4*>(obase + (long long)(ZO) * plane + (long long)p * a.W) = acc_; \
+        }                                                                                             \
+    }
+
+    GV_LOAD(zfirst, 0)
+    if (DEPTH > 1 && zfirst + 1 < zlast) GV_LOAD(zfirst + 1, DEPTH - 1)
+    // the ring is shifted by register moves (2 x (RK - 1) 16-byte moves per plane).  Keeping it still -- unrolling the march RK planes
+    // deep, or a switch over the slot -- makes hipcc spill or copy the whole ring at every merge point (measured: 254 registers + 34
+    // spilled; 401 v_mov_b64 per kernel).
+    for (int z = zfirst; z < ze + HR; ++z) {
+        f32x4 v_[GV_ROWS];
+        if (z < zlast) {
+            if (DEPTH > 1 && ((z - zfirst) & 1)) GV_PLANE(z, v_, DEPTH - 1) else GV_PLANE(z, v_, 0)
+        } else {
+#pragma unroll
+            for (int p = 0; p < GV_ROWS; ++p) v_[p] = zero4;              // beyond the volume: zero padding
+        }
+#pragma unroll
+        for (int p = 0; p < GV_ROWS; ++p) {
+#pragma unroll
+            for (int k = 0; k < RK - 1; ++k) ring[p][k] = ring[p][k + 1];
+            ring[p][RK - 1] = v_[p];
+        }
+        if (z - HR >= zs) GV_EMIT(z - HR, 0)
+    }
+#undef GV_EMIT
+#undef GV_PLANE
+#undef GV_LOAD
+}
+
 }  // namespace mh

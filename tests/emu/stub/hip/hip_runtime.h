@@ -254,6 +254,7 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
 }  // namespace emu
 
 // ------------------------------------------------------------------ HIP surface used by the product sources
+#define MH_SIMT_EMULATOR 1
 #define __global__ static
 #define __device__
 #define __host__
@@ -271,6 +272,8 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::wave_sync()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu::wave_read(v, emu::ctx().cur->lane ^ mask); }

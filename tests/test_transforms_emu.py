@@ -102,6 +102,10 @@ def test_gaussian_z_chunks(emu):
     tc.case_gaussian_z_chunks("cpu")
 
 
+def test_gaussian_rowvec_equals_tile(emu):
+    tc.case_gaussian_rowvec_equals_tile("cpu")
+
+
 def test_resample_compiled_vs_reference(emu):
     print("worst error", tc.case_resample_compiled_vs_reference("cpu"))
 

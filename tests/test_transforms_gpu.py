@@ -116,6 +116,10 @@ def test_separable_fast_path_equals_general():
     tc.case_separable_vs_general(DEV)
 
 
+def test_gaussian_rowvec_equals_tile():
+    tc.case_gaussian_rowvec_equals_tile(DEV)
+
+
 def test_gaussian_z_chunks():
     tc.case_gaussian_z_chunks(DEV)
 

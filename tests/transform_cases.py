@@ -616,6 +616,39 @@ def case_gaussian_z_chunks(device):
         assert (y.cpu().double() - ref[0]).abs().max().item() < 2e-6, shape
 
 
+def case_gaussian_rowvec_equals_tile(device):
+    """The row-vector kernel (float4-aligned volumes, gaussian.h: 16-byte loads, register x-pass, one barrier per plane) performs the
+    taps in the order of the round-1 tile kernel: BIT-IDENTICAL outputs -- ragged tiles (W = 260: a second x-tile with one live lane;
+    H = 19), every tap-count class (3 / 5 / 9 / 17), anisotropic kernels, several z-chunks; plus a zero-padded fp64 convolution."""
+    import os
+
+    import torch.nn.functional as F
+
+    from monai_amd import ops
+    from monai_amd.networks.layers import gaussian_1d
+
+    torch.manual_seed(23)
+    for shape, sig in (((2, 40, 19, 260), (1.0, 1.0, 1.0)), ((1, 70, 33, 64), (0.5, 1.0, 2.0)), ((1, 21, 16, 512), (0.4, 0.4, 0.4)),
+                       ((1, 37, 35, 20), (2.0, 2.0, 2.0)), ((1, 9, 8, 8), (0.7, 0.7, 0.7))):
+        x = torch.rand(shape).to(device)
+        ks = [gaussian_1d(torch.tensor(s)).numpy() for s in sig]
+        os.environ["MONAI_AMD_GS_IMPL"] = "tile"
+        try:
+            a = ops.separable_filter3d(x, ks)
+        finally:
+            del os.environ["MONAI_AMD_GS_IMPL"]
+        b = ops.separable_filter3d(x, ks)
+        assert torch.equal(a, b), (shape, sig, float((a - b).abs().max()))
+        ref = x.cpu().double()[None]
+        for ax, k in enumerate(ks):
+            shp = [1, 1, 1, 1, 1]
+            shp[2 + ax] = len(k)
+            pad = [0, 0, 0]
+            pad[ax] = len(k) // 2
+            ref = F.conv3d(ref.transpose(0, 1), torch.as_tensor(k).double().reshape(shp), padding=pad).transpose(0, 1)
+        assert (b.cpu().double() - ref[0]).abs().max().item() < 2e-6, shape
+
+
 def case_separable_vs_general(device):
     """The axis-aligned fast path (per-axis tap tables + LDS-staged source box, with its global-gather fallback when the
     box does not fit) must give exactly what the general kernel gives for the same matrix: a 1e-300 off-diagonal makes
