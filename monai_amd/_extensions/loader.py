@@ -47,6 +47,8 @@ def load_module(module_name: str, defines: dict | None = None, verbose_build: bo
     ``module.__file__`` is the shared library, ``module.cdll`` the ``ctypes.CDLL``."""
     from ..build import FLAGS, hipcc
 
+    if os.path.basename(module_name) != module_name or module_name in ("", ".", ".."):     # never resolve outside EXTENSION_DIRS
+        raise ValueError(f"No extension module named {module_name}")
     if module_name == "monai_amd":
         sources, deps = _package_sources()
     else:
@@ -70,21 +72,26 @@ def load_module(module_name: str, defines: dict | None = None, verbose_build: bo
     stale = not os.path.exists(out) or any(os.path.getmtime(out) < os.path.getmtime(s) for s in sources + deps)
     if stale:
         tmp = f"{out}.{os.getpid()}.tmp"
-        cmd = [hipcc()] + ["-x", "hip"] + FLAGS + define_args + sources + ["-o", tmp]
+        # `-x hip` applies to the files that follow it: device sources first, then `-x none` so host *.cpp files compile as plain C++
+        hip_src = [f for f in sources if not f.endswith(".cpp")]
+        cpp_src = [f for f in sources if f.endswith(".cpp")]
+        cmd = [hipcc()] + FLAGS + define_args + (["-x", "hip"] + hip_src if hip_src else []) + (["-x", "none"] + cpp_src if cpp_src else []) + ["-o", tmp]
         if verbose_build:
             print(" ".join(cmd), file=sys.stderr)
         pipe = None if verbose_build else subprocess.PIPE
         proc = subprocess.Popen(cmd, stdout=pipe, stderr=pipe, text=True, start_new_session=True)     # own process group: hipcc forks clang / lld
         try:
             _, err = proc.communicate(timeout=build_timeout)
-        except subprocess.TimeoutExpired as e:
+        except BaseException as e:          # timeout, Ctrl-C, anything: the detached compiler group must not outlive the call
             try:
                 os.killpg(proc.pid, signal.SIGKILL)       # exactly the group started above, compiler children included
             except ProcessLookupError:
                 pass
             proc.wait()
             _rm(tmp)
-            raise TimeoutError("Build appears to be blocked. Is there a stopped process building the same extension?") from e
+            if isinstance(e, subprocess.TimeoutExpired):
+                raise TimeoutError("Build appears to be blocked. Is there a stopped process building the same extension?") from e
+            raise
         if proc.returncode != 0:
             _rm(tmp)
             raise RuntimeError(f"Error building extension '{name}'" + ("" if verbose_build else f":\n{err}"))

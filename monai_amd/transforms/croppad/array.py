@@ -12,7 +12,7 @@ import torch
 from ... import ops
 from ...data.meta_tensor import affine_np, is_meta
 from ..lazy import LazyCapable, materialize, peek_shape, push_pending
-from ...utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple
+from ...utils.misc import as_gather_f32, ensure_tuple, ensure_tuple_rep, fall_back_tuple
 
 __all__ = ["CropForeground", "Pad", "SpatialPad", "BorderPad", "DivisiblePad", "Crop", "SpatialCrop", "CenterSpatialCrop", "is_positive",
            "generate_spatial_bounding_box", "compute_divisible_spatial_size"]
@@ -36,16 +36,17 @@ _INT_DTYPES = (torch.uint8, torch.int8, torch.int16, torch.int32, torch.int64, t
 
 def _run_crop_pad(data: torch.Tensor, start, size, value: float) -> torch.Tensor:
     """out[c, o] = data[c, o + start] inside `data`, `value` outside -- the crop + constant-pad kernel on a channel-first image with 1-3
-    spatial axes.  float32 directly; integer / bool images (label maps) through float32 and back, which is exact below 2^24."""
+    spatial axes.  The kernel copies 32-bit words: float32 directly, int32 as bit patterns, narrower integers / bool through float32
+    (exact), int64 only while every value is below 2^24 (`as_gather_f32`)."""
     if data.dtype != torch.float32 and data.dtype not in _INT_DTYPES:
         raise NotImplementedError(f"monai_amd crop / pad: {data.dtype} images are not on the HIP path (float32 and integer images are)")
     nsp = data.dim() - 1
     size = [int(v) for v in size]
     if any(v < 1 for v in size) or not data.numel():
         return data.new_zeros((data.shape[0],) + tuple(max(v, 0) for v in size))
-    x = _as4(data if data.dtype == torch.float32 else data.to(torch.float32))
-    out = ops.crop_pad(x, [0] * (3 - nsp) + [int(v) for v in start], [1] * (3 - nsp) + size, float(value)).reshape((data.shape[0],) + tuple(size))
-    return out if data.dtype == torch.float32 else out.to(data.dtype)
+    x32, kval, restore = as_gather_f32(data, value)
+    out = ops.crop_pad(_as4(x32), [0] * (3 - nsp) + [int(v) for v in start], [1] * (3 - nsp) + size, kval).reshape((data.shape[0],) + tuple(size))
+    return restore(out)
 
 
 def _wrap_crop_pad(img, out: torch.Tensor, start, cls_name: str, value: float):

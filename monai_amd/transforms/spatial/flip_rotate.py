@@ -13,7 +13,7 @@ import torch
 from ... import ops
 from ...data.meta_tensor import affine_np, is_meta
 from ..lazy import LazyCapable, LazyCapableDict, materialize, peek_affine, peek_shape, push_pending
-from ...utils.misc import ensure_tuple
+from ...utils.misc import as_gather_f32, ensure_tuple
 
 __all__ = ["Flip", "Flipd", "FlipD", "FlipDict", "Rotate90", "Rotate90d", "Rotate90D", "Rotate90Dict"]
 
@@ -49,9 +49,10 @@ def _flip_permute(img, perm, flips, record, transform=None, lazy: bool = False):
         raise NotImplementedError(f"monai_amd flip / rotate90: {data.dtype} images are not on the HIP path (float32 and integer images are)")
     size = tuple(int(v) for v in data.shape[1:])
     pad = 3 - sr
-    x4 = data.to(torch.float32).reshape((data.shape[0],) + (1,) * pad + size).contiguous()
+    x32, _, restore = as_gather_f32(data)             # int32 as bit patterns: exact for every value
+    x4 = x32.reshape((data.shape[0],) + (1,) * pad + size).contiguous()
     out = ops.flip_permute(x4, list(range(pad)) + [p + pad for p in perm], [False] * pad + list(flips))
-    out = out.reshape((data.shape[0],) + tuple(size[p] for p in perm)).to(data.dtype)
+    out = restore(out.reshape((data.shape[0],) + tuple(size[p] for p in perm)))
     if not is_meta(img):
         return out
     res = type(img)(out, meta=dict(img.meta), applied_operations=list(getattr(img, "applied_operations", [])))

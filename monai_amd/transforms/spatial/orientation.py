@@ -21,7 +21,7 @@ from ... import ops
 from ..lazy import LazyCapable, LazyCapableDict, materialize, peek_affine, peek_shape, push_pending
 from ...data.meta_tensor import is_meta
 from ...data.utils import to_affine_nd
-from ...utils.misc import ensure_tuple
+from ...utils.misc import as_gather_f32, ensure_tuple
 
 __all__ = ["Orientation", "Orientationd", "OrientationD", "OrientationDict", "io_orientation", "axcodes2ornt", "ornt_transform",
            "inv_ornt_aff", "aff2axcodes"]
@@ -174,9 +174,10 @@ class Orientation(LazyCapable):
         if data.dtype != torch.float32 and data.dtype not in ints:
             raise NotImplementedError(f"monai_amd.Orientation: {data.dtype} images are not on the HIP path (float32 and integer images are)")
         pad = 3 - sr
-        x4 = data.to(torch.float32).reshape((data.shape[0],) + (1,) * pad + spatial_shape).contiguous()      # label maps: exact below 2^24
+        x32, _, restore = as_gather_f32(data)         # label maps: int32 as bit patterns, exact for every value
+        x4 = x32.reshape((data.shape[0],) + (1,) * pad + spatial_shape).contiguous()
         out = ops.flip_permute(x4, list(range(pad)) + [p + pad for p in perm], [False] * pad + flips)
-        out = out.reshape((data.shape[0],) + tuple(spatial_shape[p] for p in perm)).to(data.dtype)
+        out = restore(out.reshape((data.shape[0],) + tuple(spatial_shape[p] for p in perm)))
         if not is_meta(data_array):
             return out
         res = type(data_array)(out, meta=dict(data_array.meta), applied_operations=list(getattr(data_array, "applied_operations", [])))

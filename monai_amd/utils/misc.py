@@ -51,3 +51,25 @@ def look_up_option(opt: Any, supported: Sequence[str], name: str = "option") -> 
         if val == s:
             return s
     raise ValueError(f"Unsupported {name}: {opt}, available options are {list(supported)}.")
+
+
+def as_gather_f32(data, pad_value: float = 0.0):
+    """View / convert a tensor for the pure-gather kernels (crop + pad, flip + permute), which copy 32-bit words without arithmetic:
+    float32 as is; int32 as its BIT PATTERN (exact for every value; pad value 0); narrower integers
+    / bool through float32 (exact: every value < 2^24); int64 through float32 only when every value is below 2^24 in magnitude --
+    otherwise ``NotImplementedError`` (with MONAI installed the call falls through to the reference, whose slicing is exact for every
+    dtype).  Returns (float32 tensor, pad value to hand to the kernel, restore function)."""
+    import torch
+
+    dt = data.dtype
+    if dt == torch.float32:
+        return data, float(pad_value), (lambda out: out)
+    if dt == torch.int32 and pad_value == 0:
+        return data.contiguous().view(torch.float32), 0.0, (lambda out: out.view(torch.int32))
+    if dt in (torch.uint8, torch.int8, torch.int16, torch.bool):
+        return data.to(torch.float32), float(pad_value), (lambda out: out.to(dt))
+    if dt in (torch.int64, torch.int32):      # int32 with a non-zero pad value: small ints are denormal / NaN bit patterns, no float argument carries them
+        if data.numel() and int(data.abs().max()) >= (1 << 24):
+            raise NotImplementedError(f"monai_amd: {dt} images with values >= 2^24 are not on the HIP gather path here (float32 would lose bits)")
+        return data.to(torch.float32), float(pad_value), (lambda out: out.to(dt))
+    raise NotImplementedError(f"monai_amd: {dt} images are not on the HIP path (float32 and integer images are)")

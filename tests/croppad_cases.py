@@ -103,3 +103,18 @@ def case_croppad_api(device):
         SpatialPadd(keys=["missing"], spatial_size=8)({"image": x})
     with pytest.raises(NotImplementedError):
         SpatialPad(20)(x.double())
+    # integer images stay exact: int32 travels as its bit pattern, int64 only while float32 holds every value
+    from monai_amd.transforms import Flip
+
+    xi = torch.randint(-2 ** 31, 2 ** 31 - 1, (1, 6, 7, 8), dtype=torch.int64).to(torch.int32).to(device)
+    assert torch.equal(SpatialCrop(roi_start=(1, 2, 3), roi_end=(5, 6, 8))(xi), xi[:, 1:5, 2:6, 3:8])
+    y = SpatialPad((8, 9, 10))(xi)
+    assert y.dtype == torch.int32 and torch.equal(torch.as_tensor(y)[:, 1:7, 1:8, 1:9], xi) and int(y[0, 0, 0, 0]) == 0
+    assert torch.equal(torch.as_tensor(Flip(spatial_axis=[0, 2])(xi)), torch.flip(xi, [1, 3]))
+    xs = (xi % 1000).to(torch.int32)
+    y = SpatialPad((8, 9, 10), value=-7)(xs)
+    assert torch.equal(torch.as_tensor(y)[:, 1:7, 1:8, 1:9], xs) and int(y[0, 0, 0, 0]) == -7
+    with pytest.raises(NotImplementedError):
+        SpatialPad((8, 9, 10), value=-7)(xi)                       # >= 2^24 with a non-zero pad value: no exact route
+    with pytest.raises(NotImplementedError):
+        Flip(0)(torch.full((1, 4, 4, 4), 2 ** 40, dtype=torch.int64, device=device))

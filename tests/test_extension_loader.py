@@ -36,3 +36,14 @@ def test_build_cache_and_defines(loader):
 def test_build_timeout(loader):
     with pytest.raises(TimeoutError, match="Build appears to be blocked"):
         loader.load_module("axpb", defines={"AXPB_SCALE": 5, "UNIQUE": os.getpid()}, build_timeout=0.01)
+
+
+def test_names_outside_the_extension_dirs_are_rejected():
+    """a name with a path separator or '..' never leaves EXTENSION_DIRS (the reference only ever joins a bare directory name)"""
+    import pytest
+
+    from monai_amd._extensions import load_module
+
+    for bad in ("../csrc", "a/b", "..", os.sep + "tmp"):
+        with pytest.raises(ValueError):
+            load_module(bad)
