@@ -187,6 +187,11 @@ class SlidingWindowInferer(Inferer):
     ``{"_target_": "SlidingWindowInferer", "roi_size": [96, 96, 96], "sw_batch_size": 4, "overlap": 0.5, ...}``
     instantiates this class unchanged once ``monai_amd.patch`` has installed it.  The arithmetic runs in
     ``monai_amd.inferers.utils.sliding_window_inference``.
+
+    ``sw_batch_size``: a network with ``forward_into`` (the HIP conv engines) is handed up to 64 windows per launch instead
+    -- the result does not depend on it, peak memory does.  ``MONAI_AMD_STRICT_SW_BATCH=1`` keeps this argument as given,
+    ``MONAI_AMD_SW_BATCH=n`` sets the launch size.  half / bfloat16 volumes are widened to fp32 for the kernels and the result
+    returned in the caller's dtype; a CPU volume with a ROCm ``sw_device`` is moved to HBM once.
     """
 
     def __init__(

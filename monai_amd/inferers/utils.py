@@ -138,7 +138,10 @@ def sliding_window_inference(
     Differences, all result-neutral: ``buffer_steps`` / ``buffer_dim`` are validated and otherwise ignored (they are
     a memory-saving schedule of the reference, not a different result -- the blend here never materialises partial
     volumes; when the logits of all windows do not fit in HBM the volume is processed slab by slab along its first spatial
-    axis with bit-identical results, see ``_slabwise``); ``sw_device`` must be the ROCm device the inputs live on.  ``process_fn`` (utils.py:232-234) is honoured with
+    axis with bit-identical results, see ``_slabwise``); ``sw_device`` must be a ROCm device (a CPU volume is moved to it once; half / bfloat16 volumes are widened to fp32 and the result
+    returned in the caller's dtype).  A predictor with ``forward_into`` (the conv engines) is given up to 64 windows per launch
+    instead of ``sw_batch_size`` -- result-neutral, but it changes peak memory; MONAI_AMD_STRICT_SW_BATCH=1 keeps the caller's value
+    and MONAI_AMD_SW_BATCH=n sets it.  ``process_fn`` (utils.py:232-234) is honoured with
     the reference's semantics: each batch is multiplied by the weight map it returns, the count map uses the first batch's.
     """
     num_spatial_dims = inputs.dim() - 2
@@ -155,6 +158,22 @@ def sliding_window_inference(
     meta_src = inputs if (type(inputs) is not torch.Tensor and hasattr(inputs, "as_tensor")) else None
     if meta_src is not None:
         inputs = inputs.as_tensor()
+    # drop-in input handling (utils.py:146-153 take any float dtype and any inputs/sw_device pair): half / bfloat16 volumes are
+    # widened to fp32 for the kernels and the result is returned in the caller's dtype; a CPU volume with a ROCm `sw_device` is
+    # moved to HBM once (the reference moves it window by window) and the result goes back to `device` or the inputs' device
+    narrow = inputs.dtype if inputs.dtype in (torch.float16, torch.bfloat16) else None
+    host_in = (not inputs.is_cuda) and sw_device is not None and torch.device(sw_device).type == "cuda"
+    if narrow is not None or host_in:
+        x = inputs.to(device=torch.device(sw_device) if host_in else inputs.device, dtype=torch.float32)
+        out = sliding_window_inference(x, roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, sw_device,
+                                       device if device is not None else inputs.device, progress, roi_weight_map, process_fn, buffer_steps,
+                                       buffer_dim, with_coord, *args, **kwargs)
+        keys, parts = _flatten_struct(out)
+        if narrow is not None:
+            parts = [t.to(narrow) if t.is_floating_point() else t for t in parts]
+        if meta_src is not None:
+            parts = [_restore_meta(t, meta_src) for t in parts]
+        return _pack_struct(parts, keys)
     _lib.require_device(inputs)
     compute_dtype = inputs.dtype
     batch_size, in_ch, *image_size_ = inputs.shape

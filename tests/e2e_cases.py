@@ -207,6 +207,29 @@ def case_blend_only_vs_golden(device):
     assert i >= 5
 
 
+def case_narrow_and_host_inputs(device):
+    """half / bfloat16 volumes: computed in fp32, returned in the caller's dtype (== the fp32 result rounded once).  On a
+    real device: a CPU volume with sw_device= the ROCm device returns on the CPU with the device result's bits."""
+    from monai_amd.inferers import SlidingWindowInferer, sliding_window_inference
+
+    torch.manual_seed(3)
+    x = torch.rand(1, 1, 20, 22, 24)
+    pred = lambda w: torch.cat([w * 2.0 - 0.5, torch.sin(w)], dim=1)
+    kw = dict(overlap=0.5, mode="gaussian")
+    ref = sliding_window_inference(x.half().float().to(device), (16, 16, 16), 2, pred, **kw)
+    y = sliding_window_inference(x.half().to(device), (16, 16, 16), 2, pred, **kw)
+    assert y.dtype == torch.float16 and torch.equal(y, ref.half())
+    yb = SlidingWindowInferer((16, 16, 16), 2, **kw)(x.bfloat16().to(device), pred)
+    refb = sliding_window_inference(x.bfloat16().float().to(device), (16, 16, 16), 2, pred, **kw)
+    assert yb.dtype == torch.bfloat16 and torch.equal(yb, refb.bfloat16())
+    if torch.device(device).type == "cuda":
+        full = sliding_window_inference(x.to(device), (16, 16, 16), 2, pred, **kw)
+        yc = sliding_window_inference(x, (16, 16, 16), 2, pred, sw_device=device, **kw)
+        assert yc.device.type == "cpu" and torch.equal(yc, full.cpu())
+        yd = sliding_window_inference(x, (16, 16, 16), 2, pred, sw_device=device, device=device, **kw)
+        assert yd.device.type == "cuda" and torch.equal(yd, full)
+
+
 def case_process_fn_vs_golden(device):
     """`process_fn` (utils.py:232-238): predictions edited per batch, a weight map that changes from batch to batch, the
     count map built from the first batch's -- bit-exact against the real reference (tests/golden/make_golden_process_fn.py)."""

@@ -136,3 +136,7 @@ def test_dropout_arguments_are_inference_inert(emu):
         b = make(0.3).eval()
         assert list(a.state_dict().keys()) == list(b.state_dict().keys())
         assert torch.equal(a(x), b(x))
+
+
+def test_narrow_and_host_inputs(emu):
+    ec.case_narrow_and_host_inputs("cpu")

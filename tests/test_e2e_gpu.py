@@ -226,3 +226,7 @@ def test_bundle_shaped_pipeline_vs_reference():
     import pipeline_case as pl
 
     print(pl.case_pipeline_vs_reference(DEV))
+
+
+def test_narrow_and_host_inputs():
+    ec.case_narrow_and_host_inputs(DEV)
