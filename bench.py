@@ -252,7 +252,7 @@ def main(argv=None):
                     "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / PEAK_FP32_TFLOPS, "winograd_algorithmic_gain": gain,
                     "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
                     "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / args.steps / ms}
-            td = pmc_traffic("conv3d_k3_wino2d_kernel" if cfg_id == ncfg else "conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
+            td = (pmc_traffic("conv3d_k3_wino2p_kernel") or pmc_traffic("conv3d_k3_wino2d_kernel")) if cfg_id == ncfg else pmc_traffic("conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
             if td:
                 roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
         blend = spans.get("sw_blend")
@@ -264,7 +264,7 @@ def main(argv=None):
                         "bytes_per_launch": blend["work"] / blend["launches"],
                         "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s "
                                               "(profiles/r02_ubench_hbm_stream_v1.txt)"}
-            td = pmc_traffic("sw_blend_kernel")
+            td = pmc_traffic("sw_blend_reg_kernel") or pmc_traffic("sw_blend_kernel")
             if td:
                 roof_hbm["traffic"], roof_hbm["traffic_detail"] = td["hbm_bytes_per_launch"], td
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}

@@ -108,6 +108,11 @@ int mh_conv3d_k3_num_configs(void);                    /* highest configuration 
  * precision (fp32-equivalent results: every product is evaluated from six exact bf16 piece products with fp32 accumulation);
  * Cin % 16 == 0, Cout % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0; selected only under MONAI_AMD_CONV_ALGO=split. */
 int mh_conv3d_k3_split_config(void);
+/* Configuration outside 0 .. num_configs(): z-streaming direct convolution on the fp16 matrix cores in two-piece split
+ * precision (kernels/conv3d_h2.h) -- every fp32 operand as hi + lo fp16 pieces, products hi*hi + lo*hi + hi*lo accumulated in
+ * fp32: fp32-equivalent results (oracle BasicUNet: max |logit difference| 4e-6, the level of two fp32 summation orders) at 3/16
+ * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cout % 32 == 0, W % 4 == 0 and |activated input| < 65504. */
+int mh_conv3d_k3_h2_config(void);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 /* w: torch layout [Cout][Cin][3][3][3] */

@@ -15,6 +15,7 @@
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_wino2s.h"
 #include "kernels/conv3d_split.h"
+#include "kernels/conv3d_h2.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/pushpull.h"
@@ -299,6 +300,7 @@ static int conv_algo_mode() {
     if (!strcmp(e, "winograd")) return 2;
     if (!strcmp(e, "wino2d")) return 3;
     if (!strcmp(e, "split")) return 4;
+    if (!strcmp(e, "h2")) return 5;
     return 0;
 }
 
@@ -307,6 +309,9 @@ static int conv_algo_mode() {
 // configuration MH_CFG_SPLIT: direct implicit GEMM on the bf16 matrix cores in 3-piece split precision (kernels/conv3d_split.h);
 // experimental, not counted by mh_conv3d_k3_num_configs, selected only under MONAI_AMD_CONV_ALGO=split
 #define MH_CFG_SPLIT (MH_NUM_CFG + 3)
+// configuration MH_CFG_H2: z-streaming direct convolution on the fp16 matrix cores in two-piece split precision, fp32-equivalent
+// results (kernels/conv3d_h2.h); not counted by mh_conv3d_k3_num_configs (its tolerance class differs from the exact fp32 tiles)
+#define MH_CFG_H2 (MH_NUM_CFG + 4)
 // z-tiles (of 4 planes) a workgroup of the split-precision kernel marches through: a pure function of D
 static inline int split_ztiles(int D) { const int t = D / SP_TZ; return t % 4 == 0 ? 4 : t % 3 == 0 ? 3 : t % 2 == 0 ? 2 : 1; }
 // z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
@@ -328,12 +333,14 @@ static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cd
 
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_split_config(void) { return MH_CFG_SPLIT; }
+int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
     if (cfg == MH_CFG_SPLIT) return Cin >= SP_CC && Cin % SP_CC == 0 && Cin <= SP_NRM_MAX && Cout >= SP_CN && Cout % SP_CN == 0;
+    if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -364,6 +371,7 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
         if (mode == 3 || (mode == 0 && big)) best = MH_CFG_WINO2D;
     }
     if (mode == 4 && mh_conv3d_k3_accepts(MH_CFG_SPLIT, Cin, Cout) && D % SP_TZ == 0 && H % SP_TY == 0 && W % SP_TX == 0) best = MH_CFG_SPLIT;
+    if (mode == 5 && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0) best = MH_CFG_H2;
     return best;
 }
 
@@ -371,6 +379,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
     if (cfg == MH_CFG_SPLIT) return (int64_t)Cin * Cout * 27 * SP_NP / 2;      // three bf16 pieces per weight
+    if (cfg == MH_CFG_H2) return (int64_t)Cin * Cout * 27 + H2_TAIL;           // two fp16 pieces per weight + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -393,6 +402,14 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
         hipLaunchKernelGGL(conv3d_k3_split_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, reinterpret_cast<__bf16*>(packed));
         return launched("conv3d_k3_split_pack");
     }
+    if (cfg == MH_CFG_H2) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
+        float* tail = packed + (int64_t)Cin * Cout * 27;
+        hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
+        hipLaunchKernelGGL(conv3d_k3_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
+                           reinterpret_cast<_Float16*>(packed), tail);
+        return launched("conv3d_k3_h2_pack");
+    }
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
     const int cinp = cin_padded(cfg, Cin), coutp = cout_padded(cfg, Cout);
@@ -403,7 +420,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
-    if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
+    if (cfg == MH_CFG_WINO2D || cfg == MH_CFG_H2) return wino2d_blocks(D, H, W);
     if (cfg == MH_CFG_SPLIT) return cdiv(W, SP_TX) * cdiv(H, SP_TY) * cdiv(D, SP_TZ * split_ztiles(D));
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
@@ -425,9 +442,28 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_CFG_SPLIT) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_H2) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == MH_CFG_H2) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
+            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0, W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
+                        in.C, out.C, in.D, in.H, in.W);
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
+            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs 16-byte aligned output and weights");
+        const int bxn = cdiv(out.W, H2_B), byn = cdiv(out.H, H2_B), zc = wino2d_zchunk(out.D, out.H, out.W);
+        const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
+        const long long total = (long long)nblk * (out.C / H2_CN) * out.N;
+        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
+        const dim3 grid((unsigned)total);
+        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
+        const float* tail = packed_w + (int64_t)in.C * out.C * 27;
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
+        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
+        return launched("conv3d_k3_h2");
+    }
     if (cfg == MH_CFG_SPLIT) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % SP_TZ || in.H % SP_TY || in.W % SP_TX)
             return fail(MH_ERR_ARG, "conv3d_k3: the split-precision kernel needs Cin %% 16 == 0, Cout %% 32 == 0, D %% 4 == 0, H %% 8 == 0, W %% 8 == 0 (got %d -> %d, %dx%dx%d)",

@@ -1,0 +1,362 @@
+// Conv3d 3x3x3 / stride 1 / zero padding 1 on the FP16 matrix cores of gfx950 in two-piece split-precision arithmetic:
+// fp32-equivalent results at 3/16 of the fp32 matrix-core cycles of a direct convolution, z-streaming like conv3d_wino2p.h.
+//
+// Same reference op and "normalise on load" contract as conv3d_mfma.h (nn.Conv3d of `Convolution`,
+// monai/networks/blocks/convolutions.py:98-171, fed by the previous block's deferred InstanceNorm + LeakyReLU).
+//
+// Arithmetic.  Every fp32 operand is split into two fp16 pieces x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 11 + 11
+// significand bits, |x - hi - lo| <= 2^-23 |x|; the weights of a layer are first scaled by a power of two so that their low
+// pieces stay normal, the accumulator is scaled back in the epilogue -- both exact).  A product x * w is evaluated as
+// hi*hi + lo*hi + hi*lo, each piece product EXACT in fp32 (11 x 11 bits), accumulated in fp32 by v_mfma_f32_32x32x16_f16;
+// the dropped lo*lo term is <= 2^-22 relative.  This is the error-free-splitting scheme of Ootomo & Yokota (fp32 GEMM on fp16
+// tensor cores), without their second accumulator: gfx950's MFMA keeps fp16 subnormals (tools/ubench/mfma_f16.hip,
+// profiles/r02_ubench_mfma_f16.txt), so unscaled low pieces lose nothing that matters.  Measured on the oracle network
+// (tools/split_precision_numerics.py, BasicUNet, 2 x 64^3): max |logit difference| 4.0e-6 and identical argmax -- the noise
+// level of two fp32 summation orders (3.6e-6); bf16 pieces need three pieces and six products for the same (conv3d_split.h).
+// Range: |activated input| must stay below 65504 (fp16); InstanceNorm-ed inputs are bounded by sqrt(voxels) * |gamma| + |beta|.
+//
+// Mapping.  GEMM M = output voxels, N = 32 output channels, K = 16 input channels per instruction, one instruction group per tap.
+// A workgroup = 8 waves owns a 16 x 16 (y, x) region x 32 couts x one z-chunk and marches along z: input plane p is
+// multiplied with the three z-taps into the accumulator sets of output planes p+1, p, p-1 (three rotating sets of 16
+// registers), so every input plane is staged once.  Wave w owns rows 2w, 2w+1 of the region = one 32-voxel M block: operand
+// A lane l = voxel (l & 31) x channels 8 (l >> 5) .. +7 (one 16-byte LDS read of a [k-group][voxel][8 channels] plane),
+// operand B = cout (l & 31) x the same 8 channels, D lane = one cout x 16 voxels (statistics reduce in-lane).  Row pitch 20
+// voxels and the second row rotated by 4 voxels make the 16-byte operand reads bank-conflict free.
+//
+// A step = 16 input channels of one input plane: the plane region [2 pieces][2 k-groups][18 x 20 voxels][8 ch] (23 KB) and the
+// chunk's weight slab [2 pieces][27 taps][2 k-groups][32 couts][8 ch] (55 KB) sit in one of two LDS buffers; one barrier per
+// step; the global loads of step s + 2 are issued right after step s + 1 has been converted into LDS.  The fp16 MFMA -- unlike
+// the fp32 one -- co-issues with another wave's VALU / LDS / memory instructions (tools/ubench/mfma_f16.hip: the MFMA wave
+// keeps 32 cycles per instruction beside a VALU wave), so the two waves of a SIMD are de-phased: one converts the next step
+// while the other multiplies.  Per step and wave: 9 (ky, kx) groups of 2 A + 6 B operand reads -> 9 MFMAs.
+#pragma once
+#include "common.h"
+
+namespace mh {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int H2_B = 16;                                   // region edge (y and x) of a workgroup
+constexpr int H2_R = 18, H2_RS = 20;                       // input region edge, LDS row pitch in voxels
+constexpr int H2_PV = H2_R * H2_RS;                        // voxels of a staged plane (360)
+constexpr int H2_KC = 16, H2_CN = 32;                      // input channels per step (MFMA K), couts per workgroup
+constexpr int H2_XV = 2 * H2_PV;                           // uint4 per piece of a step's input plane: [k-group][voxel]
+constexpr int H2_XB = 2 * H2_XV;                           // uint4 per input buffer (two pieces): 1440
+constexpr int H2_WV = 27 * 2 * H2_CN;                      // uint4 per piece of a chunk's weight slab: [tap][k-group][cout]
+constexpr int H2_WB = 2 * H2_WV;                           // uint4 per weight buffer (two pieces): 3456
+constexpr int H2_SLOTS = 3;                                // staging tasks per lane: (voxel, 4 channels); 162 voxels per wave
+constexpr int H2_WSLOTS = (H2_WB + 511) / 512;             // 7 uint4 of the weight slab per thread
+constexpr int H2_TAIL = 4;                                 // floats behind the packed slabs: {1 / scale, scale, 0, 0}
+
+__device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+template <bool STATS, bool NRM>
+__global__ void __launch_bounds__(512, 1)
+conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
+                    float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
+    __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
+    uint4* const xs = smem;
+    uint4* const ws = smem + 2 * H2_XB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave >> 2;                                 // waves w and w + 4 share a SIMD: de-phased halves
+    const int Cin = in.C, Cout = out.C, D = out.D, H = out.H, W = out.W;
+    const long long HW = (long long)H * W, DHW = (long long)D * HW;
+    const int NCH = Cin / H2_KC;                              // steps per input plane (the launcher requires Cin % 16 == 0)
+
+    // launch geometry of conv3d_wino2d.h: 1-D over (window, region, cout group), cout group fastest, XCD-aware
+    const unsigned ncg = (unsigned)(Cout / H2_CN);
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = (int)(lid % ncg);
+    lid /= ncg;
+    const unsigned b = lid % nblk;
+    const int n = (int)(lid / nblk);
+    const int x0 = (int)(b % bxn) * H2_B, y0 = (int)((b / bxn) % byn) * H2_B;
+    const int zs = (int)(b / (bxn * byn)) * zchunk, ze = min(zs + zchunk, D);
+    const int p_first = max(zs - 1, 0), p_last = min(ze, D - 1);
+    const int T = (p_last - p_first + 1) * NCH;               // steps this workgroup runs
+
+    // input staging: wave w converts channels 4q .. 4q+3 (q = w >> 1) of the step for voxels (w & 1) * 162 + lane + 64 j
+    const int q = wave >> 1;
+    unsigned soff[H2_SLOTS];          // BYTE offsets into a channel plane (unsigned: `global_load_dword v, v_off, s[base]`)
+    int loff[H2_SLOTS];               // destination in units of 8 bytes inside a piece; -1 = no task
+    unsigned sokm = 0u;
+#pragma unroll
+    for (int j = 0; j < H2_SLOTS; ++j) {
+        const int e0 = lane + 64 * j;
+        const int e = (wave & 1) * 162 + e0;
+        const int ly = e / H2_R, lx = e - ly * H2_R;
+        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        const bool task = e0 < 162;
+        const bool ok = task && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        sokm |= (unsigned)ok << j;
+        soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
+        loff[j] = task ? (((q >> 1) * H2_PV + ly * H2_RS + lx) * 2 + (q & 1)) : -1;
+    }
+
+    const float* src = in.data + (long long)n * in.n_stride + (long long)(4 * q) * DHW;
+    const uint4* const wg = wp + (long long)cg * NCH * H2_WB + tid;
+    int ip = p_first, is = 0, cs = 0;
+    const float* xptr = src + (long long)ip * HW;
+    const uint4* wptr = wg;
+    const long long xstep = (long long)H2_KC * DHW, xwrap = (long long)NCH * H2_KC * DHW;
+    const float* nptr = NRM ? in.nrm + (long long)n * in.nrm_n_stride + 16LL * q : nullptr;
+    float xin[H2_SLOTS][4];
+    u32x4 win[H2_WSLOTS];             // the last slot is partial: lanes without a piece re-read piece 0 and do not store it
+#define MH_H2_ISSUE                                                                                   \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            const char* xq_ = reinterpret_cast<const char*>(xptr + (long long)i * DHW);       /* wave-uniform: SGPR base */ \
+            _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
+        }                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j)                                         \
+            win[j] = reinterpret_cast<const u32x4*>(wptr)[(j + 1 < H2_WSLOTS || tid + 512 * j < H2_WB) ? 512 * j : 0]; \
+        xptr += xstep; wptr += H2_WB;                                                                 \
+        if (++is == NCH) { is = 0; wptr = wg; xptr -= xwrap; ++ip; xptr += HW; }                      \
+    }
+    // normalise + activate + split on the way into LDS: 4 channels of a voxel -> 8 bytes of the high plane, 8 of the low one
+#define MH_H2_COMMIT(BUF)                                                                             \
+    {                                                                                                 \
+        float4 a_[4];                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+            a_[i] = NRM ? *reinterpret_cast<const float4*>(nptr + 4 * (H2_KC * cs + i)) : make_float4(1.0f, 0.0f, 1.0f, 0.0f); \
+        uint2* xh_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB);                                    \
+        uint2* xl_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB + H2_XV);                            \
+        _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) {                                        \
+            _Float16 h_[4], l_[4];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                const float y_ = NRM ? act(xin[j][i], a_[i].x, a_[i].y, a_[i].z) : xin[j][i];         \
+                h2_split(((sokm >> j) & 1u) ? y_ : 0.0f, h_[i], l_[i]);                               \
+            }                                                                                         \
+            const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
+            const uint2 hv_ = make_uint2(__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)); \
+            const uint2 lv_ = make_uint2(__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)); \
+            if (j + 1 < H2_SLOTS || loff[j] >= 0) { xh_[loff[j]] = hv_; xl_[loff[j]] = lv_; }        \
+        }                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j)                                         \
+            if (j + 1 < H2_WSLOTS || tid + 512 * j < H2_WB) reinterpret_cast<u32x4*>(ws)[(BUF) * H2_WB + tid + 512 * j] = win[j]; \
+        if (++cs == NCH) cs = 0;                                                                      \
+    }
+
+    // operands of this lane: A = voxel (row 2w + (r >> 4), x) with r = lane & 31 and the second row rotated by 4 voxels
+    // (16-byte reads of a lane group then cover all 64 banks once); B = cout r; k-group = lane >> 5
+    const int r32 = lane & 31, kg = lane >> 5;
+    const int arow = r32 >> 4, ax = arow ? ((r32 + 12) & 15) : (r32 & 15);
+    const int abase = kg * H2_PV + (2 * wave + arow) * H2_RS + ax;
+    const int bbase = kg * H2_CN + r32;
+
+    f32x16 acc[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
+
+    // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i
+    const int co = cg * H2_CN + r32;
+    const float bco = bias ? bias[co] : 0.0f;
+    const float inv_scale = wtail[0];
+    float* const obase = out.data + (long long)n * out.n_stride + (long long)co * DHW + (long long)(y0 + 2 * wave) * W + x0;
+    Stat run;
+    run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
+
+    uint4 ah[2], al[2], bh[2][3], bl[2][3];
+#define MH_H2_FETCH(OB, T_)                                                                           \
+    {                                                                                                 \
+        constexpr int aoff_ = ((T_) / 3) * H2_RS + (T_) % 3;                                          \
+        const uint4* xb_ = xs + bcur * H2_XB + abase + aoff_;                                         \
+        const uint4* wb_ = ws + bcur * H2_WB + (T_) * (2 * H2_CN) + bbase;                            \
+        ah[OB] = xb_[0]; al[OB] = xb_[H2_XV];                                                         \
+        _Pragma("unroll") for (int kz = 0; kz < 3; ++kz) {                                            \
+            bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)];   \
+        }                                                                                             \
+    }
+#define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
+    // z-taps 0, 1, 2 of input plane p feed output planes p+1, p, p-1
+#define MH_H2_MFMA9(OB, SP1, S0, SM1)                                                                 \
+    {                                                                                                 \
+        MH_H2_MM(SP1, ah[OB], bh[OB][0]) MH_H2_MM(S0, ah[OB], bh[OB][1]) MH_H2_MM(SM1, ah[OB], bh[OB][2]) \
+        MH_H2_MM(SP1, al[OB], bh[OB][0]) MH_H2_MM(S0, al[OB], bh[OB][1]) MH_H2_MM(SM1, al[OB], bh[OB][2]) \
+        MH_H2_MM(SP1, ah[OB], bl[OB][0]) MH_H2_MM(S0, ah[OB], bl[OB][1]) MH_H2_MM(SM1, ah[OB], bl[OB][2]) \
+    }
+#define MH_H2_TAP(T_, SP1, S0, SM1)                                                                   \
+    {                                                                                                 \
+        if ((T_) + 1 < 9) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        MH_H2_MFMA9((T_) & 1, SP1, S0, SM1)                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+    // head of a step: convert the next step's staged registers into the other LDS buffer, issue the loads of the one after it
+#define MH_H2_HEAD                                                                                    \
+    {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (gi + 1 < T) MH_H2_COMMIT(bcur ^ 1)                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        if (gi + 2 < T) MH_H2_ISSUE                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+    // one step (16 channels of input plane p); the halves of a SIMD pair are de-phased: half 0 converts first while half 1
+    // multiplies, then they swap
+#define MH_H2_STEP(SP1, S0, SM1)                                                                      \
+    {                                                                                                 \
+        MH_H2_FETCH(0, 0)                                                                             \
+        if (ph == 0) MH_H2_HEAD                                                                       \
+        MH_H2_TAP(0, SP1, S0, SM1) MH_H2_TAP(1, SP1, S0, SM1) MH_H2_TAP(2, SP1, S0, SM1) MH_H2_TAP(3, SP1, S0, SM1) \
+        if (ph != 0) MH_H2_HEAD                                                                       \
+        MH_H2_TAP(4, SP1, S0, SM1) MH_H2_TAP(5, SP1, S0, SM1) MH_H2_TAP(6, SP1, S0, SM1) MH_H2_TAP(7, SP1, S0, SM1) \
+        MH_H2_TAP(8, SP1, S0, SM1)                                                                    \
+    }
+    // output plane Z is complete in accumulator set S: scale back, bias, store 4 x 16 bytes per lane, statistics, clear
+#define MH_H2_EMIT(S, Z)                                                                              \
+    {                                                                                                 \
+        float* op_ = obase + (long long)(Z) * HW;                                                     \
+        Stat loc_;                                                                                    \
+        float sum_ = 0.0f, cnt_ = 0.0f;                                                               \
+        f32x4 o_[4];                                                                                  \
+        float w_[4];                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            const int xg_ = j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);              \
+            const bool ok_ = y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                            \
+            o_[j] = f32x4{acc[S][4 * j], acc[S][4 * j + 1], acc[S][4 * j + 2], acc[S][4 * j + 3]} * inv_scale + bco; \
+            if (ok_) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j];                     \
+            w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
+            cnt_ += 4.0f * w_[j];                                                                     \
+            sum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_[j];                          \
+        }                                                                                             \
+        if (STATS) {                                                                                  \
+            loc_.n = cnt_;                                                                            \
+            loc_.mean = cnt_ > 0.0f ? sum_ / cnt_ : 0.0f;                                             \
+            float m2_ = 0.0f;                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                const f32x4 d_ = o_[j] - loc_.mean;                                                   \
+                const f32x4 q_ = d_ * d_;                                                             \
+                m2_ += ((q_[0] + q_[1]) + (q_[2] + q_[3])) * w_[j];                                   \
+            }                                                                                         \
+            loc_.m2 = m2_;                                                                            \
+            run = stat_merge(run, loc_);                                                              \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[S][i] = 0.0f;                              \
+    }
+
+#define MH_H2_PLANE(P, SP1, S0, SM1)                                                                  \
+    if ((P) <= ze) {                                                                                  \
+        const int p_ = (P);                                                                           \
+        if (p_ >= 0 && p_ <= p_last) {                                                                \
+            for (int s = 0; s < NCH; ++s) {                                                           \
+                MH_H2_STEP(SP1, S0, SM1)                                                              \
+                __syncthreads();                                                                      \
+                bcur ^= 1; ++gi;                                                                      \
+            }                                                                                         \
+            /* targets in front of the chunk (planes zs-1, zs-2) are not ours: their sets must be clean for their next plane */ \
+            if (p_ <= zs) { _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[SM1][i] = 0.0f; }     \
+            if (p_ < zs) { _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[S0][i] = 0.0f; }       \
+        }                                                                                             \
+        if (p_ - 1 >= zs) MH_H2_EMIT(SM1, p_ - 1)                                                     \
+    }
+
+    // prologue: step 0 into buffer 0, the loads of step 1 in flight
+    int bcur = 0, gi = 0;
+    MH_H2_ISSUE
+    MH_H2_COMMIT(0)
+    if (T > 1) MH_H2_ISSUE
+    __syncthreads();
+
+    // accumulator set of output plane z: (z - zs) mod 3; input plane p = zs - 1 + k feeds sets k, k - 1, k - 2 (mod 3)
+    for (int p = zs - 1; p <= ze; p += 3) {
+        MH_H2_PLANE(p, 0, 2, 1)
+        MH_H2_PLANE(p + 1, 1, 0, 2)
+        MH_H2_PLANE(p + 2, 2, 1, 0)
+    }
+#undef MH_H2_PLANE
+#undef MH_H2_EMIT
+#undef MH_H2_STEP
+#undef MH_H2_HEAD
+#undef MH_H2_TAP
+#undef MH_H2_MFMA9
+#undef MH_H2_MM
+#undef MH_H2_FETCH
+#undef MH_H2_COMMIT
+#undef MH_H2_ISSUE
+
+    if (STATS) {
+        // the two k-group halves of a lane pair hold disjoint voxels of the same cout; then the eight waves merge through LDS
+        {
+            Stat ot;
+            ot.n = __shfl_xor(run.n, 32);
+            ot.mean = __shfl_xor(run.mean, 32);
+            ot.m2 = __shfl_xor(run.m2, 32);
+            run = kg == 0 ? stat_merge(run, ot) : stat_merge(ot, run);
+        }
+        __syncthreads();     // the staging buffers are free
+        float* red = reinterpret_cast<float*>(smem);
+        if (kg == 0) {
+            red[(wave * H2_CN + r32) * 3] = run.n; red[(wave * H2_CN + r32) * 3 + 1] = run.mean; red[(wave * H2_CN + r32) * 3 + 2] = run.m2;
+        }
+        __syncthreads();
+        if (tid < H2_CN) {
+            Stat st;
+            st.n = 0.0f; st.mean = 0.0f; st.m2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                Stat ot;
+                ot.n = red[(w * H2_CN + tid) * 3]; ot.mean = red[(w * H2_CN + tid) * 3 + 1]; ot.m2 = red[(w * H2_CN + tid) * 3 + 2];
+                st = stat_merge(st, ot);
+            }
+            float* rec = stats + (((long long)n * Cout + cg * H2_CN + tid) * nblk + b) * 3;
+            rec[0] = st.n; rec[1] = st.mean; rec[2] = st.m2;
+        }
+    }
+}
+
+// Weight preparation, two launches.  (1) one workgroup: max |w| -> tail = {1 / S, S}, S the power of two that puts the largest
+// weight in [2^12, 2^13) (fp16 high pieces far from overflow, low pieces normal down to 2^-17 of the largest weight).
+__global__ void __launch_bounds__(1024)
+conv3d_k3_h2_scale_kernel(const float* __restrict__ w, long long count, float* __restrict__ tail) {
+    __shared__ float red[1024];
+    float m = 0.0f;
+    for (long long i = threadIdx.x; i < count; i += 1024) {
+        const float a = fabsf(w[i]);
+        if (a < 3.0e38f) m = fmaxf(m, a);                   // finite values only
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 0;
+        float s = 1.0f;
+        if (red[0] > 0.0f) {
+            frexpf(red[0], &e);                             // red[0] = f * 2^e, f in [0.5, 1)
+            e = 13 - e;
+            e = e > 100 ? 100 : e < -100 ? -100 : e;
+            s = ldexpf(1.0f, e);
+        }
+        tail[0] = 1.0f / s; tail[1] = s; tail[2] = 0.0f; tail[3] = 0.0f;
+    }
+}
+// (2) w [Cout][Cin][3][3][3] -> [cout group][chunk][piece][tap][k-group][32 couts][8 channels] fp16.  One thread per (cout, cin).
+__global__ void __launch_bounds__(256)
+conv3d_k3_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float16* __restrict__ packed, const float* __restrict__ tail) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int ci = idx % Cin, co = idx / Cin;
+    const int nchunk = Cin / H2_KC;
+    const float s = tail[1];
+    const long long slab = ((long long)(co / H2_CN) * nchunk + ci / H2_KC) * 2;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        _Float16 pc[2];
+        h2_split(w[((long long)co * Cin + ci) * 27 + tap] * s, pc[0], pc[1]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            packed[((((slab + p) * 27 + tap) * 2 + (ci % H2_KC) / 8) * H2_CN + (co % H2_CN)) * 8 + (ci % 8)] = pc[p];
+    }
+}
+
+}  // namespace mh

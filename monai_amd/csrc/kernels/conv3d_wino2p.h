@@ -96,10 +96,7 @@ conv3d_k3_wino2p_kernel(Tensor in, const float* __restrict__ up, const float* __
     f32x4 uin[4];
 #define MH_W2P_ISSUE                                                                                  \
     {                                                                                                 \
-        const unsigned long long xa_ = reinterpret_cast<unsigned long long>(xptr);                   \
-        const char* xq_ = reinterpret_cast<const char*>(                                              \
-            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xa_ >> 32)) << 32) |  \
-            (unsigned)__builtin_amdgcn_readfirstlane((int)xa_));          /* wave-uniform base in SGPRs */ \
+        const char* xq_ = reinterpret_cast<const char*>(xptr);            /* wave-uniform base + 32-bit lane offset */ \
         _Pragma("unroll") for (int j = 0; j < W2_SLOTS; ++j) xin[j] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) uin[j] = uptr[512 * j];                         \
         xptr += xstep; uptr += W2P_UST / 4;                                                           \

@@ -154,6 +154,12 @@ def conv3d_k3_num_configs() -> int:
     return _lib.lib().query("mh_conv3d_k3_num_configs")
 
 
+def conv3d_k3_h2_config() -> int:
+    """Id of the fp16 two-piece split-precision configuration (fp16 matrix cores, hi + lo pieces per operand, three piece
+    products, fp32 accumulation: fp32-equivalent results); outside 1 .. conv3d_k3_num_configs()."""
+    return _lib.lib().query("mh_conv3d_k3_h2_config")
+
+
 def conv3d_k3_split_config() -> int:
     """Id of the experimental split-precision configuration (bf16 matrix cores, three pieces per operand, fp32-equivalent
     results); outside 1 .. conv3d_k3_num_configs(), selected by conv3d_k3_select only under MONAI_AMD_CONV_ALGO=split."""

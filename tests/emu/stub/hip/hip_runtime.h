@@ -34,6 +34,8 @@ struct alignas(16) int4 { int x, y, z, w; };
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct alignas(16) uint4 { unsigned int x, y, z, w; };
+struct alignas(8) uint2 { unsigned int x, y; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
 // ------------------------------------------------------------------ fibers
@@ -227,6 +229,30 @@ inline f32x16_t mfma_f32_32x32x16_bf16(bf16x8_t a, bf16x8_t b, f32x16_t cin, int
     wave_sync();
     return d;
 }
+// v_mfma_f32_32x32x16_f16: the same operand layout with fp16 elements (products of two fp16 values are exact in fp32)
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+inline f32x16_t mfma_f32_32x32x16_f16(f16x8_t a, f16x8_t b, f32x16_t cin, int, int, int) {
+    Ctx& c = ctx();
+    Fiber* f = c.cur;
+    memcpy(c.slots[f->wave][f->lane][0], &a, 16);
+    memcpy(c.slots[f->wave][f->lane][1], &b, 16);
+    wave_sync();
+    const int lane = f->lane, col = lane & 31;
+    f32x16_t d = cin;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float acc = cin[r];
+        for (int g = 0; g < 2; ++g) {
+            f16x8_t av, bv;
+            memcpy(&av, c.slots[f->wave][row + 32 * g][0], 16);
+            memcpy(&bv, c.slots[f->wave][col + 32 * g][1], 16);
+            for (int j = 0; j < 8; ++j) acc += (float)av[j] * (float)bv[j];
+        }
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D: col = l & 15, row = 4 (l >> 4) + r
 inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int) {
@@ -269,6 +295,7 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu::mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

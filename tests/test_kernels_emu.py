@@ -165,3 +165,17 @@ def test_conv3d_split_precision(emu, cin, cout, dims, n):
     assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+
+
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
+def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
+    """z-streaming direct convolution on the fp16 matrix cores, two fp16 pieces per operand and three exact piece products per
+    multiply with fp32 accumulation (conv3d_h2.h) -- held to the SAME tolerance as the fp32 kernels: chunk halos, ragged regions,
+    several cout groups and channel chunks, fused statistics."""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_h2_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
+    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)

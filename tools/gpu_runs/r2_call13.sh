@@ -1,0 +1,7 @@
+O=gpurun_out/r2c13; mkdir -p $O; export TMPDIR=/tmp
+hipcc --offload-arch=gfx950 -O3 tools/ubench/mfma_f16.hip -o /tmp/mfma_f16 2>/dev/null && /tmp/mfma_f16 > $O/ubench_mfma_f16.txt 2>&1
+cat $O/ubench_mfma_f16.txt
+timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -k "fp16_split" -n 0 2>&1 | tail -8 > $O/gpu_tests_h2.txt
+cat $O/gpu_tests_h2.txt
+KB_BATCH=64 WB_SKIP_SPLIT=1 WB_SKIP_DIRECT=1 python tools/wino_bench.py > $O/wino_bench.json 2> $O/wino_bench.err
+cat $O/wino_bench.json; tail -3 $O/wino_bench.err

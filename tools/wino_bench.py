@@ -48,7 +48,10 @@ for cin, cout, e, direct in LAYERS:
     fl = 2.0 * 27 * cin * cout * e ** 3 * B
     row = {"cin": cin, "cout": cout, "edge": e}
     split = ops.conv3d_k3_split_config()
-    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d), ("split", split)):
+    h2 = ops.conv3d_k3_h2_config()
+    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d), ("split", split), ("h2", h2)):
+        if name == "h2" and os.environ.get("WB_SKIP_H2"):
+            continue
         if name == "split" and (e % 8 or os.environ.get("WB_SKIP_SPLIT")):
             continue
         if name == "wino3d" and not os.environ.get("WB_WINO3D"):
