@@ -32,6 +32,45 @@
 #pragma once
 #include "common.h"
 
+// timing diagnostics of tools/ubench/h2_variants.hip (parts of the kernel switched off; never defined in the product build)
+#ifndef H2_DIAG_NOMFMA
+#define H2_DIAG_NOMFMA 0
+#endif
+#ifndef H2_DIAG_NOCONV
+#define H2_DIAG_NOCONV 0
+#endif
+#ifndef H2_DIAG_NOCOMMIT
+#define H2_DIAG_NOCOMMIT 0
+#endif
+#ifndef H2_DIAG_NOLOADS
+#define H2_DIAG_NOLOADS 0
+#endif
+#ifndef H2_DIAG_NOFETCH
+#define H2_DIAG_NOFETCH 0
+#endif
+#ifndef H2_DIAG_NOBAR
+#define H2_DIAG_NOBAR 0
+#endif
+#ifndef H2_DIAG_NOEMIT
+#define H2_DIAG_NOEMIT 0
+#endif
+#ifndef H2_DIAG_NOSTORE
+#define H2_DIAG_NOSTORE 0
+#endif
+#ifndef H2_DIAG_TIMING
+#define H2_DIAG_TIMING 0
+#endif
+#if H2_DIAG_TIMING
+#define H2_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; }
+#define H2_TW(v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); H2_T(6) }
+#else
+#define H2_T(i)
+#define H2_TW(v)
+#endif
+#ifndef H2_DIAG_PH
+#define H2_DIAG_PH (wave >> 2)
+#endif
+
 namespace mh {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -64,7 +103,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     uint4* const ws = smem + 2 * H2_XB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = wave >> 2;                                 // waves w and w + 4 share a SIMD: de-phased halves
+    const int ph = H2_DIAG_PH;                                // waves w and w + 4 share a SIMD: de-phased halves
     const int Cin = in.C, Cout = out.C, D = out.D, H = out.H, W = out.W;
     const long long HW = (long long)H * W, DHW = (long long)D * HW;
     const int NCH = Cin / H2_KC;                              // steps per input plane (the launcher requires Cin % 16 == 0)
@@ -125,13 +164,15 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         float4 a_[4];                                                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
             a_[i] = NRM ? *reinterpret_cast<const float4*>(nptr + 4 * (H2_KC * cs + i)) : make_float4(1.0f, 0.0f, 1.0f, 0.0f); \
+        H2_TW(xin[0][0])                                                                              \
         uint2* xh_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB);                                    \
         uint2* xl_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB + H2_XV);                            \
         _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) {                                        \
             _Float16 h_[4], l_[4];                                                                    \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
                 const float y_ = NRM ? act(xin[j][i], a_[i].x, a_[i].y, a_[i].z) : xin[j][i];         \
-                h2_split(((sokm >> j) & 1u) ? y_ : 0.0f, h_[i], l_[i]);                               \
+                if (H2_DIAG_NOCONV) { h_[i] = __builtin_bit_cast(f16x2, xin[j][i])[0]; l_[i] = __builtin_bit_cast(f16x2, xin[j][i])[1]; } \
+                else h2_split(((sokm >> j) & 1u) ? y_ : 0.0f, h_[i], l_[i]);                          \
             }                                                                                         \
             const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
             const uint2 hv_ = make_uint2(__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)); \
@@ -150,11 +191,14 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const int abase = kg * H2_PV + (2 * wave + arow) * H2_RS + ax;
     const int bbase = kg * H2_CN + r32;
 
-    f32x16 acc[3];
+    // acc[0], acc[1], acc[2]: output planes p+1, p, p-1 of the current input plane p (rotated once per plane, 48 moves);
+    // acce: the completed plane waiting for its epilogue
+    f32x16 acc[3], acce;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
+    int pend = 0, pend_z = 0;
 
     // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i
     const int co = cg * H2_CN + r32;
@@ -175,7 +219,11 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)];   \
         }                                                                                             \
     }
+#if H2_DIAG_NOMFMA
+#define MH_H2_MM(S, A, B) asm volatile("" : "+v"(acc[S]) : "v"(__builtin_bit_cast(u32x4, A)), "v"(__builtin_bit_cast(u32x4, B)));
+#else
 #define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
+#endif
     // z-taps 0, 1, 2 of input plane p feed output planes p+1, p, p-1
 #define MH_H2_MFMA9(OB, SP1, S0, SM1)                                                                 \
     {                                                                                                 \
@@ -185,35 +233,17 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
 #define MH_H2_TAP(T_, SP1, S0, SM1)                                                                   \
     {                                                                                                 \
-        if ((T_) + 1 < 9) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
+        if ((T_) + 1 < 9 && !H2_DIAG_NOFETCH) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         MH_H2_MFMA9((T_) & 1, SP1, S0, SM1)                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-    // head of a step: convert the next step's staged registers into the other LDS buffer, issue the loads of the one after it
-#define MH_H2_HEAD                                                                                    \
+    // the completed output plane (in acce): scale back, bias, store 4 x 16 bytes per lane, statistics.  It runs inside the head of
+    // a step BETWEEN the conversion and the issue of the next loads: stores and loads share the vmcnt counter, so a store issued
+    // after the loads would make the next conversion wait for the store acknowledgement as well (measured: 3000 cycles per step)
+#define MH_H2_EMIT                                                                                    \
     {                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (gi + 1 < T) MH_H2_COMMIT(bcur ^ 1)                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        if (gi + 2 < T) MH_H2_ISSUE                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-    }
-    // one step (16 channels of input plane p); the halves of a SIMD pair are de-phased: half 0 converts first while half 1
-    // multiplies, then they swap
-#define MH_H2_STEP(SP1, S0, SM1)                                                                      \
-    {                                                                                                 \
-        MH_H2_FETCH(0, 0)                                                                             \
-        if (ph == 0) MH_H2_HEAD                                                                       \
-        MH_H2_TAP(0, SP1, S0, SM1) MH_H2_TAP(1, SP1, S0, SM1) MH_H2_TAP(2, SP1, S0, SM1) MH_H2_TAP(3, SP1, S0, SM1) \
-        if (ph != 0) MH_H2_HEAD                                                                       \
-        MH_H2_TAP(4, SP1, S0, SM1) MH_H2_TAP(5, SP1, S0, SM1) MH_H2_TAP(6, SP1, S0, SM1) MH_H2_TAP(7, SP1, S0, SM1) \
-        MH_H2_TAP(8, SP1, S0, SM1)                                                                    \
-    }
-    // output plane Z is complete in accumulator set S: scale back, bias, store 4 x 16 bytes per lane, statistics, clear
-#define MH_H2_EMIT(S, Z)                                                                              \
-    {                                                                                                 \
-        float* op_ = obase + (long long)(Z) * HW;                                                     \
+        float* op_ = obase + (long long)pend_z * HW;                                                  \
         Stat loc_;                                                                                    \
         float sum_ = 0.0f, cnt_ = 0.0f;                                                               \
         f32x4 o_[4];                                                                                  \
@@ -221,8 +251,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
             const int xg_ = j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);              \
             const bool ok_ = y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                            \
-            o_[j] = f32x4{acc[S][4 * j], acc[S][4 * j + 1], acc[S][4 * j + 2], acc[S][4 * j + 3]} * inv_scale + bco; \
-            if (ok_) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j];                     \
+            o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_scale + bco; \
+            if (ok_ && !H2_DIAG_NOSTORE) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j]; \
             w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
             cnt_ += 4.0f * w_[j];                                                                     \
             sum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_[j];                          \
@@ -239,25 +269,43 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             loc_.m2 = m2_;                                                                            \
             run = stat_merge(run, loc_);                                                              \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[S][i] = 0.0f;                              \
+        pend = 0;                                                                                     \
     }
-
-#define MH_H2_PLANE(P, SP1, S0, SM1)                                                                  \
-    if ((P) <= ze) {                                                                                  \
-        const int p_ = (P);                                                                           \
-        if (p_ >= 0 && p_ <= p_last) {                                                                \
-            for (int s = 0; s < NCH; ++s) {                                                           \
-                MH_H2_STEP(SP1, S0, SM1)                                                              \
-                __syncthreads();                                                                      \
-                bcur ^= 1; ++gi;                                                                      \
-            }                                                                                         \
-            /* targets in front of the chunk (planes zs-1, zs-2) are not ours: their sets must be clean for their next plane */ \
-            if (p_ <= zs) { _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[SM1][i] = 0.0f; }     \
-            if (p_ < zs) { _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[S0][i] = 0.0f; }       \
-        }                                                                                             \
-        if (p_ - 1 >= zs) MH_H2_EMIT(SM1, p_ - 1)                                                     \
+    // head of a step: convert the next step's staged registers into the other LDS buffer, issue the loads of the one after it
+#define MH_H2_HEAD                                                                                    \
+    {                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        H2_T(0)                                                                                       \
+        if (gi + 1 < T && !H2_DIAG_NOCOMMIT) MH_H2_COMMIT(bcur ^ 1)                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        H2_T(1)                                                                                       \
+        if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        H2_T(3)                                                                                       \
+        if (gi + 2 < T && !H2_DIAG_NOLOADS) MH_H2_ISSUE                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        H2_T(5)                                                                                       \
     }
-
+    // one step (16 channels of input plane p).  A wave cannot issue its staging work while it waits for the matrix pipe, so the
+    // halves of a SIMD pair run exactly out of phase: half 0 converts the next step FIRST while half 1 multiplies, then half 0
+    // multiplies while half 1 converts LAST (profiles/r02_pmc_h2_v1.txt: with half 1's conversion in the middle of its taps the
+    // matrix pipe idled while both halves were converting -- 42 % busy)
+#define MH_H2_STEP(SP1, S0, SM1)                                                                      \
+    {                                                                                                 \
+        H2_T(0)                                                                                       \
+        MH_H2_FETCH(0, 0)                                                                             \
+        if (ph == 0) MH_H2_HEAD                                                                       \
+        H2_T(0)                                                                                       \
+        MH_H2_TAP(0, SP1, S0, SM1) MH_H2_TAP(1, SP1, S0, SM1) MH_H2_TAP(2, SP1, S0, SM1) MH_H2_TAP(3, SP1, S0, SM1) \
+        MH_H2_TAP(4, SP1, S0, SM1) MH_H2_TAP(5, SP1, S0, SM1) MH_H2_TAP(6, SP1, S0, SM1) MH_H2_TAP(7, SP1, S0, SM1) \
+        MH_H2_TAP(8, SP1, S0, SM1)                                                                    \
+        H2_T(2)                                                                                       \
+        if (ph != 0) MH_H2_HEAD                                                                       \
+        H2_T(0)                                                                                       \
+    }
+#if H2_DIAG_TIMING
+    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
     // prologue: step 0 into buffer 0, the loads of step 1 in flight
     int bcur = 0, gi = 0;
     MH_H2_ISSUE
@@ -265,13 +313,33 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     if (T > 1) MH_H2_ISSUE
     __syncthreads();
 
-    // accumulator set of output plane z: (z - zs) mod 3; input plane p = zs - 1 + k feeds sets k, k - 1, k - 2 (mod 3)
-    for (int p = zs - 1; p <= ze; p += 3) {
-        MH_H2_PLANE(p, 0, 2, 1)
-        MH_H2_PLANE(p + 1, 1, 0, 2)
-        MH_H2_PLANE(p + 2, 2, 1, 0)
+    for (int p = zs - 1; p <= ze; ++p) {
+        if (p >= p_first && p <= p_last) {
+            for (int s = 0; s < NCH; ++s) {
+                MH_H2_STEP(0, 1, 2)
+                if (!H2_DIAG_NOBAR) __syncthreads();
+                H2_T(4)
+                bcur ^= 1; ++gi;
+            }
+        }
+        H2_T(0)
+        if (p - 1 >= zs) {              // output plane p-1 is complete in set 2 (planes in front of the chunk are simply dropped)
+            if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT       // only when no step ran since the previous plane (p == D)
+            acce = acc[2];
+            pend = 1; pend_z = p - 1;
+        }
+        acc[2] = acc[1];
+        acc[1] = acc[0];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+        H2_T(0)
     }
-#undef MH_H2_PLANE
+    if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT
+#if H2_DIAG_TIMING
+    if (blockIdx.x == 300 && lane == 0) {
+        for (int i = 0; i < 7; ++i) reinterpret_cast<long long*>(stats)[wave * 7 + i] = tacc[i];
+    }
+#endif
 #undef MH_H2_EMIT
 #undef MH_H2_STEP
 #undef MH_H2_HEAD

@@ -1,0 +1,76 @@
+// Development aid: times conv3d_k3_h2_kernel (32 -> 32 channels, 96^3, 64 windows) standalone, so that diagnostic builds
+// (-DH2_DIAG_NOMFMA / NOCONV / NOLOADS / NOFETCH / NOBAR / NOEMIT: parts of the kernel switched off; results are wrong, only the
+// time matters) compile in seconds on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-DH2_DIAG_...] tools/ubench/h2_variants.hip -o /tmp/h2v && /tmp/h2v
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "monai_amd.h"
+#include "kernels/conv3d_h2.h"
+using namespace mh;
+#ifndef H2V_STATS
+#define H2V_STATS true
+#endif
+
+int main(int argc, char** argv) {
+    const int N = 64, C = argc > 1 ? atoi(argv[1]) : 32, K = 32, E = 96;
+    const size_t vox = (size_t)E * E * E;
+    float *x, *y, *nrm, *bias, *stats, *packed;
+    hipMalloc(&x, sizeof(float) * N * C * vox);
+    hipMalloc(&y, sizeof(float) * N * K * vox);
+    hipMalloc(&nrm, sizeof(float) * N * C * 4);
+    hipMalloc(&bias, sizeof(float) * K);
+    const int bxn = E / H2_B, byn = E / H2_B, zc = E;
+    const unsigned nblk = bxn * byn;
+    hipMalloc(&stats, sizeof(float) * N * K * nblk * 3);
+    const size_t pf = (size_t)C * K * 27 + H2_TAIL;
+    hipMalloc(&packed, sizeof(float) * pf);
+    std::vector<float> h((size_t)C * vox);
+    unsigned s = 12345u;
+    for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
+    for (int n = 0; n < N; ++n) hipMemcpy(x + (size_t)n * C * vox, h.data(), sizeof(float) * C * vox, hipMemcpyHostToDevice);
+    std::vector<float> hn((size_t)N * C * 4);
+    for (size_t i = 0; i < hn.size(); i += 4) { hn[i] = 1.1f; hn[i + 1] = 0.1f; hn[i + 2] = 0.1f; hn[i + 3] = 0.0f; }
+    hipMemcpy(nrm, hn.data(), sizeof(float) * hn.size(), hipMemcpyHostToDevice);
+    std::vector<float> hw((size_t)K * C * 27), hb(K, 0.0f);
+    for (auto& v : hw) { s = s * 1664525u + 1013904223u; v = (((s >> 8) & 0xffff) / 65536.0f - 0.5f) * 0.1f; }
+    float* w;
+    hipMalloc(&w, sizeof(float) * hw.size());
+    hipMemcpy(w, hw.data(), sizeof(float) * hw.size(), hipMemcpyHostToDevice);
+    hipMemcpy(bias, hb.data(), sizeof(float) * K, hipMemcpyHostToDevice);
+    float* tail = packed + (size_t)C * K * 27;
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, 0, w, (long long)hw.size(), tail);
+    hipLaunchKernelGGL(conv3d_k3_h2_pack_kernel, dim3((C * K + 255) / 256), dim3(256), 0, 0, w, C, K, reinterpret_cast<_Float16*>(packed), tail);
+    Tensor in{x, (long long)C * (long long)vox, nrm, (long long)C * 4, N, C, E, E, E};
+    Tensor out{y, (long long)K * (long long)vox, nullptr, 0, N, K, E, E, E};
+    const dim3 grid(nblk * N);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int it = 0; it < 4; ++it) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((conv3d_k3_h2_kernel<H2V_STATS, true>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
+        hipEventRecord(e1);
+        hipDeviceSynchronize();
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (it && ms < best) best = ms;
+    }
+#if H2_DIAG_TIMING
+    {
+        long long t[56];
+        hipMemcpy(t, stats, sizeof(t), hipMemcpyDeviceToHost);
+        printf("cycles per step of workgroup 300 (196 steps): other | convert+LDS writes | taps | epilogue | barrier | issue loads | wait for loads\n");
+        for (int w = 0; w < 8; ++w) {
+            printf("  wave %d:", w);
+            for (int i = 0; i < 7; ++i) printf(" %7.0f", t[w * 7 + i] / 196.0);
+            printf("\n");
+        }
+    }
+#endif
+    std::vector<float> ho(64);
+    hipMemcpy(ho.data(), y + 5 * vox + 40 * E * E + 40 * E + 16, 64 * 4, hipMemcpyDeviceToHost);
+    printf("%-28s Cin %d: %.3f ms  (%.0f TFLOP/s direct-equivalent)  y[..] = %g %g\n", argc > 2 ? argv[2] : "full", C, best,
+           2.0 * 27 * C * K * vox * N / best / 1e9, ho[0], ho[1]);
+    return hipGetLastError() != hipSuccess;
+}
