@@ -340,7 +340,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
     if (cfg == MH_CFG_SPLIT) return Cin >= SP_CC && Cin % SP_CC == 0 && Cin <= SP_NRM_MAX && Cout >= SP_CN && Cout % SP_CN == 0;
-    if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cout >= H2_CN && Cout % H2_CN == 0;
+    if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -379,7 +379,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
     if (cfg == MH_CFG_SPLIT) return (int64_t)Cin * Cout * 27 * SP_NP / 2;      // three bf16 pieces per weight
-    if (cfg == MH_CFG_H2) return (int64_t)Cin * Cout * 27 + H2_TAIL;           // two fp16 pieces per weight + {1 / scale, scale}
+    if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -404,7 +404,10 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
     }
     if (cfg == MH_CFG_H2) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
-        float* tail = packed + (int64_t)Cin * Cout * 27;
+        const int64_t slab_floats = mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL;
+        float* tail = packed + slab_floats;
+        if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)slab_floats, (hipStream_t)stream) != hipSuccess)
+            return fail(MH_ERR_LAUNCH, "conv3d_k3_pack: memset failed");
         hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
         hipLaunchKernelGGL(conv3d_k3_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
                            reinterpret_cast<_Float16*>(packed), tail);
@@ -457,7 +460,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
-        const float* tail = packed_w + (int64_t)in.C * out.C * 27;
+        const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
         if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
         else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);

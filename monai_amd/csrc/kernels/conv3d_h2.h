@@ -32,50 +32,12 @@
 #pragma once
 #include "common.h"
 
-// timing diagnostics of tools/ubench/h2_variants.hip (parts of the kernel switched off; never defined in the product build)
-#ifndef H2_DIAG_NOMFMA
-#define H2_DIAG_NOMFMA 0
-#endif
-#ifndef H2_DIAG_NOCONV
-#define H2_DIAG_NOCONV 0
-#endif
-#ifndef H2_DIAG_NOCOMMIT
-#define H2_DIAG_NOCOMMIT 0
-#endif
-#ifndef H2_DIAG_NOLOADS
-#define H2_DIAG_NOLOADS 0
-#endif
-#ifndef H2_DIAG_NOFETCH
-#define H2_DIAG_NOFETCH 0
-#endif
-#ifndef H2_DIAG_NOBAR
-#define H2_DIAG_NOBAR 0
-#endif
-#ifndef H2_DIAG_NOEMIT
-#define H2_DIAG_NOEMIT 0
-#endif
-#ifndef H2_DIAG_NOSTORE
-#define H2_DIAG_NOSTORE 0
-#endif
-#ifndef H2_DIAG_TIMING
-#define H2_DIAG_TIMING 0
-#endif
-#if H2_DIAG_TIMING
-#define H2_T(i) { const long long t_ = __builtin_readcyclecounter(); tacc[i] += t_ - tlast; tlast = t_; }
-#define H2_TW(v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)); H2_T(6) }
-#else
-#define H2_T(i)
-#define H2_TW(v)
-#endif
-#ifndef H2_DIAG_PH
-#define H2_DIAG_PH (wave >> 2)
-#endif
-
 namespace mh {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H2_B = 16;                                   // region edge (y and x) of a workgroup
 constexpr int H2_R = 18, H2_RS = 20;                       // input region edge, LDS row pitch in voxels
@@ -84,26 +46,28 @@ constexpr int H2_KC = 16, H2_CN = 32;                      // input channels per
 constexpr int H2_XV = 2 * H2_PV;                           // uint4 per piece of a step's input plane: [k-group][voxel]
 constexpr int H2_XB = 2 * H2_XV;                           // uint4 per input buffer (two pieces): 1440
 constexpr int H2_WV = 27 * 2 * H2_CN;                      // uint4 per piece of a chunk's weight slab: [tap][k-group][cout]
-constexpr int H2_WB = 2 * H2_WV;                           // uint4 per weight buffer (two pieces): 3456
+constexpr int H2_WSLOTS = 7;                               // uint4 of the weight slab per thread
+constexpr int H2_WB = 512 * H2_WSLOTS;                     // uint4 per weight buffer: two pieces (3456) padded to 7 per thread (3584)
 constexpr int H2_SLOTS = 3;                                // staging tasks per lane: (voxel, 4 channels); 162 voxels per wave
-constexpr int H2_WSLOTS = (H2_WB + 511) / 512;             // 7 uint4 of the weight slab per thread
 constexpr int H2_TAIL = 4;                                 // floats behind the packed slabs: {1 / scale, scale, 0, 0}
+constexpr int H2_NRM_MAX = 128;                            // input channels (their {alpha, beta, slope} records sit in LDS)
 
 __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
 
+// EMIT / PLAIN step bodies are the same code; the epilogue of a completed plane rides in the first step of the next plane
 template <bool STATS, bool NRM>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
     __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
+    __shared__ float4 nrm_s[NRM ? H2_NRM_MAX : 1];
     uint4* const xs = smem;
     uint4* const ws = smem + 2 * H2_XB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = H2_DIAG_PH;                                // waves w and w + 4 share a SIMD: de-phased halves
     const int Cin = in.C, Cout = out.C, D = out.D, H = out.H, W = out.W;
     const long long HW = (long long)H * W, DHW = (long long)D * HW;
     const int NCH = Cin / H2_KC;                              // steps per input plane (the launcher requires Cin % 16 == 0)
@@ -120,68 +84,76 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const int p_first = max(zs - 1, 0), p_last = min(ze, D - 1);
     const int T = (p_last - p_first + 1) * NCH;               // steps this workgroup runs
 
-    // input staging: wave w converts channels 4q .. 4q+3 (q = w >> 1) of the step for voxels (w & 1) * 162 + lane + 64 j
+    // input staging: wave w converts channels 4q .. 4q+3 (q = w >> 1) of the step for voxels (w & 1) * 162 + lane + 64 j.
+    // Voxels outside the volume (zero padding) and idle lanes write into the unused pitch columns 18, 19 of their row: the padded
+    // cells of both buffers are zeroed once and never written again, so the step body has no masks and no branches.
     const int q = wave >> 1;
-    unsigned soff[H2_SLOTS];          // BYTE offsets into a channel plane (unsigned: `global_load_dword v, v_off, s[base]`)
-    int loff[H2_SLOTS];               // destination in units of 8 bytes inside a piece; -1 = no task
-    unsigned sokm = 0u;
+    unsigned soff[H2_SLOTS];          // BYTE offsets into a channel plane
+    int loff[H2_SLOTS];               // destination in units of 8 bytes inside a piece
 #pragma unroll
     for (int j = 0; j < H2_SLOTS; ++j) {
         const int e0 = lane + 64 * j;
-        const int e = (wave & 1) * 162 + e0;
+        const int e = min((wave & 1) * 162 + e0, H2_R * H2_R - 1);
         const int ly = e / H2_R, lx = e - ly * H2_R;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        const bool task = e0 < 162;
-        const bool ok = task && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sokm |= (unsigned)ok << j;
+        const bool ok = e0 < 162 && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
-        loff[j] = task ? (((q >> 1) * H2_PV + ly * H2_RS + lx) * 2 + (q & 1)) : -1;
+        loff[j] = ((q >> 1) * H2_PV + ly * H2_RS + (ok ? lx : H2_R + (lx & 1))) * 2 + (q & 1);
     }
+    for (int i = tid; i < 2 * H2_XB; i += 512) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (NRM) {
+        for (int c = tid; c < Cin; c += 512) nrm_s[c] = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
+    }
+    __syncthreads();
 
     const float* src = in.data + (long long)n * in.n_stride + (long long)(4 * q) * DHW;
-    const uint4* const wg = wp + (long long)cg * NCH * H2_WB + tid;
-    int ip = p_first, is = 0, cs = 0;
-    const float* xptr = src + (long long)ip * HW;
-    const uint4* wptr = wg;
-    const long long xstep = (long long)H2_KC * DHW, xwrap = (long long)NCH * H2_KC * DHW;
-    const float* nptr = NRM ? in.nrm + (long long)n * in.nrm_n_stride + 16LL * q : nullptr;
+    const u32x4* const wg = reinterpret_cast<const u32x4*>(wp) + (long long)cg * NCH * H2_WB + tid;
+    int is = 0, cs = 0;               // chunk of the next loads / of the next conversion
+    const float* xptr = src + (long long)p_first * HW;
+    int woff = 0;
+    const long long xstep = (long long)H2_KC * DHW, xwrap = HW - (long long)(NCH - 1) * H2_KC * DHW;
     float xin[H2_SLOTS][4];
-    u32x4 win[H2_WSLOTS];             // the last slot is partial: lanes without a piece re-read piece 0 and do not store it
-#define MH_H2_ISSUE                                                                                   \
-    {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-            const char* xq_ = reinterpret_cast<const char*>(xptr + (long long)i * DHW);       /* wave-uniform: SGPR base */ \
-            _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
-        }                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j)                                         \
-            win[j] = reinterpret_cast<const u32x4*>(wptr)[(j + 1 < H2_WSLOTS || tid + 512 * j < H2_WB) ? 512 * j : 0]; \
-        xptr += xstep; wptr += H2_WB;                                                                 \
-        if (++is == NCH) { is = 0; wptr = wg; xptr -= xwrap; ++ip; xptr += HW; }                      \
+    u32x4 win[H2_WSLOTS];
+
+    // ---- the pieces of a step's staging work; each is branch-free so that it can be interleaved with the step's MFMAs ----
+    // loads of the step after next (the registers were consumed by MH_H2_CONV / MH_H2_WST earlier in this step)
+#define MH_H2_LDX                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+        const char* xq_ = reinterpret_cast<const char*>(xptr + (long long)i * DHW);                   \
+        _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
     }
-    // normalise + activate + split on the way into LDS: 4 channels of a voxel -> 8 bytes of the high plane, 8 of the low one
-#define MH_H2_COMMIT(BUF)                                                                             \
+#define MH_H2_LDW(J0, J1)                                                                             \
+    _Pragma("unroll") for (int j = (J0); j < (J1); ++j) win[j] = wg[woff + 512 * j];
+    // advance to the next (plane, chunk) -- not beyond the last step (the loads then repeat the last step's addresses)
+#define MH_H2_ADV                                                                                     \
     {                                                                                                 \
-        float4 a_[4];                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-            a_[i] = NRM ? *reinterpret_cast<const float4*>(nptr + 4 * (H2_KC * cs + i)) : make_float4(1.0f, 0.0f, 1.0f, 0.0f); \
-        H2_TW(xin[0][0])                                                                              \
-        uint2* xh_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB);                                    \
-        uint2* xl_ = reinterpret_cast<uint2*>(xs + (BUF) * H2_XB + H2_XV);                            \
-        _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) {                                        \
-            _Float16 h_[4], l_[4];                                                                    \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                const float y_ = NRM ? act(xin[j][i], a_[i].x, a_[i].y, a_[i].z) : xin[j][i];         \
-                if (H2_DIAG_NOCONV) { h_[i] = __builtin_bit_cast(f16x2, xin[j][i])[0]; l_[i] = __builtin_bit_cast(f16x2, xin[j][i])[1]; } \
-                else h2_split(((sokm >> j) & 1u) ? y_ : 0.0f, h_[i], l_[i]);                          \
+        const bool adv_ = gi + 3 < T;                                                                 \
+        const bool wrap_ = is + 1 == NCH;                                                             \
+        xptr += adv_ ? (wrap_ ? xwrap : xstep) : 0LL;                                                 \
+        woff = adv_ ? (wrap_ ? 0 : woff + H2_WB) : woff;                                              \
+        is = adv_ ? (wrap_ ? 0 : is + 1) : is;                                                        \
+    }
+    // normalise + activate + split slot J on the way into LDS: 4 channels of a voxel -> 8 bytes of the high plane, 8 of the low one
+#define MH_H2_CONV(J)                                                                                 \
+    {                                                                                                 \
+        u32x2* xh_ = reinterpret_cast<u32x2*>(xs + (bcur ^ 1) * H2_XB);                               \
+        _Float16 h_[4], l_[4];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
+            float y_ = xin[J][i];                                                                     \
+            if (NRM) {                                                                                \
+                const float4 a_ = nrm_s[H2_KC * cs + 4 * q + i];                                      \
+                y_ = act(y_, a_.x, a_.y, a_.z);                                                       \
             }                                                                                         \
-            const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
-            const uint2 hv_ = make_uint2(__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)); \
-            const uint2 lv_ = make_uint2(__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)); \
-            if (j + 1 < H2_SLOTS || loff[j] >= 0) { xh_[loff[j]] = hv_; xl_[loff[j]] = lv_; }        \
+            h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j)                                         \
-            if (j + 1 < H2_WSLOTS || tid + 512 * j < H2_WB) reinterpret_cast<u32x4*>(ws)[(BUF) * H2_WB + tid + 512 * j] = win[j]; \
-        if (++cs == NCH) cs = 0;                                                                      \
+        const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
+        xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
+        xh_[loff[J] + 2 * H2_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
+    }
+#define MH_H2_WST                                                                                     \
+    {                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[(bcur ^ 1) * H2_WB + tid + 512 * j] = win[j]; \
+        cs = cs + 1 == NCH ? 0 : cs + 1;                                                              \
     }
 
     // operands of this lane: A = voxel (row 2w + (r >> 4), x) with r = lane & 31 and the second row rotated by 4 voxels
@@ -219,28 +191,34 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)];   \
         }                                                                                             \
     }
-#if H2_DIAG_NOMFMA
-#define MH_H2_MM(S, A, B) asm volatile("" : "+v"(acc[S]) : "v"(__builtin_bit_cast(u32x4, A)), "v"(__builtin_bit_cast(u32x4, B)));
-#else
 #define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
-#endif
     // z-taps 0, 1, 2 of input plane p feed output planes p+1, p, p-1
-#define MH_H2_MFMA9(OB, SP1, S0, SM1)                                                                 \
+#define MH_H2_MFMA9(OB)                                                                               \
     {                                                                                                 \
-        MH_H2_MM(SP1, ah[OB], bh[OB][0]) MH_H2_MM(S0, ah[OB], bh[OB][1]) MH_H2_MM(SM1, ah[OB], bh[OB][2]) \
-        MH_H2_MM(SP1, al[OB], bh[OB][0]) MH_H2_MM(S0, al[OB], bh[OB][1]) MH_H2_MM(SM1, al[OB], bh[OB][2]) \
-        MH_H2_MM(SP1, ah[OB], bl[OB][0]) MH_H2_MM(S0, ah[OB], bl[OB][1]) MH_H2_MM(SM1, ah[OB], bl[OB][2]) \
+        MH_H2_MM(0, ah[OB], bh[OB][0]) MH_H2_MM(1, ah[OB], bh[OB][1]) MH_H2_MM(2, ah[OB], bh[OB][2])  \
+        MH_H2_MM(0, al[OB], bh[OB][0]) MH_H2_MM(1, al[OB], bh[OB][1]) MH_H2_MM(2, al[OB], bh[OB][2])  \
+        MH_H2_MM(0, ah[OB], bl[OB][0]) MH_H2_MM(1, ah[OB], bl[OB][1]) MH_H2_MM(2, ah[OB], bl[OB][2])  \
     }
-#define MH_H2_TAP(T_, SP1, S0, SM1)                                                                   \
+    // one (ky, kx) group: the next group's operand reads, 9 MFMAs and a piece FILL of the staging work.  A wave issues in order
+    // and an MFMA occupies the matrix pipe for 32 cycles, so whatever is placed BETWEEN two MFMAs is free, and whatever sits in a
+    // lump before or after them is serial time of this wave (measured with the lump form: 6700 of 9700 cycles per step): the
+    // scheduler is told to deal the piece out over the gaps.
+#define MH_H2_TAP(T_, ...)                                                                            \
     {                                                                                                 \
-        if ((T_) + 1 < 9 && !H2_DIAG_NOFETCH) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        MH_H2_MFMA9((T_) & 1, SP1, S0, SM1)                                                           \
+        if ((T_) + 1 < 9) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
+        __VA_ARGS__                                                                                   \
+        MH_H2_MFMA9((T_) & 1)                                                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < 9; ++g_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                        \
+        }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-    // the completed output plane (in acce): scale back, bias, store 4 x 16 bytes per lane, statistics.  It runs inside the head of
-    // a step BETWEEN the conversion and the issue of the next loads: stores and loads share the vmcnt counter, so a store issued
-    // after the loads would make the next conversion wait for the store acknowledgement as well (measured: 3000 cycles per step)
+    // the completed output plane (in acce): scale back, bias, store 4 x 16 bytes per lane, statistics.  It is placed BEFORE the
+    // loads of the step: stores and loads share the vmcnt counter, and a store issued after the loads would make the next
+    // conversion wait for the store acknowledgement as well
 #define MH_H2_EMIT                                                                                    \
     {                                                                                                 \
         float* op_ = obase + (long long)pend_z * HW;                                                  \
@@ -250,9 +228,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         float w_[4];                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
             const int xg_ = j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);              \
-            const bool ok_ = y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                            \
+            const bool ok_ = pend && y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                    \
             o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_scale + bco; \
-            if (ok_ && !H2_DIAG_NOSTORE) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j]; \
+            if (ok_) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j];                     \
             w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
             cnt_ += 4.0f * w_[j];                                                                     \
             sum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_[j];                          \
@@ -271,60 +249,41 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         }                                                                                             \
         pend = 0;                                                                                     \
     }
-    // head of a step: convert the next step's staged registers into the other LDS buffer, issue the loads of the one after it
-#define MH_H2_HEAD                                                                                    \
+#define MH_H2_NONE
+    // one step (16 channels of input plane p): conversion of the next step's registers into the other LDS buffer first, then the
+    // epilogue stores (EM), then the loads of the step after next
+#define MH_H2_STEP(EM)                                                                                \
     {                                                                                                 \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        H2_T(0)                                                                                       \
-        if (gi + 1 < T && !H2_DIAG_NOCOMMIT) MH_H2_COMMIT(bcur ^ 1)                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        H2_T(1)                                                                                       \
-        if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        H2_T(3)                                                                                       \
-        if (gi + 2 < T && !H2_DIAG_NOLOADS) MH_H2_ISSUE                                               \
-        __builtin_amdgcn_sched_barrier(0);                                                            \
-        H2_T(5)                                                                                       \
-    }
-    // one step (16 channels of input plane p).  A wave cannot issue its staging work while it waits for the matrix pipe, so the
-    // halves of a SIMD pair run exactly out of phase: half 0 converts the next step FIRST while half 1 multiplies, then half 0
-    // multiplies while half 1 converts LAST (profiles/r02_pmc_h2_v1.txt: with half 1's conversion in the middle of its taps the
-    // matrix pipe idled while both halves were converting -- 42 % busy)
-#define MH_H2_STEP(SP1, S0, SM1)                                                                      \
-    {                                                                                                 \
-        H2_T(0)                                                                                       \
         MH_H2_FETCH(0, 0)                                                                             \
-        if (ph == 0) MH_H2_HEAD                                                                       \
-        H2_T(0)                                                                                       \
-        MH_H2_TAP(0, SP1, S0, SM1) MH_H2_TAP(1, SP1, S0, SM1) MH_H2_TAP(2, SP1, S0, SM1) MH_H2_TAP(3, SP1, S0, SM1) \
-        MH_H2_TAP(4, SP1, S0, SM1) MH_H2_TAP(5, SP1, S0, SM1) MH_H2_TAP(6, SP1, S0, SM1) MH_H2_TAP(7, SP1, S0, SM1) \
-        MH_H2_TAP(8, SP1, S0, SM1)                                                                    \
-        H2_T(2)                                                                                       \
-        if (ph != 0) MH_H2_HEAD                                                                       \
-        H2_T(0)                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
+        MH_H2_TAP(3, EM)                                                                              \
+        MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
+        MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)                      \
     }
-#if H2_DIAG_TIMING
-    long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
-#endif
-    // prologue: step 0 into buffer 0, the loads of step 1 in flight
-    int bcur = 0, gi = 0;
-    MH_H2_ISSUE
-    MH_H2_COMMIT(0)
-    if (T > 1) MH_H2_ISSUE
+
+    // prologue: step 0 into buffer 0 (the conversion pieces write the buffer "after" bcur: start from 1), the loads of step 1 in flight
+    int bcur = 1, gi = -2;
+    MH_H2_LDX MH_H2_LDW(0, H2_WSLOTS) MH_H2_ADV
+    gi = -1;
+    MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WST
+    MH_H2_LDX MH_H2_LDW(0, H2_WSLOTS) MH_H2_ADV
+    bcur = 0; gi = 0;
     __syncthreads();
 
     for (int p = zs - 1; p <= ze; ++p) {
         if (p >= p_first && p <= p_last) {
-            for (int s = 0; s < NCH; ++s) {
-                MH_H2_STEP(0, 1, 2)
-                if (!H2_DIAG_NOBAR) __syncthreads();
-                H2_T(4)
+            MH_H2_STEP(MH_H2_EMIT)
+            __syncthreads();
+            bcur ^= 1; ++gi;
+            for (int s = 1; s < NCH; ++s) {
+                MH_H2_STEP(MH_H2_NONE)
+                __syncthreads();
                 bcur ^= 1; ++gi;
             }
         }
-        H2_T(0)
         if (p - 1 >= zs) {              // output plane p-1 is complete in set 2 (planes in front of the chunk are simply dropped)
-            if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT       // only when no step ran since the previous plane (p == D)
+            if (pend) MH_H2_EMIT        // only when no step ran since the previous plane (p == D)
             acce = acc[2];
             pend = 1; pend_z = p - 1;
         }
@@ -332,23 +291,20 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         acc[1] = acc[0];
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
-        H2_T(0)
     }
-    if (pend && !H2_DIAG_NOEMIT) MH_H2_EMIT
-#if H2_DIAG_TIMING
-    if (blockIdx.x == 300 && lane == 0) {
-        for (int i = 0; i < 7; ++i) reinterpret_cast<long long*>(stats)[wave * 7 + i] = tacc[i];
-    }
-#endif
-#undef MH_H2_EMIT
+    if (pend) MH_H2_EMIT
 #undef MH_H2_STEP
-#undef MH_H2_HEAD
+#undef MH_H2_NONE
+#undef MH_H2_EMIT
 #undef MH_H2_TAP
 #undef MH_H2_MFMA9
 #undef MH_H2_MM
 #undef MH_H2_FETCH
-#undef MH_H2_COMMIT
-#undef MH_H2_ISSUE
+#undef MH_H2_WST
+#undef MH_H2_CONV
+#undef MH_H2_ADV
+#undef MH_H2_LDW
+#undef MH_H2_LDX
 
     if (STATS) {
         // the two k-group halves of a lane pair hold disjoint voxels of the same cout; then the eight waves merge through LDS
@@ -408,7 +364,8 @@ conv3d_k3_h2_scale_kernel(const float* __restrict__ w, long long count, float* _
         tail[0] = 1.0f / s; tail[1] = s; tail[2] = 0.0f; tail[3] = 0.0f;
     }
 }
-// (2) w [Cout][Cin][3][3][3] -> [cout group][chunk][piece][tap][k-group][32 couts][8 channels] fp16.  One thread per (cout, cin).
+// (2) w [Cout][Cin][3][3][3] -> [cout group][chunk][piece][tap][k-group][32 couts][8 channels] fp16, each chunk slab padded to
+// H2_WB uint4 (the pad is never used as an operand; the buffer is zeroed first).  One thread per (cout, cin).
 __global__ void __launch_bounds__(256)
 conv3d_k3_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float16* __restrict__ packed, const float* __restrict__ tail) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -416,14 +373,14 @@ conv3d_k3_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float1
     const int ci = idx % Cin, co = idx / Cin;
     const int nchunk = Cin / H2_KC;
     const float s = tail[1];
-    const long long slab = ((long long)(co / H2_CN) * nchunk + ci / H2_KC) * 2;
+    _Float16* slab = packed + ((long long)(co / H2_CN) * nchunk + ci / H2_KC) * (H2_WB * 8LL);
 #pragma unroll
     for (int tap = 0; tap < 27; ++tap) {
         _Float16 pc[2];
         h2_split(w[((long long)co * Cin + ci) * 27 + tap] * s, pc[0], pc[1]);
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            packed[((((slab + p) * 27 + tap) * 2 + (ci % H2_KC) / 8) * H2_CN + (co % H2_CN)) * 8 + (ci % 8)] = pc[p];
+            slab[(((p * 27 + tap) * 2 + (ci % H2_KC) / 8) * H2_CN + (co % H2_CN)) * 8 + (ci % 8)] = pc[p];
     }
 }
 

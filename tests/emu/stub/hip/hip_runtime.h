@@ -36,6 +36,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 struct alignas(16) uint4 { unsigned int x, y, z, w; };
 struct alignas(8) uint2 { unsigned int x, y; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 
 // ------------------------------------------------------------------ fibers

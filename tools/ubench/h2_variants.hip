@@ -23,8 +23,9 @@ int main(int argc, char** argv) {
     const int bxn = E / H2_B, byn = E / H2_B, zc = E;
     const unsigned nblk = bxn * byn;
     hipMalloc(&stats, sizeof(float) * N * K * nblk * 3);
-    const size_t pf = (size_t)C * K * 27 + H2_TAIL;
+    const size_t pf = (size_t)(C / H2_KC) * (K / H2_CN) * H2_WB * 4 + H2_TAIL;
     hipMalloc(&packed, sizeof(float) * pf);
+    hipMemset(packed, 0, sizeof(float) * pf);
     std::vector<float> h((size_t)C * vox);
     unsigned s = 12345u;
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f - 0.5f; }
@@ -38,7 +39,7 @@ int main(int argc, char** argv) {
     hipMalloc(&w, sizeof(float) * hw.size());
     hipMemcpy(w, hw.data(), sizeof(float) * hw.size(), hipMemcpyHostToDevice);
     hipMemcpy(bias, hb.data(), sizeof(float) * K, hipMemcpyHostToDevice);
-    float* tail = packed + (size_t)C * K * 27;
+    float* tail = packed + (pf - H2_TAIL);
     hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, 0, w, (long long)hw.size(), tail);
     hipLaunchKernelGGL(conv3d_k3_h2_pack_kernel, dim3((C * K + 255) / 256), dim3(256), 0, 0, w, C, K, reinterpret_cast<_Float16*>(packed), tail);
     Tensor in{x, (long long)C * (long long)vox, nrm, (long long)C * 4, N, C, E, E, E};
@@ -49,25 +50,13 @@ int main(int argc, char** argv) {
     float best = 1e9f;
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2_kernel<H2V_STATS, true>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
+        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         if (it && ms < best) best = ms;
     }
-#if H2_DIAG_TIMING
-    {
-        long long t[56];
-        hipMemcpy(t, stats, sizeof(t), hipMemcpyDeviceToHost);
-        printf("cycles per step of workgroup 300 (196 steps): other | convert+LDS writes | taps | epilogue | barrier | issue loads | wait for loads\n");
-        for (int w = 0; w < 8; ++w) {
-            printf("  wave %d:", w);
-            for (int i = 0; i < 7; ++i) printf(" %7.0f", t[w * 7 + i] / 196.0);
-            printf("\n");
-        }
-    }
-#endif
     std::vector<float> ho(64);
     hipMemcpy(ho.data(), y + 5 * vox + 40 * E * E + 40 * E + 16, 64 * 4, hipMemcpyDeviceToHost);
     printf("%-28s Cin %d: %.3f ms  (%.0f TFLOP/s direct-equivalent)  y[..] = %g %g\n", argc > 2 ? argv[2] : "full", C, best,
