@@ -39,6 +39,7 @@ if ROOT not in sys.path:
 
 METRIC = "voxels/s sliding-window 3D seg (512^3 vol, 96^3 win, ov 0.5) at 1/8 GPU"
 PEAK_FP32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
+PEAK_F16_TFLOPS = 2500.0   # MI355X dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense, without sparsity)
 PEAK_HBM_GBS = 8000.0      # HBM3E spec peak (~6.3 TB/s achievable: the guide; 6.2-7.0 TB/s measured by tools/ubench/hbm_stream.hip)
 NETS = {"swinunetr": "SwinUNETR f48", "unetr": "UNETR ViT-B/16", "unet": "UNet 16-256 res2", "basicunet": "BasicUNet", "dynunet": "DynUNet 32-320 (5 levels)", "segresnet": "SegResNet f16"}
 
@@ -235,7 +236,14 @@ def main(argv=None):
             cfg_id = int(key.split("/cfg")[1])
             from monai_amd import ops as _ops
             ncfg = _ops.conv3d_k3_num_configs()
-            if cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
+            peak, extra = PEAK_FP32_TFLOPS, {}
+            if cfg_id == _ops.conv3d_k3_h2_config():     # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
+                kname = (f"conv3d_k3_h2_kernel (z-streaming direct 3x3x3 convolution on v_mfma_f32_32x32x16_f16, every fp32 operand as hi + lo fp16 pieces, "
+                         f"products hi*hi + lo*hi + hi*lo, fp32 accumulate: fp32-equivalent results; 32|64 -> 32 ch @ {args.roi}^3 and the levels below)")
+                gain, peak = 1.0 / 3.0, PEAK_F16_TFLOPS
+                extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS,
+                         "piece_products_per_multiply": 3}
+            elif cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
                 impl = "conv3d_k3_wino2d_kernel, one wave per SIMD" if os.environ.get("MONAI_AMD_W2_IMPL", "p")[:1] == "d" else "conv3d_k3_wino2p_kernel, two waves per SIMD"
                 kname = f"{impl} (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, 32|64 -> 32 ch @ {args.roi}^3 / {args.roi // 2}^3)"
                 gain = 2.25
@@ -244,15 +252,15 @@ def main(argv=None):
             else:
                 kname, gain = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)", 1.0
             issued = tf / gain
-            roof = {"bound": "mfma", "achieved": issued, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": issued / PEAK_FP32_TFLOPS,
+            roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak,
                     "traffic": None, "kernel": kname,
                     "note": "achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); frac = the fraction of the "
-                            "fp32-MFMA peak the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops (2*27*Cin*Cout per voxel): "
+                            "dense MFMA peak of the kernel's matrix instruction (fp32: 157.3, fp16: 2500 TFLOP/s) the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops (2*27*Cin*Cout per voxel): "
                             "Winograd needs winograd_algorithmic_gain x fewer multiply-adds for them",
-                    "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / PEAK_FP32_TFLOPS, "winograd_algorithmic_gain": gain,
+                    "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / peak, "winograd_algorithmic_gain": gain if gain >= 1.0 else None, **extra,
                     "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
                     "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / args.steps / ms}
-            td = (pmc_traffic("conv3d_k3_wino2p_kernel") or pmc_traffic("conv3d_k3_wino2d_kernel")) if cfg_id == ncfg else pmc_traffic("conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
+            td = pmc_traffic("conv3d_k3_h2_kernel") if cfg_id == _ops.conv3d_k3_h2_config() else (pmc_traffic("conv3d_k3_wino2p_kernel") or pmc_traffic("conv3d_k3_wino2d_kernel")) if cfg_id == ncfg else pmc_traffic("conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
             if td:
                 roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
         blend = spans.get("sw_blend")
@@ -280,7 +288,8 @@ def main(argv=None):
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ("f32" if os.environ.get("MONAI_AMD_CONV_ALGO") in ("fp32", "direct", "wino2d", "winograd")
+                      else "f32 (3x3x3 convolutions: fp32 operands as two fp16 pieces each, three fp16 MFMA piece products, fp32 accumulate = fp32-equivalent; everything else fp32)"),
             "data": "synthetic",
             "config": {
                 "workload": f"{NETS[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic CT volume (the reference's create_test_image_3d phantom, "

@@ -292,7 +292,7 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // configuration MH_CFG_WINOGRAD: Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32 (kernels/conv3d_winograd.h)
 #define MH_CFG_WINOGRAD (MH_NUM_CFG + 1)
 static inline int winograd_regions(int D, int H, int W) { return cdiv(W, WG_OX) * cdiv(H, WG_OY) * cdiv(D, WG_OZ); }
-// MONAI_AMD_CONV_ALGO = direct | winograd | auto (default): restricts what mh_conv3d_k3_select may return
+// MONAI_AMD_CONV_ALGO = direct | winograd | wino2d | split | h2 | fp32 | auto (default): restricts what mh_conv3d_k3_select may return
 static int conv_algo_mode() {
     const char* e = getenv("MONAI_AMD_CONV_ALGO");
     if (!e) return 0;
@@ -301,6 +301,7 @@ static int conv_algo_mode() {
     if (!strcmp(e, "wino2d")) return 3;
     if (!strcmp(e, "split")) return 4;
     if (!strcmp(e, "h2")) return 5;
+    if (!strcmp(e, "fp32")) return 6;        // auto among the exact fp32 kernels only (no split precision)
     return 0;
 }
 
@@ -368,10 +369,13 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
     // best direct tile at 96^3, 1.04x at 48^3, slower below (profiles/) -- chosen for full 16 x 16 regions of large planes.
     if (mh_conv3d_k3_accepts(MH_CFG_WINO2D, Cin, Cout) && H % 2 == 0 && W % 8 == 0) {
         const bool big = H % W2_B == 0 && W % W2_B == 0 && D >= 48 && H >= 48 && W >= 48;
-        if (mode == 3 || (mode == 0 && big)) best = MH_CFG_WINO2D;
+        if (mode == 3 || ((mode == 0 || mode == 6) && big)) best = MH_CFG_WINO2D;
     }
     if (mode == 4 && mh_conv3d_k3_accepts(MH_CFG_SPLIT, Cin, Cout) && D % SP_TZ == 0 && H % SP_TY == 0 && W % SP_TX == 0) best = MH_CFG_SPLIT;
-    if (mode == 5 && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0) best = MH_CFG_H2;
+    // fp16 two-piece split precision on the fp16 matrix cores: fp32-equivalent results (the oracle network's logits move by 4e-6,
+    // the level of two fp32 summation orders) at 1.8-2.1x the speed of the kernels above on every level it takes (96^3 ... 12^3,
+    // profiles/r02_h2_vs_wino2p_*.json) -- the default wherever the shape fits; MONAI_AMD_CONV_ALGO=fp32 keeps the exact fp32 kernels
+    if ((mode == 0 || mode == 5) && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8) best = MH_CFG_H2;
     return best;
 }
 

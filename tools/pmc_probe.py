@@ -47,7 +47,7 @@ xn = torch.zeros(B, 32, 4, device=dev)
 xn[:, :, 0] = 1.1
 xn[:, :, 1] = 0.1
 xn[:, :, 2] = 0.1
-for cfg in (ops.conv3d_k3_num_configs(), 7):
+for cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_num_configs(), 7):
     packed = ops.conv3d_k3_pack(cfg, w)
     tiles = ops.conv3d_k3_stat_tiles(cfg, 96, 96, 96)
     stats = torch.empty(B * 32 * tiles * 3, device=dev)

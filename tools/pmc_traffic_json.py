@@ -17,7 +17,7 @@ ALGORITHMIC = {                                     # key (substring of the kern
     "affine_resample_kernel<double": VOL + RES_OUT, "affine_resample_kernel<float": VOL + RES_OUT,
     "separable_resample_stream_kernel<double": VOL + RES_OUT, "separable_resample_stream_kernel<float": VOL + RES_OUT,
     "gauss3d_stream_kernel": 2 * VOL, "gauss3d_rowvec_kernel": 2 * VOL,
-    "conv3d_k3_mfma_kernel": CONV, "conv3d_k3_wino2d_kernel": CONV, "conv3d_k3_wino2p_kernel": CONV, "conv3d_k3_wino2s_kernel": CONV,
+    "conv3d_k3_mfma_kernel": CONV, "conv3d_k3_wino2d_kernel": CONV, "conv3d_k3_wino2p_kernel": CONV, "conv3d_k3_wino2s_kernel": CONV, "conv3d_k3_h2_kernel": CONV,
     "sw_blend_kernel": BLEND, "sw_blend_reg_kernel": BLEND,
 }
 WIDE_READS = ("sw_blend_kernel", "sw_blend_reg_kernel", "gauss3d_rowvec_kernel")
