@@ -465,10 +465,15 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
+#define MH_H2_LAUNCH(RES_)                                                                                                                               \
+    {                                                                                                                                                \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
+        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
+    }
+        if (in.C <= 2 * H2_KC) MH_H2_LAUNCH(true) else MH_H2_LAUNCH(false)
+#undef MH_H2_LAUNCH
         return launched("conv3d_k3_h2");
     }
     if (cfg == MH_CFG_SPLIT) {

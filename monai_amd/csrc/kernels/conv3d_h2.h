@@ -24,11 +24,22 @@
 // voxels and the second row rotated by 4 voxels make the 16-byte operand reads bank-conflict free.
 //
 // A step = 16 input channels of one input plane: the plane region [2 pieces][2 k-groups][18 x 20 voxels][8 ch] (23 KB) and the
-// chunk's weight slab [2 pieces][27 taps][2 k-groups][32 couts][8 ch] (55 KB) sit in one of two LDS buffers; one barrier per
-// step; the global loads of step s + 2 are issued right after step s + 1 has been converted into LDS.  The fp16 MFMA -- unlike
-// the fp32 one -- co-issues with another wave's VALU / LDS / memory instructions (tools/ubench/mfma_f16.hip: the MFMA wave
-// keeps 32 cycles per instruction beside a VALU wave), so the two waves of a SIMD are de-phased: one converts the next step
-// while the other multiplies.  Per step and wave: 9 (ky, kx) groups of 2 A + 6 B operand reads -> 9 MFMAs.
+// chunk's weight slab [2 pieces][27 taps][2 k-groups][32 couts][8 ch] (55 KB, padded to 57 KB) sit in one of two LDS buffers (157 KB
+// + the {alpha, beta, slope} records); one barrier per step.  With at most two chunks (Cin <= 32, template RES) both slabs are
+// loaded once and stay; otherwise a slab is streamed from L2 every step.
+//
+// Schedule.  A wave issues in order and an fp16 MFMA occupies the matrix pipe for 32 cycles: what is placed BETWEEN two MFMAs
+// of a wave is free, what sits in a lump before or after them is serial time of that wave.  The first version kept the staging
+// (loads, normalise + split, LDS writes, epilogue) in a lump per step: 6700 of 9700 cycles per step were that lump, the matrix
+// pipe 42 % busy, and neither de-phasing the two waves of a SIMD nor moving work between them changed anything (the step was
+// bounded by one wave's serial time, not by a shared resource; profiles/r02_pmc_h2_v1.txt, r02_h2_step_timeline_v1.txt).  Now
+// every staging piece is branch-free (zeroed padding cells and dump cells instead of masks, clamped pointer advance instead of
+// tail branches) and is dealt out over the 81 MFMA gaps of the step by sched_group_barrier: 10.7 -> 9.0-9.4 ms for 32 -> 32
+// channels at 96^3 x 64 windows (the fp32 Winograd kernel: 17.5 ms; the matrix pipe alone at the sustained clock: 4.7 ms).
+// Also measured and not kept: 16-byte window loads of the input (fewer vector-memory instructions, 33 % more bytes: slower),
+// loads issued up to 8 groups ahead (same), a second input register set (spills at the 256-register limit of two waves per SIMD).
+// Timing experiments with parts switched off mislead on this chip: constant operands raise the clock (the matrix pipe draws
+// less power), so "without loads" variants ran up to 40 % faster than the instruction stream explains.
 #pragma once
 #include "common.h"
 
@@ -58,7 +69,9 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 }
 
 // EMIT / PLAIN step bodies are the same code; the epilogue of a completed plane rides in the first step of the next plane
-template <bool STATS, bool NRM>
+// RES: at most two channel chunks (Cin <= 32): both weight slabs stay resident in the two LDS weight buffers (chunk = buffer index)
+// and are loaded once -- the per-step weight stream from L2 (55 KB per step and CU: 2.2 of 9.4 ms) disappears
+template <bool STATS, bool NRM, bool RES>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
@@ -123,7 +136,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
     }
 #define MH_H2_LDW(J0, J1)                                                                             \
-    _Pragma("unroll") for (int j = (J0); j < (J1); ++j) win[j] = wg[woff + 512 * j];
+    if (!RES || gi < 0) _Pragma("unroll") for (int j = (J0); j < (J1); ++j) win[j] = wg[woff + 512 * j];
     // advance to the next (plane, chunk) -- not beyond the last step (the loads then repeat the last step's addresses)
 #define MH_H2_ADV                                                                                     \
     {                                                                                                 \
@@ -152,7 +165,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
 #define MH_H2_WST                                                                                     \
     {                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[(bcur ^ 1) * H2_WB + tid + 512 * j] = win[j]; \
+        if (!RES || gi < 0) _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[(bcur ^ 1) * H2_WB + tid + 512 * j] = win[j]; \
         cs = cs + 1 == NCH ? 0 : cs + 1;                                                              \
     }
 
@@ -250,16 +263,18 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         pend = 0;                                                                                     \
     }
 #define MH_H2_NONE
+#define MH_H2_SCHEDULE(...)                                                                           \
+        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
+        MH_H2_TAP(3, __VA_ARGS__)                                                                     \
+        MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
+        MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)
     // one step (16 channels of input plane p): conversion of the next step's registers into the other LDS buffer first, then the
     // epilogue stores (EM), then the loads of the step after next
 #define MH_H2_STEP(EM)                                                                                \
     {                                                                                                 \
         MH_H2_FETCH(0, 0)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
-        MH_H2_TAP(3, EM)                                                                              \
-        MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
-        MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)                      \
+        MH_H2_SCHEDULE(EM)                                                                            \
     }
 
     // prologue: step 0 into buffer 0 (the conversion pieces write the buffer "after" bcur: start from 1), the loads of step 1 in flight
@@ -268,6 +283,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     gi = -1;
     MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WST
     MH_H2_LDX MH_H2_LDW(0, H2_WSLOTS) MH_H2_ADV
+    if (RES) {        // the second slab (chunk 1, or chunk 0 again when there is one chunk) goes into buffer 1 now and stays
+        _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[H2_WB + tid + 512 * j] = win[j];
+    }
     bcur = 0; gi = 0;
     __syncthreads();
 
@@ -294,6 +312,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
     if (pend) MH_H2_EMIT
 #undef MH_H2_STEP
+#undef MH_H2_SCHEDULE
 #undef MH_H2_NONE
 #undef MH_H2_EMIT
 #undef MH_H2_TAP

@@ -48,5 +48,15 @@ def test_host_side_queries_need_no_gpu():
     dll.mh_conv3d_k3_num_configs.restype = ctypes.c_int
     n = dll.mh_conv3d_k3_num_configs()
     assert 1 <= dll.mh_conv3d_k3_select(1, 32, 96, 96, 96) <= n
-    assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == n          # large planes: the in-plane Winograd configuration
+    dll.mh_conv3d_k3_h2_config.restype = ctypes.c_int
+    env = os.environ.pop("MONAI_AMD_CONV_ALGO", None)
+    try:
+        assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == dll.mh_conv3d_k3_h2_config()      # default: fp16 two-piece split precision
+        os.environ["MONAI_AMD_CONV_ALGO"] = "fp32"
+        assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == n      # exact fp32 kernels, large planes: the in-plane Winograd configuration
+        assert dll.mh_conv3d_k3_select(32, 32, 12, 12, 12) < n       # small planes: a direct fp32 tile
+    finally:
+        os.environ.pop("MONAI_AMD_CONV_ALGO", None)
+        if env is not None:
+            os.environ["MONAI_AMD_CONV_ALGO"] = env
     assert dll.mh_instnorm_stat_tiles(96, 96, 96) > 0

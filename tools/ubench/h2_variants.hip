@@ -8,6 +8,9 @@
 #include "monai_amd.h"
 #include "kernels/conv3d_h2.h"
 using namespace mh;
+#ifndef H2V_RES
+#define H2V_RES false
+#endif
 #ifndef H2V_STATS
 #define H2V_STATS true
 #endif
@@ -42,15 +45,16 @@ int main(int argc, char** argv) {
     float* tail = packed + (pf - H2_TAIL);
     hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, 0, w, (long long)hw.size(), tail);
     hipLaunchKernelGGL(conv3d_k3_h2_pack_kernel, dim3((C * K + 255) / 256), dim3(256), 0, 0, w, C, K, reinterpret_cast<_Float16*>(packed), tail);
-    Tensor in{x, (long long)C * (long long)vox, nrm, (long long)C * 4, N, C, E, E, E};
-    Tensor out{y, (long long)K * (long long)vox, nullptr, 0, N, K, E, E, E};
+    const int alias = argc > 3 ? atoi(argv[3]) : 0;          // 1: every window reads window 0's input, 2: every window writes window 0's output
+    Tensor in{x, (alias & 1) ? 0LL : (long long)C * (long long)vox, nrm, (long long)C * 4, N, C, E, E, E};
+    Tensor out{y, (alias & 2) ? 0LL : (long long)K * (long long)vox, nullptr, 0, N, K, E, E, E};
     const dim3 grid(nblk * N);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
+        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, H2V_RES>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
