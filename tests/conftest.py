@@ -37,5 +37,14 @@ def emu():
     """Kernel library compiled for the x86 SIMT emulator (tests/emu); CPU tensors allowed inside."""
     from emu_backend import emu_backend
 
-    with emu_backend() as lib:
-        yield lib
+    # the emulator runs the exact-fp32 convolution kernels unless a test asks otherwise: the fp16 split-precision kernel (the
+    # product default, conv3d_h2.h) is an order of magnitude slower to EMULATE; its own kernel / network cases select it explicitly
+    prev = os.environ.get("MONAI_AMD_CONV_ALGO")
+    if prev is None:
+        os.environ["MONAI_AMD_CONV_ALGO"] = "fp32"
+    try:
+        with emu_backend() as lib:
+            yield lib
+    finally:
+        if prev is None:
+            os.environ.pop("MONAI_AMD_CONV_ALGO", None)

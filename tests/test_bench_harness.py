@@ -15,7 +15,8 @@ KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "
 
 
 def _run(cmd):
-    env = dict(os.environ, MONAI_AMD_BENCH_EMULATOR="1", OMP_NUM_THREADS="4", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    # exact-fp32 convolutions: the fp16 split-precision default is an order of magnitude slower to emulate (its parity is the GPU suite's job)
+    env = dict(os.environ, MONAI_AMD_BENCH_EMULATOR="1", MONAI_AMD_CONV_ALGO="fp32", OMP_NUM_THREADS="4", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

@@ -12,6 +12,16 @@ def test_net_single_window_vs_reference(emu):
     print(r, r2)
 
 
+def test_net_single_window_fp16_split_precision_vs_reference(emu, monkeypatch):
+    """The product default: 3x3x3 convolutions on the fp16 matrix cores in two-piece split precision -- the SAME golden logits of the
+    real reference and the same tolerance as the exact-fp32 kernels."""
+    monkeypatch.delenv("MONAI_AMD_CONV_ALGO", raising=False)
+    from monai_amd import ops
+
+    assert ops.conv3d_k3_select(32, 32, 32, 32, 32) == ops.conv3d_k3_h2_config()
+    print(ec.case_net_single_window_vs_golden("cpu"))
+
+
 def test_sliding_window_net5_vs_reference(emu):
     print(ec.case_sliding_window_net5_vs_golden("cpu"))
 

@@ -88,6 +88,18 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 12
     assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 13
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13
+    # the product default (no MONAI_AMD_CONV_ALGO): fp16 two-piece split precision wherever the shape fits, the fp32 kernels elsewhere
+    import os
+
+    saved = os.environ.pop("MONAI_AMD_CONV_ALGO", None)
+    try:
+        h2 = ops.conv3d_k3_h2_config()
+        assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 7
+        assert [ops.conv3d_k3_select(*a) for a in ((32, 32, 96, 96, 96), (64, 32, 96, 96, 96), (32, 64, 48, 48, 48), (64, 128, 12, 12, 12))] == [h2] * 4
+        assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13 and ops.conv3d_k3_select(256, 256, 6, 6, 6) == 13      # W % 4 != 0 / Cin > 128
+    finally:
+        if saved is not None:
+            os.environ["MONAI_AMD_CONV_ALGO"] = saved
 
 
 def test_conv_into_channel_slice(emu):
