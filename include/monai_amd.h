@@ -175,6 +175,22 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
 int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads,
                             int head_dim, float scale, void* stream);
 
+/* nn.Linear of the transformer blocks: y[M][N] = act(x[M][K] . w[N][K]^T + bias) (+ residual[M][N]) -- SABlock.qkv / out_proj
+ * (monai/networks/blocks/selfattention.py:105-218), MLPBlock.linear1 -> GELU -> linear2 (mlp.py:56-80), the residual sums of
+ * TransformerBlock.forward (transformerblock.py:88-105), PatchEmbeddingBlock's projection of the flattened patches
+ * (patchembedding.py:32-142), SwinUNETR's WindowAttention.qkv / proj and Mlp (nets/swin_unetr.py:426-532).  fp32 in and out; the
+ * products run on the fp16 matrix cores in two-piece split precision (fp32-equivalent, see mh_conv3d_k3_h2_config).  The weight
+ * matrix is packed once per layer (mh_linear_pack_f32 into mh_linear_packed_floats(N, K) floats, 16-byte aligned).
+ * act: 0 none, 1 GELU (erf form).  K % 4 == 0; x, packed_w 16-byte aligned; bias and residual may be null. */
+int64_t mh_linear_packed_floats(int N, int K);
+int mh_linear_pack_f32(const float* w, int N, int K, float* packed, void* stream);
+int mh_linear_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                  void* stream);
+
+/* nn.LayerNorm over the last dimension (TransformerBlock.norm1 / norm2, ViT.norm, SwinTransformerBlock.norm1 / norm2, PatchMerging.norm):
+ * y = (x - mean) * rsqrt(var + eps) * gamma + beta per row, biased variance.  K <= 4096; gamma / beta may be null. */
+int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M, int K, void* stream);
+
 /* ---- UNet pieces (monai/networks/nets/unet.py:106-298) --------------------------------------------------------- */
 
 /* Conv3d k=3, stride s, padding 1 (+bias) of act(in): the strided `Convolution` / `ResidualUnit` convs of the down path

@@ -16,6 +16,7 @@
 #include "kernels/conv3d_wino2s.h"
 #include "kernels/conv3d_split.h"
 #include "kernels/conv3d_h2.h"
+#include "kernels/dense.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
 #include "kernels/pushpull.h"
@@ -1206,6 +1207,52 @@ int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* 
         default: return fail(MH_ERR_UNSUPPORTED, "window_attention: head_dim %d is not built (8, 16, 32 are)", head_dim);
     }
     return launched("window_attention");
+}
+
+// ------------------------------------------------------------------------------------------ dense transformer pieces
+int64_t mh_linear_packed_floats(int N, int K) {
+    if (N < 1 || K < 1) return fail(MH_ERR_ARG, "linear_packed_floats: bad argument");
+    return (int64_t)cdiv(N, DN_BN) * cdiv(K, DN_BK) * DN_BT * 4 + H2_TAIL;
+}
+
+int mh_linear_pack_f32(const float* w, int N, int K, float* packed, void* stream) {
+    if (!w || !packed || N < 1 || K < 1) return fail(MH_ERR_ARG, "linear_pack: bad argument");
+    if (!aligned(packed, 16)) return fail(MH_ERR_ARG, "linear_pack: 16-byte aligned packed buffer required");
+    const int64_t slab_floats = mh_linear_packed_floats(N, K) - H2_TAIL;
+    float* tail = packed + slab_floats;
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)N * K, tail);
+    const long long padded = (long long)cdiv(N, DN_BN) * DN_BN * cdiv(K, DN_BK) * DN_BK;
+    hipLaunchKernelGGL(linear_h2_pack_kernel, dim3(blocks_for(padded)), dim3(256), 0, (hipStream_t)stream, w, N, K, reinterpret_cast<_Float16*>(packed), tail);
+    return launched("linear_pack");
+}
+
+int mh_linear_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                  void* stream) {
+    if (!x || !packed_w || !y || M < 1 || N < 1 || K < 1) return fail(MH_ERR_ARG, "linear: bad argument");
+    if (K % 4 || !aligned(x, 16) || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "linear: K %% 4 == 0 and 16-byte aligned x / packed weights required (K = %d)", K);
+    if (act < 0 || act > 1) return fail(MH_ERR_UNSUPPORTED, "linear: activation %d is not built (0 none, 1 GELU)", act);
+    const int ntn = cdiv(N, DN_BN);
+    const long long total = (long long)cdiv((int)((M + DN_BM - 1) / DN_BM), 1) * ntn;
+    if (M > 0x7fffffffLL || total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "linear: problem too large for one launch");
+    const dim3 grid((unsigned)total);
+    const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
+    const float* tail = packed_w + (mh_linear_packed_floats(N, K) - H2_TAIL);
+    hipStream_t s = (hipStream_t)stream;
+#define MH_LINEAR_LAUNCH(A_, R_) hipLaunchKernelGGL((linear_h2_kernel<A_, R_>), grid, dim3(256), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn)
+    if (act == 1 && residual) MH_LINEAR_LAUNCH(1, true);
+    else if (act == 1) MH_LINEAR_LAUNCH(1, false);
+    else if (residual) MH_LINEAR_LAUNCH(0, true);
+    else MH_LINEAR_LAUNCH(0, false);
+#undef MH_LINEAR_LAUNCH
+    return launched("linear");
+}
+
+int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M, int K, void* stream) {
+    if (!x || !y || M < 1 || K < 1) return fail(MH_ERR_ARG, "layernorm: bad argument");
+    if (K > 64 * LN_MAXV) return fail(MH_ERR_UNSUPPORTED, "layernorm: %d features exceed the register-resident limit of %d", K, 64 * LN_MAXV);
+    if ((M + 3) / 4 > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "layernorm: too many rows for one launch");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, y, (int)M, K);
+    return launched("layernorm");
 }
 
 // ------------------------------------------------------------------------------------------ UNet pieces

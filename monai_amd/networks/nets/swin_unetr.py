@@ -10,8 +10,9 @@ Inference engine:
   * Swin transformer (SwinTransformer :927-1069, BasicLayer :790-924, SwinTransformerBlock :544-697, PatchMerging :700-771):
     the attention core of every block -- (q * scale) k^T + relative position bias + shifted-window mask, softmax, @ v -- is the HIP
     kernel ``mh_window_attention_f32`` working straight on the qkv projection's output of all windows; the dense projections
-    (patch embedding, qkv, proj, MLP, patch-merging reduction) are plain library GEMMs (``F.linear``), LayerNorm / GELU / residual
-    adds, the cyclic shift and the window partition are torch data-movement / element-wise ops on the device;
+    (patch embedding, qkv, proj, MLP with GELU and its residual, patch-merging reduction) and every LayerNorm are the HIP kernels of
+    ``csrc/kernels/dense.h`` (``mh_linear_f32`` on the fp16 matrix cores in two-piece split precision, ``mh_layernorm_f32``); the
+    cyclic shift, the window partition / reverse and the attention residual are torch data movement on the device;
   * conv part (UnetrBasicBlock / UnetrUpBlock with UnetResBlock, UnetOutBlock): the engine of ``monai_amd.networks.nets.unetr`` --
     fp32-MFMA 3x3x3 convolutions with fused InstanceNorm statistics, deferred normalise + LeakyReLU(0.01) on load, transposed-conv
     and 1x1 kernels, in-place concat buffers.
@@ -236,7 +237,7 @@ class SwinUNETR(UNETR):
     def _block(self, blk: _SwinBlock, x):
         """SwinTransformerBlock.forward (swin_unetr.py:598-697) on channel-last x [B, d, h, w, C]"""
         b, d, h, w, c = x.shape
-        y = F.layer_norm(x, (c,), blk.norm1.weight, blk.norm1.bias, 1e-5)
+        y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-5)
         ws, ss = _get_window_size((d, h, w), blk.window_size, blk.shift_size)
         pd, ph, pw = (ws[0] - d % ws[0]) % ws[0], (ws[1] - h % ws[1]) % ws[1], (ws[2] - w % ws[2]) % ws[2]
         if pd or ph or pw:
@@ -249,23 +250,22 @@ class SwinUNETR(UNETR):
             mask = self._mask((dp, hp, wp), ws, ss, x.device)
         win = _window_partition(y, ws)                                        # [BW, S, C]
         a = blk.attn
-        qkv = F.linear(win, a.qkv.weight, a.qkv.bias)
+        qkv = self._lin(win, a.qkv.weight, a.qkv.bias)
         n = win.shape[1]
         hd = c // a.num_heads
         with _prof.span("window_attention", 4.0 * n * n * hd * a.num_heads * win.shape[0]):
-            att = ops.window_attention(qkv.contiguous(), a.num_heads, a.scale, self._bias_t(a, n), mask)
-        att = F.linear(att, a.proj.weight, a.proj.bias)
+            att = ops.window_attention(qkv, a.num_heads, a.scale, self._bias_t(a, n), mask)
+        att = self._lin(att, a.proj.weight, a.proj.bias)
         y = _window_reverse(att, ws, (b, dp, hp, wp))
         if shifted:
             y = torch.roll(y, shifts=ss, dims=(1, 2, 3))
         if pd or ph or pw:
             y = y[:, :d, :h, :w, :].contiguous()
-        x = x + y
-        m = F.layer_norm(x, (c,), blk.norm2.weight, blk.norm2.bias, 1e-5)
-        return x + F.linear(F.gelu(F.linear(m, blk.mlp.linear1.weight, blk.mlp.linear1.bias)), blk.mlp.linear2.weight, blk.mlp.linear2.bias)
+        x = (x + y).contiguous()
+        m = self._lin(ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, 1e-5), blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
+        return self._lin(m, blk.mlp.linear2.weight, blk.mlp.linear2.bias, residual=x)
 
-    @staticmethod
-    def _merge(pm: _PatchMerging, x):
+    def _merge(self, pm: _PatchMerging, x):
         """PatchMerging / PatchMergingV2 (swin_unetr.py:700-771): 2x2x2 neighbours -> channels, LayerNorm, Linear 8C -> 2C"""
         b, d, h, w, c = x.shape
         if d % 2 or h % 2 or w % 2:
@@ -275,18 +275,18 @@ class SwinUNETR(UNETR):
         else:
             order = [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0), (1, 0, 1), (0, 1, 1), (1, 1, 1)]
         x = torch.cat([x[:, i::2, j::2, k::2, :] for i, j, k in order], -1)
-        x = F.layer_norm(x, (8 * c,), pm.norm.weight, pm.norm.bias, 1e-5)
-        return F.linear(x, pm.reduction.weight)
+        x = ops.layernorm(x, pm.norm.weight, pm.norm.bias, 1e-5)
+        return self._lin(x, pm.reduction.weight, None)
 
     def _swin(self, x_in):
         """SwinTransformer.forward (swin_unetr.py:1047-1069) -> the five hidden states, channel-first"""
         pe = self.swinViT.patch_embed.proj
         b, cin, d, h, w = x_in.shape
         p = x_in.reshape(b, cin, d // 2, 2, h // 2, 2, w // 2, 2).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, d // 2, h // 2, w // 2, cin * 8)
-        x = F.linear(p, pe.weight.reshape(pe.weight.shape[0], -1), pe.bias)          # channel-last [B, d/2, h/2, w/2, C0]
+        x = self._lin(p, pe.weight, pe.bias)          # channel-last [B, d/2, h/2, w/2, C0]
 
         def proj_out(t):
-            t = F.layer_norm(t, (t.shape[-1],)) if self.normalize else t
+            t = ops.layernorm(t, None, None, 1e-5) if self.normalize else t
             return t.permute(0, 4, 1, 2, 3).contiguous()
 
         outs = [proj_out(x)]

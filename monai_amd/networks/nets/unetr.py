@@ -258,25 +258,40 @@ class UNETR(nn.Module):
         return torch.empty((n, c) + sp, dtype=torch.float32, device=like.device)
 
     # ---- ViT ---------------------------------------------------------------------------------------
+    def _lin(self, x, weight, bias, residual=None, gelu=False):
+        """nn.Linear (+ GELU) (+ residual) as ONE launch of the split-precision GEMM kernel (csrc/kernels/dense.h); the packed weight
+        is cached per parameter (re-packed when the parameter is updated in place or moved)."""
+        key = (weight.data_ptr(), weight._version, str(weight.device))
+        hit = self._packed.get(("lin", id(weight)))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.linear_pack(weight.reshape(weight.shape[0], -1)))
+            self._packed[("lin", id(weight))] = hit
+        m = x.numel() // x.shape[-1]
+        with _prof.span("linear", 2.0 * m * weight.shape[0] * x.shape[-1]):
+            return ops.linear(x, hit[1], weight.shape[0], bias, residual, gelu=gelu)
+
     def _vit(self, x_in):
+        """ViT (monai/networks/nets/vit.py:27-142): patch embedding, 12 x TransformerBlock (transformerblock.py:88-105: x + attn(norm1(x)),
+        x + mlp(norm2(x))), final norm -- LayerNorm, the four linear maps of a block (bias / GELU / residual fused into their epilogues)
+        and the attention are HIP kernels (no library GEMM; the patch gather in front is a strided copy)."""
         pe = self.vit.patch_embedding
         b = x_in.shape[0]
         fz, fy, fx = self.feat_size
         c = x_in.shape[1]
         patches = x_in.reshape(b, c, fz, 16, fy, 16, fx, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, fz * fy * fx, c * 4096)
-        t = F.linear(patches, pe.patch_embeddings.weight.reshape(self.hidden_size, -1), pe.patch_embeddings.bias) + pe.position_embeddings
+        pos = pe.position_embeddings.expand(b, -1, -1).contiguous()
+        t = self._lin(patches, pe.patch_embeddings.weight, pe.patch_embeddings.bias, residual=pos)
         hidden = []
         scale = 64 ** -0.5
-        h = self.hidden_size
         for blk in self.vit.blocks:
-            qkv = F.linear(F.layer_norm(t, (h,), blk.norm1.weight, blk.norm1.bias, 1e-5), blk.attn.qkv.weight, blk.attn.qkv.bias)
+            qkv = self._lin(ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, 1e-5), blk.attn.qkv.weight, blk.attn.qkv.bias)
             with _prof.span("attention", 4.0 * qkv.shape[1] ** 2 * 64 * self.num_heads * b):
-                a = ops.attention(qkv.contiguous(), self.num_heads, scale)
-            t = t + F.linear(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias)
-            m = F.layer_norm(t, (h,), blk.norm2.weight, blk.norm2.bias, 1e-5)
-            t = t + F.linear(F.gelu(F.linear(m, blk.mlp.linear1.weight, blk.mlp.linear1.bias)), blk.mlp.linear2.weight, blk.mlp.linear2.bias)
+                a = ops.attention(qkv, self.num_heads, scale)
+            t = self._lin(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=t)
+            m = self._lin(ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, 1e-5), blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
+            t = self._lin(m, blk.mlp.linear2.weight, blk.mlp.linear2.bias, residual=t)
             hidden.append(t)
-        return F.layer_norm(t, (h,), self.vit.norm.weight, self.vit.norm.bias, 1e-5), hidden
+        return ops.layernorm(t, self.vit.norm.weight, self.vit.norm.bias, 1e-5), hidden
 
     def _proj_feat(self, t):
         return t.view(t.size(0), *self.feat_size, self.hidden_size).permute(0, 4, 1, 2, 3).contiguous()

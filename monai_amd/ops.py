@@ -336,6 +336,52 @@ def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Option
     return out
 
 
+def linear_pack(weight: torch.Tensor) -> torch.Tensor:
+    """Pack an nn.Linear weight [N, K] for `linear` (two fp16 pieces per value, power-of-two layer scale, tile layout); once per layer."""
+    _lib.require_device(weight)
+    if weight.dim() != 2:
+        raise RuntimeError(f"monai_amd.linear_pack: weight must be [N, K], got {tuple(weight.shape)}")
+    n, k = (int(v) for v in weight.shape)
+    packed = torch.empty(_lib.lib().query("mh_linear_packed_floats", n, k), dtype=torch.float32, device=weight.device)
+    _lib.lib().call("mh_linear_pack_f32", _lib.ptr(weight.contiguous()), n, k, _lib.ptr(packed), _s(weight))
+    return packed
+
+
+def linear(x: torch.Tensor, packed_w: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           gelu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[..., N] = act(x[..., K] . W^T + bias) (+ residual) -- nn.Linear (+ nn.GELU()) (+ the residual sum of a transformer block) in one
+    launch on the fp16 matrix cores in two-piece split precision (fp32-equivalent).  `packed_w` = linear_pack(W)."""
+    _lib.require_device(x, packed_w, bias, residual, out)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    k = int(x.shape[-1])
+    m = x.numel() // k
+    shape = tuple(x.shape[:-1]) + (int(n_out),)
+    if k % 4:
+        raise NotImplementedError(f"monai_amd.linear: {k} input features are not on the HIP path (a multiple of 4 is)")
+    if residual is not None and (tuple(residual.shape) != shape or not residual.is_contiguous()):
+        raise RuntimeError(f"monai_amd.linear: residual must be contiguous {shape}, got {tuple(residual.shape)}")
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise RuntimeError(f"monai_amd.linear: out must be contiguous {shape}")
+    _lib.lib().call("mh_linear_f32", _lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out), m, int(n_out), k, 1 if gelu else 0, _s(x))
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float = 1e-5) -> torch.Tensor:
+    """nn.LayerNorm over the last dimension (<= 4096 features)."""
+    _lib.require_device(x, weight, bias)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    k = int(x.shape[-1])
+    if k > 4096:
+        raise NotImplementedError(f"monai_amd.layernorm: {k} features are not on the HIP path (<= 4096 are)")
+    out = torch.empty_like(x)
+    _lib.lib().call("mh_layernorm_f32", _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), float(eps), _lib.ptr(out), x.numel() // k, k, _s(x))
+    return out
+
+
 def conv3d_k3_strided(x, x_nrm, packed_w0, bias, out, stride: int):
     """out = conv3x3x3(act(x), stride, padding 1) + bias; packed_w0 = conv3d_k3_pack(0, weight)."""
     _lib.require_device(x, x_nrm, packed_w0, bias, out)

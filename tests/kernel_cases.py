@@ -353,3 +353,37 @@ def case_strided_conv_and_deconv_k3(device):
     out = torch.empty_like(a).to(device)
     ops.add_act(a.to(device), na.to(device), None, None, 1.0, out)
     assert (out.cpu() - _act(a, na)).abs().max().item() < 2e-6
+
+
+def case_linear(device, m, n, k, gelu=False, residual=False, bias=True, tol=2e-5):
+    """nn.Linear (+ GELU, + residual) on the fp16 matrix cores in two-piece split precision: held to the tolerance of an fp32 GEMM."""
+    gen = torch.Generator().manual_seed(1000 + m + n + k)
+    x = torch.randn((m, k), generator=gen)
+    w = torch.randn((n, k), generator=gen) / np.sqrt(k)
+    b = torch.randn(n, generator=gen) * 0.1 if bias else None
+    r = torch.randn((m, n), generator=gen) if residual else None
+    exp = F.linear(x.double(), w.double(), None if b is None else b.double())
+    if gelu:
+        exp = F.gelu(exp)
+    if r is not None:
+        exp = exp + r.double()
+    packed = ops.linear_pack(w.to(device))
+    got = ops.linear(x.to(device), packed, n, None if b is None else b.to(device), None if r is None else r.to(device), gelu=gelu).cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"linear {m}x{k} -> {n} gelu={gelu} res={residual}: max err {err}"
+    # leading dimensions are flattened
+    got3 = ops.linear(x.reshape(2, m // 2, k).to(device), packed, n, None if b is None else b.to(device), gelu=gelu)
+    assert got3.shape == (2, m // 2, n)
+    return err
+
+
+def case_layernorm(device, m, k):
+    gen = torch.Generator().manual_seed(2000 + m + k)
+    x = torch.randn((m, k), generator=gen) * 3.0 + 1.5
+    g = torch.rand(k, generator=gen) + 0.5
+    b = torch.randn(k, generator=gen) * 0.2
+    exp = F.layer_norm(x.double(), (k,), g.double(), b.double(), 1e-5)
+    got = ops.layernorm(x.to(device), g.to(device), b.to(device), 1e-5).cpu().double()
+    assert (got - exp).abs().max().item() < 5e-6, (got - exp).abs().max().item()
+    got = ops.layernorm(x.to(device), None, None, 1e-6).cpu().double()
+    assert (got - F.layer_norm(x.double(), (k,), None, None, 1e-6)).abs().max().item() < 5e-6

@@ -191,3 +191,16 @@ def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+
+
+LINEAR_CASES = [(128, 64, 16, False, False), (200, 144, 48, False, True), (66, 40, 36, True, False), (256, 192, 64, True, True)]
+@pytest.mark.parametrize("m,n,k,gelu,res", LINEAR_CASES)
+def test_linear_fp16_split_precision(emu, m, n, k, gelu, res):
+    """nn.Linear (+ GELU, + residual): ragged rows / columns / K (multiples of 4), bias on and off"""
+    kc.case_linear("cpu", m, n, k, gelu=gelu, residual=res)
+    kc.case_linear("cpu", m, n, k, gelu=gelu, residual=res, bias=False)
+
+
+@pytest.mark.parametrize("m,k", [(7, 48), (130, 768), (5, 100)])
+def test_layernorm(emu, m, k):
+    kc.case_layernorm("cpu", m, k)
