@@ -61,7 +61,7 @@ constexpr int H2_WSLOTS = 7;                               // uint4 of the weigh
 constexpr int H2_WB = 512 * H2_WSLOTS;                     // uint4 per weight buffer: two pieces (3456) padded to 7 per thread (3584)
 constexpr int H2_SLOTS = 3;                                // staging tasks per lane: (voxel, 4 channels); 162 voxels per wave
 constexpr int H2_TAIL = 4;                                 // floats behind the packed slabs: {1 / scale, scale, 0, 0}
-constexpr int H2_NRM_MAX = 128;                            // input channels (their {alpha, beta, slope} records sit in LDS)
+constexpr int H2_NRM_MAX = 256;                            // input channels: their {alpha, beta, slope} records sit in LDS, 12 bytes each (157 + 3 KB = all 160 KB)
 
 __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
     __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
-    __shared__ float4 nrm_s[NRM ? H2_NRM_MAX : 1];
+    __shared__ float nrm_s[NRM ? 3 * H2_NRM_MAX : 1];
     uint4* const xs = smem;
     uint4* const ws = smem + 2 * H2_XB;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -115,7 +115,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
     for (int i = tid; i < 2 * H2_XB; i += 512) xs[i] = make_uint4(0u, 0u, 0u, 0u);
     if (NRM) {
-        for (int c = tid; c < Cin; c += 512) nrm_s[c] = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
+        for (int c = tid; c < Cin; c += 512) {
+            const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
+            nrm_s[3 * c] = a.x; nrm_s[3 * c + 1] = a.y; nrm_s[3 * c + 2] = a.z;
+        }
     }
     __syncthreads();
 
@@ -154,8 +157,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             float y_ = xin[J][i];                                                                     \
             if (NRM) {                                                                                \
-                const float4 a_ = nrm_s[H2_KC * cs + 4 * q + i];                                      \
-                y_ = act(y_, a_.x, a_.y, a_.z);                                                       \
+                const float* a_ = nrm_s + 3 * (H2_KC * cs + 4 * q + i);                               \
+                y_ = act(y_, a_[0], a_[1], a_[2]);                                                    \
             }                                                                                         \
             h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \

@@ -96,7 +96,8 @@ def test_conv_mfma_separate_stats_and_select(emu):
         h2 = ops.conv3d_k3_h2_config()
         assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == 7
         assert [ops.conv3d_k3_select(*a) for a in ((32, 32, 96, 96, 96), (64, 32, 96, 96, 96), (32, 64, 48, 48, 48), (64, 128, 12, 12, 12))] == [h2] * 4
-        assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13 and ops.conv3d_k3_select(256, 256, 6, 6, 6) == 13      # W % 4 != 0 / Cin > 128
+        assert ops.conv3d_k3_select(256, 128, 12, 12, 12) == h2 and not ops.conv3d_k3_accepts(h2, 272, 32)
+        assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13 and ops.conv3d_k3_select(256, 256, 6, 6, 6) == 13      # W % 4 != 0
     finally:
         if saved is not None:
             os.environ["MONAI_AMD_CONV_ALGO"] = saved
@@ -179,7 +180,7 @@ def test_conv3d_split_precision(emu, cin, cout, dims, n):
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
-H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1)]
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
 def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     """z-streaming direct convolution on the fp16 matrix cores, two fp16 pieces per operand and three exact piece products per

@@ -157,7 +157,7 @@ def test_conv3d_split_precision(cin, cout, dims, n):
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
-H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1)]
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
 def test_conv3d_fp16_split_precision(cin, cout, dims, n):
     """z-streaming direct convolution on the fp16 matrix cores, two fp16 pieces per operand and three exact piece products per
