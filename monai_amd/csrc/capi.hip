@@ -1251,7 +1251,16 @@ int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, floa
     if (!x || !y || M < 1 || K < 1) return fail(MH_ERR_ARG, "layernorm: bad argument");
     if (K > 64 * LN_MAXV) return fail(MH_ERR_UNSUPPORTED, "layernorm: %d features exceed the register-resident limit of %d", K, 64 * LN_MAXV);
     if ((M + 3) / 4 > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "layernorm: too many rows for one launch");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, y, (int)M, K);
+    const dim3 grid((unsigned)((M + 3) / 4));
+    hipStream_t s = (hipStream_t)stream;
+#define MH_LN_LAUNCH(NV_) hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, s, x, gamma, beta, eps, y, (int)M, K)
+    if (K <= 64) MH_LN_LAUNCH(1);
+    else if (K <= 128) MH_LN_LAUNCH(2);
+    else if (K <= 256) MH_LN_LAUNCH(4);
+    else if (K <= 512) MH_LN_LAUNCH(8);
+    else if (K <= 1024) MH_LN_LAUNCH(16);
+    else MH_LN_LAUNCH(64);
+#undef MH_LN_LAUNCH
     return launched("layernorm");
 }
 

@@ -35,8 +35,8 @@ struct ConvCfg {
     static constexpr int W_FLOATS = CC * 27 * CN;
     static constexpr int SLOTS = (CHS + 255) / 256;          // halo-tile elements per thread per channel
     static constexpr int WV4 = (W_FLOATS / 4 + 255) / 256;   // weight float4s per thread per chunk
-    static constexpr int NRM_MAX = 512;           // max input channels (float4 each) kept in LDS
-    static constexpr int SMEM_FLOATS = IN_FLOATS + W_FLOATS + 4 * NRM_MAX;
+    static constexpr int NRM_MAX = 768;           // max input channels ({alpha, beta, slope}: 12 bytes each) kept in LDS
+    static constexpr int SMEM_FLOATS = IN_FLOATS + W_FLOATS + 3 * NRM_MAX;
     static_assert(MX * MY * MZ == 32, "an M-tile is 32 voxels");
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(CC % 2 == 0, "two input channels per MFMA");
@@ -90,7 +90,7 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     __shared__ __attribute__((aligned(16))) float smem[Cfg::SMEM_FLOATS];
     float* xs = smem;
     float* ws = smem + Cfg::IN_FLOATS;
-    float4* nrm_s = reinterpret_cast<float4*>(smem + Cfg::IN_FLOATS + Cfg::W_FLOATS);
+    float* nrm_s = smem + Cfg::IN_FLOATS + Cfg::W_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -106,8 +106,10 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
     const int tz0 = (int)(b / (tiles_x * tiles_y)) * Cfg::TZ;
     const int ct = blockIdx.y, n = blockIdx.z;
 
-    for (int c = tid; c < CinP; c += 256)
-        nrm_s[c] = c < Cin ? load_nrm(in, n, c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int c = tid; c < CinP; c += 256) {
+        const float4 a = c < Cin ? load_nrm(in, n, c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        nrm_s[3 * c] = a.x; nrm_s[3 * c + 1] = a.y; nrm_s[3 * c + 2] = a.z;
+    }
 
     // this thread's positions in the halo tile: global offset inside a channel plane, and validity
     int soff[SLOTS];
@@ -163,12 +165,12 @@ conv3d_k3_mfma_kernel(Tensor in, const float* __restrict__ wp, const float* __re
         // volume (the conv's zero padding acts on the ACTIVATED tensor) and for padded channels
 #pragma unroll
         for (int c = 0; c < CC; ++c) {
-            const float4 a = nrm_s[c0 + c];
+            const float a_x = nrm_s[3 * (c0 + c)], a_y = nrm_s[3 * (c0 + c) + 1], a_z = nrm_s[3 * (c0 + c) + 2];
             const bool cok = c0 + c < Cin;
 #pragma unroll
             for (int j = 0; j < SLOTS; ++j) {
                 const int r = tid + 256 * j;
-                if (r < CHS) xs[c * CHS + r] = (cok && sok[j]) ? act(xin[c][j], a.x, a.y, a.z) : 0.0f;
+                if (r < CHS) xs[c * CHS + r] = (cok && sok[j]) ? act(xin[c][j], a_x, a_y, a_z) : 0.0f;
             }
         }
 #pragma unroll
