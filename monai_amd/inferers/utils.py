@@ -202,7 +202,7 @@ def sliding_window_inference(
     # all-window logits that do not fit in HBM: slab by slab along the first spatial axis (see _slabwise)
     argmax_dtype = kwargs.pop("_monai_amd_argmax", None)      # fused AsDiscrete(argmax=True) epilogue (sliding_window_argmax below)
     slab_ok = (not kwargs.pop("_monai_amd_no_slabs", False) and not with_coord and process_fn is None and not any(pad_size)
-               and len(starts[0]) > 1 and parallel.window_shard(num_win).world == 1)
+               and len(starts[0]) > 1)
     if slab_ok:
         sub_kwargs = dict(kwargs, _monai_amd_no_slabs=True, _monai_amd_argmax=argmax_dtype)
 
@@ -415,11 +415,14 @@ def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
     dense = k * seg3[0] * seg3[1] * seg3[2]
     ws = _window_stride(dense)
     need = rows * ws * 4
+    # the fit decision must be the same on every rank (a rank that went slab-wise alone would dead-lock the others' collectives):
+    # under window sharding the budget is the MINIMUM over the ranks
+    limit = _logits_budget(dev)
     if dev.type == "cuda":
         free, _ = torch.cuda.mem_get_info(dev)
+        free = float(shard.agree_batch(int(free), dev))
         if need > 0.9 * free:
             raise _LogitsDoNotFit(need, free)
-    limit = _logits_budget(dev)
     if limit is not None and need > limit:
         raise _LogitsDoNotFit(need, limit)
     flat = torch.empty(rows * ws, dtype=dtype, device=dev)
@@ -466,7 +469,7 @@ class _LogitsDoNotFit(RuntimeError):
         super().__init__(
             f"monai_amd: the all-window logits buffer needs {need / 2**30:.2f} GiB, the budget is {budget / 2**30:.2f} GiB of HBM "
             "(and the volume cannot be cut into slabs along its first spatial axis: a single row of windows does not fit, or the "
-            "call uses with_coord / process_fn / window sharding, whose semantics are tied to the whole volume)"
+            "call uses with_coord / process_fn, whose semantics are tied to the whole volume)"
         )
         self.need, self.budget = need, budget
 

@@ -44,6 +44,13 @@ def _worker(rank, world, port, shape, roi, ret):
             sharded2 = inf(x, net).clone()
             del os.environ["MONAI_AMD_SW_BATCH"]
             assert torch.equal(sharded, sharded2), "the result must not depend on the round size"
+            # volumes whose logits exceed the budget go slab by slab -- also under sharding (every slab's windows are sharded, the
+            # fit decision is collective): force it with a cap of two window rows and compare with the unsharded result
+            per_win = 3 * roi[0] * roi[1] * roi[2] * 4
+            os.environ["MONAI_AMD_MAX_LOGITS_BYTES"] = str(2 * 2 * per_win + 64)
+            slabbed = inf(x, net).clone()
+            del os.environ["MONAI_AMD_MAX_LOGITS_BYTES"]
+            assert torch.equal(slabbed, sharded), "slab-wise processing under window sharding must not change a bit"
             parallel.disable_window_sharding()
             shard = parallel.partition(7, world, rank)
         ret[rank] = (single, sharded, (shard.lo, shard.hi, shard.chunk))
