@@ -1,7 +1,9 @@
-// Development aid: times conv3d_k3_h2_kernel (32 -> 32 channels, 96^3, 64 windows) standalone, so that diagnostic builds
-// (-DH2_DIAG_NOMFMA / NOCONV / NOLOADS / NOFETCH / NOBAR / NOEMIT: parts of the kernel switched off; results are wrong, only the
-// time matters) compile in seconds on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-DH2_DIAG_...] tools/ubench/h2_variants.hip -o /tmp/h2v && /tmp/h2v
+// Development aid: times conv3d_k3_h2_kernel (Cin -> 32 channels, 96^3, 64 windows) standalone, so that variants of the kernel header
+// (-DH2V_RES=true: resident weight slabs; any experimental -D switch added to conv3d_h2.h) compile in seconds on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-D...] tools/ubench/h2_variants.hip -o /tmp/h2v
+//   /tmp/h2v <Cin> <label> [alias]      alias 1: every window reads window 0's input, 2: every window writes window 0's output
+// Lesson kept from the round-2 ablations: builds that replace loads by register moves feed the matrix pipe constant data, the chip
+// then clocks 25-40 % higher, and the "saving" is mostly that -- only timings with real data count.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -10,9 +12,6 @@
 using namespace mh;
 #ifndef H2V_RES
 #define H2V_RES false
-#endif
-#ifndef H2V_STATS
-#define H2V_STATS true
 #endif
 
 int main(int argc, char** argv) {
