@@ -305,20 +305,21 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
 // Arithmetic is the same rs_comb chain (x, y, z) on the same values as the other kernels: identical results.
 constexpr int RZ_TOY = 16, RZ_TOX = 128;
 
-template <typename T> struct RzTile {     // per-thread constants of the march
-    int ad[4][2];                         // LDS address of the (y0, x0) corner of output (row j, column h)
-    int adn[4][2];                        // ... of its (y1, x0) corner in the interior path (= ad + row pitch)
-    int dx[2], dy[4];                     // boundary tiles: address steps to the x1 / y1 corner (0 when that tap is dropped or clamped)
-    T wx0[2], wx1[2], wy0[4], wy1[4];
+// RJ = output rows per thread (RZ_TOY rows over NT / 64 waves): 4 with 256 threads, 2 with 512
+template <typename T, int RJ> struct RzTile {     // per-thread constants of the march
+    int ad[RJ][2];                         // LDS address of the (y0, x0) corner of output (row j, column h)
+    int adn[RJ][2];                        // ... of its (y1, x0) corner in the interior path (= ad + row pitch)
+    int dx[2], dy[RJ];                     // boundary tiles: address steps to the x1 / y1 corner (0 when that tap is dropped or clamped)
+    T wx0[2], wx1[2], wy0[RJ], wy1[RJ];
     unsigned okm;                         // boundary tiles: bit (j*2+h)*4 + corner set = corner contributes
 };
 
 // In-plane (x, then y) interpolation of the staged source plane at this thread's 8 outputs.  Interior tiles (every tap
 // valid, so x1 = x0 + 1 and y1 = y0 + 1): two paired LDS reads per output at addresses fixed for the whole march.
-template <typename T, bool MASKED>
-__device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, const RzTile<T>& t, T (&P)[8]) {
+template <typename T, int RJ, bool MASKED>
+__device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, const RzTile<T, RJ>& t, T (&P)[2 * RJ]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < RJ; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float v[4];
@@ -337,13 +338,13 @@ __device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, c
         }
 }
 
-// NLOAD = staged floats per thread and plane (box capacity 256 * NLOAD; chosen by the launcher from the scales)
-template <typename T, int NLOAD>
-__global__ void __launch_bounds__(256)
+// NLOAD = staged floats per thread and plane (box capacity NT * NLOAD; chosen by the launcher from the scales); NT = threads
+template <typename T, int NLOAD, int NT>
+__global__ void __launch_bounds__(NT)
 separable_resample_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a,
                                  int zchunk, int nchunk) {
-    constexpr int CAP = NLOAD * 256;
-    __shared__ float box[2][CAP];
+    constexpr int CAP = NLOAD * NT, NW = NT / 64, RJ = RZ_TOY / NW;
+    __shared__ float box[2][CAP];      // staged as fp32 also for fp64 interpolation (staging doubles measured slower: twice the LDS traffic)
     __shared__ int lim[5], part[6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nbx = (a.Wo + RZ_TOX - 1) / RZ_TOX, nby = (a.Ho + RZ_TOY - 1) / RZ_TOY, tiles = nbx * nby;
@@ -394,9 +395,9 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         // every tap of one axis outside the volume (all zeros), or a box larger than the LDS plane: per-voxel gathers
         for (int oz = oz_s; oz < oz_e; ++oz) {
             const AxisTap<T> tz = tab[oz];
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < RJ; ++j)
                 for (int h = 0; h < 2; ++h) {
-                    const int jy = wave + 4 * j, jx = lane + 64 * h;
+                    const int jy = wave + NW * j, jx = lane + 64 * h;
                     if (jy >= ny || jx >= nx) continue;
                     const AxisTap<T> ty = tab[a.Do + oy0 + jy], tx = tab[a.Do + a.Ho + ox0 + jx];
                     const int zi[2] = {tz.i0, tz.i1}, yi[2] = {ty.i0, ty.i1}, xi[2] = {tx.i0, tx.i1};
@@ -416,12 +417,12 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
     }
 
     // per-thread march constants: columns lane and lane + 64, rows wave, wave + 4, wave + 8, wave + 12
-    RzTile<T> t;
+    RzTile<T, RJ> t;
     t.okm = 0u;
     bool bad = false;
     {
-        int xa[2], ya[4];
-        bool xok[2][2], yok[4][2];
+        int xa[2], ya[RJ];
+        bool xok[2][2], yok[RJ][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const AxisTap<T> e = tab[a.Do + a.Ho + ox0 + min(lane + 64 * h, nx - 1)];
@@ -431,15 +432,15 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
             t.wx0[h] = e.w0; t.wx1[h] = e.w1;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const AxisTap<T> e = tab[a.Do + oy0 + min(wave + 4 * j, ny - 1)];
+        for (int j = 0; j < RJ; ++j) {
+            const AxisTap<T> e = tab[a.Do + oy0 + min(wave + NW * j, ny - 1)];
             yok[j][0] = e.i0 >= 0; yok[j][1] = e.i1 >= 0;
             ya[j] = (yok[j][0] ? e.i0 : yok[j][1] ? e.i1 : ly) - ly;
             t.dy[j] = (yok[j][0] && yok[j][1]) ? (e.i1 - e.i0) * ex : 0;
             t.wy0[j] = e.w0; t.wy1[j] = e.w1;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < RJ; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 t.ad[j][h] = ya[j] * ex + xa[h];
@@ -454,18 +455,18 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
     __syncthreads();
     const bool masked = lim[4] != 0;
 
-    // loader: element i = tid + 256 j of the box, row-major with pitch ex
+    // loader: element i = tid + NT j of the box, row-major with pitch ex
     int goff[NLOAD];
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
-        const int i = tid + 256 * j;
+        const int i = tid + NT * j;
         const int r = i / ex, col = i - r * ex;
         goff[j] = i < ey * ex ? (ly + r) * a.Wi + lx + col : -1;
     }
     float pre[NLOAD];
     int pre_z = -1, buf = 0;
     const int dir = a.m[0] < 0.0 ? -1 : 1;
-    T Pa[8], Pb[8];
+    T Pa[2 * RJ], Pb[2 * RJ];
     int cur0 = -1, cur1 = -1;
 
 #define RZ_LOAD_PLANE(Z)                                                                        \
@@ -477,12 +478,12 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
 #define RZ_COMPUTE_PLANE(Z, P)                                                                  \
     {                                                                                           \
         if (pre_z != (Z)) RZ_LOAD_PLANE(Z)                                                      \
-        _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) if (goff[j] >= 0) box[buf][tid + 256 * j] = pre[j]; \
+        _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) if (goff[j] >= 0) box[buf][tid + NT * j] = pre[j]; \
         __syncthreads();                                                                        \
         const int zn_ = (Z) + dir;                                                              \
         if (zn_ >= 0 && zn_ < a.Di) RZ_LOAD_PLANE(zn_)                                          \
-        if (masked) rz_interp_plane<T, true>(box[buf], t, P);                                   \
-        else rz_interp_plane<T, false>(box[buf], t, P);                                         \
+        if (masked) rz_interp_plane<T, RJ, true>(box[buf], t, P);                               \
+        else rz_interp_plane<T, RJ, false>(box[buf], t, P);                                     \
         buf ^= 1;                                                                               \
     }
 
@@ -493,29 +494,29 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
             const int z0 = z0ok ? tz.i0 : tz.i1, z1 = z1ok ? tz.i1 : tz.i0;
             if (z1 != cur1 && z1 == cur0) {          // decreasing table: the old lower plane becomes the upper one
 #pragma unroll
-                for (int k = 0; k < 8; ++k) Pb[k] = Pa[k];
+                for (int k = 0; k < 2 * RJ; ++k) Pb[k] = Pa[k];
                 cur1 = cur0;
             }
             if (z0 != cur0) {
                 if (z0 == cur1) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) Pa[k] = Pb[k];
+                    for (int k = 0; k < 2 * RJ; ++k) Pa[k] = Pb[k];
                 } else RZ_COMPUTE_PLANE(z0, Pa)
                 cur0 = z0;
             }
             if (z1 != cur1) {
                 if (z1 == cur0) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) Pb[k] = Pa[k];
+                    for (int k = 0; k < 2 * RJ; ++k) Pb[k] = Pa[k];
                 } else RZ_COMPUTE_PLANE(z1, Pb)
                 cur1 = z1;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < RJ; ++j)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int jy = wave + 4 * j, jx = lane + 64 * h;
+                const int jy = wave + NW * j, jx = lane + 64 * h;
                 if (jy >= ny || jx >= nx) continue;
                 float res = 0.0f;
                 if (z0ok || z1ok) {
