@@ -113,6 +113,10 @@ int mh_conv3d_k3_split_config(void);
  * fp32: fp32-equivalent results (oracle BasicUNet: max |logit difference| 4e-6, the level of two fp32 summation orders) at 3/16
  * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cout % 32 == 0, W % 4 == 0 and |activated input| < 65504. */
 int mh_conv3d_k3_h2_config(void);
+/* Configuration outside 0 .. num_configs(): ONE input channel (the first layer of the networks), packed fp32 vector arithmetic
+ * (kernels/conv3d_c1.h) -- exact fp32 like the matrix-core tiles, bound by writing the result instead of by multiplying a zero-padded
+ * channel pair.  Needs Cin == 1, Cout % 8 == 0, W % 4 == 0; chosen by mh_conv3d_k3_select for such layers (MONAI_AMD_C1=0: never). */
+int mh_conv3d_k3_c1_config(void);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
 /* w: torch layout [Cout][Cin][3][3][3] */

@@ -16,6 +16,7 @@
 #include "kernels/conv3d_wino2s.h"
 #include "kernels/conv3d_split.h"
 #include "kernels/conv3d_h2.h"
+#include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
 #include "kernels/grid_pull.h"
@@ -314,6 +315,14 @@ static int conv_algo_mode() {
 // configuration MH_CFG_H2: z-streaming direct convolution on the fp16 matrix cores in two-piece split precision, fp32-equivalent
 // results (kernels/conv3d_h2.h); not counted by mh_conv3d_k3_num_configs (its tolerance class differs from the exact fp32 tiles)
 #define MH_CFG_H2 (MH_NUM_CFG + 4)
+// configuration MH_CFG_C1: one input channel (the first layer of every network), packed fp32 VALU, write-bound (kernels/conv3d_c1.h);
+// exact fp32 like the tiles of 1 .. MH_NUM_CFG, not counted by mh_conv3d_k3_num_configs
+#define MH_CFG_C1 (MH_NUM_CFG + 5)
+// z-chunks of the one-channel kernel: a pure function of D (the statistics record count depends on it); 24-plane marches keep
+// 64 windows of 96^3 at nine whole rounds of the chip's 2048 resident waves
+static inline int c1_chunks(int D) { return D >= 48 ? D / 24 : 1; }
+static inline int c1_zchunk(int D) { return cdiv(D, c1_chunks(D)); }
+static inline int c1_blocks(int D, int H, int W) { return cdiv(W, C1_TX) * cdiv(H, C1_TY) * cdiv(D, c1_zchunk(D)); }
 // z-tiles (of 4 planes) a workgroup of the split-precision kernel marches through: a pure function of D
 static inline int split_ztiles(int D) { const int t = D / SP_TZ; return t % 4 == 0 ? 4 : t % 3 == 0 ? 3 : t % 2 == 0 ? 2 : 1; }
 // z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
@@ -336,6 +345,7 @@ static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cd
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_split_config(void) { return MH_CFG_SPLIT; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
+int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
@@ -343,6 +353,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
     if (cfg == MH_CFG_SPLIT) return Cin >= SP_CC && Cin % SP_CC == 0 && Cin <= SP_NRM_MAX && Cout >= SP_CN && Cout % SP_CN == 0;
     if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
+    if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -377,6 +388,10 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
     // the level of two fp32 summation orders) at 1.8-2.1x the speed of the kernels above on every level it takes (96^3 ... 12^3,
     // profiles/r02_h2_vs_wino2p_*.json) -- the default wherever the shape fits; MONAI_AMD_CONV_ALGO=fp32 keeps the exact fp32 kernels
     if ((mode == 0 || mode == 5) && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8) best = MH_CFG_H2;
+    // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
+    // (MONAI_AMD_C1=0 keeps the tile: development / A-B measurements)
+    if ((mode == 0 || mode == 5 || mode == 6) && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && env_int("MONAI_AMD_C1", 1) != 0)
+        best = MH_CFG_C1;
     return best;
 }
 
@@ -385,6 +400,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
     if (cfg == MH_CFG_SPLIT) return (int64_t)Cin * Cout * 27 * SP_NP / 2;      // three bf16 pieces per weight
     if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
+    if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -418,6 +434,11 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
                            reinterpret_cast<_Float16*>(packed), tail);
         return launched("conv3d_k3_h2_pack");
     }
+    if (cfg == MH_CFG_C1) {          // [Cin = 1][27][Cout]: the direct kernel's layout
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the one-channel kernel needs Cin == 1, Cout %% 8 == 0");
+        hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for(27LL * Cout)), dim3(256), 0, (hipStream_t)stream, w, 1, 1, Cout, Cout, Cout, packed);
+        return launched("conv3d_k3_pack");
+    }
     if (cfg < 0 || cfg > MH_NUM_CFG || !w || !packed) return fail(MH_ERR_ARG, "conv3d_k3_pack: bad argument");
     const int cn = cfg == 0 ? Cout : kCfg[cfg].cn;
     const int cinp = cin_padded(cfg, Cin), coutp = cout_padded(cfg, Cout);
@@ -430,6 +451,7 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
     if (cfg == MH_CFG_WINO2D || cfg == MH_CFG_H2) return wino2d_blocks(D, H, W);
     if (cfg == MH_CFG_SPLIT) return cdiv(W, SP_TX) * cdiv(H, SP_TY) * cdiv(D, SP_TZ * split_ztiles(D));
+    if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -450,9 +472,29 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_CFG_H2) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_C1) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == MH_CFG_C1) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
+            return fail(MH_ERR_ARG, "conv3d_k3: the one-channel kernel needs Cin == 1, Cout %% 8 == 0, W %% 4 == 0 (got %d -> %d, %dx%dx%d)", in.C, out.C,
+                        in.D, in.H, in.W);
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(in.data, 16) || in.n_stride % 4 || !aligned(packed_w, 4))
+            return fail(MH_ERR_ARG, "conv3d_k3: the one-channel kernel needs 16-byte aligned input and output");
+        const int txn = cdiv(out.W, C1_TX), tyn = cdiv(out.H, C1_TY), zc = c1_zchunk(out.D);
+        const int cot = out.C % 16 == 0 ? 16 : 8;
+        const dim3 grid((unsigned)(txn * tyn * cdiv(out.D, zc)), (unsigned)(out.C / cot), (unsigned)out.N);
+#define MH_C1_LAUNCH(COT_)                                                                                                                    \
+    {                                                                                                                                         \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);      \
+        else hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);                 \
+    }
+        if (cot == 16) MH_C1_LAUNCH(16) else MH_C1_LAUNCH(8)
+#undef MH_C1_LAUNCH
+        return launched("conv3d_k3_c1");
+    }
     if (cfg == MH_CFG_H2) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
             return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0, W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
@@ -631,6 +673,15 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
     const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
+    // packed-math form (two input voxels per thread, 16-byte stores, cout groups walked inside): MONAI_AMD_DECONV_IMPL=scalar keeps the
+    // one-voxel kernel (same results bit for bit)
+    const char* impl = getenv("MONAI_AMD_DECONV_IMPL");
+    const bool pk_on = !(impl && !strcmp(impl, "scalar"));
+    if (pk_on && out.C % 8 == 0 && in.W % 2 == 0 && aligned(out.data, 16) && aligned(in.data, 8) && out.n_stride % 4 == 0 && in.n_stride % 2 == 0) {
+        hipLaunchKernelGGL((deconv_k2s2_pk_kernel<8>), dim3(blocks_for((long long)in.D * in.H * in.W / 2), (unsigned)out.N), dim3(256), 0,
+                           (hipStream_t)stream, in, w, bias, out);
+        return launched("deconv_k2s2");
+    }
     if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");

@@ -160,6 +160,12 @@ def conv3d_k3_h2_config() -> int:
     return _lib.lib().query("mh_conv3d_k3_h2_config")
 
 
+def conv3d_k3_c1_config() -> int:
+    """Id of the one-input-channel configuration (first layer of the networks: packed fp32 vector arithmetic, write-bound, exact fp32);
+    outside 1 .. conv3d_k3_num_configs()."""
+    return _lib.lib().query("mh_conv3d_k3_c1_config")
+
+
 def conv3d_k3_split_config() -> int:
     """Id of the experimental split-precision configuration (bf16 matrix cores, three pieces per operand, fp32-equivalent
     results); outside 1 .. conv3d_k3_num_configs(), selected by conv3d_k3_select only under MONAI_AMD_CONV_ALGO=split."""

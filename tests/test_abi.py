@@ -47,7 +47,9 @@ def test_host_side_queries_need_no_gpu():
     dll.mh_conv3d_k3_select.restype = ctypes.c_int
     dll.mh_conv3d_k3_num_configs.restype = ctypes.c_int
     n = dll.mh_conv3d_k3_num_configs()
-    assert 1 <= dll.mh_conv3d_k3_select(1, 32, 96, 96, 96) <= n
+    dll.mh_conv3d_k3_c1_config.restype = ctypes.c_int
+    assert dll.mh_conv3d_k3_select(1, 32, 96, 96, 96) == dll.mh_conv3d_k3_c1_config() > n      # first layer: the one-input-channel kernel
+    assert 1 <= dll.mh_conv3d_k3_select(1, 32, 9, 9, 9) <= n                                    # W % 4 != 0: an fp32 matrix-core tile
     dll.mh_conv3d_k3_h2_config.restype = ctypes.c_int
     env = os.environ.pop("MONAI_AMD_CONV_ALGO", None)
     try:

@@ -2,6 +2,8 @@
 (tests/emu) and compared with torch-CPU restatements of the reference operators.  These do not replace the
 -m gpu parity tests (tests/test_kernels_gpu.py runs the same cases on the MI355X); they exist because the
 build container has no GPU and every index/LDS/barrier bug caught here saves a GPU round trip."""
+import os
+
 import pytest
 
 import kernel_cases as kc
@@ -112,6 +114,8 @@ def test_pool_deconv_1x1_stats(emu):
     kc.case_maxpool("cpu", dims=(4, 6, 7))  # odd W -> scalar path, floor
     kc.case_deconv("cpu")
     kc.case_deconv("cpu", n=1, cin=12, cout=16, dims=(3, 4, 6))     # full 8-channel groups, ragged input-channel batch
+    kc.case_deconv_packed_equals_scalar("cpu")
+    kc.case_deconv_packed_equals_scalar("cpu", n=1, cin=3, cout=8, dims=(2, 3, 130))    # ragged last block of voxel pairs
     kc.case_conv1x1("cpu")
     kc.case_conv1x1("cpu", n=1, cin=13, cout=27, dims=(3, 5, 7))     # 16 + 8 + 3 output channels, ragged channel batch, scalar path
     kc.case_conv1x1("cpu", n=1, cin=6, cout=16, dims=(2, 4, 8))
@@ -205,3 +209,24 @@ def test_linear_fp16_split_precision(emu, m, n, k, gelu, res):
 @pytest.mark.parametrize("m,k", [(7, 48), (130, 768), (5, 100)])
 def test_layernorm(emu, m, k):
     kc.case_layernorm("cpu", m, k)
+
+
+def test_conv_one_input_channel(emu):
+    """kernels/conv3d_c1.h: the first layer (Cin = 1) on packed fp32 vector arithmetic, statistics from the epilogue"""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_c1_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, 1, 32) and not ops.conv3d_k3_accepts(cfg, 2, 32)
+    assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == cfg and ops.conv3d_k3_select(1, 32, 9, 9, 9) != cfg       # W % 4
+    saved = os.environ.get("MONAI_AMD_C1")
+    try:
+        os.environ["MONAI_AMD_C1"] = "0"
+        assert 1 <= ops.conv3d_k3_select(1, 32, 96, 96, 96) <= ops.conv3d_k3_num_configs()
+    finally:
+        os.environ.pop("MONAI_AMD_C1", None)
+        if saved is not None:
+            os.environ["MONAI_AMD_C1"] = saved
+    kc.case_conv3d("cpu", cfg, 2, 1, 32, (5, 40, 36), with_nrm=False, fused_stats=True)     # partial tiles in x and y, 16 couts per thread
+    kc.case_conv3d("cpu", cfg, 1, 1, 24, (3, 8, 8), with_nrm=True, fused_stats=True)        # 8 couts per thread, deferred norm on the input
+    kc.case_conv3d("cpu", cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)      # two z-chunks (25 planes each)
+    kc.case_conv3d("cpu", cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)     # no statistics; a second tile row of one line

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 import kernel_cases as kc
+from monai_amd import ops
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -90,6 +91,8 @@ def test_pool_deconv_1x1_stats():
     kc.case_maxpool(DEV, n=2, c=32, dims=(32, 32, 96))
     kc.case_deconv(DEV)
     kc.case_deconv(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
+    kc.case_deconv_packed_equals_scalar(DEV)
+    kc.case_deconv_packed_equals_scalar(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
     kc.case_conv1x1(DEV)
     kc.case_conv1x1(DEV, n=1, cin=13, cout=27, dims=(3, 5, 7))     # 16 + 8 + 3 output channels, ragged channel batch, scalar path
     kc.case_conv1x1(DEV, n=1, cin=6, cout=16, dims=(2, 4, 8))
@@ -182,3 +185,14 @@ def test_linear_fp16_split_precision(m, n, k, gelu, res):
 @pytest.mark.parametrize("m,k", [(7, 48), (130, 768), (5, 100)])
 def test_layernorm(m, k):
     kc.case_layernorm(DEV, m, k)
+
+
+def test_conv_one_input_channel():
+    """kernels/conv3d_c1.h on the MI355X: partial tiles, both cout group widths, z-chunks, a full-size window"""
+    cfg = ops.conv3d_k3_c1_config()
+    assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == cfg
+    kc.case_conv3d(DEV, cfg, 2, 1, 32, (5, 40, 36), with_nrm=False, fused_stats=True)
+    kc.case_conv3d(DEV, cfg, 1, 1, 24, (3, 8, 8), with_nrm=True, fused_stats=True)
+    kc.case_conv3d(DEV, cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)
+    kc.case_conv3d(DEV, cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)
+    kc.case_conv3d(DEV, cfg, 2, 1, 32, (96, 96, 96), with_nrm=False, fused_stats=True)
