@@ -673,15 +673,6 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
     const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
-    // packed-math form (two input voxels per thread, 16-byte stores, cout groups walked inside): MONAI_AMD_DECONV_IMPL=scalar keeps the
-    // one-voxel kernel (same results bit for bit)
-    const char* impl = getenv("MONAI_AMD_DECONV_IMPL");
-    const bool pk_on = !(impl && !strcmp(impl, "scalar"));
-    if (pk_on && out.C % 8 == 0 && in.W % 2 == 0 && aligned(out.data, 16) && aligned(in.data, 8) && out.n_stride % 4 == 0 && in.n_stride % 2 == 0) {
-        hipLaunchKernelGGL((deconv_k2s2_pk_kernel<8>), dim3(blocks_for((long long)in.D * in.H * in.W / 2), (unsigned)out.N), dim3(256), 0,
-                           (hipStream_t)stream, in, w, bias, out);
-        return launched("deconv_k2s2");
-    }
     if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
@@ -832,6 +823,23 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
             hipLaunchKernelGGL((separable_resample_lds_kernel<float>), dim3(nblk), dim3(256), 0, s, src, dst, (const AxisTap<float>*)tab, a);
         }
         return launched("separable_resample");
+    }
+    // general (rotated / sheared) matrices without reflection: the row-mapped kernel with compile-time mode and padding rule
+    // (bit-identical to affine_resample_kernel; MONAI_AMD_RS_GENERAL=linear keeps the linear-index kernel: A/B measurements)
+    const char* rs_general = getenv("MONAI_AMD_RS_GENERAL");
+    const bool rows_on = !(rs_general && !strcmp(rs_general, "linear"));
+    if (rows_on && i32 && pad != RS_REFLECTION && Do <= 65535 && cdiv(Ho, 4) <= 65535) {
+        const dim3 g((unsigned)cdiv(Wo, 64), (unsigned)cdiv(Ho, 4), (unsigned)Do);
+#define MH_RS_ROWS(T_, M_, P_) hipLaunchKernelGGL((affine_resample_rows_kernel<T_, M_, P_>), g, dim3(256), 0, s, src, dst, a)
+#define MH_RS_ROWS_T(T_)                                                                              \
+        {                                                                                             \
+            if (mode == RS_LINEAR) { if (pad == RS_BORDER) MH_RS_ROWS(T_, RS_LINEAR, RS_BORDER); else MH_RS_ROWS(T_, RS_LINEAR, RS_ZEROS); } \
+            else { if (pad == RS_BORDER) MH_RS_ROWS(T_, RS_NEAREST, RS_BORDER); else MH_RS_ROWS(T_, RS_NEAREST, RS_ZEROS); }                 \
+        }
+        if (compute_f64) MH_RS_ROWS_T(double) else MH_RS_ROWS_T(float)
+#undef MH_RS_ROWS_T
+#undef MH_RS_ROWS
+        return launched("affine_resample");
     }
     if (compute_f64) {
         if (i32) hipLaunchKernelGGL((affine_resample_kernel<double, int>), dim3(nb), dim3(256), 0, s, src, dst, a);

@@ -352,72 +352,6 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
         }
 }
 
-// The same op for the common shape (Cout % COT == 0, even input rows, 16-byte aligned output), packed-math form.  At 32 -> 32
-// channels the kernel above is VALU-bound, not HBM-bound: 8192 FMAs per input voxel = 116 GFLOP per 64 windows of 48^3, 1.5 ms at
-// the 78 TF of scalar v_fma_f32 against 1.2 ms for writing the 7.25 GB result.  Here the two x-taps of a (cout, dz, dy) row are one
-// f32x2 accumulator and the weights' (dx = 0, 1) pairs are uniform SGPR pairs, so the inner loop is v_pk_fma_f32 v, v(broadcast), s[pair]
-// (half the VALU instructions); one thread owns TWO x-adjacent input voxels = four consecutive outputs per row (16-byte stores,
-// whole 128-byte lines per row segment), and walks the cout groups itself, so the input is read from HBM once (the re-reads of the
-// later groups hit L1 / L2) instead of once per group.  Accumulation order and rounding are those of the kernel above (bias first,
-// input channels ascending, fused multiply-add): bit-identical results.
-template <int COT>
-__global__ void __launch_bounds__(256)
-deconv_k2s2_pk_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
-    const int Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
-    const int Wp = Wi >> 1;                                     // voxel pairs per input row
-    const long long ivol = (long long)in.D * Hi * Wi;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y;
-    if (idx >= ivol / 2) return;
-    const int xp = (int)(idx % Wp);
-    const long long t = idx / Wp;
-    const int y = (int)(t % Hi), z = (int)(t / Hi);
-    const float* src = in.data + (long long)n * in.n_stride + 2 * idx;
-    const int Ho = out.H, Wo = out.W;
-    const long long ovol = (long long)out.D * Ho * Wo;
-    float* const dst0 = out.data + (long long)n * out.n_stride + ((long long)(2 * z) * Ho + 2 * y) * Wo + 4 * xp;
-    constexpr int CB = 8;      // input channels whose loads fly together
-    for (int co0 = 0; co0 < Cout; co0 += COT) {
-        f32x2 acc[2][COT][4];
-#pragma unroll
-        for (int j = 0; j < COT; ++j) {
-            const float bj = bias ? bias[co0 + j] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) acc[0][j][k] = acc[1][j][k] = f32x2{bj, bj};
-        }
-        for (int c0 = 0; c0 < Cin; c0 += CB) {
-            f32x2 v[CB];
-#pragma unroll
-            for (int c = 0; c < CB; ++c) v[c] = *reinterpret_cast<const f32x2*>(src + (long long)min(c0 + c, Cin - 1) * ivol);
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const int ci = c0 + c;
-                if (ci < Cin) {
-                    const float4 a = load_nrm(in, n, ci);
-                    const float va0 = act(v[c][0], a.x, a.y, a.z), va1 = act(v[c][1], a.x, a.y, a.z);
-                    const f32x2 b0 = {va0, va0}, b1 = {va1, va1};
-                    const f32x2* wr = reinterpret_cast<const f32x2*>(w + ((long long)ci * Cout + co0) * 8);
-#pragma unroll
-                    for (int j = 0; j < COT; ++j)
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const f32x2 wp = wr[j * 4 + k];
-                            acc[0][j][k] = __builtin_elementwise_fma(b0, wp, acc[0][j][k]);
-                            acc[1][j][k] = __builtin_elementwise_fma(b1, wp, acc[1][j][k]);
-                        }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < COT; ++j)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {           // k = dz * 2 + dy
-                float* p = dst0 + (long long)(co0 + j) * ovol + ((long long)(k >> 1) * Ho + (k & 1)) * Wo;
-                *reinterpret_cast<f32x4*>(p) = f32x4{acc[0][j][k][0], acc[0][j][k][1], acc[1][j][k][0], acc[1][j][k][1]};
-            }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Conv3d k=1 of act(in): CO output channels [co0, co0+CO) per thread, VEC voxels per thread.
 template <int CO, int VEC>

@@ -73,6 +73,20 @@ __device__ __forceinline__ AxisTap<T> rs_axis(double coord, int size, int mode, 
     return t;
 }
 
+// rs_axis<T>(coord, size, RS_LINEAR, RS_BORDER, .) without its range tests in floating point: after the clamp 0 <= c <= size - 1 (a NaN
+// coordinate becomes 0 in fmax; rounding to float keeps the interval, its ends are integers below 2^24), so floor(c) is a valid index and
+// only the upper tap can leave the volume.  Same taps, same weights.
+template <typename T> __device__ __forceinline__ AxisTap<T> rs_axis_border_linear(double coord, int size) {
+    AxisTap<T> t;
+    const T c = (T)fmin((double)(size - 1), fmax(coord, 0.0));
+    const T f = floor(c);
+    t.i0 = (int)f;
+    t.i1 = t.i0 + 1 < size ? t.i0 + 1 : -1;
+    t.w0 = (f + (T)1) - c;
+    t.w1 = c - f;
+    return t;
+}
+
 // Two-term combine of one interpolation axis: a0*w0 + a1*w1 with the second product fused (one rounding less than the
 // separate multiply-add; every kernel of this file uses this same form, so they agree bit for bit with each other).
 __device__ __forceinline__ double rs_comb(double a0, double w0, double a1, double w1) { return fma(a1, w1, a0 * w0); }
@@ -125,6 +139,37 @@ __global__ void __launch_bounds__(256) affine_resample_kernel(const float* __res
     const AxisTap<T> ty = rs_axis<T>(cy, a.Hi, a.mode, a.pad, a.align_corners);
     const AxisTap<T> tx = rs_axis<T>(cx, a.Wi, a.mode, a.pad, a.align_corners);
     rs_gather<T, IDX>(src, dst, a.C, ivol, ovol, oidx, a.Hi, a.Wi, tz, ty, tx, a.mode == RS_NEAREST);
+}
+
+// The same kernel for the common cases, laid out so that the per-voxel instruction stream is short -- the kernel above is VALU-issue
+// bound (~170 vector instructions per output voxel, a third of them the two runtime integer divisions of the linear index and the
+// branches over the runtime mode / padding rule):
+//   * a workgroup is 4 waves = 4 output rows x 64 consecutive x; (ox, oy, oz) come from the block / thread indices: no division;
+//   * interpolation mode and padding rule are template parameters: straight-line code, no reflection path in the binary;
+//   * 32-bit offsets inside one channel volume (the launcher checks the extents).
+// Coordinates, taps and the 8-corner combine are the routines of the kernel above, evaluated in the same order: bit-identical results
+// (tests/transform_cases.py::case_separable_vs_general runs both against the separable path).
+template <typename T, int MODE, int PAD>
+__global__ void __launch_bounds__(256) affine_resample_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, ResampleArgs a) {
+    const int ox = (int)blockIdx.x * 64 + (int)(threadIdx.x & 63);
+    const int oy = (int)blockIdx.y * 4 + (int)(threadIdx.x >> 6);
+    const int oz = (int)blockIdx.z;
+    if (ox >= a.Wo || oy >= a.Ho) return;
+    const int ovol = a.Do * a.Ho * a.Wo, ivol = a.Di * a.Hi * a.Wi;
+    const int oidx = (oz * a.Ho + oy) * a.Wo + ox;
+    const double cz = ((a.m[0] * oz + a.m[1] * oy) + a.m[2] * ox) + a.m[3];
+    const double cy = ((a.m[4] * oz + a.m[5] * oy) + a.m[6] * ox) + a.m[7];
+    const double cx = ((a.m[8] * oz + a.m[9] * oy) + a.m[10] * ox) + a.m[11];
+    AxisTap<T> tz, ty, tx;
+    if (MODE == RS_LINEAR && PAD == RS_BORDER) {
+        tz = rs_axis_border_linear<T>(cz, a.Di); ty = rs_axis_border_linear<T>(cy, a.Hi); tx = rs_axis_border_linear<T>(cx, a.Wi);
+        __builtin_assume(tz.i0 >= 0); __builtin_assume(ty.i0 >= 0); __builtin_assume(tx.i0 >= 0);
+    } else {
+        tz = rs_axis<T>(cz, a.Di, MODE, PAD, a.align_corners);
+        ty = rs_axis<T>(cy, a.Hi, MODE, PAD, a.align_corners);
+        tx = rs_axis<T>(cx, a.Wi, MODE, PAD, a.align_corners);
+    }
+    rs_gather<T, int>(src, dst, a.C, ivol, ovol, oidx, a.Hi, a.Wi, tz, ty, tx, MODE == RS_NEAREST);
 }
 
 // Axis-aligned affines (no rotation / shear: every off-diagonal of the 3x3 block is exactly zero -- the Spacingd case)

@@ -271,33 +271,6 @@ def case_deconv(device, n=2, cin=16, cout=6, dims=(4, 6, 10)):
     assert torch.all(got[:, :3] == 0)
 
 
-def case_deconv_packed_equals_scalar(device, n=2, cin=12, cout=16, dims=(3, 4, 6)):
-    """The packed-math transposed convolution (two input voxels per thread, cout groups walked inside) keeps the accumulation order of
-    the one-voxel kernel: bit-identical outputs (MONAI_AMD_DECONV_IMPL=scalar selects the latter)."""
-    import os
-
-    gen = torch.Generator().manual_seed(14)
-    x = torch.randn((n, cin) + dims, generator=gen)
-    w = torch.randn((cin, cout, 2, 2, 2), generator=gen) / np.sqrt(cin)
-    b = torch.randn(cout, generator=gen) * 0.1
-    nrm = _rand_nrm(n, cin, gen)
-    outs = []
-    saved = os.environ.pop("MONAI_AMD_DECONV_IMPL", None)
-    try:
-        for impl in ("packed", "scalar"):
-            os.environ["MONAI_AMD_DECONV_IMPL"] = impl
-            out = torch.full((n, cout) + tuple(2 * d for d in dims), float("nan"), device=device)
-            ops.deconv_k2s2(x.to(device), nrm.to(device), w.to(device), b.to(device), out)
-            outs.append(out.cpu())
-    finally:
-        os.environ.pop("MONAI_AMD_DECONV_IMPL", None)
-        if saved is not None:
-            os.environ["MONAI_AMD_DECONV_IMPL"] = saved
-    assert torch.equal(outs[0], outs[1])
-    exp = F.conv_transpose3d(_act(x.double(), nrm.double()), w.double(), b.double(), stride=2)
-    assert (outs[0].double() - exp).abs().max().item() < 1e-5
-
-
 def case_conv1x1(device, n=2, cin=32, cout=5, dims=(6, 8, 12)):
     gen = torch.Generator().manual_seed(5)
     x = torch.randn((n, cin) + dims, generator=gen)

@@ -98,6 +98,10 @@ def test_separable_fast_path_equals_general(emu):
     tc.case_separable_vs_general("cpu")
 
 
+def test_general_rows_kernel_equals_linear_index_kernel(emu):
+    tc.case_general_rows_vs_linear("cpu")
+
+
 def test_gaussian_z_chunks(emu):
     tc.case_gaussian_z_chunks("cpu")
 

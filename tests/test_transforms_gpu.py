@@ -116,6 +116,10 @@ def test_separable_fast_path_equals_general():
     tc.case_separable_vs_general(DEV)
 
 
+def test_general_rows_kernel_equals_linear_index_kernel():
+    tc.case_general_rows_vs_linear(DEV)
+
+
 def test_gaussian_rowvec_equals_tile():
     tc.case_gaussian_rowvec_equals_tile(DEV)
 

@@ -649,6 +649,65 @@ def case_gaussian_rowvec_equals_tile(device):
         assert (b.cpu().double() - ref[0]).abs().max().item() < 2e-6, shape
 
 
+def case_general_rows_vs_linear(device):
+    """Rotated / sheared matrices: the row-mapped kernel with compile-time mode and padding rule (the default) gives exactly what the
+    linear-index kernel gives (MONAI_AMD_RS_GENERAL=linear), and both match a float64 torch restatement of trilinear sampling with border
+    padding.  Ragged extents (Wo % 64, Ho % 4), several channels, coordinates far outside the volume, a NaN matrix entry."""
+    import os
+
+    from monai_amd import ops
+
+    torch.manual_seed(12)
+    vol = torch.rand(3, 9, 14, 37).to(device)
+    th = 0.3
+    rot = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.1], [0.05, -0.2, 0.8]])
+    mats = []
+    for off in ((1.0, -2.0, 3.0), (-30.0, 40.0, -50.0)):
+        m = np.zeros((3, 4))
+        m[:, :3], m[:, 3] = rot, off
+        mats.append(m)
+    mn = mats[0].copy()
+    mn[1, 2] = np.nan
+    saved = os.environ.pop("MONAI_AMD_RS_GENERAL", None)
+    try:
+        for m in mats + [mn]:
+            for osz in ((7, 5, 70), (3, 9, 130), (11, 4, 64)):
+                for mode in ("bilinear", "nearest"):
+                    for pad in PADS:
+                        for f64 in (True, False):
+                            os.environ.pop("MONAI_AMD_RS_GENERAL", None)
+                            a = ops.affine_resample(vol, m.reshape(-1), osz, mode, pad, False, f64)
+                            os.environ["MONAI_AMD_RS_GENERAL"] = "linear"
+                            b = ops.affine_resample(vol, m.reshape(-1), osz, mode, pad, False, f64)
+                            assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)), (osz, mode, pad, f64)
+        os.environ.pop("MONAI_AMD_RS_GENERAL", None)
+        # independent restatement (fp64): border padding, trilinear
+        m, osz = mats[0], (7, 5, 70)
+        got = ops.affine_resample(vol, m.reshape(-1), osz, "bilinear", "border", False, True).cpu().double()
+        oz, oy, ox = np.meshgrid(*[np.arange(n, dtype=np.float64) for n in osz], indexing="ij")
+        v = vol.cpu().double().numpy()
+        c = [np.clip(m[r, 0] * oz + m[r, 1] * oy + m[r, 2] * ox + m[r, 3], 0.0, v.shape[1 + r] - 1.0) for r in range(3)]
+        f = [np.floor(x).astype(np.int64) for x in c]
+        exp = np.zeros((v.shape[0],) + osz)
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w = np.ones(osz)
+                    idx = []
+                    for r, d in enumerate((dz, dy, dx)):
+                        t = c[r] - f[r]
+                        w = w * (t if d else 1.0 - t)
+                        i = f[r] + d
+                        w = np.where(i < v.shape[1 + r], w, 0.0)
+                        idx.append(np.minimum(i, v.shape[1 + r] - 1))
+                    exp += v[:, idx[0], idx[1], idx[2]] * w
+        assert np.abs(got.numpy() - exp).max() < 1e-6
+    finally:
+        os.environ.pop("MONAI_AMD_RS_GENERAL", None)
+        if saved is not None:
+            os.environ["MONAI_AMD_RS_GENERAL"] = saved
+
+
 def case_separable_vs_general(device):
     """The axis-aligned fast path (per-axis tap tables + LDS-staged source box, with its global-gather fallback when the
     box does not fit) must give exactly what the general kernel gives for the same matrix: a 1e-300 off-diagonal makes
