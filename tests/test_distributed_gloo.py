@@ -10,6 +10,11 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+# a quarter of the default widths: the test is about sharding / gathering / blending, not about the convolutions (which other tests
+# cover at full width), and the SIMT emulator pays for every flop
+FEATURES = (16, 16, 32, 64, 128, 16)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -33,7 +38,7 @@ def _worker(rank, world, port, shape, roi, ret):
 
         with emu_backend():
             torch.manual_seed(1)
-            net = BasicUNet(3, 1, 3).eval()
+            net = BasicUNet(3, 1, 3, features=FEATURES).eval()
             torch.manual_seed(3)
             x = torch.rand(shape)
             inf = SlidingWindowInferer(roi_size=roi, sw_batch_size=2, overlap=0.5, mode="gaussian")
@@ -72,7 +77,7 @@ def test_two_rank_window_sharding_matches_single_process():
     assert p0 == (0, 4, 4) and p1 == (4, 7, 4)      # uneven split: equal chunks, last rank owns fewer real windows
 
     torch.manual_seed(1)
-    sd = oracle.make_basic_unet_state(1, 3)
+    sd = oracle.make_basic_unet_state(1, 3, features=FEATURES)
     torch.manual_seed(3)
     x = torch.rand(shape)
     with torch.no_grad():

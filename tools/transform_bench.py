@@ -59,6 +59,21 @@ for f64 in (True, False):
         ms = timeit(lambda: ops.affine_resample(raw, mm.reshape(-1), osz, "bilinear", "border", False, f64))
         nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
         res["runs"].append({"op": f"kernel affine_resample {tag} {'fp64' if f64 else 'fp32'} (1 volume)", "ms": ms, "GBps": nb / ms / 1e6, "bytes": nb})
+# the general kernel's two forms (row-mapped with compile-time mode / padding = default, linear-index = round 1) on the same matrix, and
+# on a matrix that really rotates (10 degrees in the (y, x) plane about the volume centre: gathers leave the coalesced pattern)
+th = np.deg2rad(10.0)
+cy, cx = 0.5 * (raw.shape[2] - 1), 0.5 * (raw.shape[3] - 1)
+rot = np.array([[1.25, 0, 0, 0], [0, 1.25 * np.cos(th), -0.625 * np.sin(th), 0], [0, 1.25 * np.sin(th), 0.625 * np.cos(th), 0]], dtype=np.float64)
+rot[1, 3] = cy - (rot[1, 1] * 0.5 * (osz[1] - 1) + rot[1, 2] * 0.5 * (osz[2] - 1))
+rot[2, 3] = cx - (rot[2, 1] * 0.5 * (osz[1] - 1) + rot[2, 2] * 0.5 * (osz[2] - 1))
+for f64 in (True, False):
+    for tag, mm in (("general", m + np.array([[0, 1e-9, 0, 0], [0, 0, 0, 0], [0, 0, 0, 0]])), ("rotated 10 deg", rot)):
+        for impl in ("rows", "linear"):
+            os.environ["MONAI_AMD_RS_GENERAL"] = impl
+            ms = timeit(lambda: ops.affine_resample(raw, mm.reshape(-1), osz, "bilinear", "border", False, f64))
+            nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
+            res["runs"].append({"op": f"kernel affine_resample {tag} {'fp64' if f64 else 'fp32'}, {impl} kernel (1 volume)", "ms": ms, "GBps": nb / ms / 1e6, "bytes": nb})
+os.environ.pop("MONAI_AMD_RS_GENERAL", None)
 k = gaussian_1d(1.0).numpy()
 ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
 res["runs"].append({"op": "kernel separable_filter3d 9 taps (1 volume)", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6, "bytes": 8.0 * raw.numel()})
