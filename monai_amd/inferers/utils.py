@@ -161,6 +161,10 @@ def sliding_window_inference(
     # drop-in input handling (utils.py:146-153 take any float dtype and any inputs/sw_device pair): half / bfloat16 volumes are
     # widened to fp32 for the kernels and the result is returned in the caller's dtype; a CPU volume with a ROCm `sw_device` is
     # moved to HBM once (the reference moves it window by window) and the result goes back to `device` or the inputs' device
+    if torch.is_grad_enabled() and inputs.requires_grad:
+        # the reference's result carries the autograd graph of the windows (tests/inferers/test_sliding_window_inference.py:124-139);
+        # the kernels do not record one: such a call belongs to the reference path
+        raise NotImplementedError("monai_amd: sliding_window_inference of an input that requires grad (autograd through the blend) is not on the HIP path")
     narrow = inputs.dtype if inputs.dtype in (torch.float16, torch.bfloat16) else None
     host_in = (not inputs.is_cuda) and sw_device is not None and torch.device(sw_device).type == "cuda"
     if narrow is not None or host_in:
