@@ -98,7 +98,146 @@ def _share_module_state(src, dst) -> None:
 _active = threading.local()       # ids of the instances whose wrapped method is running: only the OUTERMOST wrapper falls through
 
 
-def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_state: bool = False):
+# ---- the reference's image-in / image-out convention of array transforms -------------------------------------------------------
+# Every array transform of the reference starts with ``convert_to_tensor(img, track_meta=get_track_meta())`` (e.g.
+# monai/transforms/intensity/array.py:1618, spatial/array.py:505): numpy arrays become tensors, and the result is a MetaTensor whenever
+# MONAI's global meta tracking is on (the default) -- also for a plain input -- and a plain tensor when it is off -- also for a
+# MetaTensor input (tests/transforms/test_spacing.py:300-317, test_gaussian_smooth.py:92 pin both).  Applied around the product's
+# ``__call__`` when MONAI is importable; without MONAI plain inputs stay plain and this package's MetaTensor keeps its metadata.
+_IMAGE_KWARGS = ("img", "data_array", "data")
+
+
+def _track_meta_state():
+    """(MONAI's MetaTensor class, tracking on?) or (None, None) without MONAI."""
+    try:
+        from monai.data.meta_obj import get_track_meta
+        from monai.data.meta_tensor import MetaTensor
+    except Exception:
+        return None, None
+    return MetaTensor, bool(get_track_meta())
+
+
+def _image_in(args, kwargs):
+    import numpy as np
+    import torch
+
+    key = None
+    if args:
+        img = args[0]
+    else:
+        key = next((k for k in _IMAGE_KWARGS if k in kwargs), None)
+        if key is None:
+            return args, kwargs
+        img = kwargs[key]
+    new = img
+    if isinstance(new, np.ndarray):
+        new = torch.as_tensor(np.ascontiguousarray(new))
+    if isinstance(new, torch.Tensor):
+        meta_cls, track = _track_meta_state()
+        if meta_cls is not None and track and type(new) is torch.Tensor:
+            new = meta_cls(new)
+    if new is img:
+        return args, kwargs
+    if key is None:
+        return (new,) + tuple(args[1:]), kwargs
+    return args, dict(kwargs, **{key: new})
+
+
+def _dict_in(obj, args, kwargs):
+    """dictionary transforms: the same convention for the entries named by ``keys`` (the reference's array transform inside the
+    dictionary transform applies it per entry)"""
+    if not args or not isinstance(args[0], dict):
+        return args, kwargs
+    d = dict(args[0])
+    changed = False
+    for k in getattr(obj, "keys", ()) or ():
+        if k in d:
+            (v2,), _ = _image_in((d[k],), {})
+            if v2 is not d[k]:
+                d[k], changed = v2, True
+    return ((d,) + tuple(args[1:]), kwargs) if changed else (args, kwargs)
+
+
+def _dict_out(obj, out):
+    if isinstance(out, dict):
+        for k in getattr(obj, "keys", ()) or ():
+            if k in out:
+                out[k] = _image_out(out[k])
+    return out
+
+
+def _image_out(out):
+    import torch
+
+    meta_cls, track = _track_meta_state()
+    if meta_cls is None:
+        return out
+
+    def one(t):
+        if not isinstance(t, torch.Tensor):
+            return t
+        is_meta = type(t) is not torch.Tensor and hasattr(t, "as_tensor")
+        if track and not is_meta:
+            return meta_cls(t)
+        if not track and is_meta:
+            return t.as_tensor()
+        return t
+
+    if isinstance(out, tuple):
+        return tuple(one(t) for t in out)
+    if isinstance(out, list):
+        return [one(t) for t in out]
+    return one(out)
+
+
+def _drop_new_records(img_in, out) -> None:
+    """`tracing` off (the reference's inverse methods run their helper transforms under ``trace_transform(False)``, e.g.
+    monai/transforms/croppad/array.py:430-434): the call must leave no record of itself on the image."""
+    n = len(getattr(img_in, "applied_operations", None) or [])
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        ops_ = getattr(t, "applied_operations", None)
+        if ops_ is not None and len(ops_) > n:
+            t.applied_operations = list(ops_[:n])
+
+
+class _Tracing:
+    """The part of the reference's ``TraceableTransform`` interface (monai/transforms/inverse.py:68-110) that its own code uses on the
+    transforms it constructs by name -- which are this package's classes once the patch is installed."""
+
+    tracing = True
+
+    def trace_transform(self, to_trace: bool):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            prev = self.tracing
+            self.tracing = to_trace
+            try:
+                yield
+            finally:
+                self.tracing = prev
+
+        return ctx()
+
+
+def _recorded_by_twin(obj, data) -> bool:
+    """True when the most recent applied operation on `data` (an image, or a dictionary of images) carries the `id` of obj's reference
+    twin or of one of the twin's member transforms (a dictionary transform records through its array transform) -- i.e. the forward
+    call of this object fell through to the reference (monai/transforms/inverse.py:112-160 keys its records by `id(self)`)."""
+    twin = obj.__dict__.get("_mh_twin_obj")
+    if twin is None:
+        return False
+    ids = {id(twin)} | {id(v) for v in getattr(twin, "__dict__", {}).values()}
+    images = list(data.values()) if isinstance(data, dict) else [data]
+    for im in images:
+        ops_ = getattr(im, "applied_operations", None)
+        if ops_ and isinstance(ops_[-1], dict) and ops_[-1].get("id") in ids:
+            return True
+    return False
+
+
+def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_state: bool = False, image_io: bool = False, dict_io: bool = False):
     """Class decorator: see the module docstring.  `methods` are wrapped for call-time fall-through; `share_state` (networks) makes
     the twin share parameters / buffers and follow ``.training``.  An unsupported configuration turns the object under
     construction into an instance of the reference class (``__class__`` assignment inside ``__init__``)."""
@@ -111,9 +250,16 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
 
         @functools.wraps(orig_init)
         def __init__(self, *args, **kwargs):
+            # the constructor call of the most derived class is the one a reference twin is built from: it ENTERS first (the bases'
+            # decorated constructors run inside it, through super().__init__) and records its arguments when it returns
+            ctors = _active.__dict__.setdefault("ctors", set())
+            outermost_ctor = id(self) not in ctors
+            ctors.add(id(self))
             try:
                 orig_init(self, *args, **kwargs)
             except NotImplementedError as e:
+                if not outermost_ctor:
+                    raise                                     # the most derived constructor decides what the object becomes
                 own = type(self).__dict__.get("_mh_ref")      # a user's subclass must not silently become the reference BASE class
                 ref = reference_object(*own) if own else None
                 if ref is None or not isinstance(ref, type):
@@ -130,7 +276,10 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                     return
                 ref.__init__(self, *args, **kwargs)
                 return
-            if "_mh_ctor" not in self.__dict__:               # the outermost (most derived) constructor call wins
+            finally:
+                if outermost_ctor:
+                    ctors.discard(id(self))
+            if outermost_ctor:
                 object.__setattr__(self, "_mh_ctor", (args, kwargs))
 
         cls.__init__ = __init__
@@ -156,6 +305,11 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                     twin.lazy = self.lazy
                 except Exception:
                     pass
+            if not share_state and hasattr(twin, "tracing") and hasattr(self, "tracing"):
+                try:
+                    twin.tracing = self.tracing      # trace_transform(False) around a call that falls through
+                except Exception:
+                    pass
             return twin
 
         def wrap(mname):
@@ -169,6 +323,18 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                 outermost = id(self) not in stack
                 stack.append(id(self))
                 try:
+                    if mname == "inverse" and args and _recorded_by_twin(self, args[0]):
+                        # the forward call fell through: the record on the image is the reference twin's (its `id`), only it can undo it
+                        return self.__dict__["_mh_twin_obj"].inverse(*args, **kwargs)
+                    if image_io and mname == "__call__":
+                        a2, k2 = _image_in(args, kwargs)
+                        out = _image_out(orig(self, *a2, **k2))
+                        if not getattr(self, "tracing", True):
+                            _drop_new_records(a2[0] if a2 else None, out)
+                        return out
+                    if dict_io and mname == "__call__":
+                        a2, k2 = _dict_in(self, args, kwargs)
+                        return _dict_out(self, orig(self, *a2, **k2))
                     return orig(self, *args, **kwargs)
                 except _FALLBACK_ERRORS as e:
                     if not outermost:
@@ -186,6 +352,9 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
             return method
 
         cls._mh_twin = _mh_twin
+        if image_io and not hasattr(cls, "trace_transform"):
+            cls.tracing = _Tracing.tracing
+            cls.trace_transform = _Tracing.trace_transform
         for m in methods:
             if m in cls.__dict__ or (hasattr(cls, m) and not getattr(getattr(cls, m), "__wrapped__", None)):
                 setattr(cls, m, wrap(m))
@@ -259,7 +428,10 @@ def apply_all() -> None:
         for name, (our_mod, our_name) in names.items():
             mod = importlib.import_module(our_mod)
             obj = getattr(mod, our_name)
-            if id(obj) in seen or getattr(obj, "_mh_ref", None) is not None:
+            # own attribute only: a subclass of an already decorated class (AvgMerger < Merger, SliceInferer < SlidingWindowInferer)
+            # inherits the base's `_mh_ref` and still needs its own
+            own_ref = vars(obj).get("_mh_ref") if inspect.isclass(obj) else getattr(obj, "_mh_ref", None)
+            if id(obj) in seen or own_ref is not None:
                 seen.add(id(obj))
                 continue
             seen.add(id(obj))
@@ -269,5 +441,8 @@ def apply_all() -> None:
                     reference_fallback(ref_mod, name, methods=("forward",), share_state=True)(obj)
                 else:
                     methods = tuple(m for m in ("__call__", "inverse", "aggregate", "finalize") if callable(getattr(obj, m, None)))
-                    reference_fallback(ref_mod, name, methods=methods)(obj)
+                    # array transforms (monai.transforms.<family>.array) follow the reference's image-in / image-out convention
+                    image_io = ref_mod.startswith("monai.transforms.") and ref_mod.endswith(".array")
+                    dict_io = ref_mod.startswith("monai.transforms.") and ref_mod.endswith(".dictionary")
+                    reference_fallback(ref_mod, name, methods=methods, image_io=image_io, dict_io=dict_io)(obj)
             # plain functions are decorated where they are defined (other modules hold direct references to them)

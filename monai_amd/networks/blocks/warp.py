@@ -69,9 +69,10 @@ class Warp(nn.Module):
         if self.compiled:
             grid = grid.permute([0] + list(range(2, 2 + sd)) + [1])               # (batch, ..., spatial_dims)
             return grid_pull(image, grid, bound=self._padding_mode, extrapolate=True, interpolation=self._interp_mode)
-        if image.requires_grad or ddf.requires_grad:
-            raise RuntimeError("monai_amd.networks.blocks.Warp: the non-compiled branch is forward-only; set monai_amd.config.USE_COMPILED "
-                               "(BUILD_MONAI=1) for a differentiable warp")
+        if torch.is_grad_enabled() and (image.requires_grad or ddf.requires_grad):
+            # falls through to the reference's F.grid_sample branch when MONAI is importable (boundary B3)
+            raise NotImplementedError("monai_amd.networks.blocks.Warp: the non-compiled branch is forward-only; set monai_amd.config.USE_COMPILED "
+                                      "(BUILD_MONAI=1) for a differentiable warp on the HIP kernels")
         if self._interp_mode == "bicubic":
             raise NotImplementedError("monai_amd.networks.blocks.Warp: bicubic needs USE_COMPILED (cubic B-spline grid_pull)")
         pad = 3 - sd

@@ -70,14 +70,19 @@ class AffineTransform(nn.Module):
             raise ValueError(f"affine and image batch dimension must match, got affine={theta.shape[0]} image={n}.")
 
         plain = src.as_tensor() if hasattr(src, "as_tensor") else src
+        th = theta.detach().double().cpu().numpy()
+        ms = [index_matrix(th[b], src_size[2:], dst_sp, self.normalized, self.align_corners, self.reverse_indexing, self.zero_centered) for b in range(n)]
+        if plain.dtype != theta.dtype:
+            # after the shape / matrix checks (ValueError), as in the reference: it builds the sampling grid in theta's dtype and
+            # F.grid_sample refuses an input of another dtype (spatial_transforms.py:584-591; tests/networks/layers/test_affine_transform.py:313-333)
+            raise RuntimeError(f"grid_sampler(): expected input and grid to have same dtype, but input has {plain.dtype} and grid has {theta.dtype}")
         f64 = plain.dtype == torch.float64
         x = plain.to(torch.float32).contiguous()
         _lib.require_device(x)
-        th = theta.detach().double().cpu().numpy()
         pad = 3 - sr
         outs = []
         for b in range(n):
-            m = index_matrix(th[b], src_size[2:], dst_sp, self.normalized, self.align_corners, self.reverse_indexing, self.zero_centered)
+            m = ms[b]
             vol = x[b].reshape((x.shape[1],) + (1,) * pad + tuple(src_size[2:]))
             o = ops.affine_resample(vol, m.reshape(-1), (1,) * pad + tuple(int(v) for v in dst_sp), self.mode, self.padding_mode,
                                     self.align_corners, f64)

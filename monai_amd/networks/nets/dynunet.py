@@ -15,7 +15,7 @@ exactly once, straight into the skip half of that level's concat buffer (``torch
 On the HIP path: 3-D, kernel extents 1 / 3 and strides 1 / 2 PER AXIS (anisotropic nnU-Net plans such as kernel (1, 3, 3), stride (1, 2, 2): an
 extent-1 axis runs as a 3-tap kernel with zero outer taps, per-axis strides on the direct kernel, kernel == stride transposed convs on a gather
 kernel), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
-``res_block`` False or True, dropout inference-inert; deep-supervision heads are parameters only (they feed the training loss, the
+``res_block`` False or True, ``dropout=None`` (a net with dropout layers is the reference's); deep-supervision heads are parameters only (they feed the training loss, the
 inference output does not depend on them)."""
 
 from __future__ import annotations
@@ -135,7 +135,10 @@ class DynUNet(nn.Module):
         us = [_triple(u, "upsample_kernel_size", {1, 2}) for u in upsample_kernel_size]
         if len(us) != len(ss) - 1 or any(u != s for u, s in zip(us, ss[1:])):
             raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] on the HIP path")
-        # dropout: accepted and inert (inference engine; Dropout holds no parameters, so checkpoints load unchanged)
+        if dropout is not None:
+            # the reference puts a Dropout module (by name, e.g. "alphadropout") into every conv layer's ADN (dynunet_block.py:256-301); code that
+            # inspects or samples through those modules (tests/networks/nets/test_dynunet.py:120-124, MC dropout) needs the reference tree
+            raise NotImplementedError("monai_amd.DynUNet: dropout layers are not on the HIP path (inference engine)")
         nname, nargs = (norm_name, {}) if isinstance(norm_name, str) else (norm_name[0], norm_name[1] if len(norm_name) > 1 else {})
         if str(nname).lower() != "instance":
             raise NotImplementedError("monai_amd.DynUNet: only instance norm is on the HIP path")

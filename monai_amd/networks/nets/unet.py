@@ -102,7 +102,10 @@ class UNet(nn.Module):
             raise ValueError("the length of `kernel_size` should equal to `dimensions`.")
         if isinstance(up_kernel_size, Sequence) and len(up_kernel_size) != spatial_dims:
             raise ValueError("the length of `up_kernel_size` should equal to `dimensions`.")
-        act_name = (act if isinstance(act, str) else act[0]).upper()
+        act_name = act if isinstance(act, str) else act[0]
+        if not isinstance(act_name, str):       # an activation given as a class / factory callable (blocks/acti_norm.py accepts both)
+            raise NotImplementedError("monai_amd.UNet: the HIP path takes the activation by name")
+        act_name = act_name.upper()
         norm_name, norm_args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
         if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or act_name != "PRELU"
                 or str(norm_name).upper() not in ("INSTANCE", "BATCH") or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):

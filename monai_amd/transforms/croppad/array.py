@@ -101,7 +101,10 @@ def _pad_value(mode, kwargs) -> float:
     if str(getattr(mode, "value", mode)).lower() != "constant":
         raise NotImplementedError(f"monai_amd crop / pad: padding mode {mode!r} is not on the HIP path (constant is)")
     kw = dict(kwargs)
-    return float(kw.pop("value", kw.pop("constant_values", 0.0)))
+    v = kw.pop("value", kw.pop("constant_values", 0.0))
+    if isinstance(v, (tuple, list)) or getattr(v, "ndim", 0):
+        raise NotImplementedError("monai_amd crop / pad: per-axis constant_values are not on the HIP path (one scalar value is)")
+    return float(v)
 
 
 class Pad(LazyCapable):
@@ -251,11 +254,14 @@ class CenterSpatialCrop(Crop):
         super().__init__(lazy=lazy)
         self.roi_size = roi_size
 
+    def compute_slices(self, spatial_size):      # the reference's override (array.py:506-509): slices of the centred box for this image size
+        roi_size = fall_back_tuple(self.roi_size, spatial_size)
+        return Crop.compute_slices(roi_center=[int(i) // 2 for i in spatial_size], roi_size=roi_size)
+
     def __call__(self, img, lazy: bool | None = None):
         lazy_ = self.lazy if lazy is None else lazy
         spatial = peek_shape(img) if (lazy_ and is_meta(img)) else tuple(int(v) for v in materialize(img).shape[1:])
-        roi_size = fall_back_tuple(self.roi_size, spatial)
-        return super().__call__(img=img, slices=Crop.compute_slices(roi_center=[i // 2 for i in spatial], roi_size=roi_size), lazy=lazy)
+        return super().__call__(img=img, slices=self.compute_slices(spatial), lazy=lazy)
 
 
 def generate_spatial_bounding_box(img, select_fn: Callable = is_positive, channel_indices=None, margin: Sequence[int] | int = 0,

@@ -147,6 +147,16 @@ def requires_interp(matrix, atol: float = AFFINE_TOL):
     return oy
 
 
+def _torch_pad_mode(padding_mode) -> str:
+    """grid_sample / numpy padding names -> torch.nn.functional.pad modes (monai/transforms/croppad/functional.py:38-75,
+    `_convert_pt_pad_mode`); None = constant zeros."""
+    p = str(getattr(padding_mode, "value", padding_mode)).lower() if padding_mode is not None else "constant"
+    table = {"zeros": "constant", "constant": "constant", "grid-constant": "constant", "border": "replicate", "replicate": "replicate", "edge": "replicate",
+             "nearest": "replicate", "reflection": "reflect", "reflect": "reflect", "mirror": "reflect", "grid-mirror": "reflect",
+             "wrap": "circular", "grid-wrap": "circular", "circular": "circular"}
+    return table.get(p, "replicate")      # "nearest", "border", and others (the reference's last branch)
+
+
 def resample(data, matrix, kwargs: dict | None = None):
     """Execute the composed voxel-space affine `matrix` on `data` (monai/transforms/lazy/utils.py:148-229).
 
@@ -168,6 +178,15 @@ def resample(data, matrix, kwargs: dict | None = None):
     ndim = len(matrix) - 1
     img = data if is_meta(data) else MetaTensor(torch.as_tensor(data))
     x = img.as_tensor()
+    r = x.dim() - 1
+    if 1 <= r < ndim:
+        # a 2-D image under a matrix `apply_pending` lifted to 3-D (lazy/functional.py:258-260): when the extra axes are untouched the
+        # operation is the r-D one (the reference's axis-only branch slices its permutation / shapes to the image's rank, utils.py:199-203)
+        rest = np.delete(np.delete(matrix, list(range(r)), axis=0), list(range(r)), axis=1)
+        if np.allclose(rest, np.eye(len(rest)), atol=atol) and np.allclose(matrix[:r, r:ndim], 0.0, atol=atol) and np.allclose(matrix[r:ndim, :r], 0.0, atol=atol):
+            sub = np.eye(r + 1)
+            sub[:r, :r], sub[:r, -1] = matrix[:r, :r], matrix[:r, -1]
+            matrix, ndim = sub, r
     full = np.asarray(img.meta["affine"].detach().cpu() if isinstance(img.meta.get("affine"), torch.Tensor) else img.meta.get("affine", np.eye(4)),
                       dtype=np.float64)
     init_affine = to_affine_nd(ndim, full)
@@ -181,6 +200,8 @@ def resample(data, matrix, kwargs: dict | None = None):
         res.meta["affine"] = torch.as_tensor(new_full, dtype=torch.float64)
         return res
 
+    if not all(o > 0 for o in out_size):
+        raise ValueError(f"Resampling out_spatial_size should be positive, got {out_size}.")
     axes = requires_interp(matrix, atol=atol)
     if axes is not None and mode == "auto" and not align_corners and x.dim() - 1 == ndim:
         m = np.round(matrix)
@@ -203,7 +224,19 @@ def resample(data, matrix, kwargs: dict | None = None):
             y = ops.flip_permute(y4, list(range(pad)) + [p + pad for p in perm], [False] * pad + flip_in)
             y = y.reshape((x.shape[0],) + tuple(in_shape[p] for p in perm))
         if any(s != 0 for s in start) or tuple(int(v) for v in y.shape[1:]) != out_size:
-            y = _run_crop_pad(y.to(torch.float32), start, out_size, 0.0)
+            cur = [int(v) for v in y.shape[1:]]
+            lo = [max(-s, 0) for s in start]
+            hi = [max(s + o - n, 0) for s, o, n in zip(start, out_size, cur)]
+            pm = _torch_pad_mode(kwargs.get(LazyAttr.PADDING_MODE))
+            if pm == "constant" or not (any(lo) or any(hi)):
+                y = _run_crop_pad(y.to(torch.float32), start, out_size, 0.0)
+            else:
+                # `crop_or_pad_nd(..., mode=padding_mode)` of the reference (lazy/utils.py:222): the crop on the gather kernel, the
+                # replicated / reflected / wrapped border by torch's pad on the device
+                inner = [o - a - b for o, a, b in zip(out_size, lo, hi)]
+                y = _run_crop_pad(y.to(torch.float32), [max(s, 0) for s in start], inner, 0.0)
+                pads = [v for a, b in zip(reversed(lo), reversed(hi)) for v in (a, b)]
+                y = torch.nn.functional.pad(y[None], pads, mode=pm)[0]
         return wrap(y.to(torch.float32))
 
     interp = kwargs.get(LazyAttr.INTERP_MODE) or "bilinear"

@@ -27,10 +27,17 @@ def _mode_name(mode) -> str:
     raise ValueError(f"Unsupported mode: {mode}, available options are ['bilinear', 'nearest'].")
 
 
+# scipy.ndimage boundary names -> grid_sample padding modes, the table of the reference's `_to_torch_resample_padding_mode`
+# (monai/transforms/utils.py:2281-2297, reached through `resolves_modes` from spatial_resample / Resample)
+_NDIMAGE_PAD = {"constant": "zeros", "grid-constant": "zeros", "nearest": "border", "reflect": "reflection", "wrap": "reflection",
+                "grid-wrap": "reflection", "grid-mirror": "reflection"}
+
+
 def _pad_name(padding_mode) -> str:
     p = str(getattr(padding_mode, "value", padding_mode)).lower()
+    p = _NDIMAGE_PAD.get(p, p)
     if p not in ("zeros", "border", "reflection"):
-        raise ValueError(f"Unsupported padding_mode: {padding_mode}, available options are ['zeros', 'border', 'reflection'].")
+        raise ValueError(f"Unsupported padding_mode: {padding_mode}, available options are {sorted(_NDIMAGE_PAD) + ['zeros', 'border', 'reflection']}.")
     return p
 
 
