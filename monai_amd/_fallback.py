@@ -103,13 +103,18 @@ _active = threading.local()       # ids of the instances whose wrapped method is
 # monai/transforms/intensity/array.py:1618, spatial/array.py:505): numpy arrays become tensors, and the result is a MetaTensor whenever
 # MONAI's global meta tracking is on (the default) -- also for a plain input -- and a plain tensor when it is off -- also for a
 # MetaTensor input (tests/transforms/test_spacing.py:300-317, test_gaussian_smooth.py:92 pin both).  Applied around the product's
-# ``__call__`` when MONAI is importable; without MONAI plain inputs stay plain and this package's MetaTensor keeps its metadata.
+# ``__call__`` while the patch is installed; used on its own the package keeps plain inputs plain and its own MetaTensor's metadata.
 _IMAGE_KWARGS = ("img", "data_array", "data")
 
 
 def _track_meta_state():
-    """(MONAI's MetaTensor class, tracking on?) or (None, None) without MONAI."""
+    """(MONAI's MetaTensor class, tracking on?) while this package stands in for the reference (`patch.install()`), else (None, None):
+    used on its own the package keeps plain inputs plain."""
     try:
+        from . import patch
+
+        if not patch._installed:
+            return None, None
         from monai.data.meta_obj import get_track_meta
         from monai.data.meta_tensor import MetaTensor
     except Exception:
@@ -323,6 +328,9 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                 outermost = id(self) not in stack
                 stack.append(id(self))
                 try:
+                    if mname == "inverse" and image_io and args and not (hasattr(args[0], "applied_operations") or isinstance(args[0], dict)):
+                        # monai/transforms/inverse.py:343-347 (`get_most_recent_transform`)
+                        raise ValueError(f"`data` should be either `MetaTensor` or dictionary, got {type(args[0])}.")
                     if mname == "inverse" and args and _recorded_by_twin(self, args[0]):
                         # the forward call fell through: the record on the image is the reference twin's (its `id`), only it can undo it
                         return self.__dict__["_mh_twin_obj"].inverse(*args, **kwargs)

@@ -15,7 +15,7 @@ exactly once, straight into the skip half of that level's concat buffer (``torch
 On the HIP path: 3-D, kernel extents 1 / 3 and strides 1 / 2 PER AXIS (anisotropic nnU-Net plans such as kernel (1, 3, 3), stride (1, 2, 2): an
 extent-1 axis runs as a 3-tap kernel with zero outer taps, per-axis strides on the direct kernel, kernel == stride transposed convs on a gather
 kernel), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
-``res_block`` False or True, ``dropout=None`` (a net with dropout layers is the reference's); deep-supervision heads are parameters only (they feed the training loss, the
+``res_block`` False or True, dropout layers present in the module tree and inference-inert; deep-supervision heads are parameters only (they feed the training loss, the
 inference output does not depend on them)."""
 
 from __future__ import annotations
@@ -48,8 +48,32 @@ def _out_size(size, stride):
 
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
+def _dropout_module(dropout):
+    """The ``D`` of the reference's ``ADN`` (blocks/acti_norm.py:69-101, layers/factories.py `Dropout`) for 3-D: a probability, a name or
+    ``(name, kwargs)``.  Parameter-free and the identity in eval mode -- the inference schedule never calls it; it is in the tree because
+    the reference's is (code that walks ``net.modules()``, tests/networks/nets/test_dynunet.py:120-124)."""
+    if isinstance(dropout, (int, float)):
+        name, args = "dropout", {"p": float(dropout)}
+    elif isinstance(dropout, str):
+        name, args = dropout, {}
+    else:
+        name, args = dropout[0], (dropout[1] if len(dropout) > 1 else {})
+    kinds = {"dropout": nn.Dropout3d, "alphadropout": nn.AlphaDropout}
+    if not isinstance(name, str) or name.lower() not in kinds:
+        raise NotImplementedError(f"monai_amd.DynUNet: dropout layer {name!r} is not known to the HIP path")
+    return kinds[name.lower()](**args)
+
+
+class _ADN(nn.Module):
+    def __init__(self, dropout):
+        super().__init__()
+        self.D = _dropout_module(dropout)
+
+
 class _Conv(nn.Module):
-    """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose only child is ``conv``"""
+    """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose children are ``conv`` and, with dropout, ``adn.D``"""
+
+    _dropout = None      # set by DynUNet.__init__ while it builds its blocks
 
     def __init__(self, cin, cout, k, stride=(1, 1, 1), transposed=False, bias=False):
         super().__init__()
@@ -58,6 +82,8 @@ class _Conv(nn.Module):
             self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, bias=bias)
         else:       # get_padding, dynunet_block.py:304-315: (k - s + 1) / 2 per axis, truncated
             self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=tuple((a - b + 1) // 2 for a, b in zip(k, stride)), bias=bias)
+        if _Conv._dropout is not None:
+            self.adn = _ADN(_Conv._dropout)
 
 
 class _Block(nn.Module):
@@ -135,10 +161,10 @@ class DynUNet(nn.Module):
         us = [_triple(u, "upsample_kernel_size", {1, 2}) for u in upsample_kernel_size]
         if len(us) != len(ss) - 1 or any(u != s for u, s in zip(us, ss[1:])):
             raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] on the HIP path")
+        # dropout: the reference puts a Dropout module into every conv layer's ADN (dynunet_block.py:256-301); they are in this tree too
+        # (parameter-free: checkpoints load unchanged) and inert -- the engine runs in eval mode only, training falls through
         if dropout is not None:
-            # the reference puts a Dropout module (by name, e.g. "alphadropout") into every conv layer's ADN (dynunet_block.py:256-301); code that
-            # inspects or samples through those modules (tests/networks/nets/test_dynunet.py:120-124, MC dropout) needs the reference tree
-            raise NotImplementedError("monai_amd.DynUNet: dropout layers are not on the HIP path (inference engine)")
+            _dropout_module(dropout)          # an unknown layer name: NotImplementedError -> the reference's class
         nname, nargs = (norm_name, {}) if isinstance(norm_name, str) else (norm_name[0], norm_name[1] if len(norm_name) > 1 else {})
         if str(nname).lower() != "instance":
             raise NotImplementedError("monai_amd.DynUNet: only instance norm is on the HIP path")
@@ -165,20 +191,24 @@ class DynUNet(nn.Module):
             return _Block(cin, cout, k, s, affine, slope, res_block)
 
         # construction order = the reference's (dynunet.py:154-166): it fixes the random stream of the default initialisers
-        self.input_block = block(in_channels, f[0], ks[0], ss[0])
-        self.downsamples = nn.ModuleList([block(i, o, k, s) for i, o, k, s in zip(f[:-2], f[1:-1], ks[1:-1], ss[1:-1])])
-        self.bottleneck = block(f[-2], f[-1], ks[-1], ss[-1])
-        self.upsamples = nn.ModuleList([_UpBlock(i, o, k, u, affine, slope, trans_bias)
-                                        for i, o, k, u in zip(f[1:][::-1], f[:-1][::-1], ks[1:][::-1], us[::-1])])
-        self.output_block = _OutBlock(f[0], out_channels)
-        self.deep_supervision, self.deep_supr_num = deep_supervision, deep_supr_num
-        self.heads = [torch.rand(1)] * deep_supr_num            # one draw from the global generator, as the reference
-        if deep_supervision:
-            self.deep_supervision_heads = nn.ModuleList([_OutBlock(f[i + 1], out_channels) for i in range(deep_supr_num)])
-            if deep_supr_num >= len(strides) - 1:
-                raise ValueError("deep_supr_num should be less than the number of up sample layers.")
-            if deep_supr_num < 1:
-                raise ValueError("deep_supr_num should be larger than 0.")
+        _Conv._dropout = dropout
+        try:
+            self.input_block = block(in_channels, f[0], ks[0], ss[0])
+            self.downsamples = nn.ModuleList([block(i, o, k, s) for i, o, k, s in zip(f[:-2], f[1:-1], ks[1:-1], ss[1:-1])])
+            self.bottleneck = block(f[-2], f[-1], ks[-1], ss[-1])
+            self.upsamples = nn.ModuleList([_UpBlock(i, o, k, u, affine, slope, trans_bias)
+                                            for i, o, k, u in zip(f[1:][::-1], f[:-1][::-1], ks[1:][::-1], us[::-1])])
+            self.output_block = _OutBlock(f[0], out_channels)
+            self.deep_supervision, self.deep_supr_num = deep_supervision, deep_supr_num
+            self.heads = [torch.rand(1)] * deep_supr_num            # one draw from the global generator, as the reference
+            if deep_supervision:
+                self.deep_supervision_heads = nn.ModuleList([_OutBlock(f[i + 1], out_channels) for i in range(deep_supr_num)])
+                if deep_supr_num >= len(strides) - 1:
+                    raise ValueError("deep_supr_num should be less than the number of up sample layers.")
+                if deep_supr_num < 1:
+                    raise ValueError("deep_supr_num should be larger than 0.")
+        finally:
+            _Conv._dropout = None
         self.apply(self.initialize_weights)
 
         def create_skips(index, downs, ups, heads):

@@ -14,6 +14,7 @@ Without MONAI installed this module is not needed: use ``"_target_": "monai_amd.
 from __future__ import annotations
 
 import importlib
+import os
 import sys
 
 _TARGETS = {
@@ -188,11 +189,27 @@ def _register_transform_traits() -> None:
     for mod in (_lf, _lu):
         if ("lazy", mod.__name__) not in _installed:
             _installed[("lazy", mod.__name__)] = mod.resample
-        mod.resample = _lazy.resample
+        mod.resample = _resample_or_reference
     from monai.inferers import Inferer          # an ABC as well: `isinstance(x, Inferer)` checks in user code keep holding
 
     for our_mod_name, our_name in set(_TARGETS["monai.inferers.inferer"].values()):
         Inferer.register(getattr(importlib.import_module(our_mod_name), our_name))
+
+
+def _resample_or_reference(data, matrix, kwargs=None):
+    """`monai.transforms.lazy.utils.resample` once installed: the fused kernel path, and -- boundary B3 -- the reference's own function
+    for what that path does not cover (spline-order interpolation, CPU tensors, other dtypes)."""
+    from . import _fallback
+    from .transforms import lazy as _lazy
+
+    try:
+        return _lazy.resample(data, matrix, kwargs)
+    except _fallback._FALLBACK_ERRORS as e:
+        ref = _installed.get(("lazy", "monai.transforms.lazy.utils"))
+        if ref is None or os.environ.get("MONAI_AMD_NO_FALLTHROUGH") == "1":
+            raise
+        _fallback._note("lazy.resample", e)
+        return ref(data, matrix, kwargs)
 
 
 def uninstall() -> None:

@@ -81,7 +81,9 @@ class AsDiscrete:
         if to_onehot is not None:
             if not isinstance(to_onehot, int):
                 raise ValueError(f"the number of classes for One-Hot must be an integer, got {type(to_onehot)}.")
-            if t.dim() < 1 or t.shape[0] != 1:
+            if t.dim() < 2:      # a scalar / 1-D label: the reference's one_hot reshapes it (networks/utils.py:170-220); not a volume for the kernel
+                raise NotImplementedError("monai_amd.AsDiscrete: one-hot of a label without spatial axes is not on the HIP path")
+            if t.shape[0] != 1:
                 raise AssertionError("labels should have a channel with length equal to one.")
             t = ops.onehot(t, to_onehot)
         threshold = self.threshold if threshold is None else threshold

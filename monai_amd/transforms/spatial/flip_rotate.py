@@ -79,8 +79,8 @@ class Flip(LazyCapable):
         else:                                        # map_spatial_axes, monai/transforms/utils.py:1380-1412
             axes = []
             for a in ensure_tuple(self.spatial_axis):
-                if not isinstance(a, int):
-                    raise ValueError("spatial_axis must be None, int or sequence of ints.")
+                if not isinstance(a, int):          # the reference hands the axes to torch.flip, which raises TypeError (tests/transforms/test_flip.py:32)
+                    raise TypeError("spatial_axis must be None, int or sequence of ints.")
                 if a >= sr or a < -sr:
                     raise IndexError(f"spatial axis {a} is out of range for an image with {sr} spatial axes")
                 axes.append(a if a >= 0 else sr + a)
