@@ -25,14 +25,35 @@ def sources():
     return deps
 
 
+def _fresh() -> bool:
+    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources())
+
+
 def build(force: bool = False) -> str:
+    """One build at a time across processes (pytest-xdist starts several workers that all need the library): the others wait on the
+    lock and find it fresh; the compiler writes a temporary file that is renamed into place, so nobody ever loads a half-written one."""
+    import fcntl
+
     os.makedirs(OUT_DIR, exist_ok=True)
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in sources()):
+    if not force and _fresh():
         return OUT
-    cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-mfma", "-mavx2",
-           "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi", "-I", os.path.join(HERE, "stub"), SRC, "-o", OUT]
-    subprocess.run(cmd, check=True)
+    with open(os.path.join(OUT_DIR, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _fresh():
+                return OUT
+            cxx = CLANG if os.path.exists(CLANG) else "clang++"
+            tmp = f"{OUT}.{os.getpid()}.tmp"
+            cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-mfma", "-mavx2",
+                   "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi", "-I", os.path.join(HERE, "stub"), SRC, "-o", tmp]
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, OUT)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 
