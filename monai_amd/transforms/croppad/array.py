@@ -131,7 +131,7 @@ class Pad(LazyCapable):
         kw.update(kwargs)
         value = _pad_value(self.mode if mode is None else mode, kw)
         to_pad_ = [tuple(int(v) for v in p) for p in to_pad_]
-        if len(to_pad_) != data.dim() or to_pad_[0] != (0, 0):
+        if len(to_pad_) != len(shape_) + 1 or to_pad_[0] != (0, 0):      # rank from the (pending) shape: lazy records may ride on an empty tensor
             raise NotImplementedError(f"monai_amd pad: to_pad must list every axis and leave the channel axis alone, got {to_pad_}")
         start = [-p[0] for p in to_pad_[1:]]
         size = [int(n) + p[0] + p[1] for n, p in zip(shape_, to_pad_[1:])]
@@ -225,7 +225,7 @@ class Crop(LazyCapable):
             img = materialize(img)
         data = img.as_tensor() if is_meta(img) else torch.as_tensor(img)
         shape_ = peek_shape(img) if is_meta(img) else tuple(int(v) for v in data.shape[1:])
-        sd = data.dim() - 1
+        sd = len(shape_)                                 # rank from the (pending) shape: the reference's Zoom sends a lazy record on an empty tensor
         slices_ = (list(slices) + [slice(None)] * sd)[:sd]
         rng = [s.indices(int(n)) for s, n in zip(slices_, shape_)]
         start = [r[0] for r in rng]

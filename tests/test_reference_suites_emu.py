@@ -36,6 +36,9 @@ MODULES = [
     ("transforms/test_spacing.py", True),
     ("transforms/test_spacingd.py", True),
     ("transforms/test_spatial_resample.py", True),
+    ("transforms/spatial/test_spatial_resampled.py", True),
+    ("transforms/compose/test_compose.py", True),
+    ("transforms/inverse/test_inverse_dict.py", True),
     ("transforms/test_resampler.py", True),
     ("transforms/test_affine_grid.py", False),
     ("transforms/test_gaussian_smooth.py", True),
