@@ -334,11 +334,21 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                     if mname == "inverse" and args and _recorded_by_twin(self, args[0]):
                         # the forward call fell through: the record on the image is the reference twin's (its `id`), only it can undo it
                         return self.__dict__["_mh_twin_obj"].inverse(*args, **kwargs)
+                    if image_io and mname == "inverse" and args and hasattr(args[0], "applied_operations"):
+                        # the reference's inverse POPS the record from the object it is given (inverse.py:353-370, `pop_transform`): callers
+                        # -- RandFlip.inverse re-appends the inner record and hands the same object on -- rely on that side effect
+                        n_before = len(args[0].applied_operations)
+                        out = orig(self, *args, **kwargs)
+                        ops_ = args[0].applied_operations
+                        if out is not args[0] and len(ops_) == n_before and n_before > 0:
+                            ops_.pop()
+                        return out
                     if image_io and mname == "__call__":
                         a2, k2 = _image_in(args, kwargs)
                         out = _image_out(orig(self, *a2, **k2))
                         if not getattr(self, "tracing", True):
-                            _drop_new_records(a2[0] if a2 else None, out)
+                            img_in = a2[0] if a2 else next((k2[k] for k in _IMAGE_KWARGS if k in k2), None)
+                            _drop_new_records(img_in, out)
                         return out
                     if dict_io and mname == "__call__":
                         a2, k2 = _dict_in(self, args, kwargs)

@@ -86,7 +86,16 @@ def _inverse_crop_pad(img, cls_name: str):
     rec = img.applied_operations[-1]
     if rec.get("class") != cls_name:
         raise RuntimeError(f"monai_amd.{cls_name}.inverse: the most recent operation is {rec.get('class')!r}")
-    start, orig = rec["extra_info"]["box_start"], tuple(int(v) for v in rec["orig_size"])
+    info, orig = rec["extra_info"], tuple(int(v) for v in rec["orig_size"])
+    if "box_start" in info:
+        start = info["box_start"]
+    elif "padded" in info:        # a record written by the reference's pad_func (croppad/functional.py:182): (before, after) per axis, channel first
+        start = [-int(p[0]) for p in list(info["padded"])[1:]]
+    elif "cropped" in info:       # ... by its crop_func (:233): before / after per spatial axis, flattened
+        start = [int(v) for v in list(info["cropped"])[0::2]]
+    else:
+        raise NotImplementedError(f"monai_amd.{cls_name}.inverse: unknown record {sorted(info)}")
+    start = (list(start) + [0] * len(orig))[:len(orig)]
     out = _run_crop_pad(img.as_tensor(), [-s for s in start], orig, 0.0)
     res = type(img)(out, meta=dict(img.meta), applied_operations=list(img.applied_operations[:-1]))
     aff = affine_np(img)

@@ -123,8 +123,15 @@ class Rotate90(LazyCapable):
     def inverse(self, data):
         rec = data.applied_operations[-1]
         prev = type(data)(data.as_tensor(), meta=dict(data.meta), applied_operations=list(data.applied_operations[:-1]))
-        out = Rotate90(k=4 - rec["extra_info"]["k"], spatial_axes=tuple(rec["extra_info"]["axes"]))(prev)
-        out.applied_operations = list(data.applied_operations[:-1])
+        return self.inverse_transform(prev, rec)
+
+    def inverse_transform(self, data, transform):
+        """Undo the rotation described by the record `transform` on `data` (whose record has already been popped) -- the entry point the
+        reference's RandRotate90.inverse uses (monai/transforms/spatial/array.py:1188-1196, 1254-1259); leaves no record of its own."""
+        kept = list(getattr(data, "applied_operations", []) or [])
+        out = Rotate90(k=4 - transform["extra_info"]["k"], spatial_axes=tuple(transform["extra_info"]["axes"]))(data)
+        if hasattr(out, "applied_operations"):
+            out.applied_operations = kept
         return out
 
 
