@@ -48,6 +48,7 @@ static int launched(const char* what) {
 }
 static inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 static inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline bool fits_i32(long long n) { return n < 2147483647LL; }
 static bool dense_ok(const mh_tensor5* t) {
     return t && t->data && t->N > 0 && t->C > 0 && t->D > 0 && t->H > 0 && t->W > 0 &&
            t->n_stride >= (int64_t)t->C * t->D * t->H * t->W;
@@ -673,6 +674,25 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
     const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
+    // the same op as one GEMM on the fp32 matrix cores (kernels/nn_simple.h: deconv_k2s2_mfma_kernel): opt-in until it has been measured
+    const char* impl = getenv("MONAI_AMD_DECONV_IMPL");
+    if (impl && !strcmp(impl, "mfma") && in.W % 4 == 0 && out.C % 4 == 0 && aligned(out.data, 16) && out.n_stride % 4 == 0 &&
+        (in.C == 32 || in.C == 64 || in.C == 128 || in.C == 256) && (!in.nrm || aligned(in.nrm, 16)) && in.nrm_n_stride % 4 == 0 && fits_i32((long long)in.D * in.H * in.W + 256)) {
+        const dim3 g(blocks_for(2LL * in.D * in.H * in.W), (unsigned)out.N);      // 128 voxels (four 32-voxel wave tiles) per workgroup
+#define MH_DECONV_MFMA(KS_)                                                                                                              \
+    {                                                                                                                                        \
+        if (in.nrm) hipLaunchKernelGGL((deconv_k2s2_mfma_kernel<KS_, true>), g, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);        \
+        else hipLaunchKernelGGL((deconv_k2s2_mfma_kernel<KS_, false>), g, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);              \
+    }
+        switch (in.C) {
+            case 32: MH_DECONV_MFMA(16) break;
+            case 64: MH_DECONV_MFMA(32) break;
+            case 128: MH_DECONV_MFMA(64) break;
+            default: MH_DECONV_MFMA(128) break;
+        }
+#undef MH_DECONV_MFMA
+        return launched("deconv_k2s2");
+    }
     if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
@@ -752,7 +772,6 @@ static int stream_chunks(long long units, int Do, int slots, int prime, int min_
     return best;
 }
 
-static bool fits_i32(long long n) { return n < 2147483647LL; }
 
 int64_t mh_affine_resample_workspace_bytes(int Do, int Ho, int Wo) { return (int64_t)(Do + Ho + Wo) * (int64_t)sizeof(AxisTap<double>); }
 

@@ -352,6 +352,97 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
         }
 }
 
+// The same op as ONE GEMM on the fp32 matrix cores (exact fp32 products and sums, v_mfma_f32_32x32x2_f32): out[voxel][cout, dz, dy, dx] =
+// sum over cin of act(in)[voxel][cin] * w[cin][cout, dz, dy, dx] -- M = input voxels, K = Cin, N = 8 Cout.  The kernel above is VALU-bound,
+// not write-bound, from 32 input channels on: 8 Cin Cout multiply-adds per input voxel are 116 GFLOP per 64 windows of 32 -> 32 channels at
+// 48^3 (1.5 ms at the 78 TF of scalar v_fma_f32, measured 2.3 ms, against 1.2 ms for writing the 7.25 GB result) and twice that per byte
+// at every level below; the matrix pipe does the same flops in 0.74 ms and leaves the vector pipe to the stores.
+//   * a wave owns 32 consecutive input voxels (one MFMA M block; W % 4 == 0 keeps every aligned group of four inside a row) and holds its
+//     A operand -- the activated voxels, lane l = voxel (l & 31) x channel 2 s + (l >> 5) -- in KS = Cin / 2 registers for the whole N loop;
+//   * N is walked in chunks of 32 = 4 couts x 8 taps: B lane l = w[2 s + (l >> 5)][32 chunk + (l & 31)], 128-byte coalesced loads that hit
+//     L1 / L2 (the whole weight tensor is 32 KB ... 2 MB); no LDS, no barrier;
+//   * D lane l = column (cout, dz, dy, dx) = 32 chunk + (l & 31) x voxels 8 g + 4 (l >> 5) + r (register 4 g + r): lanes l and l ^ 1 hold
+//     dx = 0 / 1 of the same four voxels, one exchange gives each a float4 of four consecutive output floats (16-byte stores, 64-byte runs
+//     per (cout, dz, dy) row and half-wave pair).
+// Summation order: bias first, then input channels in pairs (the MFMA's two k per instruction, order inside the pair unspecified): fp32
+// rounding-level differences from the kernel above (tests bound both against fp64).  Opt-in until measured: MONAI_AMD_DECONV_IMPL=mfma.
+template <int KS, bool NRM>
+__global__ void __launch_bounds__(256)
+deconv_k2s2_mfma_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
+    constexpr int G = KS < 16 ? KS : 16;                      // k-steps whose B operands are in flight together (one group ahead)
+    const int Hi = in.H, Wi = in.W, Cout = out.C;
+    const int ivol = in.D * Hi * Wi;                          // the launcher checks that a channel volume fits 31 bits
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int n = blockIdx.y;
+    const int m0 = ((int)blockIdx.x * 4 + wave) * 32;
+    if (m0 >= ivol) return;                                   // whole wave: no barrier in this kernel
+    const int ma = min(m0 + col, ivol - 1);                   // A-operand voxel of this lane (clamped: rows beyond the volume are never stored)
+    const float* src = in.data + (long long)n * in.n_stride + ma;
+    float a[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = src[(long long)(2 * s + half) * ivol];
+    if (NRM) {
+        // the records of a channel pair are 32 contiguous bytes at a wave-uniform address: scalar loads, the half-wave picks its channel
+        const float* np = in.nrm + (long long)n * in.nrm_n_stride;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 n0 = *reinterpret_cast<const float4*>(np + 8 * s), n1 = *reinterpret_cast<const float4*>(np + 8 * s + 4);
+            a[s] = act(a[s], half ? n1.x : n0.x, half ? n1.y : n0.y, half ? n1.z : n0.z);
+        }
+    }
+    const int Ho = out.H, Wo = out.W;
+    const long long ovol = (long long)out.D * Ho * Wo;
+    const int N8 = Cout * 8;
+    // this lane's column (cout, dz, dy, dx) = 32 chunk + col; its four stores per chunk go to fixed places inside a cout volume
+    const int tap = col & 7, dz = tap >> 2, dy = (tap >> 1) & 1, dx = tap & 1;
+    long long ooff[4];
+    bool ok[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int m = m0 + 8 * g + 4 * half + 2 * dx;         // first of the two voxels whose four outputs this lane stores
+        ok[g] = m < ivol;
+        const int mc = ok[g] ? m : 0;
+        const int x = mc % Wi, t = mc / Wi, y = t % Hi, z = t / Hi;
+        ooff[g] = ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
+    }
+    float* const dst = out.data + (long long)n * out.n_stride;
+    for (int nc = 0; nc < N8; nc += 32) {
+        const int co = (nc + col) >> 3;
+        const float bj = bias ? bias[co] : 0.0f;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bj;
+        const float* wb = w + (long long)half * N8 + nc + col;
+        float bcur[G], bnext[G];
+#pragma unroll
+        for (int j = 0; j < G; ++j) bcur[j] = wb[(long long)(2 * j) * N8];
+#pragma unroll
+        for (int s0 = 0; s0 < KS; s0 += G) {
+            if (s0 + G < KS) {
+#pragma unroll
+                for (int j = 0; j < G; ++j) bnext[j] = wb[(long long)(2 * (s0 + G + j)) * N8];
+            }
+#pragma unroll
+            for (int j = 0; j < G; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + j], bcur[j], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);               // the group after next stays behind: G B registers in use, G in flight
+#pragma unroll
+            for (int j = 0; j < G; ++j) bcur[j] = bnext[j];
+        }
+        float* const cbase = dst + (long long)co * ovol;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            // lanes l (dx = 0) and l ^ 1 (dx = 1) hold the same voxels r = 0..3: the even lane takes voxels 0, 1, the odd lane voxels 2, 3
+            float e0 = acc[4 * g], e1 = acc[4 * g + 1], e2 = acc[4 * g + 2], e3 = acc[4 * g + 3];
+            MH_OPAQUE(e0); MH_OPAQUE(e1); MH_OPAQUE(e2); MH_OPAQUE(e3);      // plain values: a select of two vector elements would become a DYNAMIC element index (16 compares + selects each)
+            const float s0 = dx ? e0 : e2, s1 = dx ? e1 : e3;
+            const float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
+            const f32x4 v = dx ? f32x4{t0, e2, t1, e3} : f32x4{e0, t0, e1, t1};
+            if (ok[g]) *reinterpret_cast<f32x4*>(cbase + ooff[g]) = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Conv3d k=1 of act(in): CO output channels [co0, co0+CO) per thread, VEC voxels per thread.
 template <int CO, int VEC>

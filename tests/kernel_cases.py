@@ -271,6 +271,34 @@ def case_deconv(device, n=2, cin=16, cout=6, dims=(4, 6, 10)):
     assert torch.all(got[:, :3] == 0)
 
 
+def case_deconv_mfma(device, n=2, cin=32, cout=8, dims=(3, 5, 8)):
+    """ConvTranspose3d k2 s2 as one GEMM on the fp32 matrix cores (MONAI_AMD_DECONV_IMPL=mfma): against float64 and against the
+    one-voxel-per-thread kernel (fp32 rounding-level differences: another summation order)."""
+    import os
+
+    gen = torch.Generator().manual_seed(15)
+    x = torch.randn((n, cin) + dims, generator=gen)
+    w = torch.randn((cin, cout, 2, 2, 2), generator=gen) / np.sqrt(cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _rand_nrm(n, cin, gen)
+    outs = []
+    saved = os.environ.pop("MONAI_AMD_DECONV_IMPL", None)
+    try:
+        for impl in ("mfma", "scalar"):
+            os.environ["MONAI_AMD_DECONV_IMPL"] = impl
+            out = torch.full((n, cout) + tuple(2 * d for d in dims), float("nan"), device=device)
+            ops.deconv_k2s2(x.to(device), nrm.to(device), w.to(device), b.to(device), out)
+            outs.append(out.cpu())
+    finally:
+        os.environ.pop("MONAI_AMD_DECONV_IMPL", None)
+        if saved is not None:
+            os.environ["MONAI_AMD_DECONV_IMPL"] = saved
+    exp = F.conv_transpose3d(_act(x.double(), nrm.double()), w.double(), b.double(), stride=2)
+    assert not torch.isnan(outs[0]).any()
+    assert (outs[0].double() - exp).abs().max().item() < 2e-5 * max(1.0, np.sqrt(cin / 32.0)), (outs[0].double() - exp).abs().max().item()
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-5 * max(1.0, np.sqrt(cin / 32.0))
+
+
 def case_conv1x1(device, n=2, cin=32, cout=5, dims=(6, 8, 12)):
     gen = torch.Generator().manual_seed(5)
     x = torch.randn((n, cin) + dims, generator=gen)

@@ -229,3 +229,11 @@ def test_conv_one_input_channel(emu):
     kc.case_conv3d("cpu", cfg, 1, 1, 24, (3, 8, 8), with_nrm=True, fused_stats=True)        # 8 couts per thread, deferred norm on the input
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)      # two z-chunks (25 planes each)
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)     # no statistics; a second tile row of one line
+
+
+def test_deconv_on_the_matrix_cores(emu):
+    """kernels/nn_simple.h: deconv_k2s2_mfma_kernel (opt-in): every supported Cin, a ragged last tile (voxels % 32 != 0), batches"""
+    kc.case_deconv_mfma("cpu")
+    kc.case_deconv_mfma("cpu", n=1, cin=64, cout=4, dims=(2, 3, 4))          # 24 voxels: one partial wave tile
+    kc.case_deconv_mfma("cpu", n=1, cin=128, cout=12, dims=(1, 5, 12))       # 60 voxels: a full and a partial tile, 3 column chunks
+    kc.case_deconv_mfma("cpu", n=1, cin=256, cout=4, dims=(2, 2, 4))

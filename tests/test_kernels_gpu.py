@@ -194,3 +194,13 @@ def test_conv_one_input_channel():
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)
     kc.case_conv3d(DEV, cfg, 2, 1, 32, (96, 96, 96), with_nrm=False, fused_stats=True)
+
+
+def test_deconv_on_the_matrix_cores():
+    """kernels/nn_simple.h: deconv_k2s2_mfma_kernel (opt-in): every supported Cin, a ragged last tile (voxels % 32 != 0), batches"""
+    kc.case_deconv_mfma(DEV)
+    kc.case_deconv_mfma(DEV, n=1, cin=64, cout=4, dims=(2, 3, 4))          # 24 voxels: one partial wave tile
+    kc.case_deconv_mfma(DEV, n=1, cin=128, cout=12, dims=(1, 5, 12))       # 60 voxels: a full and a partial tile, 3 column chunks
+    kc.case_deconv_mfma(DEV, n=1, cin=256, cout=4, dims=(2, 2, 4))
+    kc.case_deconv_mfma(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
+    kc.case_deconv_mfma(DEV, n=1, cin=256, cout=128, dims=(6, 6, 8))

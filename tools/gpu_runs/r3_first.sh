@@ -1,0 +1,14 @@
+# first GPU call of round 3: what round 2 prepared on the CPU and could not measure any more
+#  1. the transposed convolution as one GEMM on the fp32 matrix cores (kernels/nn_simple.h: deconv_k2s2_mfma_kernel, opt-in): its GPU cases and the
+#     bench line with / without it (the one-voxel kernel is 6.5 % of the step: 0.89 / 2.3 ms per launch at 32 -> 32 ch, VALU-bound)
+#  2. the whole -m gpu suite + smoke() on the state the round starts from, the bench line with its kernel trace
+O=gpurun_out/r3first; mkdir -p $O; export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -n 0 -k "deconv_on_the_matrix or pool_deconv" 2>&1 | tail -5 > $O/deconv_mfma_tests.txt; cat $O/deconv_mfma_tests.txt
+for impl in scalar mfma; do
+  MONAI_AMD_DECONV_IMPL=$impl timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$impl -o bench -- python bench.py --steps 3 --warmup 1 --cpu-windows 0 > $O/bench_line_deconv_$impl.json 2> $O/bench_$impl.err
+  find $O/prof_$impl -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} > $O/kernel_trace_deconv_$impl.txt 2>&1
+  rm -rf $O/prof_$impl
+  grep -i "deconv" $O/kernel_trace_deconv_$impl.txt | cut -c1-170; cut -c1-260 $O/bench_line_deconv_$impl.json
+done
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/gpu_tests.txt; tail -3 $O/gpu_tests.txt
+python __graft_entry__.py smoke 2>&1 | tail -2 > $O/smoke.txt; cat $O/smoke.txt
