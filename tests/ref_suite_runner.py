@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE: run ONE of the reference's own unittest modules (/root/reference/tests/...) over the product classes.
 
     python tests/ref_suite_runner.py /root/reference/tests/inferers/test_sliding_window_inference.py
+    python tests/ref_suite_runner.py /root/reference/tests/networks/layers/test_grid_pull.py --compiled      # BUILD_MONAI=1, monai._C = monai_amd._C
 
 `monai_amd.patch.install()` rebinds the reference's names to the MI355X classes, the SIMT-emulator build of the kernels stands in for
 the GPU (tests/emu_backend.py: host pointers accepted, dtype rules kept), and the module's tests run unmodified.  Calls the HIP path does
@@ -19,11 +20,18 @@ sys.path[:0] = [os.path.join(HERE, "ref_shims"), os.path.dirname(HERE), HERE, "/
 os.environ.setdefault("MONAI_AMD_CONV_ALGO", "fp32")      # exact-fp32 convolutions: the split-precision default is 10x slower to emulate
 
 
-def main(path: str) -> int:
+def main(path: str, compiled: bool = False) -> int:
     warnings.filterwarnings("ignore")
     import torch  # noqa: F401
     from emu_backend import emu_backend
 
+    if compiled:
+        # the reference's BUILD_MONAI=1 state (monai/config/deviceconfig.py: USE_COMPILED = HAS_EXT and BUILD_MONAI == "1"), with
+        # monai_amd._C standing in for the compiled extension `monai._C` -- it has to be importable before `import monai`
+        os.environ["BUILD_MONAI"] = "1"
+        from monai_amd import _C
+
+        sys.modules["monai._C"] = _C
     import monai  # noqa: F401
     from monai_amd import _fallback, _lib, patch
 
@@ -60,4 +68,4 @@ def main(path: str) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(main(sys.argv[1]))
+    sys.exit(main(sys.argv[1], compiled="--compiled" in sys.argv[2:]))

@@ -106,14 +106,35 @@ def _monai_importable() -> bool:
 pytestmark = [pytest.mark.skipif(not _monai_importable(), reason="the reference checkout (/root/reference) is not present"), pytest.mark.fallthrough]
 
 
+# BUILD_MONAI=1 (`USE_COMPILED`): `monai._C` is `monai_amd._C` -- the reference's tests of its compiled resampler (224 rows of the 1D_BP tables
+# through grid_pull, Warp / DVF2DDF and Resample on the native branch) run over the HIP pushpull kernels.  Known difference in that mode, not
+# listed: test_spacing.py case 4 -- the reference's spatial_resample then composes Affine -> Resample -> grid_pull (other boundary semantics,
+# spatial/functional.py:161-173), this package keeps its grid_sample-equivalent kernel for SpatialResample in both modes.
+COMPILED = [
+    ("networks/layers/test_grid_pull.py", True),
+    ("networks/blocks/warp/test_dvf2ddf.py", True),
+    ("transforms/test_resampler.py", True),
+    ("transforms/test_affine.py", True),
+]
+
+
+@pytest.mark.parametrize("module,needs_launches", COMPILED, ids=[m + "[BUILD_MONAI=1]" for m, _ in COMPILED])
+def test_reference_module_passes_with_monai_C_from_this_package(module, needs_launches):
+    _run(module, needs_launches, ["--compiled"])
+
+
 @pytest.mark.parametrize("module,needs_launches", MODULES, ids=[m for m, _ in MODULES])
 def test_reference_module_passes_over_the_product(module, needs_launches):
+    _run(module, needs_launches, [])
+
+
+def _run(module, needs_launches, extra):
     path = os.path.join(REF_TESTS, module)
     if not os.path.exists(path):
         pytest.skip(f"{module} is not part of this reference checkout")
     env = dict(os.environ, OMP_NUM_THREADS="2")
     env.pop("MONAI_AMD_NO_FALLTHROUGH", None)        # the fall-through to the reference is part of what is tested
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_suite_runner.py"), path], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ref_suite_runner.py"), path] + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("RESULT ")]
     assert lines, (p.stdout[-1500:], p.stderr[-3000:])
     res = json.loads(lines[-1][len("RESULT "):])
