@@ -353,19 +353,20 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
 }
 
 // The same op as ONE GEMM on the fp32 matrix cores (exact fp32 products and sums, v_mfma_f32_32x32x2_f32): out[voxel][cout, dz, dy, dx] =
-// sum over cin of act(in)[voxel][cin] * w[cin][cout, dz, dy, dx] -- M = input voxels, K = Cin, N = 8 Cout.  The kernel above is VALU-bound,
-// not write-bound, from 32 input channels on: 8 Cin Cout multiply-adds per input voxel are 116 GFLOP per 64 windows of 32 -> 32 channels at
-// 48^3 (1.5 ms at the 78 TF of scalar v_fma_f32, measured 2.3 ms, against 1.2 ms for writing the 7.25 GB result) and twice that per byte
-// at every level below; the matrix pipe does the same flops in 0.74 ms and leaves the vector pipe to the stores.
-//   * a wave owns 32 consecutive input voxels (one MFMA M block; W % 4 == 0 keeps every aligned group of four inside a row) and holds its
-//     A operand -- the activated voxels, lane l = voxel (l & 31) x channel 2 s + (l >> 5) -- in KS = Cin / 2 registers for the whole N loop;
+// sum over cin of act(in)[voxel][cin] * w[cin][cout, dz, dy, dx] -- M = input voxels, K = Cin, N = 8 Cout.
+// Measured (profiles/r02_deconv_bench_v1.json, 64 windows): the kernel above is NOT bound by its 8 Cin Cout multiply-adds per voxel -- a first
+// matrix-core form with the same store pattern ran exactly as long (2.38 vs 2.43 ms at 32 -> 32 ch @ 48^3, 0.56 vs 0.57, 0.30 vs 0.28 ms below)
+// -- but by how the result is written: float2 / 16-byte pieces of 32 .. 64 contiguous bytes per (cout, dz, dy) row reach 3.0 TB/s where whole
+// 128-byte lines reach 6 (tools/ubench/hbm_stream.hip).  So this form exists for its stores:
+//   * a wave owns 32 consecutive input voxels (one MFMA M block) and holds its A operand -- the activated voxels, lane l = voxel (l & 31) x
+//     channel 2 s + (l >> 5) -- in KS = Cin / 2 registers for the whole N loop (the {alpha, beta, slope} records of a channel pair come by scalar load);
 //   * N is walked in chunks of 32 = 4 couts x 8 taps: B lane l = w[2 s + (l >> 5)][32 chunk + (l & 31)], 128-byte coalesced loads that hit
-//     L1 / L2 (the whole weight tensor is 32 KB ... 2 MB); no LDS, no barrier;
-//   * D lane l = column (cout, dz, dy, dx) = 32 chunk + (l & 31) x voxels 8 g + 4 (l >> 5) + r (register 4 g + r): lanes l and l ^ 1 hold
-//     dx = 0 / 1 of the same four voxels, one exchange gives each a float4 of four consecutive output floats (16-byte stores, 64-byte runs
-//     per (cout, dz, dy) row and half-wave pair).
-// Summation order: bias first, then input channels in pairs (the MFMA's two k per instruction, order inside the pair unspecified): fp32
-// rounding-level differences from the kernel above (tests bound both against fp64).  Opt-in until measured: MONAI_AMD_DECONV_IMPL=mfma.
+//     L1 / L2 (the whole weight tensor is 32 KB ... 2 MB), one group of 16 k-steps in flight ahead of the MFMAs;
+//   * the 32 x 32 result tile of a chunk is 16 output rows (cout, dz, dy) of 64 consecutive floats (32 voxels x dx): it goes through a
+//     wave-private LDS tile (scattered 4-byte writes, 16-byte reads) so that every store instruction writes four complete 256-byte runs.
+// Results are bit-identical to the kernel above on the MI355X and on the emulator (bias first, input channels ascending, fused multiply-adds:
+// the fp32 MFMA accumulates its two k in order).  Opt-in until measured: MONAI_AMD_DECONV_IMPL=mfma.
+constexpr int DT_PITCH = 68;      // floats per LDS row of the store tile: 64 + 4 (16-byte aligned rows, the 16 rows of a chunk start in different banks)
 template <int KS, bool NRM>
 __global__ void __launch_bounds__(256)
 deconv_k2s2_mfma_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
@@ -394,18 +395,16 @@ deconv_k2s2_mfma_kernel(Tensor in, const float* __restrict__ w, const float* __r
     const int Ho = out.H, Wo = out.W;
     const long long ovol = (long long)out.D * Ho * Wo;
     const int N8 = Cout * 8;
-    // this lane's column (cout, dz, dy, dx) = 32 chunk + col; its four stores per chunk go to fixed places inside a cout volume
-    const int tap = col & 7, dz = tap >> 2, dy = (tap >> 1) & 1, dx = tap & 1;
-    long long ooff[4];
-    bool ok[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int m = m0 + 8 * g + 4 * half + 2 * dx;         // first of the two voxels whose four outputs this lane stores
-        ok[g] = m < ivol;
-        const int mc = ok[g] ? m : 0;
+    // store side: lane l writes the 16-byte piece (l & 15) of a row = the outputs 2 x .. 2 x + 3 of the two voxels m0 + 2 (l & 15), + 1
+    const int pm = m0 + 2 * (lane & 15);
+    const bool pok = pm < ivol;                               // W % 4 == 0: the voxel pair is inside or outside together
+    long long poff;
+    {
+        const int mc = pok ? pm : 0;
         const int x = mc % Wi, t = mc / Wi, y = t % Hi, z = t / Hi;
-        ooff[g] = ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
+        poff = ((long long)(2 * z) * Ho + 2 * y) * Wo + 2 * x;
     }
+    __shared__ __attribute__((aligned(16))) float stile[4][16 * DT_PITCH];
     float* const dst = out.data + (long long)n * out.n_stride;
     for (int nc = 0; nc < N8; nc += 32) {
         const int co = (nc + col) >> 3;
@@ -429,16 +428,23 @@ deconv_k2s2_mfma_kernel(Tensor in, const float* __restrict__ w, const float* __r
 #pragma unroll
             for (int j = 0; j < G; ++j) bcur[j] = bnext[j];
         }
-        float* const cbase = dst + (long long)co * ovol;
+        // transpose through the wave's LDS tile: element (voxel m, column n) -> row n >> 1 = (cout, dz, dy), position 2 m + dx
+        float* const tile = stile[wave];
+        __builtin_amdgcn_wave_barrier();                      // the previous chunk's reads are done (wave-private tile: no workgroup barrier)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // lanes l (dx = 0) and l ^ 1 (dx = 1) hold the same voxels r = 0..3: the even lane takes voxels 0, 1, the odd lane voxels 2, 3
-            float e0 = acc[4 * g], e1 = acc[4 * g + 1], e2 = acc[4 * g + 2], e3 = acc[4 * g + 3];
-            MH_OPAQUE(e0); MH_OPAQUE(e1); MH_OPAQUE(e2); MH_OPAQUE(e3);      // plain values: a select of two vector elements would become a DYNAMIC element index (16 compares + selects each)
-            const float s0 = dx ? e0 : e2, s1 = dx ? e1 : e3;
-            const float t0 = __shfl_xor(s0, 1), t1 = __shfl_xor(s1, 1);
-            const f32x4 v = dx ? f32x4{t0, e2, t1, e3} : f32x4{e0, t0, e1, t1};
-            if (ok[g]) *reinterpret_cast<f32x4*>(cbase + ooff[g]) = v;
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+            tile[(col >> 1) * DT_PITCH + 2 * m + (col & 1)] = acc[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 4 * i + (lane >> 4), piece = lane & 15;           // 16 lanes x 16 bytes = one row of 64 floats
+            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * DT_PITCH + 4 * piece);
+            const int rco = (nc >> 3) + (row >> 2), rdz = (row >> 1) & 1, rdy = row & 1;
+            if (pok) *reinterpret_cast<f32x4*>(dst + (long long)rco * ovol + poff + ((long long)rdz * Ho + rdy) * Wo) = v;
         }
     }
 }

@@ -1,5 +1,7 @@
 """-m gpu: the kernel parity cases of tests/kernel_cases.py on the real MI355X, through the C ABI of the in-tree
 libmonai_amd.so (the same cases run on the CPU against the emulator build in tests/test_kernels_emu.py)."""
+import os
+
 import pytest
 import torch
 
@@ -196,6 +198,9 @@ def test_conv_one_input_channel():
     kc.case_conv3d(DEV, cfg, 2, 1, 32, (96, 96, 96), with_nrm=False, fused_stats=True)
 
 
+@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_DECONV_MFMA") != "1",
+                    reason="the opt-in matrix-core transposed convolution: its LDS-transposed store path was written after round 2's GPU budget was spent "
+                           "(the pair-exchange form before it passed these cases on the MI355X, profiles/r02_gpu_tests_call127.txt); tools/gpu_runs/r3_first.sh runs it")
 def test_deconv_on_the_matrix_cores():
     """kernels/nn_simple.h: deconv_k2s2_mfma_kernel (opt-in): every supported Cin, a ragged last tile (voxels % 32 != 0), batches"""
     kc.case_deconv_mfma(DEV)

@@ -3,7 +3,8 @@
 #     bench line with / without it (the one-voxel kernel is 6.5 % of the step: 0.89 / 2.3 ms per launch at 32 -> 32 ch, VALU-bound)
 #  2. the whole -m gpu suite + smoke() on the state the round starts from, the bench line with its kernel trace
 O=gpurun_out/r3first; mkdir -p $O; export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_kernels_gpu.py -q -n 0 -k "deconv_on_the_matrix or pool_deconv" 2>&1 | tail -5 > $O/deconv_mfma_tests.txt; cat $O/deconv_mfma_tests.txt
+MONAI_AMD_TEST_DECONV_MFMA=1 timeout 300 python -m pytest tests/test_kernels_gpu.py -q -n 0 -k "deconv_on_the_matrix or pool_deconv" 2>&1 | tail -5 > $O/deconv_mfma_tests.txt; cat $O/deconv_mfma_tests.txt
+python tools/deconv_bench.py > $O/deconv_bench.json 2> $O/deconv_bench.err; tr -d "\n " < $O/deconv_bench.json | cut -c1-900; echo
 for impl in scalar mfma; do
   MONAI_AMD_DECONV_IMPL=$impl timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_$impl -o bench -- python bench.py --steps 3 --warmup 1 --cpu-windows 0 > $O/bench_line_deconv_$impl.json 2> $O/bench_$impl.err
   find $O/prof_$impl -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} > $O/kernel_trace_deconv_$impl.txt 2>&1
