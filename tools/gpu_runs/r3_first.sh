@@ -11,5 +11,6 @@ for impl in scalar mfma; do
   rm -rf $O/prof_$impl
   grep -i "deconv" $O/kernel_trace_deconv_$impl.txt | cut -c1-170; cut -c1-260 $O/bench_line_deconv_$impl.json
 done
+bash tools/gpu_runs/pmc_deconv.sh > $O/pmc_deconv.log 2>&1; tail -12 $O/pmc_deconv.log | cut -c1-150
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/gpu_tests.txt; tail -3 $O/gpu_tests.txt
 python __graft_entry__.py smoke 2>&1 | tail -2 > $O/smoke.txt; cat $O/smoke.txt
