@@ -355,9 +355,10 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
 // The same op as ONE GEMM on the fp32 matrix cores (exact fp32 products and sums, v_mfma_f32_32x32x2_f32): out[voxel][cout, dz, dy, dx] =
 // sum over cin of act(in)[voxel][cin] * w[cin][cout, dz, dy, dx] -- M = input voxels, K = Cin, N = 8 Cout.
 // Measured (profiles/r02_deconv_bench_v1.json, 64 windows): the kernel above is NOT bound by its 8 Cin Cout multiply-adds per voxel -- a first
-// matrix-core form with the same store pattern ran exactly as long (2.38 vs 2.43 ms at 32 -> 32 ch @ 48^3, 0.56 vs 0.57, 0.30 vs 0.28 ms below)
-// -- but by how the result is written: float2 / 16-byte pieces of 32 .. 64 contiguous bytes per (cout, dz, dy) row reach 3.0 TB/s where whole
-// 128-byte lines reach 6 (tools/ubench/hbm_stream.hip).  So this form exists for its stores:
+// matrix-core form with the same store pattern ran exactly as long (2.38 vs 2.43 ms at 32 -> 32 ch @ 48^3, 0.56 vs 0.57, 0.30 vs 0.28 ms below).
+// Both write the 7.25 GB result at 3.0 TB/s, half of what streaming whole 128-byte lines reaches (tools/ubench/hbm_stream.hip); whether that is
+// partial-line writes fetching their lines first or the number of channel planes written at once is for the counters of
+// tools/gpu_runs/pmc_deconv.sh to say.  This form takes the first candidate out:
 //   * a wave owns 32 consecutive input voxels (one MFMA M block) and holds its A operand -- the activated voxels, lane l = voxel (l & 31) x
 //     channel 2 s + (l >> 5) -- in KS = Cin / 2 registers for the whole N loop (the {alpha, beta, slope} records of a channel pair come by scalar load);
 //   * N is walked in chunks of 32 = 4 couts x 8 taps: B lane l = w[2 s + (l >> 5)][32 chunk + (l & 31)], 128-byte coalesced loads that hit

@@ -198,3 +198,11 @@ def test_scale_intensity_vs_reference(emu):
     import normalize_cases as nc
 
     print("arrays", nc.case_scale_intensity_vs_reference("cpu"))
+
+
+def test_conventions_pinned_by_the_reference_suites(emu):
+    """what tests/test_reference_suites_emu.py established against the reference's own tests, restated without the reference"""
+    import lazy_cases as lc
+
+    tc.case_reference_argument_conventions("cpu")
+    assert lc.case_axis_only_resample_conventions("cpu")

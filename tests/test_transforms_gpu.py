@@ -153,3 +153,11 @@ def test_lazy_resampling_vs_reference():
 
     print("launches", lc.case_lazy_chains_vs_reference("cuda"))
     assert lc.case_lazy_orientation_spacing_fused("cuda")
+
+
+def test_conventions_pinned_by_the_reference_suites():
+    """what tests/test_reference_suites_emu.py established against the reference's own tests, restated without the reference"""
+    import lazy_cases as lc
+
+    tc.case_reference_argument_conventions(DEV)
+    assert lc.case_axis_only_resample_conventions(DEV)

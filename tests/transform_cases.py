@@ -649,6 +649,49 @@ def case_gaussian_rowvec_equals_tile(device):
         assert (b.cpu().double() - ref[0]).abs().max().item() < 2e-6, shape
 
 
+def case_reference_argument_conventions(device):
+    """Argument rules the reference's own tests pin (run over this package in tests/test_reference_suites_emu.py), restated so that the GPU box
+    checks them without the reference: AffineTransform refuses an image whose dtype differs from theta's AFTER its shape checks
+    (tests/networks/layers/test_affine_transform.py:280-333: ValueError first, RuntimeError for the dtype); scipy.ndimage padding names map to
+    grid_sample's (monai/transforms/utils.py:2281-2297); Flip with a non-integer axis raises TypeError (test_flip.py:32)."""
+    from monai_amd.data import MetaTensor
+    from monai_amd.networks.layers import AffineTransform
+    from monai_amd.transforms import Flip, Spacing
+    from monai_amd.transforms.spatial.functional import _pad_name
+
+    theta = torch.eye(4)[None].to(device)
+    img = torch.arange(48, dtype=torch.float32).view(2, 1, 4, 2, 3).to(device)
+    xf = AffineTransform((2, 3, 4), padding_mode="border", mode="bilinear", normalized=True)
+    assert xf(img, theta.repeat(2, 1, 1)).shape == (2, 1, 2, 3, 4)
+    for bad_img, bad_theta, err in ((img.to(torch.int32), theta.repeat(2, 1, 1), RuntimeError),        # dtype differs from theta's
+                                    (img, theta.repeat(2, 1, 1).double(), RuntimeError),
+                                    (img.to(torch.int32), theta.repeat(3, 1, 1), ValueError)):          # the batch check comes first
+        try:
+            xf(bad_img, bad_theta)
+        except err:
+            pass
+        else:
+            raise AssertionError(f"expected {err.__name__}")
+    assert [_pad_name(p) for p in ("constant", "grid-constant", "nearest", "reflect", "wrap", "grid-mirror", "zeros", "border")] == \
+        ["zeros", "zeros", "border", "reflection", "reflection", "reflection", "zeros", "border"]
+    try:
+        _pad_name("mirror!")
+    except ValueError:
+        pass
+    else:
+        raise AssertionError("unknown padding name must raise ValueError")
+    vol = MetaTensor(torch.rand(1, 6, 6, 6).to(device), affine=np.diag([2.0, 2.0, 2.0, 1.0]))
+    a = Spacing(pixdim=(1.0, 1.0, 1.0), padding_mode="constant")(vol)
+    b = Spacing(pixdim=(1.0, 1.0, 1.0), padding_mode="zeros")(vol)
+    assert torch.equal(a.as_tensor(), b.as_tensor())
+    try:
+        Flip(["s", 1])(vol)
+    except TypeError:
+        pass
+    else:
+        raise AssertionError("Flip with a non-integer axis must raise TypeError")
+
+
 def case_general_rows_vs_linear(device):
     """Rotated / sheared matrices: the row-mapped kernel with compile-time mode and padding rule (the default) gives exactly what the
     linear-index kernel gives (MONAI_AMD_RS_GENERAL=linear), and both match a float64 torch restatement of trilinear sampling with border
