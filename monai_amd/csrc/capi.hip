@@ -483,7 +483,9 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(in.data, 16) || in.n_stride % 4 || !aligned(packed_w, 4))
             return fail(MH_ERR_ARG, "conv3d_k3: the one-channel kernel needs 16-byte aligned input and output");
         const int txn = cdiv(out.W, C1_TX), tyn = cdiv(out.H, C1_TY), zc = c1_zchunk(out.D);
-        const int cot = out.C % 16 == 0 ? 16 : 8;
+        // 16 output channels per thread halve the input reads and the tap loop's overhead per output; 8 write half as many channel planes at once
+        // and need 180 instead of 256 registers (MONAI_AMD_C1_COT=8: A/B measurement, tools/gpu_runs/r3_first.sh)
+        const int cot = out.C % 16 == 0 && env_int("MONAI_AMD_C1_COT", 16) != 8 ? 16 : 8;
         const dim3 grid((unsigned)(txn * tyn * cdiv(out.D, zc)), (unsigned)(out.C / cot), (unsigned)out.N);
 #define MH_C1_LAUNCH(COT_)                                                                                                                    \
     {                                                                                                                                         \

@@ -11,6 +11,9 @@ for impl in scalar mfma; do
   rm -rf $O/prof_$impl
   grep -i "deconv" $O/kernel_trace_deconv_$impl.txt | cut -c1-170; cut -c1-260 $O/bench_line_deconv_$impl.json
 done
+MONAI_AMD_C1_COT=8 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_c1 -o bench -- python bench.py --steps 3 --warmup 1 --cpu-windows 0 > $O/bench_line_c1_cot8.json 2> $O/bench_c1.err
+find $O/prof_c1 -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} > $O/kernel_trace_c1_cot8.txt 2>&1; rm -rf $O/prof_c1
+grep -i "c1_kernel" $O/kernel_trace_c1_cot8.txt | cut -c1-170; cut -c1-200 $O/bench_line_c1_cot8.json
 bash tools/gpu_runs/pmc_deconv.sh > $O/pmc_deconv.log 2>&1; tail -12 $O/pmc_deconv.log | cut -c1-150
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $O/gpu_tests.txt; tail -3 $O/gpu_tests.txt
 python __graft_entry__.py smoke 2>&1 | tail -2 > $O/smoke.txt; cat $O/smoke.txt
