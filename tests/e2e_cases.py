@@ -143,12 +143,13 @@ def case_fused_argmax_epilogue(device):
 
     net, _ = make_net(1, 1, 5, device)
     torch.manual_seed(41)
-    x = torch.rand(2, 1, 40, 24, 16).to(device)
+    nb = 1 if str(device) == "cpu" else 2            # the emulator pays for every window of the full-width net: one volume there, a batch of two on the GPU
+    x = torch.rand(2, 1, 40, 24, 16)[:nb].to(device)
     inf = SlidingWindowInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian")
     ref = inf(x, net)
-    exp = torch.stack([AsDiscrete(argmax=True)(ref[i]) for i in range(2)])
+    exp = torch.stack([AsDiscrete(argmax=True)(ref[i]) for i in range(nb)])
     got = inf.argmax(x, net)
-    assert got.shape == (2, 1, 40, 24, 16) and got.dtype == torch.float32 and torch.equal(got, exp)
+    assert got.shape == (nb, 1, 40, 24, 16) and got.dtype == torch.float32 and torch.equal(got, exp)
     got8 = SlidingWindowArgmaxInferer(roi_size=(16, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian", labels_dtype=torch.uint8)(x, net)
     assert got8.dtype == torch.uint8 and torch.equal(got8.float(), exp)
 

@@ -25,7 +25,7 @@ def _run(cmd):
 
 
 def test_bench_single_process_line():
-    line = _run([sys.executable, "bench.py", "--cpu-windows", "8"] + ARGS)
+    line = _run([sys.executable, "bench.py", "--cpu-windows", "2"] + ARGS)
     assert KEYS <= set(line) and line["n_gpus"] == 1 and line["unit"] == "voxels/s" and line["dtype"] == "f32" and line["emulated"]
     assert line["roofline"]["bound"] == "mfma" and 0.0 < line["roofline"]["frac"] and line["roofline"]["unit"] == "TFLOP/s"
     assert line["roofline_hbm"]["bound"] == "hbm" and line["roofline_hbm"]["peak"] == 8000.0
