@@ -12,7 +12,8 @@ output is stored raw with its InstanceNorm (affine) + LeakyReLU folded into a pe
 consumer applies on load; stride-1 convs run on the fp32-MFMA tiles with fused statistics, stride-2 convs on the direct
 kernel, the k2s2 transposed convs and the 1x1 head on their own kernels; the encoder output of each level is materialised
 exactly once, straight into the skip half of that level's concat buffer (``torch.cat`` never runs).
-On the HIP path: 3-D, kernel extents 1 / 3 and strides 1 / 2 PER AXIS (anisotropic nnU-Net plans such as kernel (1, 3, 3), stride (1, 2, 2): an
+On the HIP path: 3-D, and 2-D as ONE PLANE of the 3-D engine (kernel (1, k, k), stride (1, s, s); the parameters live in the reference's 2-D modules, so
+the state_dict is the 2-D net's -- what SliceInferer drives); kernel extents 1 / 3 and strides 1 / 2 PER AXIS (anisotropic nnU-Net plans such as kernel (1, 3, 3), stride (1, 2, 2): an
 extent-1 axis runs as a 3-tap kernel with zero outer taps, per-axis strides on the direct kernel, kernel == stride transposed convs on a gather
 kernel), upsample kernels equal to the strides, instance norm, (leaky) ReLU,
 ``res_block`` False or True, dropout layers present in the module tree and inference-inert; deep-supervision heads are parameters only (they feed the training loss, the
@@ -30,14 +31,17 @@ from ... import _lib, _prof, ops
 __all__ = ["DynUNet", "DynUnet", "Dynunet"]
 
 
-def _triple(v, what: str, allowed) -> tuple:
-    """an int or a 3-sequence -> (z, y, x) ints, each one of `allowed`"""
+def _triple(v, what: str, allowed, dims: int = 3) -> tuple:
+    """an int or a `dims`-sequence -> (z, y, x) ints, each one of `allowed`; a 2-D network is the 3-D engine on one plane: its z entry is 1
+    (kernel extent 1, stride 1, upsample factor 1 -- the anisotropic plans of the 3-D path)"""
     if isinstance(v, (list, tuple)):
-        if len(v) != 3:
+        if len(v) != dims:
             raise ValueError(f"length of {what} should be the same as spatial_dims.")
         t = tuple(int(a) for a in v)
     else:
-        t = (int(v),) * 3
+        t = (int(v),) * dims
+    if dims == 2:
+        t = (1,) + t
     if any(a not in allowed for a in t):
         raise NotImplementedError(f"monai_amd.DynUNet: {what} {t} is not on the HIP path (per axis: {sorted(allowed)})")
     return t
@@ -74,14 +78,22 @@ class _Conv(nn.Module):
     """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose children are ``conv`` and, with dropout, ``adn.D``"""
 
     _dropout = None      # set by DynUNet.__init__ while it builds its blocks
+    _dims = 3            # likewise: 2 builds the reference's 2-D modules (Conv2d ...: the state_dict of a 2-D net), the engine reads them as one-plane 3-D
 
     def __init__(self, cin, cout, k, stride=(1, 1, 1), transposed=False, bias=False):
         super().__init__()
         k = (k,) * 3 if isinstance(k, int) else tuple(k)
-        if transposed:
+        stride = tuple(stride)
+        pad = tuple((a - b + 1) // 2 for a, b in zip(k, stride))       # get_padding, dynunet_block.py:304-315: (k - s + 1) / 2 per axis, truncated
+        if _Conv._dims == 2:
+            if transposed:
+                self.conv = nn.ConvTranspose2d(cin, cout, kernel_size=k[1:], stride=stride[1:], bias=bias)
+            else:
+                self.conv = nn.Conv2d(cin, cout, kernel_size=k[1:], stride=stride[1:], padding=pad[1:], bias=bias)
+        elif transposed:
             self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, bias=bias)
-        else:       # get_padding, dynunet_block.py:304-315: (k - s + 1) / 2 per axis, truncated
-            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=tuple((a - b + 1) // 2 for a, b in zip(k, stride)), bias=bias)
+        else:
+            self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias)
         if _Conv._dropout is not None:
             self.adn = _ADN(_Conv._dropout)
 
@@ -95,11 +107,12 @@ class _Block(nn.Module):
         self.conv1 = _Conv(cin, cout, kernel, stride)
         self.conv2 = _Conv(cout, cout, kernel)
         self.lrelu = nn.LeakyReLU(slope, inplace=True) if slope != 0.0 else nn.ReLU(inplace=True)
-        self.norm1 = nn.InstanceNorm3d(cout, affine=affine)
-        self.norm2 = nn.InstanceNorm3d(cout, affine=affine)
+        norm_t = nn.InstanceNorm2d if _Conv._dims == 2 else nn.InstanceNorm3d
+        self.norm1 = norm_t(cout, affine=affine)
+        self.norm2 = norm_t(cout, affine=affine)
         if res and (cin != cout or any(a != 1 for a in stride)):
             self.conv3 = _Conv(cin, cout, 1, stride)
-            self.norm3 = nn.InstanceNorm3d(cout, affine=affine)
+            self.norm3 = norm_t(cout, affine=affine)
 
 
 class _UpBlock(nn.Module):
@@ -154,11 +167,11 @@ class DynUNet(nn.Module):
         # dynunet.py:213-231 (checked before any parameter exists here; the reference checks after building)
         if len(kernel_size) != len(strides) or len(kernel_size) < 3:
             raise ValueError("length of kernel_size and strides should be the same, and no less than 3.")
-        if spatial_dims != 3:
-            raise NotImplementedError("monai_amd.DynUNet: only spatial_dims=3 is on the HIP path")
-        ks = [_triple(k, f"kernel_size in block {i}", {1, 3}) for i, k in enumerate(kernel_size)]
-        ss = [_triple(s, f"stride in block {i}", {1, 2}) for i, s in enumerate(strides)]
-        us = [_triple(u, "upsample_kernel_size", {1, 2}) for u in upsample_kernel_size]
+        if spatial_dims not in (2, 3):
+            raise NotImplementedError("monai_amd.DynUNet: spatial_dims 2 and 3 are on the HIP path")
+        ks = [_triple(k, f"kernel_size in block {i}", {1, 3}, spatial_dims) for i, k in enumerate(kernel_size)]
+        ss = [_triple(s, f"stride in block {i}", {1, 2}, spatial_dims) for i, s in enumerate(strides)]
+        us = [_triple(u, "upsample_kernel_size", {1, 2}, spatial_dims) for u in upsample_kernel_size]
         if len(us) != len(ss) - 1 or any(u != s for u, s in zip(us, ss[1:])):
             raise NotImplementedError("monai_amd.DynUNet: upsample_kernel_size must equal strides[1:] on the HIP path")
         # dropout: the reference puts a Dropout module into every conv layer's ADN (dynunet_block.py:256-301); they are in this tree too
@@ -191,7 +204,7 @@ class DynUNet(nn.Module):
             return _Block(cin, cout, k, s, affine, slope, res_block)
 
         # construction order = the reference's (dynunet.py:154-166): it fixes the random stream of the default initialisers
-        _Conv._dropout = dropout
+        _Conv._dropout, _Conv._dims = dropout, spatial_dims
         try:
             self.input_block = block(in_channels, f[0], ks[0], ss[0])
             self.downsamples = nn.ModuleList([block(i, o, k, s) for i, o, k, s in zip(f[:-2], f[1:-1], ks[1:-1], ss[1:-1])])
@@ -208,7 +221,7 @@ class DynUNet(nn.Module):
                 if deep_supr_num < 1:
                     raise ValueError("deep_supr_num should be larger than 0.")
         finally:
-            _Conv._dropout = None
+            _Conv._dropout, _Conv._dims = None, 3
         self.apply(self.initialize_weights)
 
         def create_skips(index, downs, ups, heads):
@@ -237,9 +250,15 @@ class DynUNet(nn.Module):
                 module.bias = nn.init.constant_(module.bias, 0)
 
     # ---- helpers -----------------------------------------------------------------------------------
-    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+    @staticmethod
+    def _w5(conv) -> torch.Tensor:
+        """the layer's weight as the engine sees it: 5-D; a 2-D layer's [O, I, kh, kw] is the one-plane kernel [O, I, 1, kh, kw] (a view)"""
         w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        return w if w.dim() == 5 else w.unsqueeze(2)
+
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+        w = self._w5(conv)
+        key = (w.data_ptr(), conv.weight._version, str(w.device))
         hit = self._packed.get((id(conv), cfg))
         if hit is None or hit[0] != key:
             if tuple(w.shape[2:]) != (3, 3, 3):
@@ -297,7 +316,7 @@ class DynUNet(nn.Module):
         c2, n2 = self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), 1.0)
         if not hasattr(blk, "conv3"):
             return ops.add_act(c2, n2, x, None, self._slope, dst)
-        w3 = blk.conv3.conv.weight
+        w3 = self._w5(blk.conv3.conv)
         cout = w3.shape[0]
         r = torch.empty_like(c2)
         if blk.stride == (1, 1, 1):
@@ -333,13 +352,19 @@ class DynUNet(nn.Module):
         if up.up == (2, 2, 2):
             ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout])
         else:
-            ops.deconv_ks(t, tn, tc.weight, tc.bias, cat[:, :cout], up.up)
+            ops.deconv_ks(t, tn, self._w5(tc).contiguous(), tc.bias, cat[:, :cout], up.up)
         return self._basic(up.conv_block, cat, None)
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("monai_amd.DynUNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
+        if self.spatial_dims == 2:
+            if x.dim() != 4:
+                raise NotImplementedError(f"monai_amd.DynUNet: a 2-D network takes (B, C, H, W), got {tuple(x.shape)}")
+            sp = _out_size((1,) + tuple(x.shape[2:]), self._strides[0])
+            out = torch.empty((x.shape[0], self.out_channels) + sp[1:], dtype=torch.float32, device=x.device)
+            return self.forward_into(x, out)
         sp = _out_size(x.shape[2:], self._strides[0])
         out = torch.empty((x.shape[0], self.out_channels) + sp, dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
@@ -347,6 +372,9 @@ class DynUNet(nn.Module):
     @torch.no_grad()
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         _lib.require_device(x, out)
+        if self.spatial_dims == 2 and x.dim() == 4 and out.dim() == 4:
+            self.forward_into(x.unsqueeze(2), out.unsqueeze(2))          # one plane of the 3-D engine (views: no copy)
+            return out
         if self.training:
             raise NotImplementedError("monai_amd.DynUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         total = [1, 1, 1]

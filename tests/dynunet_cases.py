@@ -30,7 +30,24 @@ CFGS = {
                                 upsample_kernel_size=[[2, 2, 1], [2, 2, 2]], filters=[8, 16, 32]),
                         shape=(2, 1, 16, 24, 6), seed=15),
 }
-IN_CH = {"basic": 1, "res_ds": 2, "stride0": 1, "aniso": 1, "aniso_basic": 1}
+IN_CH = {"basic": 1, "res_ds": 2, "stride0": 1, "aniso": 1, "aniso_basic": 1, "2d_basic": 1, "2d_res_ds": 2, "2d_aniso": 1}
+# 2-D networks (SliceInferer needs a product 2-D net): the 3-D engine on one plane -- kernel (1, k, k), stride (1, s, s)
+CFGS_2D = {
+    "2d_basic": dict(kw=dict(kernel_size=[3, 3, 3, 3], strides=[1, 2, 2, 2], upsample_kernel_size=[2, 2, 2], filters=[16, 32, 32, 64]),
+                     shape=(2, 1, 48, 64), seed=21),
+    "2d_res_ds": dict(kw=dict(kernel_size=[3, 3, 3], strides=[1, 2, 2], upsample_kernel_size=[2, 2], filters=[8, 16, 32], res_block=True,
+                              deep_supervision=True, deep_supr_num=1),
+                      shape=(1, 2, 32, 40), seed=22),
+    "2d_aniso": dict(kw=dict(kernel_size=[[3, 3], [3, 3], [3, 1]], strides=[[1, 1], [2, 2], [2, 1]], upsample_kernel_size=[[2, 2], [2, 1]],
+                             filters=[8, 8, 16], act_name="relu", trans_bias=True),
+                     shape=(1, 1, 32, 24), seed=23),
+}
+CFGS.update(CFGS_2D)
+SLICE = dict(roi_size=(32, 32), sw_batch_size=3, spatial_dim=0, overlap=0.5, mode="gaussian")
+
+
+def slice_volume():
+    return torch.rand((1, 1, 5, 48, 40), generator=torch.Generator().manual_seed(802))
 
 
 def digest(sd):
@@ -45,7 +62,7 @@ def build(cls, name):
     """seeded construction -> (eval net with perturbed norm affine / bias parameters, digest of the fresh state_dict)"""
     c = CFGS[name]
     torch.manual_seed(c["seed"])
-    net = cls(spatial_dims=3, in_channels=IN_CH[name], out_channels=3, **c["kw"])
+    net = cls(spatial_dims=2 if name in CFGS_2D else 3, in_channels=IN_CH[name], out_channels=3, **c["kw"])
     init = digest(net.state_dict())
     gen = torch.Generator().manual_seed(500 + c["seed"])
     with torch.no_grad():
@@ -65,12 +82,12 @@ def inputs(name):
     return torch.rand(CFGS[name]["shape"], generator=torch.Generator().manual_seed(700 + CFGS[name]["seed"]))
 
 
-def case_dynunet_vs_reference(device, names=tuple(CFGS)):
+def case_dynunet_vs_reference(device, names=tuple(n for n in CFGS if n not in CFGS_2D), golden="dynunet.npz"):
     """DynUNet against the real reference's output (tests/golden/make_golden_dynunet.py): state_dict keys, the same weights from the
     same seed, logits within 1e-4, identical argmax outside near-ties."""
     from monai_amd.networks.nets import DynUNet
 
-    g = np.load(os.path.join(GOLDEN, "dynunet.npz"))
+    g = np.load(os.path.join(GOLDEN, golden))
     out = {}
     for name in names:
         net, init = build(DynUNet, name)
@@ -112,6 +129,23 @@ def case_dynunet_sliding_window(device):
     return out
 
 
+def case_dynunet_2d_vs_reference(device):
+    """2-D DynUNet (the 3-D engine on one plane) and SliceInferer over it, against the real reference (tests/golden/make_golden_dynunet2d.py):
+    state_dict keys, same seed => same weights, logits within 1e-4; SliceInferer(spatial_dim=0) over a 5-slice volume."""
+    from monai_amd.inferers import SliceInferer
+    from monai_amd.networks.nets import DynUNet
+
+    out = case_dynunet_vs_reference(device, names=tuple(CFGS_2D), golden="dynunet2d.npz")
+    g = np.load(os.path.join(GOLDEN, "dynunet2d.npz"))
+    net, _ = build(DynUNet, "2d_basic")
+    y = SliceInferer(**SLICE)(slice_volume().to(device), net.to(device)).cpu()
+    exp = torch.from_numpy(g["2d_basic_slice_out"])
+    assert y.shape == exp.shape, (y.shape, exp.shape)
+    out["slice_inferer"] = (y.double() - exp.double()).abs().max().item()
+    assert out["slice_inferer"] < LOGIT_TOL, out
+    return out
+
+
 def case_dynunet_api(device):
     import pytest
 
@@ -128,7 +162,9 @@ def case_dynunet_api(device):
     with pytest.raises(NotImplementedError):
         DynUNet(3, 1, 2, [3, 3, 3], [1, 2, [2, 2, 1]], [2, 2])        # upsample kernels must equal the strides
     with pytest.raises(NotImplementedError):
-        DynUNet(2, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2])
+        DynUNet(1, 1, 2, K3, [1, 2, 2, 2], [2, 2, 2])
+    with pytest.raises(ValueError):
+        DynUNet(2, 1, 2, [[3, 3, 3]] * 3, [1, 2, 2], [2, 2])             # 3-sequences for a 2-D net
     net = DynUNet(3, 1, 2, [3, 3, 3], [1, 2, 2], [2, 2], filters=[8, 8, 8])
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1, 1, 8, 8, 8, device=device))           # training mode: inference engine only

@@ -83,6 +83,13 @@ def test_dynunet_vs_reference(emu):
     dc.case_dynunet_api("cpu")
 
 
+def test_dynunet_2d_and_slice_inferer_vs_reference(emu):
+    """a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_2d_vs_reference("cpu"))
+
+
 def test_dynunet_sliding_window_vs_reference(emu):
     import dynunet_cases as dc
 

@@ -27,6 +27,13 @@ def test_dynunet_vs_reference():
     dc.case_dynunet_api(DEV)
 
 
+def test_dynunet_2d_and_slice_inferer_vs_reference():
+    """SURVEY 8 row a9 on the MI355X: a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
+    import dynunet_cases as dc
+
+    print("max |dlogit|", dc.case_dynunet_2d_vs_reference(DEV))
+
+
 def test_dynunet_sliding_window_vs_reference():
     import dynunet_cases as dc
 
