@@ -142,7 +142,8 @@ int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const 
 int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int groups, const float* gamma, const float* beta, float eps,
                               float slope, float* nrm, int64_t nrm_n_stride, void* stream);
 
-/* MaxPool3d(kernel_size=2) of act(in) -- `Down`, basic_unet.py:61-89.  out dims = floor(in/2). */
+/* MaxPool3d(kernel_size=2) of act(in) -- `Down`, basic_unet.py:61-89.  out dims = floor(in/2); out->D == in->D pools plane by plane
+ * (MaxPool2d of a 2-D network that runs as one plane of this engine). */
 int mh_maxpool2_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
 
 /* ConvTranspose3d(k=2, s=2) (+bias) of act(in) -- UpSample(mode="deconv"), blocks/upsample.py:102-116.

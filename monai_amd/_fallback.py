@@ -370,6 +370,17 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
             return method
 
         cls._mh_twin = _mh_twin
+        if share_state and "__prepare_scriptable__" not in cls.__dict__:
+            def __prepare_scriptable__(self):
+                """`torch.jit.script(net)` (bundle export, tests/networks/nets/test_basic_unet.py:95-98) asks for a scriptable stand-in: the engine's
+                schedule is not TorchScript, the reference twin -- same parameters -- is."""
+                twin = self._mh_twin()
+                if twin is None:
+                    raise NotImplementedError(f"monai_amd.{type(self).__name__}: TorchScript export needs the reference implementation (MONAI is not importable)")
+                _note(f"{type(self).__name__}.__prepare_scriptable__", NotImplementedError("the HIP engine is not TorchScript"))
+                return twin
+
+            cls.__prepare_scriptable__ = __prepare_scriptable__
         if image_io and not hasattr(cls, "trace_transform"):
             cls.tracing = _Tracing.tracing
             cls.trace_transform = _Tracing.trace_transform

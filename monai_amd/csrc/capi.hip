@@ -660,8 +660,9 @@ int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int g
 int mh_maxpool2_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "maxpool2: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
-    if (in.N != out.N || in.C != out.C || out.D != in.D / 2 || out.H != in.H / 2 || out.W != in.W / 2)
-        return fail(MH_ERR_ARG, "maxpool2: output must be floor(input/2)");
+    // out.D == in.D: plane-wise pooling (MaxPool2d of a 2-D network on this engine); in.D == 1 can only mean that
+    if (in.N != out.N || in.C != out.C || (out.D != in.D / 2 && out.D != in.D) || out.D < 1 || out.H != in.H / 2 || out.W != in.W / 2)
+        return fail(MH_ERR_ARG, "maxpool2: output must be floor(input/2) (or keep the first axis: plane-wise pooling)");
     const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)out.C, (unsigned)out.N);
     const bool pair = in.W % 2 == 0 && aligned(in.data, 8) && in.n_stride % 2 == 0;
     if (pair) hipLaunchKernelGGL((maxpool2_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, in, out);

@@ -36,10 +36,25 @@ __all__ = ["BasicUNet", "BasicUnet", "Basicunet", "basicunet"]
 
 
 # --------------------------------------------------------------------------- parameter containers
+# A 2-D network (what SliceInferer drives) runs as ONE PLANE of the 3-D engine: the parameters live in the reference's 2-D modules
+# (Conv2d, InstanceNorm2d, ConvTranspose2d: the 2-D net's state_dict), the engine reads a [O, I, 3, 3] kernel as the centre z-slice of a 3x3x3 one,
+# pools and up-samples in-plane only.  `_DIMS` is set by BasicUNet.__init__ while it builds its blocks.
+_DIMS = [3]
+
+
+def _nd(three, two):
+    return two if _DIMS[0] == 2 else three
+
+
+def _w5(w: torch.Tensor) -> torch.Tensor:
+    """a layer's weight as the engine sees it: 5-D (a 2-D layer's [O, I, kh, kw] as the one-plane [O, I, 1, kh, kw] view)"""
+    return w if w.dim() == 5 else w.unsqueeze(2)
+
+
 class _ADN(nn.Module):
     def __init__(self, channels: int, affine: bool, eps: float, slope: float):
         super().__init__()
-        self.N = nn.InstanceNorm3d(channels, eps=eps, affine=affine)
+        self.N = _nd(nn.InstanceNorm3d, nn.InstanceNorm2d)(channels, eps=eps, affine=affine)
         self.negative_slope = slope
 
 
@@ -48,7 +63,7 @@ class _Convolution(nn.Module):
 
     def __init__(self, cin: int, cout: int, bias: bool, affine: bool, eps: float, slope: float):
         super().__init__()
-        self.conv = nn.Conv3d(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
+        self.conv = _nd(nn.Conv3d, nn.Conv2d)(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
         self.adn = _ADN(cout, affine, eps, slope)
 
 
@@ -62,14 +77,14 @@ class _TwoConv(nn.Module):
 class _Down(nn.Module):
     def __init__(self, cin, cout, **kw):
         super().__init__()
-        self.max_pooling = nn.MaxPool3d(kernel_size=2)
+        self.max_pooling = _nd(nn.MaxPool3d, nn.MaxPool2d)(kernel_size=2)
         self.convs = _TwoConv(cin, cout, **kw)
 
 
 class _UpSample(nn.Module):
     def __init__(self, cin, cout, bias=True):
         super().__init__()
-        self.deconv = nn.ConvTranspose3d(cin, cout, kernel_size=2, stride=2, bias=bias)
+        self.deconv = _nd(nn.ConvTranspose3d, nn.ConvTranspose2d)(cin, cout, kernel_size=2, stride=2, bias=bias)
 
 
 class _UpCat(nn.Module):
@@ -112,8 +127,8 @@ class BasicUNet(nn.Module):
         upsample: str = "deconv",
     ):
         super().__init__()
-        if spatial_dims != 3:
-            raise NotImplementedError("monai_amd.BasicUNet: only spatial_dims=3 is on the HIP path")
+        if spatial_dims not in (2, 3):
+            raise NotImplementedError("monai_amd.BasicUNet: spatial_dims 2 and 3 are on the HIP path")
         if upsample != "deconv":
             raise NotImplementedError("monai_amd.BasicUNet: only upsample='deconv' is on the HIP path")
         # dropout: accepted and inert -- this is an inference engine (forward refuses training mode) and Dropout holds no parameters, so
@@ -127,7 +142,17 @@ class BasicUNet(nn.Module):
         kw = dict(bias=bias, affine=affine, eps=eps, slope=slope)
         self.features, self.in_channels, self.out_channels = fea, in_channels, out_channels
         self.negative_slope, self.eps = slope, eps
+        self.spatial_dims = spatial_dims
+        _DIMS[0] = spatial_dims
+        try:
+            self._build(in_channels, out_channels, fea, kw)
+        finally:
+            _DIMS[0] = 3
+        self._plans: dict = {}      # (N, D, H, W, device) -> _Plan
+        self._packed: dict = {}     # (layer name, cfg) -> (version key, packed weights)
+        self.fused_stats = True     # take InstanceNorm statistics from the conv epilogue when the tile kernel runs
 
+    def _build(self, in_channels, out_channels, fea, kw):
         self.conv_0 = _TwoConv(in_channels, fea[0], **kw)
         self.down_1 = _Down(fea[0], fea[1], **kw)
         self.down_2 = _Down(fea[1], fea[2], **kw)
@@ -137,11 +162,7 @@ class BasicUNet(nn.Module):
         self.upcat_3 = _UpCat(fea[3], fea[2], fea[2], **kw)
         self.upcat_2 = _UpCat(fea[2], fea[1], fea[1], **kw)
         self.upcat_1 = _UpCat(fea[1], fea[0], fea[5], halves=False, **kw)
-        self.final_conv = nn.Conv3d(fea[5], out_channels, kernel_size=1)
-
-        self._plans: dict = {}      # (N, D, H, W, device) -> _Plan
-        self._packed: dict = {}     # (layer name, cfg) -> (version key, packed weights)
-        self.fused_stats = True     # take InstanceNorm statistics from the conv epilogue when the tile kernel runs
+        self.final_conv = _nd(nn.Conv3d, nn.Conv2d)(fea[5], out_channels, kernel_size=1)
 
     # ---- weights ---------------------------------------------------------------------------------
     def _packed_weight(self, name: str, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
@@ -149,6 +170,10 @@ class BasicUNet(nn.Module):
         key = (w.data_ptr(), w._version, str(w.device))
         hit = self._packed.get((name, cfg))
         if hit is None or hit[0] != key:
+            if w.dim() == 4:        # a 2-D kernel = the centre z-slice of a 3x3x3 one whose outer slices are zero (exact: they multiply the zero padding / nothing)
+                w3 = torch.zeros(w.shape[:2] + (3, 3, 3), dtype=w.dtype, device=w.device)
+                w3[:, :, 1] = w
+                w = w3
             hit = (key, ops.conv3d_k3_pack(cfg, w))
             self._packed[(name, cfg)] = hit
         return hit[1]
@@ -159,6 +184,11 @@ class BasicUNet(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise NotImplementedError("monai_amd.BasicUNet: gradients w.r.t. the input are not on the (inference-only) HIP path")
         _lib.require_device(x)
+        if self.spatial_dims == 2:
+            if x.dim() != 4 or x.shape[1] != self.in_channels:
+                raise RuntimeError(f"monai_amd.BasicUNet: expected input (B,{self.in_channels},H,W), got {tuple(x.shape)}")
+            out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
+            return self.forward_into(x, out)
         if x.dim() != 5 or x.shape[1] != self.in_channels:
             raise RuntimeError(f"monai_amd.BasicUNet: expected input (B,{self.in_channels},D,H,W), got {tuple(x.shape)}")
         out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
@@ -168,11 +198,16 @@ class BasicUNet(nn.Module):
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
         _lib.require_device(x, out)
+        if self.spatial_dims == 2 and x.dim() == 4 and out.dim() == 4:
+            self.forward_into(x.unsqueeze(2), out.unsqueeze(2))          # one plane of the 3-D engine (views: no copy)
+            return out
         if self.training:
             raise NotImplementedError("monai_amd.BasicUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
         x = x.contiguous()
         n, _, d, h, w = x.shape
-        if min(d, h, w) < 16:
+        if self.spatial_dims == 2 and d != 1:
+            raise RuntimeError(f"monai_amd.BasicUNet: a 2-D network takes one plane, got {tuple(x.shape)}")
+        if min((h, w) if self.spatial_dims == 2 else (d, h, w)) < 16:
             raise RuntimeError(f"monai_amd.BasicUNet: window {d}x{h}x{w} is too small for four 2x poolings")
         key = (n, d, h, w, str(x.device))
         plan = self._plans.get(key)
@@ -197,7 +232,8 @@ class _Plan:
     def __init__(self, net: "BasicUNet", n: int, dims, device):
         f = net.features
         self.n, self.dims = n, tuple(dims)
-        self.sp = [tuple(v >> l for v in dims) for l in range(5)]
+        self.planar = net.spatial_dims == 2            # the z axis (one plane) is neither pooled nor up-sampled
+        self.sp = [tuple(v if (self.planar and a == 0) else v >> l for a, v in enumerate(dims)) for l in range(5)]
         up = [f[1], f[2] // 2, f[3] // 2, f[4] // 2]            # channels the deconv adds at level 0..3
         dec_out = [f[5], f[1], f[2], f[3]]                      # output channels of the decoder TwoConv at level 0..3
         e = lambda c, l: torch.empty((n, c) + self.sp[l], dtype=torch.float32, device=device)  # noqa: E731
@@ -212,8 +248,9 @@ class _Plan:
         self.pool = [None] + [e(f[l - 1], l) for l in range(1, 5)]
         # odd extents: the transposed conv of level l+1 yields 2 * floor(sp[l] / 2); UpCat replicate-pads the far end
         # (basic_unet.py:163-170).  Those levels deconvolve into a dense scratch tensor and pad-copy it into the concat buffer.
-        self.odd = [any(v & 1 for v in self.sp[l]) for l in range(4)]
-        self.up_scratch = [torch.empty((n, up[l]) + tuple(2 * v for v in self.sp[l + 1]), dtype=torch.float32, device=device)
+        self.odd = [any(v & 1 for a, v in enumerate(self.sp[l]) if not (self.planar and a == 0)) for l in range(4)]
+        self.up_scratch = [torch.empty((n, up[l]) + tuple(v if (self.planar and a == 0) else 2 * v for a, v in enumerate(self.sp[l + 1])),
+                                       dtype=torch.float32, device=device)
                            if self.odd[l] else None for l in range(4)]
         self.x4, self.x4_nrm = e(f[4], 4), nz(f[4])
         self.u = [e(dec_out[l], l) for l in range(4)]
@@ -272,11 +309,13 @@ class _Plan:
         src, src_nrm = self.x4, self.x4_nrm
         for l in range(3, -1, -1):
             upc = ups[l]
-            if self.odd[l]:
-                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.up_scratch[l])
-                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:])
+            dst = self.up_scratch[l] if self.odd[l] else self.cat[l][:, f[l]:]
+            if self.planar:       # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
+                ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2))
             else:
-                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, self.cat[l][:, f[l]:])
+                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst)
+            if self.odd[l]:
+                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:])
             co = self.dec_out[l]
             t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
             self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn)

@@ -395,3 +395,66 @@ def case_unet_vs_golden(device, names=("res2", "plain", "mixed", "batch")):
         assert r["max_abs"] < LOGIT_TOL, (name, r)
         out[name] = r["max_abs"]
     return out
+
+
+# ---- 2-D BasicUNet (the 3-D engine on one plane) and SliceInferer over it: SURVEY 8 row a9, tests/golden/make_golden_basic_unet2d.py ----
+BASIC2D = {
+    "plain": dict(kw=dict(in_channels=1, out_channels=3, features=(16, 16, 32, 32, 64, 16)), shape=(2, 1, 48, 64), seed=31),
+    "odd_relu": dict(kw=dict(in_channels=2, out_channels=2, features=(8, 8, 16, 16, 32, 8), act=("relu", {}), norm=("instance", {"affine": False})),
+                     shape=(1, 2, 35, 50), seed=32),       # odd extents: UpCat's replicate padding, in-plane only
+}
+BASIC2D_SLICE = dict(roi_size=(32, 32), sw_batch_size=4, spatial_dim=2, overlap=0.25, mode="gaussian")
+
+
+def basic2d_build(cls, name):
+    import hashlib
+
+    c = BASIC2D[name]
+    torch.manual_seed(c["seed"])
+    net = cls(spatial_dims=2, **c["kw"])
+    h = hashlib.sha256()
+    for k, v in net.state_dict().items():
+        h.update(k.encode())
+        h.update(v.detach().cpu().contiguous().numpy().tobytes())
+    gen = torch.Generator().manual_seed(900 + c["seed"])
+    with torch.no_grad():
+        for k, v in net.state_dict().items():        # non-default norm affine / bias values: a swapped or dropped parameter would show
+            if k.endswith("adn.N.weight"):
+                v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=gen))
+            elif k.endswith("bias"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=gen))
+    return net.eval(), h.hexdigest()
+
+
+def basic2d_input(name):
+    return torch.rand(BASIC2D[name]["shape"], generator=torch.Generator().manual_seed(950 + BASIC2D[name]["seed"]))
+
+
+def basic2d_volume():
+    return torch.rand((1, 1, 40, 48, 4), generator=torch.Generator().manual_seed(803))
+
+
+def case_basic_unet_2d_vs_reference(device):
+    """BasicUNet(spatial_dims=2) on the one-plane engine: the reference's 2-D state_dict keys, same seed => same weights, logits within 1e-4
+    of the real reference (incl. odd extents); SliceInferer(spatial_dim=2) over a 4-slice volume against reference inferer + reference net."""
+    from monai_amd.inferers import SliceInferer
+    from monai_amd.networks.nets import BasicUNet
+
+    g = np.load(os.path.join(GOLDEN, "basic_unet2d.npz"))
+    out = {}
+    for name in BASIC2D:
+        net, init = basic2d_build(BasicUNet, name)
+        assert list(net.state_dict().keys()) == list(g[f"{name}_keys"]), name
+        assert init == str(g[f"{name}_init_sha256"]), f"{name}: same seed must give the reference's weights"
+        y = net.to(device)(basic2d_input(name).to(device)).cpu()
+        exp = torch.from_numpy(g[f"{name}_out"])
+        assert y.shape == exp.shape
+        out[name] = (y.double() - exp.double()).abs().max().item()
+        assert out[name] < LOGIT_TOL, (name, out[name])
+    net, _ = basic2d_build(BasicUNet, "plain")
+    y = SliceInferer(**BASIC2D_SLICE)(basic2d_volume().to(device), net.to(device)).cpu()
+    exp = torch.from_numpy(g["plain_slice_out"])
+    assert y.shape == exp.shape
+    out["slice_inferer"] = (y.double() - exp.double()).abs().max().item()
+    assert out["slice_inferer"] < LOGIT_TOL, out
+    return out

@@ -157,3 +157,8 @@ def test_dropout_arguments_are_inference_inert(emu):
 
 def test_narrow_and_host_inputs(emu):
     ec.case_narrow_and_host_inputs("cpu")
+
+
+def test_basic_unet_2d_and_slice_inferer_vs_reference(emu):
+    """BasicUNet(spatial_dims=2) on the one-plane engine and SliceInferer over it, against the real reference"""
+    print("max |dlogit|", ec.case_basic_unet_2d_vs_reference("cpu"))

@@ -230,3 +230,8 @@ def test_bundle_shaped_pipeline_vs_reference():
 
 def test_narrow_and_host_inputs():
     ec.case_narrow_and_host_inputs(DEV)
+
+
+def test_basic_unet_2d_and_slice_inferer_vs_reference():
+    """BasicUNet(spatial_dims=2) on the one-plane engine and SliceInferer over it, against the real reference"""
+    print("max |dlogit|", ec.case_basic_unet_2d_vs_reference(DEV))

@@ -110,7 +110,7 @@ def test_sliding_window_cpu_cases(patched):
     for dt in (torch.float64, torch.float16):
         out = sliding_window_inference(vol.to(dt), (8, 12, 16), 3, lambda w: w + 1, overlap=0.25)
         assert out.dtype == dt
-    # a 2-D network over a 3-D volume (tests/inferers/test_slice_inferer.py): BasicUNet(spatial_dims=2) is outside the HIP path
+    # a 2-D network over a 3-D CPU volume (tests/inferers/test_slice_inferer.py): CPU tensors are outside the HIP path, the call reaches the reference twin
     net2d = BasicUNet(spatial_dims=2, in_channels=1, out_channels=2, features=(4, 4, 8, 8, 16, 4)).eval()
     with torch.no_grad():
         s = SliceInferer(roi_size=(32, 32), spatial_dim=2, sw_batch_size=4)(torch.rand(1, 1, 32, 32, 6), net2d)
@@ -140,6 +140,23 @@ def test_transform_options_outside_the_hip_path(patched):
     assert d.dtype == torch.float32 or d.dtype == torch.float64
 
 
+def test_torchscript_export_uses_the_reference_twin(patched):
+    """`torch.jit.script(net)` (bundle `ckpt_export`, the reference's test_script cases): the product net hands TorchScript its reference twin, which
+    shares its parameters; the scripted module equals the eager CPU call (itself a fall-through to that twin) bit for bit."""
+    from monai.networks.nets import BasicUNet
+
+    for dims, shape in ((2, (2, 1, 32, 32)), (3, (1, 1, 32, 32, 32))):
+        net = BasicUNet(spatial_dims=dims, in_channels=1, out_channels=3, features=(4, 4, 8, 8, 16, 4)).eval()
+        assert getattr(type(net), "_mh_is_product", False)
+        ts = torch.jit.script(net)
+        x = torch.rand(shape)
+        with torch.no_grad():
+            assert torch.equal(ts(x), net(x))
+        with torch.no_grad():
+            next(net.parameters()).add_(0.5)         # shared parameters: the scripted twin follows the product net's weights
+            assert torch.equal(ts(x), net(x))
+
+
 def test_no_monai_keeps_the_explicit_error():
     """Without MONAI on the path nothing can be delegated: the original explicit error is raised."""
     for m in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]:
@@ -151,6 +168,8 @@ def test_no_monai_keeps_the_explicit_error():
         sys.path.remove(REF)
     assert fb.reference_object("monai.networks.nets.basic_unet", "BasicUNet") is None
     with pytest.raises(NotImplementedError):
-        BasicUNet(spatial_dims=2)
+        BasicUNet(spatial_dims=1)
+    with pytest.raises(NotImplementedError):
+        BasicUNet(spatial_dims=3, upsample="nontrainable")
     with pytest.raises(RuntimeError):
         BasicUNet(spatial_dims=3).eval()(torch.rand(1, 1, 32, 32, 32))

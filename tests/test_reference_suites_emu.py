@@ -90,6 +90,14 @@ if os.environ.get("MONAI_AMD_REF_SUITES") == "all":
     MODULES = MODULES + SLOW
 
 
+# Test methods whose meaning does not survive the emulator harness.
+#  test_basic_unet.py::test_script -- `convert_to_torchscript(verify=True)` compares the scripted module with the eager one at atol = 0 on CPU tensors.
+#  `torch.jit.script` of a product net compiles its reference twin (`__prepare_scriptable__`: same parameters); on a real system the eager call on CPU
+#  tensors falls through to that same twin (bit-identical), under this harness a CPU tensor counts as a device tensor and the eager call runs the HIP
+#  engine (2e-6 away).  The scripting itself is exercised by tests/test_fallthrough_with_reference.py::test_torchscript_export_uses_the_reference_twin.
+EMULATOR_ONLY_SKIPS = {"networks/nets/test_basic_unet.py": ("test_script",)}
+
+
 def _monai_importable() -> bool:
     if not os.path.isdir(REF_TESTS):
         return False
@@ -125,7 +133,7 @@ def test_reference_module_passes_with_monai_C_from_this_package(module, needs_la
 
 @pytest.mark.parametrize("module,needs_launches", MODULES, ids=[m for m, _ in MODULES])
 def test_reference_module_passes_over_the_product(module, needs_launches):
-    _run(module, needs_launches, [])
+    _run(module, needs_launches, ["--skip=" + ",".join(EMULATOR_ONLY_SKIPS[module])] if module in EMULATOR_ONLY_SKIPS else [])
 
 
 def _run(module, needs_launches, extra):
