@@ -2,6 +2,8 @@
 reference (tests/golden) and (b) the CPU oracle on bench-shaped windows, plus size-independent properties at the
 full BASELINE.json size."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -232,6 +234,8 @@ def test_narrow_and_host_inputs():
     ec.case_narrow_and_host_inputs(DEV)
 
 
+@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_UNVERIFIED_ON_GPU") != "1",
+                    reason="written after round 2's GPU budget was spent (emulator-verified against the real reference's goldens); tools/gpu_runs/r3_first.sh runs it first thing next round")
 def test_basic_unet_2d_and_slice_inferer_vs_reference():
     """BasicUNet(spatial_dims=2) on the one-plane engine and SliceInferer over it, against the real reference"""
     print("max |dlogit|", ec.case_basic_unet_2d_vs_reference(DEV))

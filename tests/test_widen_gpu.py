@@ -1,6 +1,8 @@
 """-m gpu: the widening rows of SURVEY.md 8(f) added after the last GPU session of round 1 -- the same cases the emulator
 tests run (tests/test_transforms_emu.py, tests/test_e2e_emu.py), here through the real .so on the MI355X.  Kept in a file that
 sorts after the others so that `pytest -x` reaches every test that has already run on the hardware first."""
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -27,6 +29,8 @@ def test_dynunet_vs_reference():
     dc.case_dynunet_api(DEV)
 
 
+@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_UNVERIFIED_ON_GPU") != "1",
+                    reason="written after round 2's GPU budget was spent (emulator-verified against the real reference's goldens); tools/gpu_runs/r3_first.sh runs it first thing next round")
 def test_dynunet_2d_and_slice_inferer_vs_reference():
     """SURVEY 8 row a9 on the MI355X: a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
     import dynunet_cases as dc
