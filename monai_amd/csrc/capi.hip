@@ -665,8 +665,14 @@ int mh_maxpool2_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream)
         return fail(MH_ERR_ARG, "maxpool2: output must be floor(input/2) (or keep the first axis: plane-wise pooling)");
     const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)out.C, (unsigned)out.N);
     const bool pair = in.W % 2 == 0 && aligned(in.data, 8) && in.n_stride % 2 == 0;
-    if (pair) hipLaunchKernelGGL((maxpool2_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
-    else hipLaunchKernelGGL((maxpool2_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    const bool planar = out.D == in.D && out.D != in.D / 2;      // in.D == 1 (a 2-D network's plane): 1 / 2 == 0, so this is unambiguous
+    if (planar) {
+        if (pair) hipLaunchKernelGGL((maxpool2_kernel<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+        else hipLaunchKernelGGL((maxpool2_kernel<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    } else {
+        if (pair) hipLaunchKernelGGL((maxpool2_kernel<true, 2>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+        else hipLaunchKernelGGL((maxpool2_kernel<false, 2>), grid, dim3(256), 0, (hipStream_t)stream, in, out);
+    }
     return launched("maxpool2");
 }
 

@@ -262,10 +262,9 @@ deconv_k3_kernel(Tensor in, const float* __restrict__ w, const float* __restrict
 // ---------------------------------------------------------------------------------------------------
 // MaxPool3d(2) of act(in).  One thread per output voxel; the two x-neighbours come in as one float2.  out.D == in.D: the z axis is not
 // pooled -- MaxPool2d(2) of a 2-D network running as one plane (or a stack of planes) of this engine.
-template <bool PAIR>
+template <bool PAIR, int NZ>       // NZ = 2: MaxPool3d(2); NZ = 1: plane-wise (the z axis is kept)
 __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
     const int Do = out.D, Ho = out.H, Wo = out.W, H = in.H, W = in.W;
-    const int nz = in.D == out.D ? 1 : 2;
     const long long ovol = (long long)Do * Ho * Wo;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y, n = blockIdx.z;
@@ -276,10 +275,11 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
     const float4 a = load_nrm(in, n, c);
     const float* src = in.data + (long long)n * in.n_stride + (long long)c * in.D * H * W;
     float m = -3.402823466e+38f;
-    for (int dz = 0; dz < nz; ++dz)
+#pragma unroll
+    for (int dz = 0; dz < NZ; ++dz)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
-            const float* row = src + ((long long)(nz * zo + dz) * H + (2 * yo + dy)) * W + 2 * xo;
+            const float* row = src + ((long long)(NZ * zo + dz) * H + (2 * yo + dy)) * W + 2 * xo;
             float v0, v1;
             if (PAIR) {
                 const float2 q = *reinterpret_cast<const float2*>(row);
