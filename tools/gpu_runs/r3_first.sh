@@ -1,6 +1,7 @@
 # first GPU call of round 3: what round 2 prepared on the CPU and could not measure any more
 #  1. the transposed convolution as one GEMM on the fp32 matrix cores (kernels/nn_simple.h: deconv_k2s2_mfma_kernel, opt-in): its GPU cases and the
-#     bench line with / without it (the one-voxel kernel is 6.5 % of the step: 0.89 / 2.3 ms per launch at 32 -> 32 ch, VALU-bound)
+#     bench line with / without it (the one-voxel kernel is 6.5 % of the step: 0.89 / 2.3 ms per launch at 32 -> 32 ch; not arithmetic-bound -- it writes at 3.0 TB/s,
+#     profiles/r02_deconv_bench_v1.json: the new form writes complete 256-byte runs)
 #     + the 2-D BasicUNet / DynUNet cases (one plane of the 3-D engine, SliceInferer over them) that were written after the budget was spent
 #  2. the whole -m gpu suite + smoke() on the state the round starts from, the bench line with its kernel trace
 O=gpurun_out/r3first; mkdir -p $O; export TMPDIR=/tmp
