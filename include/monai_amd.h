@@ -27,10 +27,17 @@ extern "C" {
 #define MH_ERR_LAUNCH (-2)
 #define MH_ERR_UNSUPPORTED (-3)
 
-/* Activation tensor view.  `nrm` is NULL or points at one {alpha, beta, slope, 0} float4 per (n, c):
+/* Activation tensor view.  `nrm` is NULL or points at one {alpha, beta, slope, bound} float4 per (n, c):
  * consumers see  y = fma(x, alpha, beta); y = y > 0 ? y : y*slope  (InstanceNorm3d(affine) followed by
  * LeakyReLU -- the ADN("NDA") block of monai/networks/blocks/acti_norm.py:69-101 -- applied on load
- * instead of in a pass of its own).  n_stride / nrm_n_stride are in floats. */
+ * instead of in a pass of its own).  `bound` >= max |y| over the (n, c) plane when the producer of the tensor knows
+ * one, 0 when none is given, inf / NaN when the plane (or its statistics) holds a non-finite value:
+ *   - mh_instnorm_finalize_f32 / mh_groupnorm_finalize_f32 write (|gamma| sqrt(count) + |beta|) max(1, |slope|);
+ *   - on an OUTPUT view of mh_deconv_k2s2_f32 / mh_deconv_ks_f32 / mh_add_act_f32, `nrm` (if not NULL) names identity
+ *     records prepared by mh_nrm_identity_f32; the kernel folds max |value written| into their `bound`;
+ *     mh_maxpool2_f32 / mh_pad_replicate_f32 write {1, 0, 1, bound of their input} into it.
+ * The split-precision convolution (mh_conv3d_k3_h2_config) needs the bounds of its input; nothing else reads them.
+ * n_stride / nrm_n_stride are in floats. */
 typedef struct mh_tensor5 {
     float* data;
     int64_t n_stride;
@@ -95,27 +102,34 @@ int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* s
 /* Conv3d k=3, stride 1, padding 1 (+bias) -- the conv of `Convolution`, blocks/convolutions.py:98-171.
  * Several kernel configurations exist; mh_conv3d_k3_select picks one:
  *   0                      direct VALU kernel, any channel counts
- *   1 .. n-2               fp32-MFMA implicit-GEMM tiles (v_mfma_f32_32x32x2_f32)
- *   n-1                    Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32 (Cin % 4 == 0, Cout % 16 == 0, even extents);
- *                          only selected under MONAI_AMD_CONV_ALGO=winograd
- *   n = num_configs()      Winograd F(2x2, 3x3) in (y, x) + three direct z taps, z-streaming (Cin % 8 == 0, Cout % 16 == 0,
+ *   1 .. n-1               fp32-MFMA implicit-GEMM tiles (v_mfma_f32_32x32x2_f32), exact fp32
+ *   n = num_configs()      Winograd F(2x2, 3x3) in (y, x) + three direct z taps, z-streaming, fp32 (Cin % 8 == 0, Cout % 16 == 0,
  *                          even H, W % 8 == 0); selected for full 16 x 16 regions of planes >= 48^2 with D >= 48
- * (MONAI_AMD_CONV_ALGO = direct | wino2d | winograd pins the family.)  Weights are repacked (Winograd: transformed)
- * once per configuration. */
-int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W);
-int mh_conv3d_k3_num_configs(void);                    /* highest configuration id */
-/* EXPERIMENTAL configuration outside 0 .. num_configs(): direct implicit GEMM on the bf16 matrix cores in 3-piece split
- * precision (fp32-equivalent results: every product is evaluated from six exact bf16 piece products with fp32 accumulation);
- * Cin % 16 == 0, Cout % 32 == 0, D % 4 == 0, H % 8 == 0, W % 8 == 0; selected only under MONAI_AMD_CONV_ALGO=split. */
-int mh_conv3d_k3_split_config(void);
+ *   h2_config()            fp16 matrix cores, two-piece split precision, fp32-equivalent (below)
+ *   c1_config()            one input channel, packed fp32 vector arithmetic (below)
+ * `algo` restricts the choice to an arithmetic family -- it is an ARGUMENT: the library reads no environment variable and keeps
+ * no state, what a call computes depends on its arguments alone.  `input_bounded` != 0 promises that every record of the input
+ * view the convolution will be given carries a magnitude bound (mh_tensor5 above); without it the split-precision
+ * configuration is never returned.  Weights are repacked (Winograd: transformed) once per configuration. */
+#define MH_ALGO_AUTO 0     /* fastest configuration that is fp32-equivalent for the given input: h2 for bounded inputs, fp32 otherwise */
+#define MH_ALGO_DIRECT 1   /* exact-fp32 matrix-core tiles only (no Winograd, no split precision, no one-channel kernel) */
+#define MH_ALGO_WINO2D 2   /* the in-plane Winograd configuration wherever its shape rules allow, fp32 tiles elsewhere */
+#define MH_ALGO_H2 3       /* split precision wherever it fits and the input is bounded, fp32 tiles elsewhere (no Winograd) */
+#define MH_ALGO_FP32 4     /* AUTO among the exact-fp32 kernels (tiles, in-plane Winograd, one-channel kernel) */
+int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, int H, int W);
+int mh_conv3d_k3_num_configs(void);                    /* highest configuration id of the exact-fp32 matrix-core family */
 /* Configuration outside 0 .. num_configs(): z-streaming direct convolution on the fp16 matrix cores in two-piece split
  * precision (kernels/conv3d_h2.h) -- every fp32 operand as hi + lo fp16 pieces, products hi*hi + lo*hi + hi*lo accumulated in
  * fp32: fp32-equivalent results (oracle BasicUNet: max |logit difference| 4e-6, the level of two fp32 summation orders) at 3/16
- * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cout % 32 == 0, W % 4 == 0 and |activated input| < 65504. */
+ * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cout % 32 == 0, W % 4 == 0.  The activated input of sample n is scaled by the
+ * power of two that puts the largest `bound` of its records just below 2^15 (undone exactly in the epilogue), so any finite
+ * magnitude is in range; a record without a bound, or with a non-finite one, makes that sample's output NaN (what the reference
+ * computes behind a normalisation whose statistics are non-finite, and a loud failure for a caller that broke the contract).
+ * With in->nrm == NULL there is nothing to take a scale from: the input is used as it is (|x| must stay below 65504). */
 int mh_conv3d_k3_h2_config(void);
 /* Configuration outside 0 .. num_configs(): ONE input channel (the first layer of the networks), packed fp32 vector arithmetic
  * (kernels/conv3d_c1.h) -- exact fp32 like the matrix-core tiles, bound by writing the result instead of by multiplying a zero-padded
- * channel pair.  Needs Cin == 1, Cout % 8 == 0, W % 4 == 0; chosen by mh_conv3d_k3_select for such layers (MONAI_AMD_C1=0: never). */
+ * channel pair.  Needs Cin == 1, Cout % 8 == 0, W % 4 == 0; chosen by mh_conv3d_k3_select for such layers. */
 int mh_conv3d_k3_c1_config(void);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout);
@@ -131,7 +145,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in, const float* packed_w, const
 /* InstanceNorm3d statistics (nn.InstanceNorm3d(affine=True, eps) via layers/factories.py:228-241):
  * partial {count, mean, M2} records per 4096-element chunk of each (n, c) plane, then a finalize that
  * merges `tiles` records per (n, c) in fp64 and writes the consumer-side float4
- * {alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha, slope, 0} (biased variance). */
+ * {alpha = gamma/sqrt(var+eps), beta = bias - mean*alpha, slope, bound} (biased variance; bound: see mh_tensor5). */
 int mh_instnorm_stat_tiles(int D, int H, int W);
 int mh_instnorm_stats_f32(const mh_tensor5* x, float* stats, void* stream);
 int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const float* gamma, const float* beta,
@@ -141,6 +155,10 @@ int mh_instnorm_finalize_f32(const float* stats, int tiles, int N, int C, const 
  * group's mean / variance with its own gamma / beta.  groups == C is InstanceNorm. */
 int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int groups, const float* gamma, const float* beta, float eps,
                               float slope, float* nrm, int64_t nrm_n_stride, void* stream);
+
+/* Identity records {1, 0, 1, bound = FLT_MIN ("known: nothing written yet")} for N x C channels, nrm_n_stride floats between samples: what a raw
+ * producer's output view must point at so that the kernel can leave max |value| in `bound` (mh_tensor5 above). */
+int mh_nrm_identity_f32(float* nrm, int N, int C, int64_t nrm_n_stride, void* stream);
 
 /* MaxPool3d(kernel_size=2) of act(in) -- `Down`, basic_unet.py:61-89.  out dims = floor(in/2); out->D == in->D pools plane by plane
  * (MaxPool2d of a 2-D network that runs as one plane of this engine). */

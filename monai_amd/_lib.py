@@ -18,7 +18,8 @@ import torch
 from ._fallback import UnsupportedOnDevice
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmonai_amd.so")
+# MONAI_AMD_LIB: another build of the same C ABI (the measurement flavour with A/B knobs, `python -m monai_amd.build --dev`; tools/ only)
+LIB_PATH = os.environ.get("MONAI_AMD_LIB") or os.path.join(_HERE, "csrc", "libmonai_amd.so")
 
 
 class MhTensor5(C.Structure):
@@ -57,8 +58,7 @@ SIGNATURES = {
     "mh_crop_pad_f32": (_I, [_P, _P] + [_I] * 10 + [_F, _P]),
     "mh_sw_blend_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
-    "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I]),
-    "mh_conv3d_k3_split_config": (_I, []),
+    "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mh_conv3d_k3_h2_config": (_I, []),
     "mh_conv3d_k3_c1_config": (_I, []),
     "mh_conv3d_k3_num_configs": (_I, []),
@@ -78,6 +78,7 @@ SIGNATURES = {
     "mh_minmax_workspace_floats": (_L, [_I, _L]),
     "mh_minmax_f32": (_I, [_P, _I, _L, _P, _P, _P]),
     "mh_minmax_scale_f32": (_I, [_P, _P, _I, _L, _P, _I, _F, _F, _I, _F, _P]),
+    "mh_nrm_identity_f32": (_I, [_P, _I, _I, _L, _P]),
     "mh_maxpool2_f32": (_I, [_T, _T, _P]),
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),

@@ -33,15 +33,21 @@ def hipcc() -> str:
     raise RuntimeError("monai_amd.build: hipcc not found (set HIPCC or install ROCm)")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
-        return OUT
-    cmd = [hipcc()] + FLAGS + [SRC, "-o", OUT]
+OUT_DEV = os.path.join(HERE, "csrc", "libmonai_amd_dev.so")
+
+
+def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    """dev=True: the measurement flavour (-DMH_DEV_KNOBS: A/B knobs read from the environment, capi.hip) as libmonai_amd_dev.so --
+    loaded only when MONAI_AMD_LIB names it (tools/); the product library has no knobs."""
+    out = OUT_DEV if dev else OUT
+    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps()):
+        return out
+    cmd = [hipcc()] + FLAGS + (["-DMH_DEV_KNOBS"] if dev else []) + [SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

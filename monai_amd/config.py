@@ -8,3 +8,21 @@ import os
 
 HAS_EXT = True
 USE_COMPILED = HAS_EXT and os.getenv("BUILD_MONAI", "0") == "1"
+
+
+# ---- arithmetic family of the 3x3x3 convolutions (include/monai_amd.h: MH_ALGO_*) ----------------------------------------------
+# The C library takes the family as an ARGUMENT of mh_conv3d_k3_select and keeps no state; this is the host-side switch.
+# `CONV_ALGO` (or the environment variable MONAI_AMD_CONV_ALGO, read at call time while CONV_ALGO is None):
+#   "auto"   fp16 two-piece split precision (fp32-equivalent) for inputs that carry magnitude bounds, exact fp32 otherwise
+#   "fp32"   exact-fp32 kernels only (matrix-core tiles, in-plane Winograd, the one-channel kernel)
+#   "direct" / "wino2d" / "h2"   pin one family (measurements)
+CONV_ALGOS = {"auto": 0, "direct": 1, "wino2d": 2, "h2": 3, "fp32": 4}
+CONV_ALGO = None
+
+
+def conv_algo() -> int:
+    name = CONV_ALGO if CONV_ALGO is not None else os.environ.get("MONAI_AMD_CONV_ALGO", "auto")
+    try:
+        return CONV_ALGOS[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"monai_amd: unknown convolution family {name!r} (one of {sorted(CONV_ALGOS)})") from None

@@ -10,11 +10,7 @@
 #include "kernels/common.h"
 #include "kernels/attention.h"
 #include "kernels/conv3d_mfma.h"
-#include "kernels/conv3d_winograd.h"
-#include "kernels/conv3d_wino2d.h"
 #include "kernels/conv3d_wino2p.h"
-#include "kernels/conv3d_wino2s.h"
-#include "kernels/conv3d_split.h"
 #include "kernels/conv3d_h2.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
@@ -91,8 +87,16 @@ static bool regular_axis(const int32_t* s, int n, int extent, AxisWin& a) {
 static bool regular_grid(RegGrid& g, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int D, int H, int W) {
     return sz && sy && sx && regular_axis(sz, nz, D, g.z) && regular_axis(sy, ny, H, g.y) && regular_axis(sx, nx, W, g.x);
 }
-static int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
+// Development knobs (A/B measurements under tools/): only a library built with -DMH_DEV_KNOBS (python -m monai_amd.build --dev ->
+// libmonai_amd_dev.so, never loaded by the product) reads them from the environment.  The shipped library has no hidden state:
+// every knob is its measured default and what a call computes depends on its arguments alone.
+#ifdef MH_DEV_KNOBS
+static const char* knob_str(const char* name) { return getenv(name); }
+#else
+static inline const char* knob_str(const char*) { return nullptr; }
+#endif
+static int knob_int(const char* name, int dflt) {
+    const char* e = knob_str(name);
     return e && *e ? atoi(e) : dflt;
 }
 
@@ -222,9 +226,9 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
     const bool v4 = W % 4 == 0 && rw % 4 == 0 && window_stride % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16);
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
     RegGrid rg;
-    if (regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W) && env_int("MONAI_AMD_BLEND_LEGACY", 0) == 0) {
-        const int G = env_int("MONAI_AMD_BLEND_G", MH_BLEND_G);
-        const bool nt = env_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
+    if (regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W) && knob_int("MONAI_AMD_BLEND_LEGACY", 0) == 0) {
+        const int G = knob_int("MONAI_AMD_BLEND_G", MH_BLEND_G);
+        const bool nt = knob_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
         for (int k0 = 0; k0 < K; k0 += 8) {
             const int kt = K - k0 < 8 ? K - k0 : 8;
             if (int e = launch_blend_reg<false>(kt, v4, G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, out, K, k0, D, H, W, rd, rh, rw, rg,
@@ -253,7 +257,7 @@ int mh_sw_blend_argmax_f32(const float* logits, int64_t window_stride, const flo
     const bool v4 = W % 4 == 0 && rw % 4 == 0 && window_stride % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) &&
                     aligned(labels, labels_u8 ? 4 : 16);
     const long long total = (long long)D * H * (v4 ? W / 4 : W);
-    const bool nt = env_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
+    const bool nt = knob_int("MONAI_AMD_BLEND_NT", MH_BLEND_NT) != 0;
     if (int e = launch_blend_reg<true>(K < 8 ? K : 8, v4, MH_BLEND_G, nt, blocks_for(total), (hipStream_t)stream, logits, imp, labels, K, 0, D, H, W, rd, rh,
                                        rw, rg, premultiplied ? 1 : 0, labels_u8 ? 1 : 0, window_stride))
         return e;
@@ -292,44 +296,23 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int cin_padded(int cfg, int Cin) { return cfg == 0 ? Cin : cdiv(Cin, kCfg[cfg].cc) * kCfg[cfg].cc; }
 static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv(Cout, kCfg[cfg].cn) * kCfg[cfg].cn; }
 
-// configuration MH_CFG_WINOGRAD: Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32 (kernels/conv3d_winograd.h)
-#define MH_CFG_WINOGRAD (MH_NUM_CFG + 1)
-static inline int winograd_regions(int D, int H, int W) { return cdiv(W, WG_OX) * cdiv(H, WG_OY) * cdiv(D, WG_OZ); }
-// MONAI_AMD_CONV_ALGO = direct | winograd | wino2d | split | h2 | fp32 | auto (default): restricts what mh_conv3d_k3_select may return
-static int conv_algo_mode() {
-    const char* e = getenv("MONAI_AMD_CONV_ALGO");
-    if (!e) return 0;
-    if (!strcmp(e, "direct")) return 1;
-    if (!strcmp(e, "winograd")) return 2;
-    if (!strcmp(e, "wino2d")) return 3;
-    if (!strcmp(e, "split")) return 4;
-    if (!strcmp(e, "h2")) return 5;
-    if (!strcmp(e, "fp32")) return 6;        // auto among the exact fp32 kernels only (no split precision)
-    return 0;
-}
-
-// configuration MH_CFG_WINO2D: Winograd F(2x2, 3x3) in-plane + three direct z taps, z-streaming (kernels/conv3d_wino2d.h)
-#define MH_CFG_WINO2D (MH_NUM_CFG + 2)
-// configuration MH_CFG_SPLIT: direct implicit GEMM on the bf16 matrix cores in 3-piece split precision (kernels/conv3d_split.h);
-// experimental, not counted by mh_conv3d_k3_num_configs, selected only under MONAI_AMD_CONV_ALGO=split
-#define MH_CFG_SPLIT (MH_NUM_CFG + 3)
+// configuration MH_CFG_WINO2D: Winograd F(2x2, 3x3) in-plane + three direct z taps, z-streaming (kernels/conv3d_wino2p.h)
+#define MH_CFG_WINO2D (MH_NUM_CFG + 1)
 // configuration MH_CFG_H2: z-streaming direct convolution on the fp16 matrix cores in two-piece split precision, fp32-equivalent
 // results (kernels/conv3d_h2.h); not counted by mh_conv3d_k3_num_configs (its tolerance class differs from the exact fp32 tiles)
-#define MH_CFG_H2 (MH_NUM_CFG + 4)
+#define MH_CFG_H2 (MH_NUM_CFG + 2)
 // configuration MH_CFG_C1: one input channel (the first layer of every network), packed fp32 VALU, write-bound (kernels/conv3d_c1.h);
 // exact fp32 like the tiles of 1 .. MH_NUM_CFG, not counted by mh_conv3d_k3_num_configs
-#define MH_CFG_C1 (MH_NUM_CFG + 5)
+#define MH_CFG_C1 (MH_NUM_CFG + 3)
 // z-chunks of the one-channel kernel: a pure function of D (the statistics record count depends on it); 24-plane marches keep
 // 64 windows of 96^3 at nine whole rounds of the chip's 2048 resident waves
 static inline int c1_chunks(int D) { return D >= 48 ? D / 24 : 1; }
 static inline int c1_zchunk(int D) { return cdiv(D, c1_chunks(D)); }
 static inline int c1_blocks(int D, int H, int W) { return cdiv(W, C1_TX) * cdiv(H, C1_TY) * cdiv(D, c1_zchunk(D)); }
-// z-tiles (of 4 planes) a workgroup of the split-precision kernel marches through: a pure function of D
-static inline int split_ztiles(int D) { const int t = D / SP_TZ; return t % 4 == 0 ? 4 : t % 3 == 0 ? 3 : t % 2 == 0 ? 2 : 1; }
 // z-chunks of the streaming kernel: a pure function of the extents (the statistics record count depends on it)
 static inline int wino2d_chunks(int D, int H, int W) {
     const int blocks = cdiv(W, W2_B) * cdiv(H, W2_B);
-    if (const char* e = getenv("MONAI_AMD_W2_CHUNKS")) {          // tuning knob (development)
+    if (const char* e = knob_str("MONAI_AMD_W2_CHUNKS")) {          // tuning knob (development)
         const int v = atoi(e);
         if (v >= 1 && v <= D) return v;
     }
@@ -344,15 +327,12 @@ static inline int wino2d_zchunk(int D, int H, int W) { return cdiv(D, wino2d_chu
 static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cdiv(H, W2_B) * cdiv(D, wino2d_zchunk(D, H, W)); }
 
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
-int mh_conv3d_k3_split_config(void) { return MH_CFG_SPLIT; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
-    if (cfg == MH_CFG_WINOGRAD) return Cin >= WG_KC && Cin % WG_KC == 0 && Cout >= WG_CN && Cout % WG_CN == 0;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
-    if (cfg == MH_CFG_SPLIT) return Cin >= SP_CC && Cin % SP_CC == 0 && Cin <= SP_NRM_MAX && Cout >= SP_CN && Cout % SP_CN == 0;
     if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
@@ -361,8 +341,9 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
 
 // Heuristic choice: the configuration that wastes the least matrix work -- masked voxels of partial tiles and
 // zero-padded input channels both count -- preferring the wider cout tile, then the measured preference.
-int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
+int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, int H, int W) {
     if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "conv3d_k3_select: bad argument");
+    if (algo < MH_ALGO_AUTO || algo > MH_ALGO_FP32) return fail(MH_ERR_ARG, "conv3d_k3_select: unknown algorithm family %d", algo);
     int best = 0;
     double best_score = 0.0;
     for (int c = 1; c <= MH_NUM_CFG; ++c) {
@@ -373,33 +354,28 @@ int mh_conv3d_k3_select(int Cin, int Cout, int D, int H, int W) {
         const double score = util * cpad * (1.0 + 0.02 * (k.cn / 32)) * kPref[c];
         if (score > best_score) { best_score = score; best = c; }
     }
-    // 3-D Winograd: 3.375x fewer matrix-core cycles, but with its 256 accumulation registers it runs one wave per SIMD and is
-    // issue-bound: measured at parity with the direct tiles (profiles/), so it is opt-in (MONAI_AMD_CONV_ALGO=winograd).
-    const int mode = conv_algo_mode();
-    if (mode == 2 && mh_conv3d_k3_accepts(MH_CFG_WINOGRAD, Cin, Cout) && D % 2 == 0 && H % 2 == 0 && W % 2 == 0) best = MH_CFG_WINOGRAD;
     // in-plane Winograd, z-streaming: 2.25x fewer matrix-core cycles.  On gfx950 the fp32 MFMA does not co-issue with VALU
     // work of the same wave (tools/ubench/issue.hip), so its transforms are paid for serially: measured 1.11-1.13x over the
     // best direct tile at 96^3, 1.04x at 48^3, slower below (profiles/) -- chosen for full 16 x 16 regions of large planes.
     if (mh_conv3d_k3_accepts(MH_CFG_WINO2D, Cin, Cout) && H % 2 == 0 && W % 8 == 0) {
         const bool big = H % W2_B == 0 && W % W2_B == 0 && D >= 48 && H >= 48 && W >= 48;
-        if (mode == 3 || ((mode == 0 || mode == 6) && big)) best = MH_CFG_WINO2D;
+        if (algo == MH_ALGO_WINO2D || ((algo == MH_ALGO_AUTO || algo == MH_ALGO_FP32) && big)) best = MH_CFG_WINO2D;
     }
-    if (mode == 4 && mh_conv3d_k3_accepts(MH_CFG_SPLIT, Cin, Cout) && D % SP_TZ == 0 && H % SP_TY == 0 && W % SP_TX == 0) best = MH_CFG_SPLIT;
     // fp16 two-piece split precision on the fp16 matrix cores: fp32-equivalent results (the oracle network's logits move by 4e-6,
     // the level of two fp32 summation orders) at 1.8-2.1x the speed of the kernels above on every level it takes (96^3 ... 12^3,
-    // profiles/r02_h2_vs_wino2p_*.json) -- the default wherever the shape fits; MONAI_AMD_CONV_ALGO=fp32 keeps the exact fp32 kernels
-    if ((mode == 0 || mode == 5) && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8) best = MH_CFG_H2;
+    // profiles/r02_h2_vs_wino2p_*.json).  It scales its input into fp16's range by a power of two taken from the bounds the input
+    // records carry (kernels/conv3d_h2.h), so it is chosen -- also under MH_ALGO_H2 -- only for inputs that carry them
+    // (`input_bounded`); anything else gets the exact fp32 kernels.
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8)
+        best = MH_CFG_H2;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
-    // (MONAI_AMD_C1=0 keeps the tile: development / A-B measurements)
-    if ((mode == 0 || mode == 5 || mode == 6) && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && env_int("MONAI_AMD_C1", 1) != 0)
+    if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
         best = MH_CFG_C1;
     return best;
 }
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
-    if (cfg == MH_CFG_WINOGRAD) return (int64_t)Cin * Cout * 64;
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
-    if (cfg == MH_CFG_SPLIT) return (int64_t)Cin * Cout * 27 * SP_NP / 2;      // three bf16 pieces per weight
     if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
@@ -407,22 +383,12 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
 }
 
 int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* packed, void* stream) {
-    if (cfg == MH_CFG_WINOGRAD) {
-        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0");
-        hipLaunchKernelGGL(conv3d_k3_winograd_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
-        return launched("conv3d_k3_winograd_pack");
-    }
     if (cfg == MH_CFG_WINO2D) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0");
         if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)mh_conv3d_k3_packed_floats(cfg, Cin, Cout), (hipStream_t)stream) != hipSuccess)
             return fail(MH_ERR_LAUNCH, "conv3d_k3_pack: memset failed");
         hipLaunchKernelGGL(conv3d_k3_wino2d_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
         return launched("conv3d_k3_wino2d_pack");
-    }
-    if (cfg == MH_CFG_SPLIT) {
-        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the split-precision kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
-        hipLaunchKernelGGL(conv3d_k3_split_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, reinterpret_cast<__bf16*>(packed));
-        return launched("conv3d_k3_split_pack");
     }
     if (cfg == MH_CFG_H2) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
@@ -449,9 +415,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 }
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
-    if (cfg == MH_CFG_WINOGRAD) return winograd_regions(D, H, W);
     if (cfg == MH_CFG_WINO2D || cfg == MH_CFG_H2) return wino2d_blocks(D, H, W);
-    if (cfg == MH_CFG_SPLIT) return cdiv(W, SP_TX) * cdiv(H, SP_TY) * cdiv(D, SP_TZ * split_ztiles(D));
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
@@ -483,19 +447,14 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(in.data, 16) || in.n_stride % 4 || !aligned(packed_w, 4))
             return fail(MH_ERR_ARG, "conv3d_k3: the one-channel kernel needs 16-byte aligned input and output");
         const int txn = cdiv(out.W, C1_TX), tyn = cdiv(out.H, C1_TY), zc = c1_zchunk(out.D);
-        // 16 output channels per thread halve the input reads and the tap loop's overhead per output; 8 write half as many channel planes at once
-        // and need 180 instead of 256 registers (MONAI_AMD_C1_COT=8: A/B measurement, tools/gpu_runs/r3_first.sh)
-        const int cot = out.C % 16 == 0 && env_int("MONAI_AMD_C1_COT", 16) != 8 ? 16 : 8;
+        // 8 output channels per thread: 92 registers, no scratch, 1.54 ms per 64 windows of 1 -> 32 ch @ 96^3 (16 per thread halve the input
+        // reads but need 128 registers + 36 bytes of scratch: 1.86 ms; gpurun_out/r3first -> profiles/r03_c1_cot_ab.txt)
+        constexpr int cot = 8;
         const dim3 grid((unsigned)(txn * tyn * cdiv(out.D, zc)), (unsigned)(out.C / cot), (unsigned)out.N);
-#define MH_C1_LAUNCH(COT_)                                                                                                                    \
-    {                                                                                                                                         \
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);   \
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);       \
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);      \
-        else hipLaunchKernelGGL((conv3d_k3_c1_kernel<COT_, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);                 \
-    }
-        if (cot == 16) MH_C1_LAUNCH(16) else MH_C1_LAUNCH(8)
-#undef MH_C1_LAUNCH
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
+        else hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         return launched("conv3d_k3_c1");
     }
     if (cfg == MH_CFG_H2) {
@@ -522,30 +481,6 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
 #undef MH_H2_LAUNCH
         return launched("conv3d_k3_h2");
     }
-    if (cfg == MH_CFG_SPLIT) {
-        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % SP_TZ || in.H % SP_TY || in.W % SP_TX)
-            return fail(MH_ERR_ARG, "conv3d_k3: the split-precision kernel needs Cin %% 16 == 0, Cout %% 32 == 0, D %% 4 == 0, H %% 8 == 0, W %% 8 == 0 (got %d -> %d, %dx%dx%d)",
-                        in.C, out.C, in.D, in.H, in.W);
-        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
-            return fail(MH_ERR_ARG, "conv3d_k3: the split-precision kernel needs 16-byte aligned output and weights");
-        const int bxn = out.W / SP_TX, byn = out.H / SP_TY;
-        const int zt = split_ztiles(out.D);
-        const unsigned nblk = (unsigned)(bxn * byn * (out.D / (SP_TZ * zt)));
-        const long long total = (long long)nblk * (out.C / SP_CN) * out.N;
-        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
-        const dim3 grid((unsigned)total);
-        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
-#define MH_SPLIT_LAUNCH(T_)                                                                                                                          \
-    {                                                                                                                                                \
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_split_kernel<true, true, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);   \
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_split_kernel<true, false, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);       \
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_split_kernel<false, true, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);      \
-        else hipLaunchKernelGGL((conv3d_k3_split_kernel<false, false, T_>), grid, dim3(256), 0, s, in, wq, bias, out, stats, bxn, byn, nblk);                 \
-    }
-        if (zt == 4) MH_SPLIT_LAUNCH(4) else if (zt == 3) MH_SPLIT_LAUNCH(3) else if (zt == 2) MH_SPLIT_LAUNCH(2) else MH_SPLIT_LAUNCH(1)
-#undef MH_SPLIT_LAUNCH
-        return launched("conv3d_k3_split");
-    }
     if (cfg == MH_CFG_WINO2D) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.H % 2 || in.W % 8)
             return fail(MH_ERR_ARG, "conv3d_k3: in-plane Winograd needs Cin %% 8 == 0, Cout %% 16 == 0, even H and W %% 8 == 0 (got %d -> %d, %dx%dx%d)",
@@ -557,42 +492,13 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const long long total = (long long)nblk * (out.C / W2_CN) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
-        // three implementations of the same configuration (same packing, statistics records and launch geometry, bit-identical
-        // convolution values), MONAI_AMD_W2_IMPL = p | s | d (measured at 32 -> 32 ch, 96^3, 64 windows: profiles/r02_wino2_impls.json):
-        //   p (default) conv3d_wino2p.h -- two 256-register waves per SIMD, the Winograd positions split over the pair: 17.7-17.9 ms
-        //   s           conv3d_wino2s.h -- one matrix wave + one staging wave per SIMD: 18.8 ms (a staging wave gets one VALU
-        //                                  instruction per gap of the matrix wave's MFMA stream: it becomes the critical path)
-        //   d           conv3d_wino2d.h -- round 1, one 384-register wave per SIMD: 18.7-18.9 ms
-        const char* impl = getenv("MONAI_AMD_W2_IMPL");
-        if (impl && impl[0] == 's') {        // conv3d_wino2s.h: one matrix wave + one staging wave per SIMD
-            if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else hipLaunchKernelGGL((conv3d_k3_wino2s_kernel<false, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            return launched("conv3d_k3_wino2s");
-        }
-        if (!impl || impl[0] != 'd') {
-            if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            else hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-            return launched("conv3d_k3_wino2p");
-        }
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<true, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-        else hipLaunchKernelGGL((conv3d_k3_wino2d_kernel<false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
-        return launched("conv3d_k3_wino2d");
-    }
-    if (cfg == MH_CFG_WINOGRAD) {
-        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.D % 2 || in.H % 2 || in.W % 2)
-            return fail(MH_ERR_ARG, "conv3d_k3: Winograd needs Cin %% 4 == 0, Cout %% 16 == 0 and even extents (got %d -> %d, %dx%dx%d)", in.C,
-                        out.C, in.D, in.H, in.W);
-        const int rx = cdiv(out.W, WG_OX), ry = cdiv(out.H, WG_OY), rz = cdiv(out.D, WG_OZ);
-        const dim3 grid((unsigned)(rx * ry * rz), (unsigned)(out.C / WG_CN), (unsigned)out.N);
-        if (stats) hipLaunchKernelGGL((conv3d_k3_winograd_kernel<true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, rx, ry, rz);
-        else hipLaunchKernelGGL((conv3d_k3_winograd_kernel<false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, rx, ry, rz);
-        return launched("conv3d_k3_winograd");
+        // conv3d_wino2p.h: two 256-register waves per SIMD, the Winograd positions split over the pair (17.7-17.9 ms for 32 -> 32 ch @ 96^3 x 64 windows;
+        // the one-wave form of round 1 and the matrix-wave + staging-wave form measured 18.7-18.9 ms, profiles/r02_wino2_impls.json, and were removed)
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<true, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, true>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        else hipLaunchKernelGGL((conv3d_k3_wino2p_kernel<false, false>), grid, dim3(512), 0, s, in, packed_w, bias, out, stats, bxn, byn, zc, nblk);
+        return launched("conv3d_k3_wino2p");
     }
     if (cfg == 0) {
         if (stats) return fail(MH_ERR_ARG, "conv3d_k3: the direct kernel emits no statistics");
@@ -657,8 +563,17 @@ int mh_groupnorm_finalize_f32(const float* stats, int tiles, int N, int C, int g
 }
 
 // ------------------------------------------------------------------------------------------ pool / deconv / 1x1
+int mh_nrm_identity_f32(float* nrm, int N, int C, int64_t nrm_n_stride, void* stream) {
+    if (!nrm || N < 1 || C < 1 || nrm_n_stride < 4LL * C || nrm_n_stride % 4 || !aligned(nrm, 16)) return fail(MH_ERR_ARG, "nrm_identity: bad argument");
+    hipLaunchKernelGGL(nrm_identity_kernel, dim3(blocks_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, nrm, N, C, (long long)nrm_n_stride);
+    return launched("nrm_identity");
+}
+// records an output view names (magnitude bounds, kernels/common.h) are written as float4 / by atomics
+static bool out_records_ok(const mh_tensor5* t) { return !t->nrm || (aligned(t->nrm, 16) && t->nrm_n_stride % 4 == 0 && t->nrm_n_stride >= 4LL * t->C); }
+
 int mh_maxpool2_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "maxpool2: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "maxpool2: the output view's records must be 16-byte aligned [N][>= C][4] floats");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     // out.D == in.D: plane-wise pooling (MaxPool2d of a 2-D network on this engine); in.D == 1 can only mean that
     if (in.N != out.N || in.C != out.C || (out.D != in.D / 2 && out.D != in.D) || out.D < 1 || out.H != in.H / 2 || out.W != in.W / 2)
@@ -678,30 +593,12 @@ int mh_maxpool2_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream)
 
 int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_) || !w) return fail(MH_ERR_ARG, "deconv_k2s2: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "deconv_k2s2: the output view's records must be 16-byte aligned [N][>= C][4] floats");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || out.D != 2 * in.D || out.H != 2 * in.H || out.W != 2 * in.W)
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
     const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
-    // the same op as one GEMM on the fp32 matrix cores (kernels/nn_simple.h: deconv_k2s2_mfma_kernel): opt-in until it has been measured
-    const char* impl = getenv("MONAI_AMD_DECONV_IMPL");
-    if (impl && !strcmp(impl, "mfma") && in.W % 4 == 0 && out.C % 4 == 0 && aligned(out.data, 16) && out.n_stride % 4 == 0 &&
-        (in.C == 32 || in.C == 64 || in.C == 128 || in.C == 256) && (!in.nrm || aligned(in.nrm, 16)) && in.nrm_n_stride % 4 == 0 && fits_i32((long long)in.D * in.H * in.W + 256)) {
-        const dim3 g(blocks_for(2LL * in.D * in.H * in.W), (unsigned)out.N);      // 128 voxels (four 32-voxel wave tiles) per workgroup
-#define MH_DECONV_MFMA(KS_)                                                                                                              \
-    {                                                                                                                                        \
-        if (in.nrm) hipLaunchKernelGGL((deconv_k2s2_mfma_kernel<KS_, true>), g, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);        \
-        else hipLaunchKernelGGL((deconv_k2s2_mfma_kernel<KS_, false>), g, dim3(256), 0, (hipStream_t)stream, in, w, bias, out);              \
-    }
-        switch (in.C) {
-            case 32: MH_DECONV_MFMA(16) break;
-            case 64: MH_DECONV_MFMA(32) break;
-            case 128: MH_DECONV_MFMA(64) break;
-            default: MH_DECONV_MFMA(128) break;
-        }
-#undef MH_DECONV_MFMA
-        return launched("deconv_k2s2");
-    }
     if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
@@ -763,7 +660,7 @@ template <typename K> static int resident_wgs(K kernel, int threads) {
 // resident slots -- the last, partly filled round of a 2.1-round launch takes as long as a full one -- discounted by the
 // `prime` extra planes every chunk has to read before its first output.  Chunks keep >= min_chunk output planes.
 static int stream_chunks(long long units, int Do, int slots, int prime, int min_chunk, const char* env_knob) {
-    if (const char* e = getenv(env_knob)) {                          // tuning knob (development)
+    if (const char* e = knob_str(env_knob)) {                          // tuning knob (development)
         const int v = atoi(e);
         if (v >= 1 && v <= Do) return v;
     }
@@ -809,7 +706,7 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
             // fp32 interpolation: 512 threads per workgroup (two output rows per thread instead of four, twice the waves in flight):
             // 0.253-0.267 vs 0.291-0.305 ms per 512^3 volume; fp64 interpolation (the reference default) measures the same either
             // way (0.277-0.299 ms) and keeps 256.  MONAI_AMD_RS_THREADS=256|512 overrides.
-            const bool wide = env_int("MONAI_AMD_RS_THREADS", compute_f64 ? 256 : 512) != 256;
+            const bool wide = knob_int("MONAI_AMD_RS_THREADS", compute_f64 ? 256 : 512) != 256;
             static int slots[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};     // [wide][f64][small]
             int& sl = slots[wide ? 1 : 0][compute_f64 ? 1 : 0][small ? 1 : 0];
 #define MH_RS_STREAM(T_, NL_, NT_, TAB_) hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk)
@@ -854,7 +751,7 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
     }
     // general (rotated / sheared) matrices without reflection: the row-mapped kernel with compile-time mode and padding rule
     // (bit-identical to affine_resample_kernel; MONAI_AMD_RS_GENERAL=linear keeps the linear-index kernel: A/B measurements)
-    const char* rs_general = getenv("MONAI_AMD_RS_GENERAL");
+    const char* rs_general = knob_str("MONAI_AMD_RS_GENERAL");
     const bool rows_on = !(rs_general && !strcmp(rs_general, "linear"));
     if (rows_on && i32 && pad != RS_REFLECTION && Do <= 65535 && cdiv(Ho, 4) <= 65535) {
         const dim3 g((unsigned)cdiv(Wo, 64), (unsigned)cdiv(Ho, 4), (unsigned)Do);
@@ -1174,7 +1071,7 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     hipStream_t s = (hipStream_t)stream;
     // float4-aligned volumes and up to 17 taps: the row-vector kernel (gaussian.h: 16-byte loads / stores, register x-pass, one barrier
     // per plane); MONAI_AMD_GS_IMPL=tile forces the round-1 tile kernel (bit-identical results)
-    const char* impl = getenv("MONAI_AMD_GS_IMPL");
+    const char* impl = knob_str("MONAI_AMD_GS_IMPL");
     if (rk <= 17 && W % 4 == 0 && aligned(src, 16) && aligned(dst, 16) && !(impl && impl[0] == 't')) {
         const long long vtiles = (long long)cdiv(W, GV_TX) * cdiv(H, GV_TY);
         static int vslots[4][2];
@@ -1250,6 +1147,7 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
 // ------------------------------------------------------------------------------------------ UNETR pieces
 int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, const mh_tensor5* out_, void* stream) {
     if (!dense_ok(a_) || (b_ && !dense_ok(b_)) || !dense_ok(out_)) return fail(MH_ERR_ARG, "add_act: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "add_act: the output view's records must be 16-byte aligned [N][>= C][4] floats");
     Tensor bnull = from_c(*a_);
     bnull.data = nullptr; bnull.nrm = nullptr;
     const Tensor a = from_c(*a_), b = b_ ? from_c(*b_) : bnull, out = from_c(*out_);
@@ -1267,6 +1165,7 @@ int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, cons
 
 int mh_pad_replicate_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "pad_replicate: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "pad_replicate: the output view's records must be 16-byte aligned [N][>= C][4] floats");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.C != out.C || out.D < in.D || out.H < in.H || out.W < in.W || out.D > in.D + 1 || out.H > in.H + 1 || out.W > in.W + 1)
         return fail(MH_ERR_ARG, "pad_replicate: output extents must be the input's plus 0 or 1");
@@ -1398,6 +1297,7 @@ int mh_conv3d_k3_strided3_f32(const mh_tensor5* in_, const float* packed_w, cons
 int mh_deconv_ks_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, int fz, int fy, int fx, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_) || !w || fz < 1 || fz > 2 || fy < 1 || fy > 2 || fx < 1 || fx > 2)
         return fail(MH_ERR_ARG, "deconv_ks: bad argument (factors are 1 or 2 per axis)");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "deconv_ks: the output view's records must be 16-byte aligned [N][>= C][4] floats");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || out.D != fz * in.D || out.H != fy * in.H || out.W != fx * in.W) return fail(MH_ERR_ARG, "deconv_ks: output must be factor * input");
     const unsigned nb = blocks_for((long long)out.D * out.H * out.W);

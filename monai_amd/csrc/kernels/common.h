@@ -21,9 +21,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Activation tensor view, NCDHW fp32: W contiguous, H stride W, D stride H*W, C stride D*H*W, batch
 // stride free (so a view can be a channel range of a wider buffer, e.g. one half of a concat buffer).
-// `nrm` (may be null) holds one float4 {alpha, beta, slope, 0} per (n, c): the value a consumer must
+// `nrm` (may be null) holds one float4 {alpha, beta, slope, bound} per (n, c): the value a consumer must
 // see is  y = fma(x, alpha, beta);  y = y > 0 ? y : y * slope  -- i.e. InstanceNorm(affine) followed
 // by LeakyReLU, deferred from the producer to the consumer's load (alpha=1, beta=0, slope=1: identity).
+// `bound` >= max |y| over the (n, c) plane when the producer knows one (0 = none given; NaN / inf = the plane holds,
+// or its statistics were, non-finite): the split-precision convolution scales its input by a power of two taken from it.
 struct Tensor {
     float* data;
     long long n_stride;
@@ -47,6 +49,31 @@ __device__ __forceinline__ float act(float x, float alpha, float beta, float slo
 __device__ __forceinline__ float4 load_nrm(const Tensor& t, int n, int c) {
     if (t.nrm == nullptr) return make_float4(1.0f, 0.0f, 1.0f, 0.0f);
     return *reinterpret_cast<const float4*>(t.nrm + (long long)n * t.nrm_n_stride + 4LL * c);
+}
+
+// ---- magnitude bounds of raw (identity-record) tensors --------------------------------------------------------------
+// A producer that writes a raw tensor whose consumer may be the split-precision convolution leaves max |value| per
+// (n, c) in the 4th float of the tensor's identity record {1, 0, 1, bound}: nrm_identity_kernel resets the records
+// (bound = FLT_MIN: "known, all zero so far"), every wave of the producer folds its values with ONE integer atomicMax
+// on the bit pattern of |v| -- the order of non-negative floats is the order of their bits, and inf / NaN sort above
+// every finite value, so a non-finite element poisons the bound instead of vanishing in an fmax.
+constexpr float MH_BOUND_FLOOR = 1.17549435e-38f;      // FLT_MIN
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned wave_umax(unsigned m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = (unsigned)__shfl_xor((int)m, o);
+        m = t > m ? t : m;
+    }
+    return m;
+}
+// the whole wave calls this (all lanes active or idle lanes passing 0); slot = &record[3]
+__device__ __forceinline__ void bound_commit(unsigned m, float* slot) {
+    m = wave_umax(m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(reinterpret_cast<unsigned*>(slot), m);
+}
+__device__ __forceinline__ float* bound_slot(const Tensor& t, int n, int c) {
+    return const_cast<float*>(t.nrm) + (long long)n * t.nrm_n_stride + 4LL * c + 3;
 }
 
 // Statistics record used for instance norm: element count, mean, and M2 = sum (x - mean)^2.

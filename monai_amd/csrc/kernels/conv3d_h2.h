@@ -13,7 +13,17 @@
 // profiles/r02_ubench_mfma_f16.txt), so unscaled low pieces lose nothing that matters.  Measured on the oracle network
 // (tools/split_precision_numerics.py, BasicUNet, 2 x 64^3): max |logit difference| 4.0e-6 and identical argmax -- the noise
 // level of two fp32 summation orders (3.6e-6); bf16 pieces need three pieces and six products for the same (conv3d_split.h).
-// Range: |activated input| must stay below 65504 (fp16); InstanceNorm-ed inputs are bounded by sqrt(voxels) * |gamma| + |beta|.
+// Range.  fp16 pieces need |activated input| < 65504 and lose their low piece below 2^-24, so the kernel does not take the
+// input as it comes: every input record carries a bound on |activated value| over its (n, c) plane (common.h -- sqrt(count) *
+// |gamma| + |beta| from the InstanceNorm / GroupNorm finalize, max |value| from the raw producers), the workgroup takes the
+// power of two 2^s that puts the largest bound of sample n just below 2^15, multiplies the activated input by it (folded into
+// the LeakyReLU select: no extra instruction) and the epilogue scales back by 2^-s together with the weight scale -- all exact.
+// Any finite magnitude is therefore in range, and small-magnitude tensors keep fp32-equivalent relative precision.  A bound
+// that is inf / NaN (the input plane or its statistics hold a non-finite value) or 0 (none given: a caller that selected this
+// kernel for an unbounded input) makes the sample's whole output NaN: after a normalisation that is exactly what the reference
+// computes (the statistics of such a plane are NaN, so is every normalised value and every sum that contains one), and for
+// unbounded callers it is a loud failure instead of a silent overflow.  mh_conv3d_k3_select only returns this configuration
+// for inputs that carry bounds.
 //
 // Mapping.  GEMM M = output voxels, N = 32 output channels, K = 16 input channels per instruction, one instruction group per tap.
 // A workgroup = 8 waves owns a 16 x 16 (y, x) region x 32 couts x one z-chunk and marches along z: input plane p is
@@ -79,6 +89,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     __shared__ float nrm_s[NRM ? 3 * H2_NRM_MAX : 1];
     uint4* const xs = smem;
     uint4* const ws = smem + 2 * H2_XB;
+    unsigned* const bound_s = reinterpret_cast<unsigned*>(ws);      // 8 words of the (not yet loaded) weight buffer: all 160 KB of LDS are taken
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = in.C, Cout = out.C, D = out.D, H = out.H, W = out.W;
@@ -115,12 +126,31 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
     for (int i = tid; i < 2 * H2_XB; i += 512) xs[i] = make_uint4(0u, 0u, 0u, 0u);
     if (NRM) {
+        unsigned mb = 0u;
         for (int c = tid; c < Cin; c += 512) {
             const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
             nrm_s[3 * c] = a.x; nrm_s[3 * c + 1] = a.y; nrm_s[3 * c + 2] = a.z;
+            const unsigned bb = abs_bits(a.w);
+            mb = max(mb, bb == 0u ? 0x7fc00000u : bb);        // no bound given counts as non-finite
         }
+        mb = wave_umax(mb);
+        if (lane == 0) bound_s[wave] = mb;
     }
     __syncthreads();
+    // input scale 2^e_in from the largest bound of the sample (bound < 2^eb  ->  bound * 2^(15 - eb) < 2^15); poisoned: NaN result
+    int e_in = 0;
+    bool poisoned = false;
+    if (NRM) {
+        unsigned mb = bound_s[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) mb = max(mb, bound_s[w]);
+        poisoned = mb >= 0x7f800000u;
+        e_in = poisoned ? 0 : min(max(15 - ((int)(mb >> 23) - 126), -100), 100);
+        const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
+        for (int c = tid; c < Cin; c += 512) nrm_s[3 * c + 2] *= p_;      // slope * 2^e_in: the negative branch of the scaled activation (each thread rescales the records it loaded)
+        __syncthreads();
+    }
+    const float p_in = __uint_as_float((unsigned)(e_in + 127) << 23);
 
     const float* src = in.data + (long long)n * in.n_stride + (long long)(4 * q) * DHW;
     const u32x4* const wg = reinterpret_cast<const u32x4*>(wp) + (long long)cg * NCH * H2_WB + tid;
@@ -156,9 +186,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Float16 h_[4], l_[4];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             float y_ = xin[J][i];                                                                     \
-            if (NRM) {                                                                                \
+            if (NRM) {      /* act(x) * 2^e_in: (y > 0 ? y : y * slope) * p == y * (y > 0 ? p : slope * p), exact */ \
                 const float* a_ = nrm_s + 3 * (H2_KC * cs + 4 * q + i);                               \
-                y_ = act(y_, a_[0], a_[1], a_[2]);                                                    \
+                y_ = fmaf(y_, a_[0], a_[1]);                                                          \
+                y_ = y_ * (y_ > 0.0f ? p_in : a_[2]);                                                 \
             }                                                                                         \
             h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \
@@ -191,7 +222,14 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i
     const int co = cg * H2_CN + r32;
     const float bco = bias ? bias[co] : 0.0f;
-    const float inv_scale = wtail[0];
+    // scale back: 2^-(weight scale exponent) * 2^-e_in as two power-of-two factors (their product may leave fp32's exponent range)
+    float inv_a, inv_b;
+    {
+        const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;      // wtail[1] = the weights' power-of-two scale
+        const int t1_ = t_ / 2, t2_ = t_ - t1_;
+        inv_a = poisoned ? __uint_as_float(0x7fc00000u) : __uint_as_float((unsigned)(t1_ + 127) << 23);
+        inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
+    }
     float* const obase = out.data + (long long)n * out.n_stride + (long long)co * DHW + (long long)(y0 + 2 * wave) * W + x0;
     Stat run;
     run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
@@ -245,7 +283,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
             const int xg_ = j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);              \
             const bool ok_ = pend && y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                    \
-            o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_scale + bco; \
+            o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_a * inv_b + bco; \
             if (ok_) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j];                     \
             w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
             cnt_ += 4.0f * w_[j];                                                                     \

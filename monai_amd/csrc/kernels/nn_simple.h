@@ -112,9 +112,10 @@ __global__ void __launch_bounds__(256)
 deconv_ks_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int fz, int fy, int fx) {
     const int Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C, Ho = out.H, Wo = out.W;
     const long long ivol = (long long)in.D * Hi * Wi, ovol = (long long)out.D * Ho * Wo;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const int co0 = blockIdx.y * COT, n = blockIdx.z;
-    if (idx >= ovol) return;
+    const bool valid = idx0 < ovol;
+    const long long idx = valid ? idx0 : ovol - 1;
     const int x = (int)(idx % Wo);
     const long long t = idx / Wo;
     const int y = (int)(t % Ho), z = (int)(t / Ho);
@@ -134,7 +135,10 @@ deconv_ks_kernel(Tensor in, const float* __restrict__ w, const float* __restrict
     float* dst = out.data + (long long)n * out.n_stride + idx;
 #pragma unroll
     for (int j = 0; j < COT; ++j)
-        if (co0 + j < Cout) dst[(long long)(co0 + j) * ovol] = acc[j];
+        if (co0 + j < Cout) {
+            if (valid) dst[(long long)(co0 + j) * ovol] = acc[j];
+            if (out.nrm) bound_commit(valid ? abs_bits(acc[j]) : 0u, bound_slot(out, n, co0 + j));
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -268,11 +272,13 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
     const long long ovol = (long long)Do * Ho * Wo;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y, n = blockIdx.z;
+    const float4 a = load_nrm(in, n, c);
+    // the pooled values are activated values of `in`: its bound is theirs (one writer per (n, c))
+    if (out.nrm && idx == 0) *reinterpret_cast<float4*>(bound_slot(out, n, c) - 3) = make_float4(1.0f, 0.0f, 1.0f, a.w);
     if (idx >= ovol) return;
     const int xo = (int)(idx % Wo);
     const long long t = idx / Wo;
     const int yo = (int)(t % Ho), zo = (int)(t / Ho);
-    const float4 a = load_nrm(in, n, c);
     const float* src = in.data + (long long)n * in.n_stride + (long long)c * in.D * H * W;
     float m = -3.402823466e+38f;
 #pragma unroll
@@ -301,9 +307,10 @@ __global__ void __launch_bounds__(256)
 deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
     const int Di = in.D, Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
     const long long ivol = (long long)Di * Hi * Wi;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
     const int co0 = blockIdx.y * COT, n = blockIdx.z;
-    if (idx >= ivol) return;
+    const bool valid = idx0 < ivol;                  // lanes past the volume recompute its last voxel and store nothing: the wave stays whole for the bound
+    const long long idx = valid ? idx0 : ivol - 1;
     const int x = (int)(idx % Wi);
     const long long t = idx / Wi;
     const int y = (int)(t % Hi), z = (int)(t / Hi);
@@ -343,113 +350,27 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
 #pragma unroll
     for (int j = 0; j < COT; ++j)
         if (FULL || co0 + j < Cout) {
+            if (valid) {
 #pragma unroll
-            for (int dz = 0; dz < 2; ++dz)
+                for (int dz = 0; dz < 2; ++dz)
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy) {
-                    float* p = dst + (long long)(co0 + j) * ovol + ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
-                    *reinterpret_cast<float2*>(p) = make_float2(acc[j][dz * 4 + dy * 2], acc[j][dz * 4 + dy * 2 + 1]);
-                }
+                    for (int dy = 0; dy < 2; ++dy) {
+                        float* p = dst + (long long)(co0 + j) * ovol + ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
+                        *reinterpret_cast<float2*>(p) = make_float2(acc[j][dz * 4 + dy * 2], acc[j][dz * 4 + dy * 2 + 1]);
+                    }
+            }
+            if (out.nrm) {        // magnitude bound of the raw result (common.h)
+                unsigned m = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) m = max(m, abs_bits(acc[j][k]));
+                bound_commit(valid ? m : 0u, bound_slot(out, n, co0 + j));
+            }
         }
 }
 
-// The same op as ONE GEMM on the fp32 matrix cores (exact fp32 products and sums, v_mfma_f32_32x32x2_f32): out[voxel][cout, dz, dy, dx] =
-// sum over cin of act(in)[voxel][cin] * w[cin][cout, dz, dy, dx] -- M = input voxels, K = Cin, N = 8 Cout.
-// Measured (profiles/r02_deconv_bench_v1.json, 64 windows): the kernel above is NOT bound by its 8 Cin Cout multiply-adds per voxel -- a first
-// matrix-core form with the same store pattern ran exactly as long (2.38 vs 2.43 ms at 32 -> 32 ch @ 48^3, 0.56 vs 0.57, 0.30 vs 0.28 ms below).
-// Both write the 7.25 GB result at 3.0 TB/s, half of what streaming whole 128-byte lines reaches (tools/ubench/hbm_stream.hip); whether that is
-// partial-line writes fetching their lines first or the number of channel planes written at once is for the counters of
-// tools/gpu_runs/pmc_deconv.sh to say.  This form takes the first candidate out:
-//   * a wave owns 32 consecutive input voxels (one MFMA M block) and holds its A operand -- the activated voxels, lane l = voxel (l & 31) x
-//     channel 2 s + (l >> 5) -- in KS = Cin / 2 registers for the whole N loop (the {alpha, beta, slope} records of a channel pair come by scalar load);
-//   * N is walked in chunks of 32 = 4 couts x 8 taps: B lane l = w[2 s + (l >> 5)][32 chunk + (l & 31)], 128-byte coalesced loads that hit
-//     L1 / L2 (the whole weight tensor is 32 KB ... 2 MB), one group of 16 k-steps in flight ahead of the MFMAs;
-//   * the 32 x 32 result tile of a chunk is 16 output rows (cout, dz, dy) of 64 consecutive floats (32 voxels x dx): it goes through a
-//     wave-private LDS tile (scattered 4-byte writes, 16-byte reads) so that every store instruction writes four complete 256-byte runs.
-// Results are bit-identical to the kernel above on the MI355X and on the emulator (bias first, input channels ascending, fused multiply-adds:
-// the fp32 MFMA accumulates its two k in order).  Opt-in until measured: MONAI_AMD_DECONV_IMPL=mfma.
-constexpr int DT_PITCH = 68;      // floats per LDS row of the store tile: 64 + 4 (16-byte aligned rows, the 16 rows of a chunk start in different banks)
-template <int KS, bool NRM>
-__global__ void __launch_bounds__(256)
-deconv_k2s2_mfma_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
-    constexpr int G = KS < 16 ? KS : 16;                      // k-steps whose B operands are in flight together (one group ahead)
-    const int Hi = in.H, Wi = in.W, Cout = out.C;
-    const int ivol = in.D * Hi * Wi;                          // the launcher checks that a channel volume fits 31 bits
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int half = lane >> 5, col = lane & 31;
-    const int n = blockIdx.y;
-    const int m0 = ((int)blockIdx.x * 4 + wave) * 32;
-    if (m0 >= ivol) return;                                   // whole wave: no barrier in this kernel
-    const int ma = min(m0 + col, ivol - 1);                   // A-operand voxel of this lane (clamped: rows beyond the volume are never stored)
-    const float* src = in.data + (long long)n * in.n_stride + ma;
-    float a[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a[s] = src[(long long)(2 * s + half) * ivol];
-    if (NRM) {
-        // the records of a channel pair are 32 contiguous bytes at a wave-uniform address: scalar loads, the half-wave picks its channel
-        const float* np = in.nrm + (long long)n * in.nrm_n_stride;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const float4 n0 = *reinterpret_cast<const float4*>(np + 8 * s), n1 = *reinterpret_cast<const float4*>(np + 8 * s + 4);
-            a[s] = act(a[s], half ? n1.x : n0.x, half ? n1.y : n0.y, half ? n1.z : n0.z);
-        }
-    }
-    const int Ho = out.H, Wo = out.W;
-    const long long ovol = (long long)out.D * Ho * Wo;
-    const int N8 = Cout * 8;
-    // store side: lane l writes the 16-byte piece (l & 15) of a row = the outputs 2 x .. 2 x + 3 of the two voxels m0 + 2 (l & 15), + 1
-    const int pm = m0 + 2 * (lane & 15);
-    const bool pok = pm < ivol;                               // W % 4 == 0: the voxel pair is inside or outside together
-    long long poff;
-    {
-        const int mc = pok ? pm : 0;
-        const int x = mc % Wi, t = mc / Wi, y = t % Hi, z = t / Hi;
-        poff = ((long long)(2 * z) * Ho + 2 * y) * Wo + 2 * x;
-    }
-    __shared__ __attribute__((aligned(16))) float stile[4][16 * DT_PITCH];
-    float* const dst = out.data + (long long)n * out.n_stride;
-    for (int nc = 0; nc < N8; nc += 32) {
-        const int co = (nc + col) >> 3;
-        const float bj = bias ? bias[co] : 0.0f;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bj;
-        const float* wb = w + (long long)half * N8 + nc + col;
-        float bcur[G], bnext[G];
-#pragma unroll
-        for (int j = 0; j < G; ++j) bcur[j] = wb[(long long)(2 * j) * N8];
-#pragma unroll
-        for (int s0 = 0; s0 < KS; s0 += G) {
-            if (s0 + G < KS) {
-#pragma unroll
-                for (int j = 0; j < G; ++j) bnext[j] = wb[(long long)(2 * (s0 + G + j)) * N8];
-            }
-#pragma unroll
-            for (int j = 0; j < G; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + j], bcur[j], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);               // the group after next stays behind: G B registers in use, G in flight
-#pragma unroll
-            for (int j = 0; j < G; ++j) bcur[j] = bnext[j];
-        }
-        // transpose through the wave's LDS tile: element (voxel m, column n) -> row n >> 1 = (cout, dz, dy), position 2 m + dx
-        float* const tile = stile[wave];
-        __builtin_amdgcn_wave_barrier();                      // the previous chunk's reads are done (wave-private tile: no workgroup barrier)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-            tile[(col >> 1) * DT_PITCH + 2 * m + (col & 1)] = acc[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = 4 * i + (lane >> 4), piece = lane & 15;           // 16 lanes x 16 bytes = one row of 64 floats
-            const f32x4 v = *reinterpret_cast<const f32x4*>(tile + row * DT_PITCH + 4 * piece);
-            const int rco = (nc >> 3) + (row >> 2), rdz = (row >> 1) & 1, rdy = row & 1;
-            if (pok) *reinterpret_cast<f32x4*>(dst + (long long)rco * ovol + poff + ((long long)rdz * Ho + rdy) * Wo) = v;
-        }
-    }
-}
+// Measured and removed (profiles/r02_deconv_bench_v1.json, r03_deconv_bench.json): the same op as ONE GEMM on the fp32 matrix cores, first with this
+// kernel's store pattern, then writing complete 256-byte runs through a wave-private LDS tile -- 2.38 / 2.36 ms against 2.44 ms here (32 -> 32 ch @ 48^3
+// x 64 windows), slower on the smaller levels: neither the 8 Cin Cout multiply-adds per voxel nor the store granularity bound this op.
 
 // ---------------------------------------------------------------------------------------------------
 // Conv3d k=1 of act(in): CO output channels [co0, co0+CO) per thread, VEC voxels per thread.
@@ -514,9 +435,10 @@ conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__
 template <int VEC>
 __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float slope, Tensor out) {
     const long long DHW = (long long)a.D * a.H * a.W;
-    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const long long idx0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int c = blockIdx.y, n = blockIdx.z;
-    if (idx >= DHW) return;
+    const bool valid = idx0 < DHW;                   // VEC == 4: DHW % 4 == 0 (launcher), so a group is inside or outside as a whole
+    const long long idx = valid ? idx0 : 0;
     const bool has_b = b.data != nullptr;          // no second operand: out = lrelu(act(a)) (materialise a deferred tensor)
     const float4 na = load_nrm(a, n, c), nb = load_nrm(b, n, c);
     const float* pa = a.data + (long long)n * a.n_stride + (long long)c * DHW + idx;
@@ -536,8 +458,16 @@ __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float 
         const float y = act(va[v], na.x, na.y, na.z) + (has_b ? act(vb[v], nb.x, nb.y, nb.z) : 0.0f);
         r[v] = y > 0.0f ? y : y * slope;
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(r[0], r[1], r[2], r[3]);
-    else po[0] = r[0];
+    if (valid) {
+        if (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(r[0], r[1], r[2], r[3]);
+        else po[0] = r[0];
+    }
+    if (out.nrm) {            // magnitude bound of the raw sum (common.h)
+        unsigned m = 0u;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) m = max(m, abs_bits(r[v]));
+        bound_commit(valid ? m : 0u, bound_slot(out, n, c));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -547,12 +477,21 @@ __global__ void __launch_bounds__(256) pad_replicate_kernel(Tensor in, Tensor ou
     const long long ovol = (long long)out.D * out.H * out.W, ivol = (long long)in.D * in.H * in.W;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c = blockIdx.y, n = blockIdx.z;
+    if (out.nrm && idx == 0) *reinterpret_cast<float4*>(bound_slot(out, n, c) - 3) = make_float4(1.0f, 0.0f, 1.0f, load_nrm(in, n, c).w);   // a copy: same bound
     if (idx >= ovol) return;
     const int x = (int)(idx % out.W);
     const long long t = idx / out.W;
     const int y = (int)(t % out.H), z = (int)(t / out.H);
     const long long src = ((long long)min(z, in.D - 1) * in.H + min(y, in.H - 1)) * in.W + min(x, in.W - 1);
     out.data[(long long)n * out.n_stride + (long long)c * ovol + idx] = in.data[(long long)n * in.n_stride + (long long)c * ivol + src];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Identity records {1, 0, 1, FLT_MIN} for the channels a raw producer is about to write (common.h: magnitude bounds).
+__global__ void __launch_bounds__(256) nrm_identity_kernel(float* __restrict__ nrm, int N, int C, long long nrm_n_stride) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    *reinterpret_cast<float4*>(nrm + (long long)(i / C) * nrm_n_stride + 4LL * (i % C)) = make_float4(1.0f, 0.0f, 1.0f, MH_BOUND_FLOOR);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -601,7 +540,7 @@ __global__ void __launch_bounds__(256) instnorm_stats_kernel(Tensor x, float* __
     }
 }
 
-// Merge `tiles` records per (n, c) in fp64 and emit the consumer-side {alpha, beta, slope, 0}.
+// Merge `tiles` records per (n, c) in fp64 and emit the consumer-side {alpha, beta, slope, bound}.
 // fp32 steps mirror ATen's CPU batch-norm: invstd = 1/sqrt(var + eps), alpha = gamma*invstd,
 // beta = bias - mean*alpha (the reference normalises as x*alpha + beta).
 __global__ void __launch_bounds__(64)
@@ -642,7 +581,9 @@ instnorm_finalize_kernel(const float* __restrict__ stats, int tiles, int C, int 
         o[0] = alpha;
         o[1] = bb - (float)mean * alpha;
         o[2] = slope;
-        o[3] = 0.0f;
+        // |x - mean| <= sqrt(count - 1) * std for every element of the normalised set, so |gamma * xhat + beta| <= |gamma| sqrt(count) + |beta|
+        // (times the activation's largest gain): a rigorous bound on what consumers see; NaN / inf statistics give a NaN / inf bound
+        o[3] = (fabsf(g) * (float)sqrt(cnt) + fabsf(bb)) * fmaxf(1.0f, fabsf(slope));
     }
 }
 

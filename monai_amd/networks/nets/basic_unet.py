@@ -246,12 +246,17 @@ class _Plan:
         self.tmp = [e(max(f[l], dec_out[l]) if l < 4 else f[4], l) for l in range(5)]
         self.tmp_nrm = [nz(max(f[l], dec_out[l]) if l < 4 else f[4]) for l in range(5)]
         self.pool = [None] + [e(f[l - 1], l) for l in range(1, 5)]
+        # every record of this engine carries a magnitude bound (include/monai_amd.h: mh_tensor5) -- the finalize kernels write it for the normalised
+        # tensors, the pooling kernel hands its input's on, the transposed convolutions fold max |value| into identity records -- so every
+        # convolution but the first may run on the split-precision kernel, which scales its input by them
+        self.pool_nrm = [None] + [nz(f[l - 1]) for l in range(1, 5)]
         # odd extents: the transposed conv of level l+1 yields 2 * floor(sp[l] / 2); UpCat replicate-pads the far end
         # (basic_unet.py:163-170).  Those levels deconvolve into a dense scratch tensor and pad-copy it into the concat buffer.
         self.odd = [any(v & 1 for a, v in enumerate(self.sp[l]) if not (self.planar and a == 0)) for l in range(4)]
         self.up_scratch = [torch.empty((n, up[l]) + tuple(v if (self.planar and a == 0) else 2 * v for a, v in enumerate(self.sp[l + 1])),
                                        dtype=torch.float32, device=device)
                            if self.odd[l] else None for l in range(4)]
+        self.up_scratch_nrm = [nz(up[l]) if self.odd[l] else None for l in range(4)]
         self.x4, self.x4_nrm = e(f[4], 4), nz(f[4])
         self.u = [e(dec_out[l], l) for l in range(4)]
         self.u_nrm = [nz(dec_out[l]) for l in range(4)]
@@ -268,7 +273,7 @@ class _Plan:
         """conv -> raw `out`; InstanceNorm statistics -> `out_nrm` ({alpha, beta, slope})."""
         n, cout, d, h, w = out.shape
         cin = x.shape[1]
-        cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
         packed = net._packed_weight(name, block.conv, cfg)
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if net.fused_stats else 0
         flops = 2.0 * 27 * cin * cout * d * h * w * n
@@ -296,9 +301,9 @@ class _Plan:
         self._conv(net, "conv_0.conv_1", net.conv_0.conv_1, t, tn, self.cat[0][:, : f[0]], self.cat_nrm[0][:, : f[0]])
         for l in range(1, 5):
             skip, skip_nrm = self.cat[l - 1][:, : f[l - 1]], self.cat_nrm[l - 1][:, : f[l - 1]]
-            ops.maxpool2(skip, skip_nrm, self.pool[l])
+            ops.maxpool2(skip, skip_nrm, self.pool[l], self.pool_nrm[l])
             t, tn = self.tmp[l][:, : f[l]], self.tmp_nrm[l][:, : f[l]]
-            self._conv(net, f"down_{l}.convs.conv_0", downs[l].convs.conv_0, self.pool[l], None, t, tn)
+            self._conv(net, f"down_{l}.convs.conv_0", downs[l].convs.conv_0, self.pool[l], self.pool_nrm[l], t, tn)
             if l < 4:
                 o, on = self.cat[l][:, : f[l]], self.cat_nrm[l][:, : f[l]]
             else:
@@ -310,12 +315,13 @@ class _Plan:
         for l in range(3, -1, -1):
             upc = ups[l]
             dst = self.up_scratch[l] if self.odd[l] else self.cat[l][:, f[l]:]
+            dst_nrm = ops.nrm_identity(self.up_scratch_nrm[l] if self.odd[l] else self.cat_nrm[l][:, f[l]:])
             if self.planar:       # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
-                ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2))
+                ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
             else:
-                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst)
+                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm)
             if self.odd[l]:
-                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:])
+                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
             co = self.dec_out[l]
             t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
             self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn)

@@ -296,7 +296,9 @@ class DynUNet(nn.Module):
         tiles, stats = 0, None
         flops = 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n
         if stride == (1, 1, 1) and not (cin <= 8 and cout <= 8):
-            cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+            # every record of this engine carries a magnitude bound: instnorm_finalize writes one, plain tensors come with `nrm_identity` records their
+            # producers (add_act, the transposed convolutions) folded max |value| into -- what the split-precision kernel scales its input by
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
             tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
             with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
@@ -310,12 +312,17 @@ class DynUNet(nn.Module):
         c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, x_nrm, blk.stride, self._slope)
         return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), self._slope)
 
-    def _res(self, blk: _Block, x, dst):
-        """UnetResBlock of a plain tensor into `dst` (plain): lrelu(norm2(conv2(lrelu(norm1(conv1 x)))) + shortcut)"""
-        c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, None, blk.stride, self._slope)
+    @staticmethod
+    def _records(t: torch.Tensor) -> torch.Tensor:
+        """fresh identity records for a plain tensor that is about to be written (its producer leaves the magnitude bounds in them)"""
+        return ops.nrm_identity(torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device))
+
+    def _res(self, blk: _Block, x, x_nrm, dst, dst_nrm):
+        """UnetResBlock of a plain tensor (+ its identity records) into `dst` (plain): lrelu(norm2(conv2(lrelu(norm1(conv1 x)))) + shortcut)"""
+        c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, x_nrm, blk.stride, self._slope)
         c2, n2 = self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), 1.0)
         if not hasattr(blk, "conv3"):
-            return ops.add_act(c2, n2, x, None, self._slope, dst)
+            return ops.add_act(c2, n2, x, None, self._slope, dst, dst_nrm)
         w3 = self._w5(blk.conv3.conv)
         cout = w3.shape[0]
         r = torch.empty_like(c2)
@@ -324,36 +331,38 @@ class DynUNet(nn.Module):
         else:       # the strided 1x1 shortcut as the centre tap of the strided 3x3x3 kernel
             ops.conv3d_k3_strided3(x, None, self._packed_weight(blk.conv3.conv, 0), None, r, blk.stride)
         n3 = self._finalize(blk.norm3, r, None, 0, 1.0)
-        return ops.add_act(c2, n2, r, n3, self._slope, dst)
+        return ops.add_act(c2, n2, r, n3, self._slope, dst, dst_nrm)
 
-    def _encode(self, blk: _Block, x, dst):
+    def _encode(self, blk: _Block, x, x_nrm, dst, dst_nrm):
         """an encoder block of a plain tensor, materialised into `dst` (the skip half of a concat buffer)"""
         if blk.res:
-            return self._res(blk, x, dst)
-        c, cn = self._basic(blk, x, None)
-        return ops.add_act(c, cn, None, None, 1.0, dst)
+            return self._res(blk, x, x_nrm, dst, dst_nrm)
+        c, cn = self._basic(blk, x, x_nrm)
+        return ops.add_act(c, cn, None, None, 1.0, dst, dst_nrm)
 
-    def _level(self, i: int, x, downs, ups):
+    def _level(self, i: int, x, x_nrm, downs, ups):
         """DynUNetSkipLayer.forward at depth i: down -> next level -> transposed conv + [up | skip] concat -> conv block (deferred)"""
         blk, up = downs[i], ups[i]
         cout = blk.conv1.conv.weight.shape[0]
         n = x.shape[0]
         sp = _out_size(x.shape[2:], blk.stride)
         cat = torch.empty((n, 2 * cout) + sp, dtype=torch.float32, device=x.device)       # torch.cat((out, skip), dim=1)
-        skip = self._encode(blk, x, cat[:, cout:])
+        cat_nrm = self._records(cat)
+        skip, skip_nrm = self._encode(blk, x, x_nrm, cat[:, cout:], cat_nrm[:, cout:]), cat_nrm[:, cout:]
         if i + 1 < len(downs):
-            t, tn = self._level(i + 1, skip, downs, ups)
+            t, tn = self._level(i + 1, skip, skip_nrm, downs, ups)
         elif self.bottleneck.res:
             bsp = _out_size(sp, self.bottleneck.stride)
-            t, tn = self._res(self.bottleneck, skip, torch.empty((n, self.filters[-1]) + bsp, dtype=torch.float32, device=x.device)), None
+            t = torch.empty((n, self.filters[-1]) + bsp, dtype=torch.float32, device=x.device)
+            t, tn = self._res(self.bottleneck, skip, skip_nrm, t, None), None
         else:
-            t, tn = self._basic(self.bottleneck, skip, None)
+            t, tn = self._basic(self.bottleneck, skip, skip_nrm)
         tc = up.transp_conv.conv
         if up.up == (2, 2, 2):
-            ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout])
+            ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout], cat_nrm[:, :cout])
         else:
-            ops.deconv_ks(t, tn, self._w5(tc).contiguous(), tc.bias, cat[:, :cout], up.up)
-        return self._basic(up.conv_block, cat, None)
+            ops.deconv_ks(t, tn, self._w5(tc).contiguous(), tc.bias, cat[:, :cout], up.up, cat_nrm[:, :cout])
+        return self._basic(up.conv_block, cat, cat_nrm)
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -385,7 +394,7 @@ class DynUNet(nn.Module):
         if tuple(out.shape) != (x.shape[0], self.out_channels) + _out_size(x.shape[2:], self._strides[0]):
             raise RuntimeError(f"monai_amd.DynUNet: output buffer of shape {tuple(out.shape)} does not fit input {tuple(x.shape)}")
         downs = [self.input_block] + list(self.downsamples)
-        t, tn = self._level(0, x.contiguous(), downs, list(self.upsamples[::-1]))
+        t, tn = self._level(0, x.contiguous(), None, downs, list(self.upsamples[::-1]))
         oc = self.output_block.conv.conv
         ops.conv1x1(t, tn, oc.weight.view(oc.weight.shape[0], -1), oc.bias, out)
         return out

@@ -171,7 +171,7 @@ class SegResNet(nn.Module):
         sp = tuple((v - 1) // stride + 1 for v in (d, h, w))
         out = torch.empty((n, cout) + sp, dtype=torch.float32, device=x.device)
         if stride == 1 and not (cin <= 8 and cout <= 8):
-            cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)      # every record here comes from groupnorm_finalize: it carries a magnitude bound
             tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
             with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):

@@ -324,28 +324,34 @@ class SwinUNETR(UNETR):
         def new(like, c, scale=1):
             return torch.empty((like.shape[0], c) + tuple(int(v * scale) for v in like.shape[2:]), dtype=torch.float32, device=like.device)
 
-        # decoder concat buffers [upsampled | skip]; the encoders write their halves in place
+        # decoder concat buffers [upsampled | skip]; the encoders write their halves in place.  The buffers come with identity records that the
+        # producers (residual joins, transposed convolutions) fold max |value| into: the magnitude bounds the split-precision convolution scales by.
+        # The Swin hidden states themselves arrive without bounds (plain torch tensors): convolutions that read them run on the exact-fp32 kernels.
         cat1 = new(x_in, 2 * fs)                                     # decoder1 @ full resolution
-        self._res_block(self.encoder1.layer, x_in, cat1[:, fs:])
+        cat1_nrm = self._records(cat1)
+        self._res_block(self.encoder1.layer, x_in, None, cat1[:, fs:], cat1_nrm[:, fs:])
         cat2 = new(hs[0], 2 * fs)                                    # decoder2 @ 1/2
-        self._res_block(self.encoder2.layer, hs[0], cat2[:, fs:])
+        cat2_nrm = self._records(cat2)
+        self._res_block(self.encoder2.layer, hs[0], None, cat2[:, fs:], cat2_nrm[:, fs:])
         cat3 = new(hs[1], 4 * fs)                                    # decoder3 @ 1/4
-        self._res_block(self.encoder3.layer, hs[1], cat3[:, 2 * fs:])
+        cat3_nrm = self._records(cat3)
+        self._res_block(self.encoder3.layer, hs[1], None, cat3[:, 2 * fs:], cat3_nrm[:, 2 * fs:])
         cat4 = new(hs[2], 8 * fs)                                    # decoder4 @ 1/8
-        self._res_block(self.encoder4.layer, hs[2], cat4[:, 4 * fs:])
-        cat5 = new(hs[3], 16 * fs)                                   # decoder5 @ 1/16: the skip is the raw hidden state
+        cat4_nrm = self._records(cat4)
+        self._res_block(self.encoder4.layer, hs[2], None, cat4[:, 4 * fs:], cat4_nrm[:, 4 * fs:])
+        cat5 = new(hs[3], 16 * fs)                                   # decoder5 @ 1/16: the skip is the raw hidden state (no bound: fp32 kernels)
         cat5[:, 8 * fs:].copy_(hs[3])
-        dec4 = self._res_block(self.encoder10.layer, hs[4], new(hs[4], 16 * fs))
+        dec4 = self._res_block(self.encoder10.layer, hs[4], None, new(hs[4], 16 * fs), None)
 
-        def up(blk: _UpBlock, inp, cat, cout, dst):
-            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout])
-            return self._res_block(blk.conv_block, cat, dst)
+        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst):
+            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], None if cat_nrm is None else cat_nrm[:, :cout])
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None)
 
-        dec3 = up(self.decoder5, dec4, cat5, 8 * fs, new(cat5, 8 * fs))
-        dec2 = up(self.decoder4, dec3, cat4, 4 * fs, new(cat4, 4 * fs))
-        dec1 = up(self.decoder3, dec2, cat3, 2 * fs, new(cat3, 2 * fs))
-        dec0 = up(self.decoder2, dec1, cat2, fs, new(cat2, fs))
-        last = up(self.decoder1, dec0, cat1, fs, new(cat1, fs))
+        dec3 = up(self.decoder5, dec4, cat5, None, 8 * fs, new(cat5, 8 * fs))
+        dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, new(cat4, 4 * fs))
+        dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, new(cat3, 2 * fs))
+        dec0 = up(self.decoder2, dec1, cat2, cat2_nrm, fs, new(cat2, fs))
+        last = up(self.decoder1, dec0, cat1, cat1_nrm, fs, new(cat1, fs))
         oc = self.out.conv.conv
         ops.conv1x1(last, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
         return logits

@@ -207,7 +207,9 @@ class UNet(nn.Module):
             # few channels on both sides (the 5-class top level): the matrix tiles would pad them to 32; the direct kernel runs at
             # the channels' true width
             tiny = s == 1 and cin <= 8 and cout <= 8
-            cfg = ops.conv3d_k3_select(cin, cout, d, h, w) if (s == 1 and not tiny) else 0
+            # records written by instnorm_finalize carry magnitude bounds (the split-precision kernel needs them); folded BatchNorm records do not
+            bounded = x_nrm is not None and not any(isinstance(m, nn.BatchNorm3d) for m in self.modules())
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=bounded) if (s == 1 and not tiny) else 0
             wants_stats = hasattr(unit, "adn") and not isinstance(unit.adn.N, nn.BatchNorm3d)
             stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and wants_stats) else 0
             if s == 1 and not tiny:

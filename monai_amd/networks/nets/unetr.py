@@ -212,7 +212,9 @@ class UNETR(nn.Module):
         """3x3x3 conv (no bias) + InstanceNorm(no affine) statistics -> (raw output, its {alpha, beta, slope} record)."""
         n, cin, d, h, w = x.shape
         cout = conv.weight.shape[0]
-        cfg = ops.conv3d_k3_select(cin, cout, d, h, w)
+        # every record of this engine carries a magnitude bound (instnorm_finalize writes one; plain tensors come with `nrm_identity` records that their
+        # producers -- add_act, the transposed convolutions -- folded max |value| into): what the split-precision kernel scales its input by
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
         out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         nrm = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
@@ -229,9 +231,14 @@ class UNETR(nn.Module):
         ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, slope, nrm)
         return out, nrm
 
-    def _res_block(self, blk: _ResBlock, x, out):
-        """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` into `out`."""
-        c1, n1 = self._conv3_in(blk.conv1.conv, x, None, 0.01)      # conv1 -> norm1 -> lrelu, applied on load by conv2
+    @staticmethod
+    def _records(t: torch.Tensor) -> torch.Tensor:
+        """fresh identity records for a plain tensor that is about to be written (its producers leave the magnitude bounds in them)"""
+        return ops.nrm_identity(torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device))
+
+    def _res_block(self, blk: _ResBlock, x, x_nrm, out, out_nrm):
+        """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` (+ its identity records, or None) into `out`."""
+        c1, n1 = self._conv3_in(blk.conv1.conv, x, x_nrm, 0.01)     # conv1 -> norm1 -> lrelu, applied on load by conv2
         c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 1.0)        # conv2 -> norm2 (no activation before the add)
         if hasattr(blk, "conv3"):
             w3 = blk.conv3.conv.weight
@@ -243,14 +250,14 @@ class UNETR(nn.Module):
             ops.instnorm_stats(r, stats)
             n3 = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
             ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, n3)
-            ops.add_act(c2, n2, r, n3, 0.01, out)
+            ops.add_act(c2, n2, r, n3, 0.01, out, out_nrm)
         else:
-            ops.add_act(c2, n2, x, None, 0.01, out)
+            ops.add_act(c2, n2, x, None, 0.01, out, out_nrm)
         return out
 
     @staticmethod
-    def _tconv(conv: nn.ConvTranspose3d, x, out):
-        return ops.deconv_k2s2(x, None, conv.weight, conv.bias, out)
+    def _tconv(conv: nn.ConvTranspose3d, x, out, out_nrm=None):
+        return ops.deconv_k2s2(x, None, conv.weight, conv.bias, out, out_nrm)
 
     def _new(self, like, c, scale=1):
         n = like.shape[0]
@@ -317,37 +324,44 @@ class UNETR(nn.Module):
         with torch.autocast(device_type=x_in.device.type, enabled=False):
             x, hs = self._vit(x_in)
 
-        # decoder concat buffers: [upsampled | skip]
+        # decoder concat buffers: [upsampled | skip], each with identity records its producers fold their magnitude bounds into
         cat2 = self._new(x_in, 2 * fs)                       # decoder2 @ full resolution
-        self._res_block(self.encoder1.layer, x_in, cat2[:, fs:])
+        cat2_nrm = self._records(cat2)
+        self._res_block(self.encoder1.layer, x_in, None, cat2[:, fs:], cat2_nrm[:, fs:])
 
-        def prup(blk: _PrUpBlock, t, dst):
+        def prup(blk: _PrUpBlock, t, dst, dst_nrm):
             cout = blk.transp_conv_init.conv.weight.shape[1]
-            cur = self._tconv(blk.transp_conv_init.conv, t, dst if len(blk.blocks) == 0 else self._new(t, cout, 2))
+            direct = len(blk.blocks) == 0
+            cur = self._tconv(blk.transp_conv_init.conv, t, dst if direct else self._new(t, cout, 2), dst_nrm if direct else None)
             for i, seq in enumerate(blk.blocks):
-                up = self._tconv(seq[0].conv, cur, self._new(cur, cout, 2))
+                up = self._new(cur, cout, 2)
+                up_nrm = self._records(up)
+                self._tconv(seq[0].conv, cur, up, up_nrm)
                 last = i == len(blk.blocks) - 1
-                cur = self._res_block(seq[1], up, dst if last else self._new(up, cout))
+                cur = self._res_block(seq[1], up, up_nrm, dst if last else self._new(up, cout), dst_nrm if last else None)
             return cur
 
         p2 = self._proj_feat(hs[3])
         cat3 = self._new(p2, 4 * fs, 8)                      # decoder3 @ 1/2 resolution
-        prup(self.encoder2, p2, cat3[:, 2 * fs:])
+        cat3_nrm = self._records(cat3)
+        prup(self.encoder2, p2, cat3[:, 2 * fs:], cat3_nrm[:, 2 * fs:])
         p3 = self._proj_feat(hs[6])
         cat4 = self._new(p3, 8 * fs, 4)                      # decoder4 @ 1/4
-        prup(self.encoder3, p3, cat4[:, 4 * fs:])
+        cat4_nrm = self._records(cat4)
+        prup(self.encoder3, p3, cat4[:, 4 * fs:], cat4_nrm[:, 4 * fs:])
         p4 = self._proj_feat(hs[9])
         cat5 = self._new(p4, 16 * fs, 2)                     # decoder5 @ 1/8
-        prup(self.encoder4, p4, cat5[:, 8 * fs:])
+        cat5_nrm = self._records(cat5)
+        prup(self.encoder4, p4, cat5[:, 8 * fs:], cat5_nrm[:, 8 * fs:])
 
-        def up(blk: _UpBlock, inp, cat, cout, dst):
-            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout])
-            return self._res_block(blk.conv_block, cat, dst)
+        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst):
+            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], cat_nrm[:, :cout])
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None)
 
-        dec3 = up(self.decoder5, self._proj_feat(x), cat5, 8 * fs, self._new(cat5, 8 * fs))
-        dec2 = up(self.decoder4, dec3, cat4, 4 * fs, self._new(cat4, 4 * fs))
-        dec1 = up(self.decoder3, dec2, cat3, 2 * fs, self._new(cat3, 2 * fs))
-        last = up(self.decoder2, dec1, cat2, fs, self._new(cat2, fs))
+        dec3 = up(self.decoder5, self._proj_feat(x), cat5, cat5_nrm, 8 * fs, self._new(cat5, 8 * fs))
+        dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, self._new(cat4, 4 * fs))
+        dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, self._new(cat3, 2 * fs))
+        last = up(self.decoder2, dec1, cat2, cat2_nrm, fs, self._new(cat2, fs))
         oc = self.out.conv.conv
         ops.conv1x1(last, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
         return logits

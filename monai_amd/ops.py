@@ -145,8 +145,13 @@ def avg_finalize(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     return values
 
 
-def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int) -> int:
-    return _lib.lib().query("mh_conv3d_k3_select", cin, cout, d, h, w)
+def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int, bounded: bool = False, algo: Optional[int] = None) -> int:
+    """Kernel configuration for a 3x3x3 convolution.  `bounded`: every record of the input view carries a magnitude bound
+    (written by instnorm / groupnorm_finalize, or by a raw producer into `nrm_identity` records) -- only then may the fp16
+    split-precision configuration be returned.  `algo`: MH_ALGO_* family, default `monai_amd.config.conv_algo()`."""
+    from . import config
+
+    return _lib.lib().query("mh_conv3d_k3_select", config.conv_algo() if algo is None else int(algo), int(bool(bounded)), cin, cout, d, h, w)
 
 
 def conv3d_k3_num_configs() -> int:
@@ -164,12 +169,6 @@ def conv3d_k3_c1_config() -> int:
     """Id of the one-input-channel configuration (first layer of the networks: packed fp32 vector arithmetic, write-bound, exact fp32);
     outside 1 .. conv3d_k3_num_configs()."""
     return _lib.lib().query("mh_conv3d_k3_c1_config")
-
-
-def conv3d_k3_split_config() -> int:
-    """Id of the experimental split-precision configuration (bf16 matrix cores, three pieces per operand, fp32-equivalent
-    results); outside 1 .. conv3d_k3_num_configs(), selected by conv3d_k3_select only under MONAI_AMD_CONV_ALGO=split."""
-    return _lib.lib().query("mh_conv3d_k3_split_config")
 
 
 def conv3d_k3_accepts(cfg: int, cin: int, cout: int) -> bool:
@@ -210,7 +209,7 @@ def instnorm_stats(x: torch.Tensor, stats: torch.Tensor):
 
 
 def instnorm_finalize(stats, tiles: int, n: int, c: int, gamma, beta, eps: float, slope: float, nrm: torch.Tensor):
-    """Merge `tiles` records per (n, c); write {alpha, beta, slope, 0} into nrm ([N, C, 4] slice)."""
+    """Merge `tiles` records per (n, c); write {alpha, beta, slope, bound} into nrm ([N, C, 4] slice)."""
     _lib.require_device(stats, gamma, beta, nrm)
     if nrm.dim() != 3 or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
         raise RuntimeError("monai_amd.instnorm_finalize: nrm must be a [N,C,4] slice")
@@ -222,16 +221,30 @@ def instnorm_finalize(stats, tiles: int, n: int, c: int, gamma, beta, eps: float
     return nrm
 
 
-def maxpool2(x, x_nrm, out):
-    _lib.require_device(x, x_nrm, out)
-    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+def nrm_identity(nrm: torch.Tensor) -> torch.Tensor:
+    """nrm [N, C, 4] slice <- identity records {1, 0, 1, FLT_MIN}: hand it as `out_nrm` to a raw producer (deconv_k2s2, deconv_ks,
+    add_act) and the kernel leaves max |value written| per (n, c) in the 4th component -- the magnitude bound the split-precision
+    convolution scales its input by."""
+    _lib.require_device(nrm)
+    if nrm.dim() != 3 or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
+        raise RuntimeError("monai_amd.nrm_identity: nrm must be a [N,C,4] slice")
+    n, c = nrm.shape[:2]
+    _lib.lib().call("mh_nrm_identity_f32", _lib.ptr(nrm), int(n), int(c), int(nrm.stride(0) if n > 1 else max(nrm.stride(0), 4 * c)), _s(nrm))
+    return nrm
+
+
+def maxpool2(x, x_nrm, out, out_nrm=None):
+    """out_nrm: identity records for `out` carrying the input's magnitude bounds (written by the kernel)"""
+    _lib.require_device(x, x_nrm, out, out_nrm)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out, out_nrm)
     _lib.lib().call("mh_maxpool2_f32", C.byref(xi), C.byref(xo), _s(x))
     return out
 
 
-def deconv_k2s2(x, x_nrm, weight, bias, out):
-    _lib.require_device(x, x_nrm, weight, bias, out)
-    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None):
+    """out_nrm: `nrm_identity` records of `out`; the kernel folds max |value written| into their bound"""
+    _lib.require_device(x, x_nrm, weight, bias, out, out_nrm)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out, out_nrm)
     _lib.lib().call("mh_deconv_k2s2_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
     return out
 
@@ -293,19 +306,20 @@ def separable_filter3d(src: torch.Tensor, kernels) -> torch.Tensor:
     return out
 
 
-def add_act(a, a_nrm, b, b_nrm, slope: float, out):
-    """out = leaky_relu(act(a) + act(b), slope) -- residual join of UnetResBlock."""
-    _lib.require_device(a, a_nrm, b, b_nrm, out)
-    ta, to = _lib.tensor5(a, a_nrm), _lib.tensor5(out)
+def add_act(a, a_nrm, b, b_nrm, slope: float, out, out_nrm=None):
+    """out = leaky_relu(act(a) + act(b), slope) -- residual join of UnetResBlock.  out_nrm: `nrm_identity` records of `out` (magnitude bound)."""
+    _lib.require_device(a, a_nrm, b, b_nrm, out, out_nrm)
+    ta, to = _lib.tensor5(a, a_nrm), _lib.tensor5(out, out_nrm)
     tb = None if b is None else _lib.tensor5(b, b_nrm)
     _lib.lib().call("mh_add_act_f32", C.byref(ta), None if tb is None else C.byref(tb), float(slope), C.byref(to), _s(a))
     return out
 
 
-def pad_replicate(x, out):
-    """out[z, y, x] = x[min(z, D-1), min(y, H-1), min(x, W-1)]: replicate padding at the far end (UpCat's odd-edge case)."""
-    _lib.require_device(x, out)
-    xi, xo = _lib.tensor5(x), _lib.tensor5(out)
+def pad_replicate(x, out, x_nrm=None, out_nrm=None):
+    """out[z, y, x] = x[min(z, D-1), min(y, H-1), min(x, W-1)]: replicate padding at the far end (UpCat's odd-edge case).  A raw copy:
+    x_nrm is read for its magnitude bounds only, which go into the identity records out_nrm."""
+    _lib.require_device(x, out, x_nrm, out_nrm)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out, out_nrm)
     _lib.lib().call("mh_pad_replicate_f32", C.byref(xi), C.byref(xo), _s(x))
     return out
 
@@ -505,12 +519,13 @@ def conv3d_k3_strided3(x, x_nrm, packed_w0, bias, out, strides: Sequence[int]):
     return out
 
 
-def deconv_ks(x, x_nrm, weight, bias, out, factors: Sequence[int]):
-    """out = conv_transpose3d(act(x), kernel == stride == factors (each 1 or 2)) + bias; weight [Cin, Cout, fz, fy, fx] contiguous."""
-    _lib.require_device(x, x_nrm, weight, bias, out)
+def deconv_ks(x, x_nrm, weight, bias, out, factors: Sequence[int], out_nrm=None):
+    """out = conv_transpose3d(act(x), kernel == stride == factors (each 1 or 2)) + bias; weight [Cin, Cout, fz, fy, fx] contiguous.
+    out_nrm: `nrm_identity` records of `out` (magnitude bound)."""
+    _lib.require_device(x, x_nrm, weight, bias, out, out_nrm)
     if not weight.is_contiguous() or tuple(weight.shape[2:]) != tuple(int(f) for f in factors):
         raise RuntimeError("monai_amd.deconv_ks: contiguous weight [Cin, Cout, fz, fy, fx] required")
-    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out, out_nrm)
     _lib.lib().call("mh_deconv_ks_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), int(factors[0]), int(factors[1]), int(factors[2]), _s(x))
     return out
 

@@ -458,3 +458,95 @@ def case_basic_unet_2d_vs_reference(device):
     out["slice_inferer"] = (y.double() - exp.double()).abs().max().item()
     assert out["slice_inferer"] < LOGIT_TOL, out
     return out
+
+
+# ------------------------------------------------------------------------------------------ trained-like parameter spreads
+def _spread_affine(net, seed, lo=1e-3, hi=1e3, beta_max=1e3):
+    """Give every normalisation layer of `net` trained-checkpoint-like (and far wilder) affine parameters: gamma log-uniform in [lo, hi] with random
+    signs, beta up to +-beta_max * gamma-scale -- default-initialised nets (gamma 1, beta 0) say nothing about the split-precision kernel's range."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.InstanceNorm3d, torch.nn.GroupNorm)) and getattr(m, "weight", None) is not None:
+                c = m.weight.numel()
+                mag = torch.exp(torch.rand(c, generator=gen) * (np.log(hi) - np.log(lo)) + np.log(lo))
+                sign = torch.where(torch.rand(c, generator=gen) > 0.75, -1.0, 1.0)
+                m.weight.copy_((mag * sign).to(m.weight.device))
+                m.bias.copy_((torch.randn(c, generator=gen) * mag * (beta_max / hi) * 3.0).to(m.bias.device))
+    return net
+
+
+def _rel_err(got, exp):
+    return (got.double() - exp.double()).abs().max().item() / max(1.0, exp.double().abs().max().item())
+
+
+def case_nets_with_spread_affine(device, window=(32, 32, 32), nets=("basic_unet", "dynunet_res", "segresnet")):
+    """BasicUNet / DynUNet(res) / SegResNet whose norm layers carry gamma in +-[1e-3, 1e3] and |beta| up to ~1e3 (activations from 1e-3 to far beyond
+    65504 inside the net), fed one [0, 1] window and one raw-CT-like window (x 3000 - 1000): the default path (fp16 split-precision convolutions, scaled
+    by the records' magnitude bounds) against the CPU oracle at the north-star bar -- 1e-4 of the logit scale -- and against the exact-fp32 kernels'
+    own distance from the oracle (the split-precision path must not be a worse fp32 than fp32)."""
+    from monai_amd import config
+    from monai_amd.networks.nets import BasicUNet, DynUNet, SegResNet
+    from oracle import dynunet as odyn
+
+    gen = torch.Generator().manual_seed(99)
+    x = torch.rand((2, 1) + tuple(window), generator=gen)
+    x[1] = x[1] * 3000.0 - 1000.0
+    out = {}
+    for name in nets:
+        torch.manual_seed(5)
+        if name == "basic_unet":
+            net = BasicUNet(3, 1, 5).eval()
+            ref_fn = lambda sd, v: oracle.basic_unet_forward(sd, v)      # noqa: E731
+        elif name == "dynunet_res":
+            kw = dict(kernel_size=[3, 3, 3, 3], strides=[1, 2, 2, 2], upsample_kernel_size=[2, 2, 2], filters=[32, 32, 64, 64], res_block=True,
+                      norm_name=("instance", {"affine": True}))
+            net = DynUNet(3, 1, 3, **kw).eval()
+            ref_fn = lambda sd, v: odyn.dynunet_forward(sd, v, kw["strides"], res_block=True)      # noqa: E731
+        else:
+            net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=3, blocks_down=(1, 2, 2), blocks_up=(1, 1)).eval()
+            ref_fn = lambda sd, v: odyn.segresnet_forward(sd, v, blocks_down=(1, 2, 2), blocks_up=(1, 1))      # noqa: E731
+        _spread_affine(net, seed=17)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            exp = ref_fn(sd, x)
+        assert torch.isfinite(exp).all(), name
+        net = net.to(device)
+        errs = {}
+        saved = config.CONV_ALGO
+        try:
+            for algo in ("auto", "fp32"):
+                config.CONV_ALGO = algo
+                got = net(x.to(device)).cpu()
+                assert torch.isfinite(got).all(), f"{name}/{algo}: non-finite logits"
+                errs[algo] = _rel_err(got, exp)
+        finally:
+            config.CONV_ALGO = saved
+        assert errs["auto"] < LOGIT_TOL, f"{name}: split-precision path {errs['auto']:.2e} of the logit scale (fp32 kernels: {errs['fp32']:.2e})"
+        assert errs["auto"] < 4.0 * errs["fp32"] + 2e-6, f"{name}: split precision {errs['auto']:.2e} vs exact fp32 {errs['fp32']:.2e}"
+        out[name] = errs
+    return out
+
+
+def case_net_nonfinite_inputs(device, window=(32, 32, 32)):
+    """inf / NaN voxels in one window of a batch: the reference (conv -> InstanceNorm, blocks/convolutions.py:98-171) turns THAT sample into NaN and
+    leaves the others alone; so does the engine on its default (split-precision) path and on the exact-fp32 kernels."""
+    from monai_amd import config
+
+    net, sd = make_net(1, 1, 5, device)
+    gen = torch.Generator().manual_seed(98)
+    x = torch.rand((3, 1) + tuple(window), generator=gen)
+    x[1, 0, 5, 6, 7] = float("inf")
+    x[2, 0, 9, 9, 9] = float("nan")
+    with torch.no_grad():
+        exp = oracle.basic_unet_forward(sd, x)
+    assert torch.isnan(exp[1]).all() and torch.isnan(exp[2]).all() and torch.isfinite(exp[0]).all()
+    saved = config.CONV_ALGO
+    try:
+        for algo in ("auto", "fp32"):
+            config.CONV_ALGO = algo
+            got = net(x.to(device)).cpu()
+            assert torch.isnan(got[1]).all() and torch.isnan(got[2]).all(), f"{algo}: a non-finite window must come out NaN like the reference's"
+            assert (got[0] - exp[0]).abs().max().item() < LOGIT_TOL, algo
+    finally:
+        config.CONV_ALGO = saved

@@ -316,6 +316,8 @@ static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; retu
 static inline float __fsqrt_rn(float a) { return std::sqrt(a); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 using std::fmaf;
 using std::max;
 using std::min;
@@ -339,6 +341,12 @@ template <class T, class U> static inline T emu_atomic_add(T* p, T v) {
 }
 static inline int atomicMin(int* p, int v) { const int o = *p; if (v < o) *p = v; return o; }     // LDS only: fibers of one block share a host thread
 static inline int atomicMax(int* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+// global memory (magnitude bounds of raw tensors): workgroups run on several host threads
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 static inline float unsafeAtomicAdd(float* p, float v) { return emu_atomic_add<float, unsigned int>(p, v); }
 static inline double unsafeAtomicAdd(double* p, double v) { return emu_atomic_add<double, unsigned long long>(p, v); }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };

@@ -48,17 +48,30 @@ def test_host_side_queries_need_no_gpu():
     dll.mh_conv3d_k3_num_configs.restype = ctypes.c_int
     n = dll.mh_conv3d_k3_num_configs()
     dll.mh_conv3d_k3_c1_config.restype = ctypes.c_int
-    assert dll.mh_conv3d_k3_select(1, 32, 96, 96, 96) == dll.mh_conv3d_k3_c1_config() > n      # first layer: the one-input-channel kernel
-    assert 1 <= dll.mh_conv3d_k3_select(1, 32, 9, 9, 9) <= n                                    # W % 4 != 0: an fp32 matrix-core tile
+    AUTO, FP32 = 0, 4      # MH_ALGO_*: the arithmetic family is an argument; the library reads no environment variable
+    assert dll.mh_conv3d_k3_select(AUTO, 0, 1, 32, 96, 96, 96) == dll.mh_conv3d_k3_c1_config() > n      # first layer: the one-input-channel kernel
+    assert 1 <= dll.mh_conv3d_k3_select(AUTO, 0, 1, 32, 9, 9, 9) <= n                                    # W % 4 != 0: an fp32 matrix-core tile
     dll.mh_conv3d_k3_h2_config.restype = ctypes.c_int
-    env = os.environ.pop("MONAI_AMD_CONV_ALGO", None)
+    assert dll.mh_conv3d_k3_select(AUTO, 1, 32, 32, 96, 96, 96) == dll.mh_conv3d_k3_h2_config()      # bounded input: fp16 two-piece split precision
+    assert dll.mh_conv3d_k3_select(AUTO, 0, 32, 32, 96, 96, 96) == n      # no magnitude bounds: exact fp32 (large planes: the in-plane Winograd configuration)
+    saved = os.environ.get("MONAI_AMD_CONV_ALGO")
+    os.environ["MONAI_AMD_CONV_ALGO"] = "h2"                              # ... and nothing in the environment changes that
     try:
-        assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == dll.mh_conv3d_k3_h2_config()      # default: fp16 two-piece split precision
-        os.environ["MONAI_AMD_CONV_ALGO"] = "fp32"
-        assert dll.mh_conv3d_k3_select(32, 32, 96, 96, 96) == n      # exact fp32 kernels, large planes: the in-plane Winograd configuration
-        assert dll.mh_conv3d_k3_select(32, 32, 12, 12, 12) < n       # small planes: a direct fp32 tile
+        assert dll.mh_conv3d_k3_select(AUTO, 0, 32, 32, 96, 96, 96) == n
+        assert dll.mh_conv3d_k3_select(FP32, 1, 32, 32, 96, 96, 96) == n
+        assert dll.mh_conv3d_k3_select(FP32, 1, 32, 32, 12, 12, 12) < n       # small planes: a direct fp32 tile
     finally:
         os.environ.pop("MONAI_AMD_CONV_ALGO", None)
-        if env is not None:
-            os.environ["MONAI_AMD_CONV_ALGO"] = env
+        if saved is not None:
+            os.environ["MONAI_AMD_CONV_ALGO"] = saved
     assert dll.mh_instnorm_stat_tiles(96, 96, 96) > 0
+
+
+def test_library_reads_no_environment():
+    """"no global mutable state" -- the shipped library does not even import getenv (development knobs exist only in the
+    -DMH_DEV_KNOBS build, libmonai_amd_dev.so, which the product never loads)"""
+    import subprocess
+
+    _ensure_built()
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms, [ln for ln in syms.splitlines() if "getenv" in ln]

@@ -66,6 +66,43 @@ def test_headline_many_windows_vs_oracle_192():
     print(rep)
 
 
+def test_headline_125_windows_vs_oracle_288_both_arithmetics():
+    """the COMPLETE inferer on 288^3 = 125 windows of 96^3 (5 per axis: interior voxels covered by 8 windows, every tile
+    configuration and blend pattern of the 512^3 headline) against the CPU oracle, for BOTH arithmetic families -- the default (split-precision
+    convolutions scaled by their records' magnitude bounds) and the exact-fp32 kernels -- with the parity rule of oracle/parity.py."""
+    from monai_amd import config
+    from monai_amd.inferers import SlidingWindowInferer
+    from oracle import synthetic
+
+    net, sd = ec.make_net(1, 1, 5, DEV)
+    x = torch.from_numpy(synthetic.benchmark_volume(288))[None, None]
+    inf = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
+    got = {}
+    saved = config.CONV_ALGO
+    try:
+        for algo in ("auto", "fp32"):
+            config.CONV_ALGO = algo
+            got[algo] = inf(x.to(DEV), net).cpu()
+    finally:
+        config.CONV_ALGO = saved
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        ref = osw.sliding_window_inference(x, (96, 96, 96), 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian")
+    for algo in ("auto", "fp32"):
+        print(algo, oracle.assert_label_parity(got[algo], ref, tol=ec.LOGIT_TOL, what=f"288^3 / 125 windows of 96^3 / {algo}"))
+
+
+def test_nets_with_trained_like_affine_spreads():
+    """gamma in +-[1e-3, 1e3], |beta| to ~1e3 (activations far beyond fp16's 65504 inside the nets), one raw-CT-valued window: the default path vs the
+    CPU oracle at 1e-4 of the logit scale, and never worse than 4x the exact-fp32 kernels' own distance from it"""
+    print(ec.case_nets_with_spread_affine(DEV, window=(64, 64, 64)))
+    print(ec.case_nets_with_spread_affine(DEV, window=(96, 96, 96), nets=("basic_unet",)))
+
+
+def test_net_nonfinite_inputs_like_the_reference():
+    ec.case_net_nonfinite_inputs(DEV, window=(64, 64, 64))
+
+
 def test_slice_inferer_and_adapt_on_device():
     """SURVEY 8 row a9 on the MI355X: SliceInferer drives a 2-D predictor over every slice of a 3-D volume (one window per slice --
     more than 160 windows on the slice axis), SlidingWindowInfererAdapt falls through to the plain inferer when nothing overflows."""
@@ -234,8 +271,6 @@ def test_narrow_and_host_inputs():
     ec.case_narrow_and_host_inputs(DEV)
 
 
-@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_UNVERIFIED_ON_GPU") != "1",
-                    reason="written after round 2's GPU budget was spent (emulator-verified against the real reference's goldens); tools/gpu_runs/r3_first.sh runs it first thing next round")
 def test_basic_unet_2d_and_slice_inferer_vs_reference():
     """BasicUNet(spatial_dims=2) on the one-plane engine and SliceInferer over it, against the real reference"""
     print("max |dlogit|", ec.case_basic_unet_2d_vs_reference(DEV))

@@ -80,8 +80,8 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert cfg >= 1
     from monai_amd import ops
 
-    # the BASELINE.json network: every 3x3x3 conv runs on the fp32 matrix cores -- the large planes on the in-plane
-    # Winograd configuration (the highest id), the rest on direct implicit-GEMM tiles
+    # exact-fp32 family (the emulator fixture's default, MONAI_AMD_CONV_ALGO=fp32): the large planes on the in-plane Winograd configuration
+    # (the highest fp32 id), the rest on direct implicit-GEMM tiles
     wino2d = ops.conv3d_k3_num_configs()
     c1 = ops.conv3d_k3_c1_config()           # one input channel: the packed-VALU kernel (exact fp32), a direct tile when W % 4 != 0
     assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == c1 and ops.conv3d_k3_select(1, 32, 95, 95, 95) == 7
@@ -91,19 +91,37 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert ops.conv3d_k3_select(32, 64, 24, 24, 24) == 12
     assert ops.conv3d_k3_select(64, 128, 12, 12, 12) == 13
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13
-    # the product default (no MONAI_AMD_CONV_ALGO): fp16 two-piece split precision wherever the shape fits, the fp32 kernels elsewhere
-    import os
+    # the arithmetic family is an ARGUMENT of the C entry point (the library reads no environment).  MH_ALGO_AUTO: fp16 two-piece split
+    # precision wherever the shape fits AND the input carries magnitude bounds, the exact-fp32 kernels everywhere else
+    AUTO, DIRECT, WINO2D, H2, FP32 = 0, 1, 2, 3, 4
+    h2 = ops.conv3d_k3_h2_config()
+    shapes = ((32, 32, 96, 96, 96), (64, 32, 96, 96, 96), (32, 64, 48, 48, 48), (64, 128, 12, 12, 12))
+    assert ops.conv3d_k3_select(1, 32, 96, 96, 96, algo=AUTO) == c1
+    assert [ops.conv3d_k3_select(*a, bounded=True, algo=AUTO) for a in shapes] == [h2] * 4
+    assert [ops.conv3d_k3_select(*a, bounded=True, algo=H2) for a in shapes] == [h2] * 4
+    for a in shapes:       # no bounds, no split precision -- under AUTO and even when the family is asked for by name
+        assert ops.conv3d_k3_select(*a, bounded=False, algo=AUTO) == ops.conv3d_k3_select(*a, bounded=True, algo=FP32) <= wino2d
+        assert 1 <= ops.conv3d_k3_select(*a, bounded=False, algo=H2) < wino2d
+    assert ops.conv3d_k3_select(256, 128, 12, 12, 12, bounded=True, algo=AUTO) == h2 and not ops.conv3d_k3_accepts(h2, 272, 32)
+    assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=AUTO) == 13      # W % 4 != 0
+    assert 1 <= ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True, algo=DIRECT) < wino2d
+    assert ops.conv3d_k3_select(32, 32, 24, 24, 24, bounded=True, algo=WINO2D) == wino2d
+    with pytest.raises(RuntimeError):
+        ops.conv3d_k3_select(32, 32, 24, 24, 24, algo=9)
+    # host-side switch: monai_amd.config.CONV_ALGO / the MONAI_AMD_CONV_ALGO environment variable, read by the PYTHON side at call time
+    from monai_amd import config
 
-    saved = os.environ.pop("MONAI_AMD_CONV_ALGO", None)
+    saved = config.CONV_ALGO
     try:
-        h2 = ops.conv3d_k3_h2_config()
-        assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == c1
-        assert [ops.conv3d_k3_select(*a) for a in ((32, 32, 96, 96, 96), (64, 32, 96, 96, 96), (32, 64, 48, 48, 48), (64, 128, 12, 12, 12))] == [h2] * 4
-        assert ops.conv3d_k3_select(256, 128, 12, 12, 12) == h2 and not ops.conv3d_k3_accepts(h2, 272, 32)
-        assert ops.conv3d_k3_select(128, 256, 6, 6, 6) == 13 and ops.conv3d_k3_select(256, 256, 6, 6, 6) == 13      # W % 4 != 0
+        config.CONV_ALGO = "auto"
+        assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == h2 and ops.conv3d_k3_select(32, 32, 96, 96, 96) == wino2d
+        config.CONV_ALGO = "fp32"
+        assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == wino2d
+        config.CONV_ALGO = "no-such-family"
+        with pytest.raises(ValueError):
+            ops.conv3d_k3_select(32, 32, 96, 96, 96)
     finally:
-        if saved is not None:
-            os.environ["MONAI_AMD_CONV_ALGO"] = saved
+        config.CONV_ALGO = saved
 
 
 def test_conv_into_channel_slice(emu):
@@ -142,17 +160,6 @@ def test_strided_conv_and_deconv_k3(emu):
     kc.case_strided_conv_and_deconv_k3("cpu")
 
 
-@pytest.mark.parametrize("cin,cout,dims,n", [(4, 16, (4, 8, 16), 2), (8, 32, (8, 8, 32), 1), (12, 16, (6, 10, 18), 1), (4, 16, (2, 2, 2), 1)])
-def test_conv3d_winograd(emu, cin, cout, dims, n):
-    """Winograd F(2x2x2, 3x3x3) configuration: full regions, several regions / cout groups, ragged regions."""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_num_configs() - 1
-    assert ops.conv3d_k3_accepts(cfg, cin, cout)
-    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
-    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
-
-
 WINO2D_CASES = [(8, 16, (4, 16, 16), 2), (16, 32, (6, 8, 24), 1), (8, 16, (30, 4, 8), 1), (24, 16, (3, 18, 16), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", WINO2D_CASES)
 def test_conv3d_wino2d(emu, cin, cout, dims, n):
@@ -161,24 +168,6 @@ def test_conv3d_wino2d(emu, cin, cout, dims, n):
 
     cfg = ops.conv3d_k3_num_configs()
     assert ops.conv3d_k3_accepts(cfg, cin, cout)
-    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
-    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
-
-
-@pytest.mark.parametrize("cin,cout,dims,n", [(8, 16, (5, 16, 16), 2), (16, 32, (30, 10, 24), 1)])
-def test_conv3d_wino2d_two_implementations(emu, cin, cout, dims, n):
-    kc.case_wino2d_impls_agree("cpu", n, cin, cout, dims)
-
-
-SPLIT_CASES = [(16, 32, (4, 8, 8), 1), (32, 32, (8, 16, 8), 2), (48, 64, (4, 8, 16), 1), (16, 32, (12, 8, 8), 1), (32, 32, (16, 8, 16), 1)]
-@pytest.mark.parametrize("cin,cout,dims,n", SPLIT_CASES)
-def test_conv3d_split_precision(emu, cin, cout, dims, n):
-    """Experimental configuration: direct implicit GEMM on the bf16 matrix cores, three bf16 pieces per operand and six
-    exact piece products per multiply with fp32 accumulation -- the same tolerance as the fp32 kernels."""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_split_config()
-    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
@@ -195,6 +184,18 @@ def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+
+
+def test_h2_input_scaling(emu):
+    kc.case_h2_input_scaling("cpu")
+
+
+def test_h2_nonfinite_and_missing_bounds(emu):
+    kc.case_h2_nonfinite_and_missing_bounds("cpu")
+
+
+def test_bound_producers(emu):
+    kc.case_bound_producers("cpu")
 
 
 LINEAR_CASES = [(128, 64, 16, False, False), (200, 144, 48, False, True), (66, 40, 36, True, False), (256, 192, 64, True, True)]
@@ -217,23 +218,8 @@ def test_conv_one_input_channel(emu):
     cfg = ops.conv3d_k3_c1_config()
     assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, 1, 32) and not ops.conv3d_k3_accepts(cfg, 2, 32)
     assert ops.conv3d_k3_select(1, 32, 96, 96, 96) == cfg and ops.conv3d_k3_select(1, 32, 9, 9, 9) != cfg       # W % 4
-    saved = os.environ.get("MONAI_AMD_C1")
-    try:
-        os.environ["MONAI_AMD_C1"] = "0"
-        assert 1 <= ops.conv3d_k3_select(1, 32, 96, 96, 96) <= ops.conv3d_k3_num_configs()
-    finally:
-        os.environ.pop("MONAI_AMD_C1", None)
-        if saved is not None:
-            os.environ["MONAI_AMD_C1"] = saved
+    assert 1 <= ops.conv3d_k3_select(1, 32, 96, 96, 96, algo=1) <= ops.conv3d_k3_num_configs()      # MH_ALGO_DIRECT: a matrix-core tile
     kc.case_conv3d("cpu", cfg, 2, 1, 32, (5, 40, 36), with_nrm=False, fused_stats=True)     # partial tiles in x and y, 16 couts per thread
     kc.case_conv3d("cpu", cfg, 1, 1, 24, (3, 8, 8), with_nrm=True, fused_stats=True)        # 8 couts per thread, deferred norm on the input
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)      # two z-chunks (25 planes each)
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)     # no statistics; a second tile row of one line
-
-
-def test_deconv_on_the_matrix_cores(emu):
-    """kernels/nn_simple.h: deconv_k2s2_mfma_kernel (opt-in): every supported Cin, a ragged last tile (voxels % 32 != 0), batches"""
-    kc.case_deconv_mfma("cpu")
-    kc.case_deconv_mfma("cpu", n=1, cin=64, cout=4, dims=(2, 3, 4))          # 24 voxels: one partial wave tile
-    kc.case_deconv_mfma("cpu", n=1, cin=128, cout=12, dims=(1, 5, 12))       # 60 voxels: a full and a partial tile, 3 column chunks
-    kc.case_deconv_mfma("cpu", n=1, cin=256, cout=4, dims=(2, 2, 4))

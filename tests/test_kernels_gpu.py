@@ -118,17 +118,6 @@ def test_strided_conv_and_deconv_k3():
     kc.case_strided_conv_and_deconv_k3(DEV)
 
 
-@pytest.mark.parametrize("cin,cout,dims,n", [(4, 16, (4, 8, 16), 2), (8, 32, (8, 8, 32), 1), (12, 16, (6, 10, 18), 1), (4, 16, (2, 2, 2), 1),
-                                              (32, 32, (48, 48, 48), 2), (64, 32, (24, 24, 24), 1), (128, 64, (12, 12, 12), 1)])
-def test_conv3d_winograd(cin, cout, dims, n):
-    """Winograd F(2x2x2, 3x3x3) on v_mfma_f32_16x16x4_f32: the emulator cases plus BasicUNet layer shapes."""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_num_configs() - 1
-    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
-    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
-
-
 WINO2D_CASES = [(8, 16, (4, 16, 16), 2), (16, 32, (6, 8, 24), 1), (8, 16, (30, 4, 8), 1), (24, 16, (3, 18, 16), 1),
                 (32, 32, (48, 48, 48), 2), (64, 32, (96, 96, 96), 1), (128, 64, (24, 24, 24), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", WINO2D_CASES)
@@ -140,24 +129,6 @@ def test_conv3d_wino2d(cin, cout, dims, n):
     assert ops.conv3d_k3_accepts(cfg, cin, cout)
     kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True, tol=5e-5)
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False, tol=5e-5)
-
-
-@pytest.mark.parametrize("cin,cout,dims,n", [(8, 16, (5, 16, 16), 2), (16, 32, (30, 10, 24), 1), (32, 32, (96, 96, 96), 2), (64, 32, (48, 48, 48), 3)])
-def test_conv3d_wino2d_two_implementations(cin, cout, dims, n):
-    kc.case_wino2d_impls_agree(DEV, n, cin, cout, dims)
-
-
-SPLIT_CASES = [(16, 32, (4, 8, 8), 1), (32, 32, (8, 16, 8), 2), (48, 64, (4, 8, 16), 1), (16, 32, (12, 8, 8), 1), (32, 32, (16, 8, 16), 1), (32, 32, (48, 48, 48), 2), (64, 32, (24, 24, 24), 1)]
-@pytest.mark.parametrize("cin,cout,dims,n", SPLIT_CASES)
-def test_conv3d_split_precision(cin, cout, dims, n):
-    """Experimental configuration: direct implicit GEMM on the bf16 matrix cores, three bf16 pieces per operand and six
-    exact piece products per multiply with fp32 accumulation -- the same tolerance as the fp32 kernels."""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_split_config()
-    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout)
-    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True)
-    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
 H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1)]
@@ -187,6 +158,21 @@ def test_layernorm(m, k):
     kc.case_layernorm(DEV, m, k)
 
 
+def test_h2_input_scaling():
+    """the split-precision convolution at input magnitudes 1e-20 ... 1e20 (incl. > 65504): accuracy of the exact-fp32 tiles"""
+    kc.case_h2_input_scaling(DEV)
+    kc.case_h2_input_scaling(DEV, cin=64, cout=64, dims=(24, 24, 24))
+
+
+def test_h2_nonfinite_and_missing_bounds():
+    kc.case_h2_nonfinite_and_missing_bounds(DEV)
+    kc.case_h2_nonfinite_and_missing_bounds(DEV, cin=48, cout=32, dims=(6, 20, 24))
+
+
+def test_bound_producers():
+    kc.case_bound_producers(DEV)
+
+
 def test_conv_one_input_channel():
     """kernels/conv3d_c1.h on the MI355X: partial tiles, both cout group widths, z-chunks, a full-size window"""
     cfg = ops.conv3d_k3_c1_config()
@@ -196,16 +182,3 @@ def test_conv_one_input_channel():
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)
     kc.case_conv3d(DEV, cfg, 2, 1, 32, (96, 96, 96), with_nrm=False, fused_stats=True)
-
-
-@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_UNVERIFIED_ON_GPU") != "1",
-                    reason="the opt-in matrix-core transposed convolution: its LDS-transposed store path was written after round 2's GPU budget was spent "
-                           "(the pair-exchange form before it passed these cases on the MI355X, profiles/r02_gpu_tests_call127.txt); tools/gpu_runs/r3_first.sh runs it")
-def test_deconv_on_the_matrix_cores():
-    """kernels/nn_simple.h: deconv_k2s2_mfma_kernel (opt-in): every supported Cin, a ragged last tile (voxels % 32 != 0), batches"""
-    kc.case_deconv_mfma(DEV)
-    kc.case_deconv_mfma(DEV, n=1, cin=64, cout=4, dims=(2, 3, 4))          # 24 voxels: one partial wave tile
-    kc.case_deconv_mfma(DEV, n=1, cin=128, cout=12, dims=(1, 5, 12))       # 60 voxels: a full and a partial tile, 3 column chunks
-    kc.case_deconv_mfma(DEV, n=1, cin=256, cout=4, dims=(2, 2, 4))
-    kc.case_deconv_mfma(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
-    kc.case_deconv_mfma(DEV, n=1, cin=256, cout=128, dims=(6, 6, 8))

@@ -29,8 +29,6 @@ def test_dynunet_vs_reference():
     dc.case_dynunet_api(DEV)
 
 
-@pytest.mark.skipif(os.environ.get("MONAI_AMD_TEST_UNVERIFIED_ON_GPU") != "1",
-                    reason="written after round 2's GPU budget was spent (emulator-verified against the real reference's goldens); tools/gpu_runs/r3_first.sh runs it first thing next round")
 def test_dynunet_2d_and_slice_inferer_vs_reference():
     """SURVEY 8 row a9 on the MI355X: a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
     import dynunet_cases as dc

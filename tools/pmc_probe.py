@@ -47,6 +47,7 @@ xn = torch.zeros(B, 32, 4, device=dev)
 xn[:, :, 0] = 1.1
 xn[:, :, 1] = 0.1
 xn[:, :, 2] = 0.1
+xn[:, :, 3] = 8.0          # magnitude bound of the activated input (the split-precision kernel scales by it)
 for cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_num_configs(), 7):
     packed = ops.conv3d_k3_pack(cfg, w)
     tiles = ops.conv3d_k3_stat_tiles(cfg, 96, 96, 96)

@@ -1,4 +1,4 @@
-"""Development aid: time the Winograd configuration against the best direct configuration on BasicUNet layer shapes.
+"""Development aid: time the convolution families (direct fp32 tile, in-plane Winograd, fp16 split precision) on BasicUNet layer shapes.
 MH_LIB=<path to a libmonai_amd.so variant> selects the library (default: the in-tree build)."""
 import json
 import os
@@ -31,7 +31,6 @@ def timeit(fn, iters=4, warm=1):
 
 
 wino2d = ops.conv3d_k3_num_configs()
-wino3d = wino2d - 1
 rows = []
 LAYERS = ((32, 32, 96, 7), (64, 32, 96, 7), (32, 32, 48, 10), (64, 64, 24, 12), (128, 128, 12, 13))
 if os.environ.get("WB_FIRST"):
@@ -45,16 +44,12 @@ for cin, cout, e, direct in LAYERS:
     xn[:, :, 0] = 1.1
     xn[:, :, 1] = 0.1
     xn[:, :, 2] = 0.1
+    xn[:, :, 3] = 8.0          # magnitude bound of the activated randn input (what the split-precision kernel scales by)
     fl = 2.0 * 27 * cin * cout * e ** 3 * B
     row = {"cin": cin, "cout": cout, "edge": e}
-    split = ops.conv3d_k3_split_config()
     h2 = ops.conv3d_k3_h2_config()
-    for name, cfg in (("direct", direct), ("wino3d", wino3d), ("wino2d", wino2d), ("split", split), ("h2", h2)):
+    for name, cfg in (("direct", direct), ("wino2d", wino2d), ("h2", h2)):
         if name == "h2" and os.environ.get("WB_SKIP_H2"):
-            continue
-        if name == "split" and (e % 8 or os.environ.get("WB_SKIP_SPLIT")):
-            continue
-        if name == "wino3d" and not os.environ.get("WB_WINO3D"):
             continue
         if not ops.conv3d_k3_accepts(cfg, cin, cout):
             continue
