@@ -95,6 +95,11 @@ int mh_sw_blend_argmax_f32(const float* logits, int64_t window_stride, const flo
  * merged volume), and the final in-place `values /= counts`.  2-D / 1-D problems pad with leading size-1 axes. */
 int mh_patch_accumulate_f32(float* values, uint8_t* counts, const float* patch, int NC, int D, int H, int W, int pd, int ph,
                             int pw, int z0, int y0, int x0, void* stream);
+/* The same for a whole batch of `npatch` equally sized patches (patches [npatch][NC][pd][ph][pw] dense, loc [npatch][3] HOST int32 (z, y, x)) in one
+ * launch: every merged element adds the patches that cover it in batch order -- the bits of npatch single-patch calls, also where patches of the batch
+ * overlap each other. */
+int mh_patch_accumulate_batch_f32(float* values, uint8_t* counts, const float* patches, int npatch, const int32_t* loc, int NC, int D, int H, int W,
+                                  int pd, int ph, int pw, void* stream);
 int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* stream);
 
 /* ---- network blocks (BasicUNet: monai/networks/nets/basic_unet.py:27-279) -------------------------- */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "mh_last_error": (C.c_char_p, []),
     "mh_window_extract_f32": (_I, [_P, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _I, _I, _I, _I, _P, _P]),
     "mh_patch_accumulate_f32": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "mh_patch_accumulate_batch_f32": (_I, [_P, _P, _P, _I, _IA] + [_I] * 7 + [_P]),
     "mh_avg_finalize_f32": (_I, [_P, _P, C.c_int64, _P]),
     "mh_pointwise_f32": (_I, [_I, _P, _P, _L, _F, _P]),
     "mh_channel_reduce_f32": (_I, [_I, _P, _P, _I, _L, _P]),

@@ -159,6 +159,30 @@ int mh_patch_accumulate_f32(float* values, uint8_t* counts, const float* patch, 
     return launched("patch_accumulate");
 }
 
+int mh_patch_accumulate_batch_f32(float* values, uint8_t* counts, const float* patches, int npatch, const int32_t* loc, int NC, int D, int H, int W, int pd,
+                                  int ph, int pw, void* stream) {
+    if (!values || !counts || !patches || !loc) return fail(MH_ERR_ARG, "patch_accumulate_batch: null pointer");
+    if (NC < 1 || D < 1 || H < 1 || W < 1 || pd < 1 || ph < 1 || pw < 1 || npatch < 1) return fail(MH_ERR_ARG, "patch_accumulate_batch: bad shape");
+    for (int p0 = 0; p0 < npatch; p0 += PATCH_BATCH_MAX) {          // more patches than one launch's argument block holds: consecutive launches keep the order
+        PatchBatch b;
+        b.n = npatch - p0 < PATCH_BATCH_MAX ? npatch - p0 : PATCH_BATCH_MAX;
+        int lo[3] = {D, H, W}, hi[3] = {0, 0, 0};
+        for (int i = 0; i < b.n; ++i) {
+            const int32_t* l = loc + 3 * (p0 + i);
+            if (l[0] < 0 || l[1] < 0 || l[2] < 0 || l[0] + pd > D || l[1] + ph > H || l[2] + pw > W)
+                return fail(MH_ERR_ARG, "patch_accumulate: the patch (%d,%d,%d)+(%d,%d,%d) leaves the merged volume (%d,%d,%d)", l[0], l[1], l[2], pd, ph, pw, D, H, W);
+            b.z[i] = l[0]; b.y[i] = l[1]; b.x[i] = l[2];
+            const int e[3] = {l[0] + pd, l[1] + ph, l[2] + pw};
+            for (int a = 0; a < 3; ++a) { lo[a] = l[a] < lo[a] ? l[a] : lo[a]; hi[a] = e[a] > hi[a] ? e[a] : hi[a]; }
+        }
+        const long long total = (long long)NC * (hi[0] - lo[0]) * (hi[1] - lo[1]) * (hi[2] - lo[2]);
+        if (total > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "patch_accumulate_batch: problem too large for one launch");
+        hipLaunchKernelGGL(patch_accumulate_batch_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, values, counts,
+                           patches + (long long)p0 * NC * pd * ph * pw, NC, D, H, W, pd, ph, pw, b, lo[0], lo[1], lo[2], hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    }
+    return launched("patch_accumulate_batch");
+}
+
 int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* stream) {
     if (!values || !counts || n < 1) return fail(MH_ERR_ARG, "avg_finalize: bad argument");
     if (n > 0x7fffffffLL * 256) return fail(MH_ERR_UNSUPPORTED, "avg_finalize: problem too large for one launch");

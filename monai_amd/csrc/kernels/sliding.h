@@ -339,6 +339,38 @@ patch_accumulate_kernel(float* __restrict__ values, unsigned char* __restrict__ 
     counts[o] = (unsigned char)(counts[o] + 1);
 }
 
+// A whole batch of patches in ONE launch (what a PatchInferer hands over per network call): gather form -- one thread per element of the
+// batch's bounding box in the merged volume walks the patches in batch order and adds those that cover it, so overlapping patches of a
+// batch meet in one thread, in the reference's order (patch by patch): same bits as `np` single-patch launches, no atomics.
+constexpr int PATCH_BATCH_MAX = 64;
+struct PatchBatch {
+    int n;
+    int z[PATCH_BATCH_MAX], y[PATCH_BATCH_MAX], x[PATCH_BATCH_MAX];
+};
+__global__ void __launch_bounds__(256)
+patch_accumulate_batch_kernel(float* __restrict__ values, unsigned char* __restrict__ counts, const float* __restrict__ patches, int NC, int D, int H,
+                              int W, int pd, int ph, int pw, PatchBatch b, int bz0, int by0, int bx0, int bd, int bh, int bw) {
+    const long long bvol = (long long)bd * bh * bw;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= bvol * NC) return;
+    const long long c = idx / bvol, r = idx - c * bvol;
+    const int x = bx0 + (int)(r % bw), y = by0 + (int)((r / bw) % bh), z = bz0 + (int)(r / ((long long)bw * bh));
+    const long long o = ((c * D + z) * H + y) * W + x;
+    const long long pvol = (long long)pd * ph * pw;
+    float v = values[o];
+    unsigned cnt = counts[o];
+    bool hit = false;
+    for (int p = 0; p < b.n; ++p) {
+        const int lz = z - b.z[p], ly = y - b.y[p], lx = x - b.x[p];
+        if (lz >= 0 && lz < pd && ly >= 0 && ly < ph && lx >= 0 && lx < pw) {
+            v += patches[((long long)p * NC + c) * pvol + ((long long)lz * ph + ly) * pw + lx];
+            ++cnt;
+            hit = true;
+        }
+    }
+    if (hit) { values[o] = v; counts[o] = (unsigned char)cnt; }
+}
+
 __global__ void __launch_bounds__(256)
 avg_finalize_kernel(float* __restrict__ values, const unsigned char* __restrict__ counts, long long n) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;

@@ -2,6 +2,7 @@
 
 from __future__ import annotations
 
+import itertools
 import warnings
 from abc import ABC, abstractmethod
 from collections.abc import Callable, Sequence
@@ -26,10 +27,56 @@ class Inferer(ABC):
         raise NotImplementedError(f"Subclass {self.__class__.__name__} must implement this method.")
 
 
+class _Sink:
+    """One network output on its way into a merged volume: the Merger, the output / input resolution ratio, and how a batch of
+    output patches reaches the merger -- in one kernel launch when the merger can take batches (AvgMerger on the device), patch by
+    patch through the public ``Merger.aggregate`` otherwise."""
+
+    def __init__(self, merger: Merger, ratio: tuple):
+        self.merger, self.ratio = merger, ratio
+
+    def place(self, location) -> list:
+        return [round(v * r) for v, r in zip(location, self.ratio)]
+
+    def add(self, out_batch: torch.Tensor, locations: Sequence) -> None:
+        where = [self.place(loc) for loc in locations]
+        if hasattr(self.merger, "aggregate_batch"):
+            self.merger.aggregate_batch(out_batch, where)
+            return
+        for out_patch, loc in zip(torch.chunk(out_batch, len(where)), where):
+            self.merger.aggregate(out_patch, loc)
+
+
+def _resolve_merger_class(merger_cls):
+    """a Merger subclass, or its name: in this package's merger module first, then as a dotted path (inferer.py:153-163)"""
+    if isinstance(merger_cls, str):
+        from pydoc import locate
+
+        from . import merger as here
+
+        found = getattr(here, merger_cls, None) or locate(merger_cls)
+        if found is None:
+            raise ValueError(f"The requested `merger_cls` ['{merger_cls}'] does not exist.")
+        merger_cls = found
+    if not (isinstance(merger_cls, type) and issubclass(merger_cls, Merger)):
+        raise TypeError(f"'merger' should be a subclass of `Merger`, {merger_cls} is given.")
+    return merger_cls
+
+
+def _require_callable_or_none(fn, what: str) -> None:
+    if fn is not None and not callable(fn):
+        raise TypeError(f"'{what}' should be a callable object, {type(fn)} is given.")
+
+
 class PatchInferer(Inferer):
     """Inference on patches: ``splitter`` -> batches of patches -> ``network`` -> one ``Merger`` per output.  Drop-in for
-    monai/inferers/inferer.py:100-370 with the same arguments; ``buffer_size`` (a prefetch thread in the reference) is
-    accepted and has no effect here -- the patches are views of a tensor that is already in HBM."""
+    monai/inferers/inferer.py:100-370 (same arguments, outputs pinned bit for bit by tests/golden/patch_inferer.npz and by the
+    reference's own tests/inferers/test_patch_inferer.py).  Own design: the patch stream is a generator of (batch, locations) --
+    from ``SlidingWindowSplitter.split_batches`` (one gather launch for all patches, contiguous batch slices), from any other
+    ``Splitter`` by grouping its pairs, or from already split inputs -- and each network output flows into a ``_Sink`` that hands a
+    whole batch of output patches to the merger in ONE launch (``AvgMerger.aggregate_batch`` -> ``mh_patch_accumulate_batch_f32``,
+    in patch order: the reference's bits).  ``buffer_size`` (a prefetch thread in the reference) is accepted and has no effect --
+    the patches are already in HBM."""
 
     def __init__(
         self,
@@ -44,140 +91,109 @@ class PatchInferer(Inferer):
         **merger_kwargs: Any,
     ) -> None:
         Inferer.__init__(self)
-        if not isinstance(splitter, (Splitter, type(None))):
-            raise TypeError(
-                "'splitter' should be a `Splitter` object that returns: "
-                "an iterable of pairs of (patch, location) or a MetaTensor that has `PatchKeys.LOCATION` metadata)."
-                f"{type(splitter)} is given."
-            )
-        self.splitter = splitter
-        if isinstance(merger_cls, str):
-            from pydoc import locate
-
-            from . import merger as _merger_mod
-
-            found = getattr(_merger_mod, merger_cls, None) or locate(merger_cls)
-            if found is None:
-                raise ValueError(f"The requested `merger_cls` ['{merger_cls}'] does not exist.")
-            merger_cls = found
-        if not (isinstance(merger_cls, type) and issubclass(merger_cls, Merger)):
-            raise TypeError(f"'merger' should be a subclass of `Merger`, {merger_cls} is given.")
-        self.merger_cls = merger_cls
-        self.merger_kwargs = merger_kwargs
-        if preprocessing is not None and not callable(preprocessing):
-            raise TypeError(f"'preprocessing' should be a callable object, {type(preprocessing)} is given.")
-        self.preprocessing = preprocessing
-        if postprocessing is not None and not callable(postprocessing):
-            raise TypeError(f"'postprocessing' should be a callable object, {type(postprocessing)} is given.")
-        self.postprocessing = postprocessing
+        if splitter is not None and not isinstance(splitter, Splitter):
+            raise TypeError("'splitter' should be a `Splitter` object that returns: "
+                            "an iterable of pairs of (patch, location) or a MetaTensor that has `PatchKeys.LOCATION` metadata)."
+                            f"{type(splitter)} is given.")
+        self.merger_cls = _resolve_merger_class(merger_cls)
+        _require_callable_or_none(preprocessing, "preprocessing")
+        _require_callable_or_none(postprocessing, "postprocessing")
         if batch_size < 1:
             raise ValueError(f"`batch_size` must be a positive number, {batch_size} is given.")
-        self.batch_size = batch_size
-        self.output_keys = output_keys
-        self.match_spatial_shape = match_spatial_shape
-        self.buffer_size = buffer_size
+        self.splitter, self.merger_kwargs = splitter, merger_kwargs
+        self.preprocessing, self.postprocessing = preprocessing, postprocessing
+        self.batch_size, self.output_keys = batch_size, output_keys
+        self.match_spatial_shape, self.buffer_size = match_spatial_shape, buffer_size
 
-    def _batch_sampler(self, patches):
-        """(batch of patches, their locations, number of patches in the batch)."""
-        if hasattr(patches, "meta") and isinstance(patches, torch.Tensor):     # MetaTensor of already split patches
-            total = len(patches)
-            for i in range(0, total, self.batch_size):
-                n = min(self.batch_size, total - i)
-                yield patches[i : i + n], patches[i : i + n].meta["location"], n
+    # ---- the patch stream ----------------------------------------------------------------------------
+    def _stream(self, inputs):
+        """generator of (patches [n * B, C, ...], n locations)"""
+        if self.splitter is not None:
+            if hasattr(self.splitter, "split_batches"):
+                yield from self.splitter.split_batches(inputs, self.batch_size)
+                return
+            pairs = self.splitter(inputs)
+        elif isinstance(inputs, torch.Tensor):
+            # already split: a MetaTensor whose metadata carries the locations (PatchKeys.LOCATION)
+            if not hasattr(inputs, "meta"):
+                raise ValueError("`splitter` should be set if the input is not already split into patches. "
+                                 "For inputs that are split, the location of patches needs to be provided as "
+                                 "(image, location) pairs, or as `PatchKey.LOCATION` metadata in a MetaTensor. "
+                                 f"The provided inputs type is {type(inputs)}.")
+            if "location" not in inputs.meta:
+                raise ValueError("`PatchKey.LOCATION` does not exists in `inputs.meta`. "
+                                 "If the inputs are already split into patches, the location of patches needs to be "
+                                 "provided as `PatchKey.LOCATION` metadata in a MetaTensor. "
+                                 "If the input is not already split, please provide `splitter`.")
+            for i in range(0, len(inputs), self.batch_size):
+                part = inputs[i : i + self.batch_size]
+                yield part, part.meta["location"]
             return
-        batch, locs = [], []
-        for patch, loc in patches:
-            batch.append(patch)
-            locs.append(loc)
-            if len(batch) == self.batch_size:
-                yield torch.cat(batch), locs, len(batch)
-                batch, locs = [], []
-        if batch:
-            yield torch.cat(batch), locs, len(batch)
+        else:
+            pairs = inputs                                              # an iterable of (patch, location)
+        it = iter(pairs)
+        while True:
+            group = list(itertools.islice(it, self.batch_size))
+            if not group:
+                return
+            yield (torch.cat([g[0] for g in group]) if len(group) > 1 else group[0][0]), [g[1] for g in group]
 
-    def _ensure_tuple_outputs(self, outputs: Any) -> tuple:
-        if isinstance(outputs, dict):
-            if self.output_keys is None:
-                self.output_keys = list(outputs.keys())
-            return tuple(outputs[k] for k in self.output_keys)
-        return tuple(outputs) if isinstance(outputs, (list, tuple)) else (outputs,)
-
-    def _run_inference(self, network: Callable, patch: torch.Tensor, *args: Any, **kwargs: Any) -> tuple:
+    def _forward(self, network: Callable, patches: torch.Tensor, args, kwargs) -> tuple:
         if self.preprocessing:
-            patch = self.preprocessing(patch)
-        outputs = network(patch, *args, **kwargs)
+            patches = self.preprocessing(patches)
+        result = network(patches, *args, **kwargs)
         if self.postprocessing:
-            outputs = self.postprocessing(outputs)
-        return self._ensure_tuple_outputs(outputs)
+            result = self.postprocessing(result)
+        if isinstance(result, dict):
+            if self.output_keys is None:
+                self.output_keys = list(result.keys())
+            return tuple(result[k] for k in self.output_keys)
+        return tuple(result) if isinstance(result, (list, tuple)) else (result,)
 
-    def _get_merged_shapes(self, inputs, out_patch, ratio):
-        if self.splitter is None:
-            return None, None
-        original = self.splitter.get_input_shape(inputs)
-        padded = self.splitter.get_padded_shape(inputs)
-        cropped_shape = tuple(out_patch.shape[:2]) + tuple(round(s * r) for s, r in zip(original, ratio))
-        merged_shape = tuple(out_patch.shape[:2]) + tuple(round(s * r) for s, r in zip(padded, ratio))
-        if not self.match_spatial_shape:
-            cropped_shape = merged_shape
-        return cropped_shape, merged_shape
-
-    def _initialize_mergers(self, inputs, outputs, patches, batch_size):
-        in_patch = torch.chunk(patches, batch_size)[0]
-        mergers, ratios = [], []
-        for out_patch_batch in outputs:
-            out_patch = torch.chunk(out_patch_batch, batch_size)[0]
-            ratio = tuple(op / ip for ip, op in zip(in_patch.shape[2:], out_patch.shape[2:]))
-            merger_kwargs = self.merger_kwargs.copy()
-            cropped_shape, merged_shape = self._get_merged_shapes(inputs, out_patch, ratio)
-            if "merged_shape" not in merger_kwargs:
-                merger_kwargs["merged_shape"] = merged_shape
-                if merger_kwargs["merged_shape"] is None:
-                    raise ValueError("`merged_shape` cannot be `None`.")
-            if "cropped_shape" not in merger_kwargs:
-                merger_kwargs["cropped_shape"] = cropped_shape
-            mergers.append(self.merger_cls(**merger_kwargs))
-            ratios.append(ratio)
-        return mergers, ratios
-
-    def _aggregate(self, outputs, locations, batch_size, mergers, ratios):
-        for output_patches, merger, ratio in zip(outputs, mergers, ratios):
-            for in_loc, out_patch in zip(locations, torch.chunk(output_patches, batch_size)):
-                merger.aggregate(out_patch, [round(l * r) for l, r in zip(in_loc, ratio)])
+    def _open_sinks(self, inputs, patches: torch.Tensor, outputs: tuple, n: int) -> list:
+        """one Merger per output, sized from the first batch: the output / input patch extents give the resolution ratio, the splitter
+        the original and the padded extent of the whole input"""
+        sinks = []
+        in_extent = patches.shape[2:]
+        for out in outputs:
+            lead = (out.shape[0] // n, out.shape[1])
+            ratio = tuple(o / i for i, o in zip(in_extent, out.shape[2:]))
+            kw = dict(self.merger_kwargs)
+            if self.splitter is not None:
+                full = lead + tuple(round(v * r) for v, r in zip(self.splitter.get_padded_shape(inputs), ratio))
+                crop = lead + tuple(round(v * r) for v, r in zip(self.splitter.get_input_shape(inputs), ratio))
+                kw.setdefault("merged_shape", full)
+                kw.setdefault("cropped_shape", crop if self.match_spatial_shape else full)
+            elif "merged_shape" not in kw:
+                raise ValueError("`merged_shape` cannot be `None`.")
+            sinks.append(_Sink(self.merger_cls(**kw), ratio))
+        return sinks
 
     def __call__(self, inputs, network: Callable, *args: Any, **kwargs: Any) -> Any:
-        if self.splitter is None:
-            if isinstance(inputs, torch.Tensor):
-                if hasattr(inputs, "meta"):
-                    if "location" not in inputs.meta:
-                        raise ValueError(
-                            "`PatchKey.LOCATION` does not exists in `inputs.meta`. "
-                            "If the inputs are already split into patches, the location of patches needs to be "
-                            "provided as `PatchKey.LOCATION` metadata in a MetaTensor. "
-                            "If the input is not already split, please provide `splitter`."
-                        )
-                else:
-                    raise ValueError(
-                        "`splitter` should be set if the input is not already split into patches. "
-                        "For inputs that are split, the location of patches needs to be provided as "
-                        "(image, location) pairs, or as `PatchKey.LOCATION` metadata in a MetaTensor. "
-                        f"The provided inputs type is {type(inputs)}."
-                    )
-            patches_locations = inputs
-        else:
-            patches_locations = self.splitter(inputs)
-        ratios: list = []
-        mergers: list = []
-        for patches, locations, batch_size in self._batch_sampler(patches_locations):
-            outputs = self._run_inference(network, patches, *args, **kwargs)
-            if not mergers:
-                mergers, ratios = self._initialize_mergers(inputs, outputs, patches, batch_size)
-            self._aggregate(outputs, locations, batch_size, mergers, ratios)
-        merged_outputs = [merger.finalize() for merger in mergers]
+        sinks: list = []
+        for patches, locations in self._stream(inputs):
+            outputs = self._forward(network, patches, args, kwargs)
+            if not sinks:
+                sinks = self._open_sinks(inputs, patches, outputs, len(locations))
+            for sink, out in zip(sinks, outputs):
+                sink.add(out, locations)
+        merged = [sink.merger.finalize() for sink in sinks]
         if self.output_keys:
-            return dict(zip(self.output_keys, merged_outputs))
-        if len(merged_outputs) == 1:
-            return merged_outputs[0]
-        return merged_outputs
+            return dict(zip(self.output_keys, merged))
+        return merged[0] if len(merged) == 1 else merged
+
+
+# constructor arguments of SlidingWindowInferer that are also arguments of sliding_window_inference (+ cpu_thresh), in positional order
+_SW_ARGS = ("roi_size", "sw_batch_size", "overlap", "mode", "sigma_scale", "padding_mode", "cval", "sw_device", "device", "progress", "cpu_thresh",
+            "buffer_steps", "buffer_dim", "with_coord")
+
+
+def _positional_call(inputs, network, inf, per_call, args, kwargs):
+    """Everything positional: extra positional arguments for the network travel behind sliding_window_inference's 17 own positionals
+    (utils.py:42-62), and a network keyword that happens to be called like one of them (``mode=...``) stays the network's."""
+    return sliding_window_inference(inputs, inf.roi_size, inf.sw_batch_size, network, inf.overlap, inf.mode, inf.sigma_scale, inf.padding_mode, inf.cval,
+                                    inf.sw_device, per_call["device"], inf.progress, inf.roi_weight_map, None, per_call["buffer_steps"],
+                                    per_call["buffer_dim"], inf.with_coord, *args, **kwargs)
 
 
 class SlidingWindowInferer(Inferer):
@@ -212,64 +228,36 @@ class SlidingWindowInferer(Inferer):
         buffer_dim: int = -1,
         with_coord: bool = False,
     ) -> None:
-        super().__init__()
-        self.roi_size = roi_size
-        self.sw_batch_size = sw_batch_size
-        self.overlap = overlap
-        self.mode = look_up_option(mode, ("constant", "gaussian"), "mode")  # ValueError on anything else, like BlendMode(mode)
-        self.sigma_scale = sigma_scale
-        self.padding_mode = padding_mode
-        self.cval = cval
-        self.sw_device = sw_device
-        self.device = device
-        self.progress = progress
-        self.cpu_thresh = cpu_thresh
-        self.buffer_steps = buffer_steps
-        self.buffer_dim = buffer_dim
-        self.with_coord = with_coord
+        Inferer.__init__(self)
+        mode = look_up_option(mode, ("constant", "gaussian"), "mode")      # ValueError on anything else, like the reference's BlendMode(mode)
+        # the public attributes of the reference object (bundles and SliceInferer read and rewrite them), in its positional order
+        for name, value in zip(_SW_ARGS, (roi_size, sw_batch_size, overlap, mode, sigma_scale, padding_mode, cval, sw_device, device, progress,
+                                          cpu_thresh, buffer_steps, buffer_dim, with_coord)):
+            setattr(self, name, value)
+        self.roi_weight_map = self._cached_weight_map() if cache_roi_weight_map else None
 
-        # the weight map of a static roi can be computed once (inferer.py:488-505)
-        self.roi_weight_map = None
+    def _cached_weight_map(self):
+        """``cache_roi_weight_map=True``: the importance map of a static roi, evaluated once on the host (inferer.py:488-505); a roi with a
+        non-positive entry is resolved per image, so nothing can be cached for it -- the reference's warning"""
+        roi = self.roi_size
+        if not (isinstance(roi, Sequence) and min(roi) > 0):
+            warnings.warn("cache_roi_weight_map=True, but cache is not created. (dynamic roi_size?)")
+            return None
         try:
-            if cache_roi_weight_map and isinstance(roi_size, Sequence) and min(roi_size) > 0:
-                self.roi_weight_map = compute_importance_map(ensure_tuple(self.roi_size), mode=mode, sigma_scale=sigma_scale, device="cpu")
-            if cache_roi_weight_map and self.roi_weight_map is None:
-                warnings.warn("cache_roi_weight_map=True, but cache is not created. (dynamic roi_size?)")
+            return compute_importance_map(ensure_tuple(roi), mode=self.mode, sigma_scale=self.sigma_scale, device="cpu")
         except BaseException as e:
-            raise RuntimeError(
-                f"roi size {self.roi_size}, mode={mode}, sigma_scale={sigma_scale}, device={device}\n"
-                "Seems to be OOM. Please try smaller patch size or mode='constant' instead of mode='gaussian'."
-            ) from e
+            raise RuntimeError(f"roi size {roi}, mode={self.mode}, sigma_scale={self.sigma_scale}, device={self.device}\n"
+                               "Seems to be OOM. Please try smaller patch size or mode='constant' instead of mode='gaussian'.") from e
+
+    def _too_large_for_device_output(self, inputs: torch.Tensor) -> bool:
+        return self.cpu_thresh is not None and inputs.shape[2:].numel() > self.cpu_thresh
 
     def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
         """``device`` / ``buffer_steps`` / ``buffer_dim`` may be overridden per call (inferer.py:525-527)."""
-        device = kwargs.pop("device", self.device)
-        buffer_steps = kwargs.pop("buffer_steps", self.buffer_steps)
-        buffer_dim = kwargs.pop("buffer_dim", self.buffer_dim)
-        if device is None and self.cpu_thresh is not None and inputs.shape[2:].numel() > self.cpu_thresh:
-            device = "cpu"  # hand the stitched volume back in host memory for very large images
-        return sliding_window_inference(
-            inputs,
-            self.roi_size,
-            self.sw_batch_size,
-            network,
-            self.overlap,
-            self.mode,
-            self.sigma_scale,
-            self.padding_mode,
-            self.cval,
-            self.sw_device,
-            device,
-            self.progress,
-            self.roi_weight_map,
-            None,
-            buffer_steps,
-            buffer_dim,
-            self.with_coord,
-            *args,
-            **kwargs,
-        )
-
+        per_call = {k: kwargs.pop(k, getattr(self, k)) for k in ("device", "buffer_steps", "buffer_dim")}
+        if per_call["device"] is None and self._too_large_for_device_output(inputs):
+            per_call["device"] = "cpu"             # hand the stitched volume back in host memory for very large images
+        return _positional_call(inputs, network, self, per_call, args, kwargs)
 
     def argmax(self, inputs: torch.Tensor, network: Callable, *args: Any, labels_dtype=torch.float32, **kwargs: Any):
         """``AsDiscrete(argmax=True)(self(inputs, network))`` per batch element with the argmax fused into the blend epilogue
@@ -299,21 +287,19 @@ class SlidingWindowInfererAdapt(SlidingWindowInferer):
     image of that size goes there directly -- the same externally visible behaviour (the output may land on the CPU)."""
 
     def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
-        if self.device is not None:
-            return super().__call__(inputs, network, *args, **kwargs)
-        cpu_cond = self.cpu_thresh is not None and inputs.shape[2:].numel() > self.cpu_thresh
-        gpu_stitching = inputs.is_cuda and not cpu_cond
-        for _ in range(2):
+        if self.device is not None:                # the caller fixed the output device: nothing to adapt
+            return SlidingWindowInferer.__call__(self, inputs, network, *args, **kwargs)
+        rungs = [inputs.device] if (inputs.is_cuda and not self._too_large_for_device_output(inputs)) else []
+        rungs.append(torch.device("cpu"))
+        for i, where in enumerate(rungs):
             try:
-                return super().__call__(inputs, network, *args, device=inputs.device if gpu_stitching else torch.device("cpu"), **kwargs)
-            except RuntimeError as e:
-                if not gpu_stitching or "OutOfMemoryError" not in type(e).__name__:
+                return SlidingWindowInferer.__call__(self, inputs, network, *args, device=where, **kwargs)
+            except RuntimeError as err:
+                if i + 1 == len(rungs) or "OutOfMemoryError" not in type(err).__name__:
                     raise
                 warnings.warn(f"GPU stitching failed, attempting on CPU, image dim {tuple(inputs.shape)}.")
-                gpu_stitching = False
-                self.cpu_thresh = inputs.shape[2:].numel() - 1
+                self.cpu_thresh = inputs.shape[2:].numel() - 1      # the next image of this size goes to the host rung directly
                 torch.cuda.empty_cache()
-        raise RuntimeError(f"SlidingWindowInfererAdapt could not finish: cpu_cond={cpu_cond} gpu_stitching={gpu_stitching}")
 
 
 class SliceInferer(SlidingWindowInferer):
@@ -321,30 +307,31 @@ class SliceInferer(SlidingWindowInferer):
     singleton inserted at ``spatial_dim`` and the network sees the windows with that axis squeezed."""
 
     def __init__(self, spatial_dim: int = 0, *args: Any, **kwargs: Any) -> None:
-        self.spatial_dim = spatial_dim
-        super().__init__(*args, **kwargs)
-        self.orig_roi_size = ensure_tuple(self.roi_size)
+        SlidingWindowInferer.__init__(self, *args, **kwargs)
+        self.spatial_dim, self.orig_roi_size = spatial_dim, ensure_tuple(self.roi_size)
 
     def __call__(self, inputs: torch.Tensor, network: Callable, *args: Any, **kwargs: Any):
-        if self.spatial_dim > 2:
+        axis = self.spatial_dim
+        if axis > 2:
             raise ValueError("`spatial_dim` can only be `0, 1, 2` with `[H, W, D]` respectively.")
-        self.roi_size = ensure_tuple(self.roi_size)
-        if len(self.orig_roi_size) == 2 and len(inputs.shape[2:]) == 3:
-            self.roi_size = list(self.orig_roi_size)
-            self.roi_size.insert(self.spatial_dim, 1)
-        else:
-            raise RuntimeError(
-                f"Currently, only 2D `roi_size` ({self.orig_roi_size}) with 3D `inputs` tensor (shape={inputs.shape}) is supported."
-            )
-        return super().__call__(inputs=inputs, network=lambda x: self.network_wrapper(network, x, *args, **kwargs))
+        if len(self.orig_roi_size) != 2 or inputs.dim() != 5:
+            raise RuntimeError(f"Currently, only 2D `roi_size` ({self.orig_roi_size}) with 3D `inputs` tensor (shape={inputs.shape}) is supported.")
+        plane = self.orig_roi_size
+        self.roi_size = list(plane[:axis]) + [1] + list(plane[axis:])          # one slice thick along `spatial_dim`
+
+        def on_slices(windows):
+            return self.network_wrapper(network, windows, *args, **kwargs)
+
+        return SlidingWindowInferer.__call__(self, inputs=inputs, network=on_slices)
 
     def network_wrapper(self, network: Callable, x: torch.Tensor, *args: Any, **kwargs: Any):
+        """the 2-D network sees the windows without their singleton axis; whatever it returns (tensor, mapping, sequence) gets the axis back"""
         from collections.abc import Mapping
 
-        x = x.squeeze(dim=self.spatial_dim + 2)
-        out = network(x, *args, **kwargs)
-        if isinstance(out, torch.Tensor):
-            return out.unsqueeze(dim=self.spatial_dim + 2)
-        if isinstance(out, Mapping):
-            return {k: v.unsqueeze(dim=self.spatial_dim + 2) for k, v in out.items()}
-        return tuple(o.unsqueeze(dim=self.spatial_dim + 2) for o in out)
+        at = self.spatial_dim + 2
+        result = network(x.squeeze(dim=at), *args, **kwargs)
+        if isinstance(result, Mapping):
+            return {key: value.unsqueeze(dim=at) for key, value in result.items()}
+        if isinstance(result, torch.Tensor):
+            return result.unsqueeze(dim=at)
+        return tuple(value.unsqueeze(dim=at) for value in result)

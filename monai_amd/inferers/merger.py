@@ -72,6 +72,15 @@ class AvgMerger(Merger):
             self._allocate(values.device)
         ops.patch_accumulate(self.values, self.counts, values.to(self.value_dtype).contiguous(), location)
 
+    def aggregate_batch(self, values: torch.Tensor, locations: Sequence[Sequence[int]]) -> None:
+        """Extension over the reference API: ``len(locations)`` patches at once (``values`` = their torch.cat), accumulated by ONE kernel launch in
+        patch order -- bit-identical to ``aggregate`` called patch by patch, also where patches of the batch overlap each other."""
+        if self.is_finalized:
+            raise ValueError("`AvgMerger` is already finalized. Please instantiate a new object to aggregate.")
+        if self.values is None:
+            self._allocate(values.device)
+        ops.patch_accumulate_batch(self.values, self.counts, values.to(self.value_dtype).contiguous(), locations)
+
     def finalize(self) -> torch.Tensor:
         """values /= counts, cropped to ``cropped_shape``; idempotent like the reference's."""
         if not self.is_finalized:

@@ -135,6 +135,25 @@ def patch_accumulate(values: torch.Tensor, counts: torch.Tensor, patch: torch.Te
                     *v3, *p3, *l3, _s(values))
 
 
+def patch_accumulate_batch(values: torch.Tensor, counts: torch.Tensor, patches: torch.Tensor, locations: Sequence[Sequence[int]]) -> None:
+    """AvgMerger.aggregate for a whole batch in one launch: `patches` [npatch * B, C, spatial] (the network's output for npatch patches of a
+    [B, C, ...] image, i.e. torch.cat order), `locations` npatch start tuples; same bits as npatch `patch_accumulate` calls in that order."""
+    _lib.require_device(values, patches)
+    _lib.require_device(counts, dtypes=(torch.uint8,))
+    if not (values.is_contiguous() and counts.is_contiguous() and patches.is_contiguous()):
+        raise RuntimeError("monai_amd.patch_accumulate_batch: contiguous tensors required")
+    sd, npatch = values.dim() - 2, len(locations)
+    if (sd < 1 or sd > 3 or patches.dim() != values.dim() or npatch < 1 or patches.shape[0] != npatch * values.shape[0] or patches.shape[1] != values.shape[1]
+            or counts.shape != values.shape):
+        raise RuntimeError(f"monai_amd.patch_accumulate_batch: shapes {tuple(values.shape)} / {tuple(counts.shape)} / {tuple(patches.shape)} x {npatch} do not match")
+    pad = 3 - sd
+    v3 = [1] * pad + [int(v) for v in values.shape[2:]]
+    p3 = [1] * pad + [int(v) for v in patches.shape[2:]]
+    flat = [int(v) for loc in locations for v in ([0] * pad + list(loc))]
+    _lib.lib().call("mh_patch_accumulate_batch_f32", _lib.ptr(values), _lib.ptr(counts), _lib.ptr(patches), npatch, _lib.int_array(flat),
+                    int(values.shape[0] * values.shape[1]), *v3, *p3, _s(values))
+
+
 def avg_finalize(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     """AvgMerger.finalize: values /= counts, in place."""
     _lib.require_device(values)

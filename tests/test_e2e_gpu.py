@@ -259,6 +259,7 @@ def test_patch_inferer_vs_reference():
 
     print("cases", pc.case_patch_inferer_vs_reference(DEV))
     pc.case_patch_inferer_api(DEV)
+    pc.case_gathered_split_and_batched_merge(DEV)
 
 
 def test_bundle_shaped_pipeline_vs_reference():

@@ -101,6 +101,12 @@ def test_patch_inferer_vs_reference(emu):
     print("cases", pc.case_patch_inferer_vs_reference("cpu"))
 
 
+def test_gathered_split_and_batched_merge(emu):
+    import patch_cases as pc
+
+    pc.case_gathered_split_and_batched_merge("cpu")
+
+
 def test_patch_inferer_api(emu):
     import patch_cases as pc
 
