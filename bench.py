@@ -11,16 +11,17 @@ all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + nor
 in HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2 of
 BASELINE.json).  Rank 0 prints ONE JSON line:
 
-  roofline      the dominant kernel (the Winograd 3x3x3 convolution of the 96^3 / 48^3 levels), HIP events around its
-                launches inside the timed region: `achieved` = matrix-core flops ISSUED per launch / average launch time,
-                `frac` = achieved / fp32-MFMA peak (a true fraction); the convolution's own (direct) flops are
-                `algorithmic_tflops`, their ratio is Winograd's 2.25x;
-  roofline_hbm  the blend: 20.38 GB of algorithmic traffic / its launch time, against the 8 TB/s spec; the
-                streaming ceilings of this chip are measured by tools/ubench/hbm_stream.hip (profiles/r02_ubench_hbm_stream_*.txt);
+  roofline      the dominant kernel (the split-precision 3x3x3 convolution), HIP events around its launches inside the timed
+                region: `achieved` = matrix-core flops ISSUED per launch / average launch time, `frac` = achieved / the dense
+                MFMA peak of the instruction it issues (a true fraction); the convolution's own flops are `algorithmic_tflops`;
+  roofline_hbm  the blend: 20.38 GB of algorithmic traffic (SURVEY.md 8d) / its launch time, against the 8 TB/s spec;
   cpu_baseline  the CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
-                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on a 12-window
-                sub-volume of the benchmark volume on the host cores, extrapolated per window; the same sub-volume goes
-                through the HIP path and `parity_vs_gpu` reports the headline parity rule (oracle/parity.py).
+                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on a 288^3 corner of the
+                benchmark volume = 125 windows on the host cores, extrapolated per window; the same sub-volume goes through the
+                HIP path and `parity_vs_gpu` reports the headline parity rule (oracle/parity.py);
+  extra         (N = 1) fp32_exact: the same workload with the exact-fp32 convolution kernels (config CONV_ALGO "fp32") and its parity
+                on the same 125 windows; config3: UNETR ViT-B/16 on the same volume (attention kernel's MFMA rate, one-window parity
+                vs the oracle); config4: Spacing + GaussianSmooth on 4 x 512^3 (kernel times against 8 TB/s, parity on a 128^3 volume).
 """
 
 from __future__ import annotations
@@ -66,7 +67,7 @@ def sub_volume_extents(size: int, roi: int, windows: int):
     return tuple(min(size, roi + (c - 1) * step) for c in counts)
 
 
-def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer):
+def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer, more=None):
     """CPU oracle = port of the reference path (kind "port"): the complete sliding-window inference -- window loop, BasicUNet,
     importance-weighted blend -- of a corner sub-volume of the benchmark volume on the host cores; value = size^3 voxels /
     (windows of the full volume x measured time per window).  `torch.set_num_threads(os.cpu_count())` oversubscribes oneDNN on
@@ -103,6 +104,8 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
         ref = oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
         dt = time.perf_counter() - t0
         got = inferer(sub, net)
+    if more is not None:            # the same reference for other arithmetic families of the product (extra.fp32_exact)
+        more["ref"], more["sub"], more["what"] = ref, sub, f"{ext[0]}x{ext[1]}x{ext[2]} corner sub-volume, {nsub} windows"
     parity = oracle.label_parity(got, ref, tol=1e-4)
     parity["compared"] = (f"complete inferer output (blended logits) of the {ext[0]}x{ext[1]}x{ext[2]} corner sub-volume, {nsub} windows; rule: max|dlogit| <= 1e-4 and "
                           "every argmax difference at a voxel whose oracle top-2 margin < 2 max|dlogit| (mismatch_outside_margin == 0)")
@@ -128,12 +131,242 @@ def pmc_traffic(kernel_key: str):
             with open(os.path.join(pdir, name)) as f:
                 k = json.load(f)["kernels"].get(kernel_key)
             if k is not None:
-                return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
+                return {"measured": "from_file (a builder-run rocprofv3 --pmc pass of an earlier round; counters cannot be collected inside this process)",
+                        "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
                         "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"], "measured_on": k.get("measured_on", "the bench configuration"),
                         "source": "profiles/" + name.replace(".json", ".txt")}
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def build_net(name: str, roi: int, dev):
+    from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, SwinUNETR, UNet
+
+    torch.manual_seed(1)       # weights exactly as SURVEY.md 8(d) config 1 / 3
+    if name == "swinunetr":
+        net = SwinUNETR(in_channels=1, out_channels=5, feature_size=48)
+    elif name == "unetr":
+        net = UNETR(in_channels=1, out_channels=5, img_size=(roi,) * 3)
+    elif name == "unet":
+        net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2)
+    elif name == "dynunet":
+        net = DynUNet(spatial_dims=3, in_channels=1, out_channels=5, kernel_size=[3] * 5, strides=[1, 2, 2, 2, 2], upsample_kernel_size=[2] * 4)
+    elif name == "segresnet":
+        net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=5)
+    else:
+        net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5)
+    return net.eval().to(dev)
+
+
+def timed_steps(inferer, vol, net, steps: int, warmup: int, sync):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronise on both sides"""
+    from monai_amd import _prof
+
+    out = None
+    for _ in range(warmup):
+        out = inferer(vol, net)
+    sync()
+    _prof.start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = inferer(vol, net)
+    sync()
+    dt = time.perf_counter() - t0
+    return dt, _prof.stop(), out
+
+
+def conv_roofline(spans, steps: int, ms: float, roi: int):
+    """the 3x3x3 convolution configuration with the largest share of the step, priced against the peak of the matrix instruction it issues"""
+    from monai_amd import ops as _ops
+
+    convs = {k: v for k, v in spans.items() if k.startswith("conv3d_k3/")}
+    if not convs:
+        return None
+    key, conv = max(convs.items(), key=lambda kv: kv[1]["ms_total"])
+    tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12          # the convolution's own flops: 2 * 27 * Cin * Cout per voxel
+    cfg_id = int(key.split("/cfg")[1])
+    ncfg = _ops.conv3d_k3_num_configs()
+    peak, extra, pmc_key = PEAK_FP32_TFLOPS, {}, "conv3d_k3_mfma_kernel"
+    if cfg_id == _ops.conv3d_k3_h2_config():     # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
+        kname = (f"conv3d_k3_h2_kernel (z-streaming direct 3x3x3 convolution on v_mfma_f32_32x32x16_f16, every fp32 operand as hi + lo fp16 pieces scaled into "
+                 f"fp16's range by the input records' magnitude bounds, products hi*hi + lo*hi + hi*lo, fp32 accumulate: fp32-equivalent; 32|64 -> 32 ch @ {roi}^3 and the levels below)")
+        gain, peak, pmc_key = 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
+        extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS, "piece_products_per_multiply": 3}
+    elif cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
+        kname = f"conv3d_k3_wino2p_kernel (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, two waves per SIMD, 32|64 -> 32 ch @ {roi}^3 / {roi // 2}^3)"
+        gain, pmc_key = 2.25, "conv3d_k3_wino2p_kernel"
+    else:
+        kname, gain = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {roi}^3)", 1.0
+    issued = tf / gain
+    roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": None, "kernel": kname,
+            "note": "achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); frac = the fraction of the dense MFMA peak of the "
+                    "kernel's matrix instruction (fp32: 157.3, fp16: 2500 TFLOP/s) the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops "
+                    "(2*27*Cin*Cout per voxel); Winograd needs winograd_algorithmic_gain x fewer multiply-adds for them",
+            "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / peak, "winograd_algorithmic_gain": gain if gain >= 1.0 else None, **extra,
+            "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
+            "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / steps / ms}
+    td = pmc_traffic(pmc_key)
+    if td:
+        roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
+    return roof
+
+
+def blend_roofline(spans):
+    blend = spans.get("sw_blend")
+    if not blend:
+        return None
+    gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+            "kernel": "sw_blend kernel (gather blend: logits read once, output written once)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+            "bytes_per_launch": blend["work"] / blend["launches"],
+            "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s (profiles/r02_ubench_hbm_stream_v1.txt)"}
+    td = pmc_traffic("sw_blend_reg_kernel") or pmc_traffic("sw_blend_kernel")
+    if td:
+        roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
+    return roof
+
+
+def extra_fp32_exact(args, vol, net, inferer, sync, shared):
+    """the same workload on the exact-fp32 convolution kernels (monai_amd.config.CONV_ALGO = "fp32"), and its parity on the cpu_baseline's windows"""
+    import oracle
+    from monai_amd import config
+
+    saved = config.CONV_ALGO
+    config.CONV_ALGO = "fp32"
+    try:
+        dt, spans, _ = timed_steps(inferer, vol, net, 2, 1, sync)
+        ms = 1e3 * dt / 2
+        res = {"conv_algo": "fp32", "steps": 2, "warmup": 1, "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s",
+               "roofline": conv_roofline(spans, 2, ms, args.roi)}
+        if shared.get("ref") is not None:
+            par = oracle.label_parity(inferer(shared["sub"], net), shared["ref"], tol=1e-4)
+            par["compared"] = shared["what"]
+            res["parity_vs_cpu_oracle"] = par
+    finally:
+        config.CONV_ALGO = saved
+    return res
+
+
+def extra_config3(args, vol, sync, dev):
+    """BASELINE.json configs[3]: UNETR (ViT-B/16 encoder) over the same volume -- 2 timed steps, the attention kernel's matrix-core rate, and one
+    window against the CPU oracle (oracle/unetr.py, bit-pinned to the reference by tests/golden/unetr.npz)"""
+    import oracle
+    from monai_amd.inferers import SlidingWindowInferer
+    from oracle import unetr as ounetr
+
+    net = build_net("unetr", args.roi, dev)
+    inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
+    dt, spans, _ = timed_steps(inferer, vol, net, 2, 1, sync)
+    ms = 1e3 * dt / 2
+    res = {"workload": f"UNETR ViT-B/16 5-class (seed-1 init), the same {args.size}^3 volume, {args.roi}^3 windows overlap 0.5 gaussian", "steps": 2, "warmup": 1,
+           "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s", "roofline": conv_roofline(spans, 2, ms, args.roi)}
+    att = spans.get("attention")
+    if att:
+        tf = att["work"] / (att["ms_total"] * 1e-3) / 1e12
+        res["attention"] = {"kernel": "attention_kernel (softmax(QK^T/sqrt(d))V per head on the matrix cores, S = 216, 12 heads x 64)", "ms_per_step": att["ms_total"] / 2,
+                            "tflops": tf, "bound": "mfma", "peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS, "share_of_step": att["ms_total"] / 2 / ms}
+    lin = spans.get("linear")
+    if lin:
+        res["linear"] = {"kernel": "linear_h2_kernel (nn.Linear + bias / GELU / residual, fp16 split precision)", "ms_per_step": lin["ms_total"] / 2,
+                         "fp32_equivalent_tflops": lin["work"] / (lin["ms_total"] * 1e-3) / 1e12}
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    x = vol[:, :, : args.roi, : args.roi, : args.roi].contiguous()
+    with torch.no_grad():
+        ref = ounetr.unetr_forward(sd, x.cpu())
+        got = net(x)
+    par = oracle.label_parity(got, ref, tol=1e-4)
+    par["compared"] = f"one {args.roi}^3 window of the benchmark volume through the network, product vs CPU oracle"
+    res["parity_vs_cpu_oracle"] = par
+    return res
+
+
+def extra_config4(dev):
+    """BASELINE.json configs[4]: Spacing (affine diag(.8, .8, 1.6) -> pixdim 1, trilinear, border: 512^3 -> 410x410x819) and GaussianSmooth(sigma 1) on a
+    batch of 4 x 512^3 volumes resident in HBM: transform and kernel-only times against the 8 TB/s spec (SURVEY.md 8d byte counts), and parity of both
+    on a 128^3 volume against CPU restatements of the reference path (oracle/resample.py; F.pad + depthwise F.conv3d per axis)."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    from monai_amd import ops
+    from monai_amd.data import MetaTensor
+    from monai_amd.networks.layers import gaussian_1d
+    from monai_amd.transforms import GaussianSmooth, Spacing
+    from oracle import resample as ores
+
+    def timeit(fn, iters=5, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / iters
+
+    n, e = 4, 512
+    aff = np.diag([0.8, 0.8, 1.6, 1.0])
+    vols = []
+    for s in range(n):
+        torch.manual_seed(s)
+        vols.append(MetaTensor(torch.rand(1, e, e, e).to(dev), affine=aff))
+    sp = Spacing(pixdim=(1.0, 1.0, 1.0), mode="bilinear", padding_mode="border")
+    out = sp(vols[0])
+    osz = tuple(int(v) for v in out.shape[1:])
+    res = {"workload": f"{n} x {e}^3 fp32 volumes (seeds 0..{n - 1}) in HBM: Spacing(pixdim 1, bilinear, border; fp64 coordinates) -> {list(out.shape)}, GaussianSmooth(sigma=1)", "runs": []}
+    ms = timeit(lambda: [sp(v) for v in vols])
+    nb = 4.0 * n * (e ** 3 + out.numel())
+    res["runs"].append({"op": "Spacing transform (4 volumes, host-side affine algebra included)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    gs = GaussianSmooth(sigma=1.0)
+    plain = [v.as_tensor() for v in vols]
+    ms = timeit(lambda: [gs(v) for v in plain])
+    nb = 8.0 * n * e ** 3
+    res["runs"].append({"op": "GaussianSmooth transform (4 volumes)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    raw = plain[0]
+    m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
+    for f64 in (True, False):
+        ms = timeit(lambda: ops.affine_resample(raw, m.reshape(-1), osz, "bilinear", "border", False, f64))
+        nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
+        res["runs"].append({"op": f"kernel: separable affine resample, {'fp64' if f64 else 'fp32'} interpolation (1 volume)", "bound": "hbm", "ms": ms, "GBps": nb / ms / 1e6,
+                            "frac": nb / ms / 1e6 / PEAK_HBM_GBS, "bytes": nb})
+    k = gaussian_1d(1.0).numpy()
+    ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
+    res["runs"].append({"op": "kernel: fused 3-axis Gaussian, 9 taps (1 volume)", "bound": "hbm", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
+                        "frac": 8.0 * raw.numel() / ms / 1e6 / PEAK_HBM_GBS, "bytes": 8.0 * raw.numel()})
+    # parity on a 128^3 volume
+    torch.manual_seed(11)
+    small = torch.rand(1, 128, 128, 128)
+    y = sp(MetaTensor(small.to(dev), affine=aff))
+    xform = np.linalg.inv(aff) @ y.affine.cpu().numpy()
+    ref = ores.spatial_resample_eager(small, torch.from_numpy(xform), tuple(y.shape[1:]), mode="bilinear", padding_mode="border")
+    g = gs(small.to(dev)).cpu()
+    kk = gaussian_1d(1.0)
+    gref = small[None]
+    for ax in range(3):        # separable_filtering (simplelayers.py:170-249): zero padding + depthwise conv per axis, fp32
+        shape = [1, 1, 1, 1, 1]
+        shape[2 + ax] = kk.numel()
+        pad = [0, 0, 0, 0, 0, 0]
+        pad[2 * (2 - ax)] = pad[2 * (2 - ax) + 1] = kk.numel() // 2
+        gref = F.conv3d(F.pad(gref, pad), kk.reshape(shape))
+    res["parity_vs_cpu_restatement"] = {"spacing_max_abs": float((y.cpu().as_tensor() - ref).abs().max()), "spacing_tol": 2e-6, "spacing_shape": list(y.shape),
+                                        "gaussian_max_abs": float((g - gref[0]).abs().max()), "gaussian_tol": 1e-5,
+                                        "compared": "128^3 volume, the same transforms: product vs oracle/resample.py (AffineTransform path of the reference) / zero-padded depthwise F.conv3d per axis"}
+    res["parity_vs_cpu_restatement"]["ok"] = bool(res["parity_vs_cpu_restatement"]["spacing_max_abs"] < 2e-6 and res["parity_vs_cpu_restatement"]["gaussian_max_abs"] < 1e-5)
+    return res
+
+
+def per_rank_breakdown(spans, steps: int, world: int, dev, dist):
+    """predictor / gather-wait / blend milliseconds per step of every rank (what the first SCALE run needs to be read)"""
+    keys = ("sw_predictor", "sw_gather_wait", "sw_blend")
+    mine = torch.tensor([spans.get(k, {}).get("ms_total", 0.0) / steps for k in keys], dtype=torch.float64, device=dev)
+    if world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    return [{"rank": r, "predictor_ms": float(t[0]), "gather_wait_ms": float(t[1]), "blend_ms": float(t[2])} for r, t in enumerate(allr)]
 
 
 def main(argv=None):
@@ -143,7 +376,8 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=512, help="volume edge (512 = the BASELINE.json workload)")
     ap.add_argument("--roi", type=int, default=96)
-    ap.add_argument("--cpu-windows", type=int, default=12, help="windows of the sub-volume the CPU baseline runs (0 = skip)")
+    ap.add_argument("--cpu-windows", type=int, default=125, help="windows of the corner sub-volume the CPU baseline / parity check runs (125 = 288^3; 0 = skip)")
+    ap.add_argument("--no-extra", action="store_true", help="skip extra.fp32_exact / config3 / config4 (development runs)")
     ap.add_argument("--net", default="basicunet", choices=sorted(NETS),
                     help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
                          "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16); swinunetr = SwinUNETR(feature_size=48) (SURVEY 8f-4)")
@@ -173,9 +407,8 @@ def main(argv=None):
 
     import torch.distributed as dist
 
-    from monai_amd import _prof, parallel
+    from monai_amd import config, parallel
     from monai_amd.inferers import SlidingWindowInferer
-    from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, SwinUNETR, UNet
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -185,20 +418,7 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=dev)
         parallel.enable_window_sharding()
 
-    # weights / volume exactly as SURVEY.md 8(d) config 1
-    torch.manual_seed(1)
-    if args.net == "swinunetr":
-        net = SwinUNETR(in_channels=1, out_channels=5, feature_size=48).eval().to(dev)
-    elif args.net == "unetr":
-        net = UNETR(in_channels=1, out_channels=5, img_size=(args.roi,) * 3).eval().to(dev)
-    elif args.net == "unet":
-        net = UNet(spatial_dims=3, in_channels=1, out_channels=5, channels=(16, 32, 64, 128, 256), strides=(2, 2, 2, 2), num_res_units=2).eval().to(dev)
-    elif args.net == "dynunet":
-        net = DynUNet(spatial_dims=3, in_channels=1, out_channels=5, kernel_size=[3] * 5, strides=[1, 2, 2, 2, 2], upsample_kernel_size=[2] * 4).eval().to(dev)
-    elif args.net == "segresnet":
-        net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=5).eval().to(dev)
-    else:
-        net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5).eval().to(dev)
+    net = build_net(args.net, args.roi, dev)
     vol = benchmark_volume(args.size).to(dev)
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
 
@@ -208,73 +428,17 @@ def main(argv=None):
         if not emulated:
             torch.cuda.synchronize()
 
-    out = None
-    for _ in range(args.warmup):
-        out = inferer(vol, net)
-    sync()
-    _prof.start()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = inferer(vol, net)
-    sync()
-    dt = time.perf_counter() - t0
-    spans = _prof.stop()
+    dt, spans, out = timed_steps(inferer, vol, net, args.steps, args.warmup, sync)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    ranks = per_rank_breakdown(spans, args.steps, world, dev, dist) if world > 1 else None
 
     if rank == 0:
         voxels = float(args.size) ** 3
         ms = 1e3 * dt / args.steps
-        # dominant kernel = the 3x3x3 conv tile configuration with the largest share of the step (the 96^3-level convs)
-        convs = {k: v for k, v in spans.items() if k.startswith("conv3d_k3/")}
-        roof = None
-        if convs:
-            key, conv = max(convs.items(), key=lambda kv: kv[1]["ms_total"])
-            tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12          # the convolution's own flops: 2 * 27 * Cin * Cout per voxel
-            cfg_id = int(key.split("/cfg")[1])
-            from monai_amd import ops as _ops
-            ncfg = _ops.conv3d_k3_num_configs()
-            peak, extra = PEAK_FP32_TFLOPS, {}
-            if cfg_id == _ops.conv3d_k3_h2_config():     # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
-                kname = (f"conv3d_k3_h2_kernel (z-streaming direct 3x3x3 convolution on v_mfma_f32_32x32x16_f16, every fp32 operand as hi + lo fp16 pieces, "
-                         f"products hi*hi + lo*hi + hi*lo, fp32 accumulate: fp32-equivalent results; 32|64 -> 32 ch @ {args.roi}^3 and the levels below)")
-                gain, peak = 1.0 / 3.0, PEAK_F16_TFLOPS
-                extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS,
-                         "piece_products_per_multiply": 3}
-            elif cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
-                impl = "conv3d_k3_wino2d_kernel, one wave per SIMD" if os.environ.get("MONAI_AMD_W2_IMPL", "p")[:1] == "d" else "conv3d_k3_wino2p_kernel, two waves per SIMD"
-                kname = f"{impl} (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, 32|64 -> 32 ch @ {args.roi}^3 / {args.roi // 2}^3)"
-                gain = 2.25
-            elif cfg_id == ncfg - 1:
-                kname, gain = "conv3d_k3_winograd_kernel (Winograd F(2x2x2,3x3x3) on v_mfma_f32_16x16x4_f32)", 3.375
-            else:
-                kname, gain = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {args.roi}^3)", 1.0
-            issued = tf / gain
-            roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak,
-                    "traffic": None, "kernel": kname,
-                    "note": "achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); frac = the fraction of the "
-                            "dense MFMA peak of the kernel's matrix instruction (fp32: 157.3, fp16: 2500 TFLOP/s) the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops (2*27*Cin*Cout per voxel): "
-                            "Winograd needs winograd_algorithmic_gain x fewer multiply-adds for them",
-                    "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / peak, "winograd_algorithmic_gain": gain if gain >= 1.0 else None, **extra,
-                    "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
-                    "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / args.steps / ms}
-            td = pmc_traffic("conv3d_k3_h2_kernel") if cfg_id == _ops.conv3d_k3_h2_config() else (pmc_traffic("conv3d_k3_wino2p_kernel") or pmc_traffic("conv3d_k3_wino2d_kernel")) if cfg_id == ncfg else pmc_traffic("conv3d_k3_mfma_kernel" if cfg_id < ncfg - 1 else "")
-            if td:
-                roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
-        blend = spans.get("sw_blend")
-        roof_hbm = None
-        if blend:
-            gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
-            roof_hbm = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                        "traffic": None, "kernel": "sw_blend_reg_kernel<5,4,2> (regular-grid gather blend)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
-                        "bytes_per_launch": blend["work"] / blend["launches"],
-                        "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s "
-                                              "(profiles/r02_ubench_hbm_stream_v1.txt)"}
-            td = pmc_traffic("sw_blend_reg_kernel") or pmc_traffic("sw_blend_kernel")
-            if td:
-                roof_hbm["traffic"], roof_hbm["traffic_detail"] = td["hbm_bytes_per_launch"], td
+        exact = config.conv_algo() in (config.CONV_ALGOS["fp32"], config.CONV_ALGOS["direct"], config.CONV_ALGOS["wino2d"])
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
                     for k, v in spans.items() if k.startswith("conv3d_k3/")}
         line = {
@@ -289,32 +453,41 @@ def main(argv=None):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": ("every tensor, accumulator and elementwise op is fp32; 3x3x3 convolutions on the exact-fp32 kernels (MONAI_AMD_CONV_ALGO set)"
-                           if os.environ.get("MONAI_AMD_CONV_ALGO") in ("fp32", "direct", "wino2d", "winograd") else
-                           "every tensor, accumulator and elementwise op is fp32; the multiplications of the 3x3x3 convolutions are evaluated from two fp16 pieces per "
-                           "fp32 operand (hi + lo, three exact piece products on the fp16 matrix cores, fp32 accumulation): fp32-equivalent -- max |dlogit| vs the "
-                           "fp32 CPU oracle is the same 4e-6 as with the exact-fp32 kernels (parity_vs_gpu below); MONAI_AMD_CONV_ALGO=fp32 runs those"),
+            "dtype_note": ("every tensor, accumulator and elementwise op is fp32; 3x3x3 convolutions on the exact-fp32 kernels (monai_amd.config.CONV_ALGO / MONAI_AMD_CONV_ALGO set)"
+                           if exact else
+                           "every tensor, accumulator and elementwise op is fp32; the multiplications of the 3x3x3 convolutions are evaluated from two fp16 pieces per fp32 operand "
+                           "(hi + lo, the input first scaled into fp16's range by a power of two from its records' magnitude bounds; three exact piece products on the fp16 matrix "
+                           "cores, fp32 accumulation): fp32-equivalent for any finite input magnitude -- parity_vs_gpu below; extra.fp32_exact is the same run on the exact-fp32 kernels"),
             "data": "synthetic",
             "config": {
                 "workload": f"{NETS[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic CT volume (the reference's create_test_image_3d phantom, "
                             f"SURVEY 8d config 1) resident in HBM, {args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
-            "roofline": roof,
-            "roofline_hbm": roof_hbm,
-            "attention": ({"kernel": "attention_kernel<7> (fp32 MFMA, S=216, 12 heads x 64)", "ms_per_step": spans["attention"]["ms_total"] / args.steps,
-                           "tflops": spans["attention"]["work"] / (spans["attention"]["ms_total"] * 1e-3) / 1e12,
-                           "frac_of_fp32_mfma_peak": spans["attention"]["work"] / (spans["attention"]["ms_total"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS}
-                          if "attention" in spans else None),
+            "roofline": conv_roofline(spans, args.steps, ms, args.roi),
+            "roofline_hbm": blend_roofline(spans),
             "conv_ms_per_step": conv_all,
             "checksum": float(out.double().sum().item()),
         }
+        if ranks is not None:
+            line["per_rank_ms_per_step"] = ranks
         if emulated:
             line["emulated"] = "SIMT emulator + gloo: harness test only, not a measurement"
+        shared: dict = {}
         if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
-            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer)
+            line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer, shared)
         else:
             line["cpu_baseline"] = None
+        if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated:
+            extra = {}
+            for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("config3", lambda: extra_config3(args, vol, sync, dev)),
+                             ("config4", lambda: extra_config4(dev))):
+                try:
+                    extra[name] = fn()
+                except Exception as e:      # an extra must never cost the headline line
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+            line["extra"] = extra
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -289,7 +289,8 @@ def sliding_window_inference(
                         k = int(predictor.out_channels)
                         seg_shapes, zscales = [tuple(roi_size)], [None]
                         logits = [_alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
-                    predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
+                    with _prof.span("sw_predictor"):
+                        predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
                 else:
                     if with_coord:
                         coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
@@ -341,8 +342,9 @@ def sliding_window_inference(
 
         if logits is None:
             raise RuntimeError("monai_amd: no windows were processed")
-        for work in pending:
-            work.wait()
+        with _prof.span("sw_gather_wait"):         # what the compute stream still has to wait for after its last round
+            for work in pending:
+                work.wait()
         gathered = logits
 
         if weights is None:  # importance map per output resolution (the reference resamples cumulatively, utils.py:260-263)

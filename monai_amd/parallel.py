@@ -16,6 +16,7 @@ Nothing here runs unless ``enable_window_sharding()`` was called (bench.py does,
 
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -37,6 +38,36 @@ def enable_window_sharding(group=None) -> None:
 def disable_window_sharding() -> None:
     global _GROUP, _ENABLED
     _GROUP, _ENABLED = None, False
+
+
+# ---- in-place all-gather: probed once per process group -------------------------------------------------------------------------
+# RCCL / NCCL run all_gather in place when the send buffer is exactly the rank's own slot of the receive buffer (recv + rank * count);
+# torch.distributed documents no aliasing guarantee, and other backends (or a future release) may reject or mis-handle it.  One tiny
+# probe collective per group decides: rows come back right -> the in-place form (no send copy); an exception or wrong rows -> every
+# round sends a private copy of its rows.  All ranks take the same branch (the verdict is all-reduced).
+_INPLACE_OK: dict = {}
+
+
+def _inplace_gather_ok(group, device) -> bool:
+    key = (id(group), str(device))
+    if os.environ.get("MONAI_AMD_GATHER_INPLACE") == "0":       # force the out-of-place form (tests exercise both)
+        return False
+    if key not in _INPLACE_OK:
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ok = 1
+        try:
+            buf = torch.full((world * 64,), -1.0, dtype=torch.float32, device=device)
+            mine = buf[rank * 64:(rank + 1) * 64]
+            mine.copy_(torch.arange(64, dtype=torch.float32, device=device) + 1000.0 * rank)
+            dist.all_gather_into_tensor(buf, mine, group=group)
+            want = (torch.arange(64, dtype=torch.float32, device=device)[None] + 1000.0 * torch.arange(world, dtype=torch.float32, device=device)[:, None]).reshape(-1)
+            ok = int(torch.equal(buf, want))
+        except Exception:      # a backend that refuses aliased buffers
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        _INPLACE_OK[key] = bool(int(t.item()))
+    return _INPLACE_OK[key]
 
 
 class _Pending:
@@ -108,8 +139,15 @@ class WindowShard:
         span = self.world * nb
         out = flat_rows(full, q * span, (q + 1) * span)
         mine = flat_rows(full, q * span + self.rank * nb, q * span + (self.rank + 1) * nb)
-        work = dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
-        return _Pending(work, None)
+        # the slot arithmetic the in-place form rests on: equal contiguous slots, this rank's rows exactly at recv + rank * count
+        if out.numel() != self.world * mine.numel() or mine.data_ptr() != out.data_ptr() + self.rank * mine.numel() * mine.element_size():
+            raise RuntimeError("monai_amd.parallel: the round's rows are not equal contiguous slots of the logits buffer")
+        if _inplace_gather_ok(self.group, full.device):
+            work = dist.all_gather_into_tensor(out, mine, group=self.group, async_op=True)
+            return _Pending(work, None)
+        send = mine.clone()                 # out-of-place fallback: a private send buffer, kept alive until the collective is done
+        work = dist.all_gather_into_tensor(out, send, group=self.group, async_op=True)
+        return _Pending(work, send)
 
 
 def partition(num_win: int, world: int, rank: int, group=None) -> WindowShard:

@@ -49,6 +49,13 @@ def _worker(rank, world, port, shape, roi, ret):
             sharded2 = inf(x, net).clone()
             del os.environ["MONAI_AMD_SW_BATCH"]
             assert torch.equal(sharded, sharded2), "the result must not depend on the round size"
+            # the all-gather of a round runs in place on the rank's own rows when a probe collective says the backend handles aliased
+            # buffers (parallel._inplace_gather_ok), out of place through a private send copy otherwise: same bits either way
+            assert parallel._inplace_gather_ok(None, x.device) in (True, False)
+            os.environ["MONAI_AMD_GATHER_INPLACE"] = "0"
+            staged = inf(x, net).clone()
+            del os.environ["MONAI_AMD_GATHER_INPLACE"]
+            assert torch.equal(staged, sharded), "in-place and out-of-place round gathers must agree"
             # volumes whose logits exceed the budget go slab by slab -- also under sharding (every slab's windows are sharded, the
             # fit decision is collective): force it with a cap of two window rows and compare with the unsharded result
             per_win = 3 * roi[0] * roi[1] * roi[2] * 4
