@@ -80,6 +80,18 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
                     int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx,
                     int nx, int premultiplied, void* stream);
 
+/* The blend over the MOSAIC logits layout (single-GPU fused path).  Windows i and i + m of an axis do not overlap when m * step >= roi, so the
+ * windows of one residue class per axis (i mod m, m = 2^log2m in {1, 2, 4}; the last -- clipped -- window of an axis is a class of its own, index m)
+ * tile space: the logits of class (cz, cy, cx) are ONE dense array [K][cnt_z*rd][cnt_y*rh][cnt_x*rw] at float offset class_base[(cz*5 + cy)*5 + cx]
+ * (HOST int64[125]) from `logits`, window (jz, jy, jx) of the class (j = i >> log2m) at its mosaic position; mh_sw_mosaic_class_counts gives cnt per
+ * class of an axis with n windows.  At overlap 0.5 the blend then reads 1 KB runs per wave from <= 8 (27) arrays instead of 384-byte pieces of
+ * 8 (27) x K window blocks.  Same arithmetic in the same (ascending window) order as mh_sw_blend_f32: identical bits.  Regular grids, K <= 8, extents
+ * divisible by 4; MH_ERR_UNSUPPORTED otherwise (use the window-major layout).  mh_conv1x1_windows_f32 writes the layout. */
+int mh_sw_mosaic_class_counts(int n, int log2m, int32_t* counts5);
+int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, float* out, int K,
+                           int D, int H, int W, int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
+                           void* stream);
+
 /* The same blend with the post-processing step that follows it in segmentation bundles fused into its epilogue:
  * AsDiscrete(argmax=True) (monai/transforms/post/array.py:132-237, `torch.argmax(img, dim=0, keepdim=True)`).  Every voxel's K
  * blended values are formed in registers exactly as mh_sw_blend_f32 forms them and only the label -- index of the first maximal
@@ -177,6 +189,10 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, 
 /* Conv3d k=1 (+bias) of act(in) -- `final_conv`, basic_unet.py:252.  w: [Cout][Cin]. */
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
                    void* stream);
+
+/* The same 1x1 convolution with one strided destination per batch element (the windows of a sliding-window launch written straight into the mosaic
+ * logits layout): place [N][4] HOST int64 = {float offset from `base`, channel stride, z stride, y stride}; x stays contiguous.  Cout <= 8. */
+int mh_conv1x1_windows_f32(const mh_tensor5* in, const float* w, const float* bias, float* base, int Cout, const int64_t* place, void* stream);
 
 /* ---- UNETR pieces (monai/networks/nets/unetr.py, blocks/selfattention.py, blocks/dynunet_block.py) ------------ */
 

@@ -58,6 +58,8 @@ SIGNATURES = {
     "mh_foreground_bbox_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mh_crop_pad_f32": (_I, [_P, _P] + [_I] * 10 + [_F, _P]),
     "mh_sw_blend_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
+    "mh_sw_mosaic_class_counts": (_I, [_I, _I, _IA]),
+    "mh_sw_blend_mosaic_f32": (_I, [_P, C.POINTER(C.c_int64), _I, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _P]),
     "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mh_conv3d_k3_h2_config": (_I, []),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "mh_maxpool2_f32": (_I, [_T, _T, _P]),
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
+    "mh_conv1x1_windows_f32": (_I, [_T, _P, _P, _P, _I, C.POINTER(C.c_int64), _P]),
     "mh_conv3d_k3_strided_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_conv3d_k3_strided3_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _P]),
     "mh_deconv_ks_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _P]),

@@ -271,6 +271,46 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
     return launched("sw_blend");
 }
 
+// Mosaic logits layout (kernels/sliding.h): the residue classes per axis are 2^log2m; `class_base` holds the float offset of each class array,
+// indexed (cz * 5 + cy) * 5 + cx.  mh_sw_mosaic_class_counts gives the number of windows per class of an axis (what sizes the arrays).
+int mh_sw_mosaic_class_counts(int n, int log2m, int32_t* counts5) {
+    if (n < 1 || log2m < 0 || log2m > 2 || !counts5) return fail(MH_ERR_ARG, "sw_mosaic_class_counts: bad argument (1, 2 or 4 residue classes)");
+    MosaicAxis a;
+    mosaic_axis_fill(a, n, log2m);
+    for (int c = 0; c < MOSAIC_MAX_CLASSES; ++c) counts5[c] = a.cnt[c];
+    return MH_OK;
+}
+
+int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, float* out, int K,
+                           int D, int H, int W, int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
+                           void* stream) {
+    int64_t dense = 0;
+    if (int e = blend_checks("sw_blend_mosaic", logits, imp, out, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx, dense)) return e;
+    if (!class_base || log2m_z < 0 || log2m_z > 2 || log2m_y < 0 || log2m_y > 2 || log2m_x < 0 || log2m_x > 2) return fail(MH_ERR_ARG, "sw_blend_mosaic: bad layout");
+    if (K < 1 || K > 8) return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: 1 .. 8 classes (got %d): use the window-major layout", K);
+    RegGrid rg;
+    if (!regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W)) return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: irregular window starts (use the window-major layout)");
+    if (!(W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16)))
+        return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: needs W, roi width and window starts divisible by 4 and 16-byte aligned buffers");
+    // windows i and i + m of an axis must not overlap
+    const AxisWin* ax[3] = {&rg.z, &rg.y, &rg.x};
+    const int lm[3] = {log2m_z, log2m_y, log2m_x}, rr[3] = {rd, rh, rw};
+    for (int a = 0; a < 3; ++a)
+        if (ax[a]->n > 2 && (long long)ax[a]->step << lm[a] < rr[a]) return fail(MH_ERR_ARG, "sw_blend_mosaic: %d residue classes do not separate the windows of axis %d", 1 << lm[a], a);
+    Mosaic ms;
+    mosaic_axis_fill(ms.z, nz, log2m_z); mosaic_axis_fill(ms.y, ny, log2m_y); mosaic_axis_fill(ms.x, nx, log2m_x);
+    for (int i = 0; i < MOSAIC_MAX_CLASSES * MOSAIC_MAX_CLASSES * MOSAIC_MAX_CLASSES; ++i) {
+        if (class_base[i] % 4) return fail(MH_ERR_ARG, "sw_blend_mosaic: class offsets must be multiples of 4 floats");
+        ms.base[i] = class_base[i];
+    }
+    const unsigned nb = blocks_for((long long)D * H * (W / 4));
+    hipStream_t s = (hipStream_t)stream;
+#define MH_BM_CASE(KT) case KT: hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, MH_BLEND_G>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); break;
+    switch (K) { MH_BM_CASE(1) MH_BM_CASE(2) MH_BM_CASE(3) MH_BM_CASE(4) MH_BM_CASE(5) MH_BM_CASE(6) MH_BM_CASE(7) MH_BM_CASE(8) }
+#undef MH_BM_CASE
+    return launched("sw_blend_mosaic");
+}
+
 int mh_sw_blend_argmax_f32(const float* logits, int64_t window_stride, const float* imp, void* labels, int labels_u8, int K, int D, int H, int W, int rd,
                            int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int premultiplied, void* stream) {
     if (int e = blend_checks("sw_blend_argmax", logits, imp, labels, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx, window_stride)) return e;
@@ -657,6 +697,29 @@ int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, con
         co0 += co;
     }
     return launched("conv1x1");
+}
+
+int mh_conv1x1_windows_f32(const mh_tensor5* in_, const float* w, const float* bias, float* base, int Cout, const int64_t* place, void* stream) {
+    if (!dense_ok(in_) || !w || !base || !place) return fail(MH_ERR_ARG, "conv1x1_windows: bad argument");
+    const Tensor in = from_c(*in_);
+    if (Cout < 1 || Cout > 8) return fail(MH_ERR_UNSUPPORTED, "conv1x1_windows: 1 .. 8 output channels (got %d)", Cout);
+    const long long DHW = (long long)in.D * in.H * in.W;
+    if (in.W % 4 || !aligned(in.data, 16) || in.n_stride % 4 || !aligned(base, 16)) return fail(MH_ERR_UNSUPPORTED, "conv1x1_windows: needs W %% 4 == 0 and 16-byte aligned tensors");
+    for (int n = 0; n < in.N; ++n)
+        for (int q = 0; q < 4; ++q)
+            if (place[4 * n + q] % 4) return fail(MH_ERR_ARG, "conv1x1_windows: offsets and strides must be multiples of 4 floats");
+    for (int n0 = 0; n0 < in.N; n0 += WIN_PLACE_MAX) {
+        const int nn = in.N - n0 < WIN_PLACE_MAX ? in.N - n0 : WIN_PLACE_MAX;
+        WinPlace pl;
+        for (int i = 0; i < nn; ++i) {
+            pl.off[i] = place[4 * (n0 + i)]; pl.sc[i] = place[4 * (n0 + i) + 1]; pl.sd[i] = place[4 * (n0 + i) + 2]; pl.sh[i] = place[4 * (n0 + i) + 3];
+        }
+        const dim3 grid(blocks_for(DHW / 4), (unsigned)nn);
+#define MH_1W_CASE(CO) case CO: hipLaunchKernelGGL((conv1x1_windows_kernel<CO>), grid, dim3(256), 0, (hipStream_t)stream, in, w, bias, base, pl, n0); break;
+        switch (Cout) { MH_1W_CASE(1) MH_1W_CASE(2) MH_1W_CASE(3) MH_1W_CASE(4) MH_1W_CASE(5) MH_1W_CASE(6) MH_1W_CASE(7) MH_1W_CASE(8) }
+#undef MH_1W_CASE
+    }
+    return launched("conv1x1_windows");
 }
 
 

@@ -17,7 +17,8 @@
 // input as it comes: every input record carries a bound on |activated value| over its (n, c) plane (common.h -- sqrt(count) *
 // |gamma| + |beta| from the InstanceNorm / GroupNorm finalize, max |value| from the raw producers), the workgroup takes the
 // power of two 2^s that puts the largest bound of sample n just below 2^15, multiplies the activated input by it (folded into
-// the LeakyReLU select: no extra instruction) and the epilogue scales back by 2^-s together with the weight scale -- all exact.
+// the records' alpha and beta as they are copied to LDS: no extra instruction) and the epilogue scales back by 2^-s together with
+// the weight scale -- all exact.
 // Any finite magnitude is therefore in range, and small-magnitude tensors keep fp32-equivalent relative precision.  A bound
 // that is inf / NaN (the input plane or its statistics hold a non-finite value) or 0 (none given: a caller that selected this
 // kernel for an unbounded input) makes the sample's whole output NaN: after a normalisation that is exactly what the reference
@@ -147,10 +148,12 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         poisoned = mb >= 0x7f800000u;
         e_in = poisoned ? 0 : min(max(15 - ((int)(mb >> 23) - 126), -100), 100);
         const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
-        for (int c = tid; c < Cin; c += 512) nrm_s[3 * c + 2] *= p_;      // slope * 2^e_in: the negative branch of the scaled activation (each thread rescales the records it loaded)
+        // 2^e_in folded into the records (each thread rescales the ones it loaded): fma(x, alpha p, beta p) == p fma(x, alpha, beta) exactly -- a power of two
+        // commutes with every rounding -- unless alpha p itself leaves fp32's normal range, which takes |alpha| < 1e-8 together with activations > 4e34
+        // (or the mirror image): the step loop stays instruction for instruction the unscaled one
+        for (int c = tid; c < Cin; c += 512) { nrm_s[3 * c] *= p_; nrm_s[3 * c + 1] *= p_; }
         __syncthreads();
     }
-    const float p_in = __uint_as_float((unsigned)(e_in + 127) << 23);
 
     const float* src = in.data + (long long)n * in.n_stride + (long long)(4 * q) * DHW;
     const u32x4* const wg = reinterpret_cast<const u32x4*>(wp) + (long long)cg * NCH * H2_WB + tid;
@@ -186,10 +189,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Float16 h_[4], l_[4];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             float y_ = xin[J][i];                                                                     \
-            if (NRM) {      /* act(x) * 2^e_in: (y > 0 ? y : y * slope) * p == y * (y > 0 ? p : slope * p), exact */ \
+            if (NRM) {      /* alpha, beta in LDS are pre-multiplied by 2^e_in: act(x, alpha p, beta p, slope) == p act(x, alpha, beta, slope) */ \
                 const float* a_ = nrm_s + 3 * (H2_KC * cs + 4 * q + i);                               \
-                y_ = fmaf(y_, a_[0], a_[1]);                                                          \
-                y_ = y_ * (y_ > 0.0f ? p_in : a_[2]);                                                 \
+                y_ = act(y_, a_[0], a_[1], a_[2]);                                                    \
             }                                                                                         \
             h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \

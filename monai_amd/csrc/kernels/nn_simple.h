@@ -359,13 +359,20 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
                         *reinterpret_cast<float2*>(p) = make_float2(acc[j][dz * 4 + dy * 2], acc[j][dz * 4 + dy * 2 + 1]);
                     }
             }
-            if (out.nrm) {        // magnitude bound of the raw result (common.h)
-                unsigned m = 0u;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m = max(m, abs_bits(acc[j][k]));
-                bound_commit(valid ? m : 0u, bound_slot(out, n, co0 + j));
-            }
         }
+    if (out.nrm) {
+        // magnitude bound of the raw result (common.h): ONE wave reduction over everything the wave wrote, folded into the records of all the channels of
+        // the group by one atomic instruction (lane j -> channel co0 + j).  The group's maximum bounds each of its channels (a little looser than per channel;
+        // per-channel reductions cost 8 x the shuffles and atomics and were measured at +55 % on this store-bound kernel, profiles/r03_bench_kernel_trace_stats_v1.txt)
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < COT; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m = max(m, abs_bits(acc[j][k]));
+        m = wave_umax(valid ? m : 0u);
+        const int jl = threadIdx.x & 63;
+        if (jl < COT && (FULL || co0 + jl < Cout) && m != 0u) atomicMax(reinterpret_cast<unsigned*>(bound_slot(out, n, co0 + jl)), m);
+    }
 }
 
 // Measured and removed (profiles/r02_deconv_bench_v1.json, r03_deconv_bench.json): the same op as ONE GEMM on the fp32 matrix cores, first with this
@@ -427,6 +434,59 @@ conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__
             p[0] = acc[j][0];
         }
     }
+}
+
+// The same 1x1 convolution writing each batch element (a window of the sliding-window inferer) to its own strided destination -- the
+// mosaic logits layout of sliding.h: place[n] = {float offset, channel stride, z stride, y stride} relative to `base`; rows (x) stay contiguous.
+constexpr int WIN_PLACE_MAX = 64;
+struct WinPlace {
+    long long off[WIN_PLACE_MAX], sc[WIN_PLACE_MAX], sd[WIN_PLACE_MAX], sh[WIN_PLACE_MAX];
+};
+template <int CO>
+__global__ void __launch_bounds__(256)
+conv1x1_windows_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ base, WinPlace pl, int n0) {
+    constexpr int VEC = 4;
+    const int Cin = in.C, H = in.H, W = in.W;
+    const long long DHW = (long long)in.D * H * W;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const int nl = blockIdx.y, n = n0 + nl;
+    if (idx >= DHW) return;
+    float acc[CO][VEC];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        const float bj = bias ? bias[j] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[j][v] = bj;
+    }
+    const float* src = in.data + (long long)n * in.n_stride + idx;
+    constexpr int CB = 4;
+    for (int c0 = 0; c0 < Cin; c0 += CB) {
+        float xv[CB][VEC];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const float4 q = *reinterpret_cast<const float4*>(src + (long long)min(c0 + c, Cin - 1) * DHW);
+            xv[c][0] = q.x; xv[c][1] = q.y; xv[c][2] = q.z; xv[c][3] = q.w;
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int ci = c0 + c;
+            if (ci < Cin) {
+                const float4 a = load_nrm(in, n, ci);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float f = act(xv[c][v], a.x, a.y, a.z);
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j][v] = fmaf(f, w[(long long)j * Cin + ci], acc[j][v]);
+                }
+            }
+        }
+    }
+    const int x = (int)(idx % W);
+    const long long t = idx / W;
+    const int y = (int)(t % H), z = (int)(t / H);
+    float* dst = base + pl.off[nl] + (long long)z * pl.sd[nl] + (long long)y * pl.sh[nl] + x;
+#pragma unroll
+    for (int j = 0; j < CO; ++j) *reinterpret_cast<float4*>(dst + (long long)j * pl.sc[nl]) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -322,6 +322,118 @@ sw_blend_reg_kernel(const float* __restrict__ logits, const float* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Mosaic logits layout (single-GPU fused path).  In the window-major buffer a voxel's 8 ... 27 covering windows are 8 ... 27 x K
+// separate streams of 384-byte row pieces; the blend kernel above tops out at 0.62-0.69 of 8 TB/s while a plain read stream reaches
+// 0.82-0.87 on the same chip (tools/ubench/hbm_stream.hip).  Windows i and i + m of an axis never overlap when m * step >= roi, so the
+// windows of one residue class (i mod m per axis; m a power of two; the clipped last window of each axis is a class of its own) tile
+// space without overlap: the logits of class (cz, cy, cx) are stored as ONE dense array [K][cnt_z * rd][cnt_y * rh][cnt_x * rw] -- window
+// (jz, jy, jx) of the class at its mosaic position.  At overlap 0.5 (m = 2) consecutive windows of a class are also consecutive in the
+// volume, so a wave's 256 consecutive voxels read 1 KB runs from each of the <= 8 (27) class arrays instead of 384-byte pieces of different
+// windows.  The predictor's last kernel writes the layout directly (conv1x1_windows_kernel); the arithmetic and its order (ascending
+// window index) are those of sw_blend_reg_kernel: the same bits.
+constexpr int MOSAIC_MAX_CLASSES = 5;          // m <= 4 residue classes + the last window, per axis
+struct MosaicAxis {
+    int log2m;
+    int cnt[MOSAIC_MAX_CLASSES];               // windows per class
+};
+struct Mosaic {
+    MosaicAxis z, y, x;
+    long long base[MOSAIC_MAX_CLASSES * MOSAIC_MAX_CLASSES * MOSAIC_MAX_CLASSES];      // float offset of class (cz, cy, cx)
+};
+__host__ __device__ inline void mosaic_axis_fill(MosaicAxis& a, int n, int log2m) {
+    a.log2m = log2m;
+    const int m = 1 << log2m;
+    for (int c = 0; c < MOSAIC_MAX_CLASSES; ++c) a.cnt[c] = 0;
+    for (int c = 0; c < m; ++c) a.cnt[c] = n - 1 > c ? (n - 1 - c + m - 1) >> log2m : 0;       // i in [0, n - 1) with i mod m == c
+    a.cnt[m] = 1;                                                                               // the last window
+}
+__device__ __forceinline__ void mosaic_axis_locate(const MosaicAxis& a, int n, int i, int& c, int& j) {
+    const bool last = i == n - 1;
+    c = last ? (1 << a.log2m) : (i & ((1 << a.log2m) - 1));
+    j = last ? 0 : (i >> a.log2m);
+}
+
+template <int KT, int G>
+__global__ void __launch_bounds__(256)
+sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K, int D, int H, int W, int rd,
+                       int rh, int rw, RegGrid g, Mosaic ms) {
+    constexpr int VEC = 4;
+    const int wv = W / VEC;
+    const long long total = (long long)D * H * wv;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % wv) * VEC;
+    const long long t = idx / wv;
+    const int y = (int)(t % H), z = (int)(t / H);
+    int zlo, zhi, ylo, yhi, xlo, xhi;
+    axis_cover(g.z, rd, z, zlo, zhi);
+    axis_cover(g.y, rh, y, ylo, yhi);
+    axis_cover(g.x, rw, x, xlo, xhi);
+    const int nw = (zhi - zlo + 1) * (yhi - ylo + 1) * (xhi - xlo + 1);
+    const long long plane = (long long)rh * rw;
+    const long long vox = (long long)D * H * W;
+    float acc[KT][VEC];
+    float cnt[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        cnt[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[k][v] = 0.0f;
+    }
+    int iz = zlo, iy = ylo, ix = xlo;
+    for (int done = 0; done < nw; done += G) {
+        float wt[G][VEC];
+        float lv[G][KT][VEC];
+        long long off0 = 0, base0 = 0, cs0 = 0;
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const bool ok = done + b < nw;
+            const int lz = z - axis_start(g.z, iz), ly = y - axis_start(g.y, iy), lx = x - axis_start(g.x, ix);
+            int cz, jz, cy, jy, cx, jx;
+            mosaic_axis_locate(ms.z, g.z.n, iz, cz, jz);
+            mosaic_axis_locate(ms.y, g.y.n, iy, cy, jy);
+            mosaic_axis_locate(ms.x, g.x.n, ix, cx, jx);
+            const long long Hc = (long long)ms.y.cnt[cy] * rh, Wc = (long long)ms.x.cnt[cx] * rw;
+            long long cs = (long long)ms.z.cnt[cz] * rd * Hc * Wc;
+            long long base = ms.base[(cz * MOSAIC_MAX_CLASSES + cy) * MOSAIC_MAX_CLASSES + cx] + (((long long)jz * rd + lz) * Hc + (long long)jy * rh + ly) * Wc + (long long)jx * rw + lx;
+            long long off = (long long)lz * plane + (long long)ly * rw + lx;
+            if (b == 0) { off0 = off; base0 = base; cs0 = cs; }
+            if (!ok) { off = off0; base = base0; cs = cs0; }      // past the end of the box: re-request the batch's first window (values unused)
+            if (ok) {
+                if (++ix > xhi) { ix = xlo; if (++iy > yhi) { iy = ylo; ++iz; } }
+            }
+            const f32x4 q = *reinterpret_cast<const f32x4*>(imp + off);
+            wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(logits + base + (long long)k * cs);
+                lv[b][k][0] = a[0]; lv[b][k][1] = a[1]; lv[b][k][2] = a[2]; lv[b][k][3] = a[3];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < G; ++b) {
+            const bool ok = done + b < nw;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    const float s = __fadd_rn(acc[k][v], __fmul_rn(lv[b][k][v], wt[b][v]));
+                    acc[k][v] = ok ? s : acc[k][v];
+                }
+                const float c = __fadd_rn(cnt[v], wt[b][v]);
+                cnt[v] = ok ? c : cnt[v];
+            }
+        }
+    }
+    float* op = out + ((long long)z * H + y) * W + x;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+        const f32x4 r = {__fdiv_rn(acc[k][0], cnt[0]), __fdiv_rn(acc[k][1], cnt[1]), __fdiv_rn(acc[k][2], cnt[2]), __fdiv_rn(acc[k][3], cnt[3])};
+        *reinterpret_cast<f32x4*>(op + k * vox) = r;
+    }
+}
+
 // AvgMerger (monai/inferers/merger.py:103-205): `values[slice] += patch; counts[slice] += 1` for one patch -- the patches
 // of a PatchInferer arrive one by one through a user-visible Merger object, so the accumulation order (= patch order) is
 // the reference's -- and the final `values /= counts`.  One thread per patch element, lanes along x; HBM-bound read-modify-

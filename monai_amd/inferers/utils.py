@@ -259,6 +259,7 @@ def sliding_window_inference(
 
         windows_nd = [tuple(slice(s, s + roi_size[d]) for d, s in enumerate(w)) for w in itertools.product(*starts)]
 
+    mosaic = None      # fused single-GPU path: the logits in the mosaic layout (ops.LogitsMosaic) instead of window-major rows
     logits = None      # per output: [num_win_padded, K, *seg3]
     seg_shapes = None  # per output: spatial shape of one window's prediction (native dims)
     dict_keys = None
@@ -288,9 +289,13 @@ def sliding_window_inference(
                     if logits is None:
                         k = int(predictor.out_channels)
                         seg_shapes, zscales = [tuple(roi_size)], [None]
-                        logits = [_alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
+                        mosaic = _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
+                        logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
                     with _prof.span("sw_predictor"):
-                        predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
+                        if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
+                            predictor.forward_into_windows(win_buf[:n], mosaic, w0)
+                        else:
+                            predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
                 else:
                     if with_coord:
                         coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
@@ -359,15 +364,18 @@ def sliding_window_inference(
                 if argmax_dtype is not None:       # only the label map is ever written: [B, 1, ...]
                     outputs.append(torch.empty((batch_size, 1) + _to3(osz, 1), dtype=argmax_dtype, device=dev))
                 else:
-                    outputs.append(torch.empty((batch_size, lg.shape[1]) + _to3(osz, 1), dtype=compute_dtype, device=dev))
+                    outputs.append(torch.empty((batch_size, lg.k if lg is mosaic else lg.shape[1]) + _to3(osz, 1), dtype=compute_dtype, device=dev))
         for ss, (lg, z) in enumerate(zip(gathered, zscales)):
             if z is None:
                 g = grid3
             else:
                 g = [[0]] * (3 - num_spatial_dims) + [[int(s * zz) for s in ax] for ax, zz in zip(starts, z)]
-            nbytes = 4.0 * lg[:num_win].numel() + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
+            nlog = num_win * lg.k * roi3[0] * roi3[1] * roi3[2] if lg is mosaic else lg[:num_win].numel()
+            nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
-                if argmax_dtype is not None:
+                if lg is mosaic:
+                    ops.sw_blend_mosaic(mosaic, weights[ss], outputs[ss][b])
+                elif argmax_dtype is not None:
                     _blend_argmax(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b, 0], g,
                                   _to3(seg_shapes[ss], 1), premultiplied=proc_weights is not None)
                 elif proc_weights is not None:
@@ -433,6 +441,26 @@ def _alloc_logits(shard, nb: int, k: int, seg3, dtype, dev) -> torch.Tensor:
         raise _LogitsDoNotFit(need, limit)
     flat = torch.empty(rows * ws, dtype=dtype, device=dev)
     return flat.as_strided((rows, k) + tuple(seg3), (ws, seg3[0] * seg3[1] * seg3[2], seg3[1] * seg3[2], seg3[2], 1))
+
+
+def _alloc_mosaic(predictor, shard, argmax_dtype, k: int, grid3, roi3, dtype, dev):
+    """The mosaic logits layout (ops.LogitsMosaic: the windows of one residue class per axis as dense arrays, so the blend reads long runs instead of
+    384-byte pieces of 8 ... 27 x K window blocks) when the path allows it: a predictor whose last kernel can write it (`forward_into_windows`), one GPU
+    (window sharding gathers window-major rows), the plain blend (the fused-argmax epilogue reads window-major), a regular grid with <= 4 residue
+    classes, K <= 8.  Same result bits either way; MONAI_AMD_LOGITS_LAYOUT=windows keeps the window-major buffer.  The same fit rule as _alloc_logits."""
+    if (not hasattr(predictor, "forward_into_windows") or shard.world > 1 or argmax_dtype is not None or dtype != torch.float32
+            or os.environ.get("MONAI_AMD_LOGITS_LAYOUT") == "windows" or not ops.LogitsMosaic.supported(grid3, roi3, k)):
+        return None
+    layout = ops.LogitsMosaic(grid3, roi3, k, dev, dtype, allocate=False)
+    need = 4.0 * layout.total
+    limit = _logits_budget(dev)
+    if dev.type == "cuda":
+        free, _ = torch.cuda.mem_get_info(dev)
+        if need > 0.9 * free:
+            raise _LogitsDoNotFit(need, float(free))
+    if limit is not None and need > limit:
+        raise _LogitsDoNotFit(need, limit)
+    return layout.allocate()
 
 
 def _blend_argmax(logits, imp, labels, grid, seg3, premultiplied: bool) -> None:

@@ -197,8 +197,8 @@ class BasicUNet(nn.Module):
     @torch.no_grad()
     def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
-        _lib.require_device(x, out)
-        if self.spatial_dims == 2 and x.dim() == 4 and out.dim() == 4:
+        _lib.require_device(x, out[0].flat if isinstance(out, tuple) else out)
+        if self.spatial_dims == 2 and x.dim() == 4 and not isinstance(out, tuple) and out.dim() == 4:
             self.forward_into(x.unsqueeze(2), out.unsqueeze(2))          # one plane of the 3-D engine (views: no copy)
             return out
         if self.training:
@@ -217,6 +217,13 @@ class BasicUNet(nn.Module):
             plan = self._plans[key] = _Plan(self, n, (d, h, w), x.device)
         plan.run(self, x, out)
         return out
+
+
+    @torch.no_grad()
+    def forward_into_windows(self, x: torch.Tensor, mosaic, w0: int) -> None:
+        """Forward of a batch of sliding-window windows whose logits go straight into the inferer's mosaic logits layout (ops.LogitsMosaic): batch
+        element i is window w0 + i; the final 1x1 convolution writes each window to its strided place (mh_conv1x1_windows_f32)."""
+        self.forward_into(x, (mosaic, int(w0)))
 
 
 BasicUnet = Basicunet = basicunet = BasicUNet
@@ -329,4 +336,7 @@ class _Plan:
             src, src_nrm = self.u[l], self.u_nrm[l]
 
         fc = net.final_conv
-        ops.conv1x1(src, src_nrm, fc.weight.view(fc.weight.shape[0], -1), fc.bias, logits)
+        if isinstance(logits, tuple):      # (mosaic, first window): the inferer's mosaic logits layout
+            ops.conv1x1_windows(src, src_nrm, fc.weight.view(fc.weight.shape[0], -1), fc.bias, logits[0], logits[1])
+        else:
+            ops.conv1x1(src, src_nrm, fc.weight.view(fc.weight.shape[0], -1), fc.bias, logits)

@@ -164,6 +164,110 @@ def avg_finalize(values: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
     return values
 
 
+class LogitsMosaic:
+    """The mosaic logits layout of the fused single-GPU sliding-window path (include/monai_amd.h: mh_sw_blend_mosaic_f32): per axis the windows
+    fall into 2^log2m residue classes (+ one class for the last, clipped window); the logits of class (cz, cy, cx) are one dense array
+    [K][cnt_z*rd][cnt_y*rh][cnt_x*rw] inside ONE flat allocation.  `supported(...)` says whether a window grid can use it."""
+
+    CLASSES = 5
+
+    @staticmethod
+    def residue_log2(n: int, step: int, roi: int):
+        """smallest power-of-two class count m with m * step >= roi (windows i, i + m do not overlap); None when more than 4 would be needed"""
+        if n <= 2:
+            return 0
+        for lg in (0, 1, 2):
+            if (step << lg) >= roi:
+                return lg
+        return None
+
+    @classmethod
+    def supported(cls, grid, roi, k: int) -> bool:
+        if k < 1 or k > 8 or roi[2] % 4 or any(v % 4 for v in grid[2]):
+            return False
+        for starts, r in zip(grid, roi):
+            n = len(starts)
+            if n > 1 and any(starts[i] != i * starts[1] for i in range(n - 1)):
+                return False
+            if n > 2 and cls.residue_log2(n, starts[1], r) is None:
+                return False
+        return True
+
+    def __init__(self, grid, roi, k: int, device, dtype=torch.float32, allocate: bool = True):
+        self.grid, self.roi, self.k = [list(g) for g in grid], tuple(int(v) for v in roi), int(k)
+        self.n = [len(g) for g in self.grid]
+        self.log2m = [self.residue_log2(n, g[1] if n > 1 else 1, r) for n, g, r in zip(self.n, self.grid, self.roi)]
+        self.cnt = []
+        for n, lg in zip(self.n, self.log2m):
+            c = (C.c_int32 * self.CLASSES)()
+            _lib.lib().call("mh_sw_mosaic_class_counts", int(n), int(lg), c)
+            self.cnt.append([int(v) for v in c])
+        # class arrays one after the other, each start 256-byte aligned and shifted by a further 17 x 256 bytes (HBM channel spread, as the
+        # padded window stride of the window-major buffer)
+        self.base = [0] * self.CLASSES ** 3
+        total = 0
+        for cz in range(self.CLASSES):
+            for cy in range(self.CLASSES):
+                for cx in range(self.CLASSES):
+                    size = self.k * self.cnt[0][cz] * self.roi[0] * self.cnt[1][cy] * self.roi[1] * self.cnt[2][cx] * self.roi[2]
+                    self.base[(cz * self.CLASSES + cy) * self.CLASSES + cx] = total
+                    if size:
+                        total = (total + size + 3) // 4 * 4
+                        if size * 4 >= (1 << 20):
+                            total = (total + 63) // 64 * 64 + 17 * 64
+        self.total, self._device, self._dtype = max(total, 4), device, dtype
+        self.flat = None
+        if allocate:
+            self.allocate()
+
+    def allocate(self):
+        self.flat = torch.empty(self.total, dtype=self._dtype, device=self._device)
+        return self
+
+    def place(self, w: int):
+        """(float offset, channel stride, z stride, y stride) of window w (row-major window index)"""
+        nz, ny, nx = self.n
+        idx = (w // (ny * nx), (w // nx) % ny, w % nx)
+        cls, j = [], []
+        for a in range(3):
+            last = idx[a] == self.n[a] - 1
+            m = 1 << self.log2m[a]
+            cls.append(m if last else idx[a] & (m - 1))
+            j.append(0 if last else idx[a] >> self.log2m[a])
+        dc, hc, wc = (self.cnt[a][cls[a]] * self.roi[a] for a in range(3))
+        off = self.base[(cls[0] * self.CLASSES + cls[1]) * self.CLASSES + cls[2]] + ((j[0] * self.roi[0]) * hc + j[1] * self.roi[1]) * wc + j[2] * self.roi[2]
+        return off, dc * hc * wc, hc * wc, wc
+
+    def window_view(self, w: int) -> torch.Tensor:
+        """[K, rd, rh, rw] strided view of window w's logits"""
+        off, sc, sd, sh = self.place(w)
+        return self.flat.as_strided((self.k,) + self.roi, (sc, sd, sh, 1), off)
+
+    def places(self, w0: int, n: int):
+        flat = [int(v) for w in range(w0, w0 + n) for v in self.place(w)]
+        return (C.c_int64 * len(flat))(*flat)
+
+
+def sw_blend_mosaic(mosaic: LogitsMosaic, imp: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """the blend of `sw_blend` over the mosaic logits layout: same arithmetic in the same order, identical bits"""
+    _lib.require_device(mosaic.flat, imp, out)
+    if not (imp.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("monai_amd.sw_blend_mosaic: contiguous tensors required")
+    k, d, h, w = out.shape
+    sz, sy, sx = mosaic.grid
+    _lib.lib().call("mh_sw_blend_mosaic_f32", _lib.ptr(mosaic.flat), (C.c_int64 * len(mosaic.base))(*mosaic.base), *[int(v) for v in mosaic.log2m], _lib.ptr(imp),
+                    _lib.ptr(out), k, d, h, w, *mosaic.roi, _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), _s(out))
+    return out
+
+
+def conv1x1_windows(x, x_nrm, weight, bias, mosaic: LogitsMosaic, w0: int):
+    """conv1x1 of a batch of windows written straight into the mosaic logits layout: batch element i is window w0 + i"""
+    _lib.require_device(x, x_nrm, weight, bias, mosaic.flat)
+    xi = _lib.tensor5(x, x_nrm)
+    _lib.lib().call("mh_conv1x1_windows_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(mosaic.flat), int(weight.shape[0]),
+                    mosaic.places(int(w0), int(x.shape[0])), _s(x))
+
+
 def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int, bounded: bool = False, algo: Optional[int] = None) -> int:
     """Kernel configuration for a 3x3x3 convolution.  `bounded`: every record of the input view carries a magnitude bound
     (written by instnorm / groupnorm_finalize, or by a raw producer into `nrm_identity` records) -- only then may the fp16

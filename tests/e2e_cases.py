@@ -550,3 +550,37 @@ def case_net_nonfinite_inputs(device, window=(32, 32, 32)):
             assert (got[0] - exp[0]).abs().max().item() < LOGIT_TOL, algo
     finally:
         config.CONV_ALGO = saved
+
+
+def case_mosaic_layout_equals_window_major(device):
+    """The fused single-GPU path keeps its logits in the mosaic layout (ops.LogitsMosaic) and the network's last kernel writes it directly; the window-major
+    buffer (MONAI_AMD_LOGITS_LAYOUT=windows; what window sharding and the fused argmax use) gives the SAME BITS -- overlap 0.5 with clipped last windows,
+    overlap 0.25, a volume of one window, constant and gaussian weights."""
+    from monai_amd.inferers import SlidingWindowInferer
+    from monai_amd.inferers import utils as U
+
+    net, _ = make_net(1, 1, 5, device, features=(16, 16, 32, 32, 64, 16))
+    used = []
+    real = U._alloc_mosaic
+
+    def spy(*a, **k):
+        m = real(*a, **k)
+        used.append(m is not None)
+        return m
+
+    U._alloc_mosaic = spy
+    try:
+        for shape, overlap, mode in (((1, 1, 40, 56, 36), 0.5, "gaussian"), ((1, 1, 44, 32, 52), 0.25, "constant"), ((2, 1, 32, 32, 32), 0.5, "gaussian")):
+            x = torch.rand(shape, generator=torch.Generator().manual_seed(61)).to(device)
+            inf = SlidingWindowInferer(roi_size=(32, 32, 32), sw_batch_size=3, overlap=overlap, mode=mode)
+            n0 = len(used)
+            a = inf(x, net)
+            assert used[n0:] and all(used[n0:]), "the mosaic layout did not run"
+            os.environ["MONAI_AMD_LOGITS_LAYOUT"] = "windows"
+            try:
+                b = inf(x, net)
+            finally:
+                del os.environ["MONAI_AMD_LOGITS_LAYOUT"]
+            assert torch.equal(a, b), f"{shape} overlap {overlap}: mosaic and window-major logits layouts differ by {(a - b).abs().max().item()}"
+    finally:
+        U._alloc_mosaic = real

@@ -291,7 +291,10 @@ def case_bound_producers(device):
     ops.deconv_k2s2(x.to(device), nrm.to(device), w.to(device), b.to(device), buf[:, 3:], ops.nrm_identity(rec[:, 3:]))
     r = rec.cpu()
     assert torch.all(r[:, :3] == 7.0) and torch.all(r[:, 3:, 0] == 1) and torch.all(r[:, 3:, 1] == 0) and torch.all(r[:, 3:, 2] == 1)
-    assert torch.equal(r[:, 3:, 3], buf.cpu()[:, 3:].abs().amax(dim=(2, 3, 4))), "deconv_k2s2: bound != max |value written|"
+    amax = buf.cpu()[:, 3:].abs().amax(dim=(2, 3, 4))
+    # one reduction per wave over the channel group a thread owns (4 channels here, 8 when Cout % 8 == 0): every channel gets its group's maximum
+    grp = torch.stack([amax[:, g:g + 4].amax(dim=1) for g in range(0, cout, 4)], dim=1).repeat_interleave(4, dim=1)[:, :cout]
+    assert torch.equal(r[:, 3:, 3], grp) and torch.all(r[:, 3:, 3] >= amax), "deconv_k2s2: bound != max |value written| of the channel group"
     out = torch.empty((n, cout) + (dims[0], 2 * dims[1], 2 * dims[2]), device=device)
     rec2 = torch.empty((n, cout, 4), device=device)
     ops.deconv_ks(x.to(device), nrm.to(device), w[:, :, :1].contiguous().to(device), b.to(device), out, (1, 2, 2), ops.nrm_identity(rec2))
@@ -488,3 +491,46 @@ def case_layernorm(device, m, k):
     assert (got - exp).abs().max().item() < 5e-6, (got - exp).abs().max().item()
     got = ops.layernorm(x.to(device), None, None, 1e-6).cpu().double()
     assert (got - F.layer_norm(x.double(), (k,), None, None, 1e-6)).abs().max().item() < 5e-6
+
+
+def case_sw_blend_mosaic(device):
+    """The mosaic logits layout (residue classes of non-overlapping windows stored as dense arrays, kernels/sliding.h): the blend over it is BIT-IDENTICAL to
+    the window-major blend (and so to the reference's scatter order) -- overlap 0.5 with a clipped last window (two classes + the last), overlap 0.25
+    (two classes with gaps), overlap 0.75 (four classes), axes with one / two windows, 1 ... 8 output channels; conv1x1_windows writes the layout."""
+    gen = torch.Generator().manual_seed(41)
+    for img, roi, overlap, k in (((40, 24, 56), (16, 12, 16), 0.5, 5), ((44, 20, 36), (16, 12, 16), 0.25, 3), ((28, 12, 40), (16, 12, 16), 0.75, 2),
+                                 ((16, 12, 72), (16, 12, 16), 0.5, 8), ((48, 30, 20), (16, 12, 16), 0.5, 1)):
+        itv = osw.get_scan_interval(img, roi, (overlap,) * 3)
+        starts, _ = osw.dense_patch_starts(img, roi, itv)
+        assert ops.LogitsMosaic.supported(starts, roi, k), (img, overlap)
+        nwin = int(np.prod([len(s) for s in starts]))
+        logits = torch.randn((nwin, k) + tuple(roi), generator=gen)
+        imp = osw.compute_importance_map(roi, mode="gaussian", sigma_scale=0.125)
+        exp = reference_blend(logits, imp, img, roi, starts)
+        mos = ops.LogitsMosaic(starts, roi, k, device)
+        mos.flat.fill_(float("nan"))
+        for w in range(nwin):
+            mos.window_view(w).copy_(logits[w].to(device))
+        assert int(torch.isnan(mos.flat).sum()) == mos.flat.numel() - logits.numel(), "windows must tile the class arrays exactly once"
+        out = torch.full((k,) + tuple(img), float("nan"), device=device)
+        ops.sw_blend_mosaic(mos, imp.to(device), out)
+        assert torch.equal(out.cpu(), exp), f"mosaic blend {img} overlap {overlap}: max diff {(out.cpu() - exp).abs().max().item()}"
+        # the writer: conv1x1 of a window batch straight into the layout == conv1x1 into a dense batch, window by window
+        cin = 8
+        x = torch.randn((nwin, cin) + tuple(roi), generator=gen)
+        nrm = _rand_nrm(nwin, cin, gen)
+        wgt = torch.randn((k, cin), generator=gen) / np.sqrt(cin)
+        b = torch.randn(k, generator=gen) * 0.1
+        dense = torch.empty((nwin, k) + tuple(roi), device=device)
+        ops.conv1x1(x.to(device), nrm.to(device), wgt.to(device), b.to(device), dense)
+        mos.flat.fill_(float("nan"))
+        half = nwin // 2
+        ops.conv1x1_windows(x[:half].to(device), nrm[:half].to(device), wgt.to(device), b.to(device), mos, 0)
+        if nwin - half:
+            ops.conv1x1_windows(x[half:].to(device), nrm[half:].to(device), wgt.to(device), b.to(device), mos, half)
+        for w in range(nwin):
+            assert torch.equal(mos.window_view(w).cpu(), dense[w].cpu()), (img, w)
+    # grids the layout does not take
+    assert not ops.LogitsMosaic.supported([[0, 1, 3, 5], [0, 6], [0, 4, 12]], (4, 6, 8), 3)            # irregular starts
+    assert not ops.LogitsMosaic.supported([[0, 2, 4, 6, 7], [0], [0]], (16, 8, 8), 3)                   # step 2, roi 16: more than 4 classes
+    assert not ops.LogitsMosaic.supported([[0], [0], [0, 6, 10]], (8, 8, 10), 3)                        # x extents not divisible by 4

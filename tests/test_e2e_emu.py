@@ -165,3 +165,7 @@ def test_nets_with_trained_like_affine_spreads(emu):
 
 def test_net_nonfinite_inputs_like_the_reference(emu):
     ec.case_net_nonfinite_inputs("cpu")
+
+
+def test_mosaic_layout_equals_window_major(emu):
+    ec.case_mosaic_layout_equals_window_major("cpu")

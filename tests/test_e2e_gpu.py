@@ -92,6 +92,10 @@ def test_headline_125_windows_vs_oracle_288_both_arithmetics():
         print(algo, oracle.assert_label_parity(got[algo], ref, tol=ec.LOGIT_TOL, what=f"288^3 / 125 windows of 96^3 / {algo}"))
 
 
+def test_mosaic_layout_equals_window_major():
+    ec.case_mosaic_layout_equals_window_major(DEV)
+
+
 def test_nets_with_trained_like_affine_spreads():
     """gamma in +-[1e-3, 1e3], |beta| to ~1e3 (activations far beyond fp16's 65504 inside the nets), one raw-CT-valued window: the default path vs the
     CPU oracle at 1e-4 of the logit scale, and never worse than 4x the exact-fp32 kernels' own distance from it"""

@@ -186,6 +186,10 @@ def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
+def test_sw_blend_mosaic_layout(emu):
+    kc.case_sw_blend_mosaic("cpu")
+
+
 def test_h2_input_scaling(emu):
     kc.case_h2_input_scaling("cpu")
 

@@ -158,6 +158,10 @@ def test_layernorm(m, k):
     kc.case_layernorm(DEV, m, k)
 
 
+def test_sw_blend_mosaic_layout():
+    kc.case_sw_blend_mosaic(DEV)
+
+
 def test_h2_input_scaling():
     """the split-precision convolution at input magnitudes 1e-20 ... 1e20 (incl. > 65504): accuracy of the exact-fp32 tiles"""
     kc.case_h2_input_scaling(DEV)
