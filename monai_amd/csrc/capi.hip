@@ -305,7 +305,18 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
     }
     const unsigned nb = blocks_for((long long)D * H * (W / 4));
     hipStream_t s = (hipStream_t)stream;
-#define MH_BM_CASE(KT) case KT: hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, MH_BLEND_G>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); break;
+#define MH_BM(KT, G_, NT_) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms)
+#ifdef MH_DEV_KNOBS
+    if (K == 5) {        // A/B of the window-batch size and of non-temporal accesses on the benchmark shape (tools/blend_bench.py with the -DMH_DEV_KNOBS library)
+        const int g_ = knob_int("MONAI_AMD_BLEND_G", MH_BLEND_G), nt_ = knob_int("MONAI_AMD_BLEND_NT", 0);
+        if (g_ == 1 && !nt_) { MH_BM(5, 1, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 1 && nt_) { MH_BM(5, 1, true); return launched("sw_blend_mosaic"); }
+        if (g_ == 2 && nt_) { MH_BM(5, 2, true); return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && !nt_) { MH_BM(5, 4, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && nt_) { MH_BM(5, 4, true); return launched("sw_blend_mosaic"); }
+    }
+#endif
+#define MH_BM_CASE(KT) case KT: MH_BM(KT, MH_BLEND_G, false); break;
     switch (K) { MH_BM_CASE(1) MH_BM_CASE(2) MH_BM_CASE(3) MH_BM_CASE(4) MH_BM_CASE(5) MH_BM_CASE(6) MH_BM_CASE(7) MH_BM_CASE(8) }
 #undef MH_BM_CASE
     return launched("sw_blend_mosaic");

@@ -354,7 +354,7 @@ __device__ __forceinline__ void mosaic_axis_locate(const MosaicAxis& a, int n, i
     j = last ? 0 : (i >> a.log2m);
 }
 
-template <int KT, int G>
+template <int KT, int G, bool NT>
 __global__ void __launch_bounds__(256)
 sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K, int D, int H, int W, int rd,
                        int rh, int rw, RegGrid g, Mosaic ms) {
@@ -407,7 +407,8 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
             wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(logits + base + (long long)k * cs);
+                const f32x4* lp_ = reinterpret_cast<const f32x4*>(logits + base + (long long)k * cs);
+                const f32x4 a = NT ? __builtin_nontemporal_load(lp_) : *lp_;
                 lv[b][k][0] = a[0]; lv[b][k][1] = a[1]; lv[b][k][2] = a[2]; lv[b][k][3] = a[3];
             }
         }
@@ -430,7 +431,8 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const f32x4 r = {__fdiv_rn(acc[k][0], cnt[0]), __fdiv_rn(acc[k][1], cnt[1]), __fdiv_rn(acc[k][2], cnt[2]), __fdiv_rn(acc[k][3], cnt[3])};
-        *reinterpret_cast<f32x4*>(op + k * vox) = r;
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<f32x4*>(op + k * vox));
+        else *reinterpret_cast<f32x4*>(op + k * vox) = r;
     }
 }
 

@@ -33,7 +33,7 @@ def report(got: torch.Tensor, exp: torch.Tensor):
                 max_margin_at_mismatch=(margin[mism].max().item() if mism.any() else 0.0))
 
 
-def case_net_single_window_vs_golden(device):
+def case_net_single_window_vs_golden(device, second_window=True):
     """5-class bench weights (seed 1) on the golden windows produced by the REAL reference."""
     g = np.load(os.path.join(GOLDEN, "net5.npz"))
     net, sd = make_net(1, 1, 5, device)
@@ -48,6 +48,8 @@ def case_net_single_window_vs_golden(device):
     got = net(x.to(device)).cpu()
     r = report(got, torch.from_numpy(g["net5_win32_out"]))
     assert r["max_abs"] < LOGIT_TOL, r
+    if not second_window:
+        return r, None
     torch.manual_seed(22)
     x = torch.rand(1, 1, 48, 32, 16)
     got = net(x.to(device)).cpu()
@@ -528,12 +530,12 @@ def case_nets_with_spread_affine(device, window=(32, 32, 32), nets=("basic_unet"
     return out
 
 
-def case_net_nonfinite_inputs(device, window=(32, 32, 32)):
+def case_net_nonfinite_inputs(device, window=(32, 32, 32), features=(32, 32, 64, 128, 256, 32)):
     """inf / NaN voxels in one window of a batch: the reference (conv -> InstanceNorm, blocks/convolutions.py:98-171) turns THAT sample into NaN and
     leaves the others alone; so does the engine on its default (split-precision) path and on the exact-fp32 kernels."""
     from monai_amd import config
 
-    net, sd = make_net(1, 1, 5, device)
+    net, sd = make_net(1, 1, 5, device, features=features)
     gen = torch.Generator().manual_seed(98)
     x = torch.rand((3, 1) + tuple(window), generator=gen)
     x[1, 0, 5, 6, 7] = float("inf")
@@ -552,7 +554,10 @@ def case_net_nonfinite_inputs(device, window=(32, 32, 32)):
         config.CONV_ALGO = saved
 
 
-def case_mosaic_layout_equals_window_major(device):
+MOSAIC_CASES = (((1, 1, 40, 56, 36), 0.5, "gaussian"), ((1, 1, 44, 32, 52), 0.25, "constant"), ((2, 1, 32, 32, 32), 0.5, "gaussian"))
+
+
+def case_mosaic_layout_equals_window_major(device, cases=MOSAIC_CASES):
     """The fused single-GPU path keeps its logits in the mosaic layout (ops.LogitsMosaic) and the network's last kernel writes it directly; the window-major
     buffer (MONAI_AMD_LOGITS_LAYOUT=windows; what window sharding and the fused argmax use) gives the SAME BITS -- overlap 0.5 with clipped last windows,
     overlap 0.25, a volume of one window, constant and gaussian weights."""
@@ -570,7 +575,7 @@ def case_mosaic_layout_equals_window_major(device):
 
     U._alloc_mosaic = spy
     try:
-        for shape, overlap, mode in (((1, 1, 40, 56, 36), 0.5, "gaussian"), ((1, 1, 44, 32, 52), 0.25, "constant"), ((2, 1, 32, 32, 32), 0.5, "gaussian")):
+        for shape, overlap, mode in cases:
             x = torch.rand(shape, generator=torch.Generator().manual_seed(61)).to(device)
             inf = SlidingWindowInferer(roi_size=(32, 32, 32), sw_batch_size=3, overlap=overlap, mode=mode)
             n0 = len(used)
