@@ -86,9 +86,12 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
  * (HOST int64[125]) from `logits`, window (jz, jy, jx) of the class (j = i >> log2m) at its mosaic position; mh_sw_mosaic_class_counts gives cnt per
  * class of an axis with n windows.  At overlap 0.5 the blend then reads 1 KB runs per wave from <= 8 (27) arrays instead of 384-byte pieces of
  * 8 (27) x K window blocks.  Same arithmetic in the same (ascending window) order as mh_sw_blend_f32: identical bits.  Regular grids, K <= 8, extents
- * divisible by 4; MH_ERR_UNSUPPORTED otherwise (use the window-major layout).  mh_conv1x1_windows_f32 writes the layout. */
+ * divisible by 4; MH_ERR_UNSUPPORTED otherwise (use the window-major layout).  mh_conv1x1_windows_f32 writes the layout.
+ * imp_factored != 0: `imp` is not the [rd][rh][rw] map but its factors [gz (rd) | gy (rh) | gx (rw) | floor] with map[z][y][x] = max(fl(fl(gz[z] gy[y]) gx[x]),
+ * floor) -- how compute_importance_map (monai/data/utils.py:1084-1134) forms the gaussian and the constant map; the kernel re-forms the same fp32 values in
+ * registers ((rd + rh) % 4 == 0 required). */
 int mh_sw_mosaic_class_counts(int n, int log2m, int32_t* counts5);
-int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, float* out, int K,
+int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, int imp_factored, float* out, int K,
                            int D, int H, int W, int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
                            void* stream);
 

@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
     out = OUT_DEV if dev else OUT
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in _deps()):
         return out
-    cmd = [hipcc()] + FLAGS + (["-DMH_DEV_KNOBS"] if dev else []) + [SRC, "-o", out]
+    cmd = [hipcc()] + FLAGS + (["-DMH_DEV_KNOBS"] + [f for f in os.environ.get("MONAI_AMD_DEV_FLAGS", "").split() if f] if dev else []) + [SRC, "-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

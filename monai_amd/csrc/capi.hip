@@ -281,7 +281,7 @@ int mh_sw_mosaic_class_counts(int n, int log2m, int32_t* counts5) {
     return MH_OK;
 }
 
-int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, float* out, int K,
+int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int log2m_z, int log2m_y, int log2m_x, const float* imp, int imp_factored, float* out, int K,
                            int D, int H, int W, int rd, int rh, int rw, const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx,
                            void* stream) {
     int64_t dense = 0;
@@ -290,7 +290,7 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
     if (K < 1 || K > 8) return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: 1 .. 8 classes (got %d): use the window-major layout", K);
     RegGrid rg;
     if (!regular_grid(rg, sz, nz, sy, ny, sx, nx, D, H, W)) return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: irregular window starts (use the window-major layout)");
-    if (!(W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16)))
+    if (!(W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx) && aligned(logits, 16) && aligned(imp, 16) && aligned(out, 16)) || (imp_factored && (rd + rh) % 4))
         return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: needs W, roi width and window starts divisible by 4 and 16-byte aligned buffers");
     // windows i and i + m of an axis must not overlap
     const AxisWin* ax[3] = {&rg.z, &rg.y, &rg.x};
@@ -305,20 +305,21 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
     }
     const unsigned nb = blocks_for((long long)D * H * (W / 4));
     hipStream_t s = (hipStream_t)stream;
-#define MH_BM(KT, G_, NT_) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms)
+#define MH_BM(KT, G_, NT_, SEP_) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms)
 #ifdef MH_DEV_KNOBS
-    if (K == 5) {        // A/B of the window-batch size and of non-temporal accesses on the benchmark shape (tools/blend_bench.py with the -DMH_DEV_KNOBS library)
+    if (K == 5 && !imp_factored) {        // A/B of the window-batch size and of non-temporal accesses on the benchmark shape (tools/blend_bench.py with the -DMH_DEV_KNOBS library)
         const int g_ = knob_int("MONAI_AMD_BLEND_G", MH_BLEND_G), nt_ = knob_int("MONAI_AMD_BLEND_NT", 0);
-        if (g_ == 1 && !nt_) { MH_BM(5, 1, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 1 && nt_) { MH_BM(5, 1, true); return launched("sw_blend_mosaic"); }
-        if (g_ == 2 && nt_) { MH_BM(5, 2, true); return launched("sw_blend_mosaic"); }
-        if (g_ == 4 && !nt_) { MH_BM(5, 4, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 4 && nt_) { MH_BM(5, 4, true); return launched("sw_blend_mosaic"); }
+        if (g_ == 1 && !nt_) { MH_BM(5, 1, false, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 1 && nt_) { MH_BM(5, 1, true, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 2 && nt_) { MH_BM(5, 2, true, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && !nt_) { MH_BM(5, 4, false, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && nt_) { MH_BM(5, 4, true, false); return launched("sw_blend_mosaic"); }
     }
 #endif
-#define MH_BM_CASE(KT) case KT: MH_BM(KT, MH_BLEND_G, false); break;
+#define MH_BM_CASE(KT) case KT: if (imp_factored) MH_BM(KT, MH_BLEND_G, false, true); else MH_BM(KT, MH_BLEND_G, false, false); break;
     switch (K) { MH_BM_CASE(1) MH_BM_CASE(2) MH_BM_CASE(3) MH_BM_CASE(4) MH_BM_CASE(5) MH_BM_CASE(6) MH_BM_CASE(7) MH_BM_CASE(8) }
 #undef MH_BM_CASE
+#undef MH_BM
     return launched("sw_blend_mosaic");
 }
 

@@ -13,6 +13,13 @@
 #define MH_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
+// write-once result rows of the streaming transforms (Gaussian): -DMH_DEV_NT_STORES (measurement builds) makes them non-temporal
+#ifdef MH_DEV_NT_STORES
+#define MH_STREAM_STORE4(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<mh::f32x4*>(ptr))
+#else
+#define MH_STREAM_STORE4(ptr, val) (*reinterpret_cast<mh::f32x4*>(ptr) = (val))
+#endif
+
 namespace mh {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

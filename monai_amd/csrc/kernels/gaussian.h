@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(64 * gv_waves(RK)) gauss3d_rowvec_kernel(const
                 const f32x4 rv_ = ring[p][((S0) + k) % RK];                                           \
                 acc_ = __builtin_elementwise_fma(f32x4{wkz[k], wkz[k], wkz[k], wkz[k]}, rv_, acc_);     \
             }                                                                                         \
-            if (rowok[p]) *reinterpret_cast<f32x4*>(obase + (long long)(ZO) * plane + (long long)p * a.W) = acc_; \
+            if (rowok[p]) MH_STREAM_STORE4(obase + (long long)(ZO) * plane + (long long)p * a.W, acc_);   \
         }                                                                                             \
     }
 

@@ -354,7 +354,10 @@ __device__ __forceinline__ void mosaic_axis_locate(const MosaicAxis& a, int n, i
     j = last ? 0 : (i >> a.log2m);
 }
 
-template <int KT, int G, bool NT>
+// SEP: the importance map is given by its factors -- fac = [gz (rd) | gy (rh) | gx (rw) | floor]: map[z][y][x] = max(fl(fl(gz[z] * gy[y]) * gx[x]), floor), the
+// way the reference builds the gaussian (and the constant) map (monai/data/utils.py:1084-1134) -- and is re-formed in registers, bit for bit: three
+// vectors of roi floats that stay in L1 instead of 8 ... 27 loads per output voxel group from a roi^3 map that competes with the logits stream for L2.
+template <int KT, int G, bool NT, bool SEP>
 __global__ void __launch_bounds__(256)
 sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K, int D, int H, int W, int rd,
                        int rh, int rw, RegGrid g, Mosaic ms) {
@@ -403,8 +406,16 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
             if (ok) {
                 if (++ix > xhi) { ix = xlo; if (++iy > yhi) { iy = ylo; ++iz; } }
             }
-            const f32x4 q = *reinterpret_cast<const f32x4*>(imp + off);
-            wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
+            if (SEP) {
+                const int lzc = ok ? lz : 0, lyc = ok ? ly : 0, lxc = ok ? lx : 0;          // past the end of the box: any valid entry (unused)
+                const float zy = __fmul_rn(imp[lzc], imp[rd + lyc]), fl_ = imp[rd + rh + rw];
+                const f32x4 q = *reinterpret_cast<const f32x4*>(imp + rd + rh + lxc);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) wt[b][v] = fmaxf(__fmul_rn(zy, q[v]), fl_);
+            } else {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(imp + off);
+                wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
+            }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
                 const f32x4* lp_ = reinterpret_cast<const f32x4*>(logits + base + (long long)k * cs);

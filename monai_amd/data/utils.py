@@ -84,6 +84,29 @@ def compute_importance_map(patch_size, mode="constant", sigma_scale=0.125, devic
     return weights.to(device)
 
 
+def importance_map_factors(patch_size, mode="constant", sigma_scale=0.125):
+    """The 1-D factors behind ``compute_importance_map`` for a 3-D patch: ``(gz, gy, gx, floor)`` with
+    ``map[z, y, x] == max(fl(fl(gz[z] * gy[y]) * gx[x]), floor)`` in fp32 -- the order in which the reference multiplies the axes together
+    (monai/data/utils.py:1113-1126).  The blend kernel re-forms the map from them in registers; ``None`` when the patch is not 3-D or the
+    factorisation does not reproduce the map bit for bit (checked here, on the host)."""
+    patch_size = tuple(int(p) for p in patch_size)
+    if len(patch_size) != 3:
+        return None
+    if look_up_option(mode, ("constant", "gaussian"), "mode") == "constant":
+        fac = [torch.ones(n, dtype=torch.float) for n in patch_size]
+    else:
+        fac = []
+        for n, s in zip(patch_size, ensure_tuple_rep(sigma_scale, 3)):
+            offs = torch.arange(start=-(n - 1) / 2.0, end=(n - 1) / 2.0 + 1, dtype=torch.float)
+            fac.append(torch.exp(offs**2 / (-2 * (n * s) ** 2)))
+    full = compute_importance_map(patch_size, mode=mode, sigma_scale=sigma_scale, device="cpu", dtype=torch.float32)
+    prod = (fac[0][:, None] * fac[1][None, :])[:, :, None] * fac[2][None, None, :]
+    floor = float(max(prod.min().item(), 1e-3))
+    if not torch.equal(torch.clamp(prod, min=floor), full):
+        return None
+    return fac[0], fac[1], fac[2], floor
+
+
 # --------------------------------------------------------------------------------------------------------
 # voxel <-> world affine helpers (fp64, host) -- monai/data/utils.py:737-982
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .. import _lib, _prof, ops, parallel
 from .._fallback import function_fallback
-from ..data.utils import compute_importance_map, get_valid_patch_size, window_starts
+from ..data.utils import compute_importance_map, get_valid_patch_size, importance_map_factors, window_starts
 from ..utils.misc import ensure_tuple, ensure_tuple_rep, fall_back_tuple, look_up_option
 
 __all__ = ["sliding_window_inference", "sliding_window_argmax"]
@@ -375,7 +375,7 @@ def sliding_window_inference(
             nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
                 if lg is mosaic:
-                    ops.sw_blend_mosaic(mosaic, weights[ss], outputs[ss][b])
+                    ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
                 elif argmax_dtype is not None:
                     _blend_argmax(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b, 0], g,
                                   _to3(seg_shapes[ss], 1), premultiplied=proc_weights is not None)
@@ -425,6 +425,21 @@ def _host_importance_map(patch_size, mode, sigma_scale, dtype):
             _DEVICE_MAPS.clear()
         hit = _HOST_MAPS[key] = compute_importance_map(patch_size, mode=mode, sigma_scale=sigma_scale, device="cpu", dtype=dtype)
     return hit, key
+
+
+def _factored_map(imp_key, roi3, mode, sigma_scale, dev) -> torch.Tensor:
+    """[gz | gy | gx | floor] on the device for the mosaic blend (it re-forms the importance map from its factors in registers: same fp32 values, no
+    roi^3 map competing with the logits stream for L2), or the full map when the factorisation is not available (non-3-D roi, alignment)."""
+    key = ("factored",) + imp_key + (str(dev),)
+    hit = _DEVICE_MAPS.get(key)
+    if hit is None:
+        fac = importance_map_factors(imp_key[0], mode, sigma_scale) if len(imp_key[0]) == 3 and (roi3[0] + roi3[1]) % 4 == 0 else None
+        if fac is None:
+            hit = _on_device(_HOST_MAPS[imp_key].reshape(roi3).contiguous(), dev, cache_key=imp_key + (tuple(roi3),))
+        else:
+            hit = torch.cat([fac[0], fac[1], fac[2], torch.tensor([fac[3]], dtype=torch.float32)]).to(dev)
+        _DEVICE_MAPS[key] = hit
+    return hit
 
 
 def _on_device(host_map: torch.Tensor, dev, cache_key=None) -> torch.Tensor:

@@ -249,14 +249,18 @@ class LogitsMosaic:
 
 
 def sw_blend_mosaic(mosaic: LogitsMosaic, imp: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """the blend of `sw_blend` over the mosaic logits layout: same arithmetic in the same order, identical bits"""
+    """the blend of `sw_blend` over the mosaic logits layout: same arithmetic in the same order, identical bits.  `imp`: the [rd, rh, rw] importance
+    map, or its factors as ONE 1-D tensor [gz | gy | gx | floor] (rd + rh + rw + 1 floats; see include/monai_amd.h)"""
     _lib.require_device(mosaic.flat, imp, out)
     if not (imp.is_contiguous() and out.is_contiguous()):
         raise RuntimeError("monai_amd.sw_blend_mosaic: contiguous tensors required")
+    factored = imp.dim() == 1
+    if factored and imp.numel() != sum(mosaic.roi) + 1:
+        raise RuntimeError("monai_amd.sw_blend_mosaic: factored importance map must hold rd + rh + rw + 1 floats")
     k, d, h, w = out.shape
     sz, sy, sx = mosaic.grid
     _lib.lib().call("mh_sw_blend_mosaic_f32", _lib.ptr(mosaic.flat), (C.c_int64 * len(mosaic.base))(*mosaic.base), *[int(v) for v in mosaic.log2m], _lib.ptr(imp),
-                    _lib.ptr(out), k, d, h, w, *mosaic.roi, _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), _s(out))
+                    int(factored), _lib.ptr(out), k, d, h, w, *mosaic.roi, _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), _s(out))
     return out
 
 

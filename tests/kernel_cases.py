@@ -515,6 +515,14 @@ def case_sw_blend_mosaic(device):
         out = torch.full((k,) + tuple(img), float("nan"), device=device)
         ops.sw_blend_mosaic(mos, imp.to(device), out)
         assert torch.equal(out.cpu(), exp), f"mosaic blend {img} overlap {overlap}: max diff {(out.cpu() - exp).abs().max().item()}"
+        # the importance map given by its factors [gz | gy | gx | floor] and re-formed in registers: the same bits
+        from monai_amd.data.utils import importance_map_factors
+
+        fac = importance_map_factors(roi, "gaussian", 0.125)
+        assert fac is not None
+        out.fill_(float("nan"))
+        ops.sw_blend_mosaic(mos, torch.cat([fac[0], fac[1], fac[2], torch.tensor([fac[3]])]).to(device), out)
+        assert torch.equal(out.cpu(), exp), f"mosaic blend with a factored importance map {img}: max diff {(out.cpu() - exp).abs().max().item()}"
         # the writer: conv1x1 of a window batch straight into the layout == conv1x1 into a dense batch, window by window
         cin = 8
         x = torch.randn((nwin, cin) + tuple(roi), generator=gen)

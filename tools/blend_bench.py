@@ -59,9 +59,16 @@ ref = out.clone()
 mos = ops.LogitsMosaic(starts, (R,) * 3, K, dev)
 for w in range(nwin):
     mos.window_view(w).copy_(logits[w])
+from monai_amd.data.utils import importance_map_factors  # noqa: E402
+
+fac = importance_map_factors((R,) * 3, "gaussian", 0.125)
+facvec = torch.cat([fac[0], fac[1], fac[2], torch.tensor([fac[3]])]).to(dev)
 for rep in range(2):
     out.zero_()
     run(f"mosaic layout (pass {rep})", lambda: ops.sw_blend_mosaic(mos, imp, out))
+    res["runs"][-1]["bitwise_equal_to_window_major"] = bool(torch.equal(out, ref))
+    out.zero_()
+    run(f"mosaic layout, importance map re-formed from its factors (pass {rep})", lambda: ops.sw_blend_mosaic(mos, facvec, out))
     res["runs"][-1]["bitwise_equal_to_window_major"] = bool(torch.equal(out, ref))
     out.zero_()
     run(f"window-major (pass {rep})", lambda: ops.sw_blend(logits, imp, out, starts, (R,) * 3))
