@@ -207,9 +207,10 @@ int mh_add_act_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const 
  * F.pad(x_0, sp, "replicate") for odd encoder extents -- monai/networks/nets/basic_unet.py:163-170.  Raw copy. */
 int mh_pad_replicate_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
 
-/* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*64] (the qkv Linear's output,
- * feature index = which*heads*64 + head*64 + d) -> out [B][S][heads*64] = softmax(Q K^T * scale) V per head, on
- * v_mfma_f32_32x32x2_f32 with K/V of a head resident in LDS.  head_dim 64, S <= 224 (ViT-B/16 on 96^3: S = 216). */
+/* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*HD] (the qkv Linear's output, feature index =
+ * which*heads*HD + head*HD + d) -> out [B][S][heads*HD] = softmax(Q K^T * scale) V per head, on the fp16 matrix cores in two-piece split precision
+ * (fp32-equivalent: hi*hi + lo*hi + hi*lo, fp32 accumulation; |q|, |k|, |v| < 65504), keys / values streamed through LDS in tiles of 32 with an online
+ * softmax: ANY sequence length.  head_dim 32, 64, 96 or 128; 16-byte aligned tensors. */
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream);
 
 /* Window attention of SwinUNETR's Swin transformer (WindowAttention.forward, monai/networks/nets/swin_unetr.py:519-541):

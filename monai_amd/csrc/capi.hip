@@ -1275,15 +1275,17 @@ int mh_pad_replicate_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* st
 
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream) {
     if (!qkv || !out || B < 1 || S < 1 || heads < 1) return fail(MH_ERR_ARG, "attention: bad argument");
-    if (head_dim != 64) return fail(MH_ERR_UNSUPPORTED, "attention: head_dim %d is not built (64 is)", head_dim);
-    if (S > 224) return fail(MH_ERR_UNSUPPORTED, "attention: sequence length %d exceeds the LDS-resident limit of 224", S);
-    const dim3 grid((unsigned)heads, (unsigned)B);
+    if (!aligned(qkv, 16) || !aligned(out, 16)) return fail(MH_ERR_ARG, "attention: 16-byte aligned tensors required");
+    if (B > 65535 || heads > 65535) return fail(MH_ERR_UNSUPPORTED, "attention: more than 65535 batches / heads in one launch");
+    const dim3 grid((unsigned)cdiv(S, 128), (unsigned)heads, (unsigned)B);
     hipStream_t s = (hipStream_t)stream;
-    const int kt = cdiv(S, 32);
-    if (kt <= 1) hipLaunchKernelGGL((attention_kernel<1>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
-    else if (kt <= 2) hipLaunchKernelGGL((attention_kernel<2>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
-    else if (kt <= 4) hipLaunchKernelGGL((attention_kernel<4>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
-    else hipLaunchKernelGGL((attention_kernel<7>), grid, dim3(256), 0, s, qkv, out, S, heads, scale);
+    switch (head_dim) {          // any sequence length: keys / values stream through LDS (kernels/attention.h)
+        case 32: hipLaunchKernelGGL((attention_h2_kernel<32>), grid, dim3(256), 0, s, qkv, out, S, heads, scale); break;
+        case 64: hipLaunchKernelGGL((attention_h2_kernel<64>), grid, dim3(256), 0, s, qkv, out, S, heads, scale); break;
+        case 96: hipLaunchKernelGGL((attention_h2_kernel<96>), grid, dim3(256), 0, s, qkv, out, S, heads, scale); break;
+        case 128: hipLaunchKernelGGL((attention_h2_kernel<128>), grid, dim3(256), 0, s, qkv, out, S, heads, scale); break;
+        default: return fail(MH_ERR_UNSUPPORTED, "attention: head_dim %d is not built (32, 64, 96, 128 are)", head_dim);
+    }
     return launched("attention");
 }
 

@@ -1,106 +1,171 @@
-// Multi-head self-attention core of UNETR's ViT encoder (softmax(Q K^T * scale) V) on the fp32 matrix cores.
+// Multi-head self-attention core of UNETR's ViT encoder (softmax(Q K^T * scale) V) on the matrix cores.
 //
 // Reference: SABlock.forward, monai/networks/blocks/selfattention.py:156-218 -- qkv = Linear(x) rearranged
 // "b h (qkv l d) -> qkv b l h d", att = einsum("blxd,blyd->blxy") * scale, softmax(-1), einsum("bhxy,bhyd->bhxd"),
-// "b l h d -> b h (l d)".  This kernel consumes the qkv projection output directly ([B][S][3*heads*64]) and writes
-// the pre-out_proj tensor ([B][S][heads*64]): neither the [B,heads,S,S] score tensor nor the rearranged copies exist.
-//
-// One workgroup = one (batch, head); K (transposed) and V of the head sit in LDS (2 x 57 KB at S = 216, of 160 KB).
-// A wave owns 32 queries at a time and computes the TRANSPOSED score tile S^T = K Q^T with v_mfma_f32_32x32x2_f32:
-// lane l then holds, for query (l & 31), the keys (r&3)+8(r>>2)+4(l>>5) of every key tile in its accumulator
-// registers -- exactly the A-operand layout of the following P V product (A[i=query][k] lives in lane i + 32k), so the
-// softmax runs in registers (one lane-pair shuffle for max and sum) and P is never moved: the k-slices of each PV MFMA
-// are simply the key pair (key, key+4) that the two half-waves already hold.  fp32 in, fp32 accumulate, exact expf.
+// "b l h d -> b h (l d)".  The kernel consumes the qkv projection output directly ([B][S][3*heads*HD]) and writes
+// the pre-out_proj tensor ([B][S][heads*HD]): neither the [B,heads,S,S] score tensor nor the rearranged copies exist.
+// (Round 1-2 ran this on the fp32 matrix cores with K and V of a head resident in LDS: S <= 224, 36-38 TF = 0.23 of the fp32 peak -- one LDS read
+// per 32x32x2 MFMA.  Replaced by the streaming split-precision kernel below.)
 #pragma once
 #include "common.h"
 
 namespace mh {
 
-template <int KT>   // key tiles of 32 (sequence length <= 32*KT)
-__global__ void __launch_bounds__(256) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads, float scale) {
-    constexpr int KP = KT * 32, KSTR = KP + 1;       // padded key count; odd row stride: conflict-free transposed writes
-    __shared__ float kt_s[64 * KSTR];                 // K^T : [d][key]
-    __shared__ float v_s[KP * 64];                    // V   : [key][d]
-    __shared__ float lsum[4 * 32];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, hi = lane >> 5;
-    const int head = blockIdx.x, b = blockIdx.y;
-    const int hd = heads * 64;
-    const float* base = qkv + (long long)b * S * 3 * hd;
+// ---------------------------------------------------------------------------------------------------
+// Attention for ANY sequence length, on the fp16 matrix cores in two-piece split precision (fp32-equivalent, like linear_h2_kernel and
+// conv3d_k3_h2_kernel: every fp32 operand x = hi + lo with hi = fp16(x), lo = fp16(x - hi); a product is hi*hi + lo*hi + hi*lo, each exact in fp32,
+// accumulated in fp32 by v_mfma_f32_32x32x16_f16) -- 3/16 of the fp32 matrix-core cycles.  Keys / values stream through LDS in tiles of 32 with an online softmax, so the
+// reference's own docstring example (UNETR img_size 128^3 = 512 tokens, monai/networks/nets/unetr.py:75) and anything longer run on it.
+//
+// A workgroup = 4 waves = 128 queries of one (batch, head); wave w owns queries 32 w .. 32 w + 31 and keeps, per lane (query l & 31, half l >> 5):
+//   * Q as the B operand of S^T = K Q^T (hi / lo pieces, HD / 16 k-steps);
+//   * the score tile S^T in the accumulator layout of the 32x32 MFMA: register r = key (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the tile, i.e. the two lanes of
+//     a query hold its 32 keys between them -- max / sum need one lane-pair shuffle;
+//   * O^T = V^T P^T (M = head dim, N = query, K = key): the B operand P^T wants, per k-step s and half, the keys of registers 8 s .. 8 s + 7 of THIS lane, so
+//     the probabilities never leave their registers; V^T is staged in LDS with the tile's keys permuted into that order (position 16 s + 8 half + j <->
+//     key (r & 3) + 8 (r >> 2) + 4 half, r = 8 s + j).  O^T's accumulator holds, in the lane of a query, that query's outputs: the running rescale
+//     by exp(m_old - m_new) is a per-lane scalar.
+// Range: q, k, v must stay below 65504 in magnitude (fp16); they are outputs of a Linear over LayerNorm-ed tokens (|x| of order 1-10) -- a value beyond it
+// turns the affected outputs into NaN (loud), it does not saturate silently.  exp via v_exp_f32 (exp2 of the log2(e)-scaled argument, <= 1 ulp + the
+// argument's rounding: 1e-6 relative at |s - m| ~ 20, where the probability itself is 2e-9).
+template <int HD>      // head dimension: a multiple of 32, <= 128
+__global__ void __launch_bounds__(256) attention_h2_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S, int heads, float scale) {
+    constexpr int KS = HD / 16, NT = HD / 32, PER = HD / 8;       // k-steps of K Q^T, 32-row tiles of O^T, floats a thread stages per key row
+    constexpr int KP = HD + 8, VP = 40;                            // LDS pitches in halves (16-byte aligned rows that start in different banks)
+    __shared__ __attribute__((aligned(16))) _Float16 ks[2][2][32 * KP];     // [buffer][piece][key][d]
+    __shared__ __attribute__((aligned(16))) _Float16 vs[2][2][HD * VP];     // [buffer][piece][d][permuted key]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, b = blockIdx.z;
+    const int hd = heads * HD;
+    const float* base = qkv + (long long)b * S * 3 * hd + head * HD;
+    const int query = blockIdx.x * 128 + wave * 32 + li;
+    const int ntiles = (S + 31) / 32;
 
-    for (int i = tid; i < KP * 64; i += 256) {
-        const int s = i >> 6, d = i & 63;
-        float kv = 0.0f, vv = 0.0f;
-        if (s < S) {
-            const float* row = base + (long long)s * 3 * hd + head * 64 + d;
-            kv = row[hd];
-            vv = row[2 * hd];
+    // this lane's Q slices: d = 16 s + 8 hi + j
+    f16x8 qh[KS], ql[KS];
+    {
+        const float* qrow = base + (long long)min(query, S - 1) * 3 * hd;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hi), c = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hi + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 h = (_Float16)v[j];
+                qh[s][j] = h;
+                ql[s][j] = (_Float16)(v[j] - (float)h);
+            }
         }
-        kt_s[d * KSTR + s] = kv;
-        v_s[i] = vv;
     }
+    // staging: thread -> key row tid >> 3 of the tile, PER consecutive head-dim elements
+    const int skey = tid >> 3, sd0 = (tid & 7) * PER;
+    const int spos = ((((skey & 3) + 4 * (skey >> 3)) >> 3) << 4) + (((skey >> 2) & 1) << 3) + (((skey & 3) + 4 * (skey >> 3)) & 7);   // permuted position of key skey
+    float kreg[PER], vreg[PER];
+#define MH_AT_LOAD(T)                                                                                 \
+    {                                                                                                 \
+        const int key_ = (T) * 32 + skey;                                                             \
+        const float* row_ = base + (long long)min(key_, S - 1) * 3 * hd + sd0;                        \
+        const float z_ = key_ < S ? 1.0f : 0.0f;           /* rows beyond the sequence stage zeros */ \
+        _Pragma("unroll") for (int i = 0; i < PER; i += 4) {                                          \
+            const f32x4 a_ = *reinterpret_cast<const f32x4*>(row_ + hd + i), c_ = *reinterpret_cast<const f32x4*>(row_ + 2 * hd + i); \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { kreg[i + e] = a_[e] * z_; vreg[i + e] = c_[e] * z_; } \
+        }                                                                                             \
+    }
+#define MH_AT_STORE(BUF)                                                                              \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < PER; i += 4) {                                          \
+            f16x4 h_, l_;                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                           \
+                h_[e] = (_Float16)kreg[i + e];                                                        \
+                l_[e] = (_Float16)(kreg[i + e] - (float)h_[e]);                                       \
+            }                                                                                         \
+            *reinterpret_cast<f16x4*>(&ks[BUF][0][skey * KP + sd0 + i]) = h_;                         \
+            *reinterpret_cast<f16x4*>(&ks[BUF][1][skey * KP + sd0 + i]) = l_;                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                             \
+            const _Float16 h_ = (_Float16)vreg[i];                                                    \
+            vs[BUF][0][(sd0 + i) * VP + spos] = h_;                                                   \
+            vs[BUF][1][(sd0 + i) * VP + spos] = (_Float16)(vreg[i] - (float)h_);                      \
+        }                                                                                             \
+    }
+
+    f32x16 o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[nt][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float c2 = scale * 1.44269504088896341f;          // scores are kept in log2 units: p = exp2(s c2 - m)
+
+    MH_AT_LOAD(0)
+    MH_AT_STORE(0)
     __syncthreads();
-
-    for (int qt = wave; qt < KT; qt += 4) {
-        const int query = qt * 32 + li;
-        float qreg[32];
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) MH_AT_LOAD(t + 1)               // in flight during this tile's matrix work
+        // scores of this tile: S^T = K Q^T
+        f32x16 acc;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) qreg[s] = query < S ? base[(long long)query * 3 * hd + head * 64 + 2 * s + hi] : 0.0f;
-
-        f32x16 acc[KT];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[kt][r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < 32; ++s)
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kt_s[(2 * s + hi) * KSTR + kt * 32 + li], qreg[s], acc[kt], 0, 0, 0);
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ks[buf][0][li * KP + 16 * s + 8 * hi]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&ks[buf][1][li * KP + 16 * s + 8 * hi]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], acc, 0, 0, 0);
         }
-        // softmax over the keys of query (l & 31): this lane and its partner lane ^ 32 hold them all
-        float m = -3.0e38f;
+        float mt = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float v = key < S ? acc[kt][r] * scale : -3.0e38f;
-                acc[kt][r] = v;
-                m = fmaxf(m, v);
-            }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float sum = 0.0f;
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = expf(acc[kt][r] - m);
-                acc[kt][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32);
-        if (hi == 0) lsum[wave * 32 + li] = sum;
-
-        f32x16 o[2];
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[nt][r] = 0.0f;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    o[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[kt][r], v_s[key * 64 + nt * 32 + li], o[nt], 0, 0, 0);
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            acc[r] = key < S ? acc[r] * c2 : -INFINITY;
+            mt = fmaxf(mt, acc[r]);
         }
-        // D layout of o: lane = head-dim column (l & 31), registers = query rows (r&3)+8(r>>2)+4(l>>5)
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float corr = exp2f(m_run - m_new);            // first tile: exp2(-inf) = 0
+        float psum = 0.0f;
+        f16x8 ph[2], pl[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(acc[r] - m_new);
+            psum += p;
+            const _Float16 h = (_Float16)p;
+            ph[r >> 3][r & 7] = h;
+            pl[r >> 3][r & 7] = (_Float16)(p - (float)h);
+        }
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+        // O^T = O^T corr + V^T P^T
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int q = qt * 32 + row;
-                if (q < S) out[((long long)b * S + q) * hd + head * 64 + nt * 32 + li] = o[nt][r] / lsum[wave * 32 + row];
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[nt][r] *= corr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(&vs[buf][0][(32 * nt + li) * VP + 16 * s + 8 * hi]);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(&vs[buf][1][(32 * nt + li) * VP + 16 * s + 8 * hi]);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o[nt], 0, 0, 0);
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o[nt], 0, 0, 0);
             }
+        }
+        if (t + 1 < ntiles) MH_AT_STORE(buf ^ 1)            // the other buffer: its last readers passed the barrier of the previous iteration
+        __syncthreads();
+    }
+#undef MH_AT_STORE
+#undef MH_AT_LOAD
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (query < S) {
+        float* orow = out + ((long long)b * S + query) * hd + head * HD;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)         // registers 4 g .. 4 g + 3 = four consecutive head-dim elements 32 nt + 8 g + 4 hi ..
+                *reinterpret_cast<f32x4*>(orow + 32 * nt + 8 * g + 4 * hi) =
+                    f32x4{o[nt][4 * g] * inv, o[nt][4 * g + 1] * inv, o[nt][4 * g + 2] * inv, o[nt][4 * g + 3] * inv};
     }
 }
 

@@ -25,6 +25,11 @@ namespace mh {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // Activation tensor view, NCDHW fp32: W contiguous, H stride W, D stride H*W, C stride D*H*W, batch
 // stride free (so a view can be a channel range of a wider buffer, e.g. one half of a concat buffer).

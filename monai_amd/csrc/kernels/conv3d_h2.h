@@ -56,10 +56,6 @@
 
 namespace mh {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int H2_B = 16;                                   // region edge (y and x) of a workgroup
 constexpr int H2_R = 18, H2_RS = 20;                       // input region edge, LDS row pitch in voxels

