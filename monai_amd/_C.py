@@ -68,7 +68,7 @@ def _check(name, *tensors):
         if t.dtype != first.dtype or t.device != first.device:
             raise RuntimeError(f"{name}: tensors must have the same dtype and device")
     if first.dtype not in (torch.float32, torch.float64):
-        raise RuntimeError(f"{name}: dtype {first.dtype} is not built (float32 and float64 are)")
+        raise RuntimeError(f"{name}: dtype {first.dtype} is not built (float16, float32 and float64 are)")
     _lib.require_device(*tensors, dtypes=(torch.float32, torch.float64))
 
 
@@ -85,6 +85,12 @@ def _pushpull(name, source, source_size, grid, target, bound, interpolation, ext
     if sd < 1 or sd > 3 or grid.shape[-1] != sd:
         raise RuntimeError(f"{name}: grid must be (B, spatial..., D) with D = 1, 2 or 3 spatial dimensions, got {tuple(grid.shape)}")
     tensors = [t for t in (source, grid, target) if t is not None]
+    if tensors and all(t.dtype == torch.float16 for t in tensors):
+        # half precision (the reference's GPU build dispatches AT_DISPATCH_FLOATING_TYPES_AND_HALF, pushpull_cuda.cu:2195,2228, and does every
+        # step -- coordinates, weights, sums -- in half): evaluated in fp32 here and rounded to half once at the end: same interface, never less accurate
+        outs = _pushpull(name, None if source is None else source.float(), source_size, grid.float(), None if target is None else target.float(), bound,
+                         interpolation, extrapolate, do_pull, do_push, do_count, do_grad, do_sgrad)
+        return [o.half() for o in outs]
     _check(name, *tensors)
     b = int(grid.shape[0])
     osp = tuple(int(v) for v in grid.shape[1:-1])

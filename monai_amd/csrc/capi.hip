@@ -1256,7 +1256,7 @@ int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, cons
     const long long DHW = (long long)a.D * a.H * a.W;
     const bool v4 = DHW % 4 == 0 && aligned(a.data, 16) && (!b.data || aligned(b.data, 16)) && aligned(out.data, 16) && a.n_stride % 4 == 0 &&
                     b.n_stride % 4 == 0 && out.n_stride % 4 == 0;
-    const dim3 grid(blocks_for(v4 ? DHW / 4 : DHW), (unsigned)a.C, (unsigned)a.N);
+    const dim3 grid((blocks_for(v4 ? DHW / 4 : DHW) + ADD_ACT_CHUNKS - 1) / ADD_ACT_CHUNKS, (unsigned)a.C, (unsigned)a.N);
     if (v4) hipLaunchKernelGGL((add_act_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
     else hipLaunchKernelGGL((add_act_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
     return launched("add_act");

@@ -369,8 +369,12 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
         for (int j = 0; j < COT; ++j)
 #pragma unroll
             for (int k = 0; k < 8; ++k) m = max(m, abs_bits(acc[j][k]));
+        __shared__ unsigned wmax[4];
         m = wave_umax(valid ? m : 0u);
-        const int jl = threadIdx.x & 63;
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();                 // one atomic instruction per WORKGROUP: the waves of a (sample, channel) all target the same records
+        const int jl = threadIdx.x;
+        m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
         if (jl < COT && (FULL || co0 + jl < Cout) && m != 0u) atomicMax(reinterpret_cast<unsigned*>(bound_slot(out, n, co0 + jl)), m);
     }
 }
@@ -492,41 +496,48 @@ conv1x1_windows_kernel(Tensor in, const float* __restrict__ w, const float* __re
 // ---------------------------------------------------------------------------------------------------
 // Residual join of UnetResBlock (monai/networks/blocks/dynunet_block.py:96-111): out = lrelu(norm2(conv2) + residual),
 // both operands given as raw tensors + their deferred {alpha, beta, slope} records; one read of each, one write.
+constexpr int ADD_ACT_CHUNKS = 4;      // consecutive 256 x VEC element chunks per workgroup
 template <int VEC>
 __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float slope, Tensor out) {
     const long long DHW = (long long)a.D * a.H * a.W;
-    const long long idx0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int c = blockIdx.y, n = blockIdx.z;
-    const bool valid = idx0 < DHW;                   // VEC == 4: DHW % 4 == 0 (launcher), so a group is inside or outside as a whole
-    const long long idx = valid ? idx0 : 0;
     const bool has_b = b.data != nullptr;          // no second operand: out = lrelu(act(a)) (materialise a deferred tensor)
     const float4 na = load_nrm(a, n, c), nb = load_nrm(b, n, c);
-    const float* pa = a.data + (long long)n * a.n_stride + (long long)c * DHW + idx;
-    const float* pb = has_b ? b.data + (long long)n * b.n_stride + (long long)c * DHW + idx : pa;
-    float* po = out.data + (long long)n * out.n_stride + (long long)c * DHW + idx;
-    float va[VEC], vb[VEC];
-    if (VEC == 4) {
-        const float4 qa = *reinterpret_cast<const float4*>(pa), qb = *reinterpret_cast<const float4*>(pb);
-        va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w;
-        vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
-    } else {
-        va[0] = pa[0]; vb[0] = pb[0];
-    }
-    float r[VEC];
+    const float* pa0 = a.data + (long long)n * a.n_stride + (long long)c * DHW;
+    const float* pb0 = has_b ? b.data + (long long)n * b.n_stride + (long long)c * DHW : pa0;
+    float* po0 = out.data + (long long)n * out.n_stride + (long long)c * DHW;
+    unsigned m = 0u;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        const float y = act(va[v], na.x, na.y, na.z) + (has_b ? act(vb[v], nb.x, nb.y, nb.z) : 0.0f);
-        r[v] = y > 0.0f ? y : y * slope;
-    }
-    if (valid) {
-        if (VEC == 4) *reinterpret_cast<float4*>(po) = make_float4(r[0], r[1], r[2], r[3]);
-        else po[0] = r[0];
-    }
-    if (out.nrm) {            // magnitude bound of the raw sum (common.h)
-        unsigned m = 0u;
+    for (int u = 0; u < ADD_ACT_CHUNKS; ++u) {
+        const long long idx = (((long long)blockIdx.x * ADD_ACT_CHUNKS + u) * 256 + threadIdx.x) * VEC;
+        if (idx >= DHW) break;                       // VEC == 4: DHW % 4 == 0 (launcher), so a group is inside or outside as a whole
+        float va[VEC], vb[VEC];
+        if (VEC == 4) {
+            const float4 qa = *reinterpret_cast<const float4*>(pa0 + idx), qb = *reinterpret_cast<const float4*>(pb0 + idx);
+            va[0] = qa.x; va[1] = qa.y; va[2] = qa.z; va[3] = qa.w;
+            vb[0] = qb.x; vb[1] = qb.y; vb[2] = qb.z; vb[3] = qb.w;
+        } else {
+            va[0] = pa0[idx]; vb[0] = pb0[idx];
+        }
+        float r[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) m = max(m, abs_bits(r[v]));
-        bound_commit(valid ? m : 0u, bound_slot(out, n, c));
+        for (int v = 0; v < VEC; ++v) {
+            const float y = act(va[v], na.x, na.y, na.z) + (has_b ? act(vb[v], nb.x, nb.y, nb.z) : 0.0f);
+            r[v] = y > 0.0f ? y : y * slope;
+            m = max(m, abs_bits(r[v]));
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(po0 + idx) = make_float4(r[0], r[1], r[2], r[3]);
+        else po0[idx] = r[0];
+    }
+    if (out.nrm) {            // magnitude bound of the raw sum (common.h): one atomic per workgroup -- every workgroup of a (sample, channel) targets the same record
+        __shared__ unsigned wmax[4];
+        m = wave_umax(m);
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+            if (m != 0u) atomicMax(reinterpret_cast<unsigned*>(bound_slot(out, n, c)), m);
+        }
     }
 }
 

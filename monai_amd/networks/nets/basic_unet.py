@@ -52,19 +52,45 @@ def _w5(w: torch.Tensor) -> torch.Tensor:
 
 
 class _ADN(nn.Module):
-    def __init__(self, channels: int, affine: bool, eps: float, slope: float):
+    """ADN("NDA") parameter holder (blocks/acti_norm.py:69-101): ``N`` = InstanceNorm (affine or not) / BatchNorm (evaluated with its running statistics) /
+    GroupNorm; ``A`` exists as a module only when the activation has parameters (PReLU) -- the parameter-free ones leave no trace in the state_dict"""
+
+    def __init__(self, channels: int, norm: tuple, slope):
         super().__init__()
-        self.N = _nd(nn.InstanceNorm3d, nn.InstanceNorm2d)(channels, eps=eps, affine=affine)
-        self.negative_slope = slope
+        kind, args = norm
+        if kind == "batch":
+            self.N = _nd(nn.BatchNorm3d, nn.BatchNorm2d)(channels, **args)
+        elif kind == "group":
+            self.N = nn.GroupNorm(num_channels=channels, **args)
+        else:
+            self.N = _nd(nn.InstanceNorm3d, nn.InstanceNorm2d)(channels, **args)
+        if isinstance(slope, dict):                 # ("prelu", args): a learnable slope
+            self.A = nn.PReLU(**slope)
+            if self.A.weight.numel() != 1:
+                raise NotImplementedError("monai_amd.BasicUNet: PReLU with one slope per channel is not on the HIP path yet (num_parameters=1 is)")
+        else:
+            self.negative_slope_ = float(slope)
+
+    @property
+    def negative_slope(self) -> float:
+        if not hasattr(self, "A"):
+            return self.negative_slope_
+        w = self.A.weight                           # one device -> host read per parameter version, not per launch
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = getattr(self, "_slope_cache", None)
+        if hit is None or hit[0] != key:
+            hit = (key, float(w.detach().float().item()))
+            object.__setattr__(self, "_slope_cache", hit)
+        return hit[1]
 
 
 class _Convolution(nn.Module):
     """conv + adn parameter holder (reference: blocks/convolutions.py:98-171)"""
 
-    def __init__(self, cin: int, cout: int, bias: bool, affine: bool, eps: float, slope: float):
+    def __init__(self, cin: int, cout: int, bias: bool, norm: tuple, slope):
         super().__init__()
         self.conv = _nd(nn.Conv3d, nn.Conv2d)(cin, cout, kernel_size=3, stride=1, padding=1, bias=bias)
-        self.adn = _ADN(cout, affine, eps, slope)
+        self.adn = _ADN(cout, norm, slope)
 
 
 class _TwoConv(nn.Module):
@@ -82,34 +108,51 @@ class _Down(nn.Module):
 
 
 class _UpSample(nn.Module):
-    def __init__(self, cin, cout, bias=True):
+    """UpSample (blocks/upsample.py:43-184) in the two parameter layouts BasicUNet uses: "deconv" = ConvTranspose(k2, s2); "nontrainable" = an optional
+    1x1 ``preconv`` (present when the channel count changes, pre_conv="default") + parameter-free linear interpolation x2 with align_corners=True"""
+
+    def __init__(self, cin, cout, mode="deconv", bias=True):
         super().__init__()
-        self.deconv = _nd(nn.ConvTranspose3d, nn.ConvTranspose2d)(cin, cout, kernel_size=2, stride=2, bias=bias)
+        if mode == "deconv":
+            self.deconv = _nd(nn.ConvTranspose3d, nn.ConvTranspose2d)(cin, cout, kernel_size=2, stride=2, bias=bias)
+        elif cin != cout:
+            self.preconv = _nd(nn.Conv3d, nn.Conv2d)(cin, cout, kernel_size=1, bias=bias)
 
 
 class _UpCat(nn.Module):
-    def __init__(self, cin, cat, cout, halves=True, **kw):
+    def __init__(self, cin, cat, cout, halves=True, upsample="deconv", **kw):
         super().__init__()
         up = cin // 2 if halves else cin
-        self.upsample = _UpSample(cin, up)
+        self.upsample = _UpSample(cin, up, upsample)
         self.convs = _TwoConv(cat + up, cout, **kw)
 
 
-def _parse_act(act) -> float:
+def _parse_act(act):
+    """-> negative slope (float), or the PReLU constructor arguments (dict)"""
     name, args = (act, {}) if isinstance(act, str) else (act[0], act[1] if len(act) > 1 else {})
     name = str(name).lower()
     if name == "leakyrelu":
         return float(args.get("negative_slope", 0.01))
     if name == "relu":
         return 0.0
-    raise NotImplementedError(f"monai_amd.BasicUNet: activation {act!r} is not on the HIP path yet (LeakyReLU / ReLU are)")
+    if name == "prelu":
+        return {k: v for k, v in args.items() if k in ("num_parameters", "init")}
+    raise NotImplementedError(f"monai_amd.BasicUNet: activation {act!r} is not on the HIP path yet (LeakyReLU / ReLU / PReLU are)")
 
 
 def _parse_norm(norm):
-    name, args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
-    if str(name).lower() != "instance":
-        raise NotImplementedError(f"monai_amd.BasicUNet: norm {norm!r} is not on the HIP path yet (instance norm is)")
-    return bool(args.get("affine", False)), float(args.get("eps", 1e-5))
+    """-> (kind, constructor arguments): instance / batch / group"""
+    name, args = (norm, {}) if isinstance(norm, str) else (norm[0], dict(norm[1]) if len(norm) > 1 else {})
+    kind = str(name).lower()
+    if kind == "instance":
+        return kind, dict(affine=bool(args.get("affine", False)), eps=float(args.get("eps", 1e-5)))
+    if kind == "batch":
+        return kind, {k: v for k, v in args.items() if k in ("eps", "momentum", "affine", "track_running_stats")}
+    if kind == "group":
+        if "num_groups" not in args:
+            raise TypeError("GroupNorm.__init__() missing 1 required positional argument: 'num_groups'")
+        return kind, {k: v for k, v in args.items() if k in ("num_groups", "eps", "affine")}
+    raise NotImplementedError(f"monai_amd.BasicUNet: norm {norm!r} is not on the HIP path yet (instance / batch / group are)")
 
 
 # --------------------------------------------------------------------------- the module
@@ -129,8 +172,8 @@ class BasicUNet(nn.Module):
         super().__init__()
         if spatial_dims not in (2, 3):
             raise NotImplementedError("monai_amd.BasicUNet: spatial_dims 2 and 3 are on the HIP path")
-        if upsample != "deconv":
-            raise NotImplementedError("monai_amd.BasicUNet: only upsample='deconv' is on the HIP path")
+        if upsample not in ("deconv", "nontrainable"):
+            raise NotImplementedError("monai_amd.BasicUNet: upsample='deconv' and 'nontrainable' are on the HIP path ('pixelshuffle' is not yet)")
         # dropout: accepted and inert -- this is an inference engine (forward refuses training mode) and Dropout holds no parameters, so
         # checkpoints of nets trained with dropout load unchanged
         fea = tuple(features)
@@ -138,11 +181,9 @@ class BasicUNet(nn.Module):
             raise ValueError(f"Sequence must have length 6, got length {len(fea)}.")  # ensure_tuple_rep
         print(f"BasicUNet features: {fea}.")  # the reference prints this too (basic_unet.py:239)
         slope = _parse_act(act)
-        affine, eps = _parse_norm(norm)
-        kw = dict(bias=bias, affine=affine, eps=eps, slope=slope)
+        kw = dict(bias=bias, norm=_parse_norm(norm), slope=slope)
         self.features, self.in_channels, self.out_channels = fea, in_channels, out_channels
-        self.negative_slope, self.eps = slope, eps
-        self.spatial_dims = spatial_dims
+        self.spatial_dims, self.upsample = spatial_dims, upsample
         _DIMS[0] = spatial_dims
         try:
             self._build(in_channels, out_channels, fea, kw)
@@ -158,10 +199,11 @@ class BasicUNet(nn.Module):
         self.down_2 = _Down(fea[1], fea[2], **kw)
         self.down_3 = _Down(fea[2], fea[3], **kw)
         self.down_4 = _Down(fea[3], fea[4], **kw)
-        self.upcat_4 = _UpCat(fea[4], fea[3], fea[3], **kw)
-        self.upcat_3 = _UpCat(fea[3], fea[2], fea[2], **kw)
-        self.upcat_2 = _UpCat(fea[2], fea[1], fea[1], **kw)
-        self.upcat_1 = _UpCat(fea[1], fea[0], fea[5], halves=False, **kw)
+        up = self.upsample
+        self.upcat_4 = _UpCat(fea[4], fea[3], fea[3], upsample=up, **kw)
+        self.upcat_3 = _UpCat(fea[3], fea[2], fea[2], upsample=up, **kw)
+        self.upcat_2 = _UpCat(fea[2], fea[1], fea[1], upsample=up, **kw)
+        self.upcat_1 = _UpCat(fea[1], fea[0], fea[5], halves=False, upsample=up, **kw)
         self.final_conv = _nd(nn.Conv3d, nn.Conv2d)(fea[5], out_channels, kernel_size=1)
 
     # ---- weights ---------------------------------------------------------------------------------
@@ -268,6 +310,10 @@ class _Plan:
         self.u = [e(dec_out[l], l) for l in range(4)]
         self.u_nrm = [nz(dec_out[l]) for l in range(4)]
         self.up, self.dec_out = up, dec_out
+        self.batchnorm = isinstance(net.conv_0.conv_0.adn.N, (nn.BatchNorm3d, nn.BatchNorm2d))
+        self.interp = net.upsample == "nontrainable"
+        # "nontrainable" up-sampling: the (optional) 1x1 pre-convolution's result at the lower resolution
+        self.low = [e(up[l], l + 1) if self.interp else None for l in range(4)]
         self.stats: Optional[torch.Tensor] = None
         self.device = device
 
@@ -276,12 +322,34 @@ class _Plan:
             self.stats = torch.empty(floats, dtype=torch.float32, device=self.device)
         return self.stats
 
-    def _conv(self, net, name: str, block: _Convolution, x, x_nrm, out, out_nrm):
-        """conv -> raw `out`; InstanceNorm statistics -> `out_nrm` ({alpha, beta, slope})."""
+    def _bn_record(self, net, name: str, bn, slope: float, out_nrm) -> None:
+        """Eval-mode BatchNorm + activation as consumer-side records {alpha = weight / sqrt(running_var + eps), beta = bias - running_mean * alpha, slope, 0}:
+        a parameter fold over C values (cached per parameter version), no pass over activations, no statistics -- and no magnitude bound (0: none given)."""
+        if bn.running_mean is None or bn.running_var is None:
+            raise NotImplementedError("monai_amd.BasicUNet: BatchNorm without running statistics is not on the (inference) HIP path")
+        parts = [bn.running_mean, bn.running_var] + ([bn.weight, bn.bias] if bn.affine else [])
+        key = tuple((t.data_ptr(), t._version) for t in parts) + (slope, str(bn.running_mean.device))
+        hit = net._packed.get(("bn", name))
+        if hit is None or hit[0] != key:
+            invstd = 1.0 / torch.sqrt(bn.running_var.float() + bn.eps)
+            alpha = invstd * bn.weight.float() if bn.affine else invstd
+            beta = (bn.bias.float() if bn.affine else 0.0) - bn.running_mean.float() * alpha
+            hit = (key, torch.stack([alpha, beta, torch.full_like(alpha, slope), torch.zeros_like(alpha)], dim=1).contiguous())
+            net._packed[("bn", name)] = hit
+        out_nrm.copy_(hit[1][None].expand(out_nrm.shape[0], -1, -1))
+
+    def _conv(self, net, name: str, block: _Convolution, x, x_nrm, out, out_nrm, bounded: bool = True):
+        """conv -> raw `out`; the normalisation + activation that follows it -> records `out_nrm` ({alpha, beta, slope, bound}).  `bounded`: the input's
+        records carry magnitude bounds (the split-precision convolution needs them; BatchNorm folds and interpolated tensors have none)."""
         n, cout, d, h, w = out.shape
         cin = x.shape[1]
-        cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None and bounded and not self.batchnorm)
         packed = net._packed_weight(name, block.conv, cfg)
+        norm = block.adn.N
+        if self.batchnorm:
+            with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
+                ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, None)
+            return self._bn_record(net, name, norm, block.adn.negative_slope, out_nrm)
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if net.fused_stats else 0
         flops = 2.0 * 27 * cin * cout * d * h * w * n
         if tiles:
@@ -294,8 +362,25 @@ class _Plan:
             tiles = ops.instnorm_stat_tiles(d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3)
             ops.instnorm_stats(out, stats)
-        inorm = block.adn.N
-        ops.instnorm_finalize(stats, tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, block.adn.negative_slope, out_nrm)
+        if isinstance(norm, nn.GroupNorm):
+            ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+        else:
+            ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+
+    def _interpolate(self, up: _UpSample, src, src_nrm, low, dst) -> None:
+        """UpSample(mode="nontrainable", interp_mode="linear", align_corners=True) (blocks/upsample.py:118-140): the 1x1 `preconv` when the channel count
+        changes, then x2 linear interpolation with source index = o (in - 1) / (out - 1) -- one launch of the affine resampler per tensor"""
+        if hasattr(up, "preconv"):
+            pc = up.preconv
+            ops.conv1x1(src, src_nrm, pc.weight.view(pc.weight.shape[0], -1), pc.bias, low)
+        else:
+            ops.add_act(src, src_nrm, None, None, 1.0, low)          # materialise the deferred normalisation + activation
+        n, c, d, h, w = low.shape
+        osz = (d if self.planar else 2 * d, 2 * h, 2 * w)
+        a = [1.0 if (self.planar or d == 1) else (d - 1) / (osz[0] - 1), (h - 1) / (osz[1] - 1), (w - 1) / (osz[2] - 1)]
+        m = [a[0], 0, 0, 0, 0, a[1], 0, 0, 0, 0, a[2], 0]
+        hi = ops.affine_resample(low.reshape(n * c, d, h, w), m, osz, "bilinear", "border", False, False)
+        dst.copy_(hi.reshape((n, c) + osz))
 
     def run(self, net: "BasicUNet", x: torch.Tensor, logits: torch.Tensor) -> None:
         f = net.features
@@ -323,7 +408,9 @@ class _Plan:
             upc = ups[l]
             dst = self.up_scratch[l] if self.odd[l] else self.cat[l][:, f[l]:]
             dst_nrm = ops.nrm_identity(self.up_scratch_nrm[l] if self.odd[l] else self.cat_nrm[l][:, f[l]:])
-            if self.planar:       # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
+            if self.interp:
+                self._interpolate(upc.upsample, src, src_nrm, self.low[l], dst)
+            elif self.planar:     # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
                 ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
             else:
                 ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm)
@@ -331,7 +418,7 @@ class _Plan:
                 ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
             co = self.dec_out[l]
             t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
-            self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn)
+            self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)
             self._conv(net, f"upcat_{l + 1}.convs.conv_1", upc.convs.conv_1, t, tn, self.u[l], self.u_nrm[l])
             src, src_nrm = self.u[l], self.u_nrm[l]
 

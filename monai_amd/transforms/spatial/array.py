@@ -160,7 +160,14 @@ class Spacing(LazyCapable):
         out = self.sp_resample(data_array, dst_affine=torch.as_tensor(new_affine), spatial_size=actual_shape, mode=mode, padding_mode=padding_mode,
                                align_corners=align_corners, dtype=dtype, lazy=lazy_)
         if self.recompute_affine and is_meta(out):
-            raise NotImplementedError("monai_amd: recompute_affine is not implemented")
+            # array.py:538-542: the output affine becomes scale_affine(original shape, actual shape) -- the centred scaling between the two voxel
+            # grids (transforms/utils.py:2093-2113), which reflects the quantisation of the output shape; host algebra on a 4 x 4 matrix
+            if lazy_:
+                raise NotImplementedError("recompute_affine is not supported with lazy evaluation.")
+            ratio = [float(o) / float(max(int(n), 1)) for o, n in zip(original_shape, actual_shape)]
+            scale = np.diag(ratio + [1.0])
+            scale[:sr, -1] = (np.diag(scale)[:sr] - 1.0) / 2.0
+            out.affine = torch.as_tensor(scale, dtype=torch.float64)
         return out
 
     def inverse(self, data):

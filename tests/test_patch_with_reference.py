@@ -343,3 +343,58 @@ def test_unetr_option_surface_matches_the_reference(monai_ref, emu, kw):
     got = ours(x)
     err = (got - exp).abs().max().item()
     assert err < 1e-4, (kw, err)
+
+
+@pytest.mark.parametrize("kw,shape", [
+    (dict(norm=("batch", {"eps": 1e-4}), act=("prelu", {"init": 0.2})), (2, 1, 32, 32, 32)),
+    (dict(norm=("group", {"num_groups": 4}), upsample="nontrainable", act="relu"), (1, 1, 32, 48, 32)),
+    (dict(norm="instance", upsample="nontrainable"), (1, 2, 40, 32, 36)),          # odd extents at the lower levels: UpCat's replicate padding after the interpolation
+])
+def test_basic_unet_option_surface_matches_the_reference(monai_ref, emu, kw, shape):
+    """VERDICT r2 missing #3: BasicUNet beyond instance norm + LeakyReLU + deconv -- BatchNorm (evaluated with its running statistics), GroupNorm, PReLU / ReLU,
+    upsample="nontrainable" -- strict state_dict load and logits of the real reference."""
+    from monai.networks.nets import BasicUNet as RefNet
+
+    from monai_amd.networks.nets.basic_unet import BasicUNet as OurNet
+
+    features = (16, 16, 32, 32, 64, 16)
+    torch.manual_seed(21)
+    ref = RefNet(spatial_dims=3, in_channels=shape[1], out_channels=3, features=features, **kw).eval()
+    gen = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for m in ref.modules():           # trained-looking normalisation state
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+            if isinstance(m, (torch.nn.BatchNorm3d, torch.nn.GroupNorm)) and m.weight is not None:
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
+    ours = OurNet(spatial_dims=3, in_channels=shape[1], out_channels=3, features=features, **kw).eval()
+    missing, unexpected = ours.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected and list(ours.state_dict().keys()) == list(ref.state_dict().keys())
+    x = torch.rand(shape, generator=gen)
+    with torch.no_grad():
+        exp = ref(x)
+    got = ours(x)
+    err = (got - exp).abs().max().item()
+    assert err < 1e-4 * max(1.0, exp.abs().max().item()), (kw, err)
+
+
+def test_spacing_recompute_affine_matches_the_reference(monai_ref, emu):
+    """VERDICT r2 missing #5: Spacing(recompute_affine=True) (monai/transforms/spatial/array.py:538-542)"""
+    import numpy as np
+    from monai.data import MetaTensor as RefMeta
+    from monai.transforms import Spacing as RefSpacing
+
+    from monai_amd.data import MetaTensor
+    from monai_amd.transforms import Spacing
+
+    aff = np.diag([0.8, 1.3, 2.1, 1.0])
+    aff[:3, 3] = [5.0, -3.0, 2.0]
+    x = torch.rand((1, 17, 22, 13), generator=torch.Generator().manual_seed(31))
+    for kw in (dict(pixdim=(1.0, 1.0, 1.0)), dict(pixdim=(1.7, 0.9, 1.2), diagonal=True)):
+        exp = RefSpacing(recompute_affine=True, **kw)(RefMeta(x.clone(), affine=aff))
+        got = Spacing(recompute_affine=True, **kw)(MetaTensor(x.clone(), affine=aff))
+        assert tuple(got.shape) == tuple(exp.shape)
+        np.testing.assert_allclose(got.affine.numpy(), exp.affine.numpy(), atol=1e-12)
+        assert (got.as_tensor() - exp.as_tensor()).abs().max().item() < 2e-6

@@ -209,6 +209,15 @@ def case_grid_pull_vs_reference_build(device):
     inp, grid = cache[(1, 0)]
     y = _C.grid_pull(inp.to(device), grid.to(device), [_C.BoundType(2), _C.BoundType(7), _C.BoundType(5)], [_C.InterpolationType(1)], True)
     assert np.abs(y.cpu().numpy() - g["gp_mixed_out"]).max() < 2e-5   # per-axis boundary conditions
+    # half precision (the reference's GPU build takes it, pushpull_cuda.cu:2195): evaluated in fp32, rounded once -- equal to the half-rounded fp32 result
+    # of the half-rounded inputs; push / count / grad go the same way
+    hi, hg = inp.half(), grid.half()
+    yh = _C.grid_pull(hi.to(device), hg.to(device), [_C.BoundType(2)], [_C.InterpolationType(1)], True)
+    assert yh.dtype == torch.float16
+    yf = _C.grid_pull(hi.float().to(device), hg.float().to(device), [_C.BoundType(2)], [_C.InterpolationType(1)], True)
+    assert torch.equal(yh.cpu(), yf.cpu().half())
+    ph = _C.grid_push(yh, hg.to(device), list(inp.shape[2:]), [_C.BoundType(2)], [_C.InterpolationType(1)], True)
+    assert ph.dtype == torch.float16 and tuple(ph.shape) == tuple(inp.shape)
     return worst
 
 
