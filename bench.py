@@ -77,7 +77,7 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
     from oracle.sliding_window import dense_patch_starts, get_scan_interval
 
     torch.manual_seed(1)
-    sd = oracle.make_basic_unet_state(1, 5)
+    sd = oracle.make_basic_unet_state(1, 5, **({"features": tuple(net.features)} if tuple(net.features) != (32, 32, 64, 128, 256, 32) else {}))
     ext = sub_volume_extents(size, roi, windows)
     sub = vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
     sub_cpu = sub.cpu()
@@ -140,7 +140,7 @@ def pmc_traffic(kernel_key: str):
     return None
 
 
-def build_net(name: str, roi: int, dev):
+def build_net(name: str, roi: int, dev, features=None):
     from monai_amd.networks.nets import UNETR, BasicUNet, DynUNet, SegResNet, SwinUNETR, UNet
 
     torch.manual_seed(1)       # weights exactly as SURVEY.md 8(d) config 1 / 3
@@ -155,7 +155,7 @@ def build_net(name: str, roi: int, dev):
     elif name == "segresnet":
         net = SegResNet(spatial_dims=3, init_filters=16, in_channels=1, out_channels=5)
     else:
-        net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5)
+        net = BasicUNet(spatial_dims=3, in_channels=1, out_channels=5, **({"features": features} if features else {}))
     return net.eval().to(dev)
 
 
@@ -378,6 +378,8 @@ def main(argv=None):
     ap.add_argument("--roi", type=int, default=96)
     ap.add_argument("--cpu-windows", type=int, default=125, help="windows of the corner sub-volume the CPU baseline / parity check runs (125 = 288^3; 0 = skip)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.fp32_exact / config3 / config4 (development runs)")
+    ap.add_argument("--harness-features", default="", help="TEST HARNESS ONLY (emulator runs of tests/test_bench_harness.py): BasicUNet widths, e.g. 16,16,32,32,64,16; "
+                                                           "refused on a GPU -- the benchmark network has the default widths")
     ap.add_argument("--net", default="basicunet", choices=sorted(NETS),
                     help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
                          "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16); swinunetr = SwinUNETR(feature_size=48) (SURVEY 8f-4)")
@@ -418,7 +420,10 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=dev)
         parallel.enable_window_sharding()
 
-    net = build_net(args.net, args.roi, dev)
+    feats = tuple(int(v) for v in args.harness_features.split(",")) if args.harness_features else None
+    if feats and not emulated:
+        raise SystemExit("--harness-features is for the emulator harness test only")
+    net = build_net(args.net, args.roi, dev, feats)
     vol = benchmark_volume(args.size).to(dev)
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
 

@@ -363,7 +363,7 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
     if (out.nrm) {
         // magnitude bound of the raw result (common.h): ONE wave reduction over everything the wave wrote, folded into the records of all the channels of
         // the group by one atomic instruction (lane j -> channel co0 + j).  The group's maximum bounds each of its channels (a little looser than per channel;
-        // per-channel reductions cost 8 x the shuffles and atomics and were measured at +55 % on this store-bound kernel, profiles/r03_bench_kernel_trace_stats_v1.txt)
+        // per-channel reductions cost 8 x the shuffles and atomics and were measured at +55 % on this store-bound kernel, profiles/r03_bound_epilogue_first_form_trace.txt)
         unsigned m = 0u;
 #pragma unroll
         for (int j = 0; j < COT; ++j)

@@ -16,6 +16,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "fallthrough: the test exercises the fall-through to an importable reference MONAI (monai_amd/_fallback.py)")
+    config.addinivalue_line("markers", "heavy_emu: minutes of SIMT emulation whose -m gpu twin runs the same case on the MI355X every round; "
+                                       "skipped on the CPU unless MONAI_AMD_HEAVY_EMU=1 (keeps `pytest -m 'not gpu'` to a few minutes)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("MONAI_AMD_HEAVY_EMU") == "1":
+        return
+    skip = pytest.mark.skip(reason="heavy emulator case (its -m gpu twin runs on the MI355X); MONAI_AMD_HEAVY_EMU=1 runs it here")
+    for item in items:
+        if "heavy_emu" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(autouse=True)

@@ -557,14 +557,14 @@ def case_net_nonfinite_inputs(device, window=(32, 32, 32), features=(32, 32, 64,
 MOSAIC_CASES = (((1, 1, 40, 56, 36), 0.5, "gaussian"), ((1, 1, 44, 32, 52), 0.25, "constant"), ((2, 1, 32, 32, 32), 0.5, "gaussian"))
 
 
-def case_mosaic_layout_equals_window_major(device, cases=MOSAIC_CASES):
+def case_mosaic_layout_equals_window_major(device, cases=MOSAIC_CASES, features=(16, 16, 32, 32, 64, 16)):
     """The fused single-GPU path keeps its logits in the mosaic layout (ops.LogitsMosaic) and the network's last kernel writes it directly; the window-major
     buffer (MONAI_AMD_LOGITS_LAYOUT=windows; what window sharding and the fused argmax use) gives the SAME BITS -- overlap 0.5 with clipped last windows,
     overlap 0.25, a volume of one window, constant and gaussian weights."""
     from monai_amd.inferers import SlidingWindowInferer
     from monai_amd.inferers import utils as U
 
-    net, _ = make_net(1, 1, 5, device, features=(16, 16, 32, 32, 64, 16))
+    net, _ = make_net(1, 1, 5, device, features=features)
     used = []
     real = U._alloc_mosaic
 

@@ -1,5 +1,7 @@
 """End-to-end product path (SlidingWindowInferer -> BasicUNet engine -> blend) on the CPU through the SIMT
 emulator build of the kernels, checked against the golden outputs of the real reference."""
+import pytest
+
 import e2e_cases as ec
 
 
@@ -35,6 +37,7 @@ def test_unet_vs_reference(emu):
     print(ec.case_unet_vs_golden("cpu"))
 
 
+@pytest.mark.heavy_emu
 def test_basic_unet_with_inplane_winograd(emu, monkeypatch):
     """The whole BasicUNet window path with every eligible 3x3x3 conv on the in-plane Winograd configuration."""
     monkeypatch.setenv("MONAI_AMD_CONV_ALGO", "wino2d")
@@ -53,12 +56,14 @@ def test_slabwise_equals_whole(emu):
     print(ec.case_slabwise_equals_whole("cpu"))
 
 
+@pytest.mark.heavy_emu
 def test_swin_unetr_vs_reference(emu):
     import swin_cases as sc
 
     print(sc.case_swin_unetr_vs_golden("cpu", names=("a",)))
 
 
+@pytest.mark.heavy_emu
 def test_fused_argmax_epilogue(emu):
     assert ec.case_fused_argmax_epilogue("cpu")
 
@@ -76,6 +81,7 @@ def test_dynunet_vs_reference(emu):
     dc.case_dynunet_api("cpu")
 
 
+@pytest.mark.heavy_emu
 def test_dynunet_2d_and_slice_inferer_vs_reference(emu):
     """a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
     import dynunet_cases as dc
@@ -83,6 +89,7 @@ def test_dynunet_2d_and_slice_inferer_vs_reference(emu):
     print("max |dlogit|", dc.case_dynunet_2d_vs_reference("cpu"))
 
 
+@pytest.mark.heavy_emu
 def test_dynunet_sliding_window_vs_reference(emu):
     import dynunet_cases as dc
 
@@ -97,12 +104,14 @@ def test_segresnet_vs_reference(emu):
     sc.case_segresnet_api("cpu")
 
 
+@pytest.mark.heavy_emu
 def test_ct_bundle_pipeline_vs_reference(emu):
     import pipeline_ct_case as pc
 
     print(pc.case_ct_pipeline_vs_reference("cpu"))
 
 
+@pytest.mark.heavy_emu
 def test_mri_bundle_pipeline_vs_reference(emu):
     import normalize_cases as nc
 
@@ -115,6 +124,7 @@ def test_dynunet_segresnet_window_vs_oracle(emu):
     print("max |dlogit|", dc.case_nets_window_vs_oracle("cpu", 48, (16, 32, 64)))     # the -m gpu run does this at 96^3 with nnU-Net filters
 
 
+@pytest.mark.heavy_emu
 def test_unetr_under_autocast_stays_fp32(emu):
     """an evaluator with amp=True calls the network inside torch.autocast: the engine keeps computing in fp32 and returns the same logits"""
     import torch
@@ -162,9 +172,10 @@ def test_nets_with_trained_like_affine_spreads(emu):
     print(ec.case_nets_with_spread_affine("cpu", window=(16, 16, 16), nets=("dynunet_res", "segresnet")))      # BasicUNet (32^3 at least): the -m gpu twin
 
 
+@pytest.mark.heavy_emu
 def test_net_nonfinite_inputs_like_the_reference(emu):
     ec.case_net_nonfinite_inputs("cpu", features=(32, 32, 32, 32, 32, 32))
 
 
 def test_mosaic_layout_equals_window_major(emu):
-    ec.case_mosaic_layout_equals_window_major("cpu", cases=(((1, 1, 40, 56, 36), 0.5, "gaussian"), ((1, 1, 44, 32, 36), 0.25, "constant")))
+    ec.case_mosaic_layout_equals_window_major("cpu", cases=(((1, 1, 40, 56, 32), 0.5, "gaussian"),), features=(8, 8, 8, 16, 16, 8))      # 2 x 3 x 1 windows, clipped last ones

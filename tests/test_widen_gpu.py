@@ -132,3 +132,29 @@ def test_swin_unetr_vs_reference():
     import swin_cases as sc
 
     print(sc.case_swin_unetr_vs_golden("cuda"))
+
+
+def test_basic_unet_on_the_exact_fp32_families_and_under_autocast():
+    """GPU twins of emulator cases that `pytest -m 'not gpu'` only runs with MONAI_AMD_HEAVY_EMU=1: the golden BasicUNet windows with every eligible
+    convolution on the in-plane Winograd family and on the direct fp32 tiles (config.CONV_ALGO), and a UNETR called inside torch.autocast (an evaluator
+    with amp=True): the engine keeps computing in fp32 and returns the same logits."""
+    import torch
+
+    import e2e_cases as ec
+    from monai_amd import config
+    from monai_amd.networks.nets import UNETR
+
+    saved = config.CONV_ALGO
+    try:
+        for algo in ("wino2d", "direct", "fp32"):
+            config.CONV_ALGO = algo
+            print(algo, ec.case_net_single_window_vs_golden(DEV))
+    finally:
+        config.CONV_ALGO = saved
+    torch.manual_seed(5)
+    net = UNETR(in_channels=1, out_channels=2, img_size=(32, 32, 32), feature_size=8, hidden_size=128, mlp_dim=256, num_heads=2).eval().to(DEV)
+    x = torch.rand(1, 1, 32, 32, 32).to(DEV)
+    y = net(x)
+    with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+        ya = net(x)
+    assert ya.dtype == torch.float32 and torch.equal(y, ya)
