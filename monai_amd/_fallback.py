@@ -300,10 +300,11 @@ def reference_fallback(ref_module: str, name: str, methods=("__call__",), share_
                     return None
                 args, kwargs = self.__dict__.get("_mh_ctor", ((), {}))
                 twin = ref(*args, **kwargs)
-                if share_state:
-                    _share_module_state(self, twin)
                 object.__setattr__(self, "_mh_twin_obj", twin)
             if share_state:
+                # on EVERY fetch, not only when the twin is built: nn.Module._apply (.to / .cuda / .half) swaps parameters' .data in place but REPLACES buffer
+                # tensors in _buffers, and load_state_dict(assign=True) replaces both -- a twin bound once would keep the old-device / old-dtype objects
+                _share_module_state(self, twin)
                 twin.train(self.training)
             elif "lazy" in self.__dict__ or hasattr(type(self), "lazy"):     # transforms: keep the user-visible switch in step
                 try:
@@ -436,7 +437,12 @@ def function_fallback(ref_module: str, name: str):
                 if ref is None:
                     raise
                 _note(name, e)
-                return ref(*args, **kwargs)
+                # keywords of this package's own (e.g. the fused-argmax switch of sliding_window_argmax) mean nothing to the reference -- it would forward
+                # them to the predictor: they are stripped, and what they stood for is applied to the reference's result
+                private = {k: kwargs.pop(k) for k in [k for k in kwargs if k.startswith("_monai_amd_")]}
+                result = ref(*args, **kwargs)
+                finish = getattr(fn, "_mh_after_reference", None)
+                return finish(result, private) if (finish is not None and private) else result
 
         wrapper._mh_is_product = True
         wrapper._mh_ref = (ref_module, name)

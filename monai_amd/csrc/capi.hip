@@ -675,7 +675,19 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
         return fail(MH_ERR_ARG, "deconv_k2s2: output must be 2x input");
     if (!aligned(out.data, 8) || out.n_stride % 2) return fail(MH_ERR_ARG, "deconv_k2s2: output must be 8-byte aligned");
     const unsigned nb = blocks_for((long long)in.D * in.H * in.W);
-    if (out.C % 8 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
+#ifdef MH_DEV_KNOBS
+    {       // measurement variants (tools/deconv_bench.py): 1 = 8 couts per thread (the round-2 form); 2 / 3 = two voxels per thread, 16-byte stores (3: cout group fastest); 4 = 8 couts, cout group fastest
+        const int var = knob_int("MONAI_AMD_DECONV_VAR", 0);
+        const bool x2ok = in.W % 2 == 0 && out.C % 4 == 0 && aligned(out.data, 16) && out.n_stride % 4 == 0 && aligned(in.data, 8) && in.n_stride % 2 == 0;
+        const unsigned nb2 = blocks_for((long long)in.D * in.H * in.W / 2);
+        if (var == 1 && out.C % 8 == 0) { hipLaunchKernelGGL((deconv_k2s2_kernel<8, true>), dim3(nb, (unsigned)(out.C / 8), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out); return launched("deconv_k2s2"); }
+        if (var == 2 && x2ok) { hipLaunchKernelGGL((deconv_k2s2_x2_kernel<4, false>), dim3(nb2, (unsigned)(out.C / 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out); return launched("deconv_k2s2"); }
+        if (var == 3 && x2ok) { hipLaunchKernelGGL((deconv_k2s2_x2_kernel<4, true>), dim3((unsigned)(out.C / 4), nb2, (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out); return launched("deconv_k2s2"); }
+    }
+#endif
+    // 4 output channels per thread: 2.13 / 0.46 / 0.24 ms on the BasicUNet decoder shapes against 2.42 / 0.56 / 0.27 with 8 (fewer channel planes written at once,
+    // twice the workgroups; two voxels per thread with 16-byte stores measured slower: profiles/r03_deconv_variants.json)
+    if (out.C % 4 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<4, true>), dim3(nb, (unsigned)(out.C / 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
 }

@@ -13,12 +13,9 @@
 #define MH_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
-// write-once result rows of the streaming transforms (Gaussian): -DMH_DEV_NT_STORES (measurement builds) makes them non-temporal
-#ifdef MH_DEV_NT_STORES
+// write-once result rows of the streaming transforms (Gaussian): non-temporal stores -- 0.231 vs 0.236 ms per 512^3 volume at 9 taps, 0.418 vs 0.435 at 17
+// (measured with a -DMH_DEV_NT_STORES build in round 3; for the blend, whose loads and stores interleave per voxel, non-temporal accesses cost 30 %)
 #define MH_STREAM_STORE4(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<mh::f32x4*>(ptr))
-#else
-#define MH_STREAM_STORE4(ptr, val) (*reinterpret_cast<mh::f32x4*>(ptr) = (val))
-#endif
 
 namespace mh {
 

@@ -379,6 +379,58 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
     }
 }
 
+#ifdef MH_DEV_KNOBS
+// Measurement variant (dev builds only, tools/deconv_bench.py): two x-adjacent input voxels per thread, COT output channels, 16-byte stores
+// (four consecutive outputs of a row); SWAP: the cout group is the fastest workgroup index.
+template <int COT, bool SWAP>
+__global__ void __launch_bounds__(256)
+deconv_k2s2_x2_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
+    const int Di = in.D, Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
+    const long long ivol = (long long)Di * Hi * Wi, pairs = ivol / 2;
+    const unsigned bx = SWAP ? blockIdx.y : blockIdx.x, by = SWAP ? blockIdx.x : blockIdx.y;
+    const long long pidx = (long long)bx * 256 + threadIdx.x;
+    const int co0 = by * COT, n = blockIdx.z;
+    if (pidx >= pairs) return;
+    const long long idx = 2 * pidx;
+    const int x = (int)(idx % Wi);
+    const long long t = idx / Wi;
+    const int y = (int)(t % Hi), z = (int)(t / Hi);
+    float acc[COT][2][8];
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[j][v][k] = bias ? bias[co0 + j] : 0.0f;
+    const float* src = in.data + (long long)n * in.n_stride + idx;
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float2 q = *reinterpret_cast<const float2*>(src + (long long)ci * ivol);
+        const float4 a = load_nrm(in, n, ci);
+        const float va[2] = {act(q.x, a.x, a.y, a.z), act(q.y, a.x, a.y, a.z)};
+        const float* wr = w + ((long long)ci * Cout + co0) * 8;
+#pragma unroll
+        for (int j = 0; j < COT; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                acc[j][0][k] = fmaf(va[0], wr[j * 8 + k], acc[j][0][k]);
+                acc[j][1][k] = fmaf(va[1], wr[j * 8 + k], acc[j][1][k]);
+            }
+    }
+    const int Ho = out.H, Wo = out.W;
+    const long long ovol = (long long)out.D * Ho * Wo;
+    float* dst = out.data + (long long)n * out.n_stride;
+#pragma unroll
+    for (int j = 0; j < COT; ++j)
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                float* p = dst + (long long)(co0 + j) * ovol + ((long long)(2 * z + dz) * Ho + (2 * y + dy)) * Wo + 2 * x;
+                *reinterpret_cast<float4*>(p) = make_float4(acc[j][0][dz * 4 + dy * 2], acc[j][0][dz * 4 + dy * 2 + 1], acc[j][1][dz * 4 + dy * 2], acc[j][1][dz * 4 + dy * 2 + 1]);
+            }
+}
+#endif
+
 // Measured and removed (profiles/r02_deconv_bench_v1.json, r03_deconv_bench.json): the same op as ONE GEMM on the fp32 matrix cores, first with this
 // kernel's store pattern, then writing complete 256-byte runs through a wave-private LDS tile -- 2.38 / 2.36 ms against 2.44 ms here (32 -> 32 ch @ 48^3
 // x 64 windows), slower on the smaller levels: neither the 8 Cin Cout multiply-adds per voxel nor the store granularity bound this op.

@@ -454,6 +454,19 @@ def _on_device(host_map: torch.Tensor, dev, cache_key=None) -> torch.Tensor:
     return hit
 
 
+def _finish_reference_result(result, private: dict):
+    """a call that fell through to the reference's sliding_window_inference (CPU input, float64, autograd ...) with the fused-argmax switch set:
+    AsDiscrete(argmax=True) of the reference's blended result, per output"""
+    dtype = private.get("_monai_amd_argmax")
+    if dtype is None:
+        return result
+    keys, parts = _flatten_struct(result)
+    return _pack_struct([t.argmax(dim=1, keepdim=True).to(dtype) for t in parts], keys)
+
+
+sliding_window_inference.__wrapped__._mh_after_reference = _finish_reference_result
+
+
 def _window_stride(dense: int) -> int:
     """Floats between consecutive windows' logits.  The blend reads the K class blocks of up to 8 (27) covering windows of a
     voxel concurrently; with the dense stride (K * roi * 4 B, a multiple of 128 KiB at 96^3) those streams fall on the same HBM

@@ -24,6 +24,7 @@ There is no CPU path: tensors must live on a ROCm device (RuntimeError otherwise
 
 from __future__ import annotations
 
+import threading
 from collections.abc import Sequence
 from typing import Optional
 
@@ -38,12 +39,13 @@ __all__ = ["BasicUNet", "BasicUnet", "Basicunet", "basicunet"]
 # --------------------------------------------------------------------------- parameter containers
 # A 2-D network (what SliceInferer drives) runs as ONE PLANE of the 3-D engine: the parameters live in the reference's 2-D modules
 # (Conv2d, InstanceNorm2d, ConvTranspose2d: the 2-D net's state_dict), the engine reads a [O, I, 3, 3] kernel as the centre z-slice of a 3x3x3 one,
-# pools and up-samples in-plane only.  `_DIMS` is set by BasicUNet.__init__ while it builds its blocks.
-_DIMS = [3]
+# pools and up-samples in-plane only.  The spatial rank under construction is per-THREAD state (set by BasicUNet.__init__ while it builds its blocks): two
+# networks built concurrently -- data-loader workers, a server -- must not see each other's.
+_BUILD = threading.local()
 
 
 def _nd(three, two):
-    return two if _DIMS[0] == 2 else three
+    return two if getattr(_BUILD, "dims", 3) == 2 else three
 
 
 def _w5(w: torch.Tensor) -> torch.Tensor:
@@ -184,11 +186,11 @@ class BasicUNet(nn.Module):
         kw = dict(bias=bias, norm=_parse_norm(norm), slope=slope)
         self.features, self.in_channels, self.out_channels = fea, in_channels, out_channels
         self.spatial_dims, self.upsample = spatial_dims, upsample
-        _DIMS[0] = spatial_dims
+        _BUILD.dims = spatial_dims
         try:
             self._build(in_channels, out_channels, fea, kw)
         finally:
-            _DIMS[0] = 3
+            _BUILD.dims = 3
         self._plans: dict = {}      # (N, D, H, W, device) -> _Plan
         self._packed: dict = {}     # (layer name, cfg) -> (version key, packed weights)
         self.fused_stats = True     # take InstanceNorm statistics from the conv epilogue when the tile kernel runs

@@ -21,6 +21,8 @@ inference output does not depend on them)."""
 
 from __future__ import annotations
 
+import threading
+
 from collections.abc import Sequence
 
 import torch
@@ -77,15 +79,17 @@ class _ADN(nn.Module):
 class _Conv(nn.Module):
     """``get_conv_layer(..., act=None, norm=None)``: a ``Convolution`` whose children are ``conv`` and, with dropout, ``adn.D``"""
 
-    _dropout = None      # set by DynUNet.__init__ while it builds its blocks
-    _dims = 3            # likewise: 2 builds the reference's 2-D modules (Conv2d ...: the state_dict of a 2-D net), the engine reads them as one-plane 3-D
+    # construction context, per THREAD (set by DynUNet.__init__ while it builds its blocks; concurrent constructions must not see each other's):
+    # `dropout` = the ADN's dropout argument or None; `dims` = 2 builds the reference's 2-D modules (Conv2d ...: the state_dict of a 2-D net), the engine
+    # reads them as one-plane 3-D
+    _build = threading.local()
 
     def __init__(self, cin, cout, k, stride=(1, 1, 1), transposed=False, bias=False):
         super().__init__()
         k = (k,) * 3 if isinstance(k, int) else tuple(k)
         stride = tuple(stride)
         pad = tuple((a - b + 1) // 2 for a, b in zip(k, stride))       # get_padding, dynunet_block.py:304-315: (k - s + 1) / 2 per axis, truncated
-        if _Conv._dims == 2:
+        if getattr(_Conv._build, "dims", 3) == 2:
             if transposed:
                 self.conv = nn.ConvTranspose2d(cin, cout, kernel_size=k[1:], stride=stride[1:], bias=bias)
             else:
@@ -94,8 +98,8 @@ class _Conv(nn.Module):
             self.conv = nn.ConvTranspose3d(cin, cout, kernel_size=k, stride=stride, bias=bias)
         else:
             self.conv = nn.Conv3d(cin, cout, kernel_size=k, stride=stride, padding=pad, bias=bias)
-        if _Conv._dropout is not None:
-            self.adn = _ADN(_Conv._dropout)
+        if getattr(_Conv._build, "dropout", None) is not None:
+            self.adn = _ADN(_Conv._build.dropout)
 
 
 class _Block(nn.Module):
@@ -107,7 +111,7 @@ class _Block(nn.Module):
         self.conv1 = _Conv(cin, cout, kernel, stride)
         self.conv2 = _Conv(cout, cout, kernel)
         self.lrelu = nn.LeakyReLU(slope, inplace=True) if slope != 0.0 else nn.ReLU(inplace=True)
-        norm_t = nn.InstanceNorm2d if _Conv._dims == 2 else nn.InstanceNorm3d
+        norm_t = nn.InstanceNorm2d if getattr(_Conv._build, "dims", 3) == 2 else nn.InstanceNorm3d
         self.norm1 = norm_t(cout, affine=affine)
         self.norm2 = norm_t(cout, affine=affine)
         if res and (cin != cout or any(a != 1 for a in stride)):
@@ -204,7 +208,7 @@ class DynUNet(nn.Module):
             return _Block(cin, cout, k, s, affine, slope, res_block)
 
         # construction order = the reference's (dynunet.py:154-166): it fixes the random stream of the default initialisers
-        _Conv._dropout, _Conv._dims = dropout, spatial_dims
+        _Conv._build.dropout, _Conv._build.dims = dropout, spatial_dims
         try:
             self.input_block = block(in_channels, f[0], ks[0], ss[0])
             self.downsamples = nn.ModuleList([block(i, o, k, s) for i, o, k, s in zip(f[:-2], f[1:-1], ks[1:-1], ss[1:-1])])
@@ -221,7 +225,7 @@ class DynUNet(nn.Module):
                 if deep_supr_num < 1:
                     raise ValueError("deep_supr_num should be larger than 0.")
         finally:
-            _Conv._dropout, _Conv._dims = None, 3
+            _Conv._build.dropout, _Conv._build.dims = None, 3
         self.apply(self.initialize_weights)
 
         def create_skips(index, downs, ups, heads):

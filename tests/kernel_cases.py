@@ -292,7 +292,7 @@ def case_bound_producers(device):
     r = rec.cpu()
     assert torch.all(r[:, :3] == 7.0) and torch.all(r[:, 3:, 0] == 1) and torch.all(r[:, 3:, 1] == 0) and torch.all(r[:, 3:, 2] == 1)
     amax = buf.cpu()[:, 3:].abs().amax(dim=(2, 3, 4))
-    # one reduction per wave over the channel group a thread owns (4 channels here, 8 when Cout % 8 == 0): every channel gets its group's maximum
+    # one reduction per workgroup over the channel group a thread owns (4 channels): every channel gets its group's maximum
     grp = torch.stack([amax[:, g:g + 4].amax(dim=1) for g in range(0, cout, 4)], dim=1).repeat_interleave(4, dim=1)[:, :cout]
     assert torch.equal(r[:, 3:, 3], grp) and torch.all(r[:, 3:, 3] >= amax), "deconv_k2s2: bound != max |value written| of the channel group"
     out = torch.empty((n, cout) + (dims[0], 2 * dims[1], 2 * dims[2]), device=device)

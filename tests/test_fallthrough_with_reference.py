@@ -157,6 +157,35 @@ def test_torchscript_export_uses_the_reference_twin(patched):
             assert torch.equal(ts(x), net(x))
 
 
+def test_fused_argmax_and_moved_buffers_fall_through_cleanly(patched):
+    """(a) sliding_window_argmax / SlidingWindowInferer.argmax of a CPU volume falls through to the reference WITHOUT handing this
+    package's private keyword to the predictor, and still returns the label map; (b) a net whose reference twin already exists and that is then
+    converted with .to() (nn.Module._apply REPLACES buffer tensors) keeps its twin on the new tensors."""
+    monai, ref = patched
+    from monai.inferers import SlidingWindowInferer
+    from monai.networks.nets import UNet
+
+    from monai_amd.inferers import sliding_window_argmax
+
+    torch.manual_seed(4)
+    pred = torch.nn.Conv3d(1, 3, 3, padding=1).eval()          # a plain torch predictor on the CPU: would raise on an unexpected keyword
+    x = torch.rand(1, 1, 20, 20, 20)
+    with torch.no_grad():
+        blended = ref["swi"](x, (16, 16, 16), 2, pred, overlap=0.5, mode="gaussian")
+        labels = sliding_window_argmax(x, (16, 16, 16), 2, pred, overlap=0.5, mode="gaussian")
+        labels2 = SlidingWindowInferer((16, 16, 16), 2, overlap=0.5, mode="gaussian").argmax(x, pred, labels_dtype=torch.uint8)
+    assert labels.shape == (1, 1, 20, 20, 20) and torch.equal(labels, blended.argmax(1, keepdim=True).float())
+    assert labels2.dtype == torch.uint8 and torch.equal(labels2.long(), blended.argmax(1, keepdim=True))
+    net = UNet(spatial_dims=3, in_channels=1, out_channels=2, channels=(4, 8), strides=(2,), norm="batch").train()
+    y = torch.rand(2, 1, 8, 8, 8)
+    net(y)                                                     # training mode: falls through, the twin is built and updates the running statistics
+    before = net.model[0].adn.N.running_mean.clone()
+    net = net.to(torch.float64)                                # buffers are replaced by _apply
+    net(y.double())
+    after = net.model[0].adn.N.running_mean
+    assert after.dtype == torch.float64 and not torch.equal(after.float(), before), "the twin must update the CONVERTED buffers"
+
+
 def test_no_monai_keeps_the_explicit_error():
     """Without MONAI on the path nothing can be delegated: the original explicit error is raised."""
     for m in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]:
