@@ -78,6 +78,18 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 // EMIT / PLAIN step bodies are the same code; the epilogue of a completed plane rides in the first step of the next plane
 // RES: at most two channel chunks (Cin <= 32): both weight slabs stay resident in the two LDS weight buffers (chunk = buffer index)
 // and are loaded once -- the per-step weight stream from L2 (55 KB per step and CU: 2.2 of 9.4 ms) disappears
+// timing experiments of tools/ubench/h2_variants.hip (WRONG results, real data in the pipe): -DH2X_NOBL / -DH2X_NOAL replace the LDS reads of the low weight /
+// input pieces by copies of the high ones -- how much of the step is LDS operand traffic
+#ifdef H2X_NOBL
+#define MH_H2X_BL(read, other) (other)
+#else
+#define MH_H2X_BL(read, other) (read)
+#endif
+#ifdef H2X_NOAL
+#define MH_H2X_AL(read, other) (other)
+#else
+#define MH_H2X_AL(read, other) (read)
+#endif
 template <bool STATS, bool NRM, bool RES>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
@@ -238,9 +250,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         constexpr int aoff_ = ((T_) / 3) * H2_RS + (T_) % 3;                                          \
         const uint4* xb_ = xs + bcur * H2_XB + abase + aoff_;                                         \
         const uint4* wb_ = ws + bcur * H2_WB + (T_) * (2 * H2_CN) + bbase;                            \
-        ah[OB] = xb_[0]; al[OB] = xb_[H2_XV];                                                         \
+        ah[OB] = xb_[0]; al[OB] = MH_H2X_AL(xb_[H2_XV], ah[OB]);                                      \
         _Pragma("unroll") for (int kz = 0; kz < 3; ++kz) {                                            \
-            bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)];   \
+            bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = MH_H2X_BL(wb_[H2_WV + kz * (9 * 2 * H2_CN)], bh[OB][kz]); \
         }                                                                                             \
     }
 #define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
