@@ -212,16 +212,16 @@ def conv_roofline(spans, steps: int, ms: float, roi: int):
     return roof
 
 
-def blend_roofline(spans):
+def blend_roofline(spans, mosaic: bool):
     blend = spans.get("sw_blend")
     if not blend:
         return None
     gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-            "kernel": "sw_blend kernel (gather blend: logits read once, output written once)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+            "kernel": ("sw_blend_mosaic_kernel<5,2> (gather blend over the mosaic logits layout" if mosaic else "sw_blend_reg_kernel<5,4,2> (gather blend over window-major logits") + ": logits read once, output written once)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
             "bytes_per_launch": blend["work"] / blend["launches"],
             "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s (profiles/r02_ubench_hbm_stream_v1.txt)"}
-    td = pmc_traffic("sw_blend_reg_kernel") or pmc_traffic("sw_blend_kernel")
+    td = pmc_traffic("sw_blend_mosaic_kernel" if mosaic else "sw_blend_reg_kernel")
     if td:
         roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
     return roof
@@ -470,7 +470,7 @@ def main(argv=None):
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
             "roofline": conv_roofline(spans, args.steps, ms, args.roi),
-            "roofline_hbm": blend_roofline(spans),
+            "roofline_hbm": blend_roofline(spans, mosaic=world == 1 and hasattr(net, "forward_into_windows") and os.environ.get("MONAI_AMD_LOGITS_LAYOUT") != "windows"),
             "conv_ms_per_step": conv_all,
             "checksum": float(out.double().sum().item()),
         }

@@ -18,7 +18,12 @@ imp = compute_importance_map((96,) * 3, "gaussian", 0.125).to(dev)
 out = torch.empty(5, 512, 512, 512, device=dev)
 for _ in range(3):
     ops.sw_blend(logits, imp, out, starts, (96,) * 3)
-del logits, out
+del logits
+mos = ops.LogitsMosaic(starts, (96,) * 3, 5, dev)          # the same logits volume in the mosaic layout (contents do not matter for the counters)
+mos.flat.normal_()
+for _ in range(3):
+    ops.sw_blend_mosaic(mos, imp, out)
+del mos, out
 vol = torch.rand(1, 512, 512, 512, device=dev)
 m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
 for f64 in (True, False):

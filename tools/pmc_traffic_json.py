@@ -18,9 +18,9 @@ ALGORITHMIC = {                                     # key (substring of the kern
     "separable_resample_stream_kernel<double": VOL + RES_OUT, "separable_resample_stream_kernel<float": VOL + RES_OUT,
     "gauss3d_stream_kernel": 2 * VOL, "gauss3d_rowvec_kernel": 2 * VOL,
     "conv3d_k3_mfma_kernel": CONV, "conv3d_k3_wino2d_kernel": CONV, "conv3d_k3_wino2p_kernel": CONV, "conv3d_k3_wino2s_kernel": CONV, "conv3d_k3_h2_kernel": CONV,
-    "sw_blend_kernel": BLEND, "sw_blend_reg_kernel": BLEND,
+    "sw_blend_kernel": BLEND, "sw_blend_reg_kernel": BLEND, "sw_blend_mosaic_kernel": BLEND,
 }
-WIDE_READS = ("sw_blend_kernel", "sw_blend_reg_kernel", "gauss3d_rowvec_kernel")
+WIDE_READS = ("sw_blend_kernel", "sw_blend_reg_kernel", "sw_blend_mosaic_kernel", "gauss3d_rowvec_kernel")
 
 
 def table(path, counter):
