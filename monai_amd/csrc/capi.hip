@@ -401,6 +401,20 @@ static inline int wino2d_chunks(int D, int H, int W) {
 }
 static inline int wino2d_zchunk(int D, int H, int W) { return cdiv(D, wino2d_chunks(D, H, W)); }
 static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cdiv(H, W2_B) * cdiv(D, wino2d_zchunk(D, H, W)); }
+// the split-precision kernel: regions of 16 x 16 or 8 x 32 outputs (whichever covers the plane with fewer: a pure function of the extents, like the
+// statistics record count that depends on it), the same z-chunk rule on its own region count
+static inline int h2_regions(int H, int W) { return h2_wide(H, W) ? cdiv(W, 32) * cdiv(H, 8) : cdiv(W, H2_B) * cdiv(H, H2_B); }
+static inline int h2_zchunk(int D, int H, int W) {
+    int nchunk = cdiv(16, h2_regions(H, W));
+    if (const char* e = knob_str("MONAI_AMD_W2_CHUNKS")) {          // tuning knob (development)
+        const int v = atoi(e);
+        if (v >= 1 && v <= D) return cdiv(D, v);
+    }
+    if (nchunk > D / 12) nchunk = D / 12;
+    if (nchunk < 1) nchunk = 1;
+    return cdiv(D, nchunk);
+}
+static inline int h2_blocks(int D, int H, int W) { return h2_regions(H, W) * cdiv(D, h2_zchunk(D, H, W)); }
 
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
@@ -491,7 +505,8 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 }
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
-    if (cfg == MH_CFG_WINO2D || cfg == MH_CFG_H2) return wino2d_blocks(D, H, W);
+    if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
+    if (cfg == MH_CFG_H2) return h2_blocks(D, H, W);
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
@@ -539,21 +554,23 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
                         in.C, out.C, in.D, in.H, in.W);
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
             return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs 16-byte aligned output and weights");
-        const int bxn = cdiv(out.W, H2_B), byn = cdiv(out.H, H2_B), zc = wino2d_zchunk(out.D, out.H, out.W);
+        const bool wide = h2_wide(out.H, out.W);
+        const int bxn = wide ? cdiv(out.W, 32) : cdiv(out.W, H2_B), byn = wide ? cdiv(out.H, 8) : cdiv(out.H, H2_B), zc = h2_zchunk(out.D, out.H, out.W);
         const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
         const long long total = (long long)nblk * (out.C / H2_CN) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-#define MH_H2_LAUNCH(RES_)                                                                                                                               \
+#define MH_H2_LAUNCH(RES_, WIDE_)                                                                                                                        \
     {                                                                                                                                                \
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
-        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
+        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
     }
-        if (in.C <= 2 * H2_KC) MH_H2_LAUNCH(true) else MH_H2_LAUNCH(false)
+        if (in.C <= 2 * H2_KC) { if (wide) MH_H2_LAUNCH(true, true) else MH_H2_LAUNCH(true, false) }
+        else { if (wide) MH_H2_LAUNCH(false, true) else MH_H2_LAUNCH(false, false) }
 #undef MH_H2_LAUNCH
         return launched("conv3d_k3_h2");
     }

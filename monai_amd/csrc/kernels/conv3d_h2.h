@@ -70,6 +70,17 @@ constexpr int H2_SLOTS = 3;                                // staging tasks per 
 constexpr int H2_TAIL = 4;                                 // floats behind the packed slabs: {1 / scale, scale, 0, 0}
 constexpr int H2_NRM_MAX = 256;                            // input channels: their {alpha, beta, slope} records sit in LDS, 12 bytes each (157 + 3 KB = all 160 KB)
 
+// Region geometry of a workgroup: 16 x 16 outputs (a wave = two rows of 16) or, WIDE, 8 x 32 (a wave = one row of 32) -- the same 256 voxels, the same
+// 360-voxel staged plane (18 rows x pitch 20 | 10 rows x pitch 36), so everything but the index arithmetic is shared.  The launcher picks the shape that
+// covers the (H, W) plane with fewer regions (24 x 24: three 8 x 32 regions instead of four 16 x 16 ones).
+template <bool WIDE> struct H2Geo {
+    static constexpr int BY = WIDE ? 8 : H2_B, BX = WIDE ? 32 : H2_B;
+    static constexpr int RY = BY + 2, RX = BX + 2, RS = RX + 2;      // staged rows, columns, LDS row pitch in voxels
+    static constexpr int NV = RY * RX, HALF = NV / 2;                // staged voxels (324 | 340), per staging half-workgroup (162 | 170 <= 64 H2_SLOTS)
+    static_assert(RY * RS == H2_PV && HALF * 2 == NV && HALF <= 64 * H2_SLOTS, "staged plane must stay 360 voxels");
+};
+__host__ __device__ inline bool h2_wide(int H, int W) { return ((W + 31) / 32) * ((H + 7) / 8) < ((W + 15) / 16) * ((H + 15) / 16); }
+
 __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
@@ -90,10 +101,11 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 #else
 #define MH_H2X_AL(read, other) (read)
 #endif
-template <bool STATS, bool NRM, bool RES>
+template <bool STATS, bool NRM, bool RES, bool WIDE = false>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
+    using G = H2Geo<WIDE>;
     __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
     __shared__ float nrm_s[NRM ? 3 * H2_NRM_MAX : 1];
     uint4* const xs = smem;
@@ -112,7 +124,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     lid /= ncg;
     const unsigned b = lid % nblk;
     const int n = (int)(lid / nblk);
-    const int x0 = (int)(b % bxn) * H2_B, y0 = (int)((b / bxn) % byn) * H2_B;
+    const int x0 = (int)(b % bxn) * G::BX, y0 = (int)((b / bxn) % byn) * G::BY;
     const int zs = (int)(b / (bxn * byn)) * zchunk, ze = min(zs + zchunk, D);
     const int p_first = max(zs - 1, 0), p_last = min(ze, D - 1);
     const int T = (p_last - p_first + 1) * NCH;               // steps this workgroup runs
@@ -126,12 +138,12 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #pragma unroll
     for (int j = 0; j < H2_SLOTS; ++j) {
         const int e0 = lane + 64 * j;
-        const int e = min((wave & 1) * 162 + e0, H2_R * H2_R - 1);
-        const int ly = e / H2_R, lx = e - ly * H2_R;
+        const int e = min((wave & 1) * G::HALF + e0, G::NV - 1);
+        const int ly = e / G::RX, lx = e - ly * G::RX;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        const bool ok = e0 < 162 && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const bool ok = e0 < G::HALF && gy >= 0 && gy < H && gx >= 0 && gx < W;
         soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
-        loff[j] = ((q >> 1) * H2_PV + ly * H2_RS + (ok ? lx : H2_R + (lx & 1))) * 2 + (q & 1);
+        loff[j] = ((q >> 1) * H2_PV + ly * G::RS + (ok ? lx : G::RX + (lx & 1))) * 2 + (q & 1);
     }
     for (int i = tid; i < 2 * H2_XB; i += 512) xs[i] = make_uint4(0u, 0u, 0u, 0u);
     if (NRM) {
@@ -216,8 +228,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     // operands of this lane: A = voxel (row 2w + (r >> 4), x) with r = lane & 31 and the second row rotated by 4 voxels
     // (16-byte reads of a lane group then cover all 64 banks once); B = cout r; k-group = lane >> 5
     const int r32 = lane & 31, kg = lane >> 5;
+    // (WIDE: the wave's 32 voxels are one row -- consecutive 16-byte cells, conflict-free as they are)
     const int arow = r32 >> 4, ax = arow ? ((r32 + 12) & 15) : (r32 & 15);
-    const int abase = kg * H2_PV + (2 * wave + arow) * H2_RS + ax;
+    const int abase = WIDE ? kg * H2_PV + wave * G::RS + r32 : kg * H2_PV + (2 * wave + arow) * G::RS + ax;
     const int bbase = kg * H2_CN + r32;
 
     // acc[0], acc[1], acc[2]: output planes p+1, p, p-1 of the current input plane p (rotated once per plane, 48 moves);
@@ -229,7 +242,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         for (int i = 0; i < 16; ++i) acc[s][i] = 0.0f;
     int pend = 0, pend_z = 0;
 
-    // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i
+    // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i (WIDE: the wave's one row, x = 8 j + 4 kg + i)
     const int co = cg * H2_CN + r32;
     const float bco = bias ? bias[co] : 0.0f;
     // scale back: 2^-(weight scale exponent) * 2^-e_in as two power-of-two factors (their product may leave fp32's exponent range)
@@ -240,14 +253,15 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         inv_a = poisoned ? __uint_as_float(0x7fc00000u) : __uint_as_float((unsigned)(t1_ + 127) << 23);
         inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
     }
-    float* const obase = out.data + (long long)n * out.n_stride + (long long)co * DHW + (long long)(y0 + 2 * wave) * W + x0;
+    const int orow = WIDE ? wave : 2 * wave;                 // first region row of this wave
+    float* const obase = out.data + (long long)n * out.n_stride + (long long)co * DHW + (long long)(y0 + orow) * W + x0;
     Stat run;
     run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
 
     uint4 ah[2], al[2], bh[2][3], bl[2][3];
 #define MH_H2_FETCH(OB, T_)                                                                           \
     {                                                                                                 \
-        constexpr int aoff_ = ((T_) / 3) * H2_RS + (T_) % 3;                                          \
+        constexpr int aoff_ = ((T_) / 3) * G::RS + (T_) % 3;                                          \
         const uint4* xb_ = xs + bcur * H2_XB + abase + aoff_;                                         \
         const uint4* wb_ = ws + bcur * H2_WB + (T_) * (2 * H2_CN) + bbase;                            \
         ah[OB] = xb_[0]; al[OB] = MH_H2X_AL(xb_[H2_XV], ah[OB]);                                      \
@@ -291,10 +305,11 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         f32x4 o_[4];                                                                                  \
         float w_[4];                                                                                  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-            const int xg_ = j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);              \
-            const bool ok_ = pend && y0 + 2 * wave + (j >> 1) < H && x0 + xg_ < W;                    \
+            const int xg_ = WIDE ? 8 * j + 4 * kg : j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15); \
+            const int yr_ = WIDE ? 0 : (j >> 1);                                                      \
+            const bool ok_ = pend && y0 + orow + yr_ < H && x0 + xg_ < W;                             \
             o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_a * inv_b + bco; \
-            if (ok_) *reinterpret_cast<f32x4*>(op_ + (j >> 1) * W + xg_) = o_[j];                     \
+            if (ok_) *reinterpret_cast<f32x4*>(op_ + yr_ * W + xg_) = o_[j];                          \
             w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
             cnt_ += 4.0f * w_[j];                                                                     \
             sum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_[j];                          \

@@ -1,7 +1,8 @@
 // Development aid: times conv3d_k3_h2_kernel (Cin -> 32 channels, 96^3, 64 windows) standalone, so that variants of the kernel header
 // (-DH2V_RES=true: resident weight slabs; any experimental -D switch added to conv3d_h2.h) compile in seconds on the GPU box:
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-D...] tools/ubench/h2_variants.hip -o /tmp/h2v
-//   /tmp/h2v <Cin> <label> [alias]      alias 1: every window reads window 0's input, 2: every window writes window 0's output
+//   /tmp/h2v <Cin> <label> [alias] [edge] [windows] [Cout]      alias 1: every window reads window 0's input, 2: every window writes window 0's output
+// -DH2V_WIDE=true: the 8 x 32 region shape instead of 16 x 16 (e.g. edge 24: three regions per plane instead of four)
 // Lesson kept from the round-2 ablations: builds that replace loads by register moves feed the matrix pipe constant data, the chip
 // then clocks 25-40 % higher, and the "saving" is mostly that -- only timings with real data count.
 #include <hip/hip_runtime.h>
@@ -13,17 +14,24 @@ using namespace mh;
 #ifndef H2V_RES
 #define H2V_RES false
 #endif
+#ifndef H2V_WIDE
+#define H2V_WIDE false
+#endif
 
 int main(int argc, char** argv) {
-    const int N = 64, C = argc > 1 ? atoi(argv[1]) : 32, K = 32, E = 96;
+    const int C = argc > 1 ? atoi(argv[1]) : 32, E = argc > 4 ? atoi(argv[4]) : 96, N = argc > 5 ? atoi(argv[5]) : 64, K = argc > 6 ? atoi(argv[6]) : 32;
+    using G = H2Geo<H2V_WIDE>;
     const size_t vox = (size_t)E * E * E;
     float *x, *y, *nrm, *bias, *stats, *packed;
     hipMalloc(&x, sizeof(float) * N * C * vox);
     hipMalloc(&y, sizeof(float) * N * K * vox);
     hipMalloc(&nrm, sizeof(float) * N * C * 4);
     hipMalloc(&bias, sizeof(float) * K);
-    const int bxn = E / H2_B, byn = E / H2_B, zc = E;
-    const unsigned nblk = bxn * byn;
+    const int bxn = (E + G::BX - 1) / G::BX, byn = (E + G::BY - 1) / G::BY;
+    int nchunk = (16 + bxn * byn - 1) / (bxn * byn);          // the launcher's z-chunk rule (capi.hip h2_zchunk)
+    nchunk = nchunk > E / 12 ? E / 12 : nchunk;
+    const int zc = (E + (nchunk < 1 ? 1 : nchunk) - 1) / (nchunk < 1 ? 1 : nchunk);
+    const unsigned nblk = bxn * byn * ((E + zc - 1) / zc);
     hipMalloc(&stats, sizeof(float) * N * K * nblk * 3);
     const size_t pf = (size_t)(C / H2_KC) * (K / H2_CN) * H2_WB * 4 + H2_TAIL;
     hipMalloc(&packed, sizeof(float) * pf);
@@ -47,13 +55,13 @@ int main(int argc, char** argv) {
     const int alias = argc > 3 ? atoi(argv[3]) : 0;          // 1: every window reads window 0's input, 2: every window writes window 0's output
     Tensor in{x, (alias & 1) ? 0LL : (long long)C * (long long)vox, nrm, (long long)C * 4, N, C, E, E, E};
     Tensor out{y, (alias & 2) ? 0LL : (long long)K * (long long)vox, nullptr, 0, N, K, E, E, E};
-    const dim3 grid(nblk * N);
+    const dim3 grid(nblk * N * (K / H2_CN));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     float best = 1e9f;
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, H2V_RES>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
+        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, H2V_RES, H2V_WIDE>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
@@ -61,8 +69,8 @@ int main(int argc, char** argv) {
         if (it && ms < best) best = ms;
     }
     std::vector<float> ho(64);
-    hipMemcpy(ho.data(), y + 5 * vox + 40 * E * E + 40 * E + 16, 64 * 4, hipMemcpyDeviceToHost);
-    printf("%-28s Cin %d: %.3f ms  (%.0f TFLOP/s direct-equivalent)  y[..] = %g %g\n", argc > 2 ? argv[2] : "full", C, best,
+    hipMemcpy(ho.data(), y + 5 * vox + (E / 2) * E * E + (E / 2) * E + 16, 64 * 4, hipMemcpyDeviceToHost);
+    printf("%-28s Cin %d -> %d, %d^3 x %d: %.3f ms  (%.0f TFLOP/s direct-equivalent)  y[..] = %g %g\n", argc > 2 ? argv[2] : "full", C, K, E, N, best,
            2.0 * 27 * C * K * vox * N / best / 1e9, ho[0], ho[1]);
     return hipGetLastError() != hipSuccess;
 }
