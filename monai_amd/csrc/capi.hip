@@ -403,6 +403,8 @@ static inline int wino2d_zchunk(int D, int H, int W) { return cdiv(D, wino2d_chu
 static inline int wino2d_blocks(int D, int H, int W) { return cdiv(W, W2_B) * cdiv(H, W2_B) * cdiv(D, wino2d_zchunk(D, H, W)); }
 // the split-precision kernel: regions of 16 x 16 or 8 x 32 outputs (whichever covers the plane with fewer: a pure function of the extents, like the
 // statistics record count that depends on it), the same z-chunk rule on its own region count
+// its result stores address the 32 cout planes of a workgroup through one raw buffer with 31-bit byte offsets (kernels/conv3d_h2.h)
+static inline bool h2_fits(int D, int H, int W) { return (long long)D * H * W * H2_CN * 4 < 0x80000000LL; }
 static inline int h2_regions(int H, int W) { return h2_wide(H, W) ? cdiv(W, 32) * cdiv(H, 8) : cdiv(W, H2_B) * cdiv(H, H2_B); }
 static inline int h2_zchunk(int D, int H, int W) {
     int nchunk = cdiv(16, h2_regions(H, W));
@@ -456,7 +458,7 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     // profiles/r02_h2_vs_wino2p_*.json).  It scales its input into fp16's range by a power of two taken from the bounds the input
     // records carry (kernels/conv3d_h2.h), so it is chosen -- also under MH_ALGO_H2 -- only for inputs that carry them
     // (`input_bounded`); anything else gets the exact fp32 kernels.
-    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8)
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W))
         best = MH_CFG_H2;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
     if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
@@ -554,6 +556,8 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
                         in.C, out.C, in.D, in.H, in.W);
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
             return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs 16-byte aligned output and weights");
+        if (!h2_fits(out.D, out.H, out.W))
+            return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: the fp16 split kernel addresses 32 output planes with 32-bit offsets (D*H*W < 2^24 voxels); mh_conv3d_k3_select does not return it beyond");
         const bool wide = h2_wide(out.H, out.W);
         const int bxn = wide ? cdiv(out.W, 32) : cdiv(out.W, H2_B), byn = wide ? cdiv(out.H, 8) : cdiv(out.H, H2_B), zc = h2_zchunk(out.D, out.H, out.W);
         const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));

@@ -100,6 +100,18 @@ __device__ __forceinline__ Stat stat_merge(Stat a, Stat b) {
     r.m2 = a.m2 + b.m2 + d * d * a.n * f;
     return r;
 }
+// the same merge without a branch (selects only): for epilogues that are interleaved with matrix instructions -- a branch would end the scheduling region.
+// Bit-identical to stat_merge for finite inputs.
+__device__ __forceinline__ Stat stat_merge_nb(Stat a, Stat b) {
+    Stat r;
+    r.n = a.n + b.n;
+    const bool e = r.n <= 0.0f;
+    const float d = b.mean - a.mean;
+    const float f = b.n / (e ? 1.0f : r.n);
+    r.mean = e ? 0.0f : a.mean + d * f;
+    r.m2 = e ? 0.0f : a.m2 + b.m2 + d * d * a.n * f;
+    return r;
+}
 
 // XCD-aware, bijective remap of a 1-D block index: the dispatcher places block b on XCD b % 8
 // (observed, used for L2 locality only), so give each XCD a contiguous run of logical tiles.

@@ -191,8 +191,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         const char* xq_ = reinterpret_cast<const char*>(xptr + (long long)i * DHW);                   \
         _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
     }
-#define MH_H2_LDW(J0, J1)                                                                             \
-    if (!RES || gi < 0) _Pragma("unroll") for (int j = (J0); j < (J1); ++j) win[j] = wg[woff + 512 * j];
+    // (PRO_: the prologue, where resident slabs are loaded too -- inside the loop the condition is a compile-time one: no branch in the step)
+#define MH_H2_LDWX(PRO_, J0, J1)                                                                      \
+    if (!RES || (PRO_)) _Pragma("unroll") for (int j = (J0); j < (J1); ++j) win[j] = wg[woff + 512 * j];
+#define MH_H2_LDW(J0, J1) MH_H2_LDWX(false, J0, J1)
     // advance to the next (plane, chunk) -- not beyond the last step (the loads then repeat the last step's addresses)
 #define MH_H2_ADV                                                                                     \
     {                                                                                                 \
@@ -219,11 +221,13 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
         xh_[loff[J] + 2 * H2_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
     }
-#define MH_H2_WST                                                                                     \
+#define MH_H2_WSTX(PRO_)                                                                              \
     {                                                                                                 \
-        if (!RES || gi < 0) _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[(bcur ^ 1) * H2_WB + tid + 512 * j] = win[j]; \
+        if (!RES || (PRO_)) _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[(bcur ^ 1) * H2_WB + tid + 512 * j] = win[j]; \
         cs = cs + 1 == NCH ? 0 : cs + 1;                                                              \
     }
+
+#define MH_H2_WST MH_H2_WSTX(false)
 
     // operands of this lane: A = voxel (row 2w + (r >> 4), x) with r = lane & 31 and the second row rotated by 4 voxels
     // (16-byte reads of a lane group then cover all 64 banks once); B = cout r; k-group = lane >> 5
@@ -254,7 +258,21 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
     }
     const int orow = WIDE ? wave : 2 * wave;                 // first region row of this wave
-    float* const obase = out.data + (long long)n * out.n_stride + (long long)co * DHW + (long long)(y0 + orow) * W + x0;
+    // Result stores go through a raw buffer over the 32 cout planes of this (sample, cout group): 32-bit byte offsets, and a lane without a voxel
+    // (ragged region, no completed plane yet) stores at an offset beyond the buffer, which the hardware drops -- no exec-mask branch, so the
+    // epilogue stays inside the scheduling region of the matrix instructions (the launcher keeps 32 planes below 2 GB)
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * H2_CN) * DHW, 0, (int)(H2_CN * DHW * 4), 0x00020000);
+    constexpr unsigned H2_DROP = 0x80000000u;
+    unsigned ooff[4];                                        // byte offset of register group j inside an output plane of cout r32 (or H2_DROP)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xg_ = WIDE ? 8 * j + 4 * kg : j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);
+        const int yr_ = WIDE ? 0 : (j >> 1);
+        const bool ok_ = y0 + orow + yr_ < H && x0 + xg_ < W;
+        ooff[j] = ok_ ? 4u * (unsigned)((long long)r32 * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
+    }
+    f32x4 o_[4];                                             // the plane being emitted: its pieces A (scale, bias, store), B1-B3 (statistics) sit in different taps
+    float esum_ = 0.0f, ecnt_ = 0.0f, em2_ = 0.0f, emean_ = 0.0f;
     Stat run;
     run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
 
@@ -281,7 +299,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     // and an MFMA occupies the matrix pipe for 32 cycles, so whatever is placed BETWEEN two MFMAs is free, and whatever sits in a
     // lump before or after them is serial time of this wave (measured with the lump form: 6700 of 9700 cycles per step): the
     // scheduler is told to deal the piece out over the gaps.
-#define MH_H2_TAP(T_, ...)                                                                            \
+#define MH_H2_TAPV(T_, NV_, ...)                                                                      \
     {                                                                                                 \
         if ((T_) + 1 < 9) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
         __VA_ARGS__                                                                                   \
@@ -289,66 +307,84 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int g_ = 0; g_ < 9; ++g_) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x006, 5, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                      \
             __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                        \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-    // the completed output plane (in acce): scale back, bias, store 4 x 16 bytes per lane, statistics.  It is placed BEFORE the
-    // loads of the step: stores and loads share the vmcnt counter, and a store issued after the loads would make the next
-    // conversion wait for the store acknowledgement as well
-#define MH_H2_EMIT                                                                                    \
+#define MH_H2_TAP(T_, ...) MH_H2_TAPV(T_, 5, __VA_ARGS__)
+    // the completed output plane (in acce), in four branch-free pieces that ride in the gaps of different taps of the next plane's first step:
+    // A scale back, bias, 4 x 16-byte buffer stores per lane (the plane offset goes into the vector offset, NOT into the instruction's scalar offset: a
+    // 16-byte buffer store with a scalar-register offset followed at once by a vector write of its data registers stored the NEW value of the second
+    // dword on the MI355X -- the compiler only inserts the wait state the ISA asks for when the scalar offset is not a register; placed BEFORE the loads of the step: stores and loads share the vmcnt counter, and a
+    // store issued after the loads would make the next conversion wait for the store acknowledgement as well); B1 count / sum / mean, B2 the
+    // squared deviations, B3 the merge into the running statistics.  (As one piece with `if (ok) store` and stat_merge's early return the
+    // epilogue was five basic blocks of ~200 vector instructions with no matrix instruction among them: 1.5 of 9.4 ms at 32 -> 32 channels.)
+#define MH_H2_EMIT_A                                                                                  \
     {                                                                                                 \
-        float* op_ = obase + (long long)pend_z * HW;                                                  \
-        Stat loc_;                                                                                    \
-        float sum_ = 0.0f, cnt_ = 0.0f;                                                               \
-        f32x4 o_[4];                                                                                  \
-        float w_[4];                                                                                  \
+        const unsigned so_ = (unsigned)pend_z * (unsigned)(HW * 4);                                   \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-            const int xg_ = WIDE ? 8 * j + 4 * kg : j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15); \
-            const int yr_ = WIDE ? 0 : (j >> 1);                                                      \
-            const bool ok_ = pend && y0 + orow + yr_ < H && x0 + xg_ < W;                             \
             o_[j] = f32x4{acce[4 * j], acce[4 * j + 1], acce[4 * j + 2], acce[4 * j + 3]} * inv_a * inv_b + bco; \
-            if (ok_) *reinterpret_cast<f32x4*>(op_ + yr_ * W + xg_) = o_[j];                          \
-            w_[j] = ok_ ? 1.0f : 0.0f;                                                                \
-            cnt_ += 4.0f * w_[j];                                                                     \
-            sum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_[j];                          \
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_[j]), orsrc, (pend ? ooff[j] : H2_DROP) + so_, 0, 0); \
         }                                                                                             \
+    }
+#define MH_H2_EMIT_B1                                                                                 \
+    if (STATS) {                                                                                      \
+        const float pf_ = pend ? 1.0f : 0.0f;                                                         \
+        esum_ = 0.0f; ecnt_ = 0.0f;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            const float w_ = ooff[j] != H2_DROP ? pf_ : 0.0f;                                         \
+            ecnt_ += 4.0f * w_;                                                                       \
+            esum_ += ((o_[j][0] + o_[j][1]) + (o_[j][2] + o_[j][3])) * w_;                            \
+        }                                                                                             \
+        emean_ = ecnt_ > 0.0f ? esum_ / (ecnt_ > 0.0f ? ecnt_ : 1.0f) : 0.0f;                         \
+    }
+#define MH_H2_EMIT_B2                                                                                 \
+    if (STATS) {                                                                                      \
+        em2_ = 0.0f;                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            const f32x4 d_ = o_[j] - emean_;                                                          \
+            const f32x4 q_ = d_ * d_;                                                                 \
+            em2_ += ((q_[0] + q_[1]) + (q_[2] + q_[3])) * (ooff[j] != H2_DROP && pend ? 1.0f : 0.0f); \
+        }                                                                                             \
+    }
+#define MH_H2_EMIT_B3                                                                                 \
+    {                                                                                                 \
         if (STATS) {                                                                                  \
-            loc_.n = cnt_;                                                                            \
-            loc_.mean = cnt_ > 0.0f ? sum_ / cnt_ : 0.0f;                                             \
-            float m2_ = 0.0f;                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-                const f32x4 d_ = o_[j] - loc_.mean;                                                   \
-                const f32x4 q_ = d_ * d_;                                                             \
-                m2_ += ((q_[0] + q_[1]) + (q_[2] + q_[3])) * w_[j];                                   \
-            }                                                                                         \
-            loc_.m2 = m2_;                                                                            \
-            run = stat_merge(run, loc_);                                                              \
+            Stat loc_;                                                                                \
+            loc_.n = ecnt_; loc_.mean = emean_; loc_.m2 = em2_;                                       \
+            run = stat_merge_nb(run, loc_);                                                           \
         }                                                                                             \
         pend = 0;                                                                                     \
     }
+#define MH_H2_EMIT { MH_H2_EMIT_A MH_H2_EMIT_B1 MH_H2_EMIT_B2 MH_H2_EMIT_B3 }
 #define MH_H2_NONE
-#define MH_H2_SCHEDULE(...)                                                                           \
+    // a plain step, and the first step of a plane (the previous plane's epilogue pieces in taps 3, 4, 6, 7 with more vector slots per gap)
+#define MH_H2_SCHEDULE_PLAIN                                                                          \
         MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
-        MH_H2_TAP(3, __VA_ARGS__)                                                                     \
+        MH_H2_TAP(3, MH_H2_NONE)                                                                      \
         MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
         MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)
+#define MH_H2_SCHEDULE_EMIT                                                                           \
+        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
+        MH_H2_TAPV(3, 8, MH_H2_EMIT_A)                                                                \
+        MH_H2_TAPV(4, 8, MH_H2_LDX MH_H2_EMIT_B1) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAPV(6, 8, MH_H2_LDW(0, 4) MH_H2_EMIT_B2) \
+        MH_H2_TAPV(7, 8, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV MH_H2_EMIT_B3) MH_H2_TAP(8, MH_H2_NONE)
     // one step (16 channels of input plane p): conversion of the next step's registers into the other LDS buffer first, then the
-    // epilogue stores (EM), then the loads of the step after next
-#define MH_H2_STEP(EM)                                                                                \
+    // epilogue stores, then the loads of the step after next
+#define MH_H2_STEP(SCHED_)                                                                            \
     {                                                                                                 \
         MH_H2_FETCH(0, 0)                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        MH_H2_SCHEDULE(EM)                                                                            \
+        SCHED_                                                                                        \
     }
 
     // prologue: step 0 into buffer 0 (the conversion pieces write the buffer "after" bcur: start from 1), the loads of step 1 in flight
     int bcur = 1, gi = -2;
-    MH_H2_LDX MH_H2_LDW(0, H2_WSLOTS) MH_H2_ADV
+    MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     gi = -1;
-    MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WST
-    MH_H2_LDX MH_H2_LDW(0, H2_WSLOTS) MH_H2_ADV
+    MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WSTX(true)
+    MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     if (RES) {        // the second slab (chunk 1, or chunk 0 again when there is one chunk) goes into buffer 1 now and stays
         _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[H2_WB + tid + 512 * j] = win[j];
     }
@@ -357,11 +393,11 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 
     for (int p = zs - 1; p <= ze; ++p) {
         if (p >= p_first && p <= p_last) {
-            MH_H2_STEP(MH_H2_EMIT)
+            MH_H2_STEP(MH_H2_SCHEDULE_EMIT)
             __syncthreads();
             bcur ^= 1; ++gi;
             for (int s = 1; s < NCH; ++s) {
-                MH_H2_STEP(MH_H2_NONE)
+                MH_H2_STEP(MH_H2_SCHEDULE_PLAIN)
                 __syncthreads();
                 bcur ^= 1; ++gi;
             }
@@ -378,17 +414,25 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
     if (pend) MH_H2_EMIT
 #undef MH_H2_STEP
-#undef MH_H2_SCHEDULE
+#undef MH_H2_SCHEDULE_EMIT
+#undef MH_H2_SCHEDULE_PLAIN
 #undef MH_H2_NONE
 #undef MH_H2_EMIT
+#undef MH_H2_EMIT_B3
+#undef MH_H2_EMIT_B2
+#undef MH_H2_EMIT_B1
+#undef MH_H2_EMIT_A
 #undef MH_H2_TAP
+#undef MH_H2_TAPV
 #undef MH_H2_MFMA9
 #undef MH_H2_MM
 #undef MH_H2_FETCH
 #undef MH_H2_WST
+#undef MH_H2_WSTX
 #undef MH_H2_CONV
 #undef MH_H2_ADV
 #undef MH_H2_LDW
+#undef MH_H2_LDWX
 #undef MH_H2_LDX
 
     if (STATS) {

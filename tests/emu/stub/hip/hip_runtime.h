@@ -278,6 +278,14 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
     wave_sync();
     return d;
 }
+// raw buffer stores: a {base, num_records} descriptor; a store whose 32-bit offset (+ size) leaves [0, num_records) is dropped, as the hardware does
+struct BufRsrc { char* base; unsigned num_records; };
+template <class P> inline BufRsrc make_buffer_rsrc(P* p, short, int num_records, int) { return BufRsrc{reinterpret_cast<char*>(p), (unsigned)num_records}; }
+template <class V> inline void raw_buffer_store_b128(V data, BufRsrc r, unsigned voffset, unsigned soffset, int) {
+    static_assert(sizeof(V) == 16, "b128");
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 16ull <= r.num_records) std::memcpy(r.base + off, &data, 16);
+}
 }  // namespace emu
 
 // ------------------------------------------------------------------ HIP surface used by the product sources
@@ -297,6 +305,8 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
+#define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
+#define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
