@@ -1205,18 +1205,22 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
     // per plane); MONAI_AMD_GS_IMPL=tile forces the round-1 tile kernel (bit-identical results)
     const char* impl = knob_str("MONAI_AMD_GS_IMPL");
     if (rk <= 17 && W % 4 == 0 && aligned(src, 16) && aligned(dst, 16) && !(impl && impl[0] == 't')) {
+        // up to 9 taps: the DPP / forward-accumulation form (gauss3d_rowdpp_kernel); development builds: MONAI_AMD_GS_IMPL=v keeps the round-2 row-vector kernel
+        const bool dpp = rk <= 9 && (long long)D * H * W * 4 < 0x80000000LL && !(impl && impl[0] == 'v');      // (its loads address a channel volume with 31-bit byte offsets)
         const long long vtiles = (long long)cdiv(W, GV_TX) * cdiv(H, GV_TY);
-        static int vslots[4][2];
+        static int vslots[4][2][2];
         const int vi = rk == 3 ? 0 : rk == 5 ? 1 : rk == 9 ? 2 : 3;
-        int& vs = vslots[vi][iso ? 1 : 0];
+        int& vs = vslots[vi][iso ? 1 : 0][dpp ? 1 : 0];
         if (vs == 0) {
 #define MH_GV_SLOTS(RK_) vs = iso ? resident_wgs(gauss3d_rowvec_kernel<RK_, true>, 64 * gv_waves(RK_)) : resident_wgs(gauss3d_rowvec_kernel<RK_, false>, 64 * gv_waves(RK_));
+#define MH_GD_SLOTS(RK_) vs = iso ? resident_wgs(gauss3d_rowdpp_kernel<RK_, true>, 1024) : resident_wgs(gauss3d_rowdpp_kernel<RK_, false>, 1024);
             switch (rk) {
-                case 3: MH_GV_SLOTS(3) break;
-                case 5: MH_GV_SLOTS(5) break;
-                case 9: MH_GV_SLOTS(9) break;
+                case 3: if (dpp) { MH_GD_SLOTS(3) } else { MH_GV_SLOTS(3) } break;
+                case 5: if (dpp) { MH_GD_SLOTS(5) } else { MH_GV_SLOTS(5) } break;
+                case 9: if (dpp) { MH_GD_SLOTS(9) } else { MH_GV_SLOTS(9) } break;
                 default: MH_GV_SLOTS(17) break;
             }
+#undef MH_GD_SLOTS
 #undef MH_GV_SLOTS
         }
         const int vmin = 4 * rk > 16 ? 4 * rk : 16;
@@ -1229,12 +1233,16 @@ int mh_separable_filter3d_f32(const float* src, float* dst, int NC, int D, int H
 #define MH_GV(RK_)                                                                                                        \
         if (iso) hipLaunchKernelGGL((gauss3d_rowvec_kernel<RK_, true>), dim3((unsigned)vwg), dim3(64 * gv_waves(RK_)), 0, s, src, dst, a);   \
         else hipLaunchKernelGGL((gauss3d_rowvec_kernel<RK_, false>), dim3((unsigned)vwg), dim3(64 * gv_waves(RK_)), 0, s, src, dst, a);
+#define MH_GD(RK_)                                                                                                        \
+        if (iso) hipLaunchKernelGGL((gauss3d_rowdpp_kernel<RK_, true>), dim3((unsigned)vwg), dim3(1024), 0, s, src, dst, a);   \
+        else hipLaunchKernelGGL((gauss3d_rowdpp_kernel<RK_, false>), dim3((unsigned)vwg), dim3(1024), 0, s, src, dst, a);
         switch (rk) {
-            case 3: MH_GV(3) break;
-            case 5: MH_GV(5) break;
-            case 9: MH_GV(9) break;
+            case 3: if (dpp) { MH_GD(3) } else { MH_GV(3) } break;
+            case 5: if (dpp) { MH_GD(5) } else { MH_GV(5) } break;
+            case 9: if (dpp) { MH_GD(9) } else { MH_GV(9) } break;
             default: MH_GV(17) break;
         }
+#undef MH_GD
 #undef MH_GV
         return launched("separable_filter3d_rowvec");
     }

@@ -100,6 +100,19 @@ __device__ __forceinline__ Stat stat_merge(Stat a, Stat b) {
     r.m2 = a.m2 + b.m2 + d * d * a.n * f;
     return r;
 }
+// The float of the lane to the left / right (DPP wave_shr:1 / wave_shl:1, one v_mov_b32_dpp, no LDS); lane 0 / lane 63 keep `edge`.  The value barrier is
+// needed: hipcc's SLP pass merges four such calls on the elements of a vector into ONE dpp of element 0 (seen with ROCm 7.2: wrong results).
+__device__ __forceinline__ float lane_left(float edge, float v) {
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false);
+    MH_OPAQUE(r);
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float lane_right(float edge, float v) {
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, edge), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false);
+    MH_OPAQUE(r);
+    return __builtin_bit_cast(float, r);
+}
+
 // the same merge without a branch (selects only): for epilogues that are interleaved with matrix instructions -- a branch would end the scheduling region.
 // Bit-identical to stat_merge for finite inputs.
 __device__ __forceinline__ Stat stat_merge_nb(Stat a, Stat b) {

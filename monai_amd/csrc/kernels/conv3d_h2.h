@@ -89,17 +89,13 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 // EMIT / PLAIN step bodies are the same code; the epilogue of a completed plane rides in the first step of the next plane
 // RES: at most two channel chunks (Cin <= 32): both weight slabs stay resident in the two LDS weight buffers (chunk = buffer index)
 // and are loaded once -- the per-step weight stream from L2 (55 KB per step and CU: 2.2 of 9.4 ms) disappears
-// timing experiments of tools/ubench/h2_variants.hip (WRONG results, real data in the pipe): -DH2X_NOBL / -DH2X_NOAL replace the LDS reads of the low weight /
-// input pieces by copies of the high ones -- how much of the step is LDS operand traffic
-#ifdef H2X_NOBL
-#define MH_H2X_BL(read, other) (other)
+// timing experiment of tools/ubench/h2_variants.hip: -DH2X_XTRA=n adds n unused 16-byte LDS reads per tap, operands and results unchanged.  Measured
+// (profiles/r03_h2_lds_sensitivity.txt): +12 % reads -> +0.8 % time, +37 % -> +8 %: the operand traffic (65 % of the LDS's 128 B/clk) is felt but is not the bound.
+// (Round 3's first experiment replaced the low pieces' reads by copies of the high ones: same time -- but that also changed the matrix pipe's data.)
+#ifdef H2X_XTRA
+#define MH_H2X_EXTRA_READS(P) _Pragma("unroll") for (int x_ = 0; x_ < H2X_XTRA; ++x_) { u32x4 d_ = reinterpret_cast<const u32x4*>(P)[H2_WV + (x_ + 1) * 64]; asm volatile("" :: "v"(d_)); }
 #else
-#define MH_H2X_BL(read, other) (read)
-#endif
-#ifdef H2X_NOAL
-#define MH_H2X_AL(read, other) (other)
-#else
-#define MH_H2X_AL(read, other) (read)
+#define MH_H2X_EXTRA_READS(P)
 #endif
 template <bool STATS, bool NRM, bool RES, bool WIDE = false>
 __global__ void __launch_bounds__(512, 1)
@@ -107,7 +103,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
     using G = H2Geo<WIDE>;
     __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
-    __shared__ float nrm_s[NRM ? 3 * H2_NRM_MAX : 1];
+    // input records in LDS, per QUAD of channels {alpha x 4, beta x 4, slope x 4} (48 bytes): a wave converts one quad per step and reads its records with
+    // three 16-byte broadcast reads, pairs of alphas / betas adjacent for packed arithmetic (12-byte records per channel cost 30 register moves and six
+    // ds_read2_b64 with an immediate wait per step)
+    __shared__ __attribute__((aligned(16))) float nrm_s[NRM ? 3 * H2_NRM_MAX : 4];
     uint4* const xs = smem;
     uint4* const ws = smem + 2 * H2_XB;
     unsigned* const bound_s = reinterpret_cast<unsigned*>(ws);      // 8 words of the (not yet loaded) weight buffer: all 160 KB of LDS are taken
@@ -150,7 +149,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         unsigned mb = 0u;
         for (int c = tid; c < Cin; c += 512) {
             const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
-            nrm_s[3 * c] = a.x; nrm_s[3 * c + 1] = a.y; nrm_s[3 * c + 2] = a.z;
+            float* r_ = nrm_s + 12 * (c >> 2) + (c & 3);
+            r_[0] = a.x; r_[4] = a.y; r_[8] = a.z;
             const unsigned bb = abs_bits(a.w);
             mb = max(mb, bb == 0u ? 0x7fc00000u : bb);        // no bound given counts as non-finite
         }
@@ -171,7 +171,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         // 2^e_in folded into the records (each thread rescales the ones it loaded): fma(x, alpha p, beta p) == p fma(x, alpha, beta) exactly -- a power of two
         // commutes with every rounding -- unless alpha p itself leaves fp32's normal range, which takes |alpha| < 1e-8 together with activations > 4e34
         // (or the mirror image): the step loop stays instruction for instruction the unscaled one
-        for (int c = tid; c < Cin; c += 512) { nrm_s[3 * c] *= p_; nrm_s[3 * c + 1] *= p_; }
+        for (int c = tid; c < Cin; c += 512) { float* r_ = nrm_s + 12 * (c >> 2) + (c & 3); r_[0] *= p_; r_[4] *= p_; }
         __syncthreads();
     }
 
@@ -183,13 +183,16 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const long long xstep = (long long)H2_KC * DHW, xwrap = HW - (long long)(NCH - 1) * H2_KC * DHW;
     float xin[H2_SLOTS][4];
     u32x4 win[H2_WSLOTS];
+    f32x4 nq_a = {1.0f, 1.0f, 1.0f, 1.0f}, nq_b = {0.0f, 0.0f, 0.0f, 0.0f}, nq_s = nq_a;      // records of the quad being converted
 
     // ---- the pieces of a step's staging work; each is branch-free so that it can be interleaved with the step's MFMAs ----
     // loads of the step after next (the registers were consumed by MH_H2_CONV / MH_H2_WST earlier in this step)
 #define MH_H2_LDX                                                                                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-        const char* xq_ = reinterpret_cast<const char*>(xptr + (long long)i * DHW);                   \
-        _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j) xin[j][i] = *reinterpret_cast<const float*>(xq_ + soff[j]); \
+    {       /* raw buffer loads: descriptor on the step's first channel plane (scalar registers), lane offset soff, channel offset as the scalar offset -- no vector address arithmetic */ \
+        const auto xr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xptr), 0, 0x7fffffff, 0x00020000); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j)                                      \
+                xin[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr_, soff[j], (unsigned)(i * DHW * 4), 0)); \
     }
     // (PRO_: the prologue, where resident slabs are loaded too -- inside the loop the condition is a compile-time one: no branch in the step)
 #define MH_H2_LDWX(PRO_, J0, J1)                                                                      \
@@ -205,16 +208,18 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         is = adv_ ? (wrap_ ? 0 : is + 1) : is;                                                        \
     }
     // normalise + activate + split slot J on the way into LDS: 4 channels of a voxel -> 8 bytes of the high plane, 8 of the low one
+#define MH_H2_NRMLD                                                                                   \
+    if (NRM) {      /* the quad's records: alpha, beta in LDS are pre-multiplied by 2^e_in: act(x, alpha p, beta p, slope) == p act(x, alpha, beta, slope) */ \
+        const f32x4* a_ = reinterpret_cast<const f32x4*>(nrm_s + 12 * (4 * cs + q));                  \
+        nq_a = a_[0]; nq_b = a_[1]; nq_s = a_[2];                                                     \
+    }
 #define MH_H2_CONV(J)                                                                                 \
     {                                                                                                 \
         u32x2* xh_ = reinterpret_cast<u32x2*>(xs + (bcur ^ 1) * H2_XB);                               \
         _Float16 h_[4], l_[4];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
             float y_ = xin[J][i];                                                                     \
-            if (NRM) {      /* alpha, beta in LDS are pre-multiplied by 2^e_in: act(x, alpha p, beta p, slope) == p act(x, alpha, beta, slope) */ \
-                const float* a_ = nrm_s + 3 * (H2_KC * cs + 4 * q + i);                               \
-                y_ = act(y_, a_[0], a_[1], a_[2]);                                                    \
-            }                                                                                         \
+            if (NRM) y_ = act(y_, nq_a[i], nq_b[i], nq_s[i]);                                         \
             h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \
         const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
@@ -282,9 +287,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         constexpr int aoff_ = ((T_) / 3) * G::RS + (T_) % 3;                                          \
         const uint4* xb_ = xs + bcur * H2_XB + abase + aoff_;                                         \
         const uint4* wb_ = ws + bcur * H2_WB + (T_) * (2 * H2_CN) + bbase;                            \
-        ah[OB] = xb_[0]; al[OB] = MH_H2X_AL(xb_[H2_XV], ah[OB]);                                      \
+        ah[OB] = xb_[0]; al[OB] = xb_[H2_XV];                                      \
+        MH_H2X_EXTRA_READS(wb_)                                                                       \
         _Pragma("unroll") for (int kz = 0; kz < 3; ++kz) {                                            \
-            bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = MH_H2X_BL(wb_[H2_WV + kz * (9 * 2 * H2_CN)], bh[OB][kz]); \
+            bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)]; \
         }                                                                                             \
     }
 #define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
@@ -361,12 +367,12 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_NONE
     // a plain step, and the first step of a plane (the previous plane's epilogue pieces in taps 3, 4, 6, 7 with more vector slots per gap)
 #define MH_H2_SCHEDULE_PLAIN                                                                          \
-        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
+        MH_H2_TAP(0, MH_H2_NRMLD MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2)) \
         MH_H2_TAP(3, MH_H2_NONE)                                                                      \
         MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
         MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)
 #define MH_H2_SCHEDULE_EMIT                                                                           \
-        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
+        MH_H2_TAP(0, MH_H2_NRMLD MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2)) \
         MH_H2_TAPV(3, 8, MH_H2_EMIT_A)                                                                \
         MH_H2_TAPV(4, 8, MH_H2_LDX MH_H2_EMIT_B1) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAPV(6, 8, MH_H2_LDW(0, 4) MH_H2_EMIT_B2) \
         MH_H2_TAPV(7, 8, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV MH_H2_EMIT_B3) MH_H2_TAP(8, MH_H2_NONE)
@@ -383,7 +389,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     int bcur = 1, gi = -2;
     MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     gi = -1;
-    MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WSTX(true)
+    MH_H2_NRMLD MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WSTX(true)
     MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     if (RES) {        // the second slab (chunk 1, or chunk 0 again when there is one chunk) goes into buffer 1 now and stays
         _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[H2_WB + tid + 512 * j] = win[j];
@@ -430,6 +436,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #undef MH_H2_WST
 #undef MH_H2_WSTX
 #undef MH_H2_CONV
+#undef MH_H2_NRMLD
 #undef MH_H2_ADV
 #undef MH_H2_LDW
 #undef MH_H2_LDWX

@@ -333,4 +333,131 @@ __global__ void __launch_bounds__(64 * gv_waves(RK)) gauss3d_rowvec_kernel(const
 #undef GV_LOAD
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Up to 9 taps per axis, round 3: the row-vector kernel with the two things removed that its instruction stream showed beside the arithmetic
+// (per plane and wave 110 vector instructions, of which 54 are the taps' v_pk_fma_f32):
+//   * x-pass neighbours by DPP instead of LDS: a lane needs the float4 of the lanes to its left and right (halo of at most 4 floats); two
+//     `v_mov_b32 wave_shr:1 / wave_shl:1` per float take them from the neighbouring lanes' REGISTERS -- no wave-private LDS row, no LDS round trip and
+//     no wave barriers in front of the taps.  Lanes 0 and 63 keep the `edge` operand: the halo vector they loaded from the neighbouring tile;
+//   * z-pass by forward accumulation instead of a register ring: a y-filtered row of source plane z is added, with tap k, to the accumulator of
+//     output plane z + HR - k; the accumulator that received its last tap is stored.  The march is unrolled RK planes deep, so that "which accumulator"
+//     is a compile-time index: the 28 register moves per plane that shifted the ring are gone.  An output's taps still arrive in ascending order, each
+//     as one fused multiply-add starting from zero: bit-identical to the ring form (and to gauss3d_stream_kernel).
+// Measured on the MI355X (profiles/r03_gauss_ab.json, 4 x 512^3, bit-identical outputs): 9 taps 0.223-0.226 ms per volume against 0.225-0.237 for
+// gauss3d_rowvec_kernel, 5 taps 0.200 = 0.200.  Also measured and not kept: the forward accumulation with the LDS x-pass (30 % fewer vector instructions
+// than this form, 0.250 ms: slower) and 8-row tiles with 8 waves (two to three workgroups per CU, 1.33 x the halo rows: 0.246 ms) -- neither the
+// instruction count nor the occupancy is what holds this kernel at 0.57-0.60 of 8 TB/s; a 16-byte copy on the same boxes reaches 0.77.
+template <int RK, bool ISO>
+__global__ void __launch_bounds__(1024) gauss3d_rowdpp_kernel(const float* __restrict__ src, float* __restrict__ dst, GaussArgs a) {
+    constexpr int WAVES = 16, TY = WAVES;
+    constexpr int HR = (RK - 1) / 2;
+    static_assert(HR >= 1 && HR <= 4, "one halo vector per side");
+    constexpr int NR = TY + 2 * HR;                          // rows of the tile's halo plane
+    constexpr int XR = (NR + WAVES - 1) / WAVES;             // rows a wave x-filters per plane
+    constexpr int OFF = 4 - HR;                              // first tap of output 0 inside the window of 12 floats (left | own | right vector)
+    __shared__ __attribute__((aligned(16))) float mid[2][NR * GV_TX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* wkx = a.kx;
+    const float* wky = ISO ? a.kx : a.ky;
+    const float* wkz = ISO ? a.kx : a.kz;
+    const int tiles_x = (a.W + GV_TX - 1) / GV_TX, tiles = tiles_x * ((a.H + TY - 1) / TY);
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(lid % (unsigned)tiles);
+    lid /= (unsigned)tiles;
+    const int chunk = (int)(lid % (unsigned)a.nchunk), nc = (int)(lid / (unsigned)a.nchunk);
+    const int tx0 = (tile % tiles_x) * GV_TX, ty0 = (tile / tiles_x) * TY;
+    const int zs = chunk * a.zchunk, ze = min(zs + a.zchunk, a.D);
+    const int zfirst = max(zs - HR, 0), zlast = min(ze + HR, a.D);
+    const long long plane = (long long)a.H * a.W;
+    const float* vol = src + (long long)nc * a.D * plane;
+    float* ovol = dst + (long long)nc * a.D * plane;
+
+    // Loads go through a raw buffer over this channel volume (the launcher keeps it below 2 GB): byte offsets of this lane inside a plane -- its own
+    // vector of each of its x-pass rows and, lanes 0 / 63, the halo vector left / right of the wave's 256-float segment -- or an offset beyond the
+    // buffer, which reads zeros: zero padding without a branch or a select.  The plane offset rides in the instruction's scalar offset.
+    const auto vrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(vol), 0, (int)((long long)a.D * plane * 4), 0x00020000);
+    constexpr unsigned GD_ZERO = 0x80000000u;
+    const int gx = tx0 + 4 * lane;
+    unsigned coff[XR], eoff[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int r = wave + WAVES * i, gy = ty0 + r - HR;
+        const bool rok = r < NR && gy >= 0 && gy < a.H;
+        coff[i] = rok && gx < a.W ? 4u * (unsigned)(gy * a.W + gx) : GD_ZERO;
+        const int hx = lane == 0 ? tx0 - 4 : tx0 + GV_TX;
+        eoff[i] = rok && (lane == 0 || lane == GV_LANES - 1) && hx >= 0 && hx < a.W ? 4u * (unsigned)(gy * a.W + hx) : GD_ZERO;
+    }
+    f32x4 cur[XR], ext[XR];
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    unsigned loff = (unsigned)((long long)zfirst * plane * 4);      // byte offset of the next source plane to load
+    float* optr = ovol + (long long)(ty0 + wave) * a.W + gx + ((long long)zfirst - HR) * plane;      // output plane z - HR of the current step
+#define GD_LOAD                                                                                       \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                              \
+            cur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, coff[i], loff, 0)); \
+            ext[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, eoff[i], loff, 0)); \
+        }                                                                                             \
+        loff += (unsigned)(plane * 4);                                                                \
+    }
+    f32x4 acc[RK];
+#pragma unroll
+    for (int k = 0; k < RK; ++k) acc[k] = zero4;
+    const bool rowok = ty0 + wave < a.H && gx < a.W;
+    int buf = 0;
+
+    // x- and y-pass of source plane Z -> this wave's y-filtered row vector V; prefetches plane Z + 1
+#define GD_PLANE(Z, V)                                                                                \
+    {                                                                                                 \
+        float* mb_ = mid[buf];                                                                        \
+        _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                              \
+            const int r_ = wave + WAVES * i;                                                          \
+            if (r_ < NR) {                                                                            \
+                float w_[12];                                                                         \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                       \
+                    w_[e] = lane_left(ext[i][e], cur[i][e]);                                          \
+                    w_[4 + e] = cur[i][e];                                                            \
+                    w_[8 + e] = lane_right(ext[i][e], cur[i][e]);                                     \
+                }                                                                                     \
+                float o_[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                               \
+                _Pragma("unroll") for (int k = 0; k < RK; ++k)                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) o_[e] = fmaf(wkx[k], w_[OFF + e + k], o_[e]); \
+                *reinterpret_cast<f32x4*>(mb_ + r_ * GV_TX + 4 * lane) = f32x4{o_[0], o_[1], o_[2], o_[3]}; \
+            }                                                                                         \
+        }                                                                                             \
+        if ((Z) + 1 < zlast) GD_LOAD                                                                  \
+        __syncthreads();                                                                              \
+        V = zero4;                                                                                    \
+        _Pragma("unroll") for (int j = 0; j < RK; ++j) {                                              \
+            const f32x4 m_ = *reinterpret_cast<const f32x4*>(mb_ + (wave + j) * GV_TX + 4 * lane);    \
+            V = __builtin_elementwise_fma(f32x4{wky[j], wky[j], wky[j], wky[j]}, m_, V);              \
+        }                                                                                             \
+        buf ^= 1;                                                                                     \
+    }
+
+    GD_LOAD
+    // step s of a group of RK planes: slot of output plane zo = (zo - zfirst) mod RK, a compile-time number inside the unrolled group
+    for (int zb = zfirst; zb < ze + HR; zb += RK) {
+#pragma unroll
+        for (int s = 0; s < RK; ++s) {
+            const int z = zb + s;
+            if (z < ze + HR) {                                  // (no `break`: the group must unroll completely for the slots to be registers)
+                f32x4 v_ = zero4;                               // beyond the volume: zero padding
+                if (z < zlast) GD_PLANE(z, v_)
+#pragma unroll
+                for (int k = 0; k < RK; ++k) {
+                    const int slot = (s + HR - k + RK) % RK;    // output plane z + HR - k
+                    const f32x4 wk_ = {wkz[k], wkz[k], wkz[k], wkz[k]};
+                    acc[slot] = __builtin_elementwise_fma(wk_, v_, k == 0 ? zero4 : acc[slot]);
+                }
+                const int done = (s - HR + RK) % RK;            // output plane z - HR has all its taps
+                if (z - HR >= zs && rowok) MH_STREAM_STORE4(optr, acc[done]);
+                optr += plane;
+            }
+        }
+    }
+#undef GD_PLANE
+#undef GD_LOAD
+}
+
 }  // namespace mh

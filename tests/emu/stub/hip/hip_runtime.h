@@ -278,6 +278,15 @@ inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int)
     wave_sync();
     return d;
 }
+// DPP wave shifts by one lane (the only controls the product uses): lane l reads lane l-1 (0x138 wave_shr:1) or l+1 (0x130 wave_shl:1); the lane without
+// a source keeps `old` (bound_ctrl = 0)
+inline int update_dpp(int old, int src, int ctrl, int, int, bool) {
+    const int lane = ctx().cur->lane;
+    if (ctrl == 0x138) { const int v = wave_read(src, (lane + 63) & 63); return lane == 0 ? old : v; }
+    if (ctrl == 0x130) { const int v = wave_read(src, (lane + 1) & 63); return lane == 63 ? old : v; }
+    std::fprintf(stderr, "emu: unsupported dpp control 0x%x\n", ctrl);
+    std::abort();
+}
 // raw buffer stores: a {base, num_records} descriptor; a store whose 32-bit offset (+ size) leaves [0, num_records) is dropped, as the hardware does
 struct BufRsrc { char* base; unsigned num_records; };
 template <class P> inline BufRsrc make_buffer_rsrc(P* p, short, int num_records, int) { return BufRsrc{reinterpret_cast<char*>(p), (unsigned)num_records}; }
@@ -285,6 +294,19 @@ template <class V> inline void raw_buffer_store_b128(V data, BufRsrc r, unsigned
     static_assert(sizeof(V) == 16, "b128");
     const unsigned long long off = (unsigned long long)voffset + soffset;
     if (off + 16ull <= r.num_records) std::memcpy(r.base + off, &data, 16);
+}
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+inline u32x4_t raw_buffer_load_b128(BufRsrc r, unsigned voffset, unsigned soffset, int) {      // out of range reads return zeros
+    u32x4_t v = {0u, 0u, 0u, 0u};
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 16ull <= r.num_records) std::memcpy(&v, r.base + off, 16);
+    return v;
+}
+inline unsigned raw_buffer_load_b32(BufRsrc r, unsigned voffset, unsigned soffset, int) {
+    unsigned v = 0u;
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 4ull <= r.num_records) std::memcpy(&v, r.base + off, 4);
+    return v;
 }
 }  // namespace emu
 
@@ -305,8 +327,11 @@ template <class V> inline void raw_buffer_store_b128(V data, BufRsrc r, unsigned
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
+#define __builtin_amdgcn_update_dpp emu::update_dpp
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
+#define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b32 emu::raw_buffer_load_b32
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)

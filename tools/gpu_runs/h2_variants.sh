@@ -2,7 +2,7 @@
 # VARIANTS="<flags>;<flags>;..." overrides the list; writes gpurun_out/h2v/variants.txt
 O=gpurun_out/h2v; mkdir -p $O; : > $O/variants.txt
 build() { hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -Iinclude -Imonai_amd/csrc $1 tools/ubench/h2_variants.hip -o /tmp/h2v 2>/dev/null; }
-IFS=';' read -ra VS <<< "${VARIANTS:-;-DH2V_RES=true;-DH2X_NOBL;-DH2X_NOAL;-DH2X_NOBL -DH2X_NOAL;-DH2V_RES=true -DH2X_NOBL -DH2X_NOAL}"
+IFS=';' read -ra VS <<< "${VARIANTS:-;-DH2V_RES=true;-DH2X_XTRA=1;-DH2X_XTRA=3;-DH2V_RES=true -DH2X_XTRA=3}"
 for v in "${VS[@]}"; do
   for cin in ${CINS:-32 64}; do
     case "$v" in *H2V_RES=true*) [ "$cin" -gt 32 ] && continue;; esac
