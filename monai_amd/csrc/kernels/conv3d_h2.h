@@ -190,8 +190,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_LDX                                                                                     \
     {       /* raw buffer loads: descriptor on the step's first channel plane (scalar registers), lane offset soff, channel offset as the scalar offset -- no vector address arithmetic */ \
         const auto xr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xptr), 0, 0x7fffffff, 0x00020000); \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
-            _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j)                                      \
+        _Pragma("unroll") for (int j = 0; j < H2_SLOTS; ++j)          /* slot-major: the first conversion piece waits for the first four loads only */ \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
                 xin[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr_, soff[j], (unsigned)(i * DHW * 4), 0)); \
     }
     // (PRO_: the prologue, where resident slabs are loaded too -- inside the loop the condition is a compile-time one: no branch in the step)
@@ -209,7 +209,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     }
     // normalise + activate + split slot J on the way into LDS: 4 channels of a voxel -> 8 bytes of the high plane, 8 of the low one
 #define MH_H2_NRMLD                                                                                   \
-    if (NRM) {      /* the quad's records: alpha, beta in LDS are pre-multiplied by 2^e_in: act(x, alpha p, beta p, slope) == p act(x, alpha, beta, slope) */ \
+    if (NRM) {      /* the records of the quad of the NEXT conversion (cs was advanced by MH_H2_WST): alpha, beta in LDS are pre-multiplied by 2^e_in: act(x, alpha p, beta p, slope) == p act(x, alpha, beta, slope) */ \
         const f32x4* a_ = reinterpret_cast<const f32x4*>(nrm_s + 12 * (4 * cs + q));                  \
         nq_a = a_[0]; nq_b = a_[1]; nq_s = a_[2];                                                     \
     }
@@ -367,15 +367,15 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_NONE
     // a plain step, and the first step of a plane (the previous plane's epilogue pieces in taps 3, 4, 6, 7 with more vector slots per gap)
 #define MH_H2_SCHEDULE_PLAIN                                                                          \
-        MH_H2_TAP(0, MH_H2_NRMLD MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2)) \
+        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
         MH_H2_TAP(3, MH_H2_NONE)                                                                      \
         MH_H2_TAP(4, MH_H2_LDX) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAP(6, MH_H2_LDW(0, 4))                 \
-        MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NONE)
+        MH_H2_TAP(7, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV) MH_H2_TAP(8, MH_H2_NRMLD)
 #define MH_H2_SCHEDULE_EMIT                                                                           \
-        MH_H2_TAP(0, MH_H2_NRMLD MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2)) \
+        MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
         MH_H2_TAPV(3, 8, MH_H2_EMIT_A)                                                                \
         MH_H2_TAPV(4, 8, MH_H2_LDX MH_H2_EMIT_B1) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAPV(6, 8, MH_H2_LDW(0, 4) MH_H2_EMIT_B2) \
-        MH_H2_TAPV(7, 8, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV MH_H2_EMIT_B3) MH_H2_TAP(8, MH_H2_NONE)
+        MH_H2_TAPV(7, 8, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV MH_H2_EMIT_B3) MH_H2_TAP(8, MH_H2_NRMLD)
     // one step (16 channels of input plane p): conversion of the next step's registers into the other LDS buffer first, then the
     // epilogue stores, then the loads of the step after next
 #define MH_H2_STEP(SCHED_)                                                                            \
@@ -390,6 +390,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     gi = -1;
     MH_H2_NRMLD MH_H2_CONV(0) MH_H2_CONV(1) MH_H2_CONV(2) MH_H2_WSTX(true)
+    MH_H2_NRMLD                       // the records of the quad the first step converts (every step reads the next step's in its last tap: no LDS round trip in front of the conversion)
     MH_H2_LDX MH_H2_LDWX(true, 0, H2_WSLOTS) MH_H2_ADV
     if (RES) {        // the second slab (chunk 1, or chunk 0 again when there is one chunk) goes into buffer 1 now and stays
         _Pragma("unroll") for (int j = 0; j < H2_WSLOTS; ++j) reinterpret_cast<u32x4*>(ws)[H2_WB + tid + 512 * j] = win[j];
