@@ -264,7 +264,7 @@ def extra_config3(args, vol, sync, dev):
     att = spans.get("attention")
     if att:
         tf = att["work"] / (att["ms_total"] * 1e-3) / 1e12
-        res["attention"] = {"kernel": "attention_kernel (softmax(QK^T/sqrt(d))V per head on the matrix cores, S = 216, 12 heads x 64)", "ms_per_step": att["ms_total"] / 2,
+        res["attention"] = {"kernel": "attention_h2_kernel<64> (softmax(QK^T/sqrt(d))V per head on the fp16 matrix cores in split precision, streamed keys / values, online softmax; S = 216, 12 heads x 64; rate = fp32-equivalent flops vs the fp32-MFMA peak)", "ms_per_step": att["ms_total"] / 2,
                             "tflops": tf, "bound": "mfma", "peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS, "share_of_step": att["ms_total"] / 2 / ms}
     lin = spans.get("linear")
     if lin:

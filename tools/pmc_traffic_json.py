@@ -16,11 +16,11 @@ BLEND = 1000 * 5 * 96 ** 3 * 4.0 + 5 * VOL          # every window's logits once
 ALGORITHMIC = {                                     # key (substring of the kernel name) -> algorithmic bytes per launch
     "affine_resample_kernel<double": VOL + RES_OUT, "affine_resample_kernel<float": VOL + RES_OUT,
     "separable_resample_stream_kernel<double": VOL + RES_OUT, "separable_resample_stream_kernel<float": VOL + RES_OUT,
-    "gauss3d_stream_kernel": 2 * VOL, "gauss3d_rowvec_kernel": 2 * VOL,
+    "gauss3d_stream_kernel": 2 * VOL, "gauss3d_rowvec_kernel": 2 * VOL, "gauss3d_rowdpp_kernel": 2 * VOL,
     "conv3d_k3_mfma_kernel": CONV, "conv3d_k3_wino2d_kernel": CONV, "conv3d_k3_wino2p_kernel": CONV, "conv3d_k3_wino2s_kernel": CONV, "conv3d_k3_h2_kernel": CONV,
     "sw_blend_kernel": BLEND, "sw_blend_reg_kernel": BLEND, "sw_blend_mosaic_kernel": BLEND,
 }
-WIDE_READS = ("sw_blend_kernel", "sw_blend_reg_kernel", "sw_blend_mosaic_kernel", "gauss3d_rowvec_kernel")
+WIDE_READS = ("sw_blend_kernel", "sw_blend_reg_kernel", "sw_blend_mosaic_kernel", "gauss3d_rowvec_kernel", "gauss3d_rowdpp_kernel")
 
 
 def table(path, counter):
