@@ -104,6 +104,12 @@ def test_conv_mfma_separate_stats_and_select(emu):
         assert 1 <= ops.conv3d_k3_select(*a, bounded=False, algo=H2) < wino2d
     assert ops.conv3d_k3_select(256, 128, 12, 12, 12, bounded=True, algo=AUTO) == h2 and not ops.conv3d_k3_accepts(h2, 272, 32)
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=AUTO) == 13      # W % 4 != 0
+    # the split-precision kernel addresses its 32 output planes with 31-bit byte offsets: beyond D*H*W = 2^24 voxels the selector returns the fp32 kernels
+    assert ops.conv3d_k3_select(32, 32, 255, 256, 256, bounded=True, algo=AUTO) == h2
+    assert 1 <= ops.conv3d_k3_select(32, 32, 256, 256, 256, bounded=True, algo=AUTO) <= wino2d
+    assert 1 <= ops.conv3d_k3_select(32, 32, 64, 512, 512, bounded=True, algo=H2) <= wino2d
+    # region shapes of the split-precision kernel (16 x 16 | 8 x 32, whichever covers the plane with fewer): the statistics record count follows
+    assert ops.conv3d_k3_stat_tiles(h2, 24, 24, 24) == 3 * 2 and ops.conv3d_k3_stat_tiles(h2, 96, 96, 96) == 36 and ops.conv3d_k3_stat_tiles(h2, 48, 48, 48) == 9 * 2
     assert 1 <= ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True, algo=DIRECT) < wino2d
     assert ops.conv3d_k3_select(32, 32, 24, 24, 24, bounded=True, algo=WINO2D) == wino2d
     with pytest.raises(RuntimeError):
