@@ -141,7 +141,9 @@ int mh_conv3d_k3_num_configs(void);                    /* highest configuration 
 /* Configuration outside 0 .. num_configs(): z-streaming direct convolution on the fp16 matrix cores in two-piece split
  * precision (kernels/conv3d_h2.h) -- every fp32 operand as hi + lo fp16 pieces, products hi*hi + lo*hi + hi*lo accumulated in
  * fp32: fp32-equivalent results (oracle BasicUNet: max |logit difference| 4e-6, the level of two fp32 summation orders) at 3/16
- * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cout % 32 == 0, W % 4 == 0.  The activated input of sample n is scaled by the
+ * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cin <= 256, Cout % 32 == 0, W % 4 == 0 and D * H * W < 2^24 voxels (the result stores address the
+ * 32 output planes of a workgroup through one raw buffer with 31-bit byte offsets; mh_conv3d_k3_select does not return the configuration beyond,
+ * mh_conv3d_k3_f32 answers MH_ERR_UNSUPPORTED).  The activated input of sample n is scaled by the
  * power of two that puts the largest `bound` of its records just below 2^15 (undone exactly in the epilogue), so any finite
  * magnitude is in range; a record without a bound, or with a non-finite one, makes that sample's output NaN (what the reference
  * computes behind a normalisation whose statistics are non-finite, and a loud failure for a caller that broke the contract).
