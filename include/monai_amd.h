@@ -236,6 +236,10 @@ int64_t mh_linear_packed_floats(int N, int K);
 int mh_linear_pack_f32(const float* w, int N, int K, float* packed, void* stream);
 int mh_linear_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
                   void* stream);
+/* The same map with the workgroup tile as an argument: 0 = mh_linear_f32's choice (by how many tiles the problem has), 64 = 128 rows x 64 columns (4 waves),
+ * 128 = 128 x 128 (8 waves: 2/3 of the L2 traffic per flop, for the token counts of the ViT blocks).  Both tiles give the same bits. */
+int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                       int tile, void* stream);
 
 /* nn.LayerNorm over the last dimension (TransformerBlock.norm1 / norm2, ViT.norm, SwinTransformerBlock.norm1 / norm2, PatchMerging.norm):
  * y = (x - mean) * rsqrt(var + eps) * gamma + beta per row, biased variance.  K <= 4096; gamma / beta may be null. */

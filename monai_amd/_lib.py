@@ -97,6 +97,7 @@ SIGNATURES = {
     "mh_linear_packed_floats": (_L, [_I, _I]),
     "mh_linear_pack_f32": (_I, [_P, _I, _I, _P, _P]),
     "mh_linear_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "mh_linear_tile_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "mh_layernorm_f32": (_I, [_P, _P, _P, _F, _P, _L, _I, _P]),
     "mh_affine_resample_workspace_bytes": (_L, [_I, _I, _I]),
     "mh_affine_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _I, _P, _P]),

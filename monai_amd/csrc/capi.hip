@@ -1367,16 +1367,36 @@ int mh_linear_pack_f32(const float* w, int N, int K, float* packed, void* stream
 
 int mh_linear_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
                   void* stream) {
+    return mh_linear_tile_f32(x, packed_w, bias, residual, y, M, N, K, act, 0, stream);
+}
+
+int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                       int tile, void* stream) {
     if (!x || !packed_w || !y || M < 1 || N < 1 || K < 1) return fail(MH_ERR_ARG, "linear: bad argument");
+    if (tile != 0 && tile != 64 && tile != 128) return fail(MH_ERR_ARG, "linear: tile must be 0, 64 or 128 (got %d)", tile);
     if (K % 4 || !aligned(x, 16) || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "linear: K %% 4 == 0 and 16-byte aligned x / packed weights required (K = %d)", K);
     if (act < 0 || act > 1) return fail(MH_ERR_UNSUPPORTED, "linear: activation %d is not built (0 none, 1 GELU)", act);
     const int ntn = cdiv(N, DN_BN);
     const long long total = (long long)cdiv((int)((M + DN_BM - 1) / DN_BM), 1) * ntn;
     if (M > 0x7fffffffLL || total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "linear: problem too large for one launch");
-    const dim3 grid((unsigned)total);
     const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
     const float* tail = packed_w + (mh_linear_packed_floats(N, K) - H2_TAIL);
     hipStream_t s = (hipStream_t)stream;
+    // many tokens (the ViT blocks of UNETR: M = 216 x windows): 8-wave workgroups with a 128 x 128 tile -- 2/3 of the L2 traffic per flop (kernels/dense.h) -- when
+    // they still fill the chip twice over (tile == 0); measured 1.2-1.5 x the 128 x 64 kernel at M = 13 824 (profiles/r03_linear_bench.json; 256 x 128: slower, removed)
+    const int ntn2 = cdiv(N, 2 * DN_BN);
+    const long long big1 = (long long)((M + DN_BM - 1) / DN_BM) * ntn2;
+    if (tile == 128 || (tile == 0 && big1 >= 512)) {
+        const dim3 bgrid((unsigned)big1);
+#define MH_LINEAR_BIG(A_, R_) hipLaunchKernelGGL((linear_h2_big_kernel<A_, R_, 1>), bgrid, dim3(512), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn2, ntn)
+        if (act == 1 && residual) MH_LINEAR_BIG(1, true);
+        else if (act == 1) MH_LINEAR_BIG(1, false);
+        else if (residual) MH_LINEAR_BIG(0, true);
+        else MH_LINEAR_BIG(0, false);
+#undef MH_LINEAR_BIG
+        return launched("linear");
+    }
+    const dim3 grid((unsigned)total);
 #define MH_LINEAR_LAUNCH(A_, R_) hipLaunchKernelGGL((linear_h2_kernel<A_, R_>), grid, dim3(256), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn)
     if (act == 1 && residual) MH_LINEAR_LAUNCH(1, true);
     else if (act == 1) MH_LINEAR_LAUNCH(1, false);

@@ -111,6 +111,115 @@ linear_h2_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, cons
     }
 }
 
+// The same map with a larger workgroup tile for the large token counts of the ViT blocks (round 3).  At 128 x 64 the kernel is bound by what it pulls out of
+// L2, not by the matrix pipe: every 64-column tile re-reads its 128 rows of X, every row tile the whole weight matrix -- 12 KB per chunk and 24 matrix
+// instructions, ~7.6 TB/s of L2 -> CU traffic for the qkv map of UNETR (M = 13 824 tokens) in 64-byte pieces.  Here a workgroup of 8 waves owns
+// (128 MT) x 128: wave w = rows 32 MT (w >> 1) .. x columns 64 (w & 1) .., MT x 2 accumulator tiles; per chunk 16 KB (MT = 1) feed 48 matrix instructions:
+// 2/3 of the bytes per flop.  Same packed weights (two neighbouring 64-column slabs), same staging, same arithmetic and summation order per output: bit-identical
+// results.  Measured at M = 13 824 (profiles/r03_linear_bench.json): MT = 1 is 1.2-1.5 x the 128 x 64 kernel (qkv 0.288 -> 0.197 ms); MT = 2 (256 x 128, half the
+// bytes per flop but 118 registers and 48 KB of LDS: two workgroups per CU) is slower than MT = 1 (0.219 ms) and is not instantiated.
+template <int ACT, bool RES, int MT>
+__global__ void __launch_bounds__(512)
+linear_h2_big_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias,
+                     const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn, int nslab) {
+    constexpr int BM = DN_BM * MT, BN = 2 * DN_BN;
+    constexpr int AV = 2 * BM;                               // uint4 per piece of an A tile: [k-group][row]
+    __shared__ uint4 as[2][2 * AV];
+    __shared__ uint4 bs[2][2 * DN_BT];                       // two 64-column slabs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = (int)(lid % (unsigned)ntn), tm = (int)(lid / (unsigned)ntn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nkc = (K + DN_BK - 1) / DN_BK;
+
+    // A staging: thread (row = tid >> 1, k-group = tid & 1) converts 8 consecutive k of its row (MT = 1: the first 256 threads); B: one uint4 of the two slabs per thread
+    const int srow = tid >> 1, skg = tid & 1;
+    const bool stage_a = srow < BM;
+    const bool rok = stage_a && m0 + srow < M;
+    const float* xrow = x + (long long)(rok ? m0 + srow : 0) * K + 8 * skg;
+    const int slab = 2 * tn + (tid >> 8);
+    const bool sok = slab < nslab;
+    const uint4* wsl = wp + (long long)(sok ? slab : 0) * nkc * DN_BT + (tid & 255);
+    f32x4 xa, xb;
+    uint4 wv;
+#define MH_DB_ISSUE(C)                                                                                \
+    {                                                                                                 \
+        const int k_ = (C) * DN_BK + 8 * skg;                                                         \
+        xa = (rok && k_ + 4 <= K) ? *reinterpret_cast<const f32x4*>(xrow + (C) * DN_BK) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};     \
+        xb = (rok && k_ + 8 <= K) ? *reinterpret_cast<const f32x4*>(xrow + (C) * DN_BK + 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; \
+        wv = sok ? wsl[(long long)(C) * DN_BT] : make_uint4(0u, 0u, 0u, 0u);                          \
+    }
+#define MH_DB_COMMIT(BUF)                                                                             \
+    {                                                                                                 \
+        if (stage_a) {                                                                                \
+            _Float16 h_[8], l_[8];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) { h2_split(xa[i], h_[i], l_[i]); h2_split(xb[i], h_[4 + i], l_[4 + i]); } \
+            f16x8 hv_, lv_;                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) { hv_[i] = h_[i]; lv_[i] = l_[i]; }         \
+            as[BUF][skg * BM + srow] = __builtin_bit_cast(uint4, hv_);                                \
+            as[BUF][AV + skg * BM + srow] = __builtin_bit_cast(uint4, lv_);                           \
+        }                                                                                             \
+        bs[BUF][tid] = wv;                                                                            \
+    }
+
+    const int r32 = lane & 31, kg = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int abase = kg * BM + 32 * MT * wr + r32;
+    const int bbase = wc * DN_BT + kg * DN_BN + r32;
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nb][i] = 0.0f;
+
+    MH_DB_ISSUE(0)
+    MH_DB_COMMIT(0)
+    __syncthreads();
+    for (int c = 0; c < nkc; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nkc) MH_DB_ISSUE(c + 1)
+        uint4 ah[MT], al[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) { ah[mt] = as[buf][abase + 32 * mt]; al[mt] = as[buf][AV + abase + 32 * mt]; }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint4 bh = bs[buf][bbase + 32 * nb], bl = bs[buf][DN_BV + bbase + 32 * nb];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh), acc[mt][nb], 0, 0, 0);
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[mt]), __builtin_bit_cast(f16x8, bh), acc[mt][nb], 0, 0, 0);
+                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bl), acc[mt][nb], 0, 0, 0);
+            }
+        }
+        if (c + 1 < nkc) MH_DB_COMMIT(buf ^ 1)
+        __syncthreads();
+    }
+#undef MH_DB_COMMIT
+#undef MH_DB_ISSUE
+
+    const float inv_scale = wtail[0];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int n = n0 + 64 * wc + 32 * nb + r32;
+        const float bn = (bias && n < N) ? bias[n] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m0 + 32 * MT * wr + 32 * mt + 8 * (i >> 2) + 4 * kg + (i & 3);
+                if (m < M && n < N) {
+                    float v = fmaf(acc[mt][nb][i], inv_scale, bn);
+                    if (ACT == 1) v = gelu_erf(v);
+                    if (RES) v += r[(long long)m * N + n];
+                    y[(long long)m * N + n] = v;
+                }
+            }
+    }
+}
+
 // w [N][K] -> [column tile][chunk][piece][k-group][64 columns][8 k] fp16, zero padded in N and K; tail = {1 / scale, scale} (the scale
 // kernel of conv3d_h2.h).  One thread per (n, k) of the padded matrix.
 __global__ void __launch_bounds__(256)

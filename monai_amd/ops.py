@@ -496,9 +496,10 @@ def linear_pack(weight: torch.Tensor) -> torch.Tensor:
 
 
 def linear(x: torch.Tensor, packed_w: torch.Tensor, n_out: int, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           gelu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+           gelu: bool = False, out: Optional[torch.Tensor] = None, tile: int = 0) -> torch.Tensor:
     """y[..., N] = act(x[..., K] . W^T + bias) (+ residual) -- nn.Linear (+ nn.GELU()) (+ the residual sum of a transformer block) in one
-    launch on the fp16 matrix cores in two-piece split precision (fp32-equivalent).  `packed_w` = linear_pack(W)."""
+    launch on the fp16 matrix cores in two-piece split precision (fp32-equivalent).  `packed_w` = linear_pack(W).  `tile`: workgroup tile
+    (0 = chosen by the problem size; 64 / 128 force 128 x 64 / 128 x 128 -- the same bits, the tests run both)."""
     _lib.require_device(x, packed_w, bias, residual, out)
     if not x.is_contiguous():
         x = x.contiguous()
@@ -513,7 +514,8 @@ def linear(x: torch.Tensor, packed_w: torch.Tensor, n_out: int, bias: Optional[t
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != shape or not out.is_contiguous():
         raise RuntimeError(f"monai_amd.linear: out must be contiguous {shape}")
-    _lib.lib().call("mh_linear_f32", _lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out), m, int(n_out), k, 1 if gelu else 0, _s(x))
+    _lib.lib().call("mh_linear_tile_f32", _lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out), m, int(n_out), k, 1 if gelu else 0,
+                    int(tile), _s(x))
     return out
 
 

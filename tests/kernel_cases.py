@@ -476,6 +476,10 @@ def case_linear(device, m, n, k, gelu=False, residual=False, bias=True, tol=2e-5
     got = ops.linear(x.to(device), packed, n, None if b is None else b.to(device), None if r is None else r.to(device), gelu=gelu).cpu().double()
     err = (got - exp).abs().max().item()
     assert err < tol * max(1.0, exp.abs().max().item()), f"linear {m}x{k} -> {n} gelu={gelu} res={residual}: max err {err}"
+    # the workgroup tiles (128 x 64 | 128 x 128: the large one is chosen for the token counts of the ViT blocks) give the same bits
+    for tile in (64, 128):
+        gt = ops.linear(x.to(device), packed, n, None if b is None else b.to(device), None if r is None else r.to(device), gelu=gelu, tile=tile).cpu().double()
+        assert torch.equal(gt, got), f"linear tile {tile}: {float((gt - got).abs().max())}"
     # leading dimensions are flattened
     got3 = ops.linear(x.reshape(2, m // 2, k).to(device), packed, n, None if b is None else b.to(device), gelu=gelu)
     assert got3.shape == (2, m // 2, n)
