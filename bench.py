@@ -268,7 +268,7 @@ def extra_config3(args, vol, sync, dev):
                             "tflops": tf, "bound": "mfma", "peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS, "share_of_step": att["ms_total"] / 2 / ms}
     lin = spans.get("linear")
     if lin:
-        res["linear"] = {"kernel": "linear_h2_kernel (nn.Linear + bias / GELU / residual, fp16 split precision)", "ms_per_step": lin["ms_total"] / 2,
+        res["linear"] = {"kernel": "linear_h2_big_kernel / linear_h2_kernel (nn.Linear + bias / GELU / residual on the fp16 matrix cores in split precision; 128 x 128 workgroup tiles at this token count)", "ms_per_step": lin["ms_total"] / 2,
                          "fp32_equivalent_tflops": lin["work"] / (lin["ms_total"] * 1e-3) / 1e12}
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     x = vol[:, :, : args.roi, : args.roi, : args.roi].contiguous()
