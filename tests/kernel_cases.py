@@ -11,6 +11,7 @@ from __future__ import annotations
 import itertools
 
 import numpy as np
+import pytest
 import torch
 import torch.nn.functional as F
 
@@ -480,6 +481,8 @@ def case_linear(device, m, n, k, gelu=False, residual=False, bias=True, tol=2e-5
     for tile in (64, 128):
         gt = ops.linear(x.to(device), packed, n, None if b is None else b.to(device), None if r is None else r.to(device), gelu=gelu, tile=tile).cpu().double()
         assert torch.equal(gt, got), f"linear tile {tile}: {float((gt - got).abs().max())}"
+    with pytest.raises(RuntimeError):       # an unknown tile is an argument error, not a silent default
+        ops.linear(x.to(device), packed, n, tile=96)
     # leading dimensions are flattened
     got3 = ops.linear(x.reshape(2, m // 2, k).to(device), packed, n, None if b is None else b.to(device), gelu=gelu)
     assert got3.shape == (2, m // 2, n)
