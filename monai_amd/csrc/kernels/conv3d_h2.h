@@ -36,7 +36,7 @@
 //
 // A step = 16 input channels of one input plane: the plane region [2 pieces][2 k-groups][18 x 20 voxels][8 ch] (23 KB) and the
 // chunk's weight slab [2 pieces][27 taps][2 k-groups][32 couts][8 ch] (55 KB, padded to 57 KB) sit in one of two LDS buffers (157 KB
-// + the {alpha, beta, slope} records); one barrier per step.  With at most two chunks (Cin <= 32, template RES) both slabs are
+// + the {alpha, beta, slope} records, 48 bytes per channel quad); one barrier per step.  With at most two chunks (Cin <= 32, template RES) both slabs are
 // loaded once and stay; otherwise a slab is streamed from L2 every step.
 //
 // Schedule.  A wave issues in order and an fp16 MFMA occupies the matrix pipe for 32 cycles: what is placed BETWEEN two MFMAs
@@ -47,6 +47,11 @@
 // every staging piece is branch-free (zeroed padding cells and dump cells instead of masks, clamped pointer advance instead of
 // tail branches) and is dealt out over the 81 MFMA gaps of the step by sched_group_barrier: 10.7 -> 9.0-9.4 ms for 32 -> 32
 // channels at 96^3 x 64 windows (the fp32 Winograd kernel: 17.5 ms; the matrix pipe alone at the sustained clock: 4.7 ms).
+// Round 3 (profiles/r03_h2_*.txt, r03_pmc_h2.txt): the region is 16 x 16 or 8 x 32 (H2Geo<WIDE>, whichever covers the plane with fewer regions);
+// the epilogue is four branch-free pieces in taps 3, 4, 6, 7 of the next plane's first step (raw buffer stores whose out-of-range lanes the hardware drops);
+// the input records sit in LDS per channel quad and are read in the previous step's last tap; the input planes come in by raw buffer loads (no vector
+// address arithmetic): 138 -> 91 vector instructions per step, 8.2-8.5 ms for the same launch, matrix pipe busy 0.71 of the cycles (0.61) -- and a lower
+// clock in return: the bare instruction sustains 0.67 of its peak rate on random operands (profiles/r03_ubench_mfma_sustained.txt), this kernel 0.43-0.46.
 // Also measured and not kept: 16-byte window loads of the input (fewer vector-memory instructions, 33 % more bytes: slower),
 // loads issued up to 8 groups ahead (same), a second input register set (spills at the 256-register limit of two waves per SIMD).
 // Timing experiments with parts switched off mislead on this chip: constant operands raise the clock (the matrix pipe draws
