@@ -182,8 +182,9 @@ def test_conv3d_wino2d(emu, cin, cout, dims, n):
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
-# (6, 8, 24), (3, 18, 20), (2, 24, 56) take the 8 x 32 region shape (one / three ragged / 3 x 2 regions), the others 16 x 16
-H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1)]
+# (6, 8, 24), (3, 18, 20), (2, 24, 56), (24, 8, 24) take the 8 x 32 region shape (one / three ragged / 3 x 2 regions / one region in two z-chunks), the others 16 x 16
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
+            (32, 32, (24, 8, 24), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
 def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     """z-streaming direct convolution on the fp16 matrix cores, two fp16 pieces per operand and three exact piece products per
