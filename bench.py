@@ -131,7 +131,10 @@ def pmc_traffic(kernel_key: str):
             with open(os.path.join(pdir, name)) as f:
                 k = json.load(f)["kernels"].get(kernel_key)
             if k is not None:
-                return {"measured": "from_file (a builder-run rocprofv3 --pmc pass of an earlier round; counters cannot be collected inside this process)",
+                note = ("from_file (a builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass, see `source`; counters cannot be collected inside this process)")
+                if "conv3d" in kernel_key:       # MI355X_MICROARCH.md calibrates FETCH_SIZE for 16 B/lane readers only
+                    note += "; FETCH_SIZE is uncalibrated for this kernel's 4-byte loads: a ratio below 1 is not evidence of under-fetch"
+                return {"measured": note,
                         "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
                         "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"], "measured_on": k.get("measured_on", "the bench configuration"),
                         "source": "profiles/" + name.replace(".json", ".txt")}
