@@ -62,7 +62,14 @@ class _GridAxis(NamedTuple):
 
 
 def _stride(patch: int, overlap) -> int:
-    # a float overlap is a fraction of the patch, an int one a number of elements (splitter.py:94-113)
+    """Distance of neighbouring patch starts: a float overlap is a fraction of the patch, an int one a number of elements
+    (iter_patch_position, monai/data/utils.py:241-245 -- ``round(p * (1.0 - o))``, NOT the ``round(p - p * o)`` of the padding rule:
+    the two land on opposite sides of a .5 tie for some (patch, overlap) pairs)"""
+    return round(patch * (1.0 - overlap)) if isinstance(overlap, float) else patch - overlap
+
+
+def _pad_modulus(patch: int, overlap) -> int:
+    """The modulus of the tail padding (splitter.py:184-188): ``round(ps - ps * ov)`` / ``round(ps - ov)``"""
     return round(patch - patch * overlap) if isinstance(overlap, float) else round(patch - overlap)
 
 
@@ -132,7 +139,7 @@ class SlidingWindowSplitter(Splitter):
             lead = tail = 0
             if self.pad_mode:
                 lead = max(-off, 0)
-                tail = (off - size + patch) % stride    # smallest extension after which the last patch ends on the (padded) border
+                tail = (off - size + patch) % _pad_modulus(patch, ov)    # smallest extension after which the last patch ends on the (padded) border
             starts = tuple(range(off, size + tail - patch + 1, stride))
             axes.append(_GridAxis(size, patch, stride, lead, tail, starts))
         return tuple(axes)
@@ -173,8 +180,16 @@ class SlidingWindowSplitter(Splitter):
         if n == 0:
             return None
         roi = tuple(a.patch for a in axes)
-        out = torch.empty((n, src.shape[1]) + roi, dtype=torch.float32, device=src.device)
-        return ops.window_extract(src[0].contiguous(), grid, 0, n, roi, out)
+        # the dense buffer is the volume times the overlap factor (8x at overlap 0.5): only while it is a small part of the free HBM -- beyond that the
+        # patches are sliced lazily as views, as the reference does (it keeps `batch_size` patches alive, nothing more)
+        need = 4 * n * src.shape[1] * roi[0] * roi[1] * roi[2]
+        if src.is_cuda and need > torch.cuda.mem_get_info(src.device)[0] // 4:
+            return None
+        try:
+            out = torch.empty((n, src.shape[1]) + roi, dtype=torch.float32, device=src.device)
+            return ops.window_extract(src[0].contiguous(), grid, 0, n, roi, out)
+        except RuntimeError:        # a window grid the gather kernel does not take (e.g. an irregular start list beyond its table): views
+            return None
 
     def _pairs(self, inputs: torch.Tensor) -> Iterator[tuple[torch.Tensor, tuple]]:
         if not isinstance(inputs, torch.Tensor):
@@ -213,9 +228,11 @@ def _join(patches: list) -> torch.Tensor:
     """torch.cat of the patches -- or, when they are consecutive rows of one dense buffer, the slice that already holds them"""
     first = patches[0]
     base = first._base
-    if base is not None and len(patches) > 1 and first.is_contiguous() and all(p._base is base for p in patches):
+    # one image per patch only: the batched view's dim-0 stride is the distance of consecutive patches, which a multi-image patch (dim-0 stride = the
+    # source's batch stride) cannot express -- and `is_contiguous()` ignores the stride of a size-1 dim, so it is written out, never taken from `first`
+    if base is not None and len(patches) > 1 and first.shape[0] == 1 and first.is_contiguous() and all(p._base is base for p in patches):
         step = first.numel()
         o0 = first.storage_offset()
-        if all(p.storage_offset() == o0 + i * step and p.shape == first.shape for i, p in enumerate(patches)):
-            return base.as_strided((len(patches) * first.shape[0],) + tuple(first.shape[1:]), first.stride(), o0)
+        if all(p.storage_offset() == o0 + i * step and p.shape == first.shape and p.stride()[1:] == first.stride()[1:] for i, p in enumerate(patches)):
+            return base.as_strided((len(patches),) + tuple(first.shape[1:]), (step,) + tuple(first.stride()[1:]), o0)
     return torch.cat(patches) if len(patches) > 1 else first

@@ -19,6 +19,7 @@ windows and one RCCL all-gather of the logits precedes the (replicated, determin
 from __future__ import annotations
 
 import os
+import threading
 from collections.abc import Callable, Mapping, Sequence
 from typing import Any
 
@@ -375,7 +376,7 @@ def sliding_window_inference(
             nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
                 if lg is mosaic:
-                    ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
+                    ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, imp, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
                 elif argmax_dtype is not None:
                     _blend_argmax(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b, 0], g,
                                   _to3(seg_shapes[ss], 1), premultiplied=proc_weights is not None)
@@ -414,31 +415,34 @@ def sliding_window_inference(
 # span and the kernel's own duration in profiles/r03_bench_kernel_trace_stats_v2.txt).  Result-neutral: the same values, kept.
 _HOST_MAPS: dict = {}
 _DEVICE_MAPS: dict = {}
+_MAPS_LOCK = threading.RLock()      # inferers may run concurrently in threads (a server, DataLoader workers): lookups and the clear-all eviction are atomic
 
 
 def _host_importance_map(patch_size, mode, sigma_scale, dtype):
     key = (tuple(int(v) for v in patch_size), str(mode), tuple(float(v) for v in ensure_tuple(sigma_scale)), dtype)
-    hit = _HOST_MAPS.get(key)
-    if hit is None:
-        if len(_HOST_MAPS) >= 8:
-            _HOST_MAPS.clear()
-            _DEVICE_MAPS.clear()
-        hit = _HOST_MAPS[key] = compute_importance_map(patch_size, mode=mode, sigma_scale=sigma_scale, device="cpu", dtype=dtype)
+    with _MAPS_LOCK:
+        hit = _HOST_MAPS.get(key)
+        if hit is None:
+            if len(_HOST_MAPS) >= 8:
+                _HOST_MAPS.clear()
+                _DEVICE_MAPS.clear()
+            hit = _HOST_MAPS[key] = compute_importance_map(patch_size, mode=mode, sigma_scale=sigma_scale, device="cpu", dtype=dtype)
     return hit, key
 
 
-def _factored_map(imp_key, roi3, mode, sigma_scale, dev) -> torch.Tensor:
+def _factored_map(imp_key, host_map, roi3, mode, sigma_scale, dev) -> torch.Tensor:
     """[gz | gy | gx | floor] on the device for the mosaic blend (it re-forms the importance map from its factors in registers: same fp32 values, no
     roi^3 map competing with the logits stream for L2), or the full map when the factorisation is not available (non-3-D roi, alignment)."""
     key = ("factored",) + imp_key + (str(dev),)
-    hit = _DEVICE_MAPS.get(key)
-    if hit is None:
-        fac = importance_map_factors(imp_key[0], mode, sigma_scale) if len(imp_key[0]) == 3 and (roi3[0] + roi3[1]) % 4 == 0 else None
-        if fac is None:
-            hit = _on_device(_HOST_MAPS[imp_key].reshape(roi3).contiguous(), dev, cache_key=imp_key + (tuple(roi3),))
-        else:
-            hit = torch.cat([fac[0], fac[1], fac[2], torch.tensor([fac[3]], dtype=torch.float32)]).to(dev)
-        _DEVICE_MAPS[key] = hit
+    with _MAPS_LOCK:
+        hit = _DEVICE_MAPS.get(key)
+        if hit is None:
+            fac = importance_map_factors(imp_key[0], mode, sigma_scale) if len(imp_key[0]) == 3 and (roi3[0] + roi3[1]) % 4 == 0 else None
+            if fac is None:     # the caller's own host map (never re-read from the cache: another thread may have evicted it)
+                hit = _on_device(host_map.reshape(roi3).contiguous(), dev, cache_key=imp_key + (tuple(roi3),))
+            else:
+                hit = torch.cat([fac[0], fac[1], fac[2], torch.tensor([fac[3]], dtype=torch.float32)]).to(dev)
+            _DEVICE_MAPS[key] = hit
     return hit
 
 
@@ -446,11 +450,12 @@ def _on_device(host_map: torch.Tensor, dev, cache_key=None) -> torch.Tensor:
     if cache_key is None:
         return host_map.to(dev)
     key = cache_key + (str(dev),)
-    hit = _DEVICE_MAPS.get(key)
-    if hit is None:
-        if len(_DEVICE_MAPS) >= 16:
-            _DEVICE_MAPS.clear()
-        hit = _DEVICE_MAPS[key] = host_map.to(dev)
+    with _MAPS_LOCK:
+        hit = _DEVICE_MAPS.get(key)
+        if hit is None:
+            if len(_DEVICE_MAPS) >= 16:
+                _DEVICE_MAPS.clear()
+            hit = _DEVICE_MAPS[key] = host_map.to(dev)
     return hit
 
 

@@ -185,6 +185,13 @@ class UNet(nn.Module):
             self._packed[("bn", id(bn))] = hit
         return hit[1].unsqueeze(0).expand(n, -1, -1).contiguous()
 
+    def _has_batchnorm(self) -> bool:
+        """BatchNorm anywhere in the net (its folded records carry no magnitude bounds) -- the module tree is walked once, not per convolution launch"""
+        hit = self.__dict__.get("_bn_cached")
+        if hit is None:
+            hit = self.__dict__["_bn_cached"] = any(isinstance(m, nn.BatchNorm3d) for m in self.modules())
+        return hit
+
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
         if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
             self._stats = torch.empty(floats, dtype=torch.float32, device=device)
@@ -208,7 +215,7 @@ class UNet(nn.Module):
             # the channels' true width
             tiny = s == 1 and cin <= 8 and cout <= 8
             # records written by instnorm_finalize carry magnitude bounds (the split-precision kernel needs them); folded BatchNorm records do not
-            bounded = x_nrm is not None and not any(isinstance(m, nn.BatchNorm3d) for m in self.modules())
+            bounded = x_nrm is not None and not self._has_batchnorm()
             cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=bounded) if (s == 1 and not tiny) else 0
             wants_stats = hasattr(unit, "adn") and not isinstance(unit.adn.N, nn.BatchNorm3d)
             stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and wants_stats) else 0
