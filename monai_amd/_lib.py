@@ -63,6 +63,7 @@ SIGNATURES = {
     "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mh_conv3d_k3_h2_config": (_I, []),
+    "mh_conv3d_k3_h2z_config": (_I, []),
     "mh_conv3d_k3_c1_config": (_I, []),
     "mh_conv3d_k3_num_configs": (_I, []),
     "mh_conv3d_k3_accepts": (_I, [_I, _I, _I]),

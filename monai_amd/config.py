@@ -15,8 +15,8 @@ USE_COMPILED = HAS_EXT and os.getenv("BUILD_MONAI", "0") == "1"
 # `CONV_ALGO` (or the environment variable MONAI_AMD_CONV_ALGO, read at call time while CONV_ALGO is None):
 #   "auto"   fp16 two-piece split precision (fp32-equivalent) for inputs that carry magnitude bounds, exact fp32 otherwise
 #   "fp32"   exact-fp32 kernels only (matrix-core tiles, in-plane Winograd, the one-channel kernel)
-#   "direct" / "wino2d" / "h2"   pin one family (measurements)
-CONV_ALGOS = {"auto": 0, "direct": 1, "wino2d": 2, "h2": 3, "fp32": 4}
+#   "direct" / "wino2d" / "h2" / "h2z"   pin one family (measurements): "h2" = the direct split-precision kernel only, "h2z" = its z-Winograd form wherever it fits
+CONV_ALGOS = {"auto": 0, "direct": 1, "wino2d": 2, "h2": 3, "fp32": 4, "h2z": 5}
 CONV_ALGO = None
 
 

@@ -292,6 +292,12 @@ def conv3d_k3_h2_config() -> int:
     return _lib.lib().query("mh_conv3d_k3_h2_config")
 
 
+def conv3d_k3_h2z_config() -> int:
+    """Id of the split-precision configuration behind the z-Winograd F(2, 3) transform (kernels/conv3d_h2z.h): the arithmetic of
+    `conv3d_k3_h2_config` with 2/3 of its matrix instructions; same tolerance class."""
+    return _lib.lib().query("mh_conv3d_k3_h2z_config")
+
+
 def conv3d_k3_c1_config() -> int:
     """Id of the one-input-channel configuration (first layer of the networks: packed fp32 vector arithmetic, write-bound, exact fp32);
     outside 1 .. conv3d_k3_num_configs()."""

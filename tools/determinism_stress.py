@@ -48,10 +48,10 @@ def digest(t):
 
     if t is None or not isinstance(t, torch.Tensor) or t.numel() == 0:
         return None
-    if not t.is_contiguous():
-        t = t.contiguous()
-    w = t.view(torch.int32) if t.element_size() == 4 else t.view(torch.uint8).to(torch.int32)
-    return w.sum(dtype=torch.int64)
+    # wrapping int32 sum of the words: integer addition is associative, so the digest is exact and independent of the reduction order; no int64 copy of
+    # a 7 GB activation tensor and no .contiguous() of a channel-sliced view (the reduction walks the strides)
+    w = t.view(torch.int32) if t.element_size() == 4 else t.contiguous().view(torch.uint8).to(torch.int32)
+    return w.sum(dtype=torch.int32)
 
 
 def install_hooks(log):
@@ -115,7 +115,13 @@ def worker(a):
     if not a.no_hooks:
         install_hooks(log)
     patterns = [0x7FC00000, 0x7F7FFFFF, 0x00000000, 0x3F800000, 0xFF7FFFFE]
-    first, first_out, report = None, None, {"pid": os.getpid(), "runs": a.runs, "mismatching_runs": [], "launches_per_run": None}
+    first, first_out, report = None, None, {"pid": os.getpid(), "runs": a.runs, "mismatching_runs": [], "launches_per_run": None, "schedules": []}
+    # --vary: the schedules the product picks under memory pressure (windows per launch from the free HBM, the slab-wise path when the all-window
+    # logits do not fit), forced here one after the other: the OUTPUT must not depend on them
+    vary = [("MONAI_AMD_SW_BATCH", "64"), ("MONAI_AMD_SW_BATCH", "32"), ("MONAI_AMD_SW_BATCH", "50"), ("MONAI_AMD_SW_BATCH", "13"),
+            ("MONAI_AMD_MAX_LOGITS_BYTES", str(int(6e9))), ("MONAI_AMD_MAX_LOGITS_BYTES", str(int(9e9))), ("MONAI_AMD_LOGITS_LAYOUT", "windows")]
+    if not a.vary and not a.no_hooks:
+        os.environ.setdefault("MONAI_AMD_SW_BATCH", "32")       # per-launch digests are compared as a sequence: the schedule must not follow the free memory
     t0 = time.time()
     for r in range(a.runs):
         if a.fresh_plans and hasattr(net, "_plans"):
@@ -129,6 +135,13 @@ def worker(a):
             junk.fill_(p if p < 2**31 else p - 2**32)
             del junk
         log.clear()
+        if a.vary:
+            for k_, _ in vary:
+                os.environ.pop(k_, None)
+            if r > 0:
+                k_, v_ = vary[(r - 1) % len(vary)]
+                os.environ[k_] = v_
+                report["schedules"].append(f"{k_}={v_}")
         out = inferer(vol, net)
         od = digest(out)
         torch.cuda.synchronize()
@@ -138,9 +151,12 @@ def worker(a):
             report["launches_per_run"] = len(run)
             report["first_run_output_digest"] = run[-1][2]
             continue
-        if run != first:
+        if a.vary or a.no_hooks:          # outputs only
+            if run[-1] != first[-1]:
+                report["mismatching_runs"].append({"run": r, "op": "output", "schedule": report["schedules"][-1] if report["schedules"] else None})
+        elif run != first:
             where = next((j for j, (x, y) in enumerate(zip(run, first)) if x != y), min(len(run), len(first)))
-            entry = {"run": r, "first_differing_launch": where, "op": run[where][0] if where < len(run) else "length",
+            entry = {"run": r, "output_equal": run[-1] == first[-1], "first_differing_launch": where, "op": run[where][0] if where < len(run) else "length",
                      "launch_arg": run[where][1] if where < len(run) else None, "differing_launches": sum(1 for x, y in zip(run, first) if x != y),
                      "launches": len(run), "launches_first_run": len(first)}
             if first_out is not None:
@@ -165,6 +181,7 @@ def main():
     ap.add_argument("--fresh-plans", action="store_true")
     ap.add_argument("--no-hooks", action="store_true", help="outputs only (no per-launch digests: the unperturbed timing of the product)")
     ap.add_argument("--keep-output", action="store_true")
+    ap.add_argument("--vary", action="store_true", help="force a different schedule per run (windows per launch, slab-wise path, window-major logits); compare outputs")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--features", default="", help="BasicUNet widths for emulator plumbing checks")
     a = ap.parse_args()
@@ -188,7 +205,7 @@ def main():
     firsts = {r.get("first_run_output_digest") for r in reports if "error" not in r}
     if len(firsts) > 1:
         bad += 1
-    summary = {"procs": a.procs, "runs_per_proc": a.runs, "size": a.size, "net": a.net, "poison": a.poison, "fresh_plans": a.fresh_plans, "hooks": not a.no_hooks,
+    summary = {"procs": a.procs, "runs_per_proc": a.runs, "size": a.size, "net": a.net, "poison": a.poison, "fresh_plans": a.fresh_plans, "hooks": not a.no_hooks, "vary": a.vary,
                "inferences_total": a.procs * a.runs, "workers_with_mismatch": bad, "first_run_output_digests": sorted(str(f) for f in firsts), "seconds": time.time() - t0, "workers": reports}
     print("STRESS " + json.dumps(summary))
     return 1 if bad else 0
