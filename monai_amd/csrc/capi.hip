@@ -481,7 +481,7 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
         best = MH_CFG_H2;
     // the same arithmetic behind a Winograd F(2, 3) transform along z: 2/3 of the matrix instructions (kernels/conv3d_h2z.h).  Its regions are 8 x 32: taken where they cover
     // the plane as well as the direct kernel's regions do (96 x 96, 24 x 24; not 48 x 48: 12 regions against 9) and the march has at least four plane pairs
-    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2Z, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && D >= 8 && h2_fits(D, H, W)
+    if ((algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2Z, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && D >= 8 && h2_fits(D, H, W)
         && (algo == MH_ALGO_H2Z || h2z_regions(H, W) <= h2_regions(H, W)))
         best = MH_CFG_H2Z;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
