@@ -91,6 +91,21 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// two values at once, in the form the ISA has instructions for: hi pair = ONE v_cvt_pk_f16_f32, each residual v - hi = ONE v_fma_mix_f32 (the fp16 half is widened
+// inside the instruction: fma(hi, -1, v) rounds once, exactly like v - (float)hi), lo pair = ONE v_cvt_pk_f16_f32 -- 2 instead of 4 instructions per value; the
+// same bits as h2_split
+// `m1` = -1.0f behind a value barrier (h2_minus_one): with the literal the optimiser rewrites fma(hi, -1, v) into a subtraction and the widening costs its own instruction
+__device__ __forceinline__ float h2_minus_one() {
+    float m = -1.0f;
+    MH_OPAQUE(m);
+    return m;
+}
+__device__ __forceinline__ void h2_split_pair(float v0, float v1, float m1, f16x2& hi, f16x2& lo) {
+    hi = f16x2{(_Float16)v0, (_Float16)v1};
+    const float r0 = __builtin_fmaf((float)hi[0], m1, v0), r1 = __builtin_fmaf((float)hi[1], m1, v1);
+    lo = f16x2{(_Float16)r0, (_Float16)r1};
+}
+
 // EMIT / PLAIN step bodies are the same code; the epilogue of a completed plane rides in the first step of the next plane
 // RES: at most two channel chunks (Cin <= 32): both weight slabs stay resident in the two LDS weight buffers (chunk = buffer index)
 // and are loaded once -- the per-step weight stream from L2 (55 KB per step and CU: 2.2 of 9.4 ms) disappears

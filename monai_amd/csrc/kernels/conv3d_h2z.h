@@ -49,16 +49,16 @@ constexpr int HZ_WP = 2 * HZ_WV;                            // uint4 per positio
 constexpr int HZ_BUF = 2 * HZ_XP + 2 * HZ_WP;               // uint4 per LDS buffer (two positions): 5056 = 80 896 bytes
 constexpr int HZ_WSUB = 2 * HZ_WP;                          // uint4 of weights per sub-step: 2304 = 4 x 512 uint4 + 512 uint2
 constexpr int HZ_SLOTS = 3;                                 // staging tasks per lane: (voxel, 4 channels)
-constexpr int HZ_NRM_MAX = 128;                             // input channels (their records {alpha x 4, beta x 4, slope x 4} per quad sit in LDS: 1.5 KB -- all 160 KB are taken)
+constexpr int HZ_NRM_MAX = 128;                             // input channels (their records {alpha, beta, slope, K} x 4 per quad sit in LDS: 2 KB -- all 160 KB are taken)
 static_assert(HZ_HALF * 2 == HZ_NV && HZ_HALF <= 64 * HZ_SLOTS, "staging slots");
-static_assert(2 * HZ_BUF * 16 + 3 * HZ_NRM_MAX * 4 <= 160 * 1024, "LDS budget");
+static_assert(2 * HZ_BUF * 16 + 4 * HZ_NRM_MAX * 4 <= 160 * 1024, "LDS budget");
 
 template <bool STATS, bool NRM>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                      float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
     __shared__ uint4 smem[2 * HZ_BUF];
-    __shared__ __attribute__((aligned(16))) float nrm_s[NRM ? 3 * HZ_NRM_MAX : 4];
+    __shared__ __attribute__((aligned(16))) float nrm_s[NRM ? 4 * HZ_NRM_MAX : 4];      // per channel quad {alpha x 4, beta x 4, slope x 4, K x 4} (K: the activation's med3 constant)
     unsigned* const bound_s = reinterpret_cast<unsigned*>(smem + 2 * HZ_XP);      // 8 words of the (not yet loaded) weight area of buffer 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,8 +97,9 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         unsigned mb = 0u;
         for (int c = tid; c < Cin; c += 512) {
             const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
-            float* r_ = nrm_s + 12 * (c >> 2) + (c & 3);
+            float* r_ = nrm_s + 16 * (c >> 2) + (c & 3);
             r_[0] = a.x; r_[4] = a.y; r_[8] = a.z;
+            r_[12] = __uint_as_float(a.z <= 1.0f ? 0x7f800000u : 0xff800000u);
             const unsigned bb = abs_bits(a.w);
             mb = max(mb, bb == 0u ? 0x7fc00000u : bb);        // no bound given counts as non-finite
         }
@@ -118,7 +119,7 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
         __syncthreads();              // every thread has read the bounds: the words go back to zero before the weight area is used
         if (tid < 8) bound_s[tid] = 0u;
-        for (int c = tid; c < Cin; c += 512) { float* r_ = nrm_s + 12 * (c >> 2) + (c & 3); r_[0] *= p_; r_[4] *= p_; }
+        for (int c = tid; c < Cin; c += 512) { float* r_ = nrm_s + 16 * (c >> 2) + (c & 3); r_[0] *= p_; r_[4] *= p_; }
         __syncthreads();
     }
 
@@ -126,11 +127,12 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     const u32x4* const wg4 = reinterpret_cast<const u32x4*>(wp) + (long long)cg * NCH * (2 * HZ_WSUB) + tid;
     const u32x2* const wg2 = reinterpret_cast<const u32x2*>(reinterpret_cast<const u32x4*>(wp) + (long long)cg * NCH * (2 * HZ_WSUB) + 2048) + tid;
 
+    const float m1 = h2_minus_one();
     // raw planes of the current (pair, chunk): three register sets -- rb = b, rc = c, rad = a (while V0 is formed) | d (while V3 is formed)
     float rb[HZ_SLOTS][4], rc[HZ_SLOTS][4], rad[HZ_SLOTS][4];
     u32x4 win[4];
     u32x2 win2;
-    f32x4 nq_a = {1.0f, 1.0f, 1.0f, 1.0f}, nq_b = {0.0f, 0.0f, 0.0f, 0.0f}, nq_s = nq_a;      // records of the quad being converted (chunk of the planes in the registers)
+    f32x4 nq_a = {1.0f, 1.0f, 1.0f, 1.0f}, nq_b = {0.0f, 0.0f, 0.0f, 0.0f}, nq_s = nq_a, nq_k = nq_a;      // records of the quad being converted (chunk of the planes in the registers)
 
     // state of the load stream: `ld_i` = index of the (pair, chunk) whose planes are loaded next; ld_ok = it exists
     int ld_t = 0, ld_c = 0;           // pair, chunk of the planes to load next
@@ -149,15 +151,20 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // validity of plane DZ_ of the pair whose planes are in the registers (`cv_t`), wave-uniform: a plane outside the volume loads zeros and its activation is
     // replaced by zero (a select on a scalar condition: no register)
 #define MH_HZ_VALID(DZ_) (cv_t < NP && zs + 2 * cv_t + (DZ_) >= 0 && zs + 2 * cv_t + (DZ_) < D)
+    // activation: y = fma(x, alpha, beta); y > 0 ? y : y * slope  ==  med3(y, y * slope, K) with K = +inf for slope <= 1 (the larger of the two), -inf for slope > 1
+    // (the smaller) -- two instructions instead of three; the value is one of y, y * slope either way (for y = +-0 and a NEGATIVE slope the zero's sign may differ)
 #define MH_HZ_ACT(R_, J, FV_)                                                                         \
-    if (NRM) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float y_ = act(R_[J][i], nq_a[i], nq_b[i], nq_s[i]); R_[J][i] = (FV_) ? y_ : 0.0f; } }
+    if (NRM) {      /* a plane outside the volume: its loads returned zeros and its records are zeroed -> fma(0, 0, 0) = 0 -> med3(0, 0, K) = 0 */ \
+        const float v_ = (FV_) ? 1.0f : 0.0f;                                                         \
+        const f32x4 ma_ = nq_a * v_, mb_ = nq_b * v_;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float y_ = fmaf(R_[J][i], ma_[i], mb_[i]); R_[J][i] = __builtin_amdgcn_fmed3f(y_, y_ * nq_s[i], nq_k[i]); } \
+    }
     // split 4 channels of a voxel and write 8 bytes of the high plane, 8 of the low one of position P_ in the buffer after bcur
 #define MH_HZ_PUT(P_, J, V_)                                                                          \
     {                                                                                                 \
         u32x2* xh_ = reinterpret_cast<u32x2*>(smem + (bcur ^ 1) * HZ_BUF + (P_) * HZ_XP);             \
-        _Float16 h_[4], l_[4];                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) h2_split(V_[i], h_[i], l_[i]);                  \
-        const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
+        f16x2 h01_, h23_, l01_, l23_;                                                                 \
+        h2_split_pair(V_[0], V_[1], m1, h01_, l01_); h2_split_pair(V_[2], V_[3], m1, h23_, l23_);     \
         xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
         xh_[loff[J] + 2 * HZ_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
     }
@@ -180,8 +187,8 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // records of the quad of chunk C_ (alpha, beta pre-multiplied by 2^e_in)
 #define MH_HZ_NRMLD(C_)                                                                               \
     if (NRM) {                                                                                        \
-        const f32x4* a_ = reinterpret_cast<const f32x4*>(nrm_s + 12 * (4 * (C_) + q));                \
-        nq_a = a_[0]; nq_b = a_[1]; nq_s = a_[2];                                                     \
+        const f32x4* a_ = reinterpret_cast<const f32x4*>(nrm_s + 16 * (4 * (C_) + q));                \
+        nq_a = a_[0]; nq_b = a_[1]; nq_s = a_[2]; nq_k = a_[3];                                       \
     }
     // weights of sub-step index W_ (= 2 * chunk + s) of this cout group: 4 x 16 bytes + 8 bytes per thread, registers -> the buffer after bcur
 #define MH_HZ_LDW(W_)                                                                                 \

@@ -15,35 +15,63 @@ from __future__ import annotations
 import torch
 
 
-def label_parity(got: torch.Tensor, ref: torch.Tensor, tol: float = 1e-4, channel_dim: int = 1) -> dict:
-    """got / ref: logits of the same shape (channel axis `channel_dim`).  Returns the report; `ok` is the rule above."""
-    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+def label_parity(got: torch.Tensor, ref: torch.Tensor, tol: float = 1e-4, channel_dim: int = 1, chunk_voxels: int = 1 << 24) -> dict:
+    """got / ref: logits of the same shape (channel axis `channel_dim`).  Returns the report; `ok` is the rule above.
+    Large volumes (the 512^3 x 5 headline output is 2.7 GB per side) are walked in slabs of `chunk_voxels` voxels along the first axis after the channel
+    axis; `got` may live on a GPU (each slab is copied to the host).  The rule needs max|diff| over the WHOLE volume before a mismatch can be judged against
+    the margin, so the mismatching voxels' margins are kept (they are few) and judged at the end."""
     if got.shape != ref.shape:
         raise ValueError(f"label_parity: shapes differ {tuple(got.shape)} vs {tuple(ref.shape)}")
-    diff = float((got - ref).abs().max()) if got.numel() else 0.0
-    la, lb = got.argmax(channel_dim), ref.argmax(channel_dim)
+    ref = ref.detach()
+    got = got.detach()
     k = ref.shape[channel_dim]
-    if k > 1:
-        top2 = ref.topk(2, dim=channel_dim).values
-        margin = top2.select(channel_dim, 0) - top2.select(channel_dim, 1)
-    else:
-        margin = torch.full(lb.shape, float("inf"))
-    mism = la != lb
-    outside = mism & ~(margin < 2.0 * diff)
-    dice = []
-    for c in range(k):
-        a, b = la == c, lb == c
-        den = int(a.sum()) + int(b.sum())
-        dice.append(1.0 if den == 0 else 2.0 * int((a & b).sum()) / den)
+    ax = channel_dim + 1 if channel_dim + 1 < ref.dim() else None      # slab axis
+    n_ax = ref.shape[ax] if ax is not None else 1
+    per = max(1, ref.numel() // max(k * n_ax, 1))                      # voxels per index of the slab axis
+    step = max(1, chunk_voxels // per) if ax is not None else 1
+    diff, nvox, nmis, margin_min, below = 0.0, 0, 0, float("inf"), 0
+    mis_margins = []
+    inter = [0] * k
+    cnt_a = [0] * k
+    cnt_b = [0] * k
+    for s in range(0, n_ax, step):
+        if ax is not None:
+            g = got.narrow(ax, s, min(step, n_ax - s)).float().cpu()
+            r = ref.narrow(ax, s, min(step, n_ax - s)).float().cpu()
+        else:
+            g, r = got.float().cpu(), ref.float().cpu()
+        if g.numel() == 0:
+            continue
+        diff = max(diff, float((g - r).abs().max()))
+        la, lb = g.argmax(channel_dim), r.argmax(channel_dim)
+        if k > 1:
+            top2 = r.topk(2, dim=channel_dim).values
+            margin = top2.select(channel_dim, 0) - top2.select(channel_dim, 1)
+        else:
+            margin = torch.full(lb.shape, float("inf"))
+        mism = la != lb
+        nvox += int(lb.numel())
+        nmis += int(mism.sum())
+        if bool(mism.any()):
+            mis_margins.append(margin[mism].reshape(-1))
+        margin_min = min(margin_min, float(margin.min()))
+        below += int((margin < 1e-4).sum())
+        for c in range(k):
+            a, b = la == c, lb == c
+            inter[c] += int((a & b).sum())
+            cnt_a[c] += int(a.sum())
+            cnt_b[c] += int(b.sum())
+    mm = torch.cat(mis_margins) if mis_margins else torch.zeros(0)
+    dice = [1.0 if cnt_a[c] + cnt_b[c] == 0 else 2.0 * inter[c] / (cnt_a[c] + cnt_b[c]) for c in range(k)]
     rep = {
         "max_abs_logit_diff": diff,
         "tolerance": tol,
-        "voxels": int(lb.numel()),
-        "argmax_mismatch_voxels": int(mism.sum()),
-        "mismatch_outside_margin": int(outside.sum()),
-        "max_top2_margin_at_mismatch": float(margin[mism].max()) if bool(mism.any()) else 0.0,
-        "min_top2_margin": float(margin.min()) if margin.numel() else float("inf"),
-        "voxels_with_margin_below_1e-4": int((margin < 1e-4).sum()),
+        "voxels": nvox,
+        "argmax_mismatch_voxels": nmis,
+        "mismatch_outside_margin": int((~(mm < 2.0 * diff)).sum()) if mm.numel() else 0,
+        "max_top2_margin_at_mismatch": float(mm.max()) if mm.numel() else 0.0,
+        "min_top2_margin": margin_min,
+        "voxels_with_margin_below_1e-4": below,
         "min_class_dice": min(dice) if dice else 1.0,
     }
     rep["ok"] = bool(diff <= tol and rep["mismatch_outside_margin"] == 0)

@@ -328,6 +328,7 @@ inline unsigned raw_buffer_load_b32(BufRsrc r, unsigned voffset, unsigned soffse
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
 #define __builtin_amdgcn_update_dpp emu::update_dpp
+#define __builtin_amdgcn_fmed3f(a, b, c) std::fmax(std::fmin((a), (b)), std::fmin(std::fmax((a), (b)), (c)))      // v_med3_f32 (finite / infinite operands)
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
