@@ -48,3 +48,18 @@ def test_bench_two_ranks_line_and_bitwise_sharding():
     if single is None:
         single = _run([sys.executable, "bench.py", "--cpu-windows", "0"] + ARGS)["checksum"]
     assert line["checksum"] == single          # the replicated deterministic blend: sharded == unsharded, bit for bit
+
+
+def test_bench_four_ranks_line_and_bitwise_sharding():
+    """the driver's `--gpus 4` launch of SCALE_rNN: four ranks, one JSON line from rank 0, per-rank breakdown of all four, checksum == single process"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    line = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                 "bench.py", "--gpus", "4"] + ARGS)
+    assert KEYS <= set(line) and line["n_gpus"] == 4 and line["scaling"] == "strong" and line["cpu_baseline"] is None
+    assert "sharded over 4" in line["config"]["parallelism"] and [r["rank"] for r in line["per_rank_ms_per_step"]] == [0, 1, 2, 3]
+    single = getattr(test_bench_single_process_line, "checksum", None)
+    if single is None:
+        single = _run([sys.executable, "bench.py", "--cpu-windows", "0"] + ARGS)["checksum"]
+    assert line["checksum"] == single

@@ -5,6 +5,7 @@ result must match the CPU oracle within the 1e-4 logit tolerance."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -90,6 +91,62 @@ def test_two_rank_window_sharding_matches_single_process():
     with torch.no_grad():
         ref = osw.sliding_window_inference(x, roi, 2, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian")
     assert (d0 - ref).abs().max().item() < 1e-4
+
+
+def _worker_n(rank, world, port, shape, roi, ret):
+    """world sizes 3 and 4: a padded last round, ranks that propose DIFFERENT windows-per-launch (the minimum must win on every rank,
+    or the slot arithmetic dead-locks / mis-places rows), the slab-wise path under sharding -- each against the single-process result, bitwise"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.dirname(here)]
+        from emu_backend import emu_backend
+
+        from monai_amd import parallel
+        from monai_amd.inferers import SlidingWindowInferer
+        from monai_amd.networks.nets import BasicUNet
+
+        with emu_backend():
+            torch.manual_seed(1)
+            net = BasicUNet(3, 1, 3, features=FEATURES).eval()
+            torch.manual_seed(3)
+            x = torch.rand(shape)
+            inf = SlidingWindowInferer(roi_size=roi, sw_batch_size=2, overlap=0.5, mode="gaussian")
+            single = inf(x, net).clone()
+            parallel.enable_window_sharding()
+            res = {}
+            os.environ["MONAI_AMD_SW_BATCH"] = "1"                 # 10 windows, rounds of `world`: the last round is padded (3: 12 rows, 4: 12 rows)
+            res["nb1"] = inf(x, net).clone()
+            os.environ["MONAI_AMD_SW_BATCH"] = str(2 + rank)       # every rank proposes another batch: the agreed one is the minimum (2)
+            res["disagree"] = inf(x, net).clone()
+            os.environ["MONAI_AMD_SW_BATCH"] = "2"
+            per_win = 3 * roi[0] * roi[1] * roi[2] * 4
+            # 8 windows' worth of logits: the 10 windows (padded to whole rounds of world x 2 = 12 rows) do not fit -> slab by slab, every slab's windows sharded
+            os.environ["MONAI_AMD_MAX_LOGITS_BYTES"] = str(8 * per_win + 64)
+            res["slabs"] = inf(x, net).clone()
+            del os.environ["MONAI_AMD_MAX_LOGITS_BYTES"], os.environ["MONAI_AMD_SW_BATCH"]
+            parallel.disable_window_sharding()
+        ret[rank] = (single, res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_window_sharding_world_sizes_3_and_4(world):
+    shape, roi = (1, 1, 96, 24, 16), (32, 16, 16)    # 5 x 2 x 1 = 10 windows
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_n, args=(world, _free_port(), shape, roi, ret), nprocs=world, join=True)
+    single = ret[0][0]
+    for r in range(world):
+        s, res = ret[r]
+        assert torch.equal(s, single)
+        for name, t in res.items():
+            assert torch.equal(t, single), f"rank {r} of {world}: {name} differs from the single-process result"
 
 
 def test_partition_covers_every_window_once():
