@@ -154,17 +154,29 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // activation: y = fma(x, alpha, beta); y > 0 ? y : y * slope  ==  med3(y, y * slope, K) with K = +inf for slope <= 1 (the larger of the two), -inf for slope > 1
     // (the smaller) -- two instructions instead of three; the value is one of y, y * slope either way (for y = +-0 and a NEGATIVE slope the zero's sign may differ)
 #define MH_HZ_ACT(R_, J, FV_)                                                                         \
+    MH_HZ_ACT_IMPL(R_, J, FV_)
+#ifdef HZX_OLD_ACT        /* development switch: compare + select */
+#define MH_HZ_ACT_IMPL(R_, J, FV_)                                                                    \
+    if (NRM) { _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float y_ = act(R_[J][i], nq_a[i], nq_b[i], nq_s[i]); R_[J][i] = (FV_) ? y_ : 0.0f; } }
+#else
+#define MH_HZ_ACT_IMPL(R_, J, FV_)                                                                    \
     if (NRM) {      /* a plane outside the volume: its loads returned zeros and its records are zeroed -> fma(0, 0, 0) = 0 -> med3(0, 0, K) = 0 */ \
         const float v_ = (FV_) ? 1.0f : 0.0f;                                                         \
         const f32x4 ma_ = nq_a * v_, mb_ = nq_b * v_;                                                 \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) { const float y_ = fmaf(R_[J][i], ma_[i], mb_[i]); R_[J][i] = __builtin_amdgcn_fmed3f(y_, y_ * nq_s[i], nq_k[i]); } \
     }
+#endif
+#ifdef HZX_OLD_SPLIT      /* development switch (tools/ubench/h2z_variants.hip): the four-instruction split */
+#define MH_HZ_SPLIT2(A_, B_, H_, L_) { _Float16 h0_, h1_, l0_, l1_; h2_split(A_, h0_, l0_); h2_split(B_, h1_, l1_); H_ = f16x2{h0_, h1_}; L_ = f16x2{l0_, l1_}; }
+#else
+#define MH_HZ_SPLIT2(A_, B_, H_, L_) h2_split_pair(A_, B_, m1, H_, L_);
+#endif
     // split 4 channels of a voxel and write 8 bytes of the high plane, 8 of the low one of position P_ in the buffer after bcur
 #define MH_HZ_PUT(P_, J, V_)                                                                          \
     {                                                                                                 \
         u32x2* xh_ = reinterpret_cast<u32x2*>(smem + (bcur ^ 1) * HZ_BUF + (P_) * HZ_XP);             \
         f16x2 h01_, h23_, l01_, l23_;                                                                 \
-        h2_split_pair(V_[0], V_[1], m1, h01_, l01_); h2_split_pair(V_[2], V_[3], m1, h23_, l23_);     \
+        MH_HZ_SPLIT2(V_[0], V_[1], h01_, l01_) MH_HZ_SPLIT2(V_[2], V_[3], h23_, l23_)                 \
         xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
         xh_[loff[J] + 2 * HZ_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
     }
@@ -432,6 +444,8 @@ conv3d_k3_h2z_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #undef MH_HZ_CONV23
 #undef MH_HZ_PUT
 #undef MH_HZ_ACT
+#undef MH_HZ_ACT_IMPL
+#undef MH_HZ_SPLIT2
 #undef MH_HZ_VALID
 #undef MH_HZ_LDPLANE
 
