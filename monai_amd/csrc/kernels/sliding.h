@@ -137,6 +137,75 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The blend in the summation order of the reference's BUFFERED schedule (monai/inferers/utils.py:239-253, 276-284, 324-348; `buffer_steps` > 0):
+// windows are stably sorted by their start along `buffer_dim` (_create_buffered_slices: order = (start along that axis, row-major index)), consecutive groups of
+// `bsteps` distinct starts share a slab buffer -- `buffer[win] += logit * w` in that order from zeros -- and each finished slab is ADDED to the zero-initialised
+// output (`output[slab] += buffer`), so a voxel covered by windows of two slabs sums (0 + part_1) + part_2 instead of one running sum; the count map adds the
+// weights of all covering windows in the sorted order.  The schedule itself (a memory-saving device on 16-80 GB cards) is not reproduced -- the all-window logits
+// sit in HBM -- but its ARITHMETIC is: the same bits as the reference's buffered run.  `bax` = the buffered axis (0 = z, 1 = y, 2 = x of the 3-D view).
+template <int KT, int VEC>
+__global__ void __launch_bounds__(256)
+sw_blend_buffered_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K,
+                         int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g, int bax, int bsteps, long long wstride) {
+    const int wv = W / VEC;
+    const long long total = (long long)D * H * wv;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % wv) * VEC;
+    const long long t = idx / wv;
+    const int y = (int)(t % H), z = (int)(t / H);
+
+    int lo[3], hi[3];
+    cover(g.sz, g.nz, rd, z, lo[0], hi[0]);
+    cover(g.sy, g.ny, rh, y, lo[1], hi[1]);
+    cover(g.sx, g.nx, rw, x, lo[2], hi[2]);
+    // loop nest: the buffered axis outermost, the other two in their row-major order
+    const int a0 = bax, a1 = bax == 0 ? 1 : 0, a2 = bax == 2 ? 1 : 2;
+
+    const long long plane = (long long)rh * rw, roi = plane * rd;
+    float acc[KT][VEC], part[KT][VEC];
+    float cnt[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        cnt[v] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) { acc[k][v] = 0.0f; part[k][v] = 0.0f; }
+    }
+    int group = lo[a0] / bsteps;
+    int i[3];
+    for (i[a0] = lo[a0]; i[a0] <= hi[a0]; ++i[a0]) {
+        if (i[a0] / bsteps != group) {      // the slab is complete: output += buffer, a new buffer starts from zeros
+            group = i[a0] / bsteps;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+#pragma unroll
+                for (int k = 0; k < KT; ++k) { acc[k][v] = __fadd_rn(acc[k][v], part[k][v]); part[k][v] = 0.0f; }
+        }
+        for (i[a1] = lo[a1]; i[a1] <= hi[a1]; ++i[a1]) {
+            for (i[a2] = lo[a2]; i[a2] <= hi[a2]; ++i[a2]) {
+                const int lz = z - g.sz[i[0]], ly = y - g.sy[i[1]], lx = x - g.sx[i[2]];
+                const long long w = ((long long)i[0] * g.ny + i[1]) * g.nx + i[2];
+                const long long off = (long long)lz * plane + (long long)ly * rw + lx;
+                const float* lp = logits + w * wstride + k0 * roi + off;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float wt = imp[off + v];
+#pragma unroll
+                    for (int k = 0; k < KT; ++k) part[k][v] = __fadd_rn(part[k][v], __fmul_rn(lp[k * roi + v], wt));
+                    cnt[v] = __fadd_rn(cnt[v], wt);
+                }
+            }
+        }
+    }
+    const long long vox = (long long)D * H * W;
+    float* op = out + (long long)k0 * vox + ((long long)z * H + y) * W + x;
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) op[k * vox + v] = __fdiv_rn(__fadd_rn(acc[k][v], part[k][v]), cnt[v]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Regular window grids.  dense_patch_slices (monai/data/utils.py:166-206) only ever produces starts of the form
 //   start(i) = i * step  for i < n - 1,   start(n - 1) = last <= (n - 1) * step      (the clip to image - roi)
 // so the covering range of a coordinate has a closed form: no start tables in the kernel arguments, no per-thread table

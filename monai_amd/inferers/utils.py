@@ -136,10 +136,14 @@ def sliding_window_inference(
 ):
     """See the reference docstring (monai/inferers/utils.py:63-141) for the argument semantics; they are kept.
 
-    Differences, all result-neutral: ``buffer_steps`` / ``buffer_dim`` are validated and otherwise ignored (they are
-    a memory-saving schedule of the reference, not a different result -- the blend here never materialises partial
-    volumes; when the logits of all windows do not fit in HBM the volume is processed slab by slab along its first spatial
-    axis with bit-identical results, see ``_slabwise``); ``sw_device`` must be a ROCm device (a CPU volume is moved to it once; half / bfloat16 volumes are widened to fp32 and the result
+    ``buffer_steps`` / ``buffer_dim`` (utils.py:239-253, 276-284, 324-348): the reference's buffered schedule sums in ANOTHER ORDER than its plain path
+    (windows sorted by their start along ``buffer_dim``, slabs of ``buffer_steps`` distinct starts accumulated from zero and then added to the output), so
+    its result differs from the plain one by roundings (tests/golden/buffered.npz: up to 26 000 voxels of a small volume, <= 6e-7).  The schedule itself --
+    a memory-saving device -- is not reproduced (the logits of all windows sit in HBM), its ARITHMETIC is: with ``buffer_steps`` the blend runs in the
+    buffered order (``mh_sw_blend_buffered_f32``) and returns the bits of the reference's buffered run (single-tensor predictors, as in the reference, which
+    ignores further outputs there; ``process_fn`` / multi-resolution outputs with ``buffer_steps`` are not on the HIP path).
+    Other differences, all result-neutral: when the logits of all windows do not fit in HBM the volume is processed slab by slab along its first spatial
+    axis with bit-identical results, see ``_slabwise``; ``sw_device`` must be a ROCm device (a CPU volume is moved to it once; half / bfloat16 volumes are widened to fp32 and the result
     returned in the caller's dtype).  A predictor with ``forward_into`` (the conv engines) is given up to 64 windows per launch
     instead of ``sw_batch_size`` -- result-neutral, but it changes peak memory; MONAI_AMD_STRICT_SW_BATCH=1 keeps the caller's value
     and MONAI_AMD_SW_BATCH=n sets it.  ``process_fn`` (utils.py:232-234) is honoured with
@@ -150,6 +154,10 @@ def sliding_window_inference(
     if buffered:
         if buffer_dim < -num_spatial_dims or buffer_dim > num_spatial_dims:
             raise ValueError(f"buffer_dim must be in [{-num_spatial_dims}, {num_spatial_dims}], got {buffer_dim}.")
+        if buffer_dim < 0:
+            buffer_dim += num_spatial_dims
+        if buffer_dim >= num_spatial_dims or process_fn is not None or with_coord:
+            raise NotImplementedError("monai_amd: buffer_steps with buffer_dim == the number of spatial dims, process_fn or with_coord is not on the HIP path")
     overlap = ensure_tuple_rep(overlap, num_spatial_dims)
     for o in overlap:
         if o < 0 or o >= 1:
@@ -207,7 +215,7 @@ def sliding_window_inference(
     # all-window logits that do not fit in HBM: slab by slab along the first spatial axis (see _slabwise)
     argmax_dtype = kwargs.pop("_monai_amd_argmax", None)      # fused AsDiscrete(argmax=True) epilogue (sliding_window_argmax below)
     slab_ok = (not kwargs.pop("_monai_amd_no_slabs", False) and not with_coord and process_fn is None and not any(pad_size)
-               and len(starts[0]) > 1)
+               and len(starts[0]) > 1 and not buffered)
     if slab_ok:
         sub_kwargs = dict(kwargs, _monai_amd_no_slabs=True, _monai_amd_argmax=argmax_dtype)
 
@@ -291,7 +299,7 @@ def sliding_window_inference(
                     if logits is None:
                         k = int(predictor.out_channels)
                         seg_shapes, zscales = [tuple(roi_size)], [None]
-                        mosaic = _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
+                        mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
                         logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
                     with _prof.span("sw_predictor"):
                         if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
@@ -375,7 +383,11 @@ def sliding_window_inference(
             nlog = num_win * lg.k * roi3[0] * roi3[1] * roi3[2] if lg is mosaic else lg[:num_win].numel()
             nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
-                if lg is mosaic:
+                if buffered:      # the reference's buffered summation order (single output at window resolution)
+                    if len(gathered) != 1 or z is not None or argmax_dtype is not None:
+                        raise NotImplementedError("monai_amd: buffer_steps with several / multi-resolution outputs or the fused argmax is not on the HIP path")
+                    ops.sw_blend_buffered(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1), buffer_dim + (3 - num_spatial_dims), int(buffer_steps))
+                elif lg is mosaic:
                     ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, imp, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
                 elif argmax_dtype is not None:
                     _blend_argmax(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b, 0], g,

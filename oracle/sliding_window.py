@@ -117,8 +117,12 @@ def sliding_window_inference(
     padding_mode="constant",
     cval=0.0,
     roi_weight_map=None,
+    buffer_steps=None,
+    buffer_dim=-1,
 ):
-    """Non-buffered path of monai/inferers/utils.py:42-321 on CPU tensors."""
+    """monai/inferers/utils.py:42-321 on CPU tensors: the non-buffered path, and (buffer_steps > 0) the buffered one -- see `_buffered` below."""
+    if buffer_steps is not None and buffer_steps > 0:
+        return _buffered(inputs, roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, roi_weight_map, int(buffer_steps), int(buffer_dim))
     nsp = inputs.dim() - 2
     overlap = _rep(overlap, nsp)
     for o in overlap:
@@ -203,3 +207,91 @@ def sliding_window_inference(
     if keys is not None:
         return dict(zip(keys, outputs))
     return outputs[0] if len(outputs) == 1 else tuple(outputs)
+
+
+def _buffered(inputs, roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, roi_weight_map, buffer_steps, buffer_dim):
+    """The buffered schedule of the reference on CPU tensors (single-output predictors), monai/inferers/utils.py:
+      * :142-143  a negative `buffer_dim` counts from the last spatial axis;
+      * :324-348  `_create_buffered_slices`: windows stably sorted by their start along `buffer_dim`; flush boundaries after every
+                  `min(#distinct starts, buffer_steps)` distinct starts; a slab spans [first window's start, last window's end) of its group;
+      * :239-253  per group a zero slab buffer `[1, K, *image with the slab's extent]`, `buffer[win] += p * w_t` window by window (sorted order);
+      * :264-275  the count map adds `w_t` over ALL windows in the sorted order;
+      * :276-284  the finished slab is added to the zero-initialised output (`output[slab] += buffer`: the CPU run has non_blocking = False);
+      * :297-298  one final `/=` by the count map."""
+    import numpy as np
+
+    nsp = inputs.dim() - 2
+    if buffer_dim < -nsp or buffer_dim > nsp:
+        raise ValueError(f"buffer_dim must be in [{-nsp}, {nsp}], got {buffer_dim}.")
+    if buffer_dim < 0:
+        buffer_dim += nsp
+    overlap = _rep(overlap, nsp)
+    dtype = inputs.dtype
+    batch, _, *orig_size = inputs.shape
+    roi = resolve_roi_size(roi_size, orig_size)
+    image_size = tuple(max(orig_size[i], roi[i]) for i in range(nsp))
+    pad = []
+    for k in range(inputs.dim() - 1, 1, -1):
+        diff = max(roi[k - 2] - inputs.shape[k], 0)
+        half = diff // 2
+        pad.extend([half, diff - half])
+    if any(pad):
+        inputs = F.pad(inputs, pad=pad, mode=padding_mode, value=cval)
+    interval = get_scan_interval(image_size, roi, overlap)
+    starts, patch = dense_patch_starts(image_size, roi, interval)
+    wins = np.asarray([[(s, s + patch[d]) for d, s in enumerate(w)] for w in itertools.product(*starts)])      # [num_win, nsp, 2]
+    wins = wins[np.argsort(wins[:, buffer_dim, 0], kind="mergesort")]
+    num_win = len(wins)
+    along = wins[:, buffer_dim]
+    _, counts = np.unique(along[:, 0], return_counts=True)
+    b_ends = np.cumsum(counts).tolist()
+    x = [0, *b_ends][:: min(len(b_ends), int(buffer_steps))]
+    if x[-1] < b_ends[-1]:
+        x.append(b_ends[-1])
+    groups = [(x[i], x[i + 1]) for i in range(len(x) - 1)]
+
+    if patch == tuple(roi) and roi_weight_map is not None:
+        imp = roi_weight_map
+    else:
+        imp = compute_importance_map(patch, mode=mode, sigma_scale=sigma_scale, dtype=dtype)
+    if imp.dim() == nsp:
+        imp = imp[None, None]
+    imp = imp.to(dtype)
+
+    output = count = None
+    for b in range(batch):
+        for g0, g1 in groups:
+            c_start, c_end = int(along[g0, 0]), int(along[g1 - 1, 1])
+            buf = None
+            for i0 in range(g0, g1, sw_batch_size):
+                idx = range(i0, min(i0 + sw_batch_size, g1))
+                sl = [tuple(slice(int(a), int(e)) for a, e in wins[i]) for i in idx]
+                win = torch.cat([inputs[(slice(b, b + 1), slice(None)) + s] for s in sl]) if sw_batch_size > 1 else inputs[(slice(b, b + 1), slice(None)) + sl[0]]
+                seg = predictor(win)
+                if not isinstance(seg, torch.Tensor):
+                    raise ValueError("oracle: the buffered schedule is restated for single-tensor predictors")
+                if buf is None:
+                    sp = list(image_size)
+                    sp[buffer_dim] = c_end - c_start
+                    buf = torch.zeros([1, seg.shape[1], *sp], dtype=dtype)
+                for p, s in zip(seg, sl):
+                    s = list(s)
+                    off = s[buffer_dim].start - c_start
+                    s[buffer_dim] = slice(off, off + roi[buffer_dim])
+                    buf[(slice(0, 1), slice(None), *s)] += p * imp
+            if output is None:
+                output = torch.zeros([batch, buf.shape[1], *image_size], dtype=dtype)
+                count = torch.zeros([1, 1, *image_size], dtype=dtype)
+                for i in range(num_win):
+                    count[(slice(None), slice(None), *(slice(int(a), int(e)) for a, e in wins[i]))] += imp
+            o = [slice(b, b + 1), slice(None)] + [slice(None)] * nsp
+            o[buffer_dim + 2] = slice(c_start, c_end)
+            output[tuple(o)] += buf
+    output /= count
+    if any(pad):
+        cut = []
+        for sp in range(nsp):
+            si = nsp - sp - 1
+            cut.insert(0, slice(pad[sp * 2], pad[sp * 2] + orig_size[si]))
+        output = output[(slice(None), slice(None), *cut)]
+    return output

@@ -210,6 +210,38 @@ def case_blend_only_vs_golden(device):
     assert i >= 5
 
 
+def case_buffered_blend_vs_golden(device):
+    """`buffer_steps` / `buffer_dim`: the reference's buffered schedule sums in another order than its plain path; the product reproduces that
+    order -- bit-exact against the REAL reference's buffered runs (tests/golden/buffered.npz: every buffered axis, several group sizes, padding, 2-D, batch 2)."""
+    from monai_amd.inferers import SlidingWindowInferer, sliding_window_inference
+
+    g = np.load(os.path.join(GOLDEN, "buffered.npz"))
+
+    def toy(k_out):
+        return lambda x: torch.cat([torch.sin(x[:, :1] * (1.0 + 0.37 * k)) + 0.05 * k * x[:, :1] for k in range(k_out)], dim=1)
+
+    i, differing = 0, 0
+    while f"buf_{i}_shape" in g:
+        shape = tuple(int(v) for v in g[f"buf_{i}_shape"])
+        torch.manual_seed(int(g[f"buf_{i}_seed"]))
+        x = torch.rand(shape)
+        cpu_toy = toy(int(g[f"buf_{i}_k"]))
+        pred = (lambda w: cpu_toy(w.cpu()).to(w.device))      # the predictor's own arithmetic (sin) on the host: only the blend is under test
+        kw = dict(overlap=float(g[f"buf_{i}_ov"]), mode=str(g[f"buf_{i}_mode"]), padding_mode="constant", cval=-0.5)
+        roi, sw = tuple(int(v) for v in g[f"buf_{i}_roi"]), int(g[f"buf_{i}_sw"])
+        steps, dim = int(g[f"buf_{i}_steps"]), int(g[f"buf_{i}_dim"])
+        y = sliding_window_inference(x.to(device), roi, sw, pred, buffer_steps=steps, buffer_dim=dim, **kw)
+        assert np.array_equal(y.cpu().numpy(), g[f"buf_{i}_out"]), f"buffered case {i}: not bit-identical to the reference's buffered run"
+        if i == 1:      # the inferer object: constructor arguments and per-call overrides (inferer.py:525-527)
+            y2 = SlidingWindowInferer(roi, sw, buffer_steps=steps, buffer_dim=dim, **kw)(x.to(device), pred)
+            y3 = SlidingWindowInferer(roi, sw, **kw)(x.to(device), pred, buffer_steps=steps, buffer_dim=dim)
+            assert torch.equal(y2, y) and torch.equal(y3, y)
+        differing += int(g[f"buf_{i}_differs_from_plain"])
+        i += 1
+    assert i >= 8 and differing > 1000      # the goldens do exercise a different summation order
+    return i
+
+
 def case_narrow_and_host_inputs(device):
     """half / bfloat16 volumes: computed in fp32, returned in the caller's dtype (== the fp32 result rounded once).  On a
     real device: a CPU volume with sw_device= the ROCm device returns on the CPU with the device result's bits."""

@@ -52,6 +52,11 @@ def test_process_fn_bitwise_vs_reference(emu):
     ec.case_process_fn_vs_golden("cpu")
 
 
+def test_buffered_schedule_bitwise_vs_reference(emu):
+    """row a7: `buffer_steps` / `buffer_dim` reproduce the summation order of the reference's buffered schedule"""
+    assert ec.case_buffered_blend_vs_golden("cpu") >= 8
+
+
 def test_slabwise_equals_whole(emu):
     print(ec.case_slabwise_equals_whole("cpu"))
 

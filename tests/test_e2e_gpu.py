@@ -194,6 +194,11 @@ def test_full_size_properties_512():
     assert s2 == s1 and torch.equal(b.argmax(1), lab), f"two runs differ: sums {s1!r} vs {s2!r}, {int((b.argmax(1) != lab).sum())} labels"
 
 
+def test_buffered_schedule_bitwise_vs_reference():
+    """`buffer_steps` / `buffer_dim` -- the summation order of the reference's buffered schedule, bit for bit (tests/golden/buffered.npz)"""
+    assert ec.case_buffered_blend_vs_golden(DEV) >= 8
+
+
 def test_unetr_small_vs_reference():
     print(ec.case_unetr_small_vs_golden(DEV))
 

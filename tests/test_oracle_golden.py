@@ -381,3 +381,26 @@ def test_synthetic_ct_volume_matches_reference(golden_dir):
     for idx, val in zip(g["bench_probe_idx"], g["bench_probe_val"]):
         assert vol[tuple(idx)] == val
     assert hashlib.sha256(np.ascontiguousarray(vol).tobytes()).digest() == bytes(g["bench_sha256"])
+
+
+def test_oracle_buffered_schedule_bitwise_vs_reference(golden_dir):
+    """oracle/sliding_window.py:_buffered against the REAL reference's buffered runs (tests/golden/make_golden_buffered.py): bit-exact"""
+    import numpy as np
+    import torch
+
+    from oracle import sliding_window as osw
+
+    g = np.load(os.path.join(golden_dir, "buffered.npz"))
+
+    def toy(k_out):
+        return lambda x: torch.cat([torch.sin(x[:, :1] * (1.0 + 0.37 * k)) + 0.05 * k * x[:, :1] for k in range(k_out)], dim=1)
+
+    i = 0
+    while f"buf_{i}_shape" in g:
+        torch.manual_seed(int(g[f"buf_{i}_seed"]))
+        x = torch.rand(tuple(int(v) for v in g[f"buf_{i}_shape"]))
+        y = osw.sliding_window_inference(x, tuple(int(v) for v in g[f"buf_{i}_roi"]), int(g[f"buf_{i}_sw"]), toy(int(g[f"buf_{i}_k"])), overlap=float(g[f"buf_{i}_ov"]),
+                                         mode=str(g[f"buf_{i}_mode"]), padding_mode="constant", cval=-0.5, buffer_steps=int(g[f"buf_{i}_steps"]), buffer_dim=int(g[f"buf_{i}_dim"]))
+        assert np.array_equal(y.numpy(), g[f"buf_{i}_out"]), f"buffered case {i}"
+        i += 1
+    assert i >= 8
