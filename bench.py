@@ -70,9 +70,14 @@ def sub_volume_extents(size: int, roi: int, windows: int):
 def _host_layout():
     """(procs, threads): the oracle's per-window network runs in `procs` worker processes of `threads` ATen threads each (oracle/parallel_predict.py) -- one
     oneDNN thread group does not scale beyond ~32 threads (a 256-thread group measured SLOWER than 32 on the GPU boxes of rounds 1-3), several groups do"""
-    ncpu = os.cpu_count() or 1
+    try:
+        ncpu = len(os.sched_getaffinity(0))          # the threads this process may run on (a container's cpuset), not the machine's count
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    env = os.environ.get("MONAI_AMD_BENCH_CPU_PROCS")
     threads = min(32, ncpu)
-    return max(1, min(8, ncpu // threads)), threads, ncpu
+    procs = int(env) if env else max(1, min(8, ncpu // threads))
+    return max(1, procs), threads, ncpu
 
 
 def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer, full_out, budget_s: float, more=None):

@@ -203,6 +203,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const long long xstep = (long long)H2_KC * DHW, xwrap = HW - (long long)(NCH - 1) * H2_KC * DHW;
     float xin[H2_SLOTS][4];
     u32x4 win[H2_WSLOTS];
+    const float m1 = h2_minus_one();
     f32x4 nq_a = {1.0f, 1.0f, 1.0f, 1.0f}, nq_b = {0.0f, 0.0f, 0.0f, 0.0f}, nq_s = nq_a;      // records of the quad being converted
 
     // ---- the pieces of a step's staging work; each is branch-free so that it can be interleaved with the step's MFMAs ----
@@ -236,13 +237,13 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_CONV(J)                                                                                 \
     {                                                                                                 \
         u32x2* xh_ = reinterpret_cast<u32x2*>(xs + (bcur ^ 1) * H2_XB);                               \
-        _Float16 h_[4], l_[4];                                                                        \
+        float y_[4];                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-            float y_ = xin[J][i];                                                                     \
-            if (NRM) y_ = act(y_, nq_a[i], nq_b[i], nq_s[i]);                                         \
-            h2_split(y_, h_[i], l_[i]);                                                               \
+            y_[i] = xin[J][i];                                                                        \
+            if (NRM) y_[i] = act(y_[i], nq_a[i], nq_b[i], nq_s[i]);                                   \
         }                                                                                             \
-        const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
+        f16x2 h01_, h23_, l01_, l23_;       /* round 4: pairs -- one v_cvt_pk_f16_f32 + two v_fma_mix per pair of values instead of four instructions per value: the same bits */ \
+        h2_split_pair(y_[0], y_[1], m1, h01_, l01_); h2_split_pair(y_[2], y_[3], m1, h23_, l23_);     \
         xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
         xh_[loff[J] + 2 * H2_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
     }
