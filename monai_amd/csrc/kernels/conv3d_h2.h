@@ -93,7 +93,8 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 
 // two values at once, in the form the ISA has instructions for: hi pair = ONE v_cvt_pk_f16_f32, each residual v - hi = ONE v_fma_mix_f32 (the fp16 half is widened
 // inside the instruction: fma(hi, -1, v) rounds once, exactly like v - (float)hi), lo pair = ONE v_cvt_pk_f16_f32 -- 2 instead of 4 instructions per value; the
-// same bits as h2_split
+// same bits as h2_split.  Measured in round 4 (profiles/r04_h2_split_pair_ab.txt): in conv3d_h2z.h -1 % time; in THIS file's kernel 0 ... +8 % (48^3 level: the
+// mixlo / mixhi pair writes the two halves of one register, a serial dependency in the middle of the conversion piece) -- so conv3d_k3_h2_kernel keeps h2_split
 // `m1` = -1.0f behind a value barrier (h2_minus_one): with the literal the optimiser rewrites fma(hi, -1, v) into a subtraction and the widening costs its own instruction
 __device__ __forceinline__ float h2_minus_one() {
     float m = -1.0f;
@@ -203,7 +204,6 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const long long xstep = (long long)H2_KC * DHW, xwrap = HW - (long long)(NCH - 1) * H2_KC * DHW;
     float xin[H2_SLOTS][4];
     u32x4 win[H2_WSLOTS];
-    const float m1 = h2_minus_one();
     f32x4 nq_a = {1.0f, 1.0f, 1.0f, 1.0f}, nq_b = {0.0f, 0.0f, 0.0f, 0.0f}, nq_s = nq_a;      // records of the quad being converted
 
     // ---- the pieces of a step's staging work; each is branch-free so that it can be interleaved with the step's MFMAs ----
@@ -237,13 +237,13 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_CONV(J)                                                                                 \
     {                                                                                                 \
         u32x2* xh_ = reinterpret_cast<u32x2*>(xs + (bcur ^ 1) * H2_XB);                               \
-        float y_[4];                                                                                  \
+        _Float16 h_[4], l_[4];                                                                        \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                               \
-            y_[i] = xin[J][i];                                                                        \
-            if (NRM) y_[i] = act(y_[i], nq_a[i], nq_b[i], nq_s[i]);                                   \
+            float y_ = xin[J][i];                                                                     \
+            if (NRM) y_ = act(y_, nq_a[i], nq_b[i], nq_s[i]);                                         \
+            h2_split(y_, h_[i], l_[i]);                                                               \
         }                                                                                             \
-        f16x2 h01_, h23_, l01_, l23_;       /* round 4: pairs -- one v_cvt_pk_f16_f32 + two v_fma_mix per pair of values instead of four instructions per value: the same bits */ \
-        h2_split_pair(y_[0], y_[1], m1, h01_, l01_); h2_split_pair(y_[2], y_[3], m1, h23_, l23_);     \
+        const f16x2 h01_ = {h_[0], h_[1]}, h23_ = {h_[2], h_[3]}, l01_ = {l_[0], l_[1]}, l23_ = {l_[2], l_[3]}; \
         xh_[loff[J]] = u32x2{__builtin_bit_cast(unsigned, h01_), __builtin_bit_cast(unsigned, h23_)}; \
         xh_[loff[J] + 2 * H2_XV] = u32x2{__builtin_bit_cast(unsigned, l01_), __builtin_bit_cast(unsigned, l23_)}; \
     }

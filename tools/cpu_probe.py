@@ -30,7 +30,8 @@ for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
     if os.path.exists(f):
         print(f, open(f).read().strip())
 print(subprocess.run("lscpu | grep -E 'Model name|Socket|Core|Thread|NUMA node' | head -8", shell=True, capture_output=True, text=True).stdout)
-for threads, procs in ((32, 1), (32, 2), (32, 4), (16, 8), (64, 1)):
+cfgs = [(int(a), int(b)) for a, b in (c.split("x") for c in os.environ.get("PROBE", "16x1,8x2,4x4,2x8,16x2,8x4,4x8,8x8").split(","))]      # threads x procs
+for threads, procs in cfgs:
     t0 = time.perf_counter()
     ps = [subprocess.Popen([sys.executable, __file__, "--worker", str(threads), "2"], stdout=subprocess.PIPE, text=True) for _ in range(procs)]
     per = [float(next(ln for ln in p.communicate()[0].splitlines() if ln.startswith("WORKER")).split()[1]) for p in ps]
