@@ -99,8 +99,9 @@ def _host_layout():
 
 
 def HOST_LAYOUT_UNDER_QUOTA(cpus: int):
-    """(threads, procs) under a CPU quota of `cpus`: measured on the round-4 boxes (profiles/r04_cpu_probe_v2.txt)"""
-    return 16, 8
+    """(threads, procs) under a CPU quota of `cpus`: many small workers -- measured on the round-4 boxes (profiles/r04_cpu_probe_v2.txt, quota 16 of 256 threads):
+    8 x 2 threads 5.6 windows/s, 8 x 4: 5.4, 4 x 4: 4.2, 2 x 8: 2.5, 1 x 16: 1.4, 1 x 32: 1.5 (a group wider than its share of the quota is throttled as a whole)"""
+    return 2, max(1, cpus // 2)
 
 
 def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer, full_out, budget_s: float, more=None):

@@ -135,7 +135,7 @@ def _worker_n(rank, world, port, shape, roi, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [3, 4])
+@pytest.mark.parametrize("world", [3, pytest.param(4, marks=pytest.mark.heavy_emu)])      # world 4: MONAI_AMD_HEAVY_EMU=1 (four emulator processes; bench.py --gpus 4 runs in test_bench_harness.py)
 def test_window_sharding_world_sizes_3_and_4(world):
     shape, roi = (1, 1, 96, 24, 16), (32, 16, 16)    # 5 x 2 x 1 = 10 windows
     mgr = mp.Manager()
