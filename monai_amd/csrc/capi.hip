@@ -782,17 +782,6 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
         if (var == 3 && x2ok) { hipLaunchKernelGGL((deconv_k2s2_x2_kernel<4, true>), dim3((unsigned)(out.C / 4), nb2, (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out); return launched("deconv_k2s2"); }
     }
 #endif
-    // round 4: the input column activated once into LDS, the cout groups walked inside the workgroup (kernels/nn_simple.h: deconv_k2s2_lds_kernel) -- up to 64 input
-    // channels (64 KB of LDS per workgroup), Cout a multiple of 4 and at most 256; bit-identical to the kernel below, which keeps the other shapes
-    if (in.C <= 64 && out.C % 4 == 0 && out.C <= 256
-#ifdef MH_DEV_KNOBS
-        && knob_int("MONAI_AMD_DECONV_VAR", 0) != 5          /* 5 = the round-3 kernel (A/B) */
-#endif
-    ) {
-        if (in.C <= 32) hipLaunchKernelGGL((deconv_k2s2_lds_kernel<4, 32>), dim3(nb, (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
-        else hipLaunchKernelGGL((deconv_k2s2_lds_kernel<4, 64>), dim3(nb, (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
-        return launched("deconv_k2s2_lds");
-    }
     // 4 output channels per thread: 2.13 / 0.46 / 0.24 ms on the BasicUNet decoder shapes against 2.42 / 0.56 / 0.27 with 8 (fewer channel planes written at once,
     // twice the workgroups; two voxels per thread with 16-byte stores measured slower: profiles/r03_deconv_variants.json)
     if (out.C % 4 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<4, true>), dim3(nb, (unsigned)(out.C / 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);

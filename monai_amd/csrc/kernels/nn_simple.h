@@ -379,86 +379,6 @@ deconv_k2s2_kernel(Tensor in, const float* __restrict__ w, const float* __restri
     }
 }
 
-// The same transposed convolution with the workgroup's 256 input voxels x Cin channels ACTIVATED ONCE into LDS (a private column per thread: no barrier) and the
-// output channels walked in groups of COT inside the workgroup.  deconv_k2s2_kernel runs Cout / COT workgroups per voxel tile, each re-reading and re-activating the
-// whole input column through L1 / L2: at 32 -> 32 channels that is 8 x 0.9 GB of input traffic next to the 7.25 GB it writes per 64 windows -- the traffic of a
-// device copy for a kernel that should be a pure write stream (3.1 TB/s of stores = 0.39 of HBM in round 3).  Same arithmetic in the same order
-// (bias, then channels ascending, fused multiply-adds): identical bits.  LDS = Cin KB per workgroup (the launcher takes this kernel up to 64 channels).
-template <int COT, int CK>       // CK: input channels the LDS column holds (32 | 64)
-__global__ void __launch_bounds__(256)
-deconv_k2s2_lds_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
-    __shared__ float dx_s[CK * 256];                 // [Cin <= CK][256]
-    __shared__ unsigned wmax_s[64][4];               // [cout group][wave]: max |value| written, folded into the bound records at the end
-    const int Di = in.D, Hi = in.H, Wi = in.W, Cin = in.C, Cout = out.C;
-    const long long ivol = (long long)Di * Hi * Wi;
-    const long long idx0 = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y, tid = threadIdx.x;
-    const bool valid = idx0 < ivol;                  // lanes past the volume recompute its last voxel and store nothing
-    const long long idx = valid ? idx0 : ivol - 1;
-    const int x = (int)(idx % Wi);
-    const long long t = idx / Wi;
-    const int y = (int)(t % Hi), z = (int)(t / Hi);
-    const float* src = in.data + (long long)n * in.n_stride + idx;
-    constexpr int CB = 8;                            // loads in flight
-    for (int c0 = 0; c0 < Cin; c0 += CB) {
-        float v[CB];
-#pragma unroll
-        for (int c = 0; c < CB; ++c) v[c] = src[(long long)min(c0 + c, Cin - 1) * ivol];
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-            if (c0 + c < Cin) {
-                const float4 a = load_nrm(in, n, c0 + c);
-                dx_s[(c0 + c) * 256 + tid] = act(v[c], a.x, a.y, a.z);
-            }
-    }
-    const int Ho = out.H, Wo = out.W;
-    const long long ovol = (long long)out.D * Ho * Wo;
-    float* dst = out.data + (long long)n * out.n_stride + ((long long)(2 * z) * Ho + 2 * y) * Wo + 2 * x;
-    for (int co0 = 0; co0 < Cout; co0 += COT) {
-        float acc[COT][8];
-#pragma unroll
-        for (int j = 0; j < COT; ++j) {
-            const float bj = bias ? bias[co0 + j] : 0.0f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc[j][k] = bj;
-        }
-        for (int ci = 0; ci < Cin; ++ci) {
-            const float va = dx_s[ci * 256 + tid];
-            const float* wr = w + ((long long)ci * Cout + co0) * 8;      // block-uniform: scalar loads
-#pragma unroll
-            for (int j = 0; j < COT; ++j)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[j][k] = fmaf(va, wr[j * 8 + k], acc[j][k]);
-        }
-        if (valid) {
-#pragma unroll
-            for (int j = 0; j < COT; ++j)
-#pragma unroll
-                for (int dz = 0; dz < 2; ++dz)
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-                        *reinterpret_cast<float2*>(dst + (long long)(co0 + j) * ovol + ((long long)dz * Ho + dy) * Wo) = make_float2(acc[j][dz * 4 + dy * 2], acc[j][dz * 4 + dy * 2 + 1]);
-        }
-        if (out.nrm) {      // the group's maximum bounds each of its channels (as deconv_k2s2_kernel): one wave reduction per group, the waves meet at the end
-            unsigned m = 0u;
-#pragma unroll
-            for (int j = 0; j < COT; ++j)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) m = max(m, abs_bits(acc[j][k]));
-            m = wave_umax(valid ? m : 0u);
-            if ((tid & 63) == 0) wmax_s[co0 / COT][tid >> 6] = m;
-        }
-    }
-    if (out.nrm) {
-        __syncthreads();
-        if (tid < Cout) {
-            const unsigned* r = wmax_s[tid / COT];
-            const unsigned m = max(max(r[0], r[1]), max(r[2], r[3]));
-            if (m != 0u) atomicMax(reinterpret_cast<unsigned*>(bound_slot(out, n, tid)), m);
-        }
-    }
-}
-
 #ifdef MH_DEV_KNOBS
 // Measurement variant (dev builds only, tools/deconv_bench.py): two x-adjacent input voxels per thread, COT output channels, 16-byte stores
 // (four consecutive outputs of a row); SWAP: the cout group is the fastest workgroup index.
