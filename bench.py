@@ -16,12 +16,16 @@ BASELINE.json).  Rank 0 prints ONE JSON line:
                 MFMA peak of the instruction it issues (a true fraction); the convolution's own flops are `algorithmic_tflops`;
   roofline_hbm  the blend: 20.38 GB of algorithmic traffic (SURVEY.md 8d) / its launch time, against the 8 TB/s spec;
   cpu_baseline  the CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
-                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on a 288^3 corner of the
-                benchmark volume = 125 windows on the host cores, extrapolated per window; the same sub-volume goes through the
-                HIP path and `parity_vs_gpu` reports the headline parity rule (oracle/parity.py);
+                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on the WHOLE benchmark volume --
+                all 1000 windows, the per-window network in worker processes (oracle/parallel_predict.py), the blend in the reference's
+                window order -- timed on the host cores; `parity_vs_gpu` is the headline parity rule (oracle/parity.py) over every
+                output voxel of the timed steps' result (134 217 728 voxels x 5 logits).  A probe batch prices the leg first: if it would
+                exceed --cpu-budget-s (900 s) the largest corner sub-volume that fits is taken and the line says so;
   extra         (N = 1) fp32_exact: the same workload with the exact-fp32 convolution kernels (config CONV_ALGO "fp32") and its parity
-                on the same 125 windows; config3: UNETR ViT-B/16 on the same volume (attention kernel's MFMA rate, one-window parity
-                vs the oracle); config4: Spacing + GaussianSmooth on 4 x 512^3 (kernel times against 8 TB/s, parity on a 128^3 volume).
+                against the same whole-volume reference; config3: UNETR ViT-B/16 on the same volume (attention kernel's MFMA rate, parity
+                of the complete inferer on a 27-window corner vs the oracle, the oracle's CPU time per window); config4: Spacing +
+                GaussianSmooth on 4 x 512^3 (kernel times against 8 TB/s and against a device copy measured in the same run, parity on
+                a 128^3 volume, the reference path's CPU time on one 512^3 volume with the product's full-size result against it).
 """
 
 from __future__ import annotations
