@@ -13,7 +13,6 @@
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_h2.h"
 #include "kernels/conv3d_h2z.h"
-#include "kernels/conv3d_h2zw.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -407,9 +406,6 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // configuration MH_CFG_H2Z: the split-precision arithmetic behind a Winograd F(2, 3) transform along z (kernels/conv3d_h2z.h): 2 instead of 3 fp16 matrix
 // instructions per fp32 multiply-add of the direct form; regions of 8 x 32 outputs, pairs of output planes (even z-chunks); same tolerance class as MH_CFG_H2
 #define MH_CFG_H2Z (MH_NUM_CFG + 4)
-#ifndef MH_H2Z_WIDE_REGS
-#define MH_H2Z_WIDE_REGS 1      // 1: the four-wave / 512-register form of the z-Winograd kernel (conv3d_h2zw.h); 0: the eight-wave form (conv3d_h2z.h)
-#endif
 static inline int c1_chunks(int D) { return D >= 48 ? D / 24 : 1; }
 static inline int c1_zchunk(int D) { return cdiv(D, c1_chunks(D)); }
 static inline int c1_blocks(int D, int H, int W) { return cdiv(W, C1_TX) * cdiv(H, C1_TY) * cdiv(D, c1_zchunk(D)); }
@@ -624,14 +620,6 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-        // two forms of the same kernel (identical results): four waves of 512 registers owning two rows each (conv3d_h2zw.h), or eight waves of 256 (conv3d_h2z.h)
-        if (MH_H2Z_WIDE_REGS) {
-            if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2zw_kernel<true, true>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-            else if (stats) hipLaunchKernelGGL((conv3d_k3_h2zw_kernel<true, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-            else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2zw_kernel<false, true>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-            else hipLaunchKernelGGL((conv3d_k3_h2zw_kernel<false, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-            return launched("conv3d_k3_h2zw");
-        }
         if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<true, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
         else if (stats) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);

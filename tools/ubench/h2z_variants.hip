@@ -5,11 +5,10 @@
 // Real (pseudo-random) data only: constant operands raise the matrix pipe's clock (conv3d_h2.h header).
 #include <hip/hip_runtime.h>
 #include <cmath>
-#include <cstring>
 #include <cstdio>
 #include <vector>
 #include "monai_amd.h"
-#include "kernels/conv3d_h2zw.h"
+#include "kernels/conv3d_h2z.h"
 using namespace mh;
 
 int main(int argc, char** argv) {
@@ -72,10 +71,7 @@ int main(int argc, char** argv) {
     const dim3 grid(nblk * N * (K / H2_CN)), grid2(znblk * N * (K / H2_CN));
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    float best = 1e9f, best2 = 1e9f, best3 = 1e9f;
-    float* y3;
-    hipMalloc(&y3, sizeof(float) * N * K * vox);
-    Tensor out3{y3, (long long)K * (long long)vox, nullptr, 0, N, K, E, E, E};
+    float best = 1e9f, best2 = 1e9f;
     for (int it = 0; it < 4; ++it) {
         float ms;
         hipEventRecord(e0);
@@ -96,22 +92,6 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         hipEventElapsedTime(&ms, e0, e1);
         if (it && ms < best2) best2 = ms;
-        hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2zw_kernel<true, true>), grid2, dim3(256), 0, 0, in, reinterpret_cast<const uint4*>(packed2), tail2, bias, out3, stats2, zbxn, zbyn, zzc, znblk);
-        hipEventRecord(e1);
-        hipDeviceSynchronize();
-        hipEventElapsedTime(&ms, e0, e1);
-        if (it && ms < best3) best3 = ms;
-    }
-    {       // the four-wave form must reproduce the eight-wave form bit for bit
-        std::vector<float> p((size_t)K * vox), q((size_t)K * vox);
-        size_t nd = 0;
-        for (int n : {0, N - 1}) {
-            hipMemcpy(p.data(), y2 + (size_t)n * K * vox, sizeof(float) * K * vox, hipMemcpyDeviceToHost);
-            hipMemcpy(q.data(), y3 + (size_t)n * K * vox, sizeof(float) * K * vox, hipMemcpyDeviceToHost);
-            for (size_t i = 0; i < p.size(); ++i) nd += memcmp(&p[i], &q[i], 4) != 0;
-        }
-        printf("%-24s z-Winograd, four waves x 512 registers: %.3f ms = %.3fx the direct kernel, %.3fx the eight-wave form; words differing from it: %zu\n", argc > 2 ? argv[2] : "default", best3, best / best3, best2 / best3, nd);
     }
     // difference of the two kernels on window 0 and the last window (every cout, every voxel)
     double dmax = 0.0, vmax = 0.0;
