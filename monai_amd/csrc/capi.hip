@@ -328,6 +328,14 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
     hipStream_t s = (hipStream_t)stream;
 #define MH_BM(KT, G_, NT_, SEP_) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms)
 #ifdef MH_DEV_KNOBS
+    if (const int ks_ = knob_int("MONAI_AMD_BLEND_KSPLIT", 0)) {      // A/B: one class per thread (grid.y = K): 5x the threads, 8 ... 27 read streams per wave instead of 40 ... 135
+        const dim3 gk(nb, (unsigned)K);
+        if (ks_ == 1) { if (imp_factored) hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, MH_BLEND_G, false, true>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms);
+                        else hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, MH_BLEND_G, false, false>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
+        else { if (imp_factored) hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, 4, false, true>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms);
+               else hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, 4, false, false>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
+        return launched("sw_blend_mosaic");
+    }
     if (K == 5 && !imp_factored) {        // A/B of the window-batch size and of non-temporal accesses on the benchmark shape (tools/blend_bench.py with the -DMH_DEV_KNOBS library)
         const int g_ = knob_int("MONAI_AMD_BLEND_G", MH_BLEND_G), nt_ = knob_int("MONAI_AMD_BLEND_NT", 0);
         if (g_ == 1 && !nt_) { MH_BM(5, 1, false, false); return launched("sw_blend_mosaic"); }

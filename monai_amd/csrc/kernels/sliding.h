@@ -431,6 +431,7 @@ __global__ void __launch_bounds__(256)
 sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K, int D, int H, int W, int rd,
                        int rh, int rw, RegGrid g, Mosaic ms) {
     constexpr int VEC = 4;
+    const int k0 = (int)blockIdx.y * KT;             // channel group of this workgroup (grid.y = K / KT: 1 when a thread owns all classes)
     const int wv = W / VEC;
     const long long total = (long long)D * H * wv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -487,7 +488,7 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
             }
 #pragma unroll
             for (int k = 0; k < KT; ++k) {
-                const f32x4* lp_ = reinterpret_cast<const f32x4*>(logits + base + (long long)k * cs);
+                const f32x4* lp_ = reinterpret_cast<const f32x4*>(logits + base + (long long)(k0 + k) * cs);
                 const f32x4 a = NT ? __builtin_nontemporal_load(lp_) : *lp_;
                 lv[b][k][0] = a[0]; lv[b][k][1] = a[1]; lv[b][k][2] = a[2]; lv[b][k][3] = a[3];
             }
@@ -507,7 +508,7 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
             }
         }
     }
-    float* op = out + ((long long)z * H + y) * W + x;
+    float* op = out + (long long)k0 * vox + ((long long)z * H + y) * W + x;
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const f32x4 r = {__fdiv_rn(acc[k][0], cnt[0]), __fdiv_rn(acc[k][1], cnt[1]), __fdiv_rn(acc[k][2], cnt[2]), __fdiv_rn(acc[k][3], cnt[3])};
