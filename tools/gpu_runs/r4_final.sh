@@ -16,6 +16,6 @@ try:
 except Exception as e:
     print("bench failed", e); print(open("gpurun_out/r4final/bench_line.err").read()[-3000:])
 PY
-cd /tmp && rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof -o bench -- python $OLDPWD/bench.py --steps 4 --warmup 1 --cpu-windows 0 --no-extra > $OLDPWD/$O/prof_bench.json 2> $OLDPWD/$O/prof_bench.err; cd $OLDPWD
-find $O/prof -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; head -25 $O/kernel_stats.csv | cut -c1-200
-find $O/prof -type f -size +2M -delete
+timeout 500 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python bench.py --steps 4 --warmup 1 --cpu-windows 0 --no-extra > $O/prof_bench.json 2> $O/prof_bench.err
+find $O/prof -name "*.db" | head -1 | xargs -I{} python tools/rocpd_stats.py {} > $O/bench_kernel_trace_stats.txt 2>&1; rm -rf $O/prof
+head -22 $O/bench_kernel_trace_stats.txt | cut -c1-175
