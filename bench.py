@@ -272,21 +272,33 @@ def conv_roofline(spans, steps: int, ms: float, roi: int):
 
 
 def device_copy_gbps(dev) -> float:
-    """read + write rate of a plain 1 GiB device-to-device copy on this box, measured in this run: the practical ceiling of any read-once / write-once stream,
-    printed next to every HBM-bound `frac` (`frac_of_copy_ceiling`) -- the 8 TB/s spec is not reachable by a copy on this chip (0.75-0.8 of it)"""
+    """read + write rate of a plain 1 GiB stream on this box, measured in this run: the practical ceiling of any read-once / write-once kernel, printed next to
+    every HBM-bound `frac` (`frac_of_copy_ceiling`) -- the 8 TB/s spec is not reachable by a copy on this chip.  The faster of (a) torch's device-to-device copy and
+    (b) this library's own 16-bytes-per-lane point-wise stream kernel (mh_scale_intensity_range_f32: 4 B read + 4 B written per voxel; 6.3 TB/s in round 2, the float4
+    copy of tools/ubench/hbm_stream.hip: 6.15)"""
+    from monai_amd import _lib
+
     n = 1 << 28
     a = torch.empty(n, dtype=torch.float32, device=dev).normal_()
     b = torch.empty_like(a)
-    for _ in range(2):
-        b.copy_(a)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        b.copy_(a)
-    e1.record()
-    torch.cuda.synchronize()
-    return 5 * 2.0 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    stream = _lib.stream_ptr(a)
+
+    def own():
+        _lib.lib().call("mh_scale_intensity_range_f32", _lib.ptr(a), _lib.ptr(b), n, 0.0, 1.0, 0, 0.0, 0.0, 0, 0.0, 0, 0.0, stream)
+
+    best = 0.0
+    for fn in (lambda: b.copy_(a), own):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, 5 * 2.0 * 4 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    return best
 
 
 def blend_roofline(spans, mosaic: bool):
@@ -418,7 +430,8 @@ def extra_config4(dev):  # noqa: C901
     res = {"workload": f"{n} x {e}^3 fp32 volumes (seeds 0..{n - 1}) in HBM: Spacing(pixdim 1, bilinear, border; fp64 coordinates) -> {list(out.shape)}, GaussianSmooth(sigma=1)", "runs": []}
     copy_gbps = device_copy_gbps(dev)
     res["device_copy_GBps"] = copy_gbps
-    res["device_copy_note"] = "a 1 GiB device-to-device copy (read + write) measured in this run: the practical streaming ceiling; frac = of the 8 TB/s spec, frac_of_copy_ceiling = of this"
+    res["device_copy_note"] = ("a 1 GiB read + write stream measured in this run (the faster of torch's device copy and this library's 16-bytes-per-lane point-wise kernel): "
+                               "the practical streaming ceiling; frac = of the 8 TB/s spec, frac_of_copy_ceiling = of this")
     ms = timeit(lambda: [sp(v) for v in vols])
     nb = 4.0 * n * (e ** 3 + out.numel())
     res["runs"].append({"op": "Spacing transform (4 volumes, host-side affine algebra included)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
@@ -462,7 +475,8 @@ def extra_config4(dev):  # noqa: C901
     # CPU baseline: the reference path of both transforms -- restated with the same ATen operators (oracle/resample.py: img.to(dtype) -> normalised theta ->
     # F.affine_grid + F.grid_sample -> float32; separable_filtering: F.pad + depthwise F.conv3d per axis) -- on ONE 512^3 volume on the host cores, and the product's
     # result for that volume against it at full size
-    _, threads, ncpu = _host_layout()
+    procs_, threads_, ncpu = _host_layout()
+    threads = min(32, max(threads_, procs_ * threads_))       # ONE process here: the whole share of the host (16 threads under the boxes' 16-CPU quota)
     torch.set_num_threads(threads)
     v0 = vols[0]
     x0 = v0.as_tensor().cpu()
