@@ -471,7 +471,8 @@ int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
-    if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
+    // round 4: the last cout group of the direct split kernel may be half full (Cout % 16 == 0 beyond 32: 48, 80, ... -- SwinUNETR(feature_size 48)'s full-resolution levels)
+    if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
     if (cfg == MH_CFG_H2Z) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= HZ_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
@@ -520,7 +521,7 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
 
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
-    if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
+    if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * cdiv(Cout, H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg == MH_CFG_H2Z) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * (4 * HZ_WP) * 4 + H2_TAIL;   // four transformed positions x two fp16 pieces per chunk + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
@@ -536,7 +537,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
         return launched("conv3d_k3_wino2d_pack");
     }
     if (cfg == MH_CFG_H2) {
-        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0");
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0, Cout >= 32");
         const int64_t slab_floats = mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL;
         float* tail = packed + slab_floats;
         if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)slab_floats, (hipStream_t)stream) != hipSuccess)
@@ -636,7 +637,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     }
     if (cfg == MH_CFG_H2) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
-            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 32 == 0, W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
+            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0 (>= 32), W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
                         in.C, out.C, in.D, in.H, in.W);
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
             return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs 16-byte aligned output and weights");
@@ -645,7 +646,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const bool wide = h2_wide(out.H, out.W);
         const int bxn = wide ? cdiv(out.W, 32) : cdiv(out.W, H2_B), byn = wide ? cdiv(out.H, 8) : cdiv(out.H, H2_B), zc = h2_zchunk(out.D, out.H, out.W);
         const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
-        const long long total = (long long)nblk * (out.C / H2_CN) * out.N;
+        const long long total = (long long)nblk * cdiv(out.C, H2_CN) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);

@@ -138,8 +138,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const int NCH = Cin / H2_KC;                              // steps per input plane (the launcher requires Cin % 16 == 0)
 
     // launch geometry of conv3d_wino2d.h: 1-D over (window, region, cout group), cout group fastest, XCD-aware
-    const unsigned ncg = (unsigned)(Cout / H2_CN);
-    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned ncg = (unsigned)((Cout + H2_CN - 1) / H2_CN);      // round 4: the last group may hold fewer than 32 couts (Cout % 16 == 0: 48, 80, ...): its missing
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);                    // couts have zero weights in the packed slab, their stores and statistics are dropped
     const int cg = (int)(lid % ncg);
     lid /= ncg;
     const unsigned b = lid % nblk;
@@ -274,7 +274,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 
     // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i (WIDE: the wave's one row, x = 8 j + 4 kg + i)
     const int co = cg * H2_CN + r32;
-    const float bco = bias ? bias[co] : 0.0f;
+    const bool cok = co < Cout;
+    const float bco = (bias && cok) ? bias[co] : 0.0f;
     // scale back: 2^-(weight scale exponent) * 2^-e_in as two power-of-two factors (their product may leave fp32's exponent range)
     float inv_a, inv_b;
     {
@@ -287,14 +288,14 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     // Result stores go through a raw buffer over the 32 cout planes of this (sample, cout group): 32-bit byte offsets, and a lane without a voxel
     // (ragged region, no completed plane yet) stores at an offset beyond the buffer, which the hardware drops -- no exec-mask branch, so the
     // epilogue stays inside the scheduling region of the matrix instructions (the launcher keeps 32 planes below 2 GB)
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * H2_CN) * DHW, 0, (int)(H2_CN * DHW * 4), 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * H2_CN) * DHW, 0, (int)(min(H2_CN, Cout - cg * H2_CN) * DHW * 4), 0x00020000);
     constexpr unsigned H2_DROP = 0x80000000u;
     unsigned ooff[4];                                        // byte offset of register group j inside an output plane of cout r32 (or H2_DROP)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xg_ = WIDE ? 8 * j + 4 * kg : j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);
         const int yr_ = WIDE ? 0 : (j >> 1);
-        const bool ok_ = y0 + orow + yr_ < H && x0 + xg_ < W;
+        const bool ok_ = cok && y0 + orow + yr_ < H && x0 + xg_ < W;
         ooff[j] = ok_ ? 4u * (unsigned)((long long)r32 * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
     }
     f32x4 o_[4];                                             // the plane being emitted: its pieces A (scale, bias, store), B1-B3 (statistics) sit in different taps
@@ -479,7 +480,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             red[(wave * H2_CN + r32) * 3] = run.n; red[(wave * H2_CN + r32) * 3 + 1] = run.mean; red[(wave * H2_CN + r32) * 3 + 2] = run.m2;
         }
         __syncthreads();
-        if (tid < H2_CN) {
+        if (tid < H2_CN && cg * H2_CN + tid < Cout) {
             Stat st;
             st.n = 0.0f; st.mean = 0.0f; st.m2 = 0.0f;
 #pragma unroll

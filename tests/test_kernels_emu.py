@@ -183,7 +183,8 @@ def test_conv3d_wino2d(emu, cin, cout, dims, n):
 
 
 # (6, 8, 24), (3, 18, 20), (2, 24, 56), (24, 8, 24) take the 8 x 32 region shape (one / three ragged / 3 x 2 regions / one region in two z-chunks), the others 16 x 16
-H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 48, (5, 16, 16), 2), (48, 80, (3, 8, 24), 1),      # 48 / 80 couts: a half-filled last cout group (round 4)
+            (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
             (32, 32, (24, 8, 24), 1)]
 H2Z_CASES = [(16, 32, (4, 8, 32), 2), (32, 32, (5, 10, 36), 1), (48, 64, (9, 12, 24), 1), (16, 32, (26, 8, 8), 1), (128, 32, (3, 16, 40), 1)]
 @pytest.mark.parametrize("cin,cout,dims,n", H2Z_CASES)

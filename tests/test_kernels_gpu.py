@@ -137,7 +137,8 @@ def test_conv3d_wino2d(cin, cout, dims, n):
 
 
 # (6, 8, 24), (3, 18, 20), (2, 24, 56), (24, 24, 24) take the 8 x 32 region shape, the others 16 x 16
-H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
+H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 48, (5, 16, 16), 2), (48, 80, (3, 8, 24), 1),      # 48 / 80 couts: a half-filled last cout group (round 4)
+            (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
             (128, 128, (24, 24, 24), 2)]
 @pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
 def test_conv3d_fp16_split_precision(cin, cout, dims, n):
