@@ -198,50 +198,28 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const float* __re
     __syncthreads();
     const float* bt = bias_t ? bias_t + (long long)head * S * S : nullptr;
     const float* mk = mask ? mask + (long long)(w % nW) * S * S : nullptr;
-    // round 4: keys in blocks of 8 with ONE running-maximum update per block (9 instead of 16 exponentials per 8 keys, the accumulator rescaled once per block
-    // instead of once per key) and the exponentials as v_exp_f32 on log2-scaled scores (log2(e) folded into q, bias and mask): 36 instead of 68 vector
-    // instructions per (query, key) at HD = 16
-    constexpr int KB = 8;
-    constexpr float LOG2E = 1.44269504088896341f;
     for (int r = tid; r < S; r += 256) {
         float q[HD];
 #pragma unroll
         for (int c4 = 0; c4 < HD / 4; ++c4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(base + (long long)r * C3 + 4 * c4);
-            q[4 * c4] = t[0] * scale * LOG2E; q[4 * c4 + 1] = t[1] * scale * LOG2E; q[4 * c4 + 2] = t[2] * scale * LOG2E; q[4 * c4 + 3] = t[3] * scale * LOG2E;
+            q[4 * c4] = t[0] * scale; q[4 * c4 + 1] = t[1] * scale; q[4 * c4 + 2] = t[2] * scale; q[4 * c4 + 3] = t[3] * scale;
         }
         float m = -INFINITY, l = 0.0f;
         float acc[HD];
 #pragma unroll
         for (int d = 0; d < HD; ++d) acc[d] = 0.0f;
-        for (int j0 = 0; j0 < S; j0 += KB) {
-            float sc[KB];
-            float mb = -INFINITY;
+        for (int j = 0; j < S; ++j) {
+            float sc = 0.0f;
 #pragma unroll
-            for (int jj = 0; jj < KB; ++jj) {
-                const int j = min(j0 + jj, S - 1);          // rows beyond the window: the last row, with a score of -inf (probability exactly 0)
-                float d_ = 0.0f;
+            for (int d = 0; d < HD; ++d) sc = fmaf(q[d], ks[j * HD + d], sc);
+            if (bt) sc += bt[(long long)j * S + r];
+            if (mk) sc += mk[(long long)j * S + r];
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn), pj = expf(sc - mn);
+            l = fmaf(l, corr, pj);
 #pragma unroll
-                for (int d = 0; d < HD; ++d) d_ = fmaf(q[d], ks[j * HD + d], d_);
-                float add = 0.0f;
-                if (bt) add += bt[(long long)j * S + r];
-                if (mk) add += mk[(long long)j * S + r];
-                sc[jj] = j0 + jj < S ? fmaf(add, LOG2E, d_) : -INFINITY;
-                mb = fmaxf(mb, sc[jj]);
-            }
-            const float mn = fmaxf(m, mb);
-            const float corr = exp2f(m - mn);               // first block: exp2(-inf) = 0
-            l *= corr;
-#pragma unroll
-            for (int d = 0; d < HD; ++d) acc[d] *= corr;
-#pragma unroll
-            for (int jj = 0; jj < KB; ++jj) {
-                const int j = min(j0 + jj, S - 1);
-                const float pj = exp2f(sc[jj] - mn);
-                l += pj;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) acc[d] = fmaf(pj, vs[j * HD + d], acc[d]);
-            }
+            for (int d = 0; d < HD; ++d) acc[d] = fmaf(acc[d], corr, pj * vs[j * HD + d]);
             m = mn;
         }
         const float inv = 1.0f / l;
