@@ -61,6 +61,7 @@ class PoolPredictor:
         for s in starts:
             self.num_win *= len(s)
         self.sw_batch = int(sw_batch)
+        self.batch_timeout_s = float(os.environ.get("ORACLE_POOL_BATCH_TIMEOUT_S", "900"))
         if vol.shape[0] != 1:
             raise ValueError("PoolPredictor: one image per call")
         vol = vol.contiguous().share_memory_()
@@ -69,7 +70,7 @@ class PoolPredictor:
         self._it = self._pool.imap(_work, range(0, self.num_win, self.sw_batch), chunksize=1)
 
     def __call__(self, win: torch.Tensor) -> torch.Tensor:
-        out = next(self._it)
+        out = self._it.next(timeout=self.batch_timeout_s)        # a dead worker must not hang the caller: multiprocessing.TimeoutError instead
         if out.shape[0] != win.shape[0]:
             raise RuntimeError(f"PoolPredictor: batch of {win.shape[0]} windows asked, {out.shape[0]} computed (the caller's batching differs from the workers')")
         return out
