@@ -149,7 +149,7 @@ int mh_conv3d_k3_num_configs(void);                    /* highest configuration 
 /* Configuration outside 0 .. num_configs(): z-streaming direct convolution on the fp16 matrix cores in two-piece split
  * precision (kernels/conv3d_h2.h) -- every fp32 operand as hi + lo fp16 pieces, products hi*hi + lo*hi + hi*lo accumulated in
  * fp32: fp32-equivalent results (oracle BasicUNet: max |logit difference| 4e-6, the level of two fp32 summation orders) at 3/16
- * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cin <= 256, Cout % 32 == 0, W % 4 == 0 and D * H * W < 2^24 voxels (the result stores address the
+ * of the fp32 matrix-core cycles.  Needs Cin % 16 == 0, Cin <= 256, Cout % 16 == 0 with Cout >= 32 (round 4: a half-filled last group of 32 couts -- zero weight columns, dropped stores and statistics), W % 4 == 0 and D * H * W < 2^24 voxels (the result stores address the
  * 32 output planes of a workgroup through one raw buffer with 31-bit byte offsets; mh_conv3d_k3_select does not return the configuration beyond,
  * mh_conv3d_k3_f32 answers MH_ERR_UNSUPPORTED).  The activated input of sample n is scaled by the
  * power of two that puts the largest `bound` of its records just below 2^15 (undone exactly in the epilogue), so any finite
@@ -160,7 +160,7 @@ int mh_conv3d_k3_h2_config(void);
 /* The same split-precision arithmetic behind a Winograd F(2, 3) minimal-filtering transform ALONG Z (kernels/conv3d_h2z.h): pairs of output planes from four
  * transformed input planes, 18 instead of 27 multiply-adds per (voxel, cin, cout), the nine in-plane taps direct.  Same reference op (nn.Conv3d k3 p1,
  * monai/networks/blocks/convolutions.py:98-171), same record / bound contract and tolerance class as mh_conv3d_k3_h2_config; needs Cin % 16 == 0, Cin <= 128,
- * Cout % 32 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it under MH_ALGO_AUTO where its 8 x 32 regions cover the plane as well as the direct kernel's. */
+ * Cout % 32 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it under MH_ALGO_H2Z only: measured equal in time to the direct kernel in round 4. */
 int mh_conv3d_k3_h2z_config(void);
 /* Configuration outside 0 .. num_configs(): ONE input channel (the first layer of the networks), packed fp32 vector arithmetic
  * (kernels/conv3d_c1.h) -- exact fp32 like the matrix-core tiles, bound by writing the result instead of by multiplying a zero-padded
