@@ -230,4 +230,158 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Round 4: the same window attention on the fp16 matrix cores -- attention_h2_kernel's streaming split-precision core (keys / values in LDS tiles of 32,
+// online softmax, probabilities kept in the accumulator layout) with the relative position bias and the shift mask ADDED TO THE SCORE TILE before the softmax
+// (one coalesced load per register: bias_t / mask are key-major, the 32 lanes of a tile row are 32 consecutive queries).  Head dims 16 and 32 (SwinUNETR feature
+// sizes 48 / 96): the K Q^T product has HD / 16 k-steps, O^T = V^T P^T one 32-row tile whose rows beyond HD multiply zeros (half of its matrix work is padding at
+// HD = 16 -- still a fraction of the VALU kernel's time: S^2 (2 HD) multiply-adds per head become S^2 / 1024 x 9 matrix instructions).
+// A workgroup = 4 waves = 128 queries of one (window, head).  fp32-equivalent like every split-precision kernel here; q, k, v are LayerNorm-ed projections (|x| ~ 1-10).
+template <int HD>      // 16 | 32
+__global__ void __launch_bounds__(256) window_attention_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t, const float* __restrict__ mask,
+                                                                  float* __restrict__ out, int S, int heads, int nW, float scale) {
+    constexpr int KS = HD / 16, PER = HD / 8;                  // k-steps of K Q^T; floats a thread stages per key row (2 | 4)
+    constexpr int KP = HD + 8, VP = 40;                        // LDS pitches in halves
+    __shared__ __attribute__((aligned(16))) _Float16 ks[2][2][32 * KP];     // [buffer][piece][key][d]
+    __shared__ __attribute__((aligned(16))) _Float16 vs[2][2][32 * VP];     // [buffer][piece][d (rows >= HD stay zero)][permuted key]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, w = blockIdx.z;
+    const int hd = heads * HD;
+    const float* base = qkv + (long long)w * S * 3 * hd + head * HD;
+    const int query = blockIdx.x * 128 + wave * 32 + li;
+    const int qc = min(query, S - 1);
+    const int ntiles = (S + 31) / 32;
+    const float* bt = bias_t ? bias_t + (long long)head * S * S + qc : nullptr;           // + key * S
+    const float* mk = mask ? mask + (long long)(w % nW) * S * S + qc : nullptr;
+
+    for (int i = tid; i < 2 * 2 * 32 * VP / 2; i += 256) reinterpret_cast<unsigned*>(&vs[0][0][0])[i] = 0u;      // the padding rows of V^T
+    f16x8 qh[KS], ql[KS];
+    {
+        const float* qrow = base + (long long)qc * 3 * hd;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hi), c = *reinterpret_cast<const f32x4*>(qrow + 16 * s + 8 * hi + 4);
+            const float v[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const _Float16 h = (_Float16)v[j];
+                qh[s][j] = h;
+                ql[s][j] = (_Float16)(v[j] - (float)h);
+            }
+        }
+    }
+    // staging: thread -> key row tid >> 3 of the tile, PER consecutive head-dim elements
+    const int skey = tid >> 3, sd0 = (tid & 7) * PER;
+    const int spos = ((((skey & 3) + 4 * (skey >> 3)) >> 3) << 4) + (((skey >> 2) & 1) << 3) + (((skey & 3) + 4 * (skey >> 3)) & 7);   // permuted position of key skey (attention_h2_kernel)
+    float kreg[PER], vreg[PER];
+#define MH_WA_LOAD(T)                                                                                 \
+    {                                                                                                 \
+        const int key_ = (T) * 32 + skey;                                                             \
+        const float* row_ = base + (long long)min(key_, S - 1) * 3 * hd + sd0;                        \
+        const float z_ = key_ < S ? 1.0f : 0.0f;           /* rows beyond the window stage zeros */   \
+        _Pragma("unroll") for (int i = 0; i < PER; i += 2) {                                          \
+            const f32x2 a_ = *reinterpret_cast<const f32x2*>(row_ + hd + i), c_ = *reinterpret_cast<const f32x2*>(row_ + 2 * hd + i); \
+            kreg[i] = a_[0] * z_; kreg[i + 1] = a_[1] * z_; vreg[i] = c_[0] * z_; vreg[i + 1] = c_[1] * z_; \
+        }                                                                                             \
+    }
+#define MH_WA_STORE(BUF)                                                                              \
+    {                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < PER; i += 2) {                                          \
+            f16x2 h_, l_;                                                                             \
+            _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                           \
+                h_[e] = (_Float16)kreg[i + e];                                                        \
+                l_[e] = (_Float16)(kreg[i + e] - (float)h_[e]);                                       \
+            }                                                                                         \
+            *reinterpret_cast<f16x2*>(&ks[BUF][0][skey * KP + sd0 + i]) = h_;                         \
+            *reinterpret_cast<f16x2*>(&ks[BUF][1][skey * KP + sd0 + i]) = l_;                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < PER; ++i) {                                             \
+            const _Float16 h_ = (_Float16)vreg[i];                                                    \
+            vs[BUF][0][(sd0 + i) * VP + spos] = h_;                                                   \
+            vs[BUF][1][(sd0 + i) * VP + spos] = (_Float16)(vreg[i] - (float)h_);                      \
+        }                                                                                             \
+    }
+    f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    constexpr float LOG2E = 1.44269504088896341f;
+    const float c2 = scale * LOG2E;                         // scores are kept in log2 units: p = exp2((q k scale + bias + mask) log2e - m)
+
+    MH_WA_LOAD(0)
+    __syncthreads();                                        // (the zeroed V^T rows)
+    MH_WA_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) MH_WA_LOAD(t + 1)
+        // bias + mask of this tile's (key, query) pairs: requested before the matrix work that they are added to
+        float add[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, S - 1);
+            float a_ = 0.0f;
+            if (bt) a_ += bt[(long long)key * S];
+            if (mk) a_ += mk[(long long)key * S];
+            add[r] = a_;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ks[buf][0][li * KP + 16 * s + 8 * hi]);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(&ks[buf][1][li * KP + 16 * s + 8 * hi]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, qh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, qh[s], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ql[s], acc, 0, 0, 0);
+        }
+        float mt = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            acc[r] = key < S ? fmaf(add[r], LOG2E, acc[r] * c2) : -INFINITY;
+            mt = fmaxf(mt, acc[r]);
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float corr = exp2f(m_run - m_new);
+        float psum = 0.0f;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(acc[r] - m_new);
+            psum += p;
+            const _Float16 h = (_Float16)p;
+            ph[r >> 3][r & 7] = h;
+            pl[r >> 3][r & 7] = (_Float16)(p - (float)h);
+        }
+        l_run = l_run * corr + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= corr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f16x8 vh = *reinterpret_cast<const f16x8*>(&vs[buf][0][li * VP + 16 * s + 8 * hi]);
+            const f16x8 vl = *reinterpret_cast<const f16x8*>(&vs[buf][1][li * VP + 16 * s + 8 * hi]);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s], o, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s], o, 0, 0, 0);
+        }
+        if (t + 1 < ntiles) MH_WA_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef MH_WA_STORE
+#undef MH_WA_LOAD
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    if (query < S) {
+        float* orow = out + ((long long)w * S + query) * hd + head * HD;
+#pragma unroll
+        for (int g = 0; g < HD / 8; ++g)        // registers 4 g .. 4 g + 3 = head-dim elements 8 g + 4 hi .. (rows >= HD of the tile are padding)
+            *reinterpret_cast<f32x4*>(orow + 8 * g + 4 * hi) = f32x4{o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+    }
+}
+
 }  // namespace mh

@@ -419,6 +419,27 @@ def case_attention(device, b=2, s=216, heads=3, hd=64, tol=2e-6):
     return err
 
 
+def case_window_attention(device, bw=4, s=343, heads=3, hd=16, nw=2, tol=2e-6):
+    """WindowAttention core (monai/networks/nets/swin_unetr.py:519-541): softmax((q scale) k^T + bias[head] + mask[window % nW]) v per (window, head) against
+    fp64 torch -- head dim 8 = the VALU kernel, 16 / 32 = the split-precision matrix-core kernel (round 4); ragged last key tile (343 = 10 x 32 + 23), several query blocks"""
+    gen = torch.Generator().manual_seed(7 + s + hd)
+    qkv = torch.randn(bw, s, 3 * heads * hd, generator=gen)
+    bias = torch.randn(heads, s, s, generator=gen) * 0.5              # [head][query][key]
+    mask = torch.where(torch.rand(nw, s, s, generator=gen) > 0.8, -100.0, 0.0)
+    mask = torch.minimum(mask, mask.transpose(1, 2))                  # symmetric, like the shift mask
+    scale = hd ** -0.5
+    got = ops.window_attention(qkv.to(device), heads, scale, bias.transpose(1, 2).contiguous().to(device), mask.to(device)).cpu().double()
+    q, k, v = qkv.double().reshape(bw, s, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = (q * scale) @ k.transpose(-2, -1) + bias.double()[None] + mask.double()[torch.arange(bw) % nw][:, None]
+    exp = (att.softmax(-1) @ v).transpose(1, 2).reshape(bw, s, heads * hd)
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"window attention S={s} hd={hd}: max err {err}"
+    nomask = ops.window_attention(qkv.to(device), heads, scale, None, None).cpu().double()
+    exp2 = (((q * scale) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(bw, s, heads * hd)
+    assert (nomask - exp2).abs().max().item() < tol * max(1.0, exp2.abs().max().item())
+    return err
+
+
 def case_add_act(device):
     gen = torch.Generator().manual_seed(9)
     a, b = torch.randn(2, 5, 6, 8, 12, generator=gen), torch.randn(2, 5, 6, 8, 12, generator=gen)

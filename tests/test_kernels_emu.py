@@ -253,3 +253,9 @@ def test_conv_one_input_channel(emu):
     kc.case_conv3d("cpu", cfg, 1, 1, 24, (3, 8, 8), with_nrm=True, fused_stats=True)        # 8 couts per thread, deferred norm on the input
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)      # two z-chunks (25 planes each)
     kc.case_conv3d("cpu", cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)     # no statistics; a second tile row of one line
+
+
+@pytest.mark.parametrize("s,hd", [(343, 16), (343, 32), (64, 16), (27, 8), (200, 8)])
+def test_window_attention(emu, s, hd):
+    """SwinUNETR's WindowAttention core: head dims 16 / 32 on the split-precision matrix-core kernel (round 4), 8 on the VALU kernel"""
+    kc.case_window_attention("cpu", bw=2 if "cpu" == "cpu" else 6, s=s, heads=2, hd=hd)

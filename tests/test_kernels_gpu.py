@@ -209,3 +209,9 @@ def test_conv_one_input_channel():
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (50, 4, 8), with_nrm=False, fused_stats=True)
     kc.case_conv3d(DEV, cfg, 1, 1, 16, (2, 33, 4), with_nrm=False, fused_stats=False)
     kc.case_conv3d(DEV, cfg, 2, 1, 32, (96, 96, 96), with_nrm=False, fused_stats=True)
+
+
+@pytest.mark.parametrize("s,hd", [(343, 16), (343, 32), (64, 16), (27, 8), (200, 8)])
+def test_window_attention(s, hd):
+    """SwinUNETR's WindowAttention core: head dims 16 / 32 on the split-precision matrix-core kernel (round 4), 8 on the VALU kernel"""
+    kc.case_window_attention(DEV, bw=2 if DEV == "cpu" else 6, s=s, heads=2, hd=hd)
