@@ -14,7 +14,8 @@ BASELINE.json).  Rank 0 prints ONE JSON line:
   roofline      the dominant kernel (the split-precision 3x3x3 convolution), HIP events around its launches inside the timed
                 region: `achieved` = matrix-core flops ISSUED per launch / average launch time, `frac` = achieved / the dense
                 MFMA peak of the instruction it issues (a true fraction); the convolution's own flops are `algorithmic_tflops`;
-  roofline_hbm  the blend: 20.38 GB of algorithmic traffic (SURVEY.md 8d) / its launch time, against the 8 TB/s spec;
+  roofline_hbm  the blend: 20.38 GB of algorithmic traffic / its launch time, against the 8 TB/s spec; `traffic` of both rooflines = HBM bytes per
+                launch from FETCH_SIZE / WRITE_SIZE, collected by two rocprofv3 child processes of this run (pmc_inrun; the committed builder pass if that fails);
   cpu_baseline  the CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
                 tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on the WHOLE benchmark volume --
                 all 1000 windows, the per-window network in worker processes (oracle/parallel_predict.py), the blend in the reference's
@@ -178,16 +179,77 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
     }
 
 
+_PMC_INRUN: dict = {}      # kernel key -> traffic record collected by pmc_inrun() in THIS run
+_PMC_WIDE_READS = ("sw_blend_mosaic_kernel", "sw_blend_reg_kernel")      # 16 B / lane readers: FETCH_SIZE counts their 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section)
+
+
+def pmc_inrun(budget_s: float = 150.0) -> dict:
+    """HBM bytes per launch of the blend and of the dominant convolution from the hardware counters, collected in THIS run: two `rocprofv3 --kernel-trace --pmc`
+    child processes (FETCH_SIZE, then WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over tools/pmc_probe.py, which launches the two kernels at the
+    benchmark's configuration (the mosaic blend of 1000 windows into 5 x 512^3; 32 -> 32 channels @ 96^3 x 64 windows).  Counter unit KiB per dispatch; the guide's
+    gfx950 correction (x 2 on FETCH_SIZE for 16-bytes-per-lane readers) applied to the blend only.  Every child runs under `timeout`; any failure leaves the
+    committed builder pass (`from_file`) in place."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return {}
+    tmp = tempfile.mkdtemp(prefix="monai_amd_pmc_", dir="/tmp")
+    got: dict = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = ["timeout", "-k", "5", str(int(budget_s)), rp, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
+                   sys.executable, os.path.join(here, "tools", "pmc_probe.py"), "--only", "mosaic,conv", "--conv-cfgs", "h2"]
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=budget_s + 30, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return {}
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+            db.close()
+            for key in ("sw_blend_mosaic_kernel", "conv3d_k3_h2_kernel"):
+                hit = [(n, avg) for name, n, avg in rows if key in name and "pack" not in name and "scale" not in name]
+                if len(hit) != 1:
+                    return {}
+                got.setdefault(key, {})[counter] = {"dispatches": hit[0][0], "bytes": hit[0][1] * 1024.0}
+    except Exception as e:                                         # noqa: BLE001 -- a missing profiler, a timeout, a changed schema: keep the committed pass
+        print(f"bench: in-run PMC pass failed ({type(e).__name__}: {e}); traffic stays from_file", file=sys.stderr)
+        return {}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    alg = {"sw_blend_mosaic_kernel": 1000 * 5 * 96.0 ** 3 * 4 + 5 * 512.0 ** 3 * 4, "conv3d_k3_h2_kernel": 2 * 64 * 32 * 96.0 ** 3 * 4}
+    on = {"sw_blend_mosaic_kernel": "1000 windows of 5 x 96^3 logits -> 5 x 512^3 (the benchmark's blend launch)",
+          "conv3d_k3_h2_kernel": "32 -> 32 channels @ 96^3, 64 windows per launch (the benchmark's largest convolution shape)"}
+    out = {}
+    for key, c in got.items():
+        fetch = c["FETCH_SIZE"]["bytes"] * (2.0 if key in _PMC_WIDE_READS else 1.0)
+        total = fetch + c["WRITE_SIZE"]["bytes"]
+        note = (f"in_run (this bench process ran `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` over tools/pmc_probe.py, {c['FETCH_SIZE']['dispatches']} dispatches each, "
+                f"{time.perf_counter() - t0:.0f} s; FETCH_SIZE " + ("x 2: 16-bytes-per-lane reader" if key in _PMC_WIDE_READS else "as counted") + ")")
+        if "conv3d" in key:
+            note += "; FETCH_SIZE is uncalibrated for this kernel's 4-byte loads: a ratio below 1 is not evidence of under-fetch"
+        out[key] = {"measured": note, "hbm_bytes_per_launch": total, "fetch_bytes": fetch, "write_bytes": c["WRITE_SIZE"]["bytes"], "algorithmic_bytes": alg[key],
+                    "ratio": total / alg[key], "measured_on": on[key]}
+    return out
+
+
 def pmc_traffic(kernel_key: str):
-    """HBM bytes per launch of `kernel_key` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs,
-    gfx950 corrections applied -- counters cannot be collected inside this process); the newest profiles/r*_pmc_hbm_traffic.json wins."""
+    """HBM bytes per launch of `kernel_key`: the counters collected in this run (pmc_inrun) when there are any, else the committed builder pass (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied); the newest profiles/r*_pmc_hbm_traffic.json wins."""
+    if kernel_key in _PMC_INRUN:
+        return _PMC_INRUN[kernel_key]
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     try:
         for name in sorted((f for f in os.listdir(pdir) if f.endswith("_pmc_hbm_traffic.json")), reverse=True):
             with open(os.path.join(pdir, name)) as f:
                 k = json.load(f)["kernels"].get(kernel_key)
             if k is not None:
-                note = ("from_file (a builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass, see `source`; counters cannot be collected inside this process)")
+                note = ("from_file (a builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass, see `source`; the in-run pass was skipped or failed)")
                 if "conv3d" in kernel_key:       # MI355X_MICROARCH.md calibrates FETCH_SIZE for 16 B/lane readers only
                     note += "; FETCH_SIZE is uncalibrated for this kernel's 4-byte loads: a ratio below 1 is not evidence of under-fetch"
                 return {"measured": note,
@@ -532,6 +594,7 @@ def main(argv=None):
                                                                   "fewer = a corner sub-volume (125 = 288^3), 0 = skip")
     ap.add_argument("--cpu-budget-s", type=float, default=float(os.environ.get("MONAI_AMD_BENCH_CPU_BUDGET_S", "900")),
                     help="seconds the CPU leg may take; a probe batch prices it and the largest corner sub-volume that fits is taken when the whole volume would not")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run hardware-counter passes behind roofline*.traffic (two rocprofv3 child processes, ~1 min)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.fp32_exact / config3 / config4 (development runs)")
     ap.add_argument("--harness-features", default="", help="TEST HARNESS ONLY (emulator runs of tests/test_bench_harness.py): BasicUNet widths, e.g. 16,16,32,32,64,16; "
                                                            "refused on a GPU -- the benchmark network has the default widths")
@@ -598,6 +661,9 @@ def main(argv=None):
     if rank == 0:
         voxels = float(args.size) ** 3
         ms = 1e3 * dt / args.steps
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")      # no profiler inside a profiler
+        if world == 1 and not emulated and not args.no_pmc and not profiled and args.net == "basicunet" and (args.size, args.roi) == (512, 96):
+            _PMC_INRUN.update(pmc_inrun())
         exact = config.conv_algo() in (config.CONV_ALGOS["fp32"], config.CONV_ALGOS["direct"], config.CONV_ALGOS["wino2d"])
         conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
                     for k, v in spans.items() if k.startswith("conv3d_k3/")}

@@ -292,6 +292,9 @@ int mh_sw_blend_buffered_f32(const float* logits, int64_t window_stride, const f
     return launched("sw_blend_buffered");
 }
 
+#ifndef MH_BLEND_IDX32_LIMIT
+#define MH_BLEND_IDX32_LIMIT (1LL << 31)      // floats; the SIMT-emulator build lowers it so that its small cases run both index widths (tests/emu/build_emu.py)
+#endif
 // Mosaic logits layout (kernels/sliding.h): the residue classes per axis are 2^log2m; `class_base` holds the float offset of each class array,
 // indexed (cz * 5 + cy) * 5 + cx.  mh_sw_mosaic_class_counts gives the number of windows per class of an axis (what sizes the arrays).
 int mh_sw_mosaic_class_counts(int n, int log2m, int32_t* counts5) {
@@ -324,28 +327,35 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
         if (class_base[i] % 4) return fail(MH_ERR_ARG, "sw_blend_mosaic: class offsets must be multiples of 4 floats");
         ms.base[i] = class_base[i];
     }
-    const unsigned nb = blocks_for((long long)D * H * (W / 4));
+    if (D > 65535) return fail(MH_ERR_UNSUPPORTED, "sw_blend_mosaic: more than 65535 planes (use the window-major layout)");
+    const unsigned nb = blocks_for((long long)H * (W / 4));
     hipStream_t s = (hipStream_t)stream;
-#define MH_BM(KT, G_, NT_, SEP_) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_>), dim3(nb), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms)
+    // FAST index arithmetic (kernels/sliding.h): 24-bit factors, 32-bit offsets -- when every class array's K channel planes stay below 2^31 floats (the benchmark:
+    // 5 x (5 x 96)^3 = 0.55 G), its (z-extent x y-extent) and every single extent below 2^24; else the generic 64-bit form
+    long long max_cs = 0, max_zy = 0, max_ext = std::max((long long)rd * rh, (long long)rw);
+    for (int a = 0; a < MOSAIC_MAX_CLASSES; ++a)
+        for (int b = 0; b < MOSAIC_MAX_CLASSES; ++b) {
+            const long long zy = (long long)ms.z.cnt[a] * rd * ((long long)ms.y.cnt[b] * rh);
+            max_zy = std::max(max_zy, zy);
+            for (int c = 0; c < MOSAIC_MAX_CLASSES; ++c) {
+                max_cs = std::max(max_cs, zy * ((long long)ms.x.cnt[c] * rw));
+                max_ext = std::max(max_ext, std::max((long long)ms.z.cnt[a] * rd, std::max((long long)ms.y.cnt[b] * rh, (long long)ms.x.cnt[c] * rw)));
+            }
+        }
+    const bool fast = max_cs * K < MH_BLEND_IDX32_LIMIT && max_zy < (1LL << 24) && max_ext < (1LL << 23) && knob_int("MONAI_AMD_BLEND_IDX64", 0) == 0;
+#define MH_BM(KT, G_, NT_, SEP_) { if (fast) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_, true>), dim3(nb, D), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); \
+                                   else hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_, false>), dim3(nb, D), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
 #ifdef MH_DEV_KNOBS
-    if (const int ks_ = knob_int("MONAI_AMD_BLEND_KSPLIT", 0)) {      // A/B: one class per thread (grid.y = K): 5x the threads, 8 ... 27 read streams per wave instead of 40 ... 135
-        const dim3 gk(nb, (unsigned)K);
-        if (ks_ == 1) { if (imp_factored) hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, MH_BLEND_G, false, true>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms);
-                        else hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, MH_BLEND_G, false, false>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
-        else { if (imp_factored) hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, 4, false, true>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms);
-               else hipLaunchKernelGGL((sw_blend_mosaic_kernel<1, 4, false, false>), gk, dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
-        return launched("sw_blend_mosaic");
-    }
     if (K == 5 && !imp_factored) {        // A/B of the window-batch size and of non-temporal accesses on the benchmark shape (tools/blend_bench.py with the -DMH_DEV_KNOBS library)
         const int g_ = knob_int("MONAI_AMD_BLEND_G", MH_BLEND_G), nt_ = knob_int("MONAI_AMD_BLEND_NT", 0);
-        if (g_ == 1 && !nt_) { MH_BM(5, 1, false, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 1 && nt_) { MH_BM(5, 1, true, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 2 && nt_) { MH_BM(5, 2, true, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 4 && !nt_) { MH_BM(5, 4, false, false); return launched("sw_blend_mosaic"); }
-        if (g_ == 4 && nt_) { MH_BM(5, 4, true, false); return launched("sw_blend_mosaic"); }
+        if (g_ == 1 && !nt_) { MH_BM(5, 1, false, false) return launched("sw_blend_mosaic"); }
+        if (g_ == 1 && nt_) { MH_BM(5, 1, true, false) return launched("sw_blend_mosaic"); }
+        if (g_ == 2 && nt_) { MH_BM(5, 2, true, false) return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && !nt_) { MH_BM(5, 4, false, false) return launched("sw_blend_mosaic"); }
+        if (g_ == 4 && nt_) { MH_BM(5, 4, true, false) return launched("sw_blend_mosaic"); }
     }
 #endif
-#define MH_BM_CASE(KT) case KT: if (imp_factored) MH_BM(KT, MH_BLEND_G, false, true); else MH_BM(KT, MH_BLEND_G, false, false); break;
+#define MH_BM_CASE(KT) case KT: if (imp_factored) MH_BM(KT, MH_BLEND_G, false, true) else MH_BM(KT, MH_BLEND_G, false, false) break;
     switch (K) { MH_BM_CASE(1) MH_BM_CASE(2) MH_BM_CASE(3) MH_BM_CASE(4) MH_BM_CASE(5) MH_BM_CASE(6) MH_BM_CASE(7) MH_BM_CASE(8) }
 #undef MH_BM_CASE
 #undef MH_BM

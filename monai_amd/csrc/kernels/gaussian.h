@@ -388,15 +388,19 @@ __global__ void __launch_bounds__(1024) gauss3d_rowdpp_kernel(const float* __res
         const int hx = lane == 0 ? tx0 - 4 : tx0 + GV_TX;
         eoff[i] = rok && (lane == 0 || lane == GV_LANES - 1) && hx >= 0 && hx < a.W ? 4u * (unsigned)(gy * a.W + hx) : GD_ZERO;
     }
-    f32x4 cur[XR], ext[XR];
+    // Round 4: with 7-9 taps the plane BEHIND the next one is requested too (its loads stay in flight for a whole plane step; the move into the working set is
+    // renamed away inside the unrolled group): 0.239 against 0.246-0.247 ms per 512^3 volume, bit-identical; with 5 taps the same change costs 5 % (0.217 against
+    // 0.2065: 16 more registers, one resident wave less), and the streaming resample lost 7-30 % to it (a resident workgroup less) -- profiles/r04_hbm_two_planes_ahead_ab.jsonl
+    constexpr bool TWO_AHEAD = RK >= 7;
+    f32x4 cur[XR], ext[XR], ncur[XR], next_[XR];
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     unsigned loff = (unsigned)((long long)zfirst * plane * 4);      // byte offset of the next source plane to load
     float* optr = ovol + (long long)(ty0 + wave) * a.W + gx + ((long long)zfirst - HR) * plane;      // output plane z - HR of the current step
-#define GD_LOAD                                                                                       \
+#define GD_LOAD(C_, E_)                                                                               \
     {                                                                                                 \
         _Pragma("unroll") for (int i = 0; i < XR; ++i) {                                              \
-            cur[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, coff[i], loff, 0)); \
-            ext[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, eoff[i], loff, 0)); \
+            C_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, coff[i], loff, 0)); \
+            E_[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(vrsrc, eoff[i], loff, 0)); \
         }                                                                                             \
         loff += (unsigned)(plane * 4);                                                                \
     }
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(1024) gauss3d_rowdpp_kernel(const float* __res
     const bool rowok = ty0 + wave < a.H && gx < a.W;
     int buf = 0;
 
-    // x- and y-pass of source plane Z -> this wave's y-filtered row vector V; prefetches plane Z + 1
+    // x- and y-pass of source plane Z -> this wave's y-filtered row vector V; plane Z + 1 moves into the working set, plane Z + 2 is requested
 #define GD_PLANE(Z, V)                                                                                \
     {                                                                                                 \
         float* mb_ = mid[buf];                                                                        \
@@ -425,7 +429,10 @@ __global__ void __launch_bounds__(1024) gauss3d_rowdpp_kernel(const float* __res
                 *reinterpret_cast<f32x4*>(mb_ + r_ * GV_TX + 4 * lane) = f32x4{o_[0], o_[1], o_[2], o_[3]}; \
             }                                                                                         \
         }                                                                                             \
-        if ((Z) + 1 < zlast) GD_LOAD                                                                  \
+        if (TWO_AHEAD) {                                                                              \
+            if ((Z) + 1 < zlast) { _Pragma("unroll") for (int i = 0; i < XR; ++i) { cur[i] = ncur[i]; ext[i] = next_[i]; } }   /* requested one plane step ago */ \
+            if ((Z) + 2 < zlast) GD_LOAD(ncur, next_)                                                 \
+        } else if ((Z) + 1 < zlast) GD_LOAD(cur, ext)                                                 \
         __syncthreads();                                                                              \
         V = zero4;                                                                                    \
         _Pragma("unroll") for (int j = 0; j < RK; ++j) {                                              \
@@ -435,7 +442,8 @@ __global__ void __launch_bounds__(1024) gauss3d_rowdpp_kernel(const float* __res
         buf ^= 1;                                                                                     \
     }
 
-    GD_LOAD
+    GD_LOAD(cur, ext)
+    if (TWO_AHEAD && zfirst + 1 < zlast) GD_LOAD(ncur, next_)
     // step s of a group of RK planes: slot of output plane zo = (zo - zfirst) mod RK, a compile-time number inside the unrolled group
     for (int zb = zfirst; zb < ze + HR; zb += RK) {
 #pragma unroll

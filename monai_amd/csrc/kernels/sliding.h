@@ -1,6 +1,8 @@
 // Sliding-window inferer kernels: window gather and the fused importance-weighted blend.
 // Reference behaviour: monai/inferers/utils.py:215-298 (window loop, `*= w`, `+=`, count map, `/=`).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mh {
@@ -426,25 +428,96 @@ __device__ __forceinline__ void mosaic_axis_locate(const MosaicAxis& a, int n, i
 // SEP: the importance map is given by its factors -- fac = [gz (rd) | gy (rh) | gx (rw) | floor]: map[z][y][x] = max(fl(fl(gz[z] * gy[y]) * gx[x]), floor), the
 // way the reference builds the gaussian (and the constant) map (monai/data/utils.py:1084-1134) -- and is re-formed in registers, bit for bit: three
 // vectors of roi floats that stay in L1 instead of 8 ... 27 loads per output voxel group from a roi^3 map that competes with the logits stream for L2.
-template <int KT, int G, bool NT, bool SEP>
+// Round 4 (profiles/r04_pmc_hbm_kernels.txt: the vector ALUs were busy for 0.58 of the launch -- 1 856 vector instructions per wave, the blend's own arithmetic a fifth of
+// them; the rest was 64-bit index arithmetic, table lookups and selects).  FAST (the launcher proves the bounds, else the generic 64-bit form runs):
+//   * a voxel's offset inside its class array and the array's channel stride are 32-bit, formed by 24-bit multiplies (full rate; v_mul_lo_u32 / v_mad_u64_u32 are
+//     quarter rate) -- every factor is an extent or a coordinate below 2^24, (z-extent x y-extent) < 2^24, K x stride < 2^31 floats; the K channel pointers are one
+//     64-bit add each (the stride is made opaque: the compiler otherwise re-derives every channel's offset through the whole multiply chain);
+//   * the class extents come from the class index by arithmetic (mosaic_axis_extent), not from three per-lane table loads per window in front of the logits loads;
+//   * whole batches of B windows and the <= B - 1 windows behind them are separate code (mosaic_blend_batch<B> / <1>): no "is this window real" select on every
+//     accumulate, and the accumulates pack (v_pk_mul_f32 / v_pk_add_f32);
+//   * (z, y, x) from a 2-D grid (blockIdx.y = z) instead of two 64-bit divisions per thread.
+// Same operations on the same values in the same order: the same bits.
+// the instructions themselves (operands: the low 24 bits; result: the low 32 bits of the product): __mul24 / __umul24 are shift patterns that the optimiser turned back
+// into quarter-rate 32-bit multiplies in this kernel.  The SIMT emulator keeps the 24-bit truncation, so an operand out of range shows in the tests.
+#ifdef MH_SIMT_EMULATOR
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ unsigned mos_mul(unsigned a, unsigned b) { return __umul24(a, b); }
+#else
+__device__ __forceinline__ int mul24(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned mos_mul(unsigned a, unsigned b) { unsigned r; asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+#endif
+__device__ __forceinline__ long long mos_mul(long long a, long long b) { return a * b; }
+template <bool FAST> __device__ __forceinline__ int axis_start_t(const AxisWin& a, int i) { return i == a.n - 1 ? a.last : (FAST ? mul24(i, a.step) : i * a.step); }
+// windows per class times the window extent: cnt[c] * r of mosaic_axis_fill without the table (c < m: windows i = c, c + m, ... below n - 1; the last window: one)
+__device__ __forceinline__ int mosaic_axis_extent(const MosaicAxis& a, int n, int c, bool last, int r) {
+    const int cnt = last ? 1 : (n - 2 - c + (1 << a.log2m)) >> a.log2m;
+    return mul24(cnt, r);
+}
+
+template <int KT, int B, bool NT, bool SEP, bool FAST>
+__device__ __forceinline__ void mosaic_blend_batch(const float* __restrict__ logits, const float* __restrict__ imp, int z, int y, int x, int rd, int rh, int rw,
+                                                   const RegGrid& g, const Mosaic& ms, int ylo, int yhi, int xlo, int xhi, int& iz, int& iy, int& ix,
+                                                   float (&acc)[KT][4], float (&cnt)[4]) {
+    using IT = typename std::conditional<FAST, unsigned, long long>::type;
+    float wt[B][4];
+    f32x4 lv[B][KT];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int lz = z - axis_start_t<FAST>(g.z, iz), ly = y - axis_start_t<FAST>(g.y, iy), lx = x - axis_start_t<FAST>(g.x, ix);
+        int cz, jz, cy, jy, cx, jx;
+        mosaic_axis_locate(ms.z, g.z.n, iz, cz, jz);
+        mosaic_axis_locate(ms.y, g.y.n, iy, cy, jy);
+        mosaic_axis_locate(ms.x, g.x.n, ix, cx, jx);
+        const IT Dz = (IT)mosaic_axis_extent(ms.z, g.z.n, cz, iz == g.z.n - 1, rd), Hc = (IT)mosaic_axis_extent(ms.y, g.y.n, cy, iy == g.y.n - 1, rh),
+                 Wc = (IT)mosaic_axis_extent(ms.x, g.x.n, cx, ix == g.x.n - 1, rw);
+        const IT pos = mos_mul(mos_mul((IT)(mul24(jz, rd) + lz), Hc) + (IT)(mul24(jy, rh) + ly), Wc) + (IT)(mul24(jx, rw) + lx);
+        unsigned long long cs = (unsigned long long)mos_mul(mos_mul(Dz, Hc), Wc);
+        MH_OPAQUE(cs);
+        const float* lp = logits + ms.base[mul24(mul24(cz, MOSAIC_MAX_CLASSES) + cy, MOSAIC_MAX_CLASSES) + cx] + pos;
+        if (++ix > xhi) { ix = xlo; if (++iy > yhi) { iy = ylo; ++iz; } }      // next window of the box, last axis fastest = ascending window index
+        if (SEP) {
+            const float zy = __fmul_rn(imp[lz], imp[rd + ly]), fl_ = imp[rd + rh + rw];
+            const f32x4 q = *reinterpret_cast<const f32x4*>(imp + rd + rh + lx);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) wt[b][v] = fmaxf(__fmul_rn(zy, q[v]), fl_);
+        } else {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(imp + (unsigned)(mul24(mul24(lz, rh) + ly, rw) + lx));
+            wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
+        }
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+            const f32x4* lp_ = reinterpret_cast<const f32x4*>(lp);
+            lv[b][k] = NT ? __builtin_nontemporal_load(lp_) : *lp_;
+            lp += cs;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+#pragma unroll
+            for (int k = 0; k < KT; ++k) acc[k][v] = __fadd_rn(acc[k][v], __fmul_rn(lv[b][k][v], wt[b][v]));
+            cnt[v] = __fadd_rn(cnt[v], wt[b][v]);
+        }
+}
+
+// grid: x over the (y, x-vector) pairs of a plane, y = z; a thread owns all K = KT classes of its four voxels
+template <int KT, int G, bool NT, bool SEP, bool FAST = true>
 __global__ void __launch_bounds__(256)
 sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K, int D, int H, int W, int rd,
                        int rh, int rw, RegGrid g, Mosaic ms) {
     constexpr int VEC = 4;
-    const int k0 = (int)blockIdx.y * KT;             // channel group of this workgroup (grid.y = K / KT: 1 when a thread owns all classes)
-    const int wv = W / VEC;
-    const long long total = (long long)D * H * wv;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int x = (int)(idx % wv) * VEC;
-    const long long t = idx / wv;
-    const int y = (int)(t % H), z = (int)(t / H);
+    const int z = (int)blockIdx.y;
+    const unsigned wv = (unsigned)W / VEC;
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= (unsigned)H * wv) return;
+    const int y = (int)(i / wv), x = (int)(i - (unsigned)y * wv) * VEC;
     int zlo, zhi, ylo, yhi, xlo, xhi;
     axis_cover(g.z, rd, z, zlo, zhi);
     axis_cover(g.y, rh, y, ylo, yhi);
     axis_cover(g.x, rw, x, xlo, xhi);
     const int nw = (zhi - zlo + 1) * (yhi - ylo + 1) * (xhi - xlo + 1);
-    const long long plane = (long long)rh * rw;
     const long long vox = (long long)D * H * W;
     float acc[KT][VEC];
     float cnt[VEC];
@@ -454,61 +527,10 @@ sw_blend_mosaic_kernel(const float* __restrict__ logits, const float* __restrict
 #pragma unroll
         for (int k = 0; k < KT; ++k) acc[k][v] = 0.0f;
     }
-    int iz = zlo, iy = ylo, ix = xlo;
-    for (int done = 0; done < nw; done += G) {
-        float wt[G][VEC];
-        float lv[G][KT][VEC];
-        long long off0 = 0, base0 = 0, cs0 = 0;
-#pragma unroll
-        for (int b = 0; b < G; ++b) {
-            const bool ok = done + b < nw;
-            const int lz = z - axis_start(g.z, iz), ly = y - axis_start(g.y, iy), lx = x - axis_start(g.x, ix);
-            int cz, jz, cy, jy, cx, jx;
-            mosaic_axis_locate(ms.z, g.z.n, iz, cz, jz);
-            mosaic_axis_locate(ms.y, g.y.n, iy, cy, jy);
-            mosaic_axis_locate(ms.x, g.x.n, ix, cx, jx);
-            const long long Hc = (long long)ms.y.cnt[cy] * rh, Wc = (long long)ms.x.cnt[cx] * rw;
-            long long cs = (long long)ms.z.cnt[cz] * rd * Hc * Wc;
-            long long base = ms.base[(cz * MOSAIC_MAX_CLASSES + cy) * MOSAIC_MAX_CLASSES + cx] + (((long long)jz * rd + lz) * Hc + (long long)jy * rh + ly) * Wc + (long long)jx * rw + lx;
-            long long off = (long long)lz * plane + (long long)ly * rw + lx;
-            if (b == 0) { off0 = off; base0 = base; cs0 = cs; }
-            if (!ok) { off = off0; base = base0; cs = cs0; }      // past the end of the box: re-request the batch's first window (values unused)
-            if (ok) {
-                if (++ix > xhi) { ix = xlo; if (++iy > yhi) { iy = ylo; ++iz; } }
-            }
-            if (SEP) {
-                const int lzc = ok ? lz : 0, lyc = ok ? ly : 0, lxc = ok ? lx : 0;          // past the end of the box: any valid entry (unused)
-                const float zy = __fmul_rn(imp[lzc], imp[rd + lyc]), fl_ = imp[rd + rh + rw];
-                const f32x4 q = *reinterpret_cast<const f32x4*>(imp + rd + rh + lxc);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) wt[b][v] = fmaxf(__fmul_rn(zy, q[v]), fl_);
-            } else {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(imp + off);
-                wt[b][0] = q[0]; wt[b][1] = q[1]; wt[b][2] = q[2]; wt[b][3] = q[3];
-            }
-#pragma unroll
-            for (int k = 0; k < KT; ++k) {
-                const f32x4* lp_ = reinterpret_cast<const f32x4*>(logits + base + (long long)(k0 + k) * cs);
-                const f32x4 a = NT ? __builtin_nontemporal_load(lp_) : *lp_;
-                lv[b][k][0] = a[0]; lv[b][k][1] = a[1]; lv[b][k][2] = a[2]; lv[b][k][3] = a[3];
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < G; ++b) {
-            const bool ok = done + b < nw;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-#pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    const float s = __fadd_rn(acc[k][v], __fmul_rn(lv[b][k][v], wt[b][v]));
-                    acc[k][v] = ok ? s : acc[k][v];
-                }
-                const float c = __fadd_rn(cnt[v], wt[b][v]);
-                cnt[v] = ok ? c : cnt[v];
-            }
-        }
-    }
-    float* op = out + (long long)k0 * vox + ((long long)z * H + y) * W + x;
+    int iz = zlo, iy = ylo, ix = xlo, done = 0;
+    for (; done + G <= nw; done += G) mosaic_blend_batch<KT, G, NT, SEP, FAST>(logits, imp, z, y, x, rd, rh, rw, g, ms, ylo, yhi, xlo, xhi, iz, iy, ix, acc, cnt);
+    for (; done < nw; ++done) mosaic_blend_batch<KT, 1, NT, SEP, FAST>(logits, imp, z, y, x, rd, rh, rw, g, ms, ylo, yhi, xlo, xhi, iz, iy, ix, acc, cnt);
+    float* op = out + ((long long)z * H + y) * W + x;
 #pragma unroll
     for (int k = 0; k < KT; ++k) {
         const f32x4 r = {__fdiv_rn(acc[k][0], cnt[0]), __fdiv_rn(acc[k][1], cnt[1]), __fdiv_rn(acc[k][2], cnt[2]), __fdiv_rn(acc[k][3], cnt[3])};

@@ -19,7 +19,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def sources():
-    deps = [SRC, os.path.join(HERE, "stub", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "monai_amd.h")]
+    deps = [SRC, os.path.abspath(__file__), os.path.join(HERE, "stub", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "monai_amd.h")]      # this file: the compiler flags
     kd = os.path.join(ROOT, "monai_amd", "csrc", "kernels")
     deps += [os.path.join(kd, f) for f in sorted(os.listdir(kd)) if f.endswith(".h")]
     return deps
@@ -45,7 +45,7 @@ def build(force: bool = False) -> str:
             cxx = CLANG if os.path.exists(CLANG) else "clang++"
             tmp = f"{OUT}.{os.getpid()}.tmp"
             cmd = [cxx, "-x", "c++", "-std=c++17", "-O2", "-g0", "-fPIC", "-shared", "-pthread", "-mfma", "-mavx2",
-                   "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi", "-I", os.path.join(HERE, "stub"), SRC, "-o", tmp]
+                   "-ffp-contract=off", "-fno-strict-aliasing", "-Wno-unused-value", "-Wno-psabi", "-DMH_BLEND_IDX32_LIMIT=50000", "-I", os.path.join(HERE, "stub"), SRC, "-o", tmp]
             try:
                 subprocess.run(cmd, check=True)
                 os.replace(tmp, OUT)

@@ -351,6 +351,9 @@ static inline float __fadd_rn(float a, float b) { volatile float r = a + b; retu
 static inline float __fdiv_rn(float a, float b) { volatile float r = a / b; return r; }
 static inline float __fsqrt_rn(float a) { return std::sqrt(a); }
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+// 24-bit multiplies: the hardware uses the low 24 bits of each operand (sign-extended for the signed form) -- emulated as such, so that an operand out of range shows
+static inline unsigned __umul24(unsigned a, unsigned b) { return (unsigned)((unsigned long long)(a & 0xffffffu) * (b & 0xffffffu)); }
+static inline int __mul24(int a, int b) { return (int)((long long)((a << 8) >> 8) * ((b << 8) >> 8)); }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }

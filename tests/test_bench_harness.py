@@ -63,3 +63,42 @@ def test_bench_four_ranks_line_and_bitwise_sharding():
     if single is None:
         single = _run([sys.executable, "bench.py", "--cpu-windows", "0"] + ARGS)["checksum"]
     assert line["checksum"] == single
+
+
+def test_pmc_inrun_reads_the_counter_databases(tmp_path, monkeypatch):
+    """bench.pmc_inrun(): two profiler child processes (FETCH_SIZE, WRITE_SIZE), per-kernel averages out of the rocpd `counters_collection` view, KiB -> bytes, the
+    guide's x 2 on FETCH_SIZE for the 16-bytes-per-lane blend only, pack / scale helper kernels not mistaken for the convolution -- against a stand-in `rocprofv3`
+    that writes the database a real pass would (no GPU here); a failing profiler leaves the committed pass in place."""
+    fake = tmp_path / "rocprofv3"
+    fake.write_text(f"""#!{sys.executable}
+import os, sqlite3, sys
+a = sys.argv[1:]
+d, counter = a[a.index("-d") + 1], a[a.index("--pmc") + 1]
+assert "--kernel-trace" in a and a[a.index("--") + 2].endswith("pmc_probe.py")
+if os.environ.get("FAKE_PMC_FAIL"):
+    sys.exit(3)
+os.makedirs(os.path.join(d, "host"), exist_ok=True)
+db = sqlite3.connect(os.path.join(d, "host", "p_results.db"))
+db.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+kib = {{"FETCH_SIZE": (9000000.0, 7000000.0), "WRITE_SIZE": (2621440.0, 7077888.0)}}[counter]
+for i in range(3):
+    db.execute("insert into counters_collection values (?, ?, ?)", ("void mh::sw_blend_mosaic_kernel<5, 2>(mh::Mosaic)", counter, kib[0] + i - 1))
+    db.execute("insert into counters_collection values (?, ?, ?)", ("void mh::conv3d_k3_h2_kernel<true, true, true, false>(mh::Tensor)", counter, kib[1]))
+db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2_pack_kernel(float const*)", counter, 1.0))
+db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2_scale_kernel(float const*)", counter, 1.0))
+db.commit()
+""")
+    fake.chmod(0o755)
+    sys.path.insert(0, ROOT)
+    import bench
+
+    monkeypatch.setattr("shutil.which", lambda name: str(fake) if name == "rocprofv3" else None)
+    got = bench.pmc_inrun(budget_s=60)
+    blend, conv = got["sw_blend_mosaic_kernel"], got["conv3d_k3_h2_kernel"]
+    assert blend["fetch_bytes"] == 2 * 9000000.0 * 1024 and blend["write_bytes"] == 2621440.0 * 1024
+    assert conv["fetch_bytes"] == 7000000.0 * 1024 and conv["hbm_bytes_per_launch"] == (7000000.0 + 7077888.0) * 1024
+    assert abs(blend["ratio"] - (2 * 9000000.0 + 2621440.0) * 1024 / (1000 * 5 * 96 ** 3 * 4 + 5 * 512 ** 3 * 4)) < 1e-12
+    assert blend["measured"].startswith("in_run") and "uncalibrated" in conv["measured"]
+    monkeypatch.setenv("FAKE_PMC_FAIL", "1")
+    assert bench.pmc_inrun(budget_s=60) == {}
+    assert bench.pmc_traffic("sw_blend_mosaic_kernel")["measured"].startswith("from_file")
