@@ -207,6 +207,11 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, 
 /* Conv3d k=1 (+bias) of act(in) -- `final_conv`, basic_unet.py:252.  w: [Cout][Cin]. */
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
                    void* stream);
+/* The same convolution leaving the InstanceNorm statistics of its output as it writes it (the 1x1x1 shortcut of UnetResBlock, `conv3` -> `norm3`,
+ * blocks/dynunet_block.py:72-111): stats [N][Cout][tiles][3] = {count, mean, M2} per workgroup tile, tiles = mh_conv1x1_stat_tiles(D, H, W); the
+ * records go to mh_instnorm_finalize_f32 like those of mh_instnorm_stats_f32 (no pass of its own over the tensor). */
+int mh_conv1x1_stat_tiles(int D, int H, int W);
+int mh_conv1x1_stats_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out, float* stats, void* stream);
 
 /* The same 1x1 convolution with one strided destination per batch element (the windows of a sliding-window launch written straight into the mosaic
  * logits layout): place [N][4] HOST int64 = {float offset from `base`, channel stride, z stride, y stride}; x stays contiguous.  Cout <= 8. */

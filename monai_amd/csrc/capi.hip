@@ -808,12 +808,12 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
     return launched("deconv_k2s2");
 }
 
-template <int VEC>
+template <int VEC, bool STATS>
 static void launch_1x1(int co, unsigned nb, unsigned nbatch, hipStream_t s, const Tensor& in, const float* w, const float* bias,
-                       const Tensor& out, int co0) {
+                       const Tensor& out, int co0, float* stats) {
 #define MH_1X1_CASE(CO)                                                                                               \
     case CO:                                                                                                          \
-        hipLaunchKernelGGL((conv1x1_kernel<CO, VEC>), dim3(nb, nbatch), dim3(256), 0, s, in, w, bias, out, co0);      \
+        hipLaunchKernelGGL((conv1x1_kernel<CO, VEC, STATS>), dim3(nb, nbatch), dim3(256), 0, s, in, w, bias, out, co0, stats, (int)nb);      \
         break;
     switch (co) {
         MH_1X1_CASE(1) MH_1X1_CASE(2) MH_1X1_CASE(3) MH_1X1_CASE(4)
@@ -822,21 +822,40 @@ static void launch_1x1(int co, unsigned nb, unsigned nbatch, hipStream_t s, cons
 #undef MH_1X1_CASE
 }
 
-int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, void* stream) {
+// one {count, mean, M2} record per (n, cout, workgroup): the tile count of a stats-fused 1x1x1 convolution (mh_conv1x1_stats_f32) on a D x H x W plane
+int mh_conv1x1_stat_tiles(int D, int H, int W) {
+    const long long DHW = (long long)D * H * W;
+    return (int)blocks_for(DHW % 4 == 0 ? DHW / 4 : DHW);
+}
+
+static int conv1x1_impl(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, float* stats, void* stream) {
     if (!dense_ok(in_) || !dense_ok(out_) || !w) return fail(MH_ERR_ARG, "conv1x1: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv1x1: shape mismatch");
     const long long DHW = (long long)in.D * in.H * in.W;
     const bool v4 = DHW % 4 == 0 && aligned(in.data, 16) && aligned(out.data, 16) && in.n_stride % 4 == 0 && out.n_stride % 4 == 0;
+    if (stats && !v4 && DHW % 4 == 0) return fail(MH_ERR_UNSUPPORTED, "conv1x1_stats: tensors must be 16-byte aligned when D*H*W is a multiple of 4 (the tile count assumes it)");
     const unsigned nb = blocks_for(v4 ? DHW / 4 : DHW);
     for (int co0 = 0; co0 < out.C;) {      // 16 output channels per pass where they exist (the input is read once per pass)
         const int left = out.C - co0;
         const int co = left >= 16 ? 16 : left < 8 ? left : 8;
-        if (v4) launch_1x1<4>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
-        else launch_1x1<1>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0);
+        if (stats) {
+            if (v4) launch_1x1<4, true>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0, stats);
+            else launch_1x1<1, true>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0, stats);
+        } else {
+            if (v4) launch_1x1<4, false>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0, nullptr);
+            else launch_1x1<1, false>(co, nb, (unsigned)in.N, (hipStream_t)stream, in, w, bias, out, co0, nullptr);
+        }
         co0 += co;
     }
     return launched("conv1x1");
+}
+
+int mh_conv1x1_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, void* stream) { return conv1x1_impl(in_, w, bias, out_, nullptr, stream); }
+
+int mh_conv1x1_stats_f32(const mh_tensor5* in_, const float* w, const float* bias, const mh_tensor5* out_, float* stats, void* stream) {
+    if (!stats) return fail(MH_ERR_ARG, "conv1x1_stats: null statistics buffer");
+    return conv1x1_impl(in_, w, bias, out_, stats, stream);
 }
 
 int mh_conv1x1_windows_f32(const mh_tensor5* in_, const float* w, const float* bias, float* base, int Cout, const int64_t* place, void* stream) {

@@ -436,15 +436,46 @@ deconv_k2s2_x2_kernel(Tensor in, const float* __restrict__ w, const float* __res
 // x 64 windows), slower on the smaller levels: neither the 8 Cin Cout multiply-adds per voxel nor the store granularity bound this op.
 
 // ---------------------------------------------------------------------------------------------------
+// Sums of P values per lane over the 64 lanes of a wave with 2 P - 2 + (6 - log2 P) shuffles instead of 6 P: in step k a lane keeps one half of its values and
+// sends the other half to the lane `32 >> k` away, so after log2 P steps it holds ONE value -- the partial sum of value index wave_multi_owner<P>(lane) -- and the
+// remaining lane bits are reduced the plain way.  Every lane ends with the complete sum of the value index it owns.
+template <int P> __device__ __forceinline__ int wave_multi_owner(int lane) {
+    int j = 0, off = 32;
+#pragma unroll
+    for (int n = P; n > 1; n >>= 1, off >>= 1) j += (lane & off) ? (n >> 1) : 0;
+    return j;
+}
+template <int P> __device__ __forceinline__ float wave_multi_sum(float (&s)[P], int lane) {
+    static_assert(P >= 1 && P <= 64 && (P & (P - 1)) == 0, "a power of two");
+    int off = 32;
+#pragma unroll
+    for (int n = P; n > 1; n >>= 1, off >>= 1) {
+        const bool hi = (lane & off) != 0;
+#pragma unroll
+        for (int j = 0; j < n / 2; ++j) {
+            const float keep = hi ? s[j + n / 2] : s[j], send = hi ? s[j] : s[j + n / 2];
+            s[j] = keep + __shfl_xor(send, off);
+        }
+    }
+    float r = s[0];
+    for (; off >= 1; off >>= 1) r += __shfl_xor(r, off);
+    return r;
+}
+
 // Conv3d k=1 of act(in): CO output channels [co0, co0+CO) per thread, VEC voxels per thread.
-template <int CO, int VEC>
+// STATS: the workgroup also leaves one {count, mean, M2} record per output channel for the 256 x VEC voxels it wrote (M2 about the workgroup's mean: two passes
+// over the registers, as instnorm_stats_kernel) at stats[((n * Cout + c) * tiles + blockIdx.x) * 3] -- the InstanceNorm behind a 1x1x1 shortcut convolution
+// (UnetResBlock.conv3 / norm3, dynunet_block.py:72-111) needs no pass of its own over the tensor.
+template <int CO, int VEC, bool STATS>
 __global__ void __launch_bounds__(256)
-conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int co0) {
+conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, Tensor out, int co0, float* __restrict__ stats, int tiles) {
     const int Cin = in.C;
     const long long DHW = (long long)in.D * in.H * in.W;
-    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
+    const long long idx0 = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC;
     const int n = blockIdx.y;
-    if (idx >= DHW) return;
+    const bool valid = idx0 < DHW;
+    if (!STATS && !valid) return;
+    const long long idx = valid ? idx0 : 0;          // STATS: lanes beyond the plane stay for the reductions (they recompute voxel 0 and contribute nothing)
     float acc[CO][VEC];
 #pragma unroll
     for (int j = 0; j < CO; ++j) {
@@ -480,14 +511,53 @@ conv1x1_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__
             }
         }
     }
-    float* dst = out.data + (long long)n * out.n_stride + idx;
+    if (valid) {
+        float* dst = out.data + (long long)n * out.n_stride + idx;
 #pragma unroll
-    for (int j = 0; j < CO; ++j) {
-        float* p = dst + (long long)(co0 + j) * DHW;
-        if (VEC == 4) {
-            *reinterpret_cast<float4*>(p) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
-        } else {
-            p[0] = acc[j][0];
+        for (int j = 0; j < CO; ++j) {
+            float* p = dst + (long long)(co0 + j) * DHW;
+            if (VEC == 4) {
+                *reinterpret_cast<float4*>(p) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+            } else {
+                p[0] = acc[j][0];
+            }
+        }
+    }
+    if (STATS) {
+        constexpr int P = CO <= 1 ? 1 : CO <= 2 ? 2 : CO <= 4 ? 4 : CO <= 8 ? 8 : 16;
+        __shared__ float red_s[4][P], red_q[4][P];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, own = wave_multi_owner<P>(lane);
+        const float tot = (float)min((long long)256 * VEC, DHW - (long long)blockIdx.x * 256 * VEC);      // DHW % VEC == 0 (launcher)
+        float t[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            t[j] = 0.0f;
+            if (j < CO && valid) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) t[j] += acc[j][v];
+            }
+        }
+        float r = wave_multi_sum<P>(t, lane);
+        if ((lane & (64 / P - 1)) == 0) red_s[wave][own] = r;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            t[j] = 0.0f;
+            if (j < CO && valid) {
+                const float mean = ((red_s[0][j] + red_s[1][j]) + (red_s[2][j] + red_s[3][j])) / tot;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { const float d = acc[j][v] - mean; t[j] += d * d; }
+            }
+        }
+        r = wave_multi_sum<P>(t, lane);
+        if ((lane & (64 / P - 1)) == 0) red_q[wave][own] = r;
+        __syncthreads();
+        if (threadIdx.x < CO) {
+            const int j = threadIdx.x;
+            float* rec = stats + (((long long)n * out.C + co0 + j) * tiles + blockIdx.x) * 3;
+            rec[0] = tot;
+            rec[1] = ((red_s[0][j] + red_s[1][j]) + (red_s[2][j] + red_s[3][j])) / tot;
+            rec[2] = (red_q[0][j] + red_q[1][j]) + (red_q[2][j] + red_q[3][j]);
         }
     }
 }

@@ -330,11 +330,14 @@ class DynUNet(nn.Module):
         w3 = self._w5(blk.conv3.conv)
         cout = w3.shape[0]
         r = torch.empty_like(c2)
+        stats, tiles = None, 0
         if blk.stride == (1, 1, 1):
-            ops.conv1x1(x, None, w3.view(cout, -1), None, r)
+            tiles = ops.conv1x1_stat_tiles(*r.shape[2:])          # norm3's statistics come out of the shortcut convolution itself
+            stats = self._stats_buf(r.shape[0] * cout * tiles * 3, r.device)
+            ops.conv1x1(x, None, w3.view(cout, -1), None, r, stats)
         else:       # the strided 1x1 shortcut as the centre tap of the strided 3x3x3 kernel
             ops.conv3d_k3_strided3(x, None, self._packed_weight(blk.conv3.conv, 0), None, r, blk.stride)
-        n3 = self._finalize(blk.norm3, r, None, 0, 1.0)
+        n3 = self._finalize(blk.norm3, r, stats, tiles, 1.0)
         return ops.add_act(c2, n2, r, n3, self._slope, dst, dst_nrm)
 
     def _encode(self, blk: _Block, x, x_nrm, dst, dst_nrm):

@@ -265,10 +265,9 @@ class UNETR(nn.Module):
             w3 = blk.conv3.conv.weight
             n, cout = x.shape[0], w3.shape[0]
             r = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
-            ops.conv1x1(x, None, w3.view(cout, -1), None, r)
-            tiles = ops.instnorm_stat_tiles(*x.shape[2:])
+            tiles = ops.conv1x1_stat_tiles(*x.shape[2:])          # norm3's statistics come out of the shortcut convolution itself
             stats = self._stats_buf(n * cout * tiles * 3, x.device)
-            ops.instnorm_stats(r, stats)
+            ops.conv1x1(x, None, w3.view(cout, -1), None, r, stats)
             n3 = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
             ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, n3)
             ops.add_act(c2, n2, r, n3, 0.01, out, out_nrm)

@@ -398,10 +398,18 @@ def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None):
     return out
 
 
-def conv1x1(x, x_nrm, weight, bias, out):
-    _lib.require_device(x, x_nrm, weight, bias, out)
+def conv1x1_stat_tiles(d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_conv1x1_stat_tiles", d, h, w)
+
+
+def conv1x1(x, x_nrm, weight, bias, out, stats=None):
+    """1x1x1 convolution of act(x); with `stats` ([N * Cout * conv1x1_stat_tiles(D, H, W) * 3] floats) the kernel also leaves the InstanceNorm statistics of `out`"""
+    _lib.require_device(x, x_nrm, weight, bias, out, stats)
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
-    _lib.lib().call("mh_conv1x1_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
+    if stats is None:
+        _lib.lib().call("mh_conv1x1_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
+    else:
+        _lib.lib().call("mh_conv1x1_stats_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _lib.ptr(stats), _s(x))
     return out
 
 

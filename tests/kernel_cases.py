@@ -388,6 +388,36 @@ def case_conv1x1(device, n=2, cin=32, cout=5, dims=(6, 8, 12)):
     assert (out.cpu().double() - exp).abs().max().item() < 1e-5
 
 
+def case_conv1x1_stats(device):
+    """The 1x1x1 convolution that leaves the InstanceNorm statistics of its output (UnetResBlock's conv3 -> norm3 shortcut): same output as the plain launch, bit for
+    bit, and {alpha, beta} after the finalize equal to those of a stand-alone statistics pass over the output -- 16 + 8 + tail output channels, a plane that is not a
+    whole number of workgroup tiles, a plane whose size is not a multiple of 4 (one voxel per thread), a large mean (E[x^2] - E[x]^2 would lose digits)."""
+    gen = torch.Generator().manual_seed(15)
+    for n, cin, cout, dims in ((2, 32, 16, (6, 8, 44)), (1, 8, 27, (5, 7, 9)), (2, 4, 5, (16, 16, 20)), (1, 16, 48, (4, 4, 4))):
+        x = torch.randn((n, cin) + dims, generator=gen)
+        w = torch.randn((cout, cin), generator=gen) / np.sqrt(cin)
+        b = torch.randn(cout, generator=gen) * 0.1 + 30.0
+        nrm = _rand_nrm(n, cin, gen)
+        plain = torch.empty((n, cout) + dims, device=device)
+        ops.conv1x1(x.to(device), nrm.to(device), w.to(device), b.to(device), plain)
+        out = torch.full((n, cout) + dims, float("nan"), device=device)
+        tiles = ops.conv1x1_stat_tiles(*dims)
+        stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+        ops.conv1x1(x.to(device), nrm.to(device), w.to(device), b.to(device), out, stats)
+        assert torch.equal(out, plain), (cin, cout, dims)
+        st = stats.cpu().double()
+        assert not torch.isnan(st).any()
+        vox = dims[0] * dims[1] * dims[2]
+        assert torch.all(st[..., 0].sum(-1) == vox), "every voxel counted once"
+        got = torch.empty((n, cout, 4), device=device)
+        ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, got)
+        od = out.cpu().double()
+        alpha = 1.0 / torch.sqrt(od.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+        g = got.cpu().double()
+        assert ((g[:, :, 0] - alpha).abs() / alpha).max().item() < 2e-6, (cin, cout, dims)
+        assert (g[:, :, 1] + od.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 5e-5 * max(1.0, float(alpha.max())), (cin, cout, dims)
+
+
 def case_instnorm_stats(device, n=2, c=3, dims=(10, 17, 31)):
     gen = torch.Generator().manual_seed(6)
     x = torch.randn((n, c) + dims, generator=gen) * 3 + 50.0  # large mean: E[x^2]-E[x]^2 would lose digits

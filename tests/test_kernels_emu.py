@@ -140,6 +140,7 @@ def test_pool_deconv_1x1_stats(emu):
     kc.case_deconv("cpu")
     kc.case_deconv("cpu", n=1, cin=12, cout=16, dims=(3, 4, 6))     # full 8-channel groups, ragged input-channel batch
     kc.case_conv1x1("cpu")
+    kc.case_conv1x1_stats("cpu")
     kc.case_conv1x1("cpu", n=1, cin=13, cout=27, dims=(3, 5, 7))     # 16 + 8 + 3 output channels, ragged channel batch, scalar path
     kc.case_conv1x1("cpu", n=1, cin=6, cout=16, dims=(2, 4, 8))
     kc.case_conv1x1("cpu", cin=7, cout=11, dims=(3, 5, 7))

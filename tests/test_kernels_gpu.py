@@ -94,6 +94,7 @@ def test_pool_deconv_1x1_stats():
     kc.case_deconv(DEV)
     kc.case_deconv(DEV, n=2, cin=32, cout=32, dims=(8, 16, 48))
     kc.case_conv1x1(DEV)
+    kc.case_conv1x1_stats(DEV)
     kc.case_conv1x1(DEV, n=1, cin=13, cout=27, dims=(3, 5, 7))     # 16 + 8 + 3 output channels, ragged channel batch, scalar path
     kc.case_conv1x1(DEV, n=1, cin=6, cout=16, dims=(2, 4, 8))
     kc.case_conv1x1(DEV, cin=7, cout=11, dims=(3, 5, 7))
