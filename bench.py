@@ -314,6 +314,11 @@ def conv_roofline(spans, steps: int, ms: float, roi: int):
                  f"fp16's range by the input records' magnitude bounds, products hi*hi + lo*hi + hi*lo, fp32 accumulate: fp32-equivalent; 32|64 -> 32 ch @ {roi}^3 and the levels below)")
         gain, peak, pmc_key = 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
         extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS, "piece_products_per_multiply": 3}
+    elif cfg_id == _ops.conv3d_k3_h2c_config():     # the same kernel in output channel groups of 16: two z-taps per 32-column instruction, 6 instead of 9 per in-plane tap
+        kname = (f"conv3d_k3_h2_kernel<C16> (the split-precision kernel in output channel groups of 16: columns [kz 0 | kz 1] and [kz 2 | 0], a completed plane = the sum of three "
+                 f"partial planes; 16-couts layers @ {roi}^3)")
+        gain, peak, pmc_key = 1.0 / 4.0, PEAK_F16_TFLOPS, "conv3d_k3_h2c_kernel"      # 6 x 32 columns issued per 3 x 16 useful ones, x 3 piece products
+        extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS, "piece_products_per_multiply": 3, "columns_issued_per_useful": 4.0 / 3.0}
     elif cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
         kname = f"conv3d_k3_wino2p_kernel (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, two waves per SIMD, 32|64 -> 32 ch @ {roi}^3 / {roi // 2}^3)"
         gain, pmc_key = 2.25, "conv3d_k3_wino2p_kernel"

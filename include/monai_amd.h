@@ -162,6 +162,11 @@ int mh_conv3d_k3_h2_config(void);
  * monai/networks/blocks/convolutions.py:98-171), same record / bound contract and tolerance class as mh_conv3d_k3_h2_config; needs Cin % 16 == 0, Cin <= 128,
  * Cout % 32 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it under MH_ALGO_H2Z only: measured equal in time to the direct kernel in round 4. */
 int mh_conv3d_k3_h2z_config(void);
+/* mh_conv3d_k3_h2_config's kernel with output channel groups of 16 (round 4): a 32-column matrix instruction carries two z-taps of 16 couts instead of one tap of 32
+ * ([kz 0 | kz 1] and [kz 2 | 0]: 6 instead of 9 instructions per in-plane tap), a completed plane is the sum of three partial planes.  Same reference op, record / bound
+ * contract and tolerance class; Cin % 16 == 0, Cin <= 256, Cout % 16 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it for Cout == 16 (UNETR's / SwinUNETR's full-resolution
+ * levels), where a 32-couts group would be half zero weights. */
+int mh_conv3d_k3_h2c_config(void);
 /* Configuration outside 0 .. num_configs(): ONE input channel (the first layer of the networks), packed fp32 vector arithmetic
  * (kernels/conv3d_c1.h) -- exact fp32 like the matrix-core tiles, bound by writing the result instead of by multiplying a zero-padded
  * channel pair.  Needs Cin == 1, Cout % 8 == 0, W % 4 == 0; chosen by mh_conv3d_k3_select for such layers. */

@@ -424,6 +424,10 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // configuration MH_CFG_H2Z: the split-precision arithmetic behind a Winograd F(2, 3) transform along z (kernels/conv3d_h2z.h): 2 instead of 3 fp16 matrix
 // instructions per fp32 multiply-add of the direct form; regions of 8 x 32 outputs, pairs of output planes (even z-chunks); same tolerance class as MH_CFG_H2
 #define MH_CFG_H2Z (MH_NUM_CFG + 4)
+// configuration MH_CFG_H2C: MH_CFG_H2's kernel with output channel groups of 16, two z-taps sharing a 32-column matrix instruction (kernels/conv3d_h2.h, C16): layers
+// with 16 output channels (UNETR's full-resolution levels) at 6 instead of 9 matrix instructions per tap; same arithmetic and tolerance class as MH_CFG_H2
+#define MH_CFG_H2C (MH_NUM_CFG + 5)
+#define MH_CFG_LAST MH_CFG_H2C
 static inline int c1_chunks(int D) { return D >= 48 ? D / 24 : 1; }
 static inline int c1_zchunk(int D) { return cdiv(D, c1_chunks(D)); }
 static inline int c1_blocks(int D, int H, int W) { return cdiv(W, C1_TX) * cdiv(H, C1_TY) * cdiv(D, c1_zchunk(D)); }
@@ -476,6 +480,7 @@ static inline int h2z_blocks(int D, int H, int W) { return h2z_regions(H, W) * c
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_h2z_config(void) { return MH_CFG_H2Z; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
+int mh_conv3d_k3_h2c_config(void) { return MH_CFG_H2C; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
@@ -483,6 +488,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
     // round 4: the last cout group of the direct split kernel may be half full (Cout % 16 == 0 beyond 32: 48, 80, ... -- SwinUNETR(feature_size 48)'s full-resolution levels)
     if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0;
+    if (cfg == MH_CFG_H2C) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= 16 && Cout % 16 == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
     if (cfg == MH_CFG_H2Z) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= HZ_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
@@ -518,6 +524,10 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     // (`input_bounded`); anything else gets the exact fp32 kernels.
     if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2 || algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W))
         best = MH_CFG_H2;
+    // 16 output channels: the same kernel with two z-taps per matrix instruction (6 instead of 9 per tap; a 32-column group would be half zero weights)
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2 || algo == MH_ALGO_H2Z) && input_bounded && Cout == 16 && mh_conv3d_k3_accepts(MH_CFG_H2C, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W)
+        && knob_int("MONAI_AMD_H2C", 1) != 0)
+        best = MH_CFG_H2C;
     // the same arithmetic behind a Winograd F(2, 3) transform along z: 2/3 of the matrix instructions (kernels/conv3d_h2z.h).  Its regions are 8 x 32: taken where they cover
     // the plane as well as the direct kernel's regions do (96 x 96, 24 x 24; not 48 x 48: 12 regions against 9) and the march has at least four plane pairs
     if ((algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2Z, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && D >= 8 && h2_fits(D, H, W)
@@ -532,6 +542,7 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
 int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_WINO2D) return (int64_t)(Cin / W2_KC) * (Cout / W2_CN) * W2_UBUF;
     if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * cdiv(Cout, H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
+    if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg == MH_CFG_H2Z) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * (4 * HZ_WP) * 4 + H2_TAIL;   // four transformed positions x two fp16 pieces per chunk + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
@@ -545,6 +556,17 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
             return fail(MH_ERR_LAUNCH, "conv3d_k3_pack: memset failed");
         hipLaunchKernelGGL(conv3d_k3_wino2d_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, packed);
         return launched("conv3d_k3_wino2d_pack");
+    }
+    if (cfg == MH_CFG_H2C) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the 16-couts fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0");
+        const int64_t slab_floats = mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL;
+        float* tail = packed + slab_floats;
+        if (hipMemsetAsync(packed, 0, sizeof(float) * (size_t)slab_floats, (hipStream_t)stream) != hipSuccess)
+            return fail(MH_ERR_LAUNCH, "conv3d_k3_pack: memset failed");
+        hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
+        hipLaunchKernelGGL(conv3d_k3_h2c_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
+                           reinterpret_cast<_Float16*>(packed), tail);
+        return launched("conv3d_k3_h2c_pack");
     }
     if (cfg == MH_CFG_H2) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0, Cout >= 32");
@@ -581,7 +603,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
 
 int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
-    if (cfg == MH_CFG_H2) return h2_blocks(D, H, W);
+    if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) return h2_blocks(D, H, W);
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
     if (cfg == MH_CFG_H2Z) return h2z_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
@@ -604,7 +626,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
-    if (cfg < 0 || cfg > MH_CFG_H2Z) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
+    if (cfg < 0 || cfg > MH_CFG_LAST) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     if (in.nrm && !aligned(in.nrm, 16)) return fail(MH_ERR_ARG, "conv3d_k3: nrm must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (cfg == MH_CFG_C1) {
@@ -645,9 +667,10 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         else hipLaunchKernelGGL((conv3d_k3_h2z_kernel<false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
         return launched("conv3d_k3_h2z");
     }
-    if (cfg == MH_CFG_H2) {
+    if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) {
+        const bool c16 = cfg == MH_CFG_H2C;
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
-            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0 (>= 32), W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
+            return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs Cin %% 16 == 0, Cout %% 16 == 0 (>= 32; any multiple of 16 in its 16-couts form), W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
                         in.C, out.C, in.D, in.H, in.W);
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
             return fail(MH_ERR_ARG, "conv3d_k3: the fp16 split kernel needs 16-byte aligned output and weights");
@@ -656,22 +679,27 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         const bool wide = h2_wide(out.H, out.W);
         const int bxn = wide ? cdiv(out.W, 32) : cdiv(out.W, H2_B), byn = wide ? cdiv(out.H, 8) : cdiv(out.H, H2_B), zc = h2_zchunk(out.D, out.H, out.W);
         const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
-        const long long total = (long long)nblk * cdiv(out.C, H2_CN) * out.N;
+        const long long total = (long long)nblk * (c16 ? out.C / 16 : cdiv(out.C, H2_CN)) * out.N;
         if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-#define MH_H2_LAUNCH(RES_, WIDE_)                                                                                                                        \
+#define MH_H2_LAUNCH(RES_, WIDE_, C16_)                                                                                                                  \
     {                                                                                                                                                \
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
-        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
+        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
     }
-        if (in.C <= 2 * H2_KC) { if (wide) MH_H2_LAUNCH(true, true) else MH_H2_LAUNCH(true, false) }
-        else { if (wide) MH_H2_LAUNCH(false, true) else MH_H2_LAUNCH(false, false) }
+        if (c16) {
+            if (in.C <= 2 * H2_KC) { if (wide) MH_H2_LAUNCH(true, true, true) else MH_H2_LAUNCH(true, false, true) }
+            else { if (wide) MH_H2_LAUNCH(false, true, true) else MH_H2_LAUNCH(false, false, true) }
+        } else {
+            if (in.C <= 2 * H2_KC) { if (wide) MH_H2_LAUNCH(true, true, false) else MH_H2_LAUNCH(true, false, false) }
+            else { if (wide) MH_H2_LAUNCH(false, true, false) else MH_H2_LAUNCH(false, false, false) }
+        }
 #undef MH_H2_LAUNCH
-        return launched("conv3d_k3_h2");
+        return launched(c16 ? "conv3d_k3_h2c" : "conv3d_k3_h2");
     }
     if (cfg == MH_CFG_WINO2D) {
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.H % 2 || in.W % 8)

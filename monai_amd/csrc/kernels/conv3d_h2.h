@@ -118,7 +118,11 @@ __device__ __forceinline__ void h2_split_pair(float v0, float v1, float m1, f16x
 #else
 #define MH_H2X_EXTRA_READS(P)
 #endif
-template <bool STATS, bool NRM, bool RES, bool WIDE = false>
+// C16 (round 4): output channel groups of 16 -- a layer with 16 couts (UNETR's full-resolution levels) would leave half of a 32-column matrix instruction to zero weights.
+// The columns carry two z-taps instead: B = [W(kz 0) | W(kz 1)] (accumulator X) and [W(kz 2) | 0] (accumulator Y) -- 6 instead of 9 matrix instructions per (ky, kx) tap
+// and 16 channels.  X of input plane p holds in its low 16 columns what output plane p + 1 gets from it and in its high 16 what plane p gets; Y's low 16 belong to plane
+// p - 1: a completed plane is  X(p - 2).low + X(p - 1).high + Y(p).low  -- two register-set additions and one 16-lane exchange per plane.  Packed by conv3d_k3_h2c_pack_kernel.
+template <bool STATS, bool NRM, bool RES, bool WIDE = false, bool C16 = false>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
@@ -138,7 +142,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const int NCH = Cin / H2_KC;                              // steps per input plane (the launcher requires Cin % 16 == 0)
 
     // launch geometry of conv3d_wino2d.h: 1-D over (window, region, cout group), cout group fastest, XCD-aware
-    const unsigned ncg = (unsigned)((Cout + H2_CN - 1) / H2_CN);      // round 4: the last group may hold fewer than 32 couts (Cout % 16 == 0: 48, 80, ...): its missing
+    constexpr int CG = C16 ? 16 : H2_CN;                               // output channels per workgroup
+    const unsigned ncg = (unsigned)((Cout + CG - 1) / CG);            // round 4: the last group may hold fewer than 32 couts (Cout % 16 == 0: 48, 80, ...): its missing
     unsigned lid = xcd_remap(blockIdx.x, gridDim.x);                    // couts have zero weights in the packed slab, their stores and statistics are dropped
     const int cg = (int)(lid % ncg);
     lid /= ncg;
@@ -264,8 +269,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     const int bbase = kg * H2_CN + r32;
 
     // acc[0], acc[1], acc[2]: output planes p+1, p, p-1 of the current input plane p (rotated once per plane, 48 moves);
-    // acce: the completed plane waiting for its epilogue
-    f32x16 acc[3], acce;
+    // acce: the completed plane waiting for its epilogue.  (C16: acc[0] = X, acc[1] = Y of the current plane, acc[2] = X of the plane before, accp = X of the one before that)
+    f32x16 acc[3], acce, accp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accp[i] = 0.0f;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -273,8 +280,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     int pend = 0, pend_z = 0;
 
     // epilogue: lane = cout r32; register 4 j + i = voxel row (j >> 1) of the wave's two, x = xg(j) + i (WIDE: the wave's one row, x = 8 j + 4 kg + i)
-    const int co = cg * H2_CN + r32;
-    const bool cok = co < Cout;
+    const int co = cg * CG + (C16 ? (r32 & 15) : r32);
+    const bool cok = co < Cout && (!C16 || r32 < 16);                 // C16: a completed plane sits in the lanes of the low 16 columns
     const float bco = (bias && cok) ? bias[co] : 0.0f;
     // scale back: 2^-(weight scale exponent) * 2^-e_in as two power-of-two factors (their product may leave fp32's exponent range)
     float inv_a, inv_b;
@@ -288,7 +295,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     // Result stores go through a raw buffer over the 32 cout planes of this (sample, cout group): 32-bit byte offsets, and a lane without a voxel
     // (ragged region, no completed plane yet) stores at an offset beyond the buffer, which the hardware drops -- no exec-mask branch, so the
     // epilogue stays inside the scheduling region of the matrix instructions (the launcher keeps 32 planes below 2 GB)
-    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * H2_CN) * DHW, 0, (int)(min(H2_CN, Cout - cg * H2_CN) * DHW * 4), 0x00020000);
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * CG) * DHW, 0, (int)(min(CG, Cout - cg * CG) * DHW * 4), 0x00020000);
     constexpr unsigned H2_DROP = 0x80000000u;
     unsigned ooff[4];                                        // byte offset of register group j inside an output plane of cout r32 (or H2_DROP)
 #pragma unroll
@@ -296,7 +303,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         const int xg_ = WIDE ? 8 * j + 4 * kg : j < 2 ? 8 * j + 4 * kg : ((8 * (j - 2) + 4 * kg + 12) & 15);
         const int yr_ = WIDE ? 0 : (j >> 1);
         const bool ok_ = cok && y0 + orow + yr_ < H && x0 + xg_ < W;
-        ooff[j] = ok_ ? 4u * (unsigned)((long long)r32 * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
+        ooff[j] = ok_ ? 4u * (unsigned)((long long)(C16 ? (r32 & 15) : r32) * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
     }
     f32x4 o_[4];                                             // the plane being emitted: its pieces A (scale, bias, store), B1-B3 (statistics) sit in different taps
     float esum_ = 0.0f, ecnt_ = 0.0f, em2_ = 0.0f, emean_ = 0.0f;
@@ -311,14 +318,18 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         const uint4* wb_ = ws + bcur * H2_WB + (T_) * (2 * H2_CN) + bbase;                            \
         ah[OB] = xb_[0]; al[OB] = xb_[H2_XV];                                      \
         MH_H2X_EXTRA_READS(wb_)                                                                       \
-        _Pragma("unroll") for (int kz = 0; kz < 3; ++kz) {                                            \
+        _Pragma("unroll") for (int kz = 0; kz < (C16 ? 2 : 3); ++kz) {                                \
             bh[OB][kz] = wb_[kz * (9 * 2 * H2_CN)]; bl[OB][kz] = wb_[H2_WV + kz * (9 * 2 * H2_CN)]; \
         }                                                                                             \
     }
 #define MH_H2_MM(S, A, B) acc[S] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[S], 0, 0, 0);
     // z-taps 0, 1, 2 of input plane p feed output planes p+1, p, p-1
 #define MH_H2_MFMA9(OB)                                                                               \
-    {                                                                                                 \
+    if (C16) {      /* columns [kz 0 | kz 1] -> X, [kz 2 | 0] -> Y */                                 \
+        MH_H2_MM(0, ah[OB], bh[OB][0]) MH_H2_MM(1, ah[OB], bh[OB][1])                                 \
+        MH_H2_MM(0, al[OB], bh[OB][0]) MH_H2_MM(1, al[OB], bh[OB][1])                                 \
+        MH_H2_MM(0, ah[OB], bl[OB][0]) MH_H2_MM(1, ah[OB], bl[OB][1])                                 \
+    } else {                                                                                          \
         MH_H2_MM(0, ah[OB], bh[OB][0]) MH_H2_MM(1, ah[OB], bh[OB][1]) MH_H2_MM(2, ah[OB], bh[OB][2])  \
         MH_H2_MM(0, al[OB], bh[OB][0]) MH_H2_MM(1, al[OB], bh[OB][1]) MH_H2_MM(2, al[OB], bh[OB][2])  \
         MH_H2_MM(0, ah[OB], bl[OB][0]) MH_H2_MM(1, ah[OB], bl[OB][1]) MH_H2_MM(2, ah[OB], bl[OB][2])  \
@@ -332,11 +343,11 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         if ((T_) + 1 < 9) MH_H2_FETCH(((T_) + 1) & 1, ((T_) + 1 < 9 ? (T_) + 1 : 0))                  \
         __VA_ARGS__                                                                                   \
         MH_H2_MFMA9((T_) & 1)                                                                         \
-        _Pragma("unroll") for (int g_ = 0; g_ < 9; ++g_) {                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < (C16 ? 6 : 9); ++g_) {      /* C16: the same staging work in two thirds of the gaps */ \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                      \
-            __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, C16 ? 2 : 1, 0);                              \
+            __builtin_amdgcn_sched_group_barrier(0x006, C16 ? ((NV_) * 3 + 1) / 2 : (NV_), 0);        \
+            __builtin_amdgcn_sched_group_barrier(0x230, C16 ? 2 : 1, 0);                              \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -433,13 +444,25 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         }
         if (p - 1 >= zs) {              // output plane p-1 is complete in set 2 (planes in front of the chunk are simply dropped)
             if (pend) MH_H2_EMIT        // only when no step ran since the previous plane (p == D)
-            acce = acc[2];
+            if (C16) {                  // X(p - 2).low + X(p - 1).high + Y(p).low, in the lanes of the low 16 columns
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acce[i] = (accp[i] + __shfl_xor(acc[2][i], 16)) + acc[1][i];
+            } else {
+                acce = acc[2];
+            }
             pend = 1; pend_z = p - 1;
         }
-        acc[2] = acc[1];
-        acc[1] = acc[0];
+        if (C16) {
+            accp = acc[2];
+            acc[2] = acc[0];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+            for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+        } else {
+            acc[2] = acc[1];
+            acc[1] = acc[0];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+        }
     }
     if (pend) MH_H2_EMIT
 #undef MH_H2_STEP
@@ -480,7 +503,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             red[(wave * H2_CN + r32) * 3] = run.n; red[(wave * H2_CN + r32) * 3 + 1] = run.mean; red[(wave * H2_CN + r32) * 3 + 2] = run.m2;
         }
         __syncthreads();
-        if (tid < H2_CN && cg * H2_CN + tid < Cout) {
+        if (tid < CG && cg * CG + tid < Cout) {
             Stat st;
             st.n = 0.0f; st.mean = 0.0f; st.m2 = 0.0f;
 #pragma unroll
@@ -489,7 +512,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
                 ot.n = red[(w * H2_CN + tid) * 3]; ot.mean = red[(w * H2_CN + tid) * 3 + 1]; ot.m2 = red[(w * H2_CN + tid) * 3 + 2];
                 st = stat_merge(st, ot);
             }
-            float* rec = stats + (((long long)n * Cout + cg * H2_CN + tid) * nblk + b) * 3;
+            float* rec = stats + (((long long)n * Cout + cg * CG + tid) * nblk + b) * 3;
             rec[0] = st.n; rec[1] = st.mean; rec[2] = st.m2;
         }
     }
@@ -540,6 +563,28 @@ conv3d_k3_h2_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float1
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             slab[(((p * 27 + tap) * 2 + (ci % H2_KC) / 8) * H2_CN + (co % H2_CN)) * 8 + (ci % 8)] = pc[p];
+    }
+}
+
+// The C16 form: w [Cout][Cin][3][3][3] -> [cout group of 16][chunk][piece][slot v * 9 + (ky, kx)][k-group][32 columns][8 channels]: v = 0 columns = [kz 0 | kz 1] of the
+// group's 16 couts, v = 1 columns = [kz 2 | zeros]; the slots of v = 2 stay zero (the buffer is zeroed first) and are never multiplied.
+__global__ void __launch_bounds__(256)
+conv3d_k3_h2c_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float16* __restrict__ packed, const float* __restrict__ tail) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int ci = idx % Cin, co = idx / Cin;
+    const int nchunk = Cin / H2_KC;
+    const float s = tail[1];
+    _Float16* slab = packed + ((long long)(co / 16) * nchunk + ci / H2_KC) * (H2_WB * 8LL);
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int kz = tap / 9, t9 = tap % 9;
+        const int slot = (kz == 2 ? 9 : 0) + t9, col = (kz == 1 ? 16 : 0) + (co % 16);
+        _Float16 pc[2];
+        h2_split(w[((long long)co * Cin + ci) * 27 + tap] * s, pc[0], pc[1]);
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            slab[(((p * 27 + slot) * 2 + (ci % H2_KC) / 8) * H2_CN + col) * 8 + (ci % 8)] = pc[p];
     }
 }
 

@@ -314,6 +314,12 @@ def conv3d_k3_h2z_config() -> int:
     return _lib.lib().query("mh_conv3d_k3_h2z_config")
 
 
+def conv3d_k3_h2c_config() -> int:
+    """Id of the split-precision configuration with output channel groups of 16 (two z-taps per 32-column matrix instruction): what `conv3d_k3_select` returns for
+    bounded inputs of layers with 16 output channels; same tolerance class as `conv3d_k3_h2_config`."""
+    return _lib.lib().query("mh_conv3d_k3_h2c_config")
+
+
 def conv3d_k3_c1_config() -> int:
     """Id of the one-input-channel configuration (first layer of the networks: packed fp32 vector arithmetic, write-bound, exact fp32);
     outside 1 .. conv3d_k3_num_configs()."""

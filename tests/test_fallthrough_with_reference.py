@@ -188,17 +188,26 @@ def test_fused_argmax_and_moved_buffers_fall_through_cleanly(patched):
 
 def test_no_monai_keeps_the_explicit_error():
     """Without MONAI on the path nothing can be delegated: the original explicit error is raised."""
-    for m in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]:
-        del sys.modules[m]
+    # the process is shared with other tests (pytest-xdist hands a worker tests of several files): the imported reference modules and the path entry are put back
+    # afterwards -- a second, fresh `monai` next to classes that were derived from the first one breaks every later isinstance check against the reference
+    gone = {k: sys.modules.pop(k) for k in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]}
+    had_path = REF in sys.path
     import monai_amd._fallback as fb
     from monai_amd.networks.nets import BasicUNet
 
-    if REF in sys.path:
-        sys.path.remove(REF)
-    assert fb.reference_object("monai.networks.nets.basic_unet", "BasicUNet") is None
-    with pytest.raises(NotImplementedError):
-        BasicUNet(spatial_dims=1)
-    with pytest.raises(NotImplementedError):
-        BasicUNet(spatial_dims=3, upsample="pixelshuffle")
-    with pytest.raises(RuntimeError):
-        BasicUNet(spatial_dims=3).eval()(torch.rand(1, 1, 32, 32, 32))
+    try:
+        if had_path:
+            sys.path.remove(REF)
+        assert fb.reference_object("monai.networks.nets.basic_unet", "BasicUNet") is None
+        with pytest.raises(NotImplementedError):
+            BasicUNet(spatial_dims=1)
+        with pytest.raises(NotImplementedError):
+            BasicUNet(spatial_dims=3, upsample="pixelshuffle")
+        with pytest.raises(RuntimeError):
+            BasicUNet(spatial_dims=3).eval()(torch.rand(1, 1, 32, 32, 32))
+    finally:
+        for k in [k for k in sys.modules if k == "monai" or k.startswith("monai.")]:
+            del sys.modules[k]
+        sys.modules.update(gone)
+        if had_path and REF not in sys.path:
+            sys.path.insert(0, REF)

@@ -200,6 +200,23 @@ def test_conv3d_split_precision_z_winograd(emu, cin, cout, dims, n):
     kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
+
+# 16-couts groups (two z-taps per matrix instruction): one group / two / three groups, resident and streamed weight slabs, both region shapes, ragged regions, two z-chunks
+H2C_CASES = [(16, 16, (4, 16, 16), 2), (32, 16, (5, 16, 16), 1), (48, 32, (3, 8, 24), 1), (16, 48, (6, 8, 24), 1), (32, 16, (3, 18, 20), 1), (64, 16, (2, 24, 56), 1),
+             (16, 16, (24, 8, 24), 1), (16, 16, (30, 4, 8), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", H2C_CASES)
+def test_conv3d_split_precision_16_couts(emu, cin, cout, dims, n):
+    """the direct split-precision kernel with output channel groups of 16 (conv3d_h2.h, C16): a completed plane is the sum of three partial planes held in different
+    column halves -- the SAME tolerance as the 32-couts form and the fp32 tiles; what conv3d_k3_select returns for bounded 16-couts layers"""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_h2c_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and not ops.conv3d_k3_accepts(cfg, 16, 24)
+    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+    if cout == 16 and dims[1] >= 8 and dims[2] >= 8:
+        assert ops.conv3d_k3_select(cin, cout, *dims, bounded=True, algo=0) == cfg and ops.conv3d_k3_select(cin, cout, *dims, bounded=False, algo=0) != cfg and ops.conv3d_k3_select(cin, cout, *dims, bounded=True, algo=4) != cfg      # auto: yes; unbounded input or the exact-fp32 family: no
+
 @pytest.mark.parametrize("cin,cout,dims,n", H2_CASES)
 def test_conv3d_fp16_split_precision(emu, cin, cout, dims, n):
     """z-streaming direct convolution on the fp16 matrix cores, two fp16 pieces per operand and three exact piece products per
