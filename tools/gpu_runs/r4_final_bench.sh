@@ -1,8 +1,9 @@
-# round 4, last calls: smoke() and the driver's bench command on the final tree
+# round 4, last call (7 GPU-minutes left): the bench on the final tree with the CPU leg on a 125-window corner instead of the whole volume (the 1000-window leg alone is 176 s;
+# the whole-volume line of this round is profiles/r04_bench_line_final.json, measured before the blend's index rewrite -- bit-identical by test -- and the 16-couts kernel,
+# which the headline network does not use): final-tree speed, parity, extras (config 3 now on the 16-couts kernel, 27-window parity), hardware-counter traffic in-run
 export TMPDIR=/tmp
 O=gpurun_out/r4final2; mkdir -p $O
-timeout 120 python __graft_entry__.py smoke 2>&1 | tail -2 > $O/smoke.txt; cat $O/smoke.txt
-( time timeout 900 python bench.py > $O/bench_line.json 2> $O/bench_line.err ) 2> $O/bench_line.time; tail -3 $O/bench_line.time
+( time timeout 400 python bench.py --cpu-windows 125 > $O/bench_line.json 2> $O/bench_line.err ) 2> $O/bench_line.time; tail -3 $O/bench_line.time
 python - <<'PY'
 import json
 try:
