@@ -26,3 +26,22 @@ def conv_algo() -> int:
         return CONV_ALGOS[str(name).lower()]
     except KeyError:
         raise ValueError(f"monai_amd: unknown convolution family {name!r} (one of {sorted(CONV_ALGOS)})") from None
+
+
+class conv_algo_scope:
+    """`with config.conv_algo_scope("fp32"): ...` -- the family for the calls inside the block, the previous setting restored on exit (also when the body raises)."""
+
+    def __init__(self, name: str):
+        if str(name).lower() not in CONV_ALGOS:
+            raise ValueError(f"monai_amd: unknown convolution family {name!r} (one of {sorted(CONV_ALGOS)})")
+        self.name = str(name).lower()
+
+    def __enter__(self):
+        global CONV_ALGO
+        self._saved, CONV_ALGO = CONV_ALGO, self.name
+        return self
+
+    def __exit__(self, *exc):
+        global CONV_ALGO
+        CONV_ALGO = self._saved
+        return False

@@ -40,6 +40,25 @@ def disable_window_sharding() -> None:
     _GROUP, _ENABLED = None, False
 
 
+class window_sharding:
+    """Scoped form of enable / disable_window_sharding: `with parallel.window_sharding(group): out = inferer(vol, net)` -- the previous state (off, or an outer scope's
+    group) is restored on exit, also when the body raises.  The switch itself stays a property of the process (one inference stream per rank, the layout bench.py and
+    the reference's one-process-per-GPU launchers use); two threads of one rank that shard over different groups must serialise their scopes."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __enter__(self):
+        self._saved = (_GROUP, _ENABLED)
+        enable_window_sharding(self.group)
+        return self
+
+    def __exit__(self, *exc):
+        global _GROUP, _ENABLED
+        _GROUP, _ENABLED = self._saved
+        return False
+
+
 # ---- in-place all-gather: probed once per process group -------------------------------------------------------------------------
 # RCCL / NCCL run all_gather in place when the send buffer is exactly the rank's own slot of the receive buffer (recv + rank * count);
 # torch.distributed documents no aliasing guarantee, and other backends (or a future release) may reject or mis-handle it.  One tiny

@@ -181,3 +181,46 @@ def test_round_schedule_covers_every_window_once():
                         assert w0 == q * world * nb + r * nb and 0 <= n <= nb and w0 + n <= max(num_win, w0)
                         seen += list(range(w0, w0 + n))
                 assert sorted(seen) == list(range(num_win))
+
+
+def test_scoped_switches_restore_the_previous_state():
+    """`parallel.window_sharding(group)` and `config.conv_algo_scope(name)`: scoped forms of the two process-wide host switches -- nested scopes restore the outer
+    state, an exception inside the body restores it too, an unknown family is refused before anything changes."""
+    from monai_amd import config, parallel
+
+    saved = config.CONV_ALGO
+    try:
+        config.CONV_ALGO = "auto"
+        with config.conv_algo_scope("fp32"):
+            assert config.conv_algo() == config.CONV_ALGOS["fp32"]
+            with config.conv_algo_scope("h2"):
+                assert config.conv_algo() == config.CONV_ALGOS["h2"]
+            assert config.CONV_ALGO == "fp32"
+        assert config.CONV_ALGO == "auto"
+        with pytest.raises(RuntimeError):
+            with config.conv_algo_scope("direct"):
+                raise RuntimeError("body failed")
+        assert config.CONV_ALGO == "auto"
+        with pytest.raises(ValueError):
+            config.conv_algo_scope("no-such-family")
+    finally:
+        config.CONV_ALGO = saved
+
+    assert not parallel._ENABLED
+    with pytest.raises(RuntimeError):          # no process group: refused, and nothing is left switched on
+        with parallel.window_sharding():
+            pass
+    assert not parallel._ENABLED and parallel._GROUP is None
+    port = _free_port()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with parallel.window_sharding():
+            assert parallel._ENABLED and parallel._GROUP is None
+            sub = dist.new_group([0])
+            with parallel.window_sharding(sub):
+                assert parallel._GROUP is sub
+            assert parallel._ENABLED and parallel._GROUP is None
+        assert not parallel._ENABLED
+    finally:
+        dist.destroy_process_group()
