@@ -212,13 +212,15 @@ class UNETR(nn.Module):
         self._stats = None
 
     # ---- helpers -----------------------------------------------------------------------------------
-    def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
+    def _packed_weight(self, conv: nn.Conv3d, cfg: int, part=None) -> torch.Tensor:
+        """the layer's weights packed for configuration `cfg` (cached; re-packed when the parameter changed); `part` = (lo, hi): output channels lo .. hi - 1 only"""
         w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device), cfg)
-        hit = self._packed.get(id(conv))
+        key = (w.data_ptr(), w._version, str(w.device), cfg, part)
+        slot = id(conv) if part is None else (id(conv), part)
+        hit = self._packed.get(slot)
         if hit is None or hit[0] != key:
-            hit = (key, ops.conv3d_k3_pack(cfg, w))
-            self._packed[id(conv)] = hit
+            hit = (key, ops.conv3d_k3_pack(cfg, w if part is None else w[part[0]:part[1]]))
+            self._packed[slot] = hit
         return hit[1]
 
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
@@ -235,6 +237,20 @@ class UNETR(nn.Module):
         cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
         out = torch.empty((n, cout, d, h, w), dtype=torch.float32, device=x.device)
         nrm = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
+        h2, h2c = ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config()
+        if cfg == h2 and cout % 32 == 16 and ops.conv3d_k3_accepts(h2c, cin, 16):
+            # 48, 80, ... couts on the split-precision kernel (SwinUNETR(48)'s full-resolution levels): the last 16 as a group of their own in the 16-couts form (6
+            # matrix instructions per tap) instead of a half-filled group of 32 (9): two launches into channel slices, two statistics sets (same tile count)
+            tiles = ops.conv3d_k3_stat_tiles(h2, d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            lo = 0
+            for part_cfg, hi in ((h2, cout - 16), (h2c, cout)):
+                st = stats[n * lo * tiles * 3:n * hi * tiles * 3]
+                with _prof.span(f"conv3d_k3/cfg{part_cfg}", 2.0 * 27 * cin * (hi - lo) * d * h * w * n):
+                    ops.conv3d_k3(part_cfg, x, x_nrm, self._packed_weight(conv, part_cfg, (lo, hi)), None, out[:, lo:hi], st)
+                ops.instnorm_finalize(st, tiles, n, hi - lo, None, None, 1e-5, slope, nrm[:, lo:hi])
+                lo = hi
+            return out, nrm
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
         flops = 2.0 * 27 * cin * cout * d * h * w * n
         if tiles:

@@ -621,3 +621,56 @@ def case_mosaic_layout_equals_window_major(device, cases=MOSAIC_CASES, features=
             assert torch.equal(a, b), f"{shape} overlap {overlap}: mosaic and window-major logits layouts differ by {(a - b).abs().max().item()}"
     finally:
         U._alloc_mosaic = real
+
+
+def case_conv_cout_16_mod_32_split(device, cin=32, cout=48, dims=(6, 16, 16), n=2):
+    """The conv engine of UNETR / SwinUNETR (`UNETR._conv3_in`) on a layer whose output channels are 16 mod 32 (SwinUNETR(48): 48): under the split-precision
+    family the first cout - 16 channels go through the 32-couts form, the last 16 through the 16-couts form -- two launches into channel slices of one output,
+    two statistics sets, two finalizes into slices of one record tensor.  Output against fp64 conv3d of the activated input, records against the output's own
+    statistics; both configurations must have run; under the exact-fp32 family there is one launch."""
+    import torch.nn.functional as F
+
+    import kernel_cases as kc
+    from monai_amd import config, ops
+    from monai_amd.networks.nets import UNETR
+
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    nrm = kc._with_bounds(x, kc._rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(dims))))
+    conv = torch.nn.Conv3d(cin, cout, 3, padding=1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / np.sqrt(27.0 * cin))
+    exp = F.conv3d(kc._act(x.double(), nrm.double()), conv.weight.double(), padding=1)
+    conv = conv.to(device)
+    seen = []
+    real = ops.conv3d_k3
+
+    def spy(cfg, *a, **k):
+        seen.append(int(cfg))
+        return real(cfg, *a, **k)
+
+    res = {}
+    ops.conv3d_k3 = spy
+    try:
+        for algo in ("auto", "fp32"):
+            eng = object.__new__(UNETR)          # the conv-engine helpers need only these two attributes
+            eng._packed, eng._stats = {}, None
+            seen.clear()
+            with config.conv_algo_scope(algo):
+                out, rec = eng._conv3_in(conv, x.to(device), nrm.to(device), 0.01)
+            if algo == "auto":
+                assert seen == [ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config()], seen
+            else:
+                assert len(seen) == 1 and seen[0] <= ops.conv3d_k3_num_configs(), seen
+            got = out.cpu().double()
+            err = (got - exp).abs().max().item()
+            assert err < 2e-5 * max(1.0, exp.abs().max().item()), (algo, err)
+            r = rec.cpu().double()
+            alpha = 1.0 / torch.sqrt(got.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+            assert ((r[:, :, 0] - alpha).abs() / alpha).max().item() < 1e-5, algo
+            assert (r[:, :, 1] + got.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 2e-5, algo
+            assert torch.all(r[:, :, 2] == torch.tensor(0.01, dtype=torch.float32).double()) and torch.all(r[:, :, 3] >= kc._amax(got, r[:, :, :3]))
+            res[algo] = err
+    finally:
+        ops.conv3d_k3 = real
+    return res

@@ -79,6 +79,11 @@ def test_bundle_shaped_pipeline_vs_reference(emu):
     print(pl.case_pipeline_vs_reference("cpu"))
 
 
+def test_conv_engine_splits_couts_16_mod_32(emu):
+    print(ec.case_conv_cout_16_mod_32_split("cpu"))
+    print(ec.case_conv_cout_16_mod_32_split("cpu", cin=16, cout=80, dims=(3, 8, 24), n=1))
+
+
 def test_dynunet_vs_reference(emu):
     import dynunet_cases as dc
 

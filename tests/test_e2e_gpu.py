@@ -199,6 +199,11 @@ def test_buffered_schedule_bitwise_vs_reference():
     assert ec.case_buffered_blend_vs_golden(DEV) >= 8
 
 
+def test_conv_engine_splits_couts_16_mod_32():
+    print(ec.case_conv_cout_16_mod_32_split(DEV))
+    print(ec.case_conv_cout_16_mod_32_split(DEV, cin=48, cout=48, dims=(24, 32, 32), n=2))
+
+
 def test_unetr_small_vs_reference():
     print(ec.case_unetr_small_vs_golden(DEV))
 
