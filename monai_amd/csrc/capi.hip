@@ -342,7 +342,7 @@ int mh_sw_blend_mosaic_f32(const float* logits, const int64_t* class_base, int l
                 max_ext = std::max(max_ext, std::max((long long)ms.z.cnt[a] * rd, std::max((long long)ms.y.cnt[b] * rh, (long long)ms.x.cnt[c] * rw)));
             }
         }
-    const bool fast = max_cs * K < MH_BLEND_IDX32_LIMIT && max_zy < (1LL << 24) && max_ext < (1LL << 23) && knob_int("MONAI_AMD_BLEND_IDX64", 0) == 0;
+    const bool fast = max_cs * K < MH_BLEND_IDX32_LIMIT && max_zy < (1LL << 24) && max_ext < (1LL << 23) && std::max(D, std::max(H, W)) < (1 << 23) && knob_int("MONAI_AMD_BLEND_IDX64", 0) == 0;
 #define MH_BM(KT, G_, NT_, SEP_) { if (fast) hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_, true>), dim3(nb, D), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); \
                                    else hipLaunchKernelGGL((sw_blend_mosaic_kernel<KT, G_, NT_, SEP_, false>), dim3(nb, D), dim3(256), 0, s, logits, imp, out, K, D, H, W, rd, rh, rw, rg, ms); }
 #ifdef MH_DEV_KNOBS
