@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ARGS = ["--size", "40", "--roi", "32", "--steps", "1", "--warmup", "0", "--harness-features", "16,16,32,32,64,16"]      # quarter widths: the SIMT emulator pays for every flop
+ARGS = ["--size", "40", "--roi", "32", "--steps", "1", "--warmup", "0", "--harness-features", "8,8,16,16,32,8"]      # an eighth of the widths: the SIMT emulator pays for every flop
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
         "roofline", "roofline_hbm", "cpu_baseline"}
 

@@ -11,9 +11,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-# a quarter of the default widths: the test is about sharding / gathering / blending, not about the convolutions (which other tests
+# an eighth of the default widths: the test is about sharding / gathering / blending, not about the convolutions (which other tests
 # cover at full width), and the SIMT emulator pays for every flop
-FEATURES = (16, 16, 32, 64, 128, 16)
+FEATURES = (8, 8, 16, 32, 64, 8)
 
 
 def _free_port():
