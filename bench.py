@@ -9,24 +9,14 @@ One "step" = one complete ``SlidingWindowInferer(...)(volume, net)`` call: windo
 all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + normalise.  The volume -- the reference's own
 ``create_test_image_3d`` phantom of SURVEY.md 8(d) config 1, restated bit-identically in oracle/synthetic.py -- is resident
 in HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2 of
-BASELINE.json).  Rank 0 prints ONE JSON line:
+BASELINE.json).  Rank 0 prints ONE JSON line of numbers and short labels (< 6 KB: the driver keeps a bounded tail of stdout); what every
+key means, how it is measured and which caveats apply is written down ONCE in DESIGN.md section 6.3 ("the bench line"), not in the line:
 
-  roofline      the dominant kernel (the split-precision 3x3x3 convolution), HIP events around its launches inside the timed
-                region: `achieved` = matrix-core flops ISSUED per launch / average launch time, `frac` = achieved / the dense
-                MFMA peak of the instruction it issues (a true fraction); the convolution's own flops are `algorithmic_tflops`;
-  roofline_hbm  the blend: 20.38 GB of algorithmic traffic / its launch time, against the 8 TB/s spec; `traffic` of both rooflines = HBM bytes per
-                launch from FETCH_SIZE / WRITE_SIZE, collected by two rocprofv3 child processes of this run (pmc_inrun; the committed builder pass if that fails);
-  cpu_baseline  the CPU oracle (a port of the reference path: the same ATen CPU operators, bit-identical to the reference --
-                tests/test_oracle_golden.py) running the COMPLETE inferer (windows, network, blend) on the WHOLE benchmark volume --
-                all 1000 windows, the per-window network in worker processes (oracle/parallel_predict.py), the blend in the reference's
-                window order -- timed on the host cores; `parity_vs_gpu` is the headline parity rule (oracle/parity.py) over every
-                output voxel of the timed steps' result (134 217 728 voxels x 5 logits).  A probe batch prices the leg first: if it would
-                exceed --cpu-budget-s (900 s) the largest corner sub-volume that fits is taken and the line says so;
-  extra         (N = 1) fp32_exact: the same workload with the exact-fp32 convolution kernels (config CONV_ALGO "fp32") and its parity
-                against the same whole-volume reference; config3: UNETR ViT-B/16 on the same volume (attention kernel's MFMA rate, parity
-                of the complete inferer on a 27-window corner vs the oracle, the oracle's CPU time per window); config4: Spacing +
-                GaussianSmooth on 4 x 512^3 (kernel times against 8 TB/s and against a device copy measured in the same run, parity on
-                a 128^3 volume, the reference path's CPU time on one 512^3 volume with the product's full-size result against it).
+  parity              the headline family's whole-volume parity against the CPU oracle (134 217 728 voxels x 5 logits), at top level
+  reference_self_spread   the oracle against ITSELF (1 thread vs the pool's thread layout; oneDNN off vs on): what "bit-exact argmax" means for the reference
+  roofline / roofline_hbm the dominant convolution kernel (matrix flops issued / launch time vs the fp16 MFMA peak) and the blend (bytes / time vs 8 TB/s)
+  cpu_baseline        the complete CPU-oracle inferer on the host cores (kind "port", bit-pinned to the reference by tests/test_oracle_golden.py)
+  extra               fp32_exact (exact-fp32 kernels, same workload + parity), config3 (UNETR), config4 (Spacing + GaussianSmooth on 4 x 512^3)
 """
 
 from __future__ import annotations
@@ -109,15 +99,70 @@ def HOST_LAYOUT_UNDER_QUOTA(cpus: int):
     return 2, max(1, cpus // 2)
 
 
-def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer, full_out, budget_s: float, more=None):
-    """CPU oracle = port of the reference path (kind "port": the same ATen CPU operators in the same order, pinned bit-for-bit to the real reference by
-    tests/test_oracle_golden.py -- the GPU box has no MONAI): the COMPLETE sliding-window inference -- window loop, BasicUNet, importance-weighted blend -- on the host
-    cores, and the product's output on the same voxels against it (`parity_vs_gpu`, the headline rule of oracle/parity.py on the BLENDED logits).
-    Default: the WHOLE benchmark volume (1000 windows, every output voxel compared).  The per-window network runs in several worker processes
-    (oracle/parallel_predict.py), the blend in this process in the reference's window order.  A probe batch prices the run first: when the whole volume would
-    exceed `budget_s` seconds the largest corner sub-volume that fits is taken instead (and the line says so)."""
+def _short_parity(rep: dict, family: str) -> dict:
+    """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py)"""
+    return {"family": family, "voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "tolerance": rep["tolerance"],
+            "argmax_mismatch_voxels": rep["argmax_mismatch_voxels"], "mismatch_outside_margin": rep["mismatch_outside_margin"],
+            "max_top2_margin_at_mismatch": rep["max_top2_margin_at_mismatch"], "min_top2_margin": rep["min_top2_margin"],
+            "voxels_with_margin_below_1e-4": rep["voxels_with_margin_below_1e-4"], "min_class_dice": rep["min_class_dice"], "ok": rep["ok"]}
+
+
+def _oracle_inferer(sd, sub_cpu, rr, procs: int, threads: int, factory=None):
+    """the complete CPU-oracle sliding-window inference of `sub_cpu` with the per-window network on `procs` workers x `threads` ATen threads"""
     import oracle
     from oracle import parallel_predict as pp
+
+    with torch.no_grad():
+        if procs > 1 or factory is not None:
+            with pp.PoolPredictor(sub_cpu, rr, 4, (0.5,) * 3, factory or pp.basic_unet_factory, (sd,), procs=procs, threads=threads) as pred:
+                return oracle.sliding_window_inference(sub_cpu, rr, 4, pred, overlap=0.5, mode="gaussian", sigma_scale=0.125)
+        torch.set_num_threads(threads)
+        return oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
+
+
+def reference_self_spread(sd, vol_cpu, size: int, roi: int, procs: int, threads: int, t_win: float, budget_s: float, product=None):
+    """how far the REFERENCE arithmetic is from itself.  The CPU oracle (the reference's own ATen operators) on a corner of the benchmark
+    volume in three configurations of the same host: (a) the pool's thread layout (what cpu_baseline runs), (b) ONE thread per worker (another oneDNN work split:
+    other summation orders), (c) oneDNN disabled (ATen's native convolution).  max|dlogit| and the labels that flip between them are what "bit-exact argmax"
+    can mean for the reference; `product` = (inferer, net, device volume): the product on the same voxels against (a), next to them."""
+    import oracle
+    from oracle import parallel_predict as pp
+
+    total = max(1, procs * threads)
+    out = {}
+    # windows by budget: (a) and (b) cost about the same CPU-seconds per window, (c) several times more -> a smaller corner there
+    per_win_pool = t_win / max(procs, 1) / 0.6
+    for key, want, factory, p_, t_, cost in (("one_thread_vs_pool", 125, None, total, 1, 2.2), ("onednn_off_vs_on", 27, pp.basic_unet_factory_no_onednn, procs, threads, 8.0)):
+        n = want
+        while n > 8 and n * per_win_pool * cost > budget_s / 2:
+            n = {125: 64, 64: 27, 27: 8}.get(n, 8)
+        ext = sub_volume_extents(size, roi, n)
+        rr = tuple(min(roi, e) for e in ext)
+        sub_cpu = vol_cpu[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
+        t0 = time.perf_counter()
+        base = _oracle_inferer(sd, sub_cpu, rr, procs, threads, pp.basic_unet_factory)
+        other = _oracle_inferer(sd, sub_cpu, rr, p_, t_, factory or pp.basic_unet_factory)
+        rep = oracle.label_parity(other, base, tol=1e-4)
+        rec = {"voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "label_flips": rep["argmax_mismatch_voxels"],
+               "flips_outside_margin": rep["mismatch_outside_margin"], "layout": f"{p_}x{t_} vs {procs}x{threads} threads", "seconds": time.perf_counter() - t0}
+        if product is not None:
+            inferer, net, vol = product
+            got = inferer(vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous(), net)
+            pr = oracle.label_parity(got, base, tol=1e-4)
+            rec["product_max_abs_logit_diff"], rec["product_label_flips"] = pr["max_abs_logit_diff"], pr["argmax_mismatch_voxels"]
+        out[key] = rec
+    return out
+
+
+def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, inferer, full_out, budget_s: float, more=None, spread_budget_s: float = 0.0):
+    """CPU oracle = port of the reference path (kind "port": the same ATen CPU operators in the same order, pinned bit-for-bit to the real reference by
+    tests/test_oracle_golden.py -- the GPU box has no MONAI): the COMPLETE sliding-window inference -- window loop, BasicUNet, importance-weighted blend -- on the host
+    cores, and the product's output on the same voxels against it (the headline rule of oracle/parity.py on the BLENDED logits).
+    Default: the WHOLE benchmark volume (1000 windows, every output voxel compared).  The per-window network runs in several worker processes
+    (oracle/parallel_predict.py), the blend in this process in the reference's window order.  A probe batch prices the run first: when the whole volume would
+    exceed `budget_s` seconds the largest corner sub-volume that fits is taken instead (`windows` < `windows_total` in the record).
+    -> (cpu_baseline record, parity report, reference_self_spread record or None)"""
+    import oracle
     from oracle.sliding_window import dense_patch_starts, get_scan_interval
 
     torch.manual_seed(1)
@@ -135,60 +180,52 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
         t0 = time.perf_counter()
         oracle.basic_unet_forward(sd, probe)
         t_win = (time.perf_counter() - t0) / 4
-    eff = 0.6 if procs > 1 else 1.0                      # what several groups sharing the memory system keep of their stand-alone rate (measured value is reported below)
+    eff = 0.6 if procs > 1 else 1.0                      # what several groups sharing the memory system keep of their stand-alone rate (the measured value is reported)
     fit = int(budget_s * procs * eff / max(t_win, 1e-6))
     full = windows >= nfull and fit >= nfull
-    if full:
-        ext = (size,) * 3
-    else:
-        ext = sub_volume_extents(size, roi, max(1, min(windows, fit, nfull)))
+    ext = (size,) * 3 if full else sub_volume_extents(size, roi, max(1, min(windows, fit, nfull)))
     sub = vol if full else vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
     sub_cpu = vol_cpu if full else sub.cpu()
     rr = tuple(min(roi, e) for e in ext)
     starts, _ = dense_patch_starts(ext, rr, get_scan_interval(ext, rr, (0.5,) * 3))
     nsub = len(starts[0]) * len(starts[1]) * len(starts[2])
+    t0 = time.perf_counter()
+    ref = _oracle_inferer(sd, sub_cpu, rr, procs, threads)
+    dt = time.perf_counter() - t0
     with torch.no_grad():
-        t0 = time.perf_counter()
-        if procs > 1:
-            with pp.PoolPredictor(sub_cpu, rr, 4, (0.5,) * 3, pp.basic_unet_factory, (sd,), procs=procs, threads=threads) as pred:
-                ref = oracle.sliding_window_inference(sub_cpu, rr, 4, pred, overlap=0.5, mode="gaussian", sigma_scale=0.125)
-        else:
-            ref = oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: oracle.basic_unet_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
-        dt = time.perf_counter() - t0
         got = full_out if (full and full_out is not None) else inferer(sub, net)
-    what = (f"the WHOLE {size}^3 benchmark volume, all {nsub} windows" if full else f"{ext[0]}x{ext[1]}x{ext[2]} corner sub-volume, {nsub} of {nfull} windows")
+    what = f"whole {size}^3, {nsub} windows" if full else f"{ext[0]}x{ext[1]}x{ext[2]} corner, {nsub} of {nfull} windows"
     if more is not None:            # the same reference for other arithmetic families of the product (extra.fp32_exact)
         more["ref"], more["sub"], more["what"] = ref, sub, what
     parity = oracle.label_parity(got, ref, tol=1e-4)
-    parity["compared"] = (f"complete inferer output (blended logits) of {what}; rule: max|dlogit| <= 1e-4 and "
-                          "every argmax difference at a voxel whose oracle top-2 margin < 2 max|dlogit| (mismatch_outside_margin == 0); the raw counts "
-                          "(argmax_mismatch_voxels, min_class_dice, min_top2_margin) are the literal north-star bars: bit-exact argmax, Dice == 1.0")
     per_win = dt / nsub
-    return {
-        "value": size ** 3 / (nfull * per_win),
-        "unit": "voxels/s",
-        "cores": procs * threads,
-        "kind": "port",
-        "kind_note": "the bit-pinned oracle (oracle/: the reference's own ATen CPU operators in its order, checked bit-for-bit against the real reference by tests/test_oracle_golden.py); "
-                     "the reference package itself is not installed on the GPU box",
-        "parity_vs_gpu": parity,
-        "sample": f"complete CPU-oracle sliding-window inference (windows + BasicUNet + gaussian blend, sw_batch 4) of {what} ({roi}^3 windows) on {procs} worker "
-                  f"processes x {threads} threads of {ncpu} host threads (the blend in window order in the parent): {dt:.2f} s = {per_win:.4f} s/window "
-                  f"(one batch alone on one {threads}-thread group: {t_win:.3f} s/window; pool efficiency {t_win / max(per_win * procs, 1e-9):.2f}); "
-                  + ("value = voxels of the volume / that time" if full else f"value = {size}^3 voxels / ({nfull} windows x that)"),
-    }
+    rec = {"value": size ** 3 / (nfull * per_win), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
+           "sample": f"{what}, {procs}x{threads} of {ncpu} threads",
+           "windows": nsub, "windows_total": nfull, "seconds": dt, "s_per_window": per_win, "probe_s_per_window_one_group": t_win,
+           "pool_efficiency": t_win / max(per_win * procs, 1e-9)}
+    spread = None
+    if spread_budget_s > 0:
+        try:
+            spread = reference_self_spread(sd, vol_cpu, size, roi, procs, threads, t_win, spread_budget_s, product=(inferer, net, vol))
+        except Exception as e:      # noqa: BLE001 -- the spread is evidence next to the parity, never a reason to lose it
+            spread = {"error": f"{type(e).__name__}: {e}"[:160]}
+    return rec, parity, spread
 
 
 _PMC_INRUN: dict = {}      # kernel key -> traffic record collected by pmc_inrun() in THIS run
 _PMC_WIDE_READS = ("sw_blend_mosaic_kernel", "sw_blend_reg_kernel")      # 16 B / lane readers: FETCH_SIZE counts their 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section)
 
 
+_PMC_STATUS = {"status": "not_run"}      # why the in-run pass did or did not deliver (printed as line["pmc"])
+
+
 def pmc_inrun(budget_s: float = 150.0) -> dict:
     """HBM bytes per launch of the blend and of the dominant convolution from the hardware counters, collected in THIS run: two `rocprofv3 --kernel-trace --pmc`
     child processes (FETCH_SIZE, then WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over tools/pmc_probe.py, which launches the two kernels at the
     benchmark's configuration (the mosaic blend of 1000 windows into 5 x 512^3; 32 -> 32 channels @ 96^3 x 64 windows).  Counter unit KiB per dispatch; the guide's
-    gfx950 correction (x 2 on FETCH_SIZE for 16-bytes-per-lane readers) applied to the blend only.  Every child runs under `timeout`; any failure leaves the
-    committed builder pass (`from_file`) in place."""
+    gfx950 correction (x 2 on FETCH_SIZE for 16-bytes-per-lane readers) applied to the blend only (FETCH_SIZE is uncalibrated for the convolution's 4-byte loads: its
+    read side says nothing, its write side does).  Every child runs under `timeout`; a failure is retried once, then the committed builder pass (`from_file`) stays in
+    place and `_PMC_STATUS` says what failed (the child's last stderr line included)."""
     import shutil
     import sqlite3
     import subprocess
@@ -197,50 +234,65 @@ def pmc_inrun(budget_s: float = 150.0) -> dict:
     here = os.path.dirname(os.path.abspath(__file__))
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
+        _PMC_STATUS["status"] = "failed: rocprofv3 not found"
         return {}
     tmp = tempfile.mkdtemp(prefix="monai_amd_pmc_", dir="/tmp")
     got: dict = {}
     t0 = time.perf_counter()
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            cmd = ["timeout", "-k", "5", str(int(budget_s)), rp, "--kernel-trace", "--pmc", counter, "-d", os.path.join(tmp, counter), "-o", "p", "--",
-                   sys.executable, os.path.join(here, "tools", "pmc_probe.py"), "--only", "mosaic,conv", "--conv-cfgs", "h2"]
-            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=budget_s + 30, check=True)
-            dbs = [os.path.join(r, f) for r, _, fs in os.walk(os.path.join(tmp, counter)) for f in fs if f.endswith(".db")]
-            if not dbs:
+            rows, why = None, ""
+            for attempt in range(2):
+                out_dir = os.path.join(tmp, f"{counter}_{attempt}")
+                cmd = ["timeout", "-k", "5", str(int(budget_s)), rp, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "p", "--",
+                       sys.executable, os.path.join(here, "tools", "pmc_probe.py"), "--only", "mosaic,conv", "--conv-cfgs", "h2"]
+                try:
+                    r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=budget_s + 30, text=True)
+                except subprocess.TimeoutExpired:
+                    why = f"{counter}: timeout after {budget_s:.0f} s"
+                    continue
+                if r.returncode != 0:
+                    tail = (r.stderr or "").strip().splitlines()[-1:] or [""]
+                    why = f"{counter}: rocprofv3 rc {r.returncode}: {tail[0][:100]}"
+                    continue
+                dbs = [os.path.join(d_, f) for d_, _, fs in os.walk(out_dir) for f in fs if f.endswith(".db")]
+                if not dbs:
+                    why = f"{counter}: no counter database written"
+                    continue
+                db = sqlite3.connect(dbs[0])
+                rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
+                db.close()
+                break
+            if rows is None:
+                _PMC_STATUS["status"] = "failed: " + why
                 return {}
-            db = sqlite3.connect(dbs[0])
-            rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name = ? group by kernel_name", (counter,)).fetchall()
-            db.close()
             for key in ("sw_blend_mosaic_kernel", "conv3d_k3_h2_kernel"):
                 hit = [(n, avg) for name, n, avg in rows if key in name and "pack" not in name and "scale" not in name]
                 if len(hit) != 1:
+                    _PMC_STATUS["status"] = f"failed: {counter}: {len(hit)} kernels match {key}"
                     return {}
                 got.setdefault(key, {})[counter] = {"dispatches": hit[0][0], "bytes": hit[0][1] * 1024.0}
-    except Exception as e:                                         # noqa: BLE001 -- a missing profiler, a timeout, a changed schema: keep the committed pass
-        print(f"bench: in-run PMC pass failed ({type(e).__name__}: {e}); traffic stays from_file", file=sys.stderr)
+    except Exception as e:                                         # noqa: BLE001 -- a changed schema, a full disk: keep the committed pass, say why
+        _PMC_STATUS["status"] = f"failed: {type(e).__name__}: {e}"[:160]
         return {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     alg = {"sw_blend_mosaic_kernel": 1000 * 5 * 96.0 ** 3 * 4 + 5 * 512.0 ** 3 * 4, "conv3d_k3_h2_kernel": 2 * 64 * 32 * 96.0 ** 3 * 4}
-    on = {"sw_blend_mosaic_kernel": "1000 windows of 5 x 96^3 logits -> 5 x 512^3 (the benchmark's blend launch)",
-          "conv3d_k3_h2_kernel": "32 -> 32 channels @ 96^3, 64 windows per launch (the benchmark's largest convolution shape)"}
     out = {}
     for key, c in got.items():
         fetch = c["FETCH_SIZE"]["bytes"] * (2.0 if key in _PMC_WIDE_READS else 1.0)
         total = fetch + c["WRITE_SIZE"]["bytes"]
-        note = (f"in_run (this bench process ran `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... WRITE_SIZE` over tools/pmc_probe.py, {c['FETCH_SIZE']['dispatches']} dispatches each, "
-                f"{time.perf_counter() - t0:.0f} s; FETCH_SIZE " + ("x 2: 16-bytes-per-lane reader" if key in _PMC_WIDE_READS else "as counted") + ")")
-        if "conv3d" in key:
-            note += "; FETCH_SIZE is uncalibrated for this kernel's 4-byte loads: a ratio below 1 is not evidence of under-fetch"
-        out[key] = {"measured": note, "hbm_bytes_per_launch": total, "fetch_bytes": fetch, "write_bytes": c["WRITE_SIZE"]["bytes"], "algorithmic_bytes": alg[key],
-                    "ratio": total / alg[key], "measured_on": on[key]}
+        out[key] = {"measured": "in_run", "hbm_bytes_per_launch": total, "fetch_bytes": fetch, "write_bytes": c["WRITE_SIZE"]["bytes"], "algorithmic_bytes": alg[key],
+                    "ratio": total / alg[key], "dispatches": c["FETCH_SIZE"]["dispatches"], "fetch_calibrated": key in _PMC_WIDE_READS}
+    _PMC_STATUS["status"] = "in_run"
+    _PMC_STATUS["seconds"] = round(time.perf_counter() - t0, 1)
     return out
 
 
 def pmc_traffic(kernel_key: str):
     """HBM bytes per launch of `kernel_key`: the counters collected in this run (pmc_inrun) when there are any, else the committed builder pass (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied); the newest profiles/r*_pmc_hbm_traffic.json wins."""
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied); the newest profiles/r*_pmc_hbm_traffic.json wins.  `measured`: "in_run" |
+    "from_file:<name>" -- a kernel the in-run probe does not launch (the exact-fp32 family's) is always from_file."""
     if kernel_key in _PMC_INRUN:
         return _PMC_INRUN[kernel_key]
     pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -249,13 +301,8 @@ def pmc_traffic(kernel_key: str):
             with open(os.path.join(pdir, name)) as f:
                 k = json.load(f)["kernels"].get(kernel_key)
             if k is not None:
-                note = ("from_file (a builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass, see `source`; the in-run pass was skipped or failed)")
-                if "conv3d" in kernel_key:       # MI355X_MICROARCH.md calibrates FETCH_SIZE for 16 B/lane readers only
-                    note += "; FETCH_SIZE is uncalibrated for this kernel's 4-byte loads: a ratio below 1 is not evidence of under-fetch"
-                return {"measured": note,
-                        "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
-                        "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"], "measured_on": k.get("measured_on", "the bench configuration"),
-                        "source": "profiles/" + name.replace(".json", ".txt")}
+                return {"measured": "from_file:" + name, "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "algorithmic_bytes": k["algorithmic_bytes"],
+                        "ratio": k["hbm_bytes_per_launch"] / k["algorithmic_bytes"], "fetch_calibrated": "conv3d" not in kernel_key}
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -297,44 +344,45 @@ def timed_steps(inferer, vol, net, steps: int, warmup: int, sync):
     return dt, _prof.stop(), out
 
 
+def _traffic(roof: dict, key: str) -> None:
+    td = pmc_traffic(key)
+    if td:
+        roof["traffic"] = td["hbm_bytes_per_launch"]
+        roof["traffic_src"], roof["traffic_ratio_to_algorithmic"], roof["traffic_fetch_calibrated"] = td["measured"], td["ratio"], td["fetch_calibrated"]
+        if "write_bytes" in td:
+            roof["traffic_write_bytes"] = td["write_bytes"]
+
+
 def conv_roofline(spans, steps: int, ms: float, roi: int):
-    """the 3x3x3 convolution configuration with the largest share of the step, priced against the peak of the matrix instruction it issues"""
+    """the 3x3x3 convolution configuration with the largest share of the step, priced against the peak of the matrix instruction it issues:
+    achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); the convolution's own flops
+    (2 * 27 * Cin * Cout per voxel) are `algorithmic_tflops`"""
     from monai_amd import ops as _ops
 
     convs = {k: v for k, v in spans.items() if k.startswith("conv3d_k3/")}
     if not convs:
         return None
     key, conv = max(convs.items(), key=lambda kv: kv[1]["ms_total"])
-    tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12          # the convolution's own flops: 2 * 27 * Cin * Cout per voxel
+    tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12
     cfg_id = int(key.split("/cfg")[1])
     ncfg = _ops.conv3d_k3_num_configs()
     peak, extra, pmc_key = PEAK_FP32_TFLOPS, {}, "conv3d_k3_mfma_kernel"
-    if cfg_id == _ops.conv3d_k3_h2_config():     # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
-        kname = (f"conv3d_k3_h2_kernel (z-streaming direct 3x3x3 convolution on v_mfma_f32_32x32x16_f16, every fp32 operand as hi + lo fp16 pieces scaled into "
-                 f"fp16's range by the input records' magnitude bounds, products hi*hi + lo*hi + hi*lo, fp32 accumulate: fp32-equivalent; 32|64 -> 32 ch @ {roi}^3 and the levels below)")
-        gain, peak, pmc_key = 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
-        extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS, "piece_products_per_multiply": 3}
-    elif cfg_id == _ops.conv3d_k3_h2c_config():     # the same kernel in output channel groups of 16: two z-taps per 32-column instruction, 6 instead of 9 per in-plane tap
-        kname = (f"conv3d_k3_h2_kernel<C16> (the split-precision kernel in output channel groups of 16: columns [kz 0 | kz 1] and [kz 2 | 0], a completed plane = the sum of three "
-                 f"partial planes; 16-couts layers @ {roi}^3)")
-        gain, peak, pmc_key = 1.0 / 4.0, PEAK_F16_TFLOPS, "conv3d_k3_h2c_kernel"      # 6 x 32 columns issued per 3 x 16 useful ones, x 3 piece products
-        extra = {"fp32_equivalent_tflops": tf, "fp32_equivalent_vs_fp32_mfma_peak": tf / PEAK_FP32_TFLOPS, "piece_products_per_multiply": 3, "columns_issued_per_useful": 4.0 / 3.0}
-    elif cfg_id == ncfg:      # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
-        kname = f"conv3d_k3_wino2p_kernel (Winograd F(2x2,3x3) in-plane + 3 direct z taps on v_mfma_f32_16x16x4_f32, two waves per SIMD, 32|64 -> 32 ch @ {roi}^3 / {roi // 2}^3)"
-        gain, pmc_key = 2.25, "conv3d_k3_wino2p_kernel"
+    if cfg_id == _ops.conv3d_k3_h2_config():        # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
+        kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel (v_mfma_f32_32x32x16_f16, hi+lo split)", 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
+        extra = {"fp32_equivalent_tflops": tf, "piece_products_per_multiply": 3}
+    elif cfg_id == _ops.conv3d_k3_h2c_config():     # the same kernel in output channel groups of 16: 6 x 32 columns issued per 3 x 16 useful ones, x 3 piece products
+        kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel<C16> (two z-taps per instruction)", 1.0 / 4.0, PEAK_F16_TFLOPS, "conv3d_k3_h2c_kernel"
+        extra = {"fp32_equivalent_tflops": tf, "piece_products_per_multiply": 3, "columns_issued_per_useful": 4.0 / 3.0}
+    elif cfg_id == ncfg:                            # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
+        kname, gain, pmc_key = "conv3d_k3_wino2p_kernel (F(2x2,3x3), v_mfma_f32_16x16x4_f32)", 2.25, "conv3d_k3_wino2p_kernel"
     else:
-        kname, gain = f"conv3d_k3_mfma_kernel (cfg{cfg_id}: direct 3x3x3 implicit GEMM on v_mfma_f32_32x32x2_f32 @ {roi}^3)", 1.0
+        kname, gain = f"conv3d_k3_mfma_kernel cfg{cfg_id} (v_mfma_f32_32x32x2_f32)", 1.0
     issued = tf / gain
     roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": None, "kernel": kname,
-            "note": "achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); frac = the fraction of the dense MFMA peak of the "
-                    "kernel's matrix instruction (fp32: 157.3, fp16: 2500 TFLOP/s) the matrix pipe delivers.  algorithmic_tflops counts the 3x3x3 convolution's own flops "
-                    "(2*27*Cin*Cout per voxel); Winograd needs winograd_algorithmic_gain x fewer multiply-adds for them",
-            "algorithmic_tflops": tf, "algorithmic_frac_of_peak": tf / peak, "winograd_algorithmic_gain": gain if gain >= 1.0 else None, **extra,
+            "algorithmic_tflops": tf, "issued_per_algorithmic_flop": 1.0 / gain, **extra,
             "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
-            "flops_per_launch_algorithmic": conv["work"] / conv["launches"], "share_of_step": conv["ms_total"] / steps / ms}
-    td = pmc_traffic(pmc_key)
-    if td:
-        roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
+            "share_of_step": conv["ms_total"] / steps / ms}
+    _traffic(roof, pmc_key)
     return roof
 
 
@@ -374,13 +422,18 @@ def blend_roofline(spans, mosaic: bool):
         return None
     gbs = blend["work"] / (blend["ms_total"] * 1e-3) / 1e9
     roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-            "kernel": ("sw_blend_mosaic_kernel<5,2> (gather blend over the mosaic logits layout" if mosaic else "sw_blend_reg_kernel<5,4,2> (gather blend over window-major logits") + ": logits read once, output written once)", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
-            "bytes_per_launch": blend["work"] / blend["launches"],
-            "streaming_ceilings": "float4 copy / read-only / write-only kernels of tools/ubench/hbm_stream.hip on MI355X: 6.15 / 6.55-7.0 / 6.07 TB/s (profiles/r02_ubench_hbm_stream_v1.txt)"}
-    td = pmc_traffic("sw_blend_mosaic_kernel" if mosaic else "sw_blend_reg_kernel")
-    if td:
-        roof["traffic"], roof["traffic_detail"] = td["hbm_bytes_per_launch"], td
+            "kernel": "sw_blend_mosaic_kernel<5,2>" if mosaic else "sw_blend_reg_kernel<5,4,2>", "launches": blend["launches"], "ms_avg": blend["ms_avg"],
+            "bytes_per_launch": blend["work"] / blend["launches"]}
+    _traffic(roof, "sw_blend_mosaic_kernel" if mosaic else "sw_blend_reg_kernel")
     return roof
+
+
+def _roof_brief(roof):
+    """a roofline object reduced to its numbers (the extras: the headline's objects carry the rest)"""
+    if not roof:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_src", "kernel", "ms_avg", "launches", "share_of_step", "algorithmic_tflops")
+    return {k: roof[k] for k in keep if k in roof}
 
 
 def extra_fp32_exact(args, vol, net, inferer, sync, shared):
@@ -394,11 +447,10 @@ def extra_fp32_exact(args, vol, net, inferer, sync, shared):
         dt, spans, _ = timed_steps(inferer, vol, net, 2, 1, sync)
         ms = 1e3 * dt / 2
         res = {"conv_algo": "fp32", "steps": 2, "warmup": 1, "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s",
-               "roofline": conv_roofline(spans, 2, ms, args.roi)}
+               "roofline": _roof_brief(conv_roofline(spans, 2, ms, args.roi))}
         if shared.get("ref") is not None:
-            par = oracle.label_parity(inferer(shared["sub"], net), shared["ref"], tol=1e-4)
-            par["compared"] = shared["what"]
-            res["parity_vs_cpu_oracle"] = par
+            res["parity"] = _short_parity(oracle.label_parity(inferer(shared["sub"], net), shared["ref"], tol=1e-4), "fp32-exact")
+            res["parity"]["compared"] = shared["what"]
     finally:
         config.CONV_ALGO = saved
     return res
@@ -415,17 +467,18 @@ def extra_config3(args, vol, sync, dev):
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
     dt, spans, _ = timed_steps(inferer, vol, net, 2, 1, sync)
     ms = 1e3 * dt / 2
-    res = {"workload": f"UNETR ViT-B/16 5-class (seed-1 init), the same {args.size}^3 volume, {args.roi}^3 windows overlap 0.5 gaussian", "steps": 2, "warmup": 1,
-           "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s", "roofline": conv_roofline(spans, 2, ms, args.roi)}
+    res = {"workload": f"UNETR ViT-B/16 5-class, same {args.size}^3 volume, {args.roi}^3 win ov 0.5", "steps": 2, "warmup": 1,
+           "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s", "roofline": _roof_brief(conv_roofline(spans, 2, ms, args.roi))}
     att = spans.get("attention")
     if att:
         tf = att["work"] / (att["ms_total"] * 1e-3) / 1e12
-        res["attention"] = {"kernel": "attention_h2_kernel<64> (softmax(QK^T/sqrt(d))V per head on the fp16 matrix cores in split precision, streamed keys / values, online softmax; S = 216, 12 heads x 64; rate = fp32-equivalent flops vs the fp32-MFMA peak)", "ms_per_step": att["ms_total"] / 2,
+        res["attention"] = {"kernel": "attention_h2_kernel<64> (S=216, 12 heads; fp32-eq flops)", "ms_per_step": att["ms_total"] / 2,
                             "tflops": tf, "bound": "mfma", "peak": PEAK_FP32_TFLOPS, "frac": tf / PEAK_FP32_TFLOPS, "share_of_step": att["ms_total"] / 2 / ms}
     lin = spans.get("linear")
     if lin:
-        res["linear"] = {"kernel": "linear_h2_big_kernel / linear_h2_kernel (nn.Linear + bias / GELU / residual on the fp16 matrix cores in split precision; 128 x 128 workgroup tiles at this token count)", "ms_per_step": lin["ms_total"] / 2,
-                         "fp32_equivalent_tflops": lin["work"] / (lin["ms_total"] * 1e-3) / 1e12}
+        ltf = lin["work"] / (lin["ms_total"] * 1e-3) / 1e12
+        res["linear"] = {"kernel": "linear_h2_big_kernel (128x128 tiles, hi+lo split)", "ms_per_step": lin["ms_total"] / 2, "fp32_equivalent_tflops": ltf,
+                         "issued_frac_of_fp16_peak": 3.0 * ltf / PEAK_F16_TFLOPS, "share_of_step": lin["ms_total"] / 2 / ms}
     # parity + CPU baseline: the complete inferer on a corner of the benchmark volume (27 windows at 96^3 / 512^3) against the CPU oracle of the same network
     # (oracle/unetr.py, pinned to the real reference by tests/golden/unetr.npz), its per-window network in worker processes (oracle/parallel_predict.py)
     from oracle import parallel_predict as pp
@@ -451,12 +504,10 @@ def extra_config3(args, vol, sync, dev):
             ref = oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: ounetr.unetr_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
         dt_cpu = time.perf_counter() - t0
         got = inferer(sub, net)
-    par = oracle.label_parity(got, ref, tol=1e-4)
-    par["compared"] = f"complete inferer output (blended logits) of the {ext[0]}x{ext[1]}x{ext[2]} corner of the benchmark volume, {nsub} windows of {args.roi}^3, product vs CPU oracle"
-    res["parity_vs_cpu_oracle"] = par
+    res["parity"] = _short_parity(oracle.label_parity(got, ref, tol=1e-4), "split-fp16")
+    res["parity"]["compared"] = f"{ext[0]}x{ext[1]}x{ext[2]} corner, {nsub} windows"
     res["cpu_baseline"] = {"value": float(args.size) ** 3 / (nfull * dt_cpu / nsub), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
-                           "sample": f"CPU-oracle UNETR sliding-window inference of those {nsub} of {nfull} windows on {procs} worker processes x {threads} threads (of {ncpu}, "
-                                     f"worker start-up included): {dt_cpu:.2f} s = {dt_cpu / nsub:.3f} s/window; value = {args.size}^3 voxels / ({nfull} windows x that)"}
+                           "sample": f"{nsub} of {nfull} windows, {procs}x{threads} of {ncpu} threads", "seconds": dt_cpu, "s_per_window": dt_cpu / nsub}
     return res
 
 
@@ -494,29 +545,27 @@ def extra_config4(dev):  # noqa: C901
     sp = Spacing(pixdim=(1.0, 1.0, 1.0), mode="bilinear", padding_mode="border")
     out = sp(vols[0])
     osz = tuple(int(v) for v in out.shape[1:])
-    res = {"workload": f"{n} x {e}^3 fp32 volumes (seeds 0..{n - 1}) in HBM: Spacing(pixdim 1, bilinear, border; fp64 coordinates) -> {list(out.shape)}, GaussianSmooth(sigma=1)", "runs": []}
+    res = {"workload": f"{n} x {e}^3 fp32 in HBM: Spacing(pixdim 1) -> {list(out.shape)[1:]}, GaussianSmooth(1)", "runs": []}
     copy_gbps = device_copy_gbps(dev)
     res["device_copy_GBps"] = copy_gbps
-    res["device_copy_note"] = ("a 1 GiB read + write stream measured in this run (the faster of torch's device copy and this library's 16-bytes-per-lane point-wise kernel): "
-                               "the practical streaming ceiling; frac = of the 8 TB/s spec, frac_of_copy_ceiling = of this")
     ms = timeit(lambda: [sp(v) for v in vols])
     nb = 4.0 * n * (e ** 3 + out.numel())
-    res["runs"].append({"op": "Spacing transform (4 volumes, host-side affine algebra included)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    res["runs"].append({"op": "Spacing transform x4 (incl. host algebra)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     gs = GaussianSmooth(sigma=1.0)
     plain = [v.as_tensor() for v in vols]
     ms = timeit(lambda: [gs(v) for v in plain])
     nb = 8.0 * n * e ** 3
-    res["runs"].append({"op": "GaussianSmooth transform (4 volumes)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    res["runs"].append({"op": "GaussianSmooth transform x4", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     raw = plain[0]
     m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
     for f64 in (True, False):
         ms = timeit(lambda: ops.affine_resample(raw, m.reshape(-1), osz, "bilinear", "border", False, f64))
         nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
-        res["runs"].append({"op": f"kernel: separable affine resample, {'fp64' if f64 else 'fp32'} interpolation (1 volume)", "bound": "hbm", "ms": ms, "GBps": nb / ms / 1e6,
+        res["runs"].append({"op": f"kernel: separable resample {'fp64' if f64 else 'fp32'}", "bound": "hbm", "ms": ms, "GBps": nb / ms / 1e6,
                             "frac": nb / ms / 1e6 / PEAK_HBM_GBS, "bytes": nb})
     k = gaussian_1d(1.0).numpy()
     ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
-    res["runs"].append({"op": "kernel: fused 3-axis Gaussian, 9 taps (1 volume)", "bound": "hbm", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
+    res["runs"].append({"op": "kernel: fused gaussian 9 taps", "bound": "hbm", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
                         "frac": 8.0 * raw.numel() / ms / 1e6 / PEAK_HBM_GBS, "bytes": 8.0 * raw.numel()})
     # parity on a 128^3 volume
     torch.manual_seed(11)
@@ -534,8 +583,7 @@ def extra_config4(dev):  # noqa: C901
         pad[2 * (2 - ax)] = pad[2 * (2 - ax) + 1] = kk.numel() // 2
         gref = F.conv3d(F.pad(gref, pad), kk.reshape(shape))
     res["parity_vs_cpu_restatement"] = {"spacing_max_abs": float((y.cpu().as_tensor() - ref).abs().max()), "spacing_tol": 2e-6, "spacing_shape": list(y.shape),
-                                        "gaussian_max_abs": float((g - gref[0]).abs().max()), "gaussian_tol": 1e-5,
-                                        "compared": "128^3 volume, the same transforms: product vs oracle/resample.py (AffineTransform path of the reference) / zero-padded depthwise F.conv3d per axis"}
+                                        "gaussian_max_abs": float((g - gref[0]).abs().max()), "gaussian_tol": 1e-5, "compared": "128^3 volume"}
     for r_ in res["runs"]:
         r_["frac_of_copy_ceiling"] = r_["GBps"] / copy_gbps
     res["parity_vs_cpu_restatement"]["ok"] = bool(res["parity_vs_cpu_restatement"]["spacing_max_abs"] < 2e-6 and res["parity_vs_cpu_restatement"]["gaussian_max_abs"] < 1e-5)
@@ -549,7 +597,7 @@ def extra_config4(dev):  # noqa: C901
     x0 = v0.as_tensor().cpu()
     y0 = sp(v0)
     xf0 = torch.from_numpy(np.linalg.inv(aff) @ y0.affine.cpu().numpy())
-    cpu = {"cores": threads, "of_host_threads": ncpu, "kind": "port", "volume": f"one {e}^3 fp32 volume"}
+    cpu = {"cores": threads, "of_host_threads": ncpu, "kind": "port", "volume": f"one {e}^3"}
     with torch.no_grad():
         for name, dt_ in (("spacing_fp64_s", torch.float64), ("spacing_fp32_s", torch.float32)):
             t0 = time.perf_counter()
@@ -588,6 +636,17 @@ def per_rank_breakdown(spans, steps: int, world: int, dev, dist):
     return [{"rank": r, "predictor_ms": float(t[0]), "gather_wait_ms": float(t[1]), "blend_ms": float(t[2])} for r, t in enumerate(allr)]
 
 
+def _rounded(obj, digits: int = 6):
+    """floats to `digits` significant digits: the line is a record of measurements, not of double-precision noise (and stays short)"""
+    if isinstance(obj, float):
+        return float(f"{obj:.{digits}g}") if obj == obj and abs(obj) != float("inf") else obj
+    if isinstance(obj, dict):
+        return {k: (v if k in ("value", "checksum") else _rounded(v, digits)) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [_rounded(v, digits) for v in obj]
+    return obj
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -599,6 +658,8 @@ def main(argv=None):
                                                                   "fewer = a corner sub-volume (125 = 288^3), 0 = skip")
     ap.add_argument("--cpu-budget-s", type=float, default=float(os.environ.get("MONAI_AMD_BENCH_CPU_BUDGET_S", "900")),
                     help="seconds the CPU leg may take; a probe batch prices it and the largest corner sub-volume that fits is taken when the whole volume would not")
+    ap.add_argument("--no-spread", action="store_true", help="skip reference_self_spread (the oracle against itself under other thread layouts / without oneDNN)")
+    ap.add_argument("--spread-budget-s", type=float, default=90.0, help="seconds the reference_self_spread leg may take (it sizes its corner sub-volumes by it)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the in-run hardware-counter passes behind roofline*.traffic (two rocprofv3 child processes, ~1 min)")
     ap.add_argument("--no-extra", action="store_true", help="skip extra.fp32_exact / config3 / config4 (development runs)")
     ap.add_argument("--harness-features", default="", help="TEST HARNESS ONLY (emulator runs of tests/test_bench_harness.py): BasicUNet widths, e.g. 16,16,32,32,64,16; "
@@ -670,8 +731,9 @@ def main(argv=None):
         if world == 1 and not emulated and not args.no_pmc and not profiled and args.net == "basicunet" and (args.size, args.roi) == (512, 96):
             _PMC_INRUN.update(pmc_inrun())
         exact = config.conv_algo() in (config.CONV_ALGOS["fp32"], config.CONV_ALGOS["direct"], config.CONV_ALGOS["wino2d"])
-        conv_all = {k: {"ms_total": v["ms_total"] / args.steps, "tflops": v["work"] / (v["ms_total"] * 1e-3) / 1e12}
+        conv_all = {k.split("/")[1]: {"ms": round(v["ms_total"] / args.steps, 3), "tflops": round(v["work"] / (v["ms_total"] * 1e-3) / 1e12, 2)}
                     for k, v in spans.items() if k.startswith("conv3d_k3/")}
+        family = "fp32-exact" if exact else "split-fp16"
         line = {
             "metric": METRIC,
             "value": voxels / (dt / args.steps),
@@ -684,21 +746,18 @@ def main(argv=None):
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": ("every tensor, accumulator and elementwise op is fp32; 3x3x3 convolutions on the exact-fp32 kernels (monai_amd.config.CONV_ALGO / MONAI_AMD_CONV_ALGO set)"
-                           if exact else
-                           "every tensor, accumulator and elementwise op is fp32; the multiplications of the 3x3x3 convolutions are evaluated from two fp16 pieces per fp32 operand "
-                           "(hi + lo, the input first scaled into fp16's range by a power of two from its records' magnitude bounds; three exact piece products on the fp16 matrix "
-                           "cores, fp32 accumulation): fp32-equivalent for any finite input magnitude -- parity_vs_gpu below; extra.fp32_exact is the same run on the exact-fp32 kernels"),
+            "dtype_note": "fp32 tensors + accumulators; conv products " + ("exact fp32" if exact else "from hi+lo fp16 pieces (fp32-equivalent); extra.fp32_exact = exact kernels"),
             "data": "synthetic",
             "config": {
-                "workload": f"{NETS[args.net]} 5-class (default features, seed-1 init), {args.size}^3 fp32 synthetic CT volume (the reference's create_test_image_3d phantom, "
-                            f"SURVEY 8d config 1) resident in HBM, {args.roi}^3 windows overlap 0.5 gaussian blend, sw_batch_size 4 (engine batches up to 64 windows per launch)",
+                "workload": f"{NETS[args.net]} 5-class seed 1, {args.size}^3 CT phantom in HBM, {args.roi}^3 win ov 0.5 gaussian, sw_batch 4 (engine: <= 64 windows per launch)",
                 "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
+            "parity": None,
             "roofline": conv_roofline(spans, args.steps, ms, args.roi),
             "roofline_hbm": blend_roofline(spans, mosaic=world == 1 and hasattr(net, "forward_into_windows") and os.environ.get("MONAI_AMD_LOGITS_LAYOUT") != "windows"),
             "conv_ms_per_step": conv_all,
             "checksum": float(out.double().sum().item()),
+            "pmc": dict(_PMC_STATUS),
         }
         if line["roofline_hbm"] is not None and not emulated:
             cg = device_copy_gbps(dev)
@@ -706,20 +765,31 @@ def main(argv=None):
             line["roofline_hbm"]["frac_of_copy_ceiling"] = line["roofline_hbm"]["achieved"] / cg
         if ranks is not None:
             line["per_rank_ms_per_step"] = ranks
+            pred = max(r["predictor_ms"] for r in ranks)
+            line["exposed_comm_share"] = max(r["gather_wait_ms"] for r in ranks) / ms      # what the compute stream waited for gathers, of the step
+            line["predictor_ms_max"] = pred
         if emulated:
             line["emulated"] = "SIMT emulator + gloo: harness test only, not a measurement"
         shared: dict = {}
         if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
+            spread_s = 0.0 if (emulated or args.no_spread) else args.spread_budget_s
             try:
-                line["cpu_baseline"] = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer, out, args.cpu_budget_s, shared)
+                rec, par, spread = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer, out, args.cpu_budget_s, shared, spread_s)
             except Exception as e:      # the checker's own failure (a dead pool worker, host memory) must not cost the headline line: fall back to one process on a 27-window corner
-                err = f"{type(e).__name__}: {e}"
+                err = f"{type(e).__name__}: {e}"[:160]
                 try:
                     os.environ["MONAI_AMD_BENCH_CPU_PROCS"] = "1"
-                    line["cpu_baseline"] = cpu_baseline(args.size, args.roi, 27, vol, net, inferer, None, args.cpu_budget_s, shared)
-                    line["cpu_baseline"]["fallback_after"] = err
+                    rec, par, spread = cpu_baseline(args.size, args.roi, 27, vol, net, inferer, None, args.cpu_budget_s, shared, 0.0)
+                    rec["fallback_after"] = err
                 except Exception as e2:
-                    line["cpu_baseline"] = {"error": err, "fallback_error": f"{type(e2).__name__}: {e2}"}
+                    rec, par, spread = {"error": err, "fallback_error": f"{type(e2).__name__}: {e2}"[:160]}, None, None
+            if par is not None:
+                line["parity"] = _short_parity(par, family)
+                line["parity"]["compared"] = shared.get("what", "")
+                rec["parity_vs_gpu"] = {k: par[k] for k in ("ok", "mismatch_outside_margin", "max_abs_logit_diff", "argmax_mismatch_voxels", "voxels")}
+            line["cpu_baseline"] = rec
+            if spread is not None:
+                line["reference_self_spread"] = spread
         else:
             line["cpu_baseline"] = None
         if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated:
@@ -729,9 +799,10 @@ def main(argv=None):
                 try:
                     extra[name] = fn()
                 except Exception as e:      # an extra must never cost the headline line
-                    extra[name] = {"error": f"{type(e).__name__}: {e}"}
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"[:160]}
                 torch.cuda.empty_cache()
             line["extra"] = extra
+        line = _rounded(line)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -143,7 +143,6 @@ int mh_avg_finalize_f32(float* values, const uint8_t* counts, int64_t n, void* s
 #define MH_ALGO_WINO2D 2   /* the in-plane Winograd configuration wherever its shape rules allow, fp32 tiles elsewhere */
 #define MH_ALGO_H2 3       /* split precision wherever it fits and the input is bounded, fp32 tiles elsewhere (no Winograd) */
 #define MH_ALGO_FP32 4     /* AUTO among the exact-fp32 kernels (tiles, in-plane Winograd, one-channel kernel) */
-#define MH_ALGO_H2Z 5      /* split precision behind the z-Winograd transform wherever it fits and the input is bounded, the direct split kernel / fp32 tiles elsewhere */
 int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, int H, int W);
 int mh_conv3d_k3_num_configs(void);                    /* highest configuration id of the exact-fp32 matrix-core family */
 /* Configuration outside 0 .. num_configs(): z-streaming direct convolution on the fp16 matrix cores in two-piece split
@@ -157,11 +156,6 @@ int mh_conv3d_k3_num_configs(void);                    /* highest configuration 
  * computes behind a normalisation whose statistics are non-finite, and a loud failure for a caller that broke the contract).
  * With in->nrm == NULL there is nothing to take a scale from: the input is used as it is (|x| must stay below 65504). */
 int mh_conv3d_k3_h2_config(void);
-/* The same split-precision arithmetic behind a Winograd F(2, 3) minimal-filtering transform ALONG Z (kernels/conv3d_h2z.h): pairs of output planes from four
- * transformed input planes, 18 instead of 27 multiply-adds per (voxel, cin, cout), the nine in-plane taps direct.  Same reference op (nn.Conv3d k3 p1,
- * monai/networks/blocks/convolutions.py:98-171), same record / bound contract and tolerance class as mh_conv3d_k3_h2_config; needs Cin % 16 == 0, Cin <= 128,
- * Cout % 32 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it under MH_ALGO_H2Z only: measured equal in time to the direct kernel in round 4. */
-int mh_conv3d_k3_h2z_config(void);
 /* mh_conv3d_k3_h2_config's kernel with output channel groups of 16 (round 4): a 32-column matrix instruction carries two z-taps of 16 couts instead of one tap of 32
  * ([kz 0 | kz 1] and [kz 2 | 0]: 6 instead of 9 instructions per in-plane tap), a completed plane is the sum of three partial planes.  Same reference op, record / bound
  * contract and tolerance class; Cin % 16 == 0, Cin <= 256, Cout % 16 == 0, W % 4 == 0.  mh_conv3d_k3_select returns it for Cout == 16 (UNETR's / SwinUNETR's full-resolution

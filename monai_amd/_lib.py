@@ -64,7 +64,6 @@ SIGNATURES = {
     "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
     "mh_conv3d_k3_select": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mh_conv3d_k3_h2_config": (_I, []),
-    "mh_conv3d_k3_h2z_config": (_I, []),
     "mh_conv3d_k3_h2c_config": (_I, []),
     "mh_conv3d_k3_c1_config": (_I, []),
     "mh_conv3d_k3_num_configs": (_I, []),
@@ -113,6 +112,11 @@ SIGNATURES = {
 }
 
 
+class KernelRejected(RuntimeError):
+    """An entry point refused its arguments (shape / alignment / size rule) without launching: callers with an alternative path catch THIS, not RuntimeError
+    (launch failures and HIP errors stay plain RuntimeErrors and must surface)."""
+
+
 class Library:
     """A loaded ``libmonai_amd`` with typed entry points and error translation."""
 
@@ -133,7 +137,9 @@ class Library:
         return self._mh_last_error().decode("utf-8", "replace")
 
     def check(self, rc: int) -> None:
-        if rc != 0:
+        if rc in (-1, -3):      # MH_ERR_ARG / MH_ERR_UNSUPPORTED: the entry point declined the call before launching anything
+            raise KernelRejected(f"monai_amd: {self.last_error()} (code {rc})")
+        if rc != 0:             # MH_ERR_LAUNCH and anything else: a real failure, never something to fall back from
             raise RuntimeError(f"monai_amd: {self.last_error()} (code {rc})")
 
     def call(self, name: str, *args) -> None:

@@ -15,8 +15,8 @@ USE_COMPILED = HAS_EXT and os.getenv("BUILD_MONAI", "0") == "1"
 # `CONV_ALGO` (or the environment variable MONAI_AMD_CONV_ALGO, read at call time while CONV_ALGO is None):
 #   "auto"   fp16 two-piece split precision (fp32-equivalent) for inputs that carry magnitude bounds, exact fp32 otherwise
 #   "fp32"   exact-fp32 kernels only (matrix-core tiles, in-plane Winograd, the one-channel kernel)
-#   "direct" / "wino2d" / "h2" / "h2z"   pin one family (measurements): "h2" = the direct split-precision kernel only, "h2z" = its z-Winograd form wherever it fits
-CONV_ALGOS = {"auto": 0, "direct": 1, "wino2d": 2, "h2": 3, "fp32": 4, "h2z": 5}
+#   "direct" / "wino2d" / "h2"   pin one family (measurements): "h2" = the direct split-precision kernel only
+CONV_ALGOS = {"auto": 0, "direct": 1, "wino2d": 2, "h2": 3, "fp32": 4}
 CONV_ALGO = None
 
 
@@ -45,3 +45,17 @@ class conv_algo_scope:
         global CONV_ALGO
         CONV_ALGO = self._saved
         return False
+
+
+# ---- HIP streams of the sliding-window engine ----------------------------------------------------------------------------------
+# Window batches of the fused single-GPU path alternate between this many HIP streams (inferers/utils.py:_StreamLanes): the memory-bound passes of one batch
+# overlap the matrix-bound convolutions of the other.  1 = everything on the caller's stream.  `SW_STREAMS` (or MONAI_AMD_STREAMS while it is None).
+SW_STREAMS = None
+
+
+def sw_streams() -> int:
+    v = SW_STREAMS if SW_STREAMS is not None else os.environ.get("MONAI_AMD_STREAMS", "1")
+    try:
+        return max(1, min(int(v), 4))
+    except (TypeError, ValueError):
+        raise ValueError(f"monai_amd: SW_STREAMS / MONAI_AMD_STREAMS must be an integer 1..4, got {v!r}") from None

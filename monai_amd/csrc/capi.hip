@@ -12,7 +12,6 @@
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_h2.h"
-#include "kernels/conv3d_h2z.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -421,9 +420,7 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 #define MH_CFG_C1 (MH_NUM_CFG + 3)
 // z-chunks of the one-channel kernel: a pure function of D (the statistics record count depends on it); 24-plane marches keep
 // 64 windows of 96^3 at nine whole rounds of the chip's 2048 resident waves
-// configuration MH_CFG_H2Z: the split-precision arithmetic behind a Winograd F(2, 3) transform along z (kernels/conv3d_h2z.h): 2 instead of 3 fp16 matrix
-// instructions per fp32 multiply-add of the direct form; regions of 8 x 32 outputs, pairs of output planes (even z-chunks); same tolerance class as MH_CFG_H2
-#define MH_CFG_H2Z (MH_NUM_CFG + 4)
+// (configuration id MH_NUM_CFG + 4 was round 4's z-Winograd split-precision experiment: measured equal in time to the direct kernel, removed in round 5)
 // configuration MH_CFG_H2C: MH_CFG_H2's kernel with output channel groups of 16, two z-taps sharing a 32-column matrix instruction (kernels/conv3d_h2.h, C16): layers
 // with 16 output channels (UNETR's full-resolution levels) at 6 instead of 9 matrix instructions per tap; same arithmetic and tolerance class as MH_CFG_H2
 #define MH_CFG_H2C (MH_NUM_CFG + 5)
@@ -464,21 +461,7 @@ static inline int h2_zchunk(int D, int H, int W) {
 }
 static inline int h2_blocks(int D, int H, int W) { return h2_regions(H, W) * cdiv(D, h2_zchunk(D, H, W)); }
 
-// the z-Winograd split-precision kernel: 8 x 32 regions, z-chunks of whole plane pairs (a pure function of the extents, like the statistics record count)
-static inline int h2z_regions(int H, int W) { return cdiv(W, HZ_BX) * cdiv(H, HZ_BY); }
-static inline int h2z_zchunk(int D, int H, int W) {
-    int nchunk = cdiv(16, h2z_regions(H, W));
-    if (const char* e = knob_str("MONAI_AMD_W2_CHUNKS")) {          // tuning knob (development)
-        const int v = atoi(e);
-        if (v >= 1 && v <= D) nchunk = v;
-    } else if (nchunk > D / 12) nchunk = D / 12;
-    if (nchunk < 1) nchunk = 1;
-    return (cdiv(D, nchunk) + 1) & ~1;
-}
-static inline int h2z_blocks(int D, int H, int W) { return h2z_regions(H, W) * cdiv(D, h2z_zchunk(D, H, W)); }
-
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
-int mh_conv3d_k3_h2z_config(void) { return MH_CFG_H2Z; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 int mh_conv3d_k3_h2c_config(void) { return MH_CFG_H2C; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
@@ -490,7 +473,6 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0;
     if (cfg == MH_CFG_H2C) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= 16 && Cout % 16 == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
-    if (cfg == MH_CFG_H2Z) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= HZ_NRM_MAX && Cout >= H2_CN && Cout % H2_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -499,7 +481,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
 // zero-padded input channels both count -- preferring the wider cout tile, then the measured preference.
 int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, int H, int W) {
     if (Cin < 1 || Cout < 1 || D < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "conv3d_k3_select: bad argument");
-    if (algo < MH_ALGO_AUTO || algo > MH_ALGO_H2Z) return fail(MH_ERR_ARG, "conv3d_k3_select: unknown algorithm family %d", algo);
+    if (algo < MH_ALGO_AUTO || algo > MH_ALGO_FP32) return fail(MH_ERR_ARG, "conv3d_k3_select: unknown algorithm family %d", algo);
     int best = 0;
     double best_score = 0.0;
     for (int c = 1; c <= MH_NUM_CFG; ++c) {
@@ -522,17 +504,12 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     // profiles/r02_h2_vs_wino2p_*.json).  It scales its input into fp16's range by a power of two taken from the bounds the input
     // records carry (kernels/conv3d_h2.h), so it is chosen -- also under MH_ALGO_H2 -- only for inputs that carry them
     // (`input_bounded`); anything else gets the exact fp32 kernels.
-    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2 || algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W))
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W))
         best = MH_CFG_H2;
     // 16 output channels: the same kernel with two z-taps per matrix instruction (6 instead of 9 per tap; a 32-column group would be half zero weights)
-    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2 || algo == MH_ALGO_H2Z) && input_bounded && Cout == 16 && mh_conv3d_k3_accepts(MH_CFG_H2C, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W)
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && Cout == 16 && mh_conv3d_k3_accepts(MH_CFG_H2C, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W)
         && knob_int("MONAI_AMD_H2C", 1) != 0)
         best = MH_CFG_H2C;
-    // the same arithmetic behind a Winograd F(2, 3) transform along z: 2/3 of the matrix instructions (kernels/conv3d_h2z.h).  Its regions are 8 x 32: taken where they cover
-    // the plane as well as the direct kernel's regions do (96 x 96, 24 x 24; not 48 x 48: 12 regions against 9) and the march has at least four plane pairs
-    if ((algo == MH_ALGO_H2Z) && input_bounded && mh_conv3d_k3_accepts(MH_CFG_H2Z, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && D >= 8 && h2_fits(D, H, W)
-        && (algo == MH_ALGO_H2Z || h2z_regions(H, W) <= h2_regions(H, W)))
-        best = MH_CFG_H2Z;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
     if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
         best = MH_CFG_C1;
@@ -544,7 +521,6 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * cdiv(Cout, H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
     if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
-    if (cfg == MH_CFG_H2Z) return (int64_t)(Cin / H2_KC) * (Cout / H2_CN) * (4 * HZ_WP) * 4 + H2_TAIL;   // four transformed positions x two fp16 pieces per chunk + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -579,15 +555,6 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
                            reinterpret_cast<_Float16*>(packed), tail);
         return launched("conv3d_k3_h2_pack");
     }
-    if (cfg == MH_CFG_H2Z) {
-        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the z-Winograd split kernel needs Cin %% 16 == 0, Cin <= 128, Cout %% 32 == 0");
-        const int64_t slab_floats = mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL;
-        float* tail = packed + slab_floats;
-        hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
-        hipLaunchKernelGGL(conv3d_k3_h2z_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
-                           reinterpret_cast<_Float16*>(packed), tail);
-        return launched("conv3d_k3_h2z_pack");
-    }
     if (cfg == MH_CFG_C1) {          // [Cin = 1][27][Cout]: the direct kernel's layout
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the one-channel kernel needs Cin == 1, Cout %% 8 == 0");
         hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for(27LL * Cout)), dim3(256), 0, (hipStream_t)stream, w, 1, 1, Cout, Cout, Cout, packed);
@@ -605,7 +572,6 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
     if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) return h2_blocks(D, H, W);
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
-    if (cfg == MH_CFG_H2Z) return h2z_blocks(D, H, W);
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -645,27 +611,6 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         else hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         return launched("conv3d_k3_c1");
-    }
-    if (cfg == MH_CFG_H2Z) {
-        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || in.W % 4)
-            return fail(MH_ERR_ARG, "conv3d_k3: the z-Winograd split kernel needs Cin %% 16 == 0, Cin <= 128, Cout %% 32 == 0, W %% 4 == 0 (got %d -> %d, %dx%dx%d)",
-                        in.C, out.C, in.D, in.H, in.W);
-        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16))
-            return fail(MH_ERR_ARG, "conv3d_k3: the z-Winograd split kernel needs 16-byte aligned output and weights");
-        if (!h2_fits(out.D, out.H, out.W))
-            return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: the split kernels address 32 output planes with 32-bit offsets (D*H*W < 2^24 voxels); mh_conv3d_k3_select does not return them beyond");
-        const int bxn = cdiv(out.W, HZ_BX), byn = cdiv(out.H, HZ_BY), zc = h2z_zchunk(out.D, out.H, out.W);
-        const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
-        const long long total = (long long)nblk * (out.C / H2_CN) * out.N;
-        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
-        const dim3 grid((unsigned)total);
-        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
-        const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<true, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2z_kernel<false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        else hipLaunchKernelGGL((conv3d_k3_h2z_kernel<false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);
-        return launched("conv3d_k3_h2z");
     }
     if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) {
         const bool c16 = cfg == MH_CFG_H2C;

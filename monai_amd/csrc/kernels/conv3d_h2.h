@@ -93,7 +93,7 @@ __device__ __forceinline__ void h2_split(float v, _Float16& hi, _Float16& lo) {
 
 // two values at once, in the form the ISA has instructions for: hi pair = ONE v_cvt_pk_f16_f32, each residual v - hi = ONE v_fma_mix_f32 (the fp16 half is widened
 // inside the instruction: fma(hi, -1, v) rounds once, exactly like v - (float)hi), lo pair = ONE v_cvt_pk_f16_f32 -- 2 instead of 4 instructions per value; the
-// same bits as h2_split.  Measured in round 4 (profiles/r04_h2_split_pair_ab.txt): in conv3d_h2z.h -1 % time; in THIS file's kernel 0 ... +8 % (48^3 level: the
+// same bits as h2_split.  Measured in round 4 (profiles/r04_h2_split_pair_ab.txt): in the z-Winograd experiment of that round (removed in round 5) -1 % time; in THIS file's kernel 0 ... +8 % (48^3 level: the
 // mixlo / mixhi pair writes the two halves of one register, a serial dependency in the middle of the conversion piece) -- so conv3d_k3_h2_kernel keeps h2_split
 // `m1` = -1.0f behind a value barrier (h2_minus_one): with the literal the optimiser rewrites fma(hi, -1, v) into a subtraction and the widening costs its own instruction
 __device__ __forceinline__ float h2_minus_one() {

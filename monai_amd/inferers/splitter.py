@@ -61,11 +61,12 @@ class _GridAxis(NamedTuple):
         return self.lead + self.size + self.tail
 
 
-def _stride(patch: int, overlap) -> int:
-    """Distance of neighbouring patch starts: a float overlap is a fraction of the patch, an int one a number of elements
+def _stride(patch: int, overlap, relative: bool) -> int:
+    """Distance of neighbouring patch starts: a relative overlap is a fraction of the patch, an absolute one a number of elements
     (iter_patch_position, monai/data/utils.py:241-245 -- ``round(p * (1.0 - o))``, NOT the ``round(p - p * o)`` of the padding rule:
-    the two land on opposite sides of a .5 tie for some (patch, overlap) pairs)"""
-    return round(patch * (1.0 - overlap)) if isinstance(overlap, float) else patch - overlap
+    the two land on opposite sides of a .5 tie for some (patch, overlap) pairs).  `relative` is ONE decision for all axes -- the type of the
+    FIRST overlap entry, as the reference takes it (``isinstance(overlap[0], float)``), not a per-axis one"""
+    return round(patch * (1.0 - overlap)) if relative else patch - overlap
 
 
 def _pad_modulus(patch: int, overlap) -> int:
@@ -122,6 +123,7 @@ class SlidingWindowSplitter(Splitter):
         patches = ensure_tuple_rep(self.patch_size, nd)
         overlaps = ensure_tuple_rep(self.overlap, nd)
         zero = type(overlaps[0])(0)
+        relative = isinstance(overlaps[0], float)
         overlaps = tuple(o if p else zero for o, p in zip(overlaps, patches))          # a 0 patch extent = the whole axis, no overlap
         if any(o > p for o, p in zip(overlaps, patches)):
             raise ValueError(f"`overlap` ({overlaps}) cannot be larger than patch size ({patches}).")
@@ -135,7 +137,7 @@ class SlidingWindowSplitter(Splitter):
             if not patch:                               # whole axis: one patch at the offset (the reference's get_valid_patch_size rule)
                 axes.append(_GridAxis(size, size, max(size, 1), 0, 0, tuple(range(off, 1, max(size, 1)))))
                 continue
-            stride = _stride(patch, ov)
+            stride = _stride(patch, ov, relative)
             lead = tail = 0
             if self.pad_mode:
                 lead = max(-off, 0)
@@ -188,7 +190,9 @@ class SlidingWindowSplitter(Splitter):
         try:
             out = torch.empty((n, src.shape[1]) + roi, dtype=torch.float32, device=src.device)
             return ops.window_extract(src[0].contiguous(), grid, 0, n, roi, out)
-        except RuntimeError:        # a window grid the gather kernel does not take (e.g. an irregular start list beyond its table): views
+        except (_lib.KernelRejected, torch.cuda.OutOfMemoryError):
+            # a window grid the gather kernel does not take (e.g. an irregular start list beyond its table), or no room for the dense buffer: views.
+            # Launch failures / HIP errors are NOT caught: a broken gather must fail, not degrade into a slow path
             return None
 
     def _pairs(self, inputs: torch.Tensor) -> Iterator[tuple[torch.Tensor, tuple]]:

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import os
 import threading
+import warnings
 from collections.abc import Callable, Mapping, Sequence
 from typing import Any
 
@@ -158,6 +159,20 @@ def sliding_window_inference(
             buffer_dim += num_spatial_dims
         if buffer_dim >= num_spatial_dims or process_fn is not None or with_coord:
             raise NotImplementedError("monai_amd: buffer_steps with buffer_dim == the number of spatial dims, process_fn or with_coord is not on the HIP path")
+        if kwargs.get("_monai_amd_argmax") is not None:       # rejected BEFORE any window is predicted (a fall-through would otherwise predict them all twice)
+            raise NotImplementedError("monai_amd: the fused argmax epilogue with buffer_steps is not on the HIP path (blend in the buffered order, then AsDiscrete)")
+        if not kwargs.pop("_monai_amd_buffered_inner", False):
+            # `buffer_steps` is the reference's MEMORY-SAVING option: the callers who pass it are the ones with large volumes.  The buffered summation order
+            # needs the logits of all windows resident; when they do not fit, the volume goes through the plain order slab by slab (bit-identical to the
+            # reference's plain run, which differs from its buffered run by roundings <= 1e-6 -- tests/golden/buffered.npz) instead of failing.
+            common = (roi_size, sw_batch_size, predictor, overlap, mode, sigma_scale, padding_mode, cval, sw_device, device, progress, roi_weight_map, process_fn)
+            try:
+                return sliding_window_inference(inputs, *common, buffer_steps, buffer_dim, with_coord, *args, _monai_amd_buffered_inner=True, **kwargs)
+            except _LogitsDoNotFit as e:
+                reason = str(e).split(" (")[0]
+            warnings.warn(f"{reason}: buffer_steps={buffer_steps} is served in the plain summation order, slab by slab "
+                          "(equal to the reference's unbuffered result; its buffered result differs from that by roundings)")
+            return sliding_window_inference(inputs, *common, None, -1, with_coord, *args, **kwargs)
     overlap = ensure_tuple_rep(overlap, num_spatial_dims)
     for o in overlap:
         if o < 0 or o >= 1:
@@ -280,6 +295,10 @@ def sliding_window_inference(
     zscales = None
 
     fused = fused and hasattr(predictor, "out_channels") and getattr(predictor, "window_sized_output", True)
+    # window batches on alternating HIP streams (config.SW_STREAMS): batch q + 1's memory-bound passes (pooling, transposed convolutions, the 1x1 into the logits)
+    # run next to batch q's matrix-bound convolutions instead of in front of them.  Every stream owns its window buffer and its own set of the predictor's
+    # activation buffers (`slot`); the windows' logits go to disjoint rows, so the result bits do not depend on the interleaving.
+    lanes = _StreamLanes(dev, predictor, fused and shard.world == 1 and not buffered, len(my_rounds), win_buf)
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
         steps = list(enumerate(my_rounds))
@@ -292,62 +311,66 @@ def sliding_window_inference(
                 pass
         pending = []
         for q, (w0, n) in steps:
-            if n > 0:
-                ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
-                win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
-                if fused:
-                    if logits is None:
-                        k = int(predictor.out_channels)
-                        seg_shapes, zscales = [tuple(roi_size)], [None]
-                        mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
-                        logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
+            if n > 0 and fused:
+                if logits is None:
+                    k = int(predictor.out_channels)
+                    seg_shapes, zscales = [tuple(roi_size)], [None]
+                    mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
+                    logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
+                with lanes.lane(q) as (wbuf, slot_kw):
+                    ops.window_extract(vol3, grid3, w0, n, roi3, wbuf[:n])
                     with _prof.span("sw_predictor"):
                         if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
-                            predictor.forward_into_windows(win_buf[:n], mosaic, w0)
+                            predictor.forward_into_windows(wbuf[:n], mosaic, w0, **slot_kw)
                         else:
-                            predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
+                            predictor.forward_into(wbuf[:n], logits[0][w0 : w0 + n], **slot_kw)
+            elif n > 0:
+                ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
+                win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
+                if with_coord:
+                    coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
+                    seg_out = predictor(win_data, coords, *args, **kwargs)
                 else:
-                    if with_coord:
-                        coords = [[slice(b, b + 1), slice(None)] + list(windows_nd[i]) for i in range(w0, w0 + n)]
-                        seg_out = predictor(win_data, coords, *args, **kwargs)
-                    else:
-                        seg_out = predictor(win_data, *args, **kwargs)
-                    dict_keys, segs = _flatten_struct(seg_out)
-                    w_batch = None
-                    if process_fn is not None:     # utils.py:232-238: the callback may edit the predictions and the weight map
-                        if imp_dev is None:
-                            imp_dev = imp.to(dev)
-                        segs, w_t = process_fn(segs, win_data, imp_dev)
-                        segs = tuple(segs) if isinstance(segs, (list, tuple)) else (segs,)
-                        if w_t.dim() == num_spatial_dims:
-                            w_t = w_t[None, None]
-                        w_batch = w_t.to(dtype=compute_dtype, device=dev)
-                    if logits is None:
-                        seg_shapes = [tuple(s.shape[2:]) for s in segs]
-                        zscales = [
-                            None if sh == tuple(roi_size) else [o / float(i) for o, i in zip(sh, roi_size)] for sh in seg_shapes
-                        ]
-                        logits = [_alloc_logits(shard, nb, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
-                    for ss, s in enumerate(segs):
-                        if s.dtype != compute_dtype and s.is_floating_point():
-                            # a predictor under torch.autocast returns half precision; the reference weights it in that precision and
-                            # accumulates in compute_dtype (utils.py:286-288) -- here it is widened first (never less precise)
-                            s = s.to(compute_dtype)
-                        _lib.require_device(s)
-                        dst = logits[ss][w0 : w0 + n]
-                        if w_batch is None:
-                            dst.copy_(s.reshape(dst.shape))
-                            continue
-                        if zscales[ss] is not None:      # cumulative nearest resampling, as utils.py:260-263
-                            w_batch = F.interpolate(w_batch, seg_shapes[ss], mode=_NEAREST)
-                        if w_batch.shape[0] != 1 or w_batch.shape[1] != 1:
-                            raise RuntimeError("monai_amd: process_fn must return a weight map broadcastable over batch and channels "
-                                               f"(got {tuple(w_batch.shape)}; the reference's count map needs [1, 1, *spatial])")
-                        if proc_weights is None:
-                            proc_weights = []
-                        if len(proc_weights) <= ss:      # the count map is built from the FIRST batch's map (utils.py:270-275)
-                            proc_weights.append(w_batch[0, 0].reshape(_to3(seg_shapes[ss], 1)).contiguous().clone())
-                        torch.mul(s.reshape(dst.shape), w_batch.reshape((1, 1) + tuple(dst.shape[2:])), out=dst)   # `seg *= w_t`
+                    seg_out = predictor(win_data, *args, **kwargs)
+                dict_keys, segs = _flatten_struct(seg_out)
+                w_batch = None
+                if process_fn is not None:     # utils.py:232-238: the callback may edit the predictions and the weight map
+                    if imp_dev is None:
+                        imp_dev = imp.to(dev)
+                    segs, w_t = process_fn(segs, win_data, imp_dev)
+                    segs = tuple(segs) if isinstance(segs, (list, tuple)) else (segs,)
+                    if w_t.dim() == num_spatial_dims:
+                        w_t = w_t[None, None]
+                    w_batch = w_t.to(dtype=compute_dtype, device=dev)
+                if buffered and logits is None and (len(segs) != 1 or tuple(segs[0].shape[2:]) != tuple(roi_size)):
+                    # known after the FIRST batch, not after all of them (the reference ignores further outputs there and fails on a resized one)
+                    raise NotImplementedError("monai_amd: buffer_steps with several / multi-resolution predictor outputs is not on the HIP path")
+                if logits is None:
+                    seg_shapes = [tuple(s.shape[2:]) for s in segs]
+                    zscales = [
+                        None if sh == tuple(roi_size) else [o / float(i) for o, i in zip(sh, roi_size)] for sh in seg_shapes
+                    ]
+                    logits = [_alloc_logits(shard, nb, int(s.shape[1]), _to3(sh, 1), compute_dtype, dev) for s, sh in zip(segs, seg_shapes)]
+                for ss, s in enumerate(segs):
+                    if s.dtype != compute_dtype and s.is_floating_point():
+                        # a predictor under torch.autocast returns half precision; the reference weights it in that precision and
+                        # accumulates in compute_dtype (utils.py:286-288) -- here it is widened first (never less precise)
+                        s = s.to(compute_dtype)
+                    _lib.require_device(s)
+                    dst = logits[ss][w0 : w0 + n]
+                    if w_batch is None:
+                        dst.copy_(s.reshape(dst.shape))
+                        continue
+                    if zscales[ss] is not None:      # cumulative nearest resampling, as utils.py:260-263
+                        w_batch = F.interpolate(w_batch, seg_shapes[ss], mode=_NEAREST)
+                    if w_batch.shape[0] != 1 or w_batch.shape[1] != 1:
+                        raise RuntimeError("monai_amd: process_fn must return a weight map broadcastable over batch and channels "
+                                           f"(got {tuple(w_batch.shape)}; the reference's count map needs [1, 1, *spatial])")
+                    if proc_weights is None:
+                        proc_weights = []
+                    if len(proc_weights) <= ss:      # the count map is built from the FIRST batch's map (utils.py:270-275)
+                        proc_weights.append(w_batch[0, 0].reshape(_to3(seg_shapes[ss], 1)).contiguous().clone())
+                    torch.mul(s.reshape(dst.shape), w_batch.reshape((1, 1) + tuple(dst.shape[2:])), out=dst)   # `seg *= w_t`
             if shard.world > 1:
                 if logits is None:
                     raise RuntimeError("monai_amd: a rank without windows in the first round cannot size the logits buffer "
@@ -357,6 +380,7 @@ def sliding_window_inference(
 
         if logits is None:
             raise RuntimeError("monai_amd: no windows were processed")
+        lanes.join()          # the blend (on the caller's stream) reads what the side streams wrote
         with _prof.span("sw_gather_wait"):         # what the compute stream still has to wait for after its last round
             for work in pending:
                 work.wait()
@@ -383,9 +407,7 @@ def sliding_window_inference(
             nlog = num_win * lg.k * roi3[0] * roi3[1] * roi3[2] if lg is mosaic else lg[:num_win].numel()
             nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
-                if buffered:      # the reference's buffered summation order (single output at window resolution)
-                    if len(gathered) != 1 or z is not None or argmax_dtype is not None:
-                        raise NotImplementedError("monai_amd: buffer_steps with several / multi-resolution outputs or the fused argmax is not on the HIP path")
+                if buffered:      # the reference's buffered summation order (single output at window resolution; checked after the first predictor batch)
                     ops.sw_blend_buffered(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1), buffer_dim + (3 - num_spatial_dims), int(buffer_steps))
                 elif lg is mosaic:
                     ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, imp, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
@@ -418,6 +440,73 @@ def sliding_window_inference(
     if any(pad_size):
         kwargs.update({"pad_size": pad_size})
     return _pack_struct(finals, dict_keys)
+
+
+class _StreamLanes:
+    """Window batches of the fused path dealt out over `config.SW_STREAMS` HIP streams (one GPU, a predictor with per-slot activation buffers: `plan_slots`).
+    Lane 0 is the caller's stream; batch 0 always runs there alone (it packs the weights every lane reads), the others alternate.  A side stream starts behind
+    everything the caller's stream had enqueued when it was forked (the volume, batch 0) and is joined before the blend."""
+
+    def __init__(self, dev, predictor, eligible: bool, num_batches: int, win_buf: torch.Tensor):
+        from .. import config
+
+        want = config.sw_streams()
+        slots = int(getattr(predictor, "plan_slots", 1))
+        self.n = max(1, min(want, slots)) if (eligible and dev.type == "cuda" and num_batches > 2) else 1
+        self.bufs = [win_buf] + [torch.empty_like(win_buf) for _ in range(self.n - 1)]
+        self.streams = None
+        self.dev = dev
+        self.forked = False
+
+    def lane(self, q: int):
+        import contextlib
+
+        if self.n == 1:
+            return contextlib.nullcontext((self.bufs[0], {}))
+        if self.streams is None:
+            self.streams = [torch.cuda.current_stream(self.dev)] + [_side_stream(self.dev, i) for i in range(1, self.n)]
+        i = 0 if q == 0 else q % self.n
+        if q > 0 and not self.forked:          # fork: the side streams start behind batch 0
+            ev = torch.cuda.Event()
+            ev.record(self.streams[0])
+            for st in self.streams[1:]:
+                st.wait_event(ev)
+            self.forked = True
+        return self._on(i)
+
+    def _on(self, i: int):
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if i == 0:
+                yield self.bufs[0], {"slot": 0}
+            else:
+                with torch.cuda.stream(self.streams[i]):
+                    yield self.bufs[i], {"slot": i}
+
+        return ctx()
+
+    def join(self) -> None:
+        if self.n > 1 and self.forked:
+            for st in self.streams[1:]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.streams[0].wait_event(ev)
+            self.forked = False
+
+
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev, i: int):
+    """side streams are created once per (device, lane) and reused: creating a HIP stream per call costs more than a window batch of a small volume"""
+    key = (str(dev), i)
+    with _MAPS_LOCK:
+        st = _SIDE_STREAMS.get(key)
+        if st is None:
+            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
 
 
 # ---- importance maps: host evaluation and upload happen once per (patch size, mode, sigma, dtype), not once per call -------------------------
@@ -580,8 +669,8 @@ class _LogitsDoNotFit(RuntimeError):
     def __init__(self, need: int, budget: float):
         super().__init__(
             f"monai_amd: the all-window logits buffer needs {need / 2**30:.2f} GiB, the budget is {budget / 2**30:.2f} GiB of HBM "
-            "(and the volume cannot be cut into slabs along its first spatial axis: a single row of windows does not fit, or the "
-            "call uses with_coord / process_fn, whose semantics are tied to the whole volume)"
+            "(and the volume cannot be cut into slabs along its first spatial axis: a single row of windows does not fit, the image is padded "
+            "up to the roi, or the call uses with_coord / process_fn, whose semantics are tied to the whole volume)"
         )
         self.need, self.budget = need, budget
 

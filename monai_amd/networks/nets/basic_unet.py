@@ -238,12 +238,15 @@ class BasicUNet(nn.Module):
         out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
 
+    plan_slots = 4      # independent sets of activation buffers (`slot`): concurrent forwards on different HIP streams (inferers/utils.py:_StreamLanes)
+
     @torch.no_grad()
-    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-        """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer).  `slot`: which of the `plan_slots` buffer sets to run in --
+        two forwards may be in flight at once (on different streams) only in different slots."""
         _lib.require_device(x, out[0].flat if isinstance(out, tuple) else out)
         if self.spatial_dims == 2 and x.dim() == 4 and not isinstance(out, tuple) and out.dim() == 4:
-            self.forward_into(x.unsqueeze(2), out.unsqueeze(2))          # one plane of the 3-D engine (views: no copy)
+            self.forward_into(x.unsqueeze(2), out.unsqueeze(2), slot)          # one plane of the 3-D engine (views: no copy)
             return out
         if self.training:
             raise NotImplementedError("monai_amd.BasicUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
@@ -253,10 +256,10 @@ class BasicUNet(nn.Module):
             raise RuntimeError(f"monai_amd.BasicUNet: a 2-D network takes one plane, got {tuple(x.shape)}")
         if min((h, w) if self.spatial_dims == 2 else (d, h, w)) < 16:
             raise RuntimeError(f"monai_amd.BasicUNet: window {d}x{h}x{w} is too small for four 2x poolings")
-        key = (n, d, h, w, str(x.device))
+        key = (n, d, h, w, str(x.device), int(slot))
         plan = self._plans.get(key)
         if plan is None:
-            if len(self._plans) >= 4:
+            if len(self._plans) >= 4 * self.plan_slots:
                 self._plans.clear()
             plan = self._plans[key] = _Plan(self, n, (d, h, w), x.device)
         plan.run(self, x, out)
@@ -264,10 +267,10 @@ class BasicUNet(nn.Module):
 
 
     @torch.no_grad()
-    def forward_into_windows(self, x: torch.Tensor, mosaic, w0: int) -> None:
+    def forward_into_windows(self, x: torch.Tensor, mosaic, w0: int, slot: int = 0) -> None:
         """Forward of a batch of sliding-window windows whose logits go straight into the inferer's mosaic logits layout (ops.LogitsMosaic): batch
         element i is window w0 + i; the final 1x1 convolution writes each window to its strided place (mh_conv1x1_windows_f32)."""
-        self.forward_into(x, (mosaic, int(w0)))
+        self.forward_into(x, (mosaic, int(w0)), slot)
 
 
 BasicUnet = Basicunet = basicunet = BasicUNet

@@ -308,12 +308,6 @@ def conv3d_k3_h2_config() -> int:
     return _lib.lib().query("mh_conv3d_k3_h2_config")
 
 
-def conv3d_k3_h2z_config() -> int:
-    """Id of the split-precision configuration behind the z-Winograd F(2, 3) transform (kernels/conv3d_h2z.h): the arithmetic of
-    `conv3d_k3_h2_config` with 2/3 of its matrix instructions; same tolerance class."""
-    return _lib.lib().query("mh_conv3d_k3_h2z_config")
-
-
 def conv3d_k3_h2c_config() -> int:
     """Id of the split-precision configuration with output channel groups of 16 (two z-taps per 32-column matrix instruction): what `conv3d_k3_select` returns for
     bounded inputs of layers with 16 output channels; same tolerance class as `conv3d_k3_h2_config`."""

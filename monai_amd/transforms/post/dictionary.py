@@ -1,4 +1,8 @@
-"""Dictionary wrappers ``Activationsd`` / ``AsDiscreted`` (monai/transforms/post/dictionary.py:102-212)."""
+"""Dictionary forms ``Activationsd`` / ``AsDiscreted`` of the post-processing transforms (contract: monai/transforms/post/dictionary.py:102-212 --
+constructor signatures, per-key broadcasting of scalar options, the ``converter`` attribute with its ``kwargs``, missing-key behaviour).
+
+Both are the same thing: ONE array transform (array.py, HIP kernels) applied to every key with that key's call options.  `_PerKey` holds the
+option table -- one row per key -- and the loop; a dictionary transform only names its array transform and its options."""
 
 from __future__ import annotations
 
@@ -10,64 +14,58 @@ from .array import Activations, AsDiscrete
 __all__ = ["Activationsd", "ActivationsD", "ActivationsDict", "AsDiscreted", "AsDiscreteD", "AsDiscreteDict"]
 
 
-class _MapTransform:
-    def __init__(self, keys, allow_missing_keys: bool = False) -> None:
+class _PerKey:
+    """keys + a table of per-key call options for `array_transform`; ``self.<option>`` is the column of that option (a tuple, one entry per key)"""
+
+    array_transform: type = object
+    # options that used to be boolean switches in old MONAI releases and now take a value: option name -> what to pass instead
+    valued_options: Mapping[str, str] = {}
+
+    def _bind(self, keys, allow_missing_keys: bool, converter_kwargs: dict, **options) -> None:
         self.keys = ensure_tuple(keys)
         self.allow_missing_keys = allow_missing_keys
         if not self.keys:
             raise ValueError("keys must be non empty.")
+        self._columns = tuple(options)
+        for name, value in options.items():
+            column = ensure_tuple_rep(value, len(self.keys))
+            if name in self.valued_options and any(isinstance(v, bool) for v in column):
+                raise ValueError(f"`{name}=True/False` is deprecated, please use `{name}={self.valued_options[name]}` instead.")
+            setattr(self, name, column)
+        self.converter = self.array_transform()
+        self.converter.kwargs = converter_kwargs
 
     def key_iterator(self, data: Mapping[Hashable, object], *extra):
-        """(key, *per-key options) for the keys present in `data`; a missing key raises unless allow_missing_keys."""
-        for key, *vals in zip(self.keys, *extra):
-            if key in data:
-                yield (key, *vals)
+        """(key, *per-key values) for the keys present in `data`; a missing key raises unless allow_missing_keys"""
+        for row in zip(self.keys, *extra):
+            if row[0] in data:
+                yield row
             elif not self.allow_missing_keys:
-                raise KeyError(f"Key `{key}` of transform `{self.__class__.__name__}` was missing in the data and allow_missing_keys==False.")
-
-
-class Activationsd(_MapTransform):
-    def __init__(self, keys, sigmoid: Sequence[bool] | bool = False, softmax: Sequence[bool] | bool = False,
-                 other: Sequence[Callable] | Callable | None = None, allow_missing_keys: bool = False, **kwargs) -> None:
-        super().__init__(keys, allow_missing_keys)
-        self.sigmoid = ensure_tuple_rep(sigmoid, len(self.keys))
-        self.softmax = ensure_tuple_rep(softmax, len(self.keys))
-        self.other = ensure_tuple_rep(other, len(self.keys))
-        self.converter = Activations()
-        self.converter.kwargs = kwargs
+                raise KeyError(f"Key `{row[0]}` of transform `{type(self).__name__}` was missing in the data and allow_missing_keys==False.")
 
     def __call__(self, data):
-        d = dict(data)
-        for key, sigmoid, softmax, other in self.key_iterator(d, self.sigmoid, self.softmax, self.other):
-            d[key] = self.converter(d[key], sigmoid, softmax, other)
-        return d
+        out = dict(data)
+        for key, *opts in self.key_iterator(out, *(getattr(self, c) for c in self._columns)):
+            out[key] = self.converter(out[key], *opts)
+        return out
 
 
-class AsDiscreted(_MapTransform):
+class Activationsd(_PerKey):
+    array_transform = Activations
+
+    def __init__(self, keys, sigmoid: Sequence[bool] | bool = False, softmax: Sequence[bool] | bool = False,
+                 other: Sequence[Callable] | Callable | None = None, allow_missing_keys: bool = False, **kwargs) -> None:
+        self._bind(keys, allow_missing_keys, kwargs, sigmoid=sigmoid, softmax=softmax, other=other)
+
+
+class AsDiscreted(_PerKey):
+    array_transform = AsDiscrete
+    valued_options = {"to_onehot": "num_classes", "threshold": "value"}
+
     def __init__(self, keys, argmax: Sequence[bool] | bool = False, to_onehot: Sequence[int | None] | int | None = None,
                  threshold: Sequence[float | None] | float | None = None, rounding: Sequence[str | None] | str | None = None,
                  allow_missing_keys: bool = False, **kwargs) -> None:
-        super().__init__(keys, allow_missing_keys)
-        self.argmax = ensure_tuple_rep(argmax, len(self.keys))
-        self.to_onehot = []
-        for flag in ensure_tuple_rep(to_onehot, len(self.keys)):
-            if isinstance(flag, bool):
-                raise ValueError("`to_onehot=True/False` is deprecated, please use `to_onehot=num_classes` instead.")
-            self.to_onehot.append(flag)
-        self.threshold = []
-        for flag in ensure_tuple_rep(threshold, len(self.keys)):
-            if isinstance(flag, bool):
-                raise ValueError("`threshold_values=True/False` is deprecated, please use `threshold=value` instead.")
-            self.threshold.append(flag)
-        self.rounding = ensure_tuple_rep(rounding, len(self.keys))
-        self.converter = AsDiscrete()
-        self.converter.kwargs = kwargs
-
-    def __call__(self, data):
-        d = dict(data)
-        for key, argmax, to_onehot, threshold, rounding in self.key_iterator(d, self.argmax, self.to_onehot, self.threshold, self.rounding):
-            d[key] = self.converter(d[key], argmax, to_onehot, threshold, rounding)
-        return d
+        self._bind(keys, allow_missing_keys, kwargs, argmax=argmax, to_onehot=to_onehot, threshold=threshold, rounding=rounding)
 
 
 ActivationsD = ActivationsDict = Activationsd

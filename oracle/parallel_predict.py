@@ -93,6 +93,15 @@ def basic_unet_factory(state_dict):
     return lambda w: basic_unet_forward(state_dict, w)
 
 
+def basic_unet_factory_no_onednn(state_dict):
+    """the same network with oneDNN switched off in this worker: ATen's native CPU convolution -- another summation order of the same fp32 arithmetic
+    (bench.py: reference_self_spread)"""
+    from .basic_unet import basic_unet_forward
+
+    torch.backends.mkldnn.enabled = False
+    return lambda w: basic_unet_forward(state_dict, w)
+
+
 def unetr_factory(state_dict):
     from .unetr import unetr_forward
 

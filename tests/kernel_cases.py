@@ -173,7 +173,7 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
 
     if cfg is None:
         cfg = ops.conv3d_k3_select(cin, cout, *dims)
-    if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2z_config(), ops.conv3d_k3_h2c_config()) and nrm is not None:
+    if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config()) and nrm is not None:
         # the split-precision kernel scales its input by the bounds its records carry: as loose as the finalize kernel's sqrt(count) bound
         nrm = _with_bounds(x, nrm, loosen=float(np.sqrt(np.prod(dims))))
     packed = ops.conv3d_k3_pack(cfg, w.to(device))

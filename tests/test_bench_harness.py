@@ -33,6 +33,9 @@ def test_bench_single_process_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     par = cb["parity_vs_gpu"]
     assert par["ok"] and par["mismatch_outside_margin"] == 0 and par["max_abs_logit_diff"] <= 1e-4
+    top = line["parity"]            # the same report at top level (the driver's parsed copy keeps it), the line short enough for the driver's stdout tail
+    assert top["ok"] and top["family"] == "fp32-exact" and top["voxels"] == 40 ** 3 and top["max_abs_logit_diff"] == par["max_abs_logit_diff"]
+    assert len(json.dumps(line)) < 6000
     test_bench_single_process_line.checksum = line["checksum"]
 
 
@@ -98,7 +101,7 @@ db.commit()
     assert blend["fetch_bytes"] == 2 * 9000000.0 * 1024 and blend["write_bytes"] == 2621440.0 * 1024
     assert conv["fetch_bytes"] == 7000000.0 * 1024 and conv["hbm_bytes_per_launch"] == (7000000.0 + 7077888.0) * 1024
     assert abs(blend["ratio"] - (2 * 9000000.0 + 2621440.0) * 1024 / (1000 * 5 * 96 ** 3 * 4 + 5 * 512 ** 3 * 4)) < 1e-12
-    assert blend["measured"].startswith("in_run") and "uncalibrated" in conv["measured"]
+    assert blend["measured"] == "in_run" and blend["fetch_calibrated"] and not conv["fetch_calibrated"] and bench._PMC_STATUS["status"] == "in_run"
     monkeypatch.setenv("FAKE_PMC_FAIL", "1")
-    assert bench.pmc_inrun(budget_s=60) == {}
+    assert bench.pmc_inrun(budget_s=60) == {} and bench._PMC_STATUS["status"].startswith("failed: FETCH_SIZE: rocprofv3 rc 3")
     assert bench.pmc_traffic("sw_blend_mosaic_kernel")["measured"].startswith("from_file")

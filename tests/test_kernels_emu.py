@@ -187,20 +187,6 @@ def test_conv3d_wino2d(emu, cin, cout, dims, n):
 H2_CASES = [(16, 32, (4, 16, 16), 2), (32, 48, (5, 16, 16), 2), (48, 80, (3, 8, 24), 1),      # 48 / 80 couts: a half-filled last cout group (round 4)
             (32, 64, (6, 8, 24), 1), (16, 32, (30, 4, 8), 1), (48, 32, (3, 18, 20), 1), (256, 32, (2, 8, 12), 1), (64, 32, (2, 24, 56), 1),
             (32, 32, (24, 8, 24), 1)]
-H2Z_CASES = [(16, 32, (4, 8, 32), 2), (32, 32, (5, 10, 36), 1), (48, 64, (9, 12, 24), 1), (16, 32, (26, 8, 8), 1), (128, 32, (3, 16, 40), 1)]
-@pytest.mark.parametrize("cin,cout,dims,n", H2Z_CASES)
-def test_conv3d_split_precision_z_winograd(emu, cin, cout, dims, n):
-    """the split-precision convolution behind the Winograd F(2, 3) transform along z (conv3d_h2z.h): one / ragged 8 x 32 regions, odd plane counts (a half-filled
-    last pair), two z-chunks, one to eight channel chunks, two cout groups, fused statistics -- the SAME tolerance as the direct kernel and the fp32 tiles"""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_h2z_config()
-    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and not ops.conv3d_k3_accepts(cfg, 144, 32)
-    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
-    kc.case_conv3d("cpu", cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
-
-
-
 # 16-couts groups (two z-taps per matrix instruction): one group / two / three groups, resident and streamed weight slabs, both region shapes, ragged regions, two z-chunks
 H2C_CASES = [(16, 16, (4, 16, 16), 2), (32, 16, (5, 16, 16), 1), (48, 32, (3, 8, 24), 1), (16, 48, (6, 8, 24), 1), (32, 16, (3, 18, 20), 1), (64, 16, (2, 24, 56), 1),
              (16, 16, (24, 8, 24), 1), (16, 16, (30, 4, 8), 1)]

@@ -171,21 +171,6 @@ def test_conv3d_fp16_split_precision(cin, cout, dims, n):
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
-# (cin, cout, dims, n): one / ragged regions, odd plane counts (a half-filled last pair), two z-chunks, several channel chunks and cout groups, a full-size level
-H2Z_CASES = [(16, 32, (4, 8, 32), 2), (32, 32, (5, 10, 36), 1), (48, 64, (9, 12, 24), 1), (16, 32, (26, 8, 8), 1), (128, 32, (7, 16, 40), 1), (64, 64, (24, 24, 24), 2),
-             (32, 32, (96, 96, 96), 2)]
-@pytest.mark.parametrize("cin,cout,dims,n", H2Z_CASES)
-def test_conv3d_split_precision_z_winograd(cin, cout, dims, n):
-    """the split-precision convolution behind the Winograd F(2, 3) transform along z (conv3d_h2z.h): pairs of output planes from four transformed input
-    planes -- the SAME tolerance as the direct split-precision kernel and the fp32 tiles"""
-    from monai_amd import ops
-
-    cfg = ops.conv3d_k3_h2z_config()
-    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and not ops.conv3d_k3_accepts(cfg, 144, 32)
-    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True)
-    kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
-
-
 LINEAR_CASES = [(128, 64, 16, False, False), (200, 144, 48, False, True), (66, 40, 36, True, False), (256, 192, 64, True, True), (13824, 2304, 768, False, False), (1728, 768, 3072, False, True)]
 @pytest.mark.parametrize("m,n,k,gelu,res", LINEAR_CASES)
 def test_linear_fp16_split_precision(m, n, k, gelu, res):
