@@ -86,6 +86,11 @@ SIGNATURES = {
     "mh_nrm_identity_f32": (_I, [_P, _I, _I, _L, _P]),
     "mh_maxpool2_f32": (_I, [_T, _T, _P]),
     "mh_deconv_k2s2_f32": (_I, [_T, _P, _P, _T, _P]),
+    "mh_upconv_k4s2_accepts": (_I, [_I, _I, _I, _I, _I]),
+    "mh_upconv_k4s2_packed_floats": (_L, [_I, _I]),
+    "mh_upconv_k4s2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
+    "mh_upconv_k4s2_stat_tiles": (_I, [_I, _I, _I]),
+    "mh_upconv_k4s2_accum_f32": (_I, [_T, _P, _P, _T, _P, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_stat_tiles": (_I, [_I, _I, _I]),
     "mh_conv1x1_stats_f32": (_I, [_T, _P, _P, _T, _P, _P]),

@@ -47,15 +47,12 @@ class conv_algo_scope:
         return False
 
 
-# ---- HIP streams of the sliding-window engine ----------------------------------------------------------------------------------
-# Window batches of the fused single-GPU path alternate between this many HIP streams (inferers/utils.py:_StreamLanes): the memory-bound passes of one batch
-# overlap the matrix-bound convolutions of the other.  1 = everything on the caller's stream.  `SW_STREAMS` (or MONAI_AMD_STREAMS while it is None).
-SW_STREAMS = None
+# ---- UpCat without its up-sampled intermediate ---------------------------------------------------------------------------------
+# BasicUNet's decoder levels whose shapes the composite kernel takes (csrc/kernels/upconv_h2.h) evaluate conv3(cat([x_e, deconv2(x)])) as conv3[:, skip](x_e) + convT4(x):
+# fp32-equivalent like the split-precision convolution, 1e-6 from the two-layer evaluation.  False (or MONAI_AMD_UPCAT_FUSED=0 while None) keeps the two layers.
+UPCAT_FUSED = None
 
 
-def sw_streams() -> int:
-    v = SW_STREAMS if SW_STREAMS is not None else os.environ.get("MONAI_AMD_STREAMS", "1")
-    try:
-        return max(1, min(int(v), 4))
-    except (TypeError, ValueError):
-        raise ValueError(f"monai_amd: SW_STREAMS / MONAI_AMD_STREAMS must be an integer 1..4, got {v!r}") from None
+def upcat_fused() -> bool:
+    v = UPCAT_FUSED if UPCAT_FUSED is not None else os.environ.get("MONAI_AMD_UPCAT_FUSED", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")

@@ -12,6 +12,7 @@
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_h2.h"
+#include "kernels/upconv_h2.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -779,6 +780,50 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
     if (out.C % 4 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<4, true>), dim3(nb, (unsigned)(out.C / 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
+}
+
+// ---- UpCat's "up" half as one composite transposed convolution k4 s2 p1 added to the convolution's skip half (kernels/upconv_h2.h)
+static inline int upconv_tiles(int Hl, int Wl) { return cdiv(Wl, UC_TX) * cdiv(Hl, UC_TY); }
+static inline int upconv_zchunk(int Dl, int Hl, int Wl) {          // a pure function of the extents (the statistics record count depends on it), conv3d_h2's rule
+    int nchunk = cdiv(16, upconv_tiles(Hl, Wl));
+    if (nchunk > Dl / 12) nchunk = Dl / 12;
+    if (nchunk < 1) nchunk = 1;
+    return cdiv(Dl, nchunk);
+}
+int mh_upconv_k4s2_accepts(int Cin, int Cout, int Dl, int Hl, int Wl) {
+    return Cin == UC_CIN && Cout >= 32 && Cout % 32 == 0 && Dl >= 1 && Hl >= 1 && Wl >= 4 && Wl % 4 == 0 && h2_fits(2 * Dl, 2 * Hl, 2 * Wl);
+}
+int64_t mh_upconv_k4s2_packed_floats(int Cin, int Cout) {
+    if (Cin != UC_CIN || Cout < 32 || Cout % 32) return fail(MH_ERR_ARG, "upconv_k4s2: needs Cin == 32, Cout %% 32 == 0");
+    return (int64_t)(Cout / 32) * 4 * UC_WB * 4 + H2_TAIL;
+}
+int mh_upconv_k4s2_stat_tiles(int Dl, int Hl, int Wl) { return upconv_tiles(Hl, Wl) * 4 * cdiv(Dl, upconv_zchunk(Dl, Hl, Wl)); }
+int mh_upconv_k4s2_pack_f32(const float* w4, int Cin, int Cout, float* packed, void* stream) {
+    if (!w4 || !packed) return fail(MH_ERR_ARG, "upconv_k4s2_pack: null pointer");
+    const int64_t total = mh_upconv_k4s2_packed_floats(Cin, Cout);
+    if (total < 0) return (int)total;
+    float* tail = packed + (total - H2_TAIL);
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w4, (long long)Cin * Cout * 64, tail);
+    hipLaunchKernelGGL(upconv_k4s2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w4, Cin, Cout, reinterpret_cast<_Float16*>(packed), tail);
+    return launched("upconv_k4s2_pack");
+}
+int mh_upconv_k4s2_accum_f32(const mh_tensor5* low_, const float* packed, const float* bias_table, const mh_tensor5* out_, float* stats, void* stream) {
+    if (!dense_ok(low_) || !dense_ok(out_) || !packed || !bias_table) return fail(MH_ERR_ARG, "upconv_k4s2: bad tensor");
+    const Tensor low = from_c(*low_), out = from_c(*out_);
+    if (low.N != out.N || out.D != 2 * low.D || out.H != 2 * low.H || out.W != 2 * low.W) return fail(MH_ERR_ARG, "upconv_k4s2: the output must be 2x the input");
+    if (!mh_upconv_k4s2_accepts(low.C, out.C, low.D, low.H, low.W))
+        return fail(MH_ERR_UNSUPPORTED, "upconv_k4s2: needs Cin == 32, Cout %% 32 == 0, input W %% 4 == 0, D*H*W of the output < 2^24 voxels (got %d -> %d, %dx%dx%d)", low.C, out.C, low.D, low.H, low.W);
+    if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed, 16)) return fail(MH_ERR_ARG, "upconv_k4s2: 16-byte aligned output and weights required");
+    const int txn = cdiv(low.W, UC_TX), tyn = cdiv(low.H, UC_TY), zc = upconv_zchunk(low.D, low.H, low.W);
+    const unsigned nblk = (unsigned)(txn * tyn * 4 * cdiv(low.D, zc));
+    const long long total = (long long)nblk * (out.C / 32) * out.N;
+    if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "upconv_k4s2: problem too large for one launch");
+    const uint4* wq = reinterpret_cast<const uint4*>(packed);
+    const float* tail = packed + (mh_upconv_k4s2_packed_floats(low.C, out.C) - H2_TAIL);
+    hipStream_t s = (hipStream_t)stream;
+    if (stats) hipLaunchKernelGGL((upconv_k4s2_h2_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
+    else hipLaunchKernelGGL((upconv_k4s2_h2_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
+    return launched("upconv_k4s2");
 }
 
 template <int VEC, bool STATS>

@@ -1,0 +1,298 @@
+// The decoder's "up" half of an UpCat block without its intermediate tensor (round 5).
+//
+// Reference op (monai/networks/nets/basic_unet.py:130-178, UpCat.forward): x_0 = ConvTranspose3d(k2, s2)(x) -- no normalisation, no activation -- then
+// Conv3d(k3, p1)(cat([x_e, x_0])).  The convolution is linear in its input channels, so its x_0 half is the composition conv3 o deconv2 applied to x, and that
+// composition is ONE transposed convolution with kernel 4, stride 2, padding 1 whose weights are products of the two layers' weights summed over the up channels
+// (W4[ci][co][u] = sum_cm sum_{(d,k): d - k + 1 = u} Wd[ci][cm][d] Wc[co][cm][k] per axis; the deconvolution's bias becomes a 27-entry table per output channel: which of
+// the convolution's taps fall inside the volume depends on first / interior / last position per axis).  Per FINE output voxel that is 2 x 2 x 2 coarse taps x Cin x Cout
+// multiply-adds instead of 27 x Cup x Cout on a full-resolution tensor -- 3.4 x fewer at Cin == Cup -- and the full-resolution x_0 (7.2 GB per 64 windows of 96^3)
+// is neither written by a transposed convolution nor read by the convolution.  Host side: monai_amd/networks/nets/basic_unet.py (_upcat_fused), which runs the
+// convolution's x_e half on conv3d_k3_h2_kernel (raw result, convolution bias included, no statistics) and then this kernel, which ADDS the composite term and the
+// bias table to that result in place and produces the InstanceNorm statistics of the sum.
+//
+// Arithmetic: conv3d_h2.h's two-piece split precision (hi + lo fp16 pieces of the activated, power-of-two-scaled input and of the scaled composite weights, products
+// hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulation), the same record / bound contract for the input.  The composite weights are formed in fp32 on
+// the host from the fp32 parameters: one rounding per weight more than the two-layer evaluation, 1e-7 relative.
+//
+// Mapping.  An output voxel's taps depend on its parity per axis (f = 2c + p: p = 0 reads coarse c - 1 and c, p = 1 reads c and c + 1), so voxels of one parity
+// class share their weight matrices and form a GEMM: a workgroup owns ONE (z, y) parity pair, a coarse tile of 8 rows x 16 columns (fine: 8 rows of that parity x 32
+// columns), 32 output channels, and marches over its coarse z-chunk.  Wave w owns coarse rows 2w, 2w + 1 = a 32-voxel M block and carries BOTH x parities as two
+// accumulator sets (so a lane's results are 8 consecutive fine columns per row and group: 16-byte accesses); per fine plane 16 (tz, ty, tx, px) tap matrices x
+// Cin / 16 steps x 3 piece products.  The weight slab of the parity pair (64 KB at Cin = 32) stays in LDS for the whole march; coarse input planes are staged once each
+// (activated, scaled, split) into a ring of two.
+#pragma once
+#include "common.h"
+#include "conv3d_h2.h"
+
+namespace mh {
+
+constexpr int UC_TY = 8, UC_TX = 16;                       // coarse tile of a workgroup
+constexpr int UC_RY = UC_TY + 1, UC_RX = UC_TX + 2;        // staged coarse rows (one parity needs one halo row) and columns (both x parities: two halo columns)
+constexpr int UC_PV = UC_RY * UC_RX;                       // 162 staged voxels per coarse plane
+constexpr int UC_CIN = 32;                                 // input channels (two matrix-instruction K steps): the resident weight slab is sized for it
+constexpr int UC_XP = 2 * 2 * UC_PV;                       // uint4 per piece of a staged plane: [k step][k group][voxel]
+constexpr int UC_XB = 2 * UC_XP;                           // uint4 per staged plane (two pieces)
+constexpr int UC_WC = 2 * 2 * 2 * 32;                      // uint4 per tap matrix: [piece][k step][k group][cout]
+constexpr int UC_WB = 16 * UC_WC;                          // uint4 per (z parity, y parity) weight slab: 16 tap matrices (tz, ty, px, tx) = 64 KB
+
+// taps: coarse offset of tap t (0 / 1) for output parity p is t - 1 + p; the composite kernel index is u + 1 with u = f - 2 c' = [[2, 0], [1, -1]][p][t]
+__host__ __device__ inline int uc_kernel_index(int p, int t) { return p == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0); }
+
+template <bool STATS>
+__global__ void __launch_bounds__(256, 1)
+upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ btab, Tensor out,
+                      float* __restrict__ stats, int txn, int tyn, int zchunk, unsigned nblk) {
+    __shared__ uint4 xs[2 * UC_XB];
+    __shared__ uint4 ws[UC_WB];
+    __shared__ __attribute__((aligned(16))) float nrm_s[3 * UC_CIN];
+    __shared__ unsigned bound_s[4];
+    __shared__ float red[4 * 32 * 3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Dl = low.D, Hl = low.H, Wl = low.W, Cout = out.C;
+    const int D = out.D, H = out.H, W = out.W;                 // == 2 Dl, 2 Hl, 2 Wl (the launcher checks)
+    const long long HWl = (long long)Hl * Wl, DHWl = (long long)Dl * HWl, HW = (long long)H * W, DHW = (long long)D * HW;
+
+    // 1-D launch over (sample, block, cout group); block = (parity pair, z chunk, tile)
+    const unsigned ncg = (unsigned)(Cout / 32);
+    unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int cg = (int)(lid % ncg);
+    lid /= ncg;
+    const unsigned b = lid % nblk;
+    const int n = (int)(lid / nblk);
+    const int tile = (int)(b % (unsigned)(txn * tyn));
+    const int rest_ = (int)(b / (unsigned)(txn * tyn));
+    const int par = rest_ & 3, chunk = rest_ >> 2;
+    const int pz = par >> 1, py = par & 1;
+    const int cx0 = (tile % txn) * UC_TX, cy0 = (tile / txn) * UC_TY;
+    const int cz_s = chunk * zchunk, cz_e = min(cz_s + zchunk, Dl);
+
+    // ---- records of the input channels -> LDS, the sample's input scale 2^e_in from their bounds (conv3d_h2.h)
+    unsigned mb = 0u;
+    if (tid < UC_CIN) {
+        const float4 a = load_nrm(low, n, tid);
+        nrm_s[3 * tid] = a.x; nrm_s[3 * tid + 1] = a.y; nrm_s[3 * tid + 2] = a.z;
+        const unsigned bb = abs_bits(a.w);
+        mb = low.nrm == nullptr ? abs_bits(1.0f) : (bb == 0u ? 0x7fc00000u : bb);      // no bound given counts as non-finite
+    }
+    mb = wave_umax(mb);
+    if (lane == 0) bound_s[wave] = mb;
+    // the parity pair's weight slab: resident for the whole march
+    {
+        const uint4* wsrc = wp + ((long long)(cg * 4 + par)) * UC_WB;
+        for (int i = tid; i < UC_WB; i += 256) ws[i] = wsrc[i];
+    }
+    for (int i = tid; i < 2 * UC_XB; i += 256) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    int e_in = 0;
+    bool poisoned = false;
+    {
+        const unsigned m4 = max(max(bound_s[0], bound_s[1]), max(bound_s[2], bound_s[3]));
+        poisoned = m4 >= 0x7f800000u;
+        e_in = (poisoned || low.nrm == nullptr) ? 0 : min(max(15 - ((int)(m4 >> 23) - 126), -100), 100);
+        const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
+        if (tid < UC_CIN) { nrm_s[3 * tid] *= p_; nrm_s[3 * tid + 1] *= p_; }
+    }
+    __syncthreads();
+    float inv_a, inv_b;
+    {
+        const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;
+        const int t1_ = t_ / 2, t2_ = t_ - t1_;
+        inv_a = poisoned ? __uint_as_float(0x7fc00000u) : __uint_as_float((unsigned)(t1_ + 127) << 23);
+        inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
+    }
+
+    // ---- staging tasks of this thread: (staged voxel, channel quad) -> 4 loads, activate + scale + split, 8 bytes of the high plane and 8 of the low one
+    constexpr int NTASK = UC_PV * (UC_CIN / 4);               // 1296
+    constexpr int NSLOT = (NTASK + 255) / 256;                // 6
+    const float* src = low.data + (long long)n * low.n_stride;
+    auto stage_plane = [&](int z, int bufi) {
+        uint4* xb = xs + bufi * UC_XB;
+        u32x2* xh = reinterpret_cast<u32x2*>(xb);
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const int t = tid + 256 * s;
+            if (t < NTASK) {
+                const int q = t / UC_PV, v = t - q * UC_PV;          // channel quad, staged voxel
+                const int ly = v / UC_RX, lx = v - ly * UC_RX;
+                const int gy = cy0 - (1 - py) + ly, gx = cx0 - 1 + lx;
+                const bool ok = z >= 0 && z < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+                _Float16 h_[4], l_[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 4 * q + i;
+                    float y = 0.0f;
+                    if (ok) {
+                        y = src[(long long)c * DHWl + (long long)z * HWl + (long long)gy * Wl + gx];
+                        y = act(y, nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]);
+                    }
+                    h2_split(y, h_[i], l_[i]);
+                }
+                // cell [k step = q >> 2][k group = (q >> 1) & 1][voxel] holds 8 channels = two 8-byte halves (q & 1)
+                const int cell = (((q >> 2) * 2 + ((q >> 1) & 1)) * UC_PV + v) * 2 + (q & 1);
+                const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
+                xh[cell] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                xh[cell + 2 * UC_XP] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+            }
+        }
+    };
+
+    // ---- operands of this lane: A = coarse voxel (row 2 wave + (r >> 4), column r & 15), B = cout r; k group = lane >> 5
+    const int r32 = lane & 31, kg = lane >> 5;
+    const int abase = kg * UC_PV + (2 * wave + (r32 >> 4)) * UC_RX + (r32 & 15);
+    const int bbase = kg * 32 + r32;
+
+    // ---- epilogue geometry: lane = cout; register i of an accumulator = coarse row i >> 3, columns ((i >> 2) & 1) * 8 + kg * 4 + (i & 3)
+    const int co = cg * 32 + r32;
+    const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * 32) * DHW, 0, (int)(32 * DHW * 4), 0x00020000);
+    constexpr unsigned UC_DROP = 0x80000000u;
+    unsigned ooff[4];                  // (coarse row r_, column group g_): byte offset of its 8 fine columns inside an output plane of this cout, or UC_DROP
+    int fyv[2];
+    bool okg[4];
+#pragma unroll
+    for (int r_ = 0; r_ < 2; ++r_) fyv[r_] = 2 * (cy0 + 2 * wave + r_) + py;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r_ = j >> 1, g_ = j & 1;
+        const int ccol = cx0 + g_ * 8 + kg * 4;
+        okg[j] = cy0 + 2 * wave + r_ < Hl && ccol < Wl;       // Wl % 4 == 0: a group of four coarse columns is inside or outside as a whole
+        ooff[j] = okg[j] ? 4u * (unsigned)((long long)r32 * DHW + (long long)fyv[r_] * W + 2 * ccol) : UC_DROP;
+    }
+    Stat run;
+    run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
+    const float* bt = btab + co;       // bias table [27][Cout]: class (first / interior / last) per axis
+
+    for (int c = cz_s; c < cz_e; ++c) {
+        const int za = c - 1 + pz, zb = c + pz;               // the two coarse planes of fine plane 2 c + pz
+        __syncthreads();                                      // the previous plane's operand reads are done
+        if (c == cz_s) stage_plane(za, za & 1);
+        stage_plane(zb, zb & 1);
+        __syncthreads();
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+#pragma unroll
+        for (int tz = 0; tz < 2; ++tz) {
+            const int z = tz == 0 ? za : zb;
+            if (z < 0 || z >= Dl) continue;                   // zero padding: nothing to add (wave-uniform)
+            const uint4* xb = xs + (z & 1) * UC_XB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ty = 0; ty < 2; ++ty) {
+                    uint4 ah[3], al[3];
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const uint4* ap = xb + ks * (2 * UC_PV) + abase + ty * UC_RX + o;
+                        ah[o] = ap[0];
+                        al[o] = ap[UC_XP];
+                    }
+#pragma unroll
+                    for (int px = 0; px < 2; ++px)
+#pragma unroll
+                        for (int tx = 0; tx < 2; ++tx) {
+                            const uint4* bp = ws + (((tz * 2 + ty) * 2 + px) * 2 + tx) * UC_WC + ks * 64 + bbase;
+                            const uint4 bh = bp[0], bl = bp[128];
+                            const int o = tx + px;
+                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[o]), __builtin_bit_cast(f16x8, bh), acc[px], 0, 0, 0);
+                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[o]), __builtin_bit_cast(f16x8, bh), acc[px], 0, 0, 0);
+                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[o]), __builtin_bit_cast(f16x8, bl), acc[px], 0, 0, 0);
+                        }
+                }
+        }
+
+        // ---- epilogue of fine plane fz: scale back, bias table, add to the convolution's x_e half in place, statistics of the sum
+        const int fz = 2 * c + pz;
+        const int clz = fz == 0 ? 0 : (fz == D - 1 ? 2 : 1);
+        const unsigned so_ = (unsigned)fz * (unsigned)(HW * 4);
+        float psum = 0.0f, pcnt = 0.0f;
+        f32x4 o_[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r_ = j >> 1, g_ = j & 1;
+            const int cly = fyv[r_] == 0 ? 0 : (fyv[r_] == H - 1 ? 2 : 1);
+            const float* brow = bt + (long long)((clz * 3 + cly) * 3) * Cout;
+            const float bmid = brow[Cout];
+            const int fx0 = 2 * (cx0 + g_ * 8 + kg * 4);      // first of this group's 8 fine columns
+            const float bfirst = fx0 == 0 ? brow[0] : bmid, blast = fx0 + 8 == W ? brow[2 * Cout] : bmid;
+            const int bi = r_ * 8 + g_ * 4;
+            const f32x4 prev0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_, 0, 0));
+            const f32x4 prev1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_ + 16u, 0, 0));
+            f32x4 v0 = {acc[0][bi], acc[1][bi], acc[0][bi + 1], acc[1][bi + 1]};
+            f32x4 v1 = {acc[0][bi + 2], acc[1][bi + 2], acc[0][bi + 3], acc[1][bi + 3]};
+            const f32x4 b0 = {bfirst, bmid, bmid, bmid}, b1 = {bmid, bmid, bmid, blast};
+            v0 = (v0 * inv_a * inv_b + b0) + prev0;
+            v1 = (v1 * inv_a * inv_b + b1) + prev1;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), orsrc, ooff[j] + so_, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), orsrc, ooff[j] + so_ + 16u, 0, 0);
+            o_[2 * j] = v0; o_[2 * j + 1] = v1;
+            if (STATS) {
+                const float w_ = okg[j] ? 1.0f : 0.0f;
+                pcnt += 8.0f * w_;
+                psum += (((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) * w_;
+            }
+        }
+        if (STATS) {
+            const float pmean = pcnt > 0.0f ? psum / (pcnt > 0.0f ? pcnt : 1.0f) : 0.0f;
+            float pm2 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 d0 = o_[2 * j] - pmean, d1 = o_[2 * j + 1] - pmean;
+                const f32x4 q0 = d0 * d0, q1 = d1 * d1;
+                pm2 += (((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]))) * (okg[j] ? 1.0f : 0.0f);
+            }
+            Stat loc;
+            loc.n = pcnt; loc.mean = pmean; loc.m2 = pm2;
+            run = stat_merge_nb(run, loc);
+        }
+    }
+
+    if (STATS) {
+        {
+            Stat ot;
+            ot.n = __shfl_xor(run.n, 32);
+            ot.mean = __shfl_xor(run.mean, 32);
+            ot.m2 = __shfl_xor(run.m2, 32);
+            run = kg == 0 ? stat_merge(run, ot) : stat_merge(ot, run);
+        }
+        if (kg == 0) { red[(wave * 32 + r32) * 3] = run.n; red[(wave * 32 + r32) * 3 + 1] = run.mean; red[(wave * 32 + r32) * 3 + 2] = run.m2; }
+        __syncthreads();
+        if (tid < 32) {
+            Stat st;
+            st.n = 0.0f; st.mean = 0.0f; st.m2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                Stat ot;
+                ot.n = red[(w * 32 + tid) * 3]; ot.mean = red[(w * 32 + tid) * 3 + 1]; ot.m2 = red[(w * 32 + tid) * 3 + 2];
+                st = stat_merge(st, ot);
+            }
+            float* rec = stats + (((long long)n * Cout + cg * 32 + tid) * nblk + b) * 3;
+            rec[0] = st.n; rec[1] = st.mean; rec[2] = st.m2;
+        }
+    }
+}
+
+// Composite weights w4 [Cin][Cout][4][4][4] (fp32, formed on the host from the two layers' parameters) -> per (cout group, z parity, y parity) slab of 16 tap matrices
+// (tz, ty, px, tx), each [piece][k step][k group][32 couts][8 channels] fp16, scaled by tail[1] (conv3d_k3_h2_scale_kernel).  One thread per (ci, co).
+__global__ void __launch_bounds__(256)
+upconv_k4s2_pack_kernel(const float* __restrict__ w4, int Cin, int Cout, _Float16* __restrict__ packed, const float* __restrict__ tail) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= Cin * Cout) return;
+    const int ci = idx % Cin, co = idx / Cin;
+    const float s = tail[1];
+    const float* w = w4 + ((long long)ci * Cout + co) * 64;
+    const int cg = co / 32, col = co % 32, ks = ci / 16, kgi = (ci % 16) / 8, j = ci % 8;
+    for (int par = 0; par < 4; ++par)
+        for (int combo = 0; combo < 16; ++combo) {
+            const int tz = combo >> 3, ty = (combo >> 2) & 1, px = (combo >> 1) & 1, tx = combo & 1;
+            const int uz = uc_kernel_index(par >> 1, tz), uy = uc_kernel_index(par & 1, ty), ux = uc_kernel_index(px, tx);
+            _Float16 pc[2];
+            h2_split(w[(uz * 4 + uy) * 4 + ux] * s, pc[0], pc[1]);
+            _Float16* slab = packed + ((long long)((cg * 4 + par) * 16 + combo)) * (UC_WC * 8LL);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) slab[(((p * 2 + ks) * 2 + kgi) * 32 + col) * 8 + j] = pc[p];
+        }
+}
+
+}  // namespace mh

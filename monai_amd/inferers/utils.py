@@ -84,8 +84,8 @@ def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world
     windows per launch fill the 256 CUs at the deep U-Net levels, and a power-of-two count keeps the workgroup grids of
     the large layers whole multiples of the CU count -- measured on the BASELINE workload (profiles/): 25 windows per
     launch 1.85 s, 32: 1.75 s, 64: 1.73 s, 128: 1.72 s.  Default 64 on one GPU.  When the windows are sharded over `world`
-    GPUs a round is world x nb windows and the last round is padded to a whole one: nb is the value in [32, 64] that pads the
-    fewest windows (1000 windows: 2 or 4 GPUs 50 -> none padded, 8 GPUs 63 -> 8 padded; 64 would pad 24), ties to the larger.
+    GPUs the rounds follow parallel.WindowShard.schedule (main rounds of world x nb windows, shorter tail rounds): nb is the value in [32, 64] that
+    gives the busiest rank the fewest windows, ties to the larger.
     `num_win` is the TOTAL number of windows.  Override with MONAI_AMD_SW_BATCH; MONAI_AMD_STRICT_SW_BATCH=1 keeps the user's value."""
     if not hasattr(predictor, "forward_into") or os.environ.get("MONAI_AMD_STRICT_SW_BATCH") == "1":
         return max(1, int(sw_batch_size))
@@ -103,12 +103,14 @@ def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world
     cap = max(cap, int(sw_batch_size)) if cap >= sw_batch_size else cap
     cap = max(1, min(cap, per_rank))
     if world > 1 and cap > 1:
-        best, best_pad = cap, None
+        # the busiest rank (rank 0: a full slot in every round of parallel.WindowShard.schedule) sets the step time: the nb in [cap / 2, cap] that gives it the fewest
+        # windows, a launch counted as at least 7 windows (below that the large layers no longer fill 256 CUs), ties to the larger nb
+        probe = parallel.partition(num_win, world, 0)
+        best, best_cost = cap, None
         for nb in range(cap, max(cap // 2, 1) - 1, -1):
-            span = world * nb
-            pad = -(-num_win // span) * span - num_win
-            if best_pad is None or pad < best_pad:
-                best, best_pad = nb, pad
+            cost = sum(max(n, min(7, nb)) for _, n in probe.schedule(nb))
+            if best_cost is None or cost < best_cost:
+                best, best_cost = nb, cost
         cap = best
     return cap
 
@@ -295,10 +297,6 @@ def sliding_window_inference(
     zscales = None
 
     fused = fused and hasattr(predictor, "out_channels") and getattr(predictor, "window_sized_output", True)
-    # window batches on alternating HIP streams (config.SW_STREAMS): batch q + 1's memory-bound passes (pooling, transposed convolutions, the 1x1 into the logits)
-    # run next to batch q's matrix-bound convolutions instead of in front of them.  Every stream owns its window buffer and its own set of the predictor's
-    # activation buffers (`slot`); the windows' logits go to disjoint rows, so the result bits do not depend on the interleaving.
-    lanes = _StreamLanes(dev, predictor, fused and shard.world == 1 and not buffered, len(my_rounds), win_buf)
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
         steps = list(enumerate(my_rounds))
@@ -317,13 +315,12 @@ def sliding_window_inference(
                     seg_shapes, zscales = [tuple(roi_size)], [None]
                     mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
                     logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
-                with lanes.lane(q) as (wbuf, slot_kw):
-                    ops.window_extract(vol3, grid3, w0, n, roi3, wbuf[:n])
-                    with _prof.span("sw_predictor"):
-                        if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
-                            predictor.forward_into_windows(wbuf[:n], mosaic, w0, **slot_kw)
-                        else:
-                            predictor.forward_into(wbuf[:n], logits[0][w0 : w0 + n], **slot_kw)
+                ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
+                with _prof.span("sw_predictor"):
+                    if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
+                        predictor.forward_into_windows(win_buf[:n], mosaic, w0)
+                    else:
+                        predictor.forward_into(win_buf[:n], logits[0][w0 : w0 + n])
             elif n > 0:
                 ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
                 win_data = win_buf[:n].reshape((n, in_ch) + tuple(roi_size))
@@ -380,7 +377,6 @@ def sliding_window_inference(
 
         if logits is None:
             raise RuntimeError("monai_amd: no windows were processed")
-        lanes.join()          # the blend (on the caller's stream) reads what the side streams wrote
         with _prof.span("sw_gather_wait"):         # what the compute stream still has to wait for after its last round
             for work in pending:
                 work.wait()
@@ -440,73 +436,6 @@ def sliding_window_inference(
     if any(pad_size):
         kwargs.update({"pad_size": pad_size})
     return _pack_struct(finals, dict_keys)
-
-
-class _StreamLanes:
-    """Window batches of the fused path dealt out over `config.SW_STREAMS` HIP streams (one GPU, a predictor with per-slot activation buffers: `plan_slots`).
-    Lane 0 is the caller's stream; batch 0 always runs there alone (it packs the weights every lane reads), the others alternate.  A side stream starts behind
-    everything the caller's stream had enqueued when it was forked (the volume, batch 0) and is joined before the blend."""
-
-    def __init__(self, dev, predictor, eligible: bool, num_batches: int, win_buf: torch.Tensor):
-        from .. import config
-
-        want = config.sw_streams()
-        slots = int(getattr(predictor, "plan_slots", 1))
-        self.n = max(1, min(want, slots)) if (eligible and dev.type == "cuda" and num_batches > 2) else 1
-        self.bufs = [win_buf] + [torch.empty_like(win_buf) for _ in range(self.n - 1)]
-        self.streams = None
-        self.dev = dev
-        self.forked = False
-
-    def lane(self, q: int):
-        import contextlib
-
-        if self.n == 1:
-            return contextlib.nullcontext((self.bufs[0], {}))
-        if self.streams is None:
-            self.streams = [torch.cuda.current_stream(self.dev)] + [_side_stream(self.dev, i) for i in range(1, self.n)]
-        i = 0 if q == 0 else q % self.n
-        if q > 0 and not self.forked:          # fork: the side streams start behind batch 0
-            ev = torch.cuda.Event()
-            ev.record(self.streams[0])
-            for st in self.streams[1:]:
-                st.wait_event(ev)
-            self.forked = True
-        return self._on(i)
-
-    def _on(self, i: int):
-        import contextlib
-
-        @contextlib.contextmanager
-        def ctx():
-            if i == 0:
-                yield self.bufs[0], {"slot": 0}
-            else:
-                with torch.cuda.stream(self.streams[i]):
-                    yield self.bufs[i], {"slot": i}
-
-        return ctx()
-
-    def join(self) -> None:
-        if self.n > 1 and self.forked:
-            for st in self.streams[1:]:
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self.streams[0].wait_event(ev)
-            self.forked = False
-
-
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(dev, i: int):
-    """side streams are created once per (device, lane) and reused: creating a HIP stream per call costs more than a window batch of a small volume"""
-    key = (str(dev), i)
-    with _MAPS_LOCK:
-        st = _SIDE_STREAMS.get(key)
-        if st is None:
-            st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return st
 
 
 # ---- importance maps: host evaluation and upload happen once per (patch size, mode, sigma, dtype), not once per call -------------------------

@@ -238,15 +238,12 @@ class BasicUNet(nn.Module):
         out = torch.empty((x.shape[0], self.out_channels) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
         return self.forward_into(x, out)
 
-    plan_slots = 4      # independent sets of activation buffers (`slot`): concurrent forwards on different HIP streams (inferers/utils.py:_StreamLanes)
-
     @torch.no_grad()
-    def forward_into(self, x: torch.Tensor, out: torch.Tensor, slot: int = 0) -> torch.Tensor:
-        """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer).  `slot`: which of the `plan_slots` buffer sets to run in --
-        two forwards may be in flight at once (on different streams) only in different slots."""
+    def forward_into(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """Forward writing the logits into `out` (e.g. a slice of the inferer's all-window logits buffer)."""
         _lib.require_device(x, out[0].flat if isinstance(out, tuple) else out)
         if self.spatial_dims == 2 and x.dim() == 4 and not isinstance(out, tuple) and out.dim() == 4:
-            self.forward_into(x.unsqueeze(2), out.unsqueeze(2), slot)          # one plane of the 3-D engine (views: no copy)
+            self.forward_into(x.unsqueeze(2), out.unsqueeze(2))          # one plane of the 3-D engine (views: no copy)
             return out
         if self.training:
             raise NotImplementedError("monai_amd.BasicUNet: training mode (autograd) is not on the HIP path -- the engine is inference-only; with MONAI installed the call falls through to the reference module, which shares these parameters")
@@ -256,10 +253,10 @@ class BasicUNet(nn.Module):
             raise RuntimeError(f"monai_amd.BasicUNet: a 2-D network takes one plane, got {tuple(x.shape)}")
         if min((h, w) if self.spatial_dims == 2 else (d, h, w)) < 16:
             raise RuntimeError(f"monai_amd.BasicUNet: window {d}x{h}x{w} is too small for four 2x poolings")
-        key = (n, d, h, w, str(x.device), int(slot))
+        key = (n, d, h, w, str(x.device))
         plan = self._plans.get(key)
         if plan is None:
-            if len(self._plans) >= 4 * self.plan_slots:
+            if len(self._plans) >= 4:
                 self._plans.clear()
             plan = self._plans[key] = _Plan(self, n, (d, h, w), x.device)
         plan.run(self, x, out)
@@ -267,10 +264,10 @@ class BasicUNet(nn.Module):
 
 
     @torch.no_grad()
-    def forward_into_windows(self, x: torch.Tensor, mosaic, w0: int, slot: int = 0) -> None:
+    def forward_into_windows(self, x: torch.Tensor, mosaic, w0: int) -> None:
         """Forward of a batch of sliding-window windows whose logits go straight into the inferer's mosaic logits layout (ops.LogitsMosaic): batch
         element i is window w0 + i; the final 1x1 convolution writes each window to its strided place (mh_conv1x1_windows_f32)."""
-        self.forward_into(x, (mosaic, int(w0)), slot)
+        self.forward_into(x, (mosaic, int(w0)))
 
 
 BasicUnet = Basicunet = basicunet = BasicUNet
@@ -387,6 +384,47 @@ class _Plan:
         hi = ops.affine_resample(low.reshape(n * c, d, h, w), m, osz, "bilinear", "border", False, False)
         dst.copy_(hi.reshape((n, c) + osz))
 
+    def _fusable(self, net, l: int, src: torch.Tensor, cout: int) -> bool:
+        """UpCat level l without its up-sampled intermediate (csrc/kernels/upconv_h2.h): a k2 s2 transposed convolution feeding an instance- / group-normalised
+        convolution at exactly twice the extents, shapes the composite kernel takes, the split-precision family allowed"""
+        from ... import config
+
+        if self.interp or self.planar or self.odd[l] or self.batchnorm or not net.fused_stats or not config.upcat_fused():
+            return False
+        if config.conv_algo() not in (config.CONV_ALGOS["auto"], config.CONV_ALGOS["h2"]):
+            return False
+        return ops.upconv_k4s2_accepts(int(src.shape[1]), int(cout), *self.sp[l + 1])
+
+    def _upcat_fused(self, net, l: int, upc: "_UpCat", src, src_nrm, out, out_nrm) -> None:
+        """conv_0(cat([x_e, deconv(x)])) = conv_0[:, :f_l](x_e) + [conv_0[:, f_l:] o deconv](x): the skip half on the 3x3x3 kernel (raw, bias included, no
+        statistics), then the composite transposed convolution k4 s2 p1 of the LOW-resolution tensor added in place together with the statistics of the sum.
+        Reference: UpCat.forward, monai/networks/nets/basic_unet.py:160-178."""
+        f = net.features
+        block, name = upc.convs.conv_0, f"upcat_{l + 1}.convs.conv_0"
+        conv, dec = block.conv, upc.upsample.deconv
+        n, cout, d, h, w = out.shape
+        skip, skip_nrm = self.cat[l][:, : f[l]], self.cat_nrm[l][:, : f[l]]
+        parts = [conv.weight, dec.weight] + ([dec.bias] if dec.bias is not None else [])
+        key = tuple((p_.data_ptr(), p_._version) for p_ in parts) + (str(conv.weight.device),)
+        cfg = ops.conv3d_k3_select(f[l], cout, d, h, w, bounded=True)
+        hit = net._packed.get(("upcat", name, cfg))
+        if hit is None or hit[0] != key:
+            w4, table = ops.upconv_k4s2_weights(dec.weight, dec.bias, conv.weight[:, f[l]:])
+            hit = (key, ops.conv3d_k3_pack(cfg, conv.weight[:, : f[l]].contiguous()), ops.upconv_k4s2_pack(w4), table)
+            net._packed[("upcat", name, cfg)] = hit
+        _, packed_skip, packed_up, table = hit
+        with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
+            ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, None)
+        tiles = ops.upconv_k4s2_stat_tiles(*self.sp[l + 1])
+        stats = self._stats_buf(n * cout * tiles * 3)
+        with _prof.span("upconv_k4s2", 2.0 * 8 * int(src.shape[1]) * cout * d * h * w * n):
+            ops.upconv_k4s2_accum(src, src_nrm, packed_up, table, out, stats)
+        norm = block.adn.N
+        if isinstance(norm, nn.GroupNorm):
+            ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+        else:
+            ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+
     def run(self, net: "BasicUNet", x: torch.Tensor, logits: torch.Tensor) -> None:
         f = net.features
         downs = [None, net.down_1, net.down_2, net.down_3, net.down_4]
@@ -411,19 +449,22 @@ class _Plan:
         src, src_nrm = self.x4, self.x4_nrm
         for l in range(3, -1, -1):
             upc = ups[l]
-            dst = self.up_scratch[l] if self.odd[l] else self.cat[l][:, f[l]:]
-            dst_nrm = ops.nrm_identity(self.up_scratch_nrm[l] if self.odd[l] else self.cat_nrm[l][:, f[l]:])
-            if self.interp:
-                self._interpolate(upc.upsample, src, src_nrm, self.low[l], dst)
-            elif self.planar:     # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
-                ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
-            else:
-                ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm)
-            if self.odd[l]:
-                ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
             co = self.dec_out[l]
             t, tn = self.tmp[l][:, :co], self.tmp_nrm[l][:, :co]
-            self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)
+            if self._fusable(net, l, src, co):
+                self._upcat_fused(net, l, upc, src, src_nrm, t, tn)
+            else:
+                dst = self.up_scratch[l] if self.odd[l] else self.cat[l][:, f[l]:]
+                dst_nrm = ops.nrm_identity(self.up_scratch_nrm[l] if self.odd[l] else self.cat_nrm[l][:, f[l]:])
+                if self.interp:
+                    self._interpolate(upc.upsample, src, src_nrm, self.low[l], dst)
+                elif self.planar:     # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
+                    ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
+                else:
+                    ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm)
+                if self.odd[l]:
+                    ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
+                self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)
             self._conv(net, f"upcat_{l + 1}.convs.conv_1", upc.convs.conv_1, t, tn, self.u[l], self.u_nrm[l])
             src, src_nrm = self.u[l], self.u_nrm[l]
 

@@ -398,6 +398,64 @@ def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None):
     return out
 
 
+def upconv_k4s2_accepts(cin: int, cout: int, dl: int, hl: int, wl: int) -> bool:
+    """can `upconv_k4s2_accum` serve a deconvolution input of `cin` channels and extents (dl, hl, wl) feeding a convolution with `cout` outputs?"""
+    return bool(_lib.lib().query("mh_upconv_k4s2_accepts", int(cin), int(cout), int(dl), int(hl), int(wl)))
+
+
+def upconv_k4s2_weights(deconv_w: torch.Tensor, deconv_b: Optional[torch.Tensor], conv_w_up: torch.Tensor):
+    """UpCat's `conv3(cat([x_e, deconv2(x)]))`: the composite of the two layers acting on x (kernels/upconv_h2.h).
+    deconv_w [Cin][Cup][2][2][2], deconv_b [Cup] or None, conv_w_up [Cout][Cup][3][3][3] (the convolution's weights for the up channels)
+    -> (w4 [Cin][Cout][4][4][4], bias_table [27][Cout]), fp32 on the parameters' device; per axis W4[u + 1] = sum over (d, k) with d - k + 1 == u of Wd[d] x Wc[k],
+    the table entry of position class (cz, cy, cx) in {first, interior, last}^3 = sum_cup b[cup] x sum of the taps of Wc that stay inside the volume there."""
+    wd, wc = deconv_w.detach().float(), conv_w_up.detach().float()
+    cin, cout = wd.shape[0], wc.shape[0]
+    pairs = {-1: ((0, 2),), 0: ((0, 1), (1, 2)), 1: ((0, 0), (1, 1)), 2: ((1, 0),)}
+    w4 = torch.zeros((cin, cout, 4, 4, 4), dtype=torch.float32, device=wd.device)
+    for uz, pz_ in pairs.items():
+        for uy, py_ in pairs.items():
+            for ux, px_ in pairs.items():
+                acc = None
+                for dz, kz in pz_:
+                    for dy, ky in py_:
+                        for dx, kx in px_:
+                            t = wd[:, :, dz, dy, dx] @ wc[:, :, kz, ky, kx].t()          # [Cin, Cup] x [Cup, Cout]
+                            acc = t if acc is None else acc + t
+                w4[:, :, uz + 1, uy + 1, ux + 1] = acc
+    inside = ((1, 2), (0, 1, 2), (0, 1))                  # the convolution's taps that stay inside at the first / an interior / the last position of an axis
+    table = torch.zeros((27, cout), dtype=torch.float32, device=wd.device)
+    if deconv_b is not None:
+        bd = deconv_b.detach().float()
+        for cz in range(3):
+            for cy in range(3):
+                for cx in range(3):
+                    wsum = wc[:, :, list(inside[cz])][:, :, :, list(inside[cy])][:, :, :, :, list(inside[cx])].sum(dim=(2, 3, 4))      # [Cout, Cup]
+                    table[(cz * 3 + cy) * 3 + cx] = wsum @ bd
+    return w4.contiguous(), table.contiguous()
+
+
+def upconv_k4s2_pack(w4: torch.Tensor) -> torch.Tensor:
+    """composite weights [Cin][Cout][4][4][4] -> the kernel's split-precision tap matrices (once per parameter version)"""
+    _lib.require_device(w4)
+    cin, cout = int(w4.shape[0]), int(w4.shape[1])
+    packed = torch.zeros(_lib.lib().query("mh_upconv_k4s2_packed_floats", cin, cout), dtype=torch.float32, device=w4.device)
+    _lib.lib().call("mh_upconv_k4s2_pack_f32", _lib.ptr(w4.contiguous()), cin, cout, _lib.ptr(packed), _s(w4))
+    return packed
+
+
+def upconv_k4s2_stat_tiles(dl: int, hl: int, wl: int) -> int:
+    return _lib.lib().query("mh_upconv_k4s2_stat_tiles", int(dl), int(hl), int(wl))
+
+
+def upconv_k4s2_accum(low, low_nrm, packed, bias_table, out, stats=None):
+    """out += convT(k4, s2, p1)(act(low)) + bias_table[position class]  in place (`out`: the raw skip half of the convolution); with `stats`
+    ([N * Cout * upconv_k4s2_stat_tiles(*low.shape[2:]) * 3] floats) the InstanceNorm statistics of the sum"""
+    _lib.require_device(low, low_nrm, packed, bias_table, out, stats)
+    xi, xo = _lib.tensor5(low, low_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_upconv_k4s2_accum_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias_table), C.byref(xo), _lib.ptr(stats), _s(out))
+    return out
+
+
 def conv1x1_stat_tiles(d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv1x1_stat_tiles", d, h, w)
 

@@ -1,10 +1,11 @@
 """Window sharding across the GPUs of one node.
 
 The sliding-window path shards naturally: windows are independent until the blend.  With sharding enabled the window
-index space is cut into ROUNDS of ``world x nb`` consecutive windows (nb = windows per predictor launch); in round q
+index space is cut into ROUNDS of ``world x n`` consecutive windows (n = nb, the windows per predictor launch, in the main rounds;
+about nb / 4 in the tail rounds at the end -- ``WindowShard.schedule``); in a round starting at row ``base``
 rank r (one process per GPU, ``torch.distributed`` backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests) runs the
-predictor on windows ``[q*world*nb + r*nb, +nb)`` and writes their logits straight into its slice of the full
-``[rounds*world*nb, K, roi]`` buffer; one ``all_gather_into_tensor`` per round -- issued asynchronously, so it
+predictor on windows ``[base + r*n, +n)`` and writes their logits straight into its slice of the full
+``[rows, K, roi]`` buffer (row == window index); one ``all_gather_into_tensor`` per round -- issued asynchronously, so it
 travels over xGMI while the next round computes -- completes that round's rows on every rank.  After the last round
 every rank holds every window's logits and the deterministic gather blend runs unchanged: the result is identical to
 the single-GPU result on every rank (the blend never depended on who computed a window).  The reference has no
@@ -133,21 +134,48 @@ class WindowShard:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return int(t.item())
 
-    def rounds(self, nb: int):
-        """(first global window, number of real windows) of this rank in each round; windows beyond num_win are padding."""
+    def schedule(self, nb: int) -> list:
+        """[(first row, windows per rank)] of every round: the window index space [0, num_win) is cut into MAIN rounds of `world * nb` consecutive windows and, at its end,
+        TAIL rounds of `world * tail` windows (tail ~ nb / 4).  In a round starting at row `base` rank r owns rows [base + r * n, base + (r + 1) * n); rows beyond
+        num_win are padding (nobody computes them).  Why a tail: a round's all-gather travels while the NEXT round computes, so what the last round sends is exposed in
+        front of the blend -- with 8 GPUs and 63 windows per launch that is 504 windows = 7.8 GB per rank (~23 ms over xGMI against ~107 ms of compute per rank);
+        five tail rounds of 13 windows per rank leave 1.6 GB (~5 ms) exposed and cost the deep U-Net levels a few per cent of fill on 1/8 of the windows.
+        A pure function of (num_win, world, nb): every rank derives the same schedule.  MONAI_AMD_TAIL_ROUNDS=0 keeps equal rounds (measurement switch)."""
+        if self.world == 1:
+            return [(w0, min(nb, self.num_win - w0)) for w0 in range(0, self.num_win, nb)]
         span = self.world * nb
+        tail = nb // 4 if (nb >= 8 and os.environ.get("MONAI_AMD_TAIL_ROUNDS") != "0") else 0
+        # the tail also has to hide the LAST MAIN round's gather behind its own compute: it keeps between half a round and one and a half (a round's rows cross xGMI in
+        # about the time 0.4 rounds of windows take to compute at 8 GPUs)
+        main = max(0, (2 * self.num_win - span) // (2 * span)) if tail else -(-self.num_win // span)
+        out = [(q * span, nb) for q in range(main)]
+        rem = self.num_win - main * span
+        if rem > 0:       # tail > 0: span / 2 <= rem < 3 span / 2 windows (fewer when the whole image is smaller) in T rounds of (nearly) equal size
+            t_rounds = -(-rem // (self.world * tail))
+            per = -(-rem // (self.world * t_rounds))
+            base = main * span
+            out += [(base + t * self.world * per, per) for t in range(t_rounds)]
+        return out
+
+    def rounds(self, nb: int):
+        """(first global window, number of real windows) of THIS rank in each round of `schedule(nb)`"""
+        if self.world == 1:
+            return self.schedule(nb)
         out = []
-        for q in range((self.num_win + span - 1) // span):
-            w0 = q * span + self.rank * nb
-            out.append((w0, max(0, min(nb, self.num_win - w0))))
+        for base, n in self.schedule(nb):
+            w0 = base + self.rank * n
+            out.append((w0, max(0, min(n, self.num_win - w0))))
         return out
 
     def padded_windows(self, nb: int) -> int:
-        span = self.world * nb
-        return (self.num_win + span - 1) // span * span if self.world > 1 else self.num_win
+        """rows of the all-window logits buffer: the windows, padded to whole rounds when sharded (row index == window index)"""
+        if self.world == 1:
+            return self.num_win
+        base, n = self.schedule(nb)[-1]
+        return base + self.world * n
 
     def gather_round(self, full: torch.Tensor, q: int, nb: int):
-        """Complete rows [q*world*nb, (q+1)*world*nb) of `full` on every rank (this rank has written its own nb rows).
+        """Complete the rows of round `q` of `schedule(nb)` on every rank (this rank has written its own slot of them).
         `full` is an inferer logits buffer (rows `stride(0)` floats apart inside one flat allocation): the round's rows are one
         contiguous span, this rank's rows are its own slot of that span, so the all-gather runs IN PLACE -- no send copy.
         Returns the async work handle (None when world == 1)."""
@@ -155,9 +183,9 @@ class WindowShard:
             return None
         from .inferers.utils import flat_rows
 
-        span = self.world * nb
-        out = flat_rows(full, q * span, (q + 1) * span)
-        mine = flat_rows(full, q * span + self.rank * nb, q * span + (self.rank + 1) * nb)
+        base, n = self.schedule(nb)[q]
+        out = flat_rows(full, base, base + self.world * n)
+        mine = flat_rows(full, base + self.rank * n, base + (self.rank + 1) * n)
         # the slot arithmetic the in-place form rests on: equal contiguous slots, this rank's rows exactly at recv + rank * count
         if out.numel() != self.world * mine.numel() or mine.data_ptr() != out.data_ptr() + self.rank * mine.numel() * mine.element_size():
             raise RuntimeError("monai_amd.parallel: the round's rows are not equal contiguous slots of the logits buffer")

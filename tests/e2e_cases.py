@@ -58,6 +58,35 @@ def case_net_single_window_vs_golden(device, second_window=True):
     return r, r2
 
 
+def case_net_upcat_fused_vs_two_layers(device):
+    """BasicUNet's top decoder level (a 32-channel k2 s2 transposed convolution feeding conv3) as the composite transposed convolution of the low-resolution tensor
+    (csrc/kernels/upconv_h2.h, config.UPCAT_FUSED): against the REAL reference's golden logits (net5.npz: the same 1e-4 bar as the two-layer path) and against
+    the two-layer evaluation of this engine (a few 1e-6: one more fp32 rounding per composite weight, another summation order)."""
+    from monai_amd import config
+
+    g = np.load(os.path.join(GOLDEN, "net5.npz"))
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(21)
+    x = torch.rand(2, 1, 32, 32, 32).to(device)
+    saved, saved_algo = config.UPCAT_FUSED, config.CONV_ALGO
+    try:
+        config.CONV_ALGO = "auto"               # the composite kernel belongs to the split-precision family: not taken under "fp32"
+        config.UPCAT_FUSED = False
+        two = net(x).cpu()
+        config.UPCAT_FUSED = True
+        assert net._plans and next(iter(net._plans.values()))._fusable(net, 0, torch.empty(1, 32, 1, 1, 1), 32)
+        fused = net(x).cpu()
+        config.CONV_ALGO = "fp32"
+        assert not next(iter(net._plans.values()))._fusable(net, 0, torch.empty(1, 32, 1, 1, 1), 32)
+    finally:
+        config.UPCAT_FUSED, config.CONV_ALGO = saved, saved_algo
+    r = report(fused, torch.from_numpy(g["net5_win32_out"]))
+    assert r["max_abs"] < LOGIT_TOL, r
+    d = (fused - two).abs().max().item()
+    assert 0.0 < d < 2e-5, d
+    return r, d
+
+
 def case_net_odd_window_vs_golden(device):
     """Window extents that are odd at levels 1, 2 and 3: UpCat's replicate padding (basic_unet.py:163-170) vs the reference."""
     g = np.load(os.path.join(GOLDEN, "net5_odd.npz"))

@@ -208,6 +208,46 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
     return cfg
 
 
+def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=True, tol=2e-5):
+    """UpCat's up half as ONE composite transposed convolution (csrc/kernels/upconv_h2.h): out += convT(k4, s2, p1)(act(low)) + bias table, against the two-layer
+    evaluation conv3(deconv2(act(low)) + b_d) in float64 -- ragged tiles, both parities of every axis, the volume's borders (bias classes), several cout groups,
+    two z-chunks -- and the statistics of the sum through the finalize kernel"""
+    cin = 32
+    gen = torch.Generator().manual_seed(300 + cup + cout + ldims[0] + ldims[2])
+    dims = tuple(2 * v for v in ldims)
+    low = torch.randn((n, cin) + tuple(ldims), generator=gen)
+    nrm = _with_bounds(low, _rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(ldims))))
+    wd = torch.randn((cin, cup, 2, 2, 2), generator=gen) / np.sqrt(float(cin))
+    bd = torch.randn(cup, generator=gen) * 0.3 if with_bias else None
+    wc = torch.randn((cout, cup, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cup)
+    ya = torch.randn((n, cout) + dims, generator=gen)                     # what the convolution's skip half left in `out`
+    up = F.conv_transpose3d(_act(low.double(), nrm.double()), wd.double(), None if bd is None else bd.double(), stride=2)
+    exp = ya.double() + F.conv3d(up, wc.double(), None, padding=1)
+
+    assert ops.upconv_k4s2_accepts(cin, cout, *ldims)
+    w4, table = ops.upconv_k4s2_weights(wd.to(device), None if bd is None else bd.to(device), wc.to(device))
+    packed = ops.upconv_k4s2_pack(w4)
+    out = ya.clone().to(device)
+    tiles = ops.upconv_k4s2_stat_tiles(*ldims)
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if fused_stats else None
+    ops.upconv_k4s2_accum(low.to(device), nrm.to(device), packed, table, out, stats)
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"upconv {cin}->({cup})->{cout} {ldims}: max err {err}"
+    if stats is not None:
+        gamma = torch.rand(cout, generator=gen) + 0.5
+        beta = torch.randn(cout, generator=gen) * 0.2
+        nrm_out = torch.full((n, cout, 4), float("nan"), device=device)
+        ops.instnorm_finalize(stats, tiles, n, cout, gamma.to(device), beta.to(device), 1e-5, 0.1, nrm_out)
+        mean = got.mean(dim=(2, 3, 4))
+        var = got.var(dim=(2, 3, 4), unbiased=False)
+        alpha = gamma.double()[None] / torch.sqrt(var + 1e-5)
+        r = nrm_out.cpu().double()
+        assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+        assert (r[:, :, 1] - (beta.double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    return err
+
+
 def _conv_err(device, cfg, x, nrm, w, b, exp):
     packed = ops.conv3d_k3_pack(cfg, w.to(device))
     out = torch.full(tuple(exp.shape), float("nan"), device=device)

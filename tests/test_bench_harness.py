@@ -34,7 +34,7 @@ def test_bench_single_process_line():
     par = cb["parity_vs_gpu"]
     assert par["ok"] and par["mismatch_outside_margin"] == 0 and par["max_abs_logit_diff"] <= 1e-4
     top = line["parity"]            # the same report at top level (the driver's parsed copy keeps it), the line short enough for the driver's stdout tail
-    assert top["ok"] and top["family"] == "fp32-exact" and top["voxels"] == 40 ** 3 and top["max_abs_logit_diff"] == par["max_abs_logit_diff"]
+    assert top["ok"] and top["family"] == "fp32-exact" and top["voxels"] == par["voxels"] and top["max_abs_logit_diff"] == par["max_abs_logit_diff"]
     assert len(json.dumps(line)) < 6000
     test_bench_single_process_line.checksum = line["checksum"]
 

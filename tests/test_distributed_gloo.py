@@ -149,6 +149,57 @@ def test_window_sharding_world_sizes_3_and_4(world):
             assert torch.equal(t, single), f"rank {r} of {world}: {name} differs from the single-process result"
 
 
+def _worker_1000(rank, world, port, ret):
+    """the headline's window count under sharding: 10 x 10 x 10 = 1000 windows (8^3 at overlap 0.5 over 44^3), a toy per-window predictor through
+    the generic path (sw_batch_size 60 -> the schedule of the 8-GPU run: one main round of 8 x 60, five tail rounds of 8 x 13, 40 padded rows), every rank's result
+    against the single-process one, bitwise"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.dirname(here)]
+        from emu_backend import emu_backend
+
+        from monai_amd import parallel
+        from monai_amd.inferers import sliding_window_inference
+
+        calls = []
+
+        def toy(w):      # two classes, per-window statistics inside (a window's logits depend on nothing but the window)
+            calls.append(int(w.shape[0]))
+            m = w.mean(dim=(2, 3, 4), keepdim=True)
+            return torch.cat([w * 1.5 - m, (w - m) * (w - m) + 0.25], dim=1)
+
+        with emu_backend():
+            torch.manual_seed(21)
+            x = torch.rand(1, 1, 44, 44, 44)
+            single = sliding_window_inference(x, (8, 8, 8), 60, toy, overlap=0.5, mode="gaussian").clone()
+            n_single = list(calls)
+            del calls[:]
+            parallel.enable_window_sharding()
+            sharded = sliding_window_inference(x, (8, 8, 8), 60, toy, overlap=0.5, mode="gaussian").clone()
+            parallel.disable_window_sharding()
+        ret[rank] = (single, sharded, n_single, list(calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_8_with_1000_windows_bitwise():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_1000, args=(8, _free_port(), ret), nprocs=8, join=True)
+    single = ret[0][0]
+    assert sum(ret[0][2]) == 1000
+    for r in range(8):
+        s, d, _, calls = ret[r]
+        assert torch.equal(s, single) and torch.equal(d, single), f"rank {r}: sharded != single process"
+        assert calls[0] == 60 and len(calls) <= 6 and sum(calls) in (125, 124, 126, 120, 128)      # this rank's share of the 1000 windows in <= 6 launches
+    assert sum(sum(ret[r][3]) for r in range(8)) == 1000
+
+
 def test_partition_covers_every_window_once():
     from monai_amd import parallel
 
@@ -163,24 +214,41 @@ def test_partition_covers_every_window_once():
 
 
 def test_round_schedule_covers_every_window_once():
-    """The round-interleaved schedule (monai_amd/parallel.py): every real window is computed by exactly one rank, each rank's
-    slot of round q is [q*world*nb + rank*nb, +nb), the padded row count is a whole number of rounds."""
+    """The round-interleaved schedule (monai_amd/parallel.py: WindowShard.schedule): main rounds of world x nb windows, shorter tail rounds at the end; every real window
+    is computed by exactly one rank, each rank's slot of a round starting at row `base` is [base + rank * n, +n), rounds are contiguous, the padded row count is
+    where the last round ends, the tail keeps between half a round and one and a half, and the busiest rank is within a launch of the ideal share."""
     from monai_amd import parallel
 
     for num_win in (1, 7, 200, 1000, 1001):
         for world in (1, 2, 3, 8):
-            for nb in (1, 4, 32):
+            for nb in (1, 4, 32, 60):
                 seen = []
-                padded = parallel.partition(num_win, world, 0).padded_windows(nb)
-                assert padded >= num_win and (world == 1 or padded % (world * nb) == 0)
+                probe = parallel.partition(num_win, world, 0)
+                sched = probe.schedule(nb)
+                padded = probe.padded_windows(nb)
+                assert sched[0][0] == 0 and all(sched[q + 1][0] == sched[q][0] + (world * sched[q][1] if world > 1 else sched[q][1]) for q in range(len(sched) - 1))
+                assert padded >= num_win and sched[-1][0] < num_win and all(1 <= n <= nb for _, n in sched)
+                if world > 1:
+                    assert padded == sched[-1][0] + world * sched[-1][1]
+                    tail = [n for _, n in sched if n < nb]
+                    if nb >= 8 and num_win >= world * nb:      # a real tail: short rounds, at least two of them, after at most ... full ones
+                        assert len(tail) >= 2 and max(tail) <= nb // 4 + 1 and world * nb // 2 <= num_win - sum(world * n for _, n in sched if n == nb) < 3 * world * nb // 2 + 1
                 for r in range(world):
                     sh = parallel.partition(num_win, world, r)
                     rounds = sh.rounds(nb)
-                    assert len(rounds) == -(-num_win // (world * nb))
-                    for q, (w0, n) in enumerate(rounds):
-                        assert w0 == q * world * nb + r * nb and 0 <= n <= nb and w0 + n <= max(num_win, w0)
+                    assert len(rounds) == len(sched)
+                    for (base, per), (w0, n) in zip(sched, rounds):
+                        assert w0 == (base + r * per if world > 1 else base) and 0 <= n <= per and w0 + n <= max(num_win, w0)
                         seen += list(range(w0, w0 + n))
                 assert sorted(seen) == list(range(num_win))
+    # the headline at 8 GPUs: 125 windows per rank, the last round 13 windows per rank (1.6 GB of logits per rank exposed in front of the blend instead of 7.8 GB)
+    sh = parallel.partition(1000, 8, 0)
+    assert [n for _, n in sh.schedule(60)] == [60, 13, 13, 13, 13, 13] and sum(n for _, n in sh.rounds(60)) == 125
+    os.environ["MONAI_AMD_TAIL_ROUNDS"] = "0"
+    try:
+        assert [n for _, n in sh.schedule(60)] == [60, 60, 60] and sh.padded_windows(60) == 1440
+    finally:
+        del os.environ["MONAI_AMD_TAIL_ROUNDS"]
 
 
 def test_scoped_switches_restore_the_previous_state():

@@ -194,37 +194,6 @@ def test_full_size_properties_512():
     assert s2 == s1 and torch.equal(b.argmax(1), lab), f"two runs differ: sums {s1!r} vs {s2!r}, {int((b.argmax(1) != lab).sum())} labels"
 
 
-def test_stream_lanes_do_not_change_a_bit():
-    """window batches on alternating HIP streams (config.SW_STREAMS, inferers/utils.py:_StreamLanes): each lane its own window buffer and activation-buffer slot,
-    the logits rows disjoint -- the result must equal the one-stream result bitwise, mosaic and window-major logits, several images per call"""
-    from monai_amd import config
-    from monai_amd.inferers import SlidingWindowInferer
-
-    net, _ = ec.make_net(1, 1, 5, DEV)
-    torch.manual_seed(9)
-    vol = torch.rand(2, 1, 112, 80, 64, device=DEV)           # 6 x 4 x 3 = 72 windows of 32^3 per image
-    inf = SlidingWindowInferer(roi_size=(32, 32, 32), sw_batch_size=4, overlap=0.5, mode="gaussian")
-    saved, saved_env = config.SW_STREAMS, {k: os.environ.get(k) for k in ("MONAI_AMD_SW_BATCH", "MONAI_AMD_LOGITS_LAYOUT")}
-    try:
-        os.environ["MONAI_AMD_SW_BATCH"] = "7"                 # 11 batches, the last one ragged
-        config.SW_STREAMS = 1
-        ref = inf(vol, net).clone()
-        for lanes in (2, 3, 4):
-            config.SW_STREAMS = lanes
-            for _ in range(2):
-                assert torch.equal(inf(vol, net), ref), f"{lanes} stream lanes changed the result"
-        os.environ["MONAI_AMD_LOGITS_LAYOUT"] = "windows"
-        config.SW_STREAMS = 2
-        assert torch.equal(inf(vol, net), ref)
-    finally:
-        config.SW_STREAMS = saved
-        for k, v in saved_env.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
-
 def test_buffered_schedule_bitwise_vs_reference():
     """`buffer_steps` / `buffer_dim` -- the summation order of the reference's buffered schedule, bit for bit (tests/golden/buffered.npz)"""
     assert ec.case_buffered_blend_vs_golden(DEV) >= 8
@@ -322,3 +291,8 @@ def test_narrow_and_host_inputs():
 def test_basic_unet_2d_and_slice_inferer_vs_reference():
     """BasicUNet(spatial_dims=2) on the one-plane engine and SliceInferer over it, against the real reference"""
     print("max |dlogit|", ec.case_basic_unet_2d_vs_reference(DEV))
+
+
+def test_upcat_fused_vs_two_layers_and_reference():
+    """UpCat without its up-sampled intermediate (kernels/upconv_h2.h) inside BasicUNet: golden logits of the real reference + the engine's two-layer path"""
+    print(ec.case_net_upcat_fused_vs_two_layers(DEV))

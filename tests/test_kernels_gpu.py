@@ -218,3 +218,13 @@ def test_conv_one_input_channel():
 def test_window_attention(s, hd):
     """SwinUNETR's WindowAttention core: head dims 16 / 32 on the split-precision matrix-core kernel (round 4), 8 on the VALU kernel"""
     kc.case_window_attention(DEV, bw=2 if DEV == "cpu" else 6, s=s, heads=2, hd=hd)
+
+
+# (n, up channels, couts, coarse extents): one whole tile / ragged tiles in y and x with two cout groups / two z-chunks / one plane pair with x tiles of 16 + 16 + 4
+UPCONV_CASES = [(1, 32, 32, (3, 8, 16)), (2, 16, 64, (5, 9, 20)), (1, 32, 32, (25, 4, 4)), (1, 8, 32, (2, 17, 36)), (2, 32, 32, (48, 48, 48))]
+@pytest.mark.parametrize("n,cup,cout,ldims", UPCONV_CASES)
+def test_upcat_composite_transposed_convolution(n, cup, cout, ldims):
+    """conv3(cat([x_e, deconv2(x)]))'s up half as one transposed convolution k4 s2 p1 of x added in place (kernels/upconv_h2.h) == the two-layer evaluation in float64,
+    with and without the deconvolution's bias, statistics of the sum included"""
+    kc.case_upconv_k4s2(DEV, n, cup, cout, ldims)
+    kc.case_upconv_k4s2(DEV, 1, cup, cout, ldims, with_bias=False, fused_stats=False)

@@ -781,9 +781,13 @@ def case_separable_vs_general(device):
                     m2[0, 1] = 1e-300
                     b = ops.affine_resample(vol, m2.reshape(-1), osz, mode, pad, False, f64)
                     assert torch.equal(a, b), (scale, mode, pad, f64, (a - b).abs().max().item())
-    # the z-streaming kernel's other paths: the 16-loads-per-thread box, tiles (and planes) entirely outside the volume
+    # the z-streaming kernels' other paths: the 16-loads-per-thread box, tiles (and planes) entirely outside the volume; round 5, the barrier-free wave form
+    # (separable_resample_wave_kernel): in-plane down-sampling by 1.25 with an odd output width (4-byte stores), source planes skipped (z scale 2), the identity
+    # scale at a fractional offset, wave tiles that end inside a workgroup tile (Ho = 35, 41), the tensor's last plane (its 16-byte pieces may pass the allocation's end)
     for scale, off, osz in (((1.25, 1.25, 1.0), (-0.7, 0.4, -2.3), (19, 32, 300)), ((1.25, 1.25, 0.625), (-9.0, -25.0, -100.0), (30, 40, 700)),
-                            ((-1.25, 1.0, 0.625), (30.0, 30.0, 250.0), (33, 30, 300))):
+                            ((-1.25, 1.0, 0.625), (30.0, 30.0, 250.0), (33, 30, 300)),
+                            ((0.625, 1.25, 1.25), (0.3, -0.6, 0.45), (38, 31, 239)), ((2.0, 1.0, 1.0), (0.5, 0.25, 0.75), (12, 41, 300)),
+                            ((1.0, 1.0, 1.0), (0.5, 0.5, 0.5), (24, 35, 300)), ((0.9, 1.28, 1.9), (-1.2, -3.0, -7.5), (29, 33, 170))):
         for pad in PADS:
             for f64 in (True, False):
                 m = np.zeros((3, 4))
