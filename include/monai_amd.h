@@ -175,6 +175,9 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W);
  * of the values written (fused InstanceNorm statistics). */
 int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias,
                      const mh_tensor5* out, float* stats, void* stream);
+/* mh_conv3d_k3_f32 whose result is ADDED to what `out` holds (out += conv + bias; `stats` = the statistics of the sum): the split-precision configuration
+ * (mh_conv3d_k3_h2_config) with input records and statistics only -- MH_ERR_UNSUPPORTED otherwise.  The second half of the UpCat path (mh_upconv_k4s2_f32 first). */
+int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out, float* stats, void* stream);
 
 /* InstanceNorm3d statistics (nn.InstanceNorm3d(affine=True, eps) via layers/factories.py:228-241):
  * partial {count, mean, M2} records per 4096-element chunk of each (n, c) plane, then a finalize that
@@ -207,15 +210,16 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, 
  * `Conv3d(k3, p1)(cat([x_e, x_0]))` is the composite transposed convolution k4 s2 p1 of x itself (kernels/upconv_h2.h) -- 8 instead of 27 taps per output voxel, no
  * full-resolution x_0 written or read.  w4 [Cin][Cout][4][4][4] = the composite weights (host: sum over the up channels of deconv x conv weight products),
  * bias_table [27][Cout] = what the deconvolution's bias contributes per (first / interior / last) position class of (z, y, x).
- * mh_upconv_k4s2_accum_f32 ADDS  convT4(act(low)) + bias_table  to `out` in place -- `out` holds the convolution's x_e half, raw, written by mh_conv3d_k3_f32 on the
- * skip channels alone -- and, with stats != NULL, leaves one {count, mean, M2} record per (n, cout, tile) of the SUM (mh_upconv_k4s2_stat_tiles of them per (n, c),
+ * mh_upconv_k4s2_f32 with accumulate == 0 WRITES  convT4(act(low)) + bias_table  to `out` (mh_conv3d_k3_accumulate_f32 on the skip channels then adds the
+ * convolution's x_e half and leaves the statistics of the sum); with accumulate != 0 it ADDS them to `out` in place -- `out` holding the x_e half, raw, written by
+ * mh_conv3d_k3_f32 -- and, with stats != NULL, leaves one {count, mean, M2} record per (n, cout, tile) of the SUM (mh_upconv_k4s2_stat_tiles of them per (n, c),
  * merged by mh_instnorm_finalize_f32).  Split-precision arithmetic and record / bound contract of mh_conv3d_k3_h2_config.  Cin == 32, Cout % 32 == 0,
  * low W % 4 == 0, out = 2 x low; mh_upconv_k4s2_accepts says so. */
 int mh_upconv_k4s2_accepts(int Cin, int Cout, int Dl, int Hl, int Wl);
 int64_t mh_upconv_k4s2_packed_floats(int Cin, int Cout);
 int mh_upconv_k4s2_pack_f32(const float* w4, int Cin, int Cout, float* packed, void* stream);
 int mh_upconv_k4s2_stat_tiles(int Dl, int Hl, int Wl);
-int mh_upconv_k4s2_accum_f32(const mh_tensor5* low, const float* packed, const float* bias_table, const mh_tensor5* out, float* stats, void* stream);
+int mh_upconv_k4s2_f32(const mh_tensor5* low, const float* packed, const float* bias_table, const mh_tensor5* out, int accumulate, float* stats, void* stream);
 
 /* Conv3d k=1 (+bias) of act(in) -- `final_conv`, basic_unet.py:252.  w: [Cout][Cin]. */
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,

@@ -72,6 +72,7 @@ SIGNATURES = {
     "mh_conv3d_k3_pack_f32": (_I, [_I, _P, _I, _I, _P, _P]),
     "mh_conv3d_k3_stat_tiles": (_I, [_I, _I, _I, _I]),
     "mh_conv3d_k3_f32": (_I, [_I, _T, _P, _P, _T, _P, _P]),
+    "mh_conv3d_k3_accumulate_f32": (_I, [_I, _T, _P, _P, _T, _P, _P]),
     "mh_instnorm_stat_tiles": (_I, [_I, _I, _I]),
     "mh_instnorm_stats_f32": (_I, [_T, _P, _P]),
     "mh_instnorm_finalize_f32": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _L, _P]),
@@ -90,7 +91,7 @@ SIGNATURES = {
     "mh_upconv_k4s2_packed_floats": (_L, [_I, _I]),
     "mh_upconv_k4s2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
     "mh_upconv_k4s2_stat_tiles": (_I, [_I, _I, _I]),
-    "mh_upconv_k4s2_accum_f32": (_I, [_T, _P, _P, _T, _P, _P]),
+    "mh_upconv_k4s2_f32": (_I, [_T, _P, _P, _T, _I, _P, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_stat_tiles": (_I, [_I, _I, _I]),
     "mh_conv1x1_stats_f32": (_I, [_T, _P, _P, _T, _P, _P]),

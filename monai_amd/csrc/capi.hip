@@ -588,8 +588,19 @@ static void launch_mfma(const Tensor& in, const float* wp, const float* bias, co
         hipLaunchKernelGGL((conv3d_k3_mfma_kernel<Cfg, false>), grid, dim3(256), 0, s, in, wp, bias, out, stats, tx, ty, tz);
 }
 
+static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, float* stats, void* stream, bool accumulate);
 int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
                      float* stats, void* stream) {
+    return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, false);
+}
+int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
+                                float* stats, void* stream) {
+    if (cfg != MH_CFG_H2 || !stats || !in_ || !in_->nrm)
+        return fail(MH_ERR_UNSUPPORTED, "conv3d_k3_accumulate: the accumulating form exists for the split-precision configuration with input records and statistics");
+    return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, true);
+}
+static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
+                            float* stats, void* stream, bool accumulate) {
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
@@ -637,6 +648,13 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
         else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
     }
+        if (accumulate) {       // out += conv (kernels/conv3d_h2.h, ACC): statistics and input records present (checked by the entry point)
+#define MH_H2_ACC(RES_, WIDE_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk)
+            if (in.C <= 2 * H2_KC) { if (wide) MH_H2_ACC(true, true); else MH_H2_ACC(true, false); }
+            else { if (wide) MH_H2_ACC(false, true); else MH_H2_ACC(false, false); }
+#undef MH_H2_ACC
+            return launched("conv3d_k3_h2_acc");
+        }
         if (c16) {
             if (in.C <= 2 * H2_KC) { if (wide) MH_H2_LAUNCH(true, true, true) else MH_H2_LAUNCH(true, false, true) }
             else { if (wide) MH_H2_LAUNCH(false, true, true) else MH_H2_LAUNCH(false, false, true) }
@@ -807,8 +825,9 @@ int mh_upconv_k4s2_pack_f32(const float* w4, int Cin, int Cout, float* packed, v
     hipLaunchKernelGGL(upconv_k4s2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w4, Cin, Cout, reinterpret_cast<_Float16*>(packed), tail);
     return launched("upconv_k4s2_pack");
 }
-int mh_upconv_k4s2_accum_f32(const mh_tensor5* low_, const float* packed, const float* bias_table, const mh_tensor5* out_, float* stats, void* stream) {
+int mh_upconv_k4s2_f32(const mh_tensor5* low_, const float* packed, const float* bias_table, const mh_tensor5* out_, int accumulate, float* stats, void* stream) {
     if (!dense_ok(low_) || !dense_ok(out_) || !packed || !bias_table) return fail(MH_ERR_ARG, "upconv_k4s2: bad tensor");
+    if (stats && !accumulate) return fail(MH_ERR_ARG, "upconv_k4s2: statistics are those of the sum (accumulate != 0); the writing form leaves them to the accumulating convolution");
     const Tensor low = from_c(*low_), out = from_c(*out_);
     if (low.N != out.N || out.D != 2 * low.D || out.H != 2 * low.H || out.W != 2 * low.W) return fail(MH_ERR_ARG, "upconv_k4s2: the output must be 2x the input");
     if (!mh_upconv_k4s2_accepts(low.C, out.C, low.D, low.H, low.W))
@@ -821,8 +840,10 @@ int mh_upconv_k4s2_accum_f32(const mh_tensor5* low_, const float* packed, const 
     const uint4* wq = reinterpret_cast<const uint4*>(packed);
     const float* tail = packed + (mh_upconv_k4s2_packed_floats(low.C, out.C) - H2_TAIL);
     hipStream_t s = (hipStream_t)stream;
-    if (stats) hipLaunchKernelGGL((upconv_k4s2_h2_kernel<true>), dim3((unsigned)total), dim3(256), 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
-    else hipLaunchKernelGGL((upconv_k4s2_h2_kernel<false>), dim3((unsigned)total), dim3(256), 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
+    const dim3 g((unsigned)total), bl(UC_NT);
+    if (!accumulate) hipLaunchKernelGGL((upconv_k4s2_h2_kernel<false, false>), g, bl, 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
+    else if (stats) hipLaunchKernelGGL((upconv_k4s2_h2_kernel<true, true>), g, bl, 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
+    else hipLaunchKernelGGL((upconv_k4s2_h2_kernel<false, true>), g, bl, 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
     return launched("upconv_k4s2");
 }
 

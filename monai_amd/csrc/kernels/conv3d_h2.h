@@ -122,7 +122,11 @@ __device__ __forceinline__ void h2_split_pair(float v0, float v1, float m1, f16x
 // The columns carry two z-taps instead: B = [W(kz 0) | W(kz 1)] (accumulator X) and [W(kz 2) | 0] (accumulator Y) -- 6 instead of 9 matrix instructions per (ky, kx) tap
 // and 16 channels.  X of input plane p holds in its low 16 columns what output plane p + 1 gets from it and in its high 16 what plane p gets; Y's low 16 belong to plane
 // p - 1: a completed plane is  X(p - 2).low + X(p - 1).high + Y(p).low  -- two register-set additions and one 16-lane exchange per plane.  Packed by conv3d_k3_h2c_pack_kernel.
-template <bool STATS, bool NRM, bool RES, bool WIDE = false, bool C16 = false>
+// ACC (round 5, 32-cout form only): the result is ADDED to what `out` holds -- a completed plane starts from the old values instead of from zero.  They are requested a
+// whole plane ahead (four 16-byte buffer loads per lane right after the accumulator sets rotate) and enter the fresh set as old * 2^-(scale-back exponent), an exact
+// power-of-two product, so the epilogue, its stores and the statistics are untouched: they see the sum.  Used by the UpCat path (kernels/upconv_h2.h writes the
+// decoder's up half first, this kernel adds the skip half and leaves the InstanceNorm statistics of the sum).
+template <bool STATS, bool NRM, bool RES, bool WIDE = false, bool C16 = false, bool ACC = false>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                     float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
@@ -305,6 +309,27 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         const bool ok_ = cok && y0 + orow + yr_ < H && x0 + xg_ < W;
         ooff[j] = ok_ ? 4u * (unsigned)((long long)(C16 ? (r32 & 15) : r32) * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
     }
+    static_assert(!(ACC && C16), "the accumulating form exists for the 32-cout kernel");
+    f32x4 pv[4];                                             // ACC: the old values of the plane whose accumulator set starts next
+    float pinv_a = 1.0f, pinv_b = 1.0f;                      // ACC: 2^(scale-back exponent), as two factors like inv_a, inv_b
+    if (ACC) {
+        const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;
+        const int t1_ = t_ / 2, t2_ = t_ - t1_;
+        pinv_a = __uint_as_float((unsigned)(127 - t1_) << 23);
+        pinv_b = __uint_as_float((unsigned)(127 - t2_) << 23);
+    }
+#define MH_H2_PV_LOAD(Z)                                                                              \
+    if (ACC) {      /* planes outside this workgroup's z-chunk belong to someone else (their sets are dropped): offset beyond the buffer -> zeros */ \
+        const int z_ = (Z);                                                                           \
+        const unsigned po_ = (z_ >= zs && z_ < ze) ? (unsigned)z_ * (unsigned)(HW * 4) : H2_DROP;     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+            pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, (po_ == H2_DROP || ooff[j] == H2_DROP) ? H2_DROP : ooff[j] + po_, 0, 0)); \
+    }
+#define MH_H2_PV_INTO(S)                                                                              \
+    if (ACC) {                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[S][4 * j + i] = pv[j][i] * pinv_a * pinv_b; \
+    }
     f32x4 o_[4];                                             // the plane being emitted: its pieces A (scale, bias, store), B1-B3 (statistics) sit in different taps
     float esum_ = 0.0f, ecnt_ = 0.0f, em2_ = 0.0f, emean_ = 0.0f;
     Stat run;
@@ -431,6 +456,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     bcur = 0; gi = 0;
     __syncthreads();
 
+    MH_H2_PV_LOAD(zs)                 // ACC: set 0 of the first iteration (input plane zs - 1) belongs to output plane zs
+    MH_H2_PV_INTO(0)
+    MH_H2_PV_LOAD(zs + 1)
     for (int p = zs - 1; p <= ze; ++p) {
         if (p >= p_first && p <= p_last) {
             MH_H2_STEP(MH_H2_SCHEDULE_EMIT)
@@ -460,8 +488,13 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         } else {
             acc[2] = acc[1];
             acc[1] = acc[0];
+            if (ACC) {                  // the fresh set belongs to output plane p + 2: its old values (requested a plane ago); request plane p + 3's
+                MH_H2_PV_INTO(0)
+                MH_H2_PV_LOAD(p + 3)
+            } else {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+                for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+            }
         }
     }
     if (pend) MH_H2_EMIT
@@ -487,6 +520,8 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #undef MH_H2_LDW
 #undef MH_H2_LDWX
 #undef MH_H2_LDX
+#undef MH_H2_PV_INTO
+#undef MH_H2_PV_LOAD
 
     if (STATS) {
         // the two k-group halves of a lane pair hold disjoint voxels of the same cout; then the eight waves merge through LDS

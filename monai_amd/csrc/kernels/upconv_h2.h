@@ -7,15 +7,16 @@
 // the convolution's taps fall inside the volume depends on first / interior / last position per axis).  Per FINE output voxel that is 2 x 2 x 2 coarse taps x Cin x Cout
 // multiply-adds instead of 27 x Cup x Cout on a full-resolution tensor -- 3.4 x fewer at Cin == Cup -- and the full-resolution x_0 (7.2 GB per 64 windows of 96^3)
 // is neither written by a transposed convolution nor read by the convolution.  Host side: monai_amd/networks/nets/basic_unet.py (_upcat_fused), which runs the
-// convolution's x_e half on conv3d_k3_h2_kernel (raw result, convolution bias included, no statistics) and then this kernel, which ADDS the composite term and the
-// bias table to that result in place and produces the InstanceNorm statistics of the sum.
+// composite term first (this kernel WRITES it together with the bias table) and then the convolution's x_e half on conv3d_k3_h2_kernel in its accumulating form
+// (out += conv + bias, with the InstanceNorm statistics of the sum).  Where the x_e half runs on another kernel family the order is the other way round: this kernel
+// then ADDS to the convolution's raw result in place and produces the statistics itself (RMW).
 //
 // Arithmetic: conv3d_h2.h's two-piece split precision (hi + lo fp16 pieces of the activated, power-of-two-scaled input and of the scaled composite weights, products
 // hi*hi + lo*hi + hi*lo on v_mfma_f32_32x32x16_f16, fp32 accumulation), the same record / bound contract for the input.  The composite weights are formed in fp32 on
 // the host from the fp32 parameters: one rounding per weight more than the two-layer evaluation, 1e-7 relative.
 //
 // Mapping.  An output voxel's taps depend on its parity per axis (f = 2c + p: p = 0 reads coarse c - 1 and c, p = 1 reads c and c + 1), so voxels of one parity
-// class share their weight matrices and form a GEMM: a workgroup owns ONE (z, y) parity pair, a coarse tile of 8 rows x 16 columns (fine: 8 rows of that parity x 32
+// class share their weight matrices and form a GEMM: a workgroup owns ONE (z, y) parity pair, a coarse tile of 16 rows x 16 columns (fine: 16 rows of that parity x 32
 // columns), 32 output channels, and marches over its coarse z-chunk.  Wave w owns coarse rows 2w, 2w + 1 = a 32-voxel M block and carries BOTH x parities as two
 // accumulator sets (so a lane's results are 8 consecutive fine columns per row and group: 16-byte accesses); per fine plane 16 (tz, ty, tx, px) tap matrices x
 // Cin / 16 steps x 3 piece products.  The weight slab of the parity pair (64 KB at Cin = 32) stays in LDS for the whole march; coarse input planes are staged once each
@@ -26,27 +27,36 @@
 
 namespace mh {
 
-constexpr int UC_TY = 8, UC_TX = 16;                       // coarse tile of a workgroup
+constexpr int UC_TY = 16, UC_TX = 16;                      // coarse tile of a workgroup: 8 waves x 2 rows x 16 columns
+constexpr int UC_NT = 64 * (UC_TY / 2);                    // threads
 constexpr int UC_RY = UC_TY + 1, UC_RX = UC_TX + 2;        // staged coarse rows (one parity needs one halo row) and columns (both x parities: two halo columns)
-constexpr int UC_PV = UC_RY * UC_RX;                       // 162 staged voxels per coarse plane
+constexpr int UC_PV = UC_RY * UC_RX;                       // 306 staged voxels per coarse plane
 constexpr int UC_CIN = 32;                                 // input channels (two matrix-instruction K steps): the resident weight slab is sized for it
 constexpr int UC_XP = 2 * 2 * UC_PV;                       // uint4 per piece of a staged plane: [k step][k group][voxel]
-constexpr int UC_XB = 2 * UC_XP;                           // uint4 per staged plane (two pieces)
+constexpr int UC_XB = 2 * UC_XP;                           // uint4 per staged plane (two pieces): 39 KB
 constexpr int UC_WC = 2 * 2 * 2 * 32;                      // uint4 per tap matrix: [piece][k step][k group][cout]
 constexpr int UC_WB = 16 * UC_WC;                          // uint4 per (z parity, y parity) weight slab: 16 tap matrices (tz, ty, px, tx) = 64 KB
+constexpr int UC_NTASK = UC_PV * (UC_CIN / 4);             // staging tasks per plane: (staged voxel, channel quad)
+constexpr int UC_NSLOT = (UC_NTASK + UC_NT - 1) / UC_NT;   // per thread: 5
 
 // taps: coarse offset of tap t (0 / 1) for output parity p is t - 1 + p; the composite kernel index is u + 1 with u = f - 2 c' = [[2, 0], [1, -1]][p][t]
 __host__ __device__ inline int uc_kernel_index(int p, int t) { return p == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0); }
 
-template <bool STATS>
-__global__ void __launch_bounds__(256, 1)
+// Schedule of a fine plane (the kernel is bound by the read-modify-write of the 32 output planes: 131 KB per workgroup and plane against 96 matrix instructions per wave):
+//   1. the plane's old values (the convolution's skip half: 8 x 16 bytes per lane) and the raw values of the NEXT coarse plane (5 x 4 loads per thread) are requested,
+//   2. the matrix instructions of this plane run over the two staged coarse planes (they arrive meanwhile),
+//   3. barrier; the next coarse plane is activated, scaled, split and written over the plane that is no longer needed; the sum is formed, stored, its statistics merged,
+//   4. barrier.
+// RMW: the result is added to what `out` holds (and STATS are those of the sum); otherwise it is written (the accumulating convolution adds the skip half afterwards)
+template <bool STATS, bool RMW>
+__global__ void __launch_bounds__(UC_NT, 1)
 upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ btab, Tensor out,
                       float* __restrict__ stats, int txn, int tyn, int zchunk, unsigned nblk) {
     __shared__ uint4 xs[2 * UC_XB];
     __shared__ uint4 ws[UC_WB];
     __shared__ __attribute__((aligned(16))) float nrm_s[3 * UC_CIN];
-    __shared__ unsigned bound_s[4];
-    __shared__ float red[4 * 32 * 3];
+    __shared__ unsigned bound_s[UC_NT / 64];
+    __shared__ float red[(UC_NT / 64) * 32 * 3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Dl = low.D, Hl = low.H, Wl = low.W, Cout = out.C;
@@ -80,14 +90,16 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     // the parity pair's weight slab: resident for the whole march
     {
         const uint4* wsrc = wp + ((long long)(cg * 4 + par)) * UC_WB;
-        for (int i = tid; i < UC_WB; i += 256) ws[i] = wsrc[i];
+        for (int i = tid; i < UC_WB; i += UC_NT) ws[i] = wsrc[i];
     }
-    for (int i = tid; i < 2 * UC_XB; i += 256) xs[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < 2 * UC_XB; i += UC_NT) xs[i] = make_uint4(0u, 0u, 0u, 0u);
     __syncthreads();
     int e_in = 0;
     bool poisoned = false;
     {
-        const unsigned m4 = max(max(bound_s[0], bound_s[1]), max(bound_s[2], bound_s[3]));
+        unsigned m4 = bound_s[0];
+#pragma unroll
+        for (int w = 1; w < UC_NT / 64; ++w) m4 = max(m4, bound_s[w]);
         poisoned = m4 >= 0x7f800000u;
         e_in = (poisoned || low.nrm == nullptr) ? 0 : min(max(15 - ((int)(m4 >> 23) - 126), -100), 100);
         const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
@@ -102,38 +114,48 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
     }
 
-    // ---- staging tasks of this thread: (staged voxel, channel quad) -> 4 loads, activate + scale + split, 8 bytes of the high plane and 8 of the low one
-    constexpr int NTASK = UC_PV * (UC_CIN / 4);               // 1296
-    constexpr int NSLOT = (NTASK + 255) / 256;                // 6
+    // ---- staging tasks of this thread: (staged voxel, channel quad) -> 4 raw loads one plane ahead; later activate + scale + split, 8 bytes of the high plane and 8 of the low one
+    constexpr unsigned UC_DROP = 0x80000000u;
+    unsigned soff[UC_NSLOT];          // byte offset of (channel 4 q, y, x) inside the sample's coarse plane z = 0, or UC_DROP (zero padding / no task)
+    int scell[UC_NSLOT];              // destination in 8-byte units inside a piece of a staged plane
+    int squad[UC_NSLOT];
+#pragma unroll
+    for (int s = 0; s < UC_NSLOT; ++s) {
+        const int t = min(tid + UC_NT * s, UC_NTASK - 1);
+        const int q = t / UC_PV, v = t - q * UC_PV;          // channel quad, staged voxel
+        const int ly = v / UC_RX, lx = v - ly * UC_RX;
+        const int gy = cy0 - (1 - py) + ly, gx = cx0 - 1 + lx;
+        const bool ok = tid + UC_NT * s < UC_NTASK && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
+        soff[s] = ok ? 4u * (unsigned)((long long)(4 * q) * DHWl + (long long)gy * Wl + gx) : UC_DROP;
+        // cell [k step = q >> 2][k group = (q >> 1) & 1][voxel] holds 8 channels = two 8-byte halves (q & 1); a thread without a task rewrites the last task's cell with the same zeros
+        scell[s] = (((q >> 2) * 2 + ((q >> 1) & 1)) * UC_PV + v) * 2 + (q & 1);
+        squad[s] = tid + UC_NT * s < UC_NTASK ? q : -1;
+    }
     const float* src = low.data + (long long)n * low.n_stride;
-    auto stage_plane = [&](int z, int bufi) {
-        uint4* xb = xs + bufi * UC_XB;
-        u32x2* xh = reinterpret_cast<u32x2*>(xb);
+    const long long lrest = (long long)(low.N - n) * low.n_stride * 4;
+    float sreg[UC_NSLOT][4];
+    auto load_plane = [&](int z) {          // requests only: the values are used a plane later
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (long long)z * HWl), 0, (int)(lrest < 0x7fffffffLL ? lrest : 0x7fffffffLL), 0x00020000);
 #pragma unroll
-        for (int s = 0; s < NSLOT; ++s) {
-            const int t = tid + 256 * s;
-            if (t < NTASK) {
-                const int q = t / UC_PV, v = t - q * UC_PV;          // channel quad, staged voxel
-                const int ly = v / UC_RX, lx = v - ly * UC_RX;
-                const int gy = cy0 - (1 - py) + ly, gx = cx0 - 1 + lx;
-                const bool ok = z >= 0 && z < Dl && gy >= 0 && gy < Hl && gx >= 0 && gx < Wl;
-                _Float16 h_[4], l_[4];
+        for (int s = 0; s < UC_NSLOT; ++s)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 4 * q + i;
-                    float y = 0.0f;
-                    if (ok) {
-                        y = src[(long long)c * DHWl + (long long)z * HWl + (long long)gy * Wl + gx];
-                        y = act(y, nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]);
-                    }
-                    h2_split(y, h_[i], l_[i]);
-                }
-                // cell [k step = q >> 2][k group = (q >> 1) & 1][voxel] holds 8 channels = two 8-byte halves (q & 1)
-                const int cell = (((q >> 2) * 2 + ((q >> 1) & 1)) * UC_PV + v) * 2 + (q & 1);
-                const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
-                xh[cell] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-                xh[cell + 2 * UC_XP] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+            for (int i = 0; i < 4; ++i) sreg[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[s], (unsigned)(i * DHWl * 4), 0));
+    };
+    auto convert_plane = [&](int bufi) {
+        u32x2* xh = reinterpret_cast<u32x2*>(xs + bufi * UC_XB);
+#pragma unroll
+        for (int s = 0; s < UC_NSLOT; ++s) {
+            if (squad[s] < 0) continue;
+            _Float16 h_[4], l_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 4 * squad[s] + i;
+                const float y = soff[s] != UC_DROP ? act(sreg[s][i], nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]) : 0.0f;
+                h2_split(y, h_[i], l_[i]);
             }
+            const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
+            xh[scell[s]] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+            xh[scell[s] + 2 * UC_XP] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
         }
     };
 
@@ -145,7 +167,6 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     // ---- epilogue geometry: lane = cout; register i of an accumulator = coarse row i >> 3, columns ((i >> 2) & 1) * 8 + kg * 4 + (i & 3)
     const int co = cg * 32 + r32;
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * 32) * DHW, 0, (int)(32 * DHW * 4), 0x00020000);
-    constexpr unsigned UC_DROP = 0x80000000u;
     unsigned ooff[4];                  // (coarse row r_, column group g_): byte offset of its 8 fine columns inside an output plane of this cout, or UC_DROP
     int fyv[2];
     bool okg[4];
@@ -162,13 +183,32 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
     const float* bt = btab + co;       // bias table [27][Cout]: class (first / interior / last) per axis
 
+    // prologue: the first plane's two coarse planes
+    {
+        const int za = cz_s - 1 + pz, zb = cz_s + pz;
+        if (za >= 0 && za < Dl) { load_plane(za); convert_plane(za & 1); }
+        if (zb >= 0 && zb < Dl) { load_plane(zb); convert_plane(zb & 1); }
+    }
+    __syncthreads();
+
     for (int c = cz_s; c < cz_e; ++c) {
         const int za = c - 1 + pz, zb = c + pz;               // the two coarse planes of fine plane 2 c + pz
-        __syncthreads();                                      // the previous plane's operand reads are done
-        if (c == cz_s) stage_plane(za, za & 1);
-        stage_plane(zb, zb & 1);
-        __syncthreads();
+        const int fz = 2 * c + pz;
+        const unsigned so_ = (unsigned)fz * (unsigned)(HW * 4);
+        // 1. requests: this plane's old values, the next plane's raw input
+        f32x4 prev[8];
+        if (RMW) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                prev[2 * j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_, 0, 0));
+                prev[2 * j + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_ + 16u, 0, 0));
+            }
+        }
+        const int zn = zb + 1;
+        const bool stage_next = c + 1 < cz_e && zn < Dl;
+        if (stage_next) load_plane(zn);
 
+        // 2. matrix instructions
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
@@ -201,11 +241,11 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
                         }
                 }
         }
+        __syncthreads();                                      // every wave is done with plane za: its buffer takes the next plane
+        if (stage_next) convert_plane(zn & 1);
 
-        // ---- epilogue of fine plane fz: scale back, bias table, add to the convolution's x_e half in place, statistics of the sum
-        const int fz = 2 * c + pz;
+        // 3. the sum: scale back, bias table, + old value; stores; statistics
         const int clz = fz == 0 ? 0 : (fz == D - 1 ? 2 : 1);
-        const unsigned so_ = (unsigned)fz * (unsigned)(HW * 4);
         float psum = 0.0f, pcnt = 0.0f;
         f32x4 o_[8];
 #pragma unroll
@@ -217,13 +257,12 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
             const int fx0 = 2 * (cx0 + g_ * 8 + kg * 4);      // first of this group's 8 fine columns
             const float bfirst = fx0 == 0 ? brow[0] : bmid, blast = fx0 + 8 == W ? brow[2 * Cout] : bmid;
             const int bi = r_ * 8 + g_ * 4;
-            const f32x4 prev0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_, 0, 0));
-            const f32x4 prev1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_ + 16u, 0, 0));
             f32x4 v0 = {acc[0][bi], acc[1][bi], acc[0][bi + 1], acc[1][bi + 1]};
             f32x4 v1 = {acc[0][bi + 2], acc[1][bi + 2], acc[0][bi + 3], acc[1][bi + 3]};
             const f32x4 b0 = {bfirst, bmid, bmid, bmid}, b1 = {bmid, bmid, bmid, blast};
-            v0 = (v0 * inv_a * inv_b + b0) + prev0;
-            v1 = (v1 * inv_a * inv_b + b1) + prev1;
+            v0 = v0 * inv_a * inv_b + b0;
+            v1 = v1 * inv_a * inv_b + b1;
+            if (RMW) { v0 = v0 + prev[2 * j]; v1 = v1 + prev[2 * j + 1]; }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), orsrc, ooff[j] + so_, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), orsrc, ooff[j] + so_ + 16u, 0, 0);
             o_[2 * j] = v0; o_[2 * j + 1] = v1;
@@ -246,6 +285,7 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
             loc.n = pcnt; loc.mean = pmean; loc.m2 = pm2;
             run = stat_merge_nb(run, loc);
         }
+        __syncthreads();                                      // the next plane's staged input is complete
     }
 
     if (STATS) {
@@ -262,7 +302,7 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
             Stat st;
             st.n = 0.0f; st.mean = 0.0f; st.m2 = 0.0f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < UC_NT / 64; ++w) {
                 Stat ot;
                 ot.n = red[(w * 32 + tid) * 3]; ot.mean = red[(w * 32 + tid) * 3 + 1]; ot.m2 = red[(w * 32 + tid) * 3 + 2];
                 st = stat_merge(st, ot);

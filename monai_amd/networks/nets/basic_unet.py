@@ -413,12 +413,23 @@ class _Plan:
             hit = (key, ops.conv3d_k3_pack(cfg, conv.weight[:, : f[l]].contiguous()), ops.upconv_k4s2_pack(w4), table)
             net._packed[("upcat", name, cfg)] = hit
         _, packed_skip, packed_up, table = hit
-        with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
-            ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, None)
-        tiles = ops.upconv_k4s2_stat_tiles(*self.sp[l + 1])
-        stats = self._stats_buf(n * cout * tiles * 3)
-        with _prof.span("upconv_k4s2", 2.0 * 8 * int(src.shape[1]) * cout * d * h * w * n):
-            ops.upconv_k4s2_accum(src, src_nrm, packed_up, table, out, stats)
+        up_flops = 2.0 * 8 * int(src.shape[1]) * cout * d * h * w * n
+        if cfg == ops.conv3d_k3_h2_config():
+            # the composite term is WRITTEN, the split-precision convolution of the skip channels adds itself to it and leaves the statistics of the sum
+            with _prof.span("upconv_k4s2", up_flops):
+                ops.upconv_k4s2(src, src_nrm, packed_up, table, out, accumulate=False)
+            tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3)
+            with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
+                ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, stats, accumulate=True)
+        else:
+            # another kernel family for the skip half: it writes first, the composite term is added in place together with the statistics
+            with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
+                ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, None)
+            tiles = ops.upconv_k4s2_stat_tiles(*self.sp[l + 1])
+            stats = self._stats_buf(n * cout * tiles * 3)
+            with _prof.span("upconv_k4s2", up_flops):
+                ops.upconv_k4s2(src, src_nrm, packed_up, table, out, accumulate=True, stats=stats)
         norm = block.adn.N
         if isinstance(norm, nn.GroupNorm):
             ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)

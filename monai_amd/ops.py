@@ -338,11 +338,13 @@ def conv3d_k3_stat_tiles(cfg: int, d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv3d_k3_stat_tiles", cfg, d, h, w)
 
 
-def conv3d_k3(cfg, x, x_nrm, packed_w, bias, out, stats: Optional[torch.Tensor] = None):
-    """out = conv3x3x3(act(x)) + bias; optionally emits the fused InstanceNorm statistics records."""
+def conv3d_k3(cfg, x, x_nrm, packed_w, bias, out, stats: Optional[torch.Tensor] = None, accumulate: bool = False):
+    """out = conv3x3x3(act(x)) + bias; optionally emits the fused InstanceNorm statistics records.  accumulate=True: out += ... (the split-precision configuration
+    with records and statistics only; the statistics are those of the sum)"""
     _lib.require_device(x, x_nrm, packed_w, bias, out, stats)
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
-    _lib.lib().call("mh_conv3d_k3_f32", int(cfg), C.byref(xi), _lib.ptr(packed_w), _lib.ptr(bias), C.byref(xo), _lib.ptr(stats), _s(x))
+    _lib.lib().call("mh_conv3d_k3_accumulate_f32" if accumulate else "mh_conv3d_k3_f32", int(cfg), C.byref(xi), _lib.ptr(packed_w), _lib.ptr(bias), C.byref(xo),
+                    _lib.ptr(stats), _s(x))
     return out
 
 
@@ -447,12 +449,13 @@ def upconv_k4s2_stat_tiles(dl: int, hl: int, wl: int) -> int:
     return _lib.lib().query("mh_upconv_k4s2_stat_tiles", int(dl), int(hl), int(wl))
 
 
-def upconv_k4s2_accum(low, low_nrm, packed, bias_table, out, stats=None):
-    """out += convT(k4, s2, p1)(act(low)) + bias_table[position class]  in place (`out`: the raw skip half of the convolution); with `stats`
-    ([N * Cout * upconv_k4s2_stat_tiles(*low.shape[2:]) * 3] floats) the InstanceNorm statistics of the sum"""
+def upconv_k4s2(low, low_nrm, packed, bias_table, out, accumulate: bool = False, stats=None):
+    """accumulate=False: out = convT(k4, s2, p1)(act(low)) + bias_table[position class] (the accumulating convolution adds the skip half: `conv3d_k3(..., accumulate=True)`);
+    accumulate=True: added to `out` in place (`out`: the raw skip half of the convolution); then with `stats` ([N * Cout * upconv_k4s2_stat_tiles(*low.shape[2:]) * 3]
+    floats) the InstanceNorm statistics of the sum"""
     _lib.require_device(low, low_nrm, packed, bias_table, out, stats)
     xi, xo = _lib.tensor5(low, low_nrm), _lib.tensor5(out)
-    _lib.lib().call("mh_upconv_k4s2_accum_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias_table), C.byref(xo), _lib.ptr(stats), _s(out))
+    _lib.lib().call("mh_upconv_k4s2_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias_table), C.byref(xo), int(bool(accumulate)), _lib.ptr(stats), _s(out))
     return out
 
 

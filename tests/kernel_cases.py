@@ -208,6 +208,37 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
     return cfg
 
 
+def case_conv3d_accumulate(device, n, cin, cout, dims, tol=2e-5):
+    """the split-precision convolution in its accumulating form (conv3d_h2.h, ACC: out += conv + bias, statistics of the SUM): resident and streamed weight slabs, both
+    region shapes, ragged regions, two z-chunks -- against old + conv in float64, and the finalize kernel on the statistics"""
+    gen = torch.Generator().manual_seed(500 + cin + cout + dims[0])
+    cfg = ops.conv3d_k3_h2_config()
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(dims))))
+    old = torch.randn((n, cout) + tuple(dims), generator=gen) * 2.0
+    exp = old.double() + F.conv3d(_act(x.double(), nrm.double()), w.double(), b.double(), padding=1)
+    packed = ops.conv3d_k3_pack(cfg, w.to(device))
+    out = old.clone().to(device)
+    tiles = ops.conv3d_k3_stat_tiles(cfg, *dims)
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+    ops.conv3d_k3(cfg, x.to(device), nrm.to(device), packed, b.to(device), out, stats, accumulate=True)
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"accumulating conv {cin}->{cout} {dims}: max err {err}"
+    gamma = torch.rand(cout, generator=gen) + 0.5
+    beta = torch.randn(cout, generator=gen) * 0.2
+    nrm_out = torch.full((n, cout, 4), float("nan"), device=device)
+    ops.instnorm_finalize(stats, tiles, n, cout, gamma.to(device), beta.to(device), 1e-5, 0.1, nrm_out)
+    mean, var = got.mean(dim=(2, 3, 4)), got.var(dim=(2, 3, 4), unbiased=False)
+    alpha = gamma.double()[None] / torch.sqrt(var + 1e-5)
+    r = nrm_out.cpu().double()
+    assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+    assert (r[:, :, 1] - (beta.double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    return err
+
+
 def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=True, tol=2e-5):
     """UpCat's up half as ONE composite transposed convolution (csrc/kernels/upconv_h2.h): out += convT(k4, s2, p1)(act(low)) + bias table, against the two-layer
     evaluation conv3(deconv2(act(low)) + b_d) in float64 -- ragged tiles, both parities of every axis, the volume's borders (bias classes), several cout groups,
@@ -230,8 +261,12 @@ def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=Tr
     out = ya.clone().to(device)
     tiles = ops.upconv_k4s2_stat_tiles(*ldims)
     stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if fused_stats else None
-    ops.upconv_k4s2_accum(low.to(device), nrm.to(device), packed, table, out, stats)
+    ops.upconv_k4s2(low.to(device), nrm.to(device), packed, table, out, accumulate=True, stats=stats)
     got = out.cpu().double()
+    # the writing form (the accumulating convolution adds the skip half afterwards): the same term without the old values, bit for bit the difference's source
+    alone = torch.full((n, cout) + dims, float("nan"), device=device)
+    ops.upconv_k4s2(low.to(device), nrm.to(device), packed, table, alone, accumulate=False)
+    assert ((alone.cpu().double() + ya.double()) - exp).abs().max().item() < tol * max(1.0, exp.abs().max().item())
     err = (got - exp).abs().max().item()
     assert err < tol * max(1.0, exp.abs().max().item()), f"upconv {cin}->({cup})->{cout} {ldims}: max err {err}"
     if stats is not None:

@@ -273,3 +273,11 @@ def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
     with and without the deconvolution's bias, statistics of the sum included"""
     kc.case_upconv_k4s2("cpu", n, cup, cout, ldims)
     kc.case_upconv_k4s2("cpu", 1, cup, cout, ldims, with_bias=False, fused_stats=False)
+
+
+# (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / the 8 x 32 region shape in two z-chunks / 8 x 32 regions, four chunks of channels
+ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24, 8, 24)), (1, 64, 32, (2, 24, 56))]
+@pytest.mark.parametrize("n,cin,cout,dims", ACC_CASES)
+def test_conv3d_split_precision_accumulating(emu, n, cin, cout, dims):
+    """out += conv3x3x3(act(x)) + bias with the statistics of the sum (conv3d_h2.h, ACC): the second half of the UpCat path"""
+    kc.case_conv3d_accumulate("cpu", n, cin, cout, dims)

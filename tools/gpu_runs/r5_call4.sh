@@ -1,7 +1,7 @@
 # round 5, call 4: the composite transposed convolution of UpCat (kernels/upconv_h2.h) on the MI355X -- its kernel / end-to-end cases, the headline with the two-layer
 # path and with the fused one (same box, same process family), and a kernel trace of the fused step
 export TMPDIR=/tmp
-O=gpurun_out/r5c4; mkdir -p $O
+O=${O:-gpurun_out/r5c4}; mkdir -p $O
 timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_e2e_gpu.py -q -m gpu -x -k "upcat" 2>&1 | tail -4 | tee $O/gpu_tests_upcat.txt
 for f in 0 1 0 1; do
   MONAI_AMD_UPCAT_FUSED=$f timeout 200 python bench.py --steps 3 --warmup 1 --cpu-windows 0 --no-extra --no-pmc 2>/dev/null | grep "^{" > $O/bench_fused$f.json
