@@ -83,9 +83,9 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
 /* The blend in the summation order of the reference's BUFFERED schedule (monai/inferers/utils.py:239-253, 276-284, 324-348: `buffer_steps` > 0, `buffer_dim`):
  * windows stably sorted by their start along the buffered axis, groups of `buffer_steps` distinct starts accumulated from zero and then added to the output, the
  * count map in the sorted order -- bit-identical to the reference's buffered run (its non-buffered run differs from it by roundings).  Window-major logits as
- * mh_sw_blend_f32; `buffer_axis` 0 / 1 / 2 = z / y / x of the 3-D view.  At most 160 windows per axis. */
+ * mh_sw_blend_f32; `buffer_axis` 0 / 1 / 2 = z / y / x of the 3-D view; premultiplied != 0: `logits` hold logit * weight already (process_fn), `imp` is the count's map.  At most 160 windows per axis. */
 int mh_sw_blend_buffered_f32(const float* logits, int64_t window_stride, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
-                             const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int buffer_axis, int buffer_steps, void* stream);
+                             const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int buffer_axis, int buffer_steps, int premultiplied, void* stream);
 
 /* The blend over the MOSAIC logits layout (single-GPU fused path).  Windows i and i + m of an axis do not overlap when m * step >= roi, so the
  * windows of one residue class per axis (i mod m, m = 2^log2m in {1, 2, 4}; the last -- clipped -- window of an axis is a class of its own, index m)

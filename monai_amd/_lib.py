@@ -58,7 +58,7 @@ SIGNATURES = {
     "mh_foreground_bbox_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mh_crop_pad_f32": (_I, [_P, _P] + [_I] * 10 + [_F, _P]),
     "mh_sw_blend_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),
-    "mh_sw_blend_buffered_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _I, _P]),
+    "mh_sw_blend_buffered_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _I, _I, _P]),
     "mh_sw_mosaic_class_counts": (_I, [_I, _I, _IA]),
     "mh_sw_blend_mosaic_f32": (_I, [_P, C.POINTER(C.c_int64), _I, _I, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _P]),
     "mh_sw_blend_argmax_f32": (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _IA, _I, _IA, _I, _IA, _I, _I, _P]),

@@ -274,7 +274,7 @@ int mh_sw_blend_f32(const float* logits, int64_t window_stride, const float* imp
 
 // the blend in the summation order of the reference's buffered schedule (kernels/sliding.h: sw_blend_buffered_kernel)
 int mh_sw_blend_buffered_f32(const float* logits, int64_t window_stride, const float* imp, float* out, int K, int D, int H, int W, int rd, int rh, int rw,
-                             const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int buffer_axis, int buffer_steps, void* stream) {
+                             const int32_t* sz, int nz, const int32_t* sy, int ny, const int32_t* sx, int nx, int buffer_axis, int buffer_steps, int premultiplied, void* stream) {
     if (int e = blend_checks("sw_blend_buffered", logits, imp, out, K, D, H, W, rd, rh, rw, sz, nz, sy, ny, sx, nx, window_stride)) return e;
     if (buffer_axis < 0 || buffer_axis > 2 || buffer_steps < 1) return fail(MH_ERR_ARG, "sw_blend_buffered: buffer_axis in 0..2 and buffer_steps >= 1 (got %d, %d)", buffer_axis, buffer_steps);
     const bool v4 = W % 4 == 0 && rw % 4 == 0 && all_mult4(sx, nx);
@@ -284,9 +284,13 @@ int mh_sw_blend_buffered_f32(const float* logits, int64_t window_stride, const f
     hipStream_t s = (hipStream_t)stream;
     for (int k0 = 0; k0 < K; k0 += 4) {
         const int kt = K - k0 < 4 ? K - k0 : 4;
-#define MH_BB(KT_, V_) hipLaunchKernelGGL((sw_blend_buffered_kernel<KT_, V_>), dim3(blocks_for(total)), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, buffer_axis, buffer_steps, (long long)window_stride)
-        if (v4) { if (kt == 4) MH_BB(4, 4); else if (kt == 3) MH_BB(3, 4); else if (kt == 2) MH_BB(2, 4); else MH_BB(1, 4); }
-        else { if (kt == 4) MH_BB(4, 1); else if (kt == 3) MH_BB(3, 1); else if (kt == 2) MH_BB(2, 1); else MH_BB(1, 1); }
+#define MH_BB(KT_, V_)                                                                                                                                          \
+    {                                                                                                                                                          \
+        if (premultiplied) hipLaunchKernelGGL((sw_blend_buffered_kernel<KT_, V_, true>), dim3(blocks_for(total)), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, buffer_axis, buffer_steps, (long long)window_stride); \
+        else hipLaunchKernelGGL((sw_blend_buffered_kernel<KT_, V_, false>), dim3(blocks_for(total)), dim3(256), 0, s, logits, imp, out, K, k0, D, H, W, rd, rh, rw, g, buffer_axis, buffer_steps, (long long)window_stride);           \
+    }
+        if (v4) { if (kt == 4) MH_BB(4, 4) else if (kt == 3) MH_BB(3, 4) else if (kt == 2) MH_BB(2, 4) else MH_BB(1, 4) }
+        else { if (kt == 4) MH_BB(4, 1) else if (kt == 3) MH_BB(3, 1) else if (kt == 2) MH_BB(2, 1) else MH_BB(1, 1) }
 #undef MH_BB
     }
     return launched("sw_blend_buffered");

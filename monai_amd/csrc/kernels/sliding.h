@@ -145,7 +145,9 @@ sw_blend_kernel(const float* __restrict__ logits, const float* __restrict__ imp,
 // output (`output[slab] += buffer`), so a voxel covered by windows of two slabs sums (0 + part_1) + part_2 instead of one running sum; the count map adds the
 // weights of all covering windows in the sorted order.  The schedule itself (a memory-saving device on 16-80 GB cards) is not reproduced -- the all-window logits
 // sit in HBM -- but its ARITHMETIC is: the same bits as the reference's buffered run.  `bax` = the buffered axis (0 = z, 1 = y, 2 = x of the 3-D view).
-template <int KT, int VEC>
+// PREMUL (process_fn, utils.py:232-238): `logits` already hold `p * w_t` of the callback's weight map (a separately rounded product, as the reference forms it); the kernel only
+// adds, and the count uses `imp` = the map of the batch that was current at the first flush.
+template <int KT, int VEC, bool PREMUL = false>
 __global__ void __launch_bounds__(256)
 sw_blend_buffered_kernel(const float* __restrict__ logits, const float* __restrict__ imp, float* __restrict__ out, int K,
                          int k0, int D, int H, int W, int rd, int rh, int rw, WindowGrid g, int bax, int bsteps, long long wstride) {
@@ -193,7 +195,7 @@ sw_blend_buffered_kernel(const float* __restrict__ logits, const float* __restri
                 for (int v = 0; v < VEC; ++v) {
                     const float wt = imp[off + v];
 #pragma unroll
-                    for (int k = 0; k < KT; ++k) part[k][v] = __fadd_rn(part[k][v], __fmul_rn(lp[k * roi + v], wt));
+                    for (int k = 0; k < KT; ++k) part[k][v] = __fadd_rn(part[k][v], PREMUL ? lp[k * roi + v] : __fmul_rn(lp[k * roi + v], wt));
                     cnt[v] = __fadd_rn(cnt[v], wt);
                 }
             }

@@ -141,23 +141,30 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
 #pragma unroll
             for (int i = 0; i < 4; ++i) sreg[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[s], (unsigned)(i * DHWl * 4), 0));
     };
-    auto convert_plane = [&](int bufi) {
-        u32x2* xh = reinterpret_cast<u32x2*>(xs + bufi * UC_XB);
+    u32x2 chi[UC_NSLOT], clo[UC_NSLOT];                      // the converted pieces of the next plane, held until the plane they replace is no longer read
+    auto convert_regs = [&]() {          // activate + scale + split (vector ALU work that rides between the matrix instructions)
 #pragma unroll
         for (int s = 0; s < UC_NSLOT; ++s) {
-            if (squad[s] < 0) continue;
             _Float16 h_[4], l_[4];
+            const int q_ = max(squad[s], 0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int c = 4 * squad[s] + i;
+                const int c = 4 * q_ + i;
                 const float y = soff[s] != UC_DROP ? act(sreg[s][i], nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]) : 0.0f;
                 h2_split(y, h_[i], l_[i]);
             }
             const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
-            xh[scell[s]] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
-            xh[scell[s] + 2 * UC_XP] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+            chi[s] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+            clo[s] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
         }
     };
+    auto write_regs = [&](int bufi) {
+        u32x2* xh = reinterpret_cast<u32x2*>(xs + bufi * UC_XB);
+#pragma unroll
+        for (int s = 0; s < UC_NSLOT; ++s)
+            if (squad[s] >= 0) { xh[scell[s]] = chi[s]; xh[scell[s] + 2 * UC_XP] = clo[s]; }
+    };
+    auto convert_plane = [&](int bufi) { convert_regs(); write_regs(bufi); };
 
     // ---- operands of this lane: A = coarse voxel (row 2 wave + (r >> 4), column r & 15), B = cout r; k group = lane >> 5
     const int r32 = lane & 31, kg = lane >> 5;
@@ -181,7 +188,17 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     }
     Stat run;
     run.n = 0.0f; run.mean = 0.0f; run.m2 = 0.0f;
-    const float* bt = btab + co;       // bias table [27][Cout]: class (first / interior / last) per axis
+    // bias table [27][Cout] (class first / interior / last per axis): the 3 z classes x this wave's two rows x 3 x classes of this lane's cout, once (a table load
+    // inside the epilogue would sit, with its latency, between the last matrix instruction and the stores of every plane)
+    float btr[3][2][3];
+#pragma unroll
+    for (int cz_ = 0; cz_ < 3; ++cz_)
+#pragma unroll
+        for (int r_ = 0; r_ < 2; ++r_) {
+            const int cly = fyv[r_] == 0 ? 0 : (fyv[r_] == H - 1 ? 2 : 1);
+#pragma unroll
+            for (int cx_ = 0; cx_ < 3; ++cx_) btr[cz_][r_][cx_] = btab[(long long)((cz_ * 3 + cly) * 3 + cx_) * Cout + co];
+        }
 
     // prologue: the first plane's two coarse planes
     {
@@ -208,41 +225,64 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         const bool stage_next = c + 1 < cz_e && zn < Dl;
         if (stage_next) load_plane(zn);
 
-        // 2. matrix instructions
+        // 2. matrix instructions: 16 groups (tz, k step, ty, px) of 8 operand reads -> 6 instructions; a group's operands are fetched while the group before it
+        //    multiplies (two register sets), the scheduler deals the reads -- and, in the second half, the conversion of the next plane's raw values -- out over the gaps
+        //    (a wave issues in order: an operand read right in front of its use costs the LDS latency every time; conv3d_h2.h)
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-#pragma unroll
-        for (int tz = 0; tz < 2; ++tz) {
-            const int z = tz == 0 ? za : zb;
-            if (z < 0 || z >= Dl) continue;                   // zero padding: nothing to add (wave-uniform)
-            const uint4* xb = xs + (z & 1) * UC_XB;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ty = 0; ty < 2; ++ty) {
-                    uint4 ah[3], al[3];
-#pragma unroll
-                    for (int o = 0; o < 3; ++o) {
-                        const uint4* ap = xb + ks * (2 * UC_PV) + abase + ty * UC_RX + o;
-                        ah[o] = ap[0];
-                        al[o] = ap[UC_XP];
-                    }
-#pragma unroll
-                    for (int px = 0; px < 2; ++px)
-#pragma unroll
-                        for (int tx = 0; tx < 2; ++tx) {
-                            const uint4* bp = ws + (((tz * 2 + ty) * 2 + px) * 2 + tx) * UC_WC + ks * 64 + bbase;
-                            const uint4 bh = bp[0], bl = bp[128];
-                            const int o = tx + px;
-                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[o]), __builtin_bit_cast(f16x8, bh), acc[px], 0, 0, 0);
-                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[o]), __builtin_bit_cast(f16x8, bh), acc[px], 0, 0, 0);
-                            acc[px] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[o]), __builtin_bit_cast(f16x8, bl), acc[px], 0, 0, 0);
-                        }
-                }
+        uint4 ahq[2][2], alq[2][2], bhq[2][2], blq[2][2];
+#define UC_FETCH(B_, XB_, TZ_, G_)                                                                    \
+    {                                                                                                 \
+        constexpr int ks_ = ((G_) >> 2) & 1, ty_ = ((G_) >> 1) & 1, px_ = (G_) & 1;                   \
+        const uint4* ap_ = (XB_) + ks_ * (2 * UC_PV) + abase + ty_ * UC_RX + px_;                     \
+        const uint4* bp_ = ws + ((((TZ_) * 2 + ty_) * 2 + px_) * 2) * UC_WC + ks_ * 64 + bbase;       \
+        ahq[B_][0] = ap_[0]; ahq[B_][1] = ap_[1]; alq[B_][0] = ap_[UC_XP]; alq[B_][1] = ap_[UC_XP + 1]; \
+        bhq[B_][0] = bp_[0]; blq[B_][0] = bp_[128]; bhq[B_][1] = bp_[UC_WC]; blq[B_][1] = bp_[UC_WC + 128]; \
+    }
+#define UC_MM(B_, PX_)                                                                                \
+    _Pragma("unroll") for (int tx_ = 0; tx_ < 2; ++tx_) {                                             \
+        acc[PX_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahq[B_][tx_]), __builtin_bit_cast(f16x8, bhq[B_][tx_]), acc[PX_], 0, 0, 0); \
+        acc[PX_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, alq[B_][tx_]), __builtin_bit_cast(f16x8, bhq[B_][tx_]), acc[PX_], 0, 0, 0); \
+        acc[PX_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahq[B_][tx_]), __builtin_bit_cast(f16x8, blq[B_][tx_]), acc[PX_], 0, 0, 0); \
+    }
+#define UC_GROUP(XB_, TZ_, G_, NV_)                                                                   \
+    {                                                                                                 \
+        if ((G_) + 1 < 8) UC_FETCH(((G_) + 1) & 1, XB_, TZ_, ((G_) + 1 < 8 ? (G_) + 1 : 0))            \
+        UC_MM((G_) & 1, (G_) & 1)                                                                     \
+        _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                            \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x002, NV_, 0);                                      \
+        }                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define UC_HALF(XB_, TZ_, NV_)                                                                        \
+    {                                                                                                 \
+        UC_FETCH(0, XB_, TZ_, 0)                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        UC_GROUP(XB_, TZ_, 0, NV_) UC_GROUP(XB_, TZ_, 1, NV_) UC_GROUP(XB_, TZ_, 2, NV_) UC_GROUP(XB_, TZ_, 3, NV_) \
+        UC_GROUP(XB_, TZ_, 4, NV_) UC_GROUP(XB_, TZ_, 5, NV_) UC_GROUP(XB_, TZ_, 6, NV_) UC_GROUP(XB_, TZ_, 7, NV_) \
+    }
+        if (za >= 0 && za < Dl) {                             // zero padding: nothing to add (wave-uniform)
+            const uint4* xb = xs + (za & 1) * UC_XB;
+            UC_HALF(xb, 0, 2)
         }
+        if (zb >= 0 && zb < Dl) {
+            const uint4* xb = xs + (zb & 1) * UC_XB;
+            if (stage_next) {      // the raw values requested at the top have arrived: their conversion shares this half's matrix time
+                convert_regs();
+                UC_HALF(xb, 1, 8)
+            } else {
+                UC_HALF(xb, 1, 2)
+            }
+        } else if (stage_next) convert_regs();
+#undef UC_HALF
+#undef UC_GROUP
+#undef UC_MM
+#undef UC_FETCH
         __syncthreads();                                      // every wave is done with plane za: its buffer takes the next plane
-        if (stage_next) convert_plane(zn & 1);
+        if (stage_next) write_regs(zn & 1);
 
         // 3. the sum: scale back, bias table, + old value; stores; statistics
         const int clz = fz == 0 ? 0 : (fz == D - 1 ? 2 : 1);
@@ -251,11 +291,11 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r_ = j >> 1, g_ = j & 1;
-            const int cly = fyv[r_] == 0 ? 0 : (fyv[r_] == H - 1 ? 2 : 1);
-            const float* brow = bt + (long long)((clz * 3 + cly) * 3) * Cout;
-            const float bmid = brow[Cout];
+            const float bmid = clz == 0 ? btr[0][r_][1] : (clz == 1 ? btr[1][r_][1] : btr[2][r_][1]);
+            const float bfst = clz == 0 ? btr[0][r_][0] : (clz == 1 ? btr[1][r_][0] : btr[2][r_][0]);
+            const float blst = clz == 0 ? btr[0][r_][2] : (clz == 1 ? btr[1][r_][2] : btr[2][r_][2]);
             const int fx0 = 2 * (cx0 + g_ * 8 + kg * 4);      // first of this group's 8 fine columns
-            const float bfirst = fx0 == 0 ? brow[0] : bmid, blast = fx0 + 8 == W ? brow[2 * Cout] : bmid;
+            const float bfirst = fx0 == 0 ? bfst : bmid, blast = fx0 + 8 == W ? blst : bmid;
             const int bi = r_ * 8 + g_ * 4;
             f32x4 v0 = {acc[0][bi], acc[1][bi], acc[0][bi + 1], acc[1][bi + 1]};
             f32x4 v1 = {acc[0][bi + 2], acc[1][bi + 2], acc[0][bi + 3], acc[1][bi + 3]};

@@ -143,8 +143,10 @@ def sliding_window_inference(
     (windows sorted by their start along ``buffer_dim``, slabs of ``buffer_steps`` distinct starts accumulated from zero and then added to the output), so
     its result differs from the plain one by roundings (tests/golden/buffered.npz: up to 26 000 voxels of a small volume, <= 6e-7).  The schedule itself --
     a memory-saving device -- is not reproduced (the logits of all windows sit in HBM), its ARITHMETIC is: with ``buffer_steps`` the blend runs in the
-    buffered order (``mh_sw_blend_buffered_f32``) and returns the bits of the reference's buffered run (single-tensor predictors, as in the reference, which
-    ignores further outputs there; ``process_fn`` / multi-resolution outputs with ``buffer_steps`` are not on the HIP path).
+    buffered order (``mh_sw_blend_buffered_f32``) and returns the bits of the reference's buffered run.  With ``process_fn`` / ``with_coord`` / tuple or dict
+    outputs the predictor is also CALLED as the reference calls it there (windows in the sorted order, batches that end at the slab boundaries, the sorted
+    slices as coordinates; only the FIRST output is blended, as utils.py:244 does; the count map is the weight map of the batch at the first flush):
+    ``_buffered_batches``.  Multi-resolution outputs with ``buffer_steps`` fail in the reference too and are refused.
     Other differences, all result-neutral: when the logits of all windows do not fit in HBM the volume is processed slab by slab along its first spatial
     axis with bit-identical results, see ``_slabwise``; ``sw_device`` must be a ROCm device (a CPU volume is moved to it once; half / bfloat16 volumes are widened to fp32 and the result
     returned in the caller's dtype).  A predictor with ``forward_into`` (the conv engines) is given up to 64 windows per launch
@@ -159,8 +161,8 @@ def sliding_window_inference(
             raise ValueError(f"buffer_dim must be in [{-num_spatial_dims}, {num_spatial_dims}], got {buffer_dim}.")
         if buffer_dim < 0:
             buffer_dim += num_spatial_dims
-        if buffer_dim >= num_spatial_dims or process_fn is not None or with_coord:
-            raise NotImplementedError("monai_amd: buffer_steps with buffer_dim == the number of spatial dims, process_fn or with_coord is not on the HIP path")
+        if buffer_dim >= num_spatial_dims:
+            raise NotImplementedError("monai_amd: buffer_steps with buffer_dim == the number of spatial dims is not on the HIP path")
         if kwargs.get("_monai_amd_argmax") is not None:       # rejected BEFORE any window is predicted (a fall-through would otherwise predict them all twice)
             raise NotImplementedError("monai_amd: the fused argmax epilogue with buffer_steps is not on the HIP path (blend in the buffered order, then AsDiscrete)")
         if not kwargs.pop("_monai_amd_buffered_inner", False):
@@ -297,6 +299,10 @@ def sliding_window_inference(
     zscales = None
 
     fused = fused and hasattr(predictor, "out_channels") and getattr(predictor, "window_sized_output", True)
+    # buffer_steps with a callback in the loop: the predictor sees the reference's buffered batch schedule (sorted windows, batches cut at the slab ends)
+    buffered_calls = buffered and not fused and (process_fn is not None or with_coord or shard.world == 1)
+    if buffered_calls and shard.world > 1:
+        raise NotImplementedError("monai_amd: buffer_steps with process_fn / with_coord under window sharding is not on the HIP path")
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
         steps = list(enumerate(my_rounds))
@@ -308,6 +314,15 @@ def sliding_window_inference(
             except ImportError:
                 pass
         pending = []
+        if buffered_calls:
+            steps = []            # the windows of this image are predicted here, in the reference's buffered order; the blend below reads their rows
+            keys_b, logits, count_map = _buffered_batches(b, vol3, in_ch, grid3, starts, roi_size, roi3, num_win, int(sw_batch_size), predictor, process_fn, with_coord,
+                                                          imp, buffer_dim, int(buffer_steps), shard, nb, compute_dtype, dev, args, kwargs, logits)
+            if b == 0:
+                dict_keys = keys_b
+                seg_shapes, zscales = [tuple(roi_size)], [None]
+                if count_map is not None:
+                    proc_weights = [count_map]
         for q, (w0, n) in steps:
             if n > 0 and fused:
                 if logits is None:
@@ -404,7 +419,8 @@ def sliding_window_inference(
             nbytes = 4.0 * nlog + outputs[ss][b].numel() * outputs[ss][b].element_size()  # logits read once + output written once
             with _prof.span("sw_blend", nbytes):
                 if buffered:      # the reference's buffered summation order (single output at window resolution; checked after the first predictor batch)
-                    ops.sw_blend_buffered(lg[:num_win], weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1), buffer_dim + (3 - num_spatial_dims), int(buffer_steps))
+                    ops.sw_blend_buffered(lg[:num_win], proc_weights[ss] if proc_weights is not None else weights[ss], outputs[ss][b], g, _to3(seg_shapes[ss], 1),
+                                          buffer_dim + (3 - num_spatial_dims), int(buffer_steps), premultiplied=proc_weights is not None)
                 elif lg is mosaic:
                     ops.sw_blend_mosaic(mosaic, _factored_map(imp_key, imp, roi3, mode, sigma_scale, dev) if imp_key is not None else weights[ss], outputs[ss][b])
                 elif argmax_dtype is not None:
@@ -436,6 +452,69 @@ def sliding_window_inference(
     if any(pad_size):
         kwargs.update({"pad_size": pad_size})
     return _pack_struct(finals, dict_keys)
+
+
+def _buffered_batches(b, vol3, in_ch, grid3, starts, roi_size, roi3, num_win, sw_batch_size, predictor, process_fn, with_coord, imp, buffer_dim, buffer_steps,
+                      shard, nb, dtype, dev, args, kwargs, logits):
+    """The predictor calls of the reference's buffered schedule for image `b` (monai/inferers/utils.py:215-253 with `_create_buffered_slices`, :324-348): windows
+    stably sorted by their start along `buffer_dim`; flush boundaries after every min(#distinct starts, buffer_steps) distinct starts; batches of `sw_batch_size`
+    sorted windows that END at a boundary; `with_coord` hands over the sorted slices; only the first of several outputs is kept (utils.py:244).  Every window's
+    (weighted, when a `process_fn` returned the map) prediction goes to row = its row-major index of ONE all-window buffer: `mh_sw_blend_buffered_f32` then sums in
+    the buffered order.  -> (dict keys of the predictor's output or None, [logits], the count's weight map or None = the importance map)."""
+    import itertools
+
+    import numpy as np
+
+    nsp = len(roi_size)
+    wins = np.asarray(list(itertools.product(*[range(len(s)) for s in starts])), dtype=np.int64)             # [num_win, nsp] per-axis window numbers, row-major
+    start_along = np.asarray(starts[buffer_dim], dtype=np.int64)[wins[:, buffer_dim]]
+    order = np.argsort(start_along, kind="mergesort")
+    _, counts = np.unique(start_along[order], return_counts=True)
+    b_ends = np.cumsum(counts).tolist()
+    x = [0, *b_ends][:: min(len(b_ends), buffer_steps)]
+    if x[-1] < b_ends[-1]:
+        x.append(b_ends[-1])
+    win_buf = torch.empty((sw_batch_size, in_ch) + tuple(roi3), dtype=dtype, device=dev)
+    imp_dev = imp.to(dev)
+    dict_keys, count_map = None, None
+    for gi in range(len(x) - 1):
+        for g0 in range(x[gi], x[gi + 1], sw_batch_size):
+            idx = [int(order[i]) for i in range(g0, min(g0 + sw_batch_size, x[gi + 1]))]
+            for k, w in enumerate(idx):
+                ops.window_extract(vol3, grid3, w, 1, roi3, win_buf[k : k + 1])
+            win_data = win_buf[: len(idx)].reshape((len(idx), in_ch) + tuple(roi_size))
+            if with_coord:
+                coords = [[slice(b, b + 1), slice(None)] + [slice(int(starts[d][wins[w, d]]), int(starts[d][wins[w, d]]) + int(roi_size[d])) for d in range(nsp)] for w in idx]
+                seg_out = predictor(win_data, coords, *args, **kwargs)
+            else:
+                seg_out = predictor(win_data, *args, **kwargs)
+            dict_keys, segs = _flatten_struct(seg_out)
+            w_t = None
+            if process_fn is not None:
+                segs, w_t = process_fn(segs, win_data, imp_dev)
+                segs = tuple(segs) if isinstance(segs, (list, tuple)) else (segs,)
+                if w_t.dim() == nsp:
+                    w_t = w_t[None, None]
+                w_t = w_t.to(dtype=dtype, device=dev)
+            seg = segs[0]
+            if tuple(seg.shape[2:]) != tuple(roi_size):
+                raise NotImplementedError("monai_amd: buffer_steps with a predictor whose output is not window-sized is not on the HIP path (the reference fails there too)")
+            if seg.dtype != dtype and seg.is_floating_point():
+                seg = seg.to(dtype)
+            _lib.require_device(seg)
+            if logits is None:
+                logits = [_alloc_logits(shard, nb, int(seg.shape[1]), roi3, dtype, dev)]
+            for k, w in enumerate(idx):
+                dst = logits[0][w]
+                if w_t is None:
+                    dst.copy_(seg[k].reshape(dst.shape))
+                else:
+                    torch.mul(seg[k].reshape(dst.shape), w_t[0 if w_t.shape[0] == 1 else k].reshape((-1,) + tuple(dst.shape[1:])), out=dst)      # `p * w_t`
+        if gi == 0 and b == 0 and process_fn is not None:
+            count_map = w_t[0, 0].reshape(tuple(roi3)).contiguous().clone()          # the count map is built at the FIRST flush from the map current then (utils.py:264-275)
+    if dict_keys is not None:
+        dict_keys = dict_keys[:1]
+    return dict_keys, logits, count_map
 
 
 # ---- importance maps: host evaluation and upload happen once per (patch size, mode, sigma, dtype), not once per call -------------------------

@@ -62,9 +62,11 @@ def sw_blend(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: G
     return out
 
 
-def sw_blend_buffered(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int], buffer_axis: int, buffer_steps: int) -> torch.Tensor:
+def sw_blend_buffered(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor, grid: Grid, roi: Sequence[int], buffer_axis: int, buffer_steps: int,
+                      premultiplied: bool = False) -> torch.Tensor:
     """`sw_blend` in the summation order of the reference's buffered schedule (monai/inferers/utils.py:239-253, 276-284, 324-348): windows sorted by their
-    start along `buffer_axis` (0 / 1 / 2 of the 3-D view), groups of `buffer_steps` distinct starts summed from zero and added to the output."""
+    start along `buffer_axis` (0 / 1 / 2 of the 3-D view), groups of `buffer_steps` distinct starts summed from zero and added to the output.
+    premultiplied: `logits` already hold logit * weight (process_fn); only the count uses `imp`."""
     _lib.require_device(logits, imp, out)
     if not (imp.is_contiguous() and out.is_contiguous()):
         raise RuntimeError("monai_amd.sw_blend_buffered: contiguous tensors required")
@@ -73,7 +75,7 @@ def sw_blend_buffered(logits: torch.Tensor, imp: torch.Tensor, out: torch.Tensor
     ws = _window_rows(logits, k, roi, len(sz) * len(sy) * len(sx), "sw_blend_buffered")
     _lib.lib().call(
         "mh_sw_blend_buffered_f32", _lib.ptr(logits), ws, _lib.ptr(imp), _lib.ptr(out), k, d, h, w, int(roi[0]), int(roi[1]), int(roi[2]),
-        _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), int(buffer_axis), int(buffer_steps), _s(out),
+        _lib.int_array(sz), len(sz), _lib.int_array(sy), len(sy), _lib.int_array(sx), len(sx), int(buffer_axis), int(buffer_steps), int(bool(premultiplied)), _s(out),
     )
     return out
 

@@ -194,3 +194,8 @@ def test_mosaic_layout_equals_window_major(emu):
 def test_upcat_fused_vs_two_layers_and_reference(emu):
     """UpCat without its up-sampled intermediate (kernels/upconv_h2.h) inside BasicUNet: golden logits of the real reference + the engine's two-layer path"""
     print(ec.case_net_upcat_fused_vs_two_layers("cpu"))
+
+
+def test_buffered_schedule_with_callbacks_bitwise_vs_reference(emu):
+    """SURVEY 8a row a7 with the rest of its call surface: process_fn / with_coord / tuple and dict outputs under buffer_steps"""
+    assert ec.case_buffered_calls_vs_golden("cpu") == 6
