@@ -99,12 +99,15 @@ def HOST_LAYOUT_UNDER_QUOTA(cpus: int):
     return 2, max(1, cpus // 2)
 
 
-def _short_parity(rep: dict, family: str) -> dict:
-    """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py)"""
-    return {"family": family, "voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "tolerance": rep["tolerance"],
-            "argmax_mismatch_voxels": rep["argmax_mismatch_voxels"], "mismatch_outside_margin": rep["mismatch_outside_margin"],
-            "max_top2_margin_at_mismatch": rep["max_top2_margin_at_mismatch"], "min_top2_margin": rep["min_top2_margin"],
-            "voxels_with_margin_below_1e-4": rep["voxels_with_margin_below_1e-4"], "min_class_dice": rep["min_class_dice"], "ok": rep["ok"]}
+def _short_parity(rep: dict, family: str, full: bool = True) -> dict:
+    """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py); full=False: the extras' brief form"""
+    out = {"family": family, "voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "tolerance": rep["tolerance"],
+           "argmax_mismatch_voxels": rep["argmax_mismatch_voxels"], "mismatch_outside_margin": rep["mismatch_outside_margin"],
+           "min_class_dice": rep["min_class_dice"], "ok": rep["ok"]}
+    if full:
+        out.update({"max_top2_margin_at_mismatch": rep["max_top2_margin_at_mismatch"], "min_top2_margin": rep["min_top2_margin"],
+                    "voxels_with_margin_below_1e-4": rep["voxels_with_margin_below_1e-4"]})
+    return out
 
 
 def _oracle_inferer(sd, sub_cpu, rr, procs: int, threads: int, factory=None):
@@ -201,8 +204,7 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
     per_win = dt / nsub
     rec = {"value": size ** 3 / (nfull * per_win), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
            "sample": f"{what}, {procs}x{threads} of {ncpu} threads",
-           "windows": nsub, "windows_total": nfull, "seconds": dt, "s_per_window": per_win, "probe_s_per_window_one_group": t_win,
-           "pool_efficiency": t_win / max(per_win * procs, 1e-9)}
+           "windows": nsub, "windows_total": nfull, "seconds": dt, "s_per_window": per_win}
     spread = None
     if spread_budget_s > 0:
         try:
@@ -348,9 +350,7 @@ def _traffic(roof: dict, key: str) -> None:
     td = pmc_traffic(key)
     if td:
         roof["traffic"] = td["hbm_bytes_per_launch"]
-        roof["traffic_src"], roof["traffic_ratio_to_algorithmic"], roof["traffic_fetch_calibrated"] = td["measured"], td["ratio"], td["fetch_calibrated"]
-        if "write_bytes" in td:
-            roof["traffic_write_bytes"] = td["write_bytes"]
+        roof["traffic_src"], roof["traffic_ratio"], roof["fetch_calibrated"] = td["measured"], td["ratio"], td["fetch_calibrated"]
 
 
 def conv_roofline(spans, steps: int, ms: float, roi: int):
@@ -366,22 +366,19 @@ def conv_roofline(spans, steps: int, ms: float, roi: int):
     tf = conv["work"] / (conv["ms_total"] * 1e-3) / 1e12
     cfg_id = int(key.split("/cfg")[1])
     ncfg = _ops.conv3d_k3_num_configs()
-    peak, extra, pmc_key = PEAK_FP32_TFLOPS, {}, "conv3d_k3_mfma_kernel"
+    peak, pmc_key = PEAK_FP32_TFLOPS, "conv3d_k3_mfma_kernel"
     if cfg_id == _ops.conv3d_k3_h2_config():        # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
         kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel (v_mfma_f32_32x32x16_f16, hi+lo split)", 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
-        extra = {"fp32_equivalent_tflops": tf, "piece_products_per_multiply": 3}
     elif cfg_id == _ops.conv3d_k3_h2c_config():     # the same kernel in output channel groups of 16: 6 x 32 columns issued per 3 x 16 useful ones, x 3 piece products
         kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel<C16> (two z-taps per instruction)", 1.0 / 4.0, PEAK_F16_TFLOPS, "conv3d_k3_h2c_kernel"
-        extra = {"fp32_equivalent_tflops": tf, "piece_products_per_multiply": 3, "columns_issued_per_useful": 4.0 / 3.0}
     elif cfg_id == ncfg:                            # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)
         kname, gain, pmc_key = "conv3d_k3_wino2p_kernel (F(2x2,3x3), v_mfma_f32_16x16x4_f32)", 2.25, "conv3d_k3_wino2p_kernel"
     else:
         kname, gain = f"conv3d_k3_mfma_kernel cfg{cfg_id} (v_mfma_f32_32x32x2_f32)", 1.0
     issued = tf / gain
     roof = {"bound": "mfma", "achieved": issued, "peak": peak, "unit": "TFLOP/s", "frac": issued / peak, "traffic": None, "kernel": kname,
-            "algorithmic_tflops": tf, "issued_per_algorithmic_flop": 1.0 / gain, **extra,
-            "launches": conv["launches"], "ms_avg": conv["ms_avg"], "flops_per_launch_issued": conv["work"] / conv["launches"] / gain,
-            "share_of_step": conv["ms_total"] / steps / ms}
+            "algorithmic_tflops": tf, "issued_per_algorithmic_flop": 1.0 / gain,
+            "launches": conv["launches"], "ms_avg": conv["ms_avg"], "share_of_step": conv["ms_total"] / steps / ms}
     _traffic(roof, pmc_key)
     return roof
 
@@ -449,7 +446,7 @@ def extra_fp32_exact(args, vol, net, inferer, sync, shared):
         res = {"conv_algo": "fp32", "steps": 2, "warmup": 1, "ms_per_step": ms, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s",
                "roofline": _roof_brief(conv_roofline(spans, 2, ms, args.roi))}
         if shared.get("ref") is not None:
-            res["parity"] = _short_parity(oracle.label_parity(inferer(shared["sub"], net), shared["ref"], tol=1e-4), "fp32-exact")
+            res["parity"] = _short_parity(oracle.label_parity(inferer(shared["sub"], net), shared["ref"], tol=1e-4), "fp32-exact", full=False)
             res["parity"]["compared"] = shared["what"]
     finally:
         config.CONV_ALGO = saved
@@ -504,7 +501,7 @@ def extra_config3(args, vol, sync, dev):
             ref = oracle.sliding_window_inference(sub_cpu, rr, 4, lambda w: ounetr.unetr_forward(sd, w), overlap=0.5, mode="gaussian", sigma_scale=0.125)
         dt_cpu = time.perf_counter() - t0
         got = inferer(sub, net)
-    res["parity"] = _short_parity(oracle.label_parity(got, ref, tol=1e-4), "split-fp16")
+    res["parity"] = _short_parity(oracle.label_parity(got, ref, tol=1e-4), "split-fp16", full=False)
     res["parity"]["compared"] = f"{ext[0]}x{ext[1]}x{ext[2]} corner, {nsub} windows"
     res["cpu_baseline"] = {"value": float(args.size) ** 3 / (nfull * dt_cpu / nsub), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
                            "sample": f"{nsub} of {nfull} windows, {procs}x{threads} of {ncpu} threads", "seconds": dt_cpu, "s_per_window": dt_cpu / nsub}
@@ -562,11 +559,11 @@ def extra_config4(dev):  # noqa: C901
         ms = timeit(lambda: ops.affine_resample(raw, m.reshape(-1), osz, "bilinear", "border", False, f64))
         nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
         res["runs"].append({"op": f"kernel: separable resample {'fp64' if f64 else 'fp32'}", "bound": "hbm", "ms": ms, "GBps": nb / ms / 1e6,
-                            "frac": nb / ms / 1e6 / PEAK_HBM_GBS, "bytes": nb})
+                            "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     k = gaussian_1d(1.0).numpy()
     ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
     res["runs"].append({"op": "kernel: fused gaussian 9 taps", "bound": "hbm", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
-                        "frac": 8.0 * raw.numel() / ms / 1e6 / PEAK_HBM_GBS, "bytes": 8.0 * raw.numel()})
+                        "frac": 8.0 * raw.numel() / ms / 1e6 / PEAK_HBM_GBS})
     # parity on a 128^3 volume
     torch.manual_seed(11)
     small = torch.rand(1, 128, 128, 128)
@@ -585,7 +582,7 @@ def extra_config4(dev):  # noqa: C901
     res["parity_vs_cpu_restatement"] = {"spacing_max_abs": float((y.cpu().as_tensor() - ref).abs().max()), "spacing_tol": 2e-6, "spacing_shape": list(y.shape),
                                         "gaussian_max_abs": float((g - gref[0]).abs().max()), "gaussian_tol": 1e-5, "compared": "128^3 volume"}
     for r_ in res["runs"]:
-        r_["frac_of_copy_ceiling"] = r_["GBps"] / copy_gbps
+        r_["frac_of_copy_ceiling"] = r_.pop("GBps") / copy_gbps          # GB/s = frac x 8000
     res["parity_vs_cpu_restatement"]["ok"] = bool(res["parity_vs_cpu_restatement"]["spacing_max_abs"] < 2e-6 and res["parity_vs_cpu_restatement"]["gaussian_max_abs"] < 1e-5)
     # CPU baseline: the reference path of both transforms -- restated with the same ATen operators (oracle/resample.py: img.to(dtype) -> normalised theta ->
     # F.affine_grid + F.grid_sample -> float32; separable_filtering: F.pad + depthwise F.conv3d per axis) -- on ONE 512^3 volume on the host cores, and the product's
@@ -597,7 +594,7 @@ def extra_config4(dev):  # noqa: C901
     x0 = v0.as_tensor().cpu()
     y0 = sp(v0)
     xf0 = torch.from_numpy(np.linalg.inv(aff) @ y0.affine.cpu().numpy())
-    cpu = {"cores": threads, "of_host_threads": ncpu, "kind": "port", "volume": f"one {e}^3"}
+    cpu = {"cores": threads, "kind": "port", "volume": f"one {e}^3"}
     with torch.no_grad():
         for name, dt_ in (("spacing_fp64_s", torch.float64), ("spacing_fp32_s", torch.float32)):
             t0 = time.perf_counter()
@@ -616,11 +613,7 @@ def extra_config4(dev):  # noqa: C901
             gref0 = F.conv3d(F.pad(gref0, pad), kk.reshape(shape))
         cpu["gaussian_s"] = time.perf_counter() - t0
         cpu["gaussian_512_max_abs_vs_product"] = float((gs(plain[0]).cpu() - gref0[0]).abs().max())
-    nvox_out = float(y0.numel())
-    cpu["spacing_fp64_output_voxels_per_s"] = nvox_out / cpu["spacing_fp64_s"]
-    cpu["spacing_fp32_output_voxels_per_s"] = nvox_out / cpu["spacing_fp32_s"]
-    cpu["gaussian_voxels_per_s"] = float(e) ** 3 / cpu["gaussian_s"]
-    res["cpu_baseline"] = cpu
+    res["cpu_baseline"] = cpu          # output voxels / s = 410 * 410 * 819 / spacing_*_s, 512^3 / gaussian_s
     return res
 
 
@@ -636,7 +629,7 @@ def per_rank_breakdown(spans, steps: int, world: int, dev, dist):
     return [{"rank": r, "predictor_ms": float(t[0]), "gather_wait_ms": float(t[1]), "blend_ms": float(t[2])} for r, t in enumerate(allr)]
 
 
-def _rounded(obj, digits: int = 6):
+def _rounded(obj, digits: int = 5):
     """floats to `digits` significant digits: the line is a record of measurements, not of double-precision noise (and stays short)"""
     if isinstance(obj, float):
         return float(f"{obj:.{digits}g}") if obj == obj and abs(obj) != float("inf") else obj
@@ -786,7 +779,7 @@ def main(argv=None):
             if par is not None:
                 line["parity"] = _short_parity(par, family)
                 line["parity"]["compared"] = shared.get("what", "")
-                rec["parity_vs_gpu"] = {k: par[k] for k in ("ok", "mismatch_outside_margin", "max_abs_logit_diff", "argmax_mismatch_voxels", "voxels")}
+                rec["parity_vs_gpu"] = {k: par[k] for k in ("ok", "mismatch_outside_margin", "max_abs_logit_diff", "voxels")}
             line["cpu_baseline"] = rec
             if spread is not None:
                 line["reference_self_spread"] = spread

@@ -256,9 +256,10 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
  *   bias_t  [heads][S][S] or NULL         relative position bias, TRANSPOSED: bias_t[h][key][query] = bias[h][query][key]
  *   mask    [nW][S][S] or NULL            shifted-window mask (0 / -100, symmetric); window w uses mask[w % nW]
  *   out     [BW][S][heads * head_dim]
- * head_dim 8 / 16 / 32 (feature sizes 24 / 48 / 96). */
+ * head_dim 8 / 16 / 32 (feature sizes 24 / 48 / 96).  Head dims 16 / 32 run on the fp16 matrix cores in two-piece split precision (fp32-equivalent for |q|, |k|, |v| < 65504:
+ * no input scaling -- hidden states behind a LayerNorm); exact_fp32 != 0 keeps the exact-fp32 VALU kernel wherever the window's tokens fit its LDS-resident form. */
 int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads,
-                            int head_dim, float scale, void* stream);
+                            int head_dim, float scale, int exact_fp32, void* stream);
 
 /* nn.Linear of the transformer blocks: y[M][N] = act(x[M][K] . w[N][K]^T + bias) (+ residual[M][N]) -- SABlock.qkv / out_proj
  * (monai/networks/blocks/selfattention.py:105-218), MLPBlock.linear1 -> GELU -> linear2 (mlp.py:56-80), the residual sums of

@@ -103,7 +103,7 @@ SIGNATURES = {
     "mh_add_act_f32": (_I, [_T, _T, _F, _T, _P]),
     "mh_pad_replicate_f32": (_I, [_T, _T, _P]),
     "mh_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
-    "mh_window_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mh_window_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mh_linear_packed_floats": (_L, [_I, _I]),
     "mh_linear_pack_f32": (_I, [_P, _I, _I, _P, _P]),
     "mh_linear_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),

@@ -1488,13 +1488,15 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
 }
 
 int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads, int head_dim,
-                            float scale, void* stream) {
+                            float scale, int exact_fp32, void* stream) {
     if (!qkv || !out || BW < 1 || S < 1 || heads < 1 || nW < 1) return fail(MH_ERR_ARG, "window_attention: bad argument");
     if (mask && BW % nW) return fail(MH_ERR_ARG, "window_attention: %d windows are not a multiple of the %d mask windows", BW, nW);
     if (!aligned(qkv, 16) || !aligned(out, 16)) return fail(MH_ERR_ARG, "window_attention: 16-byte aligned tensors required");
     hipStream_t s0 = (hipStream_t)stream;
     // head dims 16 / 32: the streaming split-precision kernel on the fp16 matrix cores (round 4), any number of tokens; head dim 8 (feature size 24): the VALU kernel
-    if (head_dim == 16 || head_dim == 32) {
+    // exact_fp32 (the caller pinned the exact-fp32 family): the VALU kernel wherever its LDS-resident form fits -- the split-precision kernel takes q / k / v as they come
+    // (|x| < 65504, no input scaling: ADVICE r4), which hidden states behind a LayerNorm satisfy and a caller who asked for exact fp32 did not sign up for
+    if ((head_dim == 16 || head_dim == 32) && !(exact_fp32 && S <= WA_MAX_TOKENS)) {
         const dim3 g2((unsigned)cdiv(S, 128), (unsigned)heads, (unsigned)BW);
         if (head_dim == 16) hipLaunchKernelGGL((window_attention_h2_kernel<16>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale);
         else hipLaunchKernelGGL((window_attention_h2_kernel<32>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale);

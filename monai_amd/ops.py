@@ -556,9 +556,11 @@ def attention(qkv: torch.Tensor, heads: int, scale: float, head_dim: int = 64) -
     return out
 
 
-def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
+                     exact: Optional[bool] = None) -> torch.Tensor:
     """qkv [BW, S, 3*heads*hd] -> [BW, S, heads*hd] = softmax((q*scale) k^T + bias[head] + mask[window % nW]) v per (window, head);
-    bias_t [heads, S, S] holds the relative position bias transposed (key-major), mask [nW, S, S] the shifted-window mask."""
+    bias_t [heads, S, S] holds the relative position bias transposed (key-major), mask [nW, S, S] the shifted-window mask.
+    exact: keep the exact-fp32 kernel (default: when config.CONV_ALGO pins the exact-fp32 family); otherwise head dims 16 / 32 run in fp16 split precision."""
     _lib.require_device(qkv, bias_t, mask)
     if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] % (3 * heads):
         raise RuntimeError(f"monai_amd.window_attention: qkv must be contiguous [BW, S, 3*heads*hd], got {tuple(qkv.shape)}")
@@ -573,7 +575,11 @@ def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Option
         raise RuntimeError("monai_amd.window_attention: bias_t must have one [S, S] table per head")
     nw = int(mask.shape[0]) if mask is not None else 1
     out = torch.empty((bw, s, heads * hd), dtype=torch.float32, device=qkv.device)
-    _lib.lib().call("mh_window_attention_f32", _lib.ptr(qkv), _lib.ptr(bias_t), _lib.ptr(mask), _lib.ptr(out), bw, nw, s, int(heads), hd, float(scale), _s(qkv))
+    if exact is None:
+        from . import config
+
+        exact = config.conv_algo() in (config.CONV_ALGOS["fp32"], config.CONV_ALGOS["direct"], config.CONV_ALGOS["wino2d"])
+    _lib.lib().call("mh_window_attention_f32", _lib.ptr(qkv), _lib.ptr(bias_t), _lib.ptr(mask), _lib.ptr(out), bw, nw, s, int(heads), hd, float(scale), int(bool(exact)), _s(qkv))
     return out
 
 
