@@ -2,7 +2,7 @@
 resample and fused Gaussian on one 512^3 volume, the dominant convolution) so a `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`
 pass can attribute HBM traffic per kernel.
 
-    python tools/pmc_probe.py [--only blend,mosaic,resample,gaussian,conv] [--conv-batch 64] [--conv-cfgs all|h2]
+    python tools/pmc_probe.py [--only blend,mosaic,resample,gaussian,conv,upconv] [--conv-batch 64] [--conv-cfgs all|h2]
 
 bench.py runs the `mosaic,conv` sections (h2 only) under rocprofv3 itself: `roofline*.traffic` of the driver's line."""
 import argparse
@@ -80,4 +80,18 @@ if "conv" in only:
         stats = torch.empty(B * 32 * tiles * 3, device=dev)
         for _ in range(3):
             ops.conv3d_k3(cfg, x, xn, packed, bias, y, stats)
+if "upconv" in only:
+    # UpCat's composite transposed convolution at the headline's top decoder level: 32 channels @ 48^3 -> 32 couts @ 96^3, B windows per launch (write-only form)
+    B = args.conv_batch
+    low = torch.randn(B, 32, 48, 48, 48, device=dev)
+    ln = torch.zeros(B, 32, 4, device=dev)
+    ln[:, :, 0] = 1.1
+    ln[:, :, 1] = 0.1
+    ln[:, :, 2] = 0.1
+    ln[:, :, 3] = 8.0
+    w4, table = ops.upconv_k4s2_weights(torch.randn(32, 32, 2, 2, 2, device=dev) * 0.2, torch.randn(32, device=dev) * 0.1, torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05)
+    packed = ops.upconv_k4s2_pack(w4)
+    y = torch.empty(B, 32, 96, 96, 96, device=dev)
+    for _ in range(3):
+        ops.upconv_k4s2(low, ln, packed, table, y, accumulate=False)
 torch.cuda.synchronize()
