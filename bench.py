@@ -749,6 +749,9 @@ def main(argv=None):
             "roofline": conv_roofline(spans, args.steps, ms, args.roi),
             "roofline_hbm": blend_roofline(spans, mosaic=world == 1 and hasattr(net, "forward_into_windows") and os.environ.get("MONAI_AMD_LOGITS_LAYOUT") != "windows"),
             "conv_ms_per_step": conv_all,
+            "upconv": ({"kernel": "upconv_k4s2_h2_kernel (UpCat: convT k4 s2 of the low-res tensor)", "ms_per_step": spans["upconv_k4s2"]["ms_total"] / args.steps,
+                        "ms_avg": spans["upconv_k4s2"]["ms_avg"], "fp32_equivalent_tflops": spans["upconv_k4s2"]["work"] / (spans["upconv_k4s2"]["ms_total"] * 1e-3) / 1e12}
+                       if "upconv_k4s2" in spans else None),
             "checksum": float(out.double().sum().item()),
             "pmc": dict(_PMC_STATUS),
         }
