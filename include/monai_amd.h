@@ -175,6 +175,15 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W);
  * of the values written (fused InstanceNorm statistics). */
 int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias,
                      const mh_tensor5* out, float* stats, void* stream);
+/* mh_conv3d_k3_f32 that also leaves MaxPool3d(kernel_size=2) of its output (`Down`, monai/networks/nets/basic_unet.py:61-89: the pooling behind an encoder block) without
+ * a pass over the full-resolution tensor: pool_max / pool_min [N][>= Cout][D/2][H/2][W/2] (batch stride pool_n_stride floats) receive the 2 x 2 x 2 maxima and minima of the
+ * RAW output; the consumer reads pool_max under `out`'s records after mh_pool_select_f32(pool_max, pool_min, out's records) has copied the minima over the channels whose
+ * alpha is negative (normalise + LeakyReLU is monotone in the raw value: max of the activated values = activation of the raw max for alpha >= 0, of the raw min otherwise).
+ * The split-precision configuration on even extents whose regions are 16 x 16 (mh_conv3d_k3_pool_accepts); input records and statistics required. */
+int mh_conv3d_k3_pool_accepts(int cfg, int Cin, int Cout, int D, int H, int W);
+int mh_conv3d_k3_pool_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out, float* stats, float* pool_max, float* pool_min,
+                          int64_t pool_n_stride, void* stream);
+int mh_pool_select_f32(float* pool_max, const float* pool_min, const float* nrm, int64_t nrm_n_stride, int N, int C, int64_t n_stride, int64_t vol, void* stream);
 /* mh_conv3d_k3_f32 whose result is ADDED to what `out` holds (out += conv + bias; `stats` = the statistics of the sum): the split-precision configuration
  * (mh_conv3d_k3_h2_config) with input records and statistics only -- MH_ERR_UNSUPPORTED otherwise.  The second half of the UpCat path (mh_upconv_k4s2_f32 first). */
 int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out, float* stats, void* stream);

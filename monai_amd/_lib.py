@@ -73,6 +73,9 @@ SIGNATURES = {
     "mh_conv3d_k3_stat_tiles": (_I, [_I, _I, _I, _I]),
     "mh_conv3d_k3_f32": (_I, [_I, _T, _P, _P, _T, _P, _P]),
     "mh_conv3d_k3_accumulate_f32": (_I, [_I, _T, _P, _P, _T, _P, _P]),
+    "mh_conv3d_k3_pool_accepts": (_I, [_I, _I, _I, _I, _I, _I]),
+    "mh_conv3d_k3_pool_f32": (_I, [_I, _T, _P, _P, _T, _P, _P, _P, _L, _P]),
+    "mh_pool_select_f32": (_I, [_P, _P, _P, _L, _I, _I, _L, _L, _P]),
     "mh_instnorm_stat_tiles": (_I, [_I, _I, _I]),
     "mh_instnorm_stats_f32": (_I, [_T, _P, _P]),
     "mh_instnorm_finalize_f32": (_I, [_P, _I, _I, _I, _P, _P, _F, _F, _P, _L, _P]),

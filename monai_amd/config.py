@@ -56,3 +56,14 @@ UPCAT_FUSED = None
 def upcat_fused() -> bool:
     v = UPCAT_FUSED if UPCAT_FUSED is not None else os.environ.get("MONAI_AMD_UPCAT_FUSED", "1")
     return str(v).lower() not in ("0", "false", "off", "no")
+
+
+# ---- MaxPool3d(2) inside the producing convolution ------------------------------------------------------------------------------
+# BasicUNet's encoder: the split-precision convolution in front of a pooling leaves the pooled tensor itself (csrc/kernels/conv3d_h2.h, POOL) -- bit-identical logits.
+# False (or MONAI_AMD_POOL_FUSED=0 while None) keeps the pooling pass.
+POOL_FUSED = None
+
+
+def pool_fused() -> bool:
+    v = POOL_FUSED if POOL_FUSED is not None else os.environ.get("MONAI_AMD_POOL_FUSED", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")

@@ -471,6 +471,11 @@ int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 int mh_conv3d_k3_h2c_config(void) { return MH_CFG_H2C; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 
+int mh_conv3d_k3_pool_accepts(int cfg, int Cin, int Cout, int D, int H, int W) {
+    if (cfg != MH_CFG_H2 || D < 2 || H < 2 || W < 2 || D % 2 || H % 2 || W % 4) return 0;
+    if (!(Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0) || !h2_fits(D, H, W)) return 0;
+    return !h2_wide(H, W) && h2_zchunk(D, H, W) % 2 == 0;
+}
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == 0) return 1;
     if (cfg == MH_CFG_WINO2D) return Cin >= 8 && Cin % 8 == 0 && Cout >= W2_CN && Cout % W2_CN == 0;
@@ -592,7 +597,27 @@ static void launch_mfma(const Tensor& in, const float* wp, const float* bias, co
         hipLaunchKernelGGL((conv3d_k3_mfma_kernel<Cfg, false>), grid, dim3(256), 0, s, in, wp, bias, out, stats, tx, ty, tz);
 }
 
-static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, float* stats, void* stream, bool accumulate);
+struct PoolOut { float* mx; float* mn; long long n_stride; };
+static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, float* stats, void* stream, bool accumulate,
+                            const PoolOut* pool = nullptr);
+// can mh_conv3d_k3_pool_f32 serve this layer?  the split-precision configuration's 16 x 16 regions (not the 8 x 32 shape), even extents, even z-chunks
+int mh_conv3d_k3_pool_accepts(int cfg, int Cin, int Cout, int D, int H, int W);
+int mh_conv3d_k3_pool_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_, float* stats, float* pool_max, float* pool_min,
+                          int64_t pool_n_stride, void* stream) {
+    if (!in_ || !out_ || !pool_max || !pool_min || !stats || !in_->nrm) return fail(MH_ERR_ARG, "conv3d_k3_pool: input records, statistics and both pooled tensors are required");
+    if (!mh_conv3d_k3_pool_accepts(cfg, in_->C, out_->C, out_->D, out_->H, out_->W))
+        return fail(MH_ERR_UNSUPPORTED, "conv3d_k3_pool: the pooling epilogue exists for the split-precision configuration on even extents with 16 x 16 regions");
+    if (!aligned(pool_max, 8) || !aligned(pool_min, 8) || pool_n_stride % 2 || (long long)out_->C * (out_->D / 2) * (out_->H / 2) * (out_->W / 2) > pool_n_stride)
+        return fail(MH_ERR_ARG, "conv3d_k3_pool: pooled tensors must be 8-byte aligned [N][>= C][D/2][H/2][W/2]");
+    const PoolOut po{pool_max, pool_min, (long long)pool_n_stride};
+    return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, false, &po);
+}
+int mh_pool_select_f32(float* pool_max, const float* pool_min, const float* nrm, int64_t nrm_n_stride, int N, int C, int64_t n_stride, int64_t vol, void* stream) {
+    if (!pool_max || !pool_min || !nrm || N < 1 || C < 1 || vol < 1) return fail(MH_ERR_ARG, "pool_select: bad argument");
+    const unsigned nb = (unsigned)std::min<long long>(blocks_for(vol), 64);
+    hipLaunchKernelGGL(pool_select_kernel, dim3(nb, (unsigned)C, (unsigned)N), dim3(256), 0, (hipStream_t)stream, pool_max, pool_min, nrm, (long long)nrm_n_stride, (long long)n_stride, (long long)vol);
+    return launched("pool_select");
+}
 int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
                      float* stats, void* stream) {
     return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, false);
@@ -604,7 +629,7 @@ int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in_, const float* pac
     return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, true);
 }
 static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
-                            float* stats, void* stream, bool accumulate) {
+                            float* stats, void* stream, bool accumulate, const PoolOut* pool) {
     if (!dense_ok(in_) || !dense_ok(out_) || !packed_w) return fail(MH_ERR_ARG, "conv3d_k3: bad tensor");
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv3d_k3: shape mismatch");
@@ -647,13 +672,19 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
 #define MH_H2_LAUNCH(RES_, WIDE_, C16_)                                                                                                                  \
     {                                                                                                                                                \
-        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);   \
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);       \
-        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);      \
-        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk);                 \
+        if (stats && in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);   \
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);       \
+        else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, true, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);      \
+        else hipLaunchKernelGGL((conv3d_k3_h2_kernel<false, false, RES_, WIDE_, C16_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);                 \
     }
+        if (pool) {             // MaxPool3d(2) of the following block leaves with the result (kernels/conv3d_h2.h, POOL): 16 x 16 regions, statistics and records present
+#define MH_H2_POOL(RES_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, false, false, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride)
+            if (in.C <= 2 * H2_KC) MH_H2_POOL(true); else MH_H2_POOL(false);
+#undef MH_H2_POOL
+            return launched("conv3d_k3_h2_pool");
+        }
         if (accumulate) {       // out += conv (kernels/conv3d_h2.h, ACC): statistics and input records present (checked by the entry point)
-#define MH_H2_ACC(RES_, WIDE_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk)
+#define MH_H2_ACC(RES_, WIDE_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL)
             if (in.C <= 2 * H2_KC) { if (wide) MH_H2_ACC(true, true); else MH_H2_ACC(true, false); }
             else { if (wide) MH_H2_ACC(false, true); else MH_H2_ACC(false, false); }
 #undef MH_H2_ACC

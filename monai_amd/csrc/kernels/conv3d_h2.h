@@ -126,10 +126,17 @@ __device__ __forceinline__ void h2_split_pair(float v0, float v1, float m1, f16x
 // whole plane ahead (four 16-byte buffer loads per lane right after the accumulator sets rotate) and enter the fresh set as old * 2^-(scale-back exponent), an exact
 // power-of-two product, so the epilogue, its stores and the statistics are untouched: they see the sum.  Used by the UpCat path (kernels/upconv_h2.h writes the
 // decoder's up half first, this kernel adds the skip half and leaves the InstanceNorm statistics of the sum).
-template <bool STATS, bool NRM, bool RES, bool WIDE = false, bool C16 = false, bool ACC = false>
+// POOL (round 5, 16 x 16 regions of the 32-cout form): MaxPool3d(2) of the block that follows leaves the kernel with its result.  The pooled tensor cannot be the pooled
+// ACTIVATED values (the InstanceNorm statistics of this very output are not known yet), but activation after normalisation is monotone in the raw value: increasing for
+// alpha >= 0, decreasing for alpha < 0 -- so the kernel writes the 2 x 2 x 2 MAXIMUM and MINIMUM of the raw values (pmax, pmin: [N][Cout][D/2][H/2][W/2]) and the consumer
+// reads the maxima under THIS tensor's records (mh_pool_select_f32 copies the minima over them for the channels whose alpha turned out negative).  In the epilogue: the x
+// pairs of a lane's four-voxel groups are in-lane, the y pair (rows 2w, 2w + 1 of the wave) sits in the partner lane (lane ^ 32: the second row is rotated by 4
+// voxels), the z pair is the previous plane's result held in eight registers.
+template <bool STATS, bool NRM, bool RES, bool WIDE = false, bool C16 = false, bool ACC = false, bool POOL = false>
 __global__ void __launch_bounds__(512, 1)
 conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
-                    float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk) {
+                    float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk, float* __restrict__ pmax, float* __restrict__ pmin,
+                    long long pool_n_stride) {
     using G = H2Geo<WIDE>;
     __shared__ uint4 smem[2 * (H2_XB + H2_WB)];
     // input records in LDS, per QUAD of channels {alpha x 4, beta x 4, slope x 4} (48 bytes): a wave converts one quad per step and reads its records with
@@ -330,6 +337,23 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[S][4 * j + i] = pv[j][i] * pinv_a * pinv_b; \
     }
+    static_assert(!(POOL && (C16 || WIDE)), "the pooling epilogue exists for 16 x 16 regions of the 32-cout kernel");
+    // POOL: lane kg 0 finishes the column groups x0 + 0..3 and x0 + 8..11 (its row-0 groups), lane kg 1 the groups x0 + 4..7 and x0 + 12..15: two pooled columns each,
+    // at pooled column x0 / 2 + 4 j + 2 kg
+    const long long PHW = (long long)(H / 2) * (W / 2), PDHW = (long long)(D / 2) * PHW;
+    f32x2 hmx[2], hmn[2];                                    // the even plane's in-plane maxima / minima, waiting for the odd plane
+    unsigned poff[2];
+    if (POOL) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int px_ = x0 / 2 + 4 * j + 2 * kg, py_ = (y0 + orow) / 2;
+            const bool ok_ = cok && y0 + orow + 1 < H && x0 + 8 * j + 4 * kg + 3 < W;
+            poff[j] = ok_ ? 4u * (unsigned)((long long)r32 * PDHW + (long long)py_ * (W / 2) + px_) : H2_DROP;
+            hmx[j] = f32x2{0.0f, 0.0f}; hmn[j] = f32x2{0.0f, 0.0f};
+        }
+    }
+    const auto pxrs = __builtin_amdgcn_make_buffer_rsrc(POOL ? pmax + (long long)n * pool_n_stride + (long long)(cg * CG) * PDHW : out.data, 0, POOL ? (int)(min(CG, Cout - cg * CG) * PDHW * 4) : 0, 0x00020000);
+    const auto pnrs = __builtin_amdgcn_make_buffer_rsrc(POOL ? pmin + (long long)n * pool_n_stride + (long long)(cg * CG) * PDHW : out.data, 0, POOL ? (int)(min(CG, Cout - cg * CG) * PDHW * 4) : 0, 0x00020000);
     f32x4 o_[4];                                             // the plane being emitted: its pieces A (scale, bias, store), B1-B3 (statistics) sit in different taps
     float esum_ = 0.0f, ecnt_ = 0.0f, em2_ = 0.0f, emean_ = 0.0f;
     Stat run;
@@ -412,6 +436,35 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             em2_ += ((q_[0] + q_[1]) + (q_[2] + q_[3])) * (ooff[j] != H2_DROP && pend ? 1.0f : 0.0f); \
         }                                                                                             \
     }
+    // POOL piece: in-lane x pairs, the partner lane's row-1 groups (lane ^ 32), the plane pair; stores on the odd plane of a pair only (offset beyond the buffer otherwise)
+#define MH_H2_EMIT_P                                                                                  \
+    if (POOL) {                                                                                       \
+        f32x2 xm_[4], xn_[4];                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            xm_[j] = f32x2{fmaxf(o_[j][0], o_[j][1]), fmaxf(o_[j][2], o_[j][3])};                     \
+            xn_[j] = f32x2{fminf(o_[j][0], o_[j][1]), fminf(o_[j][2], o_[j][3])};                     \
+        }                                                                                             \
+        f32x2 rm_[2], rn_[2];       /* the partner's row-1 groups: its j = 2, 3 */                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                           \
+                rm_[j][i] = __shfl_xor(xm_[2 + j][i], 32);                                            \
+                rn_[j][i] = __shfl_xor(xn_[2 + j][i], 32);                                            \
+            }                                                                                         \
+        const bool odd_ = (pend_z & 1) != 0;                                                          \
+        const unsigned pso_ = (unsigned)(pend_z >> 1) * (unsigned)(PHW * 4);                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            /* kg 0: own group j pairs with the partner's j-th row-1 group; kg 1: with the other one */ \
+            const f32x2 pm_ = kg == 0 ? rm_[j] : rm_[1 - j], pn_ = kg == 0 ? rn_[j] : rn_[1 - j];     \
+            f32x2 ym_ = f32x2{fmaxf(xm_[j][0], pm_[0]), fmaxf(xm_[j][1], pm_[1])};                    \
+            f32x2 yn_ = f32x2{fminf(xn_[j][0], pn_[0]), fminf(xn_[j][1], pn_[1])};                    \
+            const f32x2 fm_ = f32x2{fmaxf(ym_[0], hmx[j][0]), fmaxf(ym_[1], hmx[j][1])};              \
+            const f32x2 fn_ = f32x2{fminf(yn_[0], hmn[j][0]), fminf(yn_[1], hmn[j][1])};              \
+            const unsigned po_ = (pend && odd_ && poff[j] != H2_DROP) ? poff[j] + pso_ : H2_DROP;     \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, fm_), pxrs, po_, 0, 0);   \
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, fn_), pnrs, po_, 0, 0);   \
+            hmx[j] = ym_; hmn[j] = yn_;     /* an odd plane's values are overwritten by the next even plane before they are used */ \
+        }                                                                                             \
+    }
 #define MH_H2_EMIT_B3                                                                                 \
     {                                                                                                 \
         if (STATS) {                                                                                  \
@@ -421,7 +474,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         }                                                                                             \
         pend = 0;                                                                                     \
     }
-#define MH_H2_EMIT { MH_H2_EMIT_A MH_H2_EMIT_B1 MH_H2_EMIT_B2 MH_H2_EMIT_B3 }
+#define MH_H2_EMIT { MH_H2_EMIT_A MH_H2_EMIT_P MH_H2_EMIT_B1 MH_H2_EMIT_B2 MH_H2_EMIT_B3 }
 #define MH_H2_NONE
     // a plain step, and the first step of a plane (the previous plane's epilogue pieces in taps 3, 4, 6, 7 with more vector slots per gap)
 #define MH_H2_SCHEDULE_PLAIN                                                                          \
@@ -432,7 +485,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #define MH_H2_SCHEDULE_EMIT                                                                           \
         MH_H2_TAP(0, MH_H2_CONV(0)) MH_H2_TAP(1, MH_H2_CONV(1)) MH_H2_TAP(2, MH_H2_CONV(2))           \
         MH_H2_TAPV(3, 8, MH_H2_EMIT_A)                                                                \
-        MH_H2_TAPV(4, 8, MH_H2_LDX MH_H2_EMIT_B1) MH_H2_TAP(5, MH_H2_WST) MH_H2_TAPV(6, 8, MH_H2_LDW(0, 4) MH_H2_EMIT_B2) \
+        MH_H2_TAPV(4, 8, MH_H2_LDX MH_H2_EMIT_B1) MH_H2_TAPV(5, POOL ? 10 : 5, MH_H2_WST MH_H2_EMIT_P) MH_H2_TAPV(6, 8, MH_H2_LDW(0, 4) MH_H2_EMIT_B2) \
         MH_H2_TAPV(7, 8, MH_H2_LDW(4, H2_WSLOTS) MH_H2_ADV MH_H2_EMIT_B3) MH_H2_TAP(8, MH_H2_NRMLD)
     // one step (16 channels of input plane p): conversion of the next step's registers into the other LDS buffer first, then the
     // epilogue stores, then the loads of the step after next
@@ -504,6 +557,7 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #undef MH_H2_NONE
 #undef MH_H2_EMIT
 #undef MH_H2_EMIT_B3
+#undef MH_H2_EMIT_P
 #undef MH_H2_EMIT_B2
 #undef MH_H2_EMIT_B1
 #undef MH_H2_EMIT_A

@@ -299,6 +299,21 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(Tensor in, Tensor out) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The pooling epilogue of the split-precision convolution (conv3d_h2.h, POOL) leaves the 2 x 2 x 2 maxima AND minima of the RAW convolution output: the consumer reads the
+// maxima under the producer's records, which is max(act(x)) exactly when alpha >= 0 (normalise + LeakyReLU is then non-decreasing in x).  For a channel whose alpha came
+// out negative the maximum of the activated values sits at the raw MINIMUM: its plane is copied over.  One launch per tensor; channels with alpha >= 0 (all of them for
+// freshly initialised norms, most of them for trained ones) cost a record read and an exit.
+__global__ void __launch_bounds__(256) pool_select_kernel(float* __restrict__ pmax, const float* __restrict__ pmin, const float* __restrict__ nrm, long long nrm_n_stride,
+                                                          long long n_stride, long long vol) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float alpha = nrm[(long long)n * nrm_n_stride + 4LL * c];
+    if (!(alpha < 0.0f)) return;
+    float* d = pmax + (long long)n * n_stride + (long long)c * vol;
+    const float* s = pmin + (long long)n * n_stride + (long long)c * vol;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < vol; i += (long long)gridDim.x * 256) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
 // ConvTranspose3d k=2 s=2 of act(in): every input voxel owns a disjoint 2x2x2 output block, so it is eight
 // independent 1x1 convs.  One thread = one input voxel x COT output channels x 8 taps; weights
 // [Cin][Cout][8] are block-uniform (scalar loads); each (cout, dz, dy) row pair is one coalesced float2 store.

@@ -297,6 +297,7 @@ class _Plan:
         self.tmp = [e(max(f[l], dec_out[l]) if l < 4 else f[4], l) for l in range(5)]
         self.tmp_nrm = [nz(max(f[l], dec_out[l]) if l < 4 else f[4]) for l in range(5)]
         self.pool = [None] + [e(f[l - 1], l) for l in range(1, 5)]
+        self.pool_min = [None] * 5       # pooling fused into the producing convolution (csrc/kernels/conv3d_h2.h, POOL): the raw minima next to the raw maxima, allocated on first use
         # every record of this engine carries a magnitude bound (include/monai_amd.h: mh_tensor5) -- the finalize kernels write it for the normalised
         # tensors, the pooling kernel hands its input's on, the transposed convolutions fold max |value| into identity records -- so every
         # convolution but the first may run on the split-precision kernel, which scales its input by them
@@ -340,18 +341,34 @@ class _Plan:
             net._packed[("bn", name)] = hit
         out_nrm.copy_(hit[1][None].expand(out_nrm.shape[0], -1, -1))
 
-    def _conv(self, net, name: str, block: _Convolution, x, x_nrm, out, out_nrm, bounded: bool = True):
+    def _conv(self, net, name: str, block: _Convolution, x, x_nrm, out, out_nrm, bounded: bool = True, pool_level: int = 0) -> bool:
         """conv -> raw `out`; the normalisation + activation that follows it -> records `out_nrm` ({alpha, beta, slope, bound}).  `bounded`: the input's
-        records carry magnitude bounds (the split-precision convolution needs them; BatchNorm folds and interpolated tensors have none)."""
+        records carry magnitude bounds (the split-precision convolution needs them; BatchNorm folds and interpolated tensors have none).
+        `pool_level` l > 0: MaxPool3d(2) of this output feeds level l -- when the kernel can, its epilogue leaves the pooled tensor in self.pool[l] (raw maxima to be read under
+        `out_nrm`; returns True) and no pooling pass runs."""
         n, cout, d, h, w = out.shape
         cin = x.shape[1]
         cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None and bounded and not self.batchnorm)
         packed = net._packed_weight(name, block.conv, cfg)
         norm = block.adn.N
+        if pool_level and block.adn.negative_slope >= 0.0 and self._poolable(net, cfg, cin, cout, d, h, w, pool_level, x_nrm):
+            if self.pool_min[pool_level] is None:
+                self.pool_min[pool_level] = torch.empty_like(self.pool[pool_level])
+            tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3)
+            with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
+                ops.conv3d_k3_pool(cfg, x, x_nrm, packed, block.conv.bias, out, stats, self.pool[pool_level], self.pool_min[pool_level])
+            if isinstance(norm, nn.GroupNorm):
+                ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+            else:
+                ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+            ops.pool_select(self.pool[pool_level], self.pool_min[pool_level], out_nrm)
+            return True
         if self.batchnorm:
             with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
                 ops.conv3d_k3(cfg, x, x_nrm, packed, block.conv.bias, out, None)
-            return self._bn_record(net, name, norm, block.adn.negative_slope, out_nrm)
+            self._bn_record(net, name, norm, block.adn.negative_slope, out_nrm)
+            return False
         tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if net.fused_stats else 0
         flops = 2.0 * 27 * cin * cout * d * h * w * n
         if tiles:
@@ -368,6 +385,18 @@ class _Plan:
             ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
         else:
             ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+        return False
+
+    def _poolable(self, net, cfg: int, cin: int, cout: int, d: int, h: int, w: int, level: int, x_nrm) -> bool:
+        """the pooling epilogue (csrc/kernels/conv3d_h2.h, POOL): the split-precision kernel with 16 x 16 regions on even extents, a non-negative activation slope (the
+        activation must be monotone in the raw value), statistics from the epilogue, a 3-D network"""
+        from ... import config
+
+        if self.planar or self.batchnorm or not net.fused_stats or x_nrm is None or not config.pool_fused():
+            return False
+        if tuple(self.sp[level]) != (d // 2, h // 2, w // 2) or tuple(self.pool[level].shape[1:]) != (cout, d // 2, h // 2, w // 2):
+            return False
+        return ops.conv3d_k3_pool_accepts(cfg, cin, cout, d, h, w)
 
     def _interpolate(self, up: _UpSample, src, src_nrm, low, dst) -> None:
         """UpSample(mode="nontrainable", interp_mode="linear", align_corners=True) (blocks/upsample.py:118-140): the 1x1 `preconv` when the channel count
@@ -444,17 +473,21 @@ class _Plan:
         # encoder
         t, tn = self.tmp[0][:, : f[0]], self.tmp_nrm[0][:, : f[0]]
         self._conv(net, "conv_0.conv_0", net.conv_0.conv_0, x, None, t, tn)
-        self._conv(net, "conv_0.conv_1", net.conv_0.conv_1, t, tn, self.cat[0][:, : f[0]], self.cat_nrm[0][:, : f[0]])
+        pooled = self._conv(net, "conv_0.conv_1", net.conv_0.conv_1, t, tn, self.cat[0][:, : f[0]], self.cat_nrm[0][:, : f[0]], pool_level=1)
         for l in range(1, 5):
             skip, skip_nrm = self.cat[l - 1][:, : f[l - 1]], self.cat_nrm[l - 1][:, : f[l - 1]]
-            ops.maxpool2(skip, skip_nrm, self.pool[l], self.pool_nrm[l])
+            if pooled:      # the producing convolution left the raw maxima: read them under the skip tensor's records (act(max raw) == max(act(raw)), bit for bit)
+                p_in, p_nrm = self.pool[l], skip_nrm
+            else:
+                ops.maxpool2(skip, skip_nrm, self.pool[l], self.pool_nrm[l])
+                p_in, p_nrm = self.pool[l], self.pool_nrm[l]
             t, tn = self.tmp[l][:, : f[l]], self.tmp_nrm[l][:, : f[l]]
-            self._conv(net, f"down_{l}.convs.conv_0", downs[l].convs.conv_0, self.pool[l], self.pool_nrm[l], t, tn)
+            self._conv(net, f"down_{l}.convs.conv_0", downs[l].convs.conv_0, p_in, p_nrm, t, tn)
             if l < 4:
                 o, on = self.cat[l][:, : f[l]], self.cat_nrm[l][:, : f[l]]
             else:
                 o, on = self.x4, self.x4_nrm
-            self._conv(net, f"down_{l}.convs.conv_1", downs[l].convs.conv_1, t, tn, o, on)
+            pooled = self._conv(net, f"down_{l}.convs.conv_1", downs[l].convs.conv_1, t, tn, o, on, pool_level=l + 1 if l < 4 else 0)
 
         # decoder
         src, src_nrm = self.x4, self.x4_nrm

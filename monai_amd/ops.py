@@ -350,6 +350,33 @@ def conv3d_k3(cfg, x, x_nrm, packed_w, bias, out, stats: Optional[torch.Tensor] 
     return out
 
 
+def conv3d_k3_pool_accepts(cfg: int, cin: int, cout: int, d: int, h: int, w: int) -> bool:
+    return bool(_lib.lib().query("mh_conv3d_k3_pool_accepts", int(cfg), int(cin), int(cout), int(d), int(h), int(w)))
+
+
+def conv3d_k3_pool(cfg, x, x_nrm, packed_w, bias, out, stats, pool_max: torch.Tensor, pool_min: torch.Tensor):
+    """`conv3d_k3` that also writes the 2 x 2 x 2 maxima / minima of its raw output (pool_max / pool_min [N, C, D/2, H/2, W/2]): MaxPool3d(2) of the next block without a pass
+    over the full-resolution tensor.  After the output's records exist: `pool_select(pool_max, pool_min, out_nrm)`, then consumers read pool_max under out_nrm."""
+    _lib.require_device(x, x_nrm, packed_w, bias, out, stats, pool_max, pool_min)
+    if pool_max.shape != pool_min.shape or pool_max.stride() != pool_min.stride() or not pool_max[0].is_contiguous():
+        raise RuntimeError("monai_amd.conv3d_k3_pool: pool_max / pool_min must be two equally laid out [N, C, D/2, H/2, W/2] tensors, dense per sample")
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv3d_k3_pool_f32", int(cfg), C.byref(xi), _lib.ptr(packed_w), _lib.ptr(bias), C.byref(xo), _lib.ptr(stats), _lib.ptr(pool_max), _lib.ptr(pool_min),
+                    int(pool_max.stride(0)), _s(x))
+    return out
+
+
+def pool_select(pool_max: torch.Tensor, pool_min: torch.Tensor, nrm: torch.Tensor) -> torch.Tensor:
+    """channels whose record has alpha < 0 take their minima (see conv3d_k3_pool); nrm: the [N, C, 4] records the consumer will apply"""
+    _lib.require_device(pool_max, pool_min, nrm)
+    n, c = int(pool_max.shape[0]), int(pool_max.shape[1])
+    vol = int(pool_max.shape[2] * pool_max.shape[3] * pool_max.shape[4])
+    if nrm.dim() != 3 or nrm.shape[2] != 4 or nrm.stride(2) != 1 or nrm.stride(1) != 4:
+        raise RuntimeError("monai_amd.pool_select: nrm must be an [N, C, 4] record view")
+    _lib.lib().call("mh_pool_select_f32", _lib.ptr(pool_max), _lib.ptr(pool_min), _lib.ptr(nrm), int(nrm.stride(0)), n, c, int(pool_max.stride(0)), vol, _s(pool_max))
+    return pool_max
+
+
 def instnorm_stat_tiles(d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_instnorm_stat_tiles", d, h, w)
 

@@ -87,6 +87,36 @@ def case_net_upcat_fused_vs_two_layers(device):
     return r, d
 
 
+def case_net_pool_fused_bitwise(device):
+    """BasicUNet with MaxPool3d(2) leaving the producing convolution's epilogue (config.POOL_FUSED; csrc/kernels/conv3d_h2.h, POOL) against the pooling pass: the consumer reads
+    raw maxima under the producer's records instead of pooled activated values -- act(max raw) == max(act(raw)) -- so the logits are BITWISE the same; with trained-like
+    norms (negative gammas on a third of the channels: those read the raw minima) too"""
+    from monai_amd import config
+
+    net, _ = make_net(1, 1, 5, device)
+    torch.manual_seed(21)
+    x = torch.rand(2, 1, 32, 32, 32).to(device)
+    saved, saved_algo = config.POOL_FUSED, config.CONV_ALGO
+    try:
+        config.CONV_ALGO = "auto"
+        for spread in (False, True):
+            if spread:
+                with torch.no_grad():
+                    for name, p_ in net.named_parameters():
+                        if name.endswith("adn.N.weight"):
+                            p_.mul_(torch.where(torch.arange(p_.numel(), device=p_.device) % 3 == 1, -1.0, 1.0))
+            config.POOL_FUSED = False
+            two = net(x).clone()
+            config.POOL_FUSED = True
+            plan = next(iter(net._plans.values()))
+            fused = net(x).clone()
+            assert plan.pool_min[1] is not None, "the pooling epilogue did not run"
+            assert torch.equal(fused, two), (fused - two).abs().max().item()
+    finally:
+        config.POOL_FUSED, config.CONV_ALGO = saved, saved_algo
+    return True
+
+
 def case_net_odd_window_vs_golden(device):
     """Window extents that are odd at levels 1, 2 and 3: UpCat's replicate padding (basic_unet.py:163-170) vs the reference."""
     g = np.load(os.path.join(GOLDEN, "net5_odd.npz"))

@@ -295,6 +295,11 @@ template <class V> inline void raw_buffer_store_b128(V data, BufRsrc r, unsigned
     const unsigned long long off = (unsigned long long)voffset + soffset;
     if (off + 16ull <= r.num_records) std::memcpy(r.base + off, &data, 16);
 }
+template <class V> inline void raw_buffer_store_b64(V data, BufRsrc r, unsigned voffset, unsigned soffset, int) {
+    static_assert(sizeof(V) == 8, "b64");
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 8ull <= r.num_records) std::memcpy(r.base + off, &data, 8);
+}
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 inline u32x4_t raw_buffer_load_b128(BufRsrc r, unsigned voffset, unsigned soffset, int) {      // out of range reads return zeros
     u32x4_t v = {0u, 0u, 0u, 0u};
@@ -331,6 +336,7 @@ inline unsigned raw_buffer_load_b32(BufRsrc r, unsigned voffset, unsigned soffse
 #define __builtin_amdgcn_fmed3f(a, b, c) std::fmax(std::fmin((a), (b)), std::fmin(std::fmax((a), (b)), (c)))      // v_med3_f32 (finite / infinite operands)
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc
 #define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
+#define __builtin_amdgcn_raw_buffer_store_b64 emu::raw_buffer_store_b64
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
 #define __builtin_amdgcn_raw_buffer_load_b32 emu::raw_buffer_load_b32
 #define __builtin_amdgcn_readfirstlane(x) (x)

@@ -208,6 +208,41 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
     return cfg
 
 
+def case_conv3d_pool(device, n, cin, cout, dims):
+    """the split-precision convolution with the pooling epilogue (conv3d_h2.h, POOL): the convolution output and statistics bitwise those of the plain kernel, pool_max /
+    pool_min bitwise MaxPool3d(2) of +out / -(-out); pool_select copies the minima for the channels whose alpha is negative; ragged regions, two z-chunks, two cout groups"""
+    gen = torch.Generator().manual_seed(700 + cin + cout + dims[0])
+    cfg = ops.conv3d_k3_h2_config()
+    assert ops.conv3d_k3_pool_accepts(cfg, cin, cout, *dims)
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(dims))))
+    packed = ops.conv3d_k3_pack(cfg, w.to(device))
+    tiles = ops.conv3d_k3_stat_tiles(cfg, *dims)
+    plain = torch.full((n, cout) + tuple(dims), float("nan"), device=device)
+    st0 = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+    ops.conv3d_k3(cfg, x.to(device), nrm.to(device), packed, b.to(device), plain, st0)
+    out = torch.full_like(plain, float("nan"))
+    st1 = torch.full_like(st0, float("nan"))
+    pdims = tuple(v // 2 for v in dims)
+    pmx = torch.full((n, cout) + pdims, float("nan"), device=device)
+    pmn = torch.full((n, cout) + pdims, float("nan"), device=device)
+    ops.conv3d_k3_pool(cfg, x.to(device), nrm.to(device), packed, b.to(device), out, st1, pmx, pmn)
+    assert torch.equal(out.cpu(), plain.cpu()) and torch.equal(st1.cpu(), st0.cpu())
+    ref = plain.cpu()
+    assert torch.equal(pmx.cpu(), F.max_pool3d(ref, 2)), (pmx.cpu() - F.max_pool3d(ref, 2)).abs().max()
+    assert torch.equal(pmn.cpu(), -F.max_pool3d(-ref, 2))
+    rec = torch.zeros((n, cout, 4))
+    rec[:, :, 0] = torch.where(torch.arange(cout) % 3 == 1, -1.5, 0.75)[None]          # every third channel: negative alpha
+    rec[0, 0, 0] = 0.0
+    mx0 = pmx.clone()
+    ops.pool_select(pmx, pmn, rec.to(device))
+    want = torch.where((rec[:, :, 0] < 0)[:, :, None, None, None], pmn.cpu(), mx0.cpu())
+    assert torch.equal(pmx.cpu(), want)
+    return True
+
+
 def case_conv3d_accumulate(device, n, cin, cout, dims, tol=2e-5):
     """the split-precision convolution in its accumulating form (conv3d_h2.h, ACC: out += conv + bias, statistics of the SUM): resident and streamed weight slabs, both
     region shapes, ragged regions, two z-chunks -- against old + conv in float64, and the finalize kernel on the statistics"""

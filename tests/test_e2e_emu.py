@@ -199,3 +199,7 @@ def test_upcat_fused_vs_two_layers_and_reference(emu):
 def test_buffered_schedule_with_callbacks_bitwise_vs_reference(emu):
     """SURVEY 8a row a7 with the rest of its call surface: process_fn / with_coord / tuple and dict outputs under buffer_steps"""
     assert ec.case_buffered_calls_vs_golden("cpu") == 6
+
+
+def test_pooling_epilogue_leaves_the_logits_bitwise(emu):
+    assert ec.case_net_pool_fused_bitwise("cpu")

@@ -301,3 +301,7 @@ def test_upcat_fused_vs_two_layers_and_reference():
 def test_buffered_schedule_with_callbacks_bitwise_vs_reference():
     """SURVEY 8a row a7 with the rest of its call surface: process_fn / with_coord / tuple and dict outputs under buffer_steps"""
     assert ec.case_buffered_calls_vs_golden(DEV) == 6
+
+
+def test_pooling_epilogue_leaves_the_logits_bitwise():
+    assert ec.case_net_pool_fused_bitwise(DEV)

@@ -281,3 +281,11 @@ ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24
 def test_conv3d_split_precision_accumulating(emu, n, cin, cout, dims):
     """out += conv3x3x3(act(x)) + bias with the statistics of the sum (conv3d_h2.h, ACC): the second half of the UpCat path"""
     kc.case_conv3d_accumulate("cpu", n, cin, cout, dims)
+
+
+# (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / two z-chunks
+POOL_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (6, 18, 36)), (1, 16, 32, (24, 16, 32))]
+@pytest.mark.parametrize("n,cin,cout,dims", POOL_CASES)
+def test_conv3d_split_precision_pooling_epilogue(emu, n, cin, cout, dims):
+    """MaxPool3d(2) out of the producing convolution's epilogue (conv3d_h2.h, POOL): raw maxima / minima, bitwise; the convolution itself untouched"""
+    kc.case_conv3d_pool("cpu", n, cin, cout, dims)

@@ -236,3 +236,11 @@ ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24
 def test_conv3d_split_precision_accumulating(n, cin, cout, dims):
     """out += conv3x3x3(act(x)) + bias with the statistics of the sum (conv3d_h2.h, ACC): the second half of the UpCat path"""
     kc.case_conv3d_accumulate(DEV, n, cin, cout, dims)
+
+
+# (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / two z-chunks
+POOL_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (6, 18, 36)), (1, 16, 32, (24, 16, 32)), (2, 32, 32, (96, 96, 96)), (2, 64, 64, (48, 48, 48))]
+@pytest.mark.parametrize("n,cin,cout,dims", POOL_CASES)
+def test_conv3d_split_precision_pooling_epilogue(n, cin, cout, dims):
+    """MaxPool3d(2) out of the producing convolution's epilogue (conv3d_h2.h, POOL): raw maxima / minima, bitwise; the convolution itself untouched"""
+    kc.case_conv3d_pool(DEV, n, cin, cout, dims)

@@ -61,7 +61,7 @@ int main(int argc, char** argv) {
     float best = 1e9f;
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, H2V_RES, H2V_WIDE>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk);
+        hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, H2V_RES, H2V_WIDE>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
