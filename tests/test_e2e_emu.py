@@ -201,5 +201,6 @@ def test_buffered_schedule_with_callbacks_bitwise_vs_reference(emu):
     assert ec.case_buffered_calls_vs_golden("cpu") == 6
 
 
+@pytest.mark.heavy_emu
 def test_pooling_epilogue_leaves_the_logits_bitwise(emu):
     assert ec.case_net_pool_fused_bitwise("cpu")

@@ -266,7 +266,7 @@ def test_window_attention(emu, s, hd):
 
 
 # (n, up channels, couts, coarse extents): one whole tile / ragged tiles in y and x with two cout groups / two z-chunks / one plane pair with x tiles of 16 + 16 + 4
-UPCONV_CASES = [(1, 32, 32, (3, 8, 16)), (2, 16, 64, (5, 9, 20)), (1, 32, 32, (13, 4, 4)), (1, 8, 32, (2, 17, 36))]
+UPCONV_CASES = [(1, 32, 32, (3, 8, 16)), pytest.param(2, 16, 64, (5, 9, 20), marks=pytest.mark.heavy_emu), (1, 32, 32, (13, 4, 4)), (1, 8, 32, (2, 17, 36))]
 @pytest.mark.parametrize("n,cup,cout,ldims", UPCONV_CASES)
 def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
     """conv3(cat([x_e, deconv2(x)]))'s up half as one transposed convolution k4 s2 p1 of x added in place (kernels/upconv_h2.h) == the two-layer evaluation in float64,
@@ -276,7 +276,7 @@ def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
 
 
 # (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / the 8 x 32 region shape in two z-chunks / 8 x 32 regions, four chunks of channels
-ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24, 8, 24)), (1, 64, 32, (2, 24, 56))]
+ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24, 8, 24)), pytest.param(1, 64, 32, (2, 24, 56), marks=pytest.mark.heavy_emu)]
 @pytest.mark.parametrize("n,cin,cout,dims", ACC_CASES)
 def test_conv3d_split_precision_accumulating(emu, n, cin, cout, dims):
     """out += conv3x3x3(act(x)) + bias with the statistics of the sum (conv3d_h2.h, ACC): the second half of the UpCat path"""
@@ -284,7 +284,7 @@ def test_conv3d_split_precision_accumulating(emu, n, cin, cout, dims):
 
 
 # (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / two z-chunks
-POOL_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (6, 18, 36)), (1, 16, 32, (24, 16, 32))]
+POOL_CASES = [(2, 32, 32, (4, 16, 16)), pytest.param(1, 48, 64, (6, 18, 36), marks=pytest.mark.heavy_emu), (1, 16, 32, (24, 16, 32))]
 @pytest.mark.parametrize("n,cin,cout,dims", POOL_CASES)
 def test_conv3d_split_precision_pooling_epilogue(emu, n, cin, cout, dims):
     """MaxPool3d(2) out of the producing convolution's epilogue (conv3d_h2.h, POOL): raw maxima / minima, bitwise; the convolution itself untouched"""
