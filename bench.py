@@ -547,22 +547,22 @@ def extra_config4(dev):  # noqa: C901
     res["device_copy_GBps"] = copy_gbps
     ms = timeit(lambda: [sp(v) for v in vols])
     nb = 4.0 * n * (e ** 3 + out.numel())
-    res["runs"].append({"op": "Spacing transform x4 (incl. host algebra)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    res["runs"].append({"op": "Spacing x4 (with host algebra)", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     gs = GaussianSmooth(sigma=1.0)
     plain = [v.as_tensor() for v in vols]
     ms = timeit(lambda: [gs(v) for v in plain])
     nb = 8.0 * n * e ** 3
-    res["runs"].append({"op": "GaussianSmooth transform x4", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
+    res["runs"].append({"op": "GaussianSmooth x4", "ms": ms, "GBps": nb / ms / 1e6, "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     raw = plain[0]
     m = np.array([[1.25, 0, 0, 0], [0, 1.25, 0, 0], [0, 0, 0.625, 0]], dtype=np.float64)
     for f64 in (True, False):
         ms = timeit(lambda: ops.affine_resample(raw, m.reshape(-1), osz, "bilinear", "border", False, f64))
         nb = 4.0 * (raw.numel() + osz[0] * osz[1] * osz[2])
-        res["runs"].append({"op": f"kernel: separable resample {'fp64' if f64 else 'fp32'}", "bound": "hbm", "ms": ms, "GBps": nb / ms / 1e6,
+        res["runs"].append({"op": f"kernel: resample {'fp64' if f64 else 'fp32'}", "ms": ms, "GBps": nb / ms / 1e6,
                             "frac": nb / ms / 1e6 / PEAK_HBM_GBS})
     k = gaussian_1d(1.0).numpy()
     ms = timeit(lambda: ops.separable_filter3d(raw, [k, k, k]))
-    res["runs"].append({"op": "kernel: fused gaussian 9 taps", "bound": "hbm", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
+    res["runs"].append({"op": "kernel: gaussian 9 taps", "ms": ms, "GBps": 8.0 * raw.numel() / ms / 1e6,
                         "frac": 8.0 * raw.numel() / ms / 1e6 / PEAK_HBM_GBS})
     # parity on a 128^3 volume
     torch.manual_seed(11)
@@ -638,6 +638,45 @@ def _rounded(obj, digits: int = 5):
     if isinstance(obj, (list, tuple)):
         return [_rounded(v, digits) for v in obj]
     return obj
+
+
+_EXTRA_DROP = ("steps", "warmup", "launches", "algorithmic_tflops", "cores", "kind", "tolerance", "traffic_src", "min_class_dice")
+LINE_BYTES_MAX = 5800      # the driver's parsed copy keeps a line of this size whole (the 16 KB line of round 4 was cut)
+_TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "config3", "attention"), ("extra", "config3", "cpu_baseline"), ("extra", "fp32_exact", "roofline"),
+               ("conv_ms_per_step",), ("extra", "config4", "parity_vs_cpu_restatement"), ("upconv",))
+
+
+def _slim_extra(obj):
+    """the extras without what the headline's objects already say (steps, units, core counts, labels of the CPU leg): numbers and short labels only"""
+    if isinstance(obj, dict):
+        out = {}
+        for k, v in obj.items():
+            if k in _EXTRA_DROP or v is None or (k == "unit" and v == "voxels/s"):
+                continue
+            out[k] = int(round(v)) if k == "value" and isinstance(v, float) else _slim_extra(v)
+        return out
+    if isinstance(obj, (list, tuple)):
+        return [_slim_extra(v) for v in obj]
+    return obj
+
+
+def _fit_line(line, limit: int = LINE_BYTES_MAX):
+    """drop the least important sub-objects (in _TRIM_ORDER) until the JSON line fits `limit` bytes; what was dropped is named in `trimmed`"""
+    dropped = []
+    for path in _TRIM_ORDER:
+        if len(json.dumps(line)) <= limit:
+            break
+        node = line
+        for k in path[:-1]:
+            node = node.get(k) if isinstance(node, dict) else None
+            if node is None:
+                break
+        if isinstance(node, dict) and path[-1] in node:
+            del node[path[-1]]
+            dropped.append(".".join(path))
+    if dropped:
+        line["trimmed"] = dropped
+    return line
 
 
 def main(argv=None):
@@ -797,8 +836,8 @@ def main(argv=None):
                 except Exception as e:      # an extra must never cost the headline line
                     extra[name] = {"error": f"{type(e).__name__}: {e}"[:160]}
                 torch.cuda.empty_cache()
-            line["extra"] = extra
-        line = _rounded(line)
+            line["extra"] = _slim_extra(extra)
+        line = _fit_line(_rounded(line))
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

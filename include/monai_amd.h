@@ -270,6 +270,16 @@ int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int 
 int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* mask, float* out, int BW, int nW, int S, int heads,
                             int head_dim, float scale, int exact_fp32, void* stream);
 
+/* The same attention with the bias and the mask EVALUATED instead of read from S x S tables (the split-precision kernel, head dims 16 / 32):
+ * bias[h][q][k] = rel_table[(coord[q] - coord[k] + coord_off) * heads + h], the reference's relative_position_bias_table gathered through its
+ * relative_position_index (swin_unetr.py:492-528; the index is linear in the token coordinates: coord[t] = index[t][0], coord_off = index[0][0]);
+ * mask[w][q][k] = region[w % nW][q] == region[w % nW][k] ? 0 : -100, the region ids of compute_mask (swin_unetr.py:774-812) before their pairwise difference.
+ *   rel_table [table_rows][heads]; coord [S] (values in [0, 65536)); region [nW][S] (ids in [0, 65536)) or NULL.
+ * Bit-identical to mh_window_attention_f32 on the materialised tables.  _accepts: head_dim 16 / 32, S <= 1024, table_rows <= 4096. */
+int mh_window_attention_rel_accepts(int S, int head_dim, int table_rows);
+int mh_window_attention_rel_f32(const float* qkv, const float* rel_table, int table_rows, const int32_t* coord, int coord_off, const int32_t* region,
+                                float* out, int BW, int nW, int S, int heads, int head_dim, float scale, void* stream);
+
 /* nn.Linear of the transformer blocks: y[M][N] = act(x[M][K] . w[N][K]^T + bias) (+ residual[M][N]) -- SABlock.qkv / out_proj
  * (monai/networks/blocks/selfattention.py:105-218), MLPBlock.linear1 -> GELU -> linear2 (mlp.py:56-80), the residual sums of
  * TransformerBlock.forward (transformerblock.py:88-105), PatchEmbeddingBlock's projection of the flattened patches
@@ -289,6 +299,17 @@ int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias,
 /* nn.LayerNorm over the last dimension (TransformerBlock.norm1 / norm2, ViT.norm, SwinTransformerBlock.norm1 / norm2, PatchMerging.norm):
  * y = (x - mean) * rsqrt(var + eps) * gamma + beta per row, biased variance.  K <= 4096; gamma / beta may be null. */
 int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M, int K, void* stream);
+
+/* SwinTransformerBlock's data movement folded into the two token-wise kernels around the attention (monai/networks/nets/swin_unetr.py:624-672): with
+ * row_of[(window, token)] = the voxel row of x [B*D*H*W][C] that (window, token) of the padded, cyclically shifted, window-partitioned volume holds (-1 = padding),
+ *   mh_layernorm_gather_f32: y[r] = LayerNorm(x[src_row[r]]) (zeros where src_row[r] < 0) = window_partition(roll(pad(norm1(x)))) in one pass;
+ *   mh_linear_scatter_f32:   y[dst_row[m]] = act(x[m] . w^T + bias) + residual[dst_row[m]] (rows with dst_row[m] < 0 dropped)
+ *                            = shortcut + crop(roll_back(window_reverse(proj(attention)))) in the projection's epilogue.
+ * _gather_accepts: K a multiple of 4, <= 1024; 16-byte aligned tensors.  M_out = rows of y (= entries of src_row); M = rows of x (= entries of dst_row). */
+int mh_layernorm_gather_accepts(int K);
+int mh_layernorm_gather_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M_out, int K, const int32_t* src_row, void* stream);
+int mh_linear_scatter_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                          const int32_t* dst_row, void* stream);
 
 /* ---- UNet pieces (monai/networks/nets/unet.py:106-298) --------------------------------------------------------- */
 

@@ -107,11 +107,16 @@ SIGNATURES = {
     "mh_pad_replicate_f32": (_I, [_T, _T, _P]),
     "mh_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "mh_window_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mh_window_attention_rel_accepts": (_I, [_I, _I, _I]),
+    "mh_window_attention_rel_f32": (_I, [_P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
     "mh_linear_packed_floats": (_L, [_I, _I]),
     "mh_linear_pack_f32": (_I, [_P, _I, _I, _P, _P]),
     "mh_linear_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "mh_linear_tile_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "mh_layernorm_f32": (_I, [_P, _P, _P, _F, _P, _L, _I, _P]),
+    "mh_layernorm_gather_accepts": (_I, [_I]),
+    "mh_layernorm_gather_f32": (_I, [_P, _P, _P, _F, _P, _L, _I, _P, _P]),
+    "mh_linear_scatter_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "mh_affine_resample_workspace_bytes": (_L, [_I, _I, _I]),
     "mh_affine_resample_f32": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, C.POINTER(C.c_double), _I, _I, _I, _I, _P, _P]),
     "mh_separable_filter3d_f32": (_I, [_P, _P, _I, _I, _I, _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_float), _I, _P]),

@@ -67,3 +67,25 @@ POOL_FUSED = None
 def pool_fused() -> bool:
     v = POOL_FUSED if POOL_FUSED is not None else os.environ.get("MONAI_AMD_POOL_FUSED", "1")
     return str(v).lower() not in ("0", "false", "off", "no")
+
+
+# ---- SwinTransformerBlock without its copies -------------------------------------------------------------------------------------
+# SwinUNETR: norm1 + pad + roll + window_partition as one gathering LayerNorm and window_reverse + roll back + crop + the shortcut sum in the projection's epilogue
+# (csrc/kernels/dense.h: layernorm_vec_kernel's src_row, the linear kernels' rowmap) -- the same values, moved once instead of six times.  False (or
+# MONAI_AMD_SWIN_FUSED_MOVES=0 while None) keeps the separate passes.
+SWIN_FUSED_MOVES = None
+
+
+def swin_fused_moves() -> bool:
+    v = SWIN_FUSED_MOVES if SWIN_FUSED_MOVES is not None else os.environ.get("MONAI_AMD_SWIN_FUSED_MOVES", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")
+
+
+# Window attention with the relative position bias / shift mask evaluated inside the kernel (csrc/kernels/attention.h, REL) instead of read from S x S tables -- bit-identical;
+# False (or MONAI_AMD_SWIN_REL_ATTENTION=0 while None) keeps the table form.
+SWIN_REL_ATTENTION = None
+
+
+def swin_rel_attention() -> bool:
+    v = SWIN_REL_ATTENTION if SWIN_REL_ATTENTION is not None else os.environ.get("MONAI_AMD_SWIN_REL_ATTENTION", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")

@@ -1529,8 +1529,8 @@ int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* 
     // (|x| < 65504, no input scaling: ADVICE r4), which hidden states behind a LayerNorm satisfy and a caller who asked for exact fp32 did not sign up for
     if ((head_dim == 16 || head_dim == 32) && !(exact_fp32 && S <= WA_MAX_TOKENS)) {
         const dim3 g2((unsigned)cdiv(S, 128), (unsigned)heads, (unsigned)BW);
-        if (head_dim == 16) hipLaunchKernelGGL((window_attention_h2_kernel<16>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale);
-        else hipLaunchKernelGGL((window_attention_h2_kernel<32>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale);
+        if (head_dim == 16) hipLaunchKernelGGL((window_attention_h2_kernel<16, false>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale, WinRel{});
+        else hipLaunchKernelGGL((window_attention_h2_kernel<32, false>), g2, dim3(256), 0, s0, qkv, bias_t, mask, out, S, heads, nW, scale, WinRel{});
         return launched("window_attention_h2");
     }
     if (S > WA_MAX_TOKENS) return fail(MH_ERR_UNSUPPORTED, "window_attention: %d tokens per window exceed the LDS-resident limit of %d", S, WA_MAX_TOKENS);
@@ -1544,6 +1544,27 @@ int mh_window_attention_f32(const float* qkv, const float* bias_t, const float* 
         default: return fail(MH_ERR_UNSUPPORTED, "window_attention: head_dim %d is not built (8, 16, 32 are)", head_dim);
     }
     return launched("window_attention");
+}
+
+int mh_window_attention_rel_accepts(int S, int head_dim, int table_rows) {
+    return (head_dim == 16 || head_dim == 32) && S >= 1 && S <= WA_REL_TOKENS && table_rows >= 1 && table_rows <= WA_REL_ROWS;
+}
+
+int mh_window_attention_rel_f32(const float* qkv, const float* rel_table, int table_rows, const int32_t* coord, int coord_off, const int32_t* region,
+                                float* out, int BW, int nW, int S, int heads, int head_dim, float scale, void* stream) {
+    if (!qkv || !rel_table || !coord || !out || BW < 1 || S < 1 || heads < 1 || nW < 1) return fail(MH_ERR_ARG, "window_attention_rel: bad argument");
+    if (region && BW % nW) return fail(MH_ERR_ARG, "window_attention_rel: %d windows are not a multiple of the %d mask windows", BW, nW);
+    if (!aligned(qkv, 16) || !aligned(out, 16)) return fail(MH_ERR_ARG, "window_attention_rel: 16-byte aligned tensors required");
+    if (!mh_window_attention_rel_accepts(S, head_dim, table_rows))
+        return fail(MH_ERR_UNSUPPORTED, "window_attention_rel: head dim %d, %d tokens, %d table rows (built: head dims 16 / 32, <= %d tokens, <= %d rows)", head_dim, S,
+                    table_rows, WA_REL_TOKENS, WA_REL_ROWS);
+    const dim3 g2((unsigned)cdiv(S, 128), (unsigned)heads, (unsigned)BW);
+    const WinRel rel{rel_table, coord, region, table_rows, coord_off};
+    if (head_dim == 16)
+        hipLaunchKernelGGL((window_attention_h2_kernel<16, true>), g2, dim3(256), 0, (hipStream_t)stream, qkv, (const float*)nullptr, (const float*)nullptr, out, S, heads, nW, scale, rel);
+    else
+        hipLaunchKernelGGL((window_attention_h2_kernel<32, true>), g2, dim3(256), 0, (hipStream_t)stream, qkv, (const float*)nullptr, (const float*)nullptr, out, S, heads, nW, scale, rel);
+    return launched("window_attention_rel");
 }
 
 // ------------------------------------------------------------------------------------------ dense transformer pieces
@@ -1568,8 +1589,23 @@ int mh_linear_f32(const float* x, const float* packed_w, const float* bias, cons
     return mh_linear_tile_f32(x, packed_w, bias, residual, y, M, N, K, act, 0, stream);
 }
 
+static int linear_impl(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                       int tile, const int32_t* rowmap_, void* stream);
+
 int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
                        int tile, void* stream) {
+    return linear_impl(x, packed_w, bias, residual, y, M, N, K, act, tile, nullptr, stream);
+}
+
+int mh_linear_scatter_f32(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                          const int32_t* dst_row, void* stream) {
+    if (!dst_row) return fail(MH_ERR_ARG, "linear_scatter: null row map");
+    return linear_impl(x, packed_w, bias, residual, y, M, N, K, act, 0, dst_row, stream);
+}
+
+static int linear_impl(const float* x, const float* packed_w, const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                       int tile, const int32_t* rowmap_, void* stream) {
+    const int* rowmap = reinterpret_cast<const int*>(rowmap_);
     if (!x || !packed_w || !y || M < 1 || N < 1 || K < 1) return fail(MH_ERR_ARG, "linear: bad argument");
     if (tile != 0 && tile != 64 && tile != 128) return fail(MH_ERR_ARG, "linear: tile must be 0, 64 or 128 (got %d)", tile);
     if (K % 4 || !aligned(x, 16) || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "linear: K %% 4 == 0 and 16-byte aligned x / packed weights required (K = %d)", K);
@@ -1586,7 +1622,7 @@ int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias,
     const long long big1 = (long long)((M + DN_BM - 1) / DN_BM) * ntn2;
     if (tile == 128 || (tile == 0 && big1 >= 512)) {
         const dim3 bgrid((unsigned)big1);
-#define MH_LINEAR_BIG(A_, R_) hipLaunchKernelGGL((linear_h2_big_kernel<A_, R_, 1>), bgrid, dim3(512), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn2, ntn)
+#define MH_LINEAR_BIG(A_, R_) hipLaunchKernelGGL((linear_h2_big_kernel<A_, R_, 1>), bgrid, dim3(512), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn2, ntn, rowmap)
         if (act == 1 && residual) MH_LINEAR_BIG(1, true);
         else if (act == 1) MH_LINEAR_BIG(1, false);
         else if (residual) MH_LINEAR_BIG(0, true);
@@ -1595,7 +1631,7 @@ int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias,
         return launched("linear");
     }
     const dim3 grid((unsigned)total);
-#define MH_LINEAR_LAUNCH(A_, R_) hipLaunchKernelGGL((linear_h2_kernel<A_, R_>), grid, dim3(256), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn)
+#define MH_LINEAR_LAUNCH(A_, R_) hipLaunchKernelGGL((linear_h2_kernel<A_, R_>), grid, dim3(256), 0, s, x, wq, tail, bias, residual, y, (int)M, N, K, ntn, rowmap)
     if (act == 1 && residual) MH_LINEAR_LAUNCH(1, true);
     else if (act == 1) MH_LINEAR_LAUNCH(1, false);
     else if (residual) MH_LINEAR_LAUNCH(0, true);
@@ -1604,12 +1640,34 @@ int mh_linear_tile_f32(const float* x, const float* packed_w, const float* bias,
     return launched("linear");
 }
 
+static bool layernorm_vec_ok(const float* x, const float* gamma, const float* beta, const float* y, int K) {
+    return K % 4 == 0 && K <= 1024 && aligned(x, 16) && aligned(y, 16) && (!gamma || aligned(gamma, 16)) && (!beta || aligned(beta, 16));
+}
+
+// 16 / 32 / 64 lanes per row, 16-byte vectors (kernels/dense.h); M = output rows
+static void layernorm_vec_launch(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M, int K, const int32_t* src_row, hipStream_t s) {
+#define MH_LNV_LAUNCH(G_, NV_)                                                                                                                       \
+    hipLaunchKernelGGL((layernorm_vec_kernel<G_, NV_>), dim3((unsigned)((M + 4 * (64 / G_) - 1) / (4 * (64 / G_)))), dim3(256), 0, s, x, gamma, beta, eps, y, (int)M, K, \
+                       reinterpret_cast<const int*>(src_row))
+    if (K <= 64) MH_LNV_LAUNCH(16, 1);
+    else if (K <= 128) MH_LNV_LAUNCH(32, 1);
+    else if (K <= 256) MH_LNV_LAUNCH(64, 1);
+    else if (K <= 512) MH_LNV_LAUNCH(64, 2);
+    else if (K <= 768) MH_LNV_LAUNCH(64, 3);
+    else MH_LNV_LAUNCH(64, 4);
+#undef MH_LNV_LAUNCH
+}
+
 int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M, int K, void* stream) {
     if (!x || !y || M < 1 || K < 1) return fail(MH_ERR_ARG, "layernorm: bad argument");
     if (K > 64 * LN_MAXV) return fail(MH_ERR_UNSUPPORTED, "layernorm: %d features exceed the register-resident limit of %d", K, 64 * LN_MAXV);
     if ((M + 3) / 4 > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "layernorm: too many rows for one launch");
-    const dim3 grid((unsigned)((M + 3) / 4));
     hipStream_t s = (hipStream_t)stream;
+    if (layernorm_vec_ok(x, gamma, beta, y, K)) {
+        layernorm_vec_launch(x, gamma, beta, eps, y, M, K, nullptr, s);
+        return launched("layernorm");
+    }
+    const dim3 grid((unsigned)((M + 3) / 4));
 #define MH_LN_LAUNCH(NV_) hipLaunchKernelGGL((layernorm_kernel<NV_>), grid, dim3(256), 0, s, x, gamma, beta, eps, y, (int)M, K)
     if (K <= 64) MH_LN_LAUNCH(1);
     else if (K <= 128) MH_LN_LAUNCH(2);
@@ -1619,6 +1677,17 @@ int mh_layernorm_f32(const float* x, const float* gamma, const float* beta, floa
     else MH_LN_LAUNCH(64);
 #undef MH_LN_LAUNCH
     return launched("layernorm");
+}
+
+int mh_layernorm_gather_accepts(int K) { return K >= 4 && K % 4 == 0 && K <= 1024; }
+
+int mh_layernorm_gather_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t M_out, int K, const int32_t* src_row, void* stream) {
+    if (!x || !y || !src_row || M_out < 1 || K < 1) return fail(MH_ERR_ARG, "layernorm_gather: bad argument");
+    if (!mh_layernorm_gather_accepts(K) || !layernorm_vec_ok(x, gamma, beta, y, K))
+        return fail(MH_ERR_UNSUPPORTED, "layernorm_gather: rows of %d features (built: multiples of 4 up to 1024, 16-byte aligned tensors)", K);
+    if (M_out > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "layernorm_gather: too many rows for one launch");
+    layernorm_vec_launch(x, gamma, beta, eps, y, M_out, K, src_row, (hipStream_t)stream);
+    return launched("layernorm_gather");
 }
 
 // ------------------------------------------------------------------------------------------ UNet pieces

@@ -238,13 +238,30 @@ __global__ void __launch_bounds__(256) window_attention_kernel(const float* __re
 // sizes 48 / 96): the K Q^T product has HD / 16 k-steps, O^T = V^T P^T one 32-row tile whose rows beyond HD multiply zeros (half of its matrix work is padding at
 // HD = 16 -- still a fraction of the VALU kernel's time: S^2 (2 HD) multiply-adds per head become S^2 / 1024 x 9 matrix instructions).
 // A workgroup = 4 waves = 128 queries of one (window, head).  fp32-equivalent like every split-precision kernel here; q, k, v are LayerNorm-ed projections (|x| ~ 1-10).
-template <int HD>      // 16 | 32
+//
+// Round 5, REL: the bias and the mask are no longer READ as S x S tables (470 KB each per head / mask window at 7^3 tokens: 351 KB per workgroup against 66 KB of q, k, v --
+// the kernel ran at the L2's pace, 18.7 % of SwinUNETR's step) but EVALUATED from what they are made of.  The relative position index is linear in the token
+// coordinates, index[q][k] = c(q) - c(k) + off (swin_unetr.py:492-519: the per-axis differences, shifted and multiplied up), so the bias of a pair is one gather
+// from the head's column of the table (at most WA_REL_ROWS floats in LDS) at coord[q] - coord[k] + off; the shift mask is -100 where the two tokens' region ids
+// differ (swin_unetr.py:774-812).  Per key the workgroup keeps coord | region << 16 in LDS; a lane reads the four keys of an accumulator group with one 16-byte read.
+// The sums are formed in the order of the table form (0 + bias, + mask): the results are bit-identical to it.
+struct WinRel {
+    const float* table;      // [rows][heads]: the relative_position_bias_table parameter as it is
+    const int* coord;        // [S]: index[t][0] of token t
+    const int* region;       // [nW][S] region ids of the shifted volume's windows, or null
+    int rows, off;           // off = index[0][0]
+};
+constexpr int WA_REL_ROWS = 4096, WA_REL_TOKENS = 1024;
+
+template <int HD, bool REL>      // 16 | 32
 __global__ void __launch_bounds__(256) window_attention_h2_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_t, const float* __restrict__ mask,
-                                                                  float* __restrict__ out, int S, int heads, int nW, float scale) {
+                                                                  float* __restrict__ out, int S, int heads, int nW, float scale, WinRel rel) {
     constexpr int KS = HD / 16, PER = HD / 8;                  // k-steps of K Q^T; floats a thread stages per key row (2 | 4)
     constexpr int KP = HD + 8, VP = 40;                        // LDS pitches in halves
     __shared__ __attribute__((aligned(16))) _Float16 ks[2][2][32 * KP];     // [buffer][piece][key][d]
     __shared__ __attribute__((aligned(16))) _Float16 vs[2][2][32 * VP];     // [buffer][piece][d (rows >= HD stay zero)][permuted key]
+    __shared__ float tab[REL ? WA_REL_ROWS : 1];                            // this head's column of the bias table
+    __shared__ __attribute__((aligned(16))) unsigned crs[REL ? WA_REL_TOKENS : 4];     // coord | region << 16 per key (zeros beyond the window)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.y, w = blockIdx.z;
@@ -257,6 +274,14 @@ __global__ void __launch_bounds__(256) window_attention_h2_kernel(const float* _
     const float* mk = mask ? mask + (long long)(w % nW) * S * S + qc : nullptr;
 
     for (int i = tid; i < 2 * 2 * 32 * VP / 2; i += 256) reinterpret_cast<unsigned*>(&vs[0][0][0])[i] = 0u;      // the padding rows of V^T
+    unsigned cq = 0u, rq = 0u;
+    if (REL) {
+        const int* reg = rel.region ? rel.region + (long long)(w % nW) * S : nullptr;
+        for (int i = tid; i < rel.rows; i += 256) tab[i] = rel.table[(long long)i * heads + head];
+        for (int i = tid; i < ntiles * 32; i += 256) crs[i] = i < S ? ((unsigned)rel.coord[i] | ((reg ? (unsigned)reg[i] : 0u) << 16)) : 0u;
+        cq = (unsigned)(rel.coord[qc] + rel.off);
+        rq = reg ? (unsigned)reg[qc] : 0u;
+    }
     f16x8 qh[KS], ql[KS];
     {
         const float* qrow = base + (long long)qc * 3 * hd;
@@ -319,13 +344,27 @@ __global__ void __launch_bounds__(256) window_attention_h2_kernel(const float* _
         if (t + 1 < ntiles) MH_WA_LOAD(t + 1)
         // bias + mask of this tile's (key, query) pairs: requested before the matrix work that they are added to
         float add[16];
+        if (REL) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, S - 1);
-            float a_ = 0.0f;
-            if (bt) a_ += bt[(long long)key * S];
-            if (mk) a_ += mk[(long long)key * S];
-            add[r] = a_;
+            for (int g = 0; g < 4; ++g) {
+                const u32x4 v_ = *reinterpret_cast<const u32x4*>(&crs[t * 32 + 8 * g + 4 * hi]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned idx = min(cq - (v_[e] & 0xffffu), (unsigned)(rel.rows - 1));
+                    float a_ = 0.0f + tab[idx];
+                    if (rel.region) a_ += (v_[e] >> 16) != rq ? -100.0f : 0.0f;
+                    add[4 * g + e] = a_;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = min(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, S - 1);
+                float a_ = 0.0f;
+                if (bt) a_ += bt[(long long)key * S];
+                if (mk) a_ += mk[(long long)key * S];
+                add[r] = a_;
+            }
         }
         f32x16 acc;
 #pragma unroll

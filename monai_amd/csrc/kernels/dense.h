@@ -26,10 +26,12 @@ constexpr int DN_BT = 2 * DN_BV;                          // uint4 per packed (c
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // ACT: 0 none, 1 GELU (erf form, nn.GELU()).  RES: add r[m][n] after the activation.
+// rowmap (or null; round 5): the result of input row m is written to (and its residual read from) row rowmap[m], rows with rowmap[m] < 0 are dropped -- SwinUNETR's
+// proj -> window_reverse -> roll back -> crop -> shortcut + x (swin_unetr.py:650-672) inside the projection's epilogue, with the map of layernorm_vec_kernel.
 template <int ACT, bool RES>
 __global__ void __launch_bounds__(256)
 linear_h2_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias,
-                 const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn) {
+                 const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn, const int* __restrict__ rowmap) {
     __shared__ uint4 as[2][2 * DN_AV];
     __shared__ uint4 bs[2][DN_BT];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,8 +102,9 @@ linear_h2_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, cons
         const float bn = (bias && n < N) ? bias[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int m = m0 + 32 * wave + 8 * (i >> 2) + 4 * kg + (i & 3);
-            if (m < M && n < N) {
+            const int mi = m0 + 32 * wave + 8 * (i >> 2) + 4 * kg + (i & 3);
+            const int m = (rowmap && mi < M) ? rowmap[mi] : mi;          // scatter form: output (and residual) row of input row mi, < 0 = dropped
+            if (mi < M && m >= 0 && n < N) {
                 float v = fmaf(acc[nb][i], inv_scale, bn);
                 if (ACT == 1) v = gelu_erf(v);
                 if (RES) v += r[(long long)m * N + n];
@@ -121,7 +124,7 @@ linear_h2_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, cons
 template <int ACT, bool RES, int MT>
 __global__ void __launch_bounds__(512)
 linear_h2_big_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias,
-                     const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn, int nslab) {
+                     const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn, int nslab, const int* __restrict__ rowmap) {
     constexpr int BM = DN_BM * MT, BN = 2 * DN_BN;
     constexpr int AV = 2 * BM;                               // uint4 per piece of an A tile: [k-group][row]
     __shared__ uint4 as[2][2 * AV];
@@ -209,8 +212,9 @@ linear_h2_big_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int m = m0 + 32 * MT * wr + 32 * mt + 8 * (i >> 2) + 4 * kg + (i & 3);
-                if (m < M && n < N) {
+                const int mi = m0 + 32 * MT * wr + 32 * mt + 8 * (i >> 2) + 4 * kg + (i & 3);
+                const int m = (rowmap && mi < M) ? rowmap[mi] : mi;
+                if (mi < M && m >= 0 && n < N) {
                     float v = fmaf(acc[mt][nb][i], inv_scale, bn);
                     if (ACT == 1) v = gelu_erf(v);
                     if (RES) v += r[(long long)m * N + n];
@@ -275,6 +279,58 @@ layernorm_kernel(const float* __restrict__ x, const float* __restrict__ gamma, c
     for (int i = 0; i < NV; ++i) {
         const int k = lane + 64 * i;
         if (k < K) yr[k] = fmaf((v[i] - mean) * rstd, gamma ? gamma[k] : 1.0f, beta ? beta[k] : 0.0f);
+    }
+}
+
+// Round 5: rows whose length is a multiple of 4 and at most 1024 (SwinUNETR's 48 ... 768-feature stages, ViT-B's 768; 16-byte aligned rows): G = 16 | 32 | 64 lanes per
+// row, NV 16-byte vectors per lane, 64 / G rows per wave.  The one-wave-per-row form moved 192 bytes per wave instruction at 48 features (1.56 ms for 7 M rows =
+// 1.75 TB/s).  Same two-pass arithmetic; the partial sums are formed per lane and then across the row's lanes.
+// src_row (or null): output row r is the normalised INPUT row src_row[r], or zeros where src_row[r] < 0 -- SwinUNETR's norm1 -> pad -> roll -> window_partition
+// (swin_unetr.py:624-648) as one pass: the map holds, per (window, token), the voxel row it comes from (-1 = padding, which the reference appends after the norm).
+template <int G, int NV>
+__global__ void __launch_bounds__(256)
+layernorm_vec_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float* __restrict__ y,
+                     int M, int K, const int* __restrict__ src_row) {
+    constexpr int RPW = 64 / G;                                // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % G;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / G;
+    const bool rok = row < M;
+    const long long srow = rok ? (src_row ? (long long)src_row[row] : row) : -1;
+    f32x4 v[NV];
+    bool ok[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        ok[i] = srow >= 0 && 4 * (sub + G * i) < K;
+        v[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (ok[i]) v[i] = *reinterpret_cast<const f32x4*>(x + srow * K + 4 * (sub + G * i));
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)K;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = ok[i] ? f32x4{v[i][0] - mean, v[i][1] - mean, v[i][2] - mean, v[i][3] - mean} : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        q = fmaf(v[i][3], v[i][3], fmaf(v[i][2], v[i][2], fmaf(v[i][1], v[i][1], fmaf(v[i][0], v[i][0], q))));
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k = 4 * (sub + G * i);
+        if (!rok || k >= K) continue;
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (srow >= 0) {
+            f32x4 g = {1.0f, 1.0f, 1.0f, 1.0f}, b = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (gamma) g = *reinterpret_cast<const f32x4*>(gamma + k);
+            if (beta) b = *reinterpret_cast<const f32x4*>(beta + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(v[i][e] * rstd, g[e], b[e]);
+        }
+        *reinterpret_cast<f32x4*>(y + row * K + k) = o;
     }
 }
 

@@ -29,11 +29,13 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ... import _lib, _prof, ops
+from ... import _lib, _prof, config, ops
 from ...utils.misc import ensure_tuple_rep
 from .unetr import UNETR, _BasicBlock, _OutBlock, _trunc_normal_, _UpBlock
 
 __all__ = ["SwinUNETR"]
+
+_EXACT_ALGOS = tuple(config.CONV_ALGOS[k] for k in ("fp32", "direct", "wino2d"))     # the families ops.window_attention keeps on the exact-fp32 kernel
 
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
@@ -130,8 +132,27 @@ def _window_reverse(windows, ws, dims):
     return x.permute(0, 1, 4, 2, 5, 3, 6, 7).contiguous().view(b, d, h, w, -1)
 
 
-def _compute_mask(dims, ws, ss, device):
-    """swin_unetr.py:774-812: region ids of the cyclically shifted volume -> [nW, S, S] additive mask (0 / -100)"""
+def _window_rows(b, dims, ws, ss, device):
+    """int32 [b * nW * S]: the row of x.reshape(-1, C) (x channel-last [b, d, h, w, C]) that every (window, token) of the padded, cyclically shifted, window-partitioned
+    volume holds, -1 for the padding -- SwinTransformerBlock.forward's pad / roll(-shift) / window_partition (swin_unetr.py:628-648) as an index map; its inverse use
+    (scatter through the same map) is window_reverse / roll(+shift) / crop (:660-670)"""
+    d, h, w = dims
+    dp, hp, wp = (-(-d // ws[0]) * ws[0], -(-h // ws[1]) * ws[1], -(-w // ws[2]) * ws[2])
+    if b * d * h * w >= 2 ** 31:
+        raise RuntimeError("monai_amd.SwinUNETR: more than 2^31 tokens in one launch")
+    jz = (torch.arange(dp, device=device) + ss[0]) % dp            # rolled position i holds padded index (i + shift) mod extent
+    jy = (torch.arange(hp, device=device) + ss[1]) % hp
+    jx = (torch.arange(wp, device=device) + ss[2]) % wp
+    row = (jz[:, None, None] * h + jy[None, :, None]) * w + jx[None, None, :]
+    inside = (jz < d)[:, None, None] & (jy < h)[None, :, None] & (jx < w)[None, None, :]
+    row = torch.where(inside, row, torch.full_like(row, -1))
+    row = row.view(dp // ws[0], ws[0], hp // ws[1], ws[1], wp // ws[2], ws[2]).permute(0, 2, 4, 1, 3, 5).reshape(1, -1)
+    off = (torch.arange(b, device=device) * (d * h * w))[:, None]
+    return torch.where(row >= 0, row + off, row).reshape(-1).to(torch.int32).contiguous()
+
+
+def _region_ids(dims, ws, ss, device):
+    """swin_unetr.py:774-797: the region ids (0 .. 26) of the cyclically shifted volume, window-partitioned: [nW, S]"""
     d, h, w = dims
     img = torch.zeros((1, d, h, w, 1), device=device)
     cnt = 0
@@ -140,7 +161,12 @@ def _compute_mask(dims, ws, ss, device):
             for sw in (slice(-ws[2]), slice(-ws[2], -ss[2]), slice(-ss[2], None)):
                 img[:, sd, sh, sw, :] = cnt
                 cnt += 1
-    mw = _window_partition(img, ws).squeeze(-1)
+    return _window_partition(img, ws).squeeze(-1)
+
+
+def _compute_mask(dims, ws, ss, device):
+    """swin_unetr.py:774-812: region ids -> [nW, S, S] additive mask (0 where two tokens share a region, -100 elsewhere)"""
+    mw = _region_ids(dims, ws, ss, device)
     am = mw.unsqueeze(1) - mw.unsqueeze(2)
     return am.masked_fill(am != 0, -100.0).masked_fill(am == 0, 0.0).contiguous()
 
@@ -211,6 +237,8 @@ class SwinUNETR(UNETR):
         self._stats = None
         self._bias_cache: dict = {}
         self._mask_cache: dict = {}
+        self._rel_cache: dict = {}
+        self._rows_cache: dict = {}
 
     # ---- Swin transformer ----------------------------------------------------------------------------------
     def _bias_t(self, attn: _WindowAttention, n: int) -> torch.Tensor:
@@ -225,36 +253,61 @@ class SwinUNETR(UNETR):
             self._bias_cache[id(attn)] = hit
         return hit[1]
 
-    def _mask(self, dims, ws, ss, device) -> torch.Tensor:
-        key = (tuple(dims), tuple(ws), tuple(ss), str(device))
+    def _mask(self, dims, ws, ss, device, regions: bool = False) -> torch.Tensor:
+        """the shift mask of a (feature map, window, shift): [nW, S, S] additive table, or (regions) the int32 [nW, S] region ids it is the pairwise comparison of"""
+        key = (tuple(dims), tuple(ws), tuple(ss), str(device), regions)
         m = self._mask_cache.get(key)
         if m is None:
-            if len(self._mask_cache) > 16:
+            if len(self._mask_cache) > 32:
                 self._mask_cache.clear()
-            m = self._mask_cache[key] = _compute_mask(dims, ws, ss, device)
+            m = _region_ids(dims, ws, ss, device).to(torch.int32).contiguous() if regions else _compute_mask(dims, ws, ss, device)
+            self._mask_cache[key] = m
+        return m
+
+    def _rel(self, attn: _WindowAttention, n: int):
+        """(table, coord, off) when the first n x n entries of the layer's relative_position_index are what swin_unetr.py:492-519 builds -- linear in the
+        token coordinates, index[q][k] = coord[q] - coord[k] + off with coord[t] = index[t][0], off = index[0][0] (checked once per layer and n, on the buffer
+        itself: a state_dict may have replaced it) -- and the kernel that evaluates the bias from the table takes the shape; else None (the S x S table form)."""
+        t, idx = attn.relative_position_bias_table, attn.relative_position_index
+        key = (idx.data_ptr(), idx._version, str(idx.device), n, t.shape[0])
+        hit = self._rel_cache.get(id(attn))
+        if hit is None or hit[0] != key:
+            sub = idx[:n, :n].to(torch.int64)
+            coord = sub[:, 0].contiguous()
+            off = int(sub[0, 0])
+            linear = bool(torch.equal(sub, coord[:, None] - coord[None, :] + off)) and int(sub.min()) >= 0 and int(sub.max()) < t.shape[0]
+            hit = (key, (coord.to(torch.int32).contiguous(), off) if linear else None)
+            self._rel_cache[id(attn)] = hit
+        return hit[1]
+
+    def _rows(self, b, dims, ws, ss, device) -> torch.Tensor:
+        key = (b, tuple(dims), tuple(ws), tuple(ss), str(device))
+        m = self._rows_cache.get(key)
+        if m is None:
+            if len(self._rows_cache) > 24:
+                self._rows_cache.clear()
+            m = self._rows_cache[key] = _window_rows(b, dims, ws, ss, device)
         return m
 
     def _block(self, blk: _SwinBlock, x):
         """SwinTransformerBlock.forward (swin_unetr.py:598-697) on channel-last x [B, d, h, w, C]"""
         b, d, h, w, c = x.shape
-        y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-5)
         ws, ss = _get_window_size((d, h, w), blk.window_size, blk.shift_size)
         pd, ph, pw = (ws[0] - d % ws[0]) % ws[0], (ws[1] - h % ws[1]) % ws[1], (ws[2] - w % ws[2]) % ws[2]
-        if pd or ph or pw:
-            y = F.pad(y, (0, 0, 0, pw, 0, ph, 0, pd))
         dp, hp, wp = d + pd, h + ph, w + pw
         shifted = any(s > 0 for s in ss)
-        mask = None
+        a = blk.attn
+        if config.swin_fused_moves() and ops.layernorm_gather_accepts(c):
+            return self._block_mapped(blk, x, ws, ss, (dp, hp, wp), shifted)
+        y = ops.layernorm(x, blk.norm1.weight, blk.norm1.bias, 1e-5)
+        if pd or ph or pw:
+            y = F.pad(y, (0, 0, 0, pw, 0, ph, 0, pd))
+        n, hd = ws[0] * ws[1] * ws[2], c // a.num_heads
         if shifted:
             y = torch.roll(y, shifts=(-ss[0], -ss[1], -ss[2]), dims=(1, 2, 3))
-            mask = self._mask((dp, hp, wp), ws, ss, x.device)
         win = _window_partition(y, ws)                                        # [BW, S, C]
-        a = blk.attn
         qkv = self._lin(win, a.qkv.weight, a.qkv.bias)
-        n = win.shape[1]
-        hd = c // a.num_heads
-        with _prof.span("window_attention", 4.0 * n * n * hd * a.num_heads * win.shape[0]):
-            att = ops.window_attention(qkv, a.num_heads, a.scale, self._bias_t(a, n), mask)
+        att = self._attention(a, qkv, n, hd, (dp, hp, wp), ws, ss, shifted)
         att = self._lin(att, a.proj.weight, a.proj.bias)
         y = _window_reverse(att, ws, (b, dp, hp, wp))
         if shifted:
@@ -262,6 +315,35 @@ class SwinUNETR(UNETR):
         if pd or ph or pw:
             y = y[:, :d, :h, :w, :].contiguous()
         x = (x + y).contiguous()
+        m = self._lin(ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, 1e-5), blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
+        return self._lin(m, blk.mlp.linear2.weight, blk.mlp.linear2.bias, residual=x)
+
+    def _attention(self, a: _WindowAttention, qkv, n, hd, padded_dims, ws, ss, shifted):
+        """the window attention of one block: bias and mask evaluated from the table / the region ids where the kernel takes the shape (split precision, head dims
+        16 / 32) and the exact-fp32 family is not pinned; the S x S table form otherwise"""
+        t = a.relative_position_bias_table
+        rel = None
+        if (config.swin_rel_attention() and config.conv_algo() not in _EXACT_ALGOS and t.dtype == torch.float32 and t.is_contiguous()
+                and ops.window_attention_rel_accepts(n, hd, t.shape[0])):
+            rel = self._rel(a, n)
+        mask = self._mask(padded_dims, ws, ss, qkv.device, regions=rel is not None) if shifted else None
+        with _prof.span("window_attention", 4.0 * n * n * hd * a.num_heads * qkv.shape[0]):
+            if rel is not None:
+                return ops.window_attention_rel(qkv, a.num_heads, a.scale, t, rel[0], rel[1], mask)
+            return ops.window_attention(qkv, a.num_heads, a.scale, self._bias_t(a, n), mask)
+
+    def _block_mapped(self, blk: _SwinBlock, x, ws, ss, padded_dims, shifted):
+        """the block with its data movement folded into the kernels on either side of the attention (round 5): norm1 + pad + roll + window_partition = one gathering
+        LayerNorm, window_reverse + roll back + crop + the shortcut sum = the projection's epilogue, both through one row map (`_window_rows`) -- the reference's
+        six copies of the hidden state per block (swin_unetr.py:628-672) are not made"""
+        b, d, h, w, c = x.shape
+        a = blk.attn
+        n, hd = ws[0] * ws[1] * ws[2], c // a.num_heads
+        rows = self._rows(b, (d, h, w), ws, ss, x.device)
+        win = ops.layernorm_gather(x, blk.norm1.weight, blk.norm1.bias, 1e-5, rows).view(-1, n, c)
+        qkv = self._lin(win, a.qkv.weight, a.qkv.bias)
+        att = self._attention(a, qkv, n, hd, padded_dims, ws, ss, shifted)
+        x = self._lin(att, a.proj.weight, a.proj.bias, residual=x, scatter=rows)
         m = self._lin(ops.layernorm(x, blk.norm2.weight, blk.norm2.bias, 1e-5), blk.mlp.linear1.weight, blk.mlp.linear1.bias, gelu=True)
         return self._lin(m, blk.mlp.linear2.weight, blk.mlp.linear2.bias, residual=x)
 

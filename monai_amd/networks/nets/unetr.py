@@ -301,9 +301,10 @@ class UNETR(nn.Module):
         return torch.empty((n, c) + sp, dtype=torch.float32, device=like.device)
 
     # ---- ViT ---------------------------------------------------------------------------------------
-    def _lin(self, x, weight, bias, residual=None, gelu=False):
+    def _lin(self, x, weight, bias, residual=None, gelu=False, scatter=None):
         """nn.Linear (+ GELU) (+ residual) as ONE launch of the split-precision GEMM kernel (csrc/kernels/dense.h); the packed weight
-        is cached per parameter (re-packed when the parameter is updated in place or moved)."""
+        is cached per parameter (re-packed when the parameter is updated in place or moved).  scatter: int32 row map -- row m of the result lands in (and takes its
+        residual from) row scatter[m] of a tensor shaped like `residual` (ops.linear_scatter)."""
         key = (weight.data_ptr(), weight._version, str(weight.device))
         hit = self._packed.get(("lin", id(weight)))
         if hit is None or hit[0] != key:
@@ -311,6 +312,8 @@ class UNETR(nn.Module):
             self._packed[("lin", id(weight))] = hit
         m = x.numel() // x.shape[-1]
         with _prof.span("linear", 2.0 * m * weight.shape[0] * x.shape[-1]):
+            if scatter is not None:
+                return ops.linear_scatter(x, hit[1], weight.shape[0], bias, residual, scatter, gelu=gelu)
             return ops.linear(x, hit[1], weight.shape[0], bias, residual, gelu=gelu)
 
     def _vit(self, x_in):

@@ -610,6 +610,33 @@ def window_attention(qkv: torch.Tensor, heads: int, scale: float, bias_t: Option
     return out
 
 
+def window_attention_rel_accepts(s: int, hd: int, table_rows: int) -> bool:
+    return bool(_lib.lib().query("mh_window_attention_rel_accepts", int(s), int(hd), int(table_rows)))
+
+
+def window_attention_rel(qkv: torch.Tensor, heads: int, scale: float, rel_table: torch.Tensor, coord: torch.Tensor, coord_off: int,
+                         region: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """window_attention with bias[h][q][k] = rel_table[coord[q] - coord[k] + coord_off][h] and mask[w][q][k] = 0 where region[w][q] == region[w][k], else -100,
+    evaluated inside the kernel (no S x S tables; split precision, head dims 16 / 32).  rel_table [rows, heads] fp32, coord [S] int32, region [nW, S] int32 or None."""
+    _lib.require_device(qkv, rel_table)
+    _lib.require_device(coord, region, dtypes=(torch.int32,))
+    if qkv.dim() != 3 or not qkv.is_contiguous() or qkv.shape[2] % (3 * heads):
+        raise RuntimeError(f"monai_amd.window_attention_rel: qkv must be contiguous [BW, S, 3*heads*hd], got {tuple(qkv.shape)}")
+    bw, s, c3 = qkv.shape
+    hd = c3 // (3 * heads)
+    if rel_table.dim() != 2 or rel_table.shape[1] != heads or rel_table.dtype != torch.float32 or not rel_table.is_contiguous():
+        raise RuntimeError(f"monai_amd.window_attention_rel: rel_table must be contiguous fp32 [rows, {heads}], got {tuple(rel_table.shape)}")
+    if coord.dtype != torch.int32 or tuple(coord.shape) != (s,) or not coord.is_contiguous():
+        raise RuntimeError(f"monai_amd.window_attention_rel: coord must be contiguous int32 [{s}]")
+    if region is not None and (region.dtype != torch.int32 or region.dim() != 2 or region.shape[1] != s or not region.is_contiguous()):
+        raise RuntimeError(f"monai_amd.window_attention_rel: region must be contiguous int32 [nW, {s}]")
+    nw = int(region.shape[0]) if region is not None else 1
+    out = torch.empty((bw, s, heads * hd), dtype=torch.float32, device=qkv.device)
+    _lib.lib().call("mh_window_attention_rel_f32", _lib.ptr(qkv), _lib.ptr(rel_table), int(rel_table.shape[0]), _lib.ptr(coord), int(coord_off), _lib.ptr(region),
+                    _lib.ptr(out), bw, nw, s, int(heads), hd, float(scale), _s(qkv))
+    return out
+
+
 def linear_pack(weight: torch.Tensor) -> torch.Tensor:
     """Pack an nn.Linear weight [N, K] for `linear` (two fp16 pieces per value, power-of-two layer scale, tile layout); once per layer."""
     _lib.require_device(weight)
@@ -655,6 +682,44 @@ def layernorm(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[to
         raise NotImplementedError(f"monai_amd.layernorm: {k} features are not on the HIP path (<= 4096 are)")
     out = torch.empty_like(x)
     _lib.lib().call("mh_layernorm_f32", _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), float(eps), _lib.ptr(out), x.numel() // k, k, _s(x))
+    return out
+
+
+def layernorm_gather_accepts(k: int) -> bool:
+    return bool(_lib.lib().query("mh_layernorm_gather_accepts", int(k)))
+
+
+def layernorm_gather(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float, src_row: torch.Tensor) -> torch.Tensor:
+    """y[r] = LayerNorm(x.reshape(-1, K)[src_row[r]]), zeros where src_row[r] < 0: [len(src_row), K] -- SwinUNETR's norm1 -> pad -> roll -> window_partition in one pass
+    (src_row int32: the voxel row every (window, token) row holds)."""
+    _lib.require_device(x, weight, bias)
+    _lib.require_device(src_row, dtypes=(torch.int32,))
+    if not x.is_contiguous() or not src_row.is_contiguous() or src_row.dim() != 1:
+        raise RuntimeError("monai_amd.layernorm_gather: contiguous x and a contiguous 1-D int32 row map are required")
+    k = int(x.shape[-1])
+    out = torch.empty((src_row.numel(), k), dtype=torch.float32, device=x.device)
+    _lib.lib().call("mh_layernorm_gather_f32", _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), float(eps), _lib.ptr(out), src_row.numel(), k, _lib.ptr(src_row), _s(x))
+    return out
+
+
+def linear_scatter(x: torch.Tensor, packed_w: torch.Tensor, n_out: int, bias: Optional[torch.Tensor], residual: torch.Tensor, dst_row: torch.Tensor,
+                   gelu: bool = False) -> torch.Tensor:
+    """out = empty_like(residual); out[dst_row[m]] = act(x[m] . W^T + bias) + residual[dst_row[m]] for every row m of x with dst_row[m] >= 0 -- SwinUNETR's proj ->
+    window_reverse -> roll back -> crop -> shortcut + x in the projection's epilogue.  Every row of `residual` must be the image of exactly one row of x (the caller's
+    map is a bijection between the non-padding window rows and the voxel rows); residual [..., N] contiguous."""
+    _lib.require_device(x, packed_w, bias, residual)
+    _lib.require_device(dst_row, dtypes=(torch.int32,))
+    if not x.is_contiguous():
+        x = x.contiguous()
+    k = int(x.shape[-1])
+    m = x.numel() // k
+    if k % 4:
+        raise NotImplementedError(f"monai_amd.linear_scatter: {k} input features are not on the HIP path (a multiple of 4 is)")
+    if not residual.is_contiguous() or residual.shape[-1] != n_out or not dst_row.is_contiguous() or dst_row.numel() != m:
+        raise RuntimeError("monai_amd.linear_scatter: residual must be contiguous [..., N] and dst_row hold one entry per row of x")
+    out = torch.empty_like(residual)
+    _lib.lib().call("mh_linear_scatter_f32", _lib.ptr(x), _lib.ptr(packed_w), _lib.ptr(bias), _lib.ptr(residual), _lib.ptr(out), m, int(n_out), k, 1 if gelu else 0,
+                    _lib.ptr(dst_row), _s(x))
     return out
 
 

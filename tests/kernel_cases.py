@@ -580,6 +580,48 @@ def case_window_attention(device, bw=4, s=343, heads=3, hd=16, nw=2, tol=2e-6):
     return err
 
 
+def _swin_relative_index(ws):
+    """relative_position_index of a 3-D window as WindowAttention.__init__ builds it (monai/networks/nets/swin_unetr.py:492-519) -- restated from its description:
+    per-axis coordinate differences, shifted to start at 0, mixed-radix with digits (2 ws - 1)"""
+    zz, yy, xx = torch.meshgrid(torch.arange(ws[0]), torch.arange(ws[1]), torch.arange(ws[2]), indexing="ij")
+    co = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])               # [3, S]
+    rel = co[:, :, None] - co[:, None, :] + torch.tensor([ws[0] - 1, ws[1] - 1, ws[2] - 1])[:, None, None]
+    return rel[0] * (2 * ws[1] - 1) * (2 * ws[2] - 1) + rel[1] * (2 * ws[2] - 1) + rel[2]
+
+
+def case_window_attention_rel(device, bw=4, ws=(7, 7, 7), n=None, heads=3, hd=16, nw=2, masked=True, tol=2e-6):
+    """mh_window_attention_rel_f32: bias gathered from the relative-position table and mask from region ids inside the kernel == the table form
+    (mh_window_attention_f32 on the materialised [heads, S, S] bias and [nW, S, S] mask) BIT FOR BIT, and both against fp64 torch.  n < prod(ws): the
+    reference's clamped-window case (relative_position_index[:n, :n] of the full window's index, swin_unetr.py:524-528)"""
+    s_full = ws[0] * ws[1] * ws[2]
+    n = n or s_full
+    gen = torch.Generator().manual_seed(11 + n + hd)
+    rows = (2 * ws[0] - 1) * (2 * ws[1] - 1) * (2 * ws[2] - 1)
+    table = torch.randn(rows, heads, generator=gen) * 0.5
+    index = _swin_relative_index(ws)[:n, :n]
+    qkv = torch.randn(bw, n, 3 * heads * hd, generator=gen)
+    region = torch.randint(0, 5, (nw, n), generator=gen).to(torch.int32) if masked else None
+    scale = hd ** -0.5
+    bias = table[index.reshape(-1)].reshape(n, n, heads).permute(2, 0, 1).contiguous()       # [head][query][key]
+    mask = None
+    if masked:
+        diff = region[:, None, :].float() - region[:, :, None].float()
+        mask = torch.where(diff != 0, -100.0, 0.0).contiguous()
+    coord, off = index[:, 0].to(torch.int32).contiguous(), int(index[0, 0])
+    assert ops.window_attention_rel_accepts(n, hd, rows)
+    got = ops.window_attention_rel(qkv.to(device), heads, scale, table.to(device), coord.to(device), off, None if region is None else region.to(device)).cpu()
+    tab = ops.window_attention(qkv.to(device), heads, scale, bias.transpose(1, 2).contiguous().to(device), None if mask is None else mask.to(device), exact=False).cpu()
+    assert torch.equal(got, tab), f"window attention rel vs table form: {(got - tab).abs().max().item()}"
+    q, k, v = qkv.double().reshape(bw, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = (q * scale) @ k.transpose(-2, -1) + bias.double()[None]
+    if masked:
+        att = att + mask.double()[torch.arange(bw) % nw][:, None]
+    exp = (att.softmax(-1) @ v).transpose(1, 2).reshape(bw, n, heads * hd)
+    err = (got.double() - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"window attention rel n={n} hd={hd}: max err {err}"
+    return err
+
+
 def case_add_act(device):
     gen = torch.Generator().manual_seed(9)
     a, b = torch.randn(2, 5, 6, 8, 12, generator=gen), torch.randn(2, 5, 6, 8, 12, generator=gen)
@@ -660,6 +702,37 @@ def case_layernorm(device, m, k):
     assert (got - exp).abs().max().item() < 5e-6, (got - exp).abs().max().item()
     got = ops.layernorm(x.to(device), None, None, 1e-6).cpu().double()
     assert (got - F.layer_norm(x.double(), (k,), None, None, 1e-6)).abs().max().item() < 5e-6
+
+
+def case_layernorm_gather_linear_scatter(device, m_src=150, m_out=210, k=48, n=96):
+    """mh_layernorm_gather_f32 / mh_linear_scatter_f32 (SwinTransformerBlock's copies folded into the kernels around the attention): rows gathered through an int32
+    map with -1 = zero rows, and scattered back through it with the residual taken at the destination -- each against the separate operations, bit for bit"""
+    gen = torch.Generator().manual_seed(77 + k)
+    x = torch.randn(m_src, k, generator=gen) * 2.0 + 0.3
+    g, b = torch.rand(k, generator=gen) + 0.5, torch.randn(k, generator=gen) * 0.2
+    perm = torch.randperm(m_out, generator=gen)
+    rows = torch.full((m_out,), -1, dtype=torch.int32)
+    rows[perm[:m_src]] = torch.arange(m_src, dtype=torch.int32)            # every source row exactly once, the other m_out - m_src rows are padding
+    xd, gd, bd, rd = x.to(device), g.to(device), b.to(device), rows.to(device)
+    assert ops.layernorm_gather_accepts(k)
+    got = ops.layernorm_gather(xd, gd, bd, 1e-5, rd).cpu()
+    plain = ops.layernorm(xd, gd, bd, 1e-5).cpu()
+    exp = torch.zeros(m_out, k)
+    exp[rows >= 0] = plain[rows[rows >= 0].long()]
+    assert torch.equal(got, exp)
+    ref = F.layer_norm(x.double(), (k,), g.double(), b.double(), 1e-5)
+    assert (plain.double() - ref).abs().max().item() < 5e-6
+    # the way back: a linear map of the gathered rows, written to the source order with the residual added there
+    w = torch.randn(n, k, generator=gen) / k ** 0.5
+    bias = torch.randn(n, generator=gen) * 0.1
+    res = torch.randn(m_src, n, generator=gen)
+    packed = ops.linear_pack(w.to(device))
+    y_rows = ops.linear(got.to(device), packed, n, bias.to(device)).cpu()                   # [m_out, n]
+    scat = ops.linear_scatter(got.to(device), packed, n, bias.to(device), res.to(device), rd).cpu()
+    exp2 = torch.empty(m_src, n)
+    exp2[rows[rows >= 0].long()] = y_rows[rows >= 0] + res[rows[rows >= 0].long()]
+    assert torch.equal(scat, exp2), (scat - exp2).abs().max().item()
+    return True
 
 
 def case_sw_blend_mosaic(device):

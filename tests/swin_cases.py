@@ -45,3 +45,62 @@ def case_swin_unetr_vs_golden(device, names=("a", "b", "c")):
         assert err < TOL, (name, err)
         res[name] = err
     return res
+
+
+def case_swin_rel_attention_bitwise(device, shape=(1, 1, 32, 32, 64)):
+    """Round 5: the window attention that evaluates bias / mask from the relative-position table and the region ids leaves the network's output bit-identical to
+    the S x S table form (feature size 48 = head dim 16; 32 x 32 x 64 voxels: shifted 7^3 windows on padded maps, clamped 4^3 / 2^3 windows, mixed clamping)"""
+    from monai_amd import ops
+    from monai_amd.networks.nets import swin_unetr as mod
+
+    torch.manual_seed(3)
+    net = SwinUNETR(in_channels=1, out_channels=3, feature_size=48).eval().to(device)
+    x = torch.rand(shape).to(device)
+    calls = {"rel": 0, "table": 0}
+    real_rel, real_tab, real_acc = ops.window_attention_rel, ops.window_attention, ops.window_attention_rel_accepts
+
+    def count_rel(*a, **k):
+        calls["rel"] += 1
+        return real_rel(*a, **k)
+
+    def count_tab(*a, **k):
+        calls["table"] += 1
+        return real_tab(*a, **{**k, "exact": False})
+
+    # the split-precision attention in both runs whatever convolution family the session pinned (the emulator runs the exact-fp32 convolutions: conftest.emu)
+    ops.window_attention_rel, ops.window_attention = count_rel, count_tab
+    exact_algos, mod._EXACT_ALGOS = mod._EXACT_ALGOS, ()
+    try:
+        y_rel = net(x).cpu()
+        n_rel = dict(calls)
+        ops.window_attention_rel_accepts = lambda *a: False
+        y_tab = net(x).cpu()
+    finally:
+        ops.window_attention_rel, ops.window_attention, ops.window_attention_rel_accepts = real_rel, real_tab, real_acc
+        mod._EXACT_ALGOS = exact_algos
+    assert n_rel["rel"] == 8 and n_rel["table"] == 0, n_rel           # four stages x two blocks
+    assert calls["table"] == 8, calls
+    assert torch.isfinite(y_rel).all()
+    assert torch.equal(y_rel, y_tab), float((y_rel - y_tab).abs().max())
+    return n_rel
+
+
+def case_swin_fused_moves_bitwise(device, shape=(2, 1, 32, 32, 64)):
+    """Round 5: norm1 + pad + roll + window_partition as one gathering LayerNorm and window_reverse + roll back + crop + shortcut sum in the projection's epilogue
+    (config.SWIN_FUSED_MOVES) == the separate passes, bit for bit (two samples: the row map's batch offsets; padded 21 x 21 x 35 maps, shifts, clamped windows)"""
+    from monai_amd import config
+
+    torch.manual_seed(4)
+    net = SwinUNETR(in_channels=1, out_channels=2, feature_size=24).eval().to(device)
+    x = torch.rand(shape).to(device)
+    saved = config.SWIN_FUSED_MOVES
+    try:
+        config.SWIN_FUSED_MOVES = False
+        y_sep = net(x).cpu()
+        config.SWIN_FUSED_MOVES = True
+        y_fused = net(x).cpu()
+    finally:
+        config.SWIN_FUSED_MOVES = saved
+    assert torch.isfinite(y_sep).all()
+    assert torch.equal(y_sep, y_fused), float((y_sep - y_fused).abs().max())
+    return True

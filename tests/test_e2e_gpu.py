@@ -305,3 +305,16 @@ def test_buffered_schedule_with_callbacks_bitwise_vs_reference():
 
 def test_pooling_epilogue_leaves_the_logits_bitwise():
     assert ec.case_net_pool_fused_bitwise(DEV)
+
+
+def test_swin_attention_from_table_and_regions_bitwise():
+    """round 5: window attention with bias / mask evaluated in the kernel == the S x S table form through the whole SwinUNETR, bit for bit"""
+    import swin_cases as sc
+
+    print(sc.case_swin_rel_attention_bitwise(DEV))
+
+
+def test_swin_block_moves_folded_into_kernels_bitwise():
+    import swin_cases as sc
+
+    assert sc.case_swin_fused_moves_bitwise(DEV)

@@ -240,7 +240,7 @@ def test_linear_fp16_split_precision(emu, m, n, k, gelu, res):
     kc.case_linear("cpu", m, n, k, gelu=gelu, residual=res, bias=False)
 
 
-@pytest.mark.parametrize("m,k", [(7, 48), (130, 768), (5, 100)])
+@pytest.mark.parametrize("m,k", [(7, 48), (130, 768), (5, 100), (33, 96), (70, 24), (9, 192), (6, 256), (3, 50), (4, 260)])
 def test_layernorm(emu, m, k):
     kc.case_layernorm("cpu", m, k)
 
@@ -263,6 +263,18 @@ def test_conv_one_input_channel(emu):
 def test_window_attention(emu, s, hd):
     """SwinUNETR's WindowAttention core: head dims 16 / 32 on the split-precision matrix-core kernel (round 4), 8 on the VALU kernel"""
     kc.case_window_attention("cpu", bw=2 if "cpu" == "cpu" else 6, s=s, heads=2, hd=hd)
+
+
+@pytest.mark.parametrize("m_src,m_out,k,n", [(150, 210, 48, 96), (64, 64, 192, 64), (37, 50, 384, 40)])
+def test_layernorm_gather_linear_scatter(emu, m_src, m_out, k, n):
+    """SwinTransformerBlock's copies folded into the gathering LayerNorm and the projection's scattering epilogue (round 5)"""
+    assert kc.case_layernorm_gather_linear_scatter("cpu", m_src, m_out, k, n)
+
+
+@pytest.mark.parametrize("ws,n,hd,masked", [((7, 7, 7), None, 16, True), ((7, 7, 7), 216, 32, True), pytest.param((7, 7, 7), None, 32, False, marks=pytest.mark.heavy_emu), ((3, 4, 5), None, 16, True)])
+def test_window_attention_rel(emu, ws, n, hd, masked):
+    """bias from the relative-position table + mask from region ids inside the kernel (round 5) == the S x S table form bit for bit; 216 of 343 = a clamped 6^3 window"""
+    kc.case_window_attention_rel("cpu", bw=2, ws=ws, n=n, heads=2, hd=hd, masked=masked)
 
 
 # (n, up channels, couts, coarse extents): one whole tile / ragged tiles in y and x with two cout groups / two z-chunks / one plane pair with x tiles of 16 + 16 + 4
