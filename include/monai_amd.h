@@ -239,6 +239,15 @@ int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, cons
 int mh_conv1x1_stat_tiles(int D, int H, int W);
 int mh_conv1x1_stats_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out, float* stats, void* stream);
 
+/* The same 1x1x1 convolution with ALL output channels from one read of the input, on the fp16 matrix cores in two-piece split precision (fp32-equivalent;
+ * kernels/conv1x1_h2.h): UnetResBlock.conv3 (monai/networks/blocks/dynunet_block.py:72-111) where Cout > 16 made mh_conv1x1_f32 re-read the input per 16 couts.
+ * The input's records must carry magnitude bounds (as for mh_conv3d_k3_f32's split-precision configuration).  packed = mh_conv1x1_h2_pack_f32(w [Cout][Cin]);
+ * stats (or NULL): the records of mh_conv1x1_stats_f32, same tile count (mh_conv1x1_stat_tiles).  _accepts: Cin <= 1536, D*H*W % 4 == 0; 16-byte aligned tensors. */
+int mh_conv1x1_h2_accepts(int Cin, int Cout, int D, int H, int W);
+int64_t mh_conv1x1_h2_packed_floats(int Cin, int Cout);
+int mh_conv1x1_h2_pack_f32(const float* w, int Cout, int Cin, float* packed, void* stream);
+int mh_conv1x1_h2_f32(const mh_tensor5* in, const float* packed, const float* bias, const mh_tensor5* out, float* stats, void* stream);
+
 /* The same 1x1 convolution with one strided destination per batch element (the windows of a sliding-window launch written straight into the mosaic
  * logits layout): place [N][4] HOST int64 = {float offset from `base`, channel stride, z stride, y stride}; x stays contiguous.  Cout <= 8. */
 int mh_conv1x1_windows_f32(const mh_tensor5* in, const float* w, const float* bias, float* base, int Cout, const int64_t* place, void* stream);
@@ -248,6 +257,12 @@ int mh_conv1x1_windows_f32(const mh_tensor5* in, const float* w, const float* bi
 /* out = lrelu_slope(act(a) + act(b)): the residual join of UnetResBlock (dynunet_block.py:96-111); a, b carry their
  * deferred InstanceNorm records (b->nrm NULL = identity shortcut; b NULL = no second operand: materialises act(a)). */
 int mh_add_act_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const mh_tensor5* out, void* stream);
+
+/* The residual join fused into the 1x1x1 output convolution behind it: out[co] = bias[co] + sum_ci w[co][ci] lrelu(act(a[ci]) + act(b[ci]), slope) -- UnetResBlock's
+ * join (dynunet_block.py:96-111) + UnetOutBlock (:251-268) without the joined tensor in HBM; the same bits as mh_add_act_f32 followed by mh_conv1x1_f32.
+ * w [Cout][Cin]; _accepts: 1 .. 8 output channels, D*H*W % 4 == 0; 16-byte aligned tensors. */
+int mh_conv1x1_sum2_accepts(int Cout, int D, int H, int W);
+int mh_conv1x1_sum2_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, const float* w, const float* bias, const mh_tensor5* out, void* stream);
 
 /* Replicate padding at the far end of each axis (out extents = in extents + 0 or 1): `UpCat`'s
  * F.pad(x_0, sp, "replicate") for odd encoder extents -- monai/networks/nets/basic_unet.py:163-170.  Raw copy. */

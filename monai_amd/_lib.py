@@ -98,6 +98,12 @@ SIGNATURES = {
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_stat_tiles": (_I, [_I, _I, _I]),
     "mh_conv1x1_stats_f32": (_I, [_T, _P, _P, _T, _P, _P]),
+    "mh_conv1x1_h2_accepts": (_I, [_I, _I, _I, _I, _I]),
+    "mh_conv1x1_h2_packed_floats": (_L, [_I, _I]),
+    "mh_conv1x1_h2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
+    "mh_conv1x1_h2_f32": (_I, [_T, _P, _P, _T, _P, _P]),
+    "mh_conv1x1_sum2_accepts": (_I, [_I, _I, _I, _I]),
+    "mh_conv1x1_sum2_f32": (_I, [_T, _T, _F, _P, _P, _T, _P]),
     "mh_conv1x1_windows_f32": (_I, [_T, _P, _P, _P, _I, C.POINTER(C.c_int64), _P]),
     "mh_conv3d_k3_strided_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_conv3d_k3_strided3_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _P]),

@@ -21,6 +21,7 @@
 #include "kernels/post.h"
 #include "kernels/preproc.h"
 #include "kernels/nn_simple.h"
+#include "kernels/conv1x1_h2.h"
 #include "kernels/resample.h"
 #include "kernels/sliding.h"
 
@@ -932,6 +933,53 @@ int mh_conv1x1_stats_f32(const mh_tensor5* in_, const float* w, const float* bia
     return conv1x1_impl(in_, w, bias, out_, stats, stream);
 }
 
+// ---- the 1x1x1 convolution with all output channels from one read of the input (kernels/conv1x1_h2.h) ----
+int mh_conv1x1_h2_accepts(int Cin, int Cout, int D, int H, int W) {
+    const long long DHW = (long long)D * H * W;
+    return Cin >= 1 && Cin <= 16 * C1H_KS * C1H_CHUNKS && Cout >= 1 && DHW >= 4 && DHW % 4 == 0 && (DHW + 1023) / 1024 <= 0x7fffffffLL;
+}
+int64_t mh_conv1x1_h2_packed_floats(int Cin, int Cout) {
+    if (Cin < 1 || Cin > 16 * C1H_KS * C1H_CHUNKS || Cout < 1) return fail(MH_ERR_ARG, "conv1x1_h2: 1 .. %d input channels (got %d)", 16 * C1H_KS * C1H_CHUNKS, Cin);
+    return (int64_t)cdiv(Cout, 64) * cdiv(Cin, 16) * C1H_SLAB * 4 + H2_TAIL;
+}
+int mh_conv1x1_h2_pack_f32(const float* w, int Cout, int Cin, float* packed, void* stream) {
+    if (!w || !packed) return fail(MH_ERR_ARG, "conv1x1_h2_pack: null pointer");
+    const int64_t total = mh_conv1x1_h2_packed_floats(Cin, Cout);
+    if (total < 0) return (int)total;
+    if (!aligned(packed, 16)) return fail(MH_ERR_ARG, "conv1x1_h2_pack: 16-byte aligned packed buffer required");
+    float* tail = packed + (total - H2_TAIL);
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout, tail);
+    const long long padded = (long long)cdiv(Cout, 64) * 64 * cdiv(Cin, 16) * 16;
+    hipLaunchKernelGGL(conv1x1_h2_pack_kernel, dim3(blocks_for(padded)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, reinterpret_cast<_Float16*>(packed), tail);
+    return launched("conv1x1_h2_pack");
+}
+int mh_conv1x1_h2_f32(const mh_tensor5* in_, const float* packed, const float* bias, const mh_tensor5* out_, float* stats, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed) return fail(MH_ERR_ARG, "conv1x1_h2: bad tensor");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.D != out.D || in.H != out.H || in.W != out.W) return fail(MH_ERR_ARG, "conv1x1_h2: shape mismatch");
+    if (!in.nrm) return fail(MH_ERR_ARG, "conv1x1_h2: the input must carry records with magnitude bounds (the split-precision kernels scale their input by them)");
+    if (!mh_conv1x1_h2_accepts(in.C, out.C, in.D, in.H, in.W))
+        return fail(MH_ERR_UNSUPPORTED, "conv1x1_h2: needs Cin <= %d and D*H*W %% 4 == 0 (got %d channels, %dx%dx%d)", 16 * C1H_KS * C1H_CHUNKS, in.C, in.D, in.H, in.W);
+    if (!aligned(in.data, 16) || !aligned(out.data, 16) || in.n_stride % 4 || out.n_stride % 4 || !aligned(packed, 16))
+        return fail(MH_ERR_ARG, "conv1x1_h2: 16-byte aligned tensors and weights required");
+    const long long DHW = (long long)in.D * in.H * in.W;
+    const int tiles = (int)((DHW + 1023) / 1024), nks = cdiv(in.C, 16);
+    const float* tail = packed + (mh_conv1x1_h2_packed_floats(in.C, out.C) - H2_TAIL);
+    const dim3 grid((unsigned)tiles, (unsigned)in.N);
+    hipStream_t s = (hipStream_t)stream;
+    for (int co0 = 0, pass = 0; co0 < out.C; co0 += 64, ++pass) {
+        const uint4* wq = reinterpret_cast<const uint4*>(packed) + (long long)pass * nks * C1H_SLAB;
+        const bool two = out.C - co0 > 32;
+#define MH_C1H_LAUNCH(MT_, ST_) hipLaunchKernelGGL((conv1x1_h2_kernel<MT_, ST_>), grid, dim3(512), 0, s, in, wq, tail, bias, out, co0, stats, tiles)
+        if (two && stats) MH_C1H_LAUNCH(2, true);
+        else if (two) MH_C1H_LAUNCH(2, false);
+        else if (stats) MH_C1H_LAUNCH(1, true);
+        else MH_C1H_LAUNCH(1, false);
+#undef MH_C1H_LAUNCH
+    }
+    return launched("conv1x1_h2");
+}
+
 int mh_conv1x1_windows_f32(const mh_tensor5* in_, const float* w, const float* bias, float* base, int Cout, const int64_t* place, void* stream) {
     if (!dense_ok(in_) || !w || !base || !place) return fail(MH_ERR_ARG, "conv1x1_windows: bad argument");
     const Tensor in = from_c(*in_);
@@ -1489,6 +1537,24 @@ int mh_add_act_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, cons
     if (v4) hipLaunchKernelGGL((add_act_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
     else hipLaunchKernelGGL((add_act_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, out);
     return launched("add_act");
+}
+
+int mh_conv1x1_sum2_accepts(int Cout, int D, int H, int W) { return Cout >= 1 && Cout <= 8 && ((long long)D * H * W) % 4 == 0; }
+
+int mh_conv1x1_sum2_f32(const mh_tensor5* a_, const mh_tensor5* b_, float slope, const float* w, const float* bias, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(a_) || !dense_ok(b_) || !dense_ok(out_) || !w) return fail(MH_ERR_ARG, "conv1x1_sum2: bad tensor");
+    const Tensor a = from_c(*a_), b = from_c(*b_), out = from_c(*out_);
+    if (a.N != b.N || a.C != b.C || a.D != b.D || a.H != b.H || a.W != b.W || a.N != out.N || a.D != out.D || a.H != out.H || a.W != out.W)
+        return fail(MH_ERR_ARG, "conv1x1_sum2: shape mismatch");
+    const long long DHW = (long long)a.D * a.H * a.W;
+    if (!mh_conv1x1_sum2_accepts(out.C, a.D, a.H, a.W) || !aligned(a.data, 16) || !aligned(b.data, 16) || !aligned(out.data, 16) || a.n_stride % 4 || b.n_stride % 4 ||
+        out.n_stride % 4)
+        return fail(MH_ERR_UNSUPPORTED, "conv1x1_sum2: needs 1 .. 8 output channels, D*H*W %% 4 == 0 and 16-byte aligned tensors (got %d channels)", out.C);
+    const dim3 grid(blocks_for(DHW / 4), (unsigned)a.N);
+#define MH_1S_CASE(CO) case CO: hipLaunchKernelGGL((conv1x1_sum2_kernel<CO>), grid, dim3(256), 0, (hipStream_t)stream, a, b, slope, w, bias, out); break;
+    switch (out.C) { MH_1S_CASE(1) MH_1S_CASE(2) MH_1S_CASE(3) MH_1S_CASE(4) MH_1S_CASE(5) MH_1S_CASE(6) MH_1S_CASE(7) MH_1S_CASE(8) }
+#undef MH_1S_CASE
+    return launched("conv1x1_sum2");
 }
 
 int mh_pad_replicate_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* stream) {

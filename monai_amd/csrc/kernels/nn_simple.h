@@ -682,6 +682,57 @@ __global__ void __launch_bounds__(256) add_act_kernel(Tensor a, Tensor b, float 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The residual join fused into the 1x1x1 output convolution that reads it (round 5): out[co] = bias[co] + sum_ci w[co][ci] lrelu(act(a[ci]) + act(b[ci]), slope) --
+// UnetResBlock's lrelu(norm2(conv2) + residual) (dynunet_block.py:96-111) followed by UnetOutBlock (dynunet_block.py:251-268) without the joined tensor in HBM
+// (UNETR / SwinUNETR: the last decoder block feeds only the output convolution; 2 x 16 resp. 2 x 48 channels x 96^3 per window less traffic).  CO <= 8 output
+// channels per thread, four voxels per thread, the join evaluated in add_act_kernel's order, the channel sum in conv1x1_kernel's: the same bits as the two launches.
+template <int CO>
+__global__ void __launch_bounds__(256) conv1x1_sum2_kernel(Tensor a, Tensor b, float slope, const float* __restrict__ w, const float* __restrict__ bias, Tensor out) {
+    const int Cin = a.C;
+    const long long DHW = (long long)a.D * a.H * a.W;
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int n = blockIdx.y;
+    if (idx >= DHW) return;
+    float acc[CO][4];
+#pragma unroll
+    for (int j = 0; j < CO; ++j) {
+        const float bj = bias ? bias[j] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[j][v] = bj;
+    }
+    const float* pa = a.data + (long long)n * a.n_stride + idx;
+    const float* pb = b.data + (long long)n * b.n_stride + idx;
+    constexpr int CB = 4;          // channels whose loads fly together
+    for (int c0 = 0; c0 < Cin; c0 += CB) {
+        float4 qa[CB], qb[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const long long o = (long long)min(c0 + c, Cin - 1) * DHW;
+            qa[c] = *reinterpret_cast<const float4*>(pa + o);
+            qb[c] = *reinterpret_cast<const float4*>(pb + o);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int ci = c0 + c;
+            if (ci < Cin) {
+                const float4 na = load_nrm(a, n, ci), nb = load_nrm(b, n, ci);
+                const float va[4] = {qa[c].x, qa[c].y, qa[c].z, qa[c].w}, vb[4] = {qb[c].x, qb[c].y, qb[c].z, qb[c].w};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const float y = act(va[v], na.x, na.y, na.z) + act(vb[v], nb.x, nb.y, nb.z);
+                    const float f = y > 0.0f ? y : y * slope;
+#pragma unroll
+                    for (int j = 0; j < CO; ++j) acc[j][v] = fmaf(f, w[(long long)j * Cin + ci], acc[j][v]);
+                }
+            }
+        }
+    }
+    float* dst = out.data + (long long)n * out.n_stride + idx;
+#pragma unroll
+    for (int j = 0; j < CO; ++j) *reinterpret_cast<float4*>(dst + (long long)j * DHW) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Replicate padding at the far end of each axis: out[z, y, x] = in[min(z, Di-1), min(y, Hi-1), min(x, Wi-1)] -- UpCat's
 // F.pad(x_0, sp, "replicate") for odd encoder extents (monai/networks/nets/basic_unet.py:163-170).  Raw copy (no norm).
 __global__ void __launch_bounds__(256) pad_replicate_kernel(Tensor in, Tensor out) {

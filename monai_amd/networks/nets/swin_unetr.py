@@ -408,32 +408,42 @@ class SwinUNETR(UNETR):
 
         # decoder concat buffers [upsampled | skip]; the encoders write their halves in place.  The buffers come with identity records that the
         # producers (residual joins, transposed convolutions) fold max |value| into: the magnitude bounds the split-precision convolution scales by.
-        # The Swin hidden states themselves arrive without bounds (plain torch tensors): convolutions that read them run on the exact-fp32 kernels.
+        # The Swin hidden states are LayerNorm outputs without an affine map when `normalize` (proj_out, swin_unetr.py:1039-1045): every voxel's C channels have
+        # mean 0 and sum of squares <= C, so |value| <= sqrt(C) -- a rigorous bound, which puts the convolutions that read them on the split-precision kernels
+        # (round 5; before, and still with normalize=False, they arrive without bounds and run on the exact-fp32 kernels).
+        def hidden_records(t):
+            if not self.normalize:
+                return None
+            rec = torch.tensor([1.0, 0.0, 1.0, float(np.sqrt(t.shape[1])) * (1.0 + 1e-6)], dtype=torch.float32, device=t.device)
+            return rec.expand(t.shape[0], t.shape[1], 4).contiguous()
+
         cat1 = new(x_in, 2 * fs)                                     # decoder1 @ full resolution
         cat1_nrm = self._records(cat1)
         self._res_block(self.encoder1.layer, x_in, None, cat1[:, fs:], cat1_nrm[:, fs:])
         cat2 = new(hs[0], 2 * fs)                                    # decoder2 @ 1/2
         cat2_nrm = self._records(cat2)
-        self._res_block(self.encoder2.layer, hs[0], None, cat2[:, fs:], cat2_nrm[:, fs:])
+        self._res_block(self.encoder2.layer, hs[0], hidden_records(hs[0]), cat2[:, fs:], cat2_nrm[:, fs:])
         cat3 = new(hs[1], 4 * fs)                                    # decoder3 @ 1/4
         cat3_nrm = self._records(cat3)
-        self._res_block(self.encoder3.layer, hs[1], None, cat3[:, 2 * fs:], cat3_nrm[:, 2 * fs:])
+        self._res_block(self.encoder3.layer, hs[1], hidden_records(hs[1]), cat3[:, 2 * fs:], cat3_nrm[:, 2 * fs:])
         cat4 = new(hs[2], 8 * fs)                                    # decoder4 @ 1/8
         cat4_nrm = self._records(cat4)
-        self._res_block(self.encoder4.layer, hs[2], None, cat4[:, 4 * fs:], cat4_nrm[:, 4 * fs:])
-        cat5 = new(hs[3], 16 * fs)                                   # decoder5 @ 1/16: the skip is the raw hidden state (no bound: fp32 kernels)
+        self._res_block(self.encoder4.layer, hs[2], hidden_records(hs[2]), cat4[:, 4 * fs:], cat4_nrm[:, 4 * fs:])
+        cat5 = new(hs[3], 16 * fs)                                   # decoder5 @ 1/16: the skip is the hidden state itself
         cat5[:, 8 * fs:].copy_(hs[3])
-        dec4 = self._res_block(self.encoder10.layer, hs[4], None, new(hs[4], 16 * fs), None)
+        cat5_nrm = None
+        if self.normalize:
+            cat5_nrm = self._records(cat5)
+            cat5_nrm[:, 8 * fs:] = hidden_records(hs[3])
+        dec4 = self._res_block(self.encoder10.layer, hs[4], hidden_records(hs[4]), new(hs[4], 16 * fs), None)
 
-        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst):
+        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst, head=None):
             self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], None if cat_nrm is None else cat_nrm[:, :cout])
-            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None)
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None, head=head)
 
-        dec3 = up(self.decoder5, dec4, cat5, None, 8 * fs, new(cat5, 8 * fs))
+        dec3 = up(self.decoder5, dec4, cat5, cat5_nrm, 8 * fs, new(cat5, 8 * fs))
         dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, new(cat4, 4 * fs))
         dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, new(cat3, 2 * fs))
         dec0 = up(self.decoder2, dec1, cat2, cat2_nrm, fs, new(cat2, fs))
-        last = up(self.decoder1, dec0, cat1, cat1_nrm, fs, new(cat1, fs))
-        oc = self.out.conv.conv
-        ops.conv1x1(last, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
+        up(self.decoder1, dec0, cat1, cat1_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
         return logits

@@ -270,12 +270,16 @@ class UNETR(nn.Module):
         """fresh identity records for a plain tensor that is about to be written (its producers leave the magnitude bounds in them)"""
         return ops.nrm_identity(torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device))
 
-    def _res_block(self, blk: _ResBlock, x, x_nrm, out, out_nrm):
-        """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` (+ its identity records, or None) into `out`."""
+    def _res_block(self, blk: _ResBlock, x, x_nrm, out, out_nrm, head=None):
+        """UnetResBlock (dynunet_block.py:96-111) of a plain (already activated) tensor `x` (+ its identity records, or None) into `out`.
+        head = (output convolution, logits): the block's result feeds only that 1x1x1 convolution (UnetOutBlock) -- where the fused kernel takes the shape the join is
+        evaluated inside it and `out` is never written (returns the logits); otherwise the join into `out`, then the convolution."""
         c1, n1 = self._conv3_in(blk.conv1.conv, x, x_nrm, 0.01)     # conv1 -> norm1 -> lrelu, applied on load by conv2
         if not getattr(blk, "res", True):       # UnetBasicBlock: lrelu(norm2(conv2(.))), no shortcut -- materialised into `out`
             c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 0.01)
-            return ops.add_act(c2, n2, None, None, 1.0, out, out_nrm)
+            out = torch.empty_like(c2) if out is None else out
+            ops.add_act(c2, n2, None, None, 1.0, out, out_nrm)
+            return self._head(head, out)
         c2, n2 = self._conv3_in(blk.conv2.conv, c1, n1, 1.0)        # conv2 -> norm2 (no activation before the add)
         if hasattr(blk, "conv3"):
             w3 = blk.conv3.conv.weight
@@ -283,13 +287,34 @@ class UNETR(nn.Module):
             r = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
             tiles = ops.conv1x1_stat_tiles(*x.shape[2:])          # norm3's statistics come out of the shortcut convolution itself
             stats = self._stats_buf(n * cout * tiles * 3, x.device)
-            ops.conv1x1(x, None, w3.view(cout, -1), None, r, stats)
+            if x_nrm is not None and cout > 16 and ops.conv1x1_h2_wanted(x.shape[1], cout, *x.shape[2:]):
+                # more than one group of 16 output channels: all of them from ONE read of x on the matrix cores (kernels/conv1x1_h2.h; x's records carry the bounds)
+                key = (w3.data_ptr(), w3._version, str(w3.device))
+                hit = self._packed.get(("1x1", id(blk.conv3.conv)))
+                if hit is None or hit[0] != key:
+                    hit = (key, ops.conv1x1_h2_pack(w3.view(cout, -1)))
+                    self._packed[("1x1", id(blk.conv3.conv))] = hit
+                ops.conv1x1_h2(x, x_nrm, hit[1], None, r, stats)
+            else:
+                ops.conv1x1(x, None, w3.view(cout, -1), None, r, stats)
             n3 = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
             ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, n3)
-            ops.add_act(c2, n2, r, n3, 0.01, out, out_nrm)
+            res, res_nrm = r, n3
         else:
-            ops.add_act(c2, n2, x, None, 0.01, out, out_nrm)
-        return out
+            res, res_nrm = x, None
+        if head is not None and ops.conv1x1_sum2_accepts(head[0].weight.shape[0], *c2.shape[2:]):
+            oc, logits = head
+            return ops.conv1x1_sum2(c2, n2, res, res_nrm, 0.01, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
+        out = torch.empty_like(c2) if out is None else out          # (a caller with a head may leave the block's own output to this fallback)
+        ops.add_act(c2, n2, res, res_nrm, 0.01, out, out_nrm)
+        return self._head(head, out)
+
+    @staticmethod
+    def _head(head, t):
+        if head is None:
+            return t
+        oc, logits = head
+        return ops.conv1x1(t, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
 
     @staticmethod
     def _tconv(conv: nn.ConvTranspose3d, x, out, out_nrm=None):
@@ -402,14 +427,12 @@ class UNETR(nn.Module):
         cat5_nrm = self._records(cat5)
         prup(self.encoder4, p4, cat5[:, 8 * fs:], cat5_nrm[:, 8 * fs:])
 
-        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst):
+        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst, head=None):
             self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], cat_nrm[:, :cout])
-            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None)
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None, head=head)
 
         dec3 = up(self.decoder5, self._proj_feat(x), cat5, cat5_nrm, 8 * fs, self._new(cat5, 8 * fs))
         dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, self._new(cat4, 4 * fs))
         dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, self._new(cat3, 2 * fs))
-        last = up(self.decoder2, dec1, cat2, cat2_nrm, fs, self._new(cat2, fs))
-        oc = self.out.conv.conv
-        ops.conv1x1(last, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
+        up(self.decoder2, dec1, cat2, cat2_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
         return logits

@@ -503,6 +503,39 @@ def conv1x1(x, x_nrm, weight, bias, out, stats=None):
     return out
 
 
+def conv1x1_h2_accepts(cin: int, cout: int, d: int, h: int, w: int) -> bool:
+    return bool(_lib.lib().query("mh_conv1x1_h2_accepts", int(cin), int(cout), int(d), int(h), int(w)))
+
+
+def conv1x1_h2_wanted(cin: int, cout: int, d: int, h: int, w: int) -> bool:
+    """the split-precision 1x1x1 kernel takes the shape and the session has not pinned an exact-fp32 convolution family (config.CONV_ALGO / MONAI_AMD_CONV_ALGO)"""
+    from . import config
+
+    return config.conv_algo() in (config.CONV_ALGOS["auto"], config.CONV_ALGOS["h2"]) and conv1x1_h2_accepts(cin, cout, d, h, w)
+
+
+def conv1x1_h2_pack(weight: torch.Tensor) -> torch.Tensor:
+    """weight [Cout, Cin] -> the packed split-precision slabs of `conv1x1_h2` (once per layer)"""
+    _lib.require_device(weight)
+    if weight.dim() != 2:
+        raise RuntimeError(f"monai_amd.conv1x1_h2_pack: weight must be [Cout, Cin], got {tuple(weight.shape)}")
+    cout, cin = (int(v) for v in weight.shape)
+    packed = torch.empty(_lib.lib().query("mh_conv1x1_h2_packed_floats", cin, cout), dtype=torch.float32, device=weight.device)
+    _lib.lib().call("mh_conv1x1_h2_pack_f32", _lib.ptr(weight.contiguous()), cout, cin, _lib.ptr(packed), _s(weight))
+    return packed
+
+
+def conv1x1_h2(x, x_nrm, packed, bias, out, stats=None):
+    """1x1x1 convolution of act(x) with all output channels from one read of x (fp16 matrix cores, split precision: fp32-equivalent); x_nrm must carry magnitude
+    bounds.  stats as `conv1x1` (same tile count)."""
+    _lib.require_device(x, x_nrm, packed, bias, out, stats)
+    if x_nrm is None:
+        raise RuntimeError("monai_amd.conv1x1_h2: the input needs records with magnitude bounds")
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv1x1_h2_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias), C.byref(xo), _lib.ptr(stats), _s(x))
+    return out
+
+
 _MODES = {"nearest": 0, "bilinear": 1, "linear": 1, "trilinear": 1}
 _PADS = {"zeros": 0, "border": 1, "reflection": 2}
 
@@ -559,6 +592,19 @@ def add_act(a, a_nrm, b, b_nrm, slope: float, out, out_nrm=None):
     ta, to = _lib.tensor5(a, a_nrm), _lib.tensor5(out, out_nrm)
     tb = None if b is None else _lib.tensor5(b, b_nrm)
     _lib.lib().call("mh_add_act_f32", C.byref(ta), None if tb is None else C.byref(tb), float(slope), C.byref(to), _s(a))
+    return out
+
+
+def conv1x1_sum2_accepts(cout: int, d: int, h: int, w: int) -> bool:
+    return bool(_lib.lib().query("mh_conv1x1_sum2_accepts", int(cout), int(d), int(h), int(w)))
+
+
+def conv1x1_sum2(a, a_nrm, b, b_nrm, slope: float, weight, bias, out):
+    """out = conv1x1(leaky_relu(act(a) + act(b), slope)) + bias: the residual join of UnetResBlock inside the output convolution that reads it (no joined tensor);
+    the same bits as add_act followed by conv1x1.  weight [Cout <= 8, Cin]."""
+    _lib.require_device(a, a_nrm, b, b_nrm, weight, bias, out)
+    ta, tb, to = _lib.tensor5(a, a_nrm), _lib.tensor5(b, b_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv1x1_sum2_f32", C.byref(ta), C.byref(tb), float(slope), _lib.ptr(weight), _lib.ptr(bias), C.byref(to), _s(a))
     return out
 
 

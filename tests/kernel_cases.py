@@ -528,6 +528,71 @@ def case_conv1x1_stats(device):
         assert (g[:, :, 1] + od.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 5e-5 * max(1.0, float(alpha.max())), (cin, cout, dims)
 
 
+def case_conv1x1_h2(device, n=2, cin=96, cout=48, dims=(6, 8, 44), scale=1.0, loosen=3.0):
+    """mh_conv1x1_h2_f32: the 1x1x1 convolution with all output channels from one read of the input (split precision on the matrix cores) against an fp64
+    convolution at the exact-fp32 kernel's tolerance, its statistics against a stand-alone pass over its own output, and against conv1x1 (the VALU kernel) on the
+    same input -- ragged last workgroup tile (D*H*W not a multiple of 1024), Cin not a multiple of 16, Cout = 48 / 64 / 80 / 5 (half-filled second tile, two passes)"""
+    gen = torch.Generator().manual_seed(23 + cin + cout)
+    x = torch.randn((n, cin) + dims, generator=gen) * scale
+    w = torch.randn((cout, cin), generator=gen) / np.sqrt(cin)
+    b = torch.randn(cout, generator=gen) * 0.1 + 3.0
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen)
+    assert ops.conv1x1_h2_accepts(cin, cout, *dims)
+    packed = ops.conv1x1_h2_pack(w.to(device))
+    tiles = ops.conv1x1_stat_tiles(*dims)
+    out = torch.full((n, cout) + dims, float("nan"), device=device)
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device)
+    ops.conv1x1_h2(x.to(device), nrm.to(device), packed, b.to(device), out, stats)
+    plain = torch.full((n, cout) + dims, float("nan"), device=device)
+    ops.conv1x1_h2(x.to(device), nrm.to(device), packed, b.to(device), plain)
+    assert torch.equal(out, plain)
+    exp = F.conv3d(_act(x.double(), nrm.double()), w.double()[:, :, None, None, None], b.double())
+    ref_scale = max(1.0, exp.abs().max().item())
+    err = (out.cpu().double() - exp).abs().max().item()
+    valu = torch.empty((n, cout) + dims, device=device)
+    ops.conv1x1(x.to(device), nrm.to(device), w.to(device), b.to(device), valu)
+    err_valu = (valu.cpu().double() - exp).abs().max().item()
+    assert err < 4e-6 * ref_scale and err < 4 * err_valu + 1e-7 * ref_scale, (cin, cout, err, err_valu)
+    st = stats.cpu().double()
+    assert not torch.isnan(st).any()
+    vox = dims[0] * dims[1] * dims[2]
+    assert torch.all(st[..., 0].sum(-1) == vox), "every voxel counted once"
+    got = torch.empty((n, cout, 4), device=device)
+    ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, 1.0, got)
+    od = out.cpu().double()
+    alpha = 1.0 / torch.sqrt(od.var(dim=(2, 3, 4), unbiased=False) + 1e-5)
+    g = got.cpu().double()
+    assert ((g[:, :, 0] - alpha).abs() / alpha).max().item() < 2e-6, (cin, cout, dims)
+    assert (g[:, :, 1] + od.mean(dim=(2, 3, 4)) * alpha).abs().max().item() < 5e-5 * max(1.0, float(alpha.max())), (cin, cout, dims)
+    return err
+
+
+def case_conv1x1_sum2(device, n=2, cin=16, cout=5, dims=(6, 8, 44)):
+    """mh_conv1x1_sum2_f32 (the residual join inside the output convolution) == add_act followed by conv1x1, bit for bit; and both against fp64"""
+    gen = torch.Generator().manual_seed(31 + cin + cout)
+    a, b = torch.randn((n, cin) + dims, generator=gen), torch.randn((n, cin) + dims, generator=gen)
+    na, nb = _rand_nrm(n, cin, gen), _rand_nrm(n, cin, gen)
+    na[:, :, 2] = 1.0
+    w = torch.randn((cout, cin), generator=gen) / np.sqrt(cin)
+    bias = torch.randn(cout, generator=gen) * 0.1
+    got = torch.full((n, cout) + dims, float("nan"), device=device)
+    assert ops.conv1x1_sum2_accepts(cout, *dims)
+    ops.conv1x1_sum2(a.to(device), na.to(device), b.to(device), nb.to(device), 0.01, w.to(device), bias.to(device), got)
+    joined = torch.empty((n, cin) + dims, device=device)
+    ops.add_act(a.to(device), na.to(device), b.to(device), nb.to(device), 0.01, joined)
+    two = torch.empty((n, cout) + dims, device=device)
+    ops.conv1x1(joined, None, w.to(device), bias.to(device), two)
+    assert torch.equal(got, two)
+    exp = F.conv3d(F.leaky_relu(_act(a.double(), na.double()) + _act(b.double(), nb.double()), 0.01), w.double()[:, :, None, None, None], bias.double())
+    assert (got.cpu().double() - exp).abs().max().item() < 1e-5
+    # identity shortcut (no records on b)
+    ops.conv1x1_sum2(a.to(device), na.to(device), b.to(device), None, 0.01, w.to(device), bias.to(device), got)
+    ops.add_act(a.to(device), na.to(device), b.to(device), None, 0.01, joined)
+    ops.conv1x1(joined, None, w.to(device), bias.to(device), two)
+    assert torch.equal(got, two)
+    return True
+
+
 def case_instnorm_stats(device, n=2, c=3, dims=(10, 17, 31)):
     gen = torch.Generator().manual_seed(6)
     x = torch.randn((n, c) + dims, generator=gen) * 3 + 50.0  # large mean: E[x^2]-E[x]^2 would lose digits

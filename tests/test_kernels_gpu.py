@@ -220,6 +220,17 @@ def test_window_attention(s, hd):
     kc.case_window_attention(DEV, bw=2 if DEV == "cpu" else 6, s=s, heads=2, hd=hd)
 
 
+@pytest.mark.parametrize("n,cin,cout,dims,scale", [(2, 96, 48, (6, 8, 44), 1.0), (1, 40, 80, (5, 4, 60), 1e4), (2, 24, 5, (3, 4, 8), 1e-6), (1, 32, 64, (2, 2, 257 * 4), 1.0), (2, 96, 48, (48, 48, 48), 1.0), (1, 512, 256, (12, 12, 12), 1.0), (3, 768, 384, (6, 6, 6), 1.0), (1, 528, 33, (2, 3, 4), 1.0)])
+def test_conv1x1_all_couts_from_one_read(n, cin, cout, dims, scale):
+    """the split-precision 1x1x1 convolution (kernels/conv1x1_h2.h): values, statistics, input magnitudes 1e-6 ... 1e4"""
+    print(kc.case_conv1x1_h2(DEV, n, cin, cout, dims, scale))
+
+
+@pytest.mark.parametrize("cin,cout,dims", [(16, 5, (6, 8, 44)), (48, 3, (2, 5, 12)), (7, 8, (3, 4, 8))])
+def test_residual_join_inside_the_output_convolution(cin, cout, dims):
+    assert kc.case_conv1x1_sum2(DEV, 2, cin, cout, dims)
+
+
 @pytest.mark.parametrize("m_src,m_out,k,n", [(150, 210, 48, 96), (64, 64, 192, 64), (37, 50, 384, 40), (20000, 20480, 96, 288), (3000, 4000, 768, 768)])
 def test_layernorm_gather_linear_scatter(m_src, m_out, k, n):
     """SwinTransformerBlock's copies folded into the gathering LayerNorm and the projection's scattering epilogue (round 5)"""
