@@ -69,6 +69,18 @@ def pool_fused() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no")
 
 
+# ---- stride-2 3x3x3 convolutions on the fp16 matrix cores --------------------------------------------------------------------------
+# DynUNet / SegResNet / UNet down-sampling convolutions whose shapes the split-precision stride-2 kernel takes (csrc/kernels/conv3d_s2_h2.h) leave the vector-ALU
+# kernel -- fp32-equivalent like the stride-1 split-precision convolution, only for inputs with magnitude bounds and only in the "auto" / "h2" families.
+# False (or MONAI_AMD_STRIDED_H2=0 while None) keeps the direct fp32 kernel.
+STRIDED_H2 = None
+
+
+def strided_h2() -> bool:
+    v = STRIDED_H2 if STRIDED_H2 is not None else os.environ.get("MONAI_AMD_STRIDED_H2", "1")
+    return str(v).lower() not in ("0", "false", "off", "no") and conv_algo() in (CONV_ALGOS["auto"], CONV_ALGOS["h2"])
+
+
 # ---- SwinTransformerBlock without its copies -------------------------------------------------------------------------------------
 # SwinUNETR: norm1 + pad + roll + window_partition as one gathering LayerNorm and window_reverse + roll back + crop + the shortcut sum in the projection's epilogue
 # (csrc/kernels/dense.h: layernorm_vec_kernel's src_row, the linear kernels' rowmap) -- the same values, moved once instead of six times.  False (or

@@ -13,6 +13,7 @@
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_h2.h"
 #include "kernels/upconv_h2.h"
+#include "kernels/conv3d_s2_h2.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -881,6 +882,76 @@ int mh_upconv_k4s2_f32(const mh_tensor5* low_, const float* packed, const float*
     else if (stats) hipLaunchKernelGGL((upconv_k4s2_h2_kernel<true, true>), g, bl, 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
     else hipLaunchKernelGGL((upconv_k4s2_h2_kernel<false, true>), g, bl, 0, s, low, wq, tail, bias_table, out, stats, txn, tyn, zc, nblk);
     return launched("upconv_k4s2");
+}
+
+// ---- Conv3d k3 s2 p1 on the fp16 matrix cores in split precision (kernels/conv3d_s2_h2.h): phase-split pass + GEMM over the 8 parity phases
+static inline int s2_zchunk(int Do, int tiles) {          // a pure function of the extents (the statistics record count depends on it)
+    int nchunk = cdiv(32, tiles);
+    if (nchunk > Do / 8) nchunk = Do / 8;
+    if (nchunk < 1) nchunk = 1;
+    return cdiv(Do, nchunk);
+}
+int mh_conv3d_k3s2_accepts(int Cin, int Cout, int D, int H, int W) {
+    if (!(Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && D >= 2 && H >= 2 && W >= 2) || (D & 1) || (H & 1) || (W & 1)) return 0;
+    const long long ovol = (long long)(D / 2) * (H / 2) * (W / 2);
+    return ovol * 64 * 4 < 0x80000000LL && D <= 65535;
+}
+int64_t mh_conv3d_k3s2_packed_floats(int Cin, int Cout) {
+    if (!(Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0)) return fail(MH_ERR_ARG, "conv3d_k3s2: needs Cin %% 16 == 0, Cout %% 32 == 0");
+    return (int64_t)Cout * Cin * 27 + H2_TAIL;
+}
+int64_t mh_conv3d_k3s2_workspace_floats(int N, int Cin, int D, int H, int W) {
+    if (N < 1 || Cin < 16 || Cin % 16 || D < 2 || H < 2 || W < 2) return fail(MH_ERR_ARG, "conv3d_k3s2_workspace: bad argument");
+    return (int64_t)N * Cin * D * H * W + ((N + 3) / 4) * 4;
+}
+int mh_conv3d_k3s2_stat_tiles(int D, int H, int W) {
+    const S2Tile t = s2_tile(H / 2, W / 2);
+    const int tiles = t.tyn * t.txn;
+    return tiles * cdiv(D / 2, s2_zchunk(D / 2, tiles));
+}
+int mh_conv3d_k3s2_pack_f32(const float* w, int Cin, int Cout, float* packed, void* stream) {
+    if (!w || !packed) return fail(MH_ERR_ARG, "conv3d_k3s2_pack: null pointer");
+    const int64_t total = mh_conv3d_k3s2_packed_floats(Cin, Cout);
+    if (total < 0) return (int)total;
+    if (!aligned(packed, 16)) return fail(MH_ERR_ARG, "conv3d_k3s2_pack: 16-byte aligned packed buffer required");
+    float* tail = packed + (total - H2_TAIL);
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
+    hipLaunchKernelGGL(conv3d_k3s2_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, Cout % 64 == 0 ? 2 : 1,
+                       reinterpret_cast<_Float16*>(packed), tail);
+    return launched("conv3d_k3s2_pack");
+}
+int mh_conv3d_k3s2_f32(const mh_tensor5* in_, const float* packed, const float* bias, const mh_tensor5* out_, float* workspace, float* stats, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed || !workspace) return fail(MH_ERR_ARG, "conv3d_k3s2: bad argument");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D * 2 != in.D || out.H * 2 != in.H || out.W * 2 != in.W) return fail(MH_ERR_ARG, "conv3d_k3s2: the output must be half the (even) input extents");
+    if (!mh_conv3d_k3s2_accepts(in.C, out.C, in.D, in.H, in.W))
+        return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: needs Cin %% 16 == 0, Cout %% 32 == 0, even extents (got %d -> %d, %dx%dx%d)", in.C, out.C, in.D, in.H, in.W);
+    if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3s2: the input must carry records with magnitude bounds (the split-precision kernels scale their input by them)");
+    if (!aligned(in.nrm, 16) || !aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed, 16) || !aligned(workspace, 16))
+        return fail(MH_ERR_ARG, "conv3d_k3s2: 16-byte aligned records, output, weights and workspace required");
+    const long long nz = (long long)in.N * (in.C / 8);
+    if (nz > 65535) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: N * Cin / 8 must stay below 65536 per launch");
+    hipStream_t s = (hipStream_t)stream;
+    uint4* xs = reinterpret_cast<uint4*>(workspace);
+    int* expo = reinterpret_cast<int*>(workspace + (long long)in.N * in.C * in.D * in.H * in.W);
+    hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(blocks_for((long long)in.H * in.W), (unsigned)in.D, (unsigned)nz), dim3(256), 0, s, in, xs, expo);
+    const S2Tile t = s2_tile(out.H, out.W);
+    const int tiles = t.tyn * t.txn, zc = s2_zchunk(out.D, tiles);
+    const unsigned nblk = (unsigned)(tiles * cdiv(out.D, zc));
+    const int ncgw = out.C % 64 == 0 ? 2 : 1;
+    const long long total = (long long)nblk * (out.C / (32 * ncgw)) * out.N;
+    if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: problem too large for one launch");
+    const uint4* wq = reinterpret_cast<const uint4*>(packed);
+    const float* tail = packed + (mh_conv3d_k3s2_packed_floats(in.C, out.C) - H2_TAIL);
+    const dim3 g((unsigned)total), bl(S2_NT);
+#define MH_S2_LAUNCH(NCG_)                                                                                                                              \
+    {                                                                                                                                                   \
+        if (stats) hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, true>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);      \
+        else hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, false>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);            \
+    }
+    if (ncgw == 2) MH_S2_LAUNCH(2) else MH_S2_LAUNCH(1)
+#undef MH_S2_LAUNCH
+    return launched("conv3d_k3s2");
 }
 
 template <int VEC, bool STATS>

@@ -276,6 +276,33 @@ class DynUNet(nn.Module):
             self._packed[(id(conv), cfg)] = hit
         return hit[1]
 
+    def _packed_slice(self, conv: nn.Conv3d, cfg: int, c0: int, c1: int) -> torch.Tensor:
+        """packed weights of input channels c0 .. c1 - 1 of a 3x3x3 convolution (a convolution evaluated in two halves of its input channels)"""
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((id(conv), cfg, c0, c1))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, w[:, c0:c1].contiguous()))
+            self._packed[(id(conv), cfg, c0, c1)] = hit
+        return hit[1]
+
+    def _packed_s2(self, conv: nn.Conv3d) -> torch.Tensor:
+        """the stride-2 split-precision kernel's tap matrices of a [Cout, Cin, 3, 3, 3] weight (once per parameter version)"""
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((id(conv), "s2"))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3s2_pack(w))
+            self._packed[(id(conv), "s2")] = hit
+        return hit[1]
+
+    def _workspace(self, floats: int, device) -> torch.Tensor:
+        """scratch of the stride-2 kernel (the phase-split fp16 pieces of its input): one buffer, grown to the largest layer"""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < floats or ws.device != device:
+            self._ws = ws = torch.empty(floats, dtype=torch.float32, device=device)
+        return ws
+
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
         if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
             self._stats = torch.empty(floats, dtype=torch.float32, device=device)
@@ -303,11 +330,29 @@ class DynUNet(nn.Module):
             # every record of this engine carries a magnitude bound: instnorm_finalize writes one, plain tensors come with `nrm_identity` records their
             # producers (add_act, the transposed convolutions) folded max |value| into -- what the split-precision kernel scales its input by
             cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=x_nrm is not None)
+            h2 = ops.conv3d_k3_h2_config()
+            half = (cin // 32) * 16
+            if (cfg != h2 and x_nrm is not None and tuple(conv.weight.shape[2:]) == (3, 3, 3) and cin > 256 and cin % 16 == 0
+                    and ops.conv3d_k3_select(half, cout, d, h, w, bounded=True) == h2 and ops.conv3d_k3_select(cin - half, cout, d, h, w, bounded=True) == h2):
+                # more input channels than the split-precision kernel keeps records for (the 512-channel concat of nnU-Net's 12^3 level): the convolution is linear in
+                # its input channels -- one half written, the other half added onto it by the accumulating form, which leaves the statistics of the sum
+                tiles = ops.conv3d_k3_stat_tiles(h2, d, h, w)
+                stats = self._stats_buf(n * cout * tiles * 3, x.device)
+                with _prof.span(f"conv3d_k3/cfg{h2}", flops):
+                    ops.conv3d_k3(h2, x[:, :half], x_nrm[:, :half], self._packed_slice(conv, h2, 0, half), conv.bias, out, None)
+                    ops.conv3d_k3(h2, x[:, half:], x_nrm[:, half:], self._packed_slice(conv, h2, half, cin), None, out, stats, accumulate=True)
+                return out, self._finalize(norm, out, stats, tiles, slope)
             tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
             with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
-        else:       # strided, or so few channels that the matrix tiles would mostly pad: the direct kernel at the true width
+        elif tuple(conv.weight.shape[2:]) == (3, 3, 3) and ops.conv3d_k3s2_selected(cin, cout, d, h, w, stride, bounded=x_nrm is not None):
+            # the down-sampling convolution on the fp16 matrix cores (csrc/kernels/conv3d_s2_h2.h), statistics of its output included
+            tiles = ops.conv3d_k3s2_stat_tiles(d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            with _prof.span("conv3d_k3s2", flops):
+                ops.conv3d_k3s2(x, x_nrm, self._packed_s2(conv), conv.bias, out, stats, self._workspace(ops.conv3d_k3s2_workspace_floats(n, cin, d, h, w), x.device))
+        else:       # other strides, or so few channels that the matrix tiles would mostly pad: the direct kernel at the true width
             ops.conv3d_k3_strided3(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
         return out, self._finalize(norm, out, stats, tiles, slope)
 

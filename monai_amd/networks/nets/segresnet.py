@@ -177,16 +177,41 @@ class SegResNet(nn.Module):
             with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
             return out, stats, tiles
+        if ops.conv3d_k3s2_selected(cin, cout, d, h, w, stride, bounded=x_nrm is not None):
+            # the down-sampling convolution on the fp16 matrix cores (csrc/kernels/conv3d_s2_h2.h), statistics of its output included
+            tiles = ops.conv3d_k3s2_stat_tiles(d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            with _prof.span("conv3d_k3s2", 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n):
+                ops.conv3d_k3s2(x, x_nrm, self._packed_s2(conv), conv.bias, out, stats, self._workspace(ops.conv3d_k3s2_workspace_floats(n, cin, d, h, w), x.device))
+            return out, stats, tiles
         ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
         return out, None, 0
 
-    def _res_block(self, blk: _ResBlock, x, stats=None, tiles=0):
-        """x + conv2(act(norm2(conv1(act(norm1 x))))) for a plain x (whose statistics records may come from its producer)"""
+    def _packed_s2(self, conv: nn.Conv3d) -> torch.Tensor:
+        """the stride-2 split-precision kernel's tap matrices of a [Cout, Cin, 3, 3, 3] weight (once per parameter version)"""
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._packed.get((id(conv), "s2"))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3s2_pack(w))
+            self._packed[(id(conv), "s2")] = hit
+        return hit[1]
+
+    def _workspace(self, floats: int, device) -> torch.Tensor:
+        """scratch of the stride-2 kernel (the phase-split fp16 pieces of its input): one buffer, grown to the largest layer"""
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < floats or ws.device != device:
+            self._ws = ws = torch.empty(floats, dtype=torch.float32, device=device)
+        return ws
+
+    def _res_block(self, blk: _ResBlock, x, stats=None, tiles=0, out_nrm=None):
+        """x + conv2(act(norm2(conv1(act(norm1 x))))) for a plain x (whose statistics records may come from its producer); out_nrm: `nrm_identity` records
+        the join leaves the result's magnitude bounds in (the split-precision down-sampling convolution that reads it scales its input by them)"""
         n1 = self._record(blk.norm1, x, stats, tiles)
         c1, s1, t1 = self._conv3(blk.conv1.conv, x, n1)
         n2 = self._record(blk.norm2, c1, s1, t1)
         c2, _, _ = self._conv3(blk.conv2.conv, c1, n2)
-        return ops.add_act(c2, None, x, None, 1.0, torch.empty_like(c2))
+        return ops.add_act(c2, None, x, None, 1.0, torch.empty_like(c2), out_nrm)
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -207,11 +232,17 @@ class SegResNet(nn.Module):
         # encode (segresnet.py:170-182); dropout is the identity in eval mode
         t, stats, tiles = self._conv3(self.convInit.conv, x.contiguous(), None)
         down_x = []
-        for layer in self.down_layers:
+        t_nrm = None           # identity records with the magnitude bounds of `t`, left by the last residual join of a level that a strided convolution follows
+        for li, layer in enumerate(self.down_layers):
             if not isinstance(layer[0], nn.Identity):
-                t, stats, tiles = self._conv3(layer[0].conv, t, None, stride=2)
-            for blk in list(layer)[1:]:
-                t, stats, tiles = self._res_block(blk, t, stats, tiles), None, 0
+                t, stats, tiles = self._conv3(layer[0].conv, t, t_nrm, stride=2)
+                t_nrm = None
+            blks = list(layer)[1:]
+            for bi, blk in enumerate(blks):
+                feeds_down = bi == len(blks) - 1 and li + 1 < len(self.down_layers) and not isinstance(self.down_layers[li + 1][0], nn.Identity)
+                if feeds_down:
+                    t_nrm = ops.nrm_identity(torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device))
+                t, stats, tiles = self._res_block(blk, t, stats, tiles, t_nrm if feeds_down else None), None, 0
             down_x.append(t)
         down_x.reverse()
         # decode (segresnet.py:184-192): x = up(x) + skip; x = up_layer(x)

@@ -886,6 +886,50 @@ def conv3d_k3_strided3(x, x_nrm, packed_w0, bias, out, strides: Sequence[int]):
     return out
 
 
+def conv3d_k3s2_accepts(cin: int, cout: int, d: int, h: int, w: int) -> bool:
+    """can the split-precision stride-2 kernel (kernels/conv3d_s2_h2.h) serve `cin` -> `cout` channels on a d x h x w input?"""
+    return bool(_lib.lib().query("mh_conv3d_k3s2_accepts", int(cin), int(cout), int(d), int(h), int(w)))
+
+
+def conv3d_k3s2_selected(cin: int, cout: int, d: int, h: int, w: int, stride, bounded: bool) -> bool:
+    """should this stride-`stride` 3x3x3 convolution run on the split-precision stride-2 kernel? (stride (2, 2, 2), a bounded input, a shape the kernel takes, and the
+    host-side family switch `monai_amd.config.strided_h2()`)"""
+    from . import config
+
+    st = (int(stride),) * 3 if isinstance(stride, int) else tuple(int(v) for v in stride)
+    return st == (2, 2, 2) and bool(bounded) and config.strided_h2() and conv3d_k3s2_accepts(cin, cout, d, h, w)
+
+
+def conv3d_k3s2_workspace_floats(n: int, cin: int, d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_conv3d_k3s2_workspace_floats", int(n), int(cin), int(d), int(h), int(w))
+
+
+def conv3d_k3s2_pack(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout, Cin, 3, 3, 3] -> the stride-2 kernel's phase-ordered split-precision tap matrices (once per parameter version)"""
+    _lib.require_device(weight)
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    packed = torch.zeros(_lib.lib().query("mh_conv3d_k3s2_packed_floats", cin, cout), dtype=torch.float32, device=weight.device)
+    _lib.lib().call("mh_conv3d_k3s2_pack_f32", _lib.ptr(weight.contiguous()), cin, cout, _lib.ptr(packed), _s(weight))
+    return packed
+
+
+def conv3d_k3s2_stat_tiles(d: int, h: int, w: int) -> int:
+    return _lib.lib().query("mh_conv3d_k3s2_stat_tiles", int(d), int(h), int(w))
+
+
+def conv3d_k3s2(x, x_nrm, packed, bias, out, stats=None, workspace=None):
+    """out = conv3x3x3(act(x), stride 2, padding 1) + bias on the fp16 matrix cores (split precision); x_nrm: records WITH magnitude bounds.
+    stats ([N * Cout * conv3d_k3s2_stat_tiles(*x.shape[2:]) * 3] floats): the InstanceNorm statistics of `out`.  workspace: scratch of
+    `conv3d_k3s2_workspace_floats` floats (allocated here when not given)."""
+    _lib.require_device(x, x_nrm, packed, bias, out, stats, workspace)
+    need = conv3d_k3s2_workspace_floats(*x.shape)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+    xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
+    _lib.lib().call("mh_conv3d_k3s2_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias), C.byref(xo), _lib.ptr(workspace), _lib.ptr(stats), _s(x))
+    return out
+
+
 def deconv_ks(x, x_nrm, weight, bias, out, factors: Sequence[int], out_nrm=None):
     """out = conv_transpose3d(act(x), kernel == stride == factors (each 1 or 2)) + bias; weight [Cin, Cout, fz, fy, fx] contiguous.
     out_nrm: `nrm_identity` records of `out` (magnitude bound)."""

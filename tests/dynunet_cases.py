@@ -172,6 +172,61 @@ def case_dynunet_api(device):
         net.eval().to(device)(torch.zeros(1, 1, 10, 8, 8, device=device))
 
 
+def case_dynunet_wide_concat(device, cin=288, cout=32, dims=(3, 8, 12)):
+    """the engine's convolution of a concat with more input channels than the split-precision kernel keeps records for (nnU-Net's 512-channel 12^3 level): evaluated as
+    two halves of the input channels, the second ADDED onto the first with the statistics of the sum -- against ATen in float64, records included"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from monai_amd import ops
+    from monai_amd.networks.nets import DynUNet
+
+    gen = torch.Generator().manual_seed(97)
+    net = DynUNet(3, 1, 2, [3, 3, 3], [1, 2, 2], [2, 2], filters=[8, 8, 8]).eval().to(device)
+    conv = nn.Conv3d(cin, cout, 3, padding=1, bias=False)
+    norm = nn.InstanceNorm3d(cout, affine=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=gen) / np.sqrt(27.0 * cin))
+        norm.weight.copy_(1.0 + 0.2 * torch.randn(cout, generator=gen))
+        norm.bias.copy_(0.1 * torch.randn(cout, generator=gen))
+    conv, norm = conv.to(device), norm.to(device)
+    n = 2
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    rec = torch.zeros(n, cin, 4)
+    rec[:, :, 0] = torch.rand(n, cin, generator=gen) + 0.5
+    rec[:, :, 1] = torch.randn(n, cin, generator=gen) * 0.3
+    rec[:, :, 2] = 0.01
+    a, b = rec[:, :, 0][:, :, None, None, None].double(), rec[:, :, 1][:, :, None, None, None].double()
+    y = x.double() * a + b
+    y = torch.where(y > 0, y, y * 0.01)
+    rec[:, :, 3] = y.abs().amax(dim=(2, 3, 4)).float() * 1.5
+    exp = F.conv3d(y, conv.weight.detach().cpu().double(), None, padding=1)
+    calls = []
+    orig = ops.conv3d_k3
+
+    def spy(cfg, *args, **kw):
+        calls.append((cfg, bool(kw.get("accumulate", False))))
+        return orig(cfg, *args, **kw)
+
+    ops.conv3d_k3 = spy
+    try:
+        with torch.no_grad():
+            out, nrm = net._conv_norm(conv, norm, x.to(device), rec.to(device), (1, 1, 1), 0.01)
+    finally:
+        ops.conv3d_k3 = orig
+    h2 = ops.conv3d_k3_h2_config()
+    assert calls == [(h2, False), (h2, True)], calls
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < 2e-5 * max(1.0, exp.abs().max().item()), err
+    mean, var = got.mean(dim=(2, 3, 4)), got.var(dim=(2, 3, 4), unbiased=False)
+    alpha = norm.weight.detach().cpu().double()[None] / torch.sqrt(var + norm.eps)
+    r = nrm.cpu().double()
+    assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+    assert (r[:, :, 1] - (norm.bias.detach().cpu().double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    return err
+
+
 def case_nets_window_vs_oracle(device, edge=96, filters=(32, 64, 128, 256)):
     """DynUNet (nnU-Net filters) and SegResNet on one BASELINE-sized window (edge^3) against the CPU oracle (oracle/dynunet.py, itself pinned
     to the reference's goldens): the large-plane convolution configurations that the 32^3 goldens do not reach."""

@@ -318,6 +318,62 @@ def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=Tr
     return err
 
 
+def case_conv3d_k3s2(device, n, cin, cout, dims, with_bias=True, fused_stats=True, tol=2e-5):
+    """Conv3d k3 s2 p1 on the fp16 matrix cores in split precision (csrc/kernels/conv3d_s2_h2.h: phase-split pass + GEMM over the 8 parity phases) against ATen in
+    float64: ragged tiles, the zero padding at index -1 of every axis, one / two cout groups per workgroup, several z-chunks (run-in plane), and the InstanceNorm
+    statistics of the result through the finalize kernel"""
+    gen = torch.Generator().manual_seed(500 + cin + cout + dims[0] + 3 * dims[2])
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(dims))))
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    b = torch.randn(cout, generator=gen) * 0.3 if with_bias else None
+    exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None if b is None else b.double(), stride=2, padding=1)
+    assert ops.conv3d_k3s2_accepts(cin, cout, *dims)
+    packed = ops.conv3d_k3s2_pack(w.to(device))
+    out = torch.full(tuple(exp.shape), float("nan"), device=device)
+    tiles = ops.conv3d_k3s2_stat_tiles(*dims)
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if fused_stats else None
+    ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), out, stats)
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"conv3d_k3s2 {cin}->{cout} {dims}: max err {err}"
+    if stats is not None:
+        gamma = torch.rand(cout, generator=gen) + 0.5
+        beta = torch.randn(cout, generator=gen) * 0.2
+        nrm_out = torch.full((n, cout, 4), float("nan"), device=device)
+        ops.instnorm_finalize(stats, tiles, n, cout, gamma.to(device), beta.to(device), 1e-5, 0.1, nrm_out)
+        mean = got.mean(dim=(2, 3, 4))
+        var = got.var(dim=(2, 3, 4), unbiased=False)
+        alpha = gamma.double()[None] / torch.sqrt(var + 1e-5)
+        r = nrm_out.cpu().double()
+        assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+        assert (r[:, :, 1] - (beta.double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    return err
+
+
+def case_conv3d_k3s2_poison_and_scale(device):
+    """the bound contract of the split-precision family on the stride-2 kernel: huge / tiny magnitudes keep fp32-equivalent relative precision (power-of-two input
+    scale), a sample with a non-finite bound comes out NaN as a whole while its neighbour is untouched"""
+    gen = torch.Generator().manual_seed(77)
+    n, cin, cout, dims = 2, 16, 32, (4, 8, 8)
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    packed = ops.conv3d_k3s2_pack(w.to(device))
+    for mag in (3.0e4, 1.0e-6, 1.0e12):
+        x = torch.randn((n, cin) + dims, generator=gen) * mag
+        nrm = _with_bounds(x, _rand_nrm(n, cin, gen))
+        exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None, stride=2, padding=1)
+        out = torch.full(tuple(exp.shape), float("nan"), device=device)
+        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out)
+        assert (out.cpu().double() - exp).abs().max().item() < 2e-5 * exp.abs().max().item(), mag
+    x = torch.randn((n, cin) + dims, generator=gen)
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen))
+    nrm[1, 3, 3] = float("inf")
+    exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None, stride=2, padding=1)
+    out = torch.zeros(tuple(exp.shape), device=device)
+    ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out)
+    assert torch.isnan(out[1]).all() and (out[0].cpu().double() - exp[0]).abs().max().item() < 2e-5
+
+
 def _conv_err(device, cfg, x, nrm, w, b, exp):
     packed = ops.conv3d_k3_pack(cfg, w.to(device))
     out = torch.full(tuple(exp.shape), float("nan"), device=device)

@@ -91,6 +91,38 @@ def test_dynunet_vs_reference(emu):
     dc.case_dynunet_api("cpu")
 
 
+def test_dynunet_concat_wider_than_the_record_table(emu):
+    import dynunet_cases as dc
+    from monai_amd import config
+
+    with config.conv_algo_scope("auto"):
+        print("max |d|", dc.case_dynunet_wide_concat("cpu"))
+
+
+def test_strided_convolutions_of_dynunet_and_segresnet_on_matrix_cores(emu):
+    """the reference goldens with the down-sampling convolutions on the split-precision stride-2 kernel (the `emu` fixture pins the exact-fp32 family otherwise)"""
+    import dynunet_cases as dc
+    import segresnet_cases as sc
+    from monai_amd import config, ops
+
+    calls, orig = [], ops.conv3d_k3s2
+
+    def spy(x, *a, **k):
+        calls.append(tuple(x.shape))
+        return orig(x, *a, **k)
+
+    ops.conv3d_k3s2 = spy
+    try:
+        with config.conv_algo_scope("auto"):
+            print("dynunet max |dlogit|", dc.case_dynunet_vs_reference("cpu", names=("basic", "aniso_basic")))
+            assert (2, 16, 32, 32, 32) in calls and (2, 48, 8, 8, 8) in calls and (2, 16, 8, 12, 6) in calls, calls
+            calls.clear()
+            print("segresnet max |dlogit|", sc.case_segresnet_vs_reference("cpu", names=("f16",)))
+            assert len(calls) == 2, calls
+    finally:
+        ops.conv3d_k3s2 = orig
+
+
 @pytest.mark.heavy_emu
 def test_dynunet_2d_and_slice_inferer_vs_reference(emu):
     """a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""

@@ -298,6 +298,21 @@ def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
     kc.case_upconv_k4s2("cpu", 1, cup, cout, ldims, with_bias=False, fused_stats=False)
 
 
+# (n, cin, cout, dims): one tile, vector stores / two cout groups per workgroup, odd output widths (scalar stores), ragged tiles / two z-chunks with a run-in plane /
+# three channel chunks, 17 x 25 outputs in two tiles
+S2_CASES = [(1, 16, 32, (4, 8, 8)), (2, 32, 64, (6, 10, 12)), (1, 16, 32, (36, 4, 6)), pytest.param(1, 48, 96, (4, 34, 50), marks=pytest.mark.heavy_emu)]
+@pytest.mark.parametrize("n,cin,cout,dims", S2_CASES)
+def test_strided_convolution_on_matrix_cores(emu, n, cin, cout, dims):
+    """Conv3d k3 s2 p1 as 8 dense sub-convolutions over the input's parity phases on the fp16 matrix cores (kernels/conv3d_s2_h2.h) == ATen in float64, statistics included"""
+    kc.case_conv3d_k3s2("cpu", n, cin, cout, dims)
+    if n == 1:
+        kc.case_conv3d_k3s2("cpu", 1, cin, cout, dims, with_bias=False, fused_stats=False)
+
+
+def test_strided_convolution_bounds_and_poison(emu):
+    kc.case_conv3d_k3s2_poison_and_scale("cpu")
+
+
 # (n, cin, cout, dims): resident slabs / streamed slabs with ragged 16 x 16 regions and two cout groups / the 8 x 32 region shape in two z-chunks / 8 x 32 regions, four chunks of channels
 ACC_CASES = [(2, 32, 32, (4, 16, 16)), (1, 48, 64, (3, 18, 20)), (1, 16, 32, (24, 8, 24)), pytest.param(1, 64, 32, (2, 24, 56), marks=pytest.mark.heavy_emu)]
 @pytest.mark.parametrize("n,cin,cout,dims", ACC_CASES)

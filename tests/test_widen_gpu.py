@@ -29,6 +29,13 @@ def test_dynunet_vs_reference():
     dc.case_dynunet_api(DEV)
 
 
+def test_dynunet_concat_wider_than_the_record_table():
+    import dynunet_cases as dc
+
+    print("max |d|", dc.case_dynunet_wide_concat(DEV))
+    print("max |d|", dc.case_dynunet_wide_concat(DEV, cin=512, cout=256, dims=(12, 12, 12)))
+
+
 def test_dynunet_2d_and_slice_inferer_vs_reference():
     """SURVEY 8 row a9 on the MI355X: a product 2-D network (DynUNet on the one-plane 3-D engine) under SliceInferer, against the real reference"""
     import dynunet_cases as dc
