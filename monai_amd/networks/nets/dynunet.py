@@ -318,12 +318,14 @@ class DynUNet(nn.Module):
         ops.instnorm_finalize(stats, tiles, n, c, norm.weight, norm.bias, norm.eps, slope, nrm)
         return nrm
 
-    def _conv_norm(self, conv: nn.Conv3d, norm, x, x_nrm, stride, slope: float):
-        """3x3x3 conv (no bias) of the (deferred) input + InstanceNorm statistics -> (raw output, {alpha, beta, slope} record)"""
+    def _conv_norm(self, conv: nn.Conv3d, norm, x, x_nrm, stride, slope: float, out=None):
+        """3x3x3 conv (no bias) of the (deferred) input + InstanceNorm statistics -> (raw output, {alpha, beta, slope} record); `out`: where the raw output goes (a channel
+        range of a concat buffer: the skip tensor is then never materialised -- its consumers apply the record on load)"""
         n, cin, d, h, w = x.shape
         cout = conv.weight.shape[0]
         sp = _out_size((d, h, w), stride)
-        out = torch.empty((n, cout) + sp, dtype=torch.float32, device=x.device)
+        if out is None:
+            out = torch.empty((n, cout) + sp, dtype=torch.float32, device=x.device)
         tiles, stats = 0, None
         flops = 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n
         if stride == (1, 1, 1) and not (cin <= 8 and cout <= 8):
@@ -356,10 +358,10 @@ class DynUNet(nn.Module):
             ops.conv3d_k3_strided3(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)
         return out, self._finalize(norm, out, stats, tiles, slope)
 
-    def _basic(self, blk: _Block, x, x_nrm):
+    def _basic(self, blk: _Block, x, x_nrm, out=None):
         """UnetBasicBlock: conv1 -> norm1 -> lrelu -> conv2 -> norm2 -> lrelu, the last normalise + activate left to the consumer"""
         c1, n1 = self._conv_norm(blk.conv1.conv, blk.norm1, x, x_nrm, blk.stride, self._slope)
-        return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), self._slope)
+        return self._conv_norm(blk.conv2.conv, blk.norm2, c1, n1, (1, 1, 1), self._slope, out)
 
     @staticmethod
     def _records(t: torch.Tensor) -> torch.Tensor:
@@ -389,8 +391,12 @@ class DynUNet(nn.Module):
         """an encoder block of a plain tensor, materialised into `dst` (the skip half of a concat buffer)"""
         if blk.res:
             return self._res(blk, x, x_nrm, dst, dst_nrm)
-        c, cn = self._basic(blk, x, x_nrm)
-        return ops.add_act(c, cn, None, None, 1.0, dst, dst_nrm)
+        # a basic block's result stays deferred: its last convolution writes the raw values straight into `dst`, the record of norm2 + lrelu (with its magnitude bound)
+        # goes into `dst_nrm` -- both consumers (the next level's first convolution, the decoder's concat convolution) apply records on load.  Until round 5 a pass
+        # materialised it (3.5 % of the nnU-Net-shaped network's step).
+        c, cn = self._basic(blk, x, x_nrm, dst)
+        dst_nrm.copy_(cn)
+        return c
 
     def _level(self, i: int, x, x_nrm, downs, ups):
         """DynUNetSkipLayer.forward at depth i: down -> next level -> transposed conv + [up | skip] concat -> conv block (deferred)"""

@@ -897,7 +897,9 @@ def conv3d_k3s2_selected(cin: int, cout: int, d: int, h: int, w: int, stride, bo
     from . import config
 
     st = (int(stride),) * 3 if isinstance(stride, int) else tuple(int(v) for v in stride)
-    return st == (2, 2, 2) and bool(bounded) and config.strided_h2() and conv3d_k3s2_accepts(cin, cout, d, h, w)
+    # output planes below 8 x 8 fill a quarter of a workgroup's 256-voxel tile at best: measured slower than the direct kernel there (256 -> 320 @ 12^3 -> 6^3 x 64
+    # windows: 2.18 vs 1.61 ms, profiles/r05_s2_layers.txt), 3.0-3.9 x faster from 12 x 12 outputs on
+    return st == (2, 2, 2) and bool(bounded) and config.strided_h2() and h >= 16 and w >= 16 and conv3d_k3s2_accepts(cin, cout, d, h, w)
 
 
 def conv3d_k3s2_workspace_floats(n: int, cin: int, d: int, h: int, w: int) -> int:

@@ -114,8 +114,8 @@ def test_strided_convolutions_of_dynunet_and_segresnet_on_matrix_cores(emu):
     ops.conv3d_k3s2 = spy
     try:
         with config.conv_algo_scope("auto"):
-            print("dynunet max |dlogit|", dc.case_dynunet_vs_reference("cpu", names=("basic", "aniso_basic")))
-            assert (2, 16, 32, 32, 32) in calls and (2, 48, 8, 8, 8) in calls and (2, 16, 8, 12, 6) in calls, calls
+            print("dynunet max |dlogit|", dc.case_dynunet_vs_reference("cpu", names=("basic",)))
+            assert calls == [(2, 16, 32, 32, 32)], calls          # smaller planes stay on the direct kernel (ops.conv3d_k3s2_selected)
             calls.clear()
             print("segresnet max |dlogit|", sc.case_segresnet_vs_reference("cpu", names=("f16",)))
             assert len(calls) == 2, calls
