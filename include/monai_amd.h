@@ -215,6 +215,15 @@ int mh_maxpool2_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
 int mh_deconv_k2s2_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,
                        void* stream);
 
+/* The same transposed convolution (k = 2, s = 2) on the fp16 matrix cores in the split precision of mh_conv3d_k3_h2_config (kernels/deconv_h2.h): one GEMM with
+ * (cout, parity) rows whose result is stored pixel-shuffled; the input is read once per 32 (16) output channels instead of once per 4.  `in` must carry records
+ * with magnitude bounds; Cin % 16 == 0 (<= 1024), Cout % 16 == 0 (mh_deconv_k2s2_h2_accepts); w [Cin][Cout][2][2][2] packed once by mh_deconv_k2s2_h2_pack_f32 into
+ * mh_deconv_k2s2_h2_packed_floats(Cin, Cout) floats.  Output records (when the view has them) receive the magnitude bound as in mh_deconv_k2s2_f32. */
+int mh_deconv_k2s2_h2_accepts(int Cin, int Cout, int D, int H, int W);
+int64_t mh_deconv_k2s2_h2_packed_floats(int Cin, int Cout);
+int mh_deconv_k2s2_h2_pack_f32(const float* w, int Cin, int Cout, float* packed, void* stream);
+int mh_deconv_k2s2_h2_f32(const mh_tensor5* in, const float* packed, const float* bias, const mh_tensor5* out, void* stream);
+
 /* UpCat (monai/networks/nets/basic_unet.py:130-178) without its up-sampled intermediate: the `x_0 = ConvTranspose3d(k2, s2)(x)` half of
  * `Conv3d(k3, p1)(cat([x_e, x_0]))` is the composite transposed convolution k4 s2 p1 of x itself (kernels/upconv_h2.h) -- 8 instead of 27 taps per output voxel, no
  * full-resolution x_0 written or read.  w4 [Cin][Cout][4][4][4] = the composite weights (host: sum over the up channels of deconv x conv weight products),

@@ -95,6 +95,10 @@ SIGNATURES = {
     "mh_upconv_k4s2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
     "mh_upconv_k4s2_stat_tiles": (_I, [_I, _I, _I]),
     "mh_upconv_k4s2_f32": (_I, [_T, _P, _P, _T, _I, _P, _P]),
+    "mh_deconv_k2s2_h2_accepts": (_I, [_I, _I, _I, _I, _I]),
+    "mh_deconv_k2s2_h2_packed_floats": (_L, [_I, _I]),
+    "mh_deconv_k2s2_h2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
+    "mh_deconv_k2s2_h2_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv3d_k3s2_accepts": (_I, [_I, _I, _I, _I, _I]),
     "mh_conv3d_k3s2_packed_floats": (_L, [_I, _I]),
     "mh_conv3d_k3s2_workspace_floats": (_L, [_I, _I, _I, _I, _I]),

@@ -81,6 +81,18 @@ def strided_h2() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no") and conv_algo() in (CONV_ALGOS["auto"], CONV_ALGOS["h2"])
 
 
+# ---- ConvTranspose3d k2 s2 on the fp16 matrix cores -------------------------------------------------------------------------------
+# The up-sampling transposed convolutions (BasicUNet's lower decoder levels, DynUNet, UNETR) whose input carries magnitude bounds run as one split-precision GEMM with
+# (cout, parity) rows (csrc/kernels/deconv_h2.h) instead of the vector-ALU kernel -- fp32-equivalent, families "auto" / "h2" only.
+# False (or MONAI_AMD_DECONV_H2=0 while None) keeps the direct fp32 kernel.
+DECONV_H2 = None
+
+
+def deconv_h2() -> bool:
+    v = DECONV_H2 if DECONV_H2 is not None else os.environ.get("MONAI_AMD_DECONV_H2", "1")
+    return str(v).lower() not in ("0", "false", "off", "no") and conv_algo() in (CONV_ALGOS["auto"], CONV_ALGOS["h2"])
+
+
 # ---- SwinTransformerBlock without its copies -------------------------------------------------------------------------------------
 # SwinUNETR: norm1 + pad + roll + window_partition as one gathering LayerNorm and window_reverse + roll back + crop + the shortcut sum in the projection's epilogue
 # (csrc/kernels/dense.h: layernorm_vec_kernel's src_row, the linear kernels' rowmap) -- the same values, moved once instead of six times.  False (or

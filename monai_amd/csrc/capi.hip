@@ -14,6 +14,7 @@
 #include "kernels/conv3d_h2.h"
 #include "kernels/upconv_h2.h"
 #include "kernels/conv3d_s2_h2.h"
+#include "kernels/deconv_h2.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -835,6 +836,44 @@ int mh_deconv_k2s2_f32(const mh_tensor5* in_, const float* w, const float* bias,
     if (out.C % 4 == 0) hipLaunchKernelGGL((deconv_k2s2_kernel<4, true>), dim3(nb, (unsigned)(out.C / 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     else hipLaunchKernelGGL((deconv_k2s2_kernel<4, false>), dim3(nb, (unsigned)cdiv(out.C, 4), (unsigned)out.N), dim3(256), 0, (hipStream_t)stream, in, w, bias, out);
     return launched("deconv_k2s2");
+}
+
+// ---- ConvTranspose3d k2 s2 on the fp16 matrix cores in split precision (kernels/deconv_h2.h): one GEMM with (cout, parity) rows, stored pixel-shuffled
+int mh_deconv_k2s2_h2_accepts(int Cin, int Cout, int D, int H, int W) {
+    return Cin >= 16 && Cin % 16 == 0 && Cin <= DH_CIN_MAX && Cout >= 16 && Cout % 16 == 0 && D >= 1 && H >= 1 && W >= 1 && (long long)D * H * W < 0x10000000LL;
+}
+int64_t mh_deconv_k2s2_h2_packed_floats(int Cin, int Cout) {
+    if (!(Cin >= 16 && Cin % 16 == 0 && Cout >= 16 && Cout % 16 == 0)) return fail(MH_ERR_ARG, "deconv_k2s2_h2: needs Cin %% 16 == 0, Cout %% 16 == 0");
+    return (int64_t)Cin * Cout * 8 + H2_TAIL;              // two fp16 pieces per weight + {1 / scale, scale}
+}
+int mh_deconv_k2s2_h2_pack_f32(const float* w, int Cin, int Cout, float* packed, void* stream) {
+    if (!w || !packed) return fail(MH_ERR_ARG, "deconv_k2s2_h2_pack: null pointer");
+    const int64_t total = mh_deconv_k2s2_h2_packed_floats(Cin, Cout);
+    if (total < 0) return (int)total;
+    if (!aligned(packed, 16)) return fail(MH_ERR_ARG, "deconv_k2s2_h2_pack: 16-byte aligned packed buffer required");
+    float* tail = packed + (total - H2_TAIL);
+    hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 8, tail);
+    hipLaunchKernelGGL(deconv_k2s2_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, Cout % 32 == 0 ? 8 : 4,
+                       reinterpret_cast<_Float16*>(packed), tail);
+    return launched("deconv_k2s2_h2_pack");
+}
+int mh_deconv_k2s2_h2_f32(const mh_tensor5* in_, const float* packed, const float* bias, const mh_tensor5* out_, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed) return fail(MH_ERR_ARG, "deconv_k2s2_h2: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "deconv_k2s2_h2: the output view's records must be 16-byte aligned [N][>= C][4] floats");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || out.D != 2 * in.D || out.H != 2 * in.H || out.W != 2 * in.W) return fail(MH_ERR_ARG, "deconv_k2s2_h2: output must be 2x input");
+    if (!mh_deconv_k2s2_h2_accepts(in.C, out.C, in.D, in.H, in.W))
+        return fail(MH_ERR_UNSUPPORTED, "deconv_k2s2_h2: needs Cin %% 16 == 0 (<= %d), Cout %% 16 == 0 (got %d -> %d)", DH_CIN_MAX, in.C, out.C);
+    if (!in.nrm) return fail(MH_ERR_ARG, "deconv_k2s2_h2: the input must carry records with magnitude bounds (the split-precision kernels scale their input by them)");
+    if (!aligned(in.nrm, 16) || !aligned(out.data, 8) || out.n_stride % 2 || !aligned(packed, 16)) return fail(MH_ERR_ARG, "deconv_k2s2_h2: 16-byte aligned records and weights, 8-byte aligned output required");
+    if (out.N > 65535) return fail(MH_ERR_UNSUPPORTED, "deconv_k2s2_h2: at most 65535 samples per launch");
+    const uint4* wq = reinterpret_cast<const uint4*>(packed);
+    const float* tail = packed + (mh_deconv_k2s2_h2_packed_floats(in.C, out.C) - H2_TAIL);
+    const unsigned nb = (unsigned)(((long long)in.D * in.H * in.W + 127) / 128);
+    hipStream_t s = (hipStream_t)stream;
+    if (out.C % 32 == 0) hipLaunchKernelGGL((deconv_k2s2_h2_kernel<8>), dim3(nb, (unsigned)(out.C / 32), (unsigned)out.N), dim3(256), 0, s, in, wq, tail, bias, out);
+    else hipLaunchKernelGGL((deconv_k2s2_h2_kernel<4>), dim3(nb, (unsigned)(out.C / 16), (unsigned)out.N), dim3(256), 0, s, in, wq, tail, bias, out);
+    return launched("deconv_k2s2_h2");
 }
 
 // ---- UpCat's "up" half as one composite transposed convolution k4 s2 p1 added to the convolution's skip half (kernels/upconv_h2.h)

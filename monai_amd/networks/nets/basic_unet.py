@@ -505,7 +505,7 @@ class _Plan:
                 elif self.planar:     # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
                     ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
                 else:
-                    ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm)
+                    ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm, bounded=src_nrm is not None and not self.batchnorm)
                 if self.odd[l]:
                     ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
                 self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)

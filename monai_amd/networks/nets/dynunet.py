@@ -417,7 +417,7 @@ class DynUNet(nn.Module):
             t, tn = self._basic(self.bottleneck, skip, skip_nrm)
         tc = up.transp_conv.conv
         if up.up == (2, 2, 2):
-            ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout], cat_nrm[:, :cout])
+            ops.deconv_k2s2(t, tn, tc.weight, tc.bias, cat[:, :cout], cat_nrm[:, :cout], bounded=tn is not None)      # records of instnorm_finalize: they carry bounds
         else:
             ops.deconv_ks(t, tn, self._w5(tc).contiguous(), tc.bias, cat[:, :cout], up.up, cat_nrm[:, :cout])
         return self._basic(up.conv_block, cat, cat_nrm)

@@ -223,6 +223,17 @@ class UNETR(nn.Module):
             self._packed[slot] = hit
         return hit[1]
 
+    def _packed_cin(self, conv: nn.Conv3d, cfg: int, c0: int, c1: int) -> torch.Tensor:
+        """packed weights of INPUT channels c0 .. c1 - 1 (a convolution evaluated in two halves of its input channels)"""
+        w = conv.weight
+        key = (w.data_ptr(), w._version, str(w.device), cfg)
+        slot = (id(conv), "cin", c0, c1)
+        hit = self._packed.get(slot)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, w[:, c0:c1].contiguous()))
+            self._packed[slot] = hit
+        return hit[1]
+
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
         if self._stats is None or self._stats.numel() < floats or self._stats.device != device:
             self._stats = torch.empty(floats, dtype=torch.float32, device=device)
@@ -251,8 +262,20 @@ class UNETR(nn.Module):
                 ops.instnorm_finalize(st, tiles, n, hi - lo, None, None, 1e-5, slope, nrm[:, lo:hi])
                 lo = hi
             return out, nrm
-        tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
         flops = 2.0 * 27 * cin * cout * d * h * w * n
+        half = (cin // 32) * 16
+        if (cfg not in (h2, h2c) and x_nrm is not None and cin > 256 and cin % 16 == 0 and cout % 32 == 0
+                and ops.conv3d_k3_select(half, cout, d, h, w, bounded=True) == h2 and ops.conv3d_k3_select(cin - half, cout, d, h, w, bounded=True) == h2):
+            # more input channels than the split-precision kernel keeps records for (SwinUNETR(48)'s 384-channel concat at 12^3): the convolution is linear in its input
+            # channels -- one half written, the other half added onto it by the accumulating form, which leaves the statistics of the sum
+            tiles = ops.conv3d_k3_stat_tiles(h2, d, h, w)
+            stats = self._stats_buf(n * cout * tiles * 3, x.device)
+            with _prof.span(f"conv3d_k3/cfg{h2}", flops):
+                ops.conv3d_k3(h2, x[:, :half], x_nrm[:, :half], self._packed_cin(conv, h2, 0, half), None, out, None)
+                ops.conv3d_k3(h2, x[:, half:], x_nrm[:, half:], self._packed_cin(conv, h2, half, cin), None, out, stats, accumulate=True)
+            ops.instnorm_finalize(stats, tiles, n, cout, None, None, 1e-5, slope, nrm)
+            return out, nrm
+        tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
         if tiles:
             stats = self._stats_buf(n * cout * tiles * 3, x.device)
             with _prof.span(f"conv3d_k3/cfg{cfg}", flops):

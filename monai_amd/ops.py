@@ -421,10 +421,39 @@ def maxpool2(x, x_nrm, out, out_nrm=None):
     return out
 
 
-def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None):
-    """out_nrm: `nrm_identity` records of `out`; the kernel folds max |value written| into their bound"""
+_DECONV_H2_PACKED: dict = {}          # id(weight) -> (weakref to the parameter, its version, device, packed tap matrices): re-packed when the parameter changed or moved
+
+
+def deconv_k2s2_h2_packed(weight: torch.Tensor) -> torch.Tensor:
+    """[Cin, Cout, 2, 2, 2] -> the matrix-core kernel's split-precision (cout, parity) row matrices (kernels/deconv_h2.h), cached per parameter version"""
+    import weakref
+
+    hit = _DECONV_H2_PACKED.get(id(weight))
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version or hit[2] != str(weight.device):
+        if len(_DECONV_H2_PACKED) > 256:          # parameters that no longer exist
+            for k in [k for k, v in _DECONV_H2_PACKED.items() if v[0]() is None]:
+                del _DECONV_H2_PACKED[k]
+        cin, cout = int(weight.shape[0]), int(weight.shape[1])
+        packed = torch.zeros(_lib.lib().query("mh_deconv_k2s2_h2_packed_floats", cin, cout), dtype=torch.float32, device=weight.device)
+        _lib.lib().call("mh_deconv_k2s2_h2_pack_f32", _lib.ptr(weight.detach().contiguous()), cin, cout, _lib.ptr(packed), _s(weight))
+        hit = (weakref.ref(weight), weight._version, str(weight.device), packed)
+        _DECONV_H2_PACKED[id(weight)] = hit
+    return hit[3]
+
+
+def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None, bounded: bool = False):
+    """out = conv_transpose3d(act(x), k 2, s 2) + bias.  out_nrm: `nrm_identity` records of `out`; the kernel folds max |value written| into their bound.
+    bounded: every record of `x_nrm` carries a magnitude bound -- the transposed convolution then runs on the fp16 matrix cores in split precision
+    (kernels/deconv_h2.h; shapes it takes, families "auto" / "h2", `monai_amd.config.deconv_h2()`), otherwise on the direct fp32 kernel"""
     _lib.require_device(x, x_nrm, weight, bias, out, out_nrm)
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out, out_nrm)
+    if bounded and x_nrm is not None and tuple(weight.shape[2:]) == (2, 2, 2):
+        from . import config
+
+        cin, cout = int(weight.shape[0]), int(weight.shape[1])
+        if config.deconv_h2() and _lib.lib().query("mh_deconv_k2s2_h2_accepts", cin, cout, int(x.shape[2]), int(x.shape[3]), int(x.shape[4])):
+            _lib.lib().call("mh_deconv_k2s2_h2_f32", C.byref(xi), _lib.ptr(deconv_k2s2_h2_packed(weight)), _lib.ptr(bias), C.byref(xo), _s(x))
+            return out
     _lib.lib().call("mh_deconv_k2s2_f32", C.byref(xi), _lib.ptr(weight), _lib.ptr(bias), C.byref(xo), _s(x))
     return out
 

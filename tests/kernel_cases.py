@@ -318,6 +318,48 @@ def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=Tr
     return err
 
 
+def case_deconv_k2s2_h2(device, n, cin, cout, dims, with_bias=True, tol=2e-5):
+    """ConvTranspose3d k2 s2 as one split-precision GEMM with (cout, parity) rows, stored pixel-shuffled (csrc/kernels/deconv_h2.h), into a channel slice of a wider
+    buffer, against ATen in float64: volumes that end inside a wave, 16- and 32-channel output groups, more input channels than one weight chunk; the magnitude bound
+    left in the output records; a poisoned sample"""
+    from monai_amd import config
+
+    gen = torch.Generator().manual_seed(600 + cin + cout + dims[0] + 5 * dims[2])
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen=3.0)
+    w = torch.randn((cin, cout, 2, 2, 2), generator=gen) / np.sqrt(float(cin))
+    b = torch.randn(cout, generator=gen) * 0.3 if with_bias else None
+    exp = F.conv_transpose3d(_act(x.double(), nrm.double()), w.double(), None if b is None else b.double(), stride=2)
+    odims = tuple(2 * v for v in dims)
+    buf = torch.full((n, cout + 5) + odims, float("nan"), device=device)
+    rec = torch.full((n, cout + 5, 4), float("nan"), device=device)
+    with config.conv_algo_scope("auto"):
+        assert config.deconv_h2()
+        wd = w.to(device)
+        ops.deconv_k2s2(x.to(device), nrm.to(device), wd, None if b is None else b.to(device), buf[:, 5:], ops.nrm_identity(rec[:, 5:]), bounded=True)
+        got = buf[:, 5:].cpu().double()
+        err = (got - exp).abs().max().item()
+        assert err < tol * max(1.0, exp.abs().max().item()), f"deconv_k2s2_h2 {cin}->{cout} {dims}: max err {err}"
+        assert torch.isnan(buf[:, :5]).all()
+        r = rec.cpu()
+        amax = got.abs().amax(dim=(2, 3, 4)).float()
+        grp = 32 if cout % 32 == 0 else 16
+        gmax = amax.view(n, cout // grp, grp).amax(dim=2, keepdim=True).expand(-1, -1, grp).reshape(n, cout)
+        assert torch.all(r[:, 5:, 0] == 1.0) and torch.all(r[:, 5:, 1] == 0.0) and torch.all(r[:, 5:, 2] == 1.0)
+        assert torch.equal(r[:, 5:, 3], gmax), "deconv_k2s2_h2: bound != max |value written| of the channel group"
+        # against the direct fp32 kernel (same call without bounds), and a poisoned sample
+        ref = torch.empty((n, cout) + odims, device=device)
+        ops.deconv_k2s2(x.to(device), nrm.to(device), wd, None if b is None else b.to(device), ref)
+        assert (ref.cpu().double() - got).abs().max().item() < tol * max(1.0, exp.abs().max().item())
+        if n > 1:
+            bad = nrm.clone()
+            bad[1, 2, 3] = float("nan")
+            out = torch.zeros((n, cout) + odims, device=device)
+            ops.deconv_k2s2(x.to(device), bad.to(device), wd, None, out, bounded=True)
+            assert torch.isnan(out[1]).all() and torch.isfinite(out[0]).all()
+    return err
+
+
 def case_conv3d_k3s2(device, n, cin, cout, dims, with_bias=True, fused_stats=True, tol=2e-5):
     """Conv3d k3 s2 p1 on the fp16 matrix cores in split precision (csrc/kernels/conv3d_s2_h2.h: phase-split pass + GEMM over the 8 parity phases) against ATen in
     float64: ragged tiles, the zero padding at index -1 of every axis, one / two cout groups per workgroup, several z-chunks (run-in plane), and the InstanceNorm

@@ -111,16 +111,23 @@ def test_strided_convolutions_of_dynunet_and_segresnet_on_matrix_cores(emu):
         calls.append(tuple(x.shape))
         return orig(x, *a, **k)
 
-    ops.conv3d_k3s2 = spy
+    packs, orig_pack = [], ops.deconv_k2s2_h2_packed
+
+    def spy_pack(w):
+        packs.append(tuple(w.shape))
+        return orig_pack(w)
+
+    ops.conv3d_k3s2, ops.deconv_k2s2_h2_packed = spy, spy_pack
     try:
         with config.conv_algo_scope("auto"):
             print("dynunet max |dlogit|", dc.case_dynunet_vs_reference("cpu", names=("basic",)))
             assert calls == [(2, 16, 32, 32, 32)], calls          # smaller planes stay on the direct kernel (ops.conv3d_k3s2_selected)
+            assert (64, 48, 2, 2, 2) in packs and (32, 16, 2, 2, 2) in packs, packs      # its transposed convolutions ran on the matrix cores (kernels/deconv_h2.h)
             calls.clear()
             print("segresnet max |dlogit|", sc.case_segresnet_vs_reference("cpu", names=("f16",)))
             assert len(calls) == 2, calls
     finally:
-        ops.conv3d_k3s2 = orig
+        ops.conv3d_k3s2, ops.deconv_k2s2_h2_packed = orig, orig_pack
 
 
 @pytest.mark.heavy_emu

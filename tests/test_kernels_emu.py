@@ -298,6 +298,15 @@ def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
     kc.case_upconv_k4s2("cpu", 1, cup, cout, ldims, with_bias=False, fused_stats=False)
 
 
+# (n, cin, cout, dims): a volume that ends inside a wave / five k-steps (two weight chunks), 16 output channels / two groups of 32
+DECONV_H2_CASES = [(2, 16, 32, (3, 5, 7)), (2, 80, 16, (2, 4, 9)), (1, 32, 64, (4, 4, 8))]
+@pytest.mark.parametrize("n,cin,cout,dims", DECONV_H2_CASES)
+def test_transposed_convolution_on_matrix_cores(emu, n, cin, cout, dims):
+    """ConvTranspose3d k2 s2 as one split-precision GEMM with (cout, parity) rows (kernels/deconv_h2.h) == ATen in float64, bounds and poisoning included"""
+    kc.case_deconv_k2s2_h2("cpu", n, cin, cout, dims)
+    kc.case_deconv_k2s2_h2("cpu", 1, cin, cout, dims, with_bias=False)
+
+
 # (n, cin, cout, dims): one tile, vector stores / two cout groups per workgroup, odd output widths (scalar stores), ragged tiles / two z-chunks with a run-in plane /
 # three channel chunks, 17 x 25 outputs in two tiles
 S2_CASES = [(1, 16, 32, (4, 8, 8)), (2, 32, 64, (6, 10, 12)), (1, 16, 32, (36, 4, 6)), pytest.param(1, 48, 96, (4, 34, 50), marks=pytest.mark.heavy_emu)]
