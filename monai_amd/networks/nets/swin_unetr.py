@@ -435,15 +435,18 @@ class SwinUNETR(UNETR):
         if self.normalize:
             cat5_nrm = self._records(cat5)
             cat5_nrm[:, 8 * fs:] = hidden_records(hs[3])
-        dec4 = self._res_block(self.encoder10.layer, hs[4], hidden_records(hs[4]), new(hs[4], 16 * fs), None)
+        dec4 = new(hs[4], 16 * fs)
+        dec4_nrm = self._records(dec4)          # the join leaves the bounds the transposed convolution of decoder5 scales by (csrc/kernels/deconv_h2.h)
+        self._res_block(self.encoder10.layer, hs[4], hidden_records(hs[4]), dec4, dec4_nrm)
 
-        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst, head=None):
-            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], None if cat_nrm is None else cat_nrm[:, :cout])
-            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None, head=head)
+        def up(blk: _UpBlock, inp, inp_nrm, cat, cat_nrm, cout, dst, head=None):
+            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], None if cat_nrm is None else cat_nrm[:, :cout], inp_nrm)
+            dst_nrm = None if dst is None else self._records(dst)
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, dst_nrm, head=head), dst_nrm
 
-        dec3 = up(self.decoder5, dec4, cat5, cat5_nrm, 8 * fs, new(cat5, 8 * fs))
-        dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, new(cat4, 4 * fs))
-        dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, new(cat3, 2 * fs))
-        dec0 = up(self.decoder2, dec1, cat2, cat2_nrm, fs, new(cat2, fs))
-        up(self.decoder1, dec0, cat1, cat1_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
+        dec3, dec3_nrm = up(self.decoder5, dec4, dec4_nrm, cat5, cat5_nrm, 8 * fs, new(cat5, 8 * fs))
+        dec2, dec2_nrm = up(self.decoder4, dec3, dec3_nrm, cat4, cat4_nrm, 4 * fs, new(cat4, 4 * fs))
+        dec1, dec1_nrm = up(self.decoder3, dec2, dec2_nrm, cat3, cat3_nrm, 2 * fs, new(cat3, 2 * fs))
+        dec0, dec0_nrm = up(self.decoder2, dec1, dec1_nrm, cat2, cat2_nrm, fs, new(cat2, fs))
+        up(self.decoder1, dec0, dec0_nrm, cat1, cat1_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
         return logits

@@ -340,8 +340,20 @@ class UNETR(nn.Module):
         return ops.conv1x1(t, None, oc.weight.view(oc.weight.shape[0], -1), oc.bias, logits)
 
     @staticmethod
-    def _tconv(conv: nn.ConvTranspose3d, x, out, out_nrm=None):
-        return ops.deconv_k2s2(x, None, conv.weight, conv.bias, out, out_nrm)
+    def _tconv(conv: nn.ConvTranspose3d, x, out, out_nrm=None, x_nrm=None):
+        """x_nrm: identity records of the plain tensor x that carry its magnitude bounds (left by its producer, or `_bounded`): the transposed convolution then runs on
+        the matrix cores in split precision (csrc/kernels/deconv_h2.h)"""
+        return ops.deconv_k2s2(x, x_nrm, conv.weight, conv.bias, out, out_nrm, bounded=x_nrm is not None)
+
+    @staticmethod
+    def _bounded(t: torch.Tensor) -> torch.Tensor:
+        """identity records {1, 0, 1, max |t| per (n, c)} of a plain tensor nobody left bounds for (the ViT's hidden states: 768 x 6^3 values per window -- two small passes)"""
+        rec = torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device)
+        rec[:, :, 0] = 1.0
+        rec[:, :, 1] = 0.0
+        rec[:, :, 2] = 1.0
+        rec[:, :, 3] = t.abs().amax(dim=(2, 3, 4)).clamp_min(1.17549435e-38)       # NaN / inf stay: a poisoned bound, the sample's output is NaN (conv3d_h2.h)
+        return rec
 
     def _new(self, like, c, scale=1):
         n = like.shape[0]
@@ -423,18 +435,27 @@ class UNETR(nn.Module):
         self._res_block(self.encoder1.layer, x_in, None, cat2[:, fs:], cat2_nrm[:, fs:])
 
         def prup(blk: _PrUpBlock, t, dst, dst_nrm):
+            # every tensor of the chain travels with identity records its producer folds max |value| into: the next transposed convolution reads its bounds there
             cout = blk.transp_conv_init.conv.weight.shape[1]
             direct = len(blk.blocks) == 0
-            cur = self._tconv(blk.transp_conv_init.conv, t, dst if direct else self._new(t, cout, 2), dst_nrm if direct else None)
+            cur = dst if direct else self._new(t, cout, 2)
+            cur_nrm = dst_nrm if direct else self._records(cur)
+            self._tconv(blk.transp_conv_init.conv, t, cur, cur_nrm, self._bounded(t))
             for i, seq in enumerate(blk.blocks):
                 last = i == len(blk.blocks) - 1
                 if not isinstance(seq, nn.Sequential):        # conv_block=False: the bare transposed convolution
-                    cur = self._tconv(seq.conv, cur, dst if last else self._new(cur, cout, 2), dst_nrm if last else None)
+                    nxt = dst if last else self._new(cur, cout, 2)
+                    nxt_nrm = dst_nrm if last else self._records(nxt)
+                    self._tconv(seq.conv, cur, nxt, nxt_nrm, cur_nrm)
+                    cur, cur_nrm = nxt, nxt_nrm
                     continue
                 up = self._new(cur, cout, 2)
                 up_nrm = self._records(up)
-                self._tconv(seq[0].conv, cur, up, up_nrm)
-                cur = self._res_block(seq[1], up, up_nrm, dst if last else self._new(up, cout), dst_nrm if last else None)
+                self._tconv(seq[0].conv, cur, up, up_nrm, cur_nrm)
+                nxt = dst if last else self._new(up, cout)
+                nxt_nrm = dst_nrm if last else self._records(nxt)
+                self._res_block(seq[1], up, up_nrm, nxt, nxt_nrm)
+                cur, cur_nrm = nxt, nxt_nrm
             return cur
 
         p2 = self._proj_feat(hs[3])
@@ -450,12 +471,14 @@ class UNETR(nn.Module):
         cat5_nrm = self._records(cat5)
         prup(self.encoder4, p4, cat5[:, 8 * fs:], cat5_nrm[:, 8 * fs:])
 
-        def up(blk: _UpBlock, inp, cat, cat_nrm, cout, dst, head=None):
-            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], cat_nrm[:, :cout])
-            return self._res_block(blk.conv_block, cat, cat_nrm, dst, None, head=head)
+        def up(blk: _UpBlock, inp, inp_nrm, cat, cat_nrm, cout, dst, head=None):
+            self._tconv(blk.transp_conv.conv, inp, cat[:, :cout], cat_nrm[:, :cout], inp_nrm)
+            dst_nrm = None if dst is None else self._records(dst)          # the block's join leaves the bounds the next level's transposed convolution scales by
+            return self._res_block(blk.conv_block, cat, cat_nrm, dst, dst_nrm, head=head), dst_nrm
 
-        dec3 = up(self.decoder5, self._proj_feat(x), cat5, cat5_nrm, 8 * fs, self._new(cat5, 8 * fs))
-        dec2 = up(self.decoder4, dec3, cat4, cat4_nrm, 4 * fs, self._new(cat4, 4 * fs))
-        dec1 = up(self.decoder3, dec2, cat3, cat3_nrm, 2 * fs, self._new(cat3, 2 * fs))
-        up(self.decoder2, dec1, cat2, cat2_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
+        xf = self._proj_feat(x)
+        dec3, dec3_nrm = up(self.decoder5, xf, self._bounded(xf), cat5, cat5_nrm, 8 * fs, self._new(cat5, 8 * fs))
+        dec2, dec2_nrm = up(self.decoder4, dec3, dec3_nrm, cat4, cat4_nrm, 4 * fs, self._new(cat4, 4 * fs))
+        dec1, dec1_nrm = up(self.decoder3, dec2, dec2_nrm, cat3, cat3_nrm, 2 * fs, self._new(cat3, 2 * fs))
+        up(self.decoder2, dec1, dec1_nrm, cat2, cat2_nrm, fs, None, head=(self.out.conv.conv, logits))      # + UnetOutBlock
         return logits
