@@ -244,13 +244,15 @@ int mh_upconv_k4s2_f32(const mh_tensor5* low, const float* packed, const float* 
  * (monai/networks/nets/unet.py:197-237) as 8 dense stride-1 sub-convolutions over the input's parity phases (27 taps in all, no zero taps).  w: [Cout][Cin][3][3][3];
  * `in` must carry records with magnitude bounds; extents even; Cin % 16 == 0, Cout % 32 == 0 (mh_conv3d_k3s2_accepts).  `workspace`:
  * mh_conv3d_k3s2_workspace_floats(N, Cin, D, H, W) floats, 16-byte aligned, caller-owned scratch (the activated, scaled, phase-split fp16 pieces of the input).
- * With stats != NULL one {count, mean, M2} record per (n, cout, tile): mh_conv3d_k3s2_stat_tiles(D, H, W) of them per (n, c), merged by mh_instnorm_finalize_f32. */
+ * With stats != NULL one {count, mean, M2} record per (n, cout, tile): mh_conv3d_k3s2_stat_tiles(D, H, W) of them per (n, c), merged by mh_instnorm_finalize_f32.
+ * fused != 0: no split pass and no workspace (may be NULL) -- the GEMM's staging converts the fp32 input itself, once per group of 64 output channels (Cin <= 512):
+ * the better form for layers with one or two such groups, where the split pass costs as much as the GEMM. */
 int mh_conv3d_k3s2_accepts(int Cin, int Cout, int D, int H, int W);
 int64_t mh_conv3d_k3s2_packed_floats(int Cin, int Cout);
 int64_t mh_conv3d_k3s2_workspace_floats(int N, int Cin, int D, int H, int W);
 int mh_conv3d_k3s2_stat_tiles(int D, int H, int W);
 int mh_conv3d_k3s2_pack_f32(const float* w, int Cin, int Cout, float* packed, void* stream);
-int mh_conv3d_k3s2_f32(const mh_tensor5* in, const float* packed, const float* bias, const mh_tensor5* out, float* workspace, float* stats, void* stream);
+int mh_conv3d_k3s2_f32(const mh_tensor5* in, const float* packed, const float* bias, const mh_tensor5* out, float* workspace, float* stats, int fused, void* stream);
 
 /* Conv3d k=1 (+bias) of act(in) -- `final_conv`, basic_unet.py:252.  w: [Cout][Cin]. */
 int mh_conv1x1_f32(const mh_tensor5* in, const float* w, const float* bias, const mh_tensor5* out,

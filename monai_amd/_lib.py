@@ -104,7 +104,7 @@ SIGNATURES = {
     "mh_conv3d_k3s2_workspace_floats": (_L, [_I, _I, _I, _I, _I]),
     "mh_conv3d_k3s2_stat_tiles": (_I, [_I, _I, _I]),
     "mh_conv3d_k3s2_pack_f32": (_I, [_P, _I, _I, _P, _P]),
-    "mh_conv3d_k3s2_f32": (_I, [_T, _P, _P, _T, _P, _P, _P]),
+    "mh_conv3d_k3s2_f32": (_I, [_T, _P, _P, _T, _P, _P, _I, _P]),
     "mh_conv1x1_f32": (_I, [_T, _P, _P, _T, _P]),
     "mh_conv1x1_stat_tiles": (_I, [_I, _I, _I]),
     "mh_conv1x1_stats_f32": (_I, [_T, _P, _P, _T, _P, _P]),

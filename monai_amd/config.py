@@ -81,6 +81,15 @@ def strided_h2() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no") and conv_algo() in (CONV_ALGOS["auto"], CONV_ALGOS["h2"])
 
 
+# the stride-2 kernel's two forms: "0" = phase-split pass + GEMM, "1" = conversion inside the GEMM's staging, "auto" (default) = by layer shape (ops.conv3d_k3s2_fused)
+STRIDED_H2_FUSED = None
+
+
+def strided_h2_fused() -> str:
+    v = str(STRIDED_H2_FUSED if STRIDED_H2_FUSED is not None else os.environ.get("MONAI_AMD_STRIDED_H2_FUSED", "auto")).lower()
+    return "0" if v in ("0", "false", "off", "no") else ("1" if v in ("1", "true", "on", "yes") else "auto")
+
+
 # ---- ConvTranspose3d k2 s2 on the fp16 matrix cores -------------------------------------------------------------------------------
 # The up-sampling transposed convolutions (BasicUNet's lower decoder levels, DynUNet, UNETR) whose input carries magnitude bounds run as one split-precision GEMM with
 # (cout, parity) rows (csrc/kernels/deconv_h2.h) instead of the vector-ALU kernel -- fp32-equivalent, families "auto" / "h2" only.

@@ -959,21 +959,23 @@ int mh_conv3d_k3s2_pack_f32(const float* w, int Cin, int Cout, float* packed, vo
                        reinterpret_cast<_Float16*>(packed), tail);
     return launched("conv3d_k3s2_pack");
 }
-int mh_conv3d_k3s2_f32(const mh_tensor5* in_, const float* packed, const float* bias, const mh_tensor5* out_, float* workspace, float* stats, void* stream) {
-    if (!dense_ok(in_) || !dense_ok(out_) || !packed || !workspace) return fail(MH_ERR_ARG, "conv3d_k3s2: bad argument");
+int mh_conv3d_k3s2_f32(const mh_tensor5* in_, const float* packed, const float* bias, const mh_tensor5* out_, float* workspace, float* stats, int fused, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_) || !packed || (!workspace && !fused)) return fail(MH_ERR_ARG, "conv3d_k3s2: bad argument");
+    if (fused && in_->C > S2_CIN_MAX) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: the fused form keeps the records of at most %d input channels", S2_CIN_MAX);
     const Tensor in = from_c(*in_), out = from_c(*out_);
     if (in.N != out.N || out.D * 2 != in.D || out.H * 2 != in.H || out.W * 2 != in.W) return fail(MH_ERR_ARG, "conv3d_k3s2: the output must be half the (even) input extents");
     if (!mh_conv3d_k3s2_accepts(in.C, out.C, in.D, in.H, in.W))
         return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: needs Cin %% 16 == 0, Cout %% 32 == 0, even extents (got %d -> %d, %dx%dx%d)", in.C, out.C, in.D, in.H, in.W);
     if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3s2: the input must carry records with magnitude bounds (the split-precision kernels scale their input by them)");
-    if (!aligned(in.nrm, 16) || !aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed, 16) || !aligned(workspace, 16))
+    if (!aligned(in.nrm, 16) || !aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed, 16) || (!fused && !aligned(workspace, 16)))
         return fail(MH_ERR_ARG, "conv3d_k3s2: 16-byte aligned records, output, weights and workspace required");
+    if ((long long)in.D * in.H * in.W * 64 >= 0x80000000LL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: 16 input channel planes must stay below 2 GB");
     const long long nz = (long long)in.N * (in.C / 8);
-    if (nz > 65535) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: N * Cin / 8 must stay below 65536 per launch");
+    if (!fused && nz > 65535) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: N * Cin / 8 must stay below 65536 per launch");
     hipStream_t s = (hipStream_t)stream;
-    uint4* xs = reinterpret_cast<uint4*>(workspace);
-    int* expo = reinterpret_cast<int*>(workspace + (long long)in.N * in.C * in.D * in.H * in.W);
-    hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(blocks_for((long long)in.H * in.W), (unsigned)in.D, (unsigned)nz), dim3(256), 0, s, in, xs, expo);
+    uint4* xs = fused ? nullptr : reinterpret_cast<uint4*>(workspace);
+    int* expo = fused ? nullptr : reinterpret_cast<int*>(workspace + (long long)in.N * in.C * in.D * in.H * in.W);
+    if (!fused) hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(blocks_for((long long)in.H * in.W), (unsigned)in.D, (unsigned)nz), dim3(256), 0, s, in, xs, expo);
     const S2Tile t = s2_tile(out.H, out.W);
     const int tiles = t.tyn * t.txn, zc = s2_zchunk(out.D, tiles);
     const unsigned nblk = (unsigned)(tiles * cdiv(out.D, zc));
@@ -983,12 +985,13 @@ int mh_conv3d_k3s2_f32(const mh_tensor5* in_, const float* packed, const float* 
     const uint4* wq = reinterpret_cast<const uint4*>(packed);
     const float* tail = packed + (mh_conv3d_k3s2_packed_floats(in.C, out.C) - H2_TAIL);
     const dim3 g((unsigned)total), bl(S2_NT);
-#define MH_S2_LAUNCH(NCG_)                                                                                                                              \
+#define MH_S2_LAUNCH(NCG_, F_)                                                                                                                          \
     {                                                                                                                                                   \
-        if (stats) hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, true>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);      \
-        else hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, false>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);            \
+        if (stats) hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, true, F_>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);  \
+        else hipLaunchKernelGGL((conv3d_k3s2_h2_kernel<NCG_, false, F_>), g, bl, 0, s, in, xs, expo, wq, tail, bias, out, stats, t.tr, t.tc, t.txn, t.tyn, zc, nblk);        \
     }
-    if (ncgw == 2) MH_S2_LAUNCH(2) else MH_S2_LAUNCH(1)
+    if (fused) { if (ncgw == 2) MH_S2_LAUNCH(2, true) else MH_S2_LAUNCH(1, true) }
+    else { if (ncgw == 2) MH_S2_LAUNCH(2, false) else MH_S2_LAUNCH(1, false) }
 #undef MH_S2_LAUNCH
     return launched("conv3d_k3s2");
 }

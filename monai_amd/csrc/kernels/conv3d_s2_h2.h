@@ -108,8 +108,9 @@ conv3d_s2_split_kernel(Tensor in, uint4* __restrict__ ws, int* __restrict__ expo
 // ---------------------------------------------------------------------------------------------------------------------------------------------------------
 // (2) the matrix instructions of one step: NY x NX in-plane taps of the staged phase region, NZ z-taps each (NZ == 2: slot 0 = k 0 -> the NEXT output plane's
 // accumulators, slot 1 = k 2 -> this plane's), NCG groups of 32 output channels.  A's two pieces are read once per in-plane tap and meet 2 NZ NCG weight operands.
-template <int NZ, int NY, int NX, int NCG>
-__device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const uint4* __restrict__ wb, int abase, int bbase, int RS, int RV, f32x16 (&acc)[2][NCG]) {
+struct S2NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
+template <int NZ, int NY, int NX, int NCG, bool HEAVY, class SIDE>
+__device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const uint4* __restrict__ wb, int abase, int bbase, int RS, int RV, f32x16 (&acc)[2][NCG], SIDE side) {
     constexpr int CW = 32 * NCG, NG = NZ * NY * NX;           // a GROUP = one (in-plane tap, z tap): 3 NCG matrix instructions
     // a wave issues in order: an operand read right in front of its use costs the LDS latency every time (conv3d_h2.h).  Group G + 1's operands are therefore
     // fetched into a second register set while group G multiplies, and the scheduler deals the reads out over the gaps between the matrix instructions.
@@ -136,6 +137,7 @@ __device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const u
 #pragma unroll
     for (int G = 0; G < NG; ++G) {
         if (G + 1 < NG) fetch(G + 1);
+        side(G, NG);                                          // the fused form's staging work of the NEXT step (vector ALU, LDS writes, loads): it rides between this group's matrix instructions
         const int t2 = G / NZ, sz = G % NZ;
         const int zset = NZ == 1 ? 0 : (sz == 0 ? 1 : 0);     // NZ == 2: slot 0 = k 0 -> the NEXT output plane's accumulators, slot 1 = k 2 -> this plane's
         const f16x8 ah = __builtin_bit_cast(f16x8, aq[t2 & 1][0]), al = __builtin_bit_cast(f16x8, aq[t2 & 1][1]);
@@ -150,15 +152,24 @@ __device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const u
         for (int k = 0; k < 3 * NCG; ++k) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NCG == 1 ? 2 : 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, HEAVY ? (NCG == 1 ? 16 : 8) : 2, 0);
+            if (HEAVY) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// in: only its extents (C, D, H, W of the FINE input) are used; xs = the split kernel's workspace, expo its exponents.
+// FUSED == false: `in` gives the extents only; xs = the split kernel's workspace, expo its exponents.  FUSED == true (round 5, layers whose split pass costs as much as
+// their GEMM): there is no split pass -- the staging reads the fp32 input itself (a (cell, channel quad) task = four dword loads of the phase's fine voxel), activates
+// under the records (LDS, pre-multiplied by the sample's power of two), splits and writes the two pieces of the NEXT step's region while THIS step's matrix
+// instructions run (s2_step_mm's side work); the loads of the step after next are issued into the same registers right behind the conversion, so they have more than a
+// whole step to arrive.  xs / expo are unused.
 // wp [cout group][chunk][27 taps in phase order][piece][k group][32 NCG couts] uint4 + tail (conv3d_k3s2_h2_pack_kernel).
-template <int NCG, bool STATS>
+constexpr int S2_CIN_MAX = 512;                            // FUSED: input channels whose records sit in LDS
+template <int NCG, bool STATS, bool FUSED>
 __global__ void __launch_bounds__(S2_NT, 1)
 conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __restrict__ expo, const uint4* __restrict__ wp, const float* __restrict__ wtail,
                       const float* __restrict__ bias, Tensor out, float* __restrict__ stats, int TR, int TC, int txn, int tyn, int zchunk, unsigned nblk) {
@@ -168,6 +179,8 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     __shared__ uint4 xbuf[2 * S2_XB];
     __shared__ uint4 wbuf[2 * WB];
     __shared__ float red[(S2_NT / 64) * 32 * 3];
+    __shared__ float nrm_s[FUSED ? 3 * S2_CIN_MAX : 4];
+    __shared__ unsigned bound_s[S2_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int Cin = in.C, Cout = out.C, Do = out.D, Ho = out.H, Wo = out.W;
@@ -185,38 +198,104 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     const int ox0 = (tile % txn) * TC, oy0 = (tile / txn) * TR;
     const int zs = zc * zchunk, ze = min(zs + zchunk, Do);
 
-    // ---- copies of this thread: operand cells (their LDS index is the task index) and weight cells
+    // ---- FUSED: records -> LDS, the sample's input scale 2^e_in from their bounds (conv3d_h2.h)
+    int e_fused = 0;
+    bool poisoned_fused = false;
+    if (FUSED) {
+        unsigned mb = 0u;
+        for (int c = tid; c < Cin; c += S2_NT) {
+            const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * c);
+            nrm_s[3 * c] = a.x; nrm_s[3 * c + 1] = a.y; nrm_s[3 * c + 2] = a.z;
+            const unsigned bb = abs_bits(a.w);
+            mb = max(mb, bb == 0u ? 0x7fc00000u : bb);       // no bound given counts as non-finite
+        }
+        mb = wave_umax(mb);
+        if (lane == 0) bound_s[wave] = mb;
+        __syncthreads();
+        mb = bound_s[0];
+#pragma unroll
+        for (int w = 1; w < S2_NT / 64; ++w) mb = max(mb, bound_s[w]);
+        poisoned_fused = mb >= 0x7f800000u;
+        e_fused = poisoned_fused ? 0 : min(max(15 - ((int)(mb >> 23) - 126), -100), 100);
+        const float p_ = __uint_as_float((unsigned)(e_fused + 127) << 23);
+        for (int c = tid; c < Cin; c += S2_NT) { nrm_s[3 * c] *= p_; nrm_s[3 * c + 1] *= p_; }      // each thread rescales the records it wrote
+    }
+
+    // ---- copies of this thread: operand cells (split form: their LDS index is the task index; fused form: (cell, channel quad) tasks) and weight cells
     unsigned xoff[S2_XSLOTS];
+    int xcell[S2_XSLOTS], xquad[S2_XSLOTS];          // FUSED: destination in 8-byte units inside the high piece of a staged region; channel quad (or -1: no task)
+    const int Wf = in.W;
+    const long long HWf = (long long)in.H * in.W, DHWf = (long long)in.D * HWf;
 #pragma unroll
     for (int s = 0; s < S2_XSLOTS; ++s) {
-        const int t = tid + S2_NT * s;
-        const int pk = t / RV, v = t - pk * RV;
+        // fused form: a thread without a task repeats the last task (the same loads, the same values into the same cell): the staging work has no branch
+        const int t = FUSED ? min(tid + S2_NT * s, 4 * RV - 1) : tid + S2_NT * s;
+        const int pk = t / RV, v = t - pk * RV;             // split form: pk = piece * 2 + k group; fused form: pk = channel quad of the step's 16 channels
         const int ry = v / RS, rx = v - ry * RS;
         const int gy = oy0 - 1 + ry, gx = ox0 - 1 + rx;
         const bool ok = t < 4 * RV && gy >= 0 && gy < Ho && gx >= 0 && gx < Wo;
-        xoff[s] = ok ? 16u * (unsigned)((long long)pk * ovol + (long long)gy * Wo + gx) : S2_DROP;
+        if (FUSED) {
+            xoff[s] = ok ? 4u * (unsigned)((long long)(4 * pk) * DHWf + (long long)(2 * gy) * Wf + 2 * gx) : S2_DROP;
+            xcell[s] = (((pk >> 1) * RV + v) * 2 + (pk & 1));
+            xquad[s] = pk;
+        } else {
+            xoff[s] = ok ? 16u * (unsigned)((long long)pk * ovol + (long long)gy * Wo + gx) : S2_DROP;
+            xcell[s] = 0; xquad[s] = 0;
+        }
     }
-    const uint4* xsn = xs + (long long)n * nch * 32 * ovol;
+    const uint4* xsn = FUSED ? nullptr : xs + (long long)n * nch * 32 * ovol;
     const long long xrest = (long long)(in.N - n) * nch * 32 * ovol * 16;              // bytes from this sample's first cell to the end of the workspace
+    const float* fsrc = in.data + (long long)n * in.n_stride;
+    const long long frest = (long long)(in.N - n) * in.n_stride * 4;
     const uint4* wcg = wp + (long long)cg * nch * 27 * 4 * CW;
-    u32x4 xreg[S2_XSLOTS], wreg[WSLOTS];
-    auto load_step = [&](int it, int ph, int ch) {
-        const long long xo_ = ((long long)(ch * 8 + ph) * 4 * ovol + (long long)it * HWo) * 16;
-        const long long left_ = xrest - xo_;
-        const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xsn) + xo_ / 16, 0, (int)(left_ < 0x7fffffffLL ? left_ : 0x7fffffffLL), 0x00020000);
+    u32x4 xreg[FUSED ? 1 : S2_XSLOTS], wreg[WSLOTS];
+    float xraw[FUSED ? S2_XSLOTS : 1][4];
+    auto load_x = [&](int it, int ph, int ch) {
+        if (FUSED) {
+            const long long fo_ = (long long)(16 * ch) * DHWf + (long long)(2 * it + (ph >> 2)) * HWf + (long long)((ph >> 1) & 1) * Wf + (ph & 1);
+            const long long left_ = frest - fo_ * 4;
+            const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(fsrc) + fo_, 0, (int)(left_ < 0x7fffffffLL ? left_ : 0x7fffffffLL), 0x00020000);
 #pragma unroll
-        for (int s = 0; s < S2_XSLOTS; ++s) xreg[s] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[s], 0, 0);
+            for (int s = 0; s < S2_XSLOTS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xraw[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, xoff[s], (unsigned)(i * DHWf * 4), 0));
+        } else {
+            const long long xo_ = ((long long)(ch * 8 + ph) * 4 * ovol + (long long)it * HWo) * 16;
+            const long long left_ = xrest - xo_;
+            const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xsn) + xo_ / 16, 0, (int)(left_ < 0x7fffffffLL ? left_ : 0x7fffffffLL), 0x00020000);
+#pragma unroll
+            for (int s = 0; s < S2_XSLOTS; ++s) xreg[s] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[s], 0, 0);
+        }
+    };
+    auto load_w = [&](int ph, int ch) {
         const int nt_ = s2_ntaps(ph);
         const auto wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wcg) + ((long long)ch * 27 + s2_tap_offset(ph)) * 4 * CW, 0, nt_ * 4 * CW * 16, 0x00020000);
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) wreg[s] = __builtin_amdgcn_raw_buffer_load_b128(wr, 16u * (unsigned)(tid + S2_NT * s), 0, 0);
     };
-    auto store_step = [&](int bufi) {
+    auto store_x = [&](int bufi) {                          // split form: copies
         u32x4* xd = reinterpret_cast<u32x4*>(xbuf + bufi * S2_XB);
-        u32x4* wd = reinterpret_cast<u32x4*>(wbuf + bufi * WB);
 #pragma unroll
         for (int s = 0; s < S2_XSLOTS; ++s)
-            if (tid + S2_NT * s < S2_XB) xd[tid + S2_NT * s] = xreg[s];
+            if (tid + S2_NT * s < S2_XB) xd[tid + S2_NT * s] = xreg[FUSED ? 0 : s];
+    };
+    auto convert_slot = [&](int s, int bufi, int ch) {      // fused form: activate + scale + split slot s of the raw values (channels 16 ch + 4 quad .. + 3) -> 8 bytes of each piece
+        u32x2* xh = reinterpret_cast<u32x2*>(xbuf + bufi * S2_XB);
+        _Float16 h_[4], l_[4];
+        const bool keep = xoff[s] != S2_DROP;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * ch + 4 * xquad[s] + i;
+            const float ya = act(xraw[FUSED ? s : 0][i], nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]);
+            const float y = keep ? ya : 0.0f;                // zero padding is zero AFTER the activation (a select, not a branch)
+            h2_split(y, h_[i], l_[i]);
+        }
+        const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
+        xh[xcell[s]] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+        xh[xcell[s] + 4 * RV] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+    };
+    auto store_w = [&](int bufi) {
+        u32x4* wd = reinterpret_cast<u32x4*>(wbuf + bufi * WB);
 #pragma unroll
         for (int s = 0; s < WSLOTS; ++s) wd[tid + S2_NT * s] = wreg[s];
     };
@@ -231,7 +310,7 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     // ---- epilogue geometry: register 4 j + i of an accumulator = M index 32 wave + 8 j + 4 kg + i -> four consecutive columns of one row
     float inv_a, inv_b;
     {
-        const int ev = expo[n];
+        const int ev = FUSED ? (poisoned_fused ? S2_POISON : e_fused) : expo[n];
         const bool poisoned = ev == S2_POISON;
         const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - (poisoned ? 0 : ev);
         const int t1_ = t_ / 2, t2_ = t_ - t1_;
@@ -269,28 +348,67 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
 
     // ---- the march: iteration `it` = coarse plane index; a chunk that does not start at 0 first runs the odd-z phases of plane zs - 1 (their k 0 taps belong to zs)
     int it = zs > 0 ? zs - 1 : zs, ph = zs > 0 ? 4 : 0, ch = 0, buf = 0;
-    load_step(it, ph, ch);
-    store_step(0);
+    // the step after (it, ph, ch); beyond the chunk's last step it stays where it is: the fused form's side work then repeats the last step's loads and converts
+    // them into the buffer nobody reads any more -- no branch inside the matrix phase
+    auto advance = [&](int& i_, int& p_, int& c_) {
+        int i2 = i_, p2 = p_, c2 = c_ + 1;
+        if (c2 == nch) { c2 = 0; ++p2; }
+        if (p2 == 8) { p2 = 0; ++i2; }
+        const bool ok_ = i2 < ze;
+        i_ = ok_ ? i2 : i_; p_ = ok_ ? p2 : p_; c_ = ok_ ? c2 : c_;
+        return ok_;
+    };
+    load_x(it, ph, ch);
+    load_w(ph, ch);
+    if (FUSED) {
+        __syncthreads();                                      // the rescaled records are complete
+#pragma unroll
+        for (int s = 0; s < S2_XSLOTS; ++s) convert_slot(s, 0, ch);
+        int i1 = it, p1 = ph, c1 = ch;
+        advance(i1, p1, c1);
+        load_x(i1, p1, c1);                                   // the raw values of step 1 wait in the registers
+    } else {
+        store_x(0);
+    }
+    store_w(0);
     __syncthreads();
     while (true) {
-        int nit = it, nph = ph, nchk = ch + 1;
-        if (nchk == nch) { nchk = 0; ++nph; }
-        if (nph == 8) { nph = 0; ++nit; }
-        const bool has_next = nit < ze;
-        if (has_next) load_step(nit, nph, nchk);
+        int nit = it, nph = ph, nchk = ch;
+        const bool has_next = advance(nit, nph, nchk);
+        int n2it = nit, n2ph = nph, n2ch = nchk;
+        advance(n2it, n2ph, n2ch);
+        if (has_next) {
+            if (!FUSED) load_x(nit, nph, nchk);
+            load_w(nph, nchk);
+        }
         const uint4* xb = xbuf + buf * S2_XB;
         const uint4* wb = wbuf + buf * WB;
+        // FUSED: the next step's raw values (in the registers since the step before) are converted into the other buffer between this step's matrix instructions --
+        // nobody reads that buffer before the barrier below -- and the loads of the step after next follow into the same registers.  Chunk k of that work rides in
+        // group min(k, groups - 1) of the step: slots 0 .. 2, then the loads.
+        auto side = [&](int G, int NG) {
+            if (!FUSED) return;
+#pragma unroll
+            for (int k = 0; k <= S2_XSLOTS; ++k) {
+                if ((k < NG - 1 ? k : NG - 1) != G) continue;
+                if (k < S2_XSLOTS) convert_slot(k, buf ^ 1, nchk);
+                else load_x(n2it, n2ph, n2ch);
+            }
+        };
         switch (ph) {
-            case 0: s2_step_mm<1, 1, 1, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 1: s2_step_mm<1, 1, 2, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 2: s2_step_mm<1, 2, 1, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 3: s2_step_mm<1, 2, 2, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 4: s2_step_mm<2, 1, 1, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 5: s2_step_mm<2, 1, 2, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            case 6: s2_step_mm<2, 2, 1, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
-            default: s2_step_mm<2, 2, 2, NCG>(xb, wb, abase, bbase, RS, RV, acc); break;
+            case 0: s2_step_mm<1, 1, 1, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 1: s2_step_mm<1, 1, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 2: s2_step_mm<1, 2, 1, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 3: s2_step_mm<1, 2, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 4: s2_step_mm<2, 1, 1, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 5: s2_step_mm<2, 1, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            case 6: s2_step_mm<2, 2, 1, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
+            default: s2_step_mm<2, 2, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
         }
-        if (has_next) store_step(buf ^ 1);
+        if (has_next) {
+            if (!FUSED) store_x(buf ^ 1);
+            store_w(buf ^ 1);
+        }
         if (ph == 7 && ch == nch - 1) {                       // plane `it` is complete (unless it is the run-in plane zs - 1)
             if (it >= zs) {
                 const unsigned so_ = (unsigned)it * (unsigned)(HWo * 4);

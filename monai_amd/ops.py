@@ -948,16 +948,30 @@ def conv3d_k3s2_stat_tiles(d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv3d_k3s2_stat_tiles", int(d), int(h), int(w))
 
 
-def conv3d_k3s2(x, x_nrm, packed, bias, out, stats=None, workspace=None):
+def conv3d_k3s2_fused(cin: int, cout: int) -> bool:
+    """should the stride-2 kernel convert its input inside the GEMM's staging (no split pass, no workspace)?  `monai_amd.config.strided_h2_fused()`: "auto" = layers
+    with at most two groups of 64 output channels (the conversion is repeated per group) and at most 512 input channels (their records sit in LDS)"""
+    from . import config
+
+    mode = config.strided_h2_fused()
+    if cin > 512 or mode == "0":
+        return False
+    return mode == "1" or cout <= 128
+
+
+def conv3d_k3s2(x, x_nrm, packed, bias, out, stats=None, workspace=None, fused: Optional[bool] = None):
     """out = conv3x3x3(act(x), stride 2, padding 1) + bias on the fp16 matrix cores (split precision); x_nrm: records WITH magnitude bounds.
-    stats ([N * Cout * conv3d_k3s2_stat_tiles(*x.shape[2:]) * 3] floats): the InstanceNorm statistics of `out`.  workspace: scratch of
-    `conv3d_k3s2_workspace_floats` floats (allocated here when not given)."""
+    stats ([N * Cout * conv3d_k3s2_stat_tiles(*x.shape[2:]) * 3] floats): the InstanceNorm statistics of `out`.  fused (default `conv3d_k3s2_fused`): convert inside the
+    GEMM's staging; otherwise a phase-split pass into `workspace` (scratch of `conv3d_k3s2_workspace_floats` floats, allocated here when not given) comes first."""
     _lib.require_device(x, x_nrm, packed, bias, out, stats, workspace)
-    need = conv3d_k3s2_workspace_floats(*x.shape)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+    if fused is None:
+        fused = conv3d_k3s2_fused(int(x.shape[1]), int(out.shape[1]))
+    if not fused:
+        need = conv3d_k3s2_workspace_floats(*x.shape)
+        if workspace is None or workspace.numel() < need:
+            workspace = torch.empty(need, dtype=torch.float32, device=x.device)
     xi, xo = _lib.tensor5(x, x_nrm), _lib.tensor5(out)
-    _lib.lib().call("mh_conv3d_k3s2_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias), C.byref(xo), _lib.ptr(workspace), _lib.ptr(stats), _s(x))
+    _lib.lib().call("mh_conv3d_k3s2_f32", C.byref(xi), _lib.ptr(packed), _lib.ptr(bias), C.byref(xo), None if fused else _lib.ptr(workspace), _lib.ptr(stats), int(bool(fused)), _s(x))
     return out
 
 

@@ -360,7 +360,7 @@ def case_deconv_k2s2_h2(device, n, cin, cout, dims, with_bias=True, tol=2e-5):
     return err
 
 
-def case_conv3d_k3s2(device, n, cin, cout, dims, with_bias=True, fused_stats=True, tol=2e-5):
+def case_conv3d_k3s2(device, n, cin, cout, dims, with_bias=True, fused_stats=True, tol=2e-5, fused=None):
     """Conv3d k3 s2 p1 on the fp16 matrix cores in split precision (csrc/kernels/conv3d_s2_h2.h: phase-split pass + GEMM over the 8 parity phases) against ATen in
     float64: ragged tiles, the zero padding at index -1 of every axis, one / two cout groups per workgroup, several z-chunks (run-in plane), and the InstanceNorm
     statistics of the result through the finalize kernel"""
@@ -375,7 +375,17 @@ def case_conv3d_k3s2(device, n, cin, cout, dims, with_bias=True, fused_stats=Tru
     out = torch.full(tuple(exp.shape), float("nan"), device=device)
     tiles = ops.conv3d_k3s2_stat_tiles(*dims)
     stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if fused_stats else None
-    ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), out, stats)
+    if fused is None:          # both forms (phase-split pass + GEMM / conversion inside the GEMM's staging): the same products in the same order -> the same bits
+        other = torch.full(tuple(exp.shape), float("nan"), device=device)
+        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), other, None, fused=True)
+        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), out, stats, fused=False)
+        assert torch.equal(other, out), f"conv3d_k3s2 {cin}->{cout} {dims}: the fused and the split form differ"
+        if stats is not None:
+            st2 = torch.full_like(stats, float("nan"))
+            ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), other, st2, fused=True)
+            assert torch.equal(st2, stats)
+    else:
+        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None if b is None else b.to(device), out, stats, fused=fused)
     got = out.cpu().double()
     err = (got - exp).abs().max().item()
     assert err < tol * max(1.0, exp.abs().max().item()), f"conv3d_k3s2 {cin}->{cout} {dims}: max err {err}"
@@ -405,15 +415,18 @@ def case_conv3d_k3s2_poison_and_scale(device):
         nrm = _with_bounds(x, _rand_nrm(n, cin, gen))
         exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None, stride=2, padding=1)
         out = torch.full(tuple(exp.shape), float("nan"), device=device)
-        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out)
-        assert (out.cpu().double() - exp).abs().max().item() < 2e-5 * exp.abs().max().item(), mag
+        for fused in (False, True):
+            out.fill_(float("nan"))
+            ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out, fused=fused)
+            assert (out.cpu().double() - exp).abs().max().item() < 2e-5 * exp.abs().max().item(), (mag, fused)
     x = torch.randn((n, cin) + dims, generator=gen)
     nrm = _with_bounds(x, _rand_nrm(n, cin, gen))
     nrm[1, 3, 3] = float("inf")
     exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None, stride=2, padding=1)
-    out = torch.zeros(tuple(exp.shape), device=device)
-    ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out)
-    assert torch.isnan(out[1]).all() and (out[0].cpu().double() - exp[0]).abs().max().item() < 2e-5
+    for fused in (False, True):
+        out = torch.zeros(tuple(exp.shape), device=device)
+        ops.conv3d_k3s2(x.to(device), nrm.to(device), packed, None, out, fused=fused)
+        assert torch.isnan(out[1]).all() and (out[0].cpu().double() - exp[0]).abs().max().item() < 2e-5, fused
 
 
 def _conv_err(device, cfg, x, nrm, w, b, exp):

@@ -48,10 +48,11 @@ def main():
         stats = torch.empty((n, cout, tiles, 3), device=dev)
         ws = torch.empty(ops.conv3d_k3s2_workspace_floats(n, cin, edge, edge, edge), device=dev)
         t_old = timed(lambda: ops.conv3d_k3_strided(x, nrm, p0, None, out_a, 2), a.reps)
-        t_new = timed(lambda: ops.conv3d_k3s2(x, nrm, ps, None, out_b, stats, ws), a.reps)
+        t_new = timed(lambda: ops.conv3d_k3s2(x, nrm, ps, None, out_b, stats, ws, fused=False), a.reps)
+        t_fused = timed(lambda: ops.conv3d_k3s2(x, nrm, ps, None, out_b, stats, None, fused=True), a.reps) if cin <= 512 else None
         err = (out_a - out_b).abs().max().item()
         flops = 2.0 * 27 * cin * cout * o ** 3 * n
-        print(json.dumps({"layer": f"{cin}->{cout} @ {edge}^3 -> {o}^3 x {n}", "valu_ms": round(t_old, 3), "s2_ms": round(t_new, 3), "speedup": round(t_old / t_new, 2),
+        print(json.dumps({"layer": f"{cin}->{cout} @ {edge}^3 -> {o}^3 x {n}", "valu_ms": round(t_old, 3), "s2_ms": round(t_new, 3), "s2_fused_ms": None if t_fused is None else round(t_fused, 3), "speedup": round(t_old / t_new, 2),
                           "s2_tflops_fp32eq": round(flops / t_new / 1e9, 1), "stat_tiles": tiles, "max_abs_diff": err}), flush=True)
         del x, out_a, out_b, ws
 
