@@ -26,14 +26,15 @@ namespace mh {
 
 constexpr int S2_NT = 512;                                 // 8 waves, one 32-voxel M block each
 constexpr int S2_RVMAX = 304;                              // cells of a staged phase region: (TR + 1) (TC + 1)
-constexpr int S2_XB = 4 * S2_RVMAX;                        // uint4 per staged region: [piece][k group][cell]
 constexpr int S2_XSLOTS = 3;                               // copies per thread and step: 3 x 512 >= 4 x 304
+constexpr int S2_XB = S2_NT * S2_XSLOTS;                   // uint4 per staged region: [piece][k group][cell] = 4 (TR + 1)(TC + 1) <= 1216, rounded up to one cell per copy slot (no bound check in the copy)
 constexpr unsigned S2_DROP = 0x80000000u;                  // a byte offset beyond every buffer: loads return zero, stores are dropped
 constexpr int S2_POISON = 0x7fffffff;                      // exponent slot of a sample whose bound is non-finite / missing: its whole output is NaN
 
 __host__ __device__ inline int s2_ntaps(int ph) { return (1 + (ph >> 2)) * (1 + ((ph >> 1) & 1)) * (1 + (ph & 1)); }
-__host__ __device__ inline int s2_tap_offset(int ph) {     // prefix sums of s2_ntaps: phases in the order pz * 4 + py * 2 + px
-    return ph == 0 ? 0 : ph == 1 ? 1 : ph == 2 ? 3 : ph == 3 ? 5 : ph == 4 ? 9 : ph == 5 ? 11 : ph == 6 ? 15 : 19;
+__host__ __device__ inline int s2_tap_offset(int ph) {     // prefix sums of s2_ntaps {0, 1, 3, 5, 9, 11, 15, 19}: phases in the order pz * 4 + py * 2 + px; 5-bit fields of one constant (no branch)
+    constexpr unsigned long long tab = 0ull | (1ull << 5) | (3ull << 10) | (5ull << 15) | (9ull << 20) | (11ull << 25) | (15ull << 30) | (19ull << 35);
+    return (int)((tab >> (5 * ph)) & 31ull);
 }
 
 // output tile of a workgroup for an Ho x Wo plane: TC a multiple of 4 (a lane's four consecutive M indices stay in one row), TR TC <= 256, (TR + 1)(TC + 1) <= S2_RVMAX;
@@ -153,10 +154,8 @@ __device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const u
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, NCG == 1 ? 2 : 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, HEAVY ? (NCG == 1 ? 16 : 8) : 2, 0);
-            if (HEAVY) {
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -276,8 +275,7 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     auto store_x = [&](int bufi) {                          // split form: copies
         u32x4* xd = reinterpret_cast<u32x4*>(xbuf + bufi * S2_XB);
 #pragma unroll
-        for (int s = 0; s < S2_XSLOTS; ++s)
-            if (tid + S2_NT * s < S2_XB) xd[tid + S2_NT * s] = xreg[FUSED ? 0 : s];
+        for (int s = 0; s < S2_XSLOTS; ++s) xd[tid + S2_NT * s] = xreg[FUSED ? 0 : s];
     };
     auto convert_slot = [&](int s, int bufi, int ch) {      // fused form: activate + scale + split slot s of the raw values (channels 16 ch + 4 quad .. + 3) -> 8 bytes of each piece
         u32x2* xh = reinterpret_cast<u32x2*>(xbuf + bufi * S2_XB);
@@ -358,41 +356,48 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
         i_ = ok_ ? i2 : i_; p_ = ok_ ? p2 : p_; c_ = ok_ ? c2 : c_;
         return ok_;
     };
+    // Pipeline (both forms): at the start of step s the registers hold the operand cells and tap matrices of step s + 1 (requested during step s - 1).  Between
+    // step s's matrix instructions they go into the other LDS buffer -- nobody reads it before the barrier at the end of the step -- and the requests of step s + 2
+    // follow into the same registers: every load has more than a whole step to arrive, with one register set.
     load_x(it, ph, ch);
     load_w(ph, ch);
     if (FUSED) {
         __syncthreads();                                      // the rescaled records are complete
 #pragma unroll
         for (int s = 0; s < S2_XSLOTS; ++s) convert_slot(s, 0, ch);
-        int i1 = it, p1 = ph, c1 = ch;
-        advance(i1, p1, c1);
-        load_x(i1, p1, c1);                                   // the raw values of step 1 wait in the registers
     } else {
         store_x(0);
     }
     store_w(0);
+    {
+        int i1 = it, p1 = ph, c1 = ch;
+        advance(i1, p1, c1);
+        load_x(i1, p1, c1);
+        load_w(p1, c1);
+    }
     __syncthreads();
     while (true) {
         int nit = it, nph = ph, nchk = ch;
         const bool has_next = advance(nit, nph, nchk);
         int n2it = nit, n2ph = nph, n2ch = nchk;
         advance(n2it, n2ph, n2ch);
-        if (has_next) {
-            if (!FUSED) load_x(nit, nph, nchk);
-            load_w(nph, nchk);
-        }
         const uint4* xb = xbuf + buf * S2_XB;
         const uint4* wb = wbuf + buf * WB;
-        // FUSED: the next step's raw values (in the registers since the step before) are converted into the other buffer between this step's matrix instructions --
-        // nobody reads that buffer before the barrier below -- and the loads of the step after next follow into the same registers.  Chunk k of that work rides in
-        // group min(k, groups - 1) of the step: slots 0 .. 2, then the loads.
+        // chunk k of the staging work rides in group min(k, groups - 1) of the step: operand slots 0 .. 2 (fused form: activate + scale + split; split form: copies),
+        // the operand requests of step s + 2, then the tap matrices and their requests
         auto side = [&](int G, int NG) {
-            if (!FUSED) return;
 #pragma unroll
-            for (int k = 0; k <= S2_XSLOTS; ++k) {
+            for (int k = 0; k <= S2_XSLOTS + 1; ++k) {
                 if ((k < NG - 1 ? k : NG - 1) != G) continue;
-                if (k < S2_XSLOTS) convert_slot(k, buf ^ 1, nchk);
-                else load_x(n2it, n2ph, n2ch);
+                if (k < S2_XSLOTS) {
+                    if (FUSED) convert_slot(k, buf ^ 1, nchk);
+                    else reinterpret_cast<u32x4*>(xbuf + (buf ^ 1) * S2_XB)[tid + S2_NT * k] = xreg[FUSED ? 0 : k];
+                } else if (k == S2_XSLOTS) {
+                    load_x(n2it, n2ph, n2ch);
+                } else {
+                    store_w(buf ^ 1);
+                    load_w(n2ph, n2ch);
+                }
             }
         };
         switch (ph) {
@@ -404,10 +409,6 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
             case 5: s2_step_mm<2, 1, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
             case 6: s2_step_mm<2, 2, 1, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
             default: s2_step_mm<2, 2, 2, NCG, FUSED>(xb, wb, abase, bbase, RS, RV, acc, side); break;
-        }
-        if (has_next) {
-            if (!FUSED) store_x(buf ^ 1);
-            store_w(buf ^ 1);
         }
         if (ph == 7 && ch == nch - 1) {                       // plane `it` is complete (unless it is the run-in plane zs - 1)
             if (it >= zs) {
