@@ -353,7 +353,7 @@ class DynUNet(nn.Module):
             tiles = ops.conv3d_k3s2_stat_tiles(d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device)
             with _prof.span("conv3d_k3s2", flops):
-                fused = ops.conv3d_k3s2_fused(cin, cout)          # conversion inside the GEMM's staging, or a phase-split pass into the workspace first
+                fused = ops.conv3d_k3s2_fused(cin, cout, d * h * w)          # conversion inside the GEMM's staging, or a phase-split pass into the workspace first
                 ops.conv3d_k3s2(x, x_nrm, self._packed_s2(conv), conv.bias, out, stats, None if fused else self._workspace(ops.conv3d_k3s2_workspace_floats(n, cin, d, h, w), x.device), fused)
         else:       # other strides, or so few channels that the matrix tiles would mostly pad: the direct kernel at the true width
             ops.conv3d_k3_strided3(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)

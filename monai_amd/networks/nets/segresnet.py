@@ -182,7 +182,7 @@ class SegResNet(nn.Module):
             tiles = ops.conv3d_k3s2_stat_tiles(d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device)
             with _prof.span("conv3d_k3s2", 2.0 * 27 * cin * cout * sp[0] * sp[1] * sp[2] * n):
-                fused = ops.conv3d_k3s2_fused(cin, cout)          # conversion inside the GEMM's staging, or a phase-split pass into the workspace first
+                fused = ops.conv3d_k3s2_fused(cin, cout, d * h * w)          # conversion inside the GEMM's staging, or a phase-split pass into the workspace first
                 ops.conv3d_k3s2(x, x_nrm, self._packed_s2(conv), conv.bias, out, stats, None if fused else self._workspace(ops.conv3d_k3s2_workspace_floats(n, cin, d, h, w), x.device), fused)
             return out, stats, tiles
         ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, stride)

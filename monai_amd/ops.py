@@ -948,15 +948,17 @@ def conv3d_k3s2_stat_tiles(d: int, h: int, w: int) -> int:
     return _lib.lib().query("mh_conv3d_k3s2_stat_tiles", int(d), int(h), int(w))
 
 
-def conv3d_k3s2_fused(cin: int, cout: int) -> bool:
+def conv3d_k3s2_fused(cin: int, cout: int, voxels: int = 0) -> bool:
     """should the stride-2 kernel convert its input inside the GEMM's staging (no split pass, no workspace)?  `monai_amd.config.strided_h2_fused()`: "auto" = layers
-    with at most two groups of 64 output channels (the conversion is repeated per group) and at most 512 input channels (their records sit in LDS)"""
+    with ONE group of 64 output channels on large volumes (`voxels` = D * H * W of the input >= 80^3) -- measured 5.3 vs 6.1 ms (32 -> 64 @ 96^3 x 64 windows) and 2.25 vs
+    2.61 ms (16 -> 32), but 3.4 vs 2.8 ms where the conversion is repeated for a second group and slower on every smaller plane (profiles/r05_s2_layers_fused.txt);
+    at most 512 input channels (their records sit in LDS)"""
     from . import config
 
     mode = config.strided_h2_fused()
     if cin > 512 or mode == "0":
         return False
-    return mode == "1" or cout <= 128
+    return mode == "1" or (cout <= 64 and voxels >= 80 ** 3)
 
 
 def conv3d_k3s2(x, x_nrm, packed, bias, out, stats=None, workspace=None, fused: Optional[bool] = None):
@@ -965,7 +967,7 @@ def conv3d_k3s2(x, x_nrm, packed, bias, out, stats=None, workspace=None, fused: 
     GEMM's staging; otherwise a phase-split pass into `workspace` (scratch of `conv3d_k3s2_workspace_floats` floats, allocated here when not given) comes first."""
     _lib.require_device(x, x_nrm, packed, bias, out, stats, workspace)
     if fused is None:
-        fused = conv3d_k3s2_fused(int(x.shape[1]), int(out.shape[1]))
+        fused = conv3d_k3s2_fused(int(x.shape[1]), int(out.shape[1]), int(x.shape[2] * x.shape[3] * x.shape[4]))
     if not fused:
         need = conv3d_k3s2_workspace_floats(*x.shape)
         if workspace is None or workspace.numel() < need:
