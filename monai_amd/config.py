@@ -90,6 +90,17 @@ def strided_h2_fused() -> str:
     return "0" if v in ("0", "false", "off", "no") else ("1" if v in ("1", "true", "on", "yes") else "auto")
 
 
+# ---- 3x3x3 convolutions of small volumes on the fp16 matrix cores -------------------------------------------------------------------
+# Levels whose whole volume has at most 256 voxels (the 6^3 level of a 96^3 window) run on the split-precision kernel with one sample's volume as the workgroup's tile
+# (csrc/kernels/conv3d_vol_h2.h) instead of the exact-fp32 matrix tiles.  False (or MONAI_AMD_SMALL_VOLUME_H2=0 while None) keeps the fp32 tiles there.
+SMALL_VOLUME_H2 = None
+
+
+def small_volume_h2() -> bool:
+    v = SMALL_VOLUME_H2 if SMALL_VOLUME_H2 is not None else os.environ.get("MONAI_AMD_SMALL_VOLUME_H2", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")
+
+
 # ---- ConvTranspose3d k2 s2 on the fp16 matrix cores -------------------------------------------------------------------------------
 # The up-sampling transposed convolutions (BasicUNet's lower decoder levels, DynUNet, UNETR) whose input carries magnitude bounds run as one split-precision GEMM with
 # (cout, parity) rows (csrc/kernels/deconv_h2.h) instead of the vector-ALU kernel -- fp32-equivalent, families "auto" / "h2" only.

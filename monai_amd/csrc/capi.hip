@@ -15,6 +15,7 @@
 #include "kernels/upconv_h2.h"
 #include "kernels/conv3d_s2_h2.h"
 #include "kernels/deconv_h2.h"
+#include "kernels/conv3d_vol_h2.h"
 #include "kernels/conv3d_c1.h"
 #include "kernels/dense.h"
 #include "kernels/gaussian.h"
@@ -432,7 +433,14 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // configuration MH_CFG_H2C: MH_CFG_H2's kernel with output channel groups of 16, two z-taps sharing a 32-column matrix instruction (kernels/conv3d_h2.h, C16): layers
 // with 16 output channels (UNETR's full-resolution levels) at 6 instead of 9 matrix instructions per tap; same arithmetic and tolerance class as MH_CFG_H2
 #define MH_CFG_H2C (MH_NUM_CFG + 5)
-#define MH_CFG_LAST MH_CFG_H2C
+// configuration MH_CFG_H2V: the split-precision convolution for SMALL volumes (D H W <= 256 voxels: the 6^3 level of a 96^3 window), one sample's whole volume as the
+// workgroup's M tile (kernels/conv3d_vol_h2.h): where MH_CFG_H2's 16 x 16 regions would be mostly empty; same arithmetic and tolerance class as MH_CFG_H2
+#define MH_CFG_H2V (MH_NUM_CFG + 6)
+#define MH_CFG_LAST MH_CFG_H2V
+static inline bool hv_fits(int D, int H, int W) {
+    const long long vol = (long long)D * H * W, padded = (long long)(D + 2) * (H + 2) * (W + 2);
+    return vol >= 64 && vol <= 256 && padded <= HV_CELLS;
+}
 static inline int c1_chunks(int D) { return D >= 48 ? D / 24 : 1; }
 static inline int c1_zchunk(int D) { return cdiv(D, c1_chunks(D)); }
 static inline int c1_blocks(int D, int H, int W) { return cdiv(W, C1_TX) * cdiv(H, C1_TY) * cdiv(D, c1_zchunk(D)); }
@@ -473,6 +481,7 @@ int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 int mh_conv3d_k3_h2c_config(void) { return MH_CFG_H2C; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
+int mh_conv3d_k3_h2v_config(void) { return MH_CFG_H2V; }
 
 int mh_conv3d_k3_pool_accepts(int cfg, int Cin, int Cout, int D, int H, int W) {
     if (cfg != MH_CFG_H2 || D < 2 || H < 2 || W < 2 || D % 2 || H % 2 || W % 4) return 0;
@@ -486,6 +495,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0;
     if (cfg == MH_CFG_H2C) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= 16 && Cout % 16 == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
+    if (cfg == MH_CFG_H2V) return Cin >= 16 && Cin % 16 == 0 && Cin <= HV_CIN_MAX && Cout >= 32 && Cout % 32 == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -523,6 +533,9 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && Cout == 16 && mh_conv3d_k3_accepts(MH_CFG_H2C, Cin, Cout) && W % 4 == 0 && H >= 8 && W >= 8 && h2_fits(D, H, W)
         && knob_int("MONAI_AMD_H2C", 1) != 0)
         best = MH_CFG_H2C;
+    // small volumes (the 6^3 level of a 96^3 window) that the z-marching kernel's 16 x 16 regions would leave mostly empty: one sample's whole volume as the M tile
+    if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && best != MH_CFG_H2 && best != MH_CFG_H2C && mh_conv3d_k3_accepts(MH_CFG_H2V, Cin, Cout) && hv_fits(D, H, W))
+        best = MH_CFG_H2V;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
     if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
         best = MH_CFG_C1;
@@ -534,6 +547,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2) return (int64_t)(Cin / H2_KC) * cdiv(Cout, H2_CN) * H2_WB * 4 + H2_TAIL;   // padded chunk slabs of two fp16 pieces + {1 / scale, scale}
     if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
+    if (cfg == MH_CFG_H2V) return (int64_t)Cout * Cin * 27 + H2_TAIL;                             // two fp16 pieces per weight + {1 / scale, scale}
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -568,6 +582,14 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
                            reinterpret_cast<_Float16*>(packed), tail);
         return launched("conv3d_k3_h2_pack");
     }
+    if (cfg == MH_CFG_H2V) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the small-volume split kernel needs Cin %% 16 == 0 (<= 512), Cout %% 32 == 0");
+        float* tail = packed + (mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL);
+        hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
+        hipLaunchKernelGGL(conv3d_k3_vol_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, Cout % 64 == 0 ? 2 : 1,
+                           reinterpret_cast<_Float16*>(packed), tail);
+        return launched("conv3d_k3_vol_h2_pack");
+    }
     if (cfg == MH_CFG_C1) {          // [Cin = 1][27][Cout]: the direct kernel's layout
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the one-channel kernel needs Cin == 1, Cout %% 8 == 0");
         hipLaunchKernelGGL(conv3d_k3_pack_kernel, dim3(blocks_for(27LL * Cout)), dim3(256), 0, (hipStream_t)stream, w, 1, 1, Cout, Cout, Cout, packed);
@@ -585,6 +607,7 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_WINO2D) return wino2d_blocks(D, H, W);
     if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) return h2_blocks(D, H, W);
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
+    if (cfg == MH_CFG_H2V) return 1;          // the workgroup holds the sample's whole volume
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -655,6 +678,28 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         else hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         return launched("conv3d_k3_c1");
+    }
+    if (cfg == MH_CFG_H2V) {
+        if (accumulate || pool) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: the small-volume split kernel has no accumulating / pooling form");
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || !hv_fits(in.D, in.H, in.W))
+            return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs Cin %% 16 == 0 (<= 512), Cout %% 32 == 0, 64 <= D*H*W <= 256, (D+2)(H+2)(W+2) <= 512 (got %d -> %d, %dx%dx%d)",
+                        in.C, out.C, in.D, in.H, in.W);
+        if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs input records with magnitude bounds");
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs 16-byte aligned output and weights");
+        const int ncgw = out.C % 64 == 0 ? 2 : 1;
+        const long long total = (long long)(out.C / (32 * ncgw)) * out.N;
+        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
+        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
+        const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
+        const dim3 grid((unsigned)total);
+        if (ncgw == 2) {
+            if (stats) hipLaunchKernelGGL((conv3d_k3_vol_h2_kernel<2, true>), grid, dim3(HV_NT), 0, s, in, wq, tail, bias, out, stats);
+            else hipLaunchKernelGGL((conv3d_k3_vol_h2_kernel<2, false>), grid, dim3(HV_NT), 0, s, in, wq, tail, bias, out, stats);
+        } else {
+            if (stats) hipLaunchKernelGGL((conv3d_k3_vol_h2_kernel<1, true>), grid, dim3(HV_NT), 0, s, in, wq, tail, bias, out, stats);
+            else hipLaunchKernelGGL((conv3d_k3_vol_h2_kernel<1, false>), grid, dim3(HV_NT), 0, s, in, wq, tail, bias, out, stats);
+        }
+        return launched("conv3d_k3_vol_h2");
     }
     if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) {
         const bool c16 = cfg == MH_CFG_H2C;
@@ -933,7 +978,8 @@ static inline int s2_zchunk(int Do, int tiles) {          // a pure function of 
 int mh_conv3d_k3s2_accepts(int Cin, int Cout, int D, int H, int W) {
     if (!(Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0 && D >= 2 && H >= 2 && W >= 2) || (D & 1) || (H & 1) || (W & 1)) return 0;
     const long long ovol = (long long)(D / 2) * (H / 2) * (W / 2);
-    return ovol * 64 * 4 < 0x80000000LL && D <= 65535;
+    // 32-bit byte offsets: 64 output planes of a workgroup, 16 input channel planes of a step (fused form), 4 piece volumes of a phase (split form)
+    return ovol * 64 * 4 < 0x80000000LL && (long long)D * H * W * 64 < 0x80000000LL && D <= 65535;
 }
 int64_t mh_conv3d_k3s2_packed_floats(int Cin, int Cout) {
     if (!(Cin >= 16 && Cin % 16 == 0 && Cout >= 32 && Cout % 32 == 0)) return fail(MH_ERR_ARG, "conv3d_k3s2: needs Cin %% 16 == 0, Cout %% 32 == 0");
@@ -969,13 +1015,21 @@ int mh_conv3d_k3s2_f32(const mh_tensor5* in_, const float* packed, const float* 
     if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3s2: the input must carry records with magnitude bounds (the split-precision kernels scale their input by them)");
     if (!aligned(in.nrm, 16) || !aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed, 16) || (!fused && !aligned(workspace, 16)))
         return fail(MH_ERR_ARG, "conv3d_k3s2: 16-byte aligned records, output, weights and workspace required");
-    if ((long long)in.D * in.H * in.W * 64 >= 0x80000000LL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: 16 input channel planes must stay below 2 GB");
-    const long long nz = (long long)in.N * (in.C / 8);
-    if (!fused && nz > 65535) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: N * Cin / 8 must stay below 65536 per launch");
     hipStream_t s = (hipStream_t)stream;
     uint4* xs = fused ? nullptr : reinterpret_cast<uint4*>(workspace);
     int* expo = fused ? nullptr : reinterpret_cast<int*>(workspace + (long long)in.N * in.C * in.D * in.H * in.W);
-    if (!fused) hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(blocks_for((long long)in.H * in.W), (unsigned)in.D, (unsigned)nz), dim3(256), 0, s, in, xs, expo);
+    if (!fused) {       // the split pass in sample ranges whose (sample, channel group) count fits the grid's z extent
+        const int per = in.C / 8, nmax = 65535 / per;
+        if (nmax < 1) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3s2: more than 524280 input channels");
+        const long long ws_n = (long long)in.C * in.D * in.H * in.W / 4;          // uint4 per sample
+        for (int n0 = 0; n0 < in.N; n0 += nmax) {
+            Tensor part = in;
+            part.N = in.N - n0 < nmax ? in.N - n0 : nmax;
+            part.data = in.data + (long long)n0 * in.n_stride;
+            part.nrm = in.nrm + (long long)n0 * in.nrm_n_stride;
+            hipLaunchKernelGGL(conv3d_s2_split_kernel, dim3(blocks_for((long long)in.H * in.W), (unsigned)in.D, (unsigned)(part.N * per)), dim3(256), 0, s, part, xs + n0 * ws_n, expo + n0);
+        }
+    }
     const S2Tile t = s2_tile(out.H, out.W);
     const int tiles = t.tyn * t.txn, zc = s2_zchunk(out.D, tiles);
     const unsigned nblk = (unsigned)(tiles * cdiv(out.D, zc));

@@ -296,7 +296,10 @@ def conv3d_k3_select(cin: int, cout: int, d: int, h: int, w: int, bounded: bool 
     split-precision configuration be returned.  `algo`: MH_ALGO_* family, default `monai_amd.config.conv_algo()`."""
     from . import config
 
-    return _lib.lib().query("mh_conv3d_k3_select", config.conv_algo() if algo is None else int(algo), int(bool(bounded)), cin, cout, d, h, w)
+    cfg = _lib.lib().query("mh_conv3d_k3_select", config.conv_algo() if algo is None else int(algo), int(bool(bounded)), cin, cout, d, h, w)
+    if not config.small_volume_h2() and cfg == _lib.lib().query("mh_conv3d_k3_h2v_config"):      # host-side switch (measurements): what the selector returned before the small-volume kernel existed
+        cfg = _lib.lib().query("mh_conv3d_k3_select", config.CONV_ALGOS["fp32"], int(bool(bounded)), cin, cout, d, h, w)
+    return cfg
 
 
 def conv3d_k3_num_configs() -> int:
@@ -320,6 +323,12 @@ def conv3d_k3_c1_config() -> int:
     """Id of the one-input-channel configuration (first layer of the networks: packed fp32 vector arithmetic, write-bound, exact fp32);
     outside 1 .. conv3d_k3_num_configs()."""
     return _lib.lib().query("mh_conv3d_k3_c1_config")
+
+
+def conv3d_k3_h2v_config() -> int:
+    """Id of the split-precision configuration for small volumes (one sample's whole D x H x W <= 256 voxels as the workgroup's tile: the 6^3 level of a 96^3 window);
+    same tolerance class as `conv3d_k3_h2_config`."""
+    return _lib.lib().query("mh_conv3d_k3_h2v_config")
 
 
 def conv3d_k3_accepts(cfg: int, cin: int, cout: int) -> bool:

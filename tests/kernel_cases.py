@@ -318,6 +318,54 @@ def case_upconv_k4s2(device, n, cup, cout, ldims, with_bias=True, fused_stats=Tr
     return err
 
 
+def case_conv3d_k3_small_volume(device, n, cin, cout, dims, with_bias=True, fused_stats=True, tol=2e-5):
+    """Conv3d k3 p1 of a SMALL volume (D H W <= 256) with the sample's whole volume as the workgroup's tile (csrc/kernels/conv3d_vol_h2.h, mh_conv3d_k3_h2v_config) against
+    ATen in float64: volumes that do not fill the 256 rows, odd extents (scalar stores), one / two cout groups per workgroup, several channel chunks; statistics through
+    the finalize kernel; what mh_conv3d_k3_select says about such shapes; a poisoned sample"""
+    from monai_amd import config
+
+    gen = torch.Generator().manual_seed(700 + cin + cout + dims[0] + 7 * dims[2])
+    x = torch.randn((n, cin) + tuple(dims), generator=gen)
+    nrm = _with_bounds(x, _rand_nrm(n, cin, gen), loosen=float(np.sqrt(np.prod(dims))))
+    w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
+    b = torch.randn(cout, generator=gen) * 0.3 if with_bias else None
+    exp = F.conv3d(_act(x.double(), nrm.double()), w.double(), None if b is None else b.double(), padding=1)
+    cfg = ops.conv3d_k3_h2v_config()
+    with config.conv_algo_scope("auto"):
+        sel = ops.conv3d_k3_select(cin, cout, *dims, bounded=True)
+        assert sel == (ops.conv3d_k3_h2_config() if (dims[1] >= 8 and dims[2] >= 8 and dims[2] % 4 == 0 and cin <= 256) else cfg), (sel, dims)
+        assert ops.conv3d_k3_select(cin, cout, *dims, bounded=False) != cfg
+    with config.conv_algo_scope("fp32"):
+        assert ops.conv3d_k3_select(cin, cout, *dims, bounded=True) != cfg
+    packed = ops.conv3d_k3_pack(cfg, w.to(device))
+    out = torch.full(tuple(exp.shape), float("nan"), device=device)
+    tiles = ops.conv3d_k3_stat_tiles(cfg, *dims)
+    assert tiles == 1
+    stats = torch.full((n, cout, tiles, 3), float("nan"), device=device) if fused_stats else None
+    ops.conv3d_k3(cfg, x.to(device), nrm.to(device), packed, None if b is None else b.to(device), out, stats)
+    got = out.cpu().double()
+    err = (got - exp).abs().max().item()
+    assert err < tol * max(1.0, exp.abs().max().item()), f"conv3d_k3 small volume {cin}->{cout} {dims}: max err {err}"
+    if stats is not None:
+        gamma = torch.rand(cout, generator=gen) + 0.5
+        beta = torch.randn(cout, generator=gen) * 0.2
+        nrm_out = torch.full((n, cout, 4), float("nan"), device=device)
+        ops.instnorm_finalize(stats, tiles, n, cout, gamma.to(device), beta.to(device), 1e-5, 0.1, nrm_out)
+        mean = got.mean(dim=(2, 3, 4))
+        var = got.var(dim=(2, 3, 4), unbiased=False)
+        alpha = gamma.double()[None] / torch.sqrt(var + 1e-5)
+        r = nrm_out.cpu().double()
+        assert (r[:, :, 0] - alpha).abs().max().item() < 1e-5 * alpha.abs().max().item() + 1e-6
+        assert (r[:, :, 1] - (beta.double()[None] - mean * alpha)).abs().max().item() < 2e-5
+    if n > 1:
+        bad = nrm.clone()
+        bad[1, 1, 3] = float("inf")
+        out2 = torch.zeros(tuple(exp.shape), device=device)
+        ops.conv3d_k3(cfg, x.to(device), bad.to(device), packed, None, out2, None)
+        assert torch.isnan(out2[1]).all() and torch.isfinite(out2[0]).all()
+    return err
+
+
 def case_deconv_k2s2_h2(device, n, cin, cout, dims, with_bias=True, tol=2e-5):
     """ConvTranspose3d k2 s2 as one split-precision GEMM with (cout, parity) rows, stored pixel-shuffled (csrc/kernels/deconv_h2.h), into a channel slice of a wider
     buffer, against ATen in float64: volumes that end inside a wave, 16- and 32-channel output groups, more input channels than one weight chunk; the magnitude bound

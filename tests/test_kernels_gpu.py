@@ -253,6 +253,16 @@ def test_upcat_composite_transposed_convolution(n, cup, cout, ldims):
     kc.case_upconv_k4s2(DEV, 1, cup, cout, ldims, with_bias=False, fused_stats=False)
 
 
+# (n, cin, cout, dims): 64 of 256 rows / the 6^3 level, two cout groups per workgroup, two chunks / odd extents (scalar stores), three chunks / a shape the z-marching kernel takes / the benchmark networks' 6^3 layers
+SMALL_VOLUME_CASES = [(2, 16, 32, (4, 4, 4)), (2, 32, 64, (6, 6, 6)), (1, 48, 32, (3, 5, 7)), (2, 16, 64, (2, 8, 8)), (64, 256, 256, (6, 6, 6)), (8, 320, 320, (6, 6, 6))]
+@pytest.mark.parametrize("n,cin,cout,dims", SMALL_VOLUME_CASES)
+def test_small_volume_convolution_on_matrix_cores(n, cin, cout, dims):
+    """Conv3d k3 p1 with one sample's whole volume as the workgroup's tile (kernels/conv3d_vol_h2.h) == ATen in float64, statistics, selection and poisoning included"""
+    kc.case_conv3d_k3_small_volume(DEV, n, cin, cout, dims)
+    if n <= 2:
+        kc.case_conv3d_k3_small_volume(DEV, 1, cin, cout, dims, with_bias=False, fused_stats=False)
+
+
 # (n, cin, cout, dims): a volume that ends inside a wave / five k-steps (two weight chunks), 16 output channels / two groups of 32 / the decoder shapes
 DECONV_H2_CASES = [(2, 16, 32, (3, 5, 7)), (2, 80, 16, (2, 4, 9)), (1, 32, 64, (4, 4, 8)), (2, 64, 32, (48, 48, 48)), (2, 320, 256, (6, 6, 6))]
 @pytest.mark.parametrize("n,cin,cout,dims", DECONV_H2_CASES)
