@@ -103,7 +103,9 @@ def test_conv_mfma_separate_stats_and_select(emu):
         assert ops.conv3d_k3_select(*a, bounded=False, algo=AUTO) == ops.conv3d_k3_select(*a, bounded=True, algo=FP32) <= wino2d
         assert 1 <= ops.conv3d_k3_select(*a, bounded=False, algo=H2) < wino2d
     assert ops.conv3d_k3_select(256, 128, 12, 12, 12, bounded=True, algo=AUTO) == h2 and not ops.conv3d_k3_accepts(h2, 272, 32)
-    assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=AUTO) == 13      # W % 4 != 0
+    # W % 4 != 0 and a plane below 8 x 8: not the z-marching split kernel -- since round 5 the small-volume one (the whole 6^3 volume as a tile), the fp32 tiles without bounds
+    assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=AUTO) == ops.conv3d_k3_h2v_config() == ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=H2)
+    assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=False, algo=AUTO) == 13 == ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=FP32)
     # the split-precision kernel addresses its 32 output planes with 31-bit byte offsets: beyond D*H*W = 2^24 voxels the selector returns the fp32 kernels
     assert ops.conv3d_k3_select(32, 32, 255, 256, 256, bounded=True, algo=AUTO) == h2
     assert 1 <= ops.conv3d_k3_select(32, 32, 256, 256, 256, bounded=True, algo=AUTO) <= wino2d
