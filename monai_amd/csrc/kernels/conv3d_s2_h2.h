@@ -110,7 +110,6 @@ conv3d_s2_split_kernel(Tensor in, uint4* __restrict__ ws, int* __restrict__ expo
 // (2) the matrix instructions of one step: NY x NX in-plane taps of the staged phase region, NZ z-taps each (NZ == 2: slot 0 = k 0 -> the NEXT output plane's
 // accumulators, slot 1 = k 2 -> this plane's), NCG groups of 32 output channels.  A's two pieces are read once per in-plane tap and meet 2 NZ NCG weight operands.
 struct S2NoSide { __device__ __forceinline__ void operator()(int, int) const {} };
-template <int V> struct S2Int { static constexpr int value = V; };
 template <int NZ, int NY, int NX, int NCG, bool HEAVY, class SIDE>
 __device__ __forceinline__ void s2_step_mm(const uint4* __restrict__ xb, const uint4* __restrict__ wb, int abase, int bbase, int RS, int RV, f32x16 (&acc)[2][NCG], SIDE side) {
     constexpr int CW = 32 * NCG, NG = NZ * NY * NX;           // a GROUP = one (in-plane tap, z tap): 3 NCG matrix instructions
@@ -248,12 +247,9 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     const float* fsrc = in.data + (long long)n * in.n_stride;
     const long long frest = (long long)(in.N - n) * in.n_stride * 4;
     const uint4* wcg = wp + (long long)cg * nch * 27 * 4 * CW;
-    // split form: TWO operand register sets -- the cells of step k travel in set k & 1, so two steps' requests are in flight per CU (one step's 19.5 KB per CU is what the
-    // HBM latency turns into 2.4 TB/s chip-wide: profiles/r05_pmc_s2.txt -- matrix pipe 0.28, LDS 0.25 of the launch, the wave waits for data)
-    u32x4 xreg[FUSED ? 1 : S2_XSLOTS], xreg1[FUSED ? 1 : S2_XSLOTS], wreg[WSLOTS];
+    u32x4 xreg[FUSED ? 1 : S2_XSLOTS], wreg[WSLOTS];
     float xraw[FUSED ? S2_XSLOTS : 1][4];
-    auto load_x = [&](int it, int ph, int ch, auto QC) {
-        constexpr int Q = decltype(QC)::value;
+    auto load_x = [&](int it, int ph, int ch) {
         if (FUSED) {
             const long long fo_ = (long long)(16 * ch) * DHWf + (long long)(2 * it + (ph >> 2)) * HWf + (long long)((ph >> 1) & 1) * Wf + (ph & 1);
             const long long left_ = frest - fo_ * 4;
@@ -267,10 +263,7 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
             const long long left_ = xrest - xo_;
             const auto xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(xsn) + xo_ / 16, 0, (int)(left_ < 0x7fffffffLL ? left_ : 0x7fffffffLL), 0x00020000);
 #pragma unroll
-            for (int s = 0; s < S2_XSLOTS; ++s) {
-                const u32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[s], 0, 0);
-                if (Q == 0) xreg[FUSED ? 0 : s] = v_; else xreg1[FUSED ? 0 : s] = v_;
-            }
+            for (int s = 0; s < S2_XSLOTS; ++s) xreg[s] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[s], 0, 0);
         }
     };
     auto load_w = [&](int ph, int ch) {
@@ -363,10 +356,10 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
         i_ = ok_ ? i2 : i_; p_ = ok_ ? p2 : p_; c_ = ok_ ? c2 : c_;
         return ok_;
     };
-    // Pipeline: at the start of step s the registers hold the operand cells and tap matrices of step s + 1 (split form: the cells of step s + 2 are in flight in the other
-    // set).  Between step s's matrix instructions they go into the other LDS buffer -- nobody reads it before the barrier at the end of the step -- and the next requests
-    // follow into the registers just freed: every load has more than a whole step (split form: two) to arrive.
-    load_x(it, ph, ch, S2Int<0>{});
+    // Pipeline (both forms): at the start of step s the registers hold the operand cells and tap matrices of step s + 1 (requested during step s - 1).  Between
+    // step s's matrix instructions they go into the other LDS buffer -- nobody reads it before the barrier at the end of the step -- and the requests of step s + 2
+    // follow into the same registers: every load has more than a whole step to arrive, with one register set.
+    load_x(it, ph, ch);
     load_w(ph, ch);
     if (FUSED) {
         __syncthreads();                                      // the rescaled records are complete
@@ -379,40 +372,28 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
     {
         int i1 = it, p1 = ph, c1 = ch;
         advance(i1, p1, c1);
-        if (FUSED) {
-            load_x(i1, p1, c1, S2Int<0>{});
-        } else {
-            load_x(i1, p1, c1, S2Int<1>{});                   // step 1 -> set 1
-            int i2 = i1, p2 = p1, c2 = c1;
-            advance(i2, p2, c2);
-            load_x(i2, p2, c2, S2Int<0>{});                   // step 2 -> set 0 (its cells of step 0 are in LDS)
-        }
+        load_x(i1, p1, c1);
         load_w(p1, c1);
     }
     __syncthreads();
-    // one step; QC = the register set that holds step s + 1's cells ((s + 1) & 1): the loop below alternates the two instantiations
-    auto step = [&](auto QC) -> bool {
-        constexpr int Q = decltype(QC)::value;
+    while (true) {
         int nit = it, nph = ph, nchk = ch;
         const bool has_next = advance(nit, nph, nchk);
         int n2it = nit, n2ph = nph, n2ch = nchk;
         advance(n2it, n2ph, n2ch);
-        int n3it = n2it, n3ph = n2ph, n3ch = n2ch;
-        advance(n3it, n3ph, n3ch);
         const uint4* xb = xbuf + buf * S2_XB;
         const uint4* wb = wbuf + buf * WB;
         // chunk k of the staging work rides in group min(k, groups - 1) of the step: operand slots 0 .. 2 (fused form: activate + scale + split; split form: copies),
-        // the operand requests that follow into the freed registers (fused: step s + 2; split: step s + 3), then the tap matrices and their requests
+        // the operand requests of step s + 2, then the tap matrices and their requests
         auto side = [&](int G, int NG) {
 #pragma unroll
             for (int k = 0; k <= S2_XSLOTS + 1; ++k) {
                 if ((k < NG - 1 ? k : NG - 1) != G) continue;
                 if (k < S2_XSLOTS) {
                     if (FUSED) convert_slot(k, buf ^ 1, nchk);
-                    else reinterpret_cast<u32x4*>(xbuf + (buf ^ 1) * S2_XB)[tid + S2_NT * k] = Q == 0 ? xreg[FUSED ? 0 : k] : xreg1[FUSED ? 0 : k];
+                    else reinterpret_cast<u32x4*>(xbuf + (buf ^ 1) * S2_XB)[tid + S2_NT * k] = xreg[FUSED ? 0 : k];
                 } else if (k == S2_XSLOTS) {
-                    if (FUSED) load_x(n2it, n2ph, n2ch, S2Int<0>{});
-                    else load_x(n3it, n3ph, n3ch, QC);
+                    load_x(n2it, n2ph, n2ch);
                 } else {
                     store_w(buf ^ 1);
                     load_w(n2ph, n2ch);
@@ -480,12 +461,8 @@ conv3d_k3s2_h2_kernel(Tensor in, const uint4* __restrict__ xs, const int* __rest
                 for (int i = 0; i < 16; ++i) { acc[0][g][i] = acc[1][g][i]; acc[1][g][i] = 0.0f; }
         }
         __syncthreads();
+        if (!has_next) break;
         it = nit; ph = nph; ch = nchk; buf ^= 1;
-        return !has_next;
-    };
-    while (true) {
-        if (step(S2Int<1>{})) break;
-        if (step(S2Int<0>{})) break;
     }
 
     if (STATS) {
