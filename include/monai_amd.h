@@ -167,7 +167,7 @@ int mh_conv3d_k3_h2c_config(void);
 int mh_conv3d_k3_c1_config(void);
 /* mh_conv3d_k3_h2_config's arithmetic for SMALL volumes (round 5, kernels/conv3d_vol_h2.h): one sample's whole D x H x W volume is the workgroup's M tile (no z-march,
  * no halo recomputation, one statistics record per (n, cout)) -- the 6^3 level of a 96^3 window, where 16 x 16 regions would be 14 % full.  Same reference op, record /
- * bound contract and tolerance class; Cin % 16 == 0 (<= 512), Cout % 32 == 0, 64 <= D*H*W <= 256, (D+2)(H+2)(W+2) <= 512.  mh_conv3d_k3_select returns it for bounded
+ * bound contract and tolerance class; Cin % 16 == 0 (<= 768), Cout % 32 == 0, 64 <= D*H*W <= 256, (D+2)(H+2)(W+2) <= 512.  mh_conv3d_k3_select returns it for bounded
  * inputs of such volumes that mh_conv3d_k3_h2_config does not take (H or W below 8). */
 int mh_conv3d_k3_h2v_config(void);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */

@@ -583,7 +583,7 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
         return launched("conv3d_k3_h2_pack");
     }
     if (cfg == MH_CFG_H2V) {
-        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the small-volume split kernel needs Cin %% 16 == 0 (<= 512), Cout %% 32 == 0");
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the small-volume split kernel needs Cin %% 16 == 0 (<= 768), Cout %% 32 == 0");
         float* tail = packed + (mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL);
         hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
         hipLaunchKernelGGL(conv3d_k3_vol_h2_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout, Cout % 64 == 0 ? 2 : 1,
@@ -682,7 +682,7 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
     if (cfg == MH_CFG_H2V) {
         if (accumulate || pool) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: the small-volume split kernel has no accumulating / pooling form");
         if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || !hv_fits(in.D, in.H, in.W))
-            return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs Cin %% 16 == 0 (<= 512), Cout %% 32 == 0, 64 <= D*H*W <= 256, (D+2)(H+2)(W+2) <= 512 (got %d -> %d, %dx%dx%d)",
+            return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs Cin %% 16 == 0 (<= 768), Cout %% 32 == 0, 64 <= D*H*W <= 256, (D+2)(H+2)(W+2) <= 512 (got %d -> %d, %dx%dx%d)",
                         in.C, out.C, in.D, in.H, in.W);
         if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs input records with magnitude bounds");
         if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "conv3d_k3: the small-volume split kernel needs 16-byte aligned output and weights");

@@ -22,7 +22,7 @@ constexpr int HV_NT = 512;
 constexpr int HV_CELLS = 512;                              // cells of the zero-padded volume
 constexpr int HV_XB = 4 * HV_CELLS;                        // uint4 per operand buffer: [piece][k group][cell]
 constexpr int HV_XSLOTS = 4;                               // (cell, channel quad) tasks per thread and chunk: 4 x 512 = 512 cells x 4 quads
-constexpr int HV_CIN_MAX = 512;                            // input channels whose records sit in LDS
+constexpr int HV_CIN_MAX = 768;                            // input channels whose records sit in LDS (9 KB: with the two operand and the two tap buffers 156 of the 160 KB)
 constexpr unsigned HV_DROP = 0x80000000u;
 
 template <int NCG, bool STATS>

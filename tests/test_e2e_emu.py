@@ -99,6 +99,7 @@ def test_dynunet_concat_wider_than_the_record_table(emu):
         print("max |d|", dc.case_dynunet_wide_concat("cpu"))
 
 
+@pytest.mark.heavy_emu
 def test_strided_convolutions_of_dynunet_and_segresnet_on_matrix_cores(emu):
     """the reference goldens with the down-sampling convolutions on the split-precision stride-2 kernel (the `emu` fixture pins the exact-fp32 family otherwise)"""
     import dynunet_cases as dc

@@ -301,7 +301,7 @@ def test_upcat_composite_transposed_convolution(emu, n, cup, cout, ldims):
 
 
 # (n, cin, cout, dims): 64 of 256 rows / the 6^3 level, two cout groups per workgroup, two chunks / odd extents (scalar stores), three chunks / a shape the z-marching kernel takes
-SMALL_VOLUME_CASES = [(2, 16, 32, (4, 4, 4)), (2, 32, 64, (6, 6, 6)), (1, 48, 32, (3, 5, 7)), (2, 16, 64, (2, 8, 8))]
+SMALL_VOLUME_CASES = [(2, 16, 32, (4, 4, 4)), (2, 32, 64, (6, 6, 6)), (1, 48, 32, (3, 5, 7)), (2, 16, 64, (2, 8, 8)), (1, 768, 32, (4, 4, 4))]
 @pytest.mark.parametrize("n,cin,cout,dims", SMALL_VOLUME_CASES)
 def test_small_volume_convolution_on_matrix_cores(emu, n, cin, cout, dims):
     """Conv3d k3 p1 with one sample's whole volume as the workgroup's tile (kernels/conv3d_vol_h2.h) == ATen in float64, statistics, selection and poisoning included"""
