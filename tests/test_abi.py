@@ -65,6 +65,26 @@ def test_host_side_queries_need_no_gpu():
         if saved is not None:
             os.environ["MONAI_AMD_CONV_ALGO"] = saved
     assert dll.mh_instnorm_stat_tiles(96, 96, 96) > 0
+    # round 5: the small-volume split-precision configuration (bounded inputs of 64 .. 256-voxel volumes the z-marching kernel does not take), the stride-2 and the
+    # transposed k2 s2 matrix-core kernels' shape rules and buffer sizes -- host arithmetic, no device
+    dll.mh_conv3d_k3_h2v_config.restype = ctypes.c_int
+    h2v = dll.mh_conv3d_k3_h2v_config()
+    assert h2v > n and h2v != dll.mh_conv3d_k3_h2_config()
+    assert dll.mh_conv3d_k3_select(AUTO, 1, 128, 256, 6, 6, 6) == h2v and dll.mh_conv3d_k3_select(AUTO, 1, 768, 384, 6, 6, 6) == h2v
+    assert dll.mh_conv3d_k3_select(AUTO, 0, 128, 256, 6, 6, 6) < n and dll.mh_conv3d_k3_select(FP32, 1, 128, 256, 6, 6, 6) < n
+    assert dll.mh_conv3d_k3_select(AUTO, 1, 128, 256, 3, 3, 3) < n and dll.mh_conv3d_k3_select(AUTO, 1, 784, 256, 6, 6, 6) < n        # 27 voxels / more than 768 channels
+    assert dll.mh_conv3d_k3_stat_tiles(h2v, 6, 6, 6) == 1
+    dll.mh_conv3d_k3_packed_floats.restype = ctypes.c_int64
+    assert dll.mh_conv3d_k3_packed_floats(h2v, 128, 256) == 128 * 256 * 27 + 4
+    assert dll.mh_conv3d_k3s2_accepts(32, 64, 96, 96, 96) == 1 and dll.mh_conv3d_k3s2_accepts(32, 64, 95, 96, 96) == 0 and dll.mh_conv3d_k3s2_accepts(24, 64, 96, 96, 96) == 0
+    assert dll.mh_conv3d_k3s2_accepts(32, 48, 96, 96, 96) == 0 and dll.mh_conv3d_k3s2_accepts(32, 64, 512, 512, 512) == 0      # Cout % 32; 32-bit offsets
+    dll.mh_conv3d_k3s2_workspace_floats.restype = ctypes.c_int64
+    dll.mh_conv3d_k3s2_packed_floats.restype = ctypes.c_int64
+    assert dll.mh_conv3d_k3s2_workspace_floats(3, 32, 8, 8, 8) == 3 * 32 * 512 + 4 and dll.mh_conv3d_k3s2_packed_floats(32, 64) == 32 * 64 * 27 + 4
+    assert dll.mh_conv3d_k3s2_stat_tiles(96, 96, 96) == 36 and dll.mh_conv3d_k3s2_stat_tiles(24, 24, 24) == 1
+    assert dll.mh_deconv_k2s2_h2_accepts(64, 32, 48, 48, 48) == 1 and dll.mh_deconv_k2s2_h2_accepts(64, 16, 4, 4, 4) == 1 and dll.mh_deconv_k2s2_h2_accepts(60, 32, 4, 4, 4) == 0
+    dll.mh_deconv_k2s2_h2_packed_floats.restype = ctypes.c_int64
+    assert dll.mh_deconv_k2s2_h2_packed_floats(64, 32) == 64 * 32 * 8 + 4
 
 
 def test_library_reads_no_environment():
