@@ -231,6 +231,7 @@ def test_mosaic_layout_equals_window_major(emu):
     ec.case_mosaic_layout_equals_window_major("cpu", cases=(((1, 1, 40, 56, 32), 0.5, "gaussian"),), features=(8, 8, 8, 16, 16, 8))      # 2 x 3 x 1 windows, clipped last ones
 
 
+@pytest.mark.heavy_emu          # four minutes of emulated split-precision kernels; the composite kernel's own cases (test_kernels_emu.py) and the -m gpu twin stay
 def test_upcat_fused_vs_two_layers_and_reference(emu):
     """UpCat without its up-sampled intermediate (kernels/upconv_h2.h) inside BasicUNet: golden logits of the real reference + the engine's two-layer path"""
     print(ec.case_net_upcat_fused_vs_two_layers("cpu"))
