@@ -103,7 +103,7 @@ def _short_parity(rep: dict, family: str, full: bool = True) -> dict:
     """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py); full=False: the extras' brief form"""
     out = {"family": family, "voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "tolerance": rep["tolerance"],
            "argmax_mismatch_voxels": rep["argmax_mismatch_voxels"], "mismatch_outside_margin": rep["mismatch_outside_margin"],
-           "min_class_dice": rep["min_class_dice"], "ok": rep["ok"]}
+           "dice_deficit": rep["dice_deficit"], "ok": rep["ok"]}      # dice_deficit = 1 - min class Dice from the integer counts: 0.0 iff the label maps are identical
     if full:
         out.update({"max_top2_margin_at_mismatch": rep["max_top2_margin_at_mismatch"], "min_top2_margin": rep["min_top2_margin"],
                     "voxels_with_margin_below_1e-4": rep["voxels_with_margin_below_1e-4"]})
@@ -640,7 +640,7 @@ def _rounded(obj, digits: int = 5):
     return obj
 
 
-_EXTRA_DROP = ("steps", "warmup", "launches", "algorithmic_tflops", "cores", "kind", "tolerance", "traffic_src", "min_class_dice")
+_EXTRA_DROP = ("steps", "warmup", "launches", "algorithmic_tflops", "cores", "kind", "tolerance", "traffic_src")
 LINE_BYTES_MAX = 5800      # the driver's parsed copy keeps a line of this size whole (the 16 KB line of round 4 was cut)
 _TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "config3", "attention"), ("extra", "config3", "cpu_baseline"), ("extra", "fp32_exact", "roofline"),
                ("conv_ms_per_step",), ("extra", "config4", "parity_vs_cpu_restatement"), ("upconv",))
@@ -699,6 +699,9 @@ def main(argv=None):
     ap.add_argument("--net", default="basicunet", choices=sorted(NETS),
                     help="basicunet = the BASELINE.json metric (configs[1]); unetr = configs[3] (ViT-B/16 UNETR, MFMA attention path); unet = MONAI UNet 16..256, 2 res units (row a11); "
                          "dynunet = nnU-Net-shaped DynUNet (5 levels, 32..320 filters); segresnet = SegResNet(init_filters=16); swinunetr = SwinUNETR(feature_size=48) (SURVEY 8f-4)")
+    ap.add_argument("--force-shard", action="store_true", help="--gpus 1 only: initialise RCCL with ONE rank and run the window-sharded code (round schedule with its tail, padded rows, the in-place "
+                                                               "probe, one async all_gather_into_tensor per round) -- the N > 1 path exercised on a one-GPU box; the line is a development record "
+                                                               "(`forced_shard`), not the headline")
     args = ap.parse_args(argv)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -728,13 +731,18 @@ def main(argv=None):
     from monai_amd import config, parallel
     from monai_amd.inferers import SlidingWindowInferer
 
-    if world > 1:
+    forced = bool(args.force_shard) and world == 1
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced:
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if emulated:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-        parallel.enable_window_sharding()
+        parallel.enable_window_sharding(force=forced)
 
     feats = tuple(int(v) for v in args.harness_features.split(",")) if args.harness_features else None
     if feats and not emulated:
@@ -744,7 +752,7 @@ def main(argv=None):
     inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
 
     def sync():
-        if world > 1:
+        if world > 1 or forced:
             dist.barrier()
         if not emulated:
             torch.cuda.synchronize()
@@ -754,13 +762,13 @@ def main(argv=None):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ranks = per_rank_breakdown(spans, args.steps, world, dev, dist) if world > 1 else None
+    ranks = per_rank_breakdown(spans, args.steps, world, dev, dist) if (world > 1 or forced) else None
 
     if rank == 0:
         voxels = float(args.size) ** 3
         ms = 1e3 * dt / args.steps
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")      # no profiler inside a profiler
-        if world == 1 and not emulated and not args.no_pmc and not profiled and args.net == "basicunet" and (args.size, args.roi) == (512, 96):
+        if world == 1 and not forced and not emulated and not args.no_pmc and not profiled and args.net == "basicunet" and (args.size, args.roi) == (512, 96):
             _PMC_INRUN.update(pmc_inrun())
         exact = config.conv_algo() in (config.CONV_ALGOS["fp32"], config.CONV_ALGOS["direct"], config.CONV_ALGOS["wino2d"])
         conv_all = {k.split("/")[1]: {"ms": round(v["ms_total"] / args.steps, 3), "tflops": round(v["work"] / (v["ms_total"] * 1e-3) / 1e12, 2)}
@@ -782,11 +790,11 @@ def main(argv=None):
             "data": "synthetic",
             "config": {
                 "workload": f"{NETS[args.net]} 5-class seed 1, {args.size}^3 CT phantom in HBM, {args.roi}^3 win ov 0.5 gaussian, sw_batch 4 (engine: <= 64 windows per launch)",
-                "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
+                "parallelism": ("1 GPU, sharded code forced on a one-rank RCCL group" if forced else "1 GPU") if world == 1 else f"windows sharded over {world} GPUs, RCCL all-gather of logits before the blend",
             },
             "parity": None,
             "roofline": conv_roofline(spans, args.steps, ms, args.roi),
-            "roofline_hbm": blend_roofline(spans, mosaic=world == 1 and hasattr(net, "forward_into_windows") and os.environ.get("MONAI_AMD_LOGITS_LAYOUT") != "windows"),
+            "roofline_hbm": blend_roofline(spans, mosaic=world == 1 and not forced and hasattr(net, "forward_into_windows") and os.environ.get("MONAI_AMD_LOGITS_LAYOUT") != "windows"),
             "conv_ms_per_step": conv_all,
             "upconv": ({"kernel": "upconv_k4s2_h2_kernel (UpCat: convT k4 s2 of the low-res tensor)", "ms_per_step": spans["upconv_k4s2"]["ms_total"] / args.steps,
                         "ms_avg": spans["upconv_k4s2"]["ms_avg"], "fp32_equivalent_tflops": spans["upconv_k4s2"]["work"] / (spans["upconv_k4s2"]["ms_total"] * 1e-3) / 1e12}
@@ -803,10 +811,13 @@ def main(argv=None):
             pred = max(r["predictor_ms"] for r in ranks)
             line["exposed_comm_share"] = max(r["gather_wait_ms"] for r in ranks) / ms      # what the compute stream waited for gathers, of the step
             line["predictor_ms_max"] = pred
+        if forced:
+            line["forced_shard"] = {"backend": dist.get_backend(), "inplace_gather_probe": [bool(v) for v in parallel.inplace_gather_verdicts().values()],
+                                    "rounds": [n for _, n in parallel.partition(1000 if (args.size, args.roi) == (512, 96) else 1, 1, 0, force=True).schedule(64)][:12]}
         if emulated:
             line["emulated"] = "SIMT emulator + gloo: harness test only, not a measurement"
         shared: dict = {}
-        if world == 1 and args.cpu_windows > 0 and args.net == "basicunet":
+        if world == 1 and args.cpu_windows > 0 and args.net == "basicunet" and not forced:
             spread_s = 0.0 if (emulated or args.no_spread) else args.spread_budget_s
             try:
                 rec, par, spread = cpu_baseline(args.size, args.roi, args.cpu_windows, vol, net, inferer, out, args.cpu_budget_s, shared, spread_s)
@@ -827,7 +838,7 @@ def main(argv=None):
                 line["reference_self_spread"] = spread
         else:
             line["cpu_baseline"] = None
-        if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated:
+        if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated and not forced:
             extra = {}
             for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("config3", lambda: extra_config3(args, vol, sync, dev)),
                              ("config4", lambda: extra_config4(dev))):
@@ -839,7 +850,7 @@ def main(argv=None):
             line["extra"] = _slim_extra(extra)
         line = _fit_line(_rounded(line))
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

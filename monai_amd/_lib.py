@@ -144,8 +144,9 @@ SIGNATURES = {
 
 
 class KernelRejected(RuntimeError):
-    """An entry point refused its arguments (shape / alignment / size rule) without launching: callers with an alternative path catch THIS, not RuntimeError
-    (launch failures and HIP errors stay plain RuntimeErrors and must surface)."""
+    """An entry point declined a VALID call it has no kernel for (MH_ERR_UNSUPPORTED: a size / shape rule) without launching: callers with an alternative
+    path catch THIS, not RuntimeError.  Bad arguments (MH_ERR_ARG: null pointers, mismatched shapes, misalignment -- caller bugs), launch failures and HIP
+    errors stay plain RuntimeErrors and must surface."""
 
 
 class Library:
@@ -168,9 +169,9 @@ class Library:
         return self._mh_last_error().decode("utf-8", "replace")
 
     def check(self, rc: int) -> None:
-        if rc in (-1, -3):      # MH_ERR_ARG / MH_ERR_UNSUPPORTED: the entry point declined the call before launching anything
+        if rc == -3:            # MH_ERR_UNSUPPORTED: a valid call the entry point has no kernel for; nothing was launched
             raise KernelRejected(f"monai_amd: {self.last_error()} (code {rc})")
-        if rc != 0:             # MH_ERR_LAUNCH and anything else: a real failure, never something to fall back from
+        if rc != 0:             # MH_ERR_ARG (a caller bug), MH_ERR_LAUNCH and anything else: a real failure, never something to fall back from
             raise RuntimeError(f"monai_amd: {self.last_error()} (code {rc})")
 
     def call(self, name: str, *args) -> None:

@@ -191,7 +191,7 @@ class SlidingWindowSplitter(Splitter):
             out = torch.empty((n, src.shape[1]) + roi, dtype=torch.float32, device=src.device)
             return ops.window_extract(src[0].contiguous(), grid, 0, n, roi, out)
         except (_lib.KernelRejected, torch.cuda.OutOfMemoryError):
-            # a window grid the gather kernel does not take (e.g. an irregular start list beyond its table), or no room for the dense buffer: views.
+            # a gather too large for one launch (MH_ERR_UNSUPPORTED), or no room for the dense buffer: views.
             # Launch failures / HIP errors are NOT caught: a broken gather must fail, not degrade into a slow path
             return None
 

@@ -78,7 +78,7 @@ def _to3(values, fill):
     return (fill,) * (3 - len(values)) + values
 
 
-def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world: int = 1) -> int:
+def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world: int = 1, sharded: bool = False) -> int:
     """Windows per predictor call.  A generic predictor gets exactly the user's ``sw_batch_size``.  The fused engines
     size the batch for 288 GB of HBM instead (results do not depend on the batch: InstanceNorm is per sample): more
     windows per launch fill the 256 CUs at the deep U-Net levels, and a power-of-two count keeps the workgroup grids of
@@ -102,10 +102,10 @@ def _auto_batch(predictor, roi3, num_win: int, sw_batch_size: int, device, world
             cap //= 2
     cap = max(cap, int(sw_batch_size)) if cap >= sw_batch_size else cap
     cap = max(1, min(cap, per_rank))
-    if world > 1 and cap > 1:
+    if (world > 1 or sharded) and cap > 1:
         # the busiest rank (rank 0: a full slot in every round of parallel.WindowShard.schedule) sets the step time: the nb in [cap / 2, cap] that gives it the fewest
         # windows, a launch counted as at least 7 windows (below that the large layers no longer fill 256 CUs), ties to the larger nb
-        probe = parallel.partition(num_win, world, 0)
+        probe = parallel.partition(num_win, world, 0, force=sharded)
         best, best_cost = cap, None
         for nb in range(cap, max(cap // 2, 1) - 1, -1):
             cost = sum(max(n, min(7, nb)) for _, n in probe.schedule(nb))
@@ -276,7 +276,7 @@ def sliding_window_inference(
 
     # windows owned by this rank: all of them, or (window sharding on) its slot of every round -- monai_amd/parallel.py
     shard = parallel.window_shard(num_win)
-    nb = _auto_batch(predictor, roi3, num_win, sw_batch_size, dev, world=shard.world)
+    nb = _auto_batch(predictor, roi3, num_win, sw_batch_size, dev, world=shard.world, sharded=shard.sharded)
     nb = shard.agree_batch(nb, dev)
     my_rounds = shard.rounds(nb)
     fused = hasattr(predictor, "forward_into") and not with_coord and not args and not kwargs and process_fn is None
@@ -300,8 +300,8 @@ def sliding_window_inference(
 
     fused = fused and hasattr(predictor, "out_channels") and getattr(predictor, "window_sized_output", True)
     # buffer_steps with a callback in the loop: the predictor sees the reference's buffered batch schedule (sorted windows, batches cut at the slab ends)
-    buffered_calls = buffered and not fused and (process_fn is not None or with_coord or shard.world == 1)
-    if buffered_calls and shard.world > 1:
+    buffered_calls = buffered and not fused and (process_fn is not None or with_coord or not shard.sharded)
+    if buffered_calls and shard.sharded:
         raise NotImplementedError("monai_amd: buffer_steps with process_fn / with_coord under window sharding is not on the HIP path")
     for b in range(batch_size):
         vol3 = inputs[b].reshape((in_ch,) + img3)
@@ -324,12 +324,12 @@ def sliding_window_inference(
                 if count_map is not None:
                     proc_weights = [count_map]
         for q, (w0, n) in steps:
+            if fused and logits is None:       # sized from the engine's out_channels, not from a first prediction: a rank whose slot of the first round is empty allocates too
+                k = int(predictor.out_channels)
+                seg_shapes, zscales = [tuple(roi_size)], [None]
+                mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
+                logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
             if n > 0 and fused:
-                if logits is None:
-                    k = int(predictor.out_channels)
-                    seg_shapes, zscales = [tuple(roi_size)], [None]
-                    mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
-                    logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
                 ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
                 with _prof.span("sw_predictor"):
                     if mosaic is not None:     # the network's last kernel writes the windows straight into the mosaic layout
@@ -383,7 +383,7 @@ def sliding_window_inference(
                     if len(proc_weights) <= ss:      # the count map is built from the FIRST batch's map (utils.py:270-275)
                         proc_weights.append(w_batch[0, 0].reshape(_to3(seg_shapes[ss], 1)).contiguous().clone())
                     torch.mul(s.reshape(dst.shape), w_batch.reshape((1, 1) + tuple(dst.shape[2:])), out=dst)   # `seg *= w_t`
-            if shard.world > 1:
+            if shard.sharded:
                 if logits is None:
                     raise RuntimeError("monai_amd: a rank without windows in the first round cannot size the logits buffer "
                                        "(fewer windows than ranks x windows per launch: lower sw_batch_size)")
@@ -623,7 +623,7 @@ def _alloc_mosaic(predictor, shard, argmax_dtype, k: int, grid3, roi3, dtype, de
     384-byte pieces of 8 ... 27 x K window blocks) when the path allows it: a predictor whose last kernel can write it (`forward_into_windows`), one GPU
     (window sharding gathers window-major rows), the plain blend (the fused-argmax epilogue reads window-major), a regular grid with <= 4 residue
     classes, K <= 8.  Same result bits either way; MONAI_AMD_LOGITS_LAYOUT=windows keeps the window-major buffer.  The same fit rule as _alloc_logits."""
-    if (not hasattr(predictor, "forward_into_windows") or shard.world > 1 or argmax_dtype is not None or dtype != torch.float32
+    if (not hasattr(predictor, "forward_into_windows") or shard.sharded or argmax_dtype is not None or dtype != torch.float32
             or os.environ.get("MONAI_AMD_LOGITS_LAYOUT") == "windows" or not ops.LogitsMosaic.supported(grid3, roi3, k)):
         return None
     layout = ops.LogitsMosaic(grid3, roi3, k, dev, dtype, allocate=False)

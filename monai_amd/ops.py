@@ -430,7 +430,7 @@ def maxpool2(x, x_nrm, out, out_nrm=None):
     return out
 
 
-_DECONV_H2_PACKED: dict = {}          # id(weight) -> (weakref to the parameter, its version, device, packed tap matrices): re-packed when the parameter changed or moved
+_DECONV_H2_PACKED: dict = {}          # id(weight) -> (weakref to the parameter, its version, device, storage address, packed tap matrices): re-packed when the parameter changed, moved or got new storage (`param.data = other` keeps `_version`)
 
 
 def deconv_k2s2_h2_packed(weight: torch.Tensor) -> torch.Tensor:
@@ -438,16 +438,16 @@ def deconv_k2s2_h2_packed(weight: torch.Tensor) -> torch.Tensor:
     import weakref
 
     hit = _DECONV_H2_PACKED.get(id(weight))
-    if hit is None or hit[0]() is not weight or hit[1] != weight._version or hit[2] != str(weight.device):
+    if hit is None or hit[0]() is not weight or hit[1] != weight._version or hit[2] != str(weight.device) or hit[3] != weight.data_ptr():
         if len(_DECONV_H2_PACKED) > 256:          # parameters that no longer exist
             for k in [k for k, v in _DECONV_H2_PACKED.items() if v[0]() is None]:
                 del _DECONV_H2_PACKED[k]
         cin, cout = int(weight.shape[0]), int(weight.shape[1])
         packed = torch.zeros(_lib.lib().query("mh_deconv_k2s2_h2_packed_floats", cin, cout), dtype=torch.float32, device=weight.device)
         _lib.lib().call("mh_deconv_k2s2_h2_pack_f32", _lib.ptr(weight.detach().contiguous()), cin, cout, _lib.ptr(packed), _s(weight))
-        hit = (weakref.ref(weight), weight._version, str(weight.device), packed)
+        hit = (weakref.ref(weight), weight._version, str(weight.device), weight.data_ptr(), packed)
         _DECONV_H2_PACKED[id(weight)] = hit
-    return hit[3]
+    return hit[4]
 
 
 def deconv_k2s2(x, x_nrm, weight, bias, out, out_nrm=None, bounded: bool = False):

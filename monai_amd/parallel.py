@@ -12,7 +12,10 @@ the single-GPU result on every rank (the blend never depended on who computed a 
 counterpart (monai/utils/dist.py:59-140 only gathers metrics).
 
 Nothing here runs unless ``enable_window_sharding()`` was called (bench.py does, for --gpus > 1): the public
-``SlidingWindowInferer`` signature is unchanged.
+``SlidingWindowInferer`` signature is unchanged.  With ONE rank the schedule degenerates to the unsharded loop and no collective is issued --
+unless the sharding was enabled with ``force=True`` (or MONAI_AMD_SHARD_FORCE=1 is set): then a one-rank group takes exactly the code a
+larger one takes (round schedule with its tail, padded row buffer, the in-place probe, one asynchronous ``all_gather_into_tensor`` per round,
+``_Pending.wait``), which is how the RCCL path is exercised on a one-GPU box (tests/test_e2e_gpu.py, ``bench.py --force-shard``).
 """
 
 from __future__ import annotations
@@ -26,19 +29,21 @@ import torch.distributed as dist
 
 _GROUP = None
 _ENABLED = False
+_FORCE = False
 
 
-def enable_window_sharding(group=None) -> None:
-    """Shard the windows of every following sliding_window_inference call over `group` (default: WORLD)."""
-    global _GROUP, _ENABLED
+def enable_window_sharding(group=None, force: bool = False) -> None:
+    """Shard the windows of every following sliding_window_inference call over `group` (default: WORLD).
+    force: a group of ONE rank runs the sharded code too (rounds, row padding, the collectives) instead of the unsharded loop."""
+    global _GROUP, _ENABLED, _FORCE
     if not dist.is_available() or not dist.is_initialized():
         raise RuntimeError("monai_amd.parallel: torch.distributed is not initialised")
-    _GROUP, _ENABLED = group, True
+    _GROUP, _ENABLED, _FORCE = group, True, bool(force) or os.environ.get("MONAI_AMD_SHARD_FORCE") == "1"
 
 
 def disable_window_sharding() -> None:
-    global _GROUP, _ENABLED
-    _GROUP, _ENABLED = None, False
+    global _GROUP, _ENABLED, _FORCE
+    _GROUP, _ENABLED, _FORCE = None, False, False
 
 
 class window_sharding:
@@ -46,17 +51,17 @@ class window_sharding:
     group) is restored on exit, also when the body raises.  The switch itself stays a property of the process (one inference stream per rank, the layout bench.py and
     the reference's one-process-per-GPU launchers use); two threads of one rank that shard over different groups must serialise their scopes."""
 
-    def __init__(self, group=None):
-        self.group = group
+    def __init__(self, group=None, force: bool = False):
+        self.group, self.force = group, force
 
     def __enter__(self):
-        self._saved = (_GROUP, _ENABLED)
-        enable_window_sharding(self.group)
+        self._saved = (_GROUP, _ENABLED, _FORCE)
+        enable_window_sharding(self.group, self.force)
         return self
 
     def __exit__(self, *exc):
-        global _GROUP, _ENABLED
-        _GROUP, _ENABLED = self._saved
+        global _GROUP, _ENABLED, _FORCE
+        _GROUP, _ENABLED, _FORCE = self._saved
         return False
 
 
@@ -112,14 +117,20 @@ class WindowShard:
     lo: int      # first global window index of this rank (contiguous partition, see `partition`)
     hi: int      # one past the last REAL window of this rank
     group: Optional[object] = None
+    force: bool = False      # one rank, but the sharded code (see the module docstring)
 
     @property
     def base(self) -> int:
         return self.lo
 
+    @property
+    def sharded(self) -> bool:
+        """does this call run the round schedule and its collectives?"""
+        return self.world > 1 or self.force
+
     def all_gather(self, local: torch.Tensor) -> torch.Tensor:
-        """local [chunk, ...] -> [world * chunk, ...] with global window w at row w (identity when world == 1)."""
-        if self.world == 1:
+        """local [chunk, ...] -> [world * chunk, ...] with global window w at row w (identity when not sharded)."""
+        if not self.sharded:
             return local
         out = torch.empty((self.world * self.chunk,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
@@ -128,7 +139,7 @@ class WindowShard:
     # ---- round-interleaved schedule: communication of round q overlaps the computation of round q + 1 -------------
     def agree_batch(self, nb: int, device) -> int:
         """Windows per predictor launch, identical on every rank (the minimum of the ranks' own choices)."""
-        if self.world == 1:
+        if not self.sharded:
             return nb
         t = torch.tensor([int(nb)], dtype=torch.int64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
@@ -141,7 +152,7 @@ class WindowShard:
         front of the blend -- with 8 GPUs and 63 windows per launch that is 504 windows = 7.8 GB per rank (~23 ms over xGMI against ~107 ms of compute per rank);
         five tail rounds of 13 windows per rank leave 1.6 GB (~5 ms) exposed and cost the deep U-Net levels a few per cent of fill on 1/8 of the windows.
         A pure function of (num_win, world, nb): every rank derives the same schedule.  MONAI_AMD_TAIL_ROUNDS=0 keeps equal rounds (measurement switch)."""
-        if self.world == 1:
+        if not self.sharded:
             return [(w0, min(nb, self.num_win - w0)) for w0 in range(0, self.num_win, nb)]
         span = self.world * nb
         tail = nb // 4 if (nb >= 8 and os.environ.get("MONAI_AMD_TAIL_ROUNDS") != "0") else 0
@@ -159,7 +170,7 @@ class WindowShard:
 
     def rounds(self, nb: int):
         """(first global window, number of real windows) of THIS rank in each round of `schedule(nb)`"""
-        if self.world == 1:
+        if not self.sharded:
             return self.schedule(nb)
         out = []
         for base, n in self.schedule(nb):
@@ -169,7 +180,7 @@ class WindowShard:
 
     def padded_windows(self, nb: int) -> int:
         """rows of the all-window logits buffer: the windows, padded to whole rounds when sharded (row index == window index)"""
-        if self.world == 1:
+        if not self.sharded:
             return self.num_win
         base, n = self.schedule(nb)[-1]
         return base + self.world * n
@@ -178,8 +189,8 @@ class WindowShard:
         """Complete the rows of round `q` of `schedule(nb)` on every rank (this rank has written its own slot of them).
         `full` is an inferer logits buffer (rows `stride(0)` floats apart inside one flat allocation): the round's rows are one
         contiguous span, this rank's rows are its own slot of that span, so the all-gather runs IN PLACE -- no send copy.
-        Returns the async work handle (None when world == 1)."""
-        if self.world == 1:
+        Returns the async work handle (None when not sharded)."""
+        if not self.sharded:
             return None
         from .inferers.utils import flat_rows
 
@@ -197,12 +208,12 @@ class WindowShard:
         return _Pending(work, send)
 
 
-def partition(num_win: int, world: int, rank: int, group=None) -> WindowShard:
+def partition(num_win: int, world: int, rank: int, group=None, force: bool = False) -> WindowShard:
     """Contiguous equal chunks of ceil(num_win / world) windows: rank r owns [r*chunk, min((r+1)*chunk, num_win))."""
     chunk = (num_win + world - 1) // world
     lo = min(rank * chunk, num_win)
     hi = min(lo + chunk, num_win)
-    return WindowShard(num_win, world, rank, chunk, lo, hi, group)
+    return WindowShard(num_win, world, rank, chunk, lo, hi, group, force)
 
 
 def window_shard(num_win: int) -> WindowShard:
@@ -210,4 +221,9 @@ def window_shard(num_win: int) -> WindowShard:
         return WindowShard(num_win, 1, 0, num_win, 0, num_win, None)
     world = dist.get_world_size(_GROUP)
     rank = dist.get_rank(_GROUP)
-    return partition(num_win, world, rank, _GROUP)
+    return partition(num_win, world, rank, _GROUP, _FORCE)
+
+
+def inplace_gather_verdicts() -> dict:
+    """{(group id, device): did the in-place all-gather probe pass} for every group probed so far in this process (tests and bench.py report it)"""
+    return dict(_INPLACE_OK)

@@ -18,8 +18,8 @@ class _PerKey:
     """keys + a table of per-key call options for `array_transform`; ``self.<option>`` is the column of that option (a tuple, one entry per key)"""
 
     array_transform: type = object
-    # options that used to be boolean switches in old MONAI releases and now take a value: option name -> what to pass instead
-    valued_options: Mapping[str, str] = {}
+    # options that used to be boolean switches in old MONAI releases and now take a value: option name -> (the switch's old name, what to pass instead)
+    valued_options: Mapping[str, tuple] = {}
 
     def _bind(self, keys, allow_missing_keys: bool, converter_kwargs: dict, **options) -> None:
         self.keys = ensure_tuple(keys)
@@ -30,7 +30,8 @@ class _PerKey:
         for name, value in options.items():
             column = ensure_tuple_rep(value, len(self.keys))
             if name in self.valued_options and any(isinstance(v, bool) for v in column):
-                raise ValueError(f"`{name}=True/False` is deprecated, please use `{name}={self.valued_options[name]}` instead.")
+                old, new = self.valued_options[name]
+                raise ValueError(f"`{old}=True/False` is deprecated, please use `{name}={new}` instead.")
             setattr(self, name, column)
         self.converter = self.array_transform()
         self.converter.kwargs = converter_kwargs
@@ -60,7 +61,7 @@ class Activationsd(_PerKey):
 
 class AsDiscreted(_PerKey):
     array_transform = AsDiscrete
-    valued_options = {"to_onehot": "num_classes", "threshold": "value"}
+    valued_options = {"to_onehot": ("to_onehot", "num_classes"), "threshold": ("threshold_values", "value")}      # the reference's messages, post/dictionary.py:190-197
 
     def __init__(self, keys, argmax: Sequence[bool] | bool = False, to_onehot: Sequence[int | None] | int | None = None,
                  threshold: Sequence[float | None] | float | None = None, rounding: Sequence[str | None] | str | None = None,

@@ -73,6 +73,8 @@ def label_parity(got: torch.Tensor, ref: torch.Tensor, tol: float = 1e-4, channe
         "min_top2_margin": margin_min,
         "voxels_with_margin_below_1e-4": below,
         "min_class_dice": min(dice) if dice else 1.0,
+        # 1 - min class Dice formed from the integer counts (2 * inter / (a + b) rounds to 1.0 long before the labels agree): 0.0 exactly iff every label agrees
+        "dice_deficit": max([0.0] + [(cnt_a[c] + cnt_b[c] - 2 * inter[c]) / float(cnt_a[c] + cnt_b[c]) for c in range(k) if cnt_a[c] + cnt_b[c] > 0]),
     }
     rep["ok"] = bool(diff <= tol and rep["mismatch_outside_margin"] == 0)
     return rep

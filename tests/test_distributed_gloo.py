@@ -292,3 +292,70 @@ def test_scoped_switches_restore_the_previous_state():
         assert not parallel._ENABLED
     finally:
         dist.destroy_process_group()
+
+
+def _worker_forced(rank, world, port, ret):
+    """ONE rank with the sharding forced (parallel.window_sharding(force=True)): the round schedule with its tail, the padded row buffer, the in-place probe and one
+    asynchronous all-gather per round run although there is nobody to exchange with -- the form the RCCL path is exercised in on a one-GPU box"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.dirname(here)]
+        from emu_backend import emu_backend
+
+        from monai_amd import parallel
+        from monai_amd.inferers import SlidingWindowInferer, sliding_window_inference
+        from monai_amd.networks.nets import BasicUNet
+
+        gathers = []
+        real = parallel.WindowShard.gather_round
+
+        def counting(self, full, q, nb):
+            work = real(self, full, q, nb)
+            gathers.append((q, work is not None))
+            return work
+
+        parallel.WindowShard.gather_round = counting
+
+        def toy(w):
+            m = w.mean(dim=(2, 3, 4), keepdim=True)
+            return torch.cat([w * 1.5 - m, (w - m) * (w - m) + 0.25], dim=1)
+
+        with emu_backend():
+            torch.manual_seed(21)
+            x = torch.rand(1, 1, 28, 28, 28)               # 6^3 = 216 windows of 8^3 at overlap 0.5
+            single = sliding_window_inference(x, (8, 8, 8), 32, toy, overlap=0.5, mode="gaussian").clone()
+            assert not gathers
+            with parallel.window_sharding(force=True):
+                sh = parallel.window_shard(216)
+                assert sh.sharded and sh.world == 1 and [n for _, n in sh.schedule(32)] == [32] * 6 + [8, 8, 8]      # main rounds, then the tail (nb / 4)
+                forced = sliding_window_inference(x, (8, 8, 8), 32, toy, overlap=0.5, mode="gaussian").clone()
+            n_toy = len(gathers)
+            verdicts = parallel.inplace_gather_verdicts()
+            # the fused engine path (window-major rows instead of the mosaic under sharding)
+            torch.manual_seed(1)
+            net = BasicUNet(3, 1, 3, features=FEATURES).eval()
+            torch.manual_seed(3)
+            y = torch.rand(1, 1, 64, 24, 16)
+            inf = SlidingWindowInferer(roi_size=(32, 16, 16), sw_batch_size=2, overlap=0.5, mode="gaussian")
+            single_net = inf(y, net).clone()
+            with parallel.window_sharding(force=True):
+                forced_net = inf(y, net).clone()
+            assert not parallel._ENABLED and not parallel._FORCE
+        ret[rank] = (torch.equal(single, forced), torch.equal(single_net, forced_net), n_toy, len(gathers), all(g[1] for g in gathers), len(verdicts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_rank_forced_sharding_runs_the_collective_path_bitwise():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_forced, args=(1, _free_port(), ret), nprocs=1, join=True)
+    same_toy, same_net, n_toy, n_all, all_async, n_verdicts = ret[0]
+    assert same_toy and same_net, "forced one-rank sharding must not change a bit"
+    assert n_toy == 9 and n_all > n_toy and all_async, "every round must have issued its all-gather"
+    assert n_verdicts >= 1, "the in-place probe must have reached a verdict"

@@ -318,3 +318,64 @@ def test_swin_block_moves_folded_into_kernels_bitwise():
     import swin_cases as sc
 
     assert sc.case_swin_fused_moves_bitwise(DEV)
+
+
+def test_rccl_one_rank_forced_sharding_bitwise_192():
+    """The N > 1 code on the hardware it was written for, with the one GPU a box has: backend "nccl" (= RCCL) initialised with ONE rank,
+    `parallel.window_sharding(force=True)` sends the 192^3 headline case (27 windows of 96^3) through the round schedule (a main round and the short tail rounds: variable
+    slot sizes), the padded window-major row buffer, the in-place all-gather probe, one asynchronous `all_gather_into_tensor` per round and `_Pending.wait` -- the result
+    must equal the unsharded one bit for bit, also with 8 windows per launch (several main rounds + a tail) and with the out-of-place gather form."""
+    import socket
+
+    import torch.distributed as dist
+
+    from monai_amd import parallel
+    from monai_amd.inferers import SlidingWindowInferer
+    from oracle import synthetic
+
+    net, _ = ec.make_net(1, 1, 5, DEV)
+    x = torch.from_numpy(synthetic.benchmark_volume(192))[None, None].to(DEV)
+    inf = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")
+    single = inf(x, net).clone()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    issued = []
+    real = parallel.WindowShard.gather_round
+
+    def counting(self, full, q, nb):
+        work = real(self, full, q, nb)
+        issued.append((q, nb, work is not None and work.keep is None))
+        return work
+
+    parallel.WindowShard.gather_round = counting
+    try:
+        assert dist.get_backend() == "nccl"
+        with parallel.window_sharding(force=True):
+            forced = inf(x, net).clone()
+            n_default = len(issued)
+            os.environ["MONAI_AMD_SW_BATCH"] = "8"          # 27 windows: main rounds of 8, then tail rounds of 2
+            try:
+                assert [n for _, n in parallel.window_shard(27).schedule(8)] == [8, 8, 2, 2, 2, 2, 2, 2]
+                forced8 = inf(x, net).clone()
+            finally:
+                del os.environ["MONAI_AMD_SW_BATCH"]
+            verdicts = parallel.inplace_gather_verdicts()
+            inplace_rounds = [i for i in issued if i[2]]
+            os.environ["MONAI_AMD_GATHER_INPLACE"] = "0"
+            try:
+                staged = inf(x, net).clone()
+            finally:
+                del os.environ["MONAI_AMD_GATHER_INPLACE"]
+        torch.cuda.synchronize()
+        assert n_default >= 1 and len(issued) >= n_default + 8, issued
+        assert len(verdicts) >= 1, "the in-place probe must have reached a verdict on RCCL"
+        print({"inplace_gather_ok": list(verdicts.values()), "rounds_issued": len(issued), "in_place": len(inplace_rounds)})
+        assert torch.equal(forced, single), "RCCL one-rank sharded result differs from the unsharded one"
+        assert torch.equal(forced8, single) and torch.equal(staged, single)
+        assert not parallel._ENABLED and not parallel._FORCE
+    finally:
+        parallel.WindowShard.gather_round = real
+        dist.destroy_process_group()
