@@ -333,17 +333,31 @@ def timed_steps(inferer, vol, net, steps: int, warmup: int, sync):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronise on both sides"""
     from monai_amd import _prof
 
+    from monai_amd import config
+
+    # rounds of windows in flight on k > 1 streams (monai_amd.config.sw_streams): a launch's begin-end interval then covers other streams' kernels too, so the timed region
+    # records only the spans that stay meaningful (blend, gather wait) and the per-kernel durations behind `roofline` / `conv_ms_per_step` come from ONE further step on one
+    # stream right after it (same process, data and binaries; scaled to `steps` so that every formula downstream reads the same) -- `kernel_spans` in the line says which
+    multi = config.sw_streams() > 1 and vol.is_cuda and getattr(net, "stream_private_workspace", False)
     out = None
     for _ in range(warmup):
         out = inferer(vol, net)
     sync()
-    _prof.start()
+    _prof.start(coarse=multi)
     t0 = time.perf_counter()
     for _ in range(steps):
         out = inferer(vol, net)
     sync()
     dt = time.perf_counter() - t0
-    return dt, _prof.stop(), out
+    spans = _prof.stop()
+    if multi:
+        _prof.start()
+        inferer(vol, net)
+        sync()
+        for k, v in _prof.stop().items():
+            if k not in spans:
+                spans[k] = {"launches": v["launches"] * steps, "ms_total": v["ms_total"] * steps, "ms_avg": v["ms_avg"], "work": v["work"] * steps}
+    return dt, spans, out
 
 
 def _traffic(roof: dict, key: str) -> None:
@@ -802,6 +816,9 @@ def main(argv=None):
             "checksum": float(out.double().sum().item()),
             "pmc": dict(_PMC_STATUS),
         }
+        if config.sw_streams() > 1 and not emulated and getattr(net, "stream_private_workspace", False):
+            line["streams"] = config.sw_streams()
+            line["kernel_spans"] = "one single-stream step after the timed region (with rounds on several streams a launch's begin-end interval covers other streams' kernels)"
         if line["roofline_hbm"] is not None and not emulated:
             cg = device_copy_gbps(dev)
             line["roofline_hbm"]["device_copy_GBps"] = cg
