@@ -149,10 +149,29 @@ def reference_self_spread(sd, vol_cpu, size: int, roi: int, procs: int, threads:
         rec = {"voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "label_flips": rep["argmax_mismatch_voxels"],
                "flips_outside_margin": rep["mismatch_outside_margin"], "layout": f"{p_}x{t_} vs {procs}x{threads} threads", "seconds": time.perf_counter() - t0}
         if product is not None:
+            from monai_amd import config
+
             inferer, net, vol = product
-            got = inferer(vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous(), net)
-            pr = oracle.label_parity(got, base, tol=1e-4)
+            sub_dev = vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
+            pr = oracle.label_parity(inferer(sub_dev, net), base, tol=1e-4)
             rec["product_max_abs_logit_diff"], rec["product_label_flips"] = pr["max_abs_logit_diff"], pr["argmax_mismatch_voxels"]
+            # the same voxels on the exact-fp32 kernels, and on the headline kernels with the InstanceNorm statistics from a separate two-pass kernel over the stored
+            # fp32 tensor (mean, then centred squares: the order ATen's CPU batch-norm uses) instead of the convolution epilogue's per-tile records: is the distance
+            # to the reference in the fp16 pieces, in the statistics, or in the summation order of the convolutions themselves?
+            saved_algo, saved_stats = config.CONV_ALGO, getattr(net, "fused_stats", True)
+            try:
+                config.CONV_ALGO = "fp32"
+                pe = oracle.label_parity(inferer(sub_dev, net), base, tol=1e-4)
+                rec["product_fp32_exact"] = [pe["max_abs_logit_diff"], pe["argmax_mismatch_voxels"]]
+                config.CONV_ALGO = saved_algo
+                if hasattr(net, "fused_stats"):
+                    net.fused_stats = False
+                    ps = oracle.label_parity(inferer(sub_dev, net), base, tol=1e-4)
+                    rec["product_two_pass_stats"] = [ps["max_abs_logit_diff"], ps["argmax_mismatch_voxels"]]
+            finally:
+                config.CONV_ALGO = saved_algo
+                if hasattr(net, "fused_stats"):
+                    net.fused_stats = saved_stats
         out[key] = rec
     return out
 
@@ -199,7 +218,7 @@ def cpu_baseline(size: int, roi: int, windows: int, vol: torch.Tensor, net, infe
         got = full_out if (full and full_out is not None) else inferer(sub, net)
     what = f"whole {size}^3, {nsub} windows" if full else f"{ext[0]}x{ext[1]}x{ext[2]} corner, {nsub} of {nfull} windows"
     if more is not None:            # the same reference for other arithmetic families of the product (extra.fp32_exact)
-        more["ref"], more["sub"], more["what"] = ref, sub, what
+        more["ref"], more["sub"], more["what"], more["s_per_window"] = ref, sub, what, dt / nsub
     parity = oracle.label_parity(got, ref, tol=1e-4)
     per_win = dt / nsub
     rec = {"value": size ** 3 / (nfull * per_win), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
@@ -333,31 +352,17 @@ def timed_steps(inferer, vol, net, steps: int, warmup: int, sync):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + device synchronise on both sides"""
     from monai_amd import _prof
 
-    from monai_amd import config
-
-    # rounds of windows in flight on k > 1 streams (monai_amd.config.sw_streams): a launch's begin-end interval then covers other streams' kernels too, so the timed region
-    # records only the spans that stay meaningful (blend, gather wait) and the per-kernel durations behind `roofline` / `conv_ms_per_step` come from ONE further step on one
-    # stream right after it (same process, data and binaries; scaled to `steps` so that every formula downstream reads the same) -- `kernel_spans` in the line says which
-    multi = config.sw_streams() > 1 and vol.is_cuda and getattr(net, "stream_private_workspace", False)
     out = None
     for _ in range(warmup):
         out = inferer(vol, net)
     sync()
-    _prof.start(coarse=multi)
+    _prof.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         out = inferer(vol, net)
     sync()
     dt = time.perf_counter() - t0
-    spans = _prof.stop()
-    if multi:
-        _prof.start()
-        inferer(vol, net)
-        sync()
-        for k, v in _prof.stop().items():
-            if k not in spans:
-                spans[k] = {"launches": v["launches"] * steps, "ms_total": v["ms_total"] * steps, "ms_avg": v["ms_avg"], "work": v["work"] * steps}
-    return dt, spans, out
+    return dt, _prof.stop(), out
 
 
 def _traffic(roof: dict, key: str) -> None:
@@ -467,7 +472,7 @@ def extra_fp32_exact(args, vol, net, inferer, sync, shared):
     return res
 
 
-def extra_config3(args, vol, sync, dev):
+def extra_config3(args, vol, sync, dev, shared=None):
     """BASELINE.json configs[3]: UNETR (ViT-B/16 encoder) over the same volume -- 2 timed steps, the attention kernel's matrix-core rate, and one
     window against the CPU oracle (oracle/unetr.py, bit-pinned to the reference by tests/golden/unetr.npz)"""
     import oracle
@@ -496,7 +501,9 @@ def extra_config3(args, vol, sync, dev):
     from oracle.sliding_window import dense_patch_starts, get_scan_interval
 
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
-    ext = sub_volume_extents(args.size, args.roi, 27)
+    # 125 windows (288^3) when the BasicUNet leg's measured CPU rate says the UNETR oracle (0.6x the flops per window) finishes them in about a minute, else 27
+    spw = (shared or {}).get("s_per_window")
+    ext = sub_volume_extents(args.size, args.roi, 125 if (spw is not None and 0.6 * spw * 125 < 75.0) else 27)
     rr = tuple(min(args.roi, e) for e in ext)
     sub = vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
     sub_cpu = sub.cpu()
@@ -519,6 +526,33 @@ def extra_config3(args, vol, sync, dev):
     res["parity"]["compared"] = f"{ext[0]}x{ext[1]}x{ext[2]} corner, {nsub} windows"
     res["cpu_baseline"] = {"value": float(args.size) ** 3 / (nfull * dt_cpu / nsub), "unit": "voxels/s", "cores": procs * threads, "kind": "port",
                            "sample": f"{nsub} of {nfull} windows, {procs}x{threads} of {ncpu} threads", "seconds": dt_cpu, "s_per_window": dt_cpu / nsub}
+    return res
+
+
+def extra_unet(args, vol, sync, dev):
+    """MONAI UNet (16..256, strides 2, two residual units) over the same volume -- 2 timed steps, and the complete inferer on a 27-window corner
+    against the CPU oracle of the same network (oracle/unet.py, pinned to the real reference by tests/golden/unet*.npz)"""
+    import oracle
+    from monai_amd.inferers import SlidingWindowInferer
+    from oracle import unet as ounet
+
+    net = build_net("unet", args.roi, dev)
+    inferer = SlidingWindowInferer(roi_size=(args.roi,) * 3, sw_batch_size=4, overlap=0.5, mode="gaussian", sigma_scale=0.125)
+    dt, _, _ = timed_steps(inferer, vol, net, 2, 1, sync)
+    res = {"workload": f"UNet 16..256 res2 5-class, same {args.size}^3 volume", "ms_per_step": 1e3 * dt / 2, "value": float(args.size) ** 3 / (dt / 2), "unit": "voxels/s"}
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    ext = sub_volume_extents(args.size, args.roi, 27)
+    rr = tuple(min(args.roi, e) for e in ext)
+    sub = vol[:, :, : ext[0], : ext[1], : ext[2]].contiguous()
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ref = oracle.sliding_window_inference(sub.cpu(), rr, 4, lambda w: ounet.unet_forward(sd, w, (16, 32, 64, 128, 256), (2, 2, 2, 2), 2), overlap=0.5, mode="gaussian", sigma_scale=0.125)
+        dt_cpu = time.perf_counter() - t0
+        got = inferer(sub, net)
+    res["parity"] = _short_parity(oracle.label_parity(got, ref, tol=1e-4), "split-fp16", full=False)
+    res["parity"]["compared"] = f"{ext[0]}x{ext[1]}x{ext[2]} corner, 27 windows"
+    res["cpu_s_per_window"] = dt_cpu / 27
     return res
 
 
@@ -656,7 +690,7 @@ def _rounded(obj, digits: int = 5):
 
 _EXTRA_DROP = ("steps", "warmup", "launches", "algorithmic_tflops", "cores", "kind", "tolerance", "traffic_src")
 LINE_BYTES_MAX = 5800      # the driver's parsed copy keeps a line of this size whole (the 16 KB line of round 4 was cut)
-_TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "config3", "attention"), ("extra", "config3", "cpu_baseline"), ("extra", "fp32_exact", "roofline"),
+_TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "unet", "workload"), ("extra", "config3", "attention"), ("extra", "config3", "cpu_baseline"), ("extra", "fp32_exact", "roofline"),
                ("conv_ms_per_step",), ("extra", "config4", "parity_vs_cpu_restatement"), ("upconv",))
 
 
@@ -816,9 +850,6 @@ def main(argv=None):
             "checksum": float(out.double().sum().item()),
             "pmc": dict(_PMC_STATUS),
         }
-        if config.sw_streams() > 1 and not emulated and getattr(net, "stream_private_workspace", False):
-            line["streams"] = config.sw_streams()
-            line["kernel_spans"] = "one single-stream step after the timed region (with rounds on several streams a launch's begin-end interval covers other streams' kernels)"
         if line["roofline_hbm"] is not None and not emulated:
             cg = device_copy_gbps(dev)
             line["roofline_hbm"]["device_copy_GBps"] = cg
@@ -857,7 +888,7 @@ def main(argv=None):
             line["cpu_baseline"] = None
         if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated and not forced:
             extra = {}
-            for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("config3", lambda: extra_config3(args, vol, sync, dev)),
+            for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("config3", lambda: extra_config3(args, vol, sync, dev, shared)), ("unet", lambda: extra_unet(args, vol, sync, dev)),
                              ("config4", lambda: extra_config4(dev))):
                 try:
                     extra[name] = fn()

@@ -10,29 +10,17 @@ from collections import defaultdict
 import torch
 
 _spans = None  # name -> list[(start_event, end_event, work)]
-_coarse = False
-_COARSE_NAMES = ("sw_blend", "sw_gather_wait")      # spans on the caller's stream while no other stream of the package has work in flight
 
 
-def start(coarse: bool = False) -> None:
-    """coarse=True: only the spans that stay meaningful when the rounds of windows run on several streams (a launch's begin-end interval then covers other
-    streams' kernels as well): the inferer keeps its multi-stream schedule.  With the full set active the inferer runs one stream, so every span is a kernel's own time."""
-    global _spans, _coarse
-    _spans, _coarse = defaultdict(list), bool(coarse)
-
-
-def active() -> bool:
-    return _spans is not None
-
-
-def overlapped_ok() -> bool:
-    return _coarse
+def start() -> None:
+    global _spans
+    _spans = defaultdict(list)
 
 
 def stop() -> dict:
     """-> {name: {"launches": n, "ms_avg": t, "ms_total": T, "work": total work units}} (synchronises)."""
-    global _spans, _coarse
-    spans, _spans, _coarse = _spans, None, False
+    global _spans
+    spans, _spans = _spans, None
     out = {}
     if spans:
         gpu = torch.cuda.is_available()
@@ -46,7 +34,7 @@ def stop() -> dict:
 
 @contextlib.contextmanager
 def span(name: str, work: float = 0.0):
-    if _spans is None or (_coarse and name not in _COARSE_NAMES):
+    if _spans is None:
         yield
         return
     if not torch.cuda.is_available():

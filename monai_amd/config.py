@@ -58,21 +58,6 @@ def upcat_fused() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no")
 
 
-# ---- window rounds in flight on several HIP streams ------------------------------------------------------------------------------
-# The fused engines' rounds of windows (inferers/utils.py) are independent until the blend: with SW_STREAMS = k > 1 round q runs on stream q mod k, each stream with
-# its own window buffer and activation workspace, so the HBM-bound kernels of one round (first layer, final 1x1, window gather) and the partly filled launches of the
-# deep levels run beside the matrix-core-bound convolutions of another.  Same kernels on the same data: bit-identical results.  None reads MONAI_AMD_SW_STREAMS.
-SW_STREAMS = None
-
-
-def sw_streams() -> int:
-    v = SW_STREAMS if SW_STREAMS is not None else os.environ.get("MONAI_AMD_SW_STREAMS", "1")
-    try:
-        return max(1, min(4, int(v)))
-    except (TypeError, ValueError):
-        return 1
-
-
 # ---- MaxPool3d(2) inside the producing convolution ------------------------------------------------------------------------------
 # BasicUNet's encoder: the split-precision convolution in front of a pooling leaves the pooled tensor itself (csrc/kernels/conv3d_h2.h, POOL) -- bit-identical logits.
 # False (or MONAI_AMD_POOL_FUSED=0 while None) keeps the pooling pass.

@@ -18,7 +18,6 @@ windows and one RCCL all-gather of the logits precedes the (replicated, determin
 
 from __future__ import annotations
 
-import contextlib
 import os
 import threading
 import warnings
@@ -324,26 +323,12 @@ def sliding_window_inference(
                 seg_shapes, zscales = [tuple(roi_size)], [None]
                 if count_map is not None:
                     proc_weights = [count_map]
-        # rounds in flight on several streams (config.sw_streams; fused engines on a GPU): round 0 runs on the caller's stream and every side stream waits for it --
-        # whatever the first round creates lazily on that stream (packed weights, composite UpCat weights, window tables) is complete before another stream reads it
-        lanes = _round_lanes(predictor, dev, win_buf, len(steps)) if (fused and not buffered_calls) else None
         for q, (w0, n) in steps:
             if fused and logits is None:       # sized from the engine's out_channels, not from a first prediction: a rank whose slot of the first round is empty allocates too
                 k = int(predictor.out_channels)
                 seg_shapes, zscales = [tuple(roi_size)], [None]
                 mosaic = None if buffered else _alloc_mosaic(predictor, shard, argmax_dtype, k, grid3, roi3, compute_dtype, dev)
                 logits = [mosaic if mosaic is not None else _alloc_logits(shard, nb, k, roi3, compute_dtype, dev)]
-            if lanes is not None:
-                with lanes.round(q) as wb:
-                    if n > 0:
-                        ops.window_extract(vol3, grid3, w0, n, roi3, wb[:n])
-                        if mosaic is not None:
-                            predictor.forward_into_windows(wb[:n], mosaic, w0)
-                        else:
-                            predictor.forward_into(wb[:n], logits[0][w0 : w0 + n])
-                    if shard.sharded:      # issued inside the round's stream: the collective waits for this round's kernels only
-                        pending += [shard.gather_round(lg, q, nb) for lg in logits]
-                continue
             if n > 0 and fused:
                 ops.window_extract(vol3, grid3, w0, n, roi3, win_buf[:n])
                 with _prof.span("sw_predictor"):
@@ -407,8 +392,6 @@ def sliding_window_inference(
 
         if logits is None:
             raise RuntimeError("monai_amd: no windows were processed")
-        if lanes is not None:
-            lanes.join()                           # the caller's stream waits for every side stream's last round
         with _prof.span("sw_gather_wait"):         # what the compute stream still has to wait for after its last round
             for work in pending:
                 work.wait()
@@ -469,59 +452,6 @@ def sliding_window_inference(
     if any(pad_size):
         kwargs.update({"pad_size": pad_size})
     return _pack_struct(finals, dict_keys)
-
-
-class _RoundLanes:
-    """k HIP streams for the rounds of one image: lane 0 is the caller's stream, round q runs on lane q mod k with that lane's own window buffer (the engines key
-    their activation workspaces by the current stream, so each lane has its own).  Round 0's end is an event every side lane waits for before its first round; `join`
-    makes the caller's stream wait for the side lanes.  Results are bit-identical to the one-stream loop: the same kernels on the same windows, no shared mutable state."""
-
-    def __init__(self, dev, win_buf, k: int):
-        self.main = torch.cuda.current_stream(dev)
-        self.streams = [self.main] + [_side_stream(dev, i) for i in range(1, k)]
-        self.bufs = [win_buf] + [torch.empty_like(win_buf) for _ in range(1, k)]
-        self.first = None                          # event at the end of round 0
-        self.started = [True] + [False] * (k - 1)
-
-    @contextlib.contextmanager
-    def round(self, q: int):
-        i = q % len(self.streams)
-        st = self.streams[i]
-        if not self.started[i]:
-            st.wait_event(self.first)
-            self.started[i] = True
-        with torch.cuda.stream(st):
-            yield self.bufs[i]
-        if q == 0:
-            self.first = torch.cuda.Event()
-            self.first.record(self.main)
-
-    def join(self) -> None:
-        for i, st in enumerate(self.streams[1:], 1):
-            if self.started[i]:
-                self.main.wait_stream(st)
-                self.bufs[i].record_stream(st)
-
-
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(dev, i: int):
-    key = (str(dev), i)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _SIDE_STREAMS[key]
-
-
-def _round_lanes(predictor, dev, win_buf, rounds: int):
-    """the lanes of `config.sw_streams()` streams, or None: one stream, not a GPU, a single round, an engine whose scratch buffers are shared between forwards
-    (`stream_private_workspace` not declared), or a timing run that needs un-overlapped kernel durations (_prof active with the full span set)"""
-    from .. import config
-
-    k = min(config.sw_streams(), rounds)
-    if k < 2 or dev.type != "cuda" or not getattr(predictor, "stream_private_workspace", False) or (_prof.active() and not _prof.overlapped_ok()):
-        return None
-    return _RoundLanes(dev, win_buf, k)
 
 
 def _buffered_batches(b, vol3, in_ch, grid3, starts, roi_size, roi3, num_win, sw_batch_size, predictor, process_fn, with_coord, imp, buffer_dim, buffer_steps,

@@ -194,7 +194,6 @@ class BasicUNet(nn.Module):
         self._plans: dict = {}      # (N, D, H, W, device) -> _Plan
         self._packed: dict = {}     # (layer name, cfg) -> (version key, packed weights)
         self.fused_stats = True     # take InstanceNorm statistics from the conv epilogue when the tile kernel runs
-        self.stream_private_workspace = True      # every activation / statistics buffer of a forward belongs to a _Plan, and plans are per stream: rounds may overlap (inferers/utils.py)
 
     def _build(self, in_channels, out_channels, fea, kw):
         self.conv_0 = _TwoConv(in_channels, fea[0], **kw)
@@ -254,11 +253,10 @@ class BasicUNet(nn.Module):
             raise RuntimeError(f"monai_amd.BasicUNet: a 2-D network takes one plane, got {tuple(x.shape)}")
         if min((h, w) if self.spatial_dims == 2 else (d, h, w)) < 16:
             raise RuntimeError(f"monai_amd.BasicUNet: window {d}x{h}x{w} is too small for four 2x poolings")
-        # one workspace per stream: rounds of windows in flight on several streams (inferers/utils.py: _RoundLanes) must not share activations
-        key = (n, d, h, w, str(x.device), torch.cuda.current_stream(x.device).cuda_stream if x.is_cuda else 0)
+        key = (n, d, h, w, str(x.device))
         plan = self._plans.get(key)
         if plan is None:
-            if len(self._plans) >= 8:
+            if len(self._plans) >= 4:
                 self._plans.clear()
             plan = self._plans[key] = _Plan(self, n, (d, h, w), x.device)
         plan.run(self, x, out)

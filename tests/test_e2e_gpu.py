@@ -379,31 +379,3 @@ def test_rccl_one_rank_forced_sharding_bitwise_192():
     finally:
         parallel.WindowShard.gather_round = real
         dist.destroy_process_group()
-
-
-def test_rounds_on_several_streams_bitwise_192():
-    """config.SW_STREAMS = 2 / 3: the rounds of windows run on several HIP streams (inferers/utils.py: _RoundLanes), each with its own window buffer and activation
-    workspace -- the same kernels on the same windows, so the 192^3 headline case (27 windows; 8 windows per launch -> 4 rounds) must come out bit-identical to the
-    one-stream loop, repeatedly (a race between the lanes would show as run-to-run differences)."""
-    from monai_amd import config
-    from monai_amd.inferers import SlidingWindowInferer
-    from oracle import synthetic
-
-    net, _ = ec.make_net(1, 1, 5, DEV)
-    x = torch.from_numpy(synthetic.benchmark_volume(192))[None, None].to(DEV)
-    inf = SlidingWindowInferer(roi_size=(96, 96, 96), sw_batch_size=4, overlap=0.5, mode="gaussian")
-    saved = config.SW_STREAMS
-    os.environ["MONAI_AMD_SW_BATCH"] = "8"
-    try:
-        config.SW_STREAMS = 1
-        one = inf(x, net).clone()
-        for k in (2, 3, 2):
-            config.SW_STREAMS = k
-            for _ in range(3):
-                got = inf(x, net)
-                torch.cuda.synchronize()
-                assert torch.equal(got, one), f"{k} streams: result differs from the one-stream loop"
-        assert len({key[-1] for key in net._plans}) >= 2, "the side streams must have had their own workspaces"
-    finally:
-        config.SW_STREAMS = saved
-        del os.environ["MONAI_AMD_SW_BATCH"]
