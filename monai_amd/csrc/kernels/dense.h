@@ -224,113 +224,9 @@ linear_h2_big_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, 
     }
 }
 
-// Round 5: the 128 x 128 tile with FOUR waves of 64 x 64 (2 x 2 accumulator tiles each) instead of eight of 32 x 64.  Counting LDS cycles explains the 0.29 of the
-// 8-wave form: per 16-wide chunk a wave reads 2 A + 4 B operand vectors for 6 matrix instructions -- with four resident workgroups per CU that is 1536 clocks of LDS
-// reads + 512 of staging writes per chunk round against 1536 clocks of matrix work per SIMD: the LDS, not the matrix pipe, is the longer pole.  A 64 x 64 wave tile
-// reads 4 A + 4 B vectors for 12 instructions (2/3 of the LDS bytes per flop).  Same packed weights, same staging layout, same arithmetic and summation order per
-// output element: bit-identical results.
-template <int ACT, bool RES>
-__global__ void __launch_bounds__(256)
-linear_h2_w4_kernel(const float* __restrict__ x, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias,
-                    const float* __restrict__ r, float* __restrict__ y, int M, int N, int K, int ntn, int nslab, const int* __restrict__ rowmap) {
-    constexpr int BM = DN_BM, BN = 2 * DN_BN;
-    constexpr int AV = 2 * BM;                               // uint4 per piece of an A tile: [k-group][row]
-    __shared__ uint4 as[2][2 * AV];
-    __shared__ uint4 bs[2][2 * DN_BT];                       // two 64-column slabs
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = (int)(lid % (unsigned)ntn), tm = (int)(lid / (unsigned)ntn);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int nkc = (K + DN_BK - 1) / DN_BK;
-
-    // A staging: thread (row = tid >> 1, k-group = tid & 1) converts 8 consecutive k of its row; B: one uint4 of each of the two slabs per thread
-    const int srow = tid >> 1, skg = tid & 1;
-    const bool rok = m0 + srow < M;
-    const float* xrow = x + (long long)(rok ? m0 + srow : 0) * K + 8 * skg;
-    const bool sok0 = 2 * tn < nslab, sok1 = 2 * tn + 1 < nslab;
-    const uint4* wsl0 = wp + (long long)(sok0 ? 2 * tn : 0) * nkc * DN_BT + tid;
-    const uint4* wsl1 = wp + (long long)(sok1 ? 2 * tn + 1 : 0) * nkc * DN_BT + tid;
-    f32x4 xa, xb;
-    uint4 wv0, wv1;
-#define MH_D4_ISSUE(C)                                                                                \
-    {                                                                                                 \
-        const int k_ = (C) * DN_BK + 8 * skg;                                                         \
-        xa = (rok && k_ + 4 <= K) ? *reinterpret_cast<const f32x4*>(xrow + (C) * DN_BK) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};     \
-        xb = (rok && k_ + 8 <= K) ? *reinterpret_cast<const f32x4*>(xrow + (C) * DN_BK + 4) : f32x4{0.0f, 0.0f, 0.0f, 0.0f}; \
-        wv0 = sok0 ? wsl0[(long long)(C) * DN_BT] : make_uint4(0u, 0u, 0u, 0u);                       \
-        wv1 = sok1 ? wsl1[(long long)(C) * DN_BT] : make_uint4(0u, 0u, 0u, 0u);                       \
-    }
-#define MH_D4_COMMIT(BUF)                                                                             \
-    {                                                                                                 \
-        _Float16 h_[8], l_[8];                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) { h2_split(xa[i], h_[i], l_[i]); h2_split(xb[i], h_[4 + i], l_[4 + i]); } \
-        f16x8 hv_, lv_;                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) { hv_[i] = h_[i]; lv_[i] = l_[i]; }             \
-        as[BUF][skg * BM + srow] = __builtin_bit_cast(uint4, hv_);                                    \
-        as[BUF][AV + skg * BM + srow] = __builtin_bit_cast(uint4, lv_);                               \
-        bs[BUF][tid] = wv0;                                                                           \
-        bs[BUF][DN_BT + tid] = wv1;                                                                   \
-    }
-
-    const int r32 = lane & 31, kg = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int abase = kg * BM + 64 * wr + r32;
-    const int bbase = wc * DN_BT + kg * DN_BN + r32;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][nb][i] = 0.0f;
-
-    MH_D4_ISSUE(0)
-    MH_D4_COMMIT(0)
-    __syncthreads();
-    for (int c = 0; c < nkc; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nkc) MH_D4_ISSUE(c + 1)
-        uint4 ah[2], al[2];
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { ah[mt] = as[buf][abase + 32 * mt]; al[mt] = as[buf][AV + abase + 32 * mt]; }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const uint4 bh = bs[buf][bbase + 32 * nb], bl = bs[buf][DN_BV + bbase + 32 * nb];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bh), acc[mt][nb], 0, 0, 0);
-                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[mt]), __builtin_bit_cast(f16x8, bh), acc[mt][nb], 0, 0, 0);
-                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[mt]), __builtin_bit_cast(f16x8, bl), acc[mt][nb], 0, 0, 0);
-            }
-        }
-        if (c + 1 < nkc) MH_D4_COMMIT(buf ^ 1)
-        __syncthreads();
-    }
-#undef MH_D4_COMMIT
-#undef MH_D4_ISSUE
-
-    const float inv_scale = wtail[0];
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int n = n0 + 64 * wc + 32 * nb + r32;
-        const float bn = (bias && n < N) ? bias[n] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int mi = m0 + 64 * wr + 32 * mt + 8 * (i >> 2) + 4 * kg + (i & 3);
-                const int m = (rowmap && mi < M) ? rowmap[mi] : mi;
-                if (mi < M && m >= 0 && n < N) {
-                    float v = fmaf(acc[mt][nb][i], inv_scale, bn);
-                    if (ACT == 1) v = gelu_erf(v);
-                    if (RES) v += r[(long long)m * N + n];
-                    y[(long long)m * N + n] = v;
-                }
-            }
-    }
-}
-
+// Measured and not kept (round 6, profiles/r06_linear_variants.txt, tools/experiments/r06_linear_variants.patch): two 16-wide chunks per barrier with whole-cache-line X
+// loads (bit-identical, same time), four chunks per barrier (128 KB of LDS, one workgroup per CU: 0.77 x), the A operand from global memory straight into registers
+// (conversion repeated by the two waves that share the rows: 0.77 x).  Round 5's four-wave 64 x 64 form (never wired into a launcher) went into the same patch file.
 // w [N][K] -> [column tile][chunk][piece][k-group][64 columns][8 k] fp16, zero padded in N and K; tail = {1 / scale, scale} (the scale
 // kernel of conv3d_h2.h).  One thread per (n, k) of the padded matrix.
 __global__ void __launch_bounds__(256)
