@@ -15,6 +15,7 @@ producers write straight into the concat buffer)."""
 
 from __future__ import annotations
 
+import threading
 import warnings
 from collections.abc import Sequence
 
@@ -27,16 +28,42 @@ __all__ = ["UNet", "Unet"]
 
 
 # --------------------------------------------------------------------------- parameter containers (reference names)
+_ADN_SPEC = threading.local()      # (activation name, its arguments, ordering) of the network under construction -- per thread, like basic_unet._BUILD
+
+
+def _parse_act(act):
+    """-> (name, arguments) of an activation the deferred-activation records can express: y > 0 ? y : slope * y (blocks/acti_norm.py:69-101 via layers/factories.py)"""
+    name, args = (act, {}) if isinstance(act, str) else (act[0], dict(act[1]) if len(act) > 1 else {})
+    if not isinstance(name, str):       # an activation given as a class / factory callable (blocks/acti_norm.py accepts both)
+        raise NotImplementedError("monai_amd.UNet: the HIP path takes the activation by name")
+    name = name.upper()
+    if name not in ("PRELU", "RELU", "LEAKYRELU"):
+        raise NotImplementedError(f"monai_amd.UNet: activation {act!r} is not on the HIP path (PReLU / ReLU / LeakyReLU are)")
+    return name, args
+
+
 class _ADN(nn.Module):
+    """ADN parameter holder: the modules are registered in the order of `adn_ordering` (as the reference's `for item in ordering`), which is also the order of the
+    state_dict keys; Dropout(0.0) is a module without parameters (UNet always passes dropout=0.0 -> the reference creates it wherever "D" appears)"""
+
     def __init__(self, channels: int, affine):
         super().__init__()
-        # `affine`: bool -> InstanceNorm3d(affine); ("batch", kwargs) -> BatchNorm3d (evaluated with its running statistics)
-        if isinstance(affine, tuple):
-            self.N = nn.BatchNorm3d(channels, **affine[1])
-        else:
-            self.N = nn.InstanceNorm3d(channels, affine=affine)
-        self.D = nn.Dropout(0.0)
-        self.A = nn.PReLU()
+        name, args, ordering = getattr(_ADN_SPEC, "v", ("PRELU", {}, "NDA"))
+        for item in ordering:
+            if item == "N":
+                # `affine`: bool -> InstanceNorm3d(affine); ("batch", kwargs) -> BatchNorm3d (evaluated with its running statistics)
+                self.N = nn.BatchNorm3d(channels, **affine[1]) if isinstance(affine, tuple) else nn.InstanceNorm3d(channels, affine=affine)
+            elif item == "D":
+                self.D = nn.Dropout(0.0)
+            elif item == "A":
+                if name == "PRELU":
+                    self.A = nn.PReLU(**{k: v for k, v in args.items() if k in ("num_parameters", "init")})
+                elif name == "RELU":
+                    self.A = nn.ReLU(inplace=bool(args.get("inplace", False)))
+                else:
+                    self.A = nn.LeakyReLU(negative_slope=float(args.get("negative_slope", 0.01)), inplace=bool(args.get("inplace", False)))
+        # activation BEFORE the normalisation ("AN", "ADN", "DAN", "AND"): the statistics are those of the activated tensor
+        self.act_first = "A" in ordering and "N" in ordering and ordering.index("A") < ordering.index("N")
 
 
 class _Convolution(nn.Module):
@@ -47,7 +74,7 @@ class _Convolution(nn.Module):
             self.conv = nn.ConvTranspose3d(cin, cout, 3, stride=strides, padding=1, output_padding=strides - 1, bias=bias)
         else:
             self.conv = nn.Conv3d(cin, cout, 3, stride=strides, padding=1, bias=bias)
-        if not conv_only:
+        if not conv_only and getattr(_ADN_SPEC, "v", ("PRELU", {}, "NDA"))[2]:
             self.adn = _ADN(cout, affine)
 
 
@@ -102,14 +129,17 @@ class UNet(nn.Module):
             raise ValueError("the length of `kernel_size` should equal to `dimensions`.")
         if isinstance(up_kernel_size, Sequence) and len(up_kernel_size) != spatial_dims:
             raise ValueError("the length of `up_kernel_size` should equal to `dimensions`.")
-        act_name = act if isinstance(act, str) else act[0]
-        if not isinstance(act_name, str):       # an activation given as a class / factory callable (blocks/acti_norm.py accepts both)
-            raise NotImplementedError("monai_amd.UNet: the HIP path takes the activation by name")
-        act_name = act_name.upper()
+        act_name, act_args = _parse_act(act)
         norm_name, norm_args = (norm, {}) if isinstance(norm, str) else (norm[0], norm[1] if len(norm) > 1 else {})
-        if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or act_name != "PRELU"
-                or str(norm_name).upper() not in ("INSTANCE", "BATCH") or adn_ordering != "NDA" or any(int(s) not in (1, 2) for s in strides)):
-            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU + instance / batch norm, strides 1/2, 'NDA' (dropout is inference-inert)")
+        ordering = str(adn_ordering).upper()
+        if any(ch not in "NDA" for ch in ordering):
+            raise ValueError(f"ordering must be a string of {{'A': None, 'D': None, 'N': None}}, got {[ch for ch in ordering if ch not in 'NDA'][0]} in it.")   # acti_norm.py:98-99
+        if len(set(ordering)) != len(ordering):
+            raise KeyError(f"attribute '{[ch for ch in ordering if ordering.count(ch) > 1][0]}' already exists")      # nn.Module.add_module on the repeated letter
+        if (spatial_dims != 3 or kernel_size not in (3, (3, 3, 3), [3, 3, 3]) or up_kernel_size not in (3, (3, 3, 3), [3, 3, 3])
+                or str(norm_name).upper() not in ("INSTANCE", "BATCH") or any(int(s) not in (1, 2) for s in strides)):
+            raise NotImplementedError("monai_amd.UNet: the HIP path covers 3-D, kernel 3, PReLU / ReLU / LeakyReLU + instance / batch norm in any `adn_ordering`, strides 1/2 "
+                                      "(dropout is inference-inert)")
         self.dimensions, self.in_channels, self.out_channels = spatial_dims, in_channels, out_channels
         self.channels, self.strides, self.num_res_units, self.bias = tuple(channels), tuple(int(s) for s in strides), num_res_units, bias
         self.kernel_size, self.up_kernel_size, self.act, self.norm, self.dropout, self.adn_ordering = kernel_size, up_kernel_size, act, norm, dropout, adn_ordering
@@ -117,7 +147,16 @@ class UNet(nn.Module):
         if str(norm_name).upper() == "BATCH":       # eval-mode BatchNorm is a per-channel affine map: it IS a {alpha, beta} record, no statistics pass
             affine = ("batch", {k: v for k, v in norm_args.items() if k in ("eps", "momentum", "affine", "track_running_stats")})
         self.features = (channels[0],)
+        _ADN_SPEC.v = (act_name, act_args, ordering)
+        try:
+            self._create_model(in_channels, out_channels, num_res_units, bias, affine)
+        finally:
+            del _ADN_SPEC.v
+        self._packed: dict = {}
+        self._slopes: dict = {}
+        self._stats = None
 
+    def _create_model(self, in_channels, out_channels, num_res_units, bias, affine) -> None:
         def down(cin, cout, s):
             if num_res_units > 0:
                 return _ResidualUnit(cin, cout, s, num_res_units, bias, affine=affine)
@@ -142,9 +181,6 @@ class UNet(nn.Module):
             return nn.Sequential(d, _SkipConnection(sub), u)
 
         self.model = create(in_channels, out_channels, self.channels, self.strides, True)
-        self._packed: dict = {}
-        self._slopes: dict = {}
-        self._stats = None
 
     # ---- helpers -----------------------------------------------------------------------------------
     def _packed_weight(self, conv: nn.Conv3d, cfg: int) -> torch.Tensor:
@@ -156,16 +192,32 @@ class UNet(nn.Module):
             self._packed[(id(conv), cfg)] = hit
         return hit[1]
 
-    def _slope(self, prelu: nn.PReLU) -> float:
-        w = prelu.weight
+    def _slope(self, adn: _ADN) -> float:
+        """the activation of an ADN as the slope of `y > 0 ? y : slope * y`: PReLU's weight, LeakyReLU's negative_slope, 0 for ReLU, 1 (identity) without an activation"""
+        act = getattr(adn, "A", None)
+        if act is None:
+            return 1.0
+        if isinstance(act, nn.ReLU):
+            return 0.0
+        if isinstance(act, nn.LeakyReLU):
+            return float(act.negative_slope)
+        w = act.weight
         if w.numel() != 1:
             raise NotImplementedError("monai_amd.UNet: per-channel PReLU is not on the HIP path")
         key = (w.data_ptr(), w._version)
-        hit = self._slopes.get(id(prelu))
+        hit = self._slopes.get(id(act))
         if hit is None or hit[0] != key:
             hit = (key, float(w.detach().cpu()))     # one host read per weight version
-            self._slopes[id(prelu)] = hit
+            self._slopes[id(act)] = hit
         return hit[1]
+
+    def _act_record(self, slope: float, n: int, c: int, device) -> torch.Tensor:
+        """[n, c, 4] records {1, 0, slope, 0}: the bare activation (no normalisation in front of it; no magnitude bound)"""
+        hit = self._packed.get(("act", slope, n, c, str(device)))
+        if hit is None:
+            hit = torch.tensor([1.0, 0.0, slope, 0.0], dtype=torch.float32, device=device).repeat(n, c, 1).contiguous()
+            self._packed[("act", slope, n, c, str(device))] = hit
+        return hit
 
     def _bn_record(self, bn: nn.BatchNorm3d, slope: float, n: int) -> torch.Tensor:
         """Eval-mode BatchNorm3d + PReLU as the consumer-side record [n, C, 4] = {alpha, beta, slope, 0}: alpha = weight / sqrt(running_var
@@ -186,10 +238,11 @@ class UNet(nn.Module):
         return hit[1].unsqueeze(0).expand(n, -1, -1).contiguous()
 
     def _has_batchnorm(self) -> bool:
-        """BatchNorm anywhere in the net (its folded records carry no magnitude bounds) -- the module tree is walked once, not per convolution launch"""
+        """BatchNorm anywhere in the net, or ADN blocks without a normalisation (their records carry no magnitude bounds: the exact-fp32 convolutions take them) --
+        the module tree is walked once, not per convolution launch"""
         hit = self.__dict__.get("_bn_cached")
         if hit is None:
-            hit = self.__dict__["_bn_cached"] = any(isinstance(m, nn.BatchNorm3d) for m in self.modules())
+            hit = self.__dict__["_bn_cached"] = any(isinstance(m, nn.BatchNorm3d) or (isinstance(m, _ADN) and not hasattr(m, "N")) for m in self.modules())
         return hit
 
     def _stats_buf(self, floats: int, device) -> torch.Tensor:
@@ -217,7 +270,7 @@ class UNet(nn.Module):
             # records written by instnorm_finalize carry magnitude bounds (the split-precision kernel needs them); folded BatchNorm records do not
             bounded = x_nrm is not None and not self._has_batchnorm()
             cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=bounded) if (s == 1 and not tiny) else 0
-            wants_stats = hasattr(unit, "adn") and not isinstance(unit.adn.N, nn.BatchNorm3d)
+            wants_stats = hasattr(unit, "adn") and hasattr(unit.adn, "N") and not isinstance(unit.adn.N, nn.BatchNorm3d) and not unit.adn.act_first
             stats_tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w) if (s == 1 and not tiny and wants_stats) else 0
             if s == 1 and not tiny:
                 stats = self._stats_buf(n * cout * stats_tiles * 3, x.device) if stats_tiles else None
@@ -226,15 +279,23 @@ class UNet(nn.Module):
                 ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, s)
         if not hasattr(unit, "adn"):
             return out, None
-        if isinstance(unit.adn.N, nn.BatchNorm3d):
-            return out, self._bn_record(unit.adn.N, self._slope(unit.adn.A), n)
+        adn = unit.adn
+        slope = self._slope(adn)
+        if not hasattr(adn, "N"):                   # "A" / "DA" / "D": the bare activation as a record
+            return out, (self._act_record(slope, n, cout, x.device) if slope != 1.0 else None)
+        if adn.act_first:                           # "AN...": activate, THEN normalise -- the statistics are those of the activated tensor
+            if slope != 1.0:
+                out = ops.add_act(out, self._act_record(slope, n, cout, x.device), None, None, 1.0, torch.empty_like(out))
+            stats_tiles, slope = 0, 1.0
+        if isinstance(adn.N, nn.BatchNorm3d):
+            return out, self._bn_record(adn.N, slope, n)
         if not stats_tiles:
             stats_tiles = ops.instnorm_stat_tiles(*out.shape[2:])
             stats = self._stats_buf(n * cout * stats_tiles * 3, x.device)
             ops.instnorm_stats(out, stats)
         nrm = torch.empty((n, cout, 4), dtype=torch.float32, device=x.device)
         inorm = unit.adn.N
-        ops.instnorm_finalize(stats, stats_tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, self._slope(unit.adn.A), nrm)
+        ops.instnorm_finalize(stats, stats_tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, slope, nrm)
         return out, nrm
 
     def _residual_unit(self, ru: _ResidualUnit, x, x_nrm, dst):

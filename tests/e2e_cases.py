@@ -447,28 +447,43 @@ UNET_CFGS = {   # tests/golden/make_golden_unet.py
 }
 
 
+# activations / `adn_ordering` beyond the default "NDA" + PReLU (tests/golden/make_golden_unet_variants.py -> unet_variants.npz): norm-then-activation in another
+# spelling, activation BEFORE the normalisation (statistics of the activated tensor), no normalisation at all, batch norm behind a ReLU
+UNET_VARIANTS = {
+    "relu_nad": dict(channels=(8, 16, 32), strides=(2, 2), num_res_units=1, shape=(1, 1, 16, 16, 16), seed=41, kw=dict(act="RELU", adn_ordering="NAD")),
+    "lrelu_an": dict(channels=(8, 16, 32), strides=(2, 2), num_res_units=2, shape=(2, 1, 16, 16, 24), seed=42,
+                     kw=dict(act=("leakyrelu", {"negative_slope": 0.2}), adn_ordering="AN", norm=("instance", {"affine": True}))),
+    "prelu_a": dict(channels=(8, 16, 32), strides=(2, 1), num_res_units=0, shape=(1, 1, 16, 12, 20), seed=43, kw=dict(adn_ordering="A")),
+    "relu_adn_batch": dict(channels=(8, 16, 32), strides=(2, 2), num_res_units=1, shape=(1, 1, 16, 16, 16), seed=44, norm="batch", kw=dict(act="relu", adn_ordering="ADN")),
+}
+UNET_CFGS_ALL = {**UNET_CFGS, **UNET_VARIANTS}
+
+
 def unet_kwargs(name):
-    c = UNET_CFGS[name]
+    c = UNET_CFGS_ALL[name]
     kw = dict(spatial_dims=3, in_channels=1, out_channels=3, channels=c["channels"], strides=c["strides"], num_res_units=c["num_res_units"])
     if "norm" in c:
         kw["norm"] = c["norm"]
+    kw.update(c.get("kw", {}))
     return kw
 
 
 def perturb_unet(net, name):
     """PReLU slopes distinguishable from the default; batch norm: non-trivial running statistics and affine parameters"""
-    gen = torch.Generator().manual_seed(600 + UNET_CFGS[name]["seed"])
+    cfg = UNET_CFGS_ALL[name]
+    affine = "norm" in cfg or "norm" in cfg.get("kw", {})
+    gen = torch.Generator().manual_seed(600 + cfg["seed"])
     with torch.no_grad():
         for k, v in net.state_dict().items():
             if k.endswith("adn.A.weight"):
                 v.fill_(0.1 + 0.01 * (len(k) % 7))
-            elif "norm" in UNET_CFGS[name] and k.endswith("running_mean"):
+            elif "norm" in cfg and k.endswith("running_mean"):
                 v.copy_(0.1 * torch.randn(v.shape, generator=gen))
-            elif "norm" in UNET_CFGS[name] and k.endswith("running_var"):
+            elif "norm" in cfg and k.endswith("running_var"):
                 v.copy_(0.75 + 0.5 * torch.rand(v.shape, generator=gen))
-            elif "norm" in UNET_CFGS[name] and k.endswith("adn.N.weight"):
+            elif affine and k.endswith("adn.N.weight"):
                 v.copy_(1.0 + 0.2 * torch.randn(v.shape, generator=gen))
-            elif "norm" in UNET_CFGS[name] and k.endswith("adn.N.bias"):
+            elif affine and k.endswith("adn.N.bias"):
                 v.copy_(0.1 * torch.randn(v.shape, generator=gen))
     return net
 
@@ -486,7 +501,7 @@ def make_unet(name, device=None):
     """The reference-seeded UNet of tests/golden/unet.npz: same seed -> same init; PReLU slopes set as the generator did."""
     from monai_amd.networks.nets import UNet
 
-    c = UNET_CFGS[name]
+    c = UNET_CFGS_ALL[name]
     torch.manual_seed(c["seed"])
     net = UNet(**unet_kwargs(name))
     init = _full_digest(net.state_dict())
@@ -494,17 +509,17 @@ def make_unet(name, device=None):
     return (net.to(device) if device is not None else net), init
 
 
-def case_unet_vs_golden(device, names=("res2", "plain", "mixed", "batch")):
-    """MONAI UNet (residual units / plain / stride-1 level) against the reference's own output: keys, init digest, logits."""
-    g = np.load(os.path.join(GOLDEN, "unet.npz"))
+def case_unet_vs_golden(device, names=("res2", "plain", "mixed", "batch"), golden="unet.npz"):
+    """MONAI UNet (residual units / plain / stride-1 level; golden="unet_variants.npz": the UNET_VARIANTS) against the reference's own output: keys, init digest, logits."""
+    g = np.load(os.path.join(GOLDEN, golden))
     out = {}
     for name in names:
         net, init = make_unet(name)
         assert list(net.state_dict().keys()) == list(g[f"{name}_keys"]), name
         assert init == str(g[f"{name}_init_sha256"]), f"{name}: same seed must give the reference's weights"
         net = net.to(device)
-        torch.manual_seed(100 + UNET_CFGS[name]["seed"])
-        x = torch.rand(UNET_CFGS[name]["shape"])
+        torch.manual_seed(100 + UNET_CFGS_ALL[name]["seed"])
+        x = torch.rand(UNET_CFGS_ALL[name]["shape"])
         y = net(x.to(device)).cpu()
         r = report(y, torch.from_numpy(g[f"{name}_out"]))
         assert r["max_abs"] < LOGIT_TOL, (name, r)

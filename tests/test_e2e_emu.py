@@ -37,6 +37,14 @@ def test_unet_vs_reference(emu):
     print(ec.case_unet_vs_golden("cpu"))
 
 
+def test_unet_activations_and_adn_orderings_vs_reference(emu):
+    """UNet with ReLU / LeakyReLU, `adn_ordering` "NAD" / "AN" (activation before the normalisation) / "A" (no normalisation) / "ADN" + batch norm: the reference's own
+    logits (tests/golden/unet_variants.npz), state_dict keys in the reference's order"""
+    import e2e_cases
+
+    print(ec.case_unet_vs_golden("cpu", names=tuple(e2e_cases.UNET_VARIANTS), golden="unet_variants.npz"))
+
+
 @pytest.mark.heavy_emu
 def test_basic_unet_with_inplane_winograd(emu, monkeypatch):
     """The whole BasicUNet window path with every eligible 3x3x3 conv on the in-plane Winograd configuration."""
