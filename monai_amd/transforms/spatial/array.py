@@ -16,7 +16,7 @@ from ...utils.misc import ensure_tuple
 from ... import ops
 from ... import config
 from ..lazy import LazyCapable, materialize, peek_affine, peek_shape, push_pending
-from .functional import _mode_name, _pad_name, resample_plan, spatial_resample
+from .functional import _mode_name, _pad_name, memo, resample_plan, spatial_resample
 
 __all__ = ["SpatialResample", "Spacing", "Resample"]
 
@@ -99,6 +99,11 @@ class SpatialResample(LazyCapable):
         return out
 
 
+def _affine_bytes(a) -> bytes:
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    return a.astype(np.float64, copy=False).tobytes() + bytes(str(a.shape), "ascii")
+
+
 class Spacing(LazyCapable):
     """Resample the image to voxel size ``pixdim`` (array.py:338-546)."""
 
@@ -137,6 +142,22 @@ class Spacing(LazyCapable):
         else:
             warnings.warn("`data_array` is not of type MetaTensor, assuming affine to be identity.")
             input_affine = np.eye(sr + 1, dtype=np.float64)
+        ac = self.sp_resample.align_corners if align_corners is None else align_corners
+        scale_extent = self.scale_extent if scale_extent is None else scale_extent
+        if not ac and scale_extent:
+            warnings.warn("align_corners=False is not compatible with scale_extent=True.")
+        # the target grid is a pure function of (shape, affine, this transform's parameters): computed once per combination (functional.memo)
+        key = ("spacing", tuple(int(v) for v in original_shape), _affine_bytes(input_affine), self.pixdim.tobytes(), self.min_pixdim.tobytes(), self.max_pixdim.tobytes(),
+               bool(self.diagonal), bool(scale_extent))
+        new_affine, output_shape = memo(key, lambda: self._target_grid(original_shape, sr, input_affine, scale_extent))
+        new_affine = new_affine.copy()
+        actual_shape = list(output_shape) if output_spatial_shape is None else output_spatial_shape
+        out = self.sp_resample(data_array, dst_affine=torch.as_tensor(new_affine), spatial_size=actual_shape, mode=mode, padding_mode=padding_mode,
+                               align_corners=align_corners, dtype=dtype, lazy=lazy_)
+        return self._recomputed_affine(out, original_shape, actual_shape, sr, lazy_)
+
+    def _target_grid(self, original_shape, sr, input_affine, scale_extent):
+        """(new affine, output shape) of array.py:497-527: pixdim clamped into [min_pixdim, max_pixdim] -> zoom_affine -> compute_shape_offset"""
         affine_ = to_affine_nd(sr, input_affine)
         out_d = self.pixdim[:sr].copy()
         if out_d.size < sr:
@@ -149,16 +170,12 @@ class Spacing(LazyCapable):
             if mn > mx:
                 raise ValueError(f"min_pixdim is larger than max_pixdim at dim {idx}: min {mn} max {mx} out {target}.")
             out_d[idx] = _d if (mn - AFFINE_TOL) <= _d <= (mx + AFFINE_TOL) else target
-        ac = self.sp_resample.align_corners if align_corners is None else align_corners
-        scale_extent = self.scale_extent if scale_extent is None else scale_extent
-        if not ac and scale_extent:
-            warnings.warn("align_corners=False is not compatible with scale_extent=True.")
         new_affine = zoom_affine(affine_, out_d, diagonal=self.diagonal)
         output_shape, offset = compute_shape_offset(original_shape, affine_, new_affine, scale_extent)
         new_affine[:sr, -1] = offset[:sr]
-        actual_shape = list(output_shape) if output_spatial_shape is None else output_spatial_shape
-        out = self.sp_resample(data_array, dst_affine=torch.as_tensor(new_affine), spatial_size=actual_shape, mode=mode, padding_mode=padding_mode,
-                               align_corners=align_corners, dtype=dtype, lazy=lazy_)
+        return new_affine, tuple(int(v) for v in output_shape)
+
+    def _recomputed_affine(self, out, original_shape, actual_shape, sr, lazy_):
         if self.recompute_affine and is_meta(out):
             # array.py:538-542: the output affine becomes scale_affine(original shape, actual shape) -- the centred scaling between the two voxel
             # grids (transforms/utils.py:2093-2113), which reflects the quantisation of the output shape; host algebra on a 4 x 4 matrix
