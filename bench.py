@@ -10,7 +10,7 @@ all 1000 windows, (N > 1: RCCL all-gather of the per-window logits,) blend + nor
 ``create_test_image_3d`` phantom of SURVEY.md 8(d) config 1, restated bit-identically in oracle/synthetic.py -- is resident
 in HBM before the timed region.  N > 1 shards the windows of the SAME volume over the ranks (strong scaling, config 2 of
 BASELINE.json).  Rank 0 prints ONE JSON line of numbers and short labels (< 6 KB: the driver keeps a bounded tail of stdout); what every
-key means, how it is measured and which caveats apply is written down ONCE in DESIGN.md section 6.3 ("the bench line"), not in the line:
+key means, how it is measured and which caveats apply is written down ONCE in DESIGN.md section 7 ("the bench line"), not in the line:
 
   parity              the headline family's whole-volume parity against the CPU oracle (134 217 728 voxels x 5 logits), at top level
   reference_self_spread   the oracle against ITSELF (1 thread vs the pool's thread layout; oneDNN off vs on): what "bit-exact argmax" means for the reference
@@ -100,7 +100,7 @@ def HOST_LAYOUT_UNDER_QUOTA(cpus: int):
 
 
 def _short_parity(rep: dict, family: str, full: bool = True) -> dict:
-    """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py, DESIGN.md 6.3); full=False: the extras' brief form"""
+    """the numbers of oracle.label_parity under short keys (the rule itself: oracle/parity.py, DESIGN.md 7); full=False: the extras' brief form"""
     out = {"family": family, "voxels": rep["voxels"], "max_abs_logit_diff": rep["max_abs_logit_diff"], "tolerance": rep["tolerance"],
            "argmax_mismatch_voxels": rep["argmax_mismatch_voxels"], "mismatch_outside_margin": rep["mismatch_outside_margin"],
            "dice_deficit": rep["dice_deficit"], "ok": rep["ok"]}      # dice_deficit = 1 - min class Dice from the integer counts: 0.0 iff the label maps are identical
@@ -375,7 +375,7 @@ def _traffic(roof: dict, key: str) -> None:
 def conv_roofline(spans, steps: int, ms: float, roi: int):
     """the 3x3x3 convolution configuration with the largest share of the step, priced against the peak of the matrix instruction it issues:
     achieved = matrix-core flops ISSUED per launch / average launch time (HIP events in the timed region); the convolution's own flops
-    (2 * 27 * Cin * Cout per voxel) are `algorithmic_tflops` (DESIGN.md 6.3)"""
+    (2 * 27 * Cin * Cout per voxel) are `algorithmic_tflops` (DESIGN.md 7)"""
     from monai_amd import ops as _ops
 
     convs = {k: v for k, v in spans.items() if k.startswith("conv3d_k3/")}

@@ -47,7 +47,7 @@
 // every staging piece is branch-free (zeroed padding cells and dump cells instead of masks, clamped pointer advance instead of
 // tail branches) and is dealt out over the 81 MFMA gaps of the step by sched_group_barrier: 10.7 -> 9.0-9.4 ms for 32 -> 32
 // channels at 96^3 x 64 windows (the fp32 Winograd kernel: 17.5 ms; the matrix pipe alone at the sustained clock: 4.7 ms).
-// Round 3 (profiles/r03_h2_*.txt, r03_pmc_h2.txt): the region is 16 x 16 or 8 x 32 (H2Geo<WIDE>, whichever covers the plane with fewer regions);
+// Round 3 (DESIGN_HISTORY 4.1, profiles/r03_h2_*.txt, r03_pmc_h2.txt): the region is 16 x 16 or 8 x 32 (H2Geo<WIDE>, whichever covers the plane with fewer regions);
 // the epilogue is four branch-free pieces in taps 3, 4, 6, 7 of the next plane's first step (raw buffer stores whose out-of-range lanes the hardware drops);
 // the input records sit in LDS per channel quad and are read in the previous step's last tap; the input planes come in by raw buffer loads (no vector
 // address arithmetic): 138 -> 91 vector instructions per step, 8.2-8.5 ms for the same launch, matrix pipe busy 0.71 of the cycles (0.61) -- and a lower

@@ -1,4 +1,4 @@
-# round 4: the other networks through the same inferer and volume (record for DESIGN 6.0), and the bench line with the extras (no CPU leg) after the last bench.py change
+# round 4: the other networks through the same inferer and volume (record for DESIGN_HISTORY 6.0), and the bench line with the extras (no CPU leg) after the last bench.py change
 export TMPDIR=/tmp
 O=gpurun_out/r4nets; mkdir -p $O
 timeout 600 python bench.py --steps 2 --warmup 1 --cpu-windows 0 > $O/bench_extras.json 2> $O/bench_extras.err

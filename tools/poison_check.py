@@ -1,7 +1,7 @@
 """Uninitialised-read detector for the product path: run the same inference with every ``torch.empty`` buffer pre-filled with
 different bit patterns (NaN, a huge finite value, zeros) and compare the results BITWISE.  A kernel that reads a cell it (or its
 producer) never wrote shows up as a difference between the patterns -- the same defect that shows up on a GPU as a run-to-run
-difference when the caching allocator hands out different garbage (the run-to-run mismatch recorded in round 3).
+difference when the caching allocator hands out different garbage (DESIGN_HISTORY 6.0: the run-to-run mismatch recorded in round 3).
 
 Runs on an MI355X (``--device cuda``) and on the build container through the SIMT emulator (``--device cpu``, small sizes).
 Test infrastructure: nothing in monai_amd/ imports it."""

@@ -1,6 +1,6 @@
-"""Pre-processing kernels in front of the path on one 512^3 CT-like volume resident in HBM: ScaleIntensityRange,
+"""Pre-processing kernels in front of the path (DESIGN_HISTORY.md 4.4) on one 512^3 CT-like volume resident in HBM: ScaleIntensityRange,
 the CropForeground box + crop, Orientation (pure flips and a real axis permutation).  Prints one JSON document with per-op times and
-algorithmic GB/s (the byte counts of DESIGN.md section 4's table) next to a device-to-device copy of the same volume."""
+algorithmic GB/s (the byte counts of DESIGN_HISTORY.md section 4's table) next to a device-to-device copy of the same volume."""
 import json
 import os
 import sys

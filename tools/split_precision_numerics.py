@@ -1,4 +1,4 @@
-"""Feasibility study for DESIGN.md section 8 item 1 (no GPU needed): run the oracle BasicUNet with every 3x3x3
+"""Feasibility study for DESIGN_HISTORY.md section 8 item 1 (no GPU needed): run the oracle BasicUNet with every 3x3x3
 convolution evaluated in bf16 split-precision arithmetic -- both operands split into hi + mid + lo bf16 pieces, the
 six largest piece products accumulated in fp32 -- and compare logits / argmax with the plain fp32 forward.
 Products of two bf16 values are exact in fp32, so F.conv3d on the pieces (fp32 accumulation) is the arithmetic a

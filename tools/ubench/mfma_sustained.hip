@@ -1,6 +1,6 @@
 // Micro-benchmark (development aid): what does the fp16 matrix pipe of an MI355X SUSTAIN?  The 2.5 PFLOP/s dense figure is 256 CUs x 4 SIMDs x
 // 1024 FLOP/clk at 2.4 GHz; mfma_f16.hip reaches 2.0 PF in 0.5 ms bursts on smooth operands.  The split-precision convolution (conv3d_h2.h) runs
-// for seconds on activation data, and the chip lowers its clock under it.  This program runs NOTHING BUT back-to-back
+// for seconds on activation data, and the chip lowers its clock under it (DESIGN_HISTORY 4.1).  This program runs NOTHING BUT back-to-back
 // v_mfma_f32_32x32x16_f16 (operands in registers, no memory traffic) for ~0.5 s per configuration and reports the rate and the clock of every
 // launch: the rate on random operands is the practical ceiling for any kernel built on this instruction.
 //   operand data: zero | smooth (0.001 tid, 0.5) | random normal fp16 | split pieces (a "hi" piece ~N(0,1) and a "lo" piece 2^-11 of it, alternating)
