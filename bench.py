@@ -690,8 +690,8 @@ def _rounded(obj, digits: int = 5):
 
 _EXTRA_DROP = ("steps", "warmup", "launches", "algorithmic_tflops", "cores", "kind", "tolerance", "traffic_src")
 LINE_BYTES_MAX = 5800      # the driver's parsed copy keeps a line of this size whole (the 16 KB line of round 4 was cut)
-_TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "unet", "workload"), ("extra", "config3", "attention"), ("extra", "config3", "cpu_baseline"), ("extra", "fp32_exact", "roofline"),
-               ("conv_ms_per_step",), ("extra", "config4", "parity_vs_cpu_restatement"), ("upconv",))
+_TRIM_ORDER = (("extra", "config4", "cpu_baseline"), ("extra", "unet", "workload"), ("extra", "config3", "workload"), ("extra", "config4", "workload"), ("extra", "config3", "attention"),
+               ("extra", "fp32_exact", "roofline"), ("conv_ms_per_step",), ("upconv",), ("extra", "config4", "parity_vs_cpu_restatement"), ("extra", "config3", "cpu_baseline"))
 
 
 def _slim_extra(obj):

@@ -1244,8 +1244,12 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
             const bool wide = knob_int("MONAI_AMD_RS_THREADS", compute_f64 ? 256 : 512) != 256;
             static int slots[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};     // [wide][f64][small]
             int& sl = slots[wide ? 1 : 0][compute_f64 ? 1 : 0][small ? 1 : 0];
-#define MH_RS_STREAM(T_, NL_, NT_, TAB_) hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk)
-#define MH_RS_SLOTS(T_, NL_, NT_) resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_>, NT_)
+            // round 6: four consecutive x per lane, one 16-byte store per row (kernels/resample.h, VEC) -- MONAI_AMD_RS_VEC=0 in the development build keeps the scalar stores
+            static const bool vec = knob_int("MONAI_AMD_RS_VEC", 1) != 0;
+#define MH_RS_STREAM(T_, NL_, NT_, TAB_)                                                                                                              \
+    if (vec) hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_, true>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk);         \
+    else hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_, false>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk)
+#define MH_RS_SLOTS(T_, NL_, NT_) (vec ? resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_, true>, NT_) : resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_, false>, NT_))
             if (sl == 0) {
                 if (wide) sl = compute_f64 ? (small ? MH_RS_SLOTS(double, 4, 512) : MH_RS_SLOTS(double, 8, 512)) : (small ? MH_RS_SLOTS(float, 4, 512) : MH_RS_SLOTS(float, 8, 512));
                 else sl = compute_f64 ? (small ? MH_RS_SLOTS(double, 8, 256) : MH_RS_SLOTS(double, 16, 256)) : (small ? MH_RS_SLOTS(float, 8, 256) : MH_RS_SLOTS(float, 16, 256));

@@ -400,7 +400,10 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-#define MH_H2_TAP(T_, ...) MH_H2_TAPV(T_, 5, __VA_ARGS__)
+#ifndef H2X_NV
+#define H2X_NV 5      // vector instructions the scheduler may place per matrix-instruction gap of a plain tap (tools/ubench/h2_variants.hip: -DH2X_NV=n)
+#endif
+#define MH_H2_TAP(T_, ...) MH_H2_TAPV(T_, H2X_NV, __VA_ARGS__)
     // the completed output plane (in acce), in four branch-free pieces that ride in the gaps of different taps of the next plane's first step:
     // A scale back, bias, 4 x 16-byte buffer stores per lane (the plane offset goes into the vector offset, NOT into the instruction's scalar offset: a
     // 16-byte buffer store with a scalar-register offset followed at once by a vector write of its data registers stored the NEW value of the second
@@ -509,6 +512,9 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
     bcur = 0; gi = 0;
     __syncthreads();
 
+#ifdef H2X_SETPRIO      // experiment (tools/ubench/h2_variants.hip): static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(H2X_SETPRIO);
+#endif
     MH_H2_PV_LOAD(zs)                 // ACC: set 0 of the first iteration (input plane zs - 1) belongs to output plane zs
     MH_H2_PV_INTO(0)
     MH_H2_PV_LOAD(zs + 1)

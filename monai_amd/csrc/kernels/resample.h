@@ -350,48 +350,55 @@ separable_resample_lds_kernel(const float* __restrict__ src, float* __restrict__
 // Arithmetic is the same rs_comb chain (x, y, z) on the same values as the other kernels: identical results.
 constexpr int RZ_TOY = 16, RZ_TOX = 128;
 
-// RJ = output rows per thread (RZ_TOY rows over NT / 64 waves): 4 with 256 threads, 2 with 512
-template <typename T, int RJ> struct RzTile {     // per-thread constants of the march
-    int ad[RJ][2];                         // LDS address of the (y0, x0) corner of output (row j, column h)
-    int adn[RJ][2];                        // ... of its (y1, x0) corner in the interior path (= ad + row pitch)
-    int dx[2], dy[RJ];                     // boundary tiles: address steps to the x1 / y1 corner (0 when that tap is dropped or clamped)
-    T wx0[2], wx1[2], wy0[RJ], wy1[RJ];
-    unsigned okm;                         // boundary tiles: bit (j*2+h)*4 + corner set = corner contributes
+// A thread's outputs are RJ rows x NH columns.  Scalar form (NH = 2): columns lane, lane + 64 of rows wave + NW j -- a store instruction writes 256 contiguous bytes.
+// Vector form (round 6, NH = 4): columns 4 (lane & 31) .. + 3 of rows 2 (wave + NW j) + (lane >> 5) -- ONE 16-byte store per row and thread, a store instruction
+// writes two whole 512-byte row segments (a quarter of the store instructions; the same values from the same arithmetic: bit-identical output).
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));      // output rows are 4-byte aligned only (Wo is arbitrary)
+template <typename T, int RJ, int NH> struct RzTile {     // per-thread constants of the march
+    int ad[RJ][NH];                        // LDS address of the (y0, x0) corner of output (row j, column h)
+    int adn[RJ][NH];                       // ... of its (y1, x0) corner in the interior path (= ad + row pitch)
+    int dx[NH], dy[RJ];                    // boundary tiles: address steps to the x1 / y1 corner (0 when that tap is dropped or clamped)
+    T wx0[NH], wx1[NH], wy0[RJ], wy1[RJ];
+    unsigned okm;                          // boundary tiles: bit (j*NH+h)*4 + corner set = corner contributes
 };
 
 // In-plane (x, then y) interpolation of the staged source plane at this thread's 8 outputs.  Interior tiles (every tap
 // valid, so x1 = x0 + 1 and y1 = y0 + 1): two paired LDS reads per output at addresses fixed for the whole march.
-template <typename T, int RJ, bool MASKED>
-__device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, const RzTile<T, RJ>& t, T (&P)[2 * RJ]) {
+template <typename T, int RJ, int NH, bool MASKED>
+__device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, const RzTile<T, RJ, NH>& t, T (&P)[NH * RJ]) {
 #pragma unroll
     for (int j = 0; j < RJ; ++j)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             float v[4];
             if (MASKED) {
                 const int a0 = t.ad[j][h], a1 = a0 + t.dy[j];
                 v[0] = box[a0]; v[1] = box[a0 + t.dx[h]]; v[2] = box[a1]; v[3] = box[a1 + t.dx[h]];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[k] = ((t.okm >> ((j * 2 + h) * 4 + k)) & 1u) ? v[k] : 0.0f;
+                for (int k = 0; k < 4; ++k) v[k] = ((t.okm >> ((j * NH + h) * 4 + k)) & 1u) ? v[k] : 0.0f;
             } else {
                 const float* b0 = box + t.ad[j][h];
                 const float* b1 = box + t.adn[j][h];
                 v[0] = b0[0]; v[1] = b0[1]; v[2] = b1[0]; v[3] = b1[1];
             }
             const T r0 = rs_comb((T)v[0], t.wx0[h], (T)v[1], t.wx1[h]), r1 = rs_comb((T)v[2], t.wx0[h], (T)v[3], t.wx1[h]);
-            P[j * 2 + h] = rs_comb(r0, t.wy0[j], r1, t.wy1[j]);
+            P[j * NH + h] = rs_comb(r0, t.wy0[j], r1, t.wy1[j]);
         }
 }
 
 // NLOAD = staged floats per thread and plane (box capacity NT * NLOAD; chosen by the launcher from the scales); NT = threads
-template <typename T, int NLOAD, int NT>
+template <typename T, int NLOAD, int NT, bool VEC = false>
 __global__ void __launch_bounds__(NT)
 separable_resample_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a,
                                  int zchunk, int nchunk) {
-    constexpr int CAP = NLOAD * NT, NW = NT / 64, RJ = RZ_TOY / NW;
+    constexpr int CAP = NLOAD * NT, NW = NT / 64, NH = VEC ? 4 : 2, RJ = VEC ? RZ_TOY / (2 * NW) : RZ_TOY / NW;
+    static_assert(RJ >= 1 && RJ * NH * 4 <= 32, "a thread's outputs: rows x columns, four corner bits each in one mask word");
     __shared__ float box[2][CAP];      // staged as fp32 also for fp64 interpolation (staging doubles measured slower: twice the LDS traffic)
     __shared__ int lim[5], part[6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // this thread's output (row j, column h) inside the tile
+    auto rowy = [&](int j) { return VEC ? 2 * (wave + NW * j) + (lane >> 5) : wave + NW * j; };
+    auto colx = [&](int h) { return VEC ? 4 * (lane & 31) + h : lane + 64 * h; };
     const int nbx = (a.Wo + RZ_TOX - 1) / RZ_TOX, nby = (a.Ho + RZ_TOY - 1) / RZ_TOY, tiles = nbx * nby;
     unsigned lid = xcd_remap(blockIdx.x, gridDim.x);        // neighbouring tiles share an XCD's L2 (their boxes overlap)
     const int tile = (int)(lid % (unsigned)tiles);
@@ -441,8 +448,8 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         for (int oz = oz_s; oz < oz_e; ++oz) {
             const AxisTap<T> tz = tab[oz];
             for (int j = 0; j < RJ; ++j)
-                for (int h = 0; h < 2; ++h) {
-                    const int jy = wave + NW * j, jx = lane + 64 * h;
+                for (int h = 0; h < NH; ++h) {
+                    const int jy = rowy(j), jx = colx(h);
                     if (jy >= ny || jx >= nx) continue;
                     const AxisTap<T> ty = tab[a.Do + oy0 + jy], tx = tab[a.Do + a.Ho + ox0 + jx];
                     const int zi[2] = {tz.i0, tz.i1}, yi[2] = {ty.i0, ty.i1}, xi[2] = {tx.i0, tx.i1};
@@ -461,16 +468,16 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         return;
     }
 
-    // per-thread march constants: columns lane and lane + 64, rows wave, wave + 4, wave + 8, wave + 12
-    RzTile<T, RJ> t;
+    // per-thread march constants: columns colx(h), rows rowy(j)
+    RzTile<T, RJ, NH> t;
     t.okm = 0u;
     bool bad = false;
     {
-        int xa[2], ya[RJ];
-        bool xok[2][2], yok[RJ][2];
+        int xa[NH], ya[RJ];
+        bool xok[NH][2], yok[RJ][2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const AxisTap<T> e = tab[a.Do + a.Ho + ox0 + min(lane + 64 * h, nx - 1)];
+        for (int h = 0; h < NH; ++h) {
+            const AxisTap<T> e = tab[a.Do + a.Ho + ox0 + min(colx(h), nx - 1)];
             xok[h][0] = e.i0 >= 0; xok[h][1] = e.i1 >= 0;
             xa[h] = (xok[h][0] ? e.i0 : xok[h][1] ? e.i1 : lx) - lx;
             t.dx[h] = (xok[h][0] && xok[h][1]) ? e.i1 - e.i0 : 0;
@@ -478,7 +485,7 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         }
 #pragma unroll
         for (int j = 0; j < RJ; ++j) {
-            const AxisTap<T> e = tab[a.Do + oy0 + min(wave + NW * j, ny - 1)];
+            const AxisTap<T> e = tab[a.Do + oy0 + min(rowy(j), ny - 1)];
             yok[j][0] = e.i0 >= 0; yok[j][1] = e.i1 >= 0;
             ya[j] = (yok[j][0] ? e.i0 : yok[j][1] ? e.i1 : ly) - ly;
             t.dy[j] = (yok[j][0] && yok[j][1]) ? (e.i1 - e.i0) * ex : 0;
@@ -487,12 +494,12 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
 #pragma unroll
         for (int j = 0; j < RJ; ++j)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int h = 0; h < NH; ++h) {
                 t.ad[j][h] = ya[j] * ex + xa[h];
                 t.adn[j][h] = t.ad[j][h] + ex;
                 const unsigned m = (unsigned)(yok[j][0] && xok[h][0]) | (unsigned)(yok[j][0] && xok[h][1]) << 1 |
                                    (unsigned)(yok[j][1] && xok[h][0]) << 2 | (unsigned)(yok[j][1] && xok[h][1]) << 3;
-                t.okm |= m << ((j * 2 + h) * 4);
+                t.okm |= m << ((j * NH + h) * 4);
                 bad = bad || m != 15u;
             }
     }
@@ -511,7 +518,7 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
     float pre[NLOAD];
     int pre_z = -1, buf = 0;
     const int dir = a.m[0] < 0.0 ? -1 : 1;
-    T Pa[2 * RJ], Pb[2 * RJ];
+    T Pa[NH * RJ], Pb[NH * RJ];
     int cur0 = -1, cur1 = -1;
 
 #define RZ_LOAD_PLANE(Z)                                                                        \
@@ -527,8 +534,8 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         __syncthreads();                                                                        \
         const int zn_ = (Z) + dir;                                                              \
         if (zn_ >= 0 && zn_ < a.Di) RZ_LOAD_PLANE(zn_)                                          \
-        if (masked) rz_interp_plane<T, RJ, true>(box[buf], t, P);                               \
-        else rz_interp_plane<T, RJ, false>(box[buf], t, P);                                     \
+        if (masked) rz_interp_plane<T, RJ, NH, true>(box[buf], t, P);                           \
+        else rz_interp_plane<T, RJ, NH, false>(box[buf], t, P);                                 \
         buf ^= 1;                                                                               \
     }
 
@@ -539,37 +546,46 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
             const int z0 = z0ok ? tz.i0 : tz.i1, z1 = z1ok ? tz.i1 : tz.i0;
             if (z1 != cur1 && z1 == cur0) {          // decreasing table: the old lower plane becomes the upper one
 #pragma unroll
-                for (int k = 0; k < 2 * RJ; ++k) Pb[k] = Pa[k];
+                for (int k = 0; k < NH * RJ; ++k) Pb[k] = Pa[k];
                 cur1 = cur0;
             }
             if (z0 != cur0) {
                 if (z0 == cur1) {
 #pragma unroll
-                    for (int k = 0; k < 2 * RJ; ++k) Pa[k] = Pb[k];
+                    for (int k = 0; k < NH * RJ; ++k) Pa[k] = Pb[k];
                 } else RZ_COMPUTE_PLANE(z0, Pa)
                 cur0 = z0;
             }
             if (z1 != cur1) {
                 if (z1 == cur0) {
 #pragma unroll
-                    for (int k = 0; k < 2 * RJ; ++k) Pb[k] = Pa[k];
+                    for (int k = 0; k < NH * RJ; ++k) Pb[k] = Pa[k];
                 } else RZ_COMPUTE_PLANE(z1, Pb)
                 cur1 = z1;
             }
         }
 #pragma unroll
-        for (int j = 0; j < RJ; ++j)
+        for (int j = 0; j < RJ; ++j) {
+            float res[NH];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int jy = wave + NW * j, jx = lane + 64 * h;
-                if (jy >= ny || jx >= nx) continue;
-                float res = 0.0f;
+            for (int h = 0; h < NH; ++h) {
+                res[h] = 0.0f;
                 if (z0ok || z1ok) {
-                    const T p0 = z0ok ? Pa[j * 2 + h] : (T)0, p1 = z1ok ? Pb[j * 2 + h] : (T)0;
-                    res = (float)rs_comb(p0, tz.w0, p1, tz.w1);
+                    const T p0 = z0ok ? Pa[j * NH + h] : (T)0, p1 = z1ok ? Pb[j * NH + h] : (T)0;
+                    res[h] = (float)rs_comb(p0, tz.w0, p1, tz.w1);
                 }
-                q[(long long)oz * oplane + (long long)(oy0 + jy) * a.Wo + ox0 + jx] = res;
             }
+            const int jy = rowy(j);
+            if (jy >= ny) continue;
+            float* qrow = q + (long long)oz * oplane + (long long)(oy0 + jy) * a.Wo + ox0;
+            if (VEC && colx(NH - 1) < nx) {
+                *reinterpret_cast<f32x4_a4*>(qrow + colx(0)) = f32x4_a4{res[0], res[1], res[2], res[NH - 1]};
+            } else {
+#pragma unroll
+                for (int h = 0; h < NH; ++h)
+                    if (colx(h) < nx) qrow[colx(h)] = res[h];
+            }
+        }
     }
 #undef RZ_LOAD_PLANE
 #undef RZ_COMPUTE_PLANE

@@ -173,6 +173,8 @@ def sliding_window_inference(
             try:
                 return sliding_window_inference(inputs, *common, buffer_steps, buffer_dim, with_coord, *args, _monai_amd_buffered_inner=True, **kwargs)
             except _LogitsDoNotFit as e:
+                if process_fn is not None or with_coord:      # no slab-wise form exists for these (their semantics are tied to the whole volume): the plain retry could only
+                    raise                                     # repeat the predictor calls already made and fail the same way
                 reason = str(e).split(" (")[0]
             warnings.warn(f"{reason}: buffer_steps={buffer_steps} is served in the plain summation order, slab by slab "
                           "(equal to the reference's unbuffered result; its buffered result differs from that by roundings)")
@@ -477,11 +479,20 @@ def _buffered_batches(b, vol3, in_ch, grid3, starts, roi_size, roi3, num_win, sw
     win_buf = torch.empty((sw_batch_size, in_ch) + tuple(roi3), dtype=dtype, device=dev)
     imp_dev = imp.to(dev)
     dict_keys, count_map = None, None
+    if logits is None and hasattr(predictor, "out_channels"):
+        # the fit decision BEFORE any predictor call where the class count is known: a stateful predictor / process_fn must not see a batch twice because the
+        # all-window buffer turned out not to fit after the first one (the caller then retries in the plain order)
+        logits = [_alloc_logits(shard, nb, int(predictor.out_channels), roi3, dtype, dev)]
     for gi in range(len(x) - 1):
         for g0 in range(x[gi], x[gi + 1], sw_batch_size):
             idx = [int(order[i]) for i in range(g0, min(g0 + sw_batch_size, x[gi + 1]))]
-            for k, w in enumerate(idx):
-                ops.window_extract(vol3, grid3, w, 1, roi3, win_buf[k : k + 1])
+            k = 0
+            while k < len(idx):                 # one gather launch per run of consecutive window indices (the whole batch when buffer_dim is the first axis)
+                run = 1
+                while k + run < len(idx) and idx[k + run] == idx[k] + run:
+                    run += 1
+                ops.window_extract(vol3, grid3, idx[k], run, roi3, win_buf[k : k + run])
+                k += run
             win_data = win_buf[: len(idx)].reshape((len(idx), in_ch) + tuple(roi_size))
             if with_coord:
                 coords = [[slice(b, b + 1), slice(None)] + [slice(int(starts[d][wins[w, d]]), int(starts[d][wins[w, d]]) + int(roi_size[d])) for d in range(nsp)] for w in idx]
@@ -504,6 +515,8 @@ def _buffered_batches(b, vol3, in_ch, grid3, starts, roi_size, roi3, num_win, sw
             _lib.require_device(seg)
             if logits is None:
                 logits = [_alloc_logits(shard, nb, int(seg.shape[1]), roi3, dtype, dev)]
+            elif int(seg.shape[1]) != int(logits[0].shape[1]):
+                raise RuntimeError(f"monai_amd: the predictor returned {int(seg.shape[1])} channels, its `out_channels` says {int(logits[0].shape[1])}")
             for k, w in enumerate(idx):
                 dst = logits[0][w]
                 if w_t is None:

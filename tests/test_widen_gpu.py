@@ -110,9 +110,9 @@ def test_unet_batch_norm_vs_reference():
 
 def test_unet_activations_and_adn_orderings_vs_reference():
     """UNet(act=RELU / LEAKYRELU, adn_ordering="NAD" / "AN" / "A" / "ADN" with batch norm) on the HIP path, against the reference's own logits"""
-    import e2e_cases
+    import e2e_cases as ec
 
-    print(ec.case_unet_vs_golden(DEV, names=tuple(e2e_cases.UNET_VARIANTS), golden="unet_variants.npz"))
+    print(ec.case_unet_vs_golden(DEV, names=tuple(ec.UNET_VARIANTS), golden="unet_variants.npz"))
 
 
 def test_preproc_properties_at_512():
