@@ -1255,6 +1255,16 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
                 else sl = compute_f64 ? (small ? MH_RS_SLOTS(double, 8, 256) : MH_RS_SLOTS(double, 16, 256)) : (small ? MH_RS_SLOTS(float, 8, 256) : MH_RS_SLOTS(float, 16, 256));
             }
             int nchunk = stream_chunks(tiles * NC, Do, sl, 1, 8, "MONAI_AMD_RS_CHUNKS");
+            if (!compute_f64 && wide && !knob_str("MONAI_AMD_RS_CHUNKS")) {
+                // round 6 (profiles/r06_resample_variants.txt): with four workgroups of the fp32 form per CU the launch wants MANY rounds of workgroups, not whole ones --
+                // 512^3 -> 410 x 410 x 819: 11 chunks (2 rounds) 0.279 ms, 21: 0.256, 41: 0.237, 52: 0.236; the fp64 form is flat over the same sweep and keeps the rule above.
+                // >= 7 rounds of the resident slots, z-chunks of at least 8 planes
+                const long long units = tiles * NC;
+                long long want = (7LL * sl + units - 1) / units;
+                const int maxc = Do / 8 < 1 ? 1 : Do / 8;
+                want = want < 1 ? 1 : (want > maxc ? maxc : want);
+                if ((int)want > nchunk) nchunk = (int)want;
+            }
             const int zchunk = cdiv(Do, nchunk);
             nchunk = cdiv(Do, zchunk);
             const long long nwg = tiles * nchunk * NC;

@@ -387,8 +387,16 @@ __device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, c
 }
 
 // NLOAD = staged floats per thread and plane (box capacity NT * NLOAD; chosen by the launcher from the scales); NT = threads
+// Registers (round 6, profiles/r06_resample_variants.txt): the fp32 form with 512 threads needs 68 registers = 7 waves per SIMD = three workgroups per CU; asked for 8 waves
+// per SIMD it fits 62 without scratch = four workgroups, which pays once the launch is cut into enough z-chunks (capi.hip).  The fp64 form (111 registers, four
+// workgroups of 256) spills under any tighter cap and runs 1.7x slower: left alone.  -DMH_RS_MINW=n (tools/ubench/resample_variants.hip) overrides.
+#ifndef MH_RS_MINW
+#define MH_RS_BOUNDS(T_, NT_) __launch_bounds__(NT_, (sizeof(T_) == 4 && (NT_) == 512) ? 8 : 1)
+#else
+#define MH_RS_BOUNDS(T_, NT_) __launch_bounds__(NT_, MH_RS_MINW)
+#endif
 template <typename T, int NLOAD, int NT, bool VEC = false>
-__global__ void __launch_bounds__(NT)
+__global__ void MH_RS_BOUNDS(T, NT)
 separable_resample_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a,
                                  int zchunk, int nchunk) {
     constexpr int CAP = NLOAD * NT, NW = NT / 64, NH = VEC ? 4 : 2, RJ = VEC ? RZ_TOY / (2 * NW) : RZ_TOY / NW;
