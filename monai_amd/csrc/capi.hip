@@ -1244,12 +1244,16 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
             const bool wide = knob_int("MONAI_AMD_RS_THREADS", compute_f64 ? 256 : 512) != 256;
             static int slots[2][2][2] = {{{0, 0}, {0, 0}}, {{0, 0}, {0, 0}}};     // [wide][f64][small]
             int& sl = slots[wide ? 1 : 0][compute_f64 ? 1 : 0][small ? 1 : 0];
-            // round 6: four consecutive x per lane, one 16-byte store per row (kernels/resample.h, VEC) -- MONAI_AMD_RS_VEC=0 in the development build keeps the scalar stores
-            static const bool vec = knob_int("MONAI_AMD_RS_VEC", 1) != 0;
+            // round 6 (kernels/resample.h, profiles/r06_resample_variants.txt): four consecutive x per lane and one 16-byte store per row (VEC) in every form; the fp64 form
+            // of 256 threads takes its source planes by LDS-DMA into a ring of three slots (RING = 3: 0.281 -> 0.270 ms at config 4; the fp32 form does not gain from it).
+            // MONAI_AMD_RS_RING=0 in the development build keeps the register prefetch
+            static const bool ring = knob_int("MONAI_AMD_RS_RING", 1) != 0;
+            const bool use_ring = ring && compute_f64 && !wide;
 #define MH_RS_STREAM(T_, NL_, NT_, TAB_)                                                                                                              \
-    if (vec) hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_, true>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk);         \
-    else hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_, false>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk)
-#define MH_RS_SLOTS(T_, NL_, NT_) (vec ? resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_, true>, NT_) : resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_, false>, NT_))
+    if (use_ring && (NT_) == 256) hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, 256, true, sizeof(T_) == 8 ? 3 : 0>), g, dim3(256), 0, s, src, dst, TAB_, a, zchunk, nchunk); \
+    else hipLaunchKernelGGL((separable_resample_stream_kernel<T_, NL_, NT_, true, 0>), g, dim3(NT_), 0, s, src, dst, TAB_, a, zchunk, nchunk)
+#define MH_RS_SLOTS(T_, NL_, NT_) ((use_ring && (NT_) == 256) ? resident_wgs(separable_resample_stream_kernel<T_, NL_, 256, true, sizeof(T_) == 8 ? 3 : 0>, 256) \
+                                                             : resident_wgs(separable_resample_stream_kernel<T_, NL_, NT_, true, 0>, NT_))
             if (sl == 0) {
                 if (wide) sl = compute_f64 ? (small ? MH_RS_SLOTS(double, 4, 512) : MH_RS_SLOTS(double, 8, 512)) : (small ? MH_RS_SLOTS(float, 4, 512) : MH_RS_SLOTS(float, 8, 512));
                 else sl = compute_f64 ? (small ? MH_RS_SLOTS(double, 8, 256) : MH_RS_SLOTS(double, 16, 256)) : (small ? MH_RS_SLOTS(float, 8, 256) : MH_RS_SLOTS(float, 16, 256));
@@ -1261,6 +1265,13 @@ int mh_affine_resample_f32(const float* src, int NC, int Di, int Hi, int Wi, flo
                 // >= 7 rounds of the resident slots, z-chunks of at least 8 planes
                 const long long units = tiles * NC;
                 long long want = (7LL * sl + units - 1) / units;
+                const int maxc = Do / 8 < 1 ? 1 : Do / 8;
+                want = want < 1 ? 1 : (want > maxc ? maxc : want);
+                if ((int)want > nchunk) nchunk = (int)want;
+            }
+            if (use_ring && !knob_str("MONAI_AMD_RS_CHUNKS")) {      // the ring form: 11 chunks 0.310 ms, 21: 0.279, 26: 0.270, 41: 0.283 -- about 4.5 rounds of the resident slots
+                const long long units = tiles * NC;
+                long long want = (9LL * sl + 2 * units - 1) / (2 * units);
                 const int maxc = Do / 8 < 1 ? 1 : Do / 8;
                 want = want < 1 ? 1 : (want > maxc ? maxc : want);
                 if ((int)want > nchunk) nchunk = (int)want;

@@ -15,6 +15,32 @@
 #define MH_OPAQUE_S(x) asm volatile("" : "+s"(x))      // the same for a wave-uniform value (scalar register)
 #endif
 
+// LDS-DMA: global memory -> LDS without a register round trip (buffer_load_dword ... lds: lane L of the issuing wave lands at LDS offset M0 + 4 L), completion
+// counted by vmcnt like any vector-memory load.  Nothing orders a later ds_read behind it except the issuing wave's own s_waitcnt vmcnt + a barrier for the other waves'
+// reads (MI355X_MICROARCH.md, "Two waves per SIMD", item 7).  Two things about hipcc (ROCm 7.2) shape the macros: (i) given the builtin forms of the load it puts an
+// s_waitcnt vmcnt(0) of its own in front of the next LDS read that MAY alias the destination -- any read of a ring addressed by a run-time slot -- which empties the
+// ring; the load is therefore inline assembly (the compiler then knows nothing of it: its own wait counts for other loads only get more conservative, never wrong);
+// (ii) __syncthreads() carries a release fence that waits for every outstanding vector-memory operation: MH_VMCNT_BARRIER is the builtin wait + the bare s_barrier.
+// MH_LDS_DMA_F32(base, byte offset of this lane, LDS_WAVE_BASE): `base` and LDS_WAVE_BASE wave-uniform.  The SIMT emulator copies at issue.
+typedef int mh_i32x4 __attribute__((ext_vector_type(4)));
+#ifdef MH_SIMT_EMULATOR
+#define MH_LDS_DMA_F32(BASE, VOFF, LDS_WAVE_BASE) ((void)((LDS_WAVE_BASE)[threadIdx.x & 63] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(BASE) + (VOFF))))
+#define MH_VMCNT_BARRIER(N) __syncthreads()
+#define MH_VMCNT_WAIT(N) ((void)0)
+#else
+#define MH_LDS_DMA_F32(BASE, VOFF, LDS_WAVE_BASE)                                                                                             \
+    {                                                                                                                                         \
+        const unsigned long long b_ = (unsigned long long)(BASE);      /* raw buffer descriptor: base, stride 0, 2 GB of records, dword format */ \
+        const mh_i32x4 r_ = {__builtin_amdgcn_readfirstlane((int)(unsigned)b_), __builtin_amdgcn_readfirstlane((int)((unsigned)(b_ >> 32) & 0xffffu)), 0x7fffffff, 0x00020000}; \
+        /* the low 32 bits of a generic pointer into LDS are its LDS byte offset (the aperture sits in the high half); an addrspacecast here trips hipcc (ROCm 7.2: illegal V_CMP of src_shared_base) */ \
+        const unsigned m_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(LDS_WAVE_BASE)); \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" ::"s"(m_), "v"(VOFF), "s"(r_) : "memory", "m0"); \
+    }
+#define MH_VMCNT_IMM(N) (0x0f70 | ((N) & 15) | ((((N) >> 4) & 3) << 14))      /* gfx9 s_waitcnt encoding: vmcnt in bits 3:0 and 15:14, expcnt / lgkmcnt left at "no wait" */
+#define MH_VMCNT_BARRIER(N) do { __builtin_amdgcn_s_waitcnt(MH_VMCNT_IMM(N)); __builtin_amdgcn_s_barrier(); } while (0)
+#define MH_VMCNT_WAIT(N) __builtin_amdgcn_s_waitcnt(MH_VMCNT_IMM(N))
+#endif
+
 // write-once result rows of the streaming transforms (Gaussian): non-temporal stores -- 0.231 vs 0.236 ms per 512^3 volume at 9 taps, 0.418 vs 0.435 at 17
 // (measured with a -DMH_DEV_NT_STORES build in round 3; for the blend, whose loads and stores interleave per voxel, non-temporal accesses cost 30 %)
 #define MH_STREAM_STORE4(ptr, val) __builtin_nontemporal_store((val), reinterpret_cast<mh::f32x4*>(ptr))

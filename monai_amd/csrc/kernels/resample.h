@@ -395,13 +395,28 @@ __device__ __forceinline__ void rz_interp_plane(const float* __restrict__ box, c
 #else
 #define MH_RS_BOUNDS(T_, NT_) __launch_bounds__(NT_, MH_RS_MINW)
 #endif
-template <typename T, int NLOAD, int NT, bool VEC = false>
+// A tap-table entry at a wave-uniform index through the constant address space: a SCALAR load (lgkmcnt).  As a vector load it sits in the vmcnt queue behind the
+// LDS-DMA planes in flight, and waiting for it means waiting for all of them (the counter is in order).
+template <typename T> __device__ __forceinline__ AxisTap<T> rs_tap_uniform(const AxisTap<T>* __restrict__ tab, int i) {
+#if defined(MH_SIMT_EMULATOR) || !defined(__HIP_DEVICE_COMPILE__)
+    return tab[i];
+#else
+    typedef const __attribute__((address_space(4))) AxisTap<T> ctap;
+    return ((ctap*)tab)[__builtin_amdgcn_readfirstlane(i)];
+#endif
+}
+
+// RING (round 6): 0 = the source plane is prefetched into registers one plane ahead and written to one of two LDS buffers; RING = 3: the planes arrive by LDS-DMA
+// (common.h: no registers, no ds_write) into a ring of RING LDS slots, up to RING - 1 planes in flight behind the one being interpolated: a workgroup no longer waits a
+// full memory latency per source plane.  Same values from the same arithmetic: bit-identical output.
+template <typename T, int NLOAD, int NT, bool VEC = false, int RING = 0>
 __global__ void MH_RS_BOUNDS(T, NT)
 separable_resample_stream_kernel(const float* __restrict__ src, float* __restrict__ dst, const AxisTap<T>* __restrict__ tab, ResampleArgs a,
                                  int zchunk, int nchunk) {
     constexpr int CAP = NLOAD * NT, NW = NT / 64, NH = VEC ? 4 : 2, RJ = VEC ? RZ_TOY / (2 * NW) : RZ_TOY / NW;
     static_assert(RJ >= 1 && RJ * NH * 4 <= 32, "a thread's outputs: rows x columns, four corner bits each in one mask word");
-    __shared__ float box[2][CAP];      // staged as fp32 also for fp64 interpolation (staging doubles measured slower: twice the LDS traffic)
+    static_assert(RING == 0 || (RING == 3 && 2 * NLOAD <= 63), "the ring form: three slots, waits of 0 / NLOAD / 2 NLOAD outstanding loads");
+    __shared__ float box[RING ? RING : 2][CAP];      // staged as fp32 also for fp64 interpolation (staging doubles measured slower: twice the LDS traffic)
     __shared__ int lim[5], part[6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // this thread's output (row j, column h) inside the tile
@@ -523,11 +538,53 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         const int r = i / ex, col = i - r * ex;
         goff[j] = i < ey * ex ? (ly + r) * a.Wi + lx + col : -1;
     }
-    float pre[NLOAD];
+    float pre[RING ? 1 : NLOAD];
     int pre_z = -1, buf = 0;
     const int dir = a.m[0] < 0.0 ? -1 : 1;
     T Pa[NH * RJ], Pb[NH * RJ];
     int cur0 = -1, cur1 = -1;
+    // RING: the window of planes in flight -- plane r_head + k dir sits in (or is on its way into) slot (r_hs + k) % RING for k < r_cnt; all of it wave-uniform.
+    // Lanes beyond the box fetch the box's first element (every lane issues every load: the vmcnt arithmetic below counts instructions) and their cells are never read.
+    int r_head = 0, r_hs = 0, r_cnt = 0;
+    int z_end = dir > 0 ? a.Di - 1 : 0;          // last source plane (in march direction) any output of this chunk reads: nothing beyond it is requested
+    if constexpr (RING != 0) {
+        const AxisTap<T> tl = rs_tap_uniform(tab, oz_e - 1);
+        const int zl = dir > 0 ? max(tl.i0, tl.i1) : ((tl.i0 >= 0 && tl.i1 >= 0) ? min(tl.i0, tl.i1) : max(tl.i0, tl.i1));
+        if (zl >= 0) z_end = zl;
+#pragma unroll
+        for (int j = 0; j < NLOAD; ++j) goff[j] = 4 * (goff[j] >= 0 ? goff[j] : ly * a.Wi + lx);      // BYTE offsets inside a plane: scalar plane base + 32-bit lane offset, no 64-bit address registers
+    }
+#define RZ_RING_ISSUE(Z, SLOT)                                                                  \
+    {                                                                                           \
+        /* the plane index comes out of the tap table (a vector load): tell the compiler it is wave-uniform, or the plane base is not a scalar (buffer descriptor) */ \
+        const float* pl_ = p + (long long)__builtin_amdgcn_readfirstlane(Z) * iplane;           \
+        float* sl_ = box[__builtin_amdgcn_readfirstlane(SLOT)] + 64 * __builtin_amdgcn_readfirstlane(wave); \
+        _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) MH_LDS_DMA_F32(pl_, goff[j], sl_ + NT * j); \
+    }
+#define RZ_RING_PLANE(Z, P)                                                                     \
+    {                                                                                           \
+        int k_ = ((Z) - r_head) * dir;                                                          \
+        if (r_cnt == 0 || k_ < 0 || k_ >= r_cnt) {      /* not in flight (the first plane; a z step beyond the window): drain, make sure nobody reads a slot, restart */ \
+            MH_VMCNT_BARRIER(0);                                                                \
+            r_head = (Z); r_hs = 0; r_cnt = 1;                                                  \
+            RZ_RING_ISSUE((Z), 0)                                                               \
+        } else {                                                                                \
+            r_head = (Z); r_hs = (r_hs + k_) % RING; r_cnt -= k_;                               \
+        }                                                                                       \
+        /* plane Z has landed once at most (r_cnt - 1) NLOAD younger loads are outstanding (result stores issued in between only make the wait more conservative) */ \
+        if (r_cnt == 1) MH_VMCNT_BARRIER(0);                                                    \
+        else if (r_cnt == 2) MH_VMCNT_BARRIER(NLOAD);                                           \
+        else MH_VMCNT_BARRIER(2 * NLOAD);                                                       \
+        /* every wave is past its reads of the slot consumed before this one: top the window up */ \
+        while (r_cnt < RING) {                                                                  \
+            const int zn_ = r_head + r_cnt * dir;                                               \
+            if (zn_ < 0 || zn_ >= a.Di || (zn_ - z_end) * dir > 0) break;                       \
+            RZ_RING_ISSUE(zn_, (r_hs + r_cnt) % RING)                                           \
+            ++r_cnt;                                                                            \
+        }                                                                                       \
+        if (masked) rz_interp_plane<T, RJ, NH, true>(box[r_hs], t, P);                          \
+        else rz_interp_plane<T, RJ, NH, false>(box[r_hs], t, P);                                \
+    }
 
 #define RZ_LOAD_PLANE(Z)                                                                        \
     {                                                                                           \
@@ -536,7 +593,7 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
         pre_z = (Z);                                                                            \
     }
 #define RZ_COMPUTE_PLANE(Z, P)                                                                  \
-    {                                                                                           \
+    if constexpr (RING != 0) RZ_RING_PLANE(Z, P) else {                                         \
         if (pre_z != (Z)) RZ_LOAD_PLANE(Z)                                                      \
         _Pragma("unroll") for (int j = 0; j < NLOAD; ++j) if (goff[j] >= 0) box[buf][tid + NT * j] = pre[j]; \
         __syncthreads();                                                                        \
@@ -548,7 +605,7 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
     }
 
     for (int oz = oz_s; oz < oz_e; ++oz) {
-        const AxisTap<T> tz = tab[oz];
+        const AxisTap<T> tz = RING ? rs_tap_uniform(tab, oz) : tab[oz];
         const bool z0ok = tz.i0 >= 0, z1ok = tz.i1 >= 0;
         if (z0ok || z1ok) {
             const int z0 = z0ok ? tz.i0 : tz.i1, z1 = z1ok ? tz.i1 : tz.i0;
@@ -595,8 +652,11 @@ separable_resample_stream_kernel(const float* __restrict__ src, float* __restric
             }
         }
     }
+    if constexpr (RING != 0) MH_VMCNT_WAIT(0);      // no LDS-DMA may be in flight when the workgroup's LDS is handed to the next one
 #undef RZ_LOAD_PLANE
 #undef RZ_COMPUTE_PLANE
+#undef RZ_RING_PLANE
+#undef RZ_RING_ISSUE
 }
 
 // Dense grid: coords [3][Do][Ho][Wo] (planes z, y, x), fp32 or fp64 (GT); a per-axis affine (ga, gb) turns the stored

@@ -1,6 +1,6 @@
 // Development aid (round 6): separable_resample_stream_kernel standalone at BASELINE.json config 4 (512^3 -> 410 x 410 x 819, affine diag(.8, .8, 1.6) -> pixdim 1,
 // trilinear, border), so that variants of kernels/resample.h compile in seconds on the GPU box:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-DRSV_T=float -DRSV_NL=4 -DRSV_NT=512 -DRSV_VEC=true -DMH_RS_MINW=8] tools/ubench/resample_variants.hip -o /tmp/rsv
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Imonai_amd/csrc [-DRSV_T=float -DRSV_NL=4 -DRSV_NT=512 -DRSV_VEC=true -DRSV_RING=3 -DMH_RS_MINW=8] tools/ubench/resample_variants.hip -o /tmp/rsv
 //   /tmp/rsv <label> [chunks]          chunks: z-chunks per (tile, channel) column; default = the launcher's rule (capi.hip stream_chunks) on the occupancy the API reports
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -21,6 +21,9 @@ using namespace mh;
 #ifndef RSV_VEC
 #define RSV_VEC true
 #endif
+#ifndef RSV_RING
+#define RSV_RING 0
+#endif
 
 int main(int argc, char** argv) {
     const int Di = 512, Hi = 512, Wi = 512, Do = 410, Ho = 410, Wo = 819;
@@ -40,7 +43,7 @@ int main(int argc, char** argv) {
     for (auto& v : h) { s = s * 1664525u + 1013904223u; v = ((s >> 8) & 0xffff) / 65536.0f; }
     hipMemcpy(src, h.data(), ni * 4, hipMemcpyHostToDevice);
     hipLaunchKernelGGL((resample_axis_table_kernel<RSV_T>), dim3((Do + Ho + Wo + 255) / 256), dim3(256), 0, 0, tab, a);
-    auto kern = separable_resample_stream_kernel<RSV_T, RSV_NL, RSV_NT, RSV_VEC>;
+    auto kern = separable_resample_stream_kernel<RSV_T, RSV_NL, RSV_NT, RSV_VEC, RSV_RING>;
     int per_cu = 1;
     hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, RSV_NT, 0);
     const int slots = 256 * (per_cu < 1 ? 1 : per_cu);
