@@ -67,6 +67,8 @@ SIGNATURES = {
     "mh_conv3d_k3_h2c_config": (_I, []),
     "mh_conv3d_k3_c1_config": (_I, []),
     "mh_conv3d_k3_h2v_config": (_I, []),
+    "mh_conv3d_k3_h2w_config": (_I, []),
+    "mh_conv3d_k3_h2w_fits": (_I, [_I, _I, _I]),
     "mh_conv3d_k3_num_configs": (_I, []),
     "mh_conv3d_k3_accepts": (_I, [_I, _I, _I]),
     "mh_conv3d_k3_packed_floats": (_L, [_I, _I, _I]),

@@ -12,6 +12,7 @@
 #include "kernels/conv3d_mfma.h"
 #include "kernels/conv3d_wino2p.h"
 #include "kernels/conv3d_h2.h"
+#include "kernels/conv3d_wino_h2.h"
 #include "kernels/upconv_h2.h"
 #include "kernels/conv3d_s2_h2.h"
 #include "kernels/deconv_h2.h"
@@ -436,7 +437,13 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // configuration MH_CFG_H2V: the split-precision convolution for SMALL volumes (D H W <= 256 voxels: the 6^3 level of a 96^3 window), one sample's whole volume as the
 // workgroup's M tile (kernels/conv3d_vol_h2.h): where MH_CFG_H2's 16 x 16 regions would be mostly empty; same arithmetic and tolerance class as MH_CFG_H2
 #define MH_CFG_H2V (MH_NUM_CFG + 6)
-#define MH_CFG_LAST MH_CFG_H2V
+// configuration MH_CFG_H2W (round 6): in-plane Winograd F(2x2, 3x3) in front of MH_CFG_H2's split-precision product, transformed weights resident in registers
+// (kernels/conv3d_wino_h2.h): 32 input channels, planes that tile into 4 x 16 regions; same record / bound contract and tolerance class as MH_CFG_H2
+#define MH_CFG_H2W (MH_NUM_CFG + 7)
+#ifndef MH_H2W_DEFAULT
+#define MH_H2W_DEFAULT 0      // mh_conv3d_k3_select returns it only under MONAI_AMD_H2W=1 until the A/B on the MI355X says otherwise
+#endif
+#define MH_CFG_LAST MH_CFG_H2W
 static inline bool hv_fits(int D, int H, int W) {
     const long long vol = (long long)D * H * W, padded = (long long)(D + 2) * (H + 2) * (W + 2);
     return vol >= 64 && vol <= 256 && padded <= HV_CELLS;
@@ -476,14 +483,33 @@ static inline int h2_zchunk(int D, int H, int W) {
     return cdiv(D, nchunk);
 }
 static inline int h2_blocks(int D, int H, int W) { return h2_regions(H, W) * cdiv(D, h2_zchunk(D, H, W)); }
+// the Winograd split-precision kernel: 4 x 16 regions (whole ones only), z-chunks a pure function of the extents (the statistics record count depends on it)
+static inline bool hw_fits(int D, int H, int W) { return H >= HWG_BY && W >= HWG_BX && H % HWG_BY == 0 && W % HWG_BX == 0 && D >= 2 && h2_fits(D, H, W); }
+static inline int hw_regions(int H, int W) { return (H / HWG_BY) * (W / HWG_BX); }
+static inline int hw_zchunk(int D, int H, int W) {
+    int nchunk = cdiv(32, hw_regions(H, W));
+    if (const char* e = knob_str("MONAI_AMD_HW_CHUNKS")) {          // tuning knob (development)
+        const int v = atoi(e);
+        if (v >= 1 && v <= D) nchunk = v;
+    }
+    if (nchunk > D / 12) nchunk = D / 12;
+    if (nchunk < 1) nchunk = 1;
+    int zc = cdiv(D, nchunk);
+    zc += zc & 1;                                                   // even chunks: the pooling epilogue pairs planes inside a chunk
+    return zc;
+}
+static inline int hw_blocks(int D, int H, int W) { return hw_regions(H, W) * cdiv(D, hw_zchunk(D, H, W)); }
 
 int mh_conv3d_k3_num_configs(void) { return MH_CFG_WINO2D; }
 int mh_conv3d_k3_h2_config(void) { return MH_CFG_H2; }
 int mh_conv3d_k3_h2c_config(void) { return MH_CFG_H2C; }
 int mh_conv3d_k3_c1_config(void) { return MH_CFG_C1; }
 int mh_conv3d_k3_h2v_config(void) { return MH_CFG_H2V; }
+int mh_conv3d_k3_h2w_config(void) { return MH_CFG_H2W; }
+int mh_conv3d_k3_h2w_fits(int D, int H, int W) { return hw_fits(D, H, W) ? 1 : 0; }
 
 int mh_conv3d_k3_pool_accepts(int cfg, int Cin, int Cout, int D, int H, int W) {
+    if (cfg == MH_CFG_H2W) return Cin == HWG_CIN && Cout >= HWG_CN && Cout % HWG_CN == 0 && D % 2 == 0 && hw_fits(D, H, W);
     if (cfg != MH_CFG_H2 || D < 2 || H < 2 || W < 2 || D % 2 || H % 2 || W % 4) return 0;
     if (!(Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= H2_CN && Cout % (H2_CN / 2) == 0) || !h2_fits(D, H, W)) return 0;
     return !h2_wide(H, W) && h2_zchunk(D, H, W) % 2 == 0;
@@ -496,6 +522,7 @@ int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2C) return Cin >= H2_KC && Cin % H2_KC == 0 && Cin <= H2_NRM_MAX && Cout >= 16 && Cout % 16 == 0;
     if (cfg == MH_CFG_C1) return Cin == 1 && Cout >= 8 && Cout % 8 == 0;
     if (cfg == MH_CFG_H2V) return Cin >= 16 && Cin % 16 == 0 && Cin <= HV_CIN_MAX && Cout >= 32 && Cout % 32 == 0;
+    if (cfg == MH_CFG_H2W) return Cin == HWG_CIN && Cout >= HWG_CN && Cout % HWG_CN == 0;
     if (cfg < 0 || cfg > MH_NUM_CFG) return 0;
     return Cout >= 1 && cin_padded(cfg, Cin) <= Cfg1::NRM_MAX;
 }
@@ -536,6 +563,9 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     // small volumes (the 6^3 level of a 96^3 window) that the z-marching kernel's 16 x 16 regions would leave mostly empty: one sample's whole volume as the M tile
     if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && best != MH_CFG_H2 && best != MH_CFG_H2C && mh_conv3d_k3_accepts(MH_CFG_H2V, Cin, Cout) && hv_fits(D, H, W))
         best = MH_CFG_H2V;
+    // round 6: 32 input channels on planes of whole 4 x 16 regions: in-plane Winograd in front of the split product (kernels/conv3d_wino_h2.h)
+    if (best == MH_CFG_H2 && mh_conv3d_k3_accepts(MH_CFG_H2W, Cin, Cout) && hw_fits(D, H, W) && D >= 24 && knob_int("MONAI_AMD_H2W", MH_H2W_DEFAULT) != 0)
+        best = MH_CFG_H2W;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
     if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
         best = MH_CFG_C1;
@@ -548,6 +578,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg == MH_CFG_H2V) return (int64_t)Cout * Cin * 27 + H2_TAIL;                             // two fp16 pieces per weight + {1 / scale, scale}
+    if (cfg == MH_CFG_H2W) return (int64_t)(Cout / HWG_CN) * 4 * HWG_OPS * 64 * 4 + H2_TAIL;       // [cout group][wave][48 operands][64 lanes][8 halves]
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -582,6 +613,15 @@ int mh_conv3d_k3_pack_f32(int cfg, const float* w, int Cin, int Cout, float* pac
                            reinterpret_cast<_Float16*>(packed), tail);
         return launched("conv3d_k3_h2_pack");
     }
+    if (cfg == MH_CFG_H2W) {
+        if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the Winograd split kernel needs Cin == 32, Cout %% 32 == 0");
+        float* tail = packed + (mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL);
+        hipLaunchKernelGGL(conv3d_k3_h2_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (long long)Cin * Cout * 27, tail);
+        hipLaunchKernelGGL(conv3d_k3_h2w_scale_fix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tail);
+        hipLaunchKernelGGL(conv3d_k3_h2w_pack_kernel, dim3(blocks_for((long long)Cin * Cout)), dim3(256), 0, (hipStream_t)stream, w, Cin, Cout,
+                           reinterpret_cast<_Float16*>(packed), tail);
+        return launched("conv3d_k3_h2w_pack");
+    }
     if (cfg == MH_CFG_H2V) {
         if (!w || !packed || !mh_conv3d_k3_accepts(cfg, Cin, Cout)) return fail(MH_ERR_ARG, "conv3d_k3_pack: the small-volume split kernel needs Cin %% 16 == 0 (<= 768), Cout %% 32 == 0");
         float* tail = packed + (mh_conv3d_k3_packed_floats(cfg, Cin, Cout) - H2_TAIL);
@@ -608,6 +648,7 @@ int mh_conv3d_k3_stat_tiles(int cfg, int D, int H, int W) {
     if (cfg == MH_CFG_H2 || cfg == MH_CFG_H2C) return h2_blocks(D, H, W);
     if (cfg == MH_CFG_C1) return c1_blocks(D, H, W);
     if (cfg == MH_CFG_H2V) return 1;          // the workgroup holds the sample's whole volume
+    if (cfg == MH_CFG_H2W) return hw_fits(D, H, W) ? hw_blocks(D, H, W) : 0;
     if (cfg < 1 || cfg > MH_NUM_CFG) return 0;
     const CfgInfo& k = kCfg[cfg];
     return cdiv(W, k.tx) * cdiv(H, k.ty) * cdiv(D, k.tz);
@@ -650,7 +691,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
 }
 int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
                                 float* stats, void* stream) {
-    if (cfg != MH_CFG_H2 || !stats || !in_ || !in_->nrm)
+    if ((cfg != MH_CFG_H2 && cfg != MH_CFG_H2W) || !stats || !in_ || !in_->nrm)
         return fail(MH_ERR_UNSUPPORTED, "conv3d_k3_accumulate: the accumulating form exists for the split-precision configuration with input records and statistics");
     return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, true);
 }
@@ -678,6 +719,26 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
         else if (in.nrm) hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, true>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         else hipLaunchKernelGGL((conv3d_k3_c1_kernel<cot, false, false>), grid, dim3(256), 0, s, in, packed_w, bias, out, stats, txn, tyn, zc);
         return launched("conv3d_k3_c1");
+    }
+    if (cfg == MH_CFG_H2W) {
+        if (!mh_conv3d_k3_accepts(cfg, in.C, out.C) || !hw_fits(in.D, in.H, in.W))
+            return fail(MH_ERR_ARG, "conv3d_k3: the Winograd split kernel needs Cin == 32, Cout %% 32 == 0, H %% 4 == 0, W %% 16 == 0, D*H*W < 2^24 (got %d -> %d, %dx%dx%d)",
+                        in.C, out.C, in.D, in.H, in.W);
+        if (!in.nrm) return fail(MH_ERR_ARG, "conv3d_k3: the Winograd split kernel needs input records with magnitude bounds");
+        if (!aligned(out.data, 16) || out.n_stride % 4 || !aligned(packed_w, 16)) return fail(MH_ERR_ARG, "conv3d_k3: the Winograd split kernel needs 16-byte aligned output and weights");
+        if ((accumulate || pool) && !stats) return fail(MH_ERR_ARG, "conv3d_k3: the accumulating / pooling forms leave statistics");
+        const int bxn = out.W / HWG_BX, byn = out.H / HWG_BY, zc = hw_zchunk(out.D, out.H, out.W);
+        const unsigned nblk = (unsigned)(bxn * byn * cdiv(out.D, zc));
+        const long long total = (long long)nblk * (out.C / HWG_CN) * out.N;
+        if (total > 0x7fffffffLL) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: problem too large for one launch");
+        const dim3 grid((unsigned)total);
+        const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
+        const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
+        if (pool) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, true>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride);
+        else if (accumulate) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, true, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else hipLaunchKernelGGL((conv3d_k3_h2w_kernel<false, false, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        return launched("conv3d_k3_h2w");
     }
     if (cfg == MH_CFG_H2V) {
         if (accumulate || pool) return fail(MH_ERR_UNSUPPORTED, "conv3d_k3: the small-volume split kernel has no accumulating / pooling form");

@@ -331,6 +331,16 @@ def conv3d_k3_h2v_config() -> int:
     return _lib.lib().query("mh_conv3d_k3_h2v_config")
 
 
+def conv3d_k3_h2w_config() -> int:
+    """Id of the split-precision configuration behind an in-plane Winograd F(2x2, 3x3) transform (32 input channels, planes of whole 4 x 16 regions;
+    `conv3d_k3_h2w_fits`); same tolerance class as `conv3d_k3_h2_config`."""
+    return _lib.lib().query("mh_conv3d_k3_h2w_config")
+
+
+def conv3d_k3_h2w_fits(d: int, h: int, w: int) -> bool:
+    return bool(_lib.lib().query("mh_conv3d_k3_h2w_fits", int(d), int(h), int(w)))
+
+
 def conv3d_k3_accepts(cfg: int, cin: int, cout: int) -> bool:
     return bool(_lib.lib().query("mh_conv3d_k3_accepts", int(cfg), int(cin), int(cout)))
 

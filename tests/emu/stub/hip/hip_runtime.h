@@ -255,6 +255,29 @@ inline f32x16_t mfma_f32_32x32x16_f16(f16x8_t a, f16x8_t b, f32x16_t cin, int, i
     return d;
 }
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x32_f16: A[i = l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][n = l & 15], j = 0..7; D: col = l & 15, row = 4 (l >> 4) + r
+inline f32x4_t mfma_f32_16x16x32_f16(f16x8_t a, f16x8_t b, f32x4_t cin, int, int, int) {
+    Ctx& c = ctx();
+    Fiber* f = c.cur;
+    memcpy(c.slots[f->wave][f->lane][0], &a, 16);
+    memcpy(c.slots[f->wave][f->lane][1], &b, 16);
+    wave_sync();
+    const int lane = f->lane, col = lane & 15;
+    f32x4_t d = cin;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * (lane >> 4) + r;
+        float acc = cin[r];
+        for (int g = 0; g < 4; ++g) {
+            f16x8_t av, bv;
+            memcpy(&av, c.slots[f->wave][row + 16 * g][0], 16);
+            memcpy(&bv, c.slots[f->wave][col + 16 * g][1], 16);
+            for (int j = 0; j < 8; ++j) acc += (float)av[j] * (float)bv[j];
+        }
+        d[r] = acc;
+    }
+    wave_sync();
+    return d;
+}
 // v_mfma_f32_16x16x4_f32: A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15], D: col = l & 15, row = 4 (l >> 4) + r
 inline f32x4_t mfma_f32_16x16x4f32(float a, float b, f32x4_t cin, int, int, int) {
     Ctx& c = ctx();
@@ -332,6 +355,7 @@ inline unsigned raw_buffer_load_b32(BufRsrc r, unsigned voffset, unsigned soffse
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu::mfma_f32_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu::mfma_f32_32x32x16_bf16
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16 emu::mfma_f32_32x32x16_f16
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16 emu::mfma_f32_16x16x32_f16
 #define __builtin_amdgcn_update_dpp emu::update_dpp
 #define __builtin_amdgcn_fmed3f(a, b, c) std::fmax(std::fmin((a), (b)), std::fmin(std::fmax((a), (b)), (c)))      // v_med3_f32 (finite / infinite operands)
 #define __builtin_amdgcn_make_buffer_rsrc emu::make_buffer_rsrc

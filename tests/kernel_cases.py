@@ -173,7 +173,7 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
 
     if cfg is None:
         cfg = ops.conv3d_k3_select(cin, cout, *dims)
-    if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config()) and nrm is not None:
+    if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config(), ops.conv3d_k3_h2w_config()) and nrm is not None:
         # the split-precision kernel scales its input by the bounds its records carry: as loose as the finalize kernel's sqrt(count) bound
         nrm = _with_bounds(x, nrm, loosen=float(np.sqrt(np.prod(dims))))
     packed = ops.conv3d_k3_pack(cfg, w.to(device))
@@ -208,11 +208,11 @@ def case_conv3d(device, cfg, n, cin, cout, dims, with_nrm=True, fused_stats=True
     return cfg
 
 
-def case_conv3d_pool(device, n, cin, cout, dims):
+def case_conv3d_pool(device, n, cin, cout, dims, cfg=None):
     """the split-precision convolution with the pooling epilogue (conv3d_h2.h, POOL): the convolution output and statistics bitwise those of the plain kernel, pool_max /
     pool_min bitwise MaxPool3d(2) of +out / -(-out); pool_select copies the minima for the channels whose alpha is negative; ragged regions, two z-chunks, two cout groups"""
     gen = torch.Generator().manual_seed(700 + cin + cout + dims[0])
-    cfg = ops.conv3d_k3_h2_config()
+    cfg = ops.conv3d_k3_h2_config() if cfg is None else cfg
     assert ops.conv3d_k3_pool_accepts(cfg, cin, cout, *dims)
     x = torch.randn((n, cin) + tuple(dims), generator=gen)
     w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
@@ -243,11 +243,11 @@ def case_conv3d_pool(device, n, cin, cout, dims):
     return True
 
 
-def case_conv3d_accumulate(device, n, cin, cout, dims, tol=2e-5):
+def case_conv3d_accumulate(device, n, cin, cout, dims, tol=2e-5, cfg=None):
     """the split-precision convolution in its accumulating form (conv3d_h2.h, ACC: out += conv + bias, statistics of the SUM): resident and streamed weight slabs, both
     region shapes, ragged regions, two z-chunks -- against old + conv in float64, and the finalize kernel on the statistics"""
     gen = torch.Generator().manual_seed(500 + cin + cout + dims[0])
-    cfg = ops.conv3d_k3_h2_config()
+    cfg = ops.conv3d_k3_h2_config() if cfg is None else cfg
     x = torch.randn((n, cin) + tuple(dims), generator=gen)
     w = torch.randn((cout, cin, 3, 3, 3), generator=gen) / np.sqrt(27.0 * cin)
     b = torch.randn(cout, generator=gen) * 0.1

@@ -348,3 +348,17 @@ POOL_CASES = [(2, 32, 32, (4, 16, 16)), pytest.param(1, 48, 64, (6, 18, 36), mar
 def test_conv3d_split_precision_pooling_epilogue(emu, n, cin, cout, dims):
     """MaxPool3d(2) out of the producing convolution's epilogue (conv3d_h2.h, POOL): raw maxima / minima, bitwise; the convolution itself untouched"""
     kc.case_conv3d_pool("cpu", n, cin, cout, dims)
+
+
+# in-plane Winograd in front of the split product (conv3d_wino_h2.h): one region; 2 x 2 regions with the volume's borders on every side; two z-chunks are the GPU twin's
+@pytest.mark.parametrize("n,cin,cout,dims", [(1, 32, 32, (3, 4, 16)), (2, 32, 64, (5, 8, 32))])
+def test_conv_h2w_winograd_split(emu, n, cin, cout, dims):
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_h2w_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and not ops.conv3d_k3_accepts(cfg, 16, 32) and not ops.conv3d_k3_accepts(cfg, 64, 32)
+    assert ops.conv3d_k3_h2w_fits(*dims) and not ops.conv3d_k3_h2w_fits(4, 6, 16) and not ops.conv3d_k3_h2w_fits(4, 8, 24)
+    kc.case_conv3d("cpu", cfg, n, cin, cout, dims, fused_stats=True)
+    if n == 1:      # the accumulating and the pooling forms
+        kc.case_conv3d_accumulate("cpu", 1, cin, cout, (3, 4, 32), cfg=cfg)
+        kc.case_conv3d_pool("cpu", 1, cin, cout, (4, 8, 16), cfg=cfg)

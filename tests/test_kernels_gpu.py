@@ -171,6 +171,22 @@ def test_conv3d_fp16_split_precision(cin, cout, dims, n):
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
 
 
+# in-plane Winograd in front of the split product (conv3d_wino_h2.h): one region / borders on every side, two cout groups / four z-chunks of one region / the headline's two levels
+H2W_CASES = [(32, 32, (3, 4, 16), 2), (32, 64, (5, 8, 32), 2), (32, 32, (48, 4, 16), 1), (32, 32, (96, 96, 96), 2), (32, 32, (48, 48, 48), 1)]
+@pytest.mark.parametrize("cin,cout,dims,n", H2W_CASES)
+def test_conv3d_h2w_winograd_split_precision(cin, cout, dims, n):
+    """F(2x2, 3x3) in the plane, transformed weights in registers, split-precision products of the transformed operands -- held to the SAME tolerance as the direct
+    split kernel and the fp32 tiles; then the accumulating and (even extents) the pooling forms"""
+    from monai_amd import ops
+
+    cfg = ops.conv3d_k3_h2w_config()
+    assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and ops.conv3d_k3_h2w_fits(*dims)
+    kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True)
+    kc.case_conv3d_accumulate(DEV, n, cin, cout, dims, cfg=cfg)
+    if dims[0] % 2 == 0:
+        kc.case_conv3d_pool(DEV, n, cin, cout, dims, cfg=cfg)
+
+
 LINEAR_CASES = [(128, 64, 16, False, False), (200, 144, 48, False, True), (66, 40, 36, True, False), (256, 192, 64, True, True), (13824, 2304, 768, False, False), (1728, 768, 3072, False, True)]
 @pytest.mark.parametrize("m,n,k,gelu,res", LINEAR_CASES)
 def test_linear_fp16_split_precision(m, n, k, gelu, res):
