@@ -240,6 +240,13 @@ _PMC_WIDE_READS = ("sw_blend_mosaic_kernel", "sw_blend_reg_kernel")      # 16 B 
 _PMC_STATUS = {"status": "not_run"}      # why the in-run pass did or did not deliver (printed as line["pmc"])
 
 
+def _pmc_conv_key() -> str:
+    """kernel name of the configuration the selector gives the headline's 32 -> 32 layers at 96^3 (what tools/pmc_probe.py --conv-cfgs auto launches)"""
+    from monai_amd import ops as _ops
+
+    return "conv3d_k3_h2w_kernel" if _ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == _ops.conv3d_k3_h2w_config() else "conv3d_k3_h2_kernel"
+
+
 def pmc_inrun(budget_s: float = 150.0) -> dict:
     """HBM bytes per launch of the blend and of the dominant convolution from the hardware counters, collected in THIS run: two `rocprofv3 --kernel-trace --pmc`
     child processes (FETCH_SIZE, then WRITE_SIZE -- separate passes, as MI355X_MICROARCH.md prescribes) over tools/pmc_probe.py, which launches the two kernels at the
@@ -266,7 +273,7 @@ def pmc_inrun(budget_s: float = 150.0) -> dict:
             for attempt in range(2):
                 out_dir = os.path.join(tmp, f"{counter}_{attempt}")
                 cmd = ["timeout", "-k", "5", str(int(budget_s)), rp, "--kernel-trace", "--pmc", counter, "-d", out_dir, "-o", "p", "--",
-                       sys.executable, os.path.join(here, "tools", "pmc_probe.py"), "--only", "mosaic,conv", "--conv-cfgs", "h2"]
+                       sys.executable, os.path.join(here, "tools", "pmc_probe.py"), "--only", "mosaic,conv", "--conv-cfgs", "auto"]
                 try:
                     r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=budget_s + 30, text=True)
                 except subprocess.TimeoutExpired:
@@ -287,7 +294,7 @@ def pmc_inrun(budget_s: float = 150.0) -> dict:
             if rows is None:
                 _PMC_STATUS["status"] = "failed: " + why
                 return {}
-            for key in ("sw_blend_mosaic_kernel", "conv3d_k3_h2_kernel"):
+            for key in ("sw_blend_mosaic_kernel", _pmc_conv_key()):
                 hit = [(n, avg) for name, n, avg in rows if key in name and "pack" not in name and "scale" not in name]
                 if len(hit) != 1:
                     _PMC_STATUS["status"] = f"failed: {counter}: {len(hit)} kernels match {key}"
@@ -298,7 +305,7 @@ def pmc_inrun(budget_s: float = 150.0) -> dict:
         return {}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    alg = {"sw_blend_mosaic_kernel": 1000 * 5 * 96.0 ** 3 * 4 + 5 * 512.0 ** 3 * 4, "conv3d_k3_h2_kernel": 2 * 64 * 32 * 96.0 ** 3 * 4}
+    alg = {"sw_blend_mosaic_kernel": 1000 * 5 * 96.0 ** 3 * 4 + 5 * 512.0 ** 3 * 4, _pmc_conv_key(): 2 * 64 * 32 * 96.0 ** 3 * 4}
     out = {}
     for key, c in got.items():
         fetch = c["FETCH_SIZE"]["bytes"] * (2.0 if key in _PMC_WIDE_READS else 1.0)
@@ -388,6 +395,8 @@ def conv_roofline(spans, steps: int, ms: float, roi: int):
     peak, pmc_key = PEAK_FP32_TFLOPS, "conv3d_k3_mfma_kernel"
     if cfg_id == _ops.conv3d_k3_h2_config():        # fp16 two-piece split precision: three fp16 MFMA products per fp32 multiply-add
         kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel (v_mfma_f32_32x32x16_f16, hi+lo split)", 1.0 / 3.0, PEAK_F16_TFLOPS, "conv3d_k3_h2_kernel"
+    elif cfg_id == _ops.conv3d_k3_h2w_config():     # in-plane Winograd F(2x2,3x3) in front of the split product: 12 x 3 = 36 instead of 27 x 3 = 81 issued multiply-adds per (voxel, cin, cout)
+        kname, gain, peak, pmc_key = "conv3d_k3_h2w_kernel (F(2x2,3x3) + hi/lo split, v_mfma_f32_16x16x32_f16)", 27.0 / 36.0, PEAK_F16_TFLOPS, "conv3d_k3_h2w_kernel"
     elif cfg_id == _ops.conv3d_k3_h2c_config():     # the same kernel in output channel groups of 16: 6 x 32 columns issued per 3 x 16 useful ones, x 3 piece products
         kname, gain, peak, pmc_key = "conv3d_k3_h2_kernel<C16> (two z-taps per instruction)", 1.0 / 4.0, PEAK_F16_TFLOPS, "conv3d_k3_h2c_kernel"
     elif cfg_id == ncfg:                            # in-plane Winograd: 12 instead of 27 multiply-adds per (voxel, cin, cout)

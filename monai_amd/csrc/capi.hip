@@ -441,7 +441,7 @@ static inline int cout_padded(int cfg, int Cout) { return cfg == 0 ? Cout : cdiv
 // (kernels/conv3d_wino_h2.h): 32 input channels, planes that tile into 4 x 16 regions; same record / bound contract and tolerance class as MH_CFG_H2
 #define MH_CFG_H2W (MH_NUM_CFG + 7)
 #ifndef MH_H2W_DEFAULT
-#define MH_H2W_DEFAULT 0      // mh_conv3d_k3_select returns it only under MONAI_AMD_H2W=1 until the A/B on the MI355X says otherwise
+#define MH_H2W_DEFAULT 1      // measured faster than MH_CFG_H2 at 96^3 and 48^3 (profiles/r06_h2w_*.txt); -DMH_H2W_DEFAULT=0 or MONAI_AMD_H2W=0 (dev build) gives the direct kernel back
 #endif
 #define MH_CFG_LAST MH_CFG_H2W
 static inline bool hv_fits(int D, int H, int W) {
@@ -564,7 +564,7 @@ int mh_conv3d_k3_select(int algo, int input_bounded, int Cin, int Cout, int D, i
     if ((algo == MH_ALGO_AUTO || algo == MH_ALGO_H2) && input_bounded && best != MH_CFG_H2 && best != MH_CFG_H2C && mh_conv3d_k3_accepts(MH_CFG_H2V, Cin, Cout) && hv_fits(D, H, W))
         best = MH_CFG_H2V;
     // round 6: 32 input channels on planes of whole 4 x 16 regions: in-plane Winograd in front of the split product (kernels/conv3d_wino_h2.h)
-    if (best == MH_CFG_H2 && mh_conv3d_k3_accepts(MH_CFG_H2W, Cin, Cout) && hw_fits(D, H, W) && D >= 24 && knob_int("MONAI_AMD_H2W", MH_H2W_DEFAULT) != 0)
+    if (algo == MH_ALGO_AUTO && best == MH_CFG_H2 && mh_conv3d_k3_accepts(MH_CFG_H2W, Cin, Cout) && hw_fits(D, H, W) && D >= 24 && knob_int("MONAI_AMD_H2W", MH_H2W_DEFAULT) != 0)      // MH_ALGO_H2 by name: the direct kernel
         best = MH_CFG_H2W;
     // one input channel: the packed-VALU kernel is write-bound where the fp32 MFMA tile multiplies a zero-padded channel
     if (algo != MH_ALGO_DIRECT && algo != MH_ALGO_WINO2D && mh_conv3d_k3_accepts(MH_CFG_C1, Cin, Cout) && W % 4 == 0 && knob_int("MONAI_AMD_C1", 1) != 0)
@@ -578,7 +578,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg == MH_CFG_H2V) return (int64_t)Cout * Cin * 27 + H2_TAIL;                             // two fp16 pieces per weight + {1 / scale, scale}
-    if (cfg == MH_CFG_H2W) return (int64_t)(Cout / HWG_CN) * 4 * HWG_OPS * 64 * 4 + H2_TAIL;       // [cout group][wave][48 operands][64 lanes][8 halves]
+    if (cfg == MH_CFG_H2W) return (int64_t)(Cout / HWG_CN) * 8 * HWG_OPS * 64 * 4 + H2_TAIL;       // [cout group][8 waves][24 operands][64 lanes][8 halves]
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -734,10 +734,10 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-        if (pool) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, true>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride);
-        else if (accumulate) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, true, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
-        else hipLaunchKernelGGL((conv3d_k3_h2w_kernel<false, false, false>), grid, dim3(256), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        if (pool) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride);
+        else if (accumulate) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else hipLaunchKernelGGL((conv3d_k3_h2w_kernel<false, false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
         return launched("conv3d_k3_h2w");
     }
     if (cfg == MH_CFG_H2V) {

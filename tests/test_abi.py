@@ -52,7 +52,16 @@ def test_host_side_queries_need_no_gpu():
     assert dll.mh_conv3d_k3_select(AUTO, 0, 1, 32, 96, 96, 96) == dll.mh_conv3d_k3_c1_config() > n      # first layer: the one-input-channel kernel
     assert 1 <= dll.mh_conv3d_k3_select(AUTO, 0, 1, 32, 9, 9, 9) <= n                                    # W % 4 != 0: an fp32 matrix-core tile
     dll.mh_conv3d_k3_h2_config.restype = ctypes.c_int
-    assert dll.mh_conv3d_k3_select(AUTO, 1, 32, 32, 96, 96, 96) == dll.mh_conv3d_k3_h2_config()      # bounded input: fp16 two-piece split precision
+    dll.mh_conv3d_k3_h2w_config.restype = ctypes.c_int
+    dll.mh_conv3d_k3_h2w_fits.restype = ctypes.c_int
+    h2w = dll.mh_conv3d_k3_h2w_config()
+    assert h2w > n and h2w != dll.mh_conv3d_k3_h2_config()
+    # bounded input: fp16 two-piece split precision -- 32 input channels on planes of whole 4 x 16 regions: behind the in-plane Winograd transform (round 6); otherwise direct
+    assert dll.mh_conv3d_k3_select(AUTO, 1, 32, 32, 96, 96, 96) == h2w and dll.mh_conv3d_k3_select(AUTO, 1, 32, 64, 48, 48, 48) == h2w
+    assert dll.mh_conv3d_k3_select(AUTO, 1, 64, 32, 96, 96, 96) == dll.mh_conv3d_k3_h2_config() and dll.mh_conv3d_k3_select(AUTO, 1, 32, 32, 24, 24, 24) == dll.mh_conv3d_k3_h2_config()
+    assert dll.mh_conv3d_k3_h2w_fits(96, 96, 96) == 1 and dll.mh_conv3d_k3_h2w_fits(24, 24, 24) == 0 and dll.mh_conv3d_k3_h2w_fits(8, 4, 16) == 1
+    assert dll.mh_conv3d_k3_accepts(h2w, 32, 96) == 1 and dll.mh_conv3d_k3_accepts(h2w, 16, 32) == 0 and dll.mh_conv3d_k3_accepts(h2w, 32, 48) == 0
+    assert dll.mh_conv3d_k3_packed_floats(h2w, 32, 64) == 2 * 49152 + 4 and dll.mh_conv3d_k3_stat_tiles(h2w, 96, 96, 96) == 144 and dll.mh_conv3d_k3_pool_accepts(h2w, 32, 32, 96, 96, 96) == 1
     assert dll.mh_conv3d_k3_select(AUTO, 0, 32, 32, 96, 96, 96) == n      # no magnitude bounds: exact fp32 (large planes: the in-plane Winograd configuration)
     saved = os.environ.get("MONAI_AMD_CONV_ALGO")
     os.environ["MONAI_AMD_CONV_ALGO"] = "h2"                              # ... and nothing in the environment changes that

@@ -86,8 +86,9 @@ db.execute("create table counters_collection (kernel_name text, counter_name tex
 kib = {{"FETCH_SIZE": (9000000.0, 7000000.0), "WRITE_SIZE": (2621440.0, 7077888.0)}}[counter]
 for i in range(3):
     db.execute("insert into counters_collection values (?, ?, ?)", ("void mh::sw_blend_mosaic_kernel<5, 2>(mh::Mosaic)", counter, kib[0] + i - 1))
-    db.execute("insert into counters_collection values (?, ?, ?)", ("void mh::conv3d_k3_h2_kernel<true, true, true, false>(mh::Tensor)", counter, kib[1]))
-db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2_pack_kernel(float const*)", counter, 1.0))
+    db.execute("insert into counters_collection values (?, ?, ?)", ("void mh::conv3d_k3_h2w_kernel<true, false, false>(mh::Tensor)", counter, kib[1]))
+db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2w_pack_kernel(float const*)", counter, 1.0))
+db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2w_scale_fix_kernel(float*)", counter, 1.0))
 db.execute("insert into counters_collection values (?, ?, ?)", ("mh::conv3d_k3_h2_scale_kernel(float const*)", counter, 1.0))
 db.commit()
 """)
@@ -97,7 +98,7 @@ db.commit()
 
     monkeypatch.setattr("shutil.which", lambda name: str(fake) if name == "rocprofv3" else None)
     got = bench.pmc_inrun(budget_s=60)
-    blend, conv = got["sw_blend_mosaic_kernel"], got["conv3d_k3_h2_kernel"]
+    blend, conv = got["sw_blend_mosaic_kernel"], got["conv3d_k3_h2w_kernel"]      # the configuration the selector gives 32 -> 32 channels at 96^3 (bench._pmc_conv_key)
     assert blend["fetch_bytes"] == 2 * 9000000.0 * 1024 and blend["write_bytes"] == 2621440.0 * 1024
     assert conv["fetch_bytes"] == 7000000.0 * 1024 and conv["hbm_bytes_per_launch"] == (7000000.0 + 7077888.0) * 1024
     assert abs(blend["ratio"] - (2 * 9000000.0 + 2621440.0) * 1024 / (1000 * 5 * 96 ** 3 * 4 + 5 * 512 ** 3 * 4)) < 1e-12

@@ -20,7 +20,7 @@ def test_net_single_window_fp16_split_precision_vs_reference(emu, monkeypatch):
     monkeypatch.delenv("MONAI_AMD_CONV_ALGO", raising=False)
     from monai_amd import ops
 
-    assert ops.conv3d_k3_select(32, 32, 32, 32, 32, bounded=True) == ops.conv3d_k3_h2_config()
+    assert ops.conv3d_k3_select(32, 32, 32, 32, 32, bounded=True) == ops.conv3d_k3_h2w_config() and ops.conv3d_k3_select(64, 64, 16, 16, 16, bounded=True) == ops.conv3d_k3_h2_config()
     print(ec.case_net_single_window_vs_golden("cpu", second_window=False))      # the split-precision kernel is 10x slower to emulate: one golden batch
 
 

@@ -97,7 +97,8 @@ def test_conv_mfma_separate_stats_and_select(emu):
     h2 = ops.conv3d_k3_h2_config()
     shapes = ((32, 32, 96, 96, 96), (64, 32, 96, 96, 96), (32, 64, 48, 48, 48), (64, 128, 12, 12, 12))
     assert ops.conv3d_k3_select(1, 32, 96, 96, 96, algo=AUTO) == c1
-    assert [ops.conv3d_k3_select(*a, bounded=True, algo=AUTO) for a in shapes] == [h2] * 4
+    h2w = ops.conv3d_k3_h2w_config()      # round 6: 32 input channels on planes of whole 4 x 16 regions go behind the in-plane Winograd transform
+    assert [ops.conv3d_k3_select(*a, bounded=True, algo=AUTO) for a in shapes] == [h2w, h2, h2w, h2]
     assert [ops.conv3d_k3_select(*a, bounded=True, algo=H2) for a in shapes] == [h2] * 4
     for a in shapes:       # no bounds, no split precision -- under AUTO and even when the family is asked for by name
         assert ops.conv3d_k3_select(*a, bounded=False, algo=AUTO) == ops.conv3d_k3_select(*a, bounded=True, algo=FP32) <= wino2d
@@ -107,7 +108,7 @@ def test_conv_mfma_separate_stats_and_select(emu):
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=AUTO) == ops.conv3d_k3_h2v_config() == ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=H2)
     assert ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=False, algo=AUTO) == 13 == ops.conv3d_k3_select(128, 256, 6, 6, 6, bounded=True, algo=FP32)
     # the split-precision kernel addresses its 32 output planes with 31-bit byte offsets: beyond D*H*W = 2^24 voxels the selector returns the fp32 kernels
-    assert ops.conv3d_k3_select(32, 32, 255, 256, 256, bounded=True, algo=AUTO) == h2
+    assert ops.conv3d_k3_select(32, 32, 255, 256, 256, bounded=True, algo=AUTO) == h2w and ops.conv3d_k3_select(32, 32, 255, 256, 256, bounded=True, algo=H2) == h2
     assert 1 <= ops.conv3d_k3_select(32, 32, 256, 256, 256, bounded=True, algo=AUTO) <= wino2d
     assert 1 <= ops.conv3d_k3_select(32, 32, 64, 512, 512, bounded=True, algo=H2) <= wino2d
     # region shapes of the split-precision kernel (16 x 16 | 8 x 32, whichever covers the plane with fewer): the statistics record count follows
@@ -122,7 +123,9 @@ def test_conv_mfma_separate_stats_and_select(emu):
     saved = config.CONV_ALGO
     try:
         config.CONV_ALGO = "auto"
-        assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == h2 and ops.conv3d_k3_select(32, 32, 96, 96, 96) == wino2d
+        assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == h2w and ops.conv3d_k3_select(32, 32, 96, 96, 96) == wino2d
+        config.CONV_ALGO = "h2"          # the direct split-precision kernel by name
+        assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == h2
         config.CONV_ALGO = "fp32"
         assert ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True) == wino2d
         config.CONV_ALGO = "no-such-family"

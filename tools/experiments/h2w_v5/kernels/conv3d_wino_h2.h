@@ -31,7 +31,7 @@ constexpr int HWG_RY = HWG_BY + 2, HWG_RX = HWG_BX + 2;     // staged rows, colu
 constexpr int HWG_NP = HWG_RY * HWG_RX;                     // staged positions (108)
 constexpr int HWG_PB = 144;                                 // bytes per position: 32 channels fp32 + 16 (bank spread)
 constexpr int HWG_DB = (HWG_NP + 1) * HWG_PB;               // bytes per input buffer (one dump position at the end): 15 696
-constexpr int HWG_ZB = 32 * 1024;                           // bytes per Z exchange buffer: [8 waves = 2 column halves x 4 rows i][2 blocks][2 register pairs][64 lanes][16 bytes]
+constexpr int HWG_ZB = 32 * 1024;                           // bytes per Z exchange buffer: [8 waves = 2 column halves x 4 rows i][2 cout blocks][s | a1][64 lanes][16 bytes]
 constexpr int HWG_OPS = 24;                                 // B operands per wave: [slot][t][cout block][piece]
 constexpr int HWG_CIN = 32, HWG_CN = 32;
 constexpr unsigned HWG_DROP = 0x80000000u;                 // a buffer offset beyond every buffer: the hardware drops the store / returns zeros
@@ -74,6 +74,16 @@ __device__ __forceinline__ void hw_split4p(const f32x4 v, const float m1, u32x2&
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l1) : "v"(h1), "v"(m1), "v"(v[3]));
     hi = u32x2{h0, h1};
     lo = u32x2{l0, l1};
+#endif
+}
+// one v_max_f32 (fmaxf brings two canonicalising instructions with it; both operands here are arithmetic results, and a NaN in one is a NaN in both)
+__device__ __forceinline__ float hw_max(const float a, const float b) {
+#ifdef MH_SIMT_EMULATOR
+    return a != a ? a : (a > b ? a : b);
+#else
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 #endif
 }
 // the value of lane ^ 32 (hi = this lane is in the upper half): one v_permlane32_swap_b32 of two copies -- {x.lo, x.lo} and {x.hi, x.hi} -- and a select; no LDS round trip
@@ -156,22 +166,30 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * (4 * wave + i));
-            nra[i] = a.x * p_; nrb[i] = a.y * p_; nrs[i] = a.z;
+            // wave-uniform values: alpha, slope (and the median's third operand) live in scalar registers, beta in a vector register (one scalar operand per instruction)
+            nra[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.x * p_))); nrb[i] = a.y * p_; nrs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
         }
     }
     // the activation t > 0 ? t : t s in ONE branch-free instruction: for s <= 1 it is max(t, t s), for s > 1 min(t, t s) -- the median of (t, t s, +inf | -inf).  (A NaN
     // input never gets here as a result: its record's bound is non-finite and the whole sample is poisoned.)
     f32x4 nrk;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nrk[i] = nrs[i] <= 1.0f ? __builtin_inff() : -__builtin_inff();
-    const float* xptr = in.data + (long long)n * in.n_stride + (long long)p_first * HW + (long long)(4 * wave) * DHW;
+    for (int i = 0; i < 4; ++i) nrk[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nrs[i] <= 1.0f ? __builtin_inff() : -__builtin_inff())));
+    // ---- staging loads: ONE buffer descriptor over the wave's four channel volumes; the plane advance lives in the lanes' byte offsets (two additions per
+    // plane), the channel in the instruction's scalar offset (three constants) -- no descriptor arithmetic in the march ---------------------------------------
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.data + (long long)n * in.n_stride + (long long)(4 * wave) * DHW), 0, 0x7fffffff, 0x00020000);
+    const unsigned hw4 = (unsigned)(HW * 4);
+    unsigned voff[2] = {soff[0] + (unsigned)p_first * hw4, soff[1] + (unsigned)p_first * hw4};
+    const unsigned cso1 = (unsigned)(DHW * 4), cso2 = 2u * cso1, cso3 = 3u * cso1;
     float xin[2][4];
 #define MH_HW_LDX                                                                                     \
     {                                                                                                 \
-        const auto xr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xptr), 0, 0x7fffffff, 0x00020000); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                xin[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr_, soff[j], (unsigned)(i * DHW * 4), 0)); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            xin[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], 0u, 0));   \
+            xin[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso1, 0)); \
+            xin[j][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso2, 0)); \
+            xin[j][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso3, 0)); \
+        }                                                                                             \
     }
 #define MH_HW_CONV(DBO)                                                                               \
     {                                                                                                 \
@@ -184,7 +202,8 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         }                                                                                             \
     }
     int staged = p_first;             // plane whose loads are in the registers
-#define MH_HW_ADV { const bool adv_ = staged < p_last; xptr += adv_ ? HW : 0LL; staged += adv_ ? 1 : 0; }
+    // advance to the next plane -- not beyond the last one (the loads then repeat the last plane's addresses); the loads run three planes ahead of the march
+#define MH_HW_ADV(STEADY) { const unsigned st_ = staged < p_last ? hw4 : 0u; voff[0] += st_; voff[1] += st_; staged += 1; }
 
     // ---- B operands: the wave's 24 register sets [slot][z-tap][cout block][piece] -------------------------------------------------------------------------
     u32x4 wu[HWG_OPS];
@@ -202,7 +221,6 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // row i of B^T d B:  i = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3;  the wave's columns: jp, jp + 1, jp + 2 of the patch
     const int ra = wi == 0 ? 0 : wi == 2 ? 2 : 1, rb = wi == 0 ? 2 : wi == 1 ? 2 : wi == 2 ? 1 : 3;
     const float sgn = wi == 1 ? 1.0f : -1.0f;
-    const float fsg = jp ? -1.0f : 1.0f;
     const float m1 = h2_minus_one();
     const int ab0 = ((2 * tty + ra) * HWG_RX + 2 * ttx + jp) * HWG_PB + kg * 16;
     const int ab1 = ((2 * tty + rb) * HWG_RX + 2 * ttx + jp) * HWG_PB + kg * 16;
@@ -224,7 +242,15 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     const int co_l = fcb * 16 + (il & 15), co = cg * HWG_CN + co_l;
     const float bco = bias ? bias[co] : 0.0f;
     const float fs2 = fa ? -1.0f : 1.0f;
-    const int zrd = il * 16 + (fcb * 2 + frp) * 1024 + fa * 4096;       // item of transform row i0 = a' (rows i0, i0 + 1, i0 + 2; the column halves of a row are 16 KB apart)
+    // Z exchange: wave w = jp 4 + i leaves, per cout block, s = slot 0 + slot 1 and a1 = slot 1 of its completed set as two 16-byte items per lane (no register
+    // shuffling): [parity][wave][cout block][s | a1][lane][4 tile rows].  With (M0, M1) in the jp 0 wave and (M3, M2) in the jp 1 wave of row i:
+    // Z[b' = 0] = M0 + M1 + M2 = s(jp 0) + a1(jp 1),  Z[b' = 1] = M1 - M2 - M3 = a1(jp 0) - s(jp 1).  The finishing lane reads the register pair frp of its item.
+    const int zwr = wave * 4096 + lane * 16;
+    const int zrd = fa * 4096 + fcb * 2048 + il * 16 + frp * 8;         // row i0 = a' of the jp 0 half (jp 1: + 16384; row + 1: + 4096; a1: + 1024)
+    // the finishing of output plane q runs in the first vector phase after both halves are written: iteration q + 3 (jp 0) / q + 2 (jp 1); its Z parity then is
+    // k & 1 (jp 0) / (k + 1) & 1 (jp 1) in iteration k -- two base addresses, one for even and one for odd k
+    const int zrd_even = zrd + (jp ? HWG_ZB : 0), zrd_odd = zrd + (jp ? 0 : HWG_ZB);
+    const int flag = jp ? 2 : 3;                               // iterations between a plane's last input plane... the finished plane is p - flag
     float inv_a, inv_b;
     {
         const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;      // wtail[1] = the weights' power-of-two scale
@@ -264,6 +290,7 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
             u32x2 hh_, ll_;                                                                           \
             hw_split4p(e_, m1, hh_, ll_); ah[0][2 * h] = hh_[0]; ah[0][2 * h + 1] = hh_[1]; al[0][2 * h] = ll_[0]; al[0][2 * h + 1] = ll_[1]; \
             hw_split4p(f_, m1, hh_, ll_); ah[1][2 * h] = hh_[0]; ah[1][2 * h + 1] = hh_[1]; al[1][2 * h] = ll_[0]; al[1][2 * h + 1] = ll_[1]; \
+            __builtin_amdgcn_sched_barrier(0);      /* one half's six reads in flight at a time: all twelve (and the finishing's) together cost 20 registers more than the kernel has */ \
         }                                                                                             \
     }
     // 36 matrix instructions (S0 = the fresh set of output plane p + 1, S1 = plane p, S2 = plane p - 1)
@@ -279,45 +306,44 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // a plane that does not exist (p = -1, p = D): nothing is added, the fresh set must still start from zero
 #define MH_HW_SKIP(S0)                                                                                \
     { _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[S0][sl][cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    // the wave's part of the inverse transform's column half of the completed set: Z[b' = 0] = M0 + M1 + M2, Z[b' = 1] = M1 - M2 - M3; this wave holds
-    // (slot 0, slot 1) = (M0, M1) [jp 0] or (M3, M2) [jp 1]: (M0 + M1, M1) or (M2, -(M2 + M3)); items {Z0[r], Z1[r], Z0[r + 1], Z1[r + 1]}
-#define MH_HW_ZOUT(S2, Q)                                                                             \
+    // the completed set's two items per cout block into the Z buffer of parity ZP
+#define MH_HW_ZOUT(S2, ZP)                                                                            \
     {                                                                                                 \
-        char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + lane * 16 + wave * 4096;                         \
+        char* const zb_ = zs_ + (ZP) * HWG_ZB + zwr;                                                  \
         _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                            \
-            const f32x4 s_ = acc[S2][0][cb] + acc[S2][1][cb], a1_ = acc[S2][1][cb];                   \
-            if (jp) {                                                                                 \
-                MH_HW_KEEP_BRANCH;                                                                    \
-                _Pragma("unroll") for (int rp = 0; rp < 2; ++rp)                                      \
-                    *reinterpret_cast<f32x4*>(zb_ + (cb * 2 + rp) * 1024) = f32x4{a1_[2 * rp], -s_[2 * rp], a1_[2 * rp + 1], -s_[2 * rp + 1]}; \
-            } else {                                                                                  \
-                _Pragma("unroll") for (int rp = 0; rp < 2; ++rp)                                      \
-                    *reinterpret_cast<f32x4*>(zb_ + (cb * 2 + rp) * 1024) = f32x4{s_[2 * rp], a1_[2 * rp], s_[2 * rp + 1], a1_[2 * rp + 1]}; \
-            }                                                                                         \
+            *reinterpret_cast<f32x4*>(zb_ + cb * 2048) = acc[S2][0][cb] + acc[S2][1][cb];             \
+            *reinterpret_cast<f32x4*>(zb_ + cb * 2048 + 1024) = acc[S2][1][cb];                       \
         }                                                                                             \
     }
-    // output plane Q (ON: it exists and belongs to this chunk -- otherwise the stores go beyond the buffer and the statistics get weight 0):
-    // row a' = 0: Z_0 + Z_1 + Z_2, a' = 1: Z_1 - Z_2 - Z_3 with Z_i = the two column halves' sum; scale back, bias, (old values,) store, statistics, pooling
-#define MH_HW_FINISH(Q, ON)                                                                           \
+    // output plane Q from the Z buffer at ZRD (ON: the plane exists and belongs to this chunk -- otherwise the store goes beyond the buffer and the statistics get
+    // weight 0; STEADY: it is known to): row a' = 0: Z_0 + Z_1 + Z_2, a' = 1: Z_1 - Z_2 - Z_3; scale back, bias, (old values,) store, statistics, pooling
+#define MH_HW_FINISH(Q, ZRD, ON, STEADY)                                                              \
     {                                                                                                 \
-        const bool on_ = (ON);                                                                        \
-        const char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + zrd;                                       \
-        const f32x4 q0_ = *reinterpret_cast<const f32x4*>(zb_) + *reinterpret_cast<const f32x4*>(zb_ + 16384);               \
-        const f32x4 q1_ = *reinterpret_cast<const f32x4*>(zb_ + 4096) + *reinterpret_cast<const f32x4*>(zb_ + 4096 + 16384); \
-        const f32x4 q2_ = *reinterpret_cast<const f32x4*>(zb_ + 8192) + *reinterpret_cast<const f32x4*>(zb_ + 8192 + 16384); \
-        f32x4 o_ = hw_fma4(hw_fma4(q2_, fs2, hw_fma4(q1_, fs2, q0_)) * inv_a, inv_b, f32x4{bco, bco, bco, bco}); \
+        const bool on_ = (STEADY) || (ON);                                                            \
+        const unsigned so_ = on_ ? ooff + (unsigned)(Q) * hw4 : HWG_DROP;                             \
+        const char* const zb_ = zs_ + (ZRD);                                                          \
+        f32x2 z0_[3], z1_[3];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
+            z0_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096) + *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384 + 1024);        \
+            z1_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 1024) - *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384);        \
+        }                                                                                             \
+        const f32x2 fs_ = {fs2, fs2};                                                                 \
+        const f32x2 y0_ = __builtin_elementwise_fma(z0_[2], fs_, __builtin_elementwise_fma(z0_[1], fs_, z0_[0])) * inv_a; \
+        const f32x2 y1_ = __builtin_elementwise_fma(z1_[2], fs_, __builtin_elementwise_fma(z1_[1], fs_, z1_[0])) * inv_a; \
+        f32x4 o_ = {__builtin_fmaf(y0_[0], inv_b, bco), __builtin_fmaf(y1_[0], inv_b, bco), __builtin_fmaf(y0_[1], inv_b, bco), __builtin_fmaf(y1_[1], inv_b, bco)}; \
         if (ACC) o_ += pv;                                                                            \
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, on_ ? ooff + (unsigned)(Q) * (unsigned)(HW * 4) : HWG_DROP, 0, 0); \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, so_, 0, 0);      \
         if (STATS) {        /* sums of the deviations from a pivot (the lane's first value) and of their squares, branch-free: a plane that does not exist has weight 0 */ \
-            pivot = (on_ && !have_c) ? o_[0] : pivot;                                                 \
-            have_c = have_c || on_;                                                                   \
-            const f32x4 d_ = o_ - pivot, dw_ = d_ * (on_ ? 1.0f : 0.0f);                              \
+            if (!(STEADY)) { pivot = (on_ && !have_c) ? o_[0] : pivot; have_c = have_c || on_; }      \
+            const f32x4 d_ = o_ - pivot;                                                              \
+            f32x4 dw_ = d_;                                                                           \
+            if (!(STEADY)) dw_ = d_ * (on_ ? 1.0f : 0.0f);                                            \
             s1 += dw_;                                                                                \
             s2 = __builtin_elementwise_fma(dw_, d_, s2);                                              \
         }                                                                                             \
         if (ACC) {          /* the old values of the NEXT plane's row: requested a whole iteration before they are added */ \
-            const bool nx_ = (Q) + 1 >= zs && (Q) + 1 < ze;                                           \
-            pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * (unsigned)(HW * 4) : HWG_DROP, 0, 0)); \
+            const bool nx_ = (STEADY) || ((Q) + 1 >= zs && (Q) + 1 < ze);                             \
+            pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * hw4 : HWG_DROP, 0, 0)); \
         }                                                                                             \
         if (POOL) {         /* the tile pair's x pairs in-lane; the other row sits in lane ^ 32: lanes 0-31 (maxima) receive the partner's maxima, lanes 32-63 (minima) its minima */ \
             const f32x2 mx_ = {fmaxf(o_[0], o_[1]), fmaxf(o_[2], o_[3])}, mn_ = {fminf(o_[0], o_[1]), fminf(o_[2], o_[3])}; \
@@ -336,9 +362,6 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #else
 #define MH_HW_T(K)
 #endif
-#ifndef HWX_OFF
-#define HWX_OFF 0      // ablation switches (bits): 1 no transform, 2 no staging, 4 no finishing, 8 no matrix instructions, 16 no Z exchange
-#endif
 #ifndef HWX_DEAL
 #define HWX_DEAL 2      // vector instructions the scheduler may place per gap between two matrix instructions of the matrix phase (0: no dealing)
 #endif
@@ -346,68 +369,77 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #define MH_HW_DEAL                                                                                    \
     _Pragma("unroll") for (int g_ = 0; g_ < 36; ++g_) {                                               \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
         __builtin_amdgcn_sched_group_barrier(0x006, HWX_DEAL, 0);                                     \
         __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                            \
     }
 #else
 #define MH_HW_DEAL
 #endif
-    // One iteration = two phases, each closed by a barrier: the VECTOR phase (transform of plane P into the operand registers) and the MATRIX phase (36 matrix
-    // instructions; dealt out over their gaps: the staging of plane P + 2, the loads of plane P + 3, the finishing of output plane P - 2; then the Z halves of
-    // output plane P - 1).  The waves of column pair jp = 1 -- the other wave of every SIMD -- run one phase behind (one barrier before the loop, the jp = 0 waves
-    // one more at the end): the two waves of a SIMD are never in the same kind of phase.  With g the global phase count: jp 0 transforms plane P in phase 2 P and
-    // multiplies in 2 P + 1, jp 1 in 2 P + 1 and 2 P + 2.  Plane P + 2 is staged in phases 2 P + 1 / 2 P + 2 into the buffer plane P - 1 was last read from in
-    // phase 2 P - 1, and first read in phase 2 P + 4.  The Z halves of output plane q are written in phases 2 q + 3 / 2 q + 4, read in 2 q + 5 / 2 q + 6 (iteration
-    // q + 2 of either pair) and their buffer (q & 1) is rewritten by plane q + 2 from phase 2 q + 7 on.
-#define MH_HW_ITER(P, S0, S1, S2)                                                                     \
+    // One iteration k (input plane p = zs - 1 + k) = two phases, each closed by a barrier: the VECTOR phase (transform of plane p into the operand registers; the
+    // finishing of output plane p - 3 | p - 2) and the MATRIX phase (36 matrix instructions with, dealt out over their gaps, the staging of plane p + 2 and the loads
+    // of plane p + 3; then the Z items of output plane p - 1).  The waves of column pair jp = 1 -- the other wave of every SIMD -- run one phase behind (one barrier
+    // before the march, the jp = 0 waves one more at its end): the two waves of a SIMD are never in the same kind of phase.  With g the global phase count: jp 0
+    // transforms plane p in phase 2 p and multiplies in 2 p + 1, jp 1 in 2 p + 1 and 2 p + 2.  Plane p + 2 is staged in phases 2 p + 1 / 2 p + 2 into the buffer
+    // plane p - 1 was last read from in phase 2 p - 1, and first read in phase 2 p + 4.  The Z items of output plane q are written in phases 2 q + 3 / 2 q + 4,
+    // read in 2 q + 6 (jp 0, iteration q + 3) / 2 q + 5 (jp 1, iteration q + 2), and their buffer (q & 1) is rewritten by plane q + 2 from phase 2 q + 7 on.
+    // The march is unrolled six times: the roles of the three accumulator sets and of the three input buffers (period 3) and the Z parities (period 2; zs is even)
+    // are compile-time constants of slot K6 = k % 6.  GEN: the first six iterations and the last block(s), where planes may not exist; otherwise every condition
+    // is known to hold and the iteration is straight-line code.
+#define MH_HW_ITER(P, K6, GEN)                                                                        \
     {                                                                                                 \
+        constexpr int S0_ = (3 - (K6) % 3) % 3, S1_ = (S0_ + 1) % 3, S2_ = (S0_ + 2) % 3;             \
+        constexpr int db0_ = ((K6) % 3) * HWG_DB, db2_ = (((K6) + 2) % 3) * HWG_DB;                   \
         const int p_ = (P);                                                                           \
-        const bool valid_ = p_ >= p_first && p_ <= p_last;                                            \
-        const int qf_ = p_ - 2;                                                                       \
-        if (valid_) { if (!(HWX_OFF & 1)) MH_HW_XFORM(db0) }                                          \
+        const bool valid_ = !(GEN) || (p_ >= p_first && p_ <= p_last);                                \
+        const int qf_ = p_ - flag;                                                                    \
+        if (valid_) MH_HW_XFORM(db0_)                                                                 \
+        MH_HW_FINISH(qf_, ((K6) & 1) ? zrd_odd : zrd_even, qf_ >= zs && qf_ < ze, !(GEN))             \
         MH_HW_T(0)                                                                                    \
         __syncthreads();                                                                              \
         MH_HW_T(1)                                                                                    \
         if (valid_) {                                                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            if (!(HWX_OFF & 2)) { MH_HW_CONV(db2) MH_HW_LDX MH_HW_ADV }                               \
-            if (!(HWX_OFF & 4)) MH_HW_FINISH(qf_, qf_ >= zs && qf_ < ze)                              \
-            if (!(HWX_OFF & 8)) MH_HW_MMS(S0, S1, S2)                                                 \
+            MH_HW_CONV(db2_) MH_HW_LDX MH_HW_ADV(!(GEN))                                              \
+            MH_HW_MMS(S0_, S1_, S2_)                                                                  \
             MH_HW_DEAL                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            { const int t_ = db0; db0 = db1; db1 = db2; db2 = t_; }                                   \
-        } else {                                                                                      \
-            MH_HW_SKIP(S0)                                                                            \
-            if (!(HWX_OFF & 4)) MH_HW_FINISH(qf_, qf_ >= zs && qf_ < ze)                              \
-        }                                                                                             \
-        if (!(HWX_OFF & 16)) if (p_ - 1 >= zs && p_ - 1 < ze) MH_HW_ZOUT(S2, p_ - 1)                  \
+        } else MH_HW_SKIP(S0_)                                                                        \
+        if (!(GEN) || (p_ - 1 >= zs && p_ - 1 < ze)) MH_HW_ZOUT(S2_, (K6) & 1)                        \
         MH_HW_T(2)                                                                                    \
         __syncthreads();                                                                              \
         MH_HW_T(3)                                                                                    \
     }
+#define MH_HW_BLOCK(PB, GEN)                                                                          \
+    {                                                                                                 \
+        MH_HW_ITER((PB), 0, GEN) MH_HW_ITER((PB) + 1, 1, GEN) MH_HW_ITER((PB) + 2, 2, GEN)            \
+        MH_HW_ITER((PB) + 3, 3, GEN) MH_HW_ITER((PB) + 4, 4, GEN) MH_HW_ITER((PB) + 5, 5, GEN)        \
+    }
 
-    // prologue: planes p_first, p_first + 1 in buffers 0, 1, the loads of plane p_first + 2 in flight
-    int db0 = 0, db1 = HWG_DB, db2 = 2 * HWG_DB;
-    MH_HW_LDX MH_HW_ADV
-    __syncthreads();                  // the zeroed buffers
-    MH_HW_CONV(db0)
-    MH_HW_LDX MH_HW_ADV
-    MH_HW_CONV(db1)
-    MH_HW_LDX MH_HW_ADV
-    __syncthreads();
+    // prologue: iteration k uses buffer k % 3 for its own plane: planes p_first, p_first + 1 into buffers k0 % 3, (k0 + 1) % 3 with k0 = p_first - (zs - 1); the
+    // loads of plane p_first + 2 in flight
+    {
+        const int k0 = p_first - (zs - 1);
+        MH_HW_LDX MH_HW_ADV(false)
+        __syncthreads();                  // the zeroed buffers
+        MH_HW_CONV((k0 % 3) * HWG_DB)
+        MH_HW_LDX MH_HW_ADV(false)
+        MH_HW_CONV(((k0 + 1) % 3) * HWG_DB)
+        MH_HW_LDX MH_HW_ADV(false)
+        __syncthreads();
+    }
     if (jp) __syncthreads();
-    for (int p = zs - 1; p <= ze + 1; p += 3) {
-        MH_HW_ITER(p, 0, 1, 2)
-        if (p + 1 > ze + 1) break;
-        MH_HW_ITER(p + 1, 2, 0, 1)
-        if (p + 2 > ze + 1) break;
-        MH_HW_ITER(p + 2, 1, 2, 0)
+    // blocks of six iterations: p = zs - 1 + 6 b ... ; the march ends with iteration p = ze + 2 (the jp 0 waves finish output plane ze - 1 there).  Planes beyond
+    // it in the last block do nothing but keep the barrier count (every test in a GEN iteration fails for them)
+    const int p_end = ze + 2;
+    for (int pb = zs - 1; pb <= p_end; pb += 6) {
+        if (pb > zs - 1 && pb + 5 <= p_last) MH_HW_BLOCK(pb, false)
+        else MH_HW_BLOCK(pb, true)
     }
     if (!jp) __syncthreads();
 #ifdef HWX_PROF
     if (blockIdx.x == 0 && lane == 0) { _Pragma("unroll") for (int k = 0; k < 8; ++k) reinterpret_cast<long long*>(pmax)[wave * 8 + k] = tacc[k]; }
 #endif
+#undef MH_HW_BLOCK
 #undef MH_HW_T
 #undef MH_HW_DEAL
 #undef MH_HW_ITER

@@ -2,7 +2,7 @@
 resample and fused Gaussian on one 512^3 volume, the dominant convolution) so a `rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE`
 pass can attribute HBM traffic per kernel.
 
-    python tools/pmc_probe.py [--only blend,mosaic,resample,gaussian,conv,upconv] [--conv-batch 64] [--conv-cfgs all|h2]
+    python tools/pmc_probe.py [--only blend,mosaic,resample,gaussian,conv,upconv] [--conv-batch 64] [--conv-cfgs all|h2|auto]
 
 bench.py runs the `mosaic,conv` sections (h2 only) under rocprofv3 itself: `roofline*.traffic` of the driver's line."""
 import argparse
@@ -19,7 +19,7 @@ from monai_amd.data.utils import compute_importance_map, window_starts  # noqa: 
 ap = argparse.ArgumentParser()
 ap.add_argument("--only", default="blend,mosaic,resample,gaussian,conv")
 ap.add_argument("--conv-batch", type=int, default=64)
-ap.add_argument("--conv-cfgs", default="all", choices=("all", "h2"))
+ap.add_argument("--conv-cfgs", default="all", choices=("all", "h2", "auto"))
 args = ap.parse_args()
 only = set(args.only.split(","))
 
@@ -73,7 +73,10 @@ if "conv" in only:
     xn[:, :, 1] = 0.1
     xn[:, :, 2] = 0.1
     xn[:, :, 3] = 8.0          # magnitude bound of the activated input (the split-precision kernel scales by it)
-    cfgs = (ops.conv3d_k3_h2_config(),) if args.conv_cfgs == "h2" else (ops.conv3d_k3_h2_config(), ops.conv3d_k3_num_configs(), 7)
+    if args.conv_cfgs == "auto":        # what the selector gives the headline's 32 -> 32 layers at 96^3 (the Winograd split kernel since round 6)
+        cfgs = (ops.conv3d_k3_select(32, 32, 96, 96, 96, bounded=True),)
+    else:
+        cfgs = (ops.conv3d_k3_h2_config(),) if args.conv_cfgs == "h2" else (ops.conv3d_k3_h2_config(), ops.conv3d_k3_num_configs(), 7)
     for cfg in cfgs:
         packed = ops.conv3d_k3_pack(cfg, w)
         tiles = ops.conv3d_k3_stat_tiles(cfg, 96, 96, 96)
