@@ -578,7 +578,7 @@ int64_t mh_conv3d_k3_packed_floats(int cfg, int Cin, int Cout) {
     if (cfg == MH_CFG_H2C) return (int64_t)(Cin / H2_KC) * (Cout / 16) * H2_WB * 4 + H2_TAIL;         // the same slabs, one per group of 16 couts
     if (cfg == MH_CFG_C1) return (int64_t)27 * Cout;                                             // [27 taps][Cout]
     if (cfg == MH_CFG_H2V) return (int64_t)Cout * Cin * 27 + H2_TAIL;                             // two fp16 pieces per weight + {1 / scale, scale}
-    if (cfg == MH_CFG_H2W) return (int64_t)(Cout / HWG_CN) * 8 * HWG_OPS * 64 * 4 + H2_TAIL;       // [cout group][8 waves][24 operands][64 lanes][8 halves]
+    if (cfg == MH_CFG_H2W) return (int64_t)(Cout / HWG_CN) * HWG_WAVES * HWG_OPS * 64 * 4 + H2_TAIL;       // [cout group][wave][its operands][64 lanes][8 halves]
     if (cfg < 0 || cfg > MH_NUM_CFG) return fail(MH_ERR_ARG, "conv3d_k3: unknown configuration %d", cfg);
     return (int64_t)cin_padded(cfg, Cin) * cout_padded(cfg, Cout) * 27;
 }
@@ -734,10 +734,10 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
         const dim3 grid((unsigned)total);
         const uint4* wq = reinterpret_cast<const uint4*>(packed_w);
         const float* tail = packed_w + (mh_conv3d_k3_packed_floats(cfg, in.C, out.C) - H2_TAIL);
-        if (pool) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride);
-        else if (accumulate) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, true, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
-        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
-        else hipLaunchKernelGGL((conv3d_k3_h2w_kernel<false, false, false>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        if (pool) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, true>), grid, dim3(64 * HWG_WAVES), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, pool->mx, pool->mn, pool->n_stride);
+        else if (accumulate) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, true, false>), grid, dim3(64 * HWG_WAVES), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else if (stats) hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(64 * HWG_WAVES), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
+        else hipLaunchKernelGGL((conv3d_k3_h2w_kernel<false, false, false>), grid, dim3(64 * HWG_WAVES), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL);
         return launched("conv3d_k3_h2w");
     }
     if (cfg == MH_CFG_H2V) {

@@ -34,6 +34,7 @@ constexpr int HWG_DB = (HWG_NP + 1) * HWG_PB;               // bytes per input b
 constexpr int HWG_ZB = 32 * 1024;                           // bytes per Z exchange buffer: [8 waves = 2 column halves x 4 rows i][2 blocks][2 register pairs][64 lanes][16 bytes]
 constexpr int HWG_OPS = 24;                                 // B operands per wave: [slot][t][cout block][piece]
 constexpr int HWG_CIN = 32, HWG_CN = 32;
+constexpr int HWG_WAVES = 8;                                // waves of a workgroup
 constexpr unsigned HWG_DROP = 0x80000000u;                 // a buffer offset beyond every buffer: the hardware drops the store / returns zeros
 
 __device__ __forceinline__ void hw_split4(const f32x4 v, u32x2& hi, u32x2& lo) {
@@ -164,14 +165,21 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     f32x4 nrk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) nrk[i] = nrs[i] <= 1.0f ? __builtin_inff() : -__builtin_inff();
-    const float* xptr = in.data + (long long)n * in.n_stride + (long long)p_first * HW + (long long)(4 * wave) * DHW;
+    // ---- staging loads: ONE buffer descriptor over the wave's four channel volumes; the plane advance lives in the lanes' byte offsets (two additions per
+    // plane), the channel in the instruction's scalar offset (three constants) -- no descriptor arithmetic in the march ---------------------------------------
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.data + (long long)n * in.n_stride + (long long)(4 * wave) * DHW), 0, 0x7fffffff, 0x00020000);
+    const unsigned hw4 = (unsigned)(HW * 4);
+    unsigned voff[2] = {soff[0] + (unsigned)p_first * hw4, soff[1] + (unsigned)p_first * hw4};
+    const unsigned cso1 = (unsigned)(DHW * 4), cso2 = 2u * cso1, cso3 = 3u * cso1;
     float xin[2][4];
 #define MH_HW_LDX                                                                                     \
     {                                                                                                 \
-        const auto xr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xptr), 0, 0x7fffffff, 0x00020000); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                 \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                xin[j][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr_, soff[j], (unsigned)(i * DHW * 4), 0)); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+            xin[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], 0u, 0));   \
+            xin[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso1, 0)); \
+            xin[j][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso2, 0)); \
+            xin[j][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso3, 0)); \
+        }                                                                                             \
     }
 #define MH_HW_CONV(DBO)                                                                               \
     {                                                                                                 \
@@ -184,7 +192,7 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         }                                                                                             \
     }
     int staged = p_first;             // plane whose loads are in the registers
-#define MH_HW_ADV { const bool adv_ = staged < p_last; xptr += adv_ ? HW : 0LL; staged += adv_ ? 1 : 0; }
+#define MH_HW_ADV { const unsigned st_ = staged < p_last ? hw4 : 0u; voff[0] += st_; voff[1] += st_; staged += 1; }
 
     // ---- B operands: the wave's 24 register sets [slot][z-tap][cout block][piece] -------------------------------------------------------------------------
     u32x4 wu[HWG_OPS];
@@ -224,7 +232,11 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     const int co_l = fcb * 16 + (il & 15), co = cg * HWG_CN + co_l;
     const float bco = bias ? bias[co] : 0.0f;
     const float fs2 = fa ? -1.0f : 1.0f;
-    const int zrd = il * 16 + (fcb * 2 + frp) * 1024 + fa * 4096;       // item of transform row i0 = a' (rows i0, i0 + 1, i0 + 2; the column halves of a row are 16 KB apart)
+    // Z exchange: wave w = jp 4 + i leaves, per cout block, s = slot 0 + slot 1 and a1 = slot 1 of its completed set as two 16-byte items per lane (no register
+    // shuffling): [parity][wave][cout block][s | a1][lane][4 tile rows].  With (M0, M1) in the jp 0 wave and (M3, M2) in the jp 1 wave of row i:
+    // Z[b' = 0] = M0 + M1 + M2 = s(jp 0) + a1(jp 1),  Z[b' = 1] = M1 - M2 - M3 = a1(jp 0) - s(jp 1).  The finishing lane reads the register pair frp of its item.
+    const int zwr = wave * 4096 + lane * 16;
+    const int zrd = fa * 4096 + fcb * 2048 + il * 16 + frp * 8;         // row i0 = a' of the jp 0 half (jp 1: + 16384; row + 1: + 4096; a1: + 1024)
     float inv_a, inv_b;
     {
         const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;      // wtail[1] = the weights' power-of-two scale
@@ -283,17 +295,10 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // (slot 0, slot 1) = (M0, M1) [jp 0] or (M3, M2) [jp 1]: (M0 + M1, M1) or (M2, -(M2 + M3)); items {Z0[r], Z1[r], Z0[r + 1], Z1[r + 1]}
 #define MH_HW_ZOUT(S2, Q)                                                                             \
     {                                                                                                 \
-        char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + lane * 16 + wave * 4096;                         \
+        char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + zwr;                                             \
         _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                            \
-            const f32x4 s_ = acc[S2][0][cb] + acc[S2][1][cb], a1_ = acc[S2][1][cb];                   \
-            if (jp) {                                                                                 \
-                MH_HW_KEEP_BRANCH;                                                                    \
-                _Pragma("unroll") for (int rp = 0; rp < 2; ++rp)                                      \
-                    *reinterpret_cast<f32x4*>(zb_ + (cb * 2 + rp) * 1024) = f32x4{a1_[2 * rp], -s_[2 * rp], a1_[2 * rp + 1], -s_[2 * rp + 1]}; \
-            } else {                                                                                  \
-                _Pragma("unroll") for (int rp = 0; rp < 2; ++rp)                                      \
-                    *reinterpret_cast<f32x4*>(zb_ + (cb * 2 + rp) * 1024) = f32x4{s_[2 * rp], a1_[2 * rp], s_[2 * rp + 1], a1_[2 * rp + 1]}; \
-            }                                                                                         \
+            *reinterpret_cast<f32x4*>(zb_ + cb * 2048) = acc[S2][0][cb] + acc[S2][1][cb];             \
+            *reinterpret_cast<f32x4*>(zb_ + cb * 2048 + 1024) = acc[S2][1][cb];                       \
         }                                                                                             \
     }
     // output plane Q (ON: it exists and belongs to this chunk -- otherwise the stores go beyond the buffer and the statistics get weight 0):
@@ -302,11 +307,21 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     {                                                                                                 \
         const bool on_ = (ON);                                                                        \
         const char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + zrd;                                       \
-        const f32x4 q0_ = *reinterpret_cast<const f32x4*>(zb_) + *reinterpret_cast<const f32x4*>(zb_ + 16384);               \
-        const f32x4 q1_ = *reinterpret_cast<const f32x4*>(zb_ + 4096) + *reinterpret_cast<const f32x4*>(zb_ + 4096 + 16384); \
-        const f32x4 q2_ = *reinterpret_cast<const f32x4*>(zb_ + 8192) + *reinterpret_cast<const f32x4*>(zb_ + 8192 + 16384); \
-        f32x4 o_ = hw_fma4(hw_fma4(q2_, fs2, hw_fma4(q1_, fs2, q0_)) * inv_a, inv_b, f32x4{bco, bco, bco, bco}); \
-        if (ACC) o_ += pv;                                                                            \
+        f32x2 z0_[3], z1_[3];                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
+            z0_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096) + *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384 + 1024);        \
+            z1_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 1024) - *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384);        \
+        }                                                                                             \
+        const f32x2 fs_ = {fs2, fs2};                                                                 \
+        const f32x2 y0_ = __builtin_elementwise_fma(z0_[2], fs_, __builtin_elementwise_fma(z0_[1], fs_, z0_[0])) * inv_a; \
+        const f32x2 y1_ = __builtin_elementwise_fma(z1_[2], fs_, __builtin_elementwise_fma(z1_[1], fs_, z1_[0])) * inv_a; \
+        f32x4 o_ = {__builtin_fmaf(y0_[0], inv_b, bco), __builtin_fmaf(y1_[0], inv_b, bco), __builtin_fmaf(y0_[1], inv_b, bco), __builtin_fmaf(y1_[1], inv_b, bco)}; \
+        if (ACC) {          /* + the old values; then those of the NEXT plane's row are requested, a whole iteration before they are added -- and BEFORE this plane's store: loads \
+                               and stores share the vmcnt counter, and a request behind the store would make its consumer wait for the store's acknowledgement as well */ \
+            o_ += pv;                                                                                 \
+            const bool nx_ = (Q) + 1 >= zs && (Q) + 1 < ze;                                           \
+            pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * (unsigned)(HW * 4) : HWG_DROP, 0, 0)); \
+        }                                                                                             \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, on_ ? ooff + (unsigned)(Q) * (unsigned)(HW * 4) : HWG_DROP, 0, 0); \
         if (STATS) {        /* sums of the deviations from a pivot (the lane's first value) and of their squares, branch-free: a plane that does not exist has weight 0 */ \
             pivot = (on_ && !have_c) ? o_[0] : pivot;                                                 \
@@ -314,10 +329,6 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
             const f32x4 d_ = o_ - pivot, dw_ = d_ * (on_ ? 1.0f : 0.0f);                              \
             s1 += dw_;                                                                                \
             s2 = __builtin_elementwise_fma(dw_, d_, s2);                                              \
-        }                                                                                             \
-        if (ACC) {          /* the old values of the NEXT plane's row: requested a whole iteration before they are added */ \
-            const bool nx_ = (Q) + 1 >= zs && (Q) + 1 < ze;                                           \
-            pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * (unsigned)(HW * 4) : HWG_DROP, 0, 0)); \
         }                                                                                             \
         if (POOL) {         /* the tile pair's x pairs in-lane; the other row sits in lane ^ 32: lanes 0-31 (maxima) receive the partner's maxima, lanes 32-63 (minima) its minima */ \
             const f32x2 mx_ = {fmaxf(o_[0], o_[1]), fmaxf(o_[2], o_[3])}, mn_ = {fminf(o_[0], o_[1]), fminf(o_[2], o_[3])}; \
@@ -339,20 +350,21 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #ifndef HWX_OFF
 #define HWX_OFF 0      // ablation switches (bits): 1 no transform, 2 no staging, 4 no finishing, 8 no matrix instructions, 16 no Z exchange
 #endif
+    // what the scheduler may place per gap between two matrix instructions of the matrix phase.  Measured per form (profiles/r06_h2w_ab.txt): the plain form is best left to
+    // the compiler's own order (7.07 against 7.22 ms), the accumulating form needs the dealing (8.5 against 11.2 ms: without it the old-value loads end up in front of the
+    // conversion's wait), the pooling form does not care (7.98 / 8.02)
 #ifndef HWX_DEAL
-#define HWX_DEAL 2      // vector instructions the scheduler may place per gap between two matrix instructions of the matrix phase (0: no dealing)
+#define HWX_DEAL 2
 #endif
-#if HWX_DEAL > 0
 #define MH_HW_DEAL                                                                                    \
-    _Pragma("unroll") for (int g_ = 0; g_ < 36; ++g_) {                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x006, HWX_DEAL, 0);                                     \
-        __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                            \
+    if constexpr (ACC || POOL) {                                                                      \
+        _Pragma("unroll") for (int g_ = 0; g_ < 36; ++g_) {                                           \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x006, HWX_DEAL, 0);                                 \
+            __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                        \
+        }                                                                                             \
     }
-#else
-#define MH_HW_DEAL
-#endif
     // One iteration = two phases, each closed by a barrier: the VECTOR phase (transform of plane P into the operand registers) and the MATRIX phase (36 matrix
     // instructions; dealt out over their gaps: the staging of plane P + 2, the loads of plane P + 3, the finishing of output plane P - 2; then the Z halves of
     // output plane P - 1).  The waves of column pair jp = 1 -- the other wave of every SIMD -- run one phase behind (one barrier before the loop, the jp = 0 waves

@@ -31,8 +31,8 @@ constexpr int HWG_RY = HWG_BY + 2, HWG_RX = HWG_BX + 2;     // staged rows, colu
 constexpr int HWG_NP = HWG_RY * HWG_RX;                     // staged positions (108)
 constexpr int HWG_PB = 144;                                 // bytes per position: 32 channels fp32 + 16 (bank spread)
 constexpr int HWG_DB = (HWG_NP + 1) * HWG_PB;               // bytes per input buffer (one dump position at the end): 15 696
-constexpr int HWG_ZB = 32 * 1024;                           // bytes per Z exchange buffer: [8 waves = 2 column halves x 4 rows i][2 cout blocks][s | a1][64 lanes][16 bytes]
-constexpr int HWG_OPS = 24;                                 // B operands per wave: [slot][t][cout block][piece]
+constexpr int HWG_ZB = 32 * 1024;                           // bytes per Z exchange buffer: [8 waves = 2 column halves x 4 rows i][2 blocks][2 register pairs][64 lanes][16 bytes]
+constexpr int HWG_OPS = 12;                                 // B operands per wave: [slot][t][cout block][piece]
 constexpr int HWG_CIN = 32, HWG_CN = 32;
 constexpr unsigned HWG_DROP = 0x80000000u;                 // a buffer offset beyond every buffer: the hardware drops the store / returns zeros
 
@@ -76,16 +76,6 @@ __device__ __forceinline__ void hw_split4p(const f32x4 v, const float m1, u32x2&
     lo = u32x2{l0, l1};
 #endif
 }
-// one v_max_f32 (fmaxf brings two canonicalising instructions with it; both operands here are arithmetic results, and a NaN in one is a NaN in both)
-__device__ __forceinline__ float hw_max(const float a, const float b) {
-#ifdef MH_SIMT_EMULATOR
-    return a != a ? a : (a > b ? a : b);
-#else
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-#endif
-}
 // the value of lane ^ 32 (hi = this lane is in the upper half): one v_permlane32_swap_b32 of two copies -- {x.lo, x.lo} and {x.hi, x.hi} -- and a select; no LDS round trip
 __device__ __forceinline__ float hw_xchg32(const float x, const int hi) {
 #ifdef MH_SIMT_EMULATOR
@@ -103,8 +93,11 @@ __device__ __forceinline__ float hw_xchg32(const float x, const int hi) {
 #define MH_HW_KEEP_BRANCH asm volatile("" ::: "memory")
 #endif
 
+__device__ __forceinline__ float hw_uniform(const float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+constexpr int HWG_WAVES = 16;                               // one transform position (i, j) per wave: i = wave & 3, j = wave >> 2
+
 template <bool STATS, bool ACC = false, bool POOL = false>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(64 * HWG_WAVES)
 conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __restrict__ wtail, const float* __restrict__ bias, Tensor out,
                      float* __restrict__ stats, int bxn, int byn, int zchunk, unsigned nblk, float* __restrict__ pmax, float* __restrict__ pmin,
                      long long pool_n_stride) {
@@ -114,7 +107,9 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     char* const zs_ = smem + 3 * HWG_DB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wi = wave & 3, jp = wave >> 2;                    // row of transform positions, pair of columns (jp 0: j = 0, 1; jp 1: j = 3, 2)
+    const int wi = wave & 3, wj = wave >> 2;                    // the wave's transform position (row i, column j)
+    const bool stager = wave >= 8;                              // waves 8-15 stage the input planes, waves 0-7 finish the output planes
+    const int w8 = wave & 7;
     const int Cout = out.C, D = out.D, H = out.H, W = out.W;
     const long long HW = (long long)H * W, DHW = (long long)D * HW;
 
@@ -128,9 +123,10 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     const int zs = (int)(b / (bxn * byn)) * zchunk, ze = min(zs + zchunk, D);
     const int p_first = max(zs - 1, 0), p_last = min(ze, D - 1);
 
-    // ---- staging: wave w converts channel quad w (channels 4 w .. 4 w + 3) for positions lane, lane + 64 of the 108 --------------------------------------
-    unsigned soff[2];                 // byte offset of the position inside a channel plane
+    // ---- staging (waves 8-15): wave 8 + q converts channel quad q (channels 4 q .. 4 q + 3) for positions lane, lane + 64 of the 108 ------------------------
+    unsigned voff[2];                 // byte offset of the position inside the wave's first channel volume, at the plane being loaded
     int loff[2];                      // byte offset of the position's cell in an input buffer (without the quad)
+    const unsigned hw4 = (unsigned)(HW * 4);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = lane + 64 * j;
@@ -138,12 +134,12 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         const int ly = ec / HWG_RX, lx = ec - ly * HWG_RX;
         const int gy = y0 + ly - 1, gx = x0 + lx - 1;
         const bool ok = e < HWG_NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
+        voff[j] = (ok ? 4u * (unsigned)(gy * W + gx) : 0u) + (unsigned)p_first * hw4;
         loff[j] = (ok ? ec : HWG_NP) * HWG_PB;       // zero padding / idle lanes: the dump cell; the real cell stays zero
     }
-    for (int i = tid; i < (3 * HWG_DB + 2 * HWG_ZB) / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);      // the Z buffers too: a plane that does not exist is finished from zeros, not from NaN bit patterns
-    // records of this wave's four channels {alpha, beta, slope} (constant over the march) and the sample's largest bound
-    f32x4 nra, nrb, nrs;
+    for (int i = tid; i < (3 * HWG_DB + 2 * HWG_ZB) / 16; i += 64 * HWG_WAVES) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);      // the Z buffers too: a plane that does not exist is finished from zeros
+    // records of the staging wave's four channels {alpha, beta, slope} (constant over the march) and the sample's largest bound
+    f32x4 nra, nrb, nrs, nrk;
     {
         unsigned mb = 0u;
         if (lane < HWG_CIN) {
@@ -165,21 +161,15 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * (4 * wave + i));
-            // wave-uniform values: alpha, slope (and the median's third operand) live in scalar registers, beta in a vector register (one scalar operand per instruction)
-            nra[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.x * p_))); nrb[i] = a.y * p_; nrs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.z)));
+            const float4 a = *reinterpret_cast<const float4*>(in.nrm + (long long)n * in.nrm_n_stride + 4LL * (4 * w8 + i));
+            // wave-uniform values: alpha, slope and the median's third operand live in scalar registers, beta in a vector register (one scalar operand per instruction)
+            nra[i] = hw_uniform(a.x * p_); nrb[i] = a.y * p_; nrs[i] = hw_uniform(a.z);
+            // the activation t > 0 ? t : t s in ONE branch-free instruction: for s <= 1 it is max(t, t s), for s > 1 min(t, t s) -- the median of (t, t s, +inf | -inf)
+            nrk[i] = hw_uniform(a.z <= 1.0f ? __builtin_inff() : -__builtin_inff());
         }
     }
-    // the activation t > 0 ? t : t s in ONE branch-free instruction: for s <= 1 it is max(t, t s), for s > 1 min(t, t s) -- the median of (t, t s, +inf | -inf).  (A NaN
-    // input never gets here as a result: its record's bound is non-finite and the whole sample is poisoned.)
-    f32x4 nrk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) nrk[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, nrs[i] <= 1.0f ? __builtin_inff() : -__builtin_inff())));
-    // ---- staging loads: ONE buffer descriptor over the wave's four channel volumes; the plane advance lives in the lanes' byte offsets (two additions per
-    // plane), the channel in the instruction's scalar offset (three constants) -- no descriptor arithmetic in the march ---------------------------------------
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.data + (long long)n * in.n_stride + (long long)(4 * wave) * DHW), 0, 0x7fffffff, 0x00020000);
-    const unsigned hw4 = (unsigned)(HW * 4);
-    unsigned voff[2] = {soff[0] + (unsigned)p_first * hw4, soff[1] + (unsigned)p_first * hw4};
+    // staging loads: ONE buffer descriptor over the wave's four channel volumes; the plane advance lives in the lanes' byte offsets, the channel in the scalar offset
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.data + (long long)n * in.n_stride + (long long)(4 * w8) * DHW), 0, 0x7fffffff, 0x00020000);
     const unsigned cso1 = (unsigned)(DHW * 4), cso2 = 2u * cso1, cso3 = 3u * cso1;
     float xin[2][4];
 #define MH_HW_LDX                                                                                     \
@@ -193,76 +183,70 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     }
 #define MH_HW_CONV(DBO)                                                                               \
     {                                                                                                 \
-        char* const db_ = ds + (DBO) + 16 * wave;                                                     \
+        char* const db_ = ds + (DBO) + 16 * w8;                                                       \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
             f32x4 y_;                                                                                 \
             const f32x4 t_ = __builtin_elementwise_fma(f32x4{xin[j][0], xin[j][1], xin[j][2], xin[j][3]}, nra, nrb), u_ = t_ * nrs; \
-            _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = __builtin_amdgcn_fmed3f(t_[i], u_[i], nrk[i]);      /* slope <= 1: max(t, t s), slope > 1: min(t, t s)  ==  t > 0 ? t : t s */ \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = __builtin_amdgcn_fmed3f(t_[i], u_[i], nrk[i]); \
             *reinterpret_cast<f32x4*>(db_ + loff[j]) = y_;                                            \
         }                                                                                             \
     }
     int staged = p_first;             // plane whose loads are in the registers
-    // advance to the next plane -- not beyond the last one (the loads then repeat the last plane's addresses); the loads run three planes ahead of the march
-#define MH_HW_ADV(STEADY) { const unsigned st_ = staged < p_last ? hw4 : 0u; voff[0] += st_; voff[1] += st_; staged += 1; }
+#define MH_HW_ADV { const unsigned st_ = staged < p_last ? hw4 : 0u; voff[0] += st_; voff[1] += st_; staged += 1; }
 
-    // ---- B operands: the wave's 24 register sets [slot][z-tap][cout block][piece] -------------------------------------------------------------------------
+    // ---- B operands: the wave's 12 register sets [z-tap][cout block][piece] -------------------------------------------------------------------------------
     u32x4 wu[HWG_OPS];
     {
-        const u32x4* wg = reinterpret_cast<const u32x4*>(wp) + ((long long)(cg * 8 + wave) * HWG_OPS) * 64 + lane;
+        const u32x4* wg = reinterpret_cast<const u32x4*>(wp) + ((long long)(cg * HWG_WAVES + wave) * HWG_OPS) * 64 + lane;
 #pragma unroll
         for (int r = 0; r < HWG_OPS; ++r) wu[r] = wg[r * 64];
     }
-#define MH_HW_U(SL, T, CB, PC) __builtin_bit_cast(f16x8, wu[(((SL) * 3 + (T)) * 2 + (CB)) * 2 + (PC)])
+#define MH_HW_U(T, CB, PC) __builtin_bit_cast(f16x8, wu[((T) * 2 + (CB)) * 2 + (PC)])
 
     // ---- transform operands of this lane: tile row rho = lane & 15 (rows 0-3: ty 0, tx 0-3; 4-11: ty 1, tx 0-7; 12-15: ty 0, tx 4-7 -- the 16-byte reads of every
     // lane group of ds_read_b128 then cover the 64 banks once), channels 4 kg .. +3 and 16 + 4 kg .. +3 with kg = lane >> 4 -------------------------------------
     const int rho = lane & 15, kg = lane >> 4;
     const int tty = (rho >= 4 && rho < 12) ? 1 : 0, ttx = rho < 4 ? rho : rho < 12 ? rho - 4 : rho - 8;
-    // row i of B^T d B:  i = 0: d0 - d2,  1: d1 + d2,  2: d2 - d1,  3: d1 - d3;  the wave's columns: jp, jp + 1, jp + 2 of the patch
+    // B^T d B at (i, j): rows (i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3) and then columns by the same table at j
     const int ra = wi == 0 ? 0 : wi == 2 ? 2 : 1, rb = wi == 0 ? 2 : wi == 1 ? 2 : wi == 2 ? 1 : 3;
-    const float sgn = wi == 1 ? 1.0f : -1.0f;
+    const int ca = wj == 0 ? 0 : wj == 2 ? 2 : 1, cb_ = wj == 0 ? 2 : wj == 1 ? 2 : wj == 2 ? 1 : 3;
+    const float sgr = wi == 1 ? 1.0f : -1.0f, sgc = wj == 1 ? 1.0f : -1.0f;
     const float m1 = h2_minus_one();
-    const int ab0 = ((2 * tty + ra) * HWG_RX + 2 * ttx + jp) * HWG_PB + kg * 16;
-    const int ab1 = ((2 * tty + rb) * HWG_RX + 2 * ttx + jp) * HWG_PB + kg * 16;
+    const int tb = kg * 16 + ((2 * tty) * HWG_RX + 2 * ttx) * HWG_PB;
+    const int a00 = tb + (ra * HWG_RX + ca) * HWG_PB, a10 = tb + (rb * HWG_RX + ca) * HWG_PB;
+    const int a01 = tb + (ra * HWG_RX + cb_) * HWG_PB, a11 = tb + (rb * HWG_RX + cb_) * HWG_PB;
 
-    f32x4 acc[3][2][2];
+    f32x4 acc[3][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) acc[s][j][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = 0; c < 2; ++c) acc[s][c] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // ---- finishing role: wave = (cout block fcb, register pair frp, half fh of the 64 items); lanes 0-31 finish output row a' = 0 of items 32 fh + (lane & 31),
-    // lanes 32-63 row a' = 1 of the same items (the 2 x 2 pooling window of a tile is then the lane pair l, l ^ 32) ---------------------------------------------
-    const int fcb = wave >> 2, frp = (wave >> 1) & 1, fh = wave & 1;
+    // ---- finishing (waves 0-7): wave = (cout block fcb, register pair frp, half fh of the 64 items); lanes 0-31 finish output row a' = 0 of items
+    // 32 fh + (lane & 31), lanes 32-63 row a' = 1 of the same items (the 2 x 2 pooling window of a tile is then the lane pair l, l ^ 32) -------------------------
+    const int fcb = w8 >> 2, frp = (w8 >> 1) & 1, fh = w8 & 1;
     const int il = 32 * fh + (lane & 31), fa = lane >> 5;
     const int g4 = il >> 4;                                    // D rows 4 g4 + r  ->  g4 0: ty 0, tx 0-3; 1: ty 1, tx 0-3; 2: ty 1, tx 4-7; 3: ty 0, tx 4-7
     const int fty = (g4 == 1 || g4 == 2) ? 1 : 0, ftx = (g4 >= 2 ? 4 : 0) + 2 * frp;
     const int co_l = fcb * 16 + (il & 15), co = cg * HWG_CN + co_l;
     const float bco = bias ? bias[co] : 0.0f;
     const float fs2 = fa ? -1.0f : 1.0f;
-    // Z exchange: wave w = jp 4 + i leaves, per cout block, s = slot 0 + slot 1 and a1 = slot 1 of its completed set as two 16-byte items per lane (no register
-    // shuffling): [parity][wave][cout block][s | a1][lane][4 tile rows].  With (M0, M1) in the jp 0 wave and (M3, M2) in the jp 1 wave of row i:
-    // Z[b' = 0] = M0 + M1 + M2 = s(jp 0) + a1(jp 1),  Z[b' = 1] = M1 - M2 - M3 = a1(jp 0) - s(jp 1).  The finishing lane reads the register pair frp of its item.
-    const int zwr = wave * 4096 + lane * 16;
-    const int zrd = fa * 4096 + fcb * 2048 + il * 16 + frp * 8;         // row i0 = a' of the jp 0 half (jp 1: + 16384; row + 1: + 4096; a1: + 1024)
-    // the finishing of output plane q runs in the first vector phase after both halves are written: iteration q + 3 (jp 0) / q + 2 (jp 1); its Z parity then is
-    // k & 1 (jp 0) / (k + 1) & 1 (jp 1) in iteration k -- two base addresses, one for even and one for odd k
-    const int zrd_even = zrd + (jp ? HWG_ZB : 0), zrd_odd = zrd + (jp ? 0 : HWG_ZB);
-    const int flag = jp ? 2 : 3;                               // iterations between a plane's last input plane... the finished plane is p - flag
+    // Z exchange: wave (i, j) leaves its completed set M[i][j] as one 16-byte item per lane and cout block: [parity][j][i][cout block][lane][4 tile rows];
+    // Z[b' = 0] = M[i][0] + M[i][1] + M[i][2],  Z[b' = 1] = M[i][1] - M[i][2] - M[i][3].  The finishing lane reads the register pair frp of its item.
+    const int zwr = (wj * 4 + wi) * 2048 + lane * 16;
+    const int zrd = fa * 2048 + fcb * 1024 + il * 16 + frp * 8;         // row i0 = a' at j = 0 (j: + 8192 each; row + 1: + 2048)
     float inv_a, inv_b;
     {
         const int t_ = -((int)((__float_as_uint(wtail[1]) >> 23) & 0xffu) - 127) - e_in;      // wtail[1] = the weights' power-of-two scale
         const int t1_ = t_ / 2, t2_ = t_ - t1_;
-        inv_a = poisoned ? __uint_as_float(0x7fc00000u) : __uint_as_float((unsigned)(t1_ + 127) << 23);
-        inv_b = __uint_as_float((unsigned)(t2_ + 127) << 23);
+        inv_a = hw_uniform(poisoned ? __uint_as_float(0x7fc00000u) : __uint_as_float((unsigned)(t1_ + 127) << 23));
+        inv_b = hw_uniform(__uint_as_float((unsigned)(t2_ + 127) << 23));
     }
     const auto orsrc = __builtin_amdgcn_make_buffer_rsrc(out.data + (long long)n * out.n_stride + (long long)(cg * HWG_CN) * DHW, 0, (int)(HWG_CN * DHW * 4), 0x00020000);
     const unsigned ooff = 4u * (unsigned)((long long)co_l * DHW + (long long)(y0 + 2 * fty + fa) * W + x0 + 2 * ftx);
     float pivot = 0.0f;                                      // statistics of this lane's outputs as shifted sums (see MH_HW_FINISH)
     bool have_c = false;
-    f32x4 s1 = {0.0f, 0.0f, 0.0f, 0.0f}, s2 = s1;
+    f32x2 s1 = {0.0f, 0.0f}, s2 = s1;
     const long long PHW = (long long)(H / 2) * (W / 2), PDHW = (long long)(D / 2) * PHW;
     // POOL: lanes 0-31 store the maxima, lanes 32-63 the minima of their tile pair
     const auto prs = __builtin_amdgcn_make_buffer_rsrc(POOL ? (fa ? pmin : pmax) + (long long)n * pool_n_stride + (long long)(cg * HWG_CN) * PDHW : out.data, 0, POOL ? (int)(HWG_CN * PDHW * 4) : 0, 0x00020000);
@@ -272,78 +256,66 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     f32x4 pv = {0.0f, 0.0f, 0.0f, 0.0f};                     // ACC: the old values of the row being finished
 
     // ---- the pieces ---------------------------------------------------------------------------------------------------------------------------------------
-    // transform of the plane at buffer offset DBO: 12 reads of 16 bytes; E = rA - rC (jp 0: V0, jp 1: V3), F = jp 0: rB + rC (V1), jp 1: rB - rA (V2); hi / lo split
-    u32x4 ah[2], al[2];
+    // transform of the plane at buffer offset DBO: 8 reads of 16 bytes, rows then columns, the hi / lo split
+    u32x4 ah, al;
 #define MH_HW_XFORM(DBO)                                                                              \
     {                                                                                                 \
         const char* const db_ = ds + (DBO);                                                           \
         _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                               \
-            f32x4 r_[3];                                                                              \
-            _Pragma("unroll") for (int bq = 0; bq < 3; ++bq) {                                        \
-                const f32x4 u_ = *reinterpret_cast<const f32x4*>(db_ + ab0 + bq * HWG_PB + h * 64);   \
-                const f32x4 v_ = *reinterpret_cast<const f32x4*>(db_ + ab1 + bq * HWG_PB + h * 64);   \
-                r_[bq] = hw_fma4(v_, sgn, u_);                                                        \
-            }                                                                                         \
-            const f32x4 e_ = hw_fma4(r_[2], m1, r_[0]);                                               \
-            f32x4 f_;                                                                                 \
-            if (jp) { f_ = hw_fma4(r_[0], m1, r_[1]); MH_HW_KEEP_BRANCH; } else f_ = r_[1] + r_[2];   \
+            const f32x4 d00_ = *reinterpret_cast<const f32x4*>(db_ + a00 + h * 64), d10_ = *reinterpret_cast<const f32x4*>(db_ + a10 + h * 64); \
+            const f32x4 d01_ = *reinterpret_cast<const f32x4*>(db_ + a01 + h * 64), d11_ = *reinterpret_cast<const f32x4*>(db_ + a11 + h * 64); \
+            const f32x4 v_ = hw_fma4(hw_fma4(d11_, sgr, d01_), sgc, hw_fma4(d10_, sgr, d00_));        \
             u32x2 hh_, ll_;                                                                           \
-            hw_split4p(e_, m1, hh_, ll_); ah[0][2 * h] = hh_[0]; ah[0][2 * h + 1] = hh_[1]; al[0][2 * h] = ll_[0]; al[0][2 * h + 1] = ll_[1]; \
-            hw_split4p(f_, m1, hh_, ll_); ah[1][2 * h] = hh_[0]; ah[1][2 * h + 1] = hh_[1]; al[1][2 * h] = ll_[0]; al[1][2 * h + 1] = ll_[1]; \
-            __builtin_amdgcn_sched_barrier(0);      /* one half's six reads in flight at a time: all twelve (and the finishing's) together cost 20 registers more than the kernel has */ \
+            hw_split4p(v_, m1, hh_, ll_); ah[2 * h] = hh_[0]; ah[2 * h + 1] = hh_[1]; al[2 * h] = ll_[0]; al[2 * h + 1] = ll_[1]; \
         }                                                                                             \
     }
-    // 36 matrix instructions (S0 = the fresh set of output plane p + 1, S1 = plane p, S2 = plane p - 1)
-#define MH_HW_MM(S, SL, CB, A, B, FRESH)                                                              \
-    acc[S][SL][CB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), B, (FRESH) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[S][SL][CB], 0, 0, 0);
+    // 18 matrix instructions (S0 = the fresh set of output plane p + 1, S1 = plane p, S2 = plane p - 1)
+#define MH_HW_MM(S, CB, A, B, FRESH)                                                                  \
+    acc[S][CB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, A), B, (FRESH) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : acc[S][CB], 0, 0, 0);
 #define MH_HW_MMS(S0, S1, S2)                                                                         \
-    _Pragma("unroll") for (int sl = 0; sl < 2; ++sl)                                                  \
-        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                            \
-            MH_HW_MM(S0, sl, cb, ah[sl], MH_HW_U(sl, 0, cb, 0), true)  MH_HW_MM(S1, sl, cb, ah[sl], MH_HW_U(sl, 1, cb, 0), false) MH_HW_MM(S2, sl, cb, ah[sl], MH_HW_U(sl, 2, cb, 0), false) \
-            MH_HW_MM(S0, sl, cb, al[sl], MH_HW_U(sl, 0, cb, 0), false) MH_HW_MM(S1, sl, cb, al[sl], MH_HW_U(sl, 1, cb, 0), false) MH_HW_MM(S2, sl, cb, al[sl], MH_HW_U(sl, 2, cb, 0), false) \
-            MH_HW_MM(S0, sl, cb, ah[sl], MH_HW_U(sl, 0, cb, 1), false) MH_HW_MM(S1, sl, cb, ah[sl], MH_HW_U(sl, 1, cb, 1), false) MH_HW_MM(S2, sl, cb, ah[sl], MH_HW_U(sl, 2, cb, 1), false) \
-        }
-    // a plane that does not exist (p = -1, p = D): nothing is added, the fresh set must still start from zero
-#define MH_HW_SKIP(S0)                                                                                \
-    { _Pragma("unroll") for (int sl = 0; sl < 2; ++sl) _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) acc[S0][sl][cb] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-    // the completed set's two items per cout block into the Z buffer of parity ZP
-#define MH_HW_ZOUT(S2, ZP)                                                                            \
-    {                                                                                                 \
-        char* const zb_ = zs_ + (ZP) * HWG_ZB + zwr;                                                  \
-        _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                            \
-            *reinterpret_cast<f32x4*>(zb_ + cb * 2048) = acc[S2][0][cb] + acc[S2][1][cb];             \
-            *reinterpret_cast<f32x4*>(zb_ + cb * 2048 + 1024) = acc[S2][1][cb];                       \
-        }                                                                                             \
+    _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) {                                                \
+        MH_HW_MM(S0, cb, ah, MH_HW_U(0, cb, 0), true)  MH_HW_MM(S1, cb, ah, MH_HW_U(1, cb, 0), false) MH_HW_MM(S2, cb, ah, MH_HW_U(2, cb, 0), false) \
+        MH_HW_MM(S0, cb, al, MH_HW_U(0, cb, 0), false) MH_HW_MM(S1, cb, al, MH_HW_U(1, cb, 0), false) MH_HW_MM(S2, cb, al, MH_HW_U(2, cb, 0), false) \
+        MH_HW_MM(S0, cb, ah, MH_HW_U(0, cb, 1), false) MH_HW_MM(S1, cb, ah, MH_HW_U(1, cb, 1), false) MH_HW_MM(S2, cb, ah, MH_HW_U(2, cb, 1), false) \
     }
-    // output plane Q from the Z buffer at ZRD (ON: the plane exists and belongs to this chunk -- otherwise the store goes beyond the buffer and the statistics get
-    // weight 0; STEADY: it is known to): row a' = 0: Z_0 + Z_1 + Z_2, a' = 1: Z_1 - Z_2 - Z_3; scale back, bias, (old values,) store, statistics, pooling
-#define MH_HW_FINISH(Q, ZRD, ON, STEADY)                                                              \
+    // a plane that does not exist (p = -1, p = D): nothing is added, the fresh set must still start from zero
+#define MH_HW_SKIP(S0) { acc[S0][0] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; acc[S0][1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    // the completed set into the Z buffer of plane Q
+#define MH_HW_ZOUT(S2, Q)                                                                             \
     {                                                                                                 \
-        const bool on_ = (STEADY) || (ON);                                                            \
-        const unsigned so_ = on_ ? ooff + (unsigned)(Q) * hw4 : HWG_DROP;                             \
-        const char* const zb_ = zs_ + (ZRD);                                                          \
+        char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + zwr;                                             \
+        *reinterpret_cast<f32x4*>(zb_) = acc[S2][0];                                                  \
+        *reinterpret_cast<f32x4*>(zb_ + 1024) = acc[S2][1];                                           \
+    }
+    // output plane Q (ON: it exists and belongs to this chunk -- otherwise the store goes beyond the buffer and the statistics get weight 0):
+    // row a' = 0: Z_0 + Z_1 + Z_2, a' = 1: Z_1 - Z_2 - Z_3; scale back, bias, (old values,) store, statistics, pooling
+#define MH_HW_FINISH(Q, ON)                                                                           \
+    {                                                                                                 \
+        const bool on_ = (ON);                                                                        \
+        const char* const zb_ = zs_ + ((Q) & 1) * HWG_ZB + zrd;                                       \
         f32x2 z0_[3], z1_[3];                                                                         \
         _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                               \
-            z0_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096) + *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384 + 1024);        \
-            z1_[i] = *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 1024) - *reinterpret_cast<const f32x2*>(zb_ + i * 4096 + 16384);        \
+            const f32x2 m0_ = *reinterpret_cast<const f32x2*>(zb_ + i * 2048), m1_ = *reinterpret_cast<const f32x2*>(zb_ + i * 2048 + 8192); \
+            const f32x2 m2_ = *reinterpret_cast<const f32x2*>(zb_ + i * 2048 + 16384), m3_ = *reinterpret_cast<const f32x2*>(zb_ + i * 2048 + 24576); \
+            z0_[i] = (m0_ + m1_) + m2_;                                                               \
+            z1_[i] = (m1_ - m2_) - m3_;                                                               \
         }                                                                                             \
         const f32x2 fs_ = {fs2, fs2};                                                                 \
         const f32x2 y0_ = __builtin_elementwise_fma(z0_[2], fs_, __builtin_elementwise_fma(z0_[1], fs_, z0_[0])) * inv_a; \
         const f32x2 y1_ = __builtin_elementwise_fma(z1_[2], fs_, __builtin_elementwise_fma(z1_[1], fs_, z1_[0])) * inv_a; \
         f32x4 o_ = {__builtin_fmaf(y0_[0], inv_b, bco), __builtin_fmaf(y1_[0], inv_b, bco), __builtin_fmaf(y0_[1], inv_b, bco), __builtin_fmaf(y1_[1], inv_b, bco)}; \
-        if (ACC) o_ += pv;                                                                            \
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, so_, 0, 0);      \
-        if (STATS) {        /* sums of the deviations from a pivot (the lane's first value) and of their squares, branch-free: a plane that does not exist has weight 0 */ \
-            if (!(STEADY)) { pivot = (on_ && !have_c) ? o_[0] : pivot; have_c = have_c || on_; }      \
-            const f32x4 d_ = o_ - pivot;                                                              \
-            f32x4 dw_ = d_;                                                                           \
-            if (!(STEADY)) dw_ = d_ * (on_ ? 1.0f : 0.0f);                                            \
-            s1 += dw_;                                                                                \
-            s2 = __builtin_elementwise_fma(dw_, d_, s2);                                              \
-        }                                                                                             \
-        if (ACC) {          /* the old values of the NEXT plane's row: requested a whole iteration before they are added */ \
-            const bool nx_ = (STEADY) || ((Q) + 1 >= zs && (Q) + 1 < ze);                             \
+        if (ACC) {          /* + the old values; then those of the NEXT plane's row are requested, an iteration before they are added -- and BEFORE this plane's store */ \
+            o_ += pv;                                                                                 \
+            const bool nx_ = (Q) + 1 >= zs && (Q) + 1 < ze;                                           \
             pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * hw4 : HWG_DROP, 0, 0)); \
+        }                                                                                             \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, on_ ? ooff + (unsigned)(Q) * hw4 : HWG_DROP, 0, 0); \
+        if (STATS) {        /* sums of the deviations from a pivot (the lane's first value) and of their squares, branch-free: a plane that does not exist has weight 0 */ \
+            pivot = (on_ && !have_c) ? o_[0] : pivot;                                                 \
+            have_c = have_c || on_;                                                                   \
+            const f32x4 d_ = o_ - pivot, dw_ = d_ * (on_ ? 1.0f : 0.0f);                              \
+            s1 += f32x2{dw_[0], dw_[1]} + f32x2{dw_[2], dw_[3]};                                      \
+            s2 = __builtin_elementwise_fma(f32x2{dw_[2], dw_[3]}, f32x2{d_[2], d_[3]}, __builtin_elementwise_fma(f32x2{dw_[0], dw_[1]}, f32x2{d_[0], d_[1]}, s2)); \
         }                                                                                             \
         if (POOL) {         /* the tile pair's x pairs in-lane; the other row sits in lane ^ 32: lanes 0-31 (maxima) receive the partner's maxima, lanes 32-63 (minima) its minima */ \
             const f32x2 mx_ = {fmaxf(o_[0], o_[1]), fmaxf(o_[2], o_[3])}, mn_ = {fminf(o_[0], o_[1]), fminf(o_[2], o_[3])}; \
@@ -356,91 +328,67 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
             hm = on_ ? y_ : hm;                                                                       \
         }                                                                                             \
     }
-#ifdef HWX_PROF      // tools/ubench/h2w_variants.hip: cycles of the four segments of an iteration, summed per wave, written through `pmax` by workgroup 0
+#ifdef HWX_PROF      // tools/ubench/h2w_variants.hip: cycles of the segments of an iteration, summed per wave, written through `pmax` by workgroup 0
 #define MH_HW_T(K) { const long long t_ = __builtin_readcyclecounter(); tacc[K] += t_ - tlast; tlast = t_; }
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+    long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
 #else
 #define MH_HW_T(K)
 #endif
-#ifndef HWX_DEAL
-#define HWX_DEAL 2      // vector instructions the scheduler may place per gap between two matrix instructions of the matrix phase (0: no dealing)
-#endif
-#if HWX_DEAL > 0
-#define MH_HW_DEAL                                                                                    \
-    _Pragma("unroll") for (int g_ = 0; g_ < 36; ++g_) {                                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                            \
-        __builtin_amdgcn_sched_group_barrier(0x006, HWX_DEAL, 0);                                     \
-        __builtin_amdgcn_sched_group_barrier(0x230, 1, 0);                                            \
-    }
-#else
-#define MH_HW_DEAL
-#endif
-    // One iteration k (input plane p = zs - 1 + k) = two phases, each closed by a barrier: the VECTOR phase (transform of plane p into the operand registers; the
-    // finishing of output plane p - 3 | p - 2) and the MATRIX phase (36 matrix instructions with, dealt out over their gaps, the staging of plane p + 2 and the loads
-    // of plane p + 3; then the Z items of output plane p - 1).  The waves of column pair jp = 1 -- the other wave of every SIMD -- run one phase behind (one barrier
-    // before the march, the jp = 0 waves one more at its end): the two waves of a SIMD are never in the same kind of phase.  With g the global phase count: jp 0
-    // transforms plane p in phase 2 p and multiplies in 2 p + 1, jp 1 in 2 p + 1 and 2 p + 2.  Plane p + 2 is staged in phases 2 p + 1 / 2 p + 2 into the buffer
-    // plane p - 1 was last read from in phase 2 p - 1, and first read in phase 2 p + 4.  The Z items of output plane q are written in phases 2 q + 3 / 2 q + 4,
-    // read in 2 q + 6 (jp 0, iteration q + 3) / 2 q + 5 (jp 1, iteration q + 2), and their buffer (q & 1) is rewritten by plane q + 2 from phase 2 q + 7 on.
-    // The march is unrolled six times: the roles of the three accumulator sets and of the three input buffers (period 3) and the Z parities (period 2; zs is even)
-    // are compile-time constants of slot K6 = k % 6.  GEN: the first six iterations and the last block(s), where planes may not exist; otherwise every condition
-    // is known to hold and the iteration is straight-line code.
-#define MH_HW_ITER(P, K6, GEN)                                                                        \
+    // One iteration (input plane P) and ONE barrier: every wave transforms plane P at its position (i, j) and multiplies (18 matrix instructions), leaves the
+    // completed set of output plane P - 1 in the Z buffer; then the staging waves (8-15) convert plane P + 2 into the buffer plane P - 1 was read from an iteration
+    // ago and request plane P + 3, and the finishing waves (0-7) finish output plane P - 2, whose sixteen items were written before the previous barrier (its buffer
+    // is rewritten by plane P in the next iteration, behind this iteration's barrier).  Four waves per SIMD at different points of this sequence hide one another's
+    // latencies; a wave issues less than half the instructions of the eight-wave form.
+#define MH_HW_ITER(P, S0, S1, S2, STG)                                                                \
     {                                                                                                 \
-        constexpr int S0_ = (3 - (K6) % 3) % 3, S1_ = (S0_ + 1) % 3, S2_ = (S0_ + 2) % 3;             \
-        constexpr int db0_ = ((K6) % 3) * HWG_DB, db2_ = (((K6) + 2) % 3) * HWG_DB;                   \
         const int p_ = (P);                                                                           \
-        const bool valid_ = !(GEN) || (p_ >= p_first && p_ <= p_last);                                \
-        const int qf_ = p_ - flag;                                                                    \
-        if (valid_) MH_HW_XFORM(db0_)                                                                 \
-        MH_HW_FINISH(qf_, ((K6) & 1) ? zrd_odd : zrd_even, qf_ >= zs && qf_ < ze, !(GEN))             \
-        MH_HW_T(0)                                                                                    \
-        __syncthreads();                                                                              \
-        MH_HW_T(1)                                                                                    \
+        const bool valid_ = p_ >= p_first && p_ <= p_last;                                            \
+        const int qf_ = p_ - 2;                                                                       \
         if (valid_) {                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-            MH_HW_CONV(db2_) MH_HW_LDX MH_HW_ADV(!(GEN))                                              \
-            MH_HW_MMS(S0_, S1_, S2_)                                                                  \
-            MH_HW_DEAL                                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                        \
-        } else MH_HW_SKIP(S0_)                                                                        \
-        if (!(GEN) || (p_ - 1 >= zs && p_ - 1 < ze)) MH_HW_ZOUT(S2_, (K6) & 1)                        \
+            MH_HW_XFORM(db0)                                                                          \
+            MH_HW_T(0)                                                                                \
+            MH_HW_MMS(S0, S1, S2)                                                                     \
+        } else MH_HW_SKIP(S0)                                                                         \
+        if (p_ - 1 >= zs && p_ - 1 < ze) MH_HW_ZOUT(S2, p_ - 1)                                       \
+        MH_HW_T(1)                                                                                    \
+        if (STG) { if (valid_) { MH_HW_CONV(db2) MH_HW_LDX MH_HW_ADV } }                              \
+        else MH_HW_FINISH(qf_, qf_ >= zs && qf_ < ze)                                                 \
+        if (valid_) { const int t_ = db0; db0 = db1; db1 = db2; db2 = t_; }                           \
         MH_HW_T(2)                                                                                    \
         __syncthreads();                                                                              \
         MH_HW_T(3)                                                                                    \
     }
-#define MH_HW_BLOCK(PB, GEN)                                                                          \
-    {                                                                                                 \
-        MH_HW_ITER((PB), 0, GEN) MH_HW_ITER((PB) + 1, 1, GEN) MH_HW_ITER((PB) + 2, 2, GEN)            \
-        MH_HW_ITER((PB) + 3, 3, GEN) MH_HW_ITER((PB) + 4, 4, GEN) MH_HW_ITER((PB) + 5, 5, GEN)        \
+#define MH_HW_MARCH(STG)                                                                              \
+    for (int p = zs - 1; p <= ze + 1; p += 3) {                                                       \
+        MH_HW_ITER(p, 0, 1, 2, STG)                                                                   \
+        if (p + 1 > ze + 1) break;                                                                    \
+        MH_HW_ITER(p + 1, 2, 0, 1, STG)                                                               \
+        if (p + 2 > ze + 1) break;                                                                    \
+        MH_HW_ITER(p + 2, 1, 2, 0, STG)                                                               \
     }
 
-    // prologue: iteration k uses buffer k % 3 for its own plane: planes p_first, p_first + 1 into buffers k0 % 3, (k0 + 1) % 3 with k0 = p_first - (zs - 1); the
-    // loads of plane p_first + 2 in flight
-    {
-        const int k0 = p_first - (zs - 1);
-        MH_HW_LDX MH_HW_ADV(false)
+    // prologue: planes p_first, p_first + 1 in buffers 0, 1, the loads of plane p_first + 2 in flight.  The march exists twice, once per role: a role's registers
+    // (the staging waves' loads, offsets and records | the finishing waves' sums, offsets and old values) then do not count against the other's 128
+    int db0 = 0, db1 = HWG_DB, db2 = 2 * HWG_DB;
+    if (stager) {
+        MH_HW_LDX MH_HW_ADV
         __syncthreads();                  // the zeroed buffers
-        MH_HW_CONV((k0 % 3) * HWG_DB)
-        MH_HW_LDX MH_HW_ADV(false)
-        MH_HW_CONV(((k0 + 1) % 3) * HWG_DB)
-        MH_HW_LDX MH_HW_ADV(false)
+        MH_HW_CONV(db0)
+        MH_HW_LDX MH_HW_ADV
+        MH_HW_CONV(db1)
+        MH_HW_LDX MH_HW_ADV
         __syncthreads();
+        MH_HW_MARCH(true)
+    } else {
+        __syncthreads();
+        __syncthreads();
+        MH_HW_MARCH(false)
     }
-    if (jp) __syncthreads();
-    // blocks of six iterations: p = zs - 1 + 6 b ... ; the march ends with iteration p = ze + 2 (the jp 0 waves finish output plane ze - 1 there).  Planes beyond
-    // it in the last block do nothing but keep the barrier count (every test in a GEN iteration fails for them)
-    const int p_end = ze + 2;
-    for (int pb = zs - 1; pb <= p_end; pb += 6) {
-        MH_HW_BLOCK(pb, true)
-    }
-    if (!jp) __syncthreads();
+#undef MH_HW_MARCH
 #ifdef HWX_PROF
-    if (blockIdx.x == 0 && lane == 0) { _Pragma("unroll") for (int k = 0; k < 8; ++k) reinterpret_cast<long long*>(pmax)[wave * 8 + k] = tacc[k]; }
+    if (blockIdx.x == 0 && lane == 0) { _Pragma("unroll") for (int k = 0; k < 4; ++k) reinterpret_cast<long long*>(pmax)[wave * 8 + k] = tacc[k]; }
 #endif
-#undef MH_HW_BLOCK
 #undef MH_HW_T
-#undef MH_HW_DEAL
 #undef MH_HW_ITER
 #undef MH_HW_FINISH
 #undef MH_HW_ZOUT
@@ -454,10 +402,10 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #undef MH_HW_LDX
 
     if (STATS) {
-        // the lane's {count, mean, M2} from its shifted sums: 4 values per plane of the chunk
+        // the finishing lane's {count, mean, M2} from its shifted sums: 4 values per plane of the chunk (the staging waves hold nothing)
         Stat run;
         {
-            const float a1 = (s1[0] + s1[1]) + (s1[2] + s1[3]), a2 = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+            const float a1 = s1[0] + s1[1], a2 = s2[0] + s2[1];
             run.n = 4.0f * (float)(ze - zs);
             const float dm = a1 / run.n;
             run.mean = pivot + dm;
@@ -472,7 +420,7 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         }
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
-        if (lane < 16) { red[(wave * 16 + lane) * 3] = run.n; red[(wave * 16 + lane) * 3 + 1] = run.mean; red[(wave * 16 + lane) * 3 + 2] = run.m2; }
+        if (!stager && lane < 16) { red[(wave * 16 + lane) * 3] = run.n; red[(wave * 16 + lane) * 3 + 1] = run.mean; red[(wave * 16 + lane) * 3 + 2] = run.m2; }
         __syncthreads();
         if (tid < HWG_CN) {
             const int cb = tid >> 4, c16 = tid & 15;
@@ -517,9 +465,8 @@ conv3d_k3_h2w_pack_kernel(const float* __restrict__ w, int Cin, int Cout, _Float
                 const double u = tm[i][0] * G[j][0] + tm[i][1] * G[j][1] + tm[i][2] * G[j][2];
                 _Float16 pc[2];
                 h2_split((float)(u * (double)s), pc[0], pc[1]);
-                const int jpq = j >> 1, slot = (j == 0 || j == 3) ? 0 : 1;      // wave = jp 4 + i holds (slot 0, slot 1) = (j 0, j 1) or (j 3, j 2)
                 for (int p = 0; p < 2; ++p) {
-                    const long long r = (((long long)(cg * 8 + jpq * 4 + i) * HWG_OPS) + ((slot * 3 + t) * 2 + cb) * 2 + p) * 64 + ln;
+                    const long long r = (((long long)(cg * HWG_WAVES + j * 4 + i) * HWG_OPS) + (t * 2 + cb) * 2 + p) * 64 + ln;
                     packed[r * 8 + e] = pc[p];
                 }
             }

@@ -18,8 +18,8 @@ int main(int argc, char** argv) {
     hipMalloc(&y, sizeof(float) * N * K * vox);
     hipMalloc(&nrm, sizeof(float) * N * C * 4);
     hipMalloc(&bias, sizeof(float) * K);
-    hipMalloc(&dbg, 4096);
-    hipMemset(dbg, 0, 4096);
+    hipMalloc(&dbg, 8192);
+    hipMemset(dbg, 0, 8192);
     const int bxn = E / HWG_BX, byn = E / HWG_BY;
     int nchunk = (32 + bxn * byn - 1) / (bxn * byn);          // the launcher's z-chunk rule (capi.hip hw_zchunk)
     nchunk = nchunk > E / 12 ? E / 12 : nchunk;
@@ -28,7 +28,10 @@ int main(int argc, char** argv) {
     zc += zc & 1;
     const unsigned nblk = bxn * byn * ((E + zc - 1) / zc);
     hipMalloc(&stats, sizeof(float) * N * K * nblk * 3);
-    const size_t pf = (size_t)(K / HWG_CN) * 8 * HWG_OPS * 64 * 4 + H2_TAIL;
+    #ifndef HWX_WAVES
+#define HWX_WAVES 8
+#endif
+    const size_t pf = (size_t)(K / HWG_CN) * HWX_WAVES * HWG_OPS * 64 * 4 + H2_TAIL;
     hipMalloc(&packed, sizeof(float) * pf);
     std::vector<float> h((size_t)C * vox);
     unsigned s = 12345u;
@@ -55,7 +58,7 @@ int main(int argc, char** argv) {
     float best = 1e9f;
     for (int it = 0; it < 5; ++it) {
         hipEventRecord(e0);
-        hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(512), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk, dbg, (float*)nullptr, 0LL);
+        hipLaunchKernelGGL((conv3d_k3_h2w_kernel<true, false, false>), grid, dim3(64 * HWX_WAVES), 0, 0, in, reinterpret_cast<const uint4*>(packed), tail, bias, out, stats, bxn, byn, zc, nblk, dbg, (float*)nullptr, 0LL);
         hipEventRecord(e1);
         hipDeviceSynchronize();
         float ms;
@@ -67,10 +70,10 @@ int main(int argc, char** argv) {
     printf("%-34s 32 -> 32, %d^3 x %d: %.3f ms  (%.0f TFLOP/s direct-equivalent)  y[..] = %g %g\n", argc > 1 ? argv[1] : "full", E, N, best,
            2.0 * 27 * C * K * vox * N / best / 1e9, ho[0], ho[1]);
 #ifdef HWX_PROF
-    long long t[64];
+    long long t[128];
     hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost);
     const int iters = zc + 3;
-    for (int wv = 0; wv < 8; ++wv)
+    for (int wv = 0; wv < HWX_WAVES; ++wv)
         printf("   wave %d (row %d, columns %d): cycles per iteration: vector phase %5.0f | barrier %5.0f | matrix phase %5.0f | barrier %5.0f\n", wv, wv & 3, wv >> 2,
                (double)t[wv * 8] / iters, (double)t[wv * 8 + 1] / iters, (double)t[wv * 8 + 2] / iters, (double)t[wv * 8 + 3] / iters);
 #endif
