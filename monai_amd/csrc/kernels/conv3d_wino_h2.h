@@ -3,22 +3,31 @@
 // Same reference op, "normalise on load" contract, record / bound contract and tolerance class as conv3d_h2.h (nn.Conv3d of `Convolution`,
 // monai/networks/blocks/convolutions.py:98-171, fed by the previous block's deferred InstanceNorm + LeakyReLU).
 //
-// Why this shape (round 6; DESIGN.md 5.3 sized the corners that keep the transformed weights in LDS or stream them from L2 and found none that fits): the transformed
-// weights live in REGISTERS.  A workgroup is 4 waves, one per SIMD, each with the full 512-register budget.  Wave i owns ROW i of the 4 x 4 transform positions
-// xi = (i, j): its B operands U[(i, j)][z-tap t][32 cin][32 cout] as hi / lo fp16 pieces are 4 x 3 x 2 cout blocks x 2 pieces = 48 operands of
-// v_mfma_f32_16x16x32_f16 = 192 registers, loaded once per workgroup.  M = 16 tiles (a 4 x 16 output region = 2 x 8 tiles of 2 x 2), N = 16 couts per block, K = all
-// 32 input channels in ONE instruction: the transform-domain sums of the three live output planes are 4 j x 3 planes x 2 blocks x 4 = 96 registers.
+// Why this shape (round 6): the transformed weights of 32 x 32 channels are 192 KB as hi / lo fp16 pieces -- more than the LDS, and streaming them from L2
+// would cost more than the matrix instructions save.  They live in REGISTERS instead: a workgroup is 8 waves (two per SIMD, 256 registers each); wave jp 4 + i owns
+// row i and column pair jp of the 4 x 4 transform positions: its B operands U[(i, j)][z-tap t][32 cin][32 cout] as hi / lo pieces are 2 x 3 x 2 cout blocks x 2 pieces
+// = 24 operands of v_mfma_f32_16x16x32_f16 = 96 registers, loaded once per workgroup.  M = 16 tiles (a 4 x 16 output region = 2 x 8 tiles of 2 x 2), N = 16 couts per
+// block, K = all 32 input channels in ONE instruction; the transform-domain sums of the three live output planes are 2 x 3 x 2 x 4 = 48 registers.
 //
-// Per input plane p: (1) all waves stage the activated, scaled fp32 plane region [6 x 18 positions][32 channels] into LDS (144-byte position pitch: the 16-byte operand
-// reads of a lane group cover all 64 banks once); (2) wave i reads the two rows of every tile's 4 x 4 patch that ROW i of B^T d B needs (i = 0: d0 - d2, 1: d1 + d2,
-// 2: d2 - d1, 3: d1 - d3 -- a wave-uniform (row, row, sign)), forms V[i][0..3] in fp32 and splits each into hi / lo fp16 (the split comes AFTER the transform: the
-// sums are exact to fp32 rounding); (3) 72 matrix instructions: for every j, z-tap t and cout block  acc[plane p + 1 - t][j] += Vh Uh + Vl Uh + Vh Ul;
-// (4) when output plane p - 1 is complete its wave-local half of the inverse transform Z[i][b'] = sum_j M[i][j] A^T[b'][j] goes to LDS, and after the plane's barrier
-// every wave finishes a quarter of the outputs Y[a'][b'] = sum_i A^T[a'][i] Z[i][b'] (scale back, bias, statistics, one 16-byte store per output row).
-// The accumulator sets rotate by NAME (the plane loop is unrolled three times), not by register moves; a fresh set starts from the instruction's zero C operand.
+// Per input plane p: (1) the activated, scaled fp32 plane region [6 x 18 positions][32 channels] sits in one of three LDS buffers (144-byte position pitch: the 16-byte
+// operand reads of a lane group cover all 64 banks once; staged two planes ahead, a channel quad per wave); (2) the wave reads the two rows and three columns of every
+// tile's 4 x 4 patch that its positions need (row i of B^T d B: i = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3 -- wave-uniform (row, row, sign); the columns likewise),
+// forms its two V[i][j] in packed fp32 and splits each into hi / lo fp16 (the split comes AFTER the transform: the sums are exact to fp32 rounding); (3) 36 matrix
+// instructions: for both positions, every z-tap t and cout block  acc[plane p + 1 - t] += Vh Uh + Vl Uh + Vh Ul;  (4) when output plane p - 1 is complete the wave's two
+// terms of the inverse transform's column half go to LDS (no register shuffling: s = M_a + M_b and M_b as plain 16-byte items), and two iterations later every wave
+// finishes a quarter of a row pair  Y[a'][b'] = sum_i A^T[a'][i] Z[i][b']  from 8-byte reads (scale back, bias, statistics as shifted sums, one 16-byte store per row).
+// An iteration is two barrier-separated phases -- transform | matrix instructions + staging + finishing + Z items -- and the jp = 1 waves run one phase behind the jp = 0
+// waves, so the two waves of a SIMD are never in the same kind of phase.  The accumulator sets rotate by NAME (the march is unrolled three times); a fresh set starts from
+// the instruction's zero C operand.  ACC: out += ... (old values requested at the start of the iteration's vector phase); POOL: MaxPool3d(2) of the result leaves with it
+// (the 2 x 2 window of a tile is the lane pair l, l ^ 32: one v_permlane32_swap_b32).
+//
+// What bounds it (profiles/r06_h2w_variants.txt, r06_valu_rates.txt): the instruction COUNT.  A wave issues a vector instruction every ~8 cycles whatever its width, and every
+// vector / LDS / scalar instruction takes SIMD time away from the matrix pipe (26-28 % busy); hence the widest forms everywhere (packed fp32, three-instruction pair split,
+// median-of-three activation, 16-byte LDS items).  Measured forms that did not beat this one: four waves with 512 registers, sixteen waves with 128, a six-fold unrolled
+// march with compile-time buffers (tools/experiments/h2w_v5, h2w_v6).
 //
 // Weight preparation (conv3d_k3_h2w_pack_kernel): U = G g G^T per z-tap in fp64, scaled by a power of two (a quarter of conv3d_h2.h's: |U| <= 2.25 max |g|), split
-// into hi / lo fp16, stored in the waves' register order [cout group][wave i][48 operands][64 lanes][8 halves].  The input scale leaves two more bits of headroom than
+// into hi / lo fp16, stored in the waves' register order [cout group][wave][24 operands][64 lanes][8 halves].  The input scale leaves two more bits of headroom than
 // conv3d_h2.h (|V| <= 4 max |d|).
 #pragma once
 #include "common.h"
@@ -316,12 +325,7 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         const f32x2 y0_ = __builtin_elementwise_fma(z0_[2], fs_, __builtin_elementwise_fma(z0_[1], fs_, z0_[0])) * inv_a; \
         const f32x2 y1_ = __builtin_elementwise_fma(z1_[2], fs_, __builtin_elementwise_fma(z1_[1], fs_, z1_[0])) * inv_a; \
         f32x4 o_ = {__builtin_fmaf(y0_[0], inv_b, bco), __builtin_fmaf(y1_[0], inv_b, bco), __builtin_fmaf(y0_[1], inv_b, bco), __builtin_fmaf(y1_[1], inv_b, bco)}; \
-        if (ACC) {          /* + the old values; then those of the NEXT plane's row are requested, a whole iteration before they are added -- and BEFORE this plane's store: loads \
-                               and stores share the vmcnt counter, and a request behind the store would make its consumer wait for the store's acknowledgement as well */ \
-            o_ += pv;                                                                                 \
-            const bool nx_ = (Q) + 1 >= zs && (Q) + 1 < ze;                                           \
-            pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)((Q) + 1) * (unsigned)(HW * 4) : HWG_DROP, 0, 0)); \
-        }                                                                                             \
+        if (ACC) o_ += pv;      /* the old values: requested at the start of this iteration's vector phase (a barrier and the transform ago) */ \
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o_), orsrc, on_ ? ooff + (unsigned)(Q) * (unsigned)(HW * 4) : HWG_DROP, 0, 0); \
         if (STATS) {        /* sums of the deviations from a pivot (the lane's first value) and of their squares, branch-free: a plane that does not exist has weight 0 */ \
             pivot = (on_ && !have_c) ? o_[0] : pivot;                                                 \
@@ -372,11 +376,14 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // multiplies in 2 P + 1, jp 1 in 2 P + 1 and 2 P + 2.  Plane P + 2 is staged in phases 2 P + 1 / 2 P + 2 into the buffer plane P - 1 was last read from in
     // phase 2 P - 1, and first read in phase 2 P + 4.  The Z halves of output plane q are written in phases 2 q + 3 / 2 q + 4, read in 2 q + 5 / 2 q + 6 (iteration
     // q + 2 of either pair) and their buffer (q & 1) is rewritten by plane q + 2 from phase 2 q + 7 on.
-#define MH_HW_ITER(P, S0, S1, S2)                                                                     \
+#define MH_HW_ITER(P, R)                                                                              \
     {                                                                                                 \
+        constexpr int S0 = (3 - (R)) % 3, S1 = (S0 + 1) % 3, S2 = (S0 + 2) % 3;      /* R 0: (0, 1, 2), 1: (2, 0, 1), 2: (1, 2, 0) */ \
+        constexpr int db0 = (R) * HWG_DB, db2 = (((R) + 2) % 3) * HWG_DB;            /* the iteration's own buffer and the one being staged: compile-time LDS offsets */ \
         const int p_ = (P);                                                                           \
         const bool valid_ = p_ >= p_first && p_ <= p_last;                                            \
         const int qf_ = p_ - 2;                                                                       \
+        if (ACC) { const bool nx_ = qf_ >= zs && qf_ < ze; pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, nx_ ? ooff + (unsigned)qf_ * hw4 : HWG_DROP, 0, 0)); } \
         if (valid_) { if (!(HWX_OFF & 1)) MH_HW_XFORM(db0) }                                          \
         MH_HW_T(0)                                                                                    \
         __syncthreads();                                                                              \
@@ -388,7 +395,6 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
             if (!(HWX_OFF & 8)) MH_HW_MMS(S0, S1, S2)                                                 \
             MH_HW_DEAL                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                        \
-            { const int t_ = db0; db0 = db1; db1 = db2; db2 = t_; }                                   \
         } else {                                                                                      \
             MH_HW_SKIP(S0)                                                                            \
             if (!(HWX_OFF & 4)) MH_HW_FINISH(qf_, qf_ >= zs && qf_ < ze)                              \
@@ -399,22 +405,24 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
         MH_HW_T(3)                                                                                    \
     }
 
-    // prologue: planes p_first, p_first + 1 in buffers 0, 1, the loads of plane p_first + 2 in flight
-    int db0 = 0, db1 = HWG_DB, db2 = 2 * HWG_DB;
-    MH_HW_LDX MH_HW_ADV
-    __syncthreads();                  // the zeroed buffers
-    MH_HW_CONV(db0)
-    MH_HW_LDX MH_HW_ADV
-    MH_HW_CONV(db1)
-    MH_HW_LDX MH_HW_ADV
-    __syncthreads();
+    // prologue: iteration k = p - (zs - 1) works on buffer k % 3 (the buffers rotate every iteration, existing plane or not, so their LDS offsets are compile-time constants
+    // of the three-fold unrolled march): planes p_first, p_first + 1 into buffers k0 % 3, (k0 + 1) % 3 with k0 = p_first - (zs - 1); the loads of plane p_first + 2 in flight
+    {
+        const int k0 = p_first - (zs - 1);
+        MH_HW_LDX MH_HW_ADV
+        __syncthreads();                  // the zeroed buffers
+        MH_HW_CONV((k0 % 3) * HWG_DB)
+        MH_HW_LDX MH_HW_ADV
+        MH_HW_CONV(((k0 + 1) % 3) * HWG_DB)
+        MH_HW_LDX MH_HW_ADV
+        __syncthreads();
+    }
     if (jp) __syncthreads();
+    // whole blocks of three iterations up to p = ze + 1 (the iterations behind it find nothing to do but keep the barrier count)
     for (int p = zs - 1; p <= ze + 1; p += 3) {
-        MH_HW_ITER(p, 0, 1, 2)
-        if (p + 1 > ze + 1) break;
-        MH_HW_ITER(p + 1, 2, 0, 1)
-        if (p + 2 > ze + 1) break;
-        MH_HW_ITER(p + 2, 1, 2, 0)
+        MH_HW_ITER(p, 0)
+        MH_HW_ITER(p + 1, 1)
+        MH_HW_ITER(p + 2, 2)
     }
     if (!jp) __syncthreads();
 #ifdef HWX_PROF
