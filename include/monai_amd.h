@@ -173,7 +173,8 @@ int mh_conv3d_k3_h2v_config(void);
 /* mh_conv3d_k3_h2_config's arithmetic behind an in-plane Winograd F(2x2, 3x3) transform (round 6, kernels/conv3d_wino_h2.h): 2.25x fewer matrix instructions per output
  * voxel, the transformed weights resident in registers (one wave per SIMD, each owning one row of the 4 x 4 transform positions), z-streaming.  Same record / bound contract
  * and tolerance class; Cin == 32, Cout % 32 == 0, H % 4 == 0, W % 16 == 0, D >= 2 (mh_conv3d_k3_h2w_fits).  Takes mh_conv3d_k3_accumulate_f32 and mh_conv3d_k3_pool_f32
- * (even D) as well.  mh_conv3d_k3_select returns it in place of mh_conv3d_k3_h2_config for such layers when the environment sets MONAI_AMD_H2W=1. */
+ * (even D) as well.  Under MH_ALGO_AUTO mh_conv3d_k3_select returns it in place of mh_conv3d_k3_h2_config for such layers with D >= 24 (measured 1.17x at 96^3, 1.3x at 48^3:
+ * profiles/r06_h2w_ab.txt); MH_ALGO_H2 by name keeps the direct kernel. */
 int mh_conv3d_k3_h2w_config(void);
 int mh_conv3d_k3_h2w_fits(int D, int H, int W);
 int mh_conv3d_k3_accepts(int cfg, int Cin, int Cout);  /* 1 if `cfg` can run these channel counts */

@@ -443,8 +443,7 @@ class _Plan:
             net._packed[("upcat", name, cfg)] = hit
         _, packed_skip, packed_up, table = hit
         up_flops = 2.0 * 8 * int(src.shape[1]) * cout * d * h * w * n
-        import os as _os
-        if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2w_config()) and _os.environ.get("MONAI_AMD_UPCAT_CONV_FIRST", "0") != "1":
+        if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2w_config()):      # (the other order -- convolution first, composite term accumulated -- measured equal: 655.2 / 655.7 ms, round 6)
             # the composite term is WRITTEN, the split-precision convolution of the skip channels adds itself to it and leaves the statistics of the sum
             with _prof.span("upconv_k4s2", up_flops):
                 ops.upconv_k4s2(src, src_nrm, packed_up, table, out, accumulate=False)
