@@ -128,18 +128,25 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     const int zs = (int)(b / (bxn * byn)) * zchunk, ze = min(zs + zchunk, D);
     const int p_first = max(zs - 1, 0), p_last = min(ze, D - 1);
 
-    // ---- staging: wave w converts channel quad w (channels 4 w .. 4 w + 3) for positions lane, lane + 64 of the 108 --------------------------------------
-    unsigned soff[2];                 // byte offset of the position inside a channel plane
-    int loff[2];                      // byte offset of the position's cell in an input buffer (without the quad)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int e = lane + 64 * j;
-        const int ec = min(e, HWG_NP - 1);
-        const int ly = ec / HWG_RX, lx = ec - ly * HWG_RX;
-        const int gy = y0 + ly - 1, gx = x0 + lx - 1;
-        const bool ok = e < HWG_NP && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        soff[j] = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
-        loff[j] = (ok ? ec : HWG_NP) * HWG_PB;       // zero padding / idle lanes: the dump cell; the real cell stays zero
+    // ---- staging: wave w converts channel quad w (channels 4 w .. 4 w + 3); lane l < 54 owns the position PAIR (row l / 9, columns 2 (l % 9), + 1) of the
+    // 6 x 18 region: one 8-byte load per channel (half the vector-memory instructions of one 4-byte load per position: the texture-address units are the busiest
+    // unit of this kernel, profiles/r06_pmc_h2w_mem.txt), two 16-byte LDS cells.  A pair whose first column lies left of the volume (x = -1) or whose second lies
+    // right of it (x = W) is moved one column inwards: the extra element rewrites a neighbour's cell with the same value, the padding cell stays zero, and no
+    // load ever leaves its row.  Rows outside the volume and idle lanes load offset 0 and write the dump cell.
+    unsigned soff;                    // byte offset of the pair's first element inside a channel plane
+    int loff[2];                      // byte offsets of the two elements' cells in an input buffer (without the quad)
+    {
+        const int pr = min(lane, 53);
+        const int ly = pr / 9;
+        int lx = 2 * (pr - 9 * ly);
+        const int gy = y0 + ly - 1;
+        int gx = x0 + lx - 1;
+        if (gx < 0) { gx += 1; lx += 1; }                       // (x0 = 0, first pair)
+        if (gx + 1 >= W) { gx -= 1; lx -= 1; }                   // (x0 + 16 = W, last pair)
+        const bool ok = lane < 54 && gy >= 0 && gy < H;
+        soff = ok ? 4u * (unsigned)(gy * W + gx) : 0u;
+        loff[0] = (ok ? ly * HWG_RX + lx : HWG_NP) * HWG_PB;       // zero padding / idle lanes: the dump cell; the real cell stays zero
+        loff[1] = (ok ? ly * HWG_RX + lx + 1 : HWG_NP) * HWG_PB;
     }
     for (int i = tid; i < (3 * HWG_DB + 2 * HWG_ZB) / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0u, 0u, 0u, 0u);      // the Z buffers too: a plane that does not exist is finished from zeros, not from NaN bit patterns
     // records of this wave's four channels {alpha, beta, slope} (constant over the march) and the sample's largest bound
@@ -178,30 +185,28 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
     // plane), the channel in the instruction's scalar offset (three constants) -- no descriptor arithmetic in the march ---------------------------------------
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in.data + (long long)n * in.n_stride + (long long)(4 * wave) * DHW), 0, 0x7fffffff, 0x00020000);
     const unsigned hw4 = (unsigned)(HW * 4);
-    unsigned voff[2] = {soff[0] + (unsigned)p_first * hw4, soff[1] + (unsigned)p_first * hw4};
+    unsigned voff = soff + (unsigned)p_first * hw4;
     const unsigned cso1 = (unsigned)(DHW * 4), cso2 = 2u * cso1, cso3 = 3u * cso1;
-    float xin[2][4];
+    f32x2 xin[4];                     // [channel of the quad][element of the pair]
 #define MH_HW_LDX                                                                                     \
     {                                                                                                 \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
-            xin[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], 0u, 0));   \
-            xin[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso1, 0)); \
-            xin[j][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso2, 0)); \
-            xin[j][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, voff[j], cso3, 0)); \
-        }                                                                                             \
+        xin[0] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, 0u, 0));   \
+        xin[1] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, cso1, 0)); \
+        xin[2] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, cso2, 0)); \
+        xin[3] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, voff, cso3, 0)); \
     }
 #define MH_HW_CONV(DBO)                                                                               \
     {                                                                                                 \
         char* const db_ = ds + (DBO) + 16 * wave;                                                     \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
             f32x4 y_;                                                                                 \
-            const f32x4 t_ = __builtin_elementwise_fma(f32x4{xin[j][0], xin[j][1], xin[j][2], xin[j][3]}, nra, nrb), u_ = t_ * nrs; \
+            const f32x4 t_ = __builtin_elementwise_fma(f32x4{xin[0][j], xin[1][j], xin[2][j], xin[3][j]}, nra, nrb), u_ = t_ * nrs; \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) y_[i] = __builtin_amdgcn_fmed3f(t_[i], u_[i], nrk[i]);      /* slope <= 1: max(t, t s), slope > 1: min(t, t s)  ==  t > 0 ? t : t s */ \
             *reinterpret_cast<f32x4*>(db_ + loff[j]) = y_;                                            \
         }                                                                                             \
     }
     int staged = p_first;             // plane whose loads are in the registers
-#define MH_HW_ADV { const unsigned st_ = staged < p_last ? hw4 : 0u; voff[0] += st_; voff[1] += st_; staged += 1; }
+#define MH_HW_ADV { voff += staged < p_last ? hw4 : 0u; staged += 1; }
 
     // ---- B operands: the wave's 24 register sets [slot][z-tap][cout block][piece] -------------------------------------------------------------------------
     u32x4 wu[HWG_OPS];

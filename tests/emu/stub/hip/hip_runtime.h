@@ -324,6 +324,13 @@ template <class V> inline void raw_buffer_store_b64(V data, BufRsrc r, unsigned 
     if (off + 8ull <= r.num_records) std::memcpy(r.base + off, &data, 8);
 }
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+inline u32x2_t raw_buffer_load_b64(BufRsrc r, unsigned voffset, unsigned soffset, int) {      // out of range reads return zeros
+    u32x2_t v = {0u, 0u};
+    const unsigned long long off = (unsigned long long)voffset + soffset;
+    if (off + 8ull <= r.num_records) std::memcpy(&v, r.base + off, 8);
+    return v;
+}
 inline u32x4_t raw_buffer_load_b128(BufRsrc r, unsigned voffset, unsigned soffset, int) {      // out of range reads return zeros
     u32x4_t v = {0u, 0u, 0u, 0u};
     const unsigned long long off = (unsigned long long)voffset + soffset;
@@ -362,6 +369,7 @@ inline unsigned raw_buffer_load_b32(BufRsrc r, unsigned voffset, unsigned soffse
 #define __builtin_amdgcn_raw_buffer_store_b128 emu::raw_buffer_store_b128
 #define __builtin_amdgcn_raw_buffer_store_b64 emu::raw_buffer_store_b64
 #define __builtin_amdgcn_raw_buffer_load_b128 emu::raw_buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_load_b64 emu::raw_buffer_load_b64
 #define __builtin_amdgcn_raw_buffer_load_b32 emu::raw_buffer_load_b32
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
