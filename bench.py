@@ -16,7 +16,7 @@ key means, how it is measured and which caveats apply is written down ONCE in DE
   reference_self_spread   the oracle against ITSELF (1 thread vs the pool's thread layout; oneDNN off vs on): what "bit-exact argmax" means for the reference
   roofline / roofline_hbm the dominant convolution kernel (matrix flops issued / launch time vs the fp16 MFMA peak) and the blend (bytes / time vs 8 TB/s)
   cpu_baseline        the complete CPU-oracle inferer on the host cores (kind "port", bit-pinned to the reference by tests/test_oracle_golden.py)
-  extra               fp32_exact (exact-fp32 kernels, same workload + parity), config3 (UNETR), config4 (Spacing + GaussianSmooth on 4 x 512^3)
+  extra               fp32_exact (exact-fp32 kernels, same workload + parity), direct_split (the direct split-precision kernel everywhere: ms per step), config3 (UNETR), config4 (Spacing + GaussianSmooth on 4 x 512^3)
 """
 
 from __future__ import annotations
@@ -481,6 +481,20 @@ def extra_fp32_exact(args, vol, net, inferer, sync, shared):
     return res
 
 
+def extra_direct_split(args, vol, net, inferer, sync):
+    """the same workload with the DIRECT split-precision kernel on every layer (CONV_ALGO = "h2": what ran before the in-plane Winograd form of round 6): the A/B of
+    `roofline.kernel` on the box of this very run"""
+    from monai_amd import config
+
+    saved = config.CONV_ALGO
+    config.CONV_ALGO = "h2"
+    try:
+        dt, _, _ = timed_steps(inferer, vol, net, 3, 1, sync)
+    finally:
+        config.CONV_ALGO = saved
+    return {"conv_algo": "h2", "ms_per_step": 1e3 * dt / 3}
+
+
 def extra_config3(args, vol, sync, dev, shared=None):
     """BASELINE.json configs[3]: UNETR (ViT-B/16 encoder) over the same volume -- 2 timed steps, the attention kernel's matrix-core rate, and one
     window against the CPU oracle (oracle/unetr.py, bit-pinned to the reference by tests/golden/unetr.npz)"""
@@ -897,7 +911,7 @@ def main(argv=None):
             line["cpu_baseline"] = None
         if world == 1 and args.net == "basicunet" and not args.no_extra and not emulated and not forced:
             extra = {}
-            for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("config3", lambda: extra_config3(args, vol, sync, dev, shared)), ("unet", lambda: extra_unet(args, vol, sync, dev)),
+            for name, fn in (("fp32_exact", lambda: extra_fp32_exact(args, vol, net, inferer, sync, shared)), ("direct_split", lambda: extra_direct_split(args, vol, net, inferer, sync)), ("config3", lambda: extra_config3(args, vol, sync, dev, shared)), ("unet", lambda: extra_unet(args, vol, sync, dev)),
                              ("config4", lambda: extra_config4(dev))):
                 try:
                     extra[name] = fn()
