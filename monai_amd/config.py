@@ -58,6 +58,20 @@ def upcat_fused() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no")
 
 
+# Order of the two halves on the split-precision families: "conv_first" = the skip half is written by the convolution (plain form, no statistics), the composite term adds itself
+# in place and leaves the statistics of the sum; "term_first" = the composite term is written, the convolution's accumulating form adds the skip half.  Same two addends either way
+# (the sum of two floats does not depend on their order: identical raw tensors); the statistics come from the other kernel's tiles (1e-7 relative).  Since the composite kernel
+# carries its epilogue inside the matrix phase (round 6) conv_first is the faster one at the headline's top level: profiles/r06_upcat_order_ab.txt.
+UPCAT_ORDER = None
+
+
+def upcat_order() -> str:
+    v = str(UPCAT_ORDER if UPCAT_ORDER is not None else os.environ.get("MONAI_AMD_UPCAT_ORDER", "conv_first")).lower()
+    if v not in ("conv_first", "term_first"):
+        raise ValueError(f"monai_amd: unknown UpCat order {v!r} (conv_first or term_first)")
+    return v
+
+
 # ---- MaxPool3d(2) inside the producing convolution ------------------------------------------------------------------------------
 # BasicUNet's encoder: the split-precision convolution in front of a pooling leaves the pooled tensor itself (csrc/kernels/conv3d_h2.h, POOL) -- bit-identical logits.
 # False (or MONAI_AMD_POOL_FUSED=0 while None) keeps the pooling pass.

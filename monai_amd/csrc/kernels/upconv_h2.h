@@ -42,11 +42,12 @@ constexpr int UC_NSLOT = (UC_NTASK + UC_NT - 1) / UC_NT;   // per thread: 5
 // taps: coarse offset of tap t (0 / 1) for output parity p is t - 1 + p; the composite kernel index is u + 1 with u = f - 2 c' = [[2, 0], [1, -1]][p][t]
 __host__ __device__ inline int uc_kernel_index(int p, int t) { return p == 0 ? (t == 0 ? 3 : 1) : (t == 0 ? 2 : 0); }
 
-// Schedule of a fine plane (the kernel is bound by the read-modify-write of the 32 output planes: 131 KB per workgroup and plane against 96 matrix instructions per wave):
-//   1. the plane's old values (the convolution's skip half: 8 x 16 bytes per lane) and the raw values of the NEXT coarse plane (5 x 4 loads per thread) are requested,
-//   2. the matrix instructions of this plane run over the two staged coarse planes (they arrive meanwhile),
-//   3. barrier; the next coarse plane is activated, scaled, split and written over the plane that is no longer needed; the sum is formed, stored, its statistics merged,
-//   4. barrier.
+// Schedule of a fine plane (two waves per SIMD, one workgroup per CU):
+//   1. matrix instructions over the first staged coarse plane; in their gaps the PREVIOUS fine plane's epilogue (bias table, old values, 8 x 16-byte stores per lane,
+//      statistics) and then the requests for the raw values of the NEXT coarse plane (5 x 4 loads per thread, after the stores: they share vmcnt),
+//   2. matrix instructions over the second staged coarse plane; in their gaps the conversion of those raw values (activate, scale, split) and, RMW, the requests for this
+//      plane's old values,
+//   3. the sums are scaled back into registers; barrier; the converted plane is written over the coarse plane that is no longer needed; barrier.
 // RMW: the result is added to what `out` holds (and STATS are those of the sum); otherwise it is written (the accumulating convolution adds the skip half afterwards)
 template <bool STATS, bool RMW>
 __global__ void __launch_bounds__(UC_NT, 1)
@@ -81,7 +82,8 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     unsigned mb = 0u;
     if (tid < UC_CIN) {
         const float4 a = load_nrm(low, n, tid);
-        nrm_s[3 * tid] = a.x; nrm_s[3 * tid + 1] = a.y; nrm_s[3 * tid + 2] = a.z;
+        float* r_ = nrm_s + 12 * (tid >> 2) + (tid & 3);      // [channel quad][alpha | beta | slope][4]: a staging task reads its quad's records as three 16-byte values
+        r_[0] = a.x; r_[4] = a.y; r_[8] = a.z;
         const unsigned bb = abs_bits(a.w);
         mb = low.nrm == nullptr ? abs_bits(1.0f) : (bb == 0u ? 0x7fc00000u : bb);      // no bound given counts as non-finite
     }
@@ -103,7 +105,7 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         poisoned = m4 >= 0x7f800000u;
         e_in = (poisoned || low.nrm == nullptr) ? 0 : min(max(15 - ((int)(m4 >> 23) - 126), -100), 100);
         const float p_ = __uint_as_float((unsigned)(e_in + 127) << 23);
-        if (tid < UC_CIN) { nrm_s[3 * tid] *= p_; nrm_s[3 * tid + 1] *= p_; }
+        if (tid < UC_CIN) { nrm_s[12 * (tid >> 2) + (tid & 3)] *= p_; nrm_s[12 * (tid >> 2) + 4 + (tid & 3)] *= p_; }
     }
     __syncthreads();
     float inv_a, inv_b;
@@ -134,37 +136,39 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     const float* src = low.data + (long long)n * low.n_stride;
     const long long lrest = (long long)(low.N - n) * low.n_stride * 4;
     float sreg[UC_NSLOT][4];
-    auto load_plane = [&](int z) {          // requests only: the values are used a plane later
+    auto load_plane = [&](int z, bool on = true) __attribute__((always_inline)) {          // requests only: the values are used a plane later; !on: every offset beyond the buffer (branch-free inside a scheduling region)
+        const unsigned offm = on ? 0u : UC_DROP;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src + (long long)z * HWl), 0, (int)(lrest < 0x7fffffffLL ? lrest : 0x7fffffffLL), 0x00020000);
 #pragma unroll
         for (int s = 0; s < UC_NSLOT; ++s)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sreg[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[s], (unsigned)(i * DHWl * 4), 0));
+            for (int i = 0; i < 4; ++i) sreg[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, soff[s] | offm, (unsigned)(i * DHWl * 4), 0));
     };
     u32x2 chi[UC_NSLOT], clo[UC_NSLOT];                      // the converted pieces of the next plane, held until the plane they replace is no longer read
-    auto convert_regs = [&]() {          // activate + scale + split (vector ALU work that rides between the matrix instructions)
+    const float m1 = h2_minus_one();
+    auto convert_regs = [&]() __attribute__((always_inline)) {          // activate + scale + split, branch-free (vector ALU work that rides between the matrix instructions)
 #pragma unroll
         for (int s = 0; s < UC_NSLOT; ++s) {
-            _Float16 h_[4], l_[4];
-            const int q_ = max(squad[s], 0);
+            const f32x4* rq_ = reinterpret_cast<const f32x4*>(nrm_s) + 3 * max(squad[s], 0);
+            const f32x4 al_ = rq_[0], be_ = rq_[1], sl_ = rq_[2];
+            const unsigned keep_ = ~(unsigned)((int)soff[s] >> 31);      // zero padding / no task: the load returned 0, the activated value must be 0 as well
+            float y_[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 4 * q_ + i;
-                const float y = soff[s] != UC_DROP ? act(sreg[s][i], nrm_s[3 * c], nrm_s[3 * c + 1], nrm_s[3 * c + 2]) : 0.0f;
-                h2_split(y, h_[i], l_[i]);
-            }
-            const f16x2 h01 = {h_[0], h_[1]}, h23 = {h_[2], h_[3]}, l01 = {l_[0], l_[1]}, l23 = {l_[2], l_[3]};
+            for (int i = 0; i < 4; ++i) y_[i] = __uint_as_float(__float_as_uint(act(sreg[s][i], al_[i], be_[i], sl_[i])) & keep_);
+            f16x2 h01, h23, l01, l23;
+            h2_split_pair(y_[0], y_[1], m1, h01, l01);
+            h2_split_pair(y_[2], y_[3], m1, h23, l23);
             chi[s] = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
             clo[s] = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
         }
     };
-    auto write_regs = [&](int bufi) {
+    auto write_regs = [&](int bufi) __attribute__((always_inline)) {
         u32x2* xh = reinterpret_cast<u32x2*>(xs + bufi * UC_XB);
 #pragma unroll
         for (int s = 0; s < UC_NSLOT; ++s)
             if (squad[s] >= 0) { xh[scell[s]] = chi[s]; xh[scell[s] + 2 * UC_XP] = clo[s]; }
     };
-    auto convert_plane = [&](int bufi) { convert_regs(); write_regs(bufi); };
+    auto convert_plane = [&](int bufi) __attribute__((always_inline)) { convert_regs(); write_regs(bufi); };
 
     // ---- operands of this lane: A = coarse voxel (row 2 wave + (r >> 4), column r & 15), B = cout r; k group = lane >> 5
     const int r32 = lane & 31, kg = lane >> 5;
@@ -208,26 +212,87 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
     }
     __syncthreads();
 
+    // A fine plane's sums leave the matrix phase scaled back (op_) and wait there: their bias, old values, stores and statistics are branch-free pieces that ride in
+    // the matrix-instruction gaps of the NEXT plane's first half (conv3d_h2.h's scheme; round 6 -- before, the whole epilogue sat between the two barriers of a plane
+    // with no matrix instruction beside it: matrix pipe 0.34).  pend: op_ holds a plane (0 in the first iteration of a chunk: offsets beyond the buffer, weights 0).
+    f32x4 op_[8], prev[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { op_[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; prev[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+    int pend = 0, fzp = 0;
+    float ecnt_ = 0.0f, esum_ = 0.0f, emean_ = 0.0f, em2_ = 0.0f;
+    auto request_old = [&](int fz_) __attribute__((always_inline)) {          // RMW: the old values of fine plane fz_, requested half a plane ahead of their use
+        const unsigned so_ = (unsigned)fz_ * (unsigned)(HW * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            prev[2 * j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_, 0, 0));
+            prev[2 * j + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_ + 16u, 0, 0));
+        }
+    };
+    // piece A (row groups J0_, J0_ + 1): bias table, + old value, two 16-byte stores per group (the plane offset in the VECTOR offset: conv3d_h2.h on the scalar-offset hazard)
+#define UC_EMIT_J(J_)                                                                                 \
+    {                                                                                                 \
+        constexpr int j = (J_), r_ = j >> 1, g_ = j & 1;      /* compile-time: the table stays in registers */ \
+        const float bmid = clz == 0 ? btr[0][r_][1] : (clz == 1 ? btr[1][r_][1] : btr[2][r_][1]);     \
+        const float bfst = clz == 0 ? btr[0][r_][0] : (clz == 1 ? btr[1][r_][0] : btr[2][r_][0]);     \
+        const float blst = clz == 0 ? btr[0][r_][2] : (clz == 1 ? btr[1][r_][2] : btr[2][r_][2]);     \
+        const int fx0 = 2 * (cx0 + g_ * 8 + kg * 4);      /* first of this group's 8 fine columns */  \
+        const float bfirst = fx0 == 0 ? bfst : bmid, blast = fx0 + 8 == W ? blst : bmid;              \
+        const f32x4 b0 = {bfirst, bmid, bmid, bmid}, b1 = {bmid, bmid, bmid, blast};                  \
+        f32x4 v0 = op_[2 * j] + b0, v1 = op_[2 * j + 1] + b1;                                         \
+        if (RMW) { v0 = v0 + prev[2 * j]; v1 = v1 + prev[2 * j + 1]; }                                \
+        const unsigned oo_ = (pend ? ooff[j] : UC_DROP) + so_;                                        \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), orsrc, oo_, 0, 0);      \
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), orsrc, oo_ + 16u, 0, 0); \
+        op_[2 * j] = v0; op_[2 * j + 1] = v1;                                                         \
+    }
+#define UC_EMIT_A(J0_)                                                                                \
+    {                                                                                                 \
+        const unsigned so_ = (unsigned)fzp * (unsigned)(HW * 4);                                      \
+        const int clz = fzp == 0 ? 0 : (fzp == D - 1 ? 2 : 1);                                        \
+        UC_EMIT_J(J0_) UC_EMIT_J((J0_) + 1)                                                           \
+    }
+#define UC_EMIT_B1                                                                                    \
+    if (STATS) {                                                                                      \
+        const float pf_ = pend ? 1.0f : 0.0f;                                                         \
+        esum_ = 0.0f; ecnt_ = 0.0f;                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            const float w_ = okg[j] ? pf_ : 0.0f;                                                     \
+            const f32x4 v0 = op_[2 * j], v1 = op_[2 * j + 1];                                         \
+            ecnt_ += 8.0f * w_;                                                                       \
+            esum_ += (((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) * w_; \
+        }                                                                                             \
+        emean_ = ecnt_ > 0.0f ? esum_ / (ecnt_ > 0.0f ? ecnt_ : 1.0f) : 0.0f;                         \
+    }
+#define UC_EMIT_B2                                                                                    \
+    if (STATS) {                                                                                      \
+        em2_ = 0.0f;                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            const f32x4 d0 = op_[2 * j] - emean_, d1 = op_[2 * j + 1] - emean_;                       \
+            const f32x4 q0 = d0 * d0, q1 = d1 * d1;                                                   \
+            em2_ += (((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]))) * (okg[j] && pend ? 1.0f : 0.0f); \
+        }                                                                                             \
+    }
+#define UC_EMIT_B3                                                                                    \
+    {                                                                                                 \
+        if (STATS) {                                                                                  \
+            Stat loc_;                                                                                \
+            loc_.n = ecnt_; loc_.mean = emean_; loc_.m2 = em2_;                                       \
+            run = stat_merge_nb(run, loc_);                                                           \
+        }                                                                                             \
+        pend = 0;                                                                                     \
+    }
+#define UC_NONE
+
     for (int c = cz_s; c < cz_e; ++c) {
         const int za = c - 1 + pz, zb = c + pz;               // the two coarse planes of fine plane 2 c + pz
         const int fz = 2 * c + pz;
-        const unsigned so_ = (unsigned)fz * (unsigned)(HW * 4);
-        // 1. requests: this plane's old values, the next plane's raw input
-        f32x4 prev[8];
-        if (RMW) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                prev[2 * j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_, 0, 0));
-                prev[2 * j + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(orsrc, ooff[j] + so_ + 16u, 0, 0));
-            }
-        }
         const int zn = zb + 1;
         const bool stage_next = c + 1 < cz_e && zn < Dl;
-        if (stage_next) load_plane(zn);
 
-        // 2. matrix instructions: 16 groups (tz, k step, ty, px) of 8 operand reads -> 6 instructions; a group's operands are fetched while the group before it
-        //    multiplies (two register sets), the scheduler deals the reads -- and, in the second half, the conversion of the next plane's raw values -- out over the gaps
-        //    (a wave issues in order: an operand read right in front of its use costs the LDS latency every time; conv3d_h2.h)
+        // matrix instructions: 16 groups (tz, k step, ty, px) of 8 operand reads -> 6 instructions; a group's operands are fetched while the group before it
+        // multiplies (two register sets), the scheduler deals the reads -- in the first half together with the previous plane's epilogue pieces and the requests for
+        // the next coarse plane's raw values (AFTER the stores: both share vmcnt), in the second half with the conversion of those values -- out over the gaps
+        // (a wave issues in order: an operand read right in front of its use costs the LDS latency every time; conv3d_h2.h)
         f32x16 acc[2];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
@@ -246,87 +311,83 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         acc[PX_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, alq[B_][tx_]), __builtin_bit_cast(f16x8, bhq[B_][tx_]), acc[PX_], 0, 0, 0); \
         acc[PX_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ahq[B_][tx_]), __builtin_bit_cast(f16x8, blq[B_][tx_]), acc[PX_], 0, 0, 0); \
     }
-#define UC_GROUP(XB_, TZ_, G_, NV_)                                                                   \
+    // NV_ vector / scalar and NM_ vector-memory instructions per matrix-instruction gap; the code argument joins the group's scheduling region
+#define UC_GROUP(XB_, TZ_, G_, NV_, NM_, ...)                                                         \
     {                                                                                                 \
         if ((G_) + 1 < 8) UC_FETCH(((G_) + 1) & 1, XB_, TZ_, ((G_) + 1 < 8 ? (G_) + 1 : 0))            \
+        __VA_ARGS__                                                                                   \
         UC_MM((G_) & 1, (G_) & 1)                                                                     \
         _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x002, NV_, 0);                                      \
+            __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                      \
+            if ((NM_) > 0) __builtin_amdgcn_sched_group_barrier(0x010, NM_, 0);                       \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-#define UC_HALF(XB_, TZ_, NV_)                                                                        \
+#define UC_HALF(XB_, TZ_, NV_, REQ_)                                                                  \
     {                                                                                                 \
         UC_FETCH(0, XB_, TZ_, 0)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                            \
-        UC_GROUP(XB_, TZ_, 0, NV_) UC_GROUP(XB_, TZ_, 1, NV_) UC_GROUP(XB_, TZ_, 2, NV_) UC_GROUP(XB_, TZ_, 3, NV_) \
-        UC_GROUP(XB_, TZ_, 4, NV_) UC_GROUP(XB_, TZ_, 5, NV_) UC_GROUP(XB_, TZ_, 6, NV_) UC_GROUP(XB_, TZ_, 7, NV_) \
+        UC_GROUP(XB_, TZ_, 0, NV_, 0, UC_NONE) UC_GROUP(XB_, TZ_, 1, NV_, 0, UC_NONE) UC_GROUP(XB_, TZ_, 2, NV_, 0, UC_NONE) UC_GROUP(XB_, TZ_, 3, NV_, 0, UC_NONE) \
+        UC_GROUP(XB_, TZ_, 4, NV_, 2, REQ_) UC_GROUP(XB_, TZ_, 5, NV_, 0, UC_NONE) UC_GROUP(XB_, TZ_, 6, NV_, 0, UC_NONE) UC_GROUP(XB_, TZ_, 7, NV_, 0, UC_NONE) \
     }
-        if (za >= 0 && za < Dl) {                             // zero padding: nothing to add (wave-uniform)
+    // the first half with the previous plane's epilogue and the next coarse plane's requests in its gaps
+#define UC_HALF_EMIT(XB_, TZ_)                                                                        \
+    {                                                                                                 \
+        UC_FETCH(0, XB_, TZ_, 0)                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        UC_GROUP(XB_, TZ_, 0, 8, 1, UC_EMIT_A(0)) UC_GROUP(XB_, TZ_, 1, 8, 1, UC_EMIT_A(2))           \
+        UC_GROUP(XB_, TZ_, 2, 4, 4, load_plane(zn, stage_next);)                                  \
+        UC_GROUP(XB_, TZ_, 3, 8, 0, UC_EMIT_B1) UC_GROUP(XB_, TZ_, 4, 8, 0, UC_EMIT_B2) UC_GROUP(XB_, TZ_, 5, 8, 0, UC_EMIT_B3) \
+        UC_GROUP(XB_, TZ_, 6, 2, 0, UC_NONE) UC_GROUP(XB_, TZ_, 7, 2, 0, UC_NONE)                     \
+    }
+#define UC_REQ_OLD if (RMW) request_old(fz);
+        if (za >= 0 && za < Dl) {                             // zero padding: nothing to add (wave-uniform); then this is a chunk's first plane and nothing is pending
             const uint4* xb = xs + (za & 1) * UC_XB;
-            UC_HALF(xb, 0, 2)
-        }
+            UC_HALF_EMIT(xb, 0)
+        } else if (stage_next) load_plane(zn);
         if (zb >= 0 && zb < Dl) {
             const uint4* xb = xs + (zb & 1) * UC_XB;
-            if (stage_next) {      // the raw values requested at the top have arrived: their conversion shares this half's matrix time
+            if (stage_next) {      // the raw values requested in the first half have arrived: their conversion shares this half's matrix time
                 convert_regs();
-                UC_HALF(xb, 1, 8)
+                UC_HALF(xb, 1, 8, UC_REQ_OLD)
             } else {
-                UC_HALF(xb, 1, 2)
+                UC_HALF(xb, 1, 2, UC_REQ_OLD)
             }
-        } else if (stage_next) convert_regs();
+        } else {
+            if (stage_next) convert_regs();
+            UC_REQ_OLD
+        }
+        // the sums, scaled back, wait for the next plane's first half
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int bi = (j >> 1) * 8 + (j & 1) * 4;
+            const f32x4 v0 = {acc[0][bi], acc[1][bi], acc[0][bi + 1], acc[1][bi + 1]};
+            const f32x4 v1 = {acc[0][bi + 2], acc[1][bi + 2], acc[0][bi + 3], acc[1][bi + 3]};
+            op_[2 * j] = v0 * inv_a * inv_b;
+            op_[2 * j + 1] = v1 * inv_a * inv_b;
+        }
+        pend = 1;
+        fzp = fz;
+        __syncthreads();                                      // every wave is done with plane za: its buffer takes the next plane
+        if (stage_next) write_regs(zn & 1);
+        __syncthreads();                                      // the next plane's staged input is complete
+    }
+    // the chunk's last plane
+    UC_EMIT_A(0) UC_EMIT_A(2) UC_EMIT_B1 UC_EMIT_B2 UC_EMIT_B3
+#undef UC_REQ_OLD
+#undef UC_HALF_EMIT
 #undef UC_HALF
 #undef UC_GROUP
 #undef UC_MM
 #undef UC_FETCH
-        __syncthreads();                                      // every wave is done with plane za: its buffer takes the next plane
-        if (stage_next) write_regs(zn & 1);
-
-        // 3. the sum: scale back, bias table, + old value; stores; statistics
-        const int clz = fz == 0 ? 0 : (fz == D - 1 ? 2 : 1);
-        float psum = 0.0f, pcnt = 0.0f;
-        f32x4 o_[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r_ = j >> 1, g_ = j & 1;
-            const float bmid = clz == 0 ? btr[0][r_][1] : (clz == 1 ? btr[1][r_][1] : btr[2][r_][1]);
-            const float bfst = clz == 0 ? btr[0][r_][0] : (clz == 1 ? btr[1][r_][0] : btr[2][r_][0]);
-            const float blst = clz == 0 ? btr[0][r_][2] : (clz == 1 ? btr[1][r_][2] : btr[2][r_][2]);
-            const int fx0 = 2 * (cx0 + g_ * 8 + kg * 4);      // first of this group's 8 fine columns
-            const float bfirst = fx0 == 0 ? bfst : bmid, blast = fx0 + 8 == W ? blst : bmid;
-            const int bi = r_ * 8 + g_ * 4;
-            f32x4 v0 = {acc[0][bi], acc[1][bi], acc[0][bi + 1], acc[1][bi + 1]};
-            f32x4 v1 = {acc[0][bi + 2], acc[1][bi + 2], acc[0][bi + 3], acc[1][bi + 3]};
-            const f32x4 b0 = {bfirst, bmid, bmid, bmid}, b1 = {bmid, bmid, bmid, blast};
-            v0 = v0 * inv_a * inv_b + b0;
-            v1 = v1 * inv_a * inv_b + b1;
-            if (RMW) { v0 = v0 + prev[2 * j]; v1 = v1 + prev[2 * j + 1]; }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v0), orsrc, ooff[j] + so_, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v1), orsrc, ooff[j] + so_ + 16u, 0, 0);
-            o_[2 * j] = v0; o_[2 * j + 1] = v1;
-            if (STATS) {
-                const float w_ = okg[j] ? 1.0f : 0.0f;
-                pcnt += 8.0f * w_;
-                psum += (((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]))) * w_;
-            }
-        }
-        if (STATS) {
-            const float pmean = pcnt > 0.0f ? psum / (pcnt > 0.0f ? pcnt : 1.0f) : 0.0f;
-            float pm2 = 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 d0 = o_[2 * j] - pmean, d1 = o_[2 * j + 1] - pmean;
-                const f32x4 q0 = d0 * d0, q1 = d1 * d1;
-                pm2 += (((q0[0] + q0[1]) + (q0[2] + q0[3])) + ((q1[0] + q1[1]) + (q1[2] + q1[3]))) * (okg[j] ? 1.0f : 0.0f);
-            }
-            Stat loc;
-            loc.n = pcnt; loc.mean = pmean; loc.m2 = pm2;
-            run = stat_merge_nb(run, loc);
-        }
-        __syncthreads();                                      // the next plane's staged input is complete
-    }
+#undef UC_NONE
+#undef UC_EMIT_B3
+#undef UC_EMIT_B2
+#undef UC_EMIT_B1
+#undef UC_EMIT_A
+#undef UC_EMIT_J
 
     if (STATS) {
         {

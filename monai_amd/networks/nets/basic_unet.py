@@ -31,7 +31,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-from ... import _lib, _prof, ops
+from ... import _lib, _prof, config, ops
 
 __all__ = ["BasicUNet", "BasicUnet", "Basicunet", "basicunet"]
 
@@ -443,7 +443,7 @@ class _Plan:
             net._packed[("upcat", name, cfg)] = hit
         _, packed_skip, packed_up, table = hit
         up_flops = 2.0 * 8 * int(src.shape[1]) * cout * d * h * w * n
-        if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2w_config()):      # (the other order -- convolution first, composite term accumulated -- measured equal: 655.2 / 655.7 ms, round 6)
+        if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2w_config()) and config.upcat_order() == "term_first":
             # the composite term is WRITTEN, the split-precision convolution of the skip channels adds itself to it and leaves the statistics of the sum
             with _prof.span("upconv_k4s2", up_flops):
                 ops.upconv_k4s2(src, src_nrm, packed_up, table, out, accumulate=False)
@@ -452,7 +452,7 @@ class _Plan:
             with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
                 ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, stats, accumulate=True)
         else:
-            # another kernel family for the skip half: it writes first, the composite term is added in place together with the statistics
+            # the convolution writes the skip half first (any kernel family), the composite term is added in place together with the statistics of the sum
             with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * f[l] * cout * d * h * w * n):
                 ops.conv3d_k3(cfg, skip, skip_nrm, packed_skip, conv.bias, out, None)
             tiles = ops.upconv_k4s2_stat_tiles(*self.sp[l + 1])
