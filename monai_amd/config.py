@@ -72,6 +72,18 @@ def upcat_order() -> str:
     return v
 
 
+# ---- UpCat's convolution over the concatenation as two 32-channel launches ----------------------------------------------------------
+# Decoder levels the composite kernel does not take (64 input channels at the 48^3 level): conv(cat([x_e, x_0])) = conv[:, :32](x_e) + conv[:, 32:](x_0) on the Winograd
+# split-precision kernel (plain form, then accumulating form with the statistics of the sum) where the 64-channel whole would run on the direct kernel.
+# False (or MONAI_AMD_CONV_HALVES=0 while None) keeps the one launch.
+CONV_HALVES = None
+
+
+def conv_halves() -> bool:
+    v = CONV_HALVES if CONV_HALVES is not None else os.environ.get("MONAI_AMD_CONV_HALVES", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")
+
+
 # ---- MaxPool3d(2) inside the producing convolution ------------------------------------------------------------------------------
 # BasicUNet's encoder: the split-precision convolution in front of a pooling leaves the pooled tensor itself (csrc/kernels/conv3d_h2.h, POOL) -- bit-identical logits.
 # False (or MONAI_AMD_POOL_FUSED=0 while None) keeps the pooling pass.

@@ -387,11 +387,47 @@ class _Plan:
             ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
         return False
 
+    def _halves_cfg(self, net, l: int, cout: int, bounded: bool) -> int:
+        """the configuration for `_conv_halves` at decoder level l, or -1: the concatenation's convolution is linear in its input channels, and where each 32-channel half
+        alone is a shape the Winograd split-precision kernel takes (csrc/kernels/conv3d_wino_h2.h: Cin == 32) while the 64-channel whole is not, two launches of it
+        (plain form + accumulating form) cost less than one of the direct kernel: 0.90 + 1.02 ms against 2.54 ms at 64 -> 32 @ 48^3 x 64 windows."""
+        f = net.features
+        if not config.conv_halves() or self.batchnorm or not net.fused_stats or not bounded or 2 * f[l] != int(self.cat[l].shape[1]):
+            return -1
+        _, _, d, h, w = self.cat[l].shape
+        cfg = ops.conv3d_k3_select(f[l], cout, d, h, w, bounded=True)
+        if cfg != ops.conv3d_k3_h2w_config() or ops.conv3d_k3_select(2 * f[l], cout, d, h, w, bounded=True) == cfg:
+            return -1
+        return cfg
+
+    def _conv_halves(self, net, name: str, block: _Convolution, l: int, cfg: int, out, out_nrm) -> None:
+        """conv(cat([x_e, x_0])) = conv[:, :f_l](x_e) + conv[:, f_l:](x_0) + b: the skip half written by the plain form, the up-sampled half added by the accumulating form together
+        with the bias and the statistics of the sum.  Reference: UpCat.forward, monai/networks/nets/basic_unet.py:160-178 (torch.cat + Convolution)."""
+        f = net.features
+        fl = f[l]
+        conv = block.conv
+        n, cout, d, h, w = out.shape
+        key = (conv.weight.data_ptr(), conv.weight._version, str(conv.weight.device))
+        hit = net._packed.get(("halves", name, cfg))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3_pack(cfg, conv.weight[:, :fl].contiguous()), ops.conv3d_k3_pack(cfg, conv.weight[:, fl:].contiguous()))
+            net._packed[("halves", name, cfg)] = hit
+        flops = 2.0 * 27 * fl * cout * d * h * w * n
+        with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+            ops.conv3d_k3(cfg, self.cat[l][:, :fl], self.cat_nrm[l][:, :fl], hit[1], None, out, None)
+        tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+        stats = self._stats_buf(n * cout * tiles * 3)
+        with _prof.span(f"conv3d_k3/cfg{cfg}", flops):
+            ops.conv3d_k3(cfg, self.cat[l][:, fl:], self.cat_nrm[l][:, fl:], hit[2], conv.bias, out, stats, accumulate=True)
+        norm = block.adn.N
+        if isinstance(norm, nn.GroupNorm):
+            ops.groupnorm_finalize(stats, tiles, n, cout, norm.num_groups, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+        else:
+            ops.instnorm_finalize(stats, tiles, n, cout, norm.weight, norm.bias, norm.eps, block.adn.negative_slope, out_nrm)
+
     def _poolable(self, net, cfg: int, cin: int, cout: int, d: int, h: int, w: int, level: int, x_nrm) -> bool:
         """the pooling epilogue (csrc/kernels/conv3d_h2.h, POOL): the split-precision kernel with 16 x 16 regions on even extents, a non-negative activation slope (the
         activation must be monotone in the raw value), statistics from the epilogue, a 3-D network"""
-        from ... import config
-
         if self.planar or self.batchnorm or not net.fused_stats or x_nrm is None or not config.pool_fused():
             return False
         if tuple(self.sp[level]) != (d // 2, h // 2, w // 2) or tuple(self.pool[level].shape[1:]) != (cout, d // 2, h // 2, w // 2):
@@ -416,8 +452,6 @@ class _Plan:
     def _fusable(self, net, l: int, src: torch.Tensor, cout: int) -> bool:
         """UpCat level l without its up-sampled intermediate (csrc/kernels/upconv_h2.h): a k2 s2 transposed convolution feeding an instance- / group-normalised
         convolution at exactly twice the extents, shapes the composite kernel takes, the split-precision family allowed"""
-        from ... import config
-
         if self.interp or self.planar or self.odd[l] or self.batchnorm or not net.fused_stats or not config.upcat_fused():
             return False
         if config.conv_algo() not in (config.CONV_ALGOS["auto"], config.CONV_ALGOS["h2"]):
@@ -508,7 +542,11 @@ class _Plan:
                     ops.deconv_k2s2(src, src_nrm, upc.upsample.deconv.weight, upc.upsample.deconv.bias, dst, dst_nrm, bounded=src_nrm is not None and not self.batchnorm)
                 if self.odd[l]:
                     ops.pad_replicate(self.up_scratch[l], self.cat[l][:, f[l]:], self.up_scratch_nrm[l], self.cat_nrm[l][:, f[l]:])
-                self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)
+                hcfg = self._halves_cfg(net, l, co, bounded=not self.interp)
+                if hcfg >= 0:
+                    self._conv_halves(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, l, hcfg, t, tn)
+                else:
+                    self._conv(net, f"upcat_{l + 1}.convs.conv_0", upc.convs.conv_0, self.cat[l], self.cat_nrm[l], t, tn, bounded=not self.interp)
             self._conv(net, f"upcat_{l + 1}.convs.conv_1", upc.convs.conv_1, t, tn, self.u[l], self.u_nrm[l])
             src, src_nrm = self.u[l], self.u_nrm[l]
 

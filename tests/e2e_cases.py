@@ -87,6 +87,41 @@ def case_net_upcat_fused_vs_two_layers(device):
     return r, d
 
 
+def case_net_conv_halves_vs_one_launch(device, window=(48, 32, 32)):
+    """BasicUNet's 48^3-type decoder level (64-channel concatenation feeding conv3; here a (24, 16, 16) level of a (48, 32, 32) window): the convolution as two 32-channel
+    launches of the Winograd split-precision kernel -- skip half written, up-sampled half accumulated with bias and statistics (config.CONV_HALVES,
+    BasicUNet._conv_halves) -- against the CPU oracle (bit-pinned to the real reference: tests/test_oracle_golden.py) at the 1e-4 bar and against the one-launch evaluation
+    on the direct kernel (a few 1e-6: another summation order)."""
+    from monai_amd import config
+
+    net, sd = make_net(1, 1, 5, device)
+    gen = torch.Generator().manual_seed(23)
+    x = torch.rand((2, 1) + tuple(window), generator=gen)
+    with torch.no_grad():
+        exp = oracle.basic_unet_forward(sd, x)
+    xd = x.to(device)
+    saved, saved_algo = config.CONV_HALVES, config.CONV_ALGO
+    try:
+        config.CONV_ALGO = "auto"
+        config.CONV_HALVES = False
+        one = net(xd).cpu()
+        plan = next(iter(net._plans.values()))
+        assert plan._halves_cfg(net, 1, 32, bounded=True) < 0
+        config.CONV_HALVES = True
+        assert plan._halves_cfg(net, 1, 32, bounded=True) >= 0, "the 64 -> 32 convolution at (24, 16, 16) must take the two-launch path"
+        assert plan._halves_cfg(net, 2, 64, bounded=True) < 0, "128-channel concatenations stay on one launch"
+        halves = net(xd).cpu()
+        config.CONV_ALGO = "fp32"
+        assert plan._halves_cfg(net, 1, 32, bounded=True) < 0
+    finally:
+        config.CONV_HALVES, config.CONV_ALGO = saved, saved_algo
+    r = report(halves, exp)
+    assert r["max_abs"] < LOGIT_TOL, r
+    d = (halves - one).abs().max().item()
+    assert 0.0 < d < 2e-5, d
+    return r, d
+
+
 def case_net_pool_fused_bitwise(device):
     """BasicUNet with MaxPool3d(2) leaving the producing convolution's epilogue (config.POOL_FUSED; csrc/kernels/conv3d_h2.h, POOL) against the pooling pass: the consumer reads
     raw maxima under the producer's records instead of pooled activated values -- act(max raw) == max(act(raw)) -- so the logits are BITWISE the same; with trained-like

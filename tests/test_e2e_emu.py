@@ -245,6 +245,12 @@ def test_upcat_fused_vs_two_layers_and_reference(emu):
     print(ec.case_net_upcat_fused_vs_two_layers("cpu"))
 
 
+@pytest.mark.heavy_emu          # minutes of emulated split-precision kernels; the -m gpu twin runs every round
+def test_conv_halves_vs_one_launch_and_reference(emu):
+    """UpCat's convolution over a 64-channel concatenation as two 32-channel launches of the Winograd split-precision kernel (BasicUNet._conv_halves)"""
+    print(ec.case_net_conv_halves_vs_one_launch("cpu"))
+
+
 def test_buffered_schedule_with_callbacks_bitwise_vs_reference(emu):
     """SURVEY 8a row a7 with the rest of its call surface: process_fn / with_coord / tuple and dict outputs under buffer_steps"""
     assert ec.case_buffered_calls_vs_golden("cpu") == 6

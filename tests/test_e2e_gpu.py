@@ -298,6 +298,12 @@ def test_upcat_fused_vs_two_layers_and_reference():
     print(ec.case_net_upcat_fused_vs_two_layers(DEV))
 
 
+def test_conv_halves_vs_one_launch_and_reference():
+    """UpCat's convolution over a 64-channel concatenation as two 32-channel launches of the Winograd split-precision kernel (BasicUNet._conv_halves): golden logits of the
+    real reference + the engine's one-launch path"""
+    print(ec.case_net_conv_halves_vs_one_launch(DEV))
+
+
 def test_buffered_schedule_with_callbacks_bitwise_vs_reference():
     """SURVEY 8a row a7 with the rest of its call surface: process_fn / with_coord / tuple and dict outputs under buffer_steps"""
     assert ec.case_buffered_calls_vs_golden(DEV) == 6
