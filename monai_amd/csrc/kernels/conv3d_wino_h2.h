@@ -339,13 +339,13 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
             s1 += dw_;                                                                                \
             s2 = __builtin_elementwise_fma(dw_, d_, s2);                                              \
         }                                                                                             \
-        if (POOL) {         /* the tile pair's x pairs in-lane; the other row sits in lane ^ 32: lanes 0-31 (maxima) receive the partner's maxima, lanes 32-63 (minima) its minima */ \
+        if (POOL && !(HWX_OFF & 32)) {         /* the tile pair's x pairs in-lane; the other row sits in lane ^ 32: lanes 0-31 (maxima) receive the partner's maxima, lanes 32-63 (minima) its minima */ \
             const f32x2 mx_ = {fmaxf(o_[0], o_[1]), fmaxf(o_[2], o_[3])}, mn_ = {fminf(o_[0], o_[1]), fminf(o_[2], o_[3])}; \
             const f32x2 own_ = fa ? mn_ : mx_, snd_ = fa ? mx_ : mn_;                                 \
             const f32x2 rcv_ = {hw_xchg32(snd_[0], fa), hw_xchg32(snd_[1], fa)};                      \
             const f32x2 y_ = {__builtin_amdgcn_fmed3f(own_[0], rcv_[0], pk_), __builtin_amdgcn_fmed3f(own_[1], rcv_[1], pk_)};      /* pk_ = +inf: max, -inf: min */ \
             const f32x2 f_ = {__builtin_amdgcn_fmed3f(y_[0], hm[0], pk_), __builtin_amdgcn_fmed3f(y_[1], hm[1], pk_)}; \
-            const unsigned po_ = (on_ && ((Q) & 1)) ? poff + (unsigned)((Q) >> 1) * (unsigned)(PHW * 4) : HWG_DROP; \
+            const unsigned po_ = (on_ && ((Q) & 1) && !(HWX_OFF & 64)) ? poff + (unsigned)((Q) >> 1) * (unsigned)(PHW * 4) : HWG_DROP; \
             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, f_), prs, po_, 0, 0);     \
             hm = on_ ? y_ : hm;                                                                       \
         }                                                                                             \
@@ -357,7 +357,7 @@ conv3d_k3_h2w_kernel(Tensor in, const uint4* __restrict__ wp, const float* __res
 #define MH_HW_T(K)
 #endif
 #ifndef HWX_OFF
-#define HWX_OFF 0      // ablation switches (bits): 1 no transform, 2 no staging, 4 no finishing, 8 no matrix instructions, 16 no Z exchange
+#define HWX_OFF 0      // ablation switches (bits): 1 no transform, 2 no staging, 4 no finishing, 8 no matrix instructions, 16 no Z exchange, 32 no pooling arithmetic, 64 pooled stores beyond the buffer
 #endif
     // what the scheduler may place per gap between two matrix instructions of the matrix phase.  Measured per form (profiles/r06_h2w_ab.txt): the plain form is best left to
     // the compiler's own order (7.07 against 7.22 ms), the accumulating form needs the dealing (8.5 against 11.2 ms: without it the old-value loads end up in front of the

@@ -95,6 +95,12 @@ if "upconv" in only:
     w4, table = ops.upconv_k4s2_weights(torch.randn(32, 32, 2, 2, 2, device=dev) * 0.2, torch.randn(32, device=dev) * 0.1, torch.randn(32, 32, 3, 3, 3, device=dev) * 0.05)
     packed = ops.upconv_k4s2_pack(w4)
     y = torch.empty(B, 32, 96, 96, 96, device=dev)
-    for _ in range(3):
-        ops.upconv_k4s2(low, ln, packed, table, y, accumulate=False)
+    if os.environ.get("PMC_UPCONV_FORM", "write") == "rmw":      # the form the headline runs since round 6: added in place, statistics of the sum
+        y.normal_()
+        ustats = torch.empty(B * 32 * ops.upconv_k4s2_stat_tiles(48, 48, 48) * 3, device=dev)
+        for _ in range(3):
+            ops.upconv_k4s2(low, ln, packed, table, y, accumulate=True, stats=ustats)
+    else:
+        for _ in range(3):
+            ops.upconv_k4s2(low, ln, packed, table, y, accumulate=False)
 torch.cuda.synchronize()
