@@ -28,7 +28,7 @@ from collections.abc import Sequence
 import torch
 import torch.nn as nn
 
-from ... import _lib, _prof, ops
+from ... import _lib, _prof, config, ops
 
 __all__ = ["DynUNet", "DynUnet", "Dynunet"]
 
@@ -343,6 +343,17 @@ class DynUNet(nn.Module):
                 with _prof.span(f"conv3d_k3/cfg{h2}", flops):
                     ops.conv3d_k3(h2, x[:, :half], x_nrm[:, :half], self._packed_slice(conv, h2, 0, half), conv.bias, out, None)
                     ops.conv3d_k3(h2, x[:, half:], x_nrm[:, half:], self._packed_slice(conv, h2, half, cin), None, out, stats, accumulate=True)
+                return out, self._finalize(norm, out, stats, tiles, slope)
+            hw = ops.conv3d_k3_h2w_config()
+            if (cfg == h2 and cin == 64 and x_nrm is not None and tuple(conv.weight.shape[2:]) == (3, 3, 3) and config.conv_halves()
+                    and ops.conv3d_k3_select(32, cout, d, h, w, bounded=True) == hw):
+                # a 64-channel concatenation at a level whose 32-channel halves the Winograd split-precision kernel takes (the top decoder level: 64 -> 32 @ 96^3): two launches of it
+                # (plain form, then accumulating form with the statistics of the sum) cost less than one of the direct kernel -- BasicUNet._conv_halves, config.CONV_HALVES
+                tiles = ops.conv3d_k3_stat_tiles(hw, d, h, w)
+                stats = self._stats_buf(n * cout * tiles * 3, x.device)
+                with _prof.span(f"conv3d_k3/cfg{hw}", flops):
+                    ops.conv3d_k3(hw, x[:, :32], x_nrm[:, :32], self._packed_slice(conv, hw, 0, 32), None, out, None)
+                    ops.conv3d_k3(hw, x[:, 32:], x_nrm[:, 32:], self._packed_slice(conv, hw, 32, 64), conv.bias, out, stats, accumulate=True)
                 return out, self._finalize(norm, out, stats, tiles, slope)
             tiles = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
             stats = self._stats_buf(n * cout * tiles * 3, x.device) if tiles else None
