@@ -197,7 +197,9 @@ int mh_conv3d_k3_pool_f32(int cfg, const mh_tensor5* in, const float* packed_w, 
                           int64_t pool_n_stride, void* stream);
 int mh_pool_select_f32(float* pool_max, const float* pool_min, const float* nrm, int64_t nrm_n_stride, int N, int C, int64_t n_stride, int64_t vol, void* stream);
 /* mh_conv3d_k3_f32 whose result is ADDED to what `out` holds (out += conv + bias; `stats` = the statistics of the sum): the split-precision configuration
- * (mh_conv3d_k3_h2_config) with input records and statistics only -- MH_ERR_UNSUPPORTED otherwise.  The second half of the UpCat path (mh_upconv_k4s2_f32 first). */
+ * (mh_conv3d_k3_h2_config, its 16-cout form mh_conv3d_k3_h2c_config, mh_conv3d_k3_h2w_config) with input records and statistics only -- MH_ERR_UNSUPPORTED otherwise.
+ * One half of the UpCat path (mh_upconv_k4s2_f32), a convolution evaluated in halves of its input channels, a residual join x += conv(...) (SegResNet's ResBlock,
+ * monai/networks/blocks/segresnet_block.py:62-97). */
 int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in, const float* packed_w, const float* bias, const mh_tensor5* out, float* stats, void* stream);
 
 /* InstanceNorm3d statistics (nn.InstanceNorm3d(affine=True, eps) via layers/factories.py:228-241):

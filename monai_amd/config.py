@@ -84,6 +84,17 @@ def conv_halves() -> bool:
     return str(v).lower() not in ("0", "false", "off", "no")
 
 
+# ---- residual joins inside the producing convolution ----------------------------------------------------------------------------------
+# SegResNet's ResBlock x + conv2(...): where conv2 runs on a split-precision configuration its accumulating form adds itself to x in place and leaves the statistics of the sum
+# (no pass for the addition, none for the next block's norm statistics).  False (or MONAI_AMD_RESIDUAL_ACC=0 while None) keeps the addition pass.
+RESIDUAL_ACC = None
+
+
+def residual_accumulate() -> bool:
+    v = RESIDUAL_ACC if RESIDUAL_ACC is not None else os.environ.get("MONAI_AMD_RESIDUAL_ACC", "1")
+    return str(v).lower() not in ("0", "false", "off", "no")
+
+
 # ---- MaxPool3d(2) inside the producing convolution ------------------------------------------------------------------------------
 # BasicUNet's encoder: the split-precision convolution in front of a pooling leaves the pooled tensor itself (csrc/kernels/conv3d_h2.h, POOL) -- bit-identical logits.
 # False (or MONAI_AMD_POOL_FUSED=0 while None) keeps the pooling pass.

@@ -691,7 +691,7 @@ int mh_conv3d_k3_f32(int cfg, const mh_tensor5* in_, const float* packed_w, cons
 }
 int mh_conv3d_k3_accumulate_f32(int cfg, const mh_tensor5* in_, const float* packed_w, const float* bias, const mh_tensor5* out_,
                                 float* stats, void* stream) {
-    if ((cfg != MH_CFG_H2 && cfg != MH_CFG_H2W) || !stats || !in_ || !in_->nrm)
+    if ((cfg != MH_CFG_H2 && cfg != MH_CFG_H2C && cfg != MH_CFG_H2W) || !stats || !in_ || !in_->nrm)
         return fail(MH_ERR_UNSUPPORTED, "conv3d_k3_accumulate: the accumulating form exists for the split-precision configuration with input records and statistics");
     return conv3d_k3_launch(cfg, in_, packed_w, bias, out_, stats, stream, true);
 }
@@ -793,9 +793,14 @@ static int conv3d_k3_launch(int cfg, const mh_tensor5* in_, const float* packed_
             return launched("conv3d_k3_h2_pool");
         }
         if (accumulate) {       // out += conv (kernels/conv3d_h2.h, ACC): statistics and input records present (checked by the entry point)
-#define MH_H2_ACC(RES_, WIDE_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, false, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL)
-            if (in.C <= 2 * H2_KC) { if (wide) MH_H2_ACC(true, true); else MH_H2_ACC(true, false); }
-            else { if (wide) MH_H2_ACC(false, true); else MH_H2_ACC(false, false); }
+#define MH_H2_ACC(RES_, WIDE_, C16_) hipLaunchKernelGGL((conv3d_k3_h2_kernel<true, true, RES_, WIDE_, C16_, true>), grid, dim3(512), 0, s, in, wq, tail, bias, out, stats, bxn, byn, zc, nblk, (float*)nullptr, (float*)nullptr, 0LL)
+            if (c16) {          // round 6: SegResNet's residual joins at its 16-channel level (x += conv2(...), statistics of the sum)
+                if (in.C <= 2 * H2_KC) { if (wide) MH_H2_ACC(true, true, true); else MH_H2_ACC(true, false, true); }
+                else { if (wide) MH_H2_ACC(false, true, true); else MH_H2_ACC(false, false, true); }
+            } else {
+                if (in.C <= 2 * H2_KC) { if (wide) MH_H2_ACC(true, true, false); else MH_H2_ACC(true, false, false); }
+                else { if (wide) MH_H2_ACC(false, true, false); else MH_H2_ACC(false, false, false); }
+            }
 #undef MH_H2_ACC
             return launched("conv3d_k3_h2_acc");
         }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void h2_split_pair(float v0, float v1, float m1, f16x
 // The columns carry two z-taps instead: B = [W(kz 0) | W(kz 1)] (accumulator X) and [W(kz 2) | 0] (accumulator Y) -- 6 instead of 9 matrix instructions per (ky, kx) tap
 // and 16 channels.  X of input plane p holds in its low 16 columns what output plane p + 1 gets from it and in its high 16 what plane p gets; Y's low 16 belong to plane
 // p - 1: a completed plane is  X(p - 2).low + X(p - 1).high + Y(p).low  -- two register-set additions and one 16-lane exchange per plane.  Packed by conv3d_k3_h2c_pack_kernel.
-// ACC (round 5, 32-cout form only): the result is ADDED to what `out` holds -- a completed plane starts from the old values instead of from zero.  They are requested a
+// ACC (round 5; the 16-cout form since round 6: its Y set starts from the old values): the result is ADDED to what `out` holds -- a completed plane starts from the old values instead of from zero.  They are requested a
 // whole plane ahead (four 16-byte buffer loads per lane right after the accumulator sets rotate) and enter the fresh set as old * 2^-(scale-back exponent), an exact
 // power-of-two product, so the epilogue, its stores and the statistics are untouched: they see the sum.  Used by the UpCat path (kernels/upconv_h2.h writes the
 // decoder's up half first, this kernel adds the skip half and leaves the InstanceNorm statistics of the sum).
@@ -316,7 +316,6 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
         const bool ok_ = cok && y0 + orow + yr_ < H && x0 + xg_ < W;
         ooff[j] = ok_ ? 4u * (unsigned)((long long)(C16 ? (r32 & 15) : r32) * DHW + (long long)(y0 + orow + yr_) * W + x0 + xg_) : H2_DROP;
     }
-    static_assert(!(ACC && C16), "the accumulating form exists for the 32-cout kernel");
     f32x4 pv[4];                                             // ACC: the old values of the plane whose accumulator set starts next
     float pinv_a = 1.0f, pinv_b = 1.0f;                      // ACC: 2^(scale-back exponent), as two factors like inv_a, inv_b
     if (ACC) {
@@ -515,9 +514,14 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
 #ifdef H2X_SETPRIO      // experiment (tools/ubench/h2_variants.hip): static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves per SIMD, item 4)
     if (wave >= 4) __builtin_amdgcn_s_setprio(H2X_SETPRIO);
 #endif
-    MH_H2_PV_LOAD(zs)                 // ACC: set 0 of the first iteration (input plane zs - 1) belongs to output plane zs
-    MH_H2_PV_INTO(0)
-    MH_H2_PV_LOAD(zs + 1)
+    if (C16) {
+        MH_H2_PV_LOAD(zs - 1)         // ACC, C16: the Y set of input plane p + 1 belongs to output plane p and starts from its old values (the X sets start from zero); the first
+                                      // one that counts is Y(zs + 1): the rotation after iteration p takes the values requested here / there a plane earlier
+    } else {
+        MH_H2_PV_LOAD(zs)             // ACC: set 0 of the first iteration (input plane zs - 1) belongs to output plane zs
+        MH_H2_PV_INTO(0)
+        MH_H2_PV_LOAD(zs + 1)
+    }
     for (int p = zs - 1; p <= ze; ++p) {
         if (p >= p_first && p <= p_last) {
             MH_H2_STEP(MH_H2_SCHEDULE_EMIT)
@@ -543,7 +547,14 @@ conv3d_k3_h2_kernel(Tensor in, const uint4* __restrict__ wp, const float* __rest
             accp = acc[2];
             acc[2] = acc[0];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+            for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+            if (ACC) {                  // the fresh Y set (input plane p + 1) belongs to output plane p: its old values (lanes of the low 16 columns; zeros elsewhere), then request plane p + 1's
+                MH_H2_PV_INTO(1)
+                MH_H2_PV_LOAD(p + 1)
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[1][i] = 0.0f;
+            }
         } else {
             acc[2] = acc[1];
             acc[1] = acc[0];

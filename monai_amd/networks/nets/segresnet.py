@@ -18,7 +18,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from ... import _lib, _prof, ops
+from ... import _lib, _prof, config, ops
 
 __all__ = ["SegResNet"]
 
@@ -206,13 +206,27 @@ class SegResNet(nn.Module):
         return ws
 
     def _res_block(self, blk: _ResBlock, x, stats=None, tiles=0, out_nrm=None):
-        """x + conv2(act(norm2(conv1(act(norm1 x))))) for a plain x (whose statistics records may come from its producer); out_nrm: `nrm_identity` records
-        the join leaves the result's magnitude bounds in (the split-precision down-sampling convolution that reads it scales its input by them)"""
+        """x + conv2(act(norm2(conv1(act(norm1 x))))) for a plain x (whose statistics records may come from its producer) -> (result, its statistics records or None, tiles).
+        Where the second convolution's configuration has an accumulating form (the split-precision kernels) the join is that form: conv2 ADDS itself to x in place and leaves
+        the statistics of the sum (what the next block's norm1 needs) -- no pass for the addition, none for the statistics; `x` is this engine's own tensor and has no
+        other reader.  out_nrm: `nrm_identity` records the join must leave the result's magnitude bounds in (the split-precision down-sampling convolution that reads it
+        scales its input by them): that join stays a pass of its own.  Reference: ResBlock.forward, monai/networks/blocks/segresnet_block.py:62-97."""
         n1 = self._record(blk.norm1, x, stats, tiles)
         c1, s1, t1 = self._conv3(blk.conv1.conv, x, n1)
         n2 = self._record(blk.norm2, c1, s1, t1)
-        c2, _, _ = self._conv3(blk.conv2.conv, c1, n2)
-        return ops.add_act(c2, None, x, None, 1.0, torch.empty_like(c2), out_nrm)
+        conv2 = blk.conv2.conv
+        n, cin, d, h, w = c1.shape
+        cout = conv2.weight.shape[0]
+        if out_nrm is None and config.residual_accumulate() and not (cin <= 8 and cout <= 8):
+            cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=True)
+            if cfg in (ops.conv3d_k3_h2_config(), ops.conv3d_k3_h2c_config(), ops.conv3d_k3_h2w_config()):
+                tiles2 = ops.conv3d_k3_stat_tiles(cfg, d, h, w)
+                stats2 = self._stats_buf(n * cout * tiles2 * 3, x.device)
+                with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
+                    ops.conv3d_k3(cfg, c1, n2, self._packed_weight(conv2, cfg), conv2.bias, x, stats2, accumulate=True)
+                return x, stats2, tiles2
+        c2, _, _ = self._conv3(conv2, c1, n2)
+        return ops.add_act(c2, None, x, None, 1.0, torch.empty_like(c2), out_nrm), None, 0
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -243,7 +257,7 @@ class SegResNet(nn.Module):
                 feeds_down = bi == len(blks) - 1 and li + 1 < len(self.down_layers) and not isinstance(self.down_layers[li + 1][0], nn.Identity)
                 if feeds_down:
                     t_nrm = ops.nrm_identity(torch.empty((t.shape[0], t.shape[1], 4), dtype=torch.float32, device=t.device))
-                t, stats, tiles = self._res_block(blk, t, stats, tiles, t_nrm if feeds_down else None), None, 0
+                t, stats, tiles = self._res_block(blk, t, stats, tiles, t_nrm if feeds_down else None)
             down_x.append(t)
         down_x.reverse()
         # decode (segresnet.py:184-192): x = up(x) + skip; x = up_layer(x)
@@ -261,11 +275,12 @@ class SegResNet(nn.Module):
                 hi = ops.affine_resample(low.reshape(n * cout, d, h, w), m, (2 * d, 2 * h, 2 * w), "bilinear", "border", False, False)
                 hi = hi.reshape(n, cout, 2 * d, 2 * h, 2 * w)
             t = ops.add_act(hi, None, down_x[i + 1], None, 1.0, torch.empty_like(hi))
+            stats, tiles = None, 0
             for blk in upl:
-                t = self._res_block(blk, t)
+                t, stats, tiles = self._res_block(blk, t, stats, tiles)
         if not self.use_conv_final:
             out.copy_(t)
             return out
         oc = self.conv_final[2].conv
-        ops.conv1x1(t, self._record(self.conv_final[0], t, None, 0), oc.weight.view(oc.weight.shape[0], -1), oc.bias, out)
+        ops.conv1x1(t, self._record(self.conv_final[0], t, stats, tiles), oc.weight.view(oc.weight.shape[0], -1), oc.bias, out)
         return out

@@ -155,6 +155,7 @@ def test_conv3d_split_precision_16_couts(cin, cout, dims, n):
     assert cfg > ops.conv3d_k3_num_configs() and ops.conv3d_k3_accepts(cfg, cin, cout) and not ops.conv3d_k3_accepts(cfg, 16, 24)
     kc.case_conv3d(DEV, cfg, n, cin, cout, dims, fused_stats=True)
     kc.case_conv3d(DEV, cfg, 1, cin, cout, dims, with_nrm=False, fused_stats=False)
+    kc.case_conv3d_accumulate(DEV, n, cin, cout, dims, cfg=cfg)      # out += conv + bias, statistics of the sum (round 6: the Y set starts from the old values)
     if cout == 16 and dims[1] >= 8 and dims[2] >= 8:
         assert ops.conv3d_k3_select(cin, cout, *dims, bounded=True, algo=0) == cfg and ops.conv3d_k3_select(cin, cout, *dims, bounded=False, algo=0) != cfg and ops.conv3d_k3_select(cin, cout, *dims, bounded=True, algo=4) != cfg      # auto: yes; unbounded input or the exact-fp32 family: no
 
