@@ -275,6 +275,13 @@ class UNet(nn.Module):
             if s == 1 and not tiny:
                 stats = self._stats_buf(n * cout * stats_tiles * 3, x.device) if stats_tiles else None
                 ops.conv3d_k3(cfg, x, x_nrm, self._packed_weight(conv, cfg), conv.bias, out, stats)
+            elif s == 2 and bounded and ops.conv3d_k3s2_selected(cin, cout, d, h, w, s, bounded=True):
+                # the down-sampling convolution on the fp16 matrix cores (csrc/kernels/conv3d_s2_h2.h), the statistics of its output included (round 6: plain tensors of this
+                # engine carry identity records with magnitude bounds, left by the residual joins that write them)
+                tiles_ = ops.conv3d_k3s2_stat_tiles(d, h, w)
+                stats = self._stats_buf(n * cout * tiles_ * 3, x.device)
+                self._conv_s2(conv, x, x_nrm, out, stats)
+                stats_tiles = tiles_ if wants_stats else 0
             else:
                 ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(conv, 0), conv.bias, out, s)
         if not hasattr(unit, "adn"):
@@ -298,8 +305,28 @@ class UNet(nn.Module):
         ops.instnorm_finalize(stats, stats_tiles, n, cout, inorm.weight, inorm.bias, inorm.eps, slope, nrm)
         return out, nrm
 
-    def _residual_unit(self, ru: _ResidualUnit, x, x_nrm, dst):
-        """cx + res into `dst` (plain).  `x` may be deferred (raw + record): both the sub-units and the shortcut consume it."""
+    def _conv_s2(self, conv: nn.Conv3d, x, x_nrm, out, stats) -> None:
+        """3x3x3 stride-2 convolution of a bounded input on the split-precision stride-2 kernel; `stats`: the InstanceNorm statistics of `out`"""
+        n, cin, d, h, w = x.shape
+        cout = conv.weight.shape[0]
+        wt = conv.weight
+        key = (wt.data_ptr(), wt._version, str(wt.device))
+        hit = self._packed.get((id(conv), "s2"))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.conv3d_k3s2_pack(wt))
+            self._packed[(id(conv), "s2")] = hit
+        fused = ops.conv3d_k3s2_fused(cin, cout, d * h * w)          # conversion inside the GEMM's staging, or a phase-split pass into the workspace first
+        ws = None
+        if not fused:
+            need = ops.conv3d_k3s2_workspace_floats(n, cin, d, h, w)
+            ws = self.__dict__.get("_ws")
+            if ws is None or ws.numel() < need or ws.device != x.device:
+                ws = self.__dict__["_ws"] = torch.empty(need, dtype=torch.float32, device=x.device)
+        ops.conv3d_k3s2(x, x_nrm, hit[1], conv.bias, out, stats, ws, fused)
+
+    def _residual_unit(self, ru: _ResidualUnit, x, x_nrm, dst, dst_nrm=None):
+        """cx + res into `dst` (plain; dst_nrm: its `nrm_identity` records, the join leaves the magnitude bounds in them).  `x` may be deferred (raw + record): both the
+        sub-units and the shortcut consume it."""
         n = x.shape[0]
         if isinstance(ru.residual, nn.Identity):
             res, res_nrm = x, x_nrm
@@ -308,8 +335,12 @@ class UNet(nn.Module):
             cout = rc.weight.shape[0]
             s = ru.strides
             if rc.kernel_size[0] == 3:
+                cin, d, h, w = x.shape[1:]
                 res = torch.empty((n, cout) + tuple((v - 1) // s + 1 for v in x.shape[2:]), dtype=torch.float32, device=x.device)
-                ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(rc, 0), rc.bias, res, s)
+                if s == 2 and x_nrm is not None and not self._has_batchnorm() and ops.conv3d_k3s2_selected(cin, cout, d, h, w, s, bounded=True):
+                    self._conv_s2(rc, x, x_nrm, res, self._stats_buf(n * cout * ops.conv3d_k3s2_stat_tiles(d, h, w) * 3, x.device))
+                else:
+                    ops.conv3d_k3_strided(x, x_nrm, self._packed_weight(rc, 0), rc.bias, res, s)
             else:
                 res = torch.empty((n, cout) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device)
                 ops.conv1x1(x, x_nrm, rc.weight.view(cout, -1), rc.bias, res)
@@ -317,13 +348,13 @@ class UNet(nn.Module):
         cx, cn = x, x_nrm
         for unit in ru.conv:
             cx, cn = self._conv_unit(unit, cx, cn)
-        return ops.add_act(cx, cn, res, res_nrm, 1.0, dst)
+        return ops.add_act(cx, cn, res, res_nrm, 1.0, dst, dst_nrm)
 
-    def _down(self, mod, x, dst):
+    def _down(self, mod, x, dst, x_nrm=None, dst_nrm=None):
         if isinstance(mod, _ResidualUnit):
-            return self._residual_unit(mod, x, None, dst)
-        c, cn = self._conv_unit(mod, x, None)
-        return ops.add_act(c, cn, None, None, 1.0, dst)          # materialise norm + PReLU
+            return self._residual_unit(mod, x, x_nrm, dst, dst_nrm)
+        c, cn = self._conv_unit(mod, x, x_nrm)
+        return ops.add_act(c, cn, None, None, 1.0, dst, dst_nrm)          # materialise norm + PReLU
 
     def _up(self, mod, x, dst):
         if isinstance(mod, nn.Sequential):
@@ -343,7 +374,8 @@ class UNet(nn.Module):
             return mod[0].conv.weight.shape[1]
         return mod.conv.weight.shape[1] if mod.is_transposed else mod.conv.weight.shape[0]
 
-    def _block(self, seq: nn.Sequential, x, dst):
+    def _block(self, seq: nn.Sequential, x, dst, x_nrm=None):
+        """x_nrm: identity records of the plain tensor x with its magnitude bounds (None: unknown -- the network's input), what the split-precision kernels scale by"""
         down, skip, up = seq[0], seq[1], seq[2]
         s = down.strides
         n = x.shape[0]
@@ -352,11 +384,13 @@ class UNet(nn.Module):
         sub = skip.submodule
         cs = self._out_channels(sub[2]) if isinstance(sub, nn.Sequential) and isinstance(sub[1], _SkipConnection) else self._out_channels(sub)
         cat = torch.empty((n, cd + cs) + sp, dtype=torch.float32, device=x.device)      # SkipConnection: cat([x, sub(x)], 1)
-        d = self._down(down, x, cat[:, :cd])
+        # the down path's joins leave max |value| in identity records of their results: the next level's strided convolutions run on the matrix cores with them
+        d_nrm = None if self._has_batchnorm() else ops.nrm_identity(torch.empty((n, cd, 4), dtype=torch.float32, device=x.device))
+        d = self._down(down, x, cat[:, :cd], x_nrm, d_nrm)
         if isinstance(sub, nn.Sequential) and isinstance(sub[1], _SkipConnection):
-            self._block(sub, d, cat[:, cd:])
+            self._block(sub, d, cat[:, cd:], d_nrm)
         else:
-            self._down(sub, d, cat[:, cd:])
+            self._down(sub, d, cat[:, cd:], d_nrm)
         return self._up(up, cat, dst)
 
     # ---- forward -----------------------------------------------------------------------------------
