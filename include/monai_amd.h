@@ -33,7 +33,7 @@ extern "C" {
  * instead of in a pass of its own).  `bound` >= max |y| over the (n, c) plane when the producer of the tensor knows
  * one, 0 when none is given, inf / NaN when the plane (or its statistics) holds a non-finite value:
  *   - mh_instnorm_finalize_f32 / mh_groupnorm_finalize_f32 write (|gamma| sqrt(count) + |beta|) max(1, |slope|);
- *   - on an OUTPUT view of mh_deconv_k2s2_f32 / mh_deconv_ks_f32 / mh_add_act_f32, `nrm` (if not NULL) names identity
+ *   - on an OUTPUT view of mh_deconv_k2s2_f32 / mh_deconv_ks_f32 / mh_add_act_f32 / mh_pixelshuffle_f32, `nrm` (if not NULL) names identity
  *     records prepared by mh_nrm_identity_f32; the kernel folds max |value written| into their `bound`;
  *     mh_maxpool2_f32 / mh_pad_replicate_f32 write {1, 0, 1, bound of their input} into it.
  * The split-precision convolution (mh_conv3d_k3_h2_config) needs the bounds of its input; nothing else reads them.
@@ -305,6 +305,12 @@ int mh_conv1x1_sum2_f32(const mh_tensor5* a, const mh_tensor5* b, float slope, c
 /* Replicate padding at the far end of each axis (out extents = in extents + 0 or 1): `UpCat`'s
  * F.pad(x_0, sp, "replicate") for odd encoder extents -- monai/networks/nets/basic_unet.py:163-170.  Raw copy. */
 int mh_pad_replicate_f32(const mh_tensor5* in, const mh_tensor5* out, void* stream);
+
+/* SubpixelUpsample behind its convolution, scale factor 2 -- monai/networks/blocks/upsample.py:186-288 (`pixelshuffle`: monai/networks/utils.py:370-412, `pad_pool`:
+ * upsample.py:262-272): in [N][C * fz * 4][D][H][W] (the convolution's raw output) -> out [N][C][fz D][2 H][2 W], sub-voxel (i, j, k) of channel c from input channel
+ * c * fz * 4 + i * 4 + j * 2 + k; pad_pool != 0: followed by ConstantPad(1 in front of every spatial axis) + AvgPool(2, stride 1).  fz = 2: three spatial dimensions,
+ * fz = 1: two (one plane).  `out->nrm` (if not NULL): identity records, max |value written| goes into their bound. */
+int mh_pixelshuffle_f32(const mh_tensor5* in, const mh_tensor5* out, int fz, int pad_pool, void* stream);
 
 /* Self-attention core of SABlock.forward (selfattention.py:156-218): qkv [B][S][3*heads*HD] (the qkv Linear's output, feature index =
  * which*heads*HD + head*HD + d) -> out [B][S][heads*HD] = softmax(Q K^T * scale) V per head, on the fp16 matrix cores in two-piece split precision

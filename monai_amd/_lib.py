@@ -124,6 +124,7 @@ SIGNATURES = {
     "mh_deconv_k3_f32": (_I, [_T, _P, _P, _T, _I, _P]),
     "mh_add_act_f32": (_I, [_T, _T, _F, _T, _P]),
     "mh_pad_replicate_f32": (_I, [_T, _T, _P]),
+    "mh_pixelshuffle_f32": (_I, [_T, _T, _I, _I, _P]),
     "mh_attention_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _P]),
     "mh_window_attention_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mh_window_attention_rel_accepts": (_I, [_I, _I, _I]),

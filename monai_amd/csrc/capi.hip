@@ -1826,6 +1826,27 @@ int mh_pad_replicate_f32(const mh_tensor5* in_, const mh_tensor5* out_, void* st
     return launched("pad_replicate");
 }
 
+int mh_pixelshuffle_f32(const mh_tensor5* in_, const mh_tensor5* out_, int fz, int pad_pool, void* stream) {
+    if (!dense_ok(in_) || !dense_ok(out_)) return fail(MH_ERR_ARG, "pixelshuffle: bad tensor");
+    if (!out_records_ok(out_)) return fail(MH_ERR_ARG, "pixelshuffle: the output view's records must be 16-byte aligned [N][>= C][4] floats");
+    if (fz != 1 && fz != 2) return fail(MH_ERR_ARG, "pixelshuffle: fz must be 1 (two spatial dimensions on one plane) or 2");
+    const Tensor in = from_c(*in_), out = from_c(*out_);
+    if (in.N != out.N || in.C != out.C * fz * 4 || out.D != fz * in.D || out.H != 2 * in.H || out.W != 2 * in.W)
+        return fail(MH_ERR_ARG, "pixelshuffle: [N][C * %d][D][H][W] -> [N][C][%d D][2 H][2 W] expected (got %d ch %dx%dx%d -> %d ch %dx%dx%d)", fz * 4, fz, in.C, in.D, in.H, in.W,
+                    out.C, out.D, out.H, out.W);
+    if (out.C > 65535 || out.N > 65535) return fail(MH_ERR_UNSUPPORTED, "pixelshuffle: more than 65535 channels / samples in one launch");
+    const dim3 grid(blocks_for((long long)out.D * out.H * out.W), (unsigned)out.C, (unsigned)out.N);
+    hipStream_t s = (hipStream_t)stream;
+    if (fz == 2) {
+        if (pad_pool) hipLaunchKernelGGL((pixelshuffle_kernel<2, true>), grid, dim3(256), 0, s, in, out);
+        else hipLaunchKernelGGL((pixelshuffle_kernel<2, false>), grid, dim3(256), 0, s, in, out);
+    } else {
+        if (pad_pool) hipLaunchKernelGGL((pixelshuffle_kernel<1, true>), grid, dim3(256), 0, s, in, out);
+        else hipLaunchKernelGGL((pixelshuffle_kernel<1, false>), grid, dim3(256), 0, s, in, out);
+    }
+    return launched("pixelshuffle");
+}
+
 int mh_attention_f32(const float* qkv, float* out, int B, int S, int heads, int head_dim, float scale, void* stream) {
     if (!qkv || !out || B < 1 || S < 1 || heads < 1) return fail(MH_ERR_ARG, "attention: bad argument");
     if (!aligned(qkv, 16) || !aligned(out, 16)) return fail(MH_ERR_ARG, "attention: 16-byte aligned tensors required");

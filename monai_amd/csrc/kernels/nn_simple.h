@@ -749,6 +749,46 @@ __global__ void __launch_bounds__(256) pad_replicate_kernel(Tensor in, Tensor ou
 }
 
 // ---------------------------------------------------------------------------------------------------
+// SubpixelUpsample behind its convolution (monai/networks/blocks/upsample.py:186-288; pixelshuffle: monai/networks/utils.py:370-412), scale factor 2: the convolution's
+// raw output `in` [N][C * FZ * 4][Dl][Hl][Wl] -> `out` [N][C][FZ * Dl][2 Hl][2 Wl] with  sh[c][FZ z + i][2 y + j][2 x + k] = in[c * FZ * 4 + i * 4 + j * 2 + k][z][y][x]
+// (FZ = 2: three spatial dimensions; FZ = 1: the one-plane form of two) and, PADPOOL, the "pad then average" of Aitken et al. that follows it: ConstantPad(1 at the START of
+// every spatial axis, 0) + AvgPool(kernel 2, stride 1), i.e. out[Z][Y][X] = mean over the 2^dims voxels sh[Z - dz][Y - dy][X - dx], dz, dy, dx in {0, 1}, zeros in front of
+// the volume counted (the pool's count_include_pad default).  One thread per output voxel; the sum runs over (dz, dy, dx) in the pool's order.  The output is a raw tensor:
+// max |value written| goes into its identity records (common.h).
+template <int FZ, bool PADPOOL>
+__global__ void __launch_bounds__(256) pixelshuffle_kernel(Tensor in, Tensor out) {
+    const long long ovol = (long long)out.D * out.H * out.W, ivol = (long long)in.D * in.H * in.W;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.y, n = blockIdx.z;
+    unsigned mb = 0u;
+    if (idx < ovol) {
+        const int X = (int)(idx % out.W);
+        const long long t = idx / out.W;
+        const int Y = (int)(t % out.H), Z = (int)(t / out.H);
+        const float* src = in.data + (long long)n * in.n_stride + (long long)c * (FZ * 4) * ivol;
+        float acc = 0.0f;
+#pragma unroll
+        for (int dz = (PADPOOL && FZ == 2) ? 1 : 0; dz >= 0; --dz)
+#pragma unroll
+            for (int dy = PADPOOL ? 1 : 0; dy >= 0; --dy)
+#pragma unroll
+                for (int dx = PADPOOL ? 1 : 0; dx >= 0; --dx) {      // the pool visits its window from the lowest index up: (Z - 1, Y - 1, X - 1) first
+                    const int z = Z - dz, y = Y - dy, x = X - dx;
+                    float v = 0.0f;
+                    if (z >= 0 && y >= 0 && x >= 0) {
+                        const int sub = (FZ == 2 ? (z & 1) * 4 : 0) + (y & 1) * 2 + (x & 1);
+                        v = src[(long long)sub * ivol + ((long long)(FZ == 2 ? z >> 1 : z) * in.H + (y >> 1)) * in.W + (x >> 1)];
+                    }
+                    acc += v;
+                }
+        const float r = PADPOOL ? acc / (FZ == 2 ? 8.0f : 4.0f) : acc;
+        out.data[(long long)n * out.n_stride + (long long)c * ovol + idx] = r;
+        mb = abs_bits(r);
+    }
+    if (out.nrm) bound_commit(mb, bound_slot(out, n, c));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Identity records {1, 0, 1, FLT_MIN} for the channels a raw producer is about to write (common.h: magnitude bounds).
 __global__ void __launch_bounds__(256) nrm_identity_kernel(float* __restrict__ nrm, int N, int C, long long nrm_n_stride) {
     const int i = blockIdx.x * 256 + threadIdx.x;

@@ -109,14 +109,33 @@ class _Down(nn.Module):
         self.convs = _TwoConv(cin, cout, **kw)
 
 
+class _Subpixel(nn.Module):
+    """SubpixelUpsample's parameters (blocks/upsample.py:186-288, conv_block="default"): one k3 convolution to cout * 2^dims channels; pixel shuffle and pad + average
+    pooling hold none"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv_block = nn.Conv3d(cin, cout * 8, kernel_size=3, stride=1, padding=1, bias=True)
+        # the reference's ICNR initialisation (monai/networks/utils.py:350-367, Aitken et al. 2017): every group of 8 sub-voxel kernels starts as copies of ONE
+        # Kaiming-normal kernel, arranged through its transpose / reshape / repeat sequence -- the same draws from the generator, so the same seed gives the same parameters
+        oc2, dims = cout, [3, 3, 3]
+        k = nn.init.kaiming_normal_(torch.zeros([oc2, cin] + dims))
+        k = k.transpose(0, 1).reshape(oc2, cin, -1).repeat(1, 1, 8).reshape([cin, cout * 8] + dims).transpose(0, 1)
+        with torch.no_grad():
+            self.conv_block.weight.copy_(k)
+
+
 class _UpSample(nn.Module):
-    """UpSample (blocks/upsample.py:43-184) in the two parameter layouts BasicUNet uses: "deconv" = ConvTranspose(k2, s2); "nontrainable" = an optional
-    1x1 ``preconv`` (present when the channel count changes, pre_conv="default") + parameter-free linear interpolation x2 with align_corners=True"""
+    """UpSample (blocks/upsample.py:43-184) in the parameter layouts BasicUNet uses: "deconv" = ConvTranspose(k2, s2); "nontrainable" = an optional
+    1x1 ``preconv`` (present when the channel count changes, pre_conv="default") + parameter-free linear interpolation x2 with align_corners=True;
+    "pixelshuffle" = SubpixelUpsample (three spatial dimensions on the HIP path)"""
 
     def __init__(self, cin, cout, mode="deconv", bias=True):
         super().__init__()
         if mode == "deconv":
             self.deconv = _nd(nn.ConvTranspose3d, nn.ConvTranspose2d)(cin, cout, kernel_size=2, stride=2, bias=bias)
+        elif mode == "pixelshuffle":
+            self.pixelshuffle = _Subpixel(cin, cout)
         elif cin != cout:
             self.preconv = _nd(nn.Conv3d, nn.Conv2d)(cin, cout, kernel_size=1, bias=bias)
 
@@ -174,8 +193,8 @@ class BasicUNet(nn.Module):
         super().__init__()
         if spatial_dims not in (2, 3):
             raise NotImplementedError("monai_amd.BasicUNet: spatial_dims 2 and 3 are on the HIP path")
-        if upsample not in ("deconv", "nontrainable"):
-            raise NotImplementedError("monai_amd.BasicUNet: upsample='deconv' and 'nontrainable' are on the HIP path ('pixelshuffle' is not yet)")
+        if upsample not in ("deconv", "nontrainable", "pixelshuffle") or (upsample == "pixelshuffle" and spatial_dims != 3):
+            raise NotImplementedError("monai_amd.BasicUNet: upsample='deconv', 'nontrainable' and (three spatial dimensions) 'pixelshuffle' are on the HIP path")
         # dropout: accepted and inert -- this is an inference engine (forward refuses training mode) and Dropout holds no parameters, so
         # checkpoints of nets trained with dropout load unchanged
         fea = tuple(features)
@@ -315,6 +334,9 @@ class _Plan:
         self.up, self.dec_out = up, dec_out
         self.batchnorm = isinstance(net.conv_0.conv_0.adn.N, (nn.BatchNorm3d, nn.BatchNorm2d))
         self.interp = net.upsample == "nontrainable"
+        self.shuffle = net.upsample == "pixelshuffle"
+        # "pixelshuffle" up-sampling: the sub-pixel convolution's raw result (8 x the up channels) at the lower resolution
+        self.sub = [e(8 * up[l], l + 1) if self.shuffle else None for l in range(4)]
         # "nontrainable" up-sampling: the (optional) 1x1 pre-convolution's result at the lower resolution
         self.low = [e(up[l], l + 1) if self.interp else None for l in range(4)]
         self.stats: Optional[torch.Tensor] = None
@@ -449,10 +471,20 @@ class _Plan:
         hi = ops.affine_resample(low.reshape(n * c, d, h, w), m, osz, "bilinear", "border", False, False)
         dst.copy_(hi.reshape((n, c) + osz))
 
+    def _subpixel(self, net, name: str, conv: nn.Conv3d, src, src_nrm, sub, dst, dst_nrm) -> None:
+        """SubpixelUpsample (blocks/upsample.py:274-288): the k3 convolution of the (deferred) input to 8 x the up channels -- raw, no normalisation follows it -- then one pass
+        that shuffles the sub-voxels into place and applies the pad + average pooling; max |value| goes into the identity records of the result"""
+        n, cin, d, h, w = src.shape
+        cout = sub.shape[1]
+        cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=src_nrm is not None and not self.batchnorm)
+        with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
+            ops.conv3d_k3(cfg, src, src_nrm, net._packed_weight(name, conv, cfg), conv.bias, sub, None)
+        ops.pixelshuffle(sub, dst, 2, True, dst_nrm)
+
     def _fusable(self, net, l: int, src: torch.Tensor, cout: int) -> bool:
         """UpCat level l without its up-sampled intermediate (csrc/kernels/upconv_h2.h): a k2 s2 transposed convolution feeding an instance- / group-normalised
         convolution at exactly twice the extents, shapes the composite kernel takes, the split-precision family allowed"""
-        if self.interp or self.planar or self.odd[l] or self.batchnorm or not net.fused_stats or not config.upcat_fused():
+        if self.interp or self.shuffle or self.planar or self.odd[l] or self.batchnorm or not net.fused_stats or not config.upcat_fused():
             return False
         if config.conv_algo() not in (config.CONV_ALGOS["auto"], config.CONV_ALGOS["h2"]):
             return False
@@ -536,6 +568,8 @@ class _Plan:
                 dst_nrm = ops.nrm_identity(self.up_scratch_nrm[l] if self.odd[l] else self.cat_nrm[l][:, f[l]:])
                 if self.interp:
                     self._interpolate(upc.upsample, src, src_nrm, self.low[l], dst)
+                elif self.shuffle:
+                    self._subpixel(net, f"upcat_{l + 1}.upsample.pixelshuffle.conv_block", upc.upsample.pixelshuffle.conv_block, src, src_nrm, self.sub[l], dst, dst_nrm)
                 elif self.planar:     # ConvTranspose2d k2 s2 = the (1, 2, 2) kernel == stride transposed conv of the anisotropic path
                     ops.deconv_ks(src, src_nrm, _w5(upc.upsample.deconv.weight).contiguous(), upc.upsample.deconv.bias, dst, (1, 2, 2), dst_nrm)
                 else:

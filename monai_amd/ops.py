@@ -665,6 +665,15 @@ def pad_replicate(x, out, x_nrm=None, out_nrm=None):
     return out
 
 
+def pixelshuffle(x, out, fz: int = 2, pad_pool: bool = True, out_nrm=None):
+    """SubpixelUpsample behind its convolution (scale factor 2): x [N, C * fz * 4, D, H, W] raw -> out [N, C, fz * D, 2 H, 2 W], then (pad_pool) zero padding in front of every
+    spatial axis + average pooling 2, stride 1.  out_nrm: `nrm_identity` records of `out`; the kernel folds max |value written| into their bound."""
+    _lib.require_device(x, out, out_nrm)
+    xi, xo = _lib.tensor5(x), _lib.tensor5(out, out_nrm)
+    _lib.lib().call("mh_pixelshuffle_f32", C.byref(xi), C.byref(xo), int(fz), int(bool(pad_pool)), _s(x))
+    return out
+
+
 def attention(qkv: torch.Tensor, heads: int, scale: float, head_dim: int = 64) -> torch.Tensor:
     """qkv [B, S, 3*heads*head_dim] -> [B, S, heads*head_dim] = softmax(Q K^T * scale) V per head (fp16 matrix cores, split precision: fp32-equivalent;
     any sequence length; head_dim 32 / 64 / 96 / 128)."""

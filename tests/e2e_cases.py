@@ -76,6 +76,13 @@ def case_net_upcat_fused_vs_two_layers(device):
         config.UPCAT_FUSED = True
         assert net._plans and next(iter(net._plans.values()))._fusable(net, 0, torch.empty(1, 32, 1, 1, 1), 32)
         fused = net(x).cpu()
+        saved_order = config.UPCAT_ORDER
+        try:      # the other order of the two halves (composite term written, accumulating convolution after it): the same two addends, statistics from the other kernel's tiles
+            config.UPCAT_ORDER = "term_first" if config.upcat_order() == "conv_first" else "conv_first"
+            other = net(x).cpu()
+        finally:
+            config.UPCAT_ORDER = saved_order
+        assert (other - fused).abs().max().item() < 2e-5
         config.CONV_ALGO = "fp32"
         assert not next(iter(net._plans.values()))._fusable(net, 0, torch.empty(1, 32, 1, 1, 1), 32)
     finally:
@@ -120,6 +127,27 @@ def case_net_conv_halves_vs_one_launch(device, window=(48, 32, 32)):
     d = (halves - one).abs().max().item()
     assert 0.0 < d < 2e-5, d
     return r, d
+
+
+def case_basic_unet_pixelshuffle_vs_golden(device, which=("even", "odd")):
+    """BasicUNet(upsample="pixelshuffle"): UpSample -> SubpixelUpsample (k3 convolution to 8 x the channels, pixel shuffle, zero pad in front + average pooling;
+    csrc/kernels/nn_simple.h: pixelshuffle_kernel) with the REAL reference's parameters and logits (tests/golden/make_golden_pixelshuffle.py): strict state_dict load,
+    even extents and odd ones (UpCat's replicate padding behind the shuffle)."""
+    from monai_amd.networks.nets import BasicUNet
+
+    g = np.load(os.path.join(GOLDEN, "basic_unet_pixelshuffle.npz"))
+    net = BasicUNet(3, 1, 3, features=tuple(int(v) for v in g["features"]), upsample="pixelshuffle").eval()
+    assert list(net.state_dict().keys()) == [str(k) for k in g["keys"]]
+    missing, unexpected = net.load_state_dict({str(k): torch.from_numpy(g["p:" + str(k)]) for k in g["keys"]}, strict=True)
+    assert not missing and not unexpected
+    net = net.to(device)
+    errs = {}
+    for name in which:
+        x, exp = torch.from_numpy(g["x_" + name]), torch.from_numpy(g["y_" + name])
+        got = net(x.to(device)).cpu()
+        errs[name] = (got - exp).abs().max().item()
+        assert errs[name] < LOGIT_TOL * max(1.0, exp.abs().max().item()), (name, errs)
+    return errs
 
 
 def case_net_pool_fused_bitwise(device):

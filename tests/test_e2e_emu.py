@@ -245,6 +245,11 @@ def test_upcat_fused_vs_two_layers_and_reference(emu):
     print(ec.case_net_upcat_fused_vs_two_layers("cpu"))
 
 
+def test_basic_unet_pixelshuffle_vs_reference(emu):
+    """BasicUNet(upsample="pixelshuffle") on the HIP path against the real reference's golden logits (the odd-extent input; the GPU twin runs both)"""
+    print(ec.case_basic_unet_pixelshuffle_vs_golden("cpu", which=("odd",)))
+
+
 @pytest.mark.heavy_emu          # minutes of emulated split-precision kernels; the -m gpu twin runs every round
 def test_conv_halves_vs_one_launch_and_reference(emu):
     """UpCat's convolution over a 64-channel concatenation as two 32-channel launches of the Winograd split-precision kernel (BasicUNet._conv_halves)"""

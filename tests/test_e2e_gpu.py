@@ -298,6 +298,11 @@ def test_upcat_fused_vs_two_layers_and_reference():
     print(ec.case_net_upcat_fused_vs_two_layers(DEV))
 
 
+def test_basic_unet_pixelshuffle_vs_reference():
+    """BasicUNet(upsample="pixelshuffle") on the HIP path (sub-pixel convolution + pixelshuffle_kernel) against the real reference's golden logits"""
+    print(ec.case_basic_unet_pixelshuffle_vs_golden(DEV))
+
+
 def test_conv_halves_vs_one_launch_and_reference():
     """UpCat's convolution over a 64-channel concatenation as two 32-channel launches of the Winograd split-precision kernel (BasicUNet._conv_halves): golden logits of the
     real reference + the engine's one-launch path"""

@@ -349,10 +349,11 @@ def test_unetr_option_surface_matches_the_reference(monai_ref, emu, kw):
     (dict(norm=("batch", {"eps": 1e-4}), act=("prelu", {"init": 0.2})), (2, 1, 32, 32, 32)),
     (dict(norm=("group", {"num_groups": 4}), upsample="nontrainable", act="relu"), (1, 1, 32, 48, 32)),
     (dict(norm="instance", upsample="nontrainable"), (1, 2, 40, 32, 36)),          # odd extents at the lower levels: UpCat's replicate padding after the interpolation
+    (dict(upsample="pixelshuffle", act=("leakyrelu", {"negative_slope": 0.2})), (1, 1, 16, 32, 16)),      # SubpixelUpsample: k3 conv to 8 x the channels + shuffle + pad / average pool
 ])
 def test_basic_unet_option_surface_matches_the_reference(monai_ref, emu, kw, shape):
     """VERDICT r2 missing #3: BasicUNet beyond instance norm + LeakyReLU + deconv -- BatchNorm (evaluated with its running statistics), GroupNorm, PReLU / ReLU,
-    upsample="nontrainable" -- strict state_dict load and logits of the real reference."""
+    upsample="nontrainable" / "pixelshuffle" -- strict state_dict load and logits of the real reference."""
     from monai.networks.nets import BasicUNet as RefNet
 
     from monai_amd.networks.nets.basic_unet import BasicUNet as OurNet
