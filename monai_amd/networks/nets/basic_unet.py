@@ -115,12 +115,13 @@ class _Subpixel(nn.Module):
 
     def __init__(self, cin, cout):
         super().__init__()
-        self.conv_block = nn.Conv3d(cin, cout * 8, kernel_size=3, stride=1, padding=1, bias=True)
-        # the reference's ICNR initialisation (monai/networks/utils.py:350-367, Aitken et al. 2017): every group of 8 sub-voxel kernels starts as copies of ONE
+        nd = 2 if getattr(_BUILD, "dims", 3) == 2 else 3
+        self.conv_block = _nd(nn.Conv3d, nn.Conv2d)(cin, cout * 2 ** nd, kernel_size=3, stride=1, padding=1, bias=True)
+        # the reference's ICNR initialisation (monai/networks/utils.py:350-367, Aitken et al. 2017): every group of 2^dims sub-voxel kernels starts as copies of ONE
         # Kaiming-normal kernel, arranged through its transpose / reshape / repeat sequence -- the same draws from the generator, so the same seed gives the same parameters
-        oc2, dims = cout, [3, 3, 3]
+        oc2, dims = cout, [3] * nd
         k = nn.init.kaiming_normal_(torch.zeros([oc2, cin] + dims))
-        k = k.transpose(0, 1).reshape(oc2, cin, -1).repeat(1, 1, 8).reshape([cin, cout * 8] + dims).transpose(0, 1)
+        k = k.transpose(0, 1).reshape(oc2, cin, -1).repeat(1, 1, 2 ** nd).reshape([cin, cout * 2 ** nd] + dims).transpose(0, 1)
         with torch.no_grad():
             self.conv_block.weight.copy_(k)
 
@@ -128,7 +129,7 @@ class _Subpixel(nn.Module):
 class _UpSample(nn.Module):
     """UpSample (blocks/upsample.py:43-184) in the parameter layouts BasicUNet uses: "deconv" = ConvTranspose(k2, s2); "nontrainable" = an optional
     1x1 ``preconv`` (present when the channel count changes, pre_conv="default") + parameter-free linear interpolation x2 with align_corners=True;
-    "pixelshuffle" = SubpixelUpsample (three spatial dimensions on the HIP path)"""
+    "pixelshuffle" = SubpixelUpsample"""
 
     def __init__(self, cin, cout, mode="deconv", bias=True):
         super().__init__()
@@ -193,8 +194,8 @@ class BasicUNet(nn.Module):
         super().__init__()
         if spatial_dims not in (2, 3):
             raise NotImplementedError("monai_amd.BasicUNet: spatial_dims 2 and 3 are on the HIP path")
-        if upsample not in ("deconv", "nontrainable", "pixelshuffle") or (upsample == "pixelshuffle" and spatial_dims != 3):
-            raise NotImplementedError("monai_amd.BasicUNet: upsample='deconv', 'nontrainable' and (three spatial dimensions) 'pixelshuffle' are on the HIP path")
+        if upsample not in ("deconv", "nontrainable", "pixelshuffle"):
+            raise NotImplementedError("monai_amd.BasicUNet: upsample='deconv', 'nontrainable' and 'pixelshuffle' are on the HIP path")
         # dropout: accepted and inert -- this is an inference engine (forward refuses training mode) and Dropout holds no parameters, so
         # checkpoints of nets trained with dropout load unchanged
         fea = tuple(features)
@@ -336,7 +337,7 @@ class _Plan:
         self.interp = net.upsample == "nontrainable"
         self.shuffle = net.upsample == "pixelshuffle"
         # "pixelshuffle" up-sampling: the sub-pixel convolution's raw result (8 x the up channels) at the lower resolution
-        self.sub = [e(8 * up[l], l + 1) if self.shuffle else None for l in range(4)]
+        self.sub = [e((4 if self.planar else 8) * up[l], l + 1) if self.shuffle else None for l in range(4)]
         # "nontrainable" up-sampling: the (optional) 1x1 pre-convolution's result at the lower resolution
         self.low = [e(up[l], l + 1) if self.interp else None for l in range(4)]
         self.stats: Optional[torch.Tensor] = None
@@ -472,14 +473,14 @@ class _Plan:
         dst.copy_(hi.reshape((n, c) + osz))
 
     def _subpixel(self, net, name: str, conv: nn.Conv3d, src, src_nrm, sub, dst, dst_nrm) -> None:
-        """SubpixelUpsample (blocks/upsample.py:274-288): the k3 convolution of the (deferred) input to 8 x the up channels -- raw, no normalisation follows it -- then one pass
+        """SubpixelUpsample (blocks/upsample.py:274-288): the k3 convolution of the (deferred) input to 8 x (one plane: 4 x) the up channels -- raw, no normalisation follows it -- then one pass
         that shuffles the sub-voxels into place and applies the pad + average pooling; max |value| goes into the identity records of the result"""
         n, cin, d, h, w = src.shape
         cout = sub.shape[1]
         cfg = ops.conv3d_k3_select(cin, cout, d, h, w, bounded=src_nrm is not None and not self.batchnorm)
         with _prof.span(f"conv3d_k3/cfg{cfg}", 2.0 * 27 * cin * cout * d * h * w * n):
             ops.conv3d_k3(cfg, src, src_nrm, net._packed_weight(name, conv, cfg), conv.bias, sub, None)
-        ops.pixelshuffle(sub, dst, 2, True, dst_nrm)
+        ops.pixelshuffle(sub, dst, 1 if self.planar else 2, True, dst_nrm)
 
     def _fusable(self, net, l: int, src: torch.Tensor, cout: int) -> bool:
         """UpCat level l without its up-sampled intermediate (csrc/kernels/upconv_h2.h): a k2 s2 transposed convolution feeding an instance- / group-normalised

@@ -129,7 +129,7 @@ def case_net_conv_halves_vs_one_launch(device, window=(48, 32, 32)):
     return r, d
 
 
-def case_basic_unet_pixelshuffle_vs_golden(device, which=("even", "odd")):
+def case_basic_unet_pixelshuffle_vs_golden(device, which=("even", "odd", "2d")):
     """BasicUNet(upsample="pixelshuffle"): UpSample -> SubpixelUpsample (k3 convolution to 8 x the channels, pixel shuffle, zero pad in front + average pooling;
     csrc/kernels/nn_simple.h: pixelshuffle_kernel) with the REAL reference's parameters and logits (tests/golden/make_golden_pixelshuffle.py): strict state_dict load,
     even extents and odd ones (UpCat's replicate padding behind the shuffle)."""
@@ -143,10 +143,20 @@ def case_basic_unet_pixelshuffle_vs_golden(device, which=("even", "odd")):
     net = net.to(device)
     errs = {}
     for name in which:
+        if name == "2d":
+            continue
         x, exp = torch.from_numpy(g["x_" + name]), torch.from_numpy(g["y_" + name])
         got = net(x.to(device)).cpu()
         errs[name] = (got - exp).abs().max().item()
         assert errs[name] < LOGIT_TOL * max(1.0, exp.abs().max().item()), (name, errs)
+    if "2d" in which:      # two spatial dimensions: the one-plane form (4 sub-pixels per channel)
+        net2 = BasicUNet(2, 2, 3, features=tuple(int(v) for v in g["features"]), upsample="pixelshuffle").eval()
+        assert list(net2.state_dict().keys()) == [str(k) for k in g["keys2"]]
+        net2.load_state_dict({str(k): torch.from_numpy(g["p2:" + str(k)]) for k in g["keys2"]}, strict=True)
+        exp = torch.from_numpy(g["y_2d"])
+        got = net2.to(device)(torch.from_numpy(g["x_2d"]).to(device)).cpu()
+        errs["2d"] = (got - exp).abs().max().item()
+        assert errs["2d"] < LOGIT_TOL * max(1.0, exp.abs().max().item()), errs
     return errs
 
 

@@ -35,6 +35,17 @@ def main():
         for name, x in xs.items():
             out["x_" + name] = x.numpy()
             out["y_" + name] = net(x).numpy()
+    # two spatial dimensions (the engine's one-plane form): 4 sub-pixels per channel; 40: 5 at level 3 (odd)
+    torch.manual_seed(33)
+    net2 = BasicUNet(spatial_dims=2, in_channels=2, out_channels=3, features=FEATURES, upsample="pixelshuffle").eval()
+    sd2 = net2.state_dict()
+    out["keys2"] = np.array(list(sd2.keys()))
+    for k, v in sd2.items():
+        out["p2:" + k] = v.numpy()
+    x2 = torch.rand((2, 2, 48, 40), generator=gen)
+    with torch.no_grad():
+        out["x_2d"] = x2.numpy()
+        out["y_2d"] = net2(x2).numpy()
     np.savez_compressed(os.path.join(HERE, "basic_unet_pixelshuffle.npz"), **out)
     print("pixelshuffle golden written", {k: tuple(v.shape) for k, v in out.items() if k.startswith("y_")})
 

@@ -246,8 +246,8 @@ def test_upcat_fused_vs_two_layers_and_reference(emu):
 
 
 def test_basic_unet_pixelshuffle_vs_reference(emu):
-    """BasicUNet(upsample="pixelshuffle") on the HIP path against the real reference's golden logits (the odd-extent input; the GPU twin runs both)"""
-    print(ec.case_basic_unet_pixelshuffle_vs_golden("cpu", which=("odd",)))
+    """BasicUNet(upsample="pixelshuffle") on the HIP path against the real reference's golden logits (the odd-extent input and the two-dimensional net; the GPU twin runs all three)"""
+    print(ec.case_basic_unet_pixelshuffle_vs_golden("cpu", which=("odd", "2d")))
 
 
 @pytest.mark.heavy_emu          # minutes of emulated split-precision kernels; the -m gpu twin runs every round

@@ -202,7 +202,7 @@ def test_no_monai_keeps_the_explicit_error():
         with pytest.raises(NotImplementedError):
             BasicUNet(spatial_dims=1)
         with pytest.raises(NotImplementedError):
-            BasicUNet(spatial_dims=2, upsample="pixelshuffle")
+            BasicUNet(spatial_dims=3, upsample="no such mode")
         with pytest.raises(RuntimeError):
             BasicUNet(spatial_dims=3).eval()(torch.rand(1, 1, 32, 32, 32))
     finally:
