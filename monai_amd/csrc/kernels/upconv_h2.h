@@ -282,6 +282,9 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         pend = 0;                                                                                     \
     }
 #define UC_NONE
+#ifndef UC_DSG
+#define UC_DSG 2      // operand reads the scheduler may place per matrix-instruction gap (the next group's eight reads: 2 = over four gaps, 4 = over the first two)
+#endif
 
     for (int c = cz_s; c < cz_e; ++c) {
         const int za = c - 1 + pz, zb = c + pz;               // the two coarse planes of fine plane 2 c + pz
@@ -302,8 +305,9 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         constexpr int ks_ = ((G_) >> 2) & 1, ty_ = ((G_) >> 1) & 1, px_ = (G_) & 1;                   \
         const uint4* ap_ = (XB_) + ks_ * (2 * UC_PV) + abase + ty_ * UC_RX + px_;                     \
         const uint4* bp_ = ws + ((((TZ_) * 2 + ty_) * 2 + px_) * 2) * UC_WC + ks_ * 64 + bbase;       \
-        ahq[B_][0] = ap_[0]; ahq[B_][1] = ap_[1]; alq[B_][0] = ap_[UC_XP]; alq[B_][1] = ap_[UC_XP + 1]; \
-        bhq[B_][0] = bp_[0]; blq[B_][0] = bp_[128]; bhq[B_][1] = bp_[UC_WC]; blq[B_][1] = bp_[UC_WC + 128]; \
+        /* in the order the matrix instructions consume them (tx 0: ah bh | al bh | ah bl, then tx 1): the first operands are the first to arrive */ \
+        ahq[B_][0] = ap_[0]; bhq[B_][0] = bp_[0]; alq[B_][0] = ap_[UC_XP]; blq[B_][0] = bp_[128];     \
+        ahq[B_][1] = ap_[1]; bhq[B_][1] = bp_[UC_WC]; alq[B_][1] = ap_[UC_XP + 1]; blq[B_][1] = bp_[UC_WC + 128]; \
     }
 #define UC_MM(B_, PX_)                                                                                \
     _Pragma("unroll") for (int tx_ = 0; tx_ < 2; ++tx_) {                                             \
@@ -319,7 +323,7 @@ upconv_k4s2_h2_kernel(Tensor low, const uint4* __restrict__ wp, const float* __r
         UC_MM((G_) & 1, (G_) & 1)                                                                     \
         _Pragma("unroll") for (int g_ = 0; g_ < 6; ++g_) {                                            \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                        \
+            __builtin_amdgcn_sched_group_barrier(0x100, UC_DSG, 0);                                   \
             __builtin_amdgcn_sched_group_barrier(0x006, NV_, 0);                                      \
             if ((NM_) > 0) __builtin_amdgcn_sched_group_barrier(0x010, NM_, 0);                       \
         }                                                                                             \
