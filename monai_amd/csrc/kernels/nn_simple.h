@@ -586,6 +586,9 @@ constexpr int WIN_PLACE_MAX = 64;
 struct WinPlace {
     long long off[WIN_PLACE_MAX], sc[WIN_PLACE_MAX], sd[WIN_PLACE_MAX], sh[WIN_PLACE_MAX];
 };
+#ifndef MH_C1W_CB
+#define MH_C1W_CB 4
+#endif
 template <int CO>
 __global__ void __launch_bounds__(256)
 conv1x1_windows_kernel(Tensor in, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ base, WinPlace pl, int n0) {
@@ -603,7 +606,7 @@ conv1x1_windows_kernel(Tensor in, const float* __restrict__ w, const float* __re
         for (int v = 0; v < VEC; ++v) acc[j][v] = bj;
     }
     const float* src = in.data + (long long)n * in.n_stride + idx;
-    constexpr int CB = 4;
+    constexpr int CB = MH_C1W_CB;      // channels whose 16-byte loads fly together
     for (int c0 = 0; c0 < Cin; c0 += CB) {
         float xv[CB][VEC];
 #pragma unroll
