@@ -96,6 +96,31 @@ def test_host_side_queries_need_no_gpu():
     assert dll.mh_deconv_k2s2_h2_packed_floats(64, 32) == 64 * 32 * 8 + 4
 
 
+def test_argument_checks_of_the_round_6_entries_need_no_gpu():
+    """mh_pixelshuffle_f32 refuses shapes that are not [N][C * fz * 4][D][H][W] -> [N][C][fz D][2 H][2 W] and mh_conv3d_k3_accumulate_f32 names its configurations (the
+    split-precision ones incl. the 16-cout form) BEFORE anything is launched: MH_ERR_ARG / MH_ERR_UNSUPPORTED with a message, on a box without a GPU"""
+    _ensure_built()
+    dll = ctypes.CDLL(_lib.LIB_PATH)
+    dll.mh_last_error.restype = ctypes.c_char_p
+
+    def view(c, d, h, w):
+        t = _lib.MhTensor5()
+        t.data, t.n_stride, t.nrm, t.nrm_n_stride = 0x10000, c * d * h * w, None, 0
+        t.N, t.C, t.D, t.H, t.W = 1, c, d, h, w
+        return t
+
+    a = view(16, 2, 2, 2)
+    assert dll.mh_pixelshuffle_f32(ctypes.byref(a), ctypes.byref(view(2, 4, 4, 5)), 2, 1, None) == -1 and b"pixelshuffle" in dll.mh_last_error()
+    assert dll.mh_pixelshuffle_f32(ctypes.byref(a), ctypes.byref(view(4, 4, 4, 4)), 2, 1, None) == -1          # 16 channels are 2 x 8, not 4 x 8
+    assert dll.mh_pixelshuffle_f32(ctypes.byref(a), ctypes.byref(view(2, 4, 4, 4)), 3, 1, None) == -1 and b"fz" in dll.mh_last_error()
+    assert dll.mh_pixelshuffle_f32(ctypes.byref(a), ctypes.byref(view(4, 2, 4, 4)), 2, 1, None) == -1          # the one-plane form's shape under fz = 2
+    stats = (ctypes.c_float * 4)()
+    x = view(16, 4, 8, 8)
+    dll.mh_conv3d_k3_h2c_config.restype = ctypes.c_int
+    assert dll.mh_conv3d_k3_accumulate_f32(1, ctypes.byref(x), stats, None, ctypes.byref(x), stats, None) == -3 and b"accumulating form" in dll.mh_last_error()      # an fp32 tile
+    assert dll.mh_conv3d_k3_accumulate_f32(dll.mh_conv3d_k3_h2c_config(), ctypes.byref(x), stats, None, ctypes.byref(x), None, None) == -3                              # no statistics
+
+
 def test_library_reads_no_environment():
     """"no global mutable state" -- the shipped library does not even import getenv (development knobs exist only in the
     -DMH_DEV_KNOBS build, libmonai_amd_dev.so, which the product never loads)"""
